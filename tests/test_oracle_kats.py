@@ -1,0 +1,123 @@
+"""Pin the CPU oracle against the reference's own known-answer tests.
+
+Each test cites the reference test it restates (paths relative to /root/reference).
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from point_cloud_viewer_amd import synthetic
+
+U8, U16, F32, F64 = 1, 2, 3, 4
+
+
+def _roundtrip(enc, value, mn, edge):
+    L = O.lib()
+    return L.pcvo_decode_coord(enc, L.pcvo_encode_coord(enc, value, mn, edge), mn, edge)
+
+
+def test_codec_plain_scalar():
+    # src/read_write/codec.rs:158-181 plain_scalar
+    value, mn, edge = 41.33333, 40.0, 2.0
+    assert abs(_roundtrip(F32, value, mn, edge) - value) < 1e-7
+    assert abs(_roundtrip(F64, value, mn, edge) - value) < 1e-14
+
+
+def test_codec_fixpoint_scalar():
+    # src/read_write/codec.rs:183-212 fixpoint_scalar (u8 / u16 arms; u32 is not an on-disk encoding)
+    value, mn, edge = 41.33333, 40.0, 2.0
+    assert abs(_roundtrip(U8, value, mn, edge) - value) < 1e-2
+    assert abs(_roundtrip(U16, value, mn, edge) - value) < 1e-4
+
+
+def test_codec_truncation_rule():
+    # simba 0.2.1 try_convert == `as` cast: truncation toward zero, saturation, NaN -> 0
+    L = O.lib()
+    assert L.pcvo_encode_coord(U8, 0.999999, 0.0, 1.0) == 254  # 254.9997 truncates
+    assert L.pcvo_encode_coord(U8, 1.0, 0.0, 1.0) == 255
+    assert L.pcvo_encode_coord(U8, 7.0, 0.0, 1.0) == 255  # clamp
+    assert L.pcvo_encode_coord(U8, -3.0, 0.0, 1.0) == 0
+    assert L.pcvo_encode_coord(U8, float("nan"), 0.0, 1.0) == 0
+    assert L.pcvo_encode_coord(U16, 0.5, 0.0, 1.0) == 32767  # 32767.5 truncates
+
+
+def test_position_encoding_thresholds():
+    # src/read_write/codec.rs:31-40
+    L = O.lib()
+    assert L.pcvo_position_encoding(0.2, 0.001) == U8  # log2(200)=7.6 -> 7+1 = 8 bits
+    assert L.pcvo_position_encoding(0.3, 0.001) == U16  # log2(300)=8.2 -> 9 bits
+    assert L.pcvo_position_encoding(60.0, 0.001) == U16  # 15.87 -> 16
+    assert L.pcvo_position_encoding(70.0, 0.001) == F32  # 16.09 -> 17
+    assert L.pcvo_position_encoding(16000.0, 0.001) == F32  # 23.9 -> 24
+    assert L.pcvo_position_encoding(17000.0, 0.001) == F64  # 24.02 -> 25
+    assert L.pcvo_position_encoding(0.0005, 0.001) == U8  # negative log2 saturates to 0 -> 1 bit
+
+
+def test_parent_node_name():
+    # src/octree/node.rs:278-283
+    hi, lo = O.node_id_from_str("r123456")
+    import ctypes as C
+    phi, plo = C.c_uint64(), C.c_uint64()
+    assert O.lib().pcvo_node_id_parent(hi, lo, C.byref(phi), C.byref(plo)) == 1
+    assert (phi.value, plo.value) == O.node_id_from_str("r12345")
+    assert O.node_id_str(phi.value, plo.value) == "r12345"
+
+
+def test_child_index():
+    # src/octree/node.rs:285-296
+    import ctypes as C
+    L = O.lib()
+    assert L.pcvo_node_id_child_index(*O.node_id_from_str("r123451")) == 1
+    assert L.pcvo_node_id_child_index(*O.node_id_from_str("r123457")) == 7
+    phi, plo = C.c_uint64(), C.c_uint64()
+    assert L.pcvo_node_id_parent(*O.node_id_from_str("r"), C.byref(phi), C.byref(plo)) == 0  # root: None
+
+
+def test_bounding_box_of_node_ids():
+    # src/octree/node.rs:298-317 — defines x = bit 2, y = bit 1, z = bit 0
+    import ctypes as C
+    L = O.lib()
+    root_min = np.array([-5.0, -5.0, -5.0])
+    out = np.zeros(3)
+    edge = C.c_double()
+    L.pcvo_find_bounding_cube(*O.node_id_from_str("r0"), O._d(root_min), 10.0, O._d(out), C.byref(edge))
+    assert out.tolist() == [-5.0, -5.0, -5.0] and edge.value == 5.0
+    L.pcvo_find_bounding_cube(*O.node_id_from_str("r13"), O._d(root_min), 10.0, O._d(out), C.byref(edge))
+    assert out.tolist() == [-5.0, -2.5, 2.5] and edge.value == 2.5
+
+
+def test_node_id_layout():
+    # src/octree/node.rs:101-111: u128 = level << 120 | index ; proto high/low halves
+    hi, lo = O.node_id_from_str("r13")
+    assert hi == (2 << 56) and lo == 0o13
+    assert O.node_id_str(hi, lo) == "r13"
+    deep = "r" + "7" * 30
+    hi, lo = O.node_id_from_str(deep)
+    assert hi >> 56 == 30 and O.node_id_str(hi, lo) == deep
+
+
+@pytest.mark.parametrize("mode", ["literal", "closed"])
+def test_reference_octree_unit_test_cloud(mode):
+    # src/octree/tests.rs:18-46 build_test_octree; expected answer derived in SURVEY.md §8c (5):
+    # root cube min (-200,-40,0) edge 200, all levels Uint8; r=12 501, r0=0 points (no files), r4=87 500.
+    x, y, z, rgb, bmin, bmax, res = synthetic.reference_unit_test_cloud()
+    build = O.build_literal if mode == "literal" else O.build_closed
+    t = build(res, bmin, bmax, x, y, z, rgb)
+    assert t.version == 13
+    assert t.total_points() == 100001  # tests.rs:100-101 expects every point back
+    assert sorted(t.nodes) == ["r", "r0", "r4"]
+    assert t.nodes["r"]["num_points"] == 12501
+    assert t.nodes["r0"]["num_points"] == 0 and t.nodes["r0"]["files"] == 0
+    assert t.nodes["r4"]["num_points"] == 87500
+    assert all(n["encoding"] == U8 for n in t.nodes.values())
+    assert len(t.nodes["r4"]["xyz"]) == 87500 * 3 and len(t.nodes["r4"]["rgb"]) == 87500 * 3
+    # colours are passed through untouched
+    assert set(t.nodes["r"]["rgb"][0::3]) == {255} and set(t.nodes["r"]["rgb"][1::3]) == {0}
+
+
+def test_sum_of_num_points_equals_input():
+    # point_cloud_test/tests/main.rs:10-23 num_points_in_octree_meta (at reduced N)
+    n = 200_000
+    x, y, z, rgb, bmin, bmax = synthetic.uniform_ecef(n)
+    t = O.build_closed(0.001, bmin, bmax, x, y, z, rgb, threads=4)
+    assert t.total_points() == n
