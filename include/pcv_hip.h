@@ -1,0 +1,162 @@
+/* pcv_hip.h — C ABI of the MI355X-native octree-build / cull hot path of point_cloud_viewer.
+ *
+ * The reference (Rust) has no FFI boundary for this path; the boundary is the crate's public
+ * surface. Each entry point below names the reference item it replaces (paths relative to the
+ * reference checkout). A Rust veneer (point_cloud_viewer_amd/rust_shim/) binds these
+ * 1:1 and keeps `build_octree`, `Octree`, `NodeId`, `PointCulling` as the user-facing names.
+ *
+ * Rules of the ABI
+ *  - plain pointers and sizes only; the caller owns every input buffer, the library never frees them;
+ *  - every function returns an int status (PCV_OK or a negative PCV_E_*), never unwinds;
+ *    pcv_last_error(ctx) holds a human-readable message for the last failure on that context;
+ *  - a pcv_ctx is bound to one HIP device + one stream and is NOT thread-safe; use one per host
+ *    thread/device (reference: the build uses the global rayon pool, src/bin/build_octree.rs:43-46);
+ *  - buffers are tagged PCV_MEM_HOST or PCV_MEM_DEVICE; device buffers must live on the ctx's device.
+ */
+#ifndef PCV_HIP_H
+#define PCV_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCV_ABI_VERSION 1
+
+/* status codes (reference: error-chain kinds src/errors.rs:18-48; the builder itself panics) */
+#define PCV_OK 0
+#define PCV_E_INVALID (-1) /* bad argument (ErrorKind::InvalidInput) */
+#define PCV_E_HIP (-2)     /* HIP runtime failure */
+#define PCV_E_IO (-3)      /* file system failure (ErrorKind::Io) */
+#define PCV_E_OOM (-4)     /* device or host allocation failed / node table capacity exceeded */
+#define PCV_E_DEPTH (-5)   /* a node deeper than PCV_MAX_KEY_LEVELS would still have to be split */
+#define PCV_E_NOT_FOUND (-6) /* ErrorKind::NodeNotFound */
+
+#define PCV_MEM_HOST 0
+#define PCV_MEM_DEVICE 1
+
+/* position encodings == proto PositionEncoding values (point_viewer_proto_rust/src/proto.proto:82-88) */
+#define PCV_ENC_UINT8 1
+#define PCV_ENC_UINT16 2
+#define PCV_ENC_FLOAT32 3
+#define PCV_ENC_FLOAT64 4
+
+/* path digits kept per point: 3 bits per level in a 64-bit key */
+#define PCV_MAX_KEY_LEVELS 21
+/* reference src/octree/generation.rs:37 */
+#define PCV_DEFAULT_MAX_POINTS_PER_NODE 100000u
+
+typedef struct pcv_ctx pcv_ctx;
+typedef struct pcv_octree pcv_octree;
+
+/* ---- context -------------------------------------------------------------------------------- */
+/* `stream` is a hipStream_t (may be NULL = a stream owned by the context). */
+int pcv_ctx_create(int device, void* stream, pcv_ctx** out);
+void pcv_ctx_destroy(pcv_ctx* ctx);
+const char* pcv_last_error(const pcv_ctx* ctx);
+int pcv_abi_version(void);
+/* Release cached device/host scratch held by the context. */
+int pcv_ctx_trim(pcv_ctx* ctx);
+
+/* ---- inputs --------------------------------------------------------------------------------- */
+/* One batch of points, SoA. Replaces `PointsBatch` (src/lib.rs:102-107): positions Vec<Point3<f64>>,
+ * "color" U8Vec3 and optional "intensity" F32 (src/octree/mod.rs:62-74). */
+typedef struct pcv_points {
+  uint64_t n;
+  const double* x;
+  const double* y;
+  const double* z;
+  const uint8_t* color;   /* n * color_stride bytes, r,g,b first; required */
+  uint32_t color_stride;  /* 3 (as in .rgb files) or 4 (rgba, alpha ignored) */
+  const float* intensity; /* NULL = no "intensity" attribute */
+  int32_t mem;            /* PCV_MEM_HOST or PCV_MEM_DEVICE (all pointers alike) */
+} pcv_points;
+
+/* Arguments of `build_octree` (src/octree/generation.rs:289-295). */
+typedef struct pcv_build_params {
+  double resolution;            /* meters; reference CLI default 0.001 (src/bin/build_octree.rs:33) */
+  double bbox_min[3];           /* `bounding_box: Aabb`; may be loose */
+  double bbox_max[3];
+  uint32_t max_points_per_node; /* 0 = PCV_DEFAULT_MAX_POINTS_PER_NODE (the reference's constant) */
+  uint32_t flags;               /* PCV_BUILD_* */
+} pcv_build_params;
+
+/* Compute the bounding box on the device first (== build_octree_from_file's find_bounding_box pass,
+ * generation.rs:256-287); bbox_min/max are then outputs. */
+#define PCV_BUILD_COMPUTE_BBOX 1u
+/* Keep the finished node blobs in device memory only until asked for (default). */
+
+/* ---- the build ------------------------------------------------------------------------------ */
+/* Replaces build_octree (generation.rs:289-403) up to, but not including, the file writes:
+ * the result holds the finished node table and node-contiguous .xyz/.rgb/.intensity bytes. */
+int pcv_build_octree(pcv_ctx* ctx, const pcv_build_params* params, const pcv_points* points, pcv_octree** out);
+
+/* One finished node == one `proto::OctreeNode` (proto.proto:90-94) + where its bytes are. */
+typedef struct pcv_node_info {
+  uint64_t id_high;     /* NodeId u128 halves (src/octree/node.rs:101-111): level<<56 | index>>64 */
+  uint64_t id_low;
+  int64_t num_points;   /* may be 0 (node exists in meta, no files; generation.rs:241-243) */
+  uint32_t level;
+  uint32_t encoding;    /* PCV_ENC_* */
+  double cube_min[3];   /* NodeId::find_bounding_cube (node.rs:157-172) */
+  double cube_edge;
+  uint64_t xyz_offset;  /* byte offset of this node's .xyz content inside the xyz blob */
+  uint64_t point_offset;/* index of this node's first point inside the rgb / intensity blobs */
+} pcv_node_info;
+
+uint64_t pcv_octree_num_nodes(const pcv_octree* t);
+uint64_t pcv_octree_num_points(const pcv_octree* t);
+int pcv_octree_has_intensity(const pcv_octree* t);
+int pcv_octree_node(const pcv_octree* t, uint64_t i, pcv_node_info* out); /* i in (level, index) order */
+void pcv_octree_meta(const pcv_octree* t, double* resolution, double bbox_min[3], double bbox_max[3], int* version);
+/* File content of node i. which: 0 = .xyz, 1 = .rgb, 2 = .intensity. The host pointer stays valid
+ * until pcv_octree_free. Replaces Octree::get_node_data's reads (src/octree/mod.rs:285-307). */
+int pcv_octree_node_data(pcv_octree* t, uint64_t i, int which, const uint8_t** data, uint64_t* len);
+/* Device-side blobs (no copy): which as above. */
+int pcv_octree_device_blob(const pcv_octree* t, int which, const void** dptr, uint64_t* len);
+/* Write `<NodeId>.xyz/.rgb/.intensity` + meta.pb (version 13) exactly as the reference lays them out
+ * (src/read_write/raw.rs:374-449, node_writer.rs:78-89, generation.rs:390-402). */
+int pcv_octree_write_dir(pcv_octree* t, const char* directory);
+void pcv_octree_free(pcv_octree* t);
+
+/* Milliseconds spent per stage of the last pcv_build_octree on this tree (HIP events on the ctx
+ * stream). Index with PCV_STAGE_*; returns the number of stages filled. */
+#define PCV_STAGE_AABB 0
+#define PCV_STAGE_CHAIN_KEYS 1
+#define PCV_STAGE_SORT_KEYS 2
+#define PCV_STAGE_NODE_SPLIT 3
+#define PCV_STAGE_TABLE 4      /* node-table D2H + host finalize + H2D */
+#define PCV_STAGE_LEAF_ENCODE 5
+#define PCV_STAGE_SORT_RECORDS 6
+#define PCV_STAGE_PROMOTE_ENCODE 7
+#define PCV_STAGE_TOTAL 8
+#define PCV_NUM_STAGES 9
+int pcv_octree_stage_ms(const pcv_octree* t, float* ms, int cap);
+
+/* ---- stage-level entry points (unit parity against the oracle) ------------------------------ */
+/* K1: find_bounding_box (generation.rs:256-270; Aabb::grow aabb.rs:41-44). n == 0 -> Aabb::zero(). */
+int pcv_aabb_reduce(pcv_ctx* ctx, const pcv_points* points, double bbox_min[3], double bbox_max[3]);
+
+/* Per-level table: edge[k] = root_edge / 2^k (node.rs:161), encoding[k] = PositionEncoding::new
+ * (src/read_write/codec.rs:31-40). Returns max_level = first k >= 1 with edge[k] <= resolution
+ * (no node below it can be split, generation.rs:137), capped at `cap`. */
+int pcv_level_table(const double bbox_min[3], const double bbox_max[3], double resolution, int cap, double* edge,
+                    int32_t* encoding);
+
+/* K2: per-point path digits through the quantise->decode chain (ChildIndex::from_bounding_cube
+ * node.rs:34-42, encode codec.rs:102-121, decode codec.rs:124-139, cube recurrence node.rs:157-172).
+ * keys[i] has the digit of level k in bits [3*(21-k), 3*(21-k)+3), k = 1..nlevels. */
+int pcv_chain_keys(pcv_ctx* ctx, const pcv_build_params* params, const pcv_points* points, int nlevels,
+                   uint64_t* keys /* same memory space as points */);
+
+/* K3: stable LSD radix sort of 64-bit keys on bits [begin_bit, end_bit), in place. */
+int pcv_sort_keys64(pcv_ctx* ctx, uint64_t* keys, uint64_t n, int begin_bit, int end_bit, int mem);
+/* K3: stable sort of (u32 key, u32 value) pairs on bits [begin_bit, end_bit), in place. */
+int pcv_sort_pairs32(pcv_ctx* ctx, uint32_t* keys, uint32_t* values, uint64_t n, int begin_bit, int end_bit,
+                     int mem);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCV_HIP_H */

@@ -1,0 +1,11 @@
+"""MI355X-native octree build / cull hot path of point_cloud_viewer (hand-written HIP for gfx950 behind a C ABI).
+
+The package is a thin host mirror of the reference's interface for this path; all compute lives in
+libpcv_hip.so (point_cloud_viewer_amd/csrc). Importing does not require a GPU; calling does.
+"""
+from . import _lib
+from ._lib import PcvError, load_library  # noqa: F401
+from .octree import Aabb, Context, OctreeResult, build_octree, level_table, node_name  # noqa: F401
+
+__all__ = ["Aabb", "Context", "OctreeResult", "build_octree", "level_table", "node_name", "PcvError",
+           "load_library"]

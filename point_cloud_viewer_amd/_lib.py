@@ -1,0 +1,96 @@
+"""ctypes binding of libpcv_hip.so (the C ABI of include/pcv_hip.h).
+
+There is no CPU fallback: if the HIP library is missing or no MI355X is visible, calls fail loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpcv_hip.so")
+
+PCV_OK = 0
+PCV_E_INVALID, PCV_E_HIP, PCV_E_IO, PCV_E_OOM, PCV_E_DEPTH, PCV_E_NOT_FOUND = -1, -2, -3, -4, -5, -6
+MEM_HOST, MEM_DEVICE = 0, 1
+ENC_UINT8, ENC_UINT16, ENC_FLOAT32, ENC_FLOAT64 = 1, 2, 3, 4
+BUILD_COMPUTE_BBOX = 1
+MAX_KEY_LEVELS = 21
+NUM_STAGES = 9
+STAGE_NAMES = ["aabb", "chain_keys", "sort_keys", "node_split", "table", "leaf_encode", "sort_records",
+               "promote_encode", "total"]
+
+_ERR_NAMES = {PCV_E_INVALID: "PCV_E_INVALID", PCV_E_HIP: "PCV_E_HIP", PCV_E_IO: "PCV_E_IO", PCV_E_OOM: "PCV_E_OOM",
+              PCV_E_DEPTH: "PCV_E_DEPTH", PCV_E_NOT_FOUND: "PCV_E_NOT_FOUND"}
+
+
+class PcvError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{_ERR_NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+class Points(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("x", C.c_void_p), ("y", C.c_void_p), ("z", C.c_void_p), ("color", C.c_void_p),
+                ("color_stride", C.c_uint32), ("intensity", C.c_void_p), ("mem", C.c_int32)]
+
+
+class BuildParams(C.Structure):
+    _fields_ = [("resolution", C.c_double), ("bbox_min", C.c_double * 3), ("bbox_max", C.c_double * 3),
+                ("max_points_per_node", C.c_uint32), ("flags", C.c_uint32)]
+
+
+class NodeInfo(C.Structure):
+    _fields_ = [("id_high", C.c_uint64), ("id_low", C.c_uint64), ("num_points", C.c_int64), ("level", C.c_uint32),
+                ("encoding", C.c_uint32), ("cube_min", C.c_double * 3), ("cube_edge", C.c_double),
+                ("xyz_offset", C.c_uint64), ("point_offset", C.c_uint64)]
+
+
+# every symbol include/pcv_hip.h declares: name -> (restype, argtypes)
+_vp = C.c_void_p
+_SIGNATURES = {
+    "pcv_abi_version": (C.c_int, []),
+    "pcv_ctx_create": (C.c_int, [C.c_int, _vp, C.POINTER(_vp)]),
+    "pcv_ctx_destroy": (None, [_vp]),
+    "pcv_last_error": (C.c_char_p, [_vp]),
+    "pcv_ctx_trim": (C.c_int, [_vp]),
+    "pcv_build_octree": (C.c_int, [_vp, C.POINTER(BuildParams), C.POINTER(Points), C.POINTER(_vp)]),
+    "pcv_octree_num_nodes": (C.c_uint64, [_vp]),
+    "pcv_octree_num_points": (C.c_uint64, [_vp]),
+    "pcv_octree_has_intensity": (C.c_int, [_vp]),
+    "pcv_octree_node": (C.c_int, [_vp, C.c_uint64, C.POINTER(NodeInfo)]),
+    "pcv_octree_meta": (None, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                               C.POINTER(C.c_int)]),
+    "pcv_octree_node_data": (C.c_int, [_vp, C.c_uint64, C.c_int, C.POINTER(_vp), C.POINTER(C.c_uint64)]),
+    "pcv_octree_device_blob": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(C.c_uint64)]),
+    "pcv_octree_write_dir": (C.c_int, [_vp, C.c_char_p]),
+    "pcv_octree_free": (None, [_vp]),
+    "pcv_octree_stage_ms": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_int]),
+    "pcv_aabb_reduce": (C.c_int, [_vp, C.POINTER(Points), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "pcv_level_table": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_int,
+                                  C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
+    "pcv_chain_keys": (C.c_int, [_vp, C.POINTER(BuildParams), C.POINTER(Points), C.c_int, _vp]),
+    "pcv_sort_keys64": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, C.c_int, C.c_int]),
+    "pcv_sort_pairs32": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.c_int, C.c_int, C.c_int]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def load_library():
+    """Load libpcv_hip.so; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(make -C point_cloud_viewer_amd/csrc). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

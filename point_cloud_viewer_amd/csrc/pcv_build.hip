@@ -1,0 +1,731 @@
+// pcv_build.hip — host orchestration of the device-resident octree build behind the C ABI (include/pcv_hip.h).
+//
+// Replaces build_octree (reference src/octree/generation.rs:289-403). The reference streams every point
+// through one file per node per level; here the tree is derived from a stable sort of chain-exact path keys:
+//
+//   K1 aabb_reduce (optional)            find_bounding_box                   generation.rs:256-270
+//   K2 chain_keys                        per-level octant digits             generation.rs:78-83 + codec.rs
+//   K3 sort keys                         (groups points by path)             generation.rs:84-101
+//   K4 node_split                        should_split_node / recursion       generation.rs:110-193
+//   host: node table finalize            counts of the promotion pyramid     generation.rs:195-253 (closed form)
+//   K5 leaf_encode                       leaf-level quantisation             node_writer.rs:281-316
+//   K3 sort records by leaf rank         stable => per-node input order      SURVEY F11
+//   K6 promote_encode                    every-8th promotion + rewrites      generation.rs:222-238
+//
+// Everything between the first and last kernel stays in HBM; the only host round trip is the (small) node
+// table. No CPU fallback exists: if HIP fails the call fails.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "pcv_internal.h"
+
+// ------------------------------------------------------------------------------------------------
+// context, pool
+// ------------------------------------------------------------------------------------------------
+void* PcvPool::alloc(size_t bytes, hipError_t* err) {
+  *err = hipSuccess;
+  if (bytes == 0) bytes = 256;
+  bytes = (bytes + 255) & ~(size_t)255;
+  auto it = free_blocks.lower_bound(bytes);
+  if (it != free_blocks.end() && it->first <= bytes * 2 + (1u << 20)) {
+    void* p = it->second;
+    live[p] = it->first;
+    free_blocks.erase(it);
+    return p;
+  }
+  void* p = nullptr;
+  *err = hipMalloc(&p, bytes);
+  if (*err != hipSuccess) {
+    // drop the cache and retry once
+    trim();
+    *err = hipMalloc(&p, bytes);
+    if (*err != hipSuccess) return nullptr;
+  }
+  live[p] = bytes;
+  return p;
+}
+void PcvPool::release(void* p) {
+  if (!p) return;
+  auto it = live.find(p);
+  if (it == live.end()) return;
+  free_blocks.insert({it->second, p});
+  live.erase(it);
+}
+void PcvPool::trim() {
+  for (auto& kv : free_blocks) (void)hipFree(kv.second);
+  free_blocks.clear();
+}
+
+int pcv_ctx::dev_alloc(void** p, size_t bytes) {
+  hipError_t e;
+  *p = pool.alloc(bytes, &e);
+  if (!*p) return fail(e == hipErrorOutOfMemory ? PCV_E_OOM : PCV_E_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+  return PCV_OK;
+}
+void pcv_ctx::dev_free(void* p) { pool.release(p); }
+int pcv_ctx::pinned_reserve(size_t bytes) {
+  if (bytes <= pinned_bytes) return PCV_OK;
+  if (pinned) (void)hipHostFree(pinned);
+  pinned = nullptr;
+  pinned_bytes = 0;
+  hipError_t e = hipHostMalloc(&pinned, bytes, hipHostMallocDefault);
+  if (e != hipSuccess) return fail(PCV_E_OOM, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+  pinned_bytes = bytes;
+  return PCV_OK;
+}
+
+extern "C" int pcv_abi_version(void) { return PCV_ABI_VERSION; }
+
+extern "C" int pcv_ctx_create(int device, void* stream, pcv_ctx** out) {
+  if (!out) return PCV_E_INVALID;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return PCV_E_HIP;
+  if (hipSetDevice(device) != hipSuccess) return PCV_E_HIP;
+  pcv_ctx* c = new pcv_ctx();
+  c->device = device;
+  if (stream) {
+    c->stream = (hipStream_t)stream;
+  } else {
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+      delete c;
+      return PCV_E_HIP;
+    }
+    c->own_stream = true;
+  }
+  for (auto& e : c->ev)
+    if (hipEventCreate(&e) != hipSuccess) {
+      delete c;
+      return PCV_E_HIP;
+    }
+  *out = c;
+  return PCV_OK;
+}
+
+extern "C" void pcv_ctx_destroy(pcv_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  ctx->pool.trim();
+  for (auto& kv : ctx->pool.live) (void)hipFree(kv.first);
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  for (auto& e : ctx->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+extern "C" const char* pcv_last_error(const pcv_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
+
+extern "C" int pcv_ctx_trim(pcv_ctx* ctx) {
+  if (!ctx) return PCV_E_INVALID;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  ctx->pool.trim();
+  return PCV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// level table (host): reference codec.rs:31-40, node.rs:161, aabb.rs:149-157
+// ------------------------------------------------------------------------------------------------
+static uint32_t rust_as_u32(double v) {  // Rust `f64 as u32`: NaN -> 0, saturating, truncating
+  if (!(v > 0.0)) return 0;
+  if (v >= 4294967295.0) return 4294967295u;
+  return (uint32_t)v;
+}
+static int position_encoding(double edge, double resolution) {
+  uint32_t min_bits = rust_as_u32(std::log2(edge / resolution)) + 1u;  // wraps like a release build
+  if (min_bits <= 8) return PCV_ENC_UINT8;
+  if (min_bits <= 16) return PCV_ENC_UINT16;
+  if (min_bits <= 24) return PCV_ENC_FLOAT32;
+  return PCV_ENC_FLOAT64;
+}
+
+int pcv_make_levels(const double bmin[3], const double bmax[3], double resolution, int cap, PcvLevels* lv,
+                    int* max_level, std::vector<double>* edges, std::vector<int32_t>* encs) {
+  // Cube::bounding: f64::max chain of the extents (aabb.rs:149-157)
+  double edge = std::fmax(std::fmax(bmax[0] - bmin[0], bmax[1] - bmin[1]), bmax[2] - bmin[2]);
+  std::vector<double> e;
+  std::vector<int32_t> c;
+  e.push_back(edge);
+  c.push_back(position_encoding(edge, resolution));
+  int k = 0;
+  while (k < cap) {
+    ++k;
+    edge /= 2.;
+    e.push_back(edge);
+    c.push_back(position_encoding(edge, resolution));
+    if (edge <= resolution) break;  // generation.rs:137: such a node is never split
+  }
+  if (max_level) *max_level = k;
+  if (lv) {
+    std::memset(lv, 0, sizeof(*lv));
+    for (int a = 0; a < 3; ++a) lv->root_min[a] = bmin[a];
+    int nl = k < PCV_MAX_KEY_LEVELS ? k : PCV_MAX_KEY_LEVELS;
+    lv->nlevels = nl;
+    for (int j = 0; j <= nl && j < (int)e.size(); ++j) {
+      lv->edge[j] = e[j];
+      lv->enc[j] = (uint8_t)c[j];
+    }
+  }
+  if (edges) *edges = e;
+  if (encs) *encs = c;
+  return PCV_OK;
+}
+
+extern "C" int pcv_level_table(const double bbox_min[3], const double bbox_max[3], double resolution, int cap,
+                               double* edge, int32_t* encoding) {
+  std::vector<double> e;
+  std::vector<int32_t> c;
+  int ml = 0;
+  pcv_make_levels(bbox_min, bbox_max, resolution, cap, nullptr, &ml, &e, &c);
+  for (int k = 0; k <= ml; ++k) {
+    if (edge) edge[k] = e[k];
+    if (encoding) encoding[k] = c[k];
+  }
+  return ml;
+}
+
+// ------------------------------------------------------------------------------------------------
+// input staging
+// ------------------------------------------------------------------------------------------------
+struct DevPoints {
+  uint64_t n = 0;
+  const double *x = nullptr, *y = nullptr, *z = nullptr;
+  const uint8_t* color = nullptr;
+  uint32_t color_stride = 3;
+  const float* intensity = nullptr;
+};
+
+static int validate_points(pcv_ctx* ctx, const pcv_points* p, bool need_color) {
+  if (!p) return ctx->fail(PCV_E_INVALID, "points is null");
+  if (p->mem != PCV_MEM_HOST && p->mem != PCV_MEM_DEVICE) return ctx->fail(PCV_E_INVALID, "points.mem must be PCV_MEM_HOST or PCV_MEM_DEVICE");
+  if (p->n >= 0xffffffffull) return ctx->fail(PCV_E_INVALID, "at most 2^32 - 2 points per call");
+  if (p->n > 0 && (!p->x || !p->y || !p->z)) return ctx->fail(PCV_E_INVALID, "x/y/z must be non-null");
+  if (need_color) {
+    if (p->n > 0 && !p->color) return ctx->fail(PCV_E_INVALID, "color is required (on_disk.rs:20-22: colour is always present)");
+    if (p->color_stride != 3 && p->color_stride != 4) return ctx->fail(PCV_E_INVALID, "color_stride must be 3 or 4");
+  }
+  return PCV_OK;
+}
+
+static int stage_points(pcv_ctx* ctx, PcvScratch& sc, const pcv_points* p, bool with_attrs, DevPoints* d) {
+  d->n = p->n;
+  d->color_stride = p->color_stride;
+  if (p->mem == PCV_MEM_DEVICE || p->n == 0) {
+    d->x = p->x;
+    d->y = p->y;
+    d->z = p->z;
+    d->color = p->color;
+    d->intensity = p->intensity;
+    return PCV_OK;
+  }
+  double *x, *y, *z;
+  int rc;
+  if ((rc = sc.get(&x, p->n)) || (rc = sc.get(&y, p->n)) || (rc = sc.get(&z, p->n))) return rc;
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(x, p->x, p->n * 8, hipMemcpyHostToDevice, ctx->stream));
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(y, p->y, p->n * 8, hipMemcpyHostToDevice, ctx->stream));
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(z, p->z, p->n * 8, hipMemcpyHostToDevice, ctx->stream));
+  d->x = x;
+  d->y = y;
+  d->z = z;
+  if (with_attrs) {
+    uint8_t* c;
+    if ((rc = sc.get(&c, p->n * p->color_stride))) return rc;
+    PCV_HIP_CHECK(ctx, hipMemcpyAsync(c, p->color, p->n * p->color_stride, hipMemcpyHostToDevice, ctx->stream));
+    d->color = c;
+    if (p->intensity) {
+      float* f;
+      if ((rc = sc.get(&f, p->n))) return rc;
+      PCV_HIP_CHECK(ctx, hipMemcpyAsync(f, p->intensity, p->n * 4, hipMemcpyHostToDevice, ctx->stream));
+      d->intensity = f;
+    }
+  }
+  return PCV_OK;
+}
+
+static int device_aabb(pcv_ctx* ctx, PcvScratch& sc, const DevPoints& d, double bmin[3], double bmax[3]) {
+  if (d.n == 0) {  // Aabb::zero() (generation.rs:269)
+    for (int a = 0; a < 3; ++a) bmin[a] = bmax[a] = 0.;
+    return PCV_OK;
+  }
+  double* partial;
+  int rc = sc.get(&partial, (size_t)2048 * 6 + 6);
+  if (rc) return rc;
+  double* out6 = partial + 2048 * 6;
+  // the 16-byte vector loads need aligned bases; fall back to staging when the caller's views are not
+  if (((uintptr_t)d.x | (uintptr_t)d.y | (uintptr_t)d.z) & 15) {
+    double *x, *y, *z;
+    if ((rc = sc.get(&x, d.n)) || (rc = sc.get(&y, d.n)) || (rc = sc.get(&z, d.n))) return rc;
+    PCV_HIP_CHECK(ctx, hipMemcpyAsync(x, d.x, d.n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    PCV_HIP_CHECK(ctx, hipMemcpyAsync(y, d.y, d.n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    PCV_HIP_CHECK(ctx, hipMemcpyAsync(z, d.z, d.n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    pcv_launch_aabb(ctx, d.n, x, y, z, partial, out6);
+  } else {
+    pcv_launch_aabb(ctx, d.n, d.x, d.y, d.z, partial, out6);
+  }
+  double h[6];
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(h, out6, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+  PCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  for (int a = 0; a < 3; ++a) {
+    bmin[a] = h[a];
+    bmax[a] = h[3 + a];
+  }
+  return PCV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// octree object
+// ------------------------------------------------------------------------------------------------
+extern "C" void pcv_octree_free(pcv_octree* t) {
+  if (!t) return;
+  if (t->ctx) {
+    t->ctx->dev_free(t->d_xyz);
+    t->ctx->dev_free(t->d_rgb);
+    t->ctx->dev_free(t->d_int);
+  }
+  delete t;
+}
+extern "C" uint64_t pcv_octree_num_nodes(const pcv_octree* t) { return t ? t->nodes.size() : 0; }
+extern "C" uint64_t pcv_octree_num_points(const pcv_octree* t) { return t ? t->num_points : 0; }
+extern "C" int pcv_octree_has_intensity(const pcv_octree* t) { return t && t->has_intensity; }
+extern "C" int pcv_octree_node(const pcv_octree* t, uint64_t i, pcv_node_info* out) {
+  if (!t || !out || i >= t->nodes.size()) return PCV_E_INVALID;
+  *out = t->nodes[i];
+  return PCV_OK;
+}
+extern "C" void pcv_octree_meta(const pcv_octree* t, double* resolution, double bbox_min[3], double bbox_max[3],
+                                int* version) {
+  if (!t) return;
+  if (resolution) *resolution = t->resolution;
+  for (int a = 0; a < 3; ++a) {
+    if (bbox_min) bbox_min[a] = t->bbox_min[a];
+    if (bbox_max) bbox_max[a] = t->bbox_max[a];
+  }
+  if (version) *version = 13;  // CURRENT_VERSION, reference src/lib.rs:48
+}
+extern "C" int pcv_octree_stage_ms(const pcv_octree* t, float* ms, int cap) {
+  if (!t || !ms) return 0;
+  int n = cap < PCV_NUM_STAGES ? cap : PCV_NUM_STAGES;
+  for (int i = 0; i < n; ++i) ms[i] = t->stage_ms[i];
+  return n;
+}
+extern "C" int pcv_octree_device_blob(const pcv_octree* t, int which, const void** dptr, uint64_t* len) {
+  if (!t || !dptr || !len || which < 0 || which > 2) return PCV_E_INVALID;
+  *dptr = which == 0 ? t->d_xyz : (which == 1 ? t->d_rgb : t->d_int);
+  *len = which == 0 ? t->xyz_bytes : (which == 1 ? t->rgb_bytes : t->int_bytes);
+  return PCV_OK;
+}
+
+int pcv_octree_fetch_host(pcv_octree* t) {
+  if (t->host_valid) return PCV_OK;
+  pcv_ctx* ctx = t->ctx;
+  PCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  t->h_xyz.resize(t->xyz_bytes);
+  t->h_rgb.resize(t->rgb_bytes);
+  t->h_int.resize(t->int_bytes);
+  if (t->xyz_bytes) PCV_HIP_CHECK(ctx, hipMemcpyAsync(t->h_xyz.data(), t->d_xyz, t->xyz_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  if (t->rgb_bytes) PCV_HIP_CHECK(ctx, hipMemcpyAsync(t->h_rgb.data(), t->d_rgb, t->rgb_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  if (t->int_bytes) PCV_HIP_CHECK(ctx, hipMemcpyAsync(t->h_int.data(), t->d_int, t->int_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  PCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  t->host_valid = true;
+  return PCV_OK;
+}
+
+int pcv_bytes_per_coordinate(uint32_t enc) { return enc == PCV_ENC_UINT8 ? 1 : enc == PCV_ENC_UINT16 ? 2 : enc == PCV_ENC_FLOAT32 ? 4 : 8; }
+
+extern "C" int pcv_octree_node_data(pcv_octree* t, uint64_t i, int which, const uint8_t** data, uint64_t* len) {
+  if (!t || !data || !len || i >= t->nodes.size() || which < 0 || which > 2) return PCV_E_INVALID;
+  int rc = pcv_octree_fetch_host(t);
+  if (rc) return rc;
+  const pcv_node_info& nd = t->nodes[i];
+  uint64_t np = (uint64_t)nd.num_points;
+  if (which == 0) {
+    *data = t->h_xyz.data() + nd.xyz_offset;
+    *len = np * 3 * (uint64_t)pcv_bytes_per_coordinate(nd.encoding);
+  } else if (which == 1) {
+    *data = t->h_rgb.data() + nd.point_offset * 3;
+    *len = np * 3;
+  } else {
+    if (!t->has_intensity) {
+      *data = nullptr;
+      *len = 0;
+    } else {
+      *data = t->h_int.data() + nd.point_offset * 4;
+      *len = np * 4;
+    }
+  }
+  return PCV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the build
+// ------------------------------------------------------------------------------------------------
+static uint64_t ceil8(uint64_t v) { return (v + 7) / 8; }
+
+extern "C" int pcv_build_octree(pcv_ctx* ctx, const pcv_build_params* params, const pcv_points* points,
+                                pcv_octree** out) {
+  if (!ctx) return PCV_E_INVALID;
+  if (!out) return ctx->fail(PCV_E_INVALID, "out is null");
+  *out = nullptr;
+  if (!params) return ctx->fail(PCV_E_INVALID, "params is null");
+  int rc = validate_points(ctx, points, true);
+  if (rc) return rc;
+  if (!(params->resolution > 0.0) || !std::isfinite(params->resolution)) return ctx->fail(PCV_E_INVALID, "resolution must be a positive finite number");
+  const uint32_t max_points = params->max_points_per_node ? params->max_points_per_node : PCV_DEFAULT_MAX_POINTS_PER_NODE;
+  PCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const uint64_t n = points->n;
+
+  PcvScratch sc(ctx);
+  DevPoints d;
+  PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[0], st));
+  if ((rc = stage_points(ctx, sc, points, true, &d))) return rc;
+
+  pcv_octree* t = new pcv_octree();
+  t->ctx = ctx;
+  t->resolution = params->resolution;
+  t->has_intensity = points->intensity != nullptr;
+  struct Guard {
+    pcv_octree* t;
+    ~Guard() {
+      if (t) pcv_octree_free(t);
+    }
+  } guard{t};
+
+  double bmin[3], bmax[3];
+  if (params->flags & PCV_BUILD_COMPUTE_BBOX) {
+    if ((rc = device_aabb(ctx, sc, d, bmin, bmax))) return rc;
+  } else {
+    for (int a = 0; a < 3; ++a) {
+      bmin[a] = params->bbox_min[a];
+      bmax[a] = params->bbox_max[a];
+    }
+  }
+  for (int a = 0; a < 3; ++a) {
+    t->bbox_min[a] = bmin[a];
+    t->bbox_max[a] = bmax[a];
+  }
+  PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[1], st));
+  if (n == 0) {  // generation.rs:325-330: no leaves, no finished nodes, meta without nodes
+    *out = t;
+    guard.t = nullptr;
+    return PCV_OK;
+  }
+
+  PcvLevels lv;
+  int max_level = 0;
+  pcv_make_levels(bmin, bmax, params->resolution, 64, &lv, &max_level, nullptr, nullptr);
+
+  // ---- K2 keys, K3 sort ----
+  uint64_t *keys_a, *keys_b;
+  void* sort_scratch;
+  if ((rc = sc.get(&keys_a, n)) || (rc = sc.get(&keys_b, n))) return rc;
+  if ((rc = ctx->dev_alloc(&sort_scratch, pcv_sort_scratch_bytes(n)))) return rc;
+  sc.ptrs.push_back(sort_scratch);
+  pcv_launch_chain_keys(st, lv, n, d.x, d.y, d.z, keys_a);
+  PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[2], st));
+  bool in_a = true;
+  if ((rc = pcv_radix_sort_u64(ctx, keys_a, keys_b, n, 3 * (PCV_MAX_KEY_LEVELS - lv.nlevels), 3 * PCV_MAX_KEY_LEVELS,
+                               nullptr, sort_scratch, &in_a)))
+    return rc;
+  const uint64_t* sorted_keys = in_a ? keys_a : keys_b;
+  PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[3], st));
+
+  // ---- K4 node split ----
+  // every open node holds > max_points points and open nodes of one level are disjoint
+  uint64_t cap64 = 8ull * (uint64_t)(lv.nlevels + 1) * (n / max_points + 1) + 64;
+  if (cap64 > (1ull << 26)) cap64 = 1ull << 26;
+  const uint32_t cap = (uint32_t)cap64;
+  PcvNodeTableDev nt;
+  nt.capacity = cap;
+  if ((rc = sc.get(&nt.prefix, cap)) || (rc = sc.get(&nt.lo, cap)) || (rc = sc.get(&nt.hi, cap)) ||
+      (rc = sc.get(&nt.parent, cap)) || (rc = sc.get(&nt.first_child, cap)) || (rc = sc.get(&nt.level, cap)) ||
+      (rc = sc.get(&nt.child_mask, cap)) || (rc = sc.get(&nt.open, cap)) || (rc = sc.get(&nt.bounds, (size_t)cap * 9)) ||
+      (rc = sc.get(&nt.counters, 64)))
+    return rc;
+  pcv_launch_node_split(st, nt, sorted_keys, (uint32_t)n, lv, params->resolution, max_points);
+  PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[4], st));
+
+  // ---- node table to host, finalize ----
+  uint32_t counters[64];
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(counters, nt.counters, sizeof(counters), hipMemcpyDeviceToHost, st));
+  PCV_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  if (counters[1] & 2u) return ctx->fail(PCV_E_OOM, "node table capacity exceeded");
+  if (counters[1] & 1u)
+    return ctx->fail(PCV_E_DEPTH, "a node at level " + std::to_string(lv.nlevels) +
+                                      " still holds more than max_points_per_node points and is larger than the "
+                                      "resolution; PCV_MAX_KEY_LEVELS exhausted");
+  const uint32_t M = counters[0];
+  // pinned staging: prefix(8) lo hi parent first_child (4 each) level mask open (1 each)
+  const size_t host_bytes = (size_t)M * (8 + 4 * 4 + 3) + 64;
+  if ((rc = ctx->pinned_reserve(host_bytes * 4 + (size_t)M * 64))) return rc;
+  uint8_t* hp = (uint8_t*)ctx->pinned;
+  uint64_t* h_prefix = (uint64_t*)hp;
+  uint32_t* h_lo = (uint32_t*)(h_prefix + M);
+  uint32_t* h_hi = h_lo + M;
+  uint32_t* h_first = h_hi + M;
+  uint8_t* h_level = (uint8_t*)(h_first + M);
+  uint8_t* h_mask = h_level + M;
+  uint8_t* h_open = h_mask + M;
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(h_prefix, nt.prefix, (size_t)M * 8, hipMemcpyDeviceToHost, st));
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(h_lo, nt.lo, (size_t)M * 4, hipMemcpyDeviceToHost, st));
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(h_hi, nt.hi, (size_t)M * 4, hipMemcpyDeviceToHost, st));
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(h_first, nt.first_child, (size_t)M * 4, hipMemcpyDeviceToHost, st));
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(h_level, nt.level, (size_t)M, hipMemcpyDeviceToHost, st));
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(h_mask, nt.child_mask, (size_t)M, hipMemcpyDeviceToHost, st));
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(h_open, nt.open, (size_t)M, hipMemcpyDeviceToHost, st));
+  PCV_HIP_CHECK(ctx, hipStreamSynchronize(st));
+
+  // upload area (pinned, after the download area)
+  uint8_t* up = hp + ((host_bytes + 255) & ~(size_t)255);
+  uint64_t* u_walk = (uint64_t*)up;                 // M
+  uint64_t* u_xyz_off = u_walk + M;                  // M
+  uint64_t* u_point_off = u_xyz_off + M;             // M
+  double* u_node_min = (double*)(u_point_off + M);   // 3M
+  uint32_t* u_parent = (uint32_t*)(u_node_min + 3 * (size_t)M);  // M
+  uint32_t* u_child_off = u_parent + M;              // M
+  uint32_t* u_leaf_lo = u_child_off + M;             // <= M
+  uint32_t* u_leaf_node = u_leaf_lo + M;             // <= M
+  uint8_t* u_level = (uint8_t*)(u_leaf_node + M);    // M
+  const size_t up_bytes = (size_t)M * (8 * 3 + 24 + 4 * 4 + 1);
+
+  std::vector<uint64_t> pre(M);
+  // bottom-up stream lengths: |pre(inner)| = sum ceil(|pre(child)| / 8)
+  for (uint32_t i = M; i-- > 0;) {
+    if (!h_open[i]) {
+      pre[i] = (uint64_t)h_hi[i] - h_lo[i];
+    } else {
+      uint64_t acc = 0;
+      uint32_t c = h_first[i];
+      for (int dgt = 0; dgt < 8; ++dgt)
+        if ((h_mask[i] >> dgt) & 1) {
+          u_child_off[c] = (uint32_t)acc;
+          u_parent[c] = i;
+          acc += ceil8(pre[c]);
+          ++c;
+        }
+      pre[i] = acc;
+    }
+  }
+  u_parent[0] = 0xffffffffu;
+  u_child_off[0] = 0;
+  // leaves in key order == order of their sorted ranges
+  std::vector<uint32_t> leaves;
+  leaves.reserve(M);
+  for (uint32_t i = 0; i < M; ++i)
+    if (!h_open[i]) leaves.push_back(i);
+  std::sort(leaves.begin(), leaves.end(), [&](uint32_t a, uint32_t b) { return h_lo[a] < h_lo[b]; });
+  const uint32_t num_leaves = (uint32_t)leaves.size();
+  std::vector<uint32_t> rank_of(M, 0);
+  bool wide = false;
+  for (uint32_t r = 0; r < num_leaves; ++r) {
+    uint32_t i = leaves[r];
+    rank_of[i] = r;
+    u_leaf_lo[r] = h_lo[i];
+    u_leaf_node[r] = i;
+    if (lv.enc[h_level[i]] == PCV_ENC_FLOAT64) wide = true;
+  }
+  t->nodes.resize(M);
+  uint64_t xyz_off = 0, point_off = 0;
+  for (uint32_t i = 0; i < M; ++i) {
+    const int level = h_level[i];
+    u_level[i] = (uint8_t)level;
+    u_walk[i] = h_open[i] ? ((uint64_t)h_first[i] | ((uint64_t)h_mask[i] << 32) | ((uint64_t)level << 48))
+                          : ((uint64_t)rank_of[i] | (1ull << 40) | ((uint64_t)level << 48));
+    // NodeId::find_bounding_cube recurrence (node.rs:157-172): parents precede children in the table
+    if (i == 0) {
+      for (int a = 0; a < 3; ++a) u_node_min[a] = bmin[a];
+    } else {
+      const uint32_t p = u_parent[i];
+      const unsigned dgt = (unsigned)(h_prefix[i] >> (3 * (PCV_MAX_KEY_LEVELS - level))) & 7u;
+      const double e = lv.edge[level];
+      u_node_min[3 * (size_t)i + 0] = u_node_min[3 * (size_t)p + 0] + (double)((dgt >> 2) & 1) * e;
+      u_node_min[3 * (size_t)i + 1] = u_node_min[3 * (size_t)p + 1] + (double)((dgt >> 1) & 1) * e;
+      u_node_min[3 * (size_t)i + 2] = u_node_min[3 * (size_t)p + 2] + (double)(dgt & 1) * e;
+    }
+    const uint64_t np = i == 0 ? pre[0] : pre[i] - ceil8(pre[i]);
+    pcv_node_info& ni = t->nodes[i];
+    const uint64_t index = level ? (h_prefix[i] >> (3 * (PCV_MAX_KEY_LEVELS - level))) : 0;
+    ni.id_high = (uint64_t)level << 56;  // u128 = level << 120 | index ; index < 2^63 here
+    ni.id_low = index;
+    ni.num_points = (int64_t)np;
+    ni.level = (uint32_t)level;
+    ni.encoding = lv.enc[level];
+    for (int a = 0; a < 3; ++a) ni.cube_min[a] = u_node_min[3 * (size_t)i + a];
+    ni.cube_edge = lv.edge[level];
+    ni.xyz_offset = xyz_off;
+    ni.point_offset = point_off;
+    u_xyz_off[i] = xyz_off;
+    u_point_off[i] = point_off;
+    xyz_off += (np * 3 * (uint64_t)pcv_bytes_per_coordinate(ni.encoding) + 15) & ~15ull;
+    point_off += np;
+  }
+  t->num_points = point_off;
+  t->xyz_bytes = xyz_off;
+  t->rgb_bytes = point_off * 3;
+  t->int_bytes = t->has_intensity ? point_off * 4 : 0;
+
+  uint8_t* d_up;
+  if ((rc = sc.get(&d_up, up_bytes + 256))) return rc;
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_up, up, up_bytes, hipMemcpyHostToDevice, st));
+  const size_t o_walk = 0, o_xyz = o_walk + (size_t)M * 8, o_pt = o_xyz + (size_t)M * 8, o_min = o_pt + (size_t)M * 8,
+               o_par = o_min + (size_t)M * 24, o_coff = o_par + (size_t)M * 4, o_llo = o_coff + (size_t)M * 4,
+               o_lnode = o_llo + (size_t)M * 4, o_lvl = o_lnode + (size_t)M * 4;
+  PcvWalkTables wt;
+  wt.walk = (const uint64_t*)(d_up + o_walk);
+  PcvPromoteTables pt;
+  pt.leaf_lo = (const uint32_t*)(d_up + o_llo);
+  pt.leaf_node = (const uint32_t*)(d_up + o_lnode);
+  pt.parent = (const uint32_t*)(d_up + o_par);
+  pt.child_off = (const uint32_t*)(d_up + o_coff);
+  pt.level = (const uint8_t*)(d_up + o_lvl);
+  pt.node_min = (const double*)(d_up + o_min);
+  pt.xyz_off = (const uint64_t*)(d_up + o_xyz);
+  pt.point_off = (const uint64_t*)(d_up + o_pt);
+  PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[5], st));
+
+  // ---- K5 leaf encode (input order) ----
+  // the key buffers are dead now: reuse them for the records where they fit
+  const int nwords = 4 + (t->has_intensity ? 1 : 0) + (wide ? 3 : 0);
+  uint32_t *rank_a, *rank_b;
+  uint32_t* rec_a[8] = {};
+  uint32_t* rec_b[8] = {};
+  rank_a = (uint32_t*)keys_a;           // n * 4 bytes
+  rec_a[0] = (uint32_t*)keys_a + n;     // second half of keys_a
+  rank_b = (uint32_t*)keys_b;
+  rec_b[0] = (uint32_t*)keys_b + n;
+  for (int w = 1; w < nwords; ++w)
+    if ((rc = sc.get(&rec_a[w], n)) || (rc = sc.get(&rec_b[w], n))) return rc;
+  // word layout: 0 cx, 1 cy, 2 cz, 3 rgba, [4 intensity], [hi words]
+  const int w_int = t->has_intensity ? 4 : -1;
+  const int w_hi = wide ? (t->has_intensity ? 5 : 4) : -1;
+  pcv_launch_leaf_encode(st, lv, wt, n, nullptr, d.x, d.y, d.z, d.color, d.color_stride, d.intensity, rank_a, rec_a[0],
+                         rec_a[1], rec_a[2], wide ? rec_a[w_hi] : nullptr, wide ? rec_a[w_hi + 1] : nullptr,
+                         wide ? rec_a[w_hi + 2] : nullptr, rec_a[3], w_int >= 0 ? rec_a[w_int] : nullptr);
+  PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[6], st));
+
+  // ---- K3 stable record sort by leaf rank ----
+  int rank_bits = 1;
+  while ((1ull << rank_bits) < num_leaves) ++rank_bits;
+  PcvSortPayload pl;
+  pl.nwords = nwords;
+  for (int w = 0; w < nwords; ++w) {
+    pl.in[w] = rec_a[w];
+    pl.out[w] = rec_b[w];
+  }
+  bool rec_in_a = true;
+  if ((rc = pcv_radix_sort_u32(ctx, rank_a, rank_b, n, 0, rank_bits, &pl, sort_scratch, &rec_in_a))) return rc;
+  uint32_t* s_rank = rec_in_a ? rank_a : rank_b;
+  uint32_t** s_rec = rec_in_a ? rec_a : rec_b;
+  PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[7], st));
+
+  // ---- K6 promotion + final encode into node-contiguous blobs ----
+  void *bx, *br, *bi = nullptr;
+  if ((rc = ctx->dev_alloc(&bx, t->xyz_bytes))) return rc;
+  t->d_xyz = (uint8_t*)bx;
+  if ((rc = ctx->dev_alloc(&br, t->rgb_bytes))) return rc;
+  t->d_rgb = (uint8_t*)br;
+  if (t->has_intensity) {
+    if ((rc = ctx->dev_alloc(&bi, t->int_bytes))) return rc;
+    t->d_int = (uint8_t*)bi;
+  }
+  pcv_launch_promote_encode(st, lv, pt, n, s_rank, s_rec[0], s_rec[1], s_rec[2], wide ? s_rec[w_hi] : nullptr,
+                            wide ? s_rec[w_hi + 1] : nullptr, wide ? s_rec[w_hi + 2] : nullptr, s_rec[3],
+                            w_int >= 0 ? s_rec[w_int] : nullptr, t->d_xyz, t->d_rgb, t->d_int);
+  PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[8], st));
+  PCV_HIP_CHECK(ctx, hipGetLastError());
+  PCV_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  for (int sidx = 0; sidx < 8; ++sidx) (void)hipEventElapsedTime(&t->stage_ms[sidx], ctx->ev[sidx], ctx->ev[sidx + 1]);
+  (void)hipEventElapsedTime(&t->stage_ms[PCV_STAGE_TOTAL], ctx->ev[0], ctx->ev[8]);
+
+  *out = t;
+  guard.t = nullptr;
+  return PCV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage-level entry points
+// ------------------------------------------------------------------------------------------------
+extern "C" int pcv_aabb_reduce(pcv_ctx* ctx, const pcv_points* points, double bbox_min[3], double bbox_max[3]) {
+  if (!ctx) return PCV_E_INVALID;
+  int rc = validate_points(ctx, points, false);
+  if (rc) return rc;
+  if (!bbox_min || !bbox_max) return ctx->fail(PCV_E_INVALID, "null output");
+  PCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  PcvScratch sc(ctx);
+  DevPoints d;
+  if ((rc = stage_points(ctx, sc, points, false, &d))) return rc;
+  return device_aabb(ctx, sc, d, bbox_min, bbox_max);
+}
+
+extern "C" int pcv_chain_keys(pcv_ctx* ctx, const pcv_build_params* params, const pcv_points* points, int nlevels,
+                              uint64_t* keys) {
+  if (!ctx) return PCV_E_INVALID;
+  int rc = validate_points(ctx, points, false);
+  if (rc) return rc;
+  if (!params || !keys) return ctx->fail(PCV_E_INVALID, "null argument");
+  if (!(params->resolution > 0.0)) return ctx->fail(PCV_E_INVALID, "resolution must be positive");
+  PCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  PcvScratch sc(ctx);
+  DevPoints d;
+  if ((rc = stage_points(ctx, sc, points, false, &d))) return rc;
+  PcvLevels lv;
+  int max_level;
+  pcv_make_levels(params->bbox_min, params->bbox_max, params->resolution, 64, &lv, &max_level, nullptr, nullptr);
+  if (nlevels > 0 && nlevels < lv.nlevels) lv.nlevels = nlevels;
+  if (points->n == 0) return PCV_OK;
+  uint64_t* dk = keys;
+  if (points->mem == PCV_MEM_HOST && (rc = sc.get(&dk, points->n))) return rc;
+  pcv_launch_chain_keys(ctx->stream, lv, points->n, d.x, d.y, d.z, dk);
+  PCV_HIP_CHECK(ctx, hipGetLastError());
+  if (points->mem == PCV_MEM_HOST)
+    PCV_HIP_CHECK(ctx, hipMemcpyAsync(keys, dk, points->n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return PCV_OK;
+}
+
+template <typename KeyT>
+static int sort_api(pcv_ctx* ctx, KeyT* keys, uint32_t* values, uint64_t n, int begin_bit, int end_bit, int mem) {
+  if (!ctx) return PCV_E_INVALID;
+  if (n == 0) return PCV_OK;
+  if (!keys) return ctx->fail(PCV_E_INVALID, "keys is null");
+  if (begin_bit < 0 || end_bit > (int)sizeof(KeyT) * 8 || begin_bit > end_bit) return ctx->fail(PCV_E_INVALID, "bad bit range");
+  if (n >= 0xffffffffull) return ctx->fail(PCV_E_INVALID, "n must be < 2^32 - 1");
+  PCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  PcvScratch sc(ctx);
+  KeyT *a, *b;
+  uint32_t *va = nullptr, *vb = nullptr;
+  void* scratch;
+  int rc;
+  if ((rc = sc.get(&a, n)) || (rc = sc.get(&b, n))) return rc;
+  if (values && ((rc = sc.get(&va, n)) || (rc = sc.get(&vb, n)))) return rc;
+  if ((rc = ctx->dev_alloc(&scratch, pcv_sort_scratch_bytes(n)))) return rc;
+  sc.ptrs.push_back(scratch);
+  hipMemcpyKind in = mem == PCV_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+  hipMemcpyKind outk = mem == PCV_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(a, keys, n * sizeof(KeyT), in, ctx->stream));
+  if (values) PCV_HIP_CHECK(ctx, hipMemcpyAsync(va, values, n * 4, in, ctx->stream));
+  PcvSortPayload pl;
+  pl.nwords = values ? 1 : 0;
+  pl.in[0] = va;
+  pl.out[0] = vb;
+  bool in_a = true;
+  if constexpr (sizeof(KeyT) == 8) rc = pcv_radix_sort_u64(ctx, (uint64_t*)a, (uint64_t*)b, n, begin_bit, end_bit, &pl, scratch, &in_a);
+  else rc = pcv_radix_sort_u32(ctx, (uint32_t*)a, (uint32_t*)b, n, begin_bit, end_bit, &pl, scratch, &in_a);
+  if (rc) return rc;
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(keys, in_a ? a : b, n * sizeof(KeyT), outk, ctx->stream));
+  if (values) PCV_HIP_CHECK(ctx, hipMemcpyAsync(values, in_a ? va : vb, n * 4, outk, ctx->stream));
+  PCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return PCV_OK;
+}
+
+extern "C" int pcv_sort_keys64(pcv_ctx* ctx, uint64_t* keys, uint64_t n, int begin_bit, int end_bit, int mem) {
+  return sort_api<uint64_t>(ctx, keys, nullptr, n, begin_bit, end_bit, mem);
+}
+extern "C" int pcv_sort_pairs32(pcv_ctx* ctx, uint32_t* keys, uint32_t* values, uint64_t n, int begin_bit, int end_bit,
+                                int mem) {
+  if (ctx && !values) return ctx->fail(PCV_E_INVALID, "values is null");
+  return sort_api<uint32_t>(ctx, keys, values, n, begin_bit, end_bit, mem);
+}

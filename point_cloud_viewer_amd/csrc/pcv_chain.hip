@@ -1,0 +1,137 @@
+// pcv_chain.hip — K1 aabb_reduce and K2 chain_keys for gfx950.
+//
+// K1 replaces find_bounding_box (reference src/octree/generation.rs:256-270, Aabb::grow aabb.rs:41-44).
+// K2 replaces the per-point work of split()/split_node() (generation.rs:58-193): the octant digit of every
+// level along the point's quantise->decode chain, which does not depend on the tree topology.
+//
+// Bounds: K1 is a pure HBM stream (24 B/point). K2 is f64-VALU bound by construction (two correctly rounded
+// f64 divisions per coordinate per level; parity forbids reciprocals) — it reads 24 B and writes 8 B/point.
+#include "pcv_chain_dev.h"
+
+namespace {
+
+constexpr int kAabbBlock = 256;
+
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Each block reduces a grid-strided slice of the three coordinate streams; one 6-double partial per block.
+__global__ __launch_bounds__(kAabbBlock) void aabb_partial_kernel(uint64_t n, const double* __restrict__ x,
+                                                                   const double* __restrict__ y,
+                                                                   const double* __restrict__ z,
+                                                                   double* __restrict__ partial) {
+  const double inf = __longlong_as_double(0x7ff0000000000000LL);
+  double lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf};
+  const uint64_t stride = (uint64_t)gridDim.x * kAabbBlock * 2;
+  // two points per lane per iteration: 16-byte loads, fully coalesced
+  for (uint64_t i = ((uint64_t)blockIdx.x * kAabbBlock + threadIdx.x) * 2; i < n; i += stride) {
+    if (i + 1 < n) {
+      double2 vx = *reinterpret_cast<const double2*>(x + i);
+      double2 vy = *reinterpret_cast<const double2*>(y + i);
+      double2 vz = *reinterpret_cast<const double2*>(z + i);
+      lo[0] = fmin(lo[0], fmin(vx.x, vx.y));
+      hi[0] = fmax(hi[0], fmax(vx.x, vx.y));
+      lo[1] = fmin(lo[1], fmin(vy.x, vy.y));
+      hi[1] = fmax(hi[1], fmax(vy.x, vy.y));
+      lo[2] = fmin(lo[2], fmin(vz.x, vz.y));
+      hi[2] = fmax(hi[2], fmax(vz.x, vz.y));
+    } else {
+      lo[0] = fmin(lo[0], x[i]);
+      hi[0] = fmax(hi[0], x[i]);
+      lo[1] = fmin(lo[1], y[i]);
+      hi[1] = fmax(hi[1], y[i]);
+      lo[2] = fmin(lo[2], z[i]);
+      hi[2] = fmax(hi[2], z[i]);
+    }
+  }
+  __shared__ double red[kAabbBlock / 64][6];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    double l = wave_min(lo[a]), h = wave_max(hi[a]);
+    if (lane == 0) {
+      red[wave][a] = l;
+      red[wave][3 + a] = h;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    double v = red[0][threadIdx.x];
+    for (int w = 1; w < kAabbBlock / 64; ++w)
+      v = threadIdx.x < 3 ? fmin(v, red[w][threadIdx.x]) : fmax(v, red[w][threadIdx.x]);
+    partial[(uint64_t)blockIdx.x * 6 + threadIdx.x] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void aabb_final_kernel(int nblocks, const double* __restrict__ partial,
+                                                          double* __restrict__ out6) {
+  const double inf = __longlong_as_double(0x7ff0000000000000LL);
+  __shared__ double red[4][6];
+  double v[6] = {inf, inf, inf, -inf, -inf, -inf};
+  for (int b = threadIdx.x; b < nblocks; b += 256)
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      double q = partial[(uint64_t)b * 6 + a];
+      v[a] = a < 3 ? fmin(v[a], q) : fmax(v[a], q);
+    }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    double r = a < 3 ? wave_min(v[a]) : wave_max(v[a]);
+    if (lane == 0) red[wave][a] = r;
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    double r = red[0][threadIdx.x];
+    for (int w = 1; w < 4; ++w) r = threadIdx.x < 3 ? fmin(r, red[w][threadIdx.x]) : fmax(r, red[w][threadIdx.x]);
+    out6[threadIdx.x] = r;
+  }
+}
+
+// K2: one point per lane; the level loop is wave-uniform (levels, edges and encodings are kernel
+// arguments in SGPRs), so the encoding switch is a scalar branch.
+__global__ __launch_bounds__(256) void chain_keys_kernel(PcvLevels lv, uint64_t n, const double* __restrict__ x,
+                                                          const double* __restrict__ y,
+                                                          const double* __restrict__ z,
+                                                          uint64_t* __restrict__ keys) {
+  uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double px = x[i], py = y[i], pz = z[i];
+  double mx = lv.root_min[0], my = lv.root_min[1], mz = lv.root_min[2];
+  uint64_t key = 0, code;
+  for (int k = 1; k <= lv.nlevels; ++k) {
+    const double ep = lv.edge[k - 1], ec = lv.edge[k];
+    const uint32_t enc = lv.enc[k];
+    uint32_t d = pcv_chain_coord(enc, ep, ec, px, mx, code) << 2;
+    d |= pcv_chain_coord(enc, ep, ec, py, my, code) << 1;
+    d |= pcv_chain_coord(enc, ep, ec, pz, mz, code);
+    key |= (uint64_t)d << (3 * (PCV_MAX_KEY_LEVELS - k));
+  }
+  keys[i] = key;
+}
+
+}  // namespace
+
+int pcv_launch_aabb(pcv_ctx* ctx, uint64_t n, const double* x, const double* y, const double* z, double* partial,
+                    double* out6) {
+  uint64_t want = (n + (uint64_t)kAabbBlock * 2 * 8 - 1) / ((uint64_t)kAabbBlock * 2 * 8);
+  int blocks = (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+  hipLaunchKernelGGL(aabb_partial_kernel, dim3(blocks), dim3(kAabbBlock), 0, ctx->stream, n, x, y, z, partial);
+  hipLaunchKernelGGL(aabb_final_kernel, dim3(1), dim3(256), 0, ctx->stream, blocks, partial, out6);
+  return blocks;
+}
+
+void pcv_launch_chain_keys(hipStream_t s, const PcvLevels& lv, uint64_t n, const double* x, const double* y,
+                           const double* z, uint64_t* keys) {
+  if (n == 0) return;
+  uint64_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(chain_keys_kernel, dim3((unsigned)blocks), dim3(256), 0, s, lv, n, x, y, z, keys);
+}

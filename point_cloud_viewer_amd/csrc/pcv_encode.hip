@@ -1,0 +1,161 @@
+// pcv_encode.hip — K5 leaf_encode (input order) and K6 promote_encode (sorted order).
+//
+// K5: for every input point replay the quantise->decode chain, walking the node table with the digits it
+//     produces until a leaf is reached (generation.rs:78-99,167-177) and emit the record
+//     (leaf rank, leaf-level codes, colour, intensity) that the stable record sort groups by leaf.
+// K6: closed form of the bottom-up `i % 8 == 0` promotion (generation.rs:195-253,335-387):
+//     a point at position j of its node's stream climbs while j % 8 == 0 (new j = offset of the child
+//     inside the parent's stream + j / 8), each climb re-encoding decode_k -> encode_{k-1}
+//     (generation.rs:222-238); a point that stays in a non-root node is rewritten once
+//     (encode_k(decode_k(b))) at slot j - j/8 - 1; the root keeps everything it receives.
+//     Output is written node-contiguous: exactly the bytes of <node>.xyz/.rgb/.intensity.
+#include "pcv_chain_dev.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void leaf_encode_kernel(
+    PcvLevels lv, const uint64_t* __restrict__ walk, uint64_t n, const uint64_t* __restrict__ keys,
+    const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ z,
+    const uint8_t* __restrict__ color, uint32_t color_stride, const float* __restrict__ intensity,
+    uint32_t* __restrict__ rank, uint32_t* __restrict__ cx, uint32_t* __restrict__ cy, uint32_t* __restrict__ cz,
+    uint32_t* __restrict__ cx_hi, uint32_t* __restrict__ cy_hi, uint32_t* __restrict__ cz_hi,
+    uint32_t* __restrict__ rgba, uint32_t* __restrict__ inten_bits) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  // Walk the node table while replaying the chain: the digit of level L comes out of the chain step itself
+  // (identical to K2's digit by construction), so no key has to be read back.
+  // walk record = first_child | child_mask << 32 | leaf << 40 | level << 48 (leaves: low 32 bits = leaf rank)
+  uint64_t rec = walk[0];
+  double px = x[i], py = y[i], pz = z[i];
+  double mx = lv.root_min[0], my = lv.root_min[1], mz = lv.root_min[2];
+  uint64_t ccx = 0, ccy = 0, ccz = 0;
+  int L = 0;
+  do {
+    ++L;
+    const double ep = lv.edge[L - 1], ec = lv.edge[L];
+    const uint32_t enc = lv.enc[L];
+    uint32_t d = pcv_chain_coord(enc, ep, ec, px, mx, ccx) << 2;
+    d |= pcv_chain_coord(enc, ep, ec, py, my, ccy) << 1;
+    d |= pcv_chain_coord(enc, ep, ec, pz, mz, ccz);
+    const uint32_t mask = (uint32_t)(rec >> 32) & 0xffu;
+    const uint32_t idx = (uint32_t)rec + __popc(mask & ((1u << d) - 1u));
+    rec = walk[idx];
+  } while (!((rec >> 40) & 1ull) && L < lv.nlevels);
+  rank[i] = (uint32_t)rec;
+  cx[i] = (uint32_t)ccx;
+  cy[i] = (uint32_t)ccy;
+  cz[i] = (uint32_t)ccz;
+  if (cx_hi) {  // some leaf level is Float64-encoded: carry the high words too
+    cx_hi[i] = (uint32_t)(ccx >> 32);
+    cy_hi[i] = (uint32_t)(ccy >> 32);
+    cz_hi[i] = (uint32_t)(ccz >> 32);
+  }
+  const uint8_t* c = color + i * color_stride;
+  rgba[i] = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16);
+  if (inten_bits) inten_bits[i] = __float_as_uint(intensity[i]);
+}
+
+__global__ __launch_bounds__(256) void promote_encode_kernel(
+    PcvLevels lv, PcvPromoteTables pt, uint64_t n, const uint32_t* __restrict__ rank,
+    const uint32_t* __restrict__ cx, const uint32_t* __restrict__ cy, const uint32_t* __restrict__ cz,
+    const uint32_t* __restrict__ cx_hi, const uint32_t* __restrict__ cy_hi, const uint32_t* __restrict__ cz_hi,
+    const uint32_t* __restrict__ rgba, const uint32_t* __restrict__ inten_bits, uint8_t* __restrict__ xyz_blob,
+    uint8_t* __restrict__ rgb_blob, uint8_t* __restrict__ inten_blob) {
+  const uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (s >= n) return;
+  const uint32_t r = rank[s];
+  uint32_t node = pt.leaf_node[r];
+  uint32_t j = (uint32_t)s - pt.leaf_lo[r];
+  int level = pt.level[node];
+  uint64_t code[3] = {cx[s], cy[s], cz[s]};
+  if (cx_hi) {
+    code[0] |= (uint64_t)cx_hi[s] << 32;
+    code[1] |= (uint64_t)cy_hi[s] << 32;
+    code[2] |= (uint64_t)cz_hi[s] << 32;
+  }
+  // climb while this point is an every-8th element of its node's stream
+  while (node != 0 && (j & 7u) == 0) {
+    const uint32_t par = pt.parent[node];
+    const double* mn = pt.node_min + (uint64_t)node * 3;
+    const double* pm = pt.node_min + (uint64_t)par * 3;
+    const uint32_t ec = lv.enc[level], ep = lv.enc[level - 1];
+    const double edge_c = lv.edge[level], edge_p = lv.edge[level - 1];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const double q = pcv_decode_coord(ec, code[a], mn[a], edge_c);
+      code[a] = pcv_encode_coord(ep, q, pm[a], edge_p);
+    }
+    j = pt.child_off[node] + (j >> 3);
+    node = par;
+    --level;
+  }
+  uint32_t slot = j;
+  const uint32_t enc = lv.enc[level];
+  if (node != 0) {
+    slot = j - (j >> 3) - 1u;
+    const double* mn = pt.node_min + (uint64_t)node * 3;
+    const double edge = lv.edge[level];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) code[a] = pcv_encode_coord(enc, pcv_decode_coord(enc, code[a], mn[a], edge), mn[a], edge);
+  }
+  uint8_t* dst = xyz_blob + pt.xyz_off[node];
+  switch (enc) {
+    case PCV_ENC_UINT8: {
+      uint8_t* d = dst + (uint64_t)slot * 3;
+      d[0] = (uint8_t)code[0];
+      d[1] = (uint8_t)code[1];
+      d[2] = (uint8_t)code[2];
+      break;
+    }
+    case PCV_ENC_UINT16: {
+      uint16_t* d = reinterpret_cast<uint16_t*>(dst) + (uint64_t)slot * 3;
+      d[0] = (uint16_t)code[0];
+      d[1] = (uint16_t)code[1];
+      d[2] = (uint16_t)code[2];
+      break;
+    }
+    case PCV_ENC_FLOAT32: {
+      uint32_t* d = reinterpret_cast<uint32_t*>(dst) + (uint64_t)slot * 3;
+      d[0] = (uint32_t)code[0];
+      d[1] = (uint32_t)code[1];
+      d[2] = (uint32_t)code[2];
+      break;
+    }
+    default: {
+      uint64_t* d = reinterpret_cast<uint64_t*>(dst) + (uint64_t)slot * 3;
+      d[0] = code[0];
+      d[1] = code[1];
+      d[2] = code[2];
+      break;
+    }
+  }
+  const uint64_t pidx = pt.point_off[node] + slot;
+  const uint32_t c = rgba[s];
+  uint8_t* cd = rgb_blob + pidx * 3;
+  cd[0] = (uint8_t)c;
+  cd[1] = (uint8_t)(c >> 8);
+  cd[2] = (uint8_t)(c >> 16);
+  if (inten_blob) reinterpret_cast<uint32_t*>(inten_blob)[pidx] = inten_bits[s];
+}
+
+}  // namespace
+
+void pcv_launch_leaf_encode(hipStream_t s, const PcvLevels& lv, const PcvWalkTables& wt, uint64_t n,
+                            const uint64_t* keys, const double* x, const double* y, const double* z,
+                            const uint8_t* color, uint32_t color_stride, const float* intensity, uint32_t* rank,
+                            uint32_t* cx, uint32_t* cy, uint32_t* cz, uint32_t* cx_hi, uint32_t* cy_hi,
+                            uint32_t* cz_hi, uint32_t* rgba, uint32_t* inten_bits) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(leaf_encode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, lv, wt.walk, n, keys, x,
+                     y, z, color, color_stride, intensity, rank, cx, cy, cz, cx_hi, cy_hi, cz_hi, rgba, inten_bits);
+}
+
+void pcv_launch_promote_encode(hipStream_t s, const PcvLevels& lv, const PcvPromoteTables& pt, uint64_t n,
+                               const uint32_t* rank, const uint32_t* cx, const uint32_t* cy, const uint32_t* cz,
+                               const uint32_t* cx_hi, const uint32_t* cy_hi, const uint32_t* cz_hi,
+                               const uint32_t* rgba, const uint32_t* inten_bits, uint8_t* xyz_blob,
+                               uint8_t* rgb_blob, uint8_t* inten_blob) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(promote_encode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, lv, pt, n, rank, cx,
+                     cy, cz, cx_hi, cy_hi, cz_hi, rgba, inten_bits, xyz_blob, rgb_blob, inten_blob);
+}

@@ -1,0 +1,168 @@
+// pcv_internal.h — shared host-side declarations of the MI355X octree-build library.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/pcv_hip.h"
+
+#define PCV_HIP_CHECK(ctx, expr)                                                                   \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess) return (ctx)->fail(PCV_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+// Per-level constants handed to every kernel by value (lands in SGPRs; uniform across the grid).
+// edge[k], enc[k] for k = 0..nlevels: see pcv_level_table / reference codec.rs:31-40, node.rs:161.
+struct PcvLevels {
+  double root_min[3];
+  double edge[PCV_MAX_KEY_LEVELS + 2];
+  uint8_t enc[PCV_MAX_KEY_LEVELS + 3];
+  int32_t nlevels;  // number of digit levels materialised in the keys (<= PCV_MAX_KEY_LEVELS)
+};
+
+// Caching device allocator + pinned host scratch, one per context. Steady-state builds allocate nothing.
+struct PcvPool {
+  std::multimap<size_t, void*> free_blocks;
+  std::map<void*, size_t> live;
+  void* alloc(size_t bytes, hipError_t* err);
+  void release(void* p);
+  void trim();
+};
+
+struct pcv_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string last_error;
+  PcvPool pool;
+  // pinned host staging, grown on demand
+  void* pinned = nullptr;
+  size_t pinned_bytes = 0;
+  hipEvent_t ev[PCV_NUM_STAGES + 2] = {};
+
+  int fail(int code, const std::string& msg) {
+    last_error = msg;
+    return code;
+  }
+  int dev_alloc(void** p, size_t bytes);
+  void dev_free(void* p);
+  int pinned_reserve(size_t bytes);
+};
+
+// RAII bundle of pool allocations released on scope exit (unless detached).
+struct PcvScratch {
+  pcv_ctx* ctx;
+  std::vector<void*> ptrs;
+  explicit PcvScratch(pcv_ctx* c) : ctx(c) {}
+  ~PcvScratch() {
+    for (void* p : ptrs) ctx->dev_free(p);
+  }
+  template <typename T>
+  int get(T** out, size_t count) {
+    void* p = nullptr;
+    int rc = ctx->dev_alloc(&p, count * sizeof(T));
+    if (rc != PCV_OK) return rc;
+    ptrs.push_back(p);
+    *out = (T*)p;
+    return PCV_OK;
+  }
+  void detach(void* p) {
+    for (auto& q : ptrs)
+      if (q == p) {
+        q = ptrs.back();
+        ptrs.pop_back();
+        return;
+      }
+  }
+};
+
+// ---- kernels (launchers; all asynchronous on `stream`) --------------------------------------------
+// pcv_chain.hip
+int pcv_launch_aabb(pcv_ctx* ctx, uint64_t n, const double* x, const double* y, const double* z, double* partial,
+                    double* out6 /* device: min xyz, max xyz */);
+void pcv_launch_chain_keys(hipStream_t s, const PcvLevels& lv, uint64_t n, const double* x, const double* y,
+                           const double* z, uint64_t* keys);
+
+// pcv_sort.hip — stable LSD radix sort, 8-bit digits, reduce-then-scan with LDS histograms.
+struct PcvSortPayload {
+  int nwords;           // number of 32-bit payload arrays that travel with the key (0..8)
+  uint32_t* in[8];
+  uint32_t* out[8];
+};
+size_t pcv_sort_scratch_bytes(uint64_t n);
+// Sorts keys_in -> ... ping-pong between (keys_a, payload.in) and (keys_b, payload.out). Returns in
+// *result_in_a whether the final sorted data is in the a-side (true) or b-side (false).
+int pcv_radix_sort_u64(pcv_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint64_t n, int begin_bit, int end_bit,
+                       PcvSortPayload* payload, void* scratch, bool* result_in_a);
+int pcv_radix_sort_u32(pcv_ctx* ctx, uint32_t* keys_a, uint32_t* keys_b, uint64_t n, int begin_bit, int end_bit,
+                       PcvSortPayload* payload, void* scratch, bool* result_in_a);
+
+// pcv_topology.hip — node split (topology from sorted keys).
+// Device node table, structure of arrays, BFS order (level-major, prefix-sorted inside a level).
+struct PcvNodeTableDev {
+  uint32_t capacity;
+  uint64_t* prefix;      // left-aligned path key (digits beyond `level` are zero)
+  uint32_t* lo;          // [lo, hi) range in the sorted key array
+  uint32_t* hi;
+  uint32_t* parent;
+  uint32_t* first_child; // index of the first child (children are contiguous, in digit order)
+  uint8_t* level;
+  uint8_t* child_mask;   // bit c set = child c exists
+  uint8_t* open;         // 1 = split further (inner node), 0 = leaf
+  uint32_t* bounds;      // scratch: 9 bounds per node of the level being expanded
+  uint32_t* counters;    // [0] node_count, [1] error flag, [2..] level_start[k] (k = 0..PCV_MAX_KEY_LEVELS+1)
+};
+void pcv_launch_node_split(hipStream_t s, const PcvNodeTableDev& t, const uint64_t* sorted_keys, uint32_t n,
+                           const PcvLevels& lv, double resolution, uint32_t max_points_per_node);
+
+// pcv_encode.hip — leaf lookup + leaf-level encode (input order), promotion + final encode (sorted order).
+struct PcvWalkTables {
+  const uint64_t* walk;  // per node: first_child(32) | child_mask(8) << 32 | leaf(1) << 40 | level(8) << 48;
+                         // for leaves the low 32 bits hold the leaf rank
+};
+void pcv_launch_leaf_encode(hipStream_t s, const PcvLevels& lv, const PcvWalkTables& wt, uint64_t n,
+                            const uint64_t* keys, const double* x, const double* y, const double* z,
+                            const uint8_t* color, uint32_t color_stride, const float* intensity, uint32_t* rank,
+                            uint32_t* cx, uint32_t* cy, uint32_t* cz, uint32_t* cx_hi, uint32_t* cy_hi,
+                            uint32_t* cz_hi, uint32_t* rgba, uint32_t* inten_bits);
+
+struct PcvPromoteTables {
+  const uint32_t* leaf_lo;     // per leaf rank: first sorted slot
+  const uint32_t* leaf_node;   // per leaf rank: node index
+  const uint32_t* parent;      // per node
+  const uint32_t* child_off;   // per node: offset of its promoted block inside the parent's stream
+  const uint8_t* level;        // per node
+  const double* node_min;      // per node: 3 doubles
+  const uint64_t* xyz_off;     // per node: byte offset in the xyz blob
+  const uint64_t* point_off;   // per node: point offset in the rgb/intensity blobs
+};
+void pcv_launch_promote_encode(hipStream_t s, const PcvLevels& lv, const PcvPromoteTables& pt, uint64_t n,
+                               const uint32_t* rank, const uint32_t* cx, const uint32_t* cy, const uint32_t* cz,
+                               const uint32_t* cx_hi, const uint32_t* cy_hi, const uint32_t* cz_hi,
+                               const uint32_t* rgba, const uint32_t* inten_bits, uint8_t* xyz_blob,
+                               uint8_t* rgb_blob, uint8_t* inten_blob);
+
+// The finished octree (node table + node-contiguous blobs).
+struct pcv_octree {
+  pcv_ctx* ctx = nullptr;
+  double resolution = 0;
+  double bbox_min[3] = {0, 0, 0}, bbox_max[3] = {0, 0, 0};
+  bool has_intensity = false;
+  uint64_t num_points = 0;
+  std::vector<pcv_node_info> nodes;
+  uint8_t *d_xyz = nullptr, *d_rgb = nullptr, *d_int = nullptr;
+  uint64_t xyz_bytes = 0, rgb_bytes = 0, int_bytes = 0;
+  std::vector<uint8_t> h_xyz, h_rgb, h_int;
+  bool host_valid = false;
+  float stage_ms[PCV_NUM_STAGES] = {};
+};
+int pcv_octree_fetch_host(pcv_octree* t);
+int pcv_bytes_per_coordinate(uint32_t enc);
+
+// host helpers (pcv_build.hip)
+int pcv_make_levels(const double bmin[3], const double bmax[3], double resolution, int cap, PcvLevels* lv,
+                    int* max_level, std::vector<double>* edges, std::vector<int32_t>* encs);

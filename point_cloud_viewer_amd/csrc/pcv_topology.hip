@@ -1,0 +1,182 @@
+// pcv_topology.hip — K4 node_split: the octree topology from the sorted path keys.
+//
+// Replaces the recursion of split()/should_split_node()/split_node() (reference
+// src/octree/generation.rs:58-193): a child exists iff at least one point carries its path prefix, and a
+// child is split again iff `count > MAX_POINTS_PER_NODE && child.edge > resolution` (generation.rs:128-150);
+// the root is always split (generation.rs:312-323). With the keys sorted, a node is a contiguous range and its
+// eight children are found with seven lower-bound searches.
+//
+// Per level two launches: (A) one wave64 per (open node, child digit) runs a 64-ary search — every lane probes
+// one key, a ballot narrows the range 64x per step (5 dependent loads for 2^30 keys instead of 30);
+// (B) one workgroup scans the child counts and appends the new level to the node table in (parent, digit)
+// order, so the table is deterministic and BFS-ordered.
+#include "pcv_internal.h"
+
+namespace {
+
+enum { CNT_NODES = 0, CNT_ERROR = 1, CNT_LEVEL_START = 2 };
+
+__device__ __forceinline__ uint32_t wave_lower_bound(const uint64_t* __restrict__ keys, uint32_t lo, uint32_t hi,
+                                                     uint64_t target, int lane) {
+  // invariant: every key before lo is < target, every key at or after hi is >= target
+  while (hi - lo > 64) {
+    const uint32_t span = hi - lo;
+    const uint32_t step = (span + 63) / 64;
+    uint64_t idx = (uint64_t)lo + (uint64_t)(lane + 1) * step - 1;
+    const bool in = idx < hi;
+    const uint64_t v = keys[in ? idx : (uint64_t)hi - 1];
+    const uint64_t m = __ballot(in && v < target);
+    const uint32_t cnt = __popcll(m);  // probes are monotone: the mask is a prefix
+    const uint64_t nlo = (uint64_t)lo + (uint64_t)cnt * step;
+    const uint64_t nhi = (uint64_t)lo + (uint64_t)(cnt + 1) * step - 1;  // first probe that is >= target
+    lo = (uint32_t)(nlo < hi ? nlo : hi);
+    hi = (uint32_t)(nhi < hi ? nhi : hi);
+  }
+  const bool in = lo + (uint32_t)lane < hi;
+  const uint64_t v = in ? keys[lo + lane] : 0;
+  const uint64_t m = __ballot(in && v < target);
+  return lo + (uint32_t)__popcll(m);
+}
+
+__global__ __launch_bounds__(256) void init_root_kernel(PcvNodeTableDev t, uint32_t n) {
+  if (threadIdx.x == 0) {
+    t.prefix[0] = 0;
+    t.lo[0] = 0;
+    t.hi[0] = n;
+    t.parent[0] = 0xffffffffu;
+    t.first_child[0] = 0;
+    t.level[0] = 0;
+    t.child_mask[0] = 0;
+    t.open[0] = n > 0 ? 1 : 0;  // the root is always split (generation.rs:312-323)
+    t.counters[CNT_NODES] = 1;
+    t.counters[CNT_ERROR] = 0;
+    t.counters[CNT_LEVEL_START + 0] = 0;
+    t.counters[CNT_LEVEL_START + 1] = 1;
+  }
+}
+
+// (A) child boundaries of every open node of level k-1.
+__global__ __launch_bounds__(256) void split_search_kernel(PcvNodeTableDev t, const uint64_t* __restrict__ keys,
+                                                            int k) {
+  const uint32_t begin = t.counters[CNT_LEVEL_START + k - 1];
+  const uint32_t end = t.counters[CNT_LEVEL_START + k];
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave_global = (blockIdx.x * 256u + threadIdx.x) >> 6;
+  const uint32_t nwaves = gridDim.x * 4u;
+  const int shift = 3 * (PCV_MAX_KEY_LEVELS - k);
+  const uint32_t items = (end - begin) * 7u;
+  for (uint32_t it = wave_global; it < items; it += nwaves) {
+    const uint32_t node = begin + it / 7u;
+    const uint32_t c = it % 7u + 1u;
+    if (!t.open[node]) continue;  // wave-uniform
+    const uint32_t lo = t.lo[node], hi = t.hi[node];
+    const uint64_t target = t.prefix[node] | ((uint64_t)c << shift);
+    const uint32_t b = wave_lower_bound(keys, lo, hi, target, lane);
+    if (lane == 0) {
+      uint32_t* bd = t.bounds + (uint64_t)(node - begin) * 9u;
+      bd[c] = b;
+      if (c == 1) {
+        bd[0] = lo;
+        bd[8] = hi;
+      }
+    }
+  }
+}
+
+// (B) append level k. One workgroup; nodes of level k-1 are visited in order, children get consecutive
+// indices in (parent, digit) order.
+__global__ __launch_bounds__(1024) void split_assign_kernel(PcvNodeTableDev t, PcvLevels lv, double resolution,
+                                                             uint32_t max_points, int k) {
+  __shared__ uint32_t wave_tot[16];
+  __shared__ uint32_t running;
+  const uint32_t begin = t.counters[CNT_LEVEL_START + k - 1];
+  const uint32_t end = t.counters[CNT_LEVEL_START + k];
+  const uint32_t base0 = t.counters[CNT_NODES];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int shift = 3 * (PCV_MAX_KEY_LEVELS - k);
+  if (threadIdx.x == 0) running = base0;
+  __syncthreads();
+  for (uint32_t chunk = begin; chunk < end; chunk += 1024) {
+    const uint32_t node = chunk + threadIdx.x;
+    uint32_t b[9];
+    uint32_t mask = 0, cnt = 0;
+    const bool active = node < end && t.open[node];
+    if (active) {
+      const uint32_t* bd = t.bounds + (uint64_t)(node - begin) * 9u;
+#pragma unroll
+      for (int c = 0; c < 9; ++c) b[c] = bd[c];
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        if (b[c + 1] > b[c]) {
+          mask |= 1u << c;
+          ++cnt;
+        }
+    }
+    uint32_t inc = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      uint32_t v = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += v;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    uint32_t woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      uint32_t v = wave_tot[w];
+      woff += (w < wave) ? v : 0u;
+      total += v;
+    }
+    const uint32_t first = running + woff + inc - cnt;
+    if (active) {
+      t.first_child[node] = first;
+      t.child_mask[node] = (uint8_t)mask;
+      uint32_t j = first;
+      const uint64_t pfx = t.prefix[node];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        if (!((mask >> c) & 1u)) continue;
+        if (j < t.capacity) {
+          const uint32_t count = b[c + 1] - b[c];
+          // should_split_node (generation.rs:128-150): count > MAX && child edge > resolution
+          bool open = count > max_points && lv.edge[k] > resolution;
+          if (open && k >= lv.nlevels) {
+            // would need digits beyond the key width
+            atomicOr(&t.counters[CNT_ERROR], 1u);
+            open = false;
+          }
+          t.prefix[j] = pfx | ((uint64_t)c << shift);
+          t.lo[j] = b[c];
+          t.hi[j] = b[c + 1];
+          t.parent[j] = node;
+          t.first_child[j] = 0;
+          t.level[j] = (uint8_t)k;
+          t.child_mask[j] = 0;
+          t.open[j] = open ? 1 : 0;
+        } else {
+          atomicOr(&t.counters[CNT_ERROR], 2u);  // node table capacity exceeded
+        }
+        ++j;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) running += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    uint32_t total_nodes = running < t.capacity ? running : t.capacity;
+    t.counters[CNT_NODES] = total_nodes;
+    t.counters[CNT_LEVEL_START + k + 1] = total_nodes;
+  }
+}
+
+}  // namespace
+
+void pcv_launch_node_split(hipStream_t s, const PcvNodeTableDev& t, const uint64_t* sorted_keys, uint32_t n,
+                           const PcvLevels& lv, double resolution, uint32_t max_points_per_node) {
+  hipLaunchKernelGGL(init_root_kernel, dim3(1), dim3(256), 0, s, t, n);
+  for (int k = 1; k <= lv.nlevels; ++k) {
+    hipLaunchKernelGGL(split_search_kernel, dim3(512), dim3(256), 0, s, t, sorted_keys, k);
+    hipLaunchKernelGGL(split_assign_kernel, dim3(1), dim3(1024), 0, s, t, lv, resolution, max_points_per_node, k);
+  }
+}

@@ -1,0 +1,280 @@
+"""Host-side mirror of the reference's octree-build surface over the C ABI (thin; all work is in HIP).
+
+Reference names kept: `build_octree(output_directory, resolution, bounding_box, input, attributes)`
+(src/octree/generation.rs:289-295), `NodeId` Display/parse (src/octree/node.rs:59-86), `Aabb`.
+Inputs may be numpy arrays (host) or torch CUDA tensors (device-resident; zero copy).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _is_torch(a):
+    return type(a).__module__.startswith("torch")
+
+
+def node_name(id_high, id_low):
+    """NodeId Display (node.rs:73-86): 'r' + octal index padded to `level` digits."""
+    level = id_high >> 56
+    index = ((id_high & ((1 << 56) - 1)) << 64) | id_low
+    return "r" + "".join(str((index >> (3 * j)) & 7) for j in range(level - 1, -1, -1))
+
+
+class Aabb:
+    """geometry::Aabb (src/geometry/aabb.rs:13-27): mins/maxs are the inf/sup of the two corners."""
+
+    def __init__(self, a, b):
+        a = np.asarray(a, dtype=np.float64)
+        b = np.asarray(b, dtype=np.float64)
+        self.min = np.minimum(a, b)
+        self.max = np.maximum(a, b)
+
+
+class _Buf:
+    """Pointer + keep-alive for one input array."""
+
+    def __init__(self, arr, dtype, what):
+        self.keep = arr
+        if arr is None:
+            self.ptr, self.device, self.size = None, None, 0
+            return
+        if _is_torch(arr):
+            import torch
+            want = {np.float64: torch.float64, np.uint8: torch.uint8, np.float32: torch.float32,
+                    np.uint64: torch.int64, np.uint32: torch.int32}[dtype]
+            if arr.dtype != want and not (dtype is np.uint64 and arr.dtype == torch.uint64) and not (
+                    dtype is np.uint32 and arr.dtype == torch.uint32):
+                raise TypeError(f"{what}: expected torch dtype {want}, got {arr.dtype}")
+            if not arr.is_contiguous():
+                raise ValueError(f"{what}: tensor must be contiguous")
+            self.ptr = arr.data_ptr()
+            self.device = arr.is_cuda
+            self.size = arr.numel()
+        else:
+            a = np.ascontiguousarray(arr, dtype=dtype)
+            self.keep = a
+            self.ptr = a.ctypes.data
+            self.device = False
+            self.size = a.size
+
+
+class Context:
+    """One pcv_ctx: bound to one HIP device and stream, not thread-safe (include/pcv_hip.h)."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = L.load_library()
+        h = C.c_void_p()
+        rc = self.lib.pcv_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h))
+        if rc != L.PCV_OK:
+            raise L.PcvError(rc, f"pcv_ctx_create(device={device}) failed — is a HIP device visible?")
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.pcv_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != L.PCV_OK:
+            raise L.PcvError(rc, self.lib.pcv_last_error(self.handle).decode())
+
+    def _points(self, x, y, z, color=None, intensity=None):
+        bx, by, bz = _Buf(x, np.float64, "x"), _Buf(y, np.float64, "y"), _Buf(z, np.float64, "z")
+        bc = _Buf(color, np.uint8, "color")
+        bi = _Buf(intensity, np.float32, "intensity")
+        n = bx.size
+        if by.size != n or bz.size != n:
+            raise ValueError("x, y, z must have the same length")
+        devs = {b.device for b in (bx, by, bz, bc, bi) if b.ptr is not None}
+        if len(devs) > 1:
+            raise ValueError("all point arrays must live in the same memory space")
+        stride = 3
+        if color is not None:
+            if bc.size == 4 * n and n > 0:
+                stride = 4
+            elif bc.size != 3 * n:
+                raise ValueError("color must hold 3 or 4 bytes per point")
+        if intensity is not None and bi.size != n:
+            raise ValueError("intensity must hold one f32 per point")
+        p = L.Points()
+        p.n = n
+        p.x, p.y, p.z = bx.ptr, by.ptr, bz.ptr
+        p.color = bc.ptr
+        p.color_stride = stride
+        p.intensity = bi.ptr
+        p.mem = L.MEM_DEVICE if (devs and devs.pop()) else L.MEM_HOST
+        return p, (bx, by, bz, bc, bi)
+
+    @staticmethod
+    def _params(resolution, bmin, bmax, max_points_per_node=0, flags=0):
+        pr = L.BuildParams()
+        pr.resolution = float(resolution)
+        if bmin is not None:
+            for a in range(3):
+                pr.bbox_min[a] = float(bmin[a])
+                pr.bbox_max[a] = float(bmax[a])
+        pr.max_points_per_node = int(max_points_per_node)
+        pr.flags = int(flags)
+        return pr
+
+    # ---- the build -------------------------------------------------------------------------------
+    def build(self, resolution, bounding_box, x, y, z, color, intensity=None, max_points_per_node=0):
+        """build_octree up to (not including) the file writes. bounding_box=None computes it on the
+        device (== build_octree_from_file's find_bounding_box pass)."""
+        p, keep = self._points(x, y, z, color, intensity)
+        if bounding_box is None:
+            pr = self._params(resolution, None, None, max_points_per_node, L.BUILD_COMPUTE_BBOX)
+        else:
+            pr = self._params(resolution, bounding_box.min, bounding_box.max, max_points_per_node, 0)
+        h = C.c_void_p()
+        self._check(self.lib.pcv_build_octree(self.handle, C.byref(pr), C.byref(p), C.byref(h)))
+        del keep
+        return OctreeResult(self, h)
+
+    # ---- stage-level entry points ----------------------------------------------------------------
+    def aabb_reduce(self, x, y, z):
+        p, keep = self._points(x, y, z)
+        bmin, bmax = (C.c_double * 3)(), (C.c_double * 3)()
+        self._check(self.lib.pcv_aabb_reduce(self.handle, C.byref(p), bmin, bmax))
+        return np.array(bmin[:]), np.array(bmax[:])
+
+    def chain_keys(self, resolution, bounding_box, x, y, z, nlevels=0):
+        p, keep = self._points(x, y, z)
+        pr = self._params(resolution, bounding_box.min, bounding_box.max)
+        if p.mem == L.MEM_DEVICE:
+            import torch
+            keys = torch.empty(p.n, dtype=torch.int64, device=x.device)
+            self._check(self.lib.pcv_chain_keys(self.handle, C.byref(pr), C.byref(p), nlevels, keys.data_ptr()))
+            return keys
+        keys = np.zeros(p.n, dtype=np.uint64)
+        self._check(self.lib.pcv_chain_keys(self.handle, C.byref(pr), C.byref(p), nlevels, keys.ctypes.data))
+        return keys
+
+    def sort_keys64(self, keys, begin_bit=0, end_bit=64):
+        b = _Buf(keys, np.uint64, "keys")
+        self._check(self.lib.pcv_sort_keys64(self.handle, b.ptr, b.size, begin_bit, end_bit,
+                                             L.MEM_DEVICE if b.device else L.MEM_HOST))
+        return b.keep
+
+    def sort_pairs32(self, keys, values, begin_bit=0, end_bit=32):
+        k, v = _Buf(keys, np.uint32, "keys"), _Buf(values, np.uint32, "values")
+        if k.size != v.size:
+            raise ValueError("keys and values must have the same length")
+        self._check(self.lib.pcv_sort_pairs32(self.handle, k.ptr, v.ptr, k.size, begin_bit, end_bit,
+                                              L.MEM_DEVICE if k.device else L.MEM_HOST))
+        return k.keep, v.keep
+
+
+def level_table(bbox_min, bbox_max, resolution, cap=64):
+    lib = L.load_library()
+    bmin = (C.c_double * 3)(*[float(v) for v in bbox_min])
+    bmax = (C.c_double * 3)(*[float(v) for v in bbox_max])
+    edge = (C.c_double * (cap + 2))()
+    enc = (C.c_int32 * (cap + 2))()
+    ml = lib.pcv_level_table(bmin, bmax, float(resolution), cap, edge, enc)
+    return ml, np.array(edge[:ml + 1]), np.array(enc[:ml + 1], dtype=np.int32)
+
+
+class OctreeResult:
+    """A finished octree held by the library: node table + node-contiguous file bytes."""
+
+    def __init__(self, ctx, handle):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        self.handle = handle
+
+    def free(self):
+        if self.handle:
+            self.lib.pcv_octree_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    @property
+    def num_nodes(self):
+        return self.lib.pcv_octree_num_nodes(self.handle)
+
+    @property
+    def num_points(self):
+        return self.lib.pcv_octree_num_points(self.handle)
+
+    def meta(self):
+        res = C.c_double()
+        bmin, bmax = (C.c_double * 3)(), (C.c_double * 3)()
+        ver = C.c_int()
+        self.lib.pcv_octree_meta(self.handle, C.byref(res), bmin, bmax, C.byref(ver))
+        return dict(resolution=res.value, bbox_min=np.array(bmin[:]), bbox_max=np.array(bmax[:]), version=ver.value)
+
+    def node(self, i):
+        info = L.NodeInfo()
+        self.ctx._check(self.lib.pcv_octree_node(self.handle, i, C.byref(info)))
+        return info
+
+    def node_data(self, i, which):
+        ptr, ln = C.c_void_p(), C.c_uint64()
+        self.ctx._check(self.lib.pcv_octree_node_data(self.handle, i, which, C.byref(ptr), C.byref(ln)))
+        return C.string_at(ptr, ln.value) if ln.value else b""
+
+    def stage_ms(self):
+        ms = (C.c_float * L.NUM_STAGES)()
+        n = self.lib.pcv_octree_stage_ms(self.handle, ms, L.NUM_STAGES)
+        return {L.STAGE_NAMES[i]: ms[i] for i in range(n)}
+
+    def write_dir(self, directory):
+        self.ctx._check(self.lib.pcv_octree_write_dir(self.handle, str(directory).encode()))
+
+    def to_dict(self):
+        """{node name: dict(id, num_points, encoding, level, xyz, rgb, intensity)} — same shape the test-side
+        oracle wrapper uses, so parity tests are plain dict comparisons."""
+        has_int = bool(self.lib.pcv_octree_has_intensity(self.handle))
+        out = {}
+        for i in range(self.num_nodes):
+            nd = self.node(i)
+            name = node_name(nd.id_high, nd.id_low)
+            out[name] = dict(id=(nd.id_high, nd.id_low), num_points=nd.num_points, encoding=nd.encoding,
+                             level=nd.level, xyz=self.node_data(i, 0), rgb=self.node_data(i, 1),
+                             intensity=self.node_data(i, 2) if has_int else b"",
+                             cube_min=tuple(nd.cube_min), cube_edge=nd.cube_edge)
+        return out
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+def build_octree(output_directory, resolution, bounding_box, points, attributes=("color",), ctx=None,
+                 max_points_per_node=0):
+    """Drop-in for reference `build_octree` (generation.rs:289-295): builds on the GPU and writes the
+    reference's directory layout. `points` = dict(x=, y=, z=, color=, intensity=optional)."""
+    attributes = tuple(attributes)
+    if "color" not in attributes:
+        raise ValueError("the octree format requires the 'color' attribute (on_disk.rs:20-22)")
+    for a in attributes:
+        if a not in ("color", "intensity"):
+            raise ValueError(f"unsupported attribute {a!r} (octree/mod.rs:62-74 implies color and intensity)")
+    ctx = ctx or default_context()
+    inten = points.get("intensity") if "intensity" in attributes else None
+    if "intensity" in attributes and inten is None:
+        raise ValueError("attribute 'intensity' requested but not present in the input")
+    tree = ctx.build(resolution, bounding_box, points["x"], points["y"], points["z"], points["color"], inten,
+                     max_points_per_node)
+    tree.write_dir(output_directory)
+    return tree

@@ -1,0 +1,99 @@
+"""Stage-level parity of the HIP kernels against the CPU oracle (all through the C ABI)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import point_cloud_viewer_amd as pcv
+from point_cloud_viewer_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = pcv.Context(0)
+    yield c
+    c.close()
+
+
+def _clouds():
+    x, y, z, rgb, bmin, bmax = synthetic.uniform_ecef(200_000)
+    yield "uniform_ecef", x, y, z, bmin, bmax, 0.001
+    x, y, z, rgb, bmin, bmax = synthetic.gaussian_clusters(300_000, seed=4, num_clusters=5, extent=1000.0,
+                                                           sigma_range=(0.01, 20.0))
+    yield "clusters", x, y, z, bmin, bmax, 0.001
+    x, y, z, rgb, bmin, bmax = synthetic.gaussian_clusters(100_000, seed=6, num_clusters=8, extent=30000.0,
+                                                           sigma_range=(1.0, 500.0), offset=(-2.7e6, -4.3e6, 3.8e6))
+    yield "ecef_f64_levels", x, y, z, bmin, bmax, 0.001  # root edge > 16.7 km -> Float64 levels
+    x, y, z, rgb, bmin, bmax, res = synthetic.reference_unit_test_cloud()
+    yield "reference_unit_test", x, y, z, bmin, bmax, res
+
+
+def test_aabb_reduce(ctx):
+    for name, x, y, z, *_ in _clouds():
+        bmin, bmax = ctx.aabb_reduce(x, y, z)
+        omin, omax = O.aabb(x, y, z)
+        assert np.array_equal(bmin, omin) and np.array_equal(bmax, omax), name
+    bmin, bmax = ctx.aabb_reduce(np.zeros(0), np.zeros(0), np.zeros(0))
+    assert not bmin.any() and not bmax.any()  # Aabb::zero()
+    one = ctx.aabb_reduce(np.array([3.0]), np.array([-4.0]), np.array([5.5]))
+    assert one[0].tolist() == [3.0, -4.0, 5.5] and one[1].tolist() == [3.0, -4.0, 5.5]
+
+
+def test_aabb_reduce_odd_sizes_and_unaligned_views(ctx):
+    import torch
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 3, 63, 64, 65, 511, 4097, 100_003):
+        p = rng.normal(size=(3, n + 1)) * 1e3
+        bmin, bmax = ctx.aabb_reduce(p[0, :n], p[1, :n], p[2, :n])
+        assert np.array_equal(bmin, p[:, :n].min(axis=1)) and np.array_equal(bmax, p[:, :n].max(axis=1))
+        t = torch.from_numpy(p).cuda()
+        bmin, bmax = ctx.aabb_reduce(t[0, 1:], t[1, 1:], t[2, 1:])  # 8-byte-aligned device views
+        assert np.array_equal(bmin, p[:, 1:].min(axis=1)) and np.array_equal(bmax, p[:, 1:].max(axis=1))
+
+
+def test_chain_keys_bit_exact(ctx):
+    for name, x, y, z, bmin, bmax, res in _clouds():
+        ml, _, _ = pcv.level_table(bmin, bmax, res)
+        nl = min(ml, 21)
+        keys = ctx.chain_keys(res, pcv.Aabb(bmin, bmax), x, y, z)
+        want = O.chain_keys64(bmin, bmax, res, nl, x, y, z, threads=4)
+        bad = np.nonzero(keys != want)[0]
+        assert bad.size == 0, f"{name}: {bad.size} keys differ, first {bad[:5]}"
+
+
+def test_chain_keys_special_values(ctx):
+    # points on / outside the (loose) bounding box, exact cube centres, signed zeros
+    bmin, bmax = np.array([-8.0, -8.0, -8.0]), np.array([8.0, 8.0, 8.0])
+    g = np.array([-9.0, -8.0, -4.0, -0.0, 0.0, 1e-300, 4.0, 7.999999999, 8.0, 12.5, 2.0 ** -30, -2.0 ** -30])
+    x, y, z = [a.ravel() for a in np.meshgrid(g, g, g)]
+    for res in (1.0, 0.001, 1e-7):
+        ml, _, _ = pcv.level_table(bmin, bmax, res)
+        keys = ctx.chain_keys(res, pcv.Aabb(bmin, bmax), x, y, z)
+        want = O.chain_keys64(bmin, bmax, res, min(ml, 21), x, y, z)
+        assert np.array_equal(keys, want), res
+
+
+def test_sort_keys64(ctx):
+    rng = np.random.default_rng(1)
+    for n in (0, 1, 5, 4095, 4096, 4097, 70_001, 1_000_003):
+        keys = rng.integers(0, 2 ** 63, n, dtype=np.uint64)
+        if n > 10:
+            keys[::7] = keys[3]  # heavy duplicates
+        got = ctx.sort_keys64(keys.copy(), 0, 63)
+        assert np.array_equal(got, np.sort(keys)), n
+    # partial bit ranges sort on those bits only, stably: equal masked keys keep their input order
+    keys = rng.integers(0, 2 ** 63, 200_000, dtype=np.uint64)
+    got = ctx.sort_keys64(keys.copy(), 12, 33)
+    m = (keys >> np.uint64(12)) & np.uint64((1 << 21) - 1)
+    assert np.array_equal(got, keys[np.argsort(m, kind="stable")])
+
+
+def test_sort_pairs32_is_stable(ctx):
+    rng = np.random.default_rng(2)
+    for n, bits in ((1, 1), (1000, 3), (123_457, 11), (1_000_000, 14), (300_000, 32)):
+        keys = rng.integers(0, 2 ** bits, n, dtype=np.uint64).astype(np.uint32)
+        vals = np.arange(n, dtype=np.uint32)
+        k, v = ctx.sort_pairs32(keys.copy(), vals.copy(), 0, bits)
+        order = np.argsort(keys, kind="stable")
+        assert np.array_equal(k, keys[order]) and np.array_equal(v, vals[order]), (n, bits)
