@@ -1,0 +1,210 @@
+#!/usr/bin/env python
+"""bench.py — octree-build throughput on MI355X (BASELINE.json metric: octree-build Mpoints/sec + HBM GB/s).
+
+A "step" is one full pass of the hot path over one batch: pcv_build_octree on a device-resident cloud
+(chain keys -> key sort -> node split -> leaf encode -> record sort -> promotion/encode), producing the finished
+node table and node-contiguous .xyz/.rgb bytes in HBM. Inputs are resident in HBM when the timed region starts.
+
+Workload at N=1: BASELINE config 2 — 100 M synthetic Gaussian-cluster points (64 clusters in a 1000 m cube,
+sigma in [1, 20] m), f64 SoA xyz + u8 rgb, resolution 1 mm. With --gpus N>1 every rank owns 100 M points of a
+N x 100 M cloud (weak scaling); points are routed to the rank that owns their root octant with ONE all-to-all
+(point_cloud_viewer_amd/distributed.py) and each rank builds its subtrees.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+# algorithmic HBM bytes per point and launch of the HBM-bound kernels (DESIGN.md "Kernels")
+ALGO_BYTES = {
+    "downsweep_kernel<u64>": 16.0,  # read 8 B key + write 8 B key
+    "upsweep_kernel<u64>": 8.0,     # read 8 B key
+    "aabb_partial_kernel": 24.0,    # read xyz f64
+    "chain_keys_kernel": 32.0,      # read xyz f64 + write 8 B key
+    "leaf_encode_kernel": 24.0 + 3.0 + 20.0,  # read xyz + rgb, write rank + 3 codes + rgba
+    "downsweep_kernel<u32>": 2 * 4.0 + 2 * 16.0,  # key r/w + 4 payload words r/w
+    "upsweep_kernel<u32>": 4.0,
+    "promote_encode_kernel": 20.0 + 9.0,  # read record, write ~6 B xyz + 3 B rgb
+}
+
+
+def make_cloud(torch, n, seed, device, clusters=64, extent=1000.0, sigma=(1.0, 20.0), chunk=1 << 24):
+    """Config-2 distribution generated on the device (centres/sigmas from a host generator so every rank
+    shares them)."""
+    import numpy as np
+    rng = np.random.Generator(np.random.PCG64(12345))
+    centres = torch.tensor(rng.uniform(0.0, extent, (clusters, 3)), dtype=torch.float64, device=device)
+    sigmas = torch.tensor(rng.uniform(sigma[0], sigma[1], clusters), dtype=torch.float64, device=device)
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    x = torch.empty(n, dtype=torch.float64, device=device)
+    y = torch.empty_like(x)
+    z = torch.empty_like(x)
+    for s in range(0, n, chunk):
+        m = min(chunk, n - s)
+        which = torch.randint(0, clusters, (m,), generator=g, device=device)
+        p = torch.randn((m, 3), generator=g, dtype=torch.float64, device=device) * sigmas[which, None] + centres[which]
+        x[s:s + m], y[s:s + m], z[s:s + m] = p[:, 0], p[:, 1], p[:, 2]
+        del p, which
+    idx = torch.arange(n, device=device, dtype=torch.int64)
+    h = (idx * 2654435761) & 0xFFFFFF
+    rgb = torch.stack([(h >> 16) & 255, (h >> 8) & 255, h & 255], dim=1).to(torch.uint8).contiguous()
+    del idx, h
+    return x, y, z, rgb
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--points", type=int, default=100_000_000, help="points per GPU")
+    ap.add_argument("--resolution", type=float, default=0.001)
+    ap.add_argument("--cpu-sample", type=int, default=20_000_000, help="points of the workload timed on the CPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with HIP events")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import point_cloud_viewer_amd as pcv
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    n = args.points
+    x, y, z, rgb = make_cloud(torch, n, seed=1 + rank, device=dev)
+    ctx = pcv.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+
+    if world == 1:
+        bmin, bmax = ctx.aabb_reduce(x, y, z)  # exact min/max bbox (config 2), outside the timed region
+        bbox = pcv.Aabb(bmin, bmax)
+        info = {}
+
+        def step():
+            t = ctx.build(args.resolution, bbox, x, y, z, rgb)
+            info["nodes"], info["stages"] = t.num_nodes, t.stage_ms()
+            t.free()
+    else:
+        from point_cloud_viewer_amd import distributed as pdist
+        builder = pdist.ShardedOctreeBuilder(ctx, dist, dev)
+        bbox = builder.global_bbox(x, y, z)
+        info = {}
+
+        def step():
+            r = builder.build(args.resolution, bbox, x, y, z, rgb)
+            info["nodes"], info["stages"] = r.num_nodes_local, r.stage_ms
+            r.free()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    if not args.no_kernel_events:
+        ctx.set_profiling(True)
+        ctx.reset_kernel_stats()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ctx.set_profiling(False)
+    kstats = ctx.kernel_stats()
+
+    total_points = n * world * args.steps
+    value = total_points / elapsed / 1e6  # Mpoints/s, whole job
+
+    # dominant kernel by accumulated time (HIP events on the launch stream, inside the timed region)
+    roofline = None
+    timed = {k: v for k, v in kstats.items() if v[0] > 0}
+    if timed:
+        dom = max(timed, key=lambda k: timed[k][1])
+        launches, ms = timed[dom]
+        avg_ms = ms / launches
+        gbs = ALGO_BYTES.get(dom, 0.0) * n / (avg_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
+                    "launches": launches, "algorithmic_bytes_per_launch": ALGO_BYTES.get(dom, 0.0) * n}
+        # encode+sort figure the BASELINE metric names: chain keys + key sort passes
+        es_ms = sum(timed.get(k, (0, 0.0))[1] for k in ("chain_keys_kernel", "upsweep_kernel<u64>", "scan_kernel",
+                                                       "downsweep_kernel<u64>")) / args.steps
+        sort_passes = timed.get("downsweep_kernel<u64>", (0, 0))[0] / args.steps
+        es_bytes = n * (32.0 + sort_passes * 24.0)
+        encode_sort = {"GB/s": round(es_bytes / (es_ms * 1e-3) / 1e9, 1) if es_ms else None,
+                       "ms": round(es_ms, 3), "sort_passes": sort_passes,
+                       "algorithmic_bytes_per_point": 32.0 + sort_passes * 24.0}
+    else:
+        encode_sort = None
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import shutil
+        import tempfile
+        import oracle_lib as O
+        m = min(args.cpu_sample, n)
+        hx, hy, hz = x[:m].cpu().numpy(), y[:m].cpu().numpy(), z[:m].cpu().numpy()
+        hrgb = rgb[:m].cpu().numpy()
+        cores = O.num_procs()
+        base = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+        d = tempfile.mkdtemp(prefix="pcv_cpu_baseline_", dir=base)
+        try:
+            c0 = time.perf_counter()
+            O.build_literal_dir(os.path.join(d, "octree"), args.resolution, bbox.min, bbox.max, hx, hy, hz, hrgb,
+                                threads=cores)
+            cdt = time.perf_counter() - c0
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+        cpu = {"value": round(m / cdt / 1e6, 3), "unit": "Mpoints/s", "cores": cores, "kind": "port",
+               "sample": f"first {m} points of the same cloud, literal file-streaming restatement of the reference "
+                         f"(oracle/pcv_oracle_build.cpp) on tmpfs, {cores} OpenMP threads, {cdt:.1f} s"}
+
+    if rank == 0:
+        out = {
+            "metric": "octree-build Mpoints/sec", "value": round(value, 2), "unit": "Mpoints/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE config 2: 100 M Gaussian-cluster points (64 clusters, 1000 m cube, "
+                                   "sigma 1-20 m), f64 SoA xyz + u8 rgb, resolution 1 mm, full build + LOD promotion",
+                       "points_per_gpu": n, "resolution": args.resolution, "nodes": info.get("nodes"),
+                       "parallelism": "1 GPU" if world == 1 else f"root-octant sharding over {world} GPUs, one all-to-all"},
+            "roofline": roofline, "encode_sort": encode_sort, "cpu_baseline": cpu,
+            "stage_ms": {k: round(v, 3) for k, v in (info.get("stages") or {}).items()},
+            "kernel_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in kstats.items() if v[0] > 0},
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -59,6 +59,13 @@ int pcv_abi_version(void);
 /* Release cached device/host scratch held by the context. */
 int pcv_ctx_trim(pcv_ctx* ctx);
 
+/* Optional per-launch profile: when enabled every kernel launch of this context is bracketed by HIP events on
+ * the context's stream; pcv_ctx_kernel_stats returns, per kernel id (0 .. return value - 1), the kernel's name,
+ * the number of launches and their summed duration since the last reset. */
+int pcv_ctx_set_profiling(pcv_ctx* ctx, int enabled);
+int pcv_ctx_reset_kernel_stats(pcv_ctx* ctx);
+int pcv_ctx_kernel_stats(pcv_ctx* ctx, int kernel_id, const char** name, uint64_t* launches, double* total_ms);
+
 /* ---- inputs --------------------------------------------------------------------------------- */
 /* One batch of points, SoA. Replaces `PointsBatch` (src/lib.rs:102-107): positions Vec<Point3<f64>>,
  * "color" U8Vec3 and optional "intensity" F32 (src/octree/mod.rs:62-74). */

@@ -52,6 +52,10 @@ _SIGNATURES = {
     "pcv_ctx_destroy": (None, [_vp]),
     "pcv_last_error": (C.c_char_p, [_vp]),
     "pcv_ctx_trim": (C.c_int, [_vp]),
+    "pcv_ctx_set_profiling": (C.c_int, [_vp, C.c_int]),
+    "pcv_ctx_reset_kernel_stats": (C.c_int, [_vp]),
+    "pcv_ctx_kernel_stats": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64),
+                                       C.POINTER(C.c_double)]),
     "pcv_build_octree": (C.c_int, [_vp, C.POINTER(BuildParams), C.POINTER(Points), C.POINTER(_vp)]),
     "pcv_octree_num_nodes": (C.c_uint64, [_vp]),
     "pcv_octree_num_points": (C.c_uint64, [_vp]),

@@ -75,6 +75,58 @@ int pcv_ctx::pinned_reserve(size_t bytes) {
   return PCV_OK;
 }
 
+hipEvent_t pcv_ctx::prof_event() {
+  if (!prof_free.empty()) {
+    hipEvent_t e = prof_free.back();
+    prof_free.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+// Call only after the stream has been synchronised.
+void pcv_ctx::prof_resolve() {
+  for (auto& p : prof_pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+      prof_ms[p.id] += ms;
+      prof_launches[p.id] += 1;
+    }
+    prof_free.push_back(p.a);
+    prof_free.push_back(p.b);
+  }
+  prof_pending.clear();
+}
+
+static const char* kKernelNames[PCV_K_COUNT] = {
+    "aabb_partial_kernel", "chain_keys_kernel",  "upsweep_kernel<u64>",   "scan_kernel",
+    "downsweep_kernel<u64>", "split_search_kernel", "split_assign_kernel", "leaf_encode_kernel",
+    "upsweep_kernel<u32>", "downsweep_kernel<u32>", "promote_encode_kernel"};
+
+extern "C" int pcv_ctx_set_profiling(pcv_ctx* ctx, int enabled) {
+  if (!ctx) return PCV_E_INVALID;
+  ctx->profiling = enabled != 0;
+  return PCV_OK;
+}
+extern "C" int pcv_ctx_reset_kernel_stats(pcv_ctx* ctx) {
+  if (!ctx) return PCV_E_INVALID;
+  for (int i = 0; i < PCV_K_COUNT; ++i) {
+    ctx->prof_launches[i] = 0;
+    ctx->prof_ms[i] = 0;
+  }
+  return PCV_OK;
+}
+extern "C" int pcv_ctx_kernel_stats(pcv_ctx* ctx, int kernel_id, const char** name, uint64_t* launches,
+                                    double* total_ms) {
+  if (!ctx) return PCV_E_INVALID;
+  if (kernel_id < 0 || kernel_id >= PCV_K_COUNT) return PCV_K_COUNT;
+  if (name) *name = kKernelNames[kernel_id];
+  if (launches) *launches = ctx->prof_launches[kernel_id];
+  if (total_ms) *total_ms = ctx->prof_ms[kernel_id];
+  return PCV_K_COUNT;
+}
+
 extern "C" int pcv_abi_version(void) { return PCV_ABI_VERSION; }
 
 extern "C" int pcv_ctx_create(int device, void* stream, pcv_ctx** out) {
@@ -112,6 +164,11 @@ extern "C" void pcv_ctx_destroy(pcv_ctx* ctx) {
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   for (auto& e : ctx->ev)
     if (e) (void)hipEventDestroy(e);
+  for (auto& p : ctx->prof_pending) {
+    (void)hipEventDestroy(p.a);
+    (void)hipEventDestroy(p.b);
+  }
+  for (auto& e : ctx->prof_free) (void)hipEventDestroy(e);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -424,7 +481,7 @@ extern "C" int pcv_build_octree(pcv_ctx* ctx, const pcv_build_params* params, co
   if ((rc = sc.get(&keys_a, n)) || (rc = sc.get(&keys_b, n))) return rc;
   if ((rc = ctx->dev_alloc(&sort_scratch, pcv_sort_scratch_bytes(n)))) return rc;
   sc.ptrs.push_back(sort_scratch);
-  pcv_launch_chain_keys(st, lv, n, d.x, d.y, d.z, keys_a);
+  pcv_launch_chain_keys(ctx, lv, n, d.x, d.y, d.z, keys_a);
   PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[2], st));
   bool in_a = true;
   if ((rc = pcv_radix_sort_u64(ctx, keys_a, keys_b, n, 3 * (PCV_MAX_KEY_LEVELS - lv.nlevels), 3 * PCV_MAX_KEY_LEVELS,
@@ -445,7 +502,7 @@ extern "C" int pcv_build_octree(pcv_ctx* ctx, const pcv_build_params* params, co
       (rc = sc.get(&nt.child_mask, cap)) || (rc = sc.get(&nt.open, cap)) || (rc = sc.get(&nt.bounds, (size_t)cap * 9)) ||
       (rc = sc.get(&nt.counters, 64)))
     return rc;
-  pcv_launch_node_split(st, nt, sorted_keys, (uint32_t)n, lv, params->resolution, max_points);
+  pcv_launch_node_split(ctx, nt, sorted_keys, (uint32_t)n, lv, params->resolution, max_points);
   PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[4], st));
 
   // ---- node table to host, finalize ----
@@ -601,7 +658,7 @@ extern "C" int pcv_build_octree(pcv_ctx* ctx, const pcv_build_params* params, co
   // word layout: 0 cx, 1 cy, 2 cz, 3 rgba, [4 intensity], [hi words]
   const int w_int = t->has_intensity ? 4 : -1;
   const int w_hi = wide ? (t->has_intensity ? 5 : 4) : -1;
-  pcv_launch_leaf_encode(st, lv, wt, n, nullptr, d.x, d.y, d.z, d.color, d.color_stride, d.intensity, rank_a, rec_a[0],
+  pcv_launch_leaf_encode(ctx, lv, wt, n, nullptr, d.x, d.y, d.z, d.color, d.color_stride, d.intensity, rank_a, rec_a[0],
                          rec_a[1], rec_a[2], wide ? rec_a[w_hi] : nullptr, wide ? rec_a[w_hi + 1] : nullptr,
                          wide ? rec_a[w_hi + 2] : nullptr, rec_a[3], w_int >= 0 ? rec_a[w_int] : nullptr);
   PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[6], st));
@@ -631,12 +688,13 @@ extern "C" int pcv_build_octree(pcv_ctx* ctx, const pcv_build_params* params, co
     if ((rc = ctx->dev_alloc(&bi, t->int_bytes))) return rc;
     t->d_int = (uint8_t*)bi;
   }
-  pcv_launch_promote_encode(st, lv, pt, n, s_rank, s_rec[0], s_rec[1], s_rec[2], wide ? s_rec[w_hi] : nullptr,
+  pcv_launch_promote_encode(ctx, lv, pt, n, s_rank, s_rec[0], s_rec[1], s_rec[2], wide ? s_rec[w_hi] : nullptr,
                             wide ? s_rec[w_hi + 1] : nullptr, wide ? s_rec[w_hi + 2] : nullptr, s_rec[3],
                             w_int >= 0 ? s_rec[w_int] : nullptr, t->d_xyz, t->d_rgb, t->d_int);
   PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[8], st));
   PCV_HIP_CHECK(ctx, hipGetLastError());
   PCV_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  ctx->prof_resolve();
   for (int sidx = 0; sidx < 8; ++sidx) (void)hipEventElapsedTime(&t->stage_ms[sidx], ctx->ev[sidx], ctx->ev[sidx + 1]);
   (void)hipEventElapsedTime(&t->stage_ms[PCV_STAGE_TOTAL], ctx->ev[0], ctx->ev[8]);
 
@@ -678,7 +736,7 @@ extern "C" int pcv_chain_keys(pcv_ctx* ctx, const pcv_build_params* params, cons
   if (points->n == 0) return PCV_OK;
   uint64_t* dk = keys;
   if (points->mem == PCV_MEM_HOST && (rc = sc.get(&dk, points->n))) return rc;
-  pcv_launch_chain_keys(ctx->stream, lv, points->n, d.x, d.y, d.z, dk);
+  pcv_launch_chain_keys(ctx, lv, points->n, d.x, d.y, d.z, dk);
   PCV_HIP_CHECK(ctx, hipGetLastError());
   if (points->mem == PCV_MEM_HOST)
     PCV_HIP_CHECK(ctx, hipMemcpyAsync(keys, dk, points->n * 8, hipMemcpyDeviceToHost, ctx->stream));

@@ -124,14 +124,18 @@ int pcv_launch_aabb(pcv_ctx* ctx, uint64_t n, const double* x, const double* y, 
                     double* out6) {
   uint64_t want = (n + (uint64_t)kAabbBlock * 2 * 8 - 1) / ((uint64_t)kAabbBlock * 2 * 8);
   int blocks = (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
-  hipLaunchKernelGGL(aabb_partial_kernel, dim3(blocks), dim3(kAabbBlock), 0, ctx->stream, n, x, y, z, partial);
+  {
+    PcvProf prof(ctx, PCV_K_AABB);
+    hipLaunchKernelGGL(aabb_partial_kernel, dim3(blocks), dim3(kAabbBlock), 0, ctx->stream, n, x, y, z, partial);
+  }
   hipLaunchKernelGGL(aabb_final_kernel, dim3(1), dim3(256), 0, ctx->stream, blocks, partial, out6);
   return blocks;
 }
 
-void pcv_launch_chain_keys(hipStream_t s, const PcvLevels& lv, uint64_t n, const double* x, const double* y,
+void pcv_launch_chain_keys(pcv_ctx* ctx, const PcvLevels& lv, uint64_t n, const double* x, const double* y,
                            const double* z, uint64_t* keys) {
   if (n == 0) return;
   uint64_t blocks = (n + 255) / 256;
-  hipLaunchKernelGGL(chain_keys_kernel, dim3((unsigned)blocks), dim3(256), 0, s, lv, n, x, y, z, keys);
+  PcvProf prof(ctx, PCV_K_CHAIN_KEYS);
+  hipLaunchKernelGGL(chain_keys_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, lv, n, x, y, z, keys);
 }

@@ -140,22 +140,24 @@ __global__ __launch_bounds__(256) void promote_encode_kernel(
 
 }  // namespace
 
-void pcv_launch_leaf_encode(hipStream_t s, const PcvLevels& lv, const PcvWalkTables& wt, uint64_t n,
+void pcv_launch_leaf_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvWalkTables& wt, uint64_t n,
                             const uint64_t* keys, const double* x, const double* y, const double* z,
                             const uint8_t* color, uint32_t color_stride, const float* intensity, uint32_t* rank,
                             uint32_t* cx, uint32_t* cy, uint32_t* cz, uint32_t* cx_hi, uint32_t* cy_hi,
                             uint32_t* cz_hi, uint32_t* rgba, uint32_t* inten_bits) {
   if (n == 0) return;
-  hipLaunchKernelGGL(leaf_encode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, lv, wt.walk, n, keys, x,
+  PcvProf prof(ctx, PCV_K_LEAF_ENCODE);
+  hipLaunchKernelGGL(leaf_encode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, lv, wt.walk, n, keys, x,
                      y, z, color, color_stride, intensity, rank, cx, cy, cz, cx_hi, cy_hi, cz_hi, rgba, inten_bits);
 }
 
-void pcv_launch_promote_encode(hipStream_t s, const PcvLevels& lv, const PcvPromoteTables& pt, uint64_t n,
+void pcv_launch_promote_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvPromoteTables& pt, uint64_t n,
                                const uint32_t* rank, const uint32_t* cx, const uint32_t* cy, const uint32_t* cz,
                                const uint32_t* cx_hi, const uint32_t* cy_hi, const uint32_t* cz_hi,
                                const uint32_t* rgba, const uint32_t* inten_bits, uint8_t* xyz_blob,
                                uint8_t* rgb_blob, uint8_t* inten_blob) {
   if (n == 0) return;
-  hipLaunchKernelGGL(promote_encode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, lv, pt, n, rank, cx,
+  PcvProf prof(ctx, PCV_K_PROMOTE_ENCODE);
+  hipLaunchKernelGGL(promote_encode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, lv, pt, n, rank, cx,
                      cy, cz, cx_hi, cy_hi, cz_hi, rgba, inten_bits, xyz_blob, rgb_blob, inten_blob);
 }

@@ -33,6 +33,22 @@ struct PcvPool {
   void trim();
 };
 
+// Kernel ids for the optional per-launch HIP-event profile (pcv_ctx_set_profiling).
+enum PcvKernelId {
+  PCV_K_AABB = 0,
+  PCV_K_CHAIN_KEYS,
+  PCV_K_SORT_UPSWEEP64,
+  PCV_K_SORT_SCAN,
+  PCV_K_SORT_DOWNSWEEP64,
+  PCV_K_SPLIT_SEARCH,
+  PCV_K_SPLIT_ASSIGN,
+  PCV_K_LEAF_ENCODE,
+  PCV_K_SORT_UPSWEEP32,
+  PCV_K_SORT_DOWNSWEEP32,
+  PCV_K_PROMOTE_ENCODE,
+  PCV_K_COUNT
+};
+
 struct pcv_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -44,6 +60,19 @@ struct pcv_ctx {
   size_t pinned_bytes = 0;
   hipEvent_t ev[PCV_NUM_STAGES + 2] = {};
 
+  // per-launch profile: event pairs recorded on `stream`, resolved after the next stream sync
+  bool profiling = false;
+  struct ProfPending {
+    int id;
+    hipEvent_t a, b;
+  };
+  std::vector<ProfPending> prof_pending;
+  std::vector<hipEvent_t> prof_free;
+  uint64_t prof_launches[PCV_K_COUNT] = {};
+  double prof_ms[PCV_K_COUNT] = {};
+  hipEvent_t prof_event();
+  void prof_resolve();
+
   int fail(int code, const std::string& msg) {
     last_error = msg;
     return code;
@@ -51,6 +80,26 @@ struct pcv_ctx {
   int dev_alloc(void** p, size_t bytes);
   void dev_free(void* p);
   int pinned_reserve(size_t bytes);
+};
+
+// Brackets one kernel launch with HIP events on the ctx stream when profiling is on.
+struct PcvProf {
+  pcv_ctx* ctx;
+  int id;
+  hipEvent_t a = nullptr;
+  PcvProf(pcv_ctx* c, int kernel_id) : ctx(c), id(kernel_id) {
+    if (ctx->profiling) {
+      a = ctx->prof_event();
+      (void)hipEventRecord(a, ctx->stream);
+    }
+  }
+  ~PcvProf() {
+    if (a) {
+      hipEvent_t b = ctx->prof_event();
+      (void)hipEventRecord(b, ctx->stream);
+      ctx->prof_pending.push_back({id, a, b});
+    }
+  }
 };
 
 // RAII bundle of pool allocations released on scope exit (unless detached).
@@ -84,7 +133,7 @@ struct PcvScratch {
 // pcv_chain.hip
 int pcv_launch_aabb(pcv_ctx* ctx, uint64_t n, const double* x, const double* y, const double* z, double* partial,
                     double* out6 /* device: min xyz, max xyz */);
-void pcv_launch_chain_keys(hipStream_t s, const PcvLevels& lv, uint64_t n, const double* x, const double* y,
+void pcv_launch_chain_keys(pcv_ctx* ctx, const PcvLevels& lv, uint64_t n, const double* x, const double* y,
                            const double* z, uint64_t* keys);
 
 // pcv_sort.hip — stable LSD radix sort, 8-bit digits, reduce-then-scan with LDS histograms.
@@ -116,7 +165,7 @@ struct PcvNodeTableDev {
   uint32_t* bounds;      // scratch: 9 bounds per node of the level being expanded
   uint32_t* counters;    // [0] node_count, [1] error flag, [2..] level_start[k] (k = 0..PCV_MAX_KEY_LEVELS+1)
 };
-void pcv_launch_node_split(hipStream_t s, const PcvNodeTableDev& t, const uint64_t* sorted_keys, uint32_t n,
+void pcv_launch_node_split(pcv_ctx* ctx, const PcvNodeTableDev& t, const uint64_t* sorted_keys, uint32_t n,
                            const PcvLevels& lv, double resolution, uint32_t max_points_per_node);
 
 // pcv_encode.hip — leaf lookup + leaf-level encode (input order), promotion + final encode (sorted order).
@@ -124,7 +173,7 @@ struct PcvWalkTables {
   const uint64_t* walk;  // per node: first_child(32) | child_mask(8) << 32 | leaf(1) << 40 | level(8) << 48;
                          // for leaves the low 32 bits hold the leaf rank
 };
-void pcv_launch_leaf_encode(hipStream_t s, const PcvLevels& lv, const PcvWalkTables& wt, uint64_t n,
+void pcv_launch_leaf_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvWalkTables& wt, uint64_t n,
                             const uint64_t* keys, const double* x, const double* y, const double* z,
                             const uint8_t* color, uint32_t color_stride, const float* intensity, uint32_t* rank,
                             uint32_t* cx, uint32_t* cy, uint32_t* cz, uint32_t* cx_hi, uint32_t* cy_hi,
@@ -140,7 +189,7 @@ struct PcvPromoteTables {
   const uint64_t* xyz_off;     // per node: byte offset in the xyz blob
   const uint64_t* point_off;   // per node: point offset in the rgb/intensity blobs
 };
-void pcv_launch_promote_encode(hipStream_t s, const PcvLevels& lv, const PcvPromoteTables& pt, uint64_t n,
+void pcv_launch_promote_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvPromoteTables& pt, uint64_t n,
                                const uint32_t* rank, const uint32_t* cx, const uint32_t* cy, const uint32_t* cz,
                                const uint32_t* cx_hi, const uint32_t* cy_hi, const uint32_t* cz_hi,
                                const uint32_t* rgba, const uint32_t* inten_bits, uint8_t* xyz_blob,

@@ -256,11 +256,20 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
         pl.out[w] = in_a ? payload->out[w] : payload->in[w];
       }
     }
-    hipLaunchKernelGGL(upsweep_kernel<KeyT>, dim3(g.groups), dim3(kBlock), 0, ctx->stream, src, n, g.chunk, g.groups,
-                       shift, mask, hist);
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, hist, kRadix * g.groups);
-    hipLaunchKernelGGL(downsweep_kernel<KeyT>, dim3(g.groups), dim3(kBlock), 0, ctx->stream, src, dst, n, g.chunk,
-                       g.groups, shift, nbits, hist, pl);
+    {
+      PcvProf prof(ctx, sizeof(KeyT) == 8 ? PCV_K_SORT_UPSWEEP64 : PCV_K_SORT_UPSWEEP32);
+      hipLaunchKernelGGL(upsweep_kernel<KeyT>, dim3(g.groups), dim3(kBlock), 0, ctx->stream, src, n, g.chunk,
+                         g.groups, shift, mask, hist);
+    }
+    {
+      PcvProf prof(ctx, PCV_K_SORT_SCAN);
+      hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, hist, kRadix * g.groups);
+    }
+    {
+      PcvProf prof(ctx, sizeof(KeyT) == 8 ? PCV_K_SORT_DOWNSWEEP64 : PCV_K_SORT_DOWNSWEEP32);
+      hipLaunchKernelGGL(downsweep_kernel<KeyT>, dim3(g.groups), dim3(kBlock), 0, ctx->stream, src, dst, n, g.chunk,
+                         g.groups, shift, nbits, hist, pl);
+    }
     in_a = !in_a;
   }
   PCV_HIP_CHECK(ctx, hipGetLastError());

@@ -172,11 +172,18 @@ __global__ __launch_bounds__(1024) void split_assign_kernel(PcvNodeTableDev t, P
 
 }  // namespace
 
-void pcv_launch_node_split(hipStream_t s, const PcvNodeTableDev& t, const uint64_t* sorted_keys, uint32_t n,
+void pcv_launch_node_split(pcv_ctx* ctx, const PcvNodeTableDev& t, const uint64_t* sorted_keys, uint32_t n,
                            const PcvLevels& lv, double resolution, uint32_t max_points_per_node) {
+  hipStream_t s = ctx->stream;
   hipLaunchKernelGGL(init_root_kernel, dim3(1), dim3(256), 0, s, t, n);
   for (int k = 1; k <= lv.nlevels; ++k) {
-    hipLaunchKernelGGL(split_search_kernel, dim3(512), dim3(256), 0, s, t, sorted_keys, k);
-    hipLaunchKernelGGL(split_assign_kernel, dim3(1), dim3(1024), 0, s, t, lv, resolution, max_points_per_node, k);
+    {
+      PcvProf prof(ctx, PCV_K_SPLIT_SEARCH);
+      hipLaunchKernelGGL(split_search_kernel, dim3(512), dim3(256), 0, s, t, sorted_keys, k);
+    }
+    {
+      PcvProf prof(ctx, PCV_K_SPLIT_ASSIGN);
+      hipLaunchKernelGGL(split_assign_kernel, dim3(1), dim3(1024), 0, s, t, lv, resolution, max_points_per_node, k);
+    }
   }
 }

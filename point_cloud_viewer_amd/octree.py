@@ -82,6 +82,23 @@ class Context:
         except Exception:
             pass
 
+    def set_profiling(self, enabled=True):
+        """Bracket every kernel launch with HIP events on the ctx stream (see kernel_stats)."""
+        self._check(self.lib.pcv_ctx_set_profiling(self.handle, 1 if enabled else 0))
+
+    def reset_kernel_stats(self):
+        self._check(self.lib.pcv_ctx_reset_kernel_stats(self.handle))
+
+    def kernel_stats(self):
+        """{kernel name: (launches, total_ms)} accumulated since the last reset."""
+        out = {}
+        count = self.lib.pcv_ctx_kernel_stats(self.handle, -1, None, None, None)
+        for k in range(count):
+            name, launches, ms = C.c_char_p(), C.c_uint64(), C.c_double()
+            self.lib.pcv_ctx_kernel_stats(self.handle, k, C.byref(name), C.byref(launches), C.byref(ms))
+            out[name.value.decode()] = (launches.value, ms.value)
+        return out
+
     def _check(self, rc):
         if rc != L.PCV_OK:
             raise L.PcvError(rc, self.lib.pcv_last_error(self.handle).decode())
