@@ -70,16 +70,22 @@ __global__ __launch_bounds__(kBlock) void upsweep_kernel(const KeyT* __restrict_
   }
 }
 
-// Exclusive scan of `total` counters in place (digit-major order) by a single 1024-thread workgroup.
-__global__ __launch_bounds__(1024) void scan_kernel(uint32_t* __restrict__ hist, int total) {
-  __shared__ uint32_t wave_tot[16];
-  const int per = (total + 1023) / 1024;
+// One workgroup per digit: exclusive scan of that digit's `groups` counters in place (groups <= 1024) and the
+// digit's total. The scan across digits is folded into the downsweep prologue (256 values).
+__global__ __launch_bounds__(256) void scan_kernel(uint32_t* __restrict__ hist, int groups,
+                                                    uint32_t* __restrict__ totals) {
+  __shared__ uint32_t wave_tot[4];
+  uint32_t* row = hist + (uint64_t)blockIdx.x * groups;
+  const int per = (groups + 255) / 256;  // <= 4
   const int begin = threadIdx.x * per;
-  int end = begin + per;
-  if (end > total) end = total;
+  uint32_t v[4] = {0, 0, 0, 0};
   uint32_t sum = 0;
-  for (int i = begin; i < end; ++i) sum += hist[i];
-  // inclusive wave scan
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (i < per && begin + i < groups) {
+      v[i] = row[begin + i];
+      sum += v[i];
+    }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t inc = sum;
 #pragma unroll
@@ -89,21 +95,20 @@ __global__ __launch_bounds__(1024) void scan_kernel(uint32_t* __restrict__ hist,
   }
   if (lane == 63) wave_tot[wave] = inc;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t acc = 0;
-    for (int w = 0; w < 16; ++w) {
-      uint32_t t = wave_tot[w];
-      wave_tot[w] = acc;
-      acc += t;
+  uint32_t woff = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    woff += (w < wave) ? wave_tot[w] : 0u;
+    total += wave_tot[w];
+  }
+  uint32_t run = woff + inc - sum;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (i < per && begin + i < groups) {
+      row[begin + i] = run;
+      run += v[i];
     }
-  }
-  __syncthreads();
-  uint32_t run = wave_tot[wave] + inc - sum;
-  for (int i = begin; i < end; ++i) {
-    uint32_t t = hist[i];
-    hist[i] = run;
-    run += t;
-  }
+  if (threadIdx.x == 0) totals[blockIdx.x] = total;
 }
 
 struct PayloadPtrs {
@@ -117,6 +122,7 @@ __global__ __launch_bounds__(kBlock) void downsweep_kernel(const KeyT* __restric
                                                             KeyT* __restrict__ keys_out, uint64_t n, uint64_t chunk,
                                                             int groups, int shift, int nbits,
                                                             const uint32_t* __restrict__ offsets /* [256][groups] */,
+                                                            const uint32_t* __restrict__ totals /* [256] */,
                                                             PayloadPtrs pl) {
   __shared__ KeyT skeys[kTile];
   __shared__ uint32_t whist[kWaves][kRadix];
@@ -129,7 +135,23 @@ __global__ __launch_bounds__(kBlock) void downsweep_kernel(const KeyT* __restric
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const uint32_t mask = (1u << nbits) - 1u;
   const uint64_t lane_lt = (1ull << lane) - 1ull;
-  digit_base[t] = offsets[(uint64_t)t * groups + blockIdx.x];  // kBlock == kRadix
+  {
+    // global base of digit t for this workgroup = (keys with a smaller digit) + (same digit, earlier workgroups)
+    const uint32_t tot = totals[t];  // kBlock == kRadix
+    uint32_t inc = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      uint32_t v = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += v;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) woff += (w < wave) ? wave_tot[w] : 0u;
+    digit_base[t] = woff + inc - tot + offsets[(uint64_t)t * groups + blockIdx.x];
+    __syncthreads();
+  }
 
   const uint64_t begin = (uint64_t)blockIdx.x * chunk;
   uint64_t end = begin + chunk;
@@ -242,6 +264,7 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
   if (n >= 0xffffffffull) return ctx->fail(PCV_E_INVALID, "radix sort: n must be < 2^32 - 1");
   SortGeom g = make_geom(n);
   uint32_t* hist = (uint32_t*)scratch;
+  uint32_t* totals = hist + (size_t)kRadix * kMaxGroups;
   bool in_a = true;
   for (int shift = begin_bit; shift < end_bit; shift += 8) {
     int nbits = end_bit - shift < 8 ? end_bit - shift : 8;
@@ -263,12 +286,12 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
     }
     {
       PcvProf prof(ctx, PCV_K_SORT_SCAN);
-      hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, hist, kRadix * g.groups);
+      hipLaunchKernelGGL(scan_kernel, dim3(kRadix), dim3(256), 0, ctx->stream, hist, g.groups, totals);
     }
     {
       PcvProf prof(ctx, sizeof(KeyT) == 8 ? PCV_K_SORT_DOWNSWEEP64 : PCV_K_SORT_DOWNSWEEP32);
       hipLaunchKernelGGL(downsweep_kernel<KeyT>, dim3(g.groups), dim3(kBlock), 0, ctx->stream, src, dst, n, g.chunk,
-                         g.groups, shift, nbits, hist, pl);
+                         g.groups, shift, nbits, hist, totals, pl);
     }
     in_a = !in_a;
   }
@@ -279,7 +302,7 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
 
 }  // namespace
 
-size_t pcv_sort_scratch_bytes(uint64_t n) { return (size_t)kRadix * kMaxGroups * sizeof(uint32_t); }
+size_t pcv_sort_scratch_bytes(uint64_t n) { return ((size_t)kRadix * kMaxGroups + kRadix) * sizeof(uint32_t); }
 
 int pcv_radix_sort_u64(pcv_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint64_t n, int begin_bit, int end_bit,
                        PcvSortPayload* payload, void* scratch, bool* result_in_a) {
