@@ -77,6 +77,28 @@ def _load():
     lib.pcvo_meta_encode.argtypes = [C.c_int, _dp, _dp, C.c_double, C.c_uint64, _u64p, _u64p, _i64p, _ip, _u8p,
                                      C.c_uint64]
     lib.pcvo_num_procs.restype = C.c_int
+    # query path
+    lib.pcvo_mat4_try_inverse.restype = C.c_int
+    lib.pcvo_mat4_try_inverse.argtypes = [_dp, _dp]
+    lib.pcvo_perspective_new.argtypes = [C.c_double] * 6 + [_dp]
+    lib.pcvo_perspective_inverse.argtypes = [_dp, _dp]
+    lib.pcvo_perspective3_new.argtypes = [C.c_double] * 4 + [_dp]
+    lib.pcvo_frustum_new.argtypes = [_dp, _dp, _dp, _dp]
+    lib.pcvo_iso_transform_points.argtypes = [_dp, C.c_uint64, _dp, _dp, _dp, _dp, _dp, _dp]
+    lib.pcvo_cached_axes.restype = C.c_int
+    lib.pcvo_cached_axes.argtypes = [C.c_int, _dp, _dp, _dp]
+    lib.pcvo_cull_cubes.restype = C.c_int
+    lib.pcvo_cull_cubes.argtypes = [C.c_int, _dp, C.c_uint64, _dp, _u8p, _dp]
+    lib.pcvo_intersect_shapes.restype = C.c_int
+    lib.pcvo_intersect_shapes.argtypes = [C.c_int, _dp, C.c_int, _dp]
+    lib.pcvo_sat_raw.restype = C.c_int
+    lib.pcvo_sat_raw.argtypes = [C.c_int, _dp, _dp, C.c_int, _dp, C.c_int]
+    lib.pcvo_get_visible_nodes.restype = C.c_int64
+    lib.pcvo_get_visible_nodes.argtypes = [_dp, _dp, C.c_uint64, _u64p, _u64p, _i64p, _dp, _u64p, _u64p]
+    lib.pcvo_nodes_in_location.restype = C.c_int64
+    lib.pcvo_nodes_in_location.argtypes = [_dp, _dp, C.c_uint64, _u64p, _u64p, _i64p, C.c_int, _dp, _u64p, _u64p]
+    lib.pcvo_cull_points.argtypes = [C.c_int, _dp, C.c_uint64, _dp, _dp, _dp, _fp, _dp, _u8p]
+    lib.pcvo_decode_positions.argtypes = [C.c_int, _dp, C.c_double, C.c_uint64, _u8p, _dp, _dp, _dp]
     lib.pcvo_set_max_points_per_node.argtypes = [C.c_int64]
     lib.pcvo_get_max_points_per_node.restype = C.c_int64
     return lib
@@ -275,3 +297,135 @@ def compare_octrees(a, b, check_bytes=True):
             diffs.append("... (truncated)")
             break
     return diffs
+
+
+# ---- query path ---------------------------------------------------------------------------------------
+SHAPE_ALL, SHAPE_AABB, SHAPE_FRUSTUM, SHAPE_OBB, SHAPE_FRUSTUM2 = 0, 1, 2, 3, 4
+REL_IN, REL_CROSS, REL_OUT = 0, 1, 2
+
+
+def _f64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64).ravel())
+
+
+def quat_from_axis_angle(axis, angle):
+    """nalgebra UnitQuaternion::from_axis_angle (axis must be unit): (axis * sin(a/2), cos(a/2)) as i,j,k,w."""
+    import math
+    s, c = math.sin(angle / 2.0), math.cos(angle / 2.0)
+    return [axis[0] * s, axis[1] * s, axis[2] * s, c]
+
+
+def perspective_new(left, right, bottom, top, near, far):
+    m = np.zeros(16)
+    lib().pcvo_perspective_new(left, right, bottom, top, near, far, _d(m))
+    return m
+
+
+def perspective3_new(aspect, fovy, near, far):
+    m = np.zeros(16)
+    lib().pcvo_perspective3_new(aspect, fovy, near, far, _d(m))
+    return m
+
+
+def perspective_inverse(p):
+    m = np.zeros(16)
+    lib().pcvo_perspective_inverse(_d(_f64(p)), _d(m))
+    return m
+
+
+def mat4_try_inverse(m):
+    out = np.zeros(16)
+    ok = lib().pcvo_mat4_try_inverse(_d(_f64(m)), _d(out))
+    return out if ok else None
+
+
+def frustum_new(translation, quat, perspective):
+    """Frustum::new(query_from_eye, clip_from_eye) -> (clip_from_query, query_from_clip), column-major 16 each."""
+    iso = _f64(list(translation) + list(quat))
+    c, q = np.zeros(16), np.zeros(16)
+    lib().pcvo_frustum_new(_d(iso), _d(_f64(perspective)), _d(c), _d(q))
+    return c, q
+
+
+def cached_axes(kind, params):
+    corners, axes = np.zeros(24), np.zeros(78)
+    n = lib().pcvo_cached_axes(kind, _d(_f64(params)), _d(corners), _d(axes))
+    if n < 0:
+        return None
+    return corners.reshape(8, 3), axes[:3 * n].reshape(n, 3)
+
+
+def cull_cubes(kind, params, cubes4, with_sizes=False):
+    cubes4 = _f64(cubes4)
+    m = cubes4.size // 4
+    rel = np.zeros(m, dtype=np.uint8)
+    sizes = np.zeros(m) if with_sizes else None
+    rc = lib().pcvo_cull_cubes(kind, _d(_f64(params)), m, _d(cubes4), rel.ctypes.data_as(_u8p),
+                               _d(sizes) if with_sizes else None)
+    assert rc == 0
+    return (rel, sizes) if with_sizes else rel
+
+
+def intersect_shapes(kind_a, pa, kind_b, pb):
+    return lib().pcvo_intersect_shapes(kind_a, _d(_f64(pa)), kind_b, _d(_f64(pb)))
+
+
+def _tree_arrays(nodes):
+    """nodes: dict name -> dict(id=(hi,lo), num_points=..)"""
+    names = list(nodes)
+    hi = np.array([nodes[k]["id"][0] for k in names], dtype=np.uint64)
+    lo = np.array([nodes[k]["id"][1] for k in names], dtype=np.uint64)
+    npnts = np.array([nodes[k]["num_points"] for k in names], dtype=np.int64)
+    return hi, lo, npnts
+
+
+def get_visible_nodes(bmin, bmax, nodes, matrix):
+    hi, lo, npnts = _tree_arrays(nodes)
+    ohi, olo = np.zeros(hi.size, dtype=np.uint64), np.zeros(hi.size, dtype=np.uint64)
+    n = lib().pcvo_get_visible_nodes(_d(_vec3(bmin)), _d(_vec3(bmax)), hi.size, hi.ctypes.data_as(_u64p),
+                                     lo.ctypes.data_as(_u64p), npnts.ctypes.data_as(_i64p), _d(_f64(matrix)),
+                                     ohi.ctypes.data_as(_u64p), olo.ctypes.data_as(_u64p))
+    if n < 0:
+        return None
+    return [node_id_str(int(ohi[i]), int(olo[i])) for i in range(n)]
+
+
+def nodes_in_location(bmin, bmax, nodes, kind, params):
+    hi, lo, npnts = _tree_arrays(nodes)
+    ohi, olo = np.zeros(hi.size, dtype=np.uint64), np.zeros(hi.size, dtype=np.uint64)
+    pr = _f64(params if params is not None else [0.0])
+    n = lib().pcvo_nodes_in_location(_d(_vec3(bmin)), _d(_vec3(bmax)), hi.size, hi.ctypes.data_as(_u64p),
+                                     lo.ctypes.data_as(_u64p), npnts.ctypes.data_as(_i64p), kind, _d(pr),
+                                     ohi.ctypes.data_as(_u64p), olo.ctypes.data_as(_u64p))
+    if n < 0:
+        return None
+    return [node_id_str(int(ohi[i]), int(olo[i])) for i in range(n)]
+
+
+def cull_points(kind, params, x, y, z, attr=None, interval=None):
+    x, y, z = _f64(x), _f64(y), _f64(z)
+    keep = np.zeros(x.size, dtype=np.uint8)
+    ap = None
+    if attr is not None:
+        attr = np.ascontiguousarray(attr, dtype=np.float32)
+        ap = attr.ctypes.data_as(_fp)
+    iv = _f64(interval) if interval is not None else None
+    lib().pcvo_cull_points(kind, _d(_f64(params if params is not None else [0.0])), x.size, _d(x), _d(y), _d(z), ap,
+                           _d(iv) if iv is not None else None, keep.ctypes.data_as(_u8p))
+    return keep
+
+
+def iso_transform_points(iso7, x, y, z):
+    x, y, z = _f64(x), _f64(y), _f64(z)
+    ox, oy, oz = np.zeros_like(x), np.zeros_like(x), np.zeros_like(x)
+    lib().pcvo_iso_transform_points(_d(_f64(iso7)), x.size, _d(x), _d(y), _d(z), _d(ox), _d(oy), _d(oz))
+    return ox, oy, oz
+
+
+def decode_positions(enc, cube_min, edge, xyz_bytes):
+    bpc = {1: 1, 2: 2, 3: 4, 4: 8}[enc]
+    buf = np.frombuffer(xyz_bytes, dtype=np.uint8).copy()
+    n = buf.size // (3 * bpc)
+    x, y, z = np.zeros(n), np.zeros(n), np.zeros(n)
+    lib().pcvo_decode_positions(enc, _d(_vec3(cube_min)), float(edge), n, buf.ctypes.data_as(_u8p), _d(x), _d(y), _d(z))
+    return x, y, z
