@@ -163,6 +163,78 @@ int pcv_sort_keys64(pcv_ctx* ctx, uint64_t* keys, uint64_t n, int begin_bit, int
 int pcv_sort_pairs32(pcv_ctx* ctx, uint32_t* keys, uint32_t* values, uint64_t n, int begin_bit, int end_bit,
                      int mem);
 
+/* ---- octree loading (viewer side) ------------------------------------------------------------ */
+/* Replaces Octree::from_data_provider over an OnDiskDataProvider (src/octree/mod.rs:156-215,
+ * src/data_provider/on_disk.rs): parses meta.pb (versions 9..13 are accepted by the reference; this loader
+ * accepts 12/13 layouts written by the current tools) and derives every node's bounding cube
+ * (NodeId::find_bounding_cube). Node files are read on demand by pcv_octree_node_data. */
+int pcv_octree_open_dir(pcv_ctx* ctx, const char* directory, pcv_octree** out);
+
+/* ---- queries: batched transform-and-cull ------------------------------------------------------ */
+/* PointLocation variants (src/iterator.rs:12-20) that the octree path supports. params layout:
+ *   PCV_SHAPE_ALL                   -                                          AllPoints
+ *   PCV_SHAPE_AABB                  min xyz, max xyz                           geometry::Aabb
+ *   PCV_SHAPE_FRUSTUM               clip_from_query (16, nalgebra memory order = column-major); the inverse is
+ *                                   computed like Frustum::from_matrix4 (src/geometry/frustum.rs:111-117)
+ *   PCV_SHAPE_FRUSTUM_WITH_INVERSE  clip_from_query (16) then query_from_clip (16), as Frustum::new stores them
+ *                                   (frustum.rs:101-108)
+ *   PCV_SHAPE_OBB                   query_from_obb isometry: translation xyz, unit quaternion i j k w; then the
+ *                                   half extent xyz (src/geometry/obb.rs:13-45) */
+#define PCV_SHAPE_ALL 0
+#define PCV_SHAPE_AABB 1
+#define PCV_SHAPE_FRUSTUM 2
+#define PCV_SHAPE_OBB 3
+#define PCV_SHAPE_FRUSTUM_WITH_INVERSE 4
+typedef struct pcv_shape {
+  int32_t kind;
+  int32_t reserved;
+  double params[32];
+} pcv_shape;
+typedef struct pcv_shapes pcv_shapes;
+
+/* Relation (src/math/sat.rs:37-45) */
+#define PCV_REL_IN 0
+#define PCV_REL_CROSS 1
+#define PCV_REL_OUT 2
+
+/* Q1: prepares `count` shapes on the device: corners, unique edges / face normals and the deduplicated
+ * separating axes against AABBs (Intersector::cache_separating_axes_for_aabb, src/math/sat.rs:111-143). */
+int pcv_shapes_create(pcv_ctx* ctx, const pcv_shape* shapes, uint32_t count, pcv_shapes** out);
+void pcv_shapes_free(pcv_shapes* shapes);
+uint32_t pcv_shapes_count(const pcv_shapes* shapes);
+/* Inspect one prepared shape (tests): 8 corners, up to 26 axes. valid == 0: the matrix is not invertible. */
+int pcv_shapes_get(pcv_shapes* shapes, uint32_t i, double corners[24], double axes[78], uint32_t* num_axes, int* valid);
+
+/* Q2: Relation of every node cube against every shape (CachedAxesIntersector::intersect, sat.rs:167-194), row
+ * major [shape][node] (node order as pcv_octree_node), host buffers. size_on_screen (nullable, same shape) is
+ * relative_size_on_screen (src/octree/mod.rs:119-139) for the shape's clip_from_query; NaN where w == 0. */
+int pcv_cull_nodes(pcv_ctx* ctx, const pcv_shapes* shapes, pcv_octree* tree, uint8_t* relation, double* size_on_screen);
+
+/* Q3: Octree::get_visible_nodes (src/octree/mod.rs:228-283) for every frustum: node indices in the order the
+ * reference's BinaryHeap pops them. counts[f] = number of visible nodes (may exceed `capacity`; only the first
+ * `capacity` are written to node_indices[f * capacity ..]). status[f]: 0 ok, 1 matrix not invertible
+ * (the reference panics), 2 a projected corner had w == 0 (the reference panics). */
+int pcv_visible_nodes(pcv_ctx* ctx, const pcv_shapes* frusta, pcv_octree* tree, uint32_t capacity, uint32_t* counts,
+                      uint32_t* node_indices, int32_t* status);
+/* PointCloud::nodes_in_location (src/octree/mod.rs:309-331, src/octree/octree_iterator.rs): breadth-first, a node
+ * is reported and descended into iff its cube is not Relation::Out. */
+int pcv_nodes_in_location(pcv_ctx* ctx, const pcv_shapes* shapes, pcv_octree* tree, uint32_t capacity, uint32_t* counts,
+                          uint32_t* node_indices);
+
+/* Q4: FilteredIterator's keep mask (src/iterator.rs:96-119): shape.contains(p) AND, when `interval` is given,
+ * interval[0] <= intensity <= interval[1] (ClosedInterval, src/math/mod.rs:86-88). keep lives where the points live;
+ * kept (nullable) receives the number of ones. */
+int pcv_cull_points(pcv_ctx* ctx, const pcv_shapes* shapes, uint32_t shape_index, const pcv_points* points,
+                    const double* interval, uint8_t* keep, uint64_t* kept);
+/* Same on a built octree's node: positions are decoded on the fly from the node's device-resident bytes
+ * (src/read_write/codec.rs:124-139); keep is a host buffer of num_points bytes. */
+int pcv_cull_node_points(pcv_ctx* ctx, const pcv_shapes* shapes, uint32_t shape_index, pcv_octree* tree, uint64_t node,
+                         const double* interval, uint8_t* keep, uint64_t* kept);
+
+/* Q5: Isometry3 * Point3 for a batch (xray/src/generation.rs:493-497; Aabb::transform aabb.rs:58-66 uses the
+ * same product). iso = translation xyz, unit quaternion i j k w. Outputs live where the inputs live. */
+int pcv_transform_points(pcv_ctx* ctx, const double iso[7], const pcv_points* points, double* ox, double* oy, double* oz);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,7 +5,7 @@ libpcv_hip.so (point_cloud_viewer_amd/csrc). Importing does not require a GPU; c
 """
 from . import _lib
 from ._lib import PcvError, load_library  # noqa: F401
-from .octree import Aabb, Context, OctreeResult, build_octree, level_table, node_name  # noqa: F401
+from .octree import Aabb, Context, OctreeResult, Shapes, build_octree, level_table, node_name  # noqa: F401
 
 __all__ = ["Aabb", "Context", "OctreeResult", "build_octree", "level_table", "node_name", "PcvError",
            "load_library"]

@@ -38,6 +38,14 @@ class BuildParams(C.Structure):
                 ("max_points_per_node", C.c_uint32), ("flags", C.c_uint32)]
 
 
+class Shape(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("reserved", C.c_int32), ("params", C.c_double * 32)]
+
+
+SHAPE_ALL, SHAPE_AABB, SHAPE_FRUSTUM, SHAPE_OBB, SHAPE_FRUSTUM_WITH_INVERSE = 0, 1, 2, 3, 4
+REL_IN, REL_CROSS, REL_OUT = 0, 1, 2
+
+
 class NodeInfo(C.Structure):
     _fields_ = [("id_high", C.c_uint64), ("id_low", C.c_uint64), ("num_points", C.c_int64), ("level", C.c_uint32),
                 ("encoding", C.c_uint32), ("cube_min", C.c_double * 3), ("cube_edge", C.c_double),
@@ -74,6 +82,20 @@ _SIGNATURES = {
     "pcv_chain_keys": (C.c_int, [_vp, C.POINTER(BuildParams), C.POINTER(Points), C.c_int, _vp]),
     "pcv_sort_keys64": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, C.c_int, C.c_int]),
     "pcv_sort_pairs32": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.c_int, C.c_int, C.c_int]),
+    "pcv_octree_open_dir": (C.c_int, [_vp, C.c_char_p, C.POINTER(_vp)]),
+    "pcv_shapes_create": (C.c_int, [_vp, C.POINTER(Shape), C.c_uint32, C.POINTER(_vp)]),
+    "pcv_shapes_free": (None, [_vp]),
+    "pcv_shapes_count": (C.c_uint32, [_vp]),
+    "pcv_shapes_get": (C.c_int, [_vp, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                 C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
+    "pcv_cull_nodes": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "pcv_visible_nodes": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _vp, _vp, _vp]),
+    "pcv_nodes_in_location": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _vp, _vp]),
+    "pcv_cull_points": (C.c_int, [_vp, _vp, C.c_uint32, C.POINTER(Points), C.POINTER(C.c_double), _vp,
+                                  C.POINTER(C.c_uint64)]),
+    "pcv_cull_node_points": (C.c_int, [_vp, _vp, C.c_uint32, _vp, C.c_uint64, C.POINTER(C.c_double), _vp,
+                                       C.POINTER(C.c_uint64)]),
+    "pcv_transform_points": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(Points), _vp, _vp, _vp]),
 }
 
 _lib = None

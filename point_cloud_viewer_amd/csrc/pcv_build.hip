@@ -102,7 +102,8 @@ void pcv_ctx::prof_resolve() {
 static const char* kKernelNames[PCV_K_COUNT] = {
     "aabb_partial_kernel", "chain_keys_kernel",  "upsweep_kernel<u64>",   "scan_kernel",
     "downsweep_kernel<u64>", "split_search_kernel", "split_assign_kernel", "leaf_encode_kernel",
-    "upsweep_kernel<u32>", "downsweep_kernel<u32>", "promote_encode_kernel"};
+    "upsweep_kernel<u32>", "downsweep_kernel<u32>", "promote_encode_kernel", "cull_nodes_kernel",
+    "visible_nodes_kernel", "nodes_in_location_kernel", "cull_points_kernel", "transform_points_kernel"};
 
 extern "C" int pcv_ctx_set_profiling(pcv_ctx* ctx, int enabled) {
   if (!ctx) return PCV_E_INVALID;
@@ -338,6 +339,7 @@ static int device_aabb(pcv_ctx* ctx, PcvScratch& sc, const DevPoints& d, double 
 extern "C" void pcv_octree_free(pcv_octree* t) {
   if (!t) return;
   if (t->ctx) {
+    pcv_octree_release_query(t);
     t->ctx->dev_free(t->d_xyz);
     t->ctx->dev_free(t->d_rgb);
     t->ctx->dev_free(t->d_int);
@@ -394,6 +396,7 @@ int pcv_bytes_per_coordinate(uint32_t enc) { return enc == PCV_ENC_UINT8 ? 1 : e
 
 extern "C" int pcv_octree_node_data(pcv_octree* t, uint64_t i, int which, const uint8_t** data, uint64_t* len) {
   if (!t || !data || !len || i >= t->nodes.size() || which < 0 || which > 2) return PCV_E_INVALID;
+  if (!t->directory.empty()) return pcv_octree_read_node_file(t, i, which, data, len);
   int rc = pcv_octree_fetch_host(t);
   if (rc) return rc;
   const pcv_node_info& nd = t->nodes[i];

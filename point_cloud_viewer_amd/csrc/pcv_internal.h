@@ -46,6 +46,11 @@ enum PcvKernelId {
   PCV_K_SORT_UPSWEEP32,
   PCV_K_SORT_DOWNSWEEP32,
   PCV_K_PROMOTE_ENCODE,
+  PCV_K_CULL_NODES,
+  PCV_K_VISIBLE_NODES,
+  PCV_K_NODES_IN_LOCATION,
+  PCV_K_CULL_POINTS,
+  PCV_K_TRANSFORM_POINTS,
   PCV_K_COUNT
 };
 
@@ -195,6 +200,8 @@ void pcv_launch_promote_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvPromo
                                const uint32_t* rgba, const uint32_t* inten_bits, uint8_t* xyz_blob,
                                uint8_t* rgb_blob, uint8_t* inten_blob);
 
+struct PcvOctreeQuery;  // device-resident traversal tables (pcv_query.hip)
+
 // The finished octree (node table + node-contiguous blobs).
 struct pcv_octree {
   pcv_ctx* ctx = nullptr;
@@ -208,8 +215,15 @@ struct pcv_octree {
   std::vector<uint8_t> h_xyz, h_rgb, h_int;
   bool host_valid = false;
   float stage_ms[PCV_NUM_STAGES] = {};
+  PcvOctreeQuery* query = nullptr;
+  // octrees opened from a directory: node files are read on demand
+  std::string directory;
+  std::map<std::pair<uint64_t, int>, std::vector<uint8_t>> file_cache;
 };
+int pcv_octree_prepare_query(pcv_octree* t);
+void pcv_octree_release_query(pcv_octree* t);
 int pcv_octree_fetch_host(pcv_octree* t);
+int pcv_octree_read_node_file(pcv_octree* t, uint64_t i, int which, const uint8_t** data, uint64_t* len);
 int pcv_bytes_per_coordinate(uint32_t enc);
 
 // host helpers (pcv_build.hip)

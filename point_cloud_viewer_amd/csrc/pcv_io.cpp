@@ -8,6 +8,8 @@
 // NodeId Display: "r" + index in octal, zero-padded to `level` digits      src/octree/node.rs:73-86
 #include <sys/stat.h>
 
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -117,5 +119,233 @@ extern "C" int pcv_octree_write_dir(pcv_octree* t, const char* directory) {
   }
   std::vector<uint8_t> meta = pcv_encode_meta(t);
   if (!write_file(dir + "/meta.pb", meta.data(), meta.size())) return ctx->fail(PCV_E_IO, "cannot write meta.pb");
+  return PCV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Loading: Octree::from_data_provider over a directory (src/octree/mod.rs:156-215, data_provider/on_disk.rs)
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct Reader {
+  const uint8_t* p;
+  const uint8_t* end;
+  bool ok = true;
+  uint64_t varint() {
+    uint64_t v = 0;
+    for (int s = 0; p < end && s < 64; s += 7) {
+      uint8_t b = *p++;
+      v |= (uint64_t)(b & 0x7f) << s;
+      if (!(b & 0x80)) return v;
+    }
+    ok = false;
+    return 0;
+  }
+  double f64() {
+    if (end - p < 8) {
+      ok = false;
+      return 0;
+    }
+    uint64_t u = 0;
+    for (int i = 0; i < 8; ++i) u |= (uint64_t)p[i] << (8 * i);
+    p += 8;
+    double d;
+    std::memcpy(&d, &u, 8);
+    return d;
+  }
+  Reader sub() {
+    uint64_t len = varint();
+    if ((uint64_t)(end - p) < len) {
+      ok = false;
+      len = 0;
+    }
+    Reader r{p, p + len};
+    p += len;
+    return r;
+  }
+  void skip(int wire) {
+    if (wire == 0) varint();
+    else if (wire == 1 && end - p >= 8) p += 8;
+    else if (wire == 2) sub();
+    else if (wire == 5 && end - p >= 4) p += 4;
+    else ok = false;
+  }
+};
+
+void read_vec3(Reader r, double v[3]) {
+  v[0] = v[1] = v[2] = 0.;
+  while (r.p < r.end && r.ok) {
+    uint64_t t = r.varint();
+    int f = (int)(t >> 3), w = (int)(t & 7);
+    if (w == 1 && f >= 1 && f <= 3) v[f - 1] = r.f64();
+    else r.skip(w);
+  }
+}
+void read_cuboid(Reader c, double mn[3], double mx[3]) {
+  while (c.p < c.end && c.ok) {
+    uint64_t t = c.varint();
+    int f = (int)(t >> 3), w = (int)(t & 7);
+    if (f == 3 && w == 2) read_vec3(c.sub(), mn);
+    else if (f == 4 && w == 2) read_vec3(c.sub(), mx);
+    else c.skip(w);
+  }
+}
+
+bool read_file(const std::string& path, std::vector<uint8_t>* out, bool* missing) {
+  *missing = false;
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) {
+    *missing = true;
+    return false;
+  }
+  fseek(f, 0, SEEK_END);
+  long sz = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  out->resize((size_t)sz);
+  size_t got = sz ? fread(out->data(), 1, (size_t)sz, f) : 0;
+  fclose(f);
+  return got == (size_t)sz;
+}
+
+}  // namespace
+
+extern "C" int pcv_octree_open_dir(pcv_ctx* ctx, const char* directory, pcv_octree** out) {
+  if (!ctx) return PCV_E_INVALID;
+  if (!directory || !out) return ctx->fail(PCV_E_INVALID, "null argument");
+  *out = nullptr;
+  std::string dir(directory);
+  std::vector<uint8_t> buf;
+  bool missing;
+  if (!read_file(dir + "/meta.pb", &buf, &missing))
+    return ctx->fail(missing ? PCV_E_NOT_FOUND : PCV_E_IO, "cannot read " + dir + "/meta.pb");
+  int version = 0;
+  double bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0}, resolution = 0;
+  bool has_octree = false;
+  struct RawNode {
+    uint64_t hi, lo;
+    int64_t num_points;
+    uint32_t enc;
+  };
+  std::vector<RawNode> raw;
+  Reader r{buf.data(), buf.data() + buf.size()};
+  while (r.p < r.end && r.ok) {
+    uint64_t t = r.varint();
+    int f = (int)(t >> 3), w = (int)(t & 7);
+    if (f == 1 && w == 0) version = (int)r.varint();
+    else if (f == 4 && w == 2) read_cuboid(r.sub(), bmin, bmax);
+    else if (f == 6 && w == 2) {
+      has_octree = true;
+      Reader o = r.sub();
+      while (o.p < o.end && o.ok) {
+        uint64_t ot = o.varint();
+        int of = (int)(ot >> 3), ow = (int)(ot & 7);
+        if (of == 2 && ow == 1) resolution = o.f64();
+        else if (of == 1 && ow == 2 && version == 12) read_cuboid(o.sub(), bmin, bmax);  // deprecated_bounding_box
+        else if (of == 3 && ow == 2) {
+          Reader n = o.sub();
+          RawNode rn{0, 0, 0, 0};
+          while (n.p < n.end && n.ok) {
+            uint64_t nt = n.varint();
+            int nf = (int)(nt >> 3), nw = (int)(nt & 7);
+            if (nf == 2 && nw == 0) rn.enc = (uint32_t)n.varint();
+            else if (nf == 3 && nw == 0) rn.num_points = (int64_t)n.varint();
+            else if (nf == 4 && nw == 2) {
+              Reader id = n.sub();
+              while (id.p < id.end && id.ok) {
+                uint64_t it = id.varint();
+                int idf = (int)(it >> 3), idw = (int)(it & 7);
+                if (idf == 3 && idw == 0) rn.hi = id.varint();
+                else if (idf == 4 && idw == 0) rn.lo = id.varint();
+                else id.skip(idw);
+              }
+              if (!id.ok) n.ok = false;
+            } else n.skip(nw);
+          }
+          if (!n.ok) o.ok = false;
+          raw.push_back(rn);
+        } else o.skip(ow);
+      }
+      if (!o.ok) r.ok = false;
+    } else r.skip(w);
+  }
+  if (!r.ok) return ctx->fail(PCV_E_INVALID, "Could not parse meta.pb");
+  if (version != 12 && version != 13) return ctx->fail(PCV_E_INVALID, "InvalidVersion(" + std::to_string(version) + ")");
+  if (!has_octree) return ctx->fail(PCV_E_INVALID, "No octree meta found");
+
+  pcv_octree* t = new pcv_octree();
+  t->ctx = ctx;
+  t->resolution = resolution;
+  t->directory = dir;
+  for (int a = 0; a < 3; ++a) {  // Aabb::new: inf / sup
+    t->bbox_min[a] = std::fmin(bmin[a], bmax[a]);
+    t->bbox_max[a] = std::fmax(bmin[a], bmax[a]);
+  }
+  const double root_edge = std::fmax(std::fmax(t->bbox_max[0] - t->bbox_min[0], t->bbox_max[1] - t->bbox_min[1]),
+                                     t->bbox_max[2] - t->bbox_min[2]);
+  typedef unsigned __int128 u128;
+  for (const RawNode& rn : raw) {
+    if (rn.enc < 1 || rn.enc > 4) {  // codec.rs:50-53 PositionEncoding::from_proto(INVALID)
+      delete t;
+      return ctx->fail(PCV_E_INVALID, "Proto: PositionEncoding is invalid");
+    }
+    pcv_node_info ni{};
+    ni.id_high = rn.hi;
+    ni.id_low = rn.lo;
+    ni.num_points = rn.num_points;
+    ni.level = (uint32_t)(rn.hi >> 56);
+    ni.encoding = rn.enc;
+    // NodeId::find_bounding_cube (node.rs:157-172)
+    u128 v = ((u128)rn.hi << 64) | rn.lo;
+    double edge = root_edge, mn[3] = {t->bbox_min[0], t->bbox_min[1], t->bbox_min[2]};
+    for (int level = (int)ni.level - 1; level >= 0; --level) {
+      edge /= 2.;
+      unsigned ci = (unsigned)((v >> (3 * level)) & 7);
+      mn[0] += (double)((ci >> 2) & 1) * edge;
+      mn[1] += (double)((ci >> 1) & 1) * edge;
+      mn[2] += (double)(ci & 1) * edge;
+    }
+    for (int a = 0; a < 3; ++a) ni.cube_min[a] = mn[a];
+    ni.cube_edge = edge;
+    t->nodes.push_back(ni);
+    t->num_points += (uint64_t)rn.num_points;
+  }
+  std::sort(t->nodes.begin(), t->nodes.end(), [](const pcv_node_info& a, const pcv_node_info& b) {
+    if (a.level != b.level) return a.level < b.level;
+    const uint64_t ah = a.id_high & 0x00ffffffffffffffull, bh = b.id_high & 0x00ffffffffffffffull;
+    if (ah != bh) return ah < bh;
+    return a.id_low < b.id_low;
+  });
+  uint64_t point_off = 0, xyz_off = 0;
+  for (pcv_node_info& ni : t->nodes) {
+    ni.point_offset = point_off;
+    ni.xyz_offset = xyz_off;
+    point_off += (uint64_t)ni.num_points;
+    xyz_off += (uint64_t)ni.num_points * 3 * (uint64_t)pcv_bytes_per_coordinate(ni.encoding);
+  }
+  // intensity is implied by the presence of the root's .intensity file (octree/mod.rs:57-74 hard-codes both)
+  struct stat st;
+  t->has_intensity = stat((dir + "/r.intensity").c_str(), &st) == 0;
+  *out = t;
+  return PCV_OK;
+}
+
+// Octree::get_node_data (octree/mod.rs:285-307): raw file content; missing file -> NodeNotFound.
+int pcv_octree_read_node_file(pcv_octree* t, uint64_t i, int which, const uint8_t** data, uint64_t* len) {
+  pcv_ctx* ctx = t->ctx;
+  auto key = std::make_pair(i, which);
+  auto it = t->file_cache.find(key);
+  if (it == t->file_cache.end()) {
+    const char* ext = which == 0 ? ".xyz" : (which == 1 ? ".rgb" : ".intensity");
+    std::vector<uint8_t> buf;
+    bool missing;
+    const std::string path = t->directory + "/" + node_name(t->nodes[i]) + ext;
+    if (!read_file(path, &buf, &missing)) {
+      if (missing && (t->nodes[i].num_points == 0 || which == 2)) buf.clear();  // empty nodes have no files
+      else return ctx->fail(missing ? PCV_E_NOT_FOUND : PCV_E_IO, "cannot read " + path);
+    }
+    it = t->file_cache.emplace(key, std::move(buf)).first;
+  }
+  *data = it->second.data();
+  *len = it->second.size();
   return PCV_OK;
 }

@@ -156,6 +156,57 @@ class Context:
         del keep
         return OctreeResult(self, h)
 
+    # ---- loading + queries -----------------------------------------------------------------------
+    def open_dir(self, directory):
+        """Octree::from_data_provider over a directory (octree/mod.rs:156-215)."""
+        h = C.c_void_p()
+        self._check(self.lib.pcv_octree_open_dir(self.handle, str(directory).encode(), C.byref(h)))
+        return OctreeResult(self, h)
+
+    def shapes(self, shapes):
+        """Prepare query shapes on the device. Each entry: ("all",), ("aabb", min3, max3), ("frustum", clip_from_query16),
+        ("frustum2", clip_from_query16, query_from_clip16), ("obb", translation3, quat_ijkw4, half_extent3)."""
+        arr = (L.Shape * max(1, len(shapes)))()
+        for i, sh in enumerate(shapes):
+            kind = {"all": L.SHAPE_ALL, "aabb": L.SHAPE_AABB, "frustum": L.SHAPE_FRUSTUM, "obb": L.SHAPE_OBB,
+                    "frustum2": L.SHAPE_FRUSTUM_WITH_INVERSE}[sh[0]]
+            arr[i].kind = kind
+            flat = [float(v) for part in sh[1:] for v in np.asarray(part, dtype=np.float64).ravel()]
+            for j, v in enumerate(flat):
+                arr[i].params[j] = v
+        h = C.c_void_p()
+        self._check(self.lib.pcv_shapes_create(self.handle, arr, len(shapes), C.byref(h)))
+        return Shapes(self, h, len(shapes))
+
+    def cull_points(self, shapes, shape_index, x, y, z, intensity=None, interval=None):
+        """FilteredIterator keep mask for raw positions. Returns (keep uint8 array/tensor, kept count)."""
+        p, keep_alive = self._points(x, y, z, None, intensity)
+        iv = (C.c_double * 2)(*[float(v) for v in interval]) if interval is not None else None
+        kept = C.c_uint64()
+        if p.mem == L.MEM_DEVICE:
+            import torch
+            keep = torch.empty(p.n, dtype=torch.uint8, device=x.device)
+            ptr = keep.data_ptr()
+        else:
+            keep = np.zeros(p.n, dtype=np.uint8)
+            ptr = keep.ctypes.data
+        self._check(self.lib.pcv_cull_points(self.handle, shapes.handle, shape_index, C.byref(p), iv, ptr, C.byref(kept)))
+        return keep, kept.value
+
+    def transform_points(self, iso7, x, y, z):
+        """Isometry3 * Point3 for a batch; iso7 = translation xyz + unit quaternion ijkw."""
+        p, keep_alive = self._points(x, y, z)
+        iso = (C.c_double * 7)(*[float(v) for v in iso7])
+        if p.mem == L.MEM_DEVICE:
+            import torch
+            out = [torch.empty(p.n, dtype=torch.float64, device=x.device) for _ in range(3)]
+            ptrs = [o.data_ptr() for o in out]
+        else:
+            out = [np.zeros(p.n) for _ in range(3)]
+            ptrs = [o.ctypes.data for o in out]
+        self._check(self.lib.pcv_transform_points(self.handle, iso, C.byref(p), *ptrs))
+        return out
+
     # ---- stage-level entry points ----------------------------------------------------------------
     def aabb_reduce(self, x, y, z):
         p, keep = self._points(x, y, z)
@@ -198,6 +249,30 @@ def level_table(bbox_min, bbox_max, resolution, cap=64):
     enc = (C.c_int32 * (cap + 2))()
     ml = lib.pcv_level_table(bmin, bmax, float(resolution), cap, edge, enc)
     return ml, np.array(edge[:ml + 1]), np.array(enc[:ml + 1], dtype=np.int32)
+
+
+class Shapes:
+    """Prepared query shapes (device resident)."""
+
+    def __init__(self, ctx, handle, count):
+        self.ctx, self.handle, self.count = ctx, handle, count
+
+    def get(self, i):
+        corners, axes = (C.c_double * 24)(), (C.c_double * 78)()
+        n, valid = C.c_uint32(), C.c_int()
+        self.ctx._check(self.ctx.lib.pcv_shapes_get(self.handle, i, corners, axes, C.byref(n), C.byref(valid)))
+        return np.array(corners[:]).reshape(8, 3), np.array(axes[:3 * n.value]).reshape(n.value, 3), bool(valid.value)
+
+    def free(self):
+        if self.handle:
+            self.ctx.lib.pcv_shapes_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class OctreeResult:
@@ -251,6 +326,47 @@ class OctreeResult:
 
     def write_dir(self, directory):
         self.ctx._check(self.lib.pcv_octree_write_dir(self.handle, str(directory).encode()))
+
+    # ---- queries ----
+    def node_names(self):
+        return [node_name(self.node(i).id_high, self.node(i).id_low) for i in range(self.num_nodes)]
+
+    def cull_nodes(self, shapes, with_sizes=False):
+        """Relation matrix [shape][node] (0 In, 1 Cross, 2 Out) and optionally relative_size_on_screen."""
+        m, f = self.num_nodes, shapes.count
+        rel = np.zeros((f, m), dtype=np.uint8)
+        sizes = np.zeros((f, m)) if with_sizes else None
+        self.ctx._check(self.lib.pcv_cull_nodes(self.ctx.handle, shapes.handle, self.handle, rel.ctypes.data,
+                                                sizes.ctypes.data if with_sizes else None))
+        return (rel, sizes) if with_sizes else rel
+
+    def _traverse(self, fn, shapes, with_status):
+        m, f = max(1, self.num_nodes), shapes.count
+        counts = np.zeros(f, dtype=np.uint32)
+        idx = np.zeros((f, m), dtype=np.uint32)
+        status = np.zeros(f, dtype=np.int32)
+        if with_status:
+            self.ctx._check(fn(self.ctx.handle, shapes.handle, self.handle, m, counts.ctypes.data, idx.ctypes.data,
+                               status.ctypes.data))
+        else:
+            self.ctx._check(fn(self.ctx.handle, shapes.handle, self.handle, m, counts.ctypes.data, idx.ctypes.data))
+        return [idx[i, :counts[i]].copy() for i in range(f)], status
+
+    def visible_nodes(self, frusta):
+        """Octree::get_visible_nodes per frustum: (list of node-index arrays in heap pop order, status array)."""
+        return self._traverse(self.lib.pcv_visible_nodes, frusta, True)
+
+    def nodes_in_location(self, shapes):
+        return self._traverse(self.lib.pcv_nodes_in_location, shapes, False)[0]
+
+    def cull_node_points(self, shapes, shape_index, node, interval=None):
+        n = self.node(node).num_points
+        keep = np.zeros(n, dtype=np.uint8)
+        kept = C.c_uint64()
+        iv = (C.c_double * 2)(*[float(v) for v in interval]) if interval is not None else None
+        self.ctx._check(self.lib.pcv_cull_node_points(self.ctx.handle, shapes.handle, shape_index, self.handle, node, iv,
+                                                      keep.ctypes.data, C.byref(kept)))
+        return keep, kept.value
 
     def to_dict(self):
         """{node name: dict(id, num_points, encoding, level, xyz, rgb, intensity)} — same shape the test-side

@@ -1,0 +1,192 @@
+"""Parity of the HIP transform-and-cull path (Q1-Q5) against the CPU oracle: prepared shapes (corners, axes),
+Relation per (shape, node), relative_size_on_screen, get_visible_nodes order, nodes_in_location, per-point keep
+masks on raw and on encoded node data, Isometry3 point transform. All exact (f64, same operation order)."""
+import math
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import point_cloud_viewer_amd as pcv
+from point_cloud_viewer_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = pcv.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def scene(ctx):
+    x, y, z, rgb, bmin, bmax = synthetic.gaussian_clusters(300_000, seed=2, num_clusters=6, extent=100.0,
+                                                           sigma_range=(0.5, 6.0))
+    inten = (np.arange(x.size) % 251).astype(np.float32)
+    tree = ctx.build(0.001, pcv.Aabb(bmin, bmax), x, y, z, rgb, inten, max_points_per_node=2000)
+    with O.max_points_per_node(2000):
+        want = O.build_closed(0.001, bmin, bmax, x, y, z, rgb, inten, threads=4)
+    return dict(x=x, y=y, z=z, bmin=bmin, bmax=bmax, tree=tree, oracle=want, names=tree.node_names())
+
+
+def random_frusta(rng, bmin, bmax, n):
+    out = []
+    for _ in range(n):
+        eye = rng.uniform(bmin - 20, bmax + 20)
+        q = rng.normal(size=4)
+        q = q / math.sqrt(float(((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3]))
+        persp = O.perspective3_new(1.0, 1.2, 0.1, 100.0)  # BASELINE config 4
+        c, qi = O.frustum_new(eye, q, persp)
+        out.append((c, qi))
+    return out
+
+
+def test_prepared_shapes_match_oracle(ctx):
+    rng = np.random.default_rng(1)
+    fr = random_frusta(rng, np.zeros(3), np.full(3, 100.0), 50)
+    shapes = [("frustum", c) for c, _ in fr] + [("frustum2", c, q) for c, q in fr[:10]]
+    ax = np.array([0.2, 0.5, -0.7])
+    ax = ax / math.sqrt((ax[0] * ax[0] + ax[1] * ax[1]) + ax[2] * ax[2])
+    obbs = [([0.0, 0, 0], [0.0, 0, 0, 1.0], [1.0, 2, 3]),
+            ([0.0, 0, 0], O.quat_from_axis_angle([0, 0, 1.0], math.pi / 4), [1.0, 2, 3]),
+            ([4.0, -2, 9], O.quat_from_axis_angle(ax.tolist(), 0.123), [1.0, 2, 3])]
+    shapes += [("obb", t, q, h) for t, q, h in obbs]
+    shapes += [("aabb", [0.5, 1.0, -3.0], [1.5, 3.0, 3.0]), ("frustum", np.zeros(16))]
+    prepared = ctx.shapes(shapes)
+    for i, sh in enumerate(shapes):
+        corners, axes, valid = prepared.get(i)
+        kind = {"frustum": O.SHAPE_FRUSTUM, "frustum2": O.SHAPE_FRUSTUM2, "obb": O.SHAPE_OBB, "aabb": O.SHAPE_AABB}[sh[0]]
+        params = np.concatenate([np.asarray(p, dtype=np.float64).ravel() for p in sh[1:]])
+        want = O.cached_axes(kind, params)
+        if want is None:
+            assert not valid
+            continue
+        assert valid
+        assert np.array_equal(corners, want[0]), (i, sh[0])
+        assert axes.shape == want[1].shape and np.array_equal(axes, want[1]), (i, sh[0])
+    assert [prepared.get(60 + k)[1].shape[0] for k in range(3)] == [3, 5, 15]  # obb.rs:100-141 axis counts
+
+
+def test_cull_nodes_relations_and_sizes(ctx, scene):
+    rng = np.random.default_rng(3)
+    fr = random_frusta(rng, scene["bmin"], scene["bmax"], 40)
+    tree = scene["tree"]
+    prepared = ctx.shapes([("frustum", c) for c, _ in fr] + [("obb", scene["bmin"] + 30, [0, 0, 0.3, math.sqrt(1 - 0.09)], [20, 10, 5]),
+                                                               ("aabb", scene["bmin"] + 10, scene["bmin"] + 50)])
+    rel, sizes = tree.cull_nodes(prepared, with_sizes=True)
+    cubes = np.array([[*tree.node(i).cube_min, tree.node(i).cube_edge] for i in range(tree.num_nodes)])
+    for f, (c, _) in enumerate(fr):
+        want_rel, want_sz = O.cull_cubes(O.SHAPE_FRUSTUM, c, cubes, with_sizes=True)
+        assert np.array_equal(rel[f], want_rel), f
+        assert np.array_equal(sizes[f], want_sz, equal_nan=True), f
+    obb_params = list(scene["bmin"] + 30) + [0, 0, 0.3, math.sqrt(1 - 0.09)] + [20, 10, 5]
+    assert np.array_equal(rel[40], O.cull_cubes(O.SHAPE_OBB, obb_params, cubes))
+    assert np.array_equal(rel[41], O.cull_cubes(O.SHAPE_AABB, list(scene["bmin"] + 10) + list(scene["bmin"] + 50), cubes))
+    assert {0, 1, 2} <= set(np.unique(rel))  # In, Cross and Out all occur
+
+
+def test_visible_nodes_match_reference_traversal_order(ctx, scene):
+    rng = np.random.default_rng(4)
+    fr = random_frusta(rng, scene["bmin"], scene["bmax"], 64)
+    tree, names = scene["tree"], scene["names"]
+    vis, status = tree.visible_nodes(ctx.shapes([("frustum", c) for c, _ in fr] + [("frustum", np.zeros(16))]))
+    nonempty = 0
+    for f, (c, _) in enumerate(fr):
+        want = O.get_visible_nodes(scene["bmin"], scene["bmax"], scene["oracle"].nodes, c)
+        if want is None:
+            assert status[f] != 0
+            continue
+        assert status[f] == 0
+        assert [names[i] for i in vis[f]] == want, f  # same nodes, same BinaryHeap pop order
+        nonempty += len(want) > 0
+    assert nonempty > 10
+    assert status[64] == 1 and len(vis[64]) == 0  # singular matrix: the reference panics
+
+
+def test_nodes_in_location(ctx, scene):
+    rng = np.random.default_rng(5)
+    fr = random_frusta(rng, scene["bmin"], scene["bmax"], 8)
+    tree, names = scene["tree"], scene["names"]
+    obb = (scene["bmin"] + 40, O.quat_from_axis_angle([0.0, 0.0, 1.0], 0.4), [25.0, 12.0, 30.0])
+    shapes = [("all",), ("aabb", scene["bmin"] + 5, scene["bmin"] + 60), ("obb", *obb)] + [("frustum2", c, q) for c, q in fr]
+    got = tree.nodes_in_location(ctx.shapes(shapes))
+    on = scene["oracle"].nodes
+    want = [O.nodes_in_location(scene["bmin"], scene["bmax"], on, O.SHAPE_ALL, None),
+            O.nodes_in_location(scene["bmin"], scene["bmax"], on, O.SHAPE_AABB, list(scene["bmin"] + 5) + list(scene["bmin"] + 60)),
+            O.nodes_in_location(scene["bmin"], scene["bmax"], on, O.SHAPE_OBB, list(obb[0]) + list(obb[1]) + list(obb[2]))]
+    want += [O.nodes_in_location(scene["bmin"], scene["bmax"], on, O.SHAPE_FRUSTUM2, np.concatenate([c, q])) for c, q in fr]
+    for g, w in zip(got, want):
+        assert [names[i] for i in g] == w
+    assert len(want[0]) == tree.num_nodes
+
+
+def test_cull_points_raw_and_encoded(ctx, scene):
+    rng = np.random.default_rng(6)
+    fr = random_frusta(rng, scene["bmin"], scene["bmax"], 4)
+    obb = (scene["bmin"] + 40, O.quat_from_axis_angle([0.0, 1.0, 0.0], 0.9), [25.0, 12.0, 30.0])
+    shapes = [("frustum", fr[0][0]), ("frustum2", *fr[1]), ("obb", *obb), ("aabb", scene["bmin"] + 20, scene["bmin"] + 70), ("all",)]
+    kinds = [(O.SHAPE_FRUSTUM, fr[0][0]), (O.SHAPE_FRUSTUM, fr[1][0]), (O.SHAPE_OBB, list(obb[0]) + list(obb[1]) + list(obb[2])),
+             (O.SHAPE_AABB, list(scene["bmin"] + 20) + list(scene["bmin"] + 70)), (O.SHAPE_ALL, None)]
+    prepared = ctx.shapes(shapes)
+    x, y, z = scene["x"], scene["y"], scene["z"]
+    inten = (np.arange(x.size) % 251).astype(np.float32)
+    total = 0
+    for i, (kind, params) in enumerate(kinds):
+        keep, kept = ctx.cull_points(prepared, i, x, y, z)
+        want = O.cull_points(kind, params, x, y, z)
+        assert np.array_equal(keep, want) and kept == int(want.sum()), i
+        keep, kept = ctx.cull_points(prepared, i, x, y, z, inten, interval=(10.0, 99.5))
+        want = O.cull_points(kind, params, x, y, z, inten, (10.0, 99.5))
+        assert np.array_equal(keep, want) and kept == int(want.sum()), i
+        total += kept
+    assert total > 0
+    # on a built octree's nodes: decode-on-the-fly == oracle decode + contains
+    tree = scene["tree"]
+    checked = 0
+    for node in range(tree.num_nodes):
+        nd = tree.node(node)
+        if nd.num_points == 0:
+            continue
+        px, py, pz = O.decode_positions(nd.encoding, nd.cube_min, nd.cube_edge, tree.node_data(node, 0))
+        for i, (kind, params) in enumerate(kinds[:4]):
+            keep, kept = tree.cull_node_points(prepared, i, node)
+            assert np.array_equal(keep, O.cull_points(kind, params, px, py, pz)), (node, i)
+        ninten = np.frombuffer(tree.node_data(node, 2), dtype=np.float32)
+        keep, kept = tree.cull_node_points(prepared, 2, node, interval=(0.0, 50.0))
+        assert np.array_equal(keep, O.cull_points(kinds[2][0], kinds[2][1], px, py, pz, ninten, (0.0, 50.0)))
+        checked += 1
+        if checked >= 40:
+            break
+    assert checked >= 20
+
+
+def test_transform_points(ctx, scene):
+    iso = [3.5, -2.25, 10.0] + O.quat_from_axis_angle([0.6, 0.0, 0.8], 1.1)
+    x, y, z = scene["x"][:100_000], scene["y"][:100_000], scene["z"][:100_000]
+    ox, oy, oz = ctx.transform_points(iso, x, y, z)
+    wx, wy, wz = O.iso_transform_points(iso, x, y, z)
+    assert np.array_equal(ox, wx) and np.array_equal(oy, wy) and np.array_equal(oz, wz)
+
+
+def test_open_dir_round_trip_and_query(ctx, scene, tmp_path):
+    tree = scene["tree"]
+    tree.write_dir(tmp_path / "oct")
+    loaded = ctx.open_dir(tmp_path / "oct")
+    assert loaded.num_nodes == tree.num_nodes and loaded.num_points == tree.num_points
+    assert loaded.node_names() == scene["names"]
+    m = loaded.meta()
+    assert np.array_equal(m["bbox_min"], scene["bmin"]) and m["resolution"] == 0.001
+    for i in (0, 1, tree.num_nodes // 2, tree.num_nodes - 1):
+        a, b = tree.node(i), loaded.node(i)
+        assert (a.num_points, a.encoding, tuple(a.cube_min), a.cube_edge) == (b.num_points, b.encoding, tuple(b.cube_min), b.cube_edge)
+        assert loaded.node_data(i, 0) == tree.node_data(i, 0) and loaded.node_data(i, 1) == tree.node_data(i, 1)
+    rng = np.random.default_rng(8)
+    fr = random_frusta(rng, scene["bmin"], scene["bmax"], 8)
+    sh = ctx.shapes([("frustum", c) for c, _ in fr])
+    va, _ = tree.visible_nodes(sh)
+    vb, _ = loaded.visible_nodes(sh)
+    assert all(np.array_equal(p, q) for p, q in zip(va, vb))
+    with pytest.raises(pcv.PcvError):
+        ctx.open_dir(tmp_path / "missing")
