@@ -5,6 +5,7 @@ Reference names kept: `build_octree(output_directory, resolution, bounding_box, 
 Inputs may be numpy arrays (host) or torch CUDA tensors (device-resident; zero copy).
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -70,8 +71,11 @@ class Context:
         if rc != L.PCV_OK:
             raise L.PcvError(rc, f"pcv_ctx_create(device={device}) failed — is a HIP device visible?")
         self.handle = h
+        self._children = weakref.WeakSet()  # octrees / shape sets that borrow this context's pool
 
     def close(self):
+        for child in list(getattr(self, "_children", [])):
+            child.free()
         if getattr(self, "handle", None):
             self.lib.pcv_ctx_destroy(self.handle)
             self.handle = None
@@ -256,6 +260,7 @@ class Shapes:
 
     def __init__(self, ctx, handle, count):
         self.ctx, self.handle, self.count = ctx, handle, count
+        ctx._children.add(self)
 
     def get(self, i):
         corners, axes = (C.c_double * 24)(), (C.c_double * 78)()
@@ -264,7 +269,7 @@ class Shapes:
         return np.array(corners[:]).reshape(8, 3), np.array(axes[:3 * n.value]).reshape(n.value, 3), bool(valid.value)
 
     def free(self):
-        if self.handle:
+        if self.handle and self.ctx.handle:
             self.ctx.lib.pcv_shapes_free(self.handle)
             self.handle = None
 
@@ -282,9 +287,10 @@ class OctreeResult:
         self.ctx = ctx
         self.lib = ctx.lib
         self.handle = handle
+        ctx._children.add(self)
 
     def free(self):
-        if self.handle:
+        if self.handle and self.ctx.handle:
             self.lib.pcv_octree_free(self.handle)
             self.handle = None
 
