@@ -163,6 +163,12 @@ int pcv_sort_keys64(pcv_ctx* ctx, uint64_t* keys, uint64_t n, int begin_bit, int
 int pcv_sort_pairs32(pcv_ctx* ctx, uint32_t* keys, uint32_t* values, uint64_t n, int begin_bit, int end_bit,
                      int mem);
 
+/* Device self-test of the exact constant-divisor division used by the chain kernels (see pcv_chain_dev.h):
+ * compares it bit-for-bit with IEEE f64 division for every integer code / 255 and / 65535 and for
+ * samples_per_divisor pseudo-random numerators per divisor; *mismatches must come back 0. */
+int pcv_selftest_division(pcv_ctx* ctx, const double* divisors, int ndiv, uint64_t samples_per_divisor,
+                          uint64_t* mismatches);
+
 /* ---- octree loading (viewer side) ------------------------------------------------------------ */
 /* Replaces Octree::from_data_provider over an OnDiskDataProvider (src/octree/mod.rs:156-215,
  * src/data_provider/on_disk.rs): parses meta.pb (versions 9..13 are accepted by the reference; this loader

@@ -224,6 +224,8 @@ int pcv_make_levels(const double bmin[3], const double bmax[3], double resolutio
     lv->nlevels = nl;
     for (int j = 0; j <= nl && j < (int)e.size(); ++j) {
       lv->edge[j] = e[j];
+      // IEEE division on the host: correctly rounded reciprocal; 0 = "use plain division" (pcv_div_const)
+      lv->inv_edge[j] = (e[j] >= 0x1p-100 && e[j] <= 0x1p+100) ? 1.0 / e[j] : 0.0;
       lv->enc[j] = (uint8_t)c[j];
     }
   }

@@ -108,17 +108,90 @@ __global__ __launch_bounds__(256) void chain_keys_kernel(PcvLevels lv, uint64_t 
   double mx = lv.root_min[0], my = lv.root_min[1], mz = lv.root_min[2];
   uint64_t key = 0, code;
   for (int k = 1; k <= lv.nlevels; ++k) {
-    const double ep = lv.edge[k - 1], ec = lv.edge[k];
+    const double ep = lv.edge[k - 1], ec = lv.edge[k], ic = lv.inv_edge[k];
     const uint32_t enc = lv.enc[k];
-    uint32_t d = pcv_chain_coord(enc, ep, ec, px, mx, code) << 2;
-    d |= pcv_chain_coord(enc, ep, ec, py, my, code) << 1;
-    d |= pcv_chain_coord(enc, ep, ec, pz, mz, code);
+    uint32_t d = pcv_chain_coord(enc, ep, ec, ic, px, mx, code) << 2;
+    d |= pcv_chain_coord(enc, ep, ec, ic, py, my, code) << 1;
+    d |= pcv_chain_coord(enc, ep, ec, ic, pz, mz, code);
     key |= (uint64_t)d << (3 * (PCV_MAX_KEY_LEVELS - k));
   }
   keys[i] = key;
 }
 
+// Division self-test: pcv_div_code against IEEE division for every code and both divisors (exhaustive), and
+// pcv_div_const against IEEE division for pseudo-random numerators (full exponent/mantissa spread, plus values
+// straddling rounding boundaries of the quotient) over a list of divisors.
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(256) void selftest_division_kernel(const double* __restrict__ divisors, int ndiv,
+                                                                 uint64_t samples_per_divisor,
+                                                                 unsigned long long* __restrict__ mismatches) {
+  const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  unsigned long long bad = 0;
+  if (gid < 65536) {
+    const double v = (double)(uint32_t)gid;
+    bad += __double_as_longlong(pcv_div_code(v, 65535.0, 1.0 / 65535.0)) != __double_as_longlong(v / 65535.0);
+    if (gid < 256) bad += __double_as_longlong(pcv_div_code(v, 255.0, 1.0 / 255.0)) != __double_as_longlong(v / 255.0);
+  }
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  for (int d = 0; d < ndiv; ++d) {
+    const double e = divisors[d], y = (e >= 0x1p-100 && e <= 0x1p+100) ? 1.0 / e : 0.0;
+    for (uint64_t i = gid; i < samples_per_divisor; i += stride) {
+      const uint64_t h = mix64(i * 0x100000001B3ull + (uint64_t)d);
+      double x;
+      switch (h & 3) {
+        case 0:  // arbitrary bit pattern (any exponent, inf/nan/denormals included)
+          x = __longlong_as_double((long long)mix64(h));
+          break;
+        case 1: {  // metres-scale magnitudes, random mantissa
+          const int ex = (int)((h >> 8) % 80) - 40;
+          x = ldexp(1.0 + (double)(mix64(h) >> 12) * 0x1p-52, ex) * ((h & 4) ? -1.0 : 1.0);
+          break;
+        }
+        case 2: {  // numerators whose quotient sits next to a rounding boundary: x = RN(q * e) +- few ulp
+          const double q = 1.0 + (double)(mix64(h) >> 12) * 0x1p-52;
+          x = q * e;
+          x = __longlong_as_double(__double_as_longlong(x) + (long long)((h >> 4) % 5) - 2);
+          break;
+        }
+        default:  // small integers and their neighbours (codes, cell counts)
+          x = (double)(int64_t)((h >> 3) % 200001) - 100000.0 + (double)((h >> 40) & 3) * 0.25;
+      }
+      const double a = pcv_div_const(x, e, y), b = x / e;
+      const bool same = __double_as_longlong(a) == __double_as_longlong(b) || (a != a && b != b);
+      bad += same ? 0 : 1;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o, 64);
+  if ((threadIdx.x & 63) == 0 && bad) atomicAdd(mismatches, bad);
+}
+
 }  // namespace
+
+extern "C" int pcv_selftest_division(pcv_ctx* ctx, const double* divisors, int ndiv, uint64_t samples_per_divisor,
+                                     uint64_t* mismatches) {
+  if (!ctx) return PCV_E_INVALID;
+  if (!mismatches || (ndiv && !divisors) || ndiv < 0) return ctx->fail(PCV_E_INVALID, "bad argument");
+  PCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  PcvScratch sc(ctx);
+  double* dd;
+  unsigned long long* dm;
+  int rc;
+  if ((rc = sc.get(&dd, (size_t)(ndiv ? ndiv : 1))) || (rc = sc.get(&dm, 1))) return rc;
+  if (ndiv) PCV_HIP_CHECK(ctx, hipMemcpyAsync(dd, divisors, sizeof(double) * ndiv, hipMemcpyHostToDevice, ctx->stream));
+  PCV_HIP_CHECK(ctx, hipMemsetAsync(dm, 0, 8, ctx->stream));
+  hipLaunchKernelGGL(selftest_division_kernel, dim3(2048), dim3(256), 0, ctx->stream, dd, ndiv, samples_per_divisor, dm);
+  PCV_HIP_CHECK(ctx, hipGetLastError());
+  unsigned long long h = 0;
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(&h, dm, 8, hipMemcpyDeviceToHost, ctx->stream));
+  PCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  *mismatches = h;
+  return PCV_OK;
+}
 
 int pcv_launch_aabb(pcv_ctx* ctx, uint64_t n, const double* x, const double* y, const double* z, double* partial,
                     double* out6) {

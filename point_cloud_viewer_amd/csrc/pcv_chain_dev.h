@@ -8,19 +8,47 @@
 //                                                             src/read_write/codec.rs:102-121
 //   decode  : (v / max).mul_add(edge, min)  |  v.mul_add(edge, min)   src/read_write/codec.rs:124-139
 // The translation unit is compiled with -ffp-contract=off; the only fused operations are the explicit
-// __fma_rn calls that restate `mul_add`. Divisions are IEEE-correct f64 divisions (no reciprocals).
+// __fma_rn calls that restate `mul_add` and the FMA residuals of the exact constant-divisor division below, whose
+// results are bit-identical to IEEE f64 division (no approximate reciprocals anywhere).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "pcv_internal.h"
 
+// Correctly rounded x / e for a divisor that is constant across the grid, without the ~12-instruction IEEE
+// division expansion: y = RN(1/e) comes from the host; q0 = RN(x*y) is within 1.5 ulp; one residual correction
+// makes q1 faithful, and for a faithful q1 with exact residual r1 = x - e*q1 (one FMA) Markstein's theorem gives
+// RN(q1 + r1*y) == RN(x/e) (Markstein 1990; Muller et al., Handbook of Floating-Point Arithmetic, "division with
+// an FMA"). The theorem needs: y correctly rounded (it is), no overflow/underflow in the residuals. Outside
+// 2^-900 <= |x| <= 2^900 (also x == 0 for the sign of zero, inf, NaN) the IEEE division is used instead.
+// `pcv_selftest_division` checks the routine bit-for-bit against IEEE division on the device.
+__device__ __forceinline__ double pcv_div_const(double x, double e, double y) {
+  const double q0 = x * y;
+  const double r0 = __fma_rn(-e, q0, x);
+  const double q1 = __fma_rn(r0, y, q0);
+  const double r1 = __fma_rn(-e, q1, x);
+  double q = __fma_rn(r1, y, q1);
+  const double ax = fabs(x);
+  // y == 0 marks a divisor outside [2^-100, 2^100] (host side), where the residuals could leave the normal range
+  if (!(ax >= 0x1p-900 && ax <= 0x1p+900) || y == 0.0) q = x / e;
+  return q;
+}
+// v / maxval for an integer code v in [0, 65535]: same scheme, no range guard needed (verified exhaustively).
+__device__ __forceinline__ double pcv_div_code(double v, double maxval, double y) {
+  const double q0 = v * y;
+  const double r0 = __fma_rn(-maxval, q0, v);
+  const double q1 = __fma_rn(r0, y, q0);
+  const double r1 = __fma_rn(-maxval, q1, v);
+  return __fma_rn(r1, y, q1);
+}
+
 // num::clamp semantics (NaN and -0.0 pass through) — needed verbatim for the float encodings.
 __device__ __forceinline__ double pcv_clamp01(double t) { return (t < 0.0) ? 0.0 : ((t > 1.0) ? 1.0 : t); }
 
 // Rust `as u8/u16` after the clamp: NaN -> 0, truncation toward zero; t <= 1 so no upper saturation.
-__device__ __forceinline__ uint32_t pcv_fix_encode(double p, double mn, double edge, double maxval) {
-  double t = (p - mn) / edge;
+__device__ __forceinline__ uint32_t pcv_fix_encode(double p, double mn, double edge, double inv_edge, double maxval) {
+  double t = pcv_div_const(p - mn, edge, inv_edge);
   // (t > 0 ? t : 0) maps NaN, -0.0 and negatives to 0 — same integer code as clamp + `as` cast.
   t = (t > 0.0) ? t : 0.0;
   t = (t > 1.0) ? 1.0 : t;
@@ -28,22 +56,22 @@ __device__ __forceinline__ uint32_t pcv_fix_encode(double p, double mn, double e
 }
 
 // Raw code (integer value or IEEE bit pattern) of one coordinate.
-__device__ __forceinline__ uint64_t pcv_encode_coord(uint32_t enc, double p, double mn, double edge) {
+__device__ __forceinline__ uint64_t pcv_encode_coord(uint32_t enc, double p, double mn, double edge, double inv_edge) {
   switch (enc) {
-    case PCV_ENC_UINT8: return pcv_fix_encode(p, mn, edge, 255.0);
-    case PCV_ENC_UINT16: return pcv_fix_encode(p, mn, edge, 65535.0);
+    case PCV_ENC_UINT8: return pcv_fix_encode(p, mn, edge, inv_edge, 255.0);
+    case PCV_ENC_UINT16: return pcv_fix_encode(p, mn, edge, inv_edge, 65535.0);
     case PCV_ENC_FLOAT32: {
-      float f = (float)pcv_clamp01((p - mn) / edge);  // round-to-nearest-even
+      float f = (float)pcv_clamp01(pcv_div_const(p - mn, edge, inv_edge));  // round-to-nearest-even
       return (uint64_t)__float_as_uint(f);
     }
-    default: return (uint64_t)__double_as_longlong(pcv_clamp01((p - mn) / edge));
+    default: return (uint64_t)__double_as_longlong(pcv_clamp01(pcv_div_const(p - mn, edge, inv_edge)));
   }
 }
 
 __device__ __forceinline__ double pcv_decode_coord(uint32_t enc, uint64_t code, double mn, double edge) {
   switch (enc) {
-    case PCV_ENC_UINT8: return __fma_rn((double)(uint32_t)code / 255.0, edge, mn);
-    case PCV_ENC_UINT16: return __fma_rn((double)(uint32_t)code / 65535.0, edge, mn);
+    case PCV_ENC_UINT8: return __fma_rn(pcv_div_code((double)(uint32_t)code, 255.0, 1.0 / 255.0), edge, mn);
+    case PCV_ENC_UINT16: return __fma_rn(pcv_div_code((double)(uint32_t)code, 65535.0, 1.0 / 65535.0), edge, mn);
     case PCV_ENC_FLOAT32: return __fma_rn((double)__uint_as_float((uint32_t)code), edge, mn);
     default: return __fma_rn(__longlong_as_double((long long)code), edge, mn);
   }
@@ -51,13 +79,13 @@ __device__ __forceinline__ double pcv_decode_coord(uint32_t enc, uint64_t code, 
 
 // One level of the chain for one coordinate: returns the octant bit, moves `mn` to the child cube,
 // replaces `p` by its encode->decode image in the child cube and reports the code.
-__device__ __forceinline__ uint32_t pcv_chain_coord(uint32_t enc, double e_parent, double e_child, double& p,
-                                                    double& mn, uint64_t& code) {
+__device__ __forceinline__ uint32_t pcv_chain_coord(uint32_t enc, double e_parent, double e_child, double inv_e_child,
+                                                    double& p, double& mn, uint64_t& code) {
   double mx = mn + e_parent;
   double c = (mn + mx) / 2.0;
   uint32_t bit = p > c ? 1u : 0u;
   mn = mn + (bit ? e_child : 0.0);  // `bit as f64 * edge` is exactly e or +0.0
-  code = pcv_encode_coord(enc, p, mn, e_child);
+  code = pcv_encode_coord(enc, p, mn, e_child, inv_e_child);
   p = pcv_decode_coord(enc, code, mn, e_child);
   return bit;
 }

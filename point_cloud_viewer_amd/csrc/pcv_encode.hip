@@ -32,11 +32,11 @@ __global__ __launch_bounds__(256) void leaf_encode_kernel(
   int L = 0;
   do {
     ++L;
-    const double ep = lv.edge[L - 1], ec = lv.edge[L];
+    const double ep = lv.edge[L - 1], ec = lv.edge[L], ic = lv.inv_edge[L];
     const uint32_t enc = lv.enc[L];
-    uint32_t d = pcv_chain_coord(enc, ep, ec, px, mx, ccx) << 2;
-    d |= pcv_chain_coord(enc, ep, ec, py, my, ccy) << 1;
-    d |= pcv_chain_coord(enc, ep, ec, pz, mz, ccz);
+    uint32_t d = pcv_chain_coord(enc, ep, ec, ic, px, mx, ccx) << 2;
+    d |= pcv_chain_coord(enc, ep, ec, ic, py, my, ccy) << 1;
+    d |= pcv_chain_coord(enc, ep, ec, ic, pz, mz, ccz);
     const uint32_t mask = (uint32_t)(rec >> 32) & 0xffu;
     const uint32_t idx = (uint32_t)rec + __popc(mask & ((1u << d) - 1u));
     rec = walk[idx];
@@ -79,11 +79,11 @@ __global__ __launch_bounds__(256) void promote_encode_kernel(
     const double* mn = pt.node_min + (uint64_t)node * 3;
     const double* pm = pt.node_min + (uint64_t)par * 3;
     const uint32_t ec = lv.enc[level], ep = lv.enc[level - 1];
-    const double edge_c = lv.edge[level], edge_p = lv.edge[level - 1];
+    const double edge_c = lv.edge[level], edge_p = lv.edge[level - 1], inv_p = lv.inv_edge[level - 1];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       const double q = pcv_decode_coord(ec, code[a], mn[a], edge_c);
-      code[a] = pcv_encode_coord(ep, q, pm[a], edge_p);
+      code[a] = pcv_encode_coord(ep, q, pm[a], edge_p, inv_p);
     }
     j = pt.child_off[node] + (j >> 3);
     node = par;
@@ -94,9 +94,9 @@ __global__ __launch_bounds__(256) void promote_encode_kernel(
   if (node != 0) {
     slot = j - (j >> 3) - 1u;
     const double* mn = pt.node_min + (uint64_t)node * 3;
-    const double edge = lv.edge[level];
+    const double edge = lv.edge[level], inv = lv.inv_edge[level];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) code[a] = pcv_encode_coord(enc, pcv_decode_coord(enc, code[a], mn[a], edge), mn[a], edge);
+    for (int a = 0; a < 3; ++a) code[a] = pcv_encode_coord(enc, pcv_decode_coord(enc, code[a], mn[a], edge), mn[a], edge, inv);
   }
   uint8_t* dst = xyz_blob + pt.xyz_off[node];
   switch (enc) {

@@ -20,6 +20,7 @@
 struct PcvLevels {
   double root_min[3];
   double edge[PCV_MAX_KEY_LEVELS + 2];
+  double inv_edge[PCV_MAX_KEY_LEVELS + 2];  // RN(1 / edge[k]) for the exact constant-divisor division
   uint8_t enc[PCV_MAX_KEY_LEVELS + 3];
   int32_t nlevels;  // number of digit levels materialised in the keys (<= PCV_MAX_KEY_LEVELS)
 };

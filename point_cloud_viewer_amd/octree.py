@@ -230,6 +230,14 @@ class Context:
         self._check(self.lib.pcv_chain_keys(self.handle, C.byref(pr), C.byref(p), nlevels, keys.ctypes.data))
         return keys
 
+    def selftest_division(self, divisors, samples_per_divisor=1 << 22):
+        """Number of inputs for which the exact constant-divisor division differs from IEEE division (must be 0)."""
+        d = np.ascontiguousarray(divisors, dtype=np.float64)
+        bad = C.c_uint64()
+        self._check(self.lib.pcv_selftest_division(self.handle, d.ctypes.data_as(C.POINTER(C.c_double)), d.size,
+                                                   int(samples_per_divisor), C.byref(bad)))
+        return bad.value
+
     def sort_keys64(self, keys, begin_bit=0, end_bit=64):
         b = _Buf(keys, np.uint64, "keys")
         self._check(self.lib.pcv_sort_keys64(self.handle, b.ptr, b.size, begin_bit, end_bit,

@@ -97,3 +97,18 @@ def test_sort_pairs32_is_stable(ctx):
         k, v = ctx.sort_pairs32(keys.copy(), vals.copy(), 0, bits)
         order = np.argsort(keys, kind="stable")
         assert np.array_equal(k, keys[order]) and np.array_equal(v, vals[order]), (n, bits)
+
+
+def test_exact_constant_divisor_division_selftest(ctx):
+    """pcv_div_const / pcv_div_code (Markstein) == IEEE division, bit for bit: every u8/u16 code exhaustively, and
+    4 M pseudo-random numerators (any exponent, boundary-straddling quotients, inf/nan/denormals) per divisor for
+    the edges of typical level tables plus awkward divisors."""
+    divisors = []
+    for root in (1000.1234567, 283.0, 200.0, 1.0, 6378137.0 * 0.37, 30000.0 / 7.0, 0.0123):
+        e = root
+        for _ in range(22):
+            divisors.append(e)
+            e /= 2.0
+    divisors += [3.0, 7.0, 1.0 / 3.0, 0.1, 1e-30, 1e30, 1e-40, 1e200, 5e-324, 2.0 ** 52 - 1, 1.9999999999999998,
+                 1.0000000000000002]
+    assert ctx.selftest_division(divisors, 1 << 22) == 0
