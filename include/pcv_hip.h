@@ -92,7 +92,8 @@ typedef struct pcv_build_params {
 /* Compute the bounding box on the device first (== build_octree_from_file's find_bounding_box pass,
  * generation.rs:256-287); bbox_min/max are then outputs. */
 #define PCV_BUILD_COMPUTE_BBOX 1u
-/* Keep the finished node blobs in device memory only until asked for (default). */
+/* Always compute and sort full-depth path keys (disables the sampled depth speculation; same result, slower). */
+#define PCV_BUILD_NO_SPECULATION 2u
 
 /* ---- the build ------------------------------------------------------------------------------ */
 /* Replaces build_octree (generation.rs:289-403) up to, but not including, the file writes:
@@ -140,6 +141,9 @@ void pcv_octree_free(pcv_octree* t);
 #define PCV_STAGE_TOTAL 8
 #define PCV_NUM_STAGES 9
 int pcv_octree_stage_ms(const pcv_octree* t, float* ms, int cap);
+/* How the last build sized its path keys: number of digit levels sorted and the number of attempts
+ * (2 = the sampled depth estimate was too shallow and the build was redone at full depth). */
+void pcv_octree_build_info(const pcv_octree* t, int* key_levels, int* attempts);
 
 /* ---- stage-level entry points (unit parity against the oracle) ------------------------------ */
 /* K1: find_bounding_box (generation.rs:256-270; Aabb::grow aabb.rs:41-44). n == 0 -> Aabb::zero(). */

@@ -372,6 +372,11 @@ extern "C" int pcv_octree_stage_ms(const pcv_octree* t, float* ms, int cap) {
   for (int i = 0; i < n; ++i) ms[i] = t->stage_ms[i];
   return n;
 }
+extern "C" void pcv_octree_build_info(const pcv_octree* t, int* key_levels, int* attempts) {
+  if (!t) return;
+  if (key_levels) *key_levels = t->key_levels;
+  if (attempts) *attempts = t->key_attempts;
+}
 extern "C" int pcv_octree_device_blob(const pcv_octree* t, int which, const void** dptr, uint64_t* len) {
   if (!t || !dptr || !len || which < 0 || which > 2) return PCV_E_INVALID;
   *dptr = which == 0 ? t->d_xyz : (which == 1 ? t->d_rgb : t->d_int);
@@ -480,45 +485,97 @@ extern "C" int pcv_build_octree(pcv_ctx* ctx, const pcv_build_params* params, co
   int max_level = 0;
   pcv_make_levels(bmin, bmax, params->resolution, 64, &lv, &max_level, nullptr, nullptr);
 
-  // ---- K2 keys, K3 sort ----
+  // ---- K2 keys, K3 sort, K4 node split — with depth speculation ----
+  // The keys only have to cover the levels the tree really uses. A strided sample (2^18 points) gets full-depth
+  // keys, is sorted, and depth_probe measures the deepest prefix still shared by sample keys `gap` apart
+  // (gap = 0.6 x the sample-scaled node capacity, i.e. biased towards deeper). The main pass then computes and
+  // sorts only that many levels (+1), with 32-bit keys when 10 levels suffice. K4 verifies: if any node at the last
+  // key level would still have to be split, everything is redone at full depth — speculation can cost time, never
+  // correctness.
   uint64_t *keys_a, *keys_b;
   void* sort_scratch;
   if ((rc = sc.get(&keys_a, n)) || (rc = sc.get(&keys_b, n))) return rc;
   if ((rc = ctx->dev_alloc(&sort_scratch, pcv_sort_scratch_bytes(n)))) return rc;
   sc.ptrs.push_back(sort_scratch);
-  pcv_launch_chain_keys(ctx, lv, n, d.x, d.y, d.z, keys_a);
-  PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[2], st));
-  bool in_a = true;
-  if ((rc = pcv_radix_sort_u64(ctx, keys_a, keys_b, n, 3 * (PCV_MAX_KEY_LEVELS - lv.nlevels), 3 * PCV_MAX_KEY_LEVELS,
-                               nullptr, sort_scratch, &in_a)))
-    return rc;
-  const uint64_t* sorted_keys = in_a ? keys_a : keys_b;
-  PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[3], st));
+  const int full_levels = lv.nlevels;
+  int spec_levels = full_levels;
+  if (n >= (1ull << 22) && full_levels > 4 && !(params->flags & PCV_BUILD_NO_SPECULATION)) {
+    const uint32_t ns = 1u << 18;
+    const uint64_t stride = n / ns;
+    uint32_t* d_max;
+    if ((rc = sc.get(&d_max, 64))) return rc;
+    PCV_HIP_CHECK(ctx, hipMemsetAsync(d_max, 0, 4, st));
+    pcv_launch_chain_keys(ctx, lv, ns, stride, d.x, d.y, d.z, keys_a, false);
+    bool s_in_a = true;
+    if ((rc = pcv_radix_sort_u64(ctx, keys_a, keys_b, ns, 3 * (PCV_MAX_KEY_LEVELS - full_levels), 3 * PCV_MAX_KEY_LEVELS,
+                                 nullptr, sort_scratch, &s_in_a)))
+      return rc;
+    double gapd = 0.6 * (double)max_points * (double)ns / (double)n;
+    uint32_t gap = gapd < 1.0 ? 1u : (uint32_t)gapd;
+    pcv_launch_depth_probe(ctx, s_in_a ? keys_a : keys_b, ns, gap, d_max);
+    uint32_t shared = 0;
+    PCV_HIP_CHECK(ctx, hipMemcpyAsync(&shared, d_max, 4, hipMemcpyDeviceToHost, st));
+    PCV_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    // a level-`shared` node is (probably) split -> nodes of level shared + 1 exist -> that many digits are needed
+    int want = (int)shared + 1;
+    if (want < 3) want = 3;
+    if (want < full_levels) spec_levels = want;
+  }
 
-  // ---- K4 node split ----
-  // every open node holds > max_points points and open nodes of one level are disjoint
-  uint64_t cap64 = 8ull * (uint64_t)(lv.nlevels + 1) * (n / max_points + 1) + 64;
-  if (cap64 > (1ull << 26)) cap64 = 1ull << 26;
-  const uint32_t cap = (uint32_t)cap64;
   PcvNodeTableDev nt;
-  nt.capacity = cap;
-  if ((rc = sc.get(&nt.prefix, cap)) || (rc = sc.get(&nt.lo, cap)) || (rc = sc.get(&nt.hi, cap)) ||
-      (rc = sc.get(&nt.parent, cap)) || (rc = sc.get(&nt.first_child, cap)) || (rc = sc.get(&nt.level, cap)) ||
-      (rc = sc.get(&nt.child_mask, cap)) || (rc = sc.get(&nt.open, cap)) || (rc = sc.get(&nt.bounds, (size_t)cap * 9)) ||
-      (rc = sc.get(&nt.counters, 64)))
-    return rc;
-  pcv_launch_node_split(ctx, nt, sorted_keys, (uint32_t)n, lv, params->resolution, max_points);
-  PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[4], st));
-
-  // ---- node table to host, finalize ----
   uint32_t counters[64];
-  PCV_HIP_CHECK(ctx, hipMemcpyAsync(counters, nt.counters, sizeof(counters), hipMemcpyDeviceToHost, st));
-  PCV_HIP_CHECK(ctx, hipStreamSynchronize(st));
-  if (counters[1] & 2u) return ctx->fail(PCV_E_OOM, "node table capacity exceeded");
-  if (counters[1] & 1u)
-    return ctx->fail(PCV_E_DEPTH, "a node at level " + std::to_string(lv.nlevels) +
-                                      " still holds more than max_points_per_node points and is larger than the "
-                                      "resolution; PCV_MAX_KEY_LEVELS exhausted");
+  bool keys32 = false;
+  int attempts = 0;
+  for (;;) {
+    ++attempts;
+    lv.nlevels = spec_levels;
+    keys32 = spec_levels <= 10;
+    pcv_launch_chain_keys(ctx, lv, n, 1, d.x, d.y, d.z, keys_a, keys32);
+    PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[2], st));
+    bool in_a = true;
+    if (keys32)
+      rc = pcv_radix_sort_u32(ctx, (uint32_t*)keys_a, (uint32_t*)keys_b, n, 3 * (10 - spec_levels), 30, nullptr,
+                              sort_scratch, &in_a);
+    else
+      rc = pcv_radix_sort_u64(ctx, keys_a, keys_b, n, 3 * (PCV_MAX_KEY_LEVELS - spec_levels), 3 * PCV_MAX_KEY_LEVELS,
+                              nullptr, sort_scratch, &in_a);
+    if (rc) return rc;
+    const void* sorted_keys = in_a ? (const void*)keys_a : (const void*)keys_b;
+    PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[3], st));
+
+    // K4: every open node holds > max_points points and open nodes of one level are disjoint
+    if (attempts == 1) {
+      uint64_t cap64 = 8ull * (uint64_t)(full_levels + 1) * (n / max_points + 1) + 64;
+      if (cap64 > (1ull << 26)) cap64 = 1ull << 26;
+      const uint32_t cap = (uint32_t)cap64;
+      nt.capacity = cap;
+      if ((rc = sc.get(&nt.prefix, cap)) || (rc = sc.get(&nt.lo, cap)) || (rc = sc.get(&nt.hi, cap)) ||
+          (rc = sc.get(&nt.parent, cap)) || (rc = sc.get(&nt.first_child, cap)) || (rc = sc.get(&nt.level, cap)) ||
+          (rc = sc.get(&nt.child_mask, cap)) || (rc = sc.get(&nt.open, cap)) ||
+          (rc = sc.get(&nt.bounds, (size_t)cap * 9)) || (rc = sc.get(&nt.counters, 64)))
+        return rc;
+    }
+    pcv_launch_node_split(ctx, nt, sorted_keys, keys32, (uint32_t)n, lv, params->resolution, max_points);
+    PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[4], st));
+
+    // ---- node table to host ----
+    PCV_HIP_CHECK(ctx, hipMemcpyAsync(counters, nt.counters, sizeof(counters), hipMemcpyDeviceToHost, st));
+    PCV_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    if (counters[1] & 2u) return ctx->fail(PCV_E_OOM, "node table capacity exceeded");
+    if (counters[1] & 1u) {
+      if (spec_levels < full_levels) {  // speculation too shallow: redo at full depth
+        spec_levels = full_levels;
+        continue;
+      }
+      return ctx->fail(PCV_E_DEPTH, "a node at level " + std::to_string(lv.nlevels) +
+                                        " still holds more than max_points_per_node points and is larger than the "
+                                        "resolution; PCV_MAX_KEY_LEVELS exhausted");
+    }
+    break;
+  }
+  t->key_levels = spec_levels;
+  t->key_attempts = attempts;
+  lv.nlevels = full_levels;  // K5/K6 index the level tables by node level; the walk stops at leaves anyway
   const uint32_t M = counters[0];
   // pinned staging: prefix(8) lo hi parent first_child (4 each) level mask open (1 each)
   const size_t host_bytes = (size_t)M * (8 + 4 * 4 + 3) + 64;
@@ -741,7 +798,7 @@ extern "C" int pcv_chain_keys(pcv_ctx* ctx, const pcv_build_params* params, cons
   if (points->n == 0) return PCV_OK;
   uint64_t* dk = keys;
   if (points->mem == PCV_MEM_HOST && (rc = sc.get(&dk, points->n))) return rc;
-  pcv_launch_chain_keys(ctx, lv, points->n, d.x, d.y, d.z, dk);
+  pcv_launch_chain_keys(ctx, lv, points->n, 1, d.x, d.y, d.z, dk, false);
   PCV_HIP_CHECK(ctx, hipGetLastError());
   if (points->mem == PCV_MEM_HOST)
     PCV_HIP_CHECK(ctx, hipMemcpyAsync(keys, dk, points->n * 8, hipMemcpyDeviceToHost, ctx->stream));

@@ -97,25 +97,41 @@ __global__ __launch_bounds__(256) void aabb_final_kernel(int nblocks, const doub
 }
 
 // K2: one point per lane; the level loop is wave-uniform (levels, edges and encodings are kernel
-// arguments in SGPRs), so the encoding switch is a scalar branch.
-__global__ __launch_bounds__(256) void chain_keys_kernel(PcvLevels lv, uint64_t n, const double* __restrict__ x,
-                                                          const double* __restrict__ y,
-                                                          const double* __restrict__ z,
-                                                          uint64_t* __restrict__ keys) {
-  uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+// arguments in SGPRs), so the encoding switch is a scalar branch. `stride` > 1 evaluates a strided sample of the
+// input (depth probe); KeyT = u32 stores the top 10 levels only (key >> 33).
+template <typename KeyT>
+__global__ __launch_bounds__(256) void chain_keys_kernel(PcvLevels lv, uint64_t n, uint64_t stride,
+                                                          const double* __restrict__ x, const double* __restrict__ y,
+                                                          const double* __restrict__ z, KeyT* __restrict__ keys) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  double px = x[i], py = y[i], pz = z[i];
+  const uint64_t src = i * stride;
+  double px = x[src], py = y[src], pz = z[src];
   double mx = lv.root_min[0], my = lv.root_min[1], mz = lv.root_min[2];
-  uint64_t key = 0, code;
+  uint64_t key = 0, cx, cy, cz;
   for (int k = 1; k <= lv.nlevels; ++k) {
-    const double ep = lv.edge[k - 1], ec = lv.edge[k], ic = lv.inv_edge[k];
-    const uint32_t enc = lv.enc[k];
-    uint32_t d = pcv_chain_coord(enc, ep, ec, ic, px, mx, code) << 2;
-    d |= pcv_chain_coord(enc, ep, ec, ic, py, my, code) << 1;
-    d |= pcv_chain_coord(enc, ep, ec, ic, pz, mz, code);
+    const uint32_t d = pcv_chain_level(lv.enc[k], lv.edge[k - 1], lv.edge[k], lv.inv_edge[k], px, py, pz, mx, my, mz, cx, cy, cz);
     key |= (uint64_t)d << (3 * (PCV_MAX_KEY_LEVELS - k));
   }
-  keys[i] = key;
+  keys[i] = sizeof(KeyT) == 8 ? (KeyT)key : (KeyT)(key >> 33);
+}
+
+// Depth probe on a sorted sample: if two keys `gap` positions apart share their first l digits, the level-l node
+// holding them has more than `gap` sample points. The maximum such l over the sample bounds the deepest node that
+// the full input will have to split.
+__global__ __launch_bounds__(256) void depth_probe_kernel(const uint64_t* __restrict__ sorted, uint32_t n, uint32_t gap,
+                                                           uint32_t* __restrict__ max_shared_levels) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  uint32_t l = 0;
+  if (i + gap < n) {
+    const uint64_t diff = sorted[i] ^ sorted[i + gap];
+    // keys use bits 62..0; clz counts from bit 63
+    const uint32_t lead = diff ? (uint32_t)__clzll((long long)diff) : 64u;
+    l = lead >= 1 ? (lead - 1) / 3 : 0;
+    if (l > PCV_MAX_KEY_LEVELS) l = PCV_MAX_KEY_LEVELS;
+  }
+  for (int o = 32; o > 0; o >>= 1) l = max(l, (uint32_t)__shfl_xor((int)l, o, 64));
+  if ((threadIdx.x & 63) == 0 && l) atomicMax(max_shared_levels, l);
 }
 
 // Division self-test: pcv_div_code against IEEE division for every code and both divisors (exhaustive), and
@@ -205,10 +221,20 @@ int pcv_launch_aabb(pcv_ctx* ctx, uint64_t n, const double* x, const double* y, 
   return blocks;
 }
 
-void pcv_launch_chain_keys(pcv_ctx* ctx, const PcvLevels& lv, uint64_t n, const double* x, const double* y,
-                           const double* z, uint64_t* keys) {
+void pcv_launch_chain_keys(pcv_ctx* ctx, const PcvLevels& lv, uint64_t n, uint64_t stride, const double* x,
+                           const double* y, const double* z, void* keys, bool keys32) {
   if (n == 0) return;
   uint64_t blocks = (n + 255) / 256;
   PcvProf prof(ctx, PCV_K_CHAIN_KEYS);
-  hipLaunchKernelGGL(chain_keys_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, lv, n, x, y, z, keys);
+  if (keys32)
+    hipLaunchKernelGGL(chain_keys_kernel<uint32_t>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, lv, n, stride, x, y,
+                       z, (uint32_t*)keys);
+  else
+    hipLaunchKernelGGL(chain_keys_kernel<uint64_t>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, lv, n, stride, x, y,
+                       z, (uint64_t*)keys);
+}
+
+void pcv_launch_depth_probe(pcv_ctx* ctx, const uint64_t* sorted, uint32_t n, uint32_t gap, uint32_t* out) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(depth_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, sorted, n, gap, out);
 }

@@ -31,7 +31,13 @@ __device__ __forceinline__ double pcv_div_const(double x, double e, double y) {
   double q = __fma_rn(r1, y, q1);
   const double ax = fabs(x);
   // y == 0 marks a divisor outside [2^-100, 2^100] (host side), where the residuals could leave the normal range
-  if (!(ax >= 0x1p-900 && ax <= 0x1p+900) || y == 0.0) q = x / e;
+  if (__builtin_expect(!(ax >= 0x1p-900 && ax <= 0x1p+900) || y == 0.0, 0)) {
+    // The empty volatile asm pins the IEEE division inside this (almost never taken) branch: without it the
+    // compiler if-converts the branch and executes the full division expansion for every lane.
+    double xs = x;
+    asm volatile("" : "+v"(xs));
+    q = xs / e;
+  }
   return q;
 }
 // v / maxval for an integer code v in [0, 65535]: same scheme, no range guard needed (verified exhaustively).
@@ -77,15 +83,38 @@ __device__ __forceinline__ double pcv_decode_coord(uint32_t enc, uint64_t code, 
   }
 }
 
-// One level of the chain for one coordinate: returns the octant bit, moves `mn` to the child cube,
-// replaces `p` by its encode->decode image in the child cube and reports the code.
-__device__ __forceinline__ uint32_t pcv_chain_coord(uint32_t enc, double e_parent, double e_child, double inv_e_child,
-                                                    double& p, double& mn, uint64_t& code) {
-  double mx = mn + e_parent;
-  double c = (mn + mx) / 2.0;
-  uint32_t bit = p > c ? 1u : 0u;
+// One level of the chain for one coordinate with the encoding known at compile time: returns the octant bit,
+// moves `mn` to the child cube, replaces `p` by its encode->decode image in the child cube and reports the code.
+template <int ENC>
+__device__ __forceinline__ uint32_t pcv_chain_coord_t(double e_parent, double e_child, double inv_e_child, double& p,
+                                                      double& mn, uint64_t& code) {
+  const double mx = mn + e_parent;
+  const double c = (mn + mx) / 2.0;
+  const uint32_t bit = p > c ? 1u : 0u;
   mn = mn + (bit ? e_child : 0.0);  // `bit as f64 * edge` is exactly e or +0.0
-  code = pcv_encode_coord(enc, p, mn, e_child, inv_e_child);
-  p = pcv_decode_coord(enc, code, mn, e_child);
+  code = pcv_encode_coord(ENC, p, mn, e_child, inv_e_child);
+  p = pcv_decode_coord(ENC, code, mn, e_child);
   return bit;
+}
+
+// One level for all three coordinates as a single straight-line block (the encoding switch is taken once per
+// level and is wave-uniform, so the three dependency chains interleave). Returns the octant digit.
+template <int ENC>
+__device__ __forceinline__ uint32_t pcv_chain_level_t(double ep, double ec, double ic, double& px, double& py, double& pz,
+                                                      double& mx, double& my, double& mz, uint64_t& cx, uint64_t& cy,
+                                                      uint64_t& cz) {
+  const uint32_t bx = pcv_chain_coord_t<ENC>(ep, ec, ic, px, mx, cx);
+  const uint32_t by = pcv_chain_coord_t<ENC>(ep, ec, ic, py, my, cy);
+  const uint32_t bz = pcv_chain_coord_t<ENC>(ep, ec, ic, pz, mz, cz);
+  return (bx << 2) | (by << 1) | bz;
+}
+__device__ __forceinline__ uint32_t pcv_chain_level(uint32_t enc, double ep, double ec, double ic, double& px, double& py,
+                                                    double& pz, double& mx, double& my, double& mz, uint64_t& cx,
+                                                    uint64_t& cy, uint64_t& cz) {
+  switch (enc) {
+    case PCV_ENC_UINT8: return pcv_chain_level_t<PCV_ENC_UINT8>(ep, ec, ic, px, py, pz, mx, my, mz, cx, cy, cz);
+    case PCV_ENC_UINT16: return pcv_chain_level_t<PCV_ENC_UINT16>(ep, ec, ic, px, py, pz, mx, my, mz, cx, cy, cz);
+    case PCV_ENC_FLOAT32: return pcv_chain_level_t<PCV_ENC_FLOAT32>(ep, ec, ic, px, py, pz, mx, my, mz, cx, cy, cz);
+    default: return pcv_chain_level_t<PCV_ENC_FLOAT64>(ep, ec, ic, px, py, pz, mx, my, mz, cx, cy, cz);
+  }
 }

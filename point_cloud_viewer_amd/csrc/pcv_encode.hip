@@ -32,11 +32,7 @@ __global__ __launch_bounds__(256) void leaf_encode_kernel(
   int L = 0;
   do {
     ++L;
-    const double ep = lv.edge[L - 1], ec = lv.edge[L], ic = lv.inv_edge[L];
-    const uint32_t enc = lv.enc[L];
-    uint32_t d = pcv_chain_coord(enc, ep, ec, ic, px, mx, ccx) << 2;
-    d |= pcv_chain_coord(enc, ep, ec, ic, py, my, ccy) << 1;
-    d |= pcv_chain_coord(enc, ep, ec, ic, pz, mz, ccz);
+    const uint32_t d = pcv_chain_level(lv.enc[L], lv.edge[L - 1], lv.edge[L], lv.inv_edge[L], px, py, pz, mx, my, mz, ccx, ccy, ccz);
     const uint32_t mask = (uint32_t)(rec >> 32) & 0xffu;
     const uint32_t idx = (uint32_t)rec + __popc(mask & ((1u << d) - 1u));
     rec = walk[idx];

@@ -139,8 +139,10 @@ struct PcvScratch {
 // pcv_chain.hip
 int pcv_launch_aabb(pcv_ctx* ctx, uint64_t n, const double* x, const double* y, const double* z, double* partial,
                     double* out6 /* device: min xyz, max xyz */);
-void pcv_launch_chain_keys(pcv_ctx* ctx, const PcvLevels& lv, uint64_t n, const double* x, const double* y,
-                           const double* z, uint64_t* keys);
+// keys32: store the first 10 levels only as u32 (key >> 33); stride > 1: strided sample of the input.
+void pcv_launch_chain_keys(pcv_ctx* ctx, const PcvLevels& lv, uint64_t n, uint64_t stride, const double* x,
+                           const double* y, const double* z, void* keys, bool keys32);
+void pcv_launch_depth_probe(pcv_ctx* ctx, const uint64_t* sorted, uint32_t n, uint32_t gap, uint32_t* out);
 
 // pcv_sort.hip — stable LSD radix sort, 8-bit digits, reduce-then-scan with LDS histograms.
 struct PcvSortPayload {
@@ -171,7 +173,7 @@ struct PcvNodeTableDev {
   uint32_t* bounds;      // scratch: 9 bounds per node of the level being expanded
   uint32_t* counters;    // [0] node_count, [1] error flag, [2..] level_start[k] (k = 0..PCV_MAX_KEY_LEVELS+1)
 };
-void pcv_launch_node_split(pcv_ctx* ctx, const PcvNodeTableDev& t, const uint64_t* sorted_keys, uint32_t n,
+void pcv_launch_node_split(pcv_ctx* ctx, const PcvNodeTableDev& t, const void* sorted_keys, bool keys32, uint32_t n,
                            const PcvLevels& lv, double resolution, uint32_t max_points_per_node);
 
 // pcv_encode.hip — leaf lookup + leaf-level encode (input order), promotion + final encode (sorted order).
@@ -216,6 +218,8 @@ struct pcv_octree {
   std::vector<uint8_t> h_xyz, h_rgb, h_int;
   bool host_valid = false;
   float stage_ms[PCV_NUM_STAGES] = {};
+  int key_levels = 0;    // digit levels the key sort covered (depth speculation)
+  int key_attempts = 0;  // 1 = speculation held (or was off), 2 = redone at full depth
   PcvOctreeQuery* query = nullptr;
   // octrees opened from a directory: node files are read on demand
   std::string directory;

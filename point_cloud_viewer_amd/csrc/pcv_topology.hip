@@ -16,15 +16,16 @@ namespace {
 
 enum { CNT_NODES = 0, CNT_ERROR = 1, CNT_LEVEL_START = 2 };
 
-__device__ __forceinline__ uint32_t wave_lower_bound(const uint64_t* __restrict__ keys, uint32_t lo, uint32_t hi,
-                                                     uint64_t target, int lane) {
+template <typename KeyT>
+__device__ __forceinline__ uint32_t wave_lower_bound(const KeyT* __restrict__ keys, uint32_t lo, uint32_t hi,
+                                                     KeyT target, int lane) {
   // invariant: every key before lo is < target, every key at or after hi is >= target
   while (hi - lo > 64) {
     const uint32_t span = hi - lo;
     const uint32_t step = (span + 63) / 64;
     uint64_t idx = (uint64_t)lo + (uint64_t)(lane + 1) * step - 1;
     const bool in = idx < hi;
-    const uint64_t v = keys[in ? idx : (uint64_t)hi - 1];
+    const KeyT v = keys[in ? idx : (uint64_t)hi - 1];
     const uint64_t m = __ballot(in && v < target);
     const uint32_t cnt = __popcll(m);  // probes are monotone: the mask is a prefix
     const uint64_t nlo = (uint64_t)lo + (uint64_t)cnt * step;
@@ -33,7 +34,7 @@ __device__ __forceinline__ uint32_t wave_lower_bound(const uint64_t* __restrict_
     hi = (uint32_t)(nhi < hi ? nhi : hi);
   }
   const bool in = lo + (uint32_t)lane < hi;
-  const uint64_t v = in ? keys[lo + lane] : 0;
+  const KeyT v = in ? keys[lo + lane] : (KeyT)0;
   const uint64_t m = __ballot(in && v < target);
   return lo + (uint32_t)__popcll(m);
 }
@@ -56,8 +57,8 @@ __global__ __launch_bounds__(256) void init_root_kernel(PcvNodeTableDev t, uint3
 }
 
 // (A) child boundaries of every open node of level k-1.
-__global__ __launch_bounds__(256) void split_search_kernel(PcvNodeTableDev t, const uint64_t* __restrict__ keys,
-                                                            int k) {
+template <typename KeyT>
+__global__ __launch_bounds__(256) void split_search_kernel(PcvNodeTableDev t, const KeyT* __restrict__ keys, int k) {
   const uint32_t begin = t.counters[CNT_LEVEL_START + k - 1];
   const uint32_t end = t.counters[CNT_LEVEL_START + k];
   const int lane = threadIdx.x & 63;
@@ -70,8 +71,9 @@ __global__ __launch_bounds__(256) void split_search_kernel(PcvNodeTableDev t, co
     const uint32_t c = it % 7u + 1u;
     if (!t.open[node]) continue;  // wave-uniform
     const uint32_t lo = t.lo[node], hi = t.hi[node];
-    const uint64_t target = t.prefix[node] | ((uint64_t)c << shift);
-    const uint32_t b = wave_lower_bound(keys, lo, hi, target, lane);
+    const uint64_t target64 = t.prefix[node] | ((uint64_t)c << shift);
+    const KeyT target = sizeof(KeyT) == 8 ? (KeyT)target64 : (KeyT)(target64 >> 33);  // u32 keys hold key >> 33
+    const uint32_t b = wave_lower_bound<KeyT>(keys, lo, hi, target, lane);
     if (lane == 0) {
       uint32_t* bd = t.bounds + (uint64_t)(node - begin) * 9u;
       bd[c] = b;
@@ -172,14 +174,17 @@ __global__ __launch_bounds__(1024) void split_assign_kernel(PcvNodeTableDev t, P
 
 }  // namespace
 
-void pcv_launch_node_split(pcv_ctx* ctx, const PcvNodeTableDev& t, const uint64_t* sorted_keys, uint32_t n,
+void pcv_launch_node_split(pcv_ctx* ctx, const PcvNodeTableDev& t, const void* sorted_keys, bool keys32, uint32_t n,
                            const PcvLevels& lv, double resolution, uint32_t max_points_per_node) {
   hipStream_t s = ctx->stream;
   hipLaunchKernelGGL(init_root_kernel, dim3(1), dim3(256), 0, s, t, n);
   for (int k = 1; k <= lv.nlevels; ++k) {
     {
       PcvProf prof(ctx, PCV_K_SPLIT_SEARCH);
-      hipLaunchKernelGGL(split_search_kernel, dim3(512), dim3(256), 0, s, t, sorted_keys, k);
+      if (keys32)
+        hipLaunchKernelGGL(split_search_kernel<uint32_t>, dim3(512), dim3(256), 0, s, t, (const uint32_t*)sorted_keys, k);
+      else
+        hipLaunchKernelGGL(split_search_kernel<uint64_t>, dim3(512), dim3(256), 0, s, t, (const uint64_t*)sorted_keys, k);
     }
     {
       PcvProf prof(ctx, PCV_K_SPLIT_ASSIGN);

@@ -147,14 +147,16 @@ class Context:
         return pr
 
     # ---- the build -------------------------------------------------------------------------------
-    def build(self, resolution, bounding_box, x, y, z, color, intensity=None, max_points_per_node=0):
+    def build(self, resolution, bounding_box, x, y, z, color, intensity=None, max_points_per_node=0,
+              speculate_depth=True):
         """build_octree up to (not including) the file writes. bounding_box=None computes it on the
         device (== build_octree_from_file's find_bounding_box pass)."""
         p, keep = self._points(x, y, z, color, intensity)
+        flags = 0 if speculate_depth else L.BUILD_NO_SPECULATION
         if bounding_box is None:
-            pr = self._params(resolution, None, None, max_points_per_node, L.BUILD_COMPUTE_BBOX)
+            pr = self._params(resolution, None, None, max_points_per_node, flags | L.BUILD_COMPUTE_BBOX)
         else:
-            pr = self._params(resolution, bounding_box.min, bounding_box.max, max_points_per_node, 0)
+            pr = self._params(resolution, bounding_box.min, bounding_box.max, max_points_per_node, flags)
         h = C.c_void_p()
         self._check(self.lib.pcv_build_octree(self.handle, C.byref(pr), C.byref(p), C.byref(h)))
         del keep
@@ -337,6 +339,11 @@ class OctreeResult:
         ms = (C.c_float * L.NUM_STAGES)()
         n = self.lib.pcv_octree_stage_ms(self.handle, ms, L.NUM_STAGES)
         return {L.STAGE_NAMES[i]: ms[i] for i in range(n)}
+
+    def build_info(self):
+        lv, at = C.c_int(), C.c_int()
+        self.lib.pcv_octree_build_info(self.handle, C.byref(lv), C.byref(at))
+        return dict(key_levels=lv.value, attempts=at.value)
 
     def write_dir(self, directory):
         self.ctx._check(self.lib.pcv_octree_write_dir(self.handle, str(directory).encode()))

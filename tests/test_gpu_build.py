@@ -168,3 +168,43 @@ def test_large_build_properties(ctx):
     assert seen.min() == 1 and seen.max() == 1
     want = O.build_closed(0.001, bmin, bmax, x, y, z, rgb, threads=8)
     assert_same(got, want)
+
+
+def test_depth_speculation_holds_and_matches_full_depth(ctx):
+    n = 4_500_000
+    x, y, z, rgb, bmin, bmax = synthetic.gaussian_clusters(n, seed=31, num_clusters=16, extent=600.0,
+                                                           sigma_range=(0.3, 10.0))
+    a = ctx.build(0.001, pcv.Aabb(bmin, bmax), x, y, z, rgb)
+    b = ctx.build(0.001, pcv.Aabb(bmin, bmax), x, y, z, rgb, speculate_depth=False)
+    ia, ib = a.build_info(), b.build_info()
+    assert ia["attempts"] == 1 and ib["attempts"] == 1
+    assert ia["key_levels"] < ib["key_levels"]  # fewer digit levels computed and sorted
+    da, db = a.to_dict(), b.to_dict()
+    assert set(da) == set(db)
+    for k in da:
+        assert da[k]["xyz"] == db[k]["xyz"] and da[k]["rgb"] == db[k]["rgb"] and da[k]["num_points"] == db[k]["num_points"]
+    deepest = max(v["level"] for v in da.values())
+    assert ia["key_levels"] >= deepest
+    assert_same(da, O.build_closed(0.001, bmin, bmax, x, y, z, rgb, threads=8))
+
+
+def test_depth_speculation_failure_falls_back_to_full_depth(ctx):
+    """Adversarial input order: the strided depth probe only ever sees a shallow uniform cloud, the dense cluster
+    hides between the sampled indices -> the estimate is too shallow, K4 notices, the build is redone."""
+    n = 1 << 22
+    stride = n >> 18
+    rng = np.random.default_rng(7)
+    x = rng.uniform(0.0, 500.0, n)
+    y = rng.uniform(0.0, 500.0, n)
+    z = rng.uniform(0.0, 500.0, n)
+    hidden = (np.arange(n) % stride) != 0
+    m = int(hidden.sum())
+    x[hidden] = 250.0 + rng.normal(0.0, 0.01, m)
+    y[hidden] = 125.0 + rng.normal(0.0, 0.01, m)
+    z[hidden] = 333.0 + rng.normal(0.0, 0.01, m)
+    rgb = synthetic.index_colors(n)
+    bmin, bmax = np.zeros(3), np.full(3, 500.0)
+    t = ctx.build(0.001, pcv.Aabb(bmin, bmax), x, y, z, rgb)
+    info = t.build_info()
+    assert info["attempts"] == 2, info
+    assert_same(t.to_dict(), O.build_closed(0.001, bmin, bmax, x, y, z, rgb, threads=8))
