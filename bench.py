@@ -29,8 +29,9 @@ ALGO_BYTES = {
     "upsweep_kernel<u64>": 8.0,     # read 8 B key
     "aabb_partial_kernel": 24.0,    # read xyz f64
     "chain_keys_kernel": 32.0,      # read xyz f64 + write 8 B key
-    "leaf_encode_kernel": 24.0 + 3.0 + 20.0,  # read xyz + rgb, write rank + 3 codes + rgba
-    "downsweep_kernel<u32>": 2 * 4.0 + 2 * 16.0,  # key r/w + 4 payload words r/w
+    "leaf_encode_kernel": 24.0 + 3.0 + 20.0,  # read xyz + rgb, write rank + 16-byte payload
+    "downsweep_kernel<u32>": 8.0,   # keys only: read 4 B + write 4 B
+    "downsweep_rec_kernel": 2 * 4.0 + 2 * 16.0,  # rank r/w + 16-byte payload r/w
     "upsweep_kernel<u32>": 4.0,
     "promote_encode_kernel": 20.0 + 9.0,  # read record, write ~6 B xyz + 3 B rgb
 }
@@ -103,7 +104,7 @@ def main():
 
         def step():
             t = ctx.build(args.resolution, bbox, x, y, z, rgb)
-            info["nodes"], info["stages"] = t.num_nodes, t.stage_ms()
+            info["nodes"], info["stages"], info["build"] = t.num_nodes, t.stage_ms(), t.build_info()
             t.free()
     else:
         from point_cloud_viewer_amd import distributed as pdist
@@ -154,13 +155,18 @@ def main():
                     "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
                     "launches": launches, "algorithmic_bytes_per_launch": ALGO_BYTES.get(dom, 0.0) * n}
         # encode+sort figure the BASELINE metric names: chain keys + key sort passes
-        es_ms = sum(timed.get(k, (0, 0.0))[1] for k in ("chain_keys_kernel", "upsweep_kernel<u64>", "scan_kernel",
-                                                       "downsweep_kernel<u64>")) / args.steps
-        sort_passes = timed.get("downsweep_kernel<u64>", (0, 0))[0] / args.steps
-        es_bytes = n * (32.0 + sort_passes * 24.0)
-        encode_sort = {"GB/s": round(es_bytes / (es_ms * 1e-3) / 1e9, 1) if es_ms else None,
-                       "ms": round(es_ms, 3), "sort_passes": sort_passes,
-                       "algorithmic_bytes_per_point": 32.0 + sort_passes * 24.0}
+        # (stage times from the library's stage events: chain keys incl. the depth probe + the key sort)
+        st = info.get("stages") or {}
+        es_ms = st.get("chain_keys", 0.0) + st.get("sort_keys", 0.0)
+        p64 = timed.get("downsweep_kernel<u64>", (0, 0))[0] / args.steps
+        rec_passes = timed.get("downsweep_rec_kernel", (0, 0))[0] / args.steps
+        p32 = timed.get("downsweep_kernel<u32>", (0, 0))[0] / args.steps
+        key_bytes = 8.0 if p64 else 4.0
+        passes = p64 if p64 else p32
+        es_bytes_pp = 24.0 + key_bytes + passes * 3 * key_bytes
+        encode_sort = {"GB/s": round(n * es_bytes_pp / (es_ms * 1e-3) / 1e9, 1) if es_ms else None,
+                       "ms": round(es_ms, 3), "key_bits": int(key_bytes * 8), "sort_passes": passes,
+                       "record_sort_passes": rec_passes, "algorithmic_bytes_per_point": es_bytes_pp}
     else:
         encode_sort = None
 
@@ -197,7 +203,7 @@ def main():
                                    "sigma 1-20 m), f64 SoA xyz + u8 rgb, resolution 1 mm, full build + LOD promotion",
                        "points_per_gpu": n, "resolution": args.resolution, "nodes": info.get("nodes"),
                        "parallelism": "1 GPU" if world == 1 else f"root-octant sharding over {world} GPUs, one all-to-all"},
-            "roofline": roofline, "encode_sort": encode_sort, "cpu_baseline": cpu,
+            "roofline": roofline, "encode_sort": encode_sort, "cpu_baseline": cpu, "build_info": info.get("build"),
             "stage_ms": {k: round(v, 3) for k, v in (info.get("stages") or {}).items()},
             "kernel_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in kstats.items() if v[0] > 0},
         }

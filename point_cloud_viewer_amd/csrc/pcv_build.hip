@@ -102,8 +102,9 @@ void pcv_ctx::prof_resolve() {
 static const char* kKernelNames[PCV_K_COUNT] = {
     "aabb_partial_kernel", "chain_keys_kernel",  "upsweep_kernel<u64>",   "scan_kernel",
     "downsweep_kernel<u64>", "split_search_kernel", "split_assign_kernel", "leaf_encode_kernel",
-    "upsweep_kernel<u32>", "downsweep_kernel<u32>", "promote_encode_kernel", "cull_nodes_kernel",
+    "upsweep_kernel<u32>", "downsweep_kernel<u32>", "promote_encode_kernel", "downsweep_rec_kernel", "cull_nodes_kernel",
     "visible_nodes_kernel", "nodes_in_location_kernel", "cull_points_kernel", "transform_points_kernel"};
+static_assert(sizeof(kKernelNames) / sizeof(kKernelNames[0]) == PCV_K_COUNT, "kernel name table out of sync");
 
 extern "C" int pcv_ctx_set_profiling(pcv_ctx* ctx, int enabled) {
   if (!ctx) return PCV_E_INVALID;
@@ -706,38 +707,40 @@ extern "C" int pcv_build_octree(pcv_ctx* ctx, const pcv_build_params* params, co
   PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[5], st));
 
   // ---- K5 leaf encode (input order) ----
-  // the key buffers are dead now: reuse them for the records where they fit
-  const int nwords = 4 + (t->has_intensity ? 1 : 0) + (wide ? 3 : 0);
-  uint32_t *rank_a, *rank_b;
-  uint32_t* rec_a[8] = {};
-  uint32_t* rec_b[8] = {};
-  rank_a = (uint32_t*)keys_a;           // n * 4 bytes
-  rec_a[0] = (uint32_t*)keys_a + n;     // second half of keys_a
-  rank_b = (uint32_t*)keys_b;
-  rec_b[0] = (uint32_t*)keys_b + n;
-  for (int w = 1; w < nwords; ++w)
-    if ((rc = sc.get(&rec_a[w], n)) || (rc = sc.get(&rec_b[w], n))) return rc;
-  // word layout: 0 cx, 1 cy, 2 cz, 3 rgba, [4 intensity], [hi words]
-  const int w_int = t->has_intensity ? 4 : -1;
-  const int w_hi = wide ? (t->has_intensity ? 5 : 4) : -1;
-  pcv_launch_leaf_encode(ctx, lv, wt, n, nullptr, d.x, d.y, d.z, d.color, d.color_stride, d.intensity, rank_a, rec_a[0],
-                         rec_a[1], rec_a[2], wide ? rec_a[w_hi] : nullptr, wide ? rec_a[w_hi + 1] : nullptr,
-                         wide ? rec_a[w_hi + 2] : nullptr, rec_a[3], w_int >= 0 ? rec_a[w_int] : nullptr);
+  // record = rank (u32) + one 16-byte payload {code x, code y, code z, rgba}; optional 4-byte planes for the
+  // intensity and, when some leaf level is Float64-encoded, the high words of the codes.
+  // The key buffers are dead now: each (8n bytes) hosts one rank array; payloads get their own buffers.
+  uint32_t* rank_a = (uint32_t*)keys_a;
+  uint32_t* rank_b = (uint32_t*)keys_b;
+  uint4 *pay_a, *pay_b;
+  if ((rc = sc.get(&pay_a, n)) || (rc = sc.get(&pay_b, n))) return rc;
+  PcvSortPayload pl;
+  pl.vec_in = pay_a;
+  pl.vec_out = pay_b;
+  pl.nwords = (t->has_intensity ? 1 : 0) + (wide ? 3 : 0);
+  for (int w = 0; w < pl.nwords; ++w) {
+    if (w == 0) {  // first plane fits in the second half of the key buffers
+      pl.in[0] = (uint32_t*)keys_a + n;
+      pl.out[0] = (uint32_t*)keys_b + n;
+    } else if ((rc = sc.get(&pl.in[w], n)) || (rc = sc.get(&pl.out[w], n))) {
+      return rc;
+    }
+  }
+  const int w_int = t->has_intensity ? 0 : -1;
+  const int w_hi = wide ? (t->has_intensity ? 1 : 0) : -1;
+  pcv_launch_leaf_encode(ctx, lv, wt, n, d.x, d.y, d.z, d.color, d.color_stride, d.intensity, rank_a, pay_a,
+                         wide ? pl.in[w_hi] : nullptr, wide ? pl.in[w_hi + 1] : nullptr, wide ? pl.in[w_hi + 2] : nullptr,
+                         w_int >= 0 ? pl.in[w_int] : nullptr);
   PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[6], st));
 
   // ---- K3 stable record sort by leaf rank ----
   int rank_bits = 1;
   while ((1ull << rank_bits) < num_leaves) ++rank_bits;
-  PcvSortPayload pl;
-  pl.nwords = nwords;
-  for (int w = 0; w < nwords; ++w) {
-    pl.in[w] = rec_a[w];
-    pl.out[w] = rec_b[w];
-  }
   bool rec_in_a = true;
   if ((rc = pcv_radix_sort_u32(ctx, rank_a, rank_b, n, 0, rank_bits, &pl, sort_scratch, &rec_in_a))) return rc;
   uint32_t* s_rank = rec_in_a ? rank_a : rank_b;
-  uint32_t** s_rec = rec_in_a ? rec_a : rec_b;
+  const void* s_pay = rec_in_a ? (const void*)pay_a : (const void*)pay_b;
+  uint32_t** s_plane = rec_in_a ? pl.in : pl.out;
   PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[7], st));
 
   // ---- K6 promotion + final encode into node-contiguous blobs ----
@@ -750,9 +753,9 @@ extern "C" int pcv_build_octree(pcv_ctx* ctx, const pcv_build_params* params, co
     if ((rc = ctx->dev_alloc(&bi, t->int_bytes))) return rc;
     t->d_int = (uint8_t*)bi;
   }
-  pcv_launch_promote_encode(ctx, lv, pt, n, s_rank, s_rec[0], s_rec[1], s_rec[2], wide ? s_rec[w_hi] : nullptr,
-                            wide ? s_rec[w_hi + 1] : nullptr, wide ? s_rec[w_hi + 2] : nullptr, s_rec[3],
-                            w_int >= 0 ? s_rec[w_int] : nullptr, t->d_xyz, t->d_rgb, t->d_int);
+  pcv_launch_promote_encode(ctx, lv, pt, n, s_rank, s_pay, wide ? s_plane[w_hi] : nullptr,
+                            wide ? s_plane[w_hi + 1] : nullptr, wide ? s_plane[w_hi + 2] : nullptr,
+                            w_int >= 0 ? s_plane[w_int] : nullptr, t->d_xyz, t->d_rgb, t->d_int);
   PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[8], st));
   PCV_HIP_CHECK(ctx, hipGetLastError());
   PCV_HIP_CHECK(ctx, hipStreamSynchronize(st));

@@ -14,12 +14,11 @@
 namespace {
 
 __global__ __launch_bounds__(256) void leaf_encode_kernel(
-    PcvLevels lv, const uint64_t* __restrict__ walk, uint64_t n, const uint64_t* __restrict__ keys,
-    const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ z,
-    const uint8_t* __restrict__ color, uint32_t color_stride, const float* __restrict__ intensity,
-    uint32_t* __restrict__ rank, uint32_t* __restrict__ cx, uint32_t* __restrict__ cy, uint32_t* __restrict__ cz,
+    PcvLevels lv, const uint64_t* __restrict__ walk, uint64_t n, const double* __restrict__ x,
+    const double* __restrict__ y, const double* __restrict__ z, const uint8_t* __restrict__ color, uint32_t color_stride,
+    const float* __restrict__ intensity, uint32_t* __restrict__ rank, uint4* __restrict__ payload,
     uint32_t* __restrict__ cx_hi, uint32_t* __restrict__ cy_hi, uint32_t* __restrict__ cz_hi,
-    uint32_t* __restrict__ rgba, uint32_t* __restrict__ inten_bits) {
+    uint32_t* __restrict__ inten_bits) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   // Walk the node table while replaying the chain: the digit of level L comes out of the chain step itself
@@ -38,24 +37,21 @@ __global__ __launch_bounds__(256) void leaf_encode_kernel(
     rec = walk[idx];
   } while (!((rec >> 40) & 1ull) && L < lv.nlevels);
   rank[i] = (uint32_t)rec;
-  cx[i] = (uint32_t)ccx;
-  cy[i] = (uint32_t)ccy;
-  cz[i] = (uint32_t)ccz;
+  const uint8_t* c = color + i * color_stride;
+  payload[i] = make_uint4((uint32_t)ccx, (uint32_t)ccy, (uint32_t)ccz,
+                          (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16));
   if (cx_hi) {  // some leaf level is Float64-encoded: carry the high words too
     cx_hi[i] = (uint32_t)(ccx >> 32);
     cy_hi[i] = (uint32_t)(ccy >> 32);
     cz_hi[i] = (uint32_t)(ccz >> 32);
   }
-  const uint8_t* c = color + i * color_stride;
-  rgba[i] = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16);
   if (inten_bits) inten_bits[i] = __float_as_uint(intensity[i]);
 }
 
 __global__ __launch_bounds__(256) void promote_encode_kernel(
     PcvLevels lv, PcvPromoteTables pt, uint64_t n, const uint32_t* __restrict__ rank,
-    const uint32_t* __restrict__ cx, const uint32_t* __restrict__ cy, const uint32_t* __restrict__ cz,
-    const uint32_t* __restrict__ cx_hi, const uint32_t* __restrict__ cy_hi, const uint32_t* __restrict__ cz_hi,
-    const uint32_t* __restrict__ rgba, const uint32_t* __restrict__ inten_bits, uint8_t* __restrict__ xyz_blob,
+    const uint4* __restrict__ payload, const uint32_t* __restrict__ cx_hi, const uint32_t* __restrict__ cy_hi,
+    const uint32_t* __restrict__ cz_hi, const uint32_t* __restrict__ inten_bits, uint8_t* __restrict__ xyz_blob,
     uint8_t* __restrict__ rgb_blob, uint8_t* __restrict__ inten_blob) {
   const uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (s >= n) return;
@@ -63,7 +59,8 @@ __global__ __launch_bounds__(256) void promote_encode_kernel(
   uint32_t node = pt.leaf_node[r];
   uint32_t j = (uint32_t)s - pt.leaf_lo[r];
   int level = pt.level[node];
-  uint64_t code[3] = {cx[s], cy[s], cz[s]};
+  const uint4 pay = payload[s];
+  uint64_t code[3] = {pay.x, pay.y, pay.z};
   if (cx_hi) {
     code[0] |= (uint64_t)cx_hi[s] << 32;
     code[1] |= (uint64_t)cy_hi[s] << 32;
@@ -126,7 +123,7 @@ __global__ __launch_bounds__(256) void promote_encode_kernel(
     }
   }
   const uint64_t pidx = pt.point_off[node] + slot;
-  const uint32_t c = rgba[s];
+  const uint32_t c = pay.w;
   uint8_t* cd = rgb_blob + pidx * 3;
   cd[0] = (uint8_t)c;
   cd[1] = (uint8_t)(c >> 8);
@@ -136,24 +133,22 @@ __global__ __launch_bounds__(256) void promote_encode_kernel(
 
 }  // namespace
 
-void pcv_launch_leaf_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvWalkTables& wt, uint64_t n,
-                            const uint64_t* keys, const double* x, const double* y, const double* z,
-                            const uint8_t* color, uint32_t color_stride, const float* intensity, uint32_t* rank,
-                            uint32_t* cx, uint32_t* cy, uint32_t* cz, uint32_t* cx_hi, uint32_t* cy_hi,
-                            uint32_t* cz_hi, uint32_t* rgba, uint32_t* inten_bits) {
+void pcv_launch_leaf_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvWalkTables& wt, uint64_t n, const double* x,
+                            const double* y, const double* z, const uint8_t* color, uint32_t color_stride,
+                            const float* intensity, uint32_t* rank, void* payload, uint32_t* cx_hi, uint32_t* cy_hi,
+                            uint32_t* cz_hi, uint32_t* inten_bits) {
   if (n == 0) return;
   PcvProf prof(ctx, PCV_K_LEAF_ENCODE);
-  hipLaunchKernelGGL(leaf_encode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, lv, wt.walk, n, keys, x,
-                     y, z, color, color_stride, intensity, rank, cx, cy, cz, cx_hi, cy_hi, cz_hi, rgba, inten_bits);
+  hipLaunchKernelGGL(leaf_encode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, lv, wt.walk, n, x,
+                     y, z, color, color_stride, intensity, rank, (uint4*)payload, cx_hi, cy_hi, cz_hi, inten_bits);
 }
 
 void pcv_launch_promote_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvPromoteTables& pt, uint64_t n,
-                               const uint32_t* rank, const uint32_t* cx, const uint32_t* cy, const uint32_t* cz,
-                               const uint32_t* cx_hi, const uint32_t* cy_hi, const uint32_t* cz_hi,
-                               const uint32_t* rgba, const uint32_t* inten_bits, uint8_t* xyz_blob,
-                               uint8_t* rgb_blob, uint8_t* inten_blob) {
+                               const uint32_t* rank, const void* payload, const uint32_t* cx_hi, const uint32_t* cy_hi,
+                               const uint32_t* cz_hi, const uint32_t* inten_bits, uint8_t* xyz_blob, uint8_t* rgb_blob,
+                               uint8_t* inten_blob) {
   if (n == 0) return;
   PcvProf prof(ctx, PCV_K_PROMOTE_ENCODE);
-  hipLaunchKernelGGL(promote_encode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, lv, pt, n, rank, cx,
-                     cy, cz, cx_hi, cy_hi, cz_hi, rgba, inten_bits, xyz_blob, rgb_blob, inten_blob);
+  hipLaunchKernelGGL(promote_encode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, lv, pt, n, rank,
+                     (const uint4*)payload, cx_hi, cy_hi, cz_hi, inten_bits, xyz_blob, rgb_blob, inten_blob);
 }

@@ -47,6 +47,7 @@ enum PcvKernelId {
   PCV_K_SORT_UPSWEEP32,
   PCV_K_SORT_DOWNSWEEP32,
   PCV_K_PROMOTE_ENCODE,
+  PCV_K_SORT_DOWNSWEEP_REC,
   PCV_K_CULL_NODES,
   PCV_K_VISIBLE_NODES,
   PCV_K_NODES_IN_LOCATION,
@@ -146,9 +147,11 @@ void pcv_launch_depth_probe(pcv_ctx* ctx, const uint64_t* sorted, uint32_t n, ui
 
 // pcv_sort.hip — stable LSD radix sort, 8-bit digits, reduce-then-scan with LDS histograms.
 struct PcvSortPayload {
-  int nwords;           // number of 32-bit payload arrays that travel with the key (0..8)
-  uint32_t* in[8];
-  uint32_t* out[8];
+  void* vec_in = nullptr;   // optional 16-byte payload word per key (uint4), ping-pong partner in vec_out
+  void* vec_out = nullptr;
+  int nwords = 0;           // extra 32-bit payload planes that travel with the key (0..8)
+  uint32_t* in[8] = {};
+  uint32_t* out[8] = {};
 };
 size_t pcv_sort_scratch_bytes(uint64_t n);
 // Sorts keys_in -> ... ping-pong between (keys_a, payload.in) and (keys_b, payload.out). Returns in
@@ -181,11 +184,11 @@ struct PcvWalkTables {
   const uint64_t* walk;  // per node: first_child(32) | child_mask(8) << 32 | leaf(1) << 40 | level(8) << 48;
                          // for leaves the low 32 bits hold the leaf rank
 };
-void pcv_launch_leaf_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvWalkTables& wt, uint64_t n,
-                            const uint64_t* keys, const double* x, const double* y, const double* z,
-                            const uint8_t* color, uint32_t color_stride, const float* intensity, uint32_t* rank,
-                            uint32_t* cx, uint32_t* cy, uint32_t* cz, uint32_t* cx_hi, uint32_t* cy_hi,
-                            uint32_t* cz_hi, uint32_t* rgba, uint32_t* inten_bits);
+// record = rank (u32) + payload uint4 {code x, code y, code z, rgba} [+ planes: intensity bits, Float64 high words]
+void pcv_launch_leaf_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvWalkTables& wt, uint64_t n, const double* x,
+                            const double* y, const double* z, const uint8_t* color, uint32_t color_stride,
+                            const float* intensity, uint32_t* rank, void* payload /* uint4[n] */, uint32_t* cx_hi,
+                            uint32_t* cy_hi, uint32_t* cz_hi, uint32_t* inten_bits);
 
 struct PcvPromoteTables {
   const uint32_t* leaf_lo;     // per leaf rank: first sorted slot
@@ -198,10 +201,9 @@ struct PcvPromoteTables {
   const uint64_t* point_off;   // per node: point offset in the rgb/intensity blobs
 };
 void pcv_launch_promote_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvPromoteTables& pt, uint64_t n,
-                               const uint32_t* rank, const uint32_t* cx, const uint32_t* cy, const uint32_t* cz,
-                               const uint32_t* cx_hi, const uint32_t* cy_hi, const uint32_t* cz_hi,
-                               const uint32_t* rgba, const uint32_t* inten_bits, uint8_t* xyz_blob,
-                               uint8_t* rgb_blob, uint8_t* inten_blob);
+                               const uint32_t* rank, const void* payload /* uint4[n] */, const uint32_t* cx_hi,
+                               const uint32_t* cy_hi, const uint32_t* cz_hi, const uint32_t* inten_bits,
+                               uint8_t* xyz_blob, uint8_t* rgb_blob, uint8_t* inten_blob);
 
 struct PcvOctreeQuery;  // device-resident traversal tables (pcv_query.hip)
 

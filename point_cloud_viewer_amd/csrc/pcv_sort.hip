@@ -6,35 +6,38 @@
 //
 // Structure per 8-bit pass (reduce-then-scan, no inter-workgroup spinning):
 //   upsweep   : G workgroups, each counts the digits of its contiguous chunk in per-wave LDS histograms
-//   scan      : one workgroup turns the 256 x G counts (digit-major) into exclusive global offsets
+//   scan      : one workgroup per digit scans that digit's G counts; digit totals are scanned in the downsweep
 //   downsweep : the same G workgroups walk their chunk tile by tile; inside a tile each wave ranks its keys
 //               with ballot-built peer masks (64-lane match-any), a 256-entry LDS scan orders the digits,
-//               keys (and any payload words) are staged through LDS so global stores go out as runs.
-// HBM traffic per pass and key: sizeof(key) (upsweep) + 2*sizeof(key) + 8 B per payload word.
+//               keys (and the record payload) are staged through LDS so global stores go out as runs.
+// Two downsweep kernels: keys only (u32/u64, 16 keys per lane, next tile prefetched into registers) and records
+// (u32 key + one 16-byte payload word per key, 8 per lane, + optional extra 4-byte planes).
+// HBM traffic per pass and key: sizeof(key) (upsweep) + 2 * sizeof(key) + 2 * payload bytes.
 #include "pcv_internal.h"
 
 namespace {
 
 constexpr int kBlock = 256;  // 4 waves
 constexpr int kWaves = kBlock / 64;
-constexpr int kKpt = 16;  // keys per lane per tile
-constexpr int kTile = kBlock * kKpt;
 constexpr int kRadix = 256;
 constexpr int kMaxGroups = 1024;
+constexpr int kKptKeys = 16;  // keys-only kernel: keys per lane per tile
+constexpr int kKptRec = 8;    // record kernel
+constexpr int kTileUnit = kBlock * kKptKeys;  // chunk granularity (multiple of both tile sizes)
 
 struct SortGeom {
   uint64_t n;
-  uint64_t chunk;  // keys per workgroup, multiple of kTile
+  uint64_t chunk;  // keys per workgroup, multiple of kTileUnit
   int groups;
 };
 
 SortGeom make_geom(uint64_t n) {
   SortGeom g;
   g.n = n;
-  uint64_t tiles = (n + kTile - 1) / kTile;
+  uint64_t tiles = (n + kTileUnit - 1) / kTileUnit;
   uint64_t tiles_per_group = (tiles + kMaxGroups - 1) / kMaxGroups;
   if (tiles_per_group == 0) tiles_per_group = 1;
-  g.chunk = tiles_per_group * kTile;
+  g.chunk = tiles_per_group * kTileUnit;
   g.groups = (int)((n + g.chunk - 1) / g.chunk);
   if (g.groups < 1) g.groups = 1;
   return g;
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(kBlock) void upsweep_kernel(const KeyT* __restrict_
   if (end > n) end = n;
   constexpr int kVec = 16 / sizeof(KeyT);  // keys per 16-byte load
   typedef KeyT VecT __attribute__((ext_vector_type(kVec)));
-  // chunk is a multiple of kTile and buffers come from the pool (256-B aligned) => 16-byte loads are aligned
+  // chunk is a multiple of the tile and buffers come from the pool (256-B aligned) => 16-byte loads are aligned
   uint64_t i = begin + (uint64_t)threadIdx.x * kVec;
   for (; i + kVec <= end; i += (uint64_t)kBlock * kVec) {
     VecT v = *reinterpret_cast<const VecT*>(keys + i);
@@ -111,114 +114,212 @@ __global__ __launch_bounds__(256) void scan_kernel(uint32_t* __restrict__ hist, 
   if (threadIdx.x == 0) totals[blockIdx.x] = total;
 }
 
-struct PayloadPtrs {
-  int nwords;
-  const uint32_t* in[8];
-  uint32_t* out[8];
+// ---- shared pieces of the two downsweep kernels -------------------------------------------------
+
+struct DigitState {
+  uint32_t whist[kWaves][kRadix];  // per-wave digit counters, then exclusive prefix over the waves
+  uint32_t digit_base[kRadix];     // global position of the next key of each digit for this workgroup
+  uint32_t tile_start[kRadix];     // exclusive prefix of the digit counts inside the tile
+  uint32_t tile_count[kRadix];
+  uint32_t wave_tot[kWaves];
 };
 
-template <typename KeyT>
-__global__ __launch_bounds__(kBlock) void downsweep_kernel(const KeyT* __restrict__ keys_in,
-                                                            KeyT* __restrict__ keys_out, uint64_t n, uint64_t chunk,
-                                                            int groups, int shift, int nbits,
-                                                            const uint32_t* __restrict__ offsets /* [256][groups] */,
-                                                            const uint32_t* __restrict__ totals /* [256] */,
-                                                            PayloadPtrs pl) {
-  __shared__ KeyT skeys[kTile];
-  __shared__ uint32_t whist[kWaves][kRadix];
-  __shared__ uint32_t digit_base[kRadix];
-  __shared__ uint32_t tile_start[kRadix];
-  __shared__ uint32_t tile_count[kRadix];
-  __shared__ uint32_t wave_tot[kWaves];
-  uint32_t* stage32 = reinterpret_cast<uint32_t*>(skeys);
+// global base of digit t for this workgroup = (keys with a smaller digit) + (same digit, earlier workgroups)
+__device__ __forceinline__ void init_digit_base(DigitState& S, const uint32_t* __restrict__ offsets,
+                                                const uint32_t* __restrict__ totals, int groups, int t, int lane, int wave) {
+  const uint32_t tot = totals[t];  // kBlock == kRadix
+  uint32_t inc = tot;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t v = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += v;
+  }
+  if (lane == 63) S.wave_tot[wave] = inc;
+  __syncthreads();
+  uint32_t woff = 0;
+#pragma unroll
+  for (int w = 0; w < kWaves; ++w) woff += (w < wave) ? S.wave_tot[w] : 0u;
+  S.digit_base[t] = woff + inc - tot + offsets[(uint64_t)t * groups + blockIdx.x];
+#pragma unroll
+  for (int w = 0; w < kWaves; ++w) S.whist[w][t] = 0;
+  __syncthreads();
+}
 
+// Rank of one key among the earlier keys of the same digit inside this wave's slice of the tile (stable:
+// iteration-major, lane-minor == input order). 8 ballots build the mask of lanes holding the same digit.
+__device__ __forceinline__ uint32_t wave_rank(DigitState& S, int wave, uint64_t lane_lt, bool valid, uint32_t d) {
+  uint64_t peers = __ballot(valid);
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const bool bit = (d >> b) & 1u;
+    const uint64_t bal = __ballot(bit);
+    peers &= bit ? bal : ~bal;
+  }
+  const uint32_t rank_in = __popcll(peers & lane_lt);
+  const uint32_t cnt = __popcll(peers);
+  uint32_t pre = 0;
+  if (valid) pre = S.whist[wave][d];
+  __builtin_amdgcn_wave_barrier();
+  if (valid && rank_in == 0) S.whist[wave][d] = pre + cnt;
+  __builtin_amdgcn_wave_barrier();
+  return pre + rank_in;
+}
+
+// After all waves ranked their slices: per digit t the exclusive prefix over the waves, the tile count and the
+// exclusive scan over the digits. Ends with a barrier.
+__device__ __forceinline__ void digit_scan(DigitState& S, int t, int lane, int wave) {
+  __syncthreads();
+  uint32_t acc = 0;
+#pragma unroll
+  for (int w = 0; w < kWaves; ++w) {
+    uint32_t v = S.whist[w][t];
+    S.whist[w][t] = acc;
+    acc += v;
+  }
+  S.tile_count[t] = acc;
+  uint32_t inc = acc;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t v = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += v;
+  }
+  if (lane == 63) S.wave_tot[wave] = inc;
+  __syncthreads();
+  uint32_t woff = 0;
+#pragma unroll
+  for (int w = 0; w < kWaves; ++w) woff += (w < wave) ? S.wave_tot[w] : 0u;
+  S.tile_start[t] = woff + inc - acc;
+  __syncthreads();
+}
+
+// ---- keys only ------------------------------------------------------------------------------------
+template <typename KeyT>
+__global__ __launch_bounds__(kBlock, 4) void downsweep_keys_kernel(const KeyT* __restrict__ keys_in,
+                                                                   KeyT* __restrict__ keys_out, uint64_t n, uint64_t chunk,
+                                                                   int groups, int shift, int nbits,
+                                                                   const uint32_t* __restrict__ offsets,
+                                                                   const uint32_t* __restrict__ totals) {
+  constexpr int kKpt = kKptKeys, kTile = kBlock * kKpt;
+  __shared__ KeyT skeys[kTile];
+  __shared__ DigitState S;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const uint32_t mask = (1u << nbits) - 1u;
   const uint64_t lane_lt = (1ull << lane) - 1ull;
-  {
-    // global base of digit t for this workgroup = (keys with a smaller digit) + (same digit, earlier workgroups)
-    const uint32_t tot = totals[t];  // kBlock == kRadix
-    uint32_t inc = tot;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      uint32_t v = __shfl_up(inc, o, 64);
-      if (lane >= o) inc += v;
-    }
-    if (lane == 63) wave_tot[wave] = inc;
-    __syncthreads();
-    uint32_t woff = 0;
-#pragma unroll
-    for (int w = 0; w < kWaves; ++w) woff += (w < wave) ? wave_tot[w] : 0u;
-    digit_base[t] = woff + inc - tot + offsets[(uint64_t)t * groups + blockIdx.x];
-    __syncthreads();
-  }
+  init_digit_base(S, offsets, totals, groups, t, lane, wave);
 
   const uint64_t begin = (uint64_t)blockIdx.x * chunk;
   uint64_t end = begin + chunk;
   if (end > n) end = n;
+  const uint32_t wbase = wave * 64 * kKpt + lane;
+
+  KeyT key[kKpt];
+  {  // first tile
+    const uint32_t tile_n = (uint32_t)((end - begin) < (uint64_t)kTile ? (end - begin) : (uint64_t)kTile);
+#pragma unroll
+    for (int i = 0; i < kKpt; ++i) {
+      const uint32_t li = wbase + i * 64;
+      key[i] = li < tile_n ? keys_in[begin + li] : (KeyT)0;
+    }
+  }
+  for (uint64_t base = begin; base < end; base += kTile) {
+    const uint32_t tile_n = (uint32_t)((end - base) < (uint64_t)kTile ? (end - base) : (uint64_t)kTile);
+    uint16_t lpos[kKpt];
+#pragma unroll
+    for (int i = 0; i < kKpt; ++i) {
+      const bool valid = wbase + i * 64 < tile_n;
+      lpos[i] = (uint16_t)wave_rank(S, wave, lane_lt, valid, (uint32_t)(key[i] >> shift) & mask);
+    }
+    digit_scan(S, t, lane, wave);
+#pragma unroll
+    for (int i = 0; i < kKpt; ++i) {
+      if (wbase + i * 64 < tile_n) {
+        const uint32_t d = (uint32_t)(key[i] >> shift) & mask;
+        skeys[S.tile_start[d] + S.whist[wave][d] + lpos[i]] = key[i];
+      }
+    }
+    // the key registers are free now: fetch the next tile while this one drains through LDS
+    const uint64_t nbase = base + kTile;
+    if (nbase < end) {
+      const uint32_t next_n = (uint32_t)((end - nbase) < (uint64_t)kTile ? (end - nbase) : (uint64_t)kTile);
+#pragma unroll
+      for (int i = 0; i < kKpt; ++i) {
+        const uint32_t li = wbase + i * 64;
+        key[i] = li < next_n ? keys_in[nbase + li] : (KeyT)0;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kKpt; ++j) {
+      const uint32_t p = j * kBlock + t;
+      if (p < tile_n) {
+        const KeyT k = skeys[p];
+        const uint32_t d = (uint32_t)(k >> shift) & mask;
+        keys_out[S.digit_base[d] + (p - S.tile_start[d])] = k;
+      }
+    }
+    __syncthreads();
+    S.digit_base[t] += S.tile_count[t];
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) S.whist[w][t] = 0;
+    __syncthreads();
+  }
+}
+
+// ---- records: u32 key + optional 16-byte payload + extra 4-byte planes -----------------------------
+struct RecPtrs {
+  const uint4* vec_in;  // may be null
+  uint4* vec_out;
+  int nplanes;          // extra u32 planes (0..8)
+  const uint32_t* plane_in[8];
+  uint32_t* plane_out[8];
+};
+
+template <bool kHasVec>
+__global__ __launch_bounds__(kBlock, 4) void downsweep_rec_kernel(const uint32_t* __restrict__ keys_in,
+                                                                  uint32_t* __restrict__ keys_out, uint64_t n,
+                                                                  uint64_t chunk, int groups, int shift, int nbits,
+                                                                  const uint32_t* __restrict__ offsets,
+                                                                  const uint32_t* __restrict__ totals, RecPtrs rp) {
+  constexpr int kKpt = kKptRec, kTile = kBlock * kKpt;
+  __shared__ uint32_t skeys[kTile];
+  __shared__ uint4 svec[kHasVec ? kTile : 1];
+  __shared__ DigitState S;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const uint32_t mask = (1u << nbits) - 1u;
+  const uint64_t lane_lt = (1ull << lane) - 1ull;
+  init_digit_base(S, offsets, totals, groups, t, lane, wave);
+
+  const uint64_t begin = (uint64_t)blockIdx.x * chunk;
+  uint64_t end = begin + chunk;
+  if (end > n) end = n;
+  const uint32_t wbase = wave * 64 * kKpt + lane;
 
   for (uint64_t base = begin; base < end; base += kTile) {
     const uint32_t tile_n = (uint32_t)((end - base) < (uint64_t)kTile ? (end - base) : (uint64_t)kTile);
-#pragma unroll
-    for (int w = 0; w < kWaves; ++w) whist[w][t] = 0;
-    __syncthreads();
-
-    KeyT key[kKpt];
-    uint16_t lpos[kKpt];
-    const uint32_t wbase = wave * 64 * kKpt + lane;
+    uint32_t key[kKpt];
+    uint4 vec[kHasVec ? kKpt : 1];
 #pragma unroll
     for (int i = 0; i < kKpt; ++i) {
       const uint32_t li = wbase + i * 64;
       const bool valid = li < tile_n;
-      key[i] = valid ? keys_in[base + li] : (KeyT)0;
-      const uint32_t d = (uint32_t)(key[i] >> shift) & mask;
-      uint64_t peers = __ballot(valid);
-      for (int b = 0; b < nbits; ++b) {
-        const bool bit = (d >> b) & 1u;
-        const uint64_t bal = __ballot(bit);
-        peers &= bit ? bal : ~bal;
-      }
-      const uint32_t rank_in = __popcll(peers & lane_lt);
-      const uint32_t cnt = __popcll(peers);
-      uint32_t pre = 0;
-      if (valid) pre = whist[wave][d];
-      __builtin_amdgcn_wave_barrier();
-      if (valid && rank_in == 0) whist[wave][d] = pre + cnt;
-      __builtin_amdgcn_wave_barrier();
-      lpos[i] = (uint16_t)(pre + rank_in);
+      key[i] = valid ? keys_in[base + li] : 0u;
+      if (kHasVec) vec[i] = valid ? rp.vec_in[base + li] : make_uint4(0, 0, 0, 0);
     }
-    __syncthreads();
-    // digit t: exclusive prefix over the waves, tile count, then exclusive scan over the digits
-    uint32_t acc = 0;
-#pragma unroll
-    for (int w = 0; w < kWaves; ++w) {
-      uint32_t v = whist[w][t];
-      whist[w][t] = acc;
-      acc += v;
-    }
-    tile_count[t] = acc;
-    uint32_t inc = acc;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      uint32_t v = __shfl_up(inc, o, 64);
-      if (lane >= o) inc += v;
-    }
-    if (lane == 63) wave_tot[wave] = inc;
-    __syncthreads();
-    uint32_t woff = 0;
-#pragma unroll
-    for (int w = 0; w < kWaves; ++w) woff += (w < wave) ? wave_tot[w] : 0u;
-    tile_start[t] = woff + inc - acc;
-    __syncthreads();
-    // local sorted position of every key; stage keys in LDS
+    uint16_t lpos[kKpt];
 #pragma unroll
     for (int i = 0; i < kKpt; ++i) {
-      const uint32_t li = wbase + i * 64;
-      if (li < tile_n) {
-        const uint32_t d = (uint32_t)(key[i] >> shift) & mask;
-        const uint32_t p = tile_start[d] + whist[wave][d] + lpos[i];
+      const bool valid = wbase + i * 64 < tile_n;
+      lpos[i] = (uint16_t)wave_rank(S, wave, lane_lt, valid, (key[i] >> shift) & mask);
+    }
+    digit_scan(S, t, lane, wave);
+#pragma unroll
+    for (int i = 0; i < kKpt; ++i) {
+      if (wbase + i * 64 < tile_n) {
+        const uint32_t d = (key[i] >> shift) & mask;
+        const uint32_t p = S.tile_start[d] + S.whist[wave][d] + lpos[i];
         lpos[i] = (uint16_t)p;
         skeys[p] = key[i];
+        if (kHasVec) svec[p] = vec[i];
       }
     }
     __syncthreads();
@@ -227,32 +328,35 @@ __global__ __launch_bounds__(kBlock) void downsweep_kernel(const KeyT* __restric
     for (int j = 0; j < kKpt; ++j) {
       const uint32_t p = j * kBlock + t;
       if (p < tile_n) {
-        const KeyT k = skeys[p];
-        const uint32_t d = (uint32_t)(k >> shift) & mask;
-        const uint32_t g = digit_base[d] + (p - tile_start[d]);
+        const uint32_t k = skeys[p];
+        const uint32_t d = (k >> shift) & mask;
+        const uint32_t g = S.digit_base[d] + (p - S.tile_start[d]);
         gidx[j] = g;
         keys_out[g] = k;
+        if (kHasVec) rp.vec_out[g] = svec[p];
       }
     }
-    for (int w = 0; w < pl.nwords; ++w) {
-      const uint32_t* __restrict__ src = pl.in[w];
-      uint32_t* __restrict__ dst = pl.out[w];
+    for (int w = 0; w < rp.nplanes; ++w) {  // rare: intensity / Float64 high words / generic pairs API
+      const uint32_t* __restrict__ src = rp.plane_in[w];
+      uint32_t* __restrict__ dst = rp.plane_out[w];
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < kKpt; ++i) {
         const uint32_t li = wbase + i * 64;
-        if (li < tile_n) stage32[lpos[i]] = src[base + li];
+        if (li < tile_n) skeys[lpos[i]] = src[base + li];
       }
       __syncthreads();
 #pragma unroll
       for (int j = 0; j < kKpt; ++j) {
         const uint32_t p = j * kBlock + t;
-        if (p < tile_n) dst[gidx[j]] = stage32[p];
+        if (p < tile_n) dst[gidx[j]] = skeys[p];
       }
     }
     __syncthreads();
-    digit_base[t] += tile_count[t];
-    // next iteration's first barrier orders this update before any use
+    S.digit_base[t] += S.tile_count[t];
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) S.whist[w][t] = 0;
+    __syncthreads();
   }
 }
 
@@ -262,6 +366,8 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
   *result_in_a = true;
   if (n == 0 || end_bit <= begin_bit) return PCV_OK;
   if (n >= 0xffffffffull) return ctx->fail(PCV_E_INVALID, "radix sort: n must be < 2^32 - 1");
+  const bool records = payload && (payload->vec_in || payload->nwords > 0);
+  if (records && sizeof(KeyT) != 4) return ctx->fail(PCV_E_INVALID, "record sort needs 32-bit keys");
   SortGeom g = make_geom(n);
   uint32_t* hist = (uint32_t*)scratch;
   uint32_t* totals = hist + (size_t)kRadix * kMaxGroups;
@@ -271,14 +377,6 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
     uint32_t mask = (1u << nbits) - 1u;
     KeyT* src = in_a ? a : b;
     KeyT* dst = in_a ? b : a;
-    PayloadPtrs pl{};
-    if (payload) {
-      pl.nwords = payload->nwords;
-      for (int w = 0; w < payload->nwords; ++w) {
-        pl.in[w] = in_a ? payload->in[w] : payload->out[w];
-        pl.out[w] = in_a ? payload->out[w] : payload->in[w];
-      }
-    }
     {
       PcvProf prof(ctx, sizeof(KeyT) == 8 ? PCV_K_SORT_UPSWEEP64 : PCV_K_SORT_UPSWEEP32);
       hipLaunchKernelGGL(upsweep_kernel<KeyT>, dim3(g.groups), dim3(kBlock), 0, ctx->stream, src, n, g.chunk,
@@ -288,10 +386,26 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
       PcvProf prof(ctx, PCV_K_SORT_SCAN);
       hipLaunchKernelGGL(scan_kernel, dim3(kRadix), dim3(256), 0, ctx->stream, hist, g.groups, totals);
     }
-    {
+    if (!records) {
       PcvProf prof(ctx, sizeof(KeyT) == 8 ? PCV_K_SORT_DOWNSWEEP64 : PCV_K_SORT_DOWNSWEEP32);
-      hipLaunchKernelGGL(downsweep_kernel<KeyT>, dim3(g.groups), dim3(kBlock), 0, ctx->stream, src, dst, n, g.chunk,
-                         g.groups, shift, nbits, hist, totals, pl);
+      hipLaunchKernelGGL(downsweep_keys_kernel<KeyT>, dim3(g.groups), dim3(kBlock), 0, ctx->stream, src, dst, n, g.chunk,
+                         g.groups, shift, nbits, hist, totals);
+    } else {
+      RecPtrs rp{};
+      rp.vec_in = (const uint4*)(in_a ? payload->vec_in : payload->vec_out);
+      rp.vec_out = (uint4*)(in_a ? payload->vec_out : payload->vec_in);
+      rp.nplanes = payload->nwords;
+      for (int w = 0; w < payload->nwords; ++w) {
+        rp.plane_in[w] = in_a ? payload->in[w] : payload->out[w];
+        rp.plane_out[w] = in_a ? payload->out[w] : payload->in[w];
+      }
+      PcvProf prof(ctx, PCV_K_SORT_DOWNSWEEP_REC);
+      if (payload->vec_in)
+        hipLaunchKernelGGL(downsweep_rec_kernel<true>, dim3(g.groups), dim3(kBlock), 0, ctx->stream, (const uint32_t*)src,
+                           (uint32_t*)dst, n, g.chunk, g.groups, shift, nbits, hist, totals, rp);
+      else
+        hipLaunchKernelGGL(downsweep_rec_kernel<false>, dim3(g.groups), dim3(kBlock), 0, ctx->stream, (const uint32_t*)src,
+                           (uint32_t*)dst, n, g.chunk, g.groups, shift, nbits, hist, totals, rp);
     }
     in_a = !in_a;
   }
