@@ -223,12 +223,15 @@ int pcv_make_levels(const double bmin[3], const double bmax[3], double resolutio
     for (int a = 0; a < 3; ++a) lv->root_min[a] = bmin[a];
     int nl = k < PCV_MAX_KEY_LEVELS ? k : PCV_MAX_KEY_LEVELS;
     lv->nlevels = nl;
+    bool tame = std::fabs(bmin[0]) <= 0x1p+500 && std::fabs(bmin[1]) <= 0x1p+500 && std::fabs(bmin[2]) <= 0x1p+500;
     for (int j = 0; j <= nl && j < (int)e.size(); ++j) {
       lv->edge[j] = e[j];
       // IEEE division on the host: correctly rounded reciprocal; 0 = "use plain division" (pcv_div_const)
       lv->inv_edge[j] = (e[j] >= 0x1p-100 && e[j] <= 0x1p+100) ? 1.0 / e[j] : 0.0;
       lv->enc[j] = (uint8_t)c[j];
+      tame = tame && lv->inv_edge[j] != 0.0;
     }
+    lv->fast_ok = tame ? 1 : 0;
   }
   if (edges) *edges = e;
   if (encs) *encs = c;

@@ -109,9 +109,16 @@ __global__ __launch_bounds__(256) void chain_keys_kernel(PcvLevels lv, uint64_t 
   double px = x[src], py = y[src], pz = z[src];
   double mx = lv.root_min[0], my = lv.root_min[1], mz = lv.root_min[2];
   uint64_t key = 0, cx, cy, cz;
-  for (int k = 1; k <= lv.nlevels; ++k) {
-    const uint32_t d = pcv_chain_level(lv.enc[k], lv.edge[k - 1], lv.edge[k], lv.inv_edge[k], px, py, pz, mx, my, mz, cx, cy, cz);
-    key |= (uint64_t)d << (3 * (PCV_MAX_KEY_LEVELS - k));
+  if (lv.fast_ok && pcv_point_is_tame(px, py, pz)) {
+    for (int k = 1; k <= lv.nlevels; ++k) {
+      const uint32_t d = pcv_chain_level<false>(lv.enc[k], lv.edge[k - 1], lv.edge[k], lv.inv_edge[k], px, py, pz, mx, my, mz, cx, cy, cz);
+      key |= (uint64_t)d << (3 * (PCV_MAX_KEY_LEVELS - k));
+    }
+  } else {
+    for (int k = 1; k <= lv.nlevels; ++k) {
+      const uint32_t d = pcv_chain_level<true>(lv.enc[k], lv.edge[k - 1], lv.edge[k], lv.inv_edge[k], px, py, pz, mx, my, mz, cx, cy, cz);
+      key |= (uint64_t)d << (3 * (PCV_MAX_KEY_LEVELS - k));
+    }
   }
   keys[i] = sizeof(KeyT) == 8 ? (KeyT)key : (KeyT)(key >> 33);
 }

@@ -23,12 +23,16 @@
 // an FMA"). The theorem needs: y correctly rounded (it is), no overflow/underflow in the residuals. Outside
 // 2^-900 <= |x| <= 2^900 (also x == 0 for the sign of zero, inf, NaN) the IEEE division is used instead.
 // `pcv_selftest_division` checks the routine bit-for-bit against IEEE division on the device.
+// GUARD = false drops the range check; only valid where the caller has established that x is finite with
+// |x| <= 2^900 and y != 0, and only for the integer encodings (where a zero or tiny x gives code 0 either way).
+template <bool GUARD = true>
 __device__ __forceinline__ double pcv_div_const(double x, double e, double y) {
   const double q0 = x * y;
   const double r0 = __fma_rn(-e, q0, x);
   const double q1 = __fma_rn(r0, y, q0);
   const double r1 = __fma_rn(-e, q1, x);
   double q = __fma_rn(r1, y, q1);
+  if (!GUARD) return q;
   const double ax = fabs(x);
   // y == 0 marks a divisor outside [2^-100, 2^100] (host side), where the residuals could leave the normal range
   if (__builtin_expect(!(ax >= 0x1p-900 && ax <= 0x1p+900) || y == 0.0, 0)) {
@@ -53,19 +57,22 @@ __device__ __forceinline__ double pcv_div_code(double v, double maxval, double y
 __device__ __forceinline__ double pcv_clamp01(double t) { return (t < 0.0) ? 0.0 : ((t > 1.0) ? 1.0 : t); }
 
 // Rust `as u8/u16` after the clamp: NaN -> 0, truncation toward zero; t <= 1 so no upper saturation.
+template <bool GUARD = true>
 __device__ __forceinline__ uint32_t pcv_fix_encode(double p, double mn, double edge, double inv_edge, double maxval) {
-  double t = pcv_div_const(p - mn, edge, inv_edge);
-  // (t > 0 ? t : 0) maps NaN, -0.0 and negatives to 0 — same integer code as clamp + `as` cast.
-  t = (t > 0.0) ? t : 0.0;
-  t = (t > 1.0) ? 1.0 : t;
+  double t = pcv_div_const<GUARD>(p - mn, edge, inv_edge);
+  // maxNum(t, 0) maps NaN (t is never a signalling NaN: it is an arithmetic result), -0.0 and negatives to a zero —
+  // same integer code as num::clamp + `as` cast; minNum(t, 1) is the upper clamp. Two instructions instead of six.
+  t = fmax(t, 0.0);
+  t = fmin(t, 1.0);
   return (uint32_t)(maxval * t);
 }
 
 // Raw code (integer value or IEEE bit pattern) of one coordinate.
+template <bool GUARD = true>
 __device__ __forceinline__ uint64_t pcv_encode_coord(uint32_t enc, double p, double mn, double edge, double inv_edge) {
   switch (enc) {
-    case PCV_ENC_UINT8: return pcv_fix_encode(p, mn, edge, inv_edge, 255.0);
-    case PCV_ENC_UINT16: return pcv_fix_encode(p, mn, edge, inv_edge, 65535.0);
+    case PCV_ENC_UINT8: return pcv_fix_encode<GUARD>(p, mn, edge, inv_edge, 255.0);
+    case PCV_ENC_UINT16: return pcv_fix_encode<GUARD>(p, mn, edge, inv_edge, 65535.0);
     case PCV_ENC_FLOAT32: {
       float f = (float)pcv_clamp01(pcv_div_const(p - mn, edge, inv_edge));  // round-to-nearest-even
       return (uint64_t)__float_as_uint(f);
@@ -85,36 +92,45 @@ __device__ __forceinline__ double pcv_decode_coord(uint32_t enc, uint64_t code, 
 
 // One level of the chain for one coordinate with the encoding known at compile time: returns the octant bit,
 // moves `mn` to the child cube, replaces `p` by its encode->decode image in the child cube and reports the code.
-template <int ENC>
+template <int ENC, bool GUARD>
 __device__ __forceinline__ uint32_t pcv_chain_coord_t(double e_parent, double e_child, double inv_e_child, double& p,
                                                       double& mn, uint64_t& code) {
   const double mx = mn + e_parent;
   const double c = (mn + mx) / 2.0;
   const uint32_t bit = p > c ? 1u : 0u;
   mn = mn + (bit ? e_child : 0.0);  // `bit as f64 * edge` is exactly e or +0.0
-  code = pcv_encode_coord(ENC, p, mn, e_child, inv_e_child);
+  code = pcv_encode_coord<GUARD>(ENC, p, mn, e_child, inv_e_child);
   p = pcv_decode_coord(ENC, code, mn, e_child);
   return bit;
 }
 
 // One level for all three coordinates as a single straight-line block (the encoding switch is taken once per
 // level and is wave-uniform, so the three dependency chains interleave). Returns the octant digit.
-template <int ENC>
+template <int ENC, bool GUARD>
 __device__ __forceinline__ uint32_t pcv_chain_level_t(double ep, double ec, double ic, double& px, double& py, double& pz,
                                                       double& mx, double& my, double& mz, uint64_t& cx, uint64_t& cy,
                                                       uint64_t& cz) {
-  const uint32_t bx = pcv_chain_coord_t<ENC>(ep, ec, ic, px, mx, cx);
-  const uint32_t by = pcv_chain_coord_t<ENC>(ep, ec, ic, py, my, cy);
-  const uint32_t bz = pcv_chain_coord_t<ENC>(ep, ec, ic, pz, mz, cz);
+  const uint32_t bx = pcv_chain_coord_t<ENC, GUARD>(ep, ec, ic, px, mx, cx);
+  const uint32_t by = pcv_chain_coord_t<ENC, GUARD>(ep, ec, ic, py, my, cy);
+  const uint32_t bz = pcv_chain_coord_t<ENC, GUARD>(ep, ec, ic, pz, mz, cz);
   return (bx << 2) | (by << 1) | bz;
 }
+// GUARD = false: the caller checked once per point that the coordinates are finite and moderate (pcv_point_is_tame)
+// and the level table is tame (PcvLevels::fast_ok); the integer-encoded levels then run without per-division checks.
+template <bool GUARD>
 __device__ __forceinline__ uint32_t pcv_chain_level(uint32_t enc, double ep, double ec, double ic, double& px, double& py,
                                                     double& pz, double& mx, double& my, double& mz, uint64_t& cx,
                                                     uint64_t& cy, uint64_t& cz) {
   switch (enc) {
-    case PCV_ENC_UINT8: return pcv_chain_level_t<PCV_ENC_UINT8>(ep, ec, ic, px, py, pz, mx, my, mz, cx, cy, cz);
-    case PCV_ENC_UINT16: return pcv_chain_level_t<PCV_ENC_UINT16>(ep, ec, ic, px, py, pz, mx, my, mz, cx, cy, cz);
-    case PCV_ENC_FLOAT32: return pcv_chain_level_t<PCV_ENC_FLOAT32>(ep, ec, ic, px, py, pz, mx, my, mz, cx, cy, cz);
-    default: return pcv_chain_level_t<PCV_ENC_FLOAT64>(ep, ec, ic, px, py, pz, mx, my, mz, cx, cy, cz);
+    case PCV_ENC_UINT8: return pcv_chain_level_t<PCV_ENC_UINT8, GUARD>(ep, ec, ic, px, py, pz, mx, my, mz, cx, cy, cz);
+    case PCV_ENC_UINT16: return pcv_chain_level_t<PCV_ENC_UINT16, GUARD>(ep, ec, ic, px, py, pz, mx, my, mz, cx, cy, cz);
+    case PCV_ENC_FLOAT32: return pcv_chain_level_t<PCV_ENC_FLOAT32, true>(ep, ec, ic, px, py, pz, mx, my, mz, cx, cy, cz);
+    default: return pcv_chain_level_t<PCV_ENC_FLOAT64, true>(ep, ec, ic, px, py, pz, mx, my, mz, cx, cy, cz);
   }
+}
+
+// One check per point instead of one per division: finite and |v| <= 2^500 keeps every p_k - m_k of the chain
+// finite and below 2^900 (cube mins and edges are bounded by PcvLevels::fast_ok on the host).
+__device__ __forceinline__ bool pcv_point_is_tame(double x, double y, double z) {
+  return fabs(x) <= 0x1p+500 && fabs(y) <= 0x1p+500 && fabs(z) <= 0x1p+500;  // false for NaN / inf
 }

@@ -23,6 +23,7 @@ struct PcvLevels {
   double inv_edge[PCV_MAX_KEY_LEVELS + 2];  // RN(1 / edge[k]) for the exact constant-divisor division
   uint8_t enc[PCV_MAX_KEY_LEVELS + 3];
   int32_t nlevels;  // number of digit levels materialised in the keys (<= PCV_MAX_KEY_LEVELS)
+  int32_t fast_ok;  // root min and all edges are tame: unguarded exact division is valid for tame points
 };
 
 // Caching device allocator + pinned host scratch, one per context. Steady-state builds allocate nothing.

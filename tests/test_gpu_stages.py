@@ -65,7 +65,8 @@ def test_chain_keys_bit_exact(ctx):
 def test_chain_keys_special_values(ctx):
     # points on / outside the (loose) bounding box, exact cube centres, signed zeros
     bmin, bmax = np.array([-8.0, -8.0, -8.0]), np.array([8.0, 8.0, 8.0])
-    g = np.array([-9.0, -8.0, -4.0, -0.0, 0.0, 1e-300, 4.0, 7.999999999, 8.0, 12.5, 2.0 ** -30, -2.0 ** -30])
+    g = np.array([-9.0, -8.0, -4.0, -0.0, 0.0, 1e-300, 4.0, 7.999999999, 8.0, 12.5, 2.0 ** -30, -2.0 ** -30,
+                  float("nan"), float("inf"), -float("inf"), 1e200, -1e200, 5e-324])
     x, y, z = [a.ravel() for a in np.meshgrid(g, g, g)]
     for res in (1.0, 0.001, 1e-7):
         ml, _, _ = pcv.level_table(bmin, bmax, res)
