@@ -583,7 +583,7 @@ extern "C" int pcv_build_octree(pcv_ctx* ctx, const pcv_build_params* params, co
   const uint32_t M = counters[0];
   // pinned staging: prefix(8) lo hi parent first_child (4 each) level mask open (1 each)
   const size_t host_bytes = (size_t)M * (8 + 4 * 4 + 3) + 64;
-  if ((rc = ctx->pinned_reserve(host_bytes * 4 + (size_t)M * 64))) return rc;
+  if ((rc = ctx->pinned_reserve(host_bytes * 4 + (size_t)M * 64 + (size_t)M * 2 * sizeof(PcvNodeRec) + 512))) return rc;
   uint8_t* hp = (uint8_t*)ctx->pinned;
   uint64_t* h_prefix = (uint64_t*)hp;
   uint32_t* h_lo = (uint32_t*)(h_prefix + M);
@@ -690,23 +690,33 @@ extern "C" int pcv_build_octree(pcv_ctx* ctx, const pcv_build_params* params, co
   t->rgb_bytes = point_off * 3;
   t->int_bytes = t->has_intensity ? point_off * 4 : 0;
 
+  // device tables: walk records for K5, 64-byte node / leaf records for K6 (one contiguous upload)
+  uint8_t* rec_base = up + ((up_bytes + 255) & ~(size_t)255);
+  PcvNodeRec* u_node_rec = (PcvNodeRec*)rec_base;
+  PcvNodeRec* u_leaf_rec = u_node_rec + M;
+  for (uint32_t i = 0; i < M; ++i) {
+    PcvNodeRec& nr = u_node_rec[i];
+    nr.lo = h_lo[i];
+    nr.parent = u_parent[i];
+    nr.child_off = u_child_off[i];
+    nr.level = u_level[i];
+    nr.xyz_off = u_xyz_off[i];
+    nr.point_off = u_point_off[i];
+    for (int a = 0; a < 3; ++a) nr.mn[a] = u_node_min[3 * (size_t)i + a];
+    nr.pad = 0;
+  }
+  for (uint32_t r = 0; r < num_leaves; ++r) u_leaf_rec[r] = u_node_rec[leaves[r]];
+  const size_t walk_bytes = ((size_t)M * 8 + 255) & ~(size_t)255;
+  const size_t rec_bytes = (size_t)(M + num_leaves) * sizeof(PcvNodeRec);
   uint8_t* d_up;
-  if ((rc = sc.get(&d_up, up_bytes + 256))) return rc;
-  PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_up, up, up_bytes, hipMemcpyHostToDevice, st));
-  const size_t o_walk = 0, o_xyz = o_walk + (size_t)M * 8, o_pt = o_xyz + (size_t)M * 8, o_min = o_pt + (size_t)M * 8,
-               o_par = o_min + (size_t)M * 24, o_coff = o_par + (size_t)M * 4, o_llo = o_coff + (size_t)M * 4,
-               o_lnode = o_llo + (size_t)M * 4, o_lvl = o_lnode + (size_t)M * 4;
+  if ((rc = sc.get(&d_up, walk_bytes + rec_bytes + 256))) return rc;
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_up, u_walk, (size_t)M * 8, hipMemcpyHostToDevice, st));
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_up + walk_bytes, u_node_rec, rec_bytes, hipMemcpyHostToDevice, st));
   PcvWalkTables wt;
-  wt.walk = (const uint64_t*)(d_up + o_walk);
+  wt.walk = (const uint64_t*)d_up;
   PcvPromoteTables pt;
-  pt.leaf_lo = (const uint32_t*)(d_up + o_llo);
-  pt.leaf_node = (const uint32_t*)(d_up + o_lnode);
-  pt.parent = (const uint32_t*)(d_up + o_par);
-  pt.child_off = (const uint32_t*)(d_up + o_coff);
-  pt.level = (const uint8_t*)(d_up + o_lvl);
-  pt.node_min = (const double*)(d_up + o_min);
-  pt.xyz_off = (const uint64_t*)(d_up + o_xyz);
-  pt.point_off = (const uint64_t*)(d_up + o_pt);
+  pt.node_rec = (const PcvNodeRec*)(d_up + walk_bytes);
+  pt.leaf_rec = pt.node_rec + M;
   PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[5], st));
 
   // ---- K5 leaf encode (input order) ----

@@ -9,6 +9,7 @@
 //     (generation.rs:222-238); a point that stays in a non-root node is rewritten once
 //     (encode_k(decode_k(b))) at slot j - j/8 - 1; the root keeps everything it receives.
 //     Output is written node-contiguous: exactly the bytes of <node>.xyz/.rgb/.intensity.
+#include <cstdlib>
 #include "pcv_chain_dev.h"
 
 namespace {
@@ -60,14 +61,13 @@ __global__ __launch_bounds__(256) void promote_encode_kernel(
     PcvLevels lv, PcvPromoteTables pt, uint64_t n, const uint32_t* __restrict__ rank,
     const uint4* __restrict__ payload, const uint32_t* __restrict__ cx_hi, const uint32_t* __restrict__ cy_hi,
     const uint32_t* __restrict__ cz_hi, const uint32_t* __restrict__ inten_bits, uint8_t* __restrict__ xyz_blob,
-    uint8_t* __restrict__ rgb_blob, uint8_t* __restrict__ inten_blob) {
+    uint8_t* __restrict__ rgb_blob, uint8_t* __restrict__ inten_blob, int dbg) {
   const uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (s >= n) return;
   const uint32_t r = rank[s];
-  uint32_t node = pt.leaf_node[r];
-  uint32_t j = (uint32_t)s - pt.leaf_lo[r];
-  int level = pt.level[node];
   const uint4 pay = payload[s];
+  PcvNodeRec cur = pt.leaf_rec[r];
+  uint32_t j = (uint32_t)s - cur.lo;
   uint64_t code[3] = {pay.x, pay.y, pay.z};
   if (cx_hi) {
     code[0] |= (uint64_t)cx_hi[s] << 32;
@@ -75,31 +75,29 @@ __global__ __launch_bounds__(256) void promote_encode_kernel(
     code[2] |= (uint64_t)cz_hi[s] << 32;
   }
   // climb while this point is an every-8th element of its node's stream
-  while (node != 0 && (j & 7u) == 0) {
-    const uint32_t par = pt.parent[node];
-    const double* mn = pt.node_min + (uint64_t)node * 3;
-    const double* pm = pt.node_min + (uint64_t)par * 3;
-    const uint32_t ec = lv.enc[level], ep = lv.enc[level - 1];
-    const double edge_c = lv.edge[level], edge_p = lv.edge[level - 1], inv_p = lv.inv_edge[level - 1];
+  while (cur.parent != 0xffffffffu && (j & 7u) == 0) {
+    const PcvNodeRec par = pt.node_rec[cur.parent];
+    const uint32_t ec = lv.enc[cur.level], ep = lv.enc[par.level];
+    const double edge_c = lv.edge[cur.level], edge_p = lv.edge[par.level], inv_p = lv.inv_edge[par.level];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      const double q = pcv_decode_coord(ec, code[a], mn[a], edge_c);
-      code[a] = pcv_encode_coord(ep, q, pm[a], edge_p, inv_p);
+      const double q = pcv_decode_coord(ec, code[a], cur.mn[a], edge_c);
+      code[a] = pcv_encode_coord(ep, q, par.mn[a], edge_p, inv_p);
     }
-    j = pt.child_off[node] + (j >> 3);
-    node = par;
-    --level;
+    j = cur.child_off + (j >> 3);
+    cur = par;
   }
   uint32_t slot = j;
-  const uint32_t enc = lv.enc[level];
-  if (node != 0) {
+  const uint32_t enc = lv.enc[cur.level];
+  if (cur.parent != 0xffffffffu) {
     slot = j - (j >> 3) - 1u;
-    const double* mn = pt.node_min + (uint64_t)node * 3;
-    const double edge = lv.edge[level], inv = lv.inv_edge[level];
+    const double edge = lv.edge[cur.level], inv = lv.inv_edge[cur.level];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) code[a] = pcv_encode_coord(enc, pcv_decode_coord(enc, code[a], mn[a], edge), mn[a], edge, inv);
+    for (int a = 0; a < 3; ++a)
+      code[a] = pcv_encode_coord(enc, pcv_decode_coord(enc, code[a], cur.mn[a], edge), cur.mn[a], edge, inv);
   }
-  uint8_t* dst = xyz_blob + pt.xyz_off[node];
+  if (dbg == 1 && code[0] != 0x123456789ull) return;
+  uint8_t* dst = xyz_blob + cur.xyz_off;
   switch (enc) {
     case PCV_ENC_UINT8: {
       uint8_t* d = dst + (uint64_t)slot * 3;
@@ -130,7 +128,7 @@ __global__ __launch_bounds__(256) void promote_encode_kernel(
       break;
     }
   }
-  const uint64_t pidx = pt.point_off[node] + slot;
+  const uint64_t pidx = cur.point_off + slot;
   const uint32_t c = pay.w;
   uint8_t* cd = rgb_blob + pidx * 3;
   cd[0] = (uint8_t)c;
@@ -158,5 +156,6 @@ void pcv_launch_promote_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvPromo
   if (n == 0) return;
   PcvProf prof(ctx, PCV_K_PROMOTE_ENCODE);
   hipLaunchKernelGGL(promote_encode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, lv, pt, n, rank,
-                     (const uint4*)payload, cx_hi, cy_hi, cz_hi, inten_bits, xyz_blob, rgb_blob, inten_blob);
+                     (const uint4*)payload, cx_hi, cy_hi, cz_hi, inten_bits, xyz_blob, rgb_blob, inten_blob,
+                     getenv("PCV_DBG_PROMOTE") ? atoi(getenv("PCV_DBG_PROMOTE")) : 0);
 }

@@ -191,15 +191,21 @@ void pcv_launch_leaf_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvWalkTabl
                             const float* intensity, uint32_t* rank, void* payload /* uint4[n] */, uint32_t* cx_hi,
                             uint32_t* cy_hi, uint32_t* cz_hi, uint32_t* inten_bits);
 
+// Everything K6 needs about a node in one 64-byte record, so a slot's dependent loads are rank -> record (-> the
+// parent's record per climb) instead of five chained table lookups.
+struct alignas(16) PcvNodeRec {
+  uint32_t lo;         // leaves: first sorted slot of the leaf
+  uint32_t parent;     // node index of the parent, 0xffffffff for the root
+  uint32_t child_off;  // offset of this node's promoted block inside the parent's stream
+  uint32_t level;
+  uint64_t xyz_off;    // byte offset of the node's .xyz content in the xyz blob
+  uint64_t point_off;  // point offset in the rgb / intensity blobs
+  double mn[3];        // cube min (NodeId::find_bounding_cube recurrence)
+  uint64_t pad;
+};
 struct PcvPromoteTables {
-  const uint32_t* leaf_lo;     // per leaf rank: first sorted slot
-  const uint32_t* leaf_node;   // per leaf rank: node index
-  const uint32_t* parent;      // per node
-  const uint32_t* child_off;   // per node: offset of its promoted block inside the parent's stream
-  const uint8_t* level;        // per node
-  const double* node_min;      // per node: 3 doubles
-  const uint64_t* xyz_off;     // per node: byte offset in the xyz blob
-  const uint64_t* point_off;   // per node: point offset in the rgb/intensity blobs
+  const PcvNodeRec* leaf_rec;  // per leaf rank
+  const PcvNodeRec* node_rec;  // per node index
 };
 void pcv_launch_promote_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvPromoteTables& pt, uint64_t n,
                                const uint32_t* rank, const void* payload /* uint4[n] */, const uint32_t* cx_hi,
