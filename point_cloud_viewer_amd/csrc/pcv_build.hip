@@ -699,7 +699,9 @@ extern "C" int pcv_build_octree(pcv_ctx* ctx, const pcv_build_params* params, co
     nr.lo = h_lo[i];
     nr.parent = u_parent[i];
     nr.child_off = u_child_off[i];
-    nr.level = u_level[i];
+    nr.enc = lv.enc[u_level[i]];
+    nr.edge = lv.edge[u_level[i]];
+    nr.inv_edge = lv.inv_edge[u_level[i]];
     nr.xyz_off = u_xyz_off[i];
     nr.point_off = u_point_off[i];
     for (int a = 0; a < 3; ++a) nr.mn[a] = u_node_min[3 * (size_t)i + a];
@@ -714,6 +716,7 @@ extern "C" int pcv_build_octree(pcv_ctx* ctx, const pcv_build_params* params, co
   PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_up + walk_bytes, u_node_rec, rec_bytes, hipMemcpyHostToDevice, st));
   PcvWalkTables wt;
   wt.walk = (const uint64_t*)d_up;
+  wt.num_nodes = M;
   PcvPromoteTables pt;
   pt.node_rec = (const PcvNodeRec*)(d_up + walk_bytes);
   pt.leaf_rec = pt.node_rec + M;

@@ -44,13 +44,13 @@ __device__ __forceinline__ double pcv_div_const(double x, double e, double y) {
   }
   return q;
 }
-// v / maxval for an integer code v in [0, 65535]: same scheme, no range guard needed (verified exhaustively).
+// v / maxval for an integer code v in [0, maxval], maxval = 255 or 65535: one residual correction is already
+// bit-identical to IEEE division for every code (exhaustive: tests/test_oracle_kats.py on the host with exact
+// rational FMA emulation, pcv_selftest_division on the device).
 __device__ __forceinline__ double pcv_div_code(double v, double maxval, double y) {
   const double q0 = v * y;
   const double r0 = __fma_rn(-maxval, q0, v);
-  const double q1 = __fma_rn(r0, y, q0);
-  const double r1 = __fma_rn(-maxval, q1, v);
-  return __fma_rn(r1, y, q1);
+  return __fma_rn(r0, y, q0);
 }
 
 // num::clamp semantics (NaN and -0.0 pass through) — needed verbatim for the float encodings.

@@ -9,7 +9,6 @@
 //     (generation.rs:222-238); a point that stays in a non-root node is rewritten once
 //     (encode_k(decode_k(b))) at slot j - j/8 - 1; the root keeps everything it receives.
 //     Output is written node-contiguous: exactly the bytes of <node>.xyz/.rgb/.intensity.
-#include <cstdlib>
 #include "pcv_chain_dev.h"
 
 namespace {
@@ -57,47 +56,37 @@ __global__ __launch_bounds__(256) void leaf_encode_kernel(
   if (inten_bits) inten_bits[i] = __float_as_uint(intensity[i]);
 }
 
-__global__ __launch_bounds__(256) void promote_encode_kernel(
-    PcvLevels lv, PcvPromoteTables pt, uint64_t n, const uint32_t* __restrict__ rank,
-    const uint4* __restrict__ payload, const uint32_t* __restrict__ cx_hi, const uint32_t* __restrict__ cy_hi,
-    const uint32_t* __restrict__ cz_hi, const uint32_t* __restrict__ inten_bits, uint8_t* __restrict__ xyz_blob,
-    uint8_t* __restrict__ rgb_blob, uint8_t* __restrict__ inten_blob, int dbg) {
-  const uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (s >= n) return;
-  const uint32_t r = rank[s];
-  const uint4 pay = payload[s];
-  PcvNodeRec cur = pt.leaf_rec[r];
+struct PromoteOut {
+  uint8_t* xyz_blob;
+  uint8_t* rgb_blob;
+  uint8_t* inten_blob;
+};
+
+// One sorted slot: climb, final encode, store.
+__device__ __forceinline__ void promote_one(const PcvPromoteTables& pt, uint64_t s, PcvNodeRec cur, uint4 pay,
+                                            uint32_t hx, uint32_t hy, uint32_t hz, uint32_t inten, const PromoteOut& o) {
   uint32_t j = (uint32_t)s - cur.lo;
-  uint64_t code[3] = {pay.x, pay.y, pay.z};
-  if (cx_hi) {
-    code[0] |= (uint64_t)cx_hi[s] << 32;
-    code[1] |= (uint64_t)cy_hi[s] << 32;
-    code[2] |= (uint64_t)cz_hi[s] << 32;
-  }
+  uint64_t code[3] = {pay.x | ((uint64_t)hx << 32), pay.y | ((uint64_t)hy << 32), pay.z | ((uint64_t)hz << 32)};
   // climb while this point is an every-8th element of its node's stream
   while (cur.parent != 0xffffffffu && (j & 7u) == 0) {
     const PcvNodeRec par = pt.node_rec[cur.parent];
-    const uint32_t ec = lv.enc[cur.level], ep = lv.enc[par.level];
-    const double edge_c = lv.edge[cur.level], edge_p = lv.edge[par.level], inv_p = lv.inv_edge[par.level];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      const double q = pcv_decode_coord(ec, code[a], cur.mn[a], edge_c);
-      code[a] = pcv_encode_coord(ep, q, par.mn[a], edge_p, inv_p);
+      const double q = pcv_decode_coord(cur.enc, code[a], cur.mn[a], cur.edge);
+      code[a] = pcv_encode_coord(par.enc, q, par.mn[a], par.edge, par.inv_edge);
     }
     j = cur.child_off + (j >> 3);
     cur = par;
   }
   uint32_t slot = j;
-  const uint32_t enc = lv.enc[cur.level];
+  const uint32_t enc = cur.enc;
   if (cur.parent != 0xffffffffu) {
     slot = j - (j >> 3) - 1u;
-    const double edge = lv.edge[cur.level], inv = lv.inv_edge[cur.level];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
-      code[a] = pcv_encode_coord(enc, pcv_decode_coord(enc, code[a], cur.mn[a], edge), cur.mn[a], edge, inv);
+      code[a] = pcv_encode_coord(enc, pcv_decode_coord(enc, code[a], cur.mn[a], cur.edge), cur.mn[a], cur.edge, cur.inv_edge);
   }
-  if (dbg == 1 && code[0] != 0x123456789ull) return;
-  uint8_t* dst = xyz_blob + cur.xyz_off;
+  uint8_t* dst = o.xyz_blob + cur.xyz_off;
   switch (enc) {
     case PCV_ENC_UINT8: {
       uint8_t* d = dst + (uint64_t)slot * 3;
@@ -130,11 +119,46 @@ __global__ __launch_bounds__(256) void promote_encode_kernel(
   }
   const uint64_t pidx = cur.point_off + slot;
   const uint32_t c = pay.w;
-  uint8_t* cd = rgb_blob + pidx * 3;
+  uint8_t* cd = o.rgb_blob + pidx * 3;
   cd[0] = (uint8_t)c;
   cd[1] = (uint8_t)(c >> 8);
   cd[2] = (uint8_t)(c >> 16);
-  if (inten_blob) reinterpret_cast<uint32_t*>(inten_blob)[pidx] = inten_bits[s];
+  if (o.inten_blob) reinterpret_cast<uint32_t*>(o.inten_blob)[pidx] = inten;
+}
+
+// Two slots per lane (s and s + 256): the kernel is bound by the dependent loads rank -> record, so both chains
+// are started before either is consumed.
+__global__ __launch_bounds__(256) void promote_encode_kernel(
+    PcvPromoteTables pt, uint64_t n, const uint32_t* __restrict__ rank, const uint4* __restrict__ payload,
+    const uint32_t* __restrict__ cx_hi, const uint32_t* __restrict__ cy_hi, const uint32_t* __restrict__ cz_hi,
+    const uint32_t* __restrict__ inten_bits, PromoteOut o) {
+  const uint64_t s0 = (uint64_t)blockIdx.x * 512 + threadIdx.x;
+  const uint64_t s1 = s0 + 256;
+  if (s0 >= n) return;
+  const bool two = s1 < n;
+  const uint32_t r0 = rank[s0];
+  const uint32_t r1 = two ? rank[s1] : 0u;
+  const uint4 p0 = payload[s0];
+  const uint4 p1 = two ? payload[s1] : make_uint4(0, 0, 0, 0);
+  uint32_t h0[3] = {0, 0, 0}, h1[3] = {0, 0, 0}, i0 = 0, i1 = 0;
+  if (cx_hi) {
+    h0[0] = cx_hi[s0];
+    h0[1] = cy_hi[s0];
+    h0[2] = cz_hi[s0];
+    if (two) {
+      h1[0] = cx_hi[s1];
+      h1[1] = cy_hi[s1];
+      h1[2] = cz_hi[s1];
+    }
+  }
+  if (inten_bits) {
+    i0 = inten_bits[s0];
+    if (two) i1 = inten_bits[s1];
+  }
+  const PcvNodeRec c0 = pt.leaf_rec[r0];
+  const PcvNodeRec c1 = pt.leaf_rec[r1];
+  promote_one(pt, s0, c0, p0, h0[0], h0[1], h0[2], i0, o);
+  if (two) promote_one(pt, s1, c1, p1, h1[0], h1[1], h1[2], i1, o);
 }
 
 }  // namespace
@@ -155,7 +179,7 @@ void pcv_launch_promote_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvPromo
                                uint8_t* inten_blob) {
   if (n == 0) return;
   PcvProf prof(ctx, PCV_K_PROMOTE_ENCODE);
-  hipLaunchKernelGGL(promote_encode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, lv, pt, n, rank,
-                     (const uint4*)payload, cx_hi, cy_hi, cz_hi, inten_bits, xyz_blob, rgb_blob, inten_blob,
-                     getenv("PCV_DBG_PROMOTE") ? atoi(getenv("PCV_DBG_PROMOTE")) : 0);
+  PromoteOut o{xyz_blob, rgb_blob, inten_blob};
+  hipLaunchKernelGGL(promote_encode_kernel, dim3((unsigned)((n + 511) / 512)), dim3(256), 0, ctx->stream, pt, n, rank,
+                     (const uint4*)payload, cx_hi, cy_hi, cz_hi, inten_bits, o);
 }

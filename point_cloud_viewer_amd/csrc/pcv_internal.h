@@ -182,6 +182,7 @@ void pcv_launch_node_split(pcv_ctx* ctx, const PcvNodeTableDev& t, const void* s
 
 // pcv_encode.hip — leaf lookup + leaf-level encode (input order), promotion + final encode (sorted order).
 struct PcvWalkTables {
+  uint32_t num_nodes;
   const uint64_t* walk;  // per node: first_child(32) | child_mask(8) << 32 | leaf(1) << 40 | level(8) << 48;
                          // for leaves the low 32 bits hold the leaf rank
 };
@@ -191,16 +192,18 @@ void pcv_launch_leaf_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvWalkTabl
                             const float* intensity, uint32_t* rank, void* payload /* uint4[n] */, uint32_t* cx_hi,
                             uint32_t* cy_hi, uint32_t* cz_hi, uint32_t* inten_bits);
 
-// Everything K6 needs about a node in one 64-byte record, so a slot's dependent loads are rank -> record (-> the
-// parent's record per climb) instead of five chained table lookups.
+// Everything K6 needs about a node in one 80-byte record, so a slot's dependent loads are rank -> record (-> the
+// parent's record per climb) instead of chained table lookups (node, level, per-level edge/encoding, offsets).
 struct alignas(16) PcvNodeRec {
   uint32_t lo;         // leaves: first sorted slot of the leaf
   uint32_t parent;     // node index of the parent, 0xffffffff for the root
   uint32_t child_off;  // offset of this node's promoted block inside the parent's stream
-  uint32_t level;
+  uint32_t enc;        // PCV_ENC_* of the node's level
   uint64_t xyz_off;    // byte offset of the node's .xyz content in the xyz blob
   uint64_t point_off;  // point offset in the rgb / intensity blobs
   double mn[3];        // cube min (NodeId::find_bounding_cube recurrence)
+  double edge;         // cube edge of the node's level
+  double inv_edge;     // RN(1 / edge), 0 when the exact-division fast path must not be used
   uint64_t pad;
 };
 struct PcvPromoteTables {

@@ -121,3 +121,20 @@ def test_sum_of_num_points_equals_input():
     x, y, z, rgb, bmin, bmax = synthetic.uniform_ecef(n)
     t = O.build_closed(0.001, bmin, bmax, x, y, z, rgb, threads=4)
     assert t.total_points() == n
+
+
+def test_one_step_reciprocal_division_is_exact_for_every_code():
+    """The HIP kernels decode with q0 = v * RN(1/max); q = fma(fma(-max, q0, v), RN(1/max), q0) instead of an IEEE
+    division (pcv_chain_dev.h pcv_div_code). Exhaustive proof for all u8 / u16 codes, FMA emulated exactly."""
+    from fractions import Fraction as F
+
+    def fma(a, b, c):
+        e = F(a) * F(b) + F(c)
+        return float(e) if e != 0 else 0.0
+
+    for m in (255.0, 65535.0):
+        y = 1.0 / m
+        for v in range(int(m) + 1):
+            v = float(v)
+            q0 = v * y
+            assert fma(fma(-m, q0, v), y, q0) == v / m, (m, v)
