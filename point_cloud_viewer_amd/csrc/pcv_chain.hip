@@ -108,7 +108,8 @@ __global__ __launch_bounds__(256) void chain_keys_kernel(PcvLevels lv, uint64_t 
   const uint64_t src = i * stride;
   double px = x[src], py = y[src], pz = z[src];
   double mx = lv.root_min[0], my = lv.root_min[1], mz = lv.root_min[2];
-  uint64_t key = 0, cx, cy, cz;
+  uint64_t key = 0;
+  double cx, cy, cz;
   if (lv.fast_ok && pcv_point_is_tame(px, py, pz)) {
     for (int k = 1; k <= lv.nlevels; ++k) {
       const uint32_t d = pcv_chain_level<false>(lv.enc[k], lv.edge[k - 1], lv.edge[k], lv.inv_edge[k], px, py, pz, mx, my, mz, cx, cy, cz);

@@ -90,17 +90,47 @@ __device__ __forceinline__ double pcv_decode_coord(uint32_t enc, uint64_t code, 
   }
 }
 
+// Inside the chain the code is kept in the value domain (a double): the integer value for u8/u16, (double)(float)t
+// for Float32, t for Float64 — no int conversions per level; pcv_val_to_code makes the raw bits once at the end.
+template <int ENC, bool GUARD>
+__device__ __forceinline__ double pcv_encode_val(double p, double mn, double edge, double inv_edge) {
+  if (ENC == PCV_ENC_UINT8 || ENC == PCV_ENC_UINT16) {
+    const double maxval = ENC == PCV_ENC_UINT8 ? 255.0 : 65535.0;
+    double t = pcv_div_const<GUARD>(p - mn, edge, inv_edge);
+    t = fmax(t, 0.0);  // NaN, -0.0, negatives -> zero (see pcv_fix_encode)
+    t = fmin(t, 1.0);
+    return trunc(maxval * t);  // Rust `as u8/u16`: truncation toward zero, exact in f64
+  }
+  const double t = pcv_clamp01(pcv_div_const<true>(p - mn, edge, inv_edge));
+  return ENC == PCV_ENC_FLOAT32 ? (double)(float)t : t;
+}
+template <int ENC>
+__device__ __forceinline__ double pcv_decode_val(double cd, double mn, double edge) {
+  if (ENC == PCV_ENC_UINT8) return __fma_rn(pcv_div_code(cd, 255.0, 1.0 / 255.0), edge, mn);
+  if (ENC == PCV_ENC_UINT16) return __fma_rn(pcv_div_code(cd, 65535.0, 1.0 / 65535.0), edge, mn);
+  return __fma_rn(cd, edge, mn);
+}
+__device__ __forceinline__ uint64_t pcv_val_to_code(uint32_t enc, double cd) {
+  switch (enc) {
+    case PCV_ENC_UINT8:
+    case PCV_ENC_UINT16: return (uint64_t)(uint32_t)cd;
+    case PCV_ENC_FLOAT32: return (uint64_t)__float_as_uint((float)cd);
+    default: return (uint64_t)__double_as_longlong(cd);
+  }
+}
+
 // One level of the chain for one coordinate with the encoding known at compile time: returns the octant bit,
-// moves `mn` to the child cube, replaces `p` by its encode->decode image in the child cube and reports the code.
+// moves `mn` to the child cube, replaces `p` by its encode->decode image in the child cube and reports the code
+// (value domain).
 template <int ENC, bool GUARD>
 __device__ __forceinline__ uint32_t pcv_chain_coord_t(double e_parent, double e_child, double inv_e_child, double& p,
-                                                      double& mn, uint64_t& code) {
+                                                      double& mn, double& cd) {
   const double mx = mn + e_parent;
   const double c = (mn + mx) / 2.0;
   const uint32_t bit = p > c ? 1u : 0u;
   mn = mn + (bit ? e_child : 0.0);  // `bit as f64 * edge` is exactly e or +0.0
-  code = pcv_encode_coord<GUARD>(ENC, p, mn, e_child, inv_e_child);
-  p = pcv_decode_coord(ENC, code, mn, e_child);
+  cd = pcv_encode_val<ENC, GUARD>(p, mn, e_child, inv_e_child);
+  p = pcv_decode_val<ENC>(cd, mn, e_child);
   return bit;
 }
 
@@ -108,8 +138,8 @@ __device__ __forceinline__ uint32_t pcv_chain_coord_t(double e_parent, double e_
 // level and is wave-uniform, so the three dependency chains interleave). Returns the octant digit.
 template <int ENC, bool GUARD>
 __device__ __forceinline__ uint32_t pcv_chain_level_t(double ep, double ec, double ic, double& px, double& py, double& pz,
-                                                      double& mx, double& my, double& mz, uint64_t& cx, uint64_t& cy,
-                                                      uint64_t& cz) {
+                                                      double& mx, double& my, double& mz, double& cx, double& cy,
+                                                      double& cz) {
   const uint32_t bx = pcv_chain_coord_t<ENC, GUARD>(ep, ec, ic, px, mx, cx);
   const uint32_t by = pcv_chain_coord_t<ENC, GUARD>(ep, ec, ic, py, my, cy);
   const uint32_t bz = pcv_chain_coord_t<ENC, GUARD>(ep, ec, ic, pz, mz, cz);
@@ -119,8 +149,8 @@ __device__ __forceinline__ uint32_t pcv_chain_level_t(double ep, double ec, doub
 // and the level table is tame (PcvLevels::fast_ok); the integer-encoded levels then run without per-division checks.
 template <bool GUARD>
 __device__ __forceinline__ uint32_t pcv_chain_level(uint32_t enc, double ep, double ec, double ic, double& px, double& py,
-                                                    double& pz, double& mx, double& my, double& mz, uint64_t& cx,
-                                                    uint64_t& cy, uint64_t& cz) {
+                                                    double& pz, double& mx, double& my, double& mz, double& cx,
+                                                    double& cy, double& cz) {
   switch (enc) {
     case PCV_ENC_UINT8: return pcv_chain_level_t<PCV_ENC_UINT8, GUARD>(ep, ec, ic, px, py, pz, mx, my, mz, cx, cy, cz);
     case PCV_ENC_UINT16: return pcv_chain_level_t<PCV_ENC_UINT16, GUARD>(ep, ec, ic, px, py, pz, mx, my, mz, cx, cy, cz);

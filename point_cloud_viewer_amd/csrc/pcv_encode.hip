@@ -27,24 +27,26 @@ __global__ __launch_bounds__(256) void leaf_encode_kernel(
   uint64_t rec = walk[0];
   double px = x[i], py = y[i], pz = z[i];
   double mx = lv.root_min[0], my = lv.root_min[1], mz = lv.root_min[2];
-  uint64_t ccx = 0, ccy = 0, ccz = 0;
+  double vx = 0, vy = 0, vz = 0;
   int L = 0;
   if (lv.fast_ok && pcv_point_is_tame(px, py, pz)) {
     do {
       ++L;
-      const uint32_t d = pcv_chain_level<false>(lv.enc[L], lv.edge[L - 1], lv.edge[L], lv.inv_edge[L], px, py, pz, mx, my, mz, ccx, ccy, ccz);
+      const uint32_t d = pcv_chain_level<false>(lv.enc[L], lv.edge[L - 1], lv.edge[L], lv.inv_edge[L], px, py, pz, mx, my, mz, vx, vy, vz);
       const uint32_t mask = (uint32_t)(rec >> 32) & 0xffu;
       rec = walk[(uint32_t)rec + __popc(mask & ((1u << d) - 1u))];
     } while (!((rec >> 40) & 1ull) && L < lv.nlevels);
   } else {
     do {
       ++L;
-      const uint32_t d = pcv_chain_level<true>(lv.enc[L], lv.edge[L - 1], lv.edge[L], lv.inv_edge[L], px, py, pz, mx, my, mz, ccx, ccy, ccz);
+      const uint32_t d = pcv_chain_level<true>(lv.enc[L], lv.edge[L - 1], lv.edge[L], lv.inv_edge[L], px, py, pz, mx, my, mz, vx, vy, vz);
       const uint32_t mask = (uint32_t)(rec >> 32) & 0xffu;
       rec = walk[(uint32_t)rec + __popc(mask & ((1u << d) - 1u))];
     } while (!((rec >> 40) & 1ull) && L < lv.nlevels);
   }
   rank[i] = (uint32_t)rec;
+  const uint32_t leaf_enc = lv.enc[L];
+  const uint64_t ccx = pcv_val_to_code(leaf_enc, vx), ccy = pcv_val_to_code(leaf_enc, vy), ccz = pcv_val_to_code(leaf_enc, vz);
   const uint8_t* c = color + i * color_stride;
   payload[i] = make_uint4((uint32_t)ccx, (uint32_t)ccy, (uint32_t)ccz,
                           (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16));
