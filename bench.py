@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--points", type=int, default=100_000_000, help="points per GPU")
     ap.add_argument("--resolution", type=float, default=0.001)
-    ap.add_argument("--cpu-sample", type=int, default=20_000_000, help="points of the workload timed on the CPU")
+    ap.add_argument("--cpu-sample", type=int, default=50_000_000, help="points of the workload timed on the CPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with HIP events")
     args = ap.parse_args()
@@ -161,8 +161,9 @@ def main():
         p64 = timed.get("downsweep_kernel<u64>", (0, 0))[0] / args.steps
         rec_passes = timed.get("downsweep_rec_kernel", (0, 0))[0] / args.steps
         p32 = timed.get("downsweep_kernel<u32>", (0, 0))[0] / args.steps
-        key_bytes = 8.0 if p64 else 4.0
-        passes = p64 if p64 else p32
+        key32 = (info.get("build") or {}).get("key_levels", 21) <= 10  # the depth probe's own tiny sort is u64
+        key_bytes = 4.0 if key32 else 8.0
+        passes = p32 if key32 else p64 - (8 if p32 == 0 and p64 > 8 else 0)
         es_bytes_pp = 24.0 + key_bytes + passes * 3 * key_bytes
         encode_sort = {"GB/s": round(n * es_bytes_pp / (es_ms * 1e-3) / 1e9, 1) if es_ms else None,
                        "ms": round(es_ms, 3), "key_bits": int(key_bytes * 8), "sort_passes": passes,

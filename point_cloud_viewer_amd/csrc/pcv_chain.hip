@@ -139,7 +139,8 @@ __global__ __launch_bounds__(256) void depth_probe_kernel(const uint64_t* __rest
     if (l > PCV_MAX_KEY_LEVELS) l = PCV_MAX_KEY_LEVELS;
   }
   for (int o = 32; o > 0; o >>= 1) l = max(l, (uint32_t)__shfl_xor((int)l, o, 64));
-  if ((threadIdx.x & 63) == 0 && l) atomicMax(max_shared_levels, l);
+  // one atomic per wave only when it would raise the maximum (a plain read first keeps 4096 waves off one address)
+  if ((threadIdx.x & 63) == 0 && l > *(volatile uint32_t*)max_shared_levels) atomicMax(max_shared_levels, l);
 }
 
 // Division self-test: pcv_div_code against IEEE division for every code and both divisors (exhaustive), and
