@@ -37,12 +37,14 @@ ALGO_BYTES = {
 }
 
 
-def make_cloud(torch, n, seed, device, clusters=64, extent=1000.0, sigma=(1.0, 20.0), chunk=1 << 24):
+def make_cloud(torch, n, seed, device, clusters=64, extent=1000.0, sigma=(1.0, 20.0), chunk=1 << 24,
+               offset=(0.0, 0.0, 0.0)):
     """Config-2 distribution generated on the device (centres/sigmas from a host generator so every rank
     shares them)."""
     import numpy as np
     rng = np.random.Generator(np.random.PCG64(12345))
-    centres = torch.tensor(rng.uniform(0.0, extent, (clusters, 3)), dtype=torch.float64, device=device)
+    centres = torch.tensor(rng.uniform(0.0, extent, (clusters, 3)) + np.asarray(offset), dtype=torch.float64,
+                           device=device)
     sigmas = torch.tensor(rng.uniform(sigma[0], sigma[1], clusters), dtype=torch.float64, device=device)
     g = torch.Generator(device=device)
     g.manual_seed(seed)
@@ -70,6 +72,8 @@ def main():
     ap.add_argument("--points", type=int, default=100_000_000, help="points per GPU")
     ap.add_argument("--resolution", type=float, default=0.001)
     ap.add_argument("--cpu-sample", type=int, default=50_000_000, help="points of the workload timed on the CPU")
+    ap.add_argument("--ecef", action="store_true",
+                    help="BASELINE config 5: place the cloud at ECEF magnitudes (|p| ~ 6.4e6 m)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with HIP events")
     args = ap.parse_args()
@@ -94,7 +98,8 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     n = args.points
-    x, y, z, rgb = make_cloud(torch, n, seed=1 + rank, device=dev)
+    offset = (-2.7e6, -4.3e6, 3.8e6) if args.ecef else (0.0, 0.0, 0.0)
+    x, y, z, rgb = make_cloud(torch, n, seed=1 + rank, device=dev, offset=offset)
     ctx = pcv.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
 
     if world == 1:
@@ -200,7 +205,8 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "BASELINE config 2: 100 M Gaussian-cluster points (64 clusters, 1000 m cube, "
+            "config": {"workload": ("BASELINE config 5 (ECEF-offset f64 input): " if args.ecef else "BASELINE config 2: ") +
+                                   f"{n / 1e6:g} M Gaussian-cluster points (64 clusters, 1000 m cube, "
                                    "sigma 1-20 m), f64 SoA xyz + u8 rgb, resolution 1 mm, full build + LOD promotion",
                        "points_per_gpu": n, "resolution": args.resolution, "nodes": info.get("nodes"),
                        "parallelism": "1 GPU" if world == 1 else f"root-octant sharding over {world} GPUs, one all-to-all"},
