@@ -64,6 +64,27 @@ int pcv_ctx::dev_alloc(void** p, size_t bytes) {
   return PCV_OK;
 }
 void pcv_ctx::dev_free(void* p) { pool.release(p); }
+int pcv_ctx::host_alloc(void** p, size_t bytes) {
+  if (bytes == 0) bytes = 256;
+  auto it = host_free.lower_bound(bytes);
+  if (it != host_free.end() && it->first <= bytes * 2 + (1u << 20)) {
+    *p = it->second;
+    host_live[*p] = it->first;
+    host_free.erase(it);
+    return PCV_OK;
+  }
+  hipError_t e = hipHostMalloc(p, bytes, hipHostMallocDefault);
+  if (e != hipSuccess) return fail(PCV_E_OOM, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+  host_live[*p] = bytes;
+  return PCV_OK;
+}
+void pcv_ctx::host_release(void* p) {
+  if (!p) return;
+  auto it = host_live.find(p);
+  if (it == host_live.end()) return;
+  host_free.insert({it->second, p});
+  host_live.erase(it);
+}
 int pcv_ctx::pinned_reserve(size_t bytes) {
   if (bytes <= pinned_bytes) return PCV_OK;
   if (pinned) (void)hipHostFree(pinned);
@@ -164,6 +185,8 @@ extern "C" void pcv_ctx_destroy(pcv_ctx* ctx) {
   ctx->pool.trim();
   for (auto& kv : ctx->pool.live) (void)hipFree(kv.first);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  for (auto& kv : ctx->host_free) (void)hipHostFree(kv.second);
+  for (auto& kv : ctx->host_live) (void)hipHostFree(kv.first);
   for (auto& e : ctx->ev)
     if (e) (void)hipEventDestroy(e);
   for (auto& p : ctx->prof_pending) {
@@ -182,6 +205,8 @@ extern "C" int pcv_ctx_trim(pcv_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   ctx->pool.trim();
+  for (auto& kv : ctx->host_free) (void)hipHostFree(kv.second);
+  ctx->host_free.clear();
   return PCV_OK;
 }
 
@@ -346,6 +371,9 @@ extern "C" void pcv_octree_free(pcv_octree* t) {
   if (!t) return;
   if (t->ctx) {
     pcv_octree_release_query(t);
+    t->ctx->host_release(t->h_xyz.p);
+    t->ctx->host_release(t->h_rgb.p);
+    t->ctx->host_release(t->h_int.p);
     t->ctx->dev_free(t->d_xyz);
     t->ctx->dev_free(t->d_rgb);
     t->ctx->dev_free(t->d_int);
@@ -392,9 +420,10 @@ int pcv_octree_fetch_host(pcv_octree* t) {
   if (t->host_valid) return PCV_OK;
   pcv_ctx* ctx = t->ctx;
   PCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  t->h_xyz.resize(t->xyz_bytes);
-  t->h_rgb.resize(t->rgb_bytes);
-  t->h_int.resize(t->int_bytes);
+  int hrc;
+  if (t->xyz_bytes && (hrc = ctx->host_alloc((void**)&t->h_xyz.p, t->xyz_bytes))) return hrc;
+  if (t->rgb_bytes && (hrc = ctx->host_alloc((void**)&t->h_rgb.p, t->rgb_bytes))) return hrc;
+  if (t->int_bytes && (hrc = ctx->host_alloc((void**)&t->h_int.p, t->int_bytes))) return hrc;
   if (t->xyz_bytes) PCV_HIP_CHECK(ctx, hipMemcpyAsync(t->h_xyz.data(), t->d_xyz, t->xyz_bytes, hipMemcpyDeviceToHost, ctx->stream));
   if (t->rgb_bytes) PCV_HIP_CHECK(ctx, hipMemcpyAsync(t->h_rgb.data(), t->d_rgb, t->rgb_bytes, hipMemcpyDeviceToHost, ctx->stream));
   if (t->int_bytes) PCV_HIP_CHECK(ctx, hipMemcpyAsync(t->h_int.data(), t->d_int, t->int_bytes, hipMemcpyDeviceToHost, ctx->stream));

@@ -85,6 +85,11 @@ struct pcv_ctx {
     last_error = msg;
     return code;
   }
+  // cached pinned host blocks for result blobs (page-locking GBs costs more than the copy itself)
+  std::multimap<size_t, void*> host_free;
+  std::map<void*, size_t> host_live;
+  int host_alloc(void** p, size_t bytes);
+  void host_release(void* p);
   int dev_alloc(void** p, size_t bytes);
   void dev_free(void* p);
   int pinned_reserve(size_t bytes);
@@ -227,7 +232,11 @@ struct pcv_octree {
   std::vector<pcv_node_info> nodes;
   uint8_t *d_xyz = nullptr, *d_rgb = nullptr, *d_int = nullptr;
   uint64_t xyz_bytes = 0, rgb_bytes = 0, int_bytes = 0;
-  std::vector<uint8_t> h_xyz, h_rgb, h_int;
+  // host copies of the blobs, pinned (hipHostMalloc) so the D2H runs at link speed and nothing is zero-filled first
+  struct HostBlob {
+    uint8_t* p = nullptr;
+    uint8_t* data() const { return p; }
+  } h_xyz, h_rgb, h_int;
   bool host_valid = false;
   float stage_ms[PCV_NUM_STAGES] = {};
   int key_levels = 0;    // digit levels the key sort covered (depth speculation)

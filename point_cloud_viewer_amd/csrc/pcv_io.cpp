@@ -11,8 +11,11 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <atomic>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "pcv_internal.h"
@@ -106,17 +109,43 @@ extern "C" int pcv_octree_write_dir(pcv_octree* t, const char* directory) {
   ::mkdir(dir.c_str(), 0777);  // generation.rs:308 "Ignore errors, maybe directory is already there."
   struct stat st;
   if (stat(dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return ctx->fail(PCV_E_IO, "cannot create directory " + dir);
-  for (const pcv_node_info& n : t->nodes) {
-    if (n.num_points == 0) continue;
-    const std::string stem = dir + "/" + node_name(n);
-    const uint64_t np = (uint64_t)n.num_points;
-    if (!write_file(stem + ".xyz", t->h_xyz.data() + n.xyz_offset, np * 3 * (uint64_t)pcv_bytes_per_coordinate(n.encoding)))
-      return ctx->fail(PCV_E_IO, "cannot write " + stem + ".xyz");
-    if (!write_file(stem + ".rgb", t->h_rgb.data() + n.point_offset * 3, np * 3))
-      return ctx->fail(PCV_E_IO, "cannot write " + stem + ".rgb");
-    if (t->has_intensity && !write_file(stem + ".intensity", t->h_int.data() + n.point_offset * 4, np * 4))
-      return ctx->fail(PCV_E_IO, "cannot write " + stem + ".intensity");
-  }
+  // thousands of small files — written by a pool of host threads (the node blobs are already
+  // contiguous in host memory, so every file is one write()).
+  const size_t count = t->nodes.size();
+  unsigned nthreads = std::thread::hardware_concurrency();
+  if (nthreads == 0) nthreads = 4;
+  if (nthreads > 32) nthreads = 32;
+  if (nthreads > count) nthreads = count ? (unsigned)count : 1;
+  std::atomic<size_t> next{0};
+  std::atomic<int> failed{0};
+  std::string first_error;
+  std::mutex err_mu;
+  auto worker = [&]() {
+    for (;;) {
+      const size_t i = next.fetch_add(1);
+      if (i >= count || failed.load()) return;
+      const pcv_node_info& n = t->nodes[i];
+      if (n.num_points == 0) continue;  // node_writer.rs:78-89: empty nodes have no files
+      const std::string stem = dir + "/" + node_name(n);
+      const uint64_t np = (uint64_t)n.num_points;
+      const char* bad = nullptr;
+      if (!write_file(stem + ".xyz", t->h_xyz.data() + n.xyz_offset, np * 3 * (uint64_t)pcv_bytes_per_coordinate(n.encoding)))
+        bad = ".xyz";
+      else if (!write_file(stem + ".rgb", t->h_rgb.data() + n.point_offset * 3, np * 3))
+        bad = ".rgb";
+      else if (t->has_intensity && !write_file(stem + ".intensity", t->h_int.data() + n.point_offset * 4, np * 4))
+        bad = ".intensity";
+      if (bad) {
+        std::lock_guard<std::mutex> g(err_mu);
+        if (!failed.exchange(1)) first_error = "cannot write " + stem + bad;
+      }
+    }
+  };
+  std::vector<std::thread> pool;
+  for (unsigned k = 1; k < nthreads; ++k) pool.emplace_back(worker);
+  worker();
+  for (auto& th : pool) th.join();
+  if (failed.load()) return ctx->fail(PCV_E_IO, first_error);
   std::vector<uint8_t> meta = pcv_encode_meta(t);
   if (!write_file(dir + "/meta.pb", meta.data(), meta.size())) return ctx->fail(PCV_E_IO, "cannot write meta.pb");
   return PCV_OK;
