@@ -241,6 +241,22 @@ int pcv_cull_points(pcv_ctx* ctx, const pcv_shapes* shapes, uint32_t shape_index
 int pcv_cull_node_points(pcv_ctx* ctx, const pcv_shapes* shapes, uint32_t shape_index, pcv_octree* tree, uint64_t node,
                          const double* interval, uint8_t* keep, uint64_t* kept);
 
+/* Batched point query — the per-location work of ParallelIterator::try_for_each_batch
+ * (src/iterator.rs:255-333): nodes_in_location, then for every reported node the FilteredIterator keep mask on the
+ * node's decoded positions, then `retain` — here as a stable compaction in (node traversal order, point order).
+ * Outputs (capacity entries each; `mem` says where they live): decoded f64 x/y/z, rgb (3 B per point) and, when
+ * non-null and the octree has it, intensity. *count = number of points that passed (may exceed capacity: only the
+ * first `capacity` are written). Needs a built octree (device-resident node data). */
+int pcv_query_points(pcv_ctx* ctx, const pcv_shapes* shapes, uint32_t shape_index, pcv_octree* tree, const double* interval,
+                     uint64_t capacity, int mem, double* x, double* y, double* z, uint8_t* rgb, float* intensity,
+                     uint64_t* count);
+
+/* The `/nodes_data` reply blob of octree_web_viewer (octree_web_viewer/src/backend.rs:90-177) for a list of nodes:
+ * per node min xyz (3 x f64 LE), edge (f64), num_points (u32), bytes per coordinate (u8), pad to 8, raw .xyz, pad
+ * to 8, raw .rgb, pad to 8. *needed = blob size; the blob is written when out != NULL and capacity >= *needed. */
+int pcv_octree_nodes_blob(pcv_octree* t, const uint64_t* node_indices, uint64_t count, uint8_t* out, uint64_t capacity,
+                          uint64_t* needed);
+
 /* Q5: Isometry3 * Point3 for a batch (xray/src/generation.rs:493-497; Aabb::transform aabb.rs:58-66 uses the
  * same product). iso = translation xyz, unit quaternion i j k w. Outputs live where the inputs live. */
 int pcv_transform_points(pcv_ctx* ctx, const double iso[7], const pcv_points* points, double* ox, double* oy, double* oz);

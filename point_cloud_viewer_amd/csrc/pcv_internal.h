@@ -54,6 +54,7 @@ enum PcvKernelId {
   PCV_K_NODES_IN_LOCATION,
   PCV_K_CULL_POINTS,
   PCV_K_TRANSFORM_POINTS,
+  PCV_K_QUERY_COMPACT,
   PCV_K_COUNT
 };
 

@@ -527,6 +527,151 @@ __global__ __launch_bounds__(256) void transform_points_kernel(uint64_t n, const
   oz[i] = r.z;
 }
 
+// ---- batched point query (the work of ParallelIterator + FilteredIterator for one location) -------
+struct QueryJob {
+  uint64_t xyz_off;    // byte offset of the node's encoded positions in the xyz blob
+  uint64_t point_off;  // point offset in the rgb / intensity blobs
+  uint64_t first;      // index of the node's first point in the concatenated job space
+  uint32_t n;
+  uint32_t enc;
+  double cube_min[3];
+  double cube_edge;
+};
+
+__device__ __forceinline__ uint32_t find_job(const QueryJob* __restrict__ jobs, uint32_t njobs, uint64_t i) {
+  uint32_t lo = 0, hi = njobs;  // last job with first <= i
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (jobs[mid].first <= i) lo = mid;
+    else hi = mid;
+  }
+  return lo;
+}
+
+__device__ __forceinline__ V3d job_point(const QueryJob& jb, const uint8_t* __restrict__ xyz_blob, uint64_t k) {
+  PointsView v{};
+  v.encoded = xyz_blob + jb.xyz_off;
+  v.enc = jb.enc;
+  v.cube_min[0] = jb.cube_min[0];
+  v.cube_min[1] = jb.cube_min[1];
+  v.cube_min[2] = jb.cube_min[2];
+  v.cube_edge = jb.cube_edge;
+  return load_point(v, k);
+}
+
+__device__ __forceinline__ bool shape_contains(const PcvShapeDev* __restrict__ shape, V3d p) {
+  switch (shape->kind) {
+    case PCV_SHAPE_AABB:
+      return shape->bmin[0] <= p.x && shape->bmin[1] <= p.y && shape->bmin[2] <= p.z && p.x < shape->bmax[0] &&
+             p.y < shape->bmax[1] && p.z < shape->bmax[2];
+    case PCV_SHAPE_FRUSTUM:
+    case PCV_SHAPE_FRUSTUM_WITH_INVERSE: {
+      const V3d c = m4_transform_point(shape->clip_from_query, p);
+      const double mn = fmin(fmin(c.x, c.y), c.z), mx = fmax(fmax(c.x, c.y), c.z);
+      return mn > -1.0 && mx < 1.0;
+    }
+    case PCV_SHAPE_OBB: {
+      const V3d q = v_add(quat_rotate(shape->iso + 3, p), V3d{shape->iso[0], shape->iso[1], shape->iso[2]});
+      return fabs(q.x) <= shape->half[0] && fabs(q.y) <= shape->half[1] && fabs(q.z) <= shape->half[2];
+    }
+    default: return true;
+  }
+}
+
+// pass 1: keep flag per point of every job + kept count per workgroup
+__global__ __launch_bounds__(256) void query_flags_kernel(const PcvShapeDev* __restrict__ shape,
+                                                           const QueryJob* __restrict__ jobs, uint32_t njobs, uint64_t total,
+                                                           const uint8_t* __restrict__ xyz_blob,
+                                                           const float* __restrict__ inten_blob, int has_interval, double lo,
+                                                           double hi, uint8_t* __restrict__ keep,
+                                                           uint32_t* __restrict__ block_counts) {
+  __shared__ uint32_t wave_cnt[4];
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  bool k = false;
+  if (i < total) {
+    const QueryJob jb = jobs[find_job(jobs, njobs, i)];
+    const uint64_t kk = i - jb.first;
+    k = shape_contains(shape, job_point(jb, xyz_blob, kk));
+    if (has_interval) {
+      const double a = (double)inten_blob[jb.point_off + kk];
+      k = k && (lo <= a && a <= hi);
+    }
+    keep[i] = k ? 1 : 0;
+  }
+  const unsigned long long b = __ballot(k);
+  if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = (uint32_t)__popcll(b);
+  __syncthreads();
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+}
+
+// exclusive scan of nb counters by one workgroup; total to out_total
+__global__ __launch_bounds__(1024) void query_scan_kernel(uint32_t* __restrict__ counts, uint32_t nb,
+                                                           unsigned long long* __restrict__ out_total) {
+  __shared__ unsigned long long wave_tot[16];
+  __shared__ unsigned long long running;
+  if (threadIdx.x == 0) running = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (uint32_t base = 0; base < nb; base += 1024) {
+    const uint32_t idx = base + threadIdx.x;
+    const unsigned long long v = idx < nb ? counts[idx] : 0ull;
+    unsigned long long inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      unsigned long long t = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += t;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    unsigned long long woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      woff += (w < wave) ? wave_tot[w] : 0ull;
+      tot += wave_tot[w];
+    }
+    // positions fit u32 per octree (n < 2^32); keep the exclusive prefix in place
+    if (idx < nb) counts[idx] = (uint32_t)(running + woff + inc - v);
+    __syncthreads();
+    if (threadIdx.x == 0) running += tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out_total = running;
+}
+
+// pass 2: stable compaction — decoded f64 positions, colours and intensity of the kept points, in job order
+__global__ __launch_bounds__(256) void query_compact_kernel(const QueryJob* __restrict__ jobs, uint32_t njobs, uint64_t total,
+                                                             const uint8_t* __restrict__ xyz_blob,
+                                                             const uint8_t* __restrict__ rgb_blob,
+                                                             const float* __restrict__ inten_blob,
+                                                             const uint8_t* __restrict__ keep,
+                                                             const uint32_t* __restrict__ block_offsets, uint64_t capacity,
+                                                             double* __restrict__ ox, double* __restrict__ oy,
+                                                             double* __restrict__ oz, uint8_t* __restrict__ orgb,
+                                                             float* __restrict__ ointen) {
+  __shared__ uint32_t wave_cnt[4];
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool k = i < total && keep[i];
+  const unsigned long long b = __ballot(k);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(b);
+  __syncthreads();
+  if (!k) return;
+  uint32_t pos = block_offsets[blockIdx.x] + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+  for (int w = 0; w < wave; ++w) pos += wave_cnt[w];
+  if (pos >= capacity) return;
+  const QueryJob jb = jobs[find_job(jobs, njobs, i)];
+  const uint64_t kk = i - jb.first;
+  const V3d p = job_point(jb, xyz_blob, kk);
+  ox[pos] = p.x;
+  oy[pos] = p.y;
+  oz[pos] = p.z;
+  const uint8_t* c = rgb_blob + 3 * (jb.point_off + kk);
+  orgb[3 * (uint64_t)pos] = c[0];
+  orgb[3 * (uint64_t)pos + 1] = c[1];
+  orgb[3 * (uint64_t)pos + 2] = c[2];
+  if (ointen) ointen[pos] = inten_blob[jb.point_off + kk];
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -947,5 +1092,145 @@ extern "C" int pcv_transform_points(pcv_ctx* ctx, const double iso[7], const pcv
   }
   PCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->prof_resolve();
+  return PCV_OK;
+}
+
+// N3: nodes_in_location + per-point culling + stable compaction for one location in a handful of launches.
+extern "C" int pcv_query_points(pcv_ctx* ctx, const pcv_shapes* shapes, uint32_t shape_index, pcv_octree* tree,
+                                const double* interval, uint64_t capacity, int mem, double* x, double* y, double* z,
+                                uint8_t* rgb, float* intensity, uint64_t* count) {
+  if (!ctx) return PCV_E_INVALID;
+  if (!shapes || shape_index >= shapes->count || !tree || !count) return ctx->fail(PCV_E_INVALID, "bad argument");
+  if (capacity && (!x || !y || !z || !rgb)) return ctx->fail(PCV_E_INVALID, "null output");
+  if (mem != PCV_MEM_HOST && mem != PCV_MEM_DEVICE) return ctx->fail(PCV_E_INVALID, "bad mem");
+  *count = 0;
+  if (tree->nodes.empty()) return PCV_OK;
+  if (!tree->d_xyz) return ctx->fail(PCV_E_INVALID, "octree has no device-resident node data (opened from a directory)");
+  if (interval && !tree->has_intensity) return ctx->fail(PCV_E_INVALID, "octree has no intensity attribute to filter on");
+  int rc = pcv_octree_prepare_query(tree);
+  if (rc) return rc;
+  PCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  PcvScratch sc(ctx);
+  const uint32_t m = tree->query->m;
+  // 1. PointCloud::nodes_in_location for this one shape
+  uint32_t *d_cnt, *d_nodes, *d_queue;
+  if ((rc = sc.get(&d_cnt, 1)) || (rc = sc.get(&d_nodes, m)) || (rc = sc.get(&d_queue, m))) return rc;
+  QTree qt{m, tree->query->cubes, tree->query->first_child, tree->query->child_mask, tree->query->empty};
+  {
+    PcvProf prof(ctx, PCV_K_NODES_IN_LOCATION);
+    hipLaunchKernelGGL(nodes_in_location_kernel, dim3(1), dim3(64), 0, ctx->stream, shapes->dev + shape_index, 0u, 1u, qt,
+                       tree->query->fb_cubes, d_queue, m, d_cnt, d_nodes);
+  }
+  uint32_t nn = 0;
+  std::vector<uint32_t> nodes(m);
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(&nn, d_cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(nodes.data(), d_nodes, 4 * (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
+  PCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  // 2. one job per non-empty node, in traversal order
+  std::vector<QueryJob> jobs;
+  uint64_t total = 0;
+  for (uint32_t k = 0; k < nn; ++k) {
+    const pcv_node_info& nd = tree->nodes[nodes[k]];
+    if (nd.num_points <= 0) continue;
+    QueryJob jb;
+    jb.xyz_off = nd.xyz_offset;
+    jb.point_off = nd.point_offset;
+    jb.first = total;
+    jb.n = (uint32_t)nd.num_points;
+    jb.enc = nd.encoding;
+    for (int a = 0; a < 3; ++a) jb.cube_min[a] = nd.cube_min[a];
+    jb.cube_edge = nd.cube_edge;
+    jobs.push_back(jb);
+    total += (uint64_t)nd.num_points;
+  }
+  if (total == 0) return PCV_OK;
+  const uint32_t njobs = (uint32_t)jobs.size();
+  const uint32_t nb = (uint32_t)((total + 255) / 256);
+  QueryJob* d_jobs;
+  uint8_t* d_keep;
+  uint32_t* d_bc;
+  unsigned long long* d_total;
+  if ((rc = sc.get(&d_jobs, njobs)) || (rc = sc.get(&d_keep, total)) || (rc = sc.get(&d_bc, nb)) || (rc = sc.get(&d_total, 1)))
+    return rc;
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_jobs, jobs.data(), sizeof(QueryJob) * njobs, hipMemcpyHostToDevice, ctx->stream));
+  {
+    PcvProf prof(ctx, PCV_K_CULL_POINTS);
+    hipLaunchKernelGGL(query_flags_kernel, dim3(nb), dim3(256), 0, ctx->stream, shapes->dev + shape_index, d_jobs, njobs, total,
+                       tree->d_xyz, (const float*)tree->d_int, interval ? 1 : 0, interval ? interval[0] : 0.0,
+                       interval ? interval[1] : 0.0, d_keep, d_bc);
+  }
+  hipLaunchKernelGGL(query_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_bc, nb, d_total);
+  unsigned long long kept = 0;
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(&kept, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
+  PCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // also keeps `jobs` alive until the copy is done
+  *count = kept;
+  const uint64_t nout = kept < capacity ? kept : capacity;
+  if (nout) {
+    double *dx = x, *dy = y, *dz = z;
+    uint8_t* drgb = rgb;
+    float* dint = intensity;
+    const bool want_int = intensity != nullptr && tree->has_intensity;
+    if (mem == PCV_MEM_HOST) {
+      if ((rc = sc.get(&dx, nout)) || (rc = sc.get(&dy, nout)) || (rc = sc.get(&dz, nout)) || (rc = sc.get(&drgb, 3 * nout))) return rc;
+      if (want_int && (rc = sc.get(&dint, nout))) return rc;
+    }
+    {
+      PcvProf prof(ctx, PCV_K_QUERY_COMPACT);
+      hipLaunchKernelGGL(query_compact_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_jobs, njobs, total, tree->d_xyz,
+                         tree->d_rgb, (const float*)tree->d_int, d_keep, d_bc, nout, dx, dy, dz, drgb, want_int ? dint : nullptr);
+    }
+    PCV_HIP_CHECK(ctx, hipGetLastError());
+    if (mem == PCV_MEM_HOST) {
+      PCV_HIP_CHECK(ctx, hipMemcpyAsync(x, dx, 8 * nout, hipMemcpyDeviceToHost, ctx->stream));
+      PCV_HIP_CHECK(ctx, hipMemcpyAsync(y, dy, 8 * nout, hipMemcpyDeviceToHost, ctx->stream));
+      PCV_HIP_CHECK(ctx, hipMemcpyAsync(z, dz, 8 * nout, hipMemcpyDeviceToHost, ctx->stream));
+      PCV_HIP_CHECK(ctx, hipMemcpyAsync(rgb, drgb, 3 * nout, hipMemcpyDeviceToHost, ctx->stream));
+      if (want_int) PCV_HIP_CHECK(ctx, hipMemcpyAsync(intensity, dint, 4 * nout, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    PCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  ctx->prof_resolve();
+  return PCV_OK;
+}
+
+// N4: the /nodes_data reply blob of octree_web_viewer (octree_web_viewer/src/backend.rs:90-177): per node
+// min xyz (3 x f64 LE), edge (f64), num_points (u32), bytes per coordinate (u8), pad to 8, raw .xyz, pad to 8,
+// raw .rgb, pad to 8. Returns the blob size in *needed; writes it when it fits in `capacity`.
+extern "C" int pcv_octree_nodes_blob(pcv_octree* t, const uint64_t* node_indices, uint64_t count, uint8_t* out,
+                                     uint64_t capacity, uint64_t* needed) {
+  if (!t || !needed || (count && !node_indices)) return PCV_E_INVALID;
+  auto pad8 = [](uint64_t v) { return (v + 7) & ~7ull; };
+  uint64_t size = 0;
+  for (uint64_t k = 0; k < count; ++k) {
+    if (node_indices[k] >= t->nodes.size()) return t->ctx->fail(PCV_E_NOT_FOUND, "Could not get node.");
+    const pcv_node_info& nd = t->nodes[node_indices[k]];
+    const uint64_t np = (uint64_t)nd.num_points;
+    size += pad8(32 + 4 + 1) + pad8(np * 3 * (uint64_t)pcv_bytes_per_coordinate(nd.encoding)) + pad8(np * 3);
+  }
+  *needed = size;
+  if (!out || capacity < size) return PCV_OK;
+  uint8_t* w = out;
+  for (uint64_t k = 0; k < count; ++k) {
+    const pcv_node_info& nd = t->nodes[node_indices[k]];
+    const uint8_t *xyz, *rgbp;
+    uint64_t lx, lr;
+    int rc = pcv_octree_node_data(t, node_indices[k], 0, &xyz, &lx);
+    if (rc) return rc;
+    if ((rc = pcv_octree_node_data(t, node_indices[k], 1, &rgbp, &lr))) return rc;
+    uint8_t* start = w;
+    std::memcpy(w, nd.cube_min, 24);
+    std::memcpy(w + 24, &nd.cube_edge, 8);
+    const uint32_t np32 = (uint32_t)nd.num_points;
+    std::memcpy(w + 32, &np32, 4);
+    w[36] = (uint8_t)pcv_bytes_per_coordinate(nd.encoding);
+    w += 37;
+    while ((uint64_t)(w - start) % 8) *w++ = 0;
+    std::memcpy(w, xyz, lx);
+    w += lx;
+    while ((uint64_t)(w - out) % 8) *w++ = 0;
+    std::memcpy(w, rgbp, lr);
+    w += lr;
+    while ((uint64_t)(w - out) % 8) *w++ = 0;
+  }
   return PCV_OK;
 }

@@ -190,3 +190,66 @@ def test_open_dir_round_trip_and_query(ctx, scene, tmp_path):
     assert all(np.array_equal(p, q) for p, q in zip(va, vb))
     with pytest.raises(pcv.PcvError):
         ctx.open_dir(tmp_path / "missing")
+
+
+def test_query_points_batched(ctx, scene):
+    """pcv_query_points == for node in nodes_in_location: decode, FilteredIterator keep mask, retain (iterator.rs)."""
+    rng = np.random.default_rng(9)
+    fr = random_frusta(rng, scene["bmin"], scene["bmax"], 6)
+    obb = (scene["bmin"] + 45, O.quat_from_axis_angle([1.0, 0.0, 0.0], 0.5), [30.0, 20.0, 15.0])
+    shapes = [("frustum2", *fr[i]) for i in range(6)] + [("obb", *obb), ("aabb", scene["bmin"] + 10, scene["bmin"] + 60), ("all",)]
+    kinds = [(O.SHAPE_FRUSTUM2, np.concatenate(fr[i])) for i in range(6)]
+    kinds += [(O.SHAPE_OBB, list(obb[0]) + list(obb[1]) + list(obb[2])),
+              (O.SHAPE_AABB, list(scene["bmin"] + 10) + list(scene["bmin"] + 60)), (O.SHAPE_ALL, None)]
+    prepared = ctx.shapes(shapes)
+    tree, on = scene["tree"], scene["oracle"].nodes
+    nonempty = 0
+    for i, (kind, params) in enumerate(kinds):
+        for interval in (None, (20.0, 180.0)):
+            got = tree.query_points(prepared, i, interval=interval)
+            wx, wy, wz, wrgb, wint = [], [], [], [], []
+            for name in O.nodes_in_location(scene["bmin"], scene["bmax"], on, kind, params):
+                nd = on[name]
+                if nd["num_points"] == 0:
+                    continue
+                hi, lo = nd["id"]
+                idx = scene["names"].index(name)
+                info = tree.node(idx)
+                px, py, pz = O.decode_positions(nd["encoding"], info.cube_min, info.cube_edge, nd["xyz"])
+                inten = np.frombuffer(nd["intensity"], dtype=np.float32)
+                keep = O.cull_points(kind, params, px, py, pz, inten if interval else None, interval).astype(bool)
+                wx.append(px[keep]); wy.append(py[keep]); wz.append(pz[keep])
+                wrgb.append(np.frombuffer(nd["rgb"], dtype=np.uint8).reshape(-1, 3)[keep])
+                wint.append(inten[keep])
+            cat = lambda parts, dt: np.concatenate(parts) if parts else np.zeros(0, dtype=dt)
+            assert got["count"] == sum(len(p) for p in wx), (i, interval)
+            assert np.array_equal(got["x"], cat(wx, np.float64)) and np.array_equal(got["y"], cat(wy, np.float64))
+            assert np.array_equal(got["z"], cat(wz, np.float64))
+            assert np.array_equal(got["rgb"].reshape(-1, 3), cat(wrgb, np.uint8).reshape(-1, 3))
+            assert np.array_equal(got["intensity"], cat(wint, np.float32))
+            nonempty += got["count"] > 0
+    assert nonempty >= 6
+    everything = tree.query_points(prepared, 8)
+    assert everything["count"] == tree.num_points  # AllPoints returns the whole cloud
+    small = tree.query_points(prepared, 8, capacity=1000)  # capacity smaller than the result
+    assert small["count"] == tree.num_points and len(small["x"]) == 1000 and np.array_equal(small["x"], everything["x"][:1000])
+
+
+def test_nodes_blob_matches_web_viewer_wire_format(ctx, scene):
+    # octree_web_viewer/src/backend.rs:90-177
+    import struct
+    tree = scene["tree"]
+    picks = [0, 1, tree.num_nodes // 3, tree.num_nodes - 1]
+    want = b""
+
+    def pad(b):
+        return b + b"\0" * ((8 - len(b) % 8) % 8)
+
+    for i in picks:
+        nd = tree.node(i)
+        bpc = {1: 1, 2: 2, 3: 4, 4: 8}[nd.encoding]
+        head = struct.pack("<4dIB", *nd.cube_min, nd.cube_edge, nd.num_points, bpc)
+        want = pad(want + head)
+        want = pad(want + tree.node_data(i, 0))
+        want = pad(want + tree.node_data(i, 1))
+    assert tree.nodes_blob(picks) == want
