@@ -79,27 +79,30 @@ def main():
                       "mean_visible": float(nvis.mean()), "max_visible": int(nvis.max()),
                       "status_nonzero": int((status != 0).sum())}))
 
-    # (c) cull the points of the visible nodes of sampled frusta, decoding the node bytes on the fly
+    # (c) batched point query: nodes_in_location + decode-on-the-fly culling + stable compaction, per frustum
     ctx.reset_kernel_stats()
-    pts = 0
-    enc_bytes = 0
+    sample = list(range(args.cull_frusta))
     kept = 0
-    sample = [f for f in range(args.frusta) if len(vis[f]) > 0][:args.cull_frusta]
     t0 = time.perf_counter()
     for f in sample:
-        for node in vis[f]:
-            nd = tree.node(int(node))
-            k, c = tree.cull_node_points(shapes, f, int(node))
-            pts += nd.num_points
-            enc_bytes += nd.num_points * 3 * {1: 1, 2: 2, 3: 4, 4: 8}[nd.encoding]
-            kept += c
+        r = tree.query_points(shapes, f, capacity=1 << 22)
+        kept += r["count"]
     wall_c = time.perf_counter() - t0
-    ks = ctx.kernel_stats()["cull_points_kernel"]
-    print(json.dumps({"part": "cull_points", "frusta": len(sample), "launches": ks[0], "points": pts, "kept": kept,
-                      "kernel_ms": round(ks[1], 3),
-                      "points_per_s_kernel": round(pts / (ks[1] * 1e-3), 1) if ks[1] else None,
-                      "encoded_GB_per_s_kernel": round((enc_bytes + pts) / (ks[1] * 1e-3) / 1e9, 2) if ks[1] else None,
-                      "wall_ms_incl_per_node_calls": round(wall_c * 1e3, 1)}))
+    st = ctx.kernel_stats()
+    kms = st["cull_points_kernel"][1] + st["query_compact_kernel"][1] + st["nodes_in_location_kernel"][1]
+    print(json.dumps({"part": "query_points", "frusta": len(sample), "kept_points": kept,
+                      "kernel_ms": round(kms, 3), "cull_kernel_ms": round(st["cull_points_kernel"][1], 3),
+                      "frusta_per_s_kernel": round(len(sample) / (kms * 1e-3), 1),
+                      "wall_ms_incl_D2H_and_python": round(wall_c * 1e3, 1)}))
+    # one large location (an AABB covering a quarter of the cloud per axis) to see the streaming rate
+    big = ctx.shapes([("aabb", bmin, bmin + (bmax - bmin) * 0.63)])
+    ctx.reset_kernel_stats()
+    r = tree.query_points(big, 0, capacity=1)
+    st = ctx.kernel_stats()
+    tested = None
+    print(json.dumps({"part": "query_points_big_aabb", "kept_points": r["count"],
+                      "cull_kernel_ms": round(st["cull_points_kernel"][1], 3),
+                      "compact_kernel_ms": round(st["query_compact_kernel"][1], 3)}))
 
     # CPU restatement (1 thread) on a bounded sample
     cubes = np.array([[*tree.node(i).cube_min, tree.node(i).cube_edge] for i in range(M)])

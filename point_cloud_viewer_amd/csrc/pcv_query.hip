@@ -768,6 +768,8 @@ struct PcvOctreeQuery {
   uint32_t* first_child = nullptr;
   uint8_t* child_mask = nullptr;
   uint8_t* empty = nullptr;
+  std::vector<uint32_t> h_first_child;  // host copies for host-side traversals
+  std::vector<uint8_t> h_child_mask;
 };
 
 int pcv_octree_prepare_query(pcv_octree* t) {
@@ -830,6 +832,8 @@ int pcv_octree_prepare_query(pcv_octree* t) {
   }
   PcvOctreeQuery* q = new PcvOctreeQuery();
   q->m = m;
+  q->h_first_child = first;
+  q->h_child_mask = mask;
   void* p;
   int rc;
   size_t bytes = (size_t)(m + 1) * (64 + 4 + 2);
@@ -1112,20 +1116,34 @@ extern "C" int pcv_query_points(pcv_ctx* ctx, const pcv_shapes* shapes, uint32_t
   PCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   PcvScratch sc(ctx);
   const uint32_t m = tree->query->m;
-  // 1. PointCloud::nodes_in_location for this one shape
-  uint32_t *d_cnt, *d_nodes, *d_queue;
-  if ((rc = sc.get(&d_cnt, 1)) || (rc = sc.get(&d_nodes, m)) || (rc = sc.get(&d_queue, m))) return rc;
-  QTree qt{m, tree->query->cubes, tree->query->first_child, tree->query->child_mask, tree->query->empty};
+  // 1. PointCloud::nodes_in_location for this one shape: the Relation of every node cube in one dense launch
+  //    (same sat() as the traversal kernel), then the breadth-first walk of NodeIdsIterator on the host.
+  uint8_t* d_rel;
+  if ((rc = sc.get(&d_rel, m))) return rc;
   {
-    PcvProf prof(ctx, PCV_K_NODES_IN_LOCATION);
-    hipLaunchKernelGGL(nodes_in_location_kernel, dim3(1), dim3(64), 0, ctx->stream, shapes->dev + shape_index, 0u, 1u, qt,
-                       tree->query->fb_cubes, d_queue, m, d_cnt, d_nodes);
+    PcvProf prof(ctx, PCV_K_CULL_NODES);
+    hipLaunchKernelGGL(cull_nodes_kernel, dim3((m + 255) / 256, 1), dim3(256), 0, ctx->stream, shapes->dev + shape_index, m,
+                       tree->query->fb_cubes, d_rel, (double*)nullptr);
   }
-  uint32_t nn = 0;
-  std::vector<uint32_t> nodes(m);
-  PCV_HIP_CHECK(ctx, hipMemcpyAsync(&nn, d_cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
-  PCV_HIP_CHECK(ctx, hipMemcpyAsync(nodes.data(), d_nodes, 4 * (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
+  std::vector<uint8_t> rel(m);
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(rel.data(), d_rel, m, hipMemcpyDeviceToHost, ctx->stream));
   PCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  std::vector<uint32_t> nodes;
+  nodes.reserve(m);
+  {
+    std::vector<uint32_t> queue;
+    queue.reserve(m);
+    queue.push_back(0);
+    for (size_t head = 0; head < queue.size(); ++head) {
+      const uint32_t cur = queue[head];
+      if (rel[cur] == 2) continue;
+      uint32_t c = tree->query->h_first_child[cur];
+      for (int ci = 0; ci < 8; ++ci)
+        if ((tree->query->h_child_mask[cur] >> ci) & 1) queue.push_back(c++);
+      nodes.push_back(cur);
+    }
+  }
+  const uint32_t nn = (uint32_t)nodes.size();
   // 2. one job per non-empty node, in traversal order
   std::vector<QueryJob> jobs;
   uint64_t total = 0;
