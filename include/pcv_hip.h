@@ -173,6 +173,19 @@ int pcv_sort_pairs32(pcv_ctx* ctx, uint32_t* keys, uint32_t* values, uint64_t n,
 int pcv_selftest_division(pcv_ctx* ctx, const double* divisors, int ndiv, uint64_t samples_per_divisor,
                           uint64_t* mismatches);
 
+/* ---- PLY ingest (host side) --------------------------------------------------------- */
+/* Replaces PlyIterator (src/read_write/ply.rs:328-556): binary little-endian PLY, element `vertex` first; x/y/z of
+ * any scalar type cast to f64 plus the header's `comment offset: x y z`; red/green/blue (uchar) -> colour;
+ * `intensity` (float) kept; alpha and all other properties skipped. One pass; the arrays can go straight into
+ * pcv_build_octree with PCV_BUILD_COMPUTE_BBOX (== build_octree_from_file, generation.rs:272-287).
+ * `err` (nullable) receives a message on failure. */
+typedef struct pcv_ply pcv_ply;
+int pcv_ply_read(const char* path, pcv_ply** out, char* err, uint64_t errcap);
+uint64_t pcv_ply_num_points(const pcv_ply* ply);
+/* Fills `out` with host pointers owned by `ply` (color / intensity are NULL when the file has none). */
+int pcv_ply_points(const pcv_ply* ply, pcv_points* out);
+void pcv_ply_free(pcv_ply* ply);
+
 /* ---- octree loading (viewer side) ------------------------------------------------------------ */
 /* Replaces Octree::from_data_provider over an OnDiskDataProvider (src/octree/mod.rs:156-215,
  * src/data_provider/on_disk.rs): parses meta.pb (versions 9..13 are accepted by the reference; this loader

@@ -5,7 +5,8 @@ libpcv_hip.so (point_cloud_viewer_amd/csrc). Importing does not require a GPU; c
 """
 from . import _lib
 from ._lib import PcvError, load_library  # noqa: F401
-from .octree import Aabb, Context, OctreeResult, Shapes, build_octree, level_table, node_name  # noqa: F401
+from .octree import (Aabb, Context, OctreeResult, Shapes, build_octree, build_octree_from_file, level_table,  # noqa: F401
+                     node_name, read_ply)
 
 __all__ = ["Aabb", "Context", "OctreeResult", "build_octree", "level_table", "node_name", "PcvError",
            "load_library"]

@@ -85,6 +85,10 @@ _SIGNATURES = {
     "pcv_sort_keys64": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, C.c_int, C.c_int]),
     "pcv_sort_pairs32": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.c_int, C.c_int, C.c_int]),
     "pcv_selftest_division": (C.c_int, [_vp, C.POINTER(C.c_double), C.c_int, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "pcv_ply_read": (C.c_int, [C.c_char_p, C.POINTER(_vp), C.c_char_p, C.c_uint64]),
+    "pcv_ply_num_points": (C.c_uint64, [_vp]),
+    "pcv_ply_points": (C.c_int, [_vp, C.POINTER(Points)]),
+    "pcv_ply_free": (None, [_vp]),
     "pcv_octree_open_dir": (C.c_int, [_vp, C.c_char_p, C.POINTER(_vp)]),
     "pcv_shapes_create": (C.c_int, [_vp, C.POINTER(Shape), C.c_uint32, C.POINTER(_vp)]),
     "pcv_shapes_free": (None, [_vp]),

@@ -20,7 +20,13 @@ namespace {
 constexpr int kBlock = 256;  // 4 waves
 constexpr int kWaves = kBlock / 64;
 constexpr int kRadix = 256;
-constexpr int kMaxGroups = 1024;
+#ifndef PCV_SORT_GROUPS
+#define PCV_SORT_GROUPS 1024
+#endif
+#ifndef PCV_KEYS_WAVES
+#define PCV_KEYS_WAVES 4
+#endif
+constexpr int kMaxGroups = PCV_SORT_GROUPS;
 constexpr int kKptKeys = 16;  // keys-only kernel: keys per lane per tile
 constexpr int kKptRec = 8;    // record kernel
 constexpr int kTileUnit = kBlock * kKptKeys;  // chunk granularity (multiple of both tile sizes)
@@ -58,7 +64,18 @@ __global__ __launch_bounds__(kBlock) void upsweep_kernel(const KeyT* __restrict_
   typedef KeyT VecT __attribute__((ext_vector_type(kVec)));
   // chunk is a multiple of the tile and buffers come from the pool (256-B aligned) => 16-byte loads are aligned
   uint64_t i = begin + (uint64_t)threadIdx.x * kVec;
-  for (; i + kVec <= end; i += (uint64_t)kBlock * kVec) {
+  constexpr uint64_t kStep = (uint64_t)kBlock * kVec;
+  // four 16-byte loads in flight per lane: the loop is latency bound otherwise
+  for (; i + 3 * kStep + kVec <= end; i += 4 * kStep) {
+    VecT v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const VecT*>(keys + i + u * kStep);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int k = 0; k < kVec; ++k) atomicAdd(&wh[wave][(uint32_t)(v[u][k] >> shift) & mask], 1u);
+  }
+  for (; i + kVec <= end; i += kStep) {
     VecT v = *reinterpret_cast<const VecT*>(keys + i);
 #pragma unroll
     for (int k = 0; k < kVec; ++k) atomicAdd(&wh[wave][(uint32_t)(v[k] >> shift) & mask], 1u);
@@ -79,12 +96,15 @@ __global__ __launch_bounds__(256) void scan_kernel(uint32_t* __restrict__ hist, 
                                                     uint32_t* __restrict__ totals) {
   __shared__ uint32_t wave_tot[4];
   uint32_t* row = hist + (uint64_t)blockIdx.x * groups;
-  const int per = (groups + 255) / 256;  // <= 4
+  constexpr int kPerMax = (kMaxGroups + 255) / 256;
+  const int per = (groups + 255) / 256;  // <= kPerMax
   const int begin = threadIdx.x * per;
-  uint32_t v[4] = {0, 0, 0, 0};
+  uint32_t v[kPerMax];
   uint32_t sum = 0;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < kPerMax; ++i) v[i] = 0;
+#pragma unroll
+  for (int i = 0; i < kPerMax; ++i)
     if (i < per && begin + i < groups) {
       v[i] = row[begin + i];
       sum += v[i];
@@ -106,7 +126,7 @@ __global__ __launch_bounds__(256) void scan_kernel(uint32_t* __restrict__ hist, 
   }
   uint32_t run = woff + inc - sum;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < kPerMax; ++i)
     if (i < per && begin + i < groups) {
       row[begin + i] = run;
       run += v[i];
@@ -194,7 +214,7 @@ __device__ __forceinline__ void digit_scan(DigitState& S, int t, int lane, int w
 
 // ---- keys only ------------------------------------------------------------------------------------
 template <typename KeyT>
-__global__ __launch_bounds__(kBlock, 4) void downsweep_keys_kernel(const KeyT* __restrict__ keys_in,
+__global__ __launch_bounds__(kBlock, PCV_KEYS_WAVES) void downsweep_keys_kernel(const KeyT* __restrict__ keys_in,
                                                                    KeyT* __restrict__ keys_out, uint64_t n, uint64_t chunk,
                                                                    int groups, int shift, int nbits,
                                                                    const uint32_t* __restrict__ offsets,

@@ -430,6 +430,51 @@ class OctreeResult:
         return out
 
 
+def read_ply(path):
+    """PlyIterator in one pass (src/read_write/ply.rs): dict(x, y, z float64; color (n,3) uint8 or None; intensity or None)."""
+    lib = L.load_library()
+    h = C.c_void_p()
+    err = C.create_string_buffer(512)
+    rc = lib.pcv_ply_read(str(path).encode(), C.byref(h), err, 512)
+    if rc != L.PCV_OK:
+        raise L.PcvError(rc, err.value.decode())
+    try:
+        p = L.Points()
+        lib.pcv_ply_points(h, C.byref(p))
+        n = p.n
+
+        def arr(ptr, ctype, count, dtype):
+            if not ptr or count == 0:
+                return None if not ptr else np.zeros(0, dtype=dtype)
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(count,)).astype(dtype, copy=True)
+
+        out = dict(x=arr(p.x, C.c_double, n, np.float64), y=arr(p.y, C.c_double, n, np.float64),
+                   z=arr(p.z, C.c_double, n, np.float64), color=arr(p.color, C.c_uint8, 3 * n, np.uint8),
+                   intensity=arr(p.intensity, C.c_float, n, np.float32))
+        if n == 0:
+            out["x"] = out["y"] = out["z"] = np.zeros(0)
+        if out["color"] is not None:
+            out["color"] = out["color"].reshape(-1, 3)
+        return out
+    finally:
+        lib.pcv_ply_free(h)
+
+
+def build_octree_from_file(output_directory, resolution, filename, attributes=("color", "intensity"), ctx=None):
+    """Drop-in for reference `build_octree_from_file` (generation.rs:272-287): one parsing pass, bounding box on the
+    device, build, directory write. Like the reference binary (src/bin/build_octree.rs:47-52) the default attribute
+    list asks for intensity; a PLY without it raises (the reference panics)."""
+    pts = read_ply(filename)
+    if pts["color"] is None:
+        raise ValueError("the PLY has no red/green/blue properties; the octree format requires colour")
+    cloud = dict(x=pts["x"], y=pts["y"], z=pts["z"], color=pts["color"])
+    if "intensity" in attributes:
+        if pts["intensity"] is None:
+            raise ValueError("attribute 'intensity' requested but the PLY has none")
+        cloud["intensity"] = pts["intensity"]
+    return build_octree(output_directory, resolution, None, cloud, attributes, ctx)
+
+
 _default_ctx = None
 
 

@@ -208,3 +208,24 @@ def test_depth_speculation_failure_falls_back_to_full_depth(ctx):
     info = t.build_info()
     assert info["attempts"] == 2, info
     assert_same(t.to_dict(), O.build_closed(0.001, bmin, bmax, x, y, z, rgb, threads=8))
+
+
+def test_build_octree_from_file(ctx, tmp_path):
+    """build_octree_from_file (generation.rs:272-287): PLY (f32 coordinates + header offset) -> octree directory."""
+    import struct
+    x, y, z, rgb, _, _ = synthetic.gaussian_clusters(200_000, seed=41, num_clusters=3, extent=80.0, sigma_range=(0.05, 2.0))
+    xf, yf, zf = x.astype(np.float32), y.astype(np.float32), z.astype(np.float32)
+    inten = (np.arange(x.size) % 17).astype(np.float32)
+    off = (500000.25, -4.0e6, 1234.5)
+    with open(tmp_path / "cloud.ply", "wb") as f:
+        f.write((f"ply\nformat binary_little_endian 1.0\ncomment offset: {off[0]!r} {off[1]!r} {off[2]!r}\n"
+                 f"element vertex {x.size}\nproperty float x\nproperty float y\nproperty float z\nproperty uchar red\n"
+                 "property uchar green\nproperty uchar blue\nproperty float intensity\nend_header\n").encode())
+        rec = np.zeros(x.size, dtype=[("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("r", "u1"), ("g", "u1"), ("b", "u1"), ("i", "<f4")])
+        rec["x"], rec["y"], rec["z"], rec["r"], rec["g"], rec["b"], rec["i"] = xf, yf, zf, rgb[:, 0], rgb[:, 1], rgb[:, 2], inten
+        f.write(rec.tobytes())
+    pcv.build_octree_from_file(tmp_path / "gpu", 0.001, tmp_path / "cloud.ply", ctx=ctx)
+    px, py, pz = xf.astype(np.float64) + off[0], yf.astype(np.float64) + off[1], zf.astype(np.float64) + off[2]
+    bmin, bmax = O.aabb(px, py, pz)
+    O.build_literal_dir(tmp_path / "cpu", 0.001, bmin, bmax, px, py, pz, rgb, inten, threads=4)
+    assert not O.compare_octrees(O.load_dir(tmp_path / "gpu"), O.load_dir(tmp_path / "cpu"))

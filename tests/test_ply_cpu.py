@@ -1,0 +1,95 @@
+"""Host-side PLY ingest (pcv_ply_read) against fixtures equivalent to the reference's src/test_data/*.ply
+(8 vertices: xyz = 1..24 as f32, rgb = 255..232, optional alpha / NaN intensity) and the behaviours pinned by
+src/read_write/ply.rs:753-836. The fixtures are generated here (the reference's files are not copied)."""
+import struct
+
+import numpy as np
+import pytest
+
+import point_cloud_viewer_amd as pcv
+
+
+def _write_ply(path, props, rows, extra_header=(), face_element=True):
+    head = ["ply", "format binary_little_endian 1.0", *extra_header, f"element vertex {len(rows)}"]
+    head += [f"property {t} {n}" for t, n in props]
+    if face_element:
+        head += ["element face 0", "property list uchar int vertex_indices"]
+    head += ["end_header"]
+    fmt = "<" + "".join({"float": "f", "double": "d", "uchar": "B", "ushort": "H", "int": "i", "short": "h"}[t]
+                         for t, _ in props)
+    with open(path, "wb") as f:
+        f.write(("\n".join(head) + "\n").encode())
+        for r in rows:
+            f.write(struct.pack(fmt, *r))
+
+
+def _reference_rows(extra=None):
+    rows = []
+    for i in range(8):
+        r = [3 * i + 1.0, 3 * i + 2.0, 3 * i + 3.0, 255 - 3 * i, 254 - 3 * i, 253 - 3 * i]
+        if extra is not None:
+            r.append(extra(i))
+        rows.append(r)
+    return rows
+
+
+XYZ_RGB = [("float", "x"), ("float", "y"), ("float", "z"), ("uchar", "red"), ("uchar", "green"), ("uchar", "blue")]
+
+
+def test_xyz_f32_rgb_u8_le(tmp_path):
+    # ply.rs:753-771 test_xyz_f32_rgb_u8_le
+    _write_ply(tmp_path / "a.ply", XYZ_RGB, _reference_rows())
+    p = pcv.read_ply(tmp_path / "a.ply")
+    assert p["x"].size == 8
+    assert (p["x"][0], p["y"][0], p["z"][0]) == (1.0, 2.0, 3.0) and tuple(p["color"][0]) == (255, 254, 253)
+    assert (p["x"][7], p["y"][7], p["z"][7]) == (22.0, 23.0, 24.0) and tuple(p["color"][7]) == (234, 233, 232)
+    assert p["intensity"] is None
+
+
+def test_xyz_f32_rgba_u8_le_alpha_is_skipped(tmp_path):
+    # ply.rs:773-783: alpha is read past, colours are unchanged
+    _write_ply(tmp_path / "a.ply", XYZ_RGB + [("uchar", "alpha")], _reference_rows(lambda i: 200 + i))
+    p = pcv.read_ply(tmp_path / "a.ply")
+    assert tuple(p["color"][0]) == (255, 254, 253) and tuple(p["color"][7]) == (234, 233, 232)
+    assert p["z"].tolist() == [3.0 * i + 3.0 for i in range(8)]
+
+
+def test_xyz_f32_rgb_u8_intensity_f32(tmp_path):
+    # ply.rs:785-794: intensities are NaN in the fixture
+    _write_ply(tmp_path / "a.ply", XYZ_RGB + [("float", "intensity")], _reference_rows(lambda i: float("nan")))
+    p = pcv.read_ply(tmp_path / "a.ply")
+    assert p["intensity"].dtype == np.float32 and np.isnan(p["intensity"]).all() and p["intensity"].size == 8
+
+
+def test_offset_comment_and_type_casts(tmp_path):
+    # ply.rs:191-204 `comment offset:` + :488-493 cast-then-add; x/y/z of any scalar type; unknown props skipped
+    props = [("double", "x"), ("int", "y"), ("short", "z"), ("ushort", "label"), ("uchar", "r"), ("uchar", "g"), ("uchar", "b")]
+    rows = [[0.125, -7, 3, 65535, 1, 2, 3], [1e6 + 0.5, 2 ** 30, -32768, 0, 4, 5, 6]]
+    _write_ply(tmp_path / "a.ply", props, rows, extra_header=["comment offset: 100.5 -2 1e3", "comment anything else"],
+               face_element=False)
+    p = pcv.read_ply(tmp_path / "a.ply")
+    assert p["x"].tolist() == [0.125 + 100.5, 1e6 + 0.5 + 100.5]
+    assert p["y"].tolist() == [-7.0 - 2.0, float(2 ** 30) - 2.0]
+    assert p["z"].tolist() == [3.0 + 1000.0, -32768.0 + 1000.0]
+    assert p["color"].tolist() == [[1, 2, 3], [4, 5, 6]]
+
+
+def test_rejects_what_the_reference_rejects(tmp_path):
+    (tmp_path / "not.ply").write_bytes(b"plx\n")
+    with pytest.raises(pcv.PcvError, match="Not a PLY file"):
+        pcv.read_ply(tmp_path / "not.ply")
+    (tmp_path / "ascii.ply").write_bytes(b"ply\nformat ascii 1.0\nelement vertex 0\nproperty float x\nproperty float y\n"
+                                         b"property float z\nend_header\n")
+    with pytest.raises(pcv.PcvError, match="Unsupported PLY format"):
+        pcv.read_ply(tmp_path / "ascii.ply")
+    (tmp_path / "noz.ply").write_bytes(b"ply\nformat binary_little_endian 1.0\nelement vertex 0\nproperty float x\n"
+                                       b"property float y\nend_header\n")
+    with pytest.raises(pcv.PcvError, match="'x', 'y', 'z'"):
+        pcv.read_ply(tmp_path / "noz.ply")
+    with pytest.raises(pcv.PcvError, match="Could not open"):
+        pcv.read_ply(tmp_path / "missing.ply")
+    _write_ply(tmp_path / "short.ply", XYZ_RGB, _reference_rows())
+    data = (tmp_path / "short.ply").read_bytes()
+    (tmp_path / "short.ply").write_bytes(data[:-5])
+    with pytest.raises(pcv.PcvError, match="unexpected end of file"):
+        pcv.read_ply(tmp_path / "short.ply")
