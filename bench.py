@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=50_000_000, help="points of the workload timed on the CPU")
     ap.add_argument("--ecef", action="store_true",
                     help="BASELINE config 5: place the cloud at ECEF magnitudes (|p| ~ 6.4e6 m)")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the multi-GPU code path (owner kernel, partition, exchange) even with one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-to-files end-to-end leg (N=1 only)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with HIP events")
@@ -93,17 +95,21 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29517")
+        if world == 1:
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     n = args.points
     offset = (-2.7e6, -4.3e6, 3.8e6) if args.ecef else (0.0, 0.0, 0.0)
     x, y, z, rgb = make_cloud(torch, n, seed=1 + rank, device=dev, offset=offset)
     ctx = pcv.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
 
-    if world == 1:
+    if world == 1 and not args.force_sharded:
         bmin, bmax = ctx.aabb_reduce(x, y, z)  # exact min/max bbox (config 2), outside the timed region
         bbox = pcv.Aabb(bmin, bmax)
         info = {}
@@ -178,7 +184,7 @@ def main():
         encode_sort = None
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.force_sharded:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import shutil
         import tempfile
@@ -201,7 +207,7 @@ def main():
                          f"(oracle/pcv_oracle_build.cpp) on tmpfs, {cores} OpenMP threads, {cdt:.1f} s"}
 
     e2e = None
-    if rank == 0 and world == 1 and not args.no_e2e:
+    if rank == 0 and world == 1 and not args.no_e2e and not args.force_sharded:
         # One untimed-region pass from HOST arrays to files on tmpfs: H2D staging + build, D2H of the node blobs,
         # threaded file writes. Never part of `value` (tier rule (4)); reported so the PCIe / file-system cost is visible.
         import shutil

@@ -161,6 +161,12 @@ int pcv_level_table(const double bbox_min[3], const double bbox_max[3], double r
 int pcv_chain_keys(pcv_ctx* ctx, const pcv_build_params* params, const pcv_points* points, int nlevels,
                    uint64_t* keys /* same memory space as points */);
 
+/* Multi-GPU routing: owner[i] = (root octant of point i) * world / 8, where the root octant is
+ * ChildIndex::from_bounding_cube against the GLOBAL root cube (node.rs:34-42); counts[r] = points owned by rank r.
+ * Device-resident points only; owner is a device buffer of n u32, counts a host array of `world` entries. */
+int pcv_root_owners(pcv_ctx* ctx, const pcv_build_params* params, const pcv_points* points, uint32_t world,
+                    uint32_t* owner, uint64_t* counts);
+
 /* K3: stable LSD radix sort of 64-bit keys on bits [begin_bit, end_bit), in place. */
 int pcv_sort_keys64(pcv_ctx* ctx, uint64_t* keys, uint64_t n, int begin_bit, int end_bit, int mem);
 /* K3: stable sort of (u32 key, u32 value) pairs on bits [begin_bit, end_bit), in place. */

@@ -82,6 +82,7 @@ _SIGNATURES = {
     "pcv_level_table": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_int,
                                   C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "pcv_chain_keys": (C.c_int, [_vp, C.POINTER(BuildParams), C.POINTER(Points), C.c_int, _vp]),
+    "pcv_root_owners": (C.c_int, [_vp, C.POINTER(BuildParams), C.POINTER(Points), C.c_uint32, _vp, C.POINTER(C.c_uint64)]),
     "pcv_sort_keys64": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, C.c_int, C.c_int]),
     "pcv_sort_pairs32": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.c_int, C.c_int, C.c_int]),
     "pcv_selftest_division": (C.c_int, [_vp, C.POINTER(C.c_double), C.c_int, C.c_uint64, C.POINTER(C.c_uint64)]),

@@ -143,6 +143,31 @@ __global__ __launch_bounds__(256) void depth_probe_kernel(const uint64_t* __rest
   if ((threadIdx.x & 63) == 0 && l > *(volatile uint32_t*)max_shared_levels) atomicMax(max_shared_levels, l);
 }
 
+// Multi-GPU routing: owner rank of every point = its root octant (ChildIndex::from_bounding_cube against the
+// root cube, node.rs:34-42 — needs only the point and the global root cube) mapped to contiguous octant ranges,
+// plus the number of points per owner.
+__global__ __launch_bounds__(256) void root_owner_kernel(PcvLevels lv, uint64_t n, const double* __restrict__ x,
+                                                          const double* __restrict__ y, const double* __restrict__ z,
+                                                          uint32_t world, uint32_t* __restrict__ owner,
+                                                          unsigned long long* __restrict__ counts /* [world] */) {
+  __shared__ uint32_t cnt[8];
+  if (threadIdx.x < 8) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    const double e = lv.edge[0];
+    const double cx = (lv.root_min[0] + (lv.root_min[0] + e)) / 2.0;
+    const double cy = (lv.root_min[1] + (lv.root_min[1] + e)) / 2.0;
+    const double cz = (lv.root_min[2] + (lv.root_min[2] + e)) / 2.0;
+    const uint32_t d = ((x[i] > cx ? 1u : 0u) << 2) | ((y[i] > cy ? 1u : 0u) << 1) | (z[i] > cz ? 1u : 0u);
+    const uint32_t o = (d * world) >> 3;
+    owner[i] = o;
+    atomicAdd(&cnt[o], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < world && cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)cnt[threadIdx.x]);
+}
+
 // Division self-test: pcv_div_code against IEEE division for every code and both divisors (exhaustive), and
 // pcv_div_const against IEEE division for pseudo-random numerators (full exponent/mantissa spread, plus values
 // straddling rounding boundaries of the quotient) over a list of divisors.
@@ -215,6 +240,33 @@ extern "C" int pcv_selftest_division(pcv_ctx* ctx, const double* divisors, int n
   PCV_HIP_CHECK(ctx, hipMemcpyAsync(&h, dm, 8, hipMemcpyDeviceToHost, ctx->stream));
   PCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   *mismatches = h;
+  return PCV_OK;
+}
+
+extern "C" int pcv_root_owners(pcv_ctx* ctx, const pcv_build_params* params, const pcv_points* points, uint32_t world,
+                               uint32_t* owner, uint64_t* counts) {
+  if (!ctx) return PCV_E_INVALID;
+  if (!params || !points || !owner || !counts) return ctx->fail(PCV_E_INVALID, "null argument");
+  if (world < 1 || world > 8) return ctx->fail(PCV_E_INVALID, "world must be 1..8 (one root octant range per rank)");
+  if (points->mem != PCV_MEM_DEVICE) return ctx->fail(PCV_E_INVALID, "pcv_root_owners works on device-resident points");
+  for (uint32_t r = 0; r < world; ++r) counts[r] = 0;
+  if (points->n == 0) return PCV_OK;
+  PCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  PcvLevels lv;
+  int max_level;
+  pcv_make_levels(params->bbox_min, params->bbox_max, params->resolution, 4, &lv, &max_level, nullptr, nullptr);
+  PcvScratch sc(ctx);
+  unsigned long long* d_counts;
+  int rc;
+  if ((rc = sc.get(&d_counts, 8))) return rc;
+  PCV_HIP_CHECK(ctx, hipMemsetAsync(d_counts, 0, 64, ctx->stream));
+  hipLaunchKernelGGL(root_owner_kernel, dim3((unsigned)((points->n + 255) / 256)), dim3(256), 0, ctx->stream, lv, points->n,
+                     points->x, points->y, points->z, world, owner, d_counts);
+  PCV_HIP_CHECK(ctx, hipGetLastError());
+  unsigned long long h[8];
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(h, d_counts, 64, hipMemcpyDeviceToHost, ctx->stream));
+  PCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  for (uint32_t r = 0; r < world; ++r) counts[r] = h[r];
   return PCV_OK;
 }
 

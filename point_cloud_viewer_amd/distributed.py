@@ -40,18 +40,18 @@ class HipBackend:
     def aabb(self, x, y, z):
         return self.ctx.aabb_reduce(x, y, z)
 
-    def root_digits(self, resolution, bbox, x, y, z):
-        keys = self.ctx.chain_keys(resolution, bbox, x, y, z, nlevels=1)  # digit of level 1 in bits 60..62
-        return (keys >> 60) & 7
+    def owners(self, resolution, bbox, x, y, z, world):
+        """(owner per point, points per owner): one HIP kernel (root octant compare + wave-aggregated counts)."""
+        return self.ctx.root_owners(resolution, bbox, x, y, z, world)
 
     def stable_order(self, owner):
         """Indices that sort `owner` (small ints) stably: one 3-bit pass of the HIP radix sort."""
         torch = self.torch
         n = owner.numel()
-        keys = owner.to(torch.int32).contiguous()
+        keys = owner.to(torch.int32).clone()
         idx = torch.arange(n, dtype=torch.int32, device=owner.device)
         self.ctx.sort_pairs32(keys, idx, 0, 3)
-        return idx.to(torch.int64)
+        return idx
 
     def build(self, resolution, bbox, x, y, z, rgb, intensity, max_points_per_node=0):
         return self.ctx.build(resolution, bbox, x, y, z, rgb, intensity, max_points_per_node)
@@ -170,9 +170,7 @@ class ShardedOctreeBuilder:
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        digits = self.backend.root_digits(resolution, bbox, x, y, z)
-        owner = (digits.to(torch.int64) * world) // 8
-        send_counts = torch.bincount(owner, minlength=world).cpu().numpy().astype(np.int64).tolist()
+        owner, send_counts = self.backend.owners(resolution, bbox, x, y, z, world)
         order = self.backend.stable_order(owner)
         planes = [x, y, z, rgb] + ([intensity] if intensity is not None else [])
         outs, matrix = self._exchange(planes, order, send_counts)

@@ -240,6 +240,18 @@ class Context:
                                                    int(samples_per_divisor), C.byref(bad)))
         return bad.value
 
+    def root_owners(self, resolution, bounding_box, x, y, z, world):
+        """(owner int32 tensor, counts list) for device-resident points: owner = root octant * world // 8."""
+        import torch
+        p, keep = self._points(x, y, z)
+        if p.mem != L.MEM_DEVICE:
+            raise ValueError("root_owners needs device tensors")
+        pr = self._params(resolution, bounding_box.min, bounding_box.max)
+        owner = torch.empty(p.n, dtype=torch.int32, device=x.device)
+        counts = (C.c_uint64 * 8)()
+        self._check(self.lib.pcv_root_owners(self.handle, C.byref(pr), C.byref(p), int(world), owner.data_ptr(), counts))
+        return owner, [int(counts[r]) for r in range(world)]
+
     def sort_keys64(self, keys, begin_bit=0, end_bit=64):
         b = _Buf(keys, np.uint64, "keys")
         self._check(self.lib.pcv_sort_keys64(self.handle, b.ptr, b.size, begin_bit, end_bit,

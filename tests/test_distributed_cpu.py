@@ -44,9 +44,10 @@ class HostBackend:
     def aabb(self, x, y, z):
         return self.O.aabb(x.numpy(), y.numpy(), z.numpy())
 
-    def root_digits(self, resolution, bbox, x, y, z):
+    def owners(self, resolution, bbox, x, y, z, world):
         keys = self.O.chain_keys64(bbox.min, bbox.max, resolution, 1, x.numpy(), y.numpy(), z.numpy())
-        return torch.from_numpy((keys >> np.uint64(60)).astype(np.int64))
+        owner = torch.from_numpy(((keys >> np.uint64(60)).astype(np.int64) * world) // 8)
+        return owner, torch.bincount(owner, minlength=world).tolist()
 
     def stable_order(self, owner):
         return torch.argsort(owner, stable=True)

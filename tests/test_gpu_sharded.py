@@ -63,10 +63,12 @@ def test_virtual_ranks_on_one_gpu(world):
         sl = slice(r * n // world, (r + 1) * n // world)
         tx, ty, tz = (torch.from_numpy(np.ascontiguousarray(a[sl])).cuda() for a in (x, y, z))
         trgb = torch.from_numpy(np.ascontiguousarray(rgb[sl])).cuda()
-        digits = backend.root_digits(0.001, bbox, tx, ty, tz)
-        owner = (digits.to(torch.int64) * world) // 8
-        order = backend.stable_order(owner)
-        assert torch.equal(order, torch.argsort(owner, stable=True))
+        owner, counts = backend.owners(0.001, bbox, tx, ty, tz, world)
+        keys = O.chain_keys64(bmin, bmax, 0.001, 1, x[sl], y[sl], z[sl])
+        assert np.array_equal(owner.cpu().numpy(), ((keys >> np.uint64(60)).astype(np.int64) * world) // 8)
+        assert counts == np.bincount(owner.cpu().numpy(), minlength=world).tolist()
+        order = backend.stable_order(owner).to(torch.int64)
+        assert torch.equal(order, torch.argsort(owner.to(torch.int64), stable=True))
         so = owner[order]
         for d in range(world):
             sel = order[so == d]
