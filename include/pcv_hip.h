@@ -167,6 +167,19 @@ int pcv_chain_keys(pcv_ctx* ctx, const pcv_build_params* params, const pcv_point
 int pcv_root_owners(pcv_ctx* ctx, const pcv_build_params* params, const pcv_points* points, uint32_t world,
                     uint32_t* owner, uint64_t* counts);
 
+/* Stable partition of the point planes by owner: row k (in input order) of the points owned by rank r goes to
+ * dst[r].x[k], .y[k], .z[k], .color[k * color_stride ..], .intensity[k]. The caller points dst[r] at its send buffer
+ * for rank r, and dst[own rank] straight at the receive buffer. All pointers are device pointers. */
+typedef struct pcv_route_dst {
+  double* x;
+  double* y;
+  double* z;
+  uint8_t* color;
+  float* intensity; /* NULL when the points carry none */
+} pcv_route_dst;
+int pcv_partition_by_owner(pcv_ctx* ctx, const pcv_points* points, const uint32_t* owner, uint32_t world,
+                           const pcv_route_dst* dst);
+
 /* K3: stable LSD radix sort of 64-bit keys on bits [begin_bit, end_bit), in place. */
 int pcv_sort_keys64(pcv_ctx* ctx, uint64_t* keys, uint64_t n, int begin_bit, int end_bit, int mem);
 /* K3: stable sort of (u32 key, u32 value) pairs on bits [begin_bit, end_bit), in place. */

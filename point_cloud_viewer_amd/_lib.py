@@ -47,6 +47,10 @@ SHAPE_ALL, SHAPE_AABB, SHAPE_FRUSTUM, SHAPE_OBB, SHAPE_FRUSTUM_WITH_INVERSE = 0,
 REL_IN, REL_CROSS, REL_OUT = 0, 1, 2
 
 
+class RouteDst(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("z", C.c_void_p), ("color", C.c_void_p), ("intensity", C.c_void_p)]
+
+
 class NodeInfo(C.Structure):
     _fields_ = [("id_high", C.c_uint64), ("id_low", C.c_uint64), ("num_points", C.c_int64), ("level", C.c_uint32),
                 ("encoding", C.c_uint32), ("cube_min", C.c_double * 3), ("cube_edge", C.c_double),
@@ -83,6 +87,7 @@ _SIGNATURES = {
                                   C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "pcv_chain_keys": (C.c_int, [_vp, C.POINTER(BuildParams), C.POINTER(Points), C.c_int, _vp]),
     "pcv_root_owners": (C.c_int, [_vp, C.POINTER(BuildParams), C.POINTER(Points), C.c_uint32, _vp, C.POINTER(C.c_uint64)]),
+    "pcv_partition_by_owner": (C.c_int, [_vp, C.POINTER(Points), _vp, C.c_uint32, C.POINTER(RouteDst)]),
     "pcv_sort_keys64": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, C.c_int, C.c_int]),
     "pcv_sort_pairs32": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.c_int, C.c_int, C.c_int]),
     "pcv_selftest_division": (C.c_int, [_vp, C.POINTER(C.c_double), C.c_int, C.c_uint64, C.POINTER(C.c_uint64)]),

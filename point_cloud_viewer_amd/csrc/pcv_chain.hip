@@ -153,19 +153,151 @@ __global__ __launch_bounds__(256) void root_owner_kernel(PcvLevels lv, uint64_t 
   __shared__ uint32_t cnt[8];
   if (threadIdx.x < 8) cnt[threadIdx.x] = 0;
   __syncthreads();
-  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) {
-    const double e = lv.edge[0];
-    const double cx = (lv.root_min[0] + (lv.root_min[0] + e)) / 2.0;
-    const double cy = (lv.root_min[1] + (lv.root_min[1] + e)) / 2.0;
-    const double cz = (lv.root_min[2] + (lv.root_min[2] + e)) / 2.0;
-    const uint32_t d = ((x[i] > cx ? 1u : 0u) << 2) | ((y[i] > cy ? 1u : 0u) << 1) | (z[i] > cz ? 1u : 0u);
-    const uint32_t o = (d * world) >> 3;
-    owner[i] = o;
-    atomicAdd(&cnt[o], 1u);
+  const double e = lv.edge[0];
+  const double cx = (lv.root_min[0] + (lv.root_min[0] + e)) / 2.0;
+  const double cy = (lv.root_min[1] + (lv.root_min[1] + e)) / 2.0;
+  const double cz = (lv.root_min[2] + (lv.root_min[2] + e)) / 2.0;
+  uint32_t wcount[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // wave-uniform: ballots, no per-point atomics
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  for (uint64_t i0 = (uint64_t)blockIdx.x * 256; i0 < n; i0 += stride) {
+    const uint64_t i = i0 + threadIdx.x;
+    uint32_t o = 0xffu;
+    if (i < n) {
+      const uint32_t d = ((x[i] > cx ? 1u : 0u) << 2) | ((y[i] > cy ? 1u : 0u) << 1) | (z[i] > cz ? 1u : 0u);
+      o = (d * world) >> 3;
+      owner[i] = o;
+    }
+    for (uint32_t k = 0; k < world; ++k) wcount[k] += (uint32_t)__popcll(__ballot(o == k));
   }
+  if ((threadIdx.x & 63) == 0)
+    for (uint32_t k = 0; k < world; ++k)
+      if (wcount[k]) atomicAdd(&cnt[k], wcount[k]);
   __syncthreads();
   if (threadIdx.x < world && cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)cnt[threadIdx.x]);
+}
+
+// Stable partition of the point planes by owner (<= 8 destinations), writing every owner's rows to its own
+// destination pointers (send buffers of the other ranks, the receive buffer for the own rank): count per tile,
+// scan per owner, scatter. Input order is preserved inside every destination.
+constexpr int kPartTile = 4096;  // 256 lanes x 16 rows, wave-striped like the radix sort
+
+__global__ __launch_bounds__(256) void partition_count_kernel(uint64_t n, const uint32_t* __restrict__ owner, uint32_t world,
+                                                               uint32_t ntiles, uint32_t* __restrict__ tile_counts /* [world][ntiles] */) {
+  __shared__ uint32_t cnt[8];
+  if (threadIdx.x < 8) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const uint64_t base = (uint64_t)blockIdx.x * kPartTile;
+  uint32_t local[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 16; ++i) {
+    const uint64_t idx = base + (uint64_t)i * 256 + threadIdx.x;
+    if (idx < n) {
+      const uint32_t o = owner[idx];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) local[k] += (o == (uint32_t)k) ? 1u : 0u;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    uint32_t v = local[k];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&cnt[k], v);
+  }
+  __syncthreads();
+  if (threadIdx.x < world) tile_counts[(uint64_t)threadIdx.x * ntiles + blockIdx.x] = cnt[threadIdx.x];
+}
+
+// one workgroup per owner: exclusive scan of its ntiles counters in place
+__global__ __launch_bounds__(1024) void partition_scan_kernel(uint32_t* __restrict__ tile_counts, uint32_t ntiles) {
+  __shared__ uint32_t wave_tot[16];
+  __shared__ uint32_t running;
+  uint32_t* row = tile_counts + (uint64_t)blockIdx.x * ntiles;
+  if (threadIdx.x == 0) running = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (uint32_t base = 0; base < ntiles; base += 1024) {
+    const uint32_t idx = base + threadIdx.x;
+    const uint32_t v = idx < ntiles ? row[idx] : 0u;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      uint32_t t = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += t;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      woff += (w < wave) ? wave_tot[w] : 0u;
+      tot += wave_tot[w];
+    }
+    if (idx < ntiles) row[idx] = running + woff + inc - v;
+    __syncthreads();
+    if (threadIdx.x == 0) running += tot;
+    __syncthreads();
+  }
+}
+
+struct PartDst {
+  double* x[8];
+  double* y[8];
+  double* z[8];
+  uint8_t* color[8];
+  float* intensity[8];
+};
+
+__global__ __launch_bounds__(256) void partition_scatter_kernel(uint64_t n, const uint32_t* __restrict__ owner, uint32_t world,
+                                                                 uint32_t ntiles, const uint32_t* __restrict__ tile_base,
+                                                                 const double* __restrict__ x, const double* __restrict__ y,
+                                                                 const double* __restrict__ z, const uint8_t* __restrict__ color,
+                                                                 uint32_t color_stride, const float* __restrict__ intensity,
+                                                                 PartDst dst) {
+  __shared__ uint32_t wave_cnt[4][8];
+  __shared__ PartDst sdst;  // per-lane owner indexes the pointer table: LDS lookup instead of a private copy
+  if (threadIdx.x == 0) sdst = dst;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint64_t lane_lt = (1ull << lane) - 1ull;
+  const uint64_t base = (uint64_t)blockIdx.x * kPartTile + (uint64_t)wave * 1024 + lane;
+  uint32_t own[16];
+  uint32_t wcount[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // wave-uniform
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const uint64_t idx = base + (uint64_t)i * 64;
+    own[i] = idx < n ? owner[idx] : 0xffu;
+    for (uint32_t k = 0; k < world; ++k) wcount[k] += (uint32_t)__popcll(__ballot(own[i] == k));
+  }
+  if (lane == 0)
+    for (uint32_t k = 0; k < world; ++k) wave_cnt[wave][k] = wcount[k];
+  __syncthreads();
+  uint32_t run[8];  // next free row of each owner for this wave
+  for (uint32_t k = 0; k < world; ++k) {
+    uint32_t r = tile_base[(uint64_t)k * ntiles + blockIdx.x];
+    for (int w = 0; w < wave; ++w) r += wave_cnt[w][k];
+    run[k] = r;
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const uint64_t idx = base + (uint64_t)i * 64;
+    const uint32_t o = own[i];
+    uint32_t pos = 0;
+    for (uint32_t k = 0; k < world; ++k) {
+      const uint64_t m = __ballot(o == k);
+      if (o == k) pos = run[k] + (uint32_t)__popcll(m & lane_lt);
+      run[k] += (uint32_t)__popcll(m);
+    }
+    if (idx < n) {
+      sdst.x[o][pos] = x[idx];
+      sdst.y[o][pos] = y[idx];
+      sdst.z[o][pos] = z[idx];
+      const uint8_t* c = color + idx * color_stride;
+      uint8_t* d = sdst.color[o] + (uint64_t)pos * color_stride;
+      d[0] = c[0];
+      d[1] = c[1];
+      d[2] = c[2];
+      if (color_stride == 4) d[3] = c[3];
+      if (intensity) sdst.intensity[o][pos] = intensity[idx];
+    }
+  }
 }
 
 // Division self-test: pcv_div_code against IEEE division for every code and both divisors (exhaustive), and
@@ -260,13 +392,54 @@ extern "C" int pcv_root_owners(pcv_ctx* ctx, const pcv_build_params* params, con
   int rc;
   if ((rc = sc.get(&d_counts, 8))) return rc;
   PCV_HIP_CHECK(ctx, hipMemsetAsync(d_counts, 0, 64, ctx->stream));
-  hipLaunchKernelGGL(root_owner_kernel, dim3((unsigned)((points->n + 255) / 256)), dim3(256), 0, ctx->stream, lv, points->n,
-                     points->x, points->y, points->z, world, owner, d_counts);
+  {
+    PcvProf prof(ctx, PCV_K_ROOT_OWNER);
+    hipLaunchKernelGGL(root_owner_kernel, dim3((unsigned)std::min<uint64_t>((points->n + 255) / 256, 8192)), dim3(256), 0, ctx->stream, lv, points->n,
+                       points->x, points->y, points->z, world, owner, d_counts);
+  }
   PCV_HIP_CHECK(ctx, hipGetLastError());
   unsigned long long h[8];
   PCV_HIP_CHECK(ctx, hipMemcpyAsync(h, d_counts, 64, hipMemcpyDeviceToHost, ctx->stream));
   PCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   for (uint32_t r = 0; r < world; ++r) counts[r] = h[r];
+  return PCV_OK;
+}
+
+extern "C" int pcv_partition_by_owner(pcv_ctx* ctx, const pcv_points* points, const uint32_t* owner, uint32_t world,
+                                      const pcv_route_dst* dst) {
+  if (!ctx) return PCV_E_INVALID;
+  if (!points || !owner || !dst) return ctx->fail(PCV_E_INVALID, "null argument");
+  if (world < 1 || world > 8) return ctx->fail(PCV_E_INVALID, "world must be 1..8");
+  if (points->mem != PCV_MEM_DEVICE) return ctx->fail(PCV_E_INVALID, "pcv_partition_by_owner works on device-resident points");
+  if (points->color_stride != 3 && points->color_stride != 4) return ctx->fail(PCV_E_INVALID, "color_stride must be 3 or 4");
+  const uint64_t n = points->n;
+  if (n == 0) return PCV_OK;
+  PCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  PcvScratch sc(ctx);
+  const uint32_t ntiles = (uint32_t)((n + kPartTile - 1) / kPartTile);
+  uint32_t* tile_counts;
+  int rc;
+  if ((rc = sc.get(&tile_counts, (size_t)world * ntiles))) return rc;
+  PartDst pd{};
+  for (uint32_t k = 0; k < world; ++k) {
+    pd.x[k] = dst[k].x;
+    pd.y[k] = dst[k].y;
+    pd.z[k] = dst[k].z;
+    pd.color[k] = dst[k].color;
+    pd.intensity[k] = dst[k].intensity;
+  }
+  {
+    PcvProf prof(ctx, PCV_K_PARTITION_COUNT);
+    hipLaunchKernelGGL(partition_count_kernel, dim3(ntiles), dim3(256), 0, ctx->stream, n, owner, world, ntiles, tile_counts);
+  }
+  hipLaunchKernelGGL(partition_scan_kernel, dim3(world), dim3(1024), 0, ctx->stream, tile_counts, ntiles);
+  {
+    PcvProf prof(ctx, PCV_K_PARTITION_SCATTER);
+    hipLaunchKernelGGL(partition_scatter_kernel, dim3(ntiles), dim3(256), 0, ctx->stream, n, owner, world, ntiles, tile_counts,
+                       points->x, points->y, points->z, points->color, points->color_stride, points->intensity, pd);
+  }
+  PCV_HIP_CHECK(ctx, hipGetLastError());
+  PCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return PCV_OK;
 }
 

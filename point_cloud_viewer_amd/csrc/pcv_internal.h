@@ -55,6 +55,9 @@ enum PcvKernelId {
   PCV_K_CULL_POINTS,
   PCV_K_TRANSFORM_POINTS,
   PCV_K_QUERY_COMPACT,
+  PCV_K_ROOT_OWNER,
+  PCV_K_PARTITION_COUNT,
+  PCV_K_PARTITION_SCATTER,
   PCV_K_COUNT
 };
 

@@ -44,14 +44,9 @@ class HipBackend:
         """(owner per point, points per owner): one HIP kernel (root octant compare + wave-aggregated counts)."""
         return self.ctx.root_owners(resolution, bbox, x, y, z, world)
 
-    def stable_order(self, owner):
-        """Indices that sort `owner` (small ints) stably: one 3-bit pass of the HIP radix sort."""
-        torch = self.torch
-        n = owner.numel()
-        keys = owner.to(torch.int32).clone()
-        idx = torch.arange(n, dtype=torch.int32, device=owner.device)
-        self.ctx.sort_pairs32(keys, idx, 0, 3)
-        return idx
+    def partition(self, owner, x, y, z, rgb, intensity, dsts):
+        """Stable partition of the planes by owner straight into the destination views (count / scan / scatter)."""
+        self.ctx.partition_by_owner(owner, x, y, z, rgb, intensity, dsts)
 
     def build(self, resolution, bbox, x, y, z, rgb, intensity, max_points_per_node=0):
         return self.ctx.build(resolution, bbox, x, y, z, rgb, intensity, max_points_per_node)
@@ -131,9 +126,9 @@ class ShardedOctreeBuilder:
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         return _oct.Aabb(lo.cpu().numpy(), hi.cpu().numpy())
 
-    def _exchange(self, planes, order, send_counts):
-        """One grouped send/recv round for all planes. planes: list of tensors with leading dim n (local input order);
-        order: stable permutation grouping rows by destination; send_counts[d] rows go to rank d."""
+    def _route(self, owner, send_counts, x, y, z, rgb, intensity):
+        """Partition by owner and exchange: rows for rank r go to a send buffer, own rows directly into the receive
+        buffer; ONE grouped send/recv round moves everything else (RCCL: one ncclGroup == one all-to-all(v))."""
         torch, dist = self.torch, self.dist
         world, rank = self.world, self.rank
         counts = torch.tensor(send_counts, dtype=torch.int64, device=self.device)
@@ -142,26 +137,38 @@ class ShardedOctreeBuilder:
         matrix = torch.stack(allc).cpu().numpy()  # matrix[src][dst]
         recv_counts = matrix[:, rank]
         n_recv = int(recv_counts.sum())
-        send_off = np.concatenate([[0], np.cumsum(send_counts)])
-        recv_off = np.concatenate([[0], np.cumsum(recv_counts)])
-        outs, ops = [], []
-        for p in planes:
-            sorted_p = p.index_select(0, order)  # rows grouped by destination, input order inside each group
-            out = torch.empty((n_recv,) + tuple(p.shape[1:]), dtype=p.dtype, device=p.device)
-            outs.append(out)
-            # own rows never leave the device
-            out[recv_off[rank]:recv_off[rank + 1]].copy_(sorted_p[send_off[rank]:send_off[rank + 1]])
+        n_local = int(sum(send_counts))
+        send_off = np.concatenate([[0], np.cumsum(send_counts)]).astype(np.int64)
+        recv_off = np.concatenate([[0], np.cumsum(recv_counts)]).astype(np.int64)
+        planes = {"x": x, "y": y, "z": z, "color": rgb}
+        if intensity is not None:
+            planes["intensity"] = intensity
+
+        def empty_like_rows(p, rows):
+            return torch.empty((rows,) + tuple(p.shape[1:]), dtype=p.dtype, device=p.device)
+
+        send = {k: empty_like_rows(p, n_local) for k, p in planes.items()}
+        recv = {k: empty_like_rows(p, n_recv) for k, p in planes.items()}
+        dsts = []
+        for r in range(world):
+            buf, off, cnt = (recv, recv_off[rank], send_counts[rank]) if r == rank else (send, send_off[r], send_counts[r])
+            d = {k: v[off:off + cnt] for k, v in buf.items()}
+            d.setdefault("intensity", None)
+            dsts.append(d)
+        self.backend.partition(owner, x, y, z, rgb, intensity, dsts)
+        ops = []
+        for k in planes:
             for peer in range(world):
                 if peer == rank:
                     continue
                 if send_counts[peer] > 0:
-                    ops.append(dist.P2POp(dist.isend, sorted_p[send_off[peer]:send_off[peer + 1]], peer))
+                    ops.append(dist.P2POp(dist.isend, send[k][send_off[peer]:send_off[peer + 1]], peer))
                 if recv_counts[peer] > 0:
-                    ops.append(dist.P2POp(dist.irecv, out[recv_off[peer]:recv_off[peer + 1]], peer))
+                    ops.append(dist.P2POp(dist.irecv, recv[k][recv_off[peer]:recv_off[peer + 1]], peer))
         if ops:
-            for w in dist.batch_isend_irecv(ops):  # NCCL/RCCL: one group == one all-to-all(v)
+            for w in dist.batch_isend_irecv(ops):
                 w.wait()
-        return outs, matrix
+        return recv, matrix
 
     def build(self, resolution, bbox, x, y, z, rgb, intensity=None, max_points_per_node=0):
         torch = self.torch
@@ -171,15 +178,12 @@ class ShardedOctreeBuilder:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         owner, send_counts = self.backend.owners(resolution, bbox, x, y, z, world)
-        order = self.backend.stable_order(owner)
-        planes = [x, y, z, rgb] + ([intensity] if intensity is not None else [])
-        outs, matrix = self._exchange(planes, order, send_counts)
+        recv, matrix = self._route(owner, send_counts, x, y, z, rgb, intensity)
         exchange_ms = 0.0
         if timed:
             e1.record()
             e1.synchronize()
             exchange_ms = e0.elapsed_time(e1)
-        rx, ry, rz, rrgb = outs[:4]
-        rint = outs[4] if intensity is not None else None
-        tree = self.backend.build(resolution, bbox, rx, ry, rz, rrgb, rint, max_points_per_node)
+        tree = self.backend.build(resolution, bbox, recv["x"], recv["y"], recv["z"], recv["color"], recv.get("intensity"),
+                                  max_points_per_node)
         return ShardedOctree(self, tree, exchange_ms, matrix)

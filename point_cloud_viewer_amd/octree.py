@@ -252,6 +252,17 @@ class Context:
         self._check(self.lib.pcv_root_owners(self.handle, C.byref(pr), C.byref(p), int(world), owner.data_ptr(), counts))
         return owner, [int(counts[r]) for r in range(world)]
 
+    def partition_by_owner(self, owner, x, y, z, color, intensity, dsts):
+        """Stable partition of device planes by owner. dsts: per owner a dict(x=, y=, z=, color=, intensity=) of
+        device tensors (views into send / receive buffers) that receive that owner's rows in input order."""
+        p, keep = self._points(x, y, z, color, intensity)
+        arr = (L.RouteDst * len(dsts))()
+        for k, d in enumerate(dsts):
+            arr[k].x, arr[k].y, arr[k].z = d["x"].data_ptr(), d["y"].data_ptr(), d["z"].data_ptr()
+            arr[k].color = d["color"].data_ptr()
+            arr[k].intensity = d["intensity"].data_ptr() if d.get("intensity") is not None else None
+        self._check(self.lib.pcv_partition_by_owner(self.handle, C.byref(p), owner.data_ptr(), len(dsts), arr))
+
     def sort_keys64(self, keys, begin_bit=0, end_bit=64):
         b = _Buf(keys, np.uint64, "keys")
         self._check(self.lib.pcv_sort_keys64(self.handle, b.ptr, b.size, begin_bit, end_bit,

@@ -49,8 +49,15 @@ class HostBackend:
         owner = torch.from_numpy(((keys >> np.uint64(60)).astype(np.int64) * world) // 8)
         return owner, torch.bincount(owner, minlength=world).tolist()
 
-    def stable_order(self, owner):
-        return torch.argsort(owner, stable=True)
+    def partition(self, owner, x, y, z, rgb, intensity, dsts):
+        for k, d in enumerate(dsts):
+            sel = owner == k  # boolean-mask selection keeps input order
+            d["x"].copy_(x[sel])
+            d["y"].copy_(y[sel])
+            d["z"].copy_(z[sel])
+            d["color"].copy_(rgb[sel])
+            if intensity is not None:
+                d["intensity"].copy_(intensity[sel])
 
     def build(self, resolution, bbox, x, y, z, rgb, intensity, max_points_per_node=0):
         with self.O.max_points_per_node(self.cap):

@@ -65,14 +65,18 @@ def test_virtual_ranks_on_one_gpu(world):
         trgb = torch.from_numpy(np.ascontiguousarray(rgb[sl])).cuda()
         owner, counts = backend.owners(0.001, bbox, tx, ty, tz, world)
         keys = O.chain_keys64(bmin, bmax, 0.001, 1, x[sl], y[sl], z[sl])
-        assert np.array_equal(owner.cpu().numpy(), ((keys >> np.uint64(60)).astype(np.int64) * world) // 8)
-        assert counts == np.bincount(owner.cpu().numpy(), minlength=world).tolist()
-        order = backend.stable_order(owner).to(torch.int64)
-        assert torch.equal(order, torch.argsort(owner.to(torch.int64), stable=True))
-        so = owner[order]
+        want_owner = ((keys >> np.uint64(60)).astype(np.int64) * world) // 8
+        assert np.array_equal(owner.cpu().numpy(), want_owner)
+        assert counts == np.bincount(want_owner, minlength=world).tolist()
+        dsts = [dict(x=torch.empty(c, dtype=torch.float64, device="cuda"), y=torch.empty(c, dtype=torch.float64, device="cuda"),
+                     z=torch.empty(c, dtype=torch.float64, device="cuda"), color=torch.empty((c, 3), dtype=torch.uint8, device="cuda"),
+                     intensity=None) for c in counts]
+        backend.partition(owner, tx, ty, tz, trgb, None, dsts)
         for d in range(world):
-            sel = order[so == d]
-            parts[d].append((tx[sel], ty[sel], tz[sel], trgb[sel]))
+            sel = torch.from_numpy(want_owner == d).cuda()
+            assert torch.equal(dsts[d]["x"], tx[sel]) and torch.equal(dsts[d]["z"], tz[sel])  # stable
+            assert torch.equal(dsts[d]["color"], trgb[sel])
+            parts[d].append((dsts[d]["x"], dsts[d]["y"], dsts[d]["z"], dsts[d]["color"]))
     merged = {}
     for d in range(world):  # receivers concatenate in source-rank order
         rx, ry, rz, rrgb = (torch.cat([p[i] for p in parts[d]]).contiguous() for i in range(4))
