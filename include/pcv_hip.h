@@ -95,10 +95,40 @@ typedef struct pcv_build_params {
 /* Always compute and sort full-depth path keys (disables the sampled depth speculation; same result, slower). */
 #define PCV_BUILD_NO_SPECULATION 2u
 
+/* Multi-GPU build: level-1 nodes whose bit is set are split even if this rank's share of their points
+ * is below the capacity — the split decision of the GLOBAL tree, made from the all-reduced bucket counts. */
+#define PCV_BUILD_FORCE_SPLIT_L1(mask8) (((uint32_t)(mask8) & 0xffu) << 8)
+
 /* ---- the build ------------------------------------------------------------------------------ */
 /* Replaces build_octree (generation.rs:289-403) up to, but not including, the file writes:
  * the result holds the finished node table and node-contiguous .xyz/.rgb/.intensity bytes. */
 int pcv_build_octree(pcv_ctx* ctx, const pcv_build_params* params, const pcv_points* points, pcv_octree** out);
+
+/* The same build in two steps, for the multi-GPU path: when the level-2 subtrees of one level-1 node live on
+ * different ranks, the every-8th promotion (generation.rs:195-253) into the level-1 node and into the root runs over
+ * streams that span ranks, so the stream offsets must be agreed between the topology and the encode phase.
+ *   pcv_build_begin       K1..K4 + the bottom-up stream lengths |pre(node)| of the local tree
+ *   pcv_build_top_streams lengths of the local level-1 / level-2 streams (0 = node absent on this rank)
+ *   pcv_build_finish      K5, record sort, K6. With a layout, the root and the level-1 nodes are laid out at their
+ *                         GLOBAL size and this rank fills only its own slots (the rest is zero): the element-wise sum
+ *                         of all ranks' top-node bytes is the finished node. NULL layout == pcv_build_octree.
+ * The caller's device buffers must stay valid and no other call may be made on the context in between; after a
+ * failed pcv_build_finish the tree can only be freed. */
+typedef struct pcv_top_streams {
+  uint64_t l1[8];          /* |pre(r_c)|: points the level-1 node c holds before its own promotion */
+  uint64_t l2[64];         /* |pre(r_cd)| at index c * 8 + d */
+  uint32_t l1_split_mask;  /* bit c: level-1 node c is an inner node here */
+  uint32_t reserved;
+} pcv_top_streams;
+typedef struct pcv_top_layout {
+  uint64_t root_points;    /* global |pre(root)| == points the root keeps */
+  uint64_t l1_stream[8];   /* global |pre(r_c)| */
+  uint32_t l1_offset[8];   /* offset of r_c's promoted segment inside pre(root) */
+  uint32_t l2_offset[64];  /* offset of r_cd's promoted segment inside pre(r_c) */
+} pcv_top_layout;
+int pcv_build_begin(pcv_ctx* ctx, const pcv_build_params* params, const pcv_points* points, pcv_octree** out);
+int pcv_build_top_streams(const pcv_octree* tree, pcv_top_streams* out);
+int pcv_build_finish(pcv_octree* tree, const pcv_top_layout* top /* nullable */);
 
 /* One finished node == one `proto::OctreeNode` (proto.proto:90-94) + where its bytes are. */
 typedef struct pcv_node_info {
@@ -123,6 +153,9 @@ void pcv_octree_meta(const pcv_octree* t, double* resolution, double bbox_min[3]
 int pcv_octree_node_data(pcv_octree* t, uint64_t i, int which, const uint8_t** data, uint64_t* len);
 /* Device-side blobs (no copy): which as above. */
 int pcv_octree_device_blob(const pcv_octree* t, int which, const void** dptr, uint64_t* len);
+/* Copy the bytes of node i (which: 0 .xyz, 1 .rgb, 2 .intensity) out of the device blob into `dst` (host or device
+ * memory, `capacity` bytes) without staging the whole octree on the host. */
+int pcv_octree_copy_node(const pcv_octree* tree, uint64_t i, int which, void* dst, uint64_t capacity, int mem);
 /* Write `<NodeId>.xyz/.rgb/.intensity` + meta.pb (version 13) exactly as the reference lays them out
  * (src/read_write/raw.rs:374-449, node_writer.rs:78-89, generation.rs:390-402). */
 int pcv_octree_write_dir(pcv_octree* t, const char* directory);
@@ -161,13 +194,17 @@ int pcv_level_table(const double bbox_min[3], const double bbox_max[3], double r
 int pcv_chain_keys(pcv_ctx* ctx, const pcv_build_params* params, const pcv_points* points, int nlevels,
                    uint64_t* keys /* same memory space as points */);
 
-/* Multi-GPU routing: owner[i] = (root octant of point i) * world / 8, where the root octant is
- * ChildIndex::from_bounding_cube against the GLOBAL root cube (node.rs:34-42); counts[r] = points owned by rank r.
- * Device-resident points only; owner is a device buffer of n u32, counts a host array of `world` entries. */
-int pcv_root_owners(pcv_ctx* ctx, const pcv_build_params* params, const pcv_points* points, uint32_t world,
-                    uint32_t* owner, uint64_t* counts);
+/* Multi-GPU routing (skew remedy): bucket[i] = 8 * d1 + d2, the level-1 and level-2 octant digits of
+ * point i along the same quantise->decode chain K2 follows (ChildIndex::from_bounding_cube node.rs:34-42 against the
+ * GLOBAL root cube, then against the level-1 cube after one encode/decode step); counts[b] = points in bucket b.
+ * The ranks all-reduce the 64 counts, decide which level-1 nodes the global tree splits, and bin-pack the buckets
+ * (whole octants where the level-1 node stays a leaf) onto ranks. Device-resident points only; bucket is a device
+ * buffer of n u32, counts a host array of 64 entries. */
+int pcv_route_buckets(pcv_ctx* ctx, const pcv_build_params* params, const pcv_points* points, uint32_t* bucket,
+                      uint64_t counts[64]);
 
-/* Stable partition of the point planes by owner: row k (in input order) of the points owned by rank r goes to
+/* Stable partition of the point planes by owner (owner[i] is a rank, or a bucket when rank_of_bucket maps the 64
+ * buckets to ranks): row k (in input order) of the points owned by rank r goes to
  * dst[r].x[k], .y[k], .z[k], .color[k * color_stride ..], .intensity[k]. The caller points dst[r] at its send buffer
  * for rank r, and dst[own rank] straight at the receive buffer. All pointers are device pointers. */
 typedef struct pcv_route_dst {
@@ -178,7 +215,7 @@ typedef struct pcv_route_dst {
   float* intensity; /* NULL when the points carry none */
 } pcv_route_dst;
 int pcv_partition_by_owner(pcv_ctx* ctx, const pcv_points* points, const uint32_t* owner, uint32_t world,
-                           const pcv_route_dst* dst);
+                           const pcv_route_dst* dst, const uint8_t* rank_of_bucket /* nullable host array of 64 */);
 
 /* K3: stable LSD radix sort of 64-bit keys on bits [begin_bit, end_bit), in place. */
 int pcv_sort_keys64(pcv_ctx* ctx, uint64_t* keys, uint64_t n, int begin_bit, int end_bit, int mem);

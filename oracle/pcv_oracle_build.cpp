@@ -764,8 +764,21 @@ struct CNode {
   std::vector<uint8_t> origin_level;  // for inner nodes: leaf level each pre[] entry came from
 };
 
+// Multi-rank variant (tests of the sharded build only): `force_mask` splits the listed level-1 nodes whatever their
+// local count, `streams_out` (8 level-1 + 64 level-2 stream lengths + split mask) reports the local top of the tree,
+// and `layout` (root_points, l1_stream[8], l1_offset[8], l2_offset[64]) lays the root and the level-1 nodes out at their
+// GLOBAL size: this rank's points land in their global slots, all other slots stay zero.
+struct TopLayout {
+  uint64_t root_points;
+  uint64_t l1_stream[8];
+  uint64_t l1_offset[8];
+  uint64_t l2_offset[64];
+};
+
 static Result* build_closed(const Aabb& bbox, double resolution, size_t n, const double* x, const double* y,
-                            const double* z, const uint8_t* rgb, const float* intensity, int num_threads) {
+                            const double* z, const uint8_t* rgb, const float* intensity, int num_threads,
+                            unsigned force_mask = 0, const TopLayout* layout = nullptr, uint64_t* streams_out = nullptr) {
+  if (streams_out) std::memset(streams_out, 0, sizeof(uint64_t) * 73);
   Result* r = new Result();
   r->version = CURRENT_VERSION;
   r->bbox = bbox;
@@ -809,6 +822,7 @@ static Result* build_closed(const Aabb& bbox, double resolution, size_t n, const
       ch.parent = (int)qi;
       for (int k = 0; k < 8; ++k) ch.child[k] = -1;
       ch.leaf = !((int64_t)lists[c].size() > MAX_POINTS_PER_NODE && t.edge[lvl] > resolution);
+      if (lvl == 1 && ((force_mask >> c) & 1u)) ch.leaf = false;
       ch.pre = std::move(lists[c]);
       nodes[qi].child[c] = (int)nodes.size();
       nodes.push_back(std::move(ch));
@@ -821,6 +835,11 @@ static Result* build_closed(const Aabb& bbox, double resolution, size_t n, const
   // final placement per node: (point index, leaf level it started at)
   std::vector<std::vector<uint32_t>> post_idx(nodes.size());
   std::vector<std::vector<uint8_t>> post_origin(nodes.size());
+  // gpos[qi][j]: position of pre[j] in the node's GLOBAL stream (only differs from j for level <= 1 with a layout)
+  std::vector<std::vector<uint64_t>> gpos(nodes.size());
+  std::vector<std::vector<uint64_t>> post_slot(nodes.size());
+  std::vector<int64_t> global_size(nodes.size(), -1);
+  auto digit_of = [&](const CNode& nd) { return (unsigned)nd.id.child_index(); };
   for (size_t qi = nodes.size(); qi-- > 0;) {
     CNode& nd = nodes[qi];
     if (!nd.leaf) {
@@ -829,19 +848,36 @@ static Result* build_closed(const Aabb& bbox, double resolution, size_t n, const
       for (int c = 0; c < 8; ++c) {
         if (nd.child[c] < 0) continue;
         CNode& ch = nodes[(size_t)nd.child[c]];
-        for (size_t j = 0; j < ch.pre.size(); j += 8) {
+        if (streams_out && nd.level == 0) streams_out[c] = ch.pre.size();
+        if (streams_out && nd.level == 1) streams_out[8 + digit_of(nd) * 8 + (unsigned)c] = ch.pre.size();
+        if (streams_out && nd.level == 0 && !ch.leaf) streams_out[72] |= 1ull << c;
+        const bool global = layout && nd.level <= 1;
+        uint64_t base = 0;
+        if (global) base = nd.level == 0 ? layout->l1_offset[c] : layout->l2_offset[digit_of(nd) * 8 + (unsigned)c];
+        const std::vector<uint64_t>& cg = gpos[(size_t)nd.child[c]];
+        for (size_t j = 0; j < ch.pre.size(); ++j) {
+          const uint64_t g = cg.empty() ? j : cg[j];
+          if (g % 8 != 0) continue;
           nd.pre.push_back(ch.pre[j]);
           nd.origin_level.push_back(ch.origin_level[j]);
+          if (global) gpos[qi].push_back(base + g / 8);
         }
       }
     }
   }
   for (size_t qi = 0; qi < nodes.size(); ++qi) {
     CNode& nd = nodes[qi];
+    const bool global = layout && nd.level <= 1;
+    if (global) {
+      const uint64_t stream = nd.level == 0 ? layout->root_points : layout->l1_stream[digit_of(nd)];
+      global_size[qi] = (int64_t)(nd.level == 0 ? stream : stream - (stream + 7) / 8);
+    }
     for (size_t j = 0; j < nd.pre.size(); ++j) {
-      if (nd.level != 0 && j % 8 == 0) continue;  // promoted away; the root keeps everything
+      const uint64_t g = gpos[qi].empty() ? j : gpos[qi][j];
+      if (nd.level != 0 && g % 8 == 0) continue;  // promoted away; the root keeps everything
       post_idx[qi].push_back(nd.pre[j]);
       post_origin[qi].push_back(nd.origin_level[j]);
+      if (global) post_slot[qi].push_back(nd.level == 0 ? g : g - g / 8 - 1);
     }
   }
   // Bytes: replay the chain down to the leaf level, then decode/encode upward, plus the one rewrite
@@ -852,19 +888,21 @@ static Result* build_closed(const Aabb& bbox, double resolution, size_t n, const
     const CNode& nd = nodes[qi];
     ResultNode& out = r->nodes[qi];
     out.id = nd.id;
-    out.num_points = (int64_t)post_idx[qi].size();
+    const size_t m_local = post_idx[qi].size();
+    const size_t m = global_size[qi] >= 0 ? (size_t)global_size[qi] : m_local;
+    out.num_points = (int64_t)m;
     Enc enc = t.enc[nd.level];
     out.enc = enc;
     int bpc = bytes_per_coordinate(enc);
-    size_t m = post_idx[qi].size();
     out.has_xyz = out.has_rgb = m > 0;
     out.has_intensity = m > 0 && intensity != nullptr;
-    out.xyz.resize(m * 3 * (size_t)bpc);
-    out.rgb.resize(m * 3);
-    if (intensity) out.intensity.resize(m * 4);
-    for (size_t s = 0; s < m; ++s) {
-      uint32_t i = post_idx[qi][s];
-      int L = post_origin[qi][s];
+    out.xyz.assign(m * 3 * (size_t)bpc, 0);
+    out.rgb.assign(m * 3, 0);
+    if (intensity) out.intensity.assign(m * 4, 0);
+    for (size_t sl = 0; sl < m_local; ++sl) {
+      const size_t s = global_size[qi] >= 0 ? (size_t)post_slot[qi][sl] : sl;
+      uint32_t i = post_idx[qi][sl];
+      int L = post_origin[qi][sl];
       double p[3] = {x[i], y[i], z[i]};
       double mn[3] = {t.root.mn[0], t.root.mn[1], t.root.mn[2]};
       double mins[48][3];
@@ -1049,6 +1087,23 @@ void* pcvo_build_closed(double resolution, const double bmin[3], const double bm
                         int num_threads) {
   Aabb b{{bmin[0], bmin[1], bmin[2]}, {bmax[0], bmax[1], bmax[2]}};
   return build_closed(b, resolution, n, x, y, z, rgb, intensity, num_threads);
+}
+
+// One rank's share of a multi-rank build (see TopLayout). layout: 1 + 8 + 8 + 64 u64 or NULL; streams_out: 73 u64 or NULL.
+void* pcvo_build_closed_shard(double resolution, const double bmin[3], const double bmax[3], uint64_t n, const double* x,
+                              const double* y, const double* z, const uint8_t* rgb, const float* intensity,
+                              int num_threads, unsigned force_mask, const uint64_t* layout, uint64_t* streams_out) {
+  Aabb b{{bmin[0], bmin[1], bmin[2]}, {bmax[0], bmax[1], bmax[2]}};
+  TopLayout tl;
+  if (layout) {
+    tl.root_points = layout[0];
+    for (int c = 0; c < 8; ++c) {
+      tl.l1_stream[c] = layout[1 + c];
+      tl.l1_offset[c] = layout[9 + c];
+    }
+    for (int i = 0; i < 64; ++i) tl.l2_offset[i] = layout[17 + i];
+  }
+  return build_closed(b, resolution, n, x, y, z, rgb, intensity, num_threads, force_mask, layout ? &tl : nullptr, streams_out);
 }
 
 // Load an octree directory (ours or the oracle's) for comparison.

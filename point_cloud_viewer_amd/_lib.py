@@ -51,6 +51,15 @@ class RouteDst(C.Structure):
     _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("z", C.c_void_p), ("color", C.c_void_p), ("intensity", C.c_void_p)]
 
 
+class TopStreams(C.Structure):
+    _fields_ = [("l1", C.c_uint64 * 8), ("l2", C.c_uint64 * 64), ("l1_split_mask", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class TopLayout(C.Structure):
+    _fields_ = [("root_points", C.c_uint64), ("l1_stream", C.c_uint64 * 8), ("l1_offset", C.c_uint32 * 8),
+                ("l2_offset", C.c_uint32 * 64)]
+
+
 class NodeInfo(C.Structure):
     _fields_ = [("id_high", C.c_uint64), ("id_low", C.c_uint64), ("num_points", C.c_int64), ("level", C.c_uint32),
                 ("encoding", C.c_uint32), ("cube_min", C.c_double * 3), ("cube_edge", C.c_double),
@@ -86,8 +95,12 @@ _SIGNATURES = {
     "pcv_level_table": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_int,
                                   C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "pcv_chain_keys": (C.c_int, [_vp, C.POINTER(BuildParams), C.POINTER(Points), C.c_int, _vp]),
-    "pcv_root_owners": (C.c_int, [_vp, C.POINTER(BuildParams), C.POINTER(Points), C.c_uint32, _vp, C.POINTER(C.c_uint64)]),
-    "pcv_partition_by_owner": (C.c_int, [_vp, C.POINTER(Points), _vp, C.c_uint32, C.POINTER(RouteDst)]),
+    "pcv_route_buckets": (C.c_int, [_vp, C.POINTER(BuildParams), C.POINTER(Points), _vp, C.POINTER(C.c_uint64)]),
+    "pcv_partition_by_owner": (C.c_int, [_vp, C.POINTER(Points), _vp, C.c_uint32, C.POINTER(RouteDst), _vp]),
+    "pcv_octree_copy_node": (C.c_int, [_vp, C.c_uint64, C.c_int, _vp, C.c_uint64, C.c_int]),
+    "pcv_build_begin": (C.c_int, [_vp, C.POINTER(BuildParams), C.POINTER(Points), C.POINTER(_vp)]),
+    "pcv_build_top_streams": (C.c_int, [_vp, C.POINTER(TopStreams)]),
+    "pcv_build_finish": (C.c_int, [_vp, C.POINTER(TopLayout)]),
     "pcv_sort_keys64": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, C.c_int, C.c_int]),
     "pcv_sort_pairs32": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.c_int, C.c_int, C.c_int]),
     "pcv_selftest_division": (C.c_int, [_vp, C.POINTER(C.c_double), C.c_int, C.c_uint64, C.POINTER(C.c_uint64)]),

@@ -125,7 +125,7 @@ static const char* kKernelNames[PCV_K_COUNT] = {
     "downsweep_kernel<u64>", "split_search_kernel", "split_assign_kernel", "leaf_encode_kernel",
     "upsweep_kernel<u32>", "downsweep_kernel<u32>", "promote_encode_kernel", "downsweep_rec_kernel", "cull_nodes_kernel",
     "visible_nodes_kernel", "nodes_in_location_kernel", "cull_points_kernel", "transform_points_kernel",
-    "query_compact_kernel", "root_owner_kernel", "partition_count_kernel", "partition_scatter_kernel"};
+    "query_compact_kernel", "route_bucket_kernel", "partition_count_kernel", "partition_scatter_kernel"};
 static_assert(sizeof(kKernelNames) / sizeof(kKernelNames[0]) == PCV_K_COUNT, "kernel name table out of sync");
 
 extern "C" int pcv_ctx_set_profiling(pcv_ctx* ctx, int enabled) {
@@ -368,8 +368,24 @@ static int device_aabb(pcv_ctx* ctx, PcvScratch& sc, const DevPoints& d, double 
 // ------------------------------------------------------------------------------------------------
 // octree object
 // ------------------------------------------------------------------------------------------------
+// State of a build between pcv_build_begin (through the topology) and pcv_build_finish (encode + promotion).
+struct PcvBuild {
+  pcv_ctx* ctx;
+  PcvScratch sc;
+  DevPoints d;
+  uint64_t n = 0;
+  PcvLevels lv;
+  uint64_t *keys_a = nullptr, *keys_b = nullptr;
+  void* sort_scratch = nullptr;
+  uint32_t M = 0;
+  size_t host_bytes = 0;
+  std::vector<uint64_t> pre;  // |pre(node)| stream lengths, bottom-up
+  explicit PcvBuild(pcv_ctx* c) : ctx(c), sc(c) {}
+};
+
 extern "C" void pcv_octree_free(pcv_octree* t) {
   if (!t) return;
+  delete t->pending;
   if (t->ctx) {
     pcv_octree_release_query(t);
     t->ctx->host_release(t->h_xyz.p);
@@ -460,13 +476,40 @@ extern "C" int pcv_octree_node_data(pcv_octree* t, uint64_t i, int which, const 
   return PCV_OK;
 }
 
+extern "C" int pcv_octree_copy_node(const pcv_octree* t, uint64_t i, int which, void* dst, uint64_t capacity, int mem) {
+  if (!t || i >= t->nodes.size() || which < 0 || which > 2 || (mem != PCV_MEM_HOST && mem != PCV_MEM_DEVICE)) return PCV_E_INVALID;
+  pcv_ctx* ctx = t->ctx;
+  if (!t->directory.empty()) return ctx->fail(PCV_E_INVALID, "pcv_octree_copy_node works on built octrees (device blobs)");
+  const pcv_node_info& nd = t->nodes[i];
+  const uint64_t np = (uint64_t)nd.num_points;
+  const uint8_t* src = nullptr;
+  uint64_t len = 0;
+  if (which == 0) {
+    src = t->d_xyz + nd.xyz_offset;
+    len = np * 3 * (uint64_t)pcv_bytes_per_coordinate(nd.encoding);
+  } else if (which == 1) {
+    src = t->d_rgb + nd.point_offset * 3;
+    len = np * 3;
+  } else if (t->has_intensity) {
+    src = t->d_int + nd.point_offset * 4;
+    len = np * 4;
+  }
+  if (len > capacity) return ctx->fail(PCV_E_INVALID, "destination too small for the node's bytes");
+  if (len == 0) return PCV_OK;
+  if (!dst) return ctx->fail(PCV_E_INVALID, "dst is null");
+  PCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, len, mem == PCV_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+  PCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return PCV_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // the build
 // ------------------------------------------------------------------------------------------------
 static uint64_t ceil8(uint64_t v) { return (v + 7) / 8; }
 
-extern "C" int pcv_build_octree(pcv_ctx* ctx, const pcv_build_params* params, const pcv_points* points,
-                                pcv_octree** out) {
+extern "C" int pcv_build_begin(pcv_ctx* ctx, const pcv_build_params* params, const pcv_points* points,
+                               pcv_octree** out) {
   if (!ctx) return PCV_E_INVALID;
   if (!out) return ctx->fail(PCV_E_INVALID, "out is null");
   *out = nullptr;
@@ -479,13 +522,13 @@ extern "C" int pcv_build_octree(pcv_ctx* ctx, const pcv_build_params* params, co
   hipStream_t st = ctx->stream;
   const uint64_t n = points->n;
 
-  PcvScratch sc(ctx);
-  DevPoints d;
-  PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[0], st));
-  if ((rc = stage_points(ctx, sc, points, true, &d))) return rc;
-
+  PcvBuild* bs = new PcvBuild(ctx);
   pcv_octree* t = new pcv_octree();
+  t->pending = bs;  // owned by the tree from here on
   t->ctx = ctx;
+  PcvScratch& sc = bs->sc;
+  DevPoints& d = bs->d;
+  bs->n = n;
   t->resolution = params->resolution;
   t->has_intensity = points->intensity != nullptr;
   struct Guard {
@@ -494,6 +537,8 @@ extern "C" int pcv_build_octree(pcv_ctx* ctx, const pcv_build_params* params, co
       if (t) pcv_octree_free(t);
     }
   } guard{t};
+  PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[0], st));
+  if ((rc = stage_points(ctx, sc, points, true, &d))) return rc;
 
   double bmin[3], bmax[3];
   if (params->flags & PCV_BUILD_COMPUTE_BBOX) {
@@ -510,12 +555,14 @@ extern "C" int pcv_build_octree(pcv_ctx* ctx, const pcv_build_params* params, co
   }
   PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[1], st));
   if (n == 0) {  // generation.rs:325-330: no leaves, no finished nodes, meta without nodes
+    delete t->pending;
+    t->pending = nullptr;
     *out = t;
     guard.t = nullptr;
     return PCV_OK;
   }
 
-  PcvLevels lv;
+  PcvLevels& lv = bs->lv;
   int max_level = 0;
   pcv_make_levels(bmin, bmax, params->resolution, 64, &lv, &max_level, nullptr, nullptr);
 
@@ -526,8 +573,9 @@ extern "C" int pcv_build_octree(pcv_ctx* ctx, const pcv_build_params* params, co
   // sorts only that many levels (+1), with 32-bit keys when 10 levels suffice. K4 verifies: if any node at the last
   // key level would still have to be split, everything is redone at full depth — speculation can cost time, never
   // correctness.
-  uint64_t *keys_a, *keys_b;
-  void* sort_scratch;
+  uint64_t*& keys_a = bs->keys_a;
+  uint64_t*& keys_b = bs->keys_b;
+  void*& sort_scratch = bs->sort_scratch;
   if ((rc = sc.get(&keys_a, n)) || (rc = sc.get(&keys_b, n))) return rc;
   if ((rc = ctx->dev_alloc(&sort_scratch, pcv_sort_scratch_bytes(n)))) return rc;
   sc.ptrs.push_back(sort_scratch);
@@ -589,7 +637,8 @@ extern "C" int pcv_build_octree(pcv_ctx* ctx, const pcv_build_params* params, co
           (rc = sc.get(&nt.bounds, (size_t)cap * 9)) || (rc = sc.get(&nt.counters, 64)))
         return rc;
     }
-    pcv_launch_node_split(ctx, nt, sorted_keys, keys32, (uint32_t)n, lv, params->resolution, max_points);
+    pcv_launch_node_split(ctx, nt, sorted_keys, keys32, (uint32_t)n, lv, params->resolution, max_points,
+                          (params->flags >> 8) & 0xffu);
     PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[4], st));
 
     // ---- node table to host ----
@@ -611,8 +660,10 @@ extern "C" int pcv_build_octree(pcv_ctx* ctx, const pcv_build_params* params, co
   t->key_attempts = attempts;
   lv.nlevels = full_levels;  // K5/K6 index the level tables by node level; the walk stops at leaves anyway
   const uint32_t M = counters[0];
+  bs->M = M;
   // pinned staging: prefix(8) lo hi parent first_child (4 each) level mask open (1 each)
   const size_t host_bytes = (size_t)M * (8 + 4 * 4 + 3) + 64;
+  bs->host_bytes = host_bytes;
   if ((rc = ctx->pinned_reserve(host_bytes * 4 + (size_t)M * 64 + (size_t)M * 2 * sizeof(PcvNodeRec) + 512))) return rc;
   uint8_t* hp = (uint8_t*)ctx->pinned;
   uint64_t* h_prefix = (uint64_t*)hp;
@@ -642,9 +693,10 @@ extern "C" int pcv_build_octree(pcv_ctx* ctx, const pcv_build_params* params, co
   uint32_t* u_leaf_lo = u_child_off + M;             // <= M
   uint32_t* u_leaf_node = u_leaf_lo + M;             // <= M
   uint8_t* u_level = (uint8_t*)(u_leaf_node + M);    // M
-  const size_t up_bytes = (size_t)M * (8 * 3 + 24 + 4 * 4 + 1);
+  (void)u_walk; (void)u_leaf_lo; (void)u_level;
 
-  std::vector<uint64_t> pre(M);
+  std::vector<uint64_t>& pre = bs->pre;
+  pre.assign(M, 0);
   // bottom-up stream lengths: |pre(inner)| = sum ceil(|pre(child)| / 8)
   for (uint32_t i = M; i-- > 0;) {
     if (!h_open[i]) {
@@ -664,6 +716,100 @@ extern "C" int pcv_build_octree(pcv_ctx* ctx, const pcv_build_params* params, co
   }
   u_parent[0] = 0xffffffffu;
   u_child_off[0] = 0;
+  *out = t;
+  guard.t = nullptr;
+  return PCV_OK;
+}
+
+extern "C" int pcv_build_top_streams(const pcv_octree* t, pcv_top_streams* out) {
+  if (!t || !out) return PCV_E_INVALID;
+  std::memset(out, 0, sizeof(*out));
+  const PcvBuild* bs = t->pending;
+  if (!bs) return t->nodes.empty() ? PCV_OK : t->ctx->fail(PCV_E_INVALID, "pcv_build_top_streams needs a tree between pcv_build_begin and pcv_build_finish");
+  pcv_ctx* ctx = t->ctx;
+  const uint32_t M = bs->M;
+  const uint8_t* hp = (const uint8_t*)ctx->pinned;  // the node table staged by pcv_build_begin
+  const uint32_t* h_first = (const uint32_t*)(hp + (size_t)M * 16);
+  const uint8_t* h_mask = hp + (size_t)M * 21;
+  const uint8_t* h_open = hp + (size_t)M * 22;
+  uint32_t c1 = h_first[0];
+  for (int c = 0; c < 8; ++c) {
+    if (!((h_mask[0] >> c) & 1)) continue;
+    const uint32_t i = c1++;
+    out->l1[c] = bs->pre[i];
+    if (!h_open[i]) continue;
+    out->l1_split_mask |= 1u << c;
+    uint32_t c2 = h_first[i];
+    for (int dg = 0; dg < 8; ++dg)
+      if ((h_mask[i] >> dg) & 1) out->l2[c * 8 + dg] = bs->pre[c2++];
+  }
+  return PCV_OK;
+}
+
+extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
+  if (!t) return PCV_E_INVALID;
+  PcvBuild* bs = t->pending;
+  if (!bs) return t->nodes.empty() && t->num_points == 0 ? PCV_OK : t->ctx->fail(PCV_E_INVALID, "pcv_build_finish: nothing pending");
+  pcv_ctx* ctx = t->ctx;
+  PCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  int rc;
+  struct Done {  // the build state is released on every exit path; on failure the tree stays valid but empty
+    pcv_octree* t;
+    ~Done() {
+      delete t->pending;
+      t->pending = nullptr;
+    }
+  } done{t};
+  PcvScratch& sc = bs->sc;
+  DevPoints& d = bs->d;
+  PcvLevels& lv = bs->lv;
+  const uint64_t n = bs->n;
+  const uint32_t M = bs->M;
+  const size_t host_bytes = bs->host_bytes;
+  uint64_t* keys_a = bs->keys_a;
+  uint64_t* keys_b = bs->keys_b;
+  void* sort_scratch = bs->sort_scratch;
+  std::vector<uint64_t>& pre = bs->pre;
+  double bmin[3] = {t->bbox_min[0], t->bbox_min[1], t->bbox_min[2]};
+  uint8_t* hp = (uint8_t*)ctx->pinned;
+  uint64_t* h_prefix = (uint64_t*)hp;
+  uint32_t* h_lo = (uint32_t*)(h_prefix + M);
+  uint32_t* h_hi = h_lo + M;
+  uint32_t* h_first = h_hi + M;
+  uint8_t* h_level = (uint8_t*)(h_first + M);
+  uint8_t* h_mask = h_level + M;
+  uint8_t* h_open = h_mask + M;
+  // upload area (pinned, after the download area)
+  uint8_t* up = hp + ((host_bytes + 255) & ~(size_t)255);
+  uint64_t* u_walk = (uint64_t*)up;                 // M
+  uint64_t* u_xyz_off = u_walk + M;                  // M
+  uint64_t* u_point_off = u_xyz_off + M;             // M
+  double* u_node_min = (double*)(u_point_off + M);   // 3M
+  uint32_t* u_parent = (uint32_t*)(u_node_min + 3 * (size_t)M);  // M
+  uint32_t* u_child_off = u_parent + M;              // M
+  uint32_t* u_leaf_lo = u_child_off + M;             // <= M
+  uint32_t* u_leaf_node = u_leaf_lo + M;             // <= M
+  uint8_t* u_level = (uint8_t*)(u_leaf_node + M);    // M
+  const size_t up_bytes = (size_t)M * (8 * 3 + 24 + 4 * 4 + 1);
+
+  uint32_t top_nodes = 0;  // nodes of level <= 1 hold GLOBAL streams when a layout is given (multi-GPU build)
+  if (top) {
+    pre[0] = top->root_points;
+    uint32_t c1 = h_first[0];
+    top_nodes = 1;
+    for (int c = 0; c < 8; ++c) {
+      if (!((h_mask[0] >> c) & 1)) continue;
+      const uint32_t i = c1++;
+      ++top_nodes;
+      pre[i] = top->l1_stream[c];
+      u_child_off[i] = top->l1_offset[c];
+      if (!h_open[i]) continue;
+      uint32_t c2 = h_first[i];
+      for (int dg = 0; dg < 8; ++dg)
+        if ((h_mask[i] >> dg) & 1) u_child_off[c2++] = top->l2_offset[c * 8 + dg];
+    }
+  }
   // leaves in key order == order of their sorted ranges
   std::vector<uint32_t> leaves;
   leaves.reserve(M);
@@ -799,6 +945,13 @@ extern "C" int pcv_build_octree(pcv_ctx* ctx, const pcv_build_params* params, co
     if ((rc = ctx->dev_alloc(&bi, t->int_bytes))) return rc;
     t->d_int = (uint8_t*)bi;
   }
+  if (top_nodes) {  // global-size top nodes are only partly filled by this rank: the rest must read as zero
+    const uint64_t tx = top_nodes < M ? u_xyz_off[top_nodes] : t->xyz_bytes;
+    const uint64_t tp = top_nodes < M ? u_point_off[top_nodes] : t->num_points;
+    if (tx) PCV_HIP_CHECK(ctx, hipMemsetAsync(t->d_xyz, 0, tx, st));
+    if (tp) PCV_HIP_CHECK(ctx, hipMemsetAsync(t->d_rgb, 0, tp * 3, st));
+    if (tp && t->d_int) PCV_HIP_CHECK(ctx, hipMemsetAsync(t->d_int, 0, tp * 4, st));
+  }
   pcv_launch_promote_encode(ctx, lv, pt, n, s_rank, s_pay, wide ? s_plane[w_hi] : nullptr,
                             wide ? s_plane[w_hi + 1] : nullptr, wide ? s_plane[w_hi + 2] : nullptr,
                             w_int >= 0 ? s_plane[w_int] : nullptr, t->d_xyz, t->d_rgb, t->d_int);
@@ -808,10 +961,21 @@ extern "C" int pcv_build_octree(pcv_ctx* ctx, const pcv_build_params* params, co
   ctx->prof_resolve();
   for (int sidx = 0; sidx < 8; ++sidx) (void)hipEventElapsedTime(&t->stage_ms[sidx], ctx->ev[sidx], ctx->ev[sidx + 1]);
   (void)hipEventElapsedTime(&t->stage_ms[PCV_STAGE_TOTAL], ctx->ev[0], ctx->ev[8]);
-
-  *out = t;
-  guard.t = nullptr;
   return PCV_OK;
+}
+
+extern "C" int pcv_build_octree(pcv_ctx* ctx, const pcv_build_params* params, const pcv_points* points,
+                                pcv_octree** out) {
+  if (!ctx) return PCV_E_INVALID;
+  if (!out) return ctx->fail(PCV_E_INVALID, "out is null");
+  pcv_octree* t = nullptr;
+  int rc = pcv_build_begin(ctx, params, points, &t);
+  if (rc == PCV_OK && (rc = pcv_build_finish(t, nullptr)) != PCV_OK) {
+    pcv_octree_free(t);
+    t = nullptr;
+  }
+  *out = t;
+  return rc;
 }
 
 // ------------------------------------------------------------------------------------------------

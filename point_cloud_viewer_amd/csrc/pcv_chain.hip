@@ -143,37 +143,42 @@ __global__ __launch_bounds__(256) void depth_probe_kernel(const uint64_t* __rest
   if ((threadIdx.x & 63) == 0 && l > *(volatile uint32_t*)max_shared_levels) atomicMax(max_shared_levels, l);
 }
 
-// Multi-GPU routing: owner rank of every point = its root octant (ChildIndex::from_bounding_cube against the
-// root cube, node.rs:34-42 — needs only the point and the global root cube) mapped to contiguous octant ranges,
-// plus the number of points per owner.
-__global__ __launch_bounds__(256) void root_owner_kernel(PcvLevels lv, uint64_t n, const double* __restrict__ x,
-                                                          const double* __restrict__ y, const double* __restrict__ z,
-                                                          uint32_t world, uint32_t* __restrict__ owner,
-                                                          unsigned long long* __restrict__ counts /* [world] */) {
-  __shared__ uint32_t cnt[8];
-  if (threadIdx.x < 8) cnt[threadIdx.x] = 0;
+// Multi-GPU routing: the bucket of a point is its level-1 and level-2 octant digit (the first two steps of
+// the K2 chain, so bit-identical to what the owner's build computes again), bucket = 8 * d1 + d2. The 64 counts
+// are what the ranks all-reduce to decide the global top of the tree and to bin-pack buckets onto ranks.
+__global__ __launch_bounds__(256) void route_bucket_kernel(PcvLevels lv, uint64_t n, const double* __restrict__ x,
+                                                            const double* __restrict__ y, const double* __restrict__ z,
+                                                            uint32_t* __restrict__ bucket,
+                                                            unsigned long long* __restrict__ counts /* [64] */) {
+  __shared__ uint32_t hist[64];
+  if (threadIdx.x < 64) hist[threadIdx.x] = 0;
   __syncthreads();
-  const double e = lv.edge[0];
-  const double cx = (lv.root_min[0] + (lv.root_min[0] + e)) / 2.0;
-  const double cy = (lv.root_min[1] + (lv.root_min[1] + e)) / 2.0;
-  const double cz = (lv.root_min[2] + (lv.root_min[2] + e)) / 2.0;
-  uint32_t wcount[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // wave-uniform: ballots, no per-point atomics
+  const int lane = threadIdx.x & 63;
   const uint64_t stride = (uint64_t)gridDim.x * 256;
   for (uint64_t i0 = (uint64_t)blockIdx.x * 256; i0 < n; i0 += stride) {
     const uint64_t i = i0 + threadIdx.x;
-    uint32_t o = 0xffu;
-    if (i < n) {
-      const uint32_t d = ((x[i] > cx ? 1u : 0u) << 2) | ((y[i] > cy ? 1u : 0u) << 1) | (z[i] > cz ? 1u : 0u);
-      o = (d * world) >> 3;
-      owner[i] = o;
+    const bool in = i < n;
+    uint32_t b = 0;
+    if (in) {
+      double px = x[i], py = y[i], pz = z[i];
+      double mx = lv.root_min[0], my = lv.root_min[1], mz = lv.root_min[2];
+      double cx, cy, cz;
+      for (int k = 1; k <= lv.nlevels; ++k)  // nlevels <= 2 here; always the guarded (exact for any input) variant
+        b = (b << 3) | pcv_chain_level<true>(lv.enc[k], lv.edge[k - 1], lv.edge[k], lv.inv_edge[k], px, py, pz, mx, my, mz, cx, cy, cz);
+      if (lv.nlevels < 2) b <<= 3;
+      bucket[i] = b;
     }
-    for (uint32_t k = 0; k < world; ++k) wcount[k] += (uint32_t)__popcll(__ballot(o == k));
+    // wave-aggregated histogram: lanes with the same bucket elect one leader (match-any by 6 ballots)
+    uint64_t peers = __ballot(in);
+#pragma unroll
+    for (int bit = 0; bit < 6; ++bit) {
+      const uint64_t m = __ballot((b >> bit) & 1u);
+      peers &= ((b >> bit) & 1u) ? m : ~m;
+    }
+    if (in && (peers & ((1ull << lane) - 1ull)) == 0) atomicAdd(&hist[b], (uint32_t)__popcll(peers));
   }
-  if ((threadIdx.x & 63) == 0)
-    for (uint32_t k = 0; k < world; ++k)
-      if (wcount[k]) atomicAdd(&cnt[k], wcount[k]);
   __syncthreads();
-  if (threadIdx.x < world && cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)cnt[threadIdx.x]);
+  if (threadIdx.x < 64 && hist[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
 }
 
 // Stable partition of the point planes by owner (<= 8 destinations), writing every owner's rows to its own
@@ -182,16 +187,19 @@ __global__ __launch_bounds__(256) void root_owner_kernel(PcvLevels lv, uint64_t 
 constexpr int kPartTile = 4096;  // 256 lanes x 16 rows, wave-striped like the radix sort
 
 __global__ __launch_bounds__(256) void partition_count_kernel(uint64_t n, const uint32_t* __restrict__ owner, uint32_t world,
-                                                               uint32_t ntiles, uint32_t* __restrict__ tile_counts /* [world][ntiles] */) {
+                                                               uint32_t ntiles, uint32_t* __restrict__ tile_counts /* [world][ntiles] */,
+                                                               const uint8_t* __restrict__ remap /* [64] bucket -> rank, or null */) {
   __shared__ uint32_t cnt[8];
+  __shared__ uint8_t rank_of[64];
   if (threadIdx.x < 8) cnt[threadIdx.x] = 0;
+  if (threadIdx.x < 64) rank_of[threadIdx.x] = remap ? remap[threadIdx.x] : (uint8_t)threadIdx.x;
   __syncthreads();
   const uint64_t base = (uint64_t)blockIdx.x * kPartTile;
   uint32_t local[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int i = 0; i < 16; ++i) {
     const uint64_t idx = base + (uint64_t)i * 256 + threadIdx.x;
     if (idx < n) {
-      const uint32_t o = owner[idx];
+      const uint32_t o = rank_of[owner[idx] & 63u];
 #pragma unroll
       for (int k = 0; k < 8; ++k) local[k] += (o == (uint32_t)k) ? 1u : 0u;
     }
@@ -251,10 +259,13 @@ __global__ __launch_bounds__(256) void partition_scatter_kernel(uint64_t n, cons
                                                                  const double* __restrict__ x, const double* __restrict__ y,
                                                                  const double* __restrict__ z, const uint8_t* __restrict__ color,
                                                                  uint32_t color_stride, const float* __restrict__ intensity,
-                                                                 PartDst dst) {
+                                                                 PartDst dst, const uint8_t* __restrict__ remap) {
   __shared__ uint32_t wave_cnt[4][8];
   __shared__ PartDst sdst;  // per-lane owner indexes the pointer table: LDS lookup instead of a private copy
+  __shared__ uint8_t rank_of[64];
   if (threadIdx.x == 0) sdst = dst;
+  if (threadIdx.x < 64) rank_of[threadIdx.x] = remap ? remap[threadIdx.x] : (uint8_t)threadIdx.x;
+  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t lane_lt = (1ull << lane) - 1ull;
   const uint64_t base = (uint64_t)blockIdx.x * kPartTile + (uint64_t)wave * 1024 + lane;
@@ -263,7 +274,7 @@ __global__ __launch_bounds__(256) void partition_scatter_kernel(uint64_t n, cons
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const uint64_t idx = base + (uint64_t)i * 64;
-    own[i] = idx < n ? owner[idx] : 0xffu;
+    own[i] = idx < n ? (uint32_t)rank_of[owner[idx] & 63u] : 0xffu;
     for (uint32_t k = 0; k < world; ++k) wcount[k] += (uint32_t)__popcll(__ballot(own[i] == k));
   }
   if (lane == 0)
@@ -375,51 +386,61 @@ extern "C" int pcv_selftest_division(pcv_ctx* ctx, const double* divisors, int n
   return PCV_OK;
 }
 
-extern "C" int pcv_root_owners(pcv_ctx* ctx, const pcv_build_params* params, const pcv_points* points, uint32_t world,
-                               uint32_t* owner, uint64_t* counts) {
+extern "C" int pcv_route_buckets(pcv_ctx* ctx, const pcv_build_params* params, const pcv_points* points, uint32_t* bucket,
+                                 uint64_t counts[64]) {
   if (!ctx) return PCV_E_INVALID;
-  if (!params || !points || !owner || !counts) return ctx->fail(PCV_E_INVALID, "null argument");
-  if (world < 1 || world > 8) return ctx->fail(PCV_E_INVALID, "world must be 1..8 (one root octant range per rank)");
-  if (points->mem != PCV_MEM_DEVICE) return ctx->fail(PCV_E_INVALID, "pcv_root_owners works on device-resident points");
-  for (uint32_t r = 0; r < world; ++r) counts[r] = 0;
-  if (points->n == 0) return PCV_OK;
+  if (!params || !points || !counts) return ctx->fail(PCV_E_INVALID, "null argument");
+  for (int b = 0; b < 64; ++b) counts[b] = 0;
+  if (points->n == 0) return PCV_OK;  // an empty input slice (a rank without points) is fine
+  if (!bucket) return ctx->fail(PCV_E_INVALID, "bucket is null");
+  if (points->mem != PCV_MEM_DEVICE) return ctx->fail(PCV_E_INVALID, "pcv_route_buckets works on device-resident points");
   PCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   PcvLevels lv;
   int max_level;
-  pcv_make_levels(params->bbox_min, params->bbox_max, params->resolution, 4, &lv, &max_level, nullptr, nullptr);
+  pcv_make_levels(params->bbox_min, params->bbox_max, params->resolution, 2, &lv, &max_level, nullptr, nullptr);
   PcvScratch sc(ctx);
   unsigned long long* d_counts;
   int rc;
-  if ((rc = sc.get(&d_counts, 8))) return rc;
-  PCV_HIP_CHECK(ctx, hipMemsetAsync(d_counts, 0, 64, ctx->stream));
+  if ((rc = sc.get(&d_counts, 64))) return rc;
+  PCV_HIP_CHECK(ctx, hipMemsetAsync(d_counts, 0, 64 * 8, ctx->stream));
   {
-    PcvProf prof(ctx, PCV_K_ROOT_OWNER);
-    hipLaunchKernelGGL(root_owner_kernel, dim3((unsigned)std::min<uint64_t>((points->n + 255) / 256, 8192)), dim3(256), 0, ctx->stream, lv, points->n,
-                       points->x, points->y, points->z, world, owner, d_counts);
+    PcvProf prof(ctx, PCV_K_ROUTE_BUCKET);
+    hipLaunchKernelGGL(route_bucket_kernel, dim3((unsigned)std::min<uint64_t>((points->n + 255) / 256, 8192)), dim3(256), 0,
+                       ctx->stream, lv, points->n, points->x, points->y, points->z, bucket, d_counts);
   }
   PCV_HIP_CHECK(ctx, hipGetLastError());
-  unsigned long long h[8];
-  PCV_HIP_CHECK(ctx, hipMemcpyAsync(h, d_counts, 64, hipMemcpyDeviceToHost, ctx->stream));
+  unsigned long long h[64];
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(h, d_counts, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
   PCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  for (uint32_t r = 0; r < world; ++r) counts[r] = h[r];
+  for (int b = 0; b < 64; ++b) counts[b] = h[b];
   return PCV_OK;
 }
 
 extern "C" int pcv_partition_by_owner(pcv_ctx* ctx, const pcv_points* points, const uint32_t* owner, uint32_t world,
-                                      const pcv_route_dst* dst) {
+                                      const pcv_route_dst* dst, const uint8_t* rank_of_bucket) {
   if (!ctx) return PCV_E_INVALID;
-  if (!points || !owner || !dst) return ctx->fail(PCV_E_INVALID, "null argument");
+  if (!points || !dst) return ctx->fail(PCV_E_INVALID, "null argument");
   if (world < 1 || world > 8) return ctx->fail(PCV_E_INVALID, "world must be 1..8");
+  if (points->n == 0) return PCV_OK;
+  if (!owner) return ctx->fail(PCV_E_INVALID, "owner is null");
   if (points->mem != PCV_MEM_DEVICE) return ctx->fail(PCV_E_INVALID, "pcv_partition_by_owner works on device-resident points");
   if (points->color_stride != 3 && points->color_stride != 4) return ctx->fail(PCV_E_INVALID, "color_stride must be 3 or 4");
+  if (rank_of_bucket)
+    for (int b = 0; b < 64; ++b)
+      if (rank_of_bucket[b] >= world) return ctx->fail(PCV_E_INVALID, "rank_of_bucket entry out of range");
   const uint64_t n = points->n;
   if (n == 0) return PCV_OK;
   PCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   PcvScratch sc(ctx);
   const uint32_t ntiles = (uint32_t)((n + kPartTile - 1) / kPartTile);
   uint32_t* tile_counts;
+  uint8_t* d_remap = nullptr;
   int rc;
   if ((rc = sc.get(&tile_counts, (size_t)world * ntiles))) return rc;
+  if (rank_of_bucket) {
+    if ((rc = sc.get(&d_remap, 64))) return rc;
+    PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_remap, rank_of_bucket, 64, hipMemcpyHostToDevice, ctx->stream));
+  }
   PartDst pd{};
   for (uint32_t k = 0; k < world; ++k) {
     pd.x[k] = dst[k].x;
@@ -430,13 +451,15 @@ extern "C" int pcv_partition_by_owner(pcv_ctx* ctx, const pcv_points* points, co
   }
   {
     PcvProf prof(ctx, PCV_K_PARTITION_COUNT);
-    hipLaunchKernelGGL(partition_count_kernel, dim3(ntiles), dim3(256), 0, ctx->stream, n, owner, world, ntiles, tile_counts);
+    hipLaunchKernelGGL(partition_count_kernel, dim3(ntiles), dim3(256), 0, ctx->stream, n, owner, world, ntiles, tile_counts,
+                       (const uint8_t*)d_remap);
   }
   hipLaunchKernelGGL(partition_scan_kernel, dim3(world), dim3(1024), 0, ctx->stream, tile_counts, ntiles);
   {
     PcvProf prof(ctx, PCV_K_PARTITION_SCATTER);
     hipLaunchKernelGGL(partition_scatter_kernel, dim3(ntiles), dim3(256), 0, ctx->stream, n, owner, world, ntiles, tile_counts,
-                       points->x, points->y, points->z, points->color, points->color_stride, points->intensity, pd);
+                       points->x, points->y, points->z, points->color, points->color_stride, points->intensity, pd,
+                       (const uint8_t*)d_remap);
   }
   PCV_HIP_CHECK(ctx, hipGetLastError());
   PCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));

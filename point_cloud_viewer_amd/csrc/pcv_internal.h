@@ -55,7 +55,7 @@ enum PcvKernelId {
   PCV_K_CULL_POINTS,
   PCV_K_TRANSFORM_POINTS,
   PCV_K_QUERY_COMPACT,
-  PCV_K_ROOT_OWNER,
+  PCV_K_ROUTE_BUCKET,
   PCV_K_PARTITION_COUNT,
   PCV_K_PARTITION_SCATTER,
   PCV_K_COUNT
@@ -187,7 +187,8 @@ struct PcvNodeTableDev {
   uint32_t* counters;    // [0] node_count, [1] error flag, [2..] level_start[k] (k = 0..PCV_MAX_KEY_LEVELS+1)
 };
 void pcv_launch_node_split(pcv_ctx* ctx, const PcvNodeTableDev& t, const void* sorted_keys, bool keys32, uint32_t n,
-                           const PcvLevels& lv, double resolution, uint32_t max_points_per_node);
+                           const PcvLevels& lv, double resolution, uint32_t max_points_per_node,
+                           uint32_t force_split_level1_mask);
 
 // pcv_encode.hip — leaf lookup + leaf-level encode (input order), promotion + final encode (sorted order).
 struct PcvWalkTables {
@@ -227,8 +228,10 @@ void pcv_launch_promote_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvPromo
 struct PcvOctreeQuery;  // device-resident traversal tables (pcv_query.hip)
 
 // The finished octree (node table + node-contiguous blobs).
+struct PcvBuild;  // pcv_build.hip: state between pcv_build_begin and pcv_build_finish
 struct pcv_octree {
   pcv_ctx* ctx = nullptr;
+  PcvBuild* pending = nullptr;
   double resolution = 0;
   double bbox_min[3] = {0, 0, 0}, bbox_max[3] = {0, 0, 0};
   bool has_intensity = false;

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void split_search_kernel(PcvNodeTableDev t, co
 // (B) append level k. One workgroup; nodes of level k-1 are visited in order, children get consecutive
 // indices in (parent, digit) order.
 __global__ __launch_bounds__(1024) void split_assign_kernel(PcvNodeTableDev t, PcvLevels lv, double resolution,
-                                                             uint32_t max_points, int k) {
+                                                             uint32_t max_points, int k, uint32_t force_mask) {
   __shared__ uint32_t wave_tot[16];
   __shared__ uint32_t running;
   const uint32_t begin = t.counters[CNT_LEVEL_START + k - 1];
@@ -142,6 +142,9 @@ __global__ __launch_bounds__(1024) void split_assign_kernel(PcvNodeTableDev t, P
           const uint32_t count = b[c + 1] - b[c];
           // should_split_node (generation.rs:128-150): count > MAX && child edge > resolution
           bool open = count > max_points && lv.edge[k] > resolution;
+          // multi-GPU build: a level-1 node that is split in the GLOBAL tree is split here too, whatever share of
+          // its points this rank holds (pcv_build_params.flags, PCV_BUILD_FORCE_SPLIT_L1)
+          if (k == 1 && ((force_mask >> c) & 1u)) open = true;
           if (open && k >= lv.nlevels) {
             // would need digits beyond the key width
             atomicOr(&t.counters[CNT_ERROR], 1u);
@@ -175,7 +178,8 @@ __global__ __launch_bounds__(1024) void split_assign_kernel(PcvNodeTableDev t, P
 }  // namespace
 
 void pcv_launch_node_split(pcv_ctx* ctx, const PcvNodeTableDev& t, const void* sorted_keys, bool keys32, uint32_t n,
-                           const PcvLevels& lv, double resolution, uint32_t max_points_per_node) {
+                           const PcvLevels& lv, double resolution, uint32_t max_points_per_node,
+                           uint32_t force_split_level1_mask) {
   hipStream_t s = ctx->stream;
   hipLaunchKernelGGL(init_root_kernel, dim3(1), dim3(256), 0, s, t, n);
   for (int k = 1; k <= lv.nlevels; ++k) {
@@ -188,7 +192,8 @@ void pcv_launch_node_split(pcv_ctx* ctx, const PcvNodeTableDev& t, const void* s
     }
     {
       PcvProf prof(ctx, PCV_K_SPLIT_ASSIGN);
-      hipLaunchKernelGGL(split_assign_kernel, dim3(1), dim3(1024), 0, s, t, lv, resolution, max_points_per_node, k);
+      hipLaunchKernelGGL(split_assign_kernel, dim3(1), dim3(1024), 0, s, t, lv, resolution, max_points_per_node, k,
+                         force_split_level1_mask);
     }
   }
 }

@@ -1,19 +1,27 @@
-"""Multi-GPU octree build: shard by root octant, ONE all-to-all(v), independent subtree builds.
+"""Multi-GPU octree build: shard by level-2 bucket, ONE all-to-all(v), independent subtree builds.
 
-The reference is single-process (rayon tasks over nodes, src/octree/generation.rs:152-193); subtrees below the
-root are independent, which is what this module exploits across the GPUs of one node:
+The reference is single-process (rayon tasks over nodes, src/octree/generation.rs:152-193). Subtrees are independent of
+each other, which is what this module exploits across the GPUs of one node:
 
   1. every rank holds a contiguous slice of the input (rank order == input order);
-  2. the level-1 digit c1 = ChildIndex::from_bounding_cube(root cube, p) (src/octree/node.rs:34-42) depends only on
-     the point and the global root cube, so each rank computes it locally (HIP, K2 with one level);
-  3. octants are owned in contiguous ranges: owner(c) = c * world // 8; a stable partition by owner followed by one
-     grouped send/recv round (RCCL: a single ncclGroup == one all-to-all(v) over xGMI; planes x, y, z, rgb[, intensity])
-     routes every point to its owner. Receivers concatenate in source-rank order, so each octant's stream stays in
-     global input order — the property that makes per-node point order identical to the reference;
-  4. each rank runs the ordinary single-GPU build on what it received, with the GLOBAL bounding box. Its local
-     root holds exactly the points its octants promote to the root, in child order;
-  5. the global root is the concatenation of the local roots in rank order (== child order); all other nodes are
-     disjoint between ranks. No other collective touches point data.
+  2. the bucket of a point — its level-1 and level-2 octant digits, 64 buckets — needs only the point and the GLOBAL
+     root cube (ChildIndex::from_bounding_cube node.rs:34-42 plus one encode/decode step of the chain), so each rank
+     computes it locally (HIP) together with the 64 bucket counts; one tiny all-reduce makes the counts global;
+  3. from the global counts every rank derives the same plan: which level-1 nodes the global tree splits
+     (count > capacity && child edge > resolution, generation.rs:128-150), and a bin-packing (largest first) of the
+     buckets onto ranks — whole octants where the level-1 node stays a leaf. Gaussian-cluster clouds put very different
+     numbers of points into the 8 root octants; 64 buckets even that out (SURVEY §8e "skew");
+  4. a stable partition by owner followed by one grouped send/recv round (RCCL: a single ncclGroup == one
+     all-to-all(v) over xGMI; planes x, y, z, rgb[, intensity]) routes every point to its owner. Receivers concatenate
+     in source-rank order, so each bucket's stream stays in global input order — the property that makes per-node
+     point order identical to the reference;
+  5. each rank runs the ordinary build on what it received, with the GLOBAL bounding box and the global split
+     decision for the level-1 nodes. Everything from level 2 down is exactly the single-GPU result;
+  6. the every-8th promotion (generation.rs:195-253) into a level-1 node and into the root runs over streams that
+     span ranks: the ranks all-reduce the lengths of their level-1/level-2 streams (72 numbers) between the topology
+     and the encode phase, which fixes every promoted point's global slot. Each rank then writes its points into
+     global-size top nodes (other slots zero), and one small all-reduce(sum) of those bytes (<= 9 nodes, a few MB)
+     finishes the root and the level-1 nodes on every rank. No other collective touches point data.
 
 The backend is pluggable so that the routing/merge logic can be exercised on CPU tensors with the gloo backend
 (tests/test_distributed_cpu.py injects a host backend); the product backend is HIP (`HipBackend`).
@@ -22,10 +30,74 @@ import numpy as np
 
 from . import octree as _oct
 
+DEFAULT_MAX_POINTS_PER_NODE = 100000  # generation.rs:37
 
-def owner_of_octant(c, world):
-    """Contiguous octant ranges per rank (world in 1, 2, 4, 8; other sizes leave some ranks idle)."""
-    return (c * world) // 8
+
+def _ceil8(v):
+    return (int(v) + 7) // 8
+
+
+def plan_buckets(global_counts, world, max_points_per_node, level1_can_split):
+    """(rank_of_bucket[64], split_mask) from the GLOBAL bucket counts — pure and deterministic, every rank computes the
+    same plan. Units are single buckets below level-1 nodes the global tree splits, whole octants otherwise; units go
+    largest-first to the least-loaded rank (ties: lower bucket, lower rank)."""
+    g = np.asarray(global_counts, dtype=np.int64).reshape(8, 8)
+    octant = g.sum(axis=1)
+    units, split_mask = [], 0
+    for c in range(8):
+        if level1_can_split and octant[c] > max_points_per_node:
+            split_mask |= 1 << c
+            units += [(int(g[c, d]), [c * 8 + d]) for d in range(8) if g[c, d] > 0]
+        elif octant[c] > 0:
+            units.append((int(octant[c]), list(range(c * 8, c * 8 + 8))))
+    rank_of = np.zeros(64, dtype=np.uint8)
+    loads = [0] * world
+    for weight, buckets in sorted(units, key=lambda u: (-u[0], u[1][0])):
+        r = min(range(world), key=lambda k: (loads[k], k))
+        loads[r] += weight
+        rank_of[buckets] = r
+    return rank_of, split_mask
+
+
+def top_layout(l1, l2, split_mask):
+    """Global streams of the top of the tree from the summed local stream lengths: offsets of every level-2 node's
+    promoted segment inside its level-1 node's stream, of every level-1 node's inside the root's (SURVEY Appendix A:
+    |pre(inner)| = sum over children of ceil(|pre(child)| / 8))."""
+    l1_stream, l1_offset, l2_offset = [0] * 8, [0] * 8, [0] * 64
+    for c in range(8):
+        if (split_mask >> c) & 1:
+            acc = 0
+            for d in range(8):
+                l2_offset[c * 8 + d] = acc
+                acc += _ceil8(l2[c * 8 + d])
+            l1_stream[c] = acc
+        else:
+            l1_stream[c] = int(l1[c])
+    acc = 0
+    for c in range(8):
+        l1_offset[c] = acc
+        acc += _ceil8(l1_stream[c])
+    return dict(root_points=acc, l1_stream=l1_stream, l1_offset=l1_offset, l2_offset=l2_offset)
+
+
+def top_nodes(layout, encodings, has_intensity):
+    """Finished root + level-1 nodes described by a layout: [(name, level, digit, num_points, encoding, xyz_off, rgb_off,
+    int_off)] and the total byte size of the buffer that holds their xyz | rgb | intensity bytes."""
+    bpc = {1: 1, 2: 2, 3: 4, 4: 8}
+    specs = [("r", 0, 0, layout["root_points"])]
+    for c in range(8):
+        s = layout["l1_stream"][c]
+        if s > 0:
+            specs.append((f"r{c}", 1, c, s - _ceil8(s)))
+    out, off = [], 0
+    for name, level, digit, npts in specs:
+        enc = int(encodings[level])
+        xyz = npts * 3 * bpc[enc]
+        out.append(dict(name=name, level=level, digit=digit, num_points=npts, encoding=enc, xyz=(off, xyz),
+                        rgb=(off + xyz, npts * 3), intensity=(off + xyz + npts * 3, npts * 4 if has_intensity else 0)))
+        off += xyz + npts * 3 + (npts * 4 if has_intensity else 0)
+        off = (off + 15) & ~15
+    return out, off
 
 
 class HipBackend:
@@ -40,65 +112,74 @@ class HipBackend:
     def aabb(self, x, y, z):
         return self.ctx.aabb_reduce(x, y, z)
 
-    def owners(self, resolution, bbox, x, y, z, world):
-        """(owner per point, points per owner): one HIP kernel (root octant compare + wave-aggregated counts)."""
-        return self.ctx.root_owners(resolution, bbox, x, y, z, world)
+    def level_table(self, resolution, bbox):
+        """(max_level, edges, encodings) of the global cube (PositionEncoding::new codec.rs:31-40)."""
+        return _oct.level_table(bbox.min, bbox.max, resolution)
 
-    def partition(self, owner, x, y, z, rgb, intensity, dsts):
+    def buckets(self, resolution, bbox, x, y, z):
+        """(bucket per point, 64 counts): one HIP kernel (two chain levels + wave-aggregated histogram)."""
+        return self.ctx.route_buckets(resolution, bbox, x, y, z)
+
+    def partition(self, bucket, rank_of_bucket, x, y, z, rgb, intensity, dsts):
         """Stable partition of the planes by owner straight into the destination views (count / scan / scatter)."""
-        self.ctx.partition_by_owner(owner, x, y, z, rgb, intensity, dsts)
+        self.ctx.partition_by_owner(bucket, x, y, z, rgb, intensity, dsts, rank_of_bucket)
 
-    def build(self, resolution, bbox, x, y, z, rgb, intensity, max_points_per_node=0):
-        return self.ctx.build(resolution, bbox, x, y, z, rgb, intensity, max_points_per_node)
+    def build_begin(self, resolution, bbox, x, y, z, rgb, intensity, max_points_per_node, force_split_level1):
+        return self.ctx.build_begin(resolution, bbox, x, y, z, rgb, intensity, max_points_per_node, force_split_level1)
 
 
 class ShardedOctree:
-    """Result of a sharded build: this rank's subtrees plus its share of the root."""
+    """Result of a sharded build: this rank's subtrees (level >= 2) plus the finished root and level-1 nodes, which
+    every rank holds after the top all-reduce."""
 
-    def __init__(self, builder, local_tree, exchange_ms, counts):
+    def __init__(self, builder, local_tree, top, top_bytes, stage_ms, counts, plan):
         self.builder = builder
         self.local = local_tree
-        self.exchange_ms = exchange_ms
-        self.counts = counts  # world x world matrix: counts[src][dst]
+        self.top = top              # list of node dicts (top_nodes)
+        self.top_bytes = top_bytes  # uint8 tensor: xyz | rgb | intensity of the top nodes
+        self._stage_ms = stage_ms
+        self.counts = counts        # world x world matrix: counts[src][dst]
+        self.plan = plan            # (rank_of_bucket, split_mask)
 
     @property
     def num_nodes_local(self):
         return self.local.num_nodes
 
     @property
-    def num_points_local(self):
-        return self.local.num_points
-
-    @property
     def stage_ms(self):
         ms = dict(self.local.stage_ms()) if hasattr(self.local, "stage_ms") else {}
-        ms["exchange"] = self.exchange_ms
+        ms.update(self._stage_ms)
         return ms
 
     def free(self):
         if hasattr(self.local, "free"):
             self.local.free()
 
+    def top_dict(self):
+        """The finished root and level-1 nodes as {name: node dict} (host bytes)."""
+        raw = self.top_bytes.cpu().numpy() if hasattr(self.top_bytes, "cpu") else np.asarray(self.top_bytes)
+        out = {}
+        for nd in self.top:
+            cut = lambda k: raw[nd[k][0]:nd[k][0] + nd[k][1]].tobytes()
+            out[nd["name"]] = dict(id=(nd["level"] << 56, nd["digit"]), num_points=nd["num_points"],
+                                   encoding=nd["encoding"], level=nd["level"], xyz=cut("xyz"), rgb=cut("rgb"),
+                                   intensity=cut("intensity"))
+        return out
+
     def gather(self, dst=0):
-        """Merge all ranks' node dictionaries on `dst` (tests, directory writing). Root = concatenation in rank
-        order; everything else is disjoint."""
+        """Merge all ranks' node dictionaries on `dst` (tests, directory writing): the top nodes come from the
+        all-reduced buffer, every deeper node is built by exactly one rank."""
         dist = self.builder.dist
-        local = self.local.to_dict()
+        local = {k: v for k, v in self.local.to_dict().items() if v["level"] >= 2}
         gathered = [None] * dist.get_world_size() if dist.get_rank() == dst else None
         dist.gather_object(local, gathered, dst=dst)
         if dist.get_rank() != dst:
             return None
-        merged = {}
+        merged = self.top_dict()
         for part in gathered:
             for name, nd in part.items():
-                if name == "r" and "r" in merged:
-                    r = merged["r"]
-                    r["num_points"] += nd["num_points"]
-                    for f in ("xyz", "rgb", "intensity"):
-                        r[f] = r[f] + nd[f]
-                else:
-                    assert name not in merged, f"node {name} built by two ranks"
-                    merged[name] = dict(nd)
+                assert name not in merged, f"node {name} built by two ranks"
+                merged[name] = dict(nd)
         return merged
 
 
@@ -110,6 +191,8 @@ class ShardedOctreeBuilder:
         self.device = device
         self.rank = dist.get_rank()
         self.world = dist.get_world_size()
+        if self.world > 8:
+            raise ValueError("the sharded build addresses at most 8 ranks (one node)")
         self.backend = backend or HipBackend(ctx, device)
 
     # -- global bounding box (== find_bounding_box over the whole input, generation.rs:256-270) --
@@ -126,7 +209,13 @@ class ShardedOctreeBuilder:
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         return _oct.Aabb(lo.cpu().numpy(), hi.cpu().numpy())
 
-    def _route(self, owner, send_counts, x, y, z, rgb, intensity):
+    def _sum_i64(self, values):
+        """All-reduce(sum) of a small host vector of int64."""
+        t = self.torch.tensor(np.asarray(values, dtype=np.int64), device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t.cpu().numpy()
+
+    def _route(self, bucket, rank_of_bucket, send_counts, x, y, z, rgb, intensity):
         """Partition by owner and exchange: rows for rank r go to a send buffer, own rows directly into the receive
         buffer; ONE grouped send/recv round moves everything else (RCCL: one ncclGroup == one all-to-all(v))."""
         torch, dist = self.torch, self.dist
@@ -155,7 +244,7 @@ class ShardedOctreeBuilder:
             d = {k: v[off:off + cnt] for k, v in buf.items()}
             d.setdefault("intensity", None)
             dsts.append(d)
-        self.backend.partition(owner, x, y, z, rgb, intensity, dsts)
+        self.backend.partition(bucket, rank_of_bucket, x, y, z, rgb, intensity, dsts)
         ops = []
         for k in planes:
             for peer in range(world):
@@ -173,17 +262,61 @@ class ShardedOctreeBuilder:
     def build(self, resolution, bbox, x, y, z, rgb, intensity=None, max_points_per_node=0):
         torch = self.torch
         world = self.world
+        cap = max_points_per_node or DEFAULT_MAX_POINTS_PER_NODE
         timed = self.device.type == "cuda" if hasattr(self.device, "type") else False
+        marks = []
+
+        def mark():
+            if timed:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                marks.append(e)
+
+        mark()
+        max_level, edges, encodings = self.backend.level_table(resolution, bbox)
+        can_split = max_level >= 2 and edges[1] > resolution
+        # 1. buckets + global plan
+        bucket, counts = self.backend.buckets(resolution, bbox, x, y, z)
+        global_counts = self._sum_i64(counts)
+        rank_of_bucket, split_mask = plan_buckets(global_counts, world, cap, can_split)
+        send_counts = np.bincount(rank_of_bucket, weights=counts, minlength=world).astype(np.int64).tolist()
+        # 2. the exchange
+        recv, matrix = self._route(bucket, rank_of_bucket, send_counts, x, y, z, rgb, intensity)
+        del bucket
+        mark()
+        # 3. local topology, then the global streams of the top of the tree
+        pending = self.backend.build_begin(resolution, bbox, recv["x"], recv["y"], recv["z"], recv["color"],
+                                           recv.get("intensity"), cap, split_mask)
+        l1, l2, _ = pending.top_streams()
+        for c in range(8):
+            if (split_mask >> c) & 1:
+                l1[c] = 0  # a split level-1 node's stream is the sum over its level-2 nodes, derived below
+        summed = self._sum_i64(np.concatenate([l1, l2]))
+        layout = top_layout(summed[:8], summed[8:], split_mask)
+        tree = pending.finish(layout)
+        mark()
+        # 4. finish the root and the level-1 nodes: sum of every rank's sparsely filled global-size nodes
+        specs, nbytes = top_nodes(layout, encodings, intensity is not None)
+        top = torch.zeros(max(nbytes, 16), dtype=torch.uint8, device=self.device)
+        index_of = {}
+        for i in range(min(tree.num_nodes, 9)):
+            nd = tree.node(i)
+            if nd.level <= 1:
+                index_of[_oct.node_name(nd.id_high, nd.id_low)] = i
+        for nd in specs:
+            i = index_of.get(nd["name"])
+            if i is None:
+                continue
+            for which, key in enumerate(("xyz", "rgb", "intensity")):
+                off, length = nd[key]
+                if length:
+                    tree.copy_node_into(i, which, top[off:off + length])
+        if world > 1:
+            self.dist.all_reduce(top, op=self.dist.ReduceOp.SUM)
+        mark()
+        ms = {}
         if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        owner, send_counts = self.backend.owners(resolution, bbox, x, y, z, world)
-        recv, matrix = self._route(owner, send_counts, x, y, z, rgb, intensity)
-        exchange_ms = 0.0
-        if timed:
-            e1.record()
-            e1.synchronize()
-            exchange_ms = e0.elapsed_time(e1)
-        tree = self.backend.build(resolution, bbox, recv["x"], recv["y"], recv["z"], recv["color"], recv.get("intensity"),
-                                  max_points_per_node)
-        return ShardedOctree(self, tree, exchange_ms, matrix)
+            marks[-1].synchronize()
+            ms = {"exchange": marks[0].elapsed_time(marks[1]), "local_build": marks[1].elapsed_time(marks[2]),
+                  "top_merge": marks[2].elapsed_time(marks[3])}
+        return ShardedOctree(self, tree, specs, top, ms, matrix, (rank_of_bucket, split_mask))

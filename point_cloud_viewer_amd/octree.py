@@ -240,28 +240,43 @@ class Context:
                                                    int(samples_per_divisor), C.byref(bad)))
         return bad.value
 
-    def root_owners(self, resolution, bounding_box, x, y, z, world):
-        """(owner int32 tensor, counts list) for device-resident points: owner = root octant * world // 8."""
+    def route_buckets(self, resolution, bounding_box, x, y, z):
+        """(bucket int32 tensor, 64 counts) for device-resident points: bucket = 8 * level-1 digit + level-2 digit."""
         import torch
         p, keep = self._points(x, y, z)
         if p.mem != L.MEM_DEVICE:
-            raise ValueError("root_owners needs device tensors")
+            raise ValueError("route_buckets needs device tensors")
         pr = self._params(resolution, bounding_box.min, bounding_box.max)
-        owner = torch.empty(p.n, dtype=torch.int32, device=x.device)
-        counts = (C.c_uint64 * 8)()
-        self._check(self.lib.pcv_root_owners(self.handle, C.byref(pr), C.byref(p), int(world), owner.data_ptr(), counts))
-        return owner, [int(counts[r]) for r in range(world)]
+        bucket = torch.empty(p.n, dtype=torch.int32, device=x.device)
+        counts = (C.c_uint64 * 64)()
+        self._check(self.lib.pcv_route_buckets(self.handle, C.byref(pr), C.byref(p), bucket.data_ptr(), counts))
+        return bucket, np.array(counts[:], dtype=np.int64)
 
-    def partition_by_owner(self, owner, x, y, z, color, intensity, dsts):
+    def partition_by_owner(self, owner, x, y, z, color, intensity, dsts, rank_of_bucket=None):
         """Stable partition of device planes by owner. dsts: per owner a dict(x=, y=, z=, color=, intensity=) of
-        device tensors (views into send / receive buffers) that receive that owner's rows in input order."""
+        device tensors (views into send / receive buffers) that receive that owner's rows in input order. With
+        rank_of_bucket (64 entries) `owner` holds buckets and the table maps them to ranks."""
         p, keep = self._points(x, y, z, color, intensity)
         arr = (L.RouteDst * len(dsts))()
         for k, d in enumerate(dsts):
             arr[k].x, arr[k].y, arr[k].z = d["x"].data_ptr(), d["y"].data_ptr(), d["z"].data_ptr()
             arr[k].color = d["color"].data_ptr()
             arr[k].intensity = d["intensity"].data_ptr() if d.get("intensity") is not None else None
-        self._check(self.lib.pcv_partition_by_owner(self.handle, C.byref(p), owner.data_ptr(), len(dsts), arr))
+        table = None
+        if rank_of_bucket is not None:
+            table = (C.c_uint8 * 64)(*[int(v) for v in rank_of_bucket])
+        self._check(self.lib.pcv_partition_by_owner(self.handle, C.byref(p), owner.data_ptr(), len(dsts), arr, table))
+
+    def build_begin(self, resolution, bounding_box, x, y, z, color, intensity=None, max_points_per_node=0,
+                    force_split_level1=0):
+        """First half of the two-step build (multi-GPU path): topology + stream lengths. Returns a PendingBuild; the
+        input tensors must stay alive until finish()."""
+        p, keep = self._points(x, y, z, color, intensity)
+        flags = (int(force_split_level1) & 0xFF) << 8
+        pr = self._params(resolution, bounding_box.min, bounding_box.max, max_points_per_node, flags)
+        h = C.c_void_p()
+        self._check(self.lib.pcv_build_begin(self.handle, C.byref(pr), C.byref(p), C.byref(h)))
+        return PendingBuild(self, h, keep)
 
     def sort_keys64(self, keys, begin_bit=0, end_bit=64):
         b = _Buf(keys, np.uint64, "keys")
@@ -286,6 +301,52 @@ def level_table(bbox_min, bbox_max, resolution, cap=64):
     enc = (C.c_int32 * (cap + 2))()
     ml = lib.pcv_level_table(bmin, bmax, float(resolution), cap, edge, enc)
     return ml, np.array(edge[:ml + 1]), np.array(enc[:ml + 1], dtype=np.int32)
+
+
+class PendingBuild:
+    """A tree between pcv_build_begin and pcv_build_finish."""
+
+    def __init__(self, ctx, handle, keep):
+        self.ctx, self.handle, self._keep = ctx, handle, keep
+        ctx._children.add(self)
+
+    def top_streams(self):
+        """(l1[8], l2[64], l1_split_mask): local stream lengths of the level-1 / level-2 nodes (0 = absent)."""
+        ts = L.TopStreams()
+        self.ctx._check(self.ctx.lib.pcv_build_top_streams(self.handle, C.byref(ts)))
+        return np.array(ts.l1[:], dtype=np.int64), np.array(ts.l2[:], dtype=np.int64), int(ts.l1_split_mask)
+
+    def finish(self, layout=None):
+        """Second half: encode, record sort, promotion. layout = dict(root_points, l1_stream[8], l1_offset[8],
+        l2_offset[64]) with the GLOBAL top-of-tree streams, or None for a self-contained tree."""
+        tl = None
+        if layout is not None:
+            tl = L.TopLayout()
+            tl.root_points = int(layout["root_points"])
+            for c in range(8):
+                tl.l1_stream[c] = int(layout["l1_stream"][c])
+                tl.l1_offset[c] = int(layout["l1_offset"][c])
+            for b in range(64):
+                tl.l2_offset[b] = int(layout["l2_offset"][b])
+        h, self.handle = self.handle, None
+        rc = self.ctx.lib.pcv_build_finish(h, C.byref(tl) if tl is not None else None)
+        self._keep = None
+        if rc != L.PCV_OK:
+            msg = self.ctx.lib.pcv_last_error(self.ctx.handle)
+            self.ctx.lib.pcv_octree_free(h)
+            raise L.PcvError(rc, msg.decode() if msg else "")
+        return OctreeResult(self.ctx, h)
+
+    def free(self):
+        if self.handle is not None and self.ctx.handle is not None:
+            self.ctx.lib.pcv_octree_free(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class Shapes:
@@ -437,6 +498,14 @@ class OctreeResult:
         buf = np.zeros(need.value, dtype=np.uint8)
         self.ctx._check(self.lib.pcv_octree_nodes_blob(self.handle, ip, idx.size, buf.ctypes.data, buf.size, C.byref(need)))
         return buf.tobytes()
+
+    def copy_node_into(self, i, which, dst):
+        """Copy node i's bytes (0 xyz, 1 rgb, 2 intensity) from the device blob into a uint8 tensor/array view."""
+        if hasattr(dst, "data_ptr"):
+            ptr, cap, mem = dst.data_ptr(), dst.numel() * dst.element_size(), (L.MEM_DEVICE if dst.is_cuda else L.MEM_HOST)
+        else:
+            ptr, cap, mem = dst.ctypes.data, dst.nbytes, L.MEM_HOST
+        self.ctx._check(self.lib.pcv_octree_copy_node(self.handle, i, which, ptr, cap, mem))
 
     def to_dict(self):
         """{node name: dict(id, num_points, encoding, level, xyz, rgb, intensity)} — same shape the test-side

@@ -213,6 +213,22 @@ def build_closed(resolution, bmin, bmax, x, y, z, rgb, intensity=None, threads=1
     return Octree(h)
 
 
+def build_closed_shard(resolution, bmin, bmax, x, y, z, rgb, intensity=None, threads=1, force_mask=0, layout=None):
+    """One rank's share of a multi-rank build. Returns (Octree, streams[73]) — streams = 8 level-1 + 64 level-2 stream
+    lengths + the local level-1 split mask. layout = array of 1 + 8 + 8 + 64 u64 (root_points, l1_stream, l1_offset,
+    l2_offset) or None."""
+    x, y, z, rgb, intensity, ip = _pts(x, y, z, rgb, intensity)
+    bmin, bmax = _vec3(bmin), _vec3(bmax)
+    streams = np.zeros(73, dtype=np.uint64)
+    lay = None if layout is None else np.ascontiguousarray(layout, dtype=np.uint64)
+    f = lib().pcvo_build_closed_shard
+    f.restype = C.c_void_p
+    f.argtypes = [C.c_double, _dp, _dp, C.c_uint64, _dp, _dp, _dp, _u8p, _fp, C.c_int, C.c_uint, C.c_void_p, C.c_void_p]
+    h = f(resolution, _d(bmin), _d(bmax), x.size, _d(x), _d(y), _d(z), rgb.ctypes.data_as(_u8p), ip, threads,
+          int(force_mask), None if lay is None else lay.ctypes.data, streams.ctypes.data)
+    return Octree(h), streams
+
+
 def load_dir(path):
     return Octree(lib().pcvo_load_dir(str(path).encode()))
 

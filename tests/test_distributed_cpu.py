@@ -23,11 +23,26 @@ def _free_port():
     return p
 
 
+class _Node:
+    def __init__(self, level, id_high, id_low):
+        self.level, self.id_high, self.id_low = level, id_high, id_low
+
+
 class _HostTree:
+    """Stand-in for OctreeResult on top of an oracle tree (nodes in breadth-first order like the library's)."""
+
     def __init__(self, oct_):
         self.oct = oct_
-        self.num_nodes = len(oct_.nodes)
-        self.num_points = oct_.total_points()
+        self.names = sorted(oct_.nodes, key=lambda k: (oct_.nodes[k]["level"], oct_.nodes[k]["id"]))
+        self.num_nodes = len(self.names)
+
+    def node(self, i):
+        nd = self.oct.nodes[self.names[i]]
+        return _Node(nd["level"], nd["id"][0], nd["id"][1])
+
+    def copy_node_into(self, i, which, dst):
+        data = self.oct.nodes[self.names[i]][("xyz", "rgb", "intensity")[which]]
+        dst.copy_(torch.frombuffer(bytearray(data), dtype=torch.uint8))
 
     def to_dict(self):
         return {k: dict(num_points=v["num_points"], encoding=v["encoding"], xyz=v["xyz"], rgb=v["rgb"],
@@ -37,6 +52,27 @@ class _HostTree:
         return {}
 
 
+class _HostPending:
+    def __init__(self, O, cap, args, force_mask):
+        self.O, self.cap, self.args, self.force_mask = O, cap, args, force_mask
+
+    def _run(self, layout):
+        resolution, bbox, x, y, z, rgb, intensity = self.args
+        with self.O.max_points_per_node(self.cap):
+            return self.O.build_closed_shard(resolution, bbox.min, bbox.max, x.numpy(), y.numpy(), z.numpy(), rgb.numpy(),
+                                             None if intensity is None else intensity.numpy(),
+                                             force_mask=self.force_mask, layout=layout)
+
+    def top_streams(self):
+        _, s = self._run(None)
+        return s[:8].astype(np.int64), s[8:72].astype(np.int64), int(s[72])
+
+    def finish(self, layout):
+        flat = [layout["root_points"]] + list(layout["l1_stream"]) + list(layout["l1_offset"]) + list(layout["l2_offset"])
+        t, _ = self._run(np.array(flat, dtype=np.uint64))
+        return _HostTree(t)
+
+
 class HostBackend:
     def __init__(self, O, cap):
         self.O, self.cap = O, cap
@@ -44,12 +80,16 @@ class HostBackend:
     def aabb(self, x, y, z):
         return self.O.aabb(x.numpy(), y.numpy(), z.numpy())
 
-    def owners(self, resolution, bbox, x, y, z, world):
-        keys = self.O.chain_keys64(bbox.min, bbox.max, resolution, 1, x.numpy(), y.numpy(), z.numpy())
-        owner = torch.from_numpy(((keys >> np.uint64(60)).astype(np.int64) * world) // 8)
-        return owner, torch.bincount(owner, minlength=world).tolist()
+    def level_table(self, resolution, bbox):
+        return self.O.level_table(bbox.min, bbox.max, resolution)
 
-    def partition(self, owner, x, y, z, rgb, intensity, dsts):
+    def buckets(self, resolution, bbox, x, y, z):
+        keys = self.O.chain_keys64(bbox.min, bbox.max, resolution, 2, x.numpy(), y.numpy(), z.numpy())
+        bucket = torch.from_numpy((keys >> np.uint64(57)).astype(np.int64) & 63)
+        return bucket, np.bincount(bucket.numpy(), minlength=64).astype(np.int64)
+
+    def partition(self, bucket, rank_of_bucket, x, y, z, rgb, intensity, dsts):
+        owner = torch.from_numpy(np.asarray(rank_of_bucket, dtype=np.int64))[bucket]
         for k, d in enumerate(dsts):
             sel = owner == k  # boolean-mask selection keeps input order
             d["x"].copy_(x[sel])
@@ -59,11 +99,9 @@ class HostBackend:
             if intensity is not None:
                 d["intensity"].copy_(intensity[sel])
 
-    def build(self, resolution, bbox, x, y, z, rgb, intensity, max_points_per_node=0):
-        with self.O.max_points_per_node(self.cap):
-            t = self.O.build_closed(resolution, bbox.min, bbox.max, x.numpy(), y.numpy(), z.numpy(), rgb.numpy(),
-                                    None if intensity is None else intensity.numpy())
-        return _HostTree(t)
+    def build_begin(self, resolution, bbox, x, y, z, rgb, intensity, max_points_per_node, force_split_level1):
+        assert max_points_per_node == self.cap
+        return _HostPending(self.O, self.cap, (resolution, bbox, x, y, z, rgb, intensity), force_split_level1)
 
 
 def _worker(rank, world, port, n, cap, with_intensity, out_path):
@@ -90,8 +128,11 @@ def _worker(rank, world, port, n, cap, with_intensity, out_path):
     b = pdist.ShardedOctreeBuilder(None, dist, torch.device("cpu"), backend=HostBackend(O, cap))
     bbox = b.global_bbox(tx, ty, tz)
     assert np.array_equal(bbox.min, bmin) and np.array_equal(bbox.max, bmax)
-    res = b.build(0.001, bbox, tx, ty, tz, trgb, tint)
+    res = b.build(0.001, bbox, tx, ty, tz, trgb, tint, max_points_per_node=cap)
     assert int(res.counts.sum()) == n
+    rank_of, split_mask = res.plan
+    assert split_mask != 0  # some level-1 node is split globally ...
+    assert any(len(set(rank_of[c * 8:c * 8 + 8].tolist())) > 1 for c in range(8) if (split_mask >> c) & 1)  # ... across ranks
     merged = res.gather(dst=0)
     if rank == 0:
         with O.max_points_per_node(cap):
@@ -117,9 +158,27 @@ def test_sharded_build_equals_single_build(tmp_path, world, with_intensity):
     assert out.read_text() == "OK", out.read_text()
 
 
-def test_octant_ownership_is_contiguous_and_balanced():
-    from point_cloud_viewer_amd.distributed import owner_of_octant
+def test_bucket_plan_is_balanced_and_keeps_unsplit_octants_whole():
+    from point_cloud_viewer_amd.distributed import plan_buckets, top_layout
+    rng = np.random.default_rng(5)
+    g = rng.integers(0, 5_000_000, 64)
+    g[8:16] = [10, 0, 3, 0, 0, 7, 0, 1]  # octant 1 stays a leaf (21 points)
+    g[24:32] = 0                          # octant 3 is empty
     for world in (1, 2, 4, 8):
-        owners = [owner_of_octant(c, world) for c in range(8)]
-        assert owners == sorted(owners) and set(owners) == set(range(world))
-        assert all(owners.count(r) == 8 // world for r in range(world))
+        rank_of, mask = plan_buckets(g, world, 100_000, True)
+        assert mask == 0b11110101
+        assert len(set(rank_of[8:16])) == 1  # a leaf octant lives on ONE rank
+        loads = np.bincount(rank_of, weights=g, minlength=world)
+        assert loads.max() <= 1.1 * loads.mean() + 1
+        again, _ = plan_buckets(g.copy(), world, 100_000, True)
+        assert np.array_equal(rank_of, again)
+    rank_of, mask = plan_buckets(g, 4, 100_000, False)  # level-1 nodes cannot split: whole octants only
+    assert mask == 0 and all(len(set(rank_of[c * 8:c * 8 + 8])) == 1 for c in range(8))
+    # layout: stream lengths follow |pre(inner)| = sum ceil(|pre(child)| / 8)
+    l2 = np.zeros(64, dtype=np.int64)
+    l2[0:3] = [17, 8, 1]
+    l1 = np.zeros(8, dtype=np.int64)
+    l1[5] = 9
+    lay = top_layout(l1, l2, 0b1)
+    assert lay["l2_offset"][:3] == [0, 3, 4] and lay["l1_stream"][0] == 5 and lay["l1_stream"][5] == 9
+    assert lay["l1_offset"][5] == 1 and lay["root_points"] == 3

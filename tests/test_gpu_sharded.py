@@ -48,45 +48,71 @@ def test_world_size_one_over_rccl():
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4, 8])
-def test_virtual_ranks_on_one_gpu(world):
+def test_route_buckets_and_partition_kernels():
     import torch
+    n = 300_001
+    x, y, z, rgb, bmin, bmax = synthetic.gaussian_clusters(n, seed=31, num_clusters=9, extent=200.0, sigma_range=(0.02, 9.0))
+    inten = (np.arange(n) % 251).astype(np.float32)
+    ctx = pcv.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    bbox = pcv.Aabb(bmin, bmax)
+    tx, ty, tz = (torch.from_numpy(a).cuda() for a in (x, y, z))
+    trgb, tint = torch.from_numpy(rgb).cuda(), torch.from_numpy(inten).cuda()
+    bucket, counts = ctx.route_buckets(0.001, bbox, tx, ty, tz)
+    keys = O.chain_keys64(bmin, bmax, 0.001, 2, x, y, z)
+    want = ((keys >> np.uint64(57)).astype(np.int64) & 63)
+    assert np.array_equal(bucket.cpu().numpy(), want)
+    assert np.array_equal(counts, np.bincount(want, minlength=64))
+    for world in (1, 3, 8):
+        rank_of, _ = pdist.plan_buckets(counts, world, 5000, True)
+        owner = rank_of[want].astype(np.int64)
+        cnt = np.bincount(owner, minlength=world)
+        dsts = [dict(x=torch.empty(c, dtype=torch.float64, device="cuda"), y=torch.empty(c, dtype=torch.float64, device="cuda"),
+                     z=torch.empty(c, dtype=torch.float64, device="cuda"), color=torch.empty((c, 3), dtype=torch.uint8, device="cuda"),
+                     intensity=torch.empty(c, dtype=torch.float32, device="cuda")) for c in cnt]
+        ctx.partition_by_owner(bucket, tx, ty, tz, trgb, tint, dsts, rank_of)
+        for d in range(world):
+            sel = torch.from_numpy(owner == d).cuda()
+            assert torch.equal(dsts[d]["x"], tx[sel]) and torch.equal(dsts[d]["y"], ty[sel]) and torch.equal(dsts[d]["z"], tz[sel])
+            assert torch.equal(dsts[d]["color"], trgb[sel]) and torch.equal(dsts[d]["intensity"], tint[sel])  # stable
+
+
+@pytest.mark.parametrize("world,cap,with_intensity", [(2, 0, False), (4, 20_000, True), (8, 3_000, False)])
+def test_virtual_ranks_on_one_gpu(world, cap, with_intensity):
+    """The real ShardedOctreeBuilder + HipBackend, N virtual ranks as threads on one GPU (tests/thread_dist.py)."""
+    import torch
+    from thread_dist import run_ranks
     n = 400_000
     x, y, z, rgb, bmin, bmax = synthetic.gaussian_clusters(n, seed=29, num_clusters=7, extent=300.0,
                                                            sigma_range=(0.02, 5.0))
-    ctx = pcv.Context(0, stream=torch.cuda.current_stream().cuda_stream)
-    backend = pdist.HipBackend(ctx, torch.device("cuda", 0))
-    bbox = pcv.Aabb(bmin, bmax)
-    # every virtual rank owns a contiguous input slice, computes digits + stable partition with the HIP kernels
-    parts = {d: [] for d in range(world)}
-    for r in range(world):
-        sl = slice(r * n // world, (r + 1) * n // world)
+    inten = (np.arange(n) % 977).astype(np.float32) if with_intensity else None
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def rank_main(rank, dist):
+        torch.cuda.set_device(0)
+        ctx = pcv.Context(0, stream=stream)
+        sl = slice(rank * n // world, (rank + 1) * n // world)
+        if world == 8 and rank == 5:
+            sl = slice(0, 0)  # a rank without input
+        if world == 8 and rank == 4:
+            sl = slice(4 * n // 8, 6 * n // 8)
         tx, ty, tz = (torch.from_numpy(np.ascontiguousarray(a[sl])).cuda() for a in (x, y, z))
         trgb = torch.from_numpy(np.ascontiguousarray(rgb[sl])).cuda()
-        owner, counts = backend.owners(0.001, bbox, tx, ty, tz, world)
-        keys = O.chain_keys64(bmin, bmax, 0.001, 1, x[sl], y[sl], z[sl])
-        want_owner = ((keys >> np.uint64(60)).astype(np.int64) * world) // 8
-        assert np.array_equal(owner.cpu().numpy(), want_owner)
-        assert counts == np.bincount(want_owner, minlength=world).tolist()
-        dsts = [dict(x=torch.empty(c, dtype=torch.float64, device="cuda"), y=torch.empty(c, dtype=torch.float64, device="cuda"),
-                     z=torch.empty(c, dtype=torch.float64, device="cuda"), color=torch.empty((c, 3), dtype=torch.uint8, device="cuda"),
-                     intensity=None) for c in counts]
-        backend.partition(owner, tx, ty, tz, trgb, None, dsts)
-        for d in range(world):
-            sel = torch.from_numpy(want_owner == d).cuda()
-            assert torch.equal(dsts[d]["x"], tx[sel]) and torch.equal(dsts[d]["z"], tz[sel])  # stable
-            assert torch.equal(dsts[d]["color"], trgb[sel])
-            parts[d].append((dsts[d]["x"], dsts[d]["y"], dsts[d]["z"], dsts[d]["color"]))
-    merged = {}
-    for d in range(world):  # receivers concatenate in source-rank order
-        rx, ry, rz, rrgb = (torch.cat([p[i] for p in parts[d]]).contiguous() for i in range(4))
-        tree = backend.build(0.001, bbox, rx, ry, rz, rrgb, None)
-        for name, nd in tree.to_dict().items():
-            if name == "r" and "r" in merged:
-                merged["r"]["num_points"] += nd["num_points"]
-                merged["r"]["xyz"] += nd["xyz"]
-                merged["r"]["rgb"] += nd["rgb"]
-            else:
-                assert name not in merged
-                merged[name] = nd
-    _same(merged, O.build_closed(0.001, bmin, bmax, x, y, z, rgb, threads=4))
+        tint = torch.from_numpy(np.ascontiguousarray(inten[sl])).cuda() if with_intensity else None
+        b = pdist.ShardedOctreeBuilder(ctx, dist, dev)
+        bbox = b.global_bbox(tx, ty, tz)
+        assert np.array_equal(bbox.min, bmin) and np.array_equal(bbox.max, bmax)
+        res = b.build(0.001, bbox, tx, ty, tz, trgb, tint, max_points_per_node=cap)
+        merged = res.gather(0)
+        return merged, res.plan
+
+    out = run_ranks(world, rank_main)
+    merged, (rank_of, split_mask) = out[0]
+    with O.max_points_per_node(cap or 100_000):
+        want = O.build_closed(0.001, bmin, bmax, x, y, z, rgb, inten, threads=4)
+    assert set(merged) == set(want.nodes)
+    for name, nd in want.nodes.items():
+        for f in ("num_points", "encoding", "xyz", "rgb") + (("intensity",) if with_intensity else ()):
+            assert merged[name][f] == nd[f], (name, f)
+    if cap:
+        assert split_mask != 0 and len(set(rank_of.tolist())) == world
