@@ -219,6 +219,8 @@ int pcv_partition_by_owner(pcv_ctx* ctx, const pcv_points* points, const uint32_
 
 /* K3: stable LSD radix sort of 64-bit keys on bits [begin_bit, end_bit), in place. */
 int pcv_sort_keys64(pcv_ctx* ctx, uint64_t* keys, uint64_t n, int begin_bit, int end_bit, int mem);
+/* K3: the 32-bit key variant the build uses when ten levels of path digits suffice. */
+int pcv_sort_keys32(pcv_ctx* ctx, uint32_t* keys, uint64_t n, int begin_bit, int end_bit, int mem);
 /* K3: stable sort of (u32 key, u32 value) pairs on bits [begin_bit, end_bit), in place. */
 int pcv_sort_pairs32(pcv_ctx* ctx, uint32_t* keys, uint32_t* values, uint64_t n, int begin_bit, int end_bit,
                      int mem);

@@ -102,6 +102,7 @@ _SIGNATURES = {
     "pcv_build_top_streams": (C.c_int, [_vp, C.POINTER(TopStreams)]),
     "pcv_build_finish": (C.c_int, [_vp, C.POINTER(TopLayout)]),
     "pcv_sort_keys64": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, C.c_int, C.c_int]),
+    "pcv_sort_keys32": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, C.c_int, C.c_int]),
     "pcv_sort_pairs32": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.c_int, C.c_int, C.c_int]),
     "pcv_selftest_division": (C.c_int, [_vp, C.POINTER(C.c_double), C.c_int, C.c_uint64, C.POINTER(C.c_uint64)]),
     "pcv_ply_read": (C.c_int, [C.c_char_p, C.POINTER(_vp), C.c_char_p, C.c_uint64]),

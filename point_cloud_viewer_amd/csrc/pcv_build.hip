@@ -145,6 +145,11 @@ extern "C" int pcv_ctx_kernel_stats(pcv_ctx* ctx, int kernel_id, const char** na
                                     double* total_ms) {
   if (!ctx) return PCV_E_INVALID;
   if (kernel_id < 0 || kernel_id >= PCV_K_COUNT) return PCV_K_COUNT;
+  if (!ctx->prof_pending.empty()) {  // launches of the stage-level entry points are resolved on first read
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->prof_resolve();
+  }
   if (name) *name = kKernelNames[kernel_id];
   if (launches) *launches = ctx->prof_launches[kernel_id];
   if (total_ms) *total_ms = ctx->prof_ms[kernel_id];
@@ -1056,6 +1061,9 @@ static int sort_api(pcv_ctx* ctx, KeyT* keys, uint32_t* values, uint64_t n, int 
 
 extern "C" int pcv_sort_keys64(pcv_ctx* ctx, uint64_t* keys, uint64_t n, int begin_bit, int end_bit, int mem) {
   return sort_api<uint64_t>(ctx, keys, nullptr, n, begin_bit, end_bit, mem);
+}
+extern "C" int pcv_sort_keys32(pcv_ctx* ctx, uint32_t* keys, uint64_t n, int begin_bit, int end_bit, int mem) {
+  return sort_api<uint32_t>(ctx, keys, nullptr, n, begin_bit, end_bit, mem);
 }
 extern "C" int pcv_sort_pairs32(pcv_ctx* ctx, uint32_t* keys, uint32_t* values, uint64_t n, int begin_bit, int end_bit,
                                 int mem) {

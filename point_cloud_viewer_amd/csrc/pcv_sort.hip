@@ -27,7 +27,10 @@ constexpr int kRadix = 256;
 #define PCV_KEYS_WAVES 4
 #endif
 constexpr int kMaxGroups = PCV_SORT_GROUPS;
-constexpr int kKptKeys = 16;  // keys-only kernel: keys per lane per tile
+#ifndef PCV_KEYS_KPT
+#define PCV_KEYS_KPT 16
+#endif
+constexpr int kKptKeys = PCV_KEYS_KPT;  // keys-only kernel: keys per lane per tile
 constexpr int kKptRec = 8;    // record kernel
 constexpr int kTileUnit = kBlock * kKptKeys;  // chunk granularity (multiple of both tile sizes)
 
@@ -139,8 +142,7 @@ __global__ __launch_bounds__(256) void scan_kernel(uint32_t* __restrict__ hist, 
 struct DigitState {
   uint32_t whist[kWaves][kRadix];  // per-wave digit counters, then exclusive prefix over the waves
   uint32_t digit_base[kRadix];     // global position of the next key of each digit for this workgroup
-  uint32_t tile_start[kRadix];     // exclusive prefix of the digit counts inside the tile
-  uint32_t tile_count[kRadix];
+  uint32_t delta[kRadix];          // digit_base - (digit's start inside the tile): LDS slot p goes to delta[digit] + p
   uint32_t wave_tot[kWaves];
 };
 
@@ -165,38 +167,65 @@ __device__ __forceinline__ void init_digit_base(DigitState& S, const uint32_t* _
   __syncthreads();
 }
 
-// Rank of one key among the earlier keys of the same digit inside this wave's slice of the tile (stable:
-// iteration-major, lane-minor == input order). 8 ballots build the mask of lanes holding the same digit.
-__device__ __forceinline__ uint32_t wave_rank(DigitState& S, int wave, uint64_t lane_lt, bool valid, uint32_t d) {
-  uint64_t peers = __ballot(valid);
+// Rank of every key of this lane among the earlier keys of the same digit inside the wave's slice of the tile
+// (stable: iteration-major, lane-minor == input order). Per key, 8 ballots build the mask of lanes holding the same
+// digit; every lane reads the wave's digit counter, then the first lane of the group bumps it by the group size
+// (non-returning LDS add). A wave's LDS operations retire in issue order, so the reads and adds of all kKpt
+// iterations are issued back to back — no round trip per key — and every read still sees exactly the counts of the
+// earlier iterations.
+// The kernel is VALU-issue bound (a wave64 op takes 4 clocks on a 16-lane SIMD), so the mask arithmetic is written
+// on 32-bit halves in the shape the ISA has single instructions for: one sign-extracting bit-field op per digit bit,
+// one compare (the ballot), one three-input bit op per half (p & ~(ballot ^ m)), mbcnt for the lanes below.
+template <int kKpt, typename KeyT, bool kFull>
+__device__ __forceinline__ void wave_rank_all(DigitState& S, int wave, uint32_t wbase, uint32_t tile_n,
+                                              const KeyT (&key)[kKpt], int shift, uint32_t mask, uint16_t (&lpos)[kKpt]) {
+  constexpr int kBatch = 8;  // adds in flight; more costs registers the 16-keys-per-lane kernel does not have
+  static_assert(kKpt % kBatch == 0, "keys per lane must be a multiple of the batch");
 #pragma unroll
-  for (int b = 0; b < 8; ++b) {
-    const bool bit = (d >> b) & 1u;
-    const uint64_t bal = __ballot(bit);
-    peers &= bit ? bal : ~bal;
+  for (int i0 = 0; i0 < kKpt; i0 += kBatch) {
+    uint32_t pre[kBatch], rank_in[kBatch];
+#pragma unroll
+    for (int j = 0; j < kBatch; ++j) {
+      const int i = i0 + j;
+      const bool valid = kFull || wbase + i * 64 < tile_n;
+      const uint32_t d = (uint32_t)(key[i] >> shift) & mask;
+      uint32_t plo = 0xffffffffu, phi = 0xffffffffu;
+      if (!kFull) {
+        const uint64_t vm = __ballot(valid);
+        plo = (uint32_t)vm;
+        phi = (uint32_t)(vm >> 32);
+      }
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        int m;  // all ones when bit b of the digit is set (asm: keep the optimiser from re-deriving it the long way)
+        asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(d), "n"(b));
+        const uint64_t bal = __builtin_amdgcn_ballot_w64(m != 0);
+        plo = __builtin_amdgcn_bitop3_b32(plo, (uint32_t)bal, (uint32_t)m, 0x90);  // p & ~(ballot ^ m)
+        phi = __builtin_amdgcn_bitop3_b32(phi, (uint32_t)(bal >> 32), (uint32_t)m, 0x90);
+      }
+      rank_in[j] = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+      uint32_t* slot = &S.whist[wave][d];
+      pre[j] = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (valid && rank_in[j] == 0)
+        (void)__hip_atomic_fetch_add(slot, (uint32_t)(__popc(plo) + __popc(phi)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+#pragma unroll
+    for (int j = 0; j < kBatch; ++j) lpos[i0 + j] = (uint16_t)(pre[j] + rank_in[j]);
   }
-  const uint32_t rank_in = __popcll(peers & lane_lt);
-  const uint32_t cnt = __popcll(peers);
-  uint32_t pre = 0;
-  if (valid) pre = S.whist[wave][d];
-  __builtin_amdgcn_wave_barrier();
-  if (valid && rank_in == 0) S.whist[wave][d] = pre + cnt;
-  __builtin_amdgcn_wave_barrier();
-  return pre + rank_in;
 }
 
-// After all waves ranked their slices: per digit t the exclusive prefix over the waves, the tile count and the
-// exclusive scan over the digits. Ends with a barrier.
+// After all waves ranked their slices: per digit t the exclusive prefix over the waves (folded together with the
+// digit's start inside the tile, so the LDS slot of a key is whist[wave][d] + its rank), the global position of the
+// digit's run (delta) and the advance of digit_base. Starts and ends with a barrier.
 __device__ __forceinline__ void digit_scan(DigitState& S, int t, int lane, int wave) {
   __syncthreads();
+  uint32_t pre[kWaves];
   uint32_t acc = 0;
 #pragma unroll
   for (int w = 0; w < kWaves; ++w) {
-    uint32_t v = S.whist[w][t];
-    S.whist[w][t] = acc;
-    acc += v;
+    pre[w] = acc;
+    acc += S.whist[w][t];
   }
-  S.tile_count[t] = acc;
   uint32_t inc = acc;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -208,7 +237,12 @@ __device__ __forceinline__ void digit_scan(DigitState& S, int t, int lane, int w
   uint32_t woff = 0;
 #pragma unroll
   for (int w = 0; w < kWaves; ++w) woff += (w < wave) ? S.wave_tot[w] : 0u;
-  S.tile_start[t] = woff + inc - acc;
+  const uint32_t start = woff + inc - acc;
+#pragma unroll
+  for (int w = 0; w < kWaves; ++w) S.whist[w][t] = start + pre[w];
+  const uint32_t base = S.digit_base[t];
+  S.delta[t] = base - start;
+  S.digit_base[t] = base + acc;
   __syncthreads();
 }
 
@@ -224,7 +258,6 @@ __global__ __launch_bounds__(kBlock, PCV_KEYS_WAVES) void downsweep_keys_kernel(
   __shared__ DigitState S;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const uint32_t mask = (1u << nbits) - 1u;
-  const uint64_t lane_lt = (1ull << lane) - 1ull;
   init_digit_base(S, offsets, totals, groups, t, lane, wave);
 
   const uint64_t begin = (uint64_t)blockIdx.x * chunk;
@@ -244,17 +277,16 @@ __global__ __launch_bounds__(kBlock, PCV_KEYS_WAVES) void downsweep_keys_kernel(
   for (uint64_t base = begin; base < end; base += kTile) {
     const uint32_t tile_n = (uint32_t)((end - base) < (uint64_t)kTile ? (end - base) : (uint64_t)kTile);
     uint16_t lpos[kKpt];
-#pragma unroll
-    for (int i = 0; i < kKpt; ++i) {
-      const bool valid = wbase + i * 64 < tile_n;
-      lpos[i] = (uint16_t)wave_rank(S, wave, lane_lt, valid, (uint32_t)(key[i] >> shift) & mask);
-    }
+    if (tile_n == (uint32_t)kTile)
+      wave_rank_all<kKpt, KeyT, true>(S, wave, wbase, tile_n, key, shift, mask, lpos);
+    else
+      wave_rank_all<kKpt, KeyT, false>(S, wave, wbase, tile_n, key, shift, mask, lpos);
     digit_scan(S, t, lane, wave);
 #pragma unroll
     for (int i = 0; i < kKpt; ++i) {
       if (wbase + i * 64 < tile_n) {
         const uint32_t d = (uint32_t)(key[i] >> shift) & mask;
-        skeys[S.tile_start[d] + S.whist[wave][d] + lpos[i]] = key[i];
+        skeys[S.whist[wave][d] + lpos[i]] = key[i];
       }
     }
     // the key registers are free now: fetch the next tile while this one drains through LDS
@@ -274,13 +306,11 @@ __global__ __launch_bounds__(kBlock, PCV_KEYS_WAVES) void downsweep_keys_kernel(
       if (p < tile_n) {
         const KeyT k = skeys[p];
         const uint32_t d = (uint32_t)(k >> shift) & mask;
-        keys_out[S.digit_base[d] + (p - S.tile_start[d])] = k;
+        keys_out[S.delta[d] + p] = k;
       }
     }
-    __syncthreads();
-    S.digit_base[t] += S.tile_count[t];
 #pragma unroll
-    for (int w = 0; w < kWaves; ++w) S.whist[w][t] = 0;
+    for (int w = 0; w < kWaves; ++w) S.whist[w][t] = 0;  // last read before the barrier above
     __syncthreads();
   }
 }
@@ -306,7 +336,6 @@ __global__ __launch_bounds__(kBlock, 4) void downsweep_rec_kernel(const uint32_t
   __shared__ DigitState S;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const uint32_t mask = (1u << nbits) - 1u;
-  const uint64_t lane_lt = (1ull << lane) - 1ull;
   init_digit_base(S, offsets, totals, groups, t, lane, wave);
 
   const uint64_t begin = (uint64_t)blockIdx.x * chunk;
@@ -326,17 +355,16 @@ __global__ __launch_bounds__(kBlock, 4) void downsweep_rec_kernel(const uint32_t
       if (kHasVec) vec[i] = valid ? rp.vec_in[base + li] : make_uint4(0, 0, 0, 0);
     }
     uint16_t lpos[kKpt];
-#pragma unroll
-    for (int i = 0; i < kKpt; ++i) {
-      const bool valid = wbase + i * 64 < tile_n;
-      lpos[i] = (uint16_t)wave_rank(S, wave, lane_lt, valid, (key[i] >> shift) & mask);
-    }
+    if (tile_n == (uint32_t)kTile)
+      wave_rank_all<kKpt, uint32_t, true>(S, wave, wbase, tile_n, key, shift, mask, lpos);
+    else
+      wave_rank_all<kKpt, uint32_t, false>(S, wave, wbase, tile_n, key, shift, mask, lpos);
     digit_scan(S, t, lane, wave);
 #pragma unroll
     for (int i = 0; i < kKpt; ++i) {
       if (wbase + i * 64 < tile_n) {
         const uint32_t d = (key[i] >> shift) & mask;
-        const uint32_t p = S.tile_start[d] + S.whist[wave][d] + lpos[i];
+        const uint32_t p = S.whist[wave][d] + lpos[i];
         lpos[i] = (uint16_t)p;
         skeys[p] = key[i];
         if (kHasVec) svec[p] = vec[i];
@@ -350,7 +378,7 @@ __global__ __launch_bounds__(kBlock, 4) void downsweep_rec_kernel(const uint32_t
       if (p < tile_n) {
         const uint32_t k = skeys[p];
         const uint32_t d = (k >> shift) & mask;
-        const uint32_t g = S.digit_base[d] + (p - S.tile_start[d]);
+        const uint32_t g = S.delta[d] + p;
         gidx[j] = g;
         keys_out[g] = k;
         if (kHasVec) rp.vec_out[g] = svec[p];
@@ -372,10 +400,8 @@ __global__ __launch_bounds__(kBlock, 4) void downsweep_rec_kernel(const uint32_t
         if (p < tile_n) dst[gidx[j]] = skeys[p];
       }
     }
-    __syncthreads();
-    S.digit_base[t] += S.tile_count[t];
 #pragma unroll
-    for (int w = 0; w < kWaves; ++w) S.whist[w][t] = 0;
+    for (int w = 0; w < kWaves; ++w) S.whist[w][t] = 0;  // last read before the barrier after the LDS scatter
     __syncthreads();
   }
 }

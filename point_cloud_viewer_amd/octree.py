@@ -284,6 +284,12 @@ class Context:
                                              L.MEM_DEVICE if b.device else L.MEM_HOST))
         return b.keep
 
+    def sort_keys32(self, keys, begin_bit=0, end_bit=32):
+        b = _Buf(keys, np.uint32, "keys")
+        self._check(self.lib.pcv_sort_keys32(self.handle, b.ptr, b.size, begin_bit, end_bit,
+                                             L.MEM_DEVICE if b.device else L.MEM_HOST))
+        return b.keep
+
     def sort_pairs32(self, keys, values, begin_bit=0, end_bit=32):
         k, v = _Buf(keys, np.uint32, "keys"), _Buf(values, np.uint32, "values")
         if k.size != v.size:
