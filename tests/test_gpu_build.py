@@ -97,6 +97,29 @@ def test_degenerate_inputs(ctx):
             assert_same(got, want)
 
 
+def test_special_coordinates_take_the_guarded_chain(ctx):
+    """Signed zeros, denormals, huge values, NaN and infinities mixed into an ordinary cloud: the kernels route such
+    points through the guarded division variant; the bytes must not change."""
+    n = 60_000
+    x, y, z, rgb, bmin, bmax = synthetic.gaussian_clusters(n, seed=41, num_clusters=4, extent=16.0, sigma_range=(0.01, 1.5))
+    special = np.array([-0.0, 0.0, 5e-324, 1e-310, 2.0 ** -701, 2.0 ** -699, 1e-300, 1e200, -1e200, 2.0 ** 501,
+                        float("nan"), float("inf"), -float("inf"), 8.0, -8.0, 2.0 ** -30, -(2.0 ** -30)])
+    rng = np.random.default_rng(7)
+    for coords in (x, y, z):
+        idx = rng.choice(n, 3000, replace=False)
+        coords[idx] = rng.choice(special, idx.size)
+    # the second box cuts the cloud in half: the outside points collapse onto its faces (clamped codes) and the tree gets
+    # deep — at 1e-7 m deeper than the 21 key levels, which test_depth_overflow_is_reported covers
+    for lo, hi, resolutions in ((bmin, bmax, (0.001, 1e-7)),
+                                (np.array([-8.0, -8.0, -8.0]), np.array([8.0, 8.0, 8.0]), (0.001,)),
+                                (np.array([0.0, -0.0, -8.0]), np.array([8.0, 8.0, 8.0]), (0.001, 1e-7))):
+        for res in resolutions:
+            with O.max_points_per_node(900):
+                want = O.build_closed(res, lo, hi, x, y, z, rgb, threads=4)
+            got = ctx.build(res, pcv.Aabb(lo, hi), x, y, z, rgb, max_points_per_node=900).to_dict()
+            assert_same(got, want)
+
+
 def test_device_resident_inputs_and_computed_bbox(ctx):
     import torch
     x, y, z, rgb, bmin, bmax = synthetic.gaussian_clusters(300_000, seed=21, num_clusters=4, extent=500.0,
