@@ -1,0 +1,13 @@
+#!/bin/bash
+# rocprofv3 passes over bench.py on the GPU box (run through gpurun): per-kernel durations (--kernel-trace --stats) and,
+# in separate passes as MI355X_MICROARCH.md prescribes, the HBM counters FETCH_SIZE and WRITE_SIZE.
+# usage: gpurun -- 'bash tools/profile_bench.sh TAG [extra bench.py flags]'   -> gpurun_out/TAG_{stats,fetch,write}/
+TAG=${1:-prof}; shift
+OUT=$GRAFT_REPO_ROOT/gpurun_out
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_stats -o r -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-e2e --no-kernel-events "$@" > $OUT/${TAG}_stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/${TAG}_fetch -o r -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-e2e --no-kernel-events "$@" > $OUT/${TAG}_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/${TAG}_write -o r -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-e2e --no-kernel-events "$@" > $OUT/${TAG}_write.log 2>&1
+tail -1 $OUT/${TAG}_stats.log
+ls $OUT/${TAG}_stats $OUT/${TAG}_fetch $OUT/${TAG}_write

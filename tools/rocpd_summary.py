@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--fetch")
     ap.add_argument("--write")
     ap.add_argument("--keep", default="kernel", help="substring a kernel name must contain to be listed")
+    ap.add_argument("--command", default="python bench.py (defaults: BASELINE config 2, 100 M points, 1 GPU)")
     ap.add_argument("-o", required=True)
     a = ap.parse_args()
     stats = [r for r in kernel_stats(a.stats) if a.keep in r[0] and not r[0].startswith("at::")]
@@ -55,6 +56,17 @@ def main():
                     f"{'' if fk is None else f'{fk * 2 * 1024 / 1e6:.1f}'},{'' if wk is None else f'{wk:.0f}'},"
                     f"{'' if wk is None else f'{wk * 1024 / 1e6:.1f}'}\n")
     print(open(a.o + ".csv").read())
+    # machine-readable HBM traffic per launch (bytes; FETCH_SIZE already doubled per the gfx950 correction) for bench.py
+    import json
+    traffic = {}
+    for n, c, t, av, p in stats:
+        fk, wk = fetch.get(n), write.get(n)
+        if fk is not None and wk is not None:
+            traffic[n.split("<")[0]] = max(traffic.get(n.split("<")[0], 0), round(fk * 2 * 1024 + wk * 1024))
+    with open(a.o + "_traffic.json", "w") as f:
+        json.dump({"note": "HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB counters, separate rocprofv3 --pmc passes); "
+                           "for kernels launched with several key widths the larger launch is listed",
+                   "command": a.command, "bytes_per_launch": traffic}, f, indent=1)
 
 
 if __name__ == "__main__":
