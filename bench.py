@@ -33,7 +33,8 @@ ALGO_BYTES = {
     "downsweep_kernel<u32>": 8.0,   # keys only: read 4 B + write 4 B
     "downsweep_rec_kernel": 2 * 4.0 + 2 * 16.0,  # rank r/w + 16-byte payload r/w
     "upsweep_kernel<u32>": 4.0,
-    "promote_encode_kernel": 20.0 + 9.0,  # read record, write ~6 B xyz + 3 B rgb
+    "promote_settle_kernel": 20.0 + 7.0 / 8.0 * 9.0,  # read record; 7 of 8 points write ~6 B xyz + 3 B rgb
+    "promote_climb_kernel": 4.0 + (16.0 + 9.0) / 8.0,  # read ranks; every 8th point: payload in, xyz + rgb out
 }
 
 

@@ -123,9 +123,10 @@ void pcv_ctx::prof_resolve() {
 static const char* kKernelNames[PCV_K_COUNT] = {
     "aabb_partial_kernel", "chain_keys_kernel",  "upsweep_kernel<u64>",   "scan_kernel",
     "downsweep_kernel<u64>", "split_search_kernel", "split_assign_kernel", "leaf_encode_kernel",
-    "upsweep_kernel<u32>", "downsweep_kernel<u32>", "promote_encode_kernel", "downsweep_rec_kernel", "cull_nodes_kernel",
+    "upsweep_kernel<u32>", "downsweep_kernel<u32>", "promote_settle_kernel", "downsweep_rec_kernel", "cull_nodes_kernel",
     "visible_nodes_kernel", "nodes_in_location_kernel", "cull_points_kernel", "transform_points_kernel",
-    "query_compact_kernel", "route_bucket_kernel", "partition_count_kernel", "partition_scatter_kernel"};
+    "query_compact_kernel", "route_bucket_kernel", "partition_count_kernel", "partition_scatter_kernel",
+    "promote_climb_kernel"};
 static_assert(sizeof(kKernelNames) / sizeof(kKernelNames[0]) == PCV_K_COUNT, "kernel name table out of sync");
 
 extern "C" int pcv_ctx_set_profiling(pcv_ctx* ctx, int enabled) {

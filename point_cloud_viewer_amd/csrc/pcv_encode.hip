@@ -64,13 +64,14 @@ struct PromoteOut {
   uint8_t* inten_blob;
 };
 
-// One sorted slot: climb, final encode, store.
+// One sorted slot: climb, final encode, store. CLIMB = false: the caller knows the point stays in its leaf.
+template <bool CLIMB>
 __device__ __forceinline__ void promote_one(const PcvPromoteTables& pt, uint64_t s, PcvNodeRec cur, uint4 pay,
                                             uint32_t hx, uint32_t hy, uint32_t hz, uint32_t inten, const PromoteOut& o) {
   uint32_t j = (uint32_t)s - cur.lo;
   uint64_t code[3] = {pay.x | ((uint64_t)hx << 32), pay.y | ((uint64_t)hy << 32), pay.z | ((uint64_t)hz << 32)};
   // climb while this point is an every-8th element of its node's stream
-  while (cur.parent != 0xffffffffu && (j & 7u) == 0) {
+  while (CLIMB && cur.parent != 0xffffffffu && (j & 7u) == 0) {
     const PcvNodeRec par = pt.node_rec[cur.parent];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -128,9 +129,11 @@ __device__ __forceinline__ void promote_one(const PcvPromoteTables& pt, uint64_t
   if (o.inten_blob) reinterpret_cast<uint32_t*>(o.inten_blob)[pidx] = inten;
 }
 
-// Two slots per lane (s and s + 256): the kernel is bound by the dependent loads rank -> record, so both chains
-// are started before either is consumed.
-__global__ __launch_bounds__(256) void promote_encode_kernel(
+// K6 runs as two kernels over the sorted records. Seven of eight points stay in their leaf: `settle` streams over all
+// slots (two per lane, both record chains started before either is consumed) and finishes those with straight-line
+// code. The every-8th points climb a data-dependent number of levels (decode + encode per level): `climb` visits one
+// octet of slots per lane, so its waves are full of climbers instead of carrying seven idle lanes through the loop.
+__global__ __launch_bounds__(256) void promote_settle_kernel(
     PcvPromoteTables pt, uint64_t n, const uint32_t* __restrict__ rank, const uint4* __restrict__ payload,
     const uint32_t* __restrict__ cx_hi, const uint32_t* __restrict__ cy_hi, const uint32_t* __restrict__ cz_hi,
     const uint32_t* __restrict__ inten_bits, PromoteOut o) {
@@ -159,8 +162,57 @@ __global__ __launch_bounds__(256) void promote_encode_kernel(
   }
   const PcvNodeRec c0 = pt.leaf_rec[r0];
   const PcvNodeRec c1 = pt.leaf_rec[r1];
-  promote_one(pt, s0, c0, p0, h0[0], h0[1], h0[2], i0, o);
-  if (two) promote_one(pt, s1, c1, p1, h1[0], h1[1], h1[2], i1, o);
+  const bool stay0 = c0.parent == 0xffffffffu || (((uint32_t)s0 - c0.lo) & 7u) != 0;
+  const bool stay1 = two && (c1.parent == 0xffffffffu || (((uint32_t)s1 - c1.lo) & 7u) != 0);
+  if (stay0) promote_one<false>(pt, s0, c0, p0, h0[0], h0[1], h0[2], i0, o);
+  if (stay1) promote_one<false>(pt, s1, c1, p1, h1[0], h1[1], h1[2], i1, o);
+}
+
+__device__ __forceinline__ void climb_slot(const PcvPromoteTables& pt, uint64_t s, const PcvNodeRec& rec,
+                                           const uint4* __restrict__ payload, const uint32_t* __restrict__ cx_hi,
+                                           const uint32_t* __restrict__ cy_hi, const uint32_t* __restrict__ cz_hi,
+                                           const uint32_t* __restrict__ inten_bits, const PromoteOut& o) {
+  const uint4 p = payload[s];
+  uint32_t h[3] = {0, 0, 0}, in = 0;
+  if (cx_hi) {
+    h[0] = cx_hi[s];
+    h[1] = cy_hi[s];
+    h[2] = cz_hi[s];
+  }
+  if (inten_bits) in = inten_bits[s];
+  promote_one<true>(pt, s, rec, p, h[0], h[1], h[2], in, o);
+}
+
+__global__ __launch_bounds__(256) void promote_climb_kernel(
+    PcvPromoteTables pt, uint64_t n, const uint32_t* __restrict__ rank, const uint4* __restrict__ payload,
+    const uint32_t* __restrict__ cx_hi, const uint32_t* __restrict__ cy_hi, const uint32_t* __restrict__ cz_hi,
+    const uint32_t* __restrict__ inten_bits, PromoteOut o) {
+  const uint64_t s0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 8;  // this lane's octet of sorted slots
+  if (s0 >= n) return;
+  uint32_t r[8];
+  if (s0 + 8 <= n) {  // rank comes from the pool (256-byte aligned) and s0 is a multiple of 8: two 16-byte loads
+    const uint4 a = *reinterpret_cast<const uint4*>(rank + s0);
+    const uint4 b = *reinterpret_cast<const uint4*>(rank + s0 + 4);
+    r[0] = a.x, r[1] = a.y, r[2] = a.z, r[3] = a.w, r[4] = b.x, r[5] = b.y, r[6] = b.z, r[7] = b.w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r[k] = s0 + k < n ? rank[s0 + k] : 0xffffffffu;
+  }
+  const PcvNodeRec first = pt.leaf_rec[r[0]];
+  if (r[7] == r[0]) {  // ranks are sorted: the whole octet lies in one leaf, which holds exactly one climber of it
+    if (first.parent != 0xffffffffu)
+      climb_slot(pt, s0 + ((first.lo - (uint32_t)s0) & 7u), first, payload, cx_hi, cy_hi, cz_hi, inten_bits, o);
+    return;
+  }
+  // a leaf ends inside the octet (or the input ends): look at every slot
+#pragma unroll 1
+  for (int k = 0; k < 8; ++k) {
+    if (r[k] == 0xffffffffu) break;
+    const PcvNodeRec rec = r[k] == r[0] ? first : pt.leaf_rec[r[k]];
+    const uint64_t s = s0 + k;
+    if (rec.parent != 0xffffffffu && (((uint32_t)s - rec.lo) & 7u) == 0)
+      climb_slot(pt, s, rec, payload, cx_hi, cy_hi, cz_hi, inten_bits, o);
+  }
 }
 
 }  // namespace
@@ -180,8 +232,15 @@ void pcv_launch_promote_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvPromo
                                const uint32_t* cz_hi, const uint32_t* inten_bits, uint8_t* xyz_blob, uint8_t* rgb_blob,
                                uint8_t* inten_blob) {
   if (n == 0) return;
-  PcvProf prof(ctx, PCV_K_PROMOTE_ENCODE);
   PromoteOut o{xyz_blob, rgb_blob, inten_blob};
-  hipLaunchKernelGGL(promote_encode_kernel, dim3((unsigned)((n + 511) / 512)), dim3(256), 0, ctx->stream, pt, n, rank,
-                     (const uint4*)payload, cx_hi, cy_hi, cz_hi, inten_bits, o);
+  {
+    PcvProf prof(ctx, PCV_K_PROMOTE_ENCODE);
+    hipLaunchKernelGGL(promote_settle_kernel, dim3((unsigned)((n + 511) / 512)), dim3(256), 0, ctx->stream, pt, n, rank,
+                       (const uint4*)payload, cx_hi, cy_hi, cz_hi, inten_bits, o);
+  }
+  {
+    PcvProf prof(ctx, PCV_K_PROMOTE_CLIMB);
+    hipLaunchKernelGGL(promote_climb_kernel, dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, ctx->stream, pt, n, rank,
+                       (const uint4*)payload, cx_hi, cy_hi, cz_hi, inten_bits, o);
+  }
 }

@@ -58,6 +58,7 @@ enum PcvKernelId {
   PCV_K_ROUTE_BUCKET,
   PCV_K_PARTITION_COUNT,
   PCV_K_PARTITION_SCATTER,
+  PCV_K_PROMOTE_CLIMB,
   PCV_K_COUNT
 };
 
