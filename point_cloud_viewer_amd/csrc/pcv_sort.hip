@@ -52,6 +52,24 @@ SortGeom make_geom(uint64_t n) {
   return g;
 }
 
+// One histogram update per group of lanes holding the same digit: the lanes are matched with ballots (as in the
+// downsweep ranking) and only the first of each group issues the LDS add, with the group size. Plain per-lane LDS
+// atomics serialise on equal addresses, and the digits of path keys / leaf ranks are heavily skewed (the upper
+// digits take a few dozen values), which cost up to 60 % over uniform keys.
+__device__ __forceinline__ void count_digit(uint32_t* __restrict__ wh, uint32_t d, uint64_t valid_mask, bool valid) {
+  uint32_t plo = (uint32_t)valid_mask, phi = (uint32_t)(valid_mask >> 32);
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    int m;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(d), "n"(b));
+    const uint64_t bal = __builtin_amdgcn_ballot_w64(m != 0);
+    plo = __builtin_amdgcn_bitop3_b32(plo, (uint32_t)bal, (uint32_t)m, 0x90);  // p & ~(ballot ^ m)
+    phi = __builtin_amdgcn_bitop3_b32(phi, (uint32_t)(bal >> 32), (uint32_t)m, 0x90);
+  }
+  const uint32_t below = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+  if (valid && below == 0) atomicAdd(&wh[d], (uint32_t)(__popc(plo) + __popc(phi)));
+}
+
 template <typename KeyT>
 __global__ __launch_bounds__(kBlock) void upsweep_kernel(const KeyT* __restrict__ keys, uint64_t n, uint64_t chunk,
                                                           int groups, int shift, uint32_t mask,
@@ -73,15 +91,18 @@ __global__ __launch_bounds__(kBlock) void upsweep_kernel(const KeyT* __restrict_
     VecT v[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const VecT*>(keys + i + u * kStep);
+    // the loop condition is not wave-uniform in the last iterations of a chunk: match only the lanes that are here
+    const uint64_t here = __builtin_amdgcn_ballot_w64(true);
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
-      for (int k = 0; k < kVec; ++k) atomicAdd(&wh[wave][(uint32_t)(v[u][k] >> shift) & mask], 1u);
+      for (int k = 0; k < kVec; ++k) count_digit(wh[wave], (uint32_t)(v[u][k] >> shift) & mask, here, true);
   }
   for (; i + kVec <= end; i += kStep) {
     VecT v = *reinterpret_cast<const VecT*>(keys + i);
+    const uint64_t here = __builtin_amdgcn_ballot_w64(true);
 #pragma unroll
-    for (int k = 0; k < kVec; ++k) atomicAdd(&wh[wave][(uint32_t)(v[k] >> shift) & mask], 1u);
+    for (int k = 0; k < kVec; ++k) count_digit(wh[wave], (uint32_t)(v[k] >> shift) & mask, here, true);
   }
   for (; i < end; ++i) atomicAdd(&wh[wave][(uint32_t)(keys[i] >> shift) & mask], 1u);  // ragged tail (< kVec keys)
   __syncthreads();
