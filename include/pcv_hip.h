@@ -159,6 +159,12 @@ int pcv_octree_copy_node(const pcv_octree* tree, uint64_t i, int which, void* ds
 /* Write `<NodeId>.xyz/.rgb/.intensity` + meta.pb (version 13) exactly as the reference lays them out
  * (src/read_write/raw.rs:374-449, node_writer.rs:78-89, generation.rs:390-402). */
 int pcv_octree_write_dir(pcv_octree* t, const char* directory);
+/* Multi-GPU output: every rank writes the node files of its own subtrees (level >= min_level, no meta.pb) ... */
+int pcv_octree_write_nodes(pcv_octree* t, const char* directory, uint32_t min_level);
+/* ... and one rank writes meta.pb for the gathered node table (id_high, id_low, num_points, encoding are used).
+ * Host only; returns PCV_E_IO when the file cannot be written. Layout: proto.proto:58-149, octree/mod.rs:87-99. */
+int pcv_write_meta(const char* directory, double resolution, const double bbox_min[3], const double bbox_max[3],
+                   const pcv_node_info* nodes, uint64_t count);
 void pcv_octree_free(pcv_octree* t);
 
 /* Milliseconds spent per stage of the last pcv_build_octree on this tree (HIP events on the ctx

@@ -97,6 +97,9 @@ _SIGNATURES = {
     "pcv_chain_keys": (C.c_int, [_vp, C.POINTER(BuildParams), C.POINTER(Points), C.c_int, _vp]),
     "pcv_route_buckets": (C.c_int, [_vp, C.POINTER(BuildParams), C.POINTER(Points), _vp, C.POINTER(C.c_uint64)]),
     "pcv_partition_by_owner": (C.c_int, [_vp, C.POINTER(Points), _vp, C.c_uint32, C.POINTER(RouteDst), _vp]),
+    "pcv_octree_write_nodes": (C.c_int, [_vp, C.c_char_p, C.c_uint32]),
+    "pcv_write_meta": (C.c_int, [C.c_char_p, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(NodeInfo),
+                                 C.c_uint64]),
     "pcv_octree_copy_node": (C.c_int, [_vp, C.c_uint64, C.c_int, _vp, C.c_uint64, C.c_int]),
     "pcv_build_begin": (C.c_int, [_vp, C.POINTER(BuildParams), C.POINTER(Points), C.POINTER(_vp)]),
     "pcv_build_top_streams": (C.c_int, [_vp, C.POINTER(TopStreams)]),

@@ -67,10 +67,12 @@ bool write_file(const std::string& path, const uint8_t* data, uint64_t len) {
 }  // namespace
 
 // octree/mod.rs:87-99 to_meta_proto + node.rs:260-270 to_node_proto + node.rs:101-106 NodeId::to_proto
-std::vector<uint8_t> pcv_encode_meta(const pcv_octree* t) {
+static std::vector<uint8_t> encode_meta(double resolution, const double bbox_min[3], const double bbox_max[3],
+                                        const pcv_node_info* nodes, size_t count) {
   std::vector<uint8_t> octree;
-  f64_field(octree, 2, t->resolution);
-  for (const pcv_node_info& n : t->nodes) {
+  f64_field(octree, 2, resolution);
+  for (size_t k = 0; k < count; ++k) {
+    const pcv_node_info& n = nodes[k];
     std::vector<uint8_t> node, id;
     tag(node, 2, 0);
     varint(node, n.encoding);
@@ -90,8 +92,8 @@ std::vector<uint8_t> pcv_encode_meta(const pcv_octree* t) {
     bytes_field(octree, 3, node);
   }
   std::vector<uint8_t> cuboid;
-  bytes_field(cuboid, 3, vec3d(t->bbox_min));
-  bytes_field(cuboid, 4, vec3d(t->bbox_max));
+  bytes_field(cuboid, 3, vec3d(bbox_min));
+  bytes_field(cuboid, 4, vec3d(bbox_max));
   std::vector<uint8_t> meta;
   tag(meta, 1, 0);
   varint(meta, 13);  // CURRENT_VERSION src/lib.rs:48
@@ -99,8 +101,25 @@ std::vector<uint8_t> pcv_encode_meta(const pcv_octree* t) {
   bytes_field(meta, 6, octree);
   return meta;
 }
+std::vector<uint8_t> pcv_encode_meta(const pcv_octree* t) {
+  return encode_meta(t->resolution, t->bbox_min, t->bbox_max, t->nodes.data(), t->nodes.size());
+}
 
-extern "C" int pcv_octree_write_dir(pcv_octree* t, const char* directory) {
+extern "C" int pcv_write_meta(const char* directory, double resolution, const double bbox_min[3], const double bbox_max[3],
+                              const pcv_node_info* nodes, uint64_t count) {
+  if (!directory || !bbox_min || !bbox_max || (count && !nodes)) return PCV_E_INVALID;
+  std::string dir(directory);
+  ::mkdir(dir.c_str(), 0777);
+  std::vector<uint8_t> meta = encode_meta(resolution, bbox_min, bbox_max, nodes, (size_t)count);
+  return write_file(dir + "/meta.pb", meta.data(), meta.size()) ? PCV_OK : PCV_E_IO;
+}
+
+static int write_nodes(pcv_octree* t, const char* directory, uint32_t min_level, bool with_meta);
+extern "C" int pcv_octree_write_dir(pcv_octree* t, const char* directory) { return write_nodes(t, directory, 0, true); }
+extern "C" int pcv_octree_write_nodes(pcv_octree* t, const char* directory, uint32_t min_level) {
+  return write_nodes(t, directory, min_level, false);
+}
+static int write_nodes(pcv_octree* t, const char* directory, uint32_t min_level, bool with_meta) {
   if (!t || !directory) return PCV_E_INVALID;
   pcv_ctx* ctx = t->ctx;
   int rc = pcv_octree_fetch_host(t);
@@ -125,7 +144,7 @@ extern "C" int pcv_octree_write_dir(pcv_octree* t, const char* directory) {
       const size_t i = next.fetch_add(1);
       if (i >= count || failed.load()) return;
       const pcv_node_info& n = t->nodes[i];
-      if (n.num_points == 0) continue;  // node_writer.rs:78-89: empty nodes have no files
+      if (n.num_points == 0 || n.level < min_level) continue;  // node_writer.rs:78-89: empty nodes have no files
       const std::string stem = dir + "/" + node_name(n);
       const uint64_t np = (uint64_t)n.num_points;
       const char* bad = nullptr;
@@ -146,6 +165,7 @@ extern "C" int pcv_octree_write_dir(pcv_octree* t, const char* directory) {
   worker();
   for (auto& th : pool) th.join();
   if (failed.load()) return ctx->fail(PCV_E_IO, first_error);
+  if (!with_meta) return PCV_OK;
   std::vector<uint8_t> meta = pcv_encode_meta(t);
   if (!write_file(dir + "/meta.pb", meta.data(), meta.size())) return ctx->fail(PCV_E_IO, "cannot write meta.pb");
   return PCV_OK;

@@ -132,8 +132,9 @@ class ShardedOctree:
     """Result of a sharded build: this rank's subtrees (level >= 2) plus the finished root and level-1 nodes, which
     every rank holds after the top all-reduce."""
 
-    def __init__(self, builder, local_tree, top, top_bytes, stage_ms, counts, plan):
+    def __init__(self, builder, local_tree, top, top_bytes, stage_ms, counts, plan, resolution, bbox):
         self.builder = builder
+        self.resolution, self.bbox = resolution, bbox
         self.local = local_tree
         self.top = top              # list of node dicts (top_nodes)
         self.top_bytes = top_bytes  # uint8 tensor: xyz | rgb | intensity of the top nodes
@@ -165,6 +166,35 @@ class ShardedOctree:
                                    encoding=nd["encoding"], level=nd["level"], xyz=cut("xyz"), rgb=cut("rgb"),
                                    intensity=cut("intensity"))
         return out
+
+    def write_dir(self, directory, dst=0):
+        """The reference's output directory from all ranks (shared file system): every rank writes the node files of
+        its own subtrees, `dst` adds the finished root / level-1 nodes and meta.pb for the gathered node table."""
+        import os
+        dist = self.builder.dist
+        os.makedirs(directory, exist_ok=True)
+        self.local.write_nodes(directory, 2)
+        mine = []
+        for i in range(self.local.num_nodes):
+            nd = self.local.node(i)
+            if nd.level >= 2:
+                mine.append((nd.id_high, nd.id_low, nd.num_points, nd.encoding))
+        gathered = [None] * dist.get_world_size() if dist.get_rank() == dst else None
+        dist.gather_object(mine, gathered, dst=dst)
+        if dist.get_rank() == dst:
+            nodes = []
+            for name, nd in self.top_dict().items():
+                nodes.append((nd["id"][0], nd["id"][1], nd["num_points"], nd["encoding"]))
+                if nd["num_points"]:  # node_writer.rs:78-89: empty nodes have no files
+                    for ext in ("xyz", "rgb", "intensity"):
+                        if nd[ext]:
+                            with open(os.path.join(directory, f"{name}.{ext}"), "wb") as f:
+                                f.write(nd[ext])
+            for part in gathered:
+                nodes += part
+            nodes.sort(key=lambda t: (t[0], t[1]))  # (level, index): the reference's order is nondeterministic
+            _oct.write_meta(directory, self.resolution, self.bbox.min, self.bbox.max, nodes)
+        dist.barrier()
 
     def gather(self, dst=0):
         """Merge all ranks' node dictionaries on `dst` (tests, directory writing): the top nodes come from the
@@ -319,4 +349,4 @@ class ShardedOctreeBuilder:
             marks[-1].synchronize()
             ms = {"exchange": marks[0].elapsed_time(marks[1]), "local_build": marks[1].elapsed_time(marks[2]),
                   "top_merge": marks[2].elapsed_time(marks[3])}
-        return ShardedOctree(self, tree, specs, top, ms, matrix, (rank_of_bucket, split_mask))
+        return ShardedOctree(self, tree, specs, top, ms, matrix, (rank_of_bucket, split_mask), resolution, bbox)

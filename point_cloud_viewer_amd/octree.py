@@ -505,6 +505,10 @@ class OctreeResult:
         self.ctx._check(self.lib.pcv_octree_nodes_blob(self.handle, ip, idx.size, buf.ctypes.data, buf.size, C.byref(need)))
         return buf.tobytes()
 
+    def write_nodes(self, directory, min_level=0):
+        """Node files of the nodes at level >= min_level, without meta.pb (multi-GPU output)."""
+        self.ctx._check(self.lib.pcv_octree_write_nodes(self.handle, str(directory).encode(), int(min_level)))
+
     def copy_node_into(self, i, which, dst):
         """Copy node i's bytes (0 xyz, 1 rgb, 2 intensity) from the device blob into a uint8 tensor/array view."""
         if hasattr(dst, "data_ptr"):
@@ -526,6 +530,19 @@ class OctreeResult:
                              intensity=self.node_data(i, 2) if has_int else b"",
                              cube_min=tuple(nd.cube_min), cube_edge=nd.cube_edge)
         return out
+
+
+def write_meta(directory, resolution, bbox_min, bbox_max, nodes):
+    """meta.pb (version 13) for a list of (id_high, id_low, num_points, encoding) tuples."""
+    lib = L.load_library()
+    arr = (L.NodeInfo * max(1, len(nodes)))()
+    for k, (hi, lo, npts, enc) in enumerate(nodes):
+        arr[k].id_high, arr[k].id_low, arr[k].num_points, arr[k].encoding = int(hi), int(lo), int(npts), int(enc)
+    bmin = (C.c_double * 3)(*[float(v) for v in bbox_min])
+    bmax = (C.c_double * 3)(*[float(v) for v in bbox_max])
+    rc = lib.pcv_write_meta(str(directory).encode(), float(resolution), bmin, bmax, arr, len(nodes))
+    if rc != L.PCV_OK:
+        raise L.PcvError(rc, f"cannot write meta.pb in {directory}")
 
 
 def read_ply(path):

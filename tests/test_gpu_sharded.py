@@ -77,7 +77,7 @@ def test_route_buckets_and_partition_kernels():
 
 
 @pytest.mark.parametrize("world,cap,with_intensity", [(2, 0, False), (4, 20_000, True), (8, 3_000, False)])
-def test_virtual_ranks_on_one_gpu(world, cap, with_intensity):
+def test_virtual_ranks_on_one_gpu(world, cap, with_intensity, tmp_path):
     """The real ShardedOctreeBuilder + HipBackend, N virtual ranks as threads on one GPU (tests/thread_dist.py)."""
     import torch
     from thread_dist import run_ranks
@@ -104,6 +104,8 @@ def test_virtual_ranks_on_one_gpu(world, cap, with_intensity):
         assert np.array_equal(bbox.min, bmin) and np.array_equal(bbox.max, bmax)
         res = b.build(0.001, bbox, tx, ty, tz, trgb, tint, max_points_per_node=cap)
         merged = res.gather(0)
+        if world == 4:  # the reference's directory, written by all ranks together
+            res.write_dir(str(tmp_path / "sharded"))
         return merged, res.plan
 
     out = run_ranks(world, rank_main)
@@ -116,3 +118,8 @@ def test_virtual_ranks_on_one_gpu(world, cap, with_intensity):
             assert merged[name][f] == nd[f], (name, f)
     if cap:
         assert split_mask != 0 and len(set(rank_of.tolist())) == world
+    if world == 4:
+        with O.max_points_per_node(cap):
+            O.build_literal_dir(tmp_path / "oracle", 0.001, bmin, bmax, x, y, z, rgb, inten, threads=4)
+        diffs = O.compare_octrees(O.load_dir(tmp_path / "sharded"), O.load_dir(tmp_path / "oracle"))
+        assert not diffs, diffs[:10]
