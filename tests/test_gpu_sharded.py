@@ -123,3 +123,32 @@ def test_virtual_ranks_on_one_gpu(world, cap, with_intensity, tmp_path):
             O.build_literal_dir(tmp_path / "oracle", 0.001, bmin, bmax, x, y, z, rgb, inten, threads=4)
         diffs = O.compare_octrees(O.load_dir(tmp_path / "sharded"), O.load_dir(tmp_path / "oracle"))
         assert not diffs, diffs[:10]
+
+
+@pytest.mark.parametrize("world,n", [(8, 3000), (3, 50_000), (5, 1)])
+def test_virtual_ranks_small_clouds_and_idle_ranks(world, n):
+    """Fewer work units than ranks (level-1 nodes stay leaves, some ranks receive nothing), odd world sizes, one point."""
+    import torch
+    from thread_dist import run_ranks
+    x, y, z, rgb, bmin, bmax = synthetic.gaussian_clusters(n, seed=37, num_clusters=3, extent=40.0, sigma_range=(0.5, 3.0))
+    if n == 1:
+        bmin, bmax = np.array([x[0] - 1.0, y[0] - 1.0, z[0] - 1.0]), np.array([x[0] + 1.0, y[0] + 1.0, z[0] + 1.0])
+    if n == 3000:  # a loose box: every point lies in the upper-x half of the root cube -> at most 4 of 8 octants in use
+        bmin = bmin - np.array([3.0 * (bmax[0] - bmin[0]), 0.0, 0.0])
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def rank_main(rank, dist):
+        torch.cuda.set_device(0)
+        ctx = pcv.Context(0, stream=stream)
+        sl = slice(rank * n // world, (rank + 1) * n // world)
+        tx, ty, tz = (torch.from_numpy(np.ascontiguousarray(a[sl])).cuda() for a in (x, y, z))
+        trgb = torch.from_numpy(np.ascontiguousarray(rgb[sl])).cuda()
+        b = pdist.ShardedOctreeBuilder(ctx, dist, dev)
+        res = b.build(0.001, pcv.Aabb(bmin, bmax), tx, ty, tz, trgb)
+        return res.gather(0), res.num_nodes_local
+
+    out = run_ranks(world, rank_main)
+    _same(out[0][0], O.build_closed(0.001, bmin, bmax, x, y, z, rgb))
+    if n == 3000:
+        assert sum(1 for _, nodes in out if nodes == 0) >= 1  # at least one rank had nothing to build

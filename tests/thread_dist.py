@@ -15,7 +15,7 @@ class ThreadWorld:
         self.barrier = threading.Barrier(world)
         self.slots = [None] * world
         self.mail = {}
-        self.lock = threading.Lock()
+        self.lock = threading.Condition()
 
     def dist(self, rank):
         return ThreadDist(self, rank)
@@ -72,17 +72,20 @@ class ThreadDist:
         return SimpleNamespace(op=op, tensor=tensor, peer=peer)
 
     def batch_isend_irecv(self, ops):
-        for o in ops:
-            if o.op == "isend":
-                with self.w.lock:
+        """Point-to-point like the real thing: only the ranks named in the ops take part (no world-wide rendezvous)."""
+        with self.w.lock:
+            for o in ops:
+                if o.op == "isend":
                     self.w.mail.setdefault((self.rank, o.peer), []).append(o.tensor.clone())
-        self.w.barrier.wait()
+            self.w.lock.notify_all()
         for o in ops:
             if o.op == "irecv":
                 with self.w.lock:
+                    ok = self.w.lock.wait_for(lambda: self.w.mail.get((o.peer, self.rank)), timeout=120)
+                    if not ok:
+                        raise TimeoutError(f"rank {self.rank}: no message from rank {o.peer}")
                     msg = self.w.mail[(o.peer, self.rank)].pop(0)
                 o.tensor.copy_(msg)
-        self.w.barrier.wait()
         return [_Done() for _ in ops]
 
     def gather_object(self, obj, out, dst=0):
