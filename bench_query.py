@@ -99,10 +99,20 @@ def main():
     ctx.reset_kernel_stats()
     r = tree.query_points(big, 0, capacity=1)
     st = ctx.kernel_stats()
-    tested = None
-    print(json.dumps({"part": "query_points_big_aabb", "kept_points": r["count"],
-                      "cull_kernel_ms": round(st["cull_points_kernel"][1], 3),
-                      "compact_kernel_ms": round(st["query_compact_kernel"][1], 3)}))
+    bpc = {1: 1, 2: 2, 3: 4, 4: 8}
+    visited = tree.nodes_in_location(big)[0]
+    tested = sum(tree.node(int(i)).num_points for i in visited)
+    enc_bytes = sum(tree.node(int(i)).num_points * 3 * bpc[tree.node(int(i)).encoding] for i in visited)
+    cull_ms = st["cull_points_kernel"][1]
+    # K8 roofline: HBM stream of the encoded node bytes (+ 1 flag byte per point written)
+    gbs = (enc_bytes + tested) / (cull_ms * 1e-3) / 1e9
+    print(json.dumps({"part": "query_points_big_aabb", "nodes_visited": int(len(visited)), "points_tested": int(tested),
+                      "kept_points": r["count"], "cull_kernel_ms": round(cull_ms, 3),
+                      "compact_kernel_ms": round(st["query_compact_kernel"][1], 3),
+                      "roofline": {"bound": "hbm", "kernel": "cull_points_kernel", "achieved": round(gbs, 1), "peak": 8000.0,
+                                   "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
+                                   "algorithmic_bytes_per_launch": int(enc_bytes + tested),
+                                   "points_per_s": round(tested / (cull_ms * 1e-3), 1)}}))
 
     # CPU restatement (1 thread) on a bounded sample
     cubes = np.array([[*tree.node(i).cube_min, tree.node(i).cube_edge] for i in range(M)])

@@ -816,12 +816,24 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
         if ((h_mask[i] >> dg) & 1) u_child_off[c2++] = top->l2_offset[c * 8 + dg];
     }
   }
-  // leaves in key order == order of their sorted ranges
+  // leaves in key order == order of their sorted ranges: depth-first, children in digit order (no sort needed)
   std::vector<uint32_t> leaves;
   leaves.reserve(M);
-  for (uint32_t i = 0; i < M; ++i)
-    if (!h_open[i]) leaves.push_back(i);
-  std::sort(leaves.begin(), leaves.end(), [&](uint32_t a, uint32_t b) { return h_lo[a] < h_lo[b]; });
+  {
+    std::vector<uint32_t> stack;
+    stack.reserve(8 * (PCV_MAX_KEY_LEVELS + 1));
+    stack.push_back(0);
+    while (!stack.empty()) {
+      const uint32_t i = stack.back();
+      stack.pop_back();
+      if (!h_open[i]) {
+        leaves.push_back(i);
+        continue;
+      }
+      const uint32_t nchild = (uint32_t)__builtin_popcount(h_mask[i]);
+      for (uint32_t c = nchild; c-- > 0;) stack.push_back(h_first[i] + c);  // reversed: digit 0 is popped first
+    }
+  }
   const uint32_t num_leaves = (uint32_t)leaves.size();
   std::vector<uint32_t> rank_of(M, 0);
   bool wide = false;
