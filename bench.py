@@ -118,6 +118,8 @@ def main():
         def step():
             t = ctx.build(args.resolution, bbox, x, y, z, rgb)
             info["nodes"], info["stages"], info["build"] = t.num_nodes, t.stage_ms(), t.build_info()
+            info.setdefault("gpu_ms", []).append(round(info["stages"]["total"], 3))
+            info.setdefault("all_stages", []).append({k: round(v, 2) for k, v in info["stages"].items()})
             t.free()
     else:
         from point_cloud_viewer_amd import distributed as pdist
@@ -135,17 +137,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if not args.no_kernel_events:
+        ctx.set_profiling(True)  # already during warmup, so that the event pool exists before the timed region
     for _ in range(args.warmup):
         step()
     if not args.no_kernel_events:
-        ctx.set_profiling(True)
         ctx.reset_kernel_stats()
+    import gc
+    gc.collect()
+    gc.disable()  # no collector pauses inside the timed region (the steps allocate no Python garbage to speak of)
     barrier()
     t0 = time.perf_counter()
+    step_marks = [t0]
     for _ in range(args.steps):
         step()
+        step_marks.append(time.perf_counter())  # every step ends with a stream sync inside the library
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
+    per_step_ms = [round((b - a) * 1e3, 3) for a, b in zip(step_marks[:-1], step_marks[1:])]
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -259,7 +269,7 @@ def main():
             "roofline": roofline, "encode_sort": encode_sort, "cpu_baseline": cpu, "end_to_end": e2e,
             "build_info": info.get("build"),
             "stage_ms": {k: round(v, 3) for k, v in (info.get("stages") or {}).items()},
-            "kernel_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in kstats.items() if v[0] > 0},
+            "wall_ms_each_step": per_step_ms, "stages_each_step": (info.get("all_stages") or []) if os.environ.get("PCV_BENCH_DEBUG") else None, "gpu_ms_each_step": (info.get("gpu_ms") or [])[-args.steps:], "kernel_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in kstats.items() if v[0] > 0},
         }
         print(json.dumps(out))
     if dist is not None:

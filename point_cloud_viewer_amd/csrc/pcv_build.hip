@@ -27,8 +27,10 @@ void* PcvPool::alloc(size_t bytes, hipError_t* err) {
   *err = hipSuccess;
   if (bytes == 0) bytes = 256;
   bytes = (bytes + 255) & ~(size_t)255;
+  // Reuse a cached block only if it is about the requested size: a loose match lets a small request grab a big block
+  // and the big request that follows pays a multi-millisecond hipMalloc in the middle of a build.
   auto it = free_blocks.lower_bound(bytes);
-  if (it != free_blocks.end() && it->first <= bytes * 2 + (1u << 20)) {
+  if (it != free_blocks.end() && it->first <= bytes + bytes / 8 + (64u << 10)) {
     void* p = it->second;
     live[p] = it->first;
     free_blocks.erase(it);
@@ -167,6 +169,10 @@ extern "C" int pcv_ctx_create(int device, void* stream, pcv_ctx** out) {
   if (hipSetDevice(device) != hipSuccess) return PCV_E_HIP;
   pcv_ctx* c = new pcv_ctx();
   c->device = device;
+  if (hipHostMalloc((void**)&c->mailbox, 64 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) {
+    delete c;
+    return PCV_E_OOM;
+  }
   if (stream) {
     c->stream = (hipStream_t)stream;
   } else {
@@ -192,6 +198,7 @@ extern "C" void pcv_ctx_destroy(pcv_ctx* ctx) {
   ctx->pool.trim();
   for (auto& kv : ctx->pool.live) (void)hipFree(kv.first);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
   for (auto& kv : ctx->host_free) (void)hipHostFree(kv.second);
   for (auto& kv : ctx->host_live) (void)hipHostFree(kv.first);
   for (auto& e : ctx->ev)
@@ -362,8 +369,9 @@ static int device_aabb(pcv_ctx* ctx, PcvScratch& sc, const DevPoints& d, double 
     pcv_launch_aabb(ctx, d.n, d.x, d.y, d.z, partial, out6);
   }
   double h[6];
-  PCV_HIP_CHECK(ctx, hipMemcpyAsync(h, out6, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(ctx->mailbox, out6, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
   PCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  std::memcpy(h, ctx->mailbox, sizeof(h));
   for (int a = 0; a < 3; ++a) {
     bmin[a] = h[a];
     bmax[a] = h[3 + a];
@@ -601,9 +609,9 @@ extern "C" int pcv_build_begin(pcv_ctx* ctx, const pcv_build_params* params, con
     double gapd = 0.6 * (double)max_points * (double)ns / (double)n;
     uint32_t gap = gapd < 1.0 ? 1u : (uint32_t)gapd;
     pcv_launch_depth_probe(ctx, s_in_a ? keys_a : keys_b, ns, gap, d_max);
-    uint32_t shared = 0;
-    PCV_HIP_CHECK(ctx, hipMemcpyAsync(&shared, d_max, 4, hipMemcpyDeviceToHost, st));
+    PCV_HIP_CHECK(ctx, hipMemcpyAsync(ctx->mailbox, d_max, 4, hipMemcpyDeviceToHost, st));
     PCV_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    const uint32_t shared = *(const uint32_t*)ctx->mailbox;
     // a level-`shared` node is (probably) split -> nodes of level shared + 1 exist -> that many digits are needed
     int want = (int)shared + 1;
     if (want < 3) want = 3;
@@ -648,8 +656,9 @@ extern "C" int pcv_build_begin(pcv_ctx* ctx, const pcv_build_params* params, con
     PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[4], st));
 
     // ---- node table to host ----
-    PCV_HIP_CHECK(ctx, hipMemcpyAsync(counters, nt.counters, sizeof(counters), hipMemcpyDeviceToHost, st));
+    PCV_HIP_CHECK(ctx, hipMemcpyAsync(ctx->mailbox, nt.counters, sizeof(counters), hipMemcpyDeviceToHost, st));
     PCV_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    std::memcpy(counters, ctx->mailbox, sizeof(counters));
     if (counters[1] & 2u) return ctx->fail(PCV_E_OOM, "node table capacity exceeded");
     if (counters[1] & 1u) {
       if (spec_levels < full_levels) {  // speculation too shallow: redo at full depth

@@ -409,10 +409,9 @@ extern "C" int pcv_route_buckets(pcv_ctx* ctx, const pcv_build_params* params, c
                        ctx->stream, lv, points->n, points->x, points->y, points->z, bucket, d_counts);
   }
   PCV_HIP_CHECK(ctx, hipGetLastError());
-  unsigned long long h[64];
-  PCV_HIP_CHECK(ctx, hipMemcpyAsync(h, d_counts, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(ctx->mailbox, d_counts, 64 * 8, hipMemcpyDeviceToHost, ctx->stream));
   PCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  for (int b = 0; b < 64; ++b) counts[b] = h[b];
+  for (int b = 0; b < 64; ++b) counts[b] = ctx->mailbox[b];
   return PCV_OK;
 }
 

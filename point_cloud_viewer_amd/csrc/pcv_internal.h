@@ -68,6 +68,9 @@ struct pcv_ctx {
   bool own_stream = false;
   std::string last_error;
   PcvPool pool;
+  // small pinned mailbox for scalar read-backs (counters, flags): a D2H copy into pageable memory (a stack variable)
+  // makes the runtime pin pages on the fly, which now and then costs milliseconds in the middle of a build
+  uint64_t* mailbox = nullptr;  // 64 x u64
   // pinned host staging, grown on demand
   void* pinned = nullptr;
   size_t pinned_bytes = 0;
