@@ -130,6 +130,7 @@ def main():
         def step():
             r = builder.build(args.resolution, bbox, x, y, z, rgb)
             info["nodes"], info["stages"] = r.num_nodes_local, r.stage_ms
+            info["build"] = r.local.build_info() if hasattr(r.local, "build_info") else None
             r.free()
 
     def barrier():
@@ -177,11 +178,11 @@ def main():
         # HBM bytes per launch from the PMC passes of the same command (tools/profile_bench.sh -> profiles/): only
         # quoted for the workload those passes ran (default points, 1 GPU, plain build)
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01_bench_100M_kernel_stats_v3_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r01_bench_100M_kernel_stats_v4_traffic.json")
         if os.path.exists(tpath) and n == 100_000_000 and world == 1 and not args.force_sharded and not args.ecef:
             with open(tpath) as f:
                 traffic = json.load(f)["bytes_per_launch"].get(dom)
-            traffic_src = "profiles/r01_bench_100M_kernel_stats_v3_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
+            traffic_src = "profiles/r01_bench_100M_kernel_stats_v4_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 4),
                     "launches": launches, "algorithmic_bytes_per_launch": ALGO_BYTES.get(dom, 0.0) * n}
@@ -265,15 +266,29 @@ def main():
                                    f"{n / 1e6:g} M Gaussian-cluster points (64 clusters, 1000 m cube, "
                                    "sigma 1-20 m), f64 SoA xyz + u8 rgb, resolution 1 mm, full build + LOD promotion",
                        "points_per_gpu": n, "resolution": args.resolution, "nodes": info.get("nodes"),
-                       "parallelism": "1 GPU" if world == 1 else f"root-octant sharding over {world} GPUs, one all-to-all"},
+                       "parallelism": "1 GPU" if world == 1 else
+                       f"{world} GPUs, one process each: 64 level-2 buckets bin-packed onto ranks, one all-to-all(v) over RCCL"},
             "roofline": roofline, "encode_sort": encode_sort, "cpu_baseline": cpu, "end_to_end": e2e,
             "build_info": info.get("build"),
             "stage_ms": {k: round(v, 3) for k, v in (info.get("stages") or {}).items()},
-            "wall_ms_each_step": per_step_ms, "stages_each_step": (info.get("all_stages") or []) if os.environ.get("PCV_BENCH_DEBUG") else None, "gpu_ms_each_step": (info.get("gpu_ms") or [])[-args.steps:], "kernel_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in kstats.items() if v[0] > 0},
+            "wall_ms_each_step": per_step_ms, "gpu_ms_each_step": (info.get("gpu_ms") or [])[-args.steps:],
+            "kernel_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in kstats.items() if v[0] > 0},
         }
-        print(json.dumps(out))
+        if os.environ.get("PCV_BENCH_DEBUG"):
+            out["stages_each_step"] = info.get("all_stages") or []
+    # RCCL prints a version banner on stdout when the communicator goes away: tear it down and flush the C streams
+    # first, so that the JSON line is the last thing this process writes
     if dist is not None:
         dist.destroy_process_group()
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    if rank == 0:
+        if world > 1:
+            time.sleep(1.5)  # let the other ranks finish writing their own teardown chatter first
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -379,10 +379,9 @@ extern "C" int pcv_selftest_division(pcv_ctx* ctx, const double* divisors, int n
   PCV_HIP_CHECK(ctx, hipMemsetAsync(dm, 0, 8, ctx->stream));
   hipLaunchKernelGGL(selftest_division_kernel, dim3(2048), dim3(256), 0, ctx->stream, dd, ndiv, samples_per_divisor, dm);
   PCV_HIP_CHECK(ctx, hipGetLastError());
-  unsigned long long h = 0;
-  PCV_HIP_CHECK(ctx, hipMemcpyAsync(&h, dm, 8, hipMemcpyDeviceToHost, ctx->stream));
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(ctx->mailbox, dm, 8, hipMemcpyDeviceToHost, ctx->stream));
   PCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  *mismatches = h;
+  *mismatches = ctx->mailbox[0];
   return PCV_OK;
 }
 

@@ -980,11 +980,10 @@ static int run_cull_points(pcv_ctx* ctx, const pcv_shapes* shapes, uint32_t shap
   }
   PCV_HIP_CHECK(ctx, hipGetLastError());
   if (mem == PCV_MEM_HOST) PCV_HIP_CHECK(ctx, hipMemcpyAsync(keep, d_keep, v.n, hipMemcpyDeviceToHost, ctx->stream));
-  unsigned long long hc = 0;
-  PCV_HIP_CHECK(ctx, hipMemcpyAsync(&hc, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(ctx->mailbox, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
   PCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->prof_resolve();
-  if (kept) *kept = hc;
+  if (kept) *kept = ctx->mailbox[0];
   return PCV_OK;
 }
 
@@ -1052,11 +1051,10 @@ extern "C" int pcv_cull_node_points(pcv_ctx* ctx, const pcv_shapes* shapes, uint
   }
   PCV_HIP_CHECK(ctx, hipGetLastError());
   PCV_HIP_CHECK(ctx, hipMemcpyAsync(keep, d_keep, v.n, hipMemcpyDeviceToHost, ctx->stream));
-  unsigned long long hc = 0;
-  PCV_HIP_CHECK(ctx, hipMemcpyAsync(&hc, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(ctx->mailbox, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
   PCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->prof_resolve();
-  if (kept) *kept = hc;
+  if (kept) *kept = ctx->mailbox[0];
   return PCV_OK;
 }
 
@@ -1178,9 +1176,9 @@ extern "C" int pcv_query_points(pcv_ctx* ctx, const pcv_shapes* shapes, uint32_t
                        interval ? interval[1] : 0.0, d_keep, d_bc);
   }
   hipLaunchKernelGGL(query_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_bc, nb, d_total);
-  unsigned long long kept = 0;
-  PCV_HIP_CHECK(ctx, hipMemcpyAsync(&kept, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(ctx->mailbox, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
   PCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // also keeps `jobs` alive until the copy is done
+  const unsigned long long kept = ctx->mailbox[0];
   *count = kept;
   const uint64_t nout = kept < capacity ? kept : capacity;
   if (nout) {
