@@ -127,6 +127,19 @@ typedef struct pcv_top_layout {
   uint32_t l2_offset[64];  /* offset of r_cd's promoted segment inside pre(r_c) */
 } pcv_top_layout;
 int pcv_build_begin(pcv_ctx* ctx, const pcv_build_params* params, const pcv_points* points, pcv_octree** out);
+/* pcv_build_begin for points that crossed the exchange as their level-1 chain state (pcv_route_buckets with a
+ * pcv_route_state): the root octant digit and the Float32 level-1 codes — with the colour 16 B per point in four 4-byte
+ * planes instead of 27 B. The chain continues at level 2 from decode(code) — the position the sending rank held after level 1,
+ * so everything downstream is bit-identical. Device memory only; params carry the GLOBAL bounding box. */
+typedef struct pcv_routed_points {
+  uint64_t n;
+  const uint32_t* cx;      /* Float32 bit patterns of the level-1 codes (codec.rs:102-121 with the level-1 child cube) */
+  const uint32_t* cy;
+  const uint32_t* cz;
+  const uint32_t* oct_rgb; /* level-1 digit (0..7) in byte 0, r, g, b in bytes 1..3 */
+  const float* intensity;  /* NULL = no "intensity" attribute */
+} pcv_routed_points;
+int pcv_build_begin_routed(pcv_ctx* ctx, const pcv_build_params* params, const pcv_routed_points* routed, pcv_octree** out);
 int pcv_build_top_streams(const pcv_octree* tree, pcv_top_streams* out);
 int pcv_build_finish(pcv_octree* tree, const pcv_top_layout* top /* nullable */);
 
@@ -206,22 +219,26 @@ int pcv_chain_keys(pcv_ctx* ctx, const pcv_build_params* params, const pcv_point
  * The ranks all-reduce the 64 counts, decide which level-1 nodes the global tree splits, and bin-pack the buckets
  * (whole octants where the level-1 node stays a leaf) onto ranks. Device-resident points only; bucket is a device
  * buffer of n u32, counts a host array of 64 entries. */
+typedef struct pcv_route_state {  /* optional outputs of pcv_route_buckets: the level-1 chain state of every point */
+  uint32_t* cx;                  /* device, n x u32: Float32 bit patterns of the level-1 codes */
+  uint32_t* cy;
+  uint32_t* cz;
+  uint32_t* oct_rgb;             /* device, n x u32: level-1 digit | r << 8 | g << 16 | b << 24 (needs points->color) */
+} pcv_route_state;
 int pcv_route_buckets(pcv_ctx* ctx, const pcv_build_params* params, const pcv_points* points, uint32_t* bucket,
-                      uint64_t counts[64]);
+                      uint64_t counts[64], const pcv_route_state* state /* nullable; needs a Float32-encoded level 1 */);
 
-/* Stable partition of the point planes by owner (owner[i] is a rank, or a bucket when rank_of_bucket maps the 64
- * buckets to ranks): row k (in input order) of the points owned by rank r goes to
- * dst[r].x[k], .y[k], .z[k], .color[k * color_stride ..], .intensity[k]. The caller points dst[r] at its send buffer
- * for rank r, and dst[own rank] straight at the receive buffer. All pointers are device pointers. */
-typedef struct pcv_route_dst {
-  double* x;
-  double* y;
-  double* z;
-  uint8_t* color;
-  float* intensity; /* NULL when the points carry none */
-} pcv_route_dst;
-int pcv_partition_by_owner(pcv_ctx* ctx, const pcv_points* points, const uint32_t* owner, uint32_t world,
-                           const pcv_route_dst* dst, const uint8_t* rank_of_bucket /* nullable host array of 64 */);
+/* Stable partition of up to 8 row-aligned planes by owner (owner[i] is a rank, or a bucket when rank_of_bucket maps the
+ * 64 buckets to ranks): row k (in input order) of the rows owned by rank r goes to row k of dst[r * nplanes + p] for
+ * every plane p. The caller points dst[r * nplanes + p] at its send buffer for rank r, and the own rank's entries
+ * straight at the receive buffer. All pointers are device pointers; rows are 1..16 bytes. */
+typedef struct pcv_plane {
+  const void* src;
+  uint32_t elem_bytes;
+} pcv_plane;
+int pcv_partition_by_owner(pcv_ctx* ctx, uint64_t n, const uint32_t* owner, uint32_t world,
+                           const uint8_t* rank_of_bucket /* nullable host array of 64 */, uint32_t nplanes,
+                           const pcv_plane* planes, void* const* dst /* [world][nplanes] */);
 
 /* K3: stable LSD radix sort of 64-bit keys on bits [begin_bit, end_bit), in place. */
 int pcv_sort_keys64(pcv_ctx* ctx, uint64_t* keys, uint64_t n, int begin_bit, int end_bit, int mem);

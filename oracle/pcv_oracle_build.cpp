@@ -744,6 +744,39 @@ static inline uint8_t chain_step(const LevelTable& t, int k /*child level*/, dou
   return d;
 }
 
+// Routed input of the multi-rank build (tests only): a point given as its level-1 chain state — octant digit and the
+// raw level-1 codes — instead of raw coordinates. chain_start() puts (p, mn, code) into the state chain_step() leaves
+// behind after level 1 and returns the next level to run (2), or 1 for raw coordinates.
+struct RoutedIn {
+  const uint8_t* oct;
+  const uint32_t* c[3];
+};
+static inline int chain_start(const LevelTable& t, const RoutedIn* r, size_t i, const double* x, const double* y,
+                              const double* z, double p[3], double mn[3], uint64_t code[3], unsigned* d1) {
+  mn[0] = t.root.mn[0];
+  mn[1] = t.root.mn[1];
+  mn[2] = t.root.mn[2];
+  code[0] = code[1] = code[2] = 0;
+  *d1 = 0;
+  if (!r) {
+    p[0] = x[i];
+    p[1] = y[i];
+    p[2] = z[i];
+    return 1;
+  }
+  const unsigned d = r->oct[i];
+  const double e = t.edge[1];
+  mn[0] += (double)((d >> 2) & 1) * e;  // node.rs:163-169, as in chain_step
+  mn[1] += (double)((d >> 1) & 1) * e;
+  mn[2] += (double)(d & 1) * e;
+  for (int a = 0; a < 3; ++a) {
+    code[a] = r->c[a][i];
+    p[a] = decode_coord(t.enc[1], code[a], mn[a], e);
+  }
+  *d1 = d;
+  return 2;
+}
+
 // Path digits of one point for levels 1..nlevels, 3 bits per level, level 1 most significant.
 static inline u128 chain_key(const LevelTable& t, int nlevels, const double p0[3]) {
   double p[3] = {p0[0], p0[1], p0[2]};
@@ -777,7 +810,8 @@ struct TopLayout {
 
 static Result* build_closed(const Aabb& bbox, double resolution, size_t n, const double* x, const double* y,
                             const double* z, const uint8_t* rgb, const float* intensity, int num_threads,
-                            unsigned force_mask = 0, const TopLayout* layout = nullptr, uint64_t* streams_out = nullptr) {
+                            unsigned force_mask = 0, const TopLayout* layout = nullptr, uint64_t* streams_out = nullptr,
+                            const RoutedIn* routed = nullptr) {
   if (streams_out) std::memset(streams_out, 0, sizeof(uint64_t) * 73);
   Result* r = new Result();
   r->version = CURRENT_VERSION;
@@ -790,8 +824,14 @@ static Result* build_closed(const Aabb& bbox, double resolution, size_t n, const
   std::vector<u128> keys(n);
 #pragma omp parallel for schedule(static) num_threads(num_threads)
   for (size_t i = 0; i < n; ++i) {
-    double p[3] = {x[i], y[i], z[i]};
-    keys[i] = chain_key(t, nlev, p);
+    double p[3], mn[3];
+    uint64_t code[3];
+    unsigned d1;
+    const int k0 = chain_start(t, routed, i, x, y, z, p, mn, code, &d1);
+    u128 key = d1;
+    for (int k = k0; k <= nlev; ++k) key = (key << 3) | chain_step(t, k, p, mn, code);
+    if (k0 > nlev) key = d1;
+    keys[i] = key;
   }
   // Top-down stable split of index lists (generation.rs:58-193 without the files).
   std::vector<CNode> nodes;
@@ -903,14 +943,20 @@ static Result* build_closed(const Aabb& bbox, double resolution, size_t n, const
       const size_t s = global_size[qi] >= 0 ? (size_t)post_slot[qi][sl] : sl;
       uint32_t i = post_idx[qi][sl];
       int L = post_origin[qi][sl];
-      double p[3] = {x[i], y[i], z[i]};
-      double mn[3] = {t.root.mn[0], t.root.mn[1], t.root.mn[2]};
+      double p[3], mn[3];
       double mins[48][3];
-      uint64_t code[3] = {0, 0, 0};
-      mins[0][0] = mn[0];
-      mins[0][1] = mn[1];
-      mins[0][2] = mn[2];
-      for (int k = 1; k <= L; ++k) {
+      uint64_t code[3];
+      unsigned d1;
+      mins[0][0] = t.root.mn[0];
+      mins[0][1] = t.root.mn[1];
+      mins[0][2] = t.root.mn[2];
+      const int k0 = chain_start(t, routed, i, x, y, z, p, mn, code, &d1);
+      if (k0 == 2) {
+        mins[1][0] = mn[0];
+        mins[1][1] = mn[1];
+        mins[1][2] = mn[2];
+      }
+      for (int k = k0; k <= L; ++k) {
         chain_step(t, k, p, mn, code);
         mins[k][0] = mn[0];
         mins[k][1] = mn[1];
@@ -1092,7 +1138,9 @@ void* pcvo_build_closed(double resolution, const double bmin[3], const double bm
 // One rank's share of a multi-rank build (see TopLayout). layout: 1 + 8 + 8 + 64 u64 or NULL; streams_out: 73 u64 or NULL.
 void* pcvo_build_closed_shard(double resolution, const double bmin[3], const double bmax[3], uint64_t n, const double* x,
                               const double* y, const double* z, const uint8_t* rgb, const float* intensity,
-                              int num_threads, unsigned force_mask, const uint64_t* layout, uint64_t* streams_out) {
+                              int num_threads, unsigned force_mask, const uint64_t* layout, uint64_t* streams_out,
+                              const uint8_t* r_oct, const uint32_t* r_cx, const uint32_t* r_cy, const uint32_t* r_cz) {
+  RoutedIn ri{r_oct, {r_cx, r_cy, r_cz}};
   Aabb b{{bmin[0], bmin[1], bmin[2]}, {bmax[0], bmax[1], bmax[2]}};
   TopLayout tl;
   if (layout) {
@@ -1103,7 +1151,24 @@ void* pcvo_build_closed_shard(double resolution, const double bmin[3], const dou
     }
     for (int i = 0; i < 64; ++i) tl.l2_offset[i] = layout[17 + i];
   }
-  return build_closed(b, resolution, n, x, y, z, rgb, intensity, num_threads, force_mask, layout ? &tl : nullptr, streams_out);
+  return build_closed(b, resolution, n, x, y, z, rgb, intensity, num_threads, force_mask, layout ? &tl : nullptr, streams_out,
+                      r_oct ? &ri : nullptr);
+}
+
+// Level-1 chain state of raw points: octant digit + raw level-1 codes (what crosses the exchange of the multi-rank build).
+void pcvo_chain_state1(const double bmin[3], const double bmax[3], double resolution, uint64_t n, const double* x,
+                       const double* y, const double* z, uint8_t* oct, uint32_t* cx, uint32_t* cy, uint32_t* cz) {
+  Aabb b{{bmin[0], bmin[1], bmin[2]}, {bmax[0], bmax[1], bmax[2]}};
+  LevelTable t = make_level_table(b, resolution, 40);
+  for (uint64_t i = 0; i < n; ++i) {
+    double p[3] = {x[i], y[i], z[i]};
+    double mn[3] = {t.root.mn[0], t.root.mn[1], t.root.mn[2]};
+    uint64_t code[3];
+    oct[i] = chain_step(t, 1, p, mn, code);
+    cx[i] = (uint32_t)code[0];
+    cy[i] = (uint32_t)code[1];
+    cz[i] = (uint32_t)code[2];
+  }
 }
 
 // Load an octree directory (ours or the oracle's) for comparison.

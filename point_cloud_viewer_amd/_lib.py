@@ -47,8 +47,17 @@ SHAPE_ALL, SHAPE_AABB, SHAPE_FRUSTUM, SHAPE_OBB, SHAPE_FRUSTUM_WITH_INVERSE = 0,
 REL_IN, REL_CROSS, REL_OUT = 0, 1, 2
 
 
-class RouteDst(C.Structure):
-    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("z", C.c_void_p), ("color", C.c_void_p), ("intensity", C.c_void_p)]
+class RouteState(C.Structure):
+    _fields_ = [("cx", C.c_void_p), ("cy", C.c_void_p), ("cz", C.c_void_p), ("oct_rgb", C.c_void_p)]
+
+
+class Plane(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("elem_bytes", C.c_uint32)]
+
+
+class RoutedPoints(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("cx", C.c_void_p), ("cy", C.c_void_p), ("cz", C.c_void_p), ("oct_rgb", C.c_void_p),
+                ("intensity", C.c_void_p)]
 
 
 class TopStreams(C.Structure):
@@ -95,8 +104,11 @@ _SIGNATURES = {
     "pcv_level_table": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_int,
                                   C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "pcv_chain_keys": (C.c_int, [_vp, C.POINTER(BuildParams), C.POINTER(Points), C.c_int, _vp]),
-    "pcv_route_buckets": (C.c_int, [_vp, C.POINTER(BuildParams), C.POINTER(Points), _vp, C.POINTER(C.c_uint64)]),
-    "pcv_partition_by_owner": (C.c_int, [_vp, C.POINTER(Points), _vp, C.c_uint32, C.POINTER(RouteDst), _vp]),
+    "pcv_route_buckets": (C.c_int, [_vp, C.POINTER(BuildParams), C.POINTER(Points), _vp, C.POINTER(C.c_uint64),
+                                    C.POINTER(RouteState)]),
+    "pcv_partition_by_owner": (C.c_int, [_vp, C.c_uint64, _vp, C.c_uint32, _vp, C.c_uint32, C.POINTER(Plane),
+                                         C.POINTER(C.c_void_p)]),
+    "pcv_build_begin_routed": (C.c_int, [_vp, C.POINTER(BuildParams), C.POINTER(RoutedPoints), C.POINTER(_vp)]),
     "pcv_octree_write_nodes": (C.c_int, [_vp, C.c_char_p, C.c_uint32]),
     "pcv_write_meta": (C.c_int, [C.c_char_p, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(NodeInfo),
                                  C.c_uint64]),

@@ -296,6 +296,7 @@ extern "C" int pcv_level_table(const double bbox_min[3], const double bbox_max[3
 struct DevPoints {
   uint64_t n = 0;
   const double *x = nullptr, *y = nullptr, *z = nullptr;
+  PcvRouted routed;  // multi-GPU build: level-1 chain state instead of raw coordinates
   const uint8_t* color = nullptr;
   uint32_t color_stride = 3;
   const float* intensity = nullptr;
@@ -522,6 +523,8 @@ extern "C" int pcv_octree_copy_node(const pcv_octree* t, uint64_t i, int which, 
 // ------------------------------------------------------------------------------------------------
 static uint64_t ceil8(uint64_t v) { return (v + 7) / 8; }
 
+static int build_begin_impl(pcv_ctx* ctx, const pcv_build_params* params, const pcv_points* points,
+                            const pcv_routed_points* routed, pcv_octree** out);
 extern "C" int pcv_build_begin(pcv_ctx* ctx, const pcv_build_params* params, const pcv_points* points,
                                pcv_octree** out) {
   if (!ctx) return PCV_E_INVALID;
@@ -530,11 +533,28 @@ extern "C" int pcv_build_begin(pcv_ctx* ctx, const pcv_build_params* params, con
   if (!params) return ctx->fail(PCV_E_INVALID, "params is null");
   int rc = validate_points(ctx, points, true);
   if (rc) return rc;
+  return build_begin_impl(ctx, params, points, nullptr, out);
+}
+extern "C" int pcv_build_begin_routed(pcv_ctx* ctx, const pcv_build_params* params, const pcv_routed_points* routed,
+                                      pcv_octree** out) {
+  if (!ctx) return PCV_E_INVALID;
+  if (!out) return ctx->fail(PCV_E_INVALID, "out is null");
+  *out = nullptr;
+  if (!params || !routed) return ctx->fail(PCV_E_INVALID, "null argument");
+  if (routed->n >= 0xffffffffull) return ctx->fail(PCV_E_INVALID, "at most 2^32 - 2 points per call");
+  if (routed->n > 0 && (!routed->oct_rgb || !routed->cx || !routed->cy || !routed->cz))
+    return ctx->fail(PCV_E_INVALID, "cx, cy, cz and oct_rgb must be non-null");
+  if (params->flags & PCV_BUILD_COMPUTE_BBOX) return ctx->fail(PCV_E_INVALID, "routed points need the global bounding box");
+  return build_begin_impl(ctx, params, nullptr, routed, out);
+}
+static int build_begin_impl(pcv_ctx* ctx, const pcv_build_params* params, const pcv_points* points,
+                            const pcv_routed_points* routed, pcv_octree** out) {
+  int rc;
   if (!(params->resolution > 0.0) || !std::isfinite(params->resolution)) return ctx->fail(PCV_E_INVALID, "resolution must be a positive finite number");
   const uint32_t max_points = params->max_points_per_node ? params->max_points_per_node : PCV_DEFAULT_MAX_POINTS_PER_NODE;
   PCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
-  const uint64_t n = points->n;
+  const uint64_t n = routed ? routed->n : points->n;
 
   PcvBuild* bs = new PcvBuild(ctx);
   pcv_octree* t = new pcv_octree();
@@ -544,7 +564,7 @@ extern "C" int pcv_build_begin(pcv_ctx* ctx, const pcv_build_params* params, con
   DevPoints& d = bs->d;
   bs->n = n;
   t->resolution = params->resolution;
-  t->has_intensity = points->intensity != nullptr;
+  t->has_intensity = (routed ? routed->intensity : points->intensity) != nullptr;
   struct Guard {
     pcv_octree* t;
     ~Guard() {
@@ -552,7 +572,19 @@ extern "C" int pcv_build_begin(pcv_ctx* ctx, const pcv_build_params* params, con
     }
   } guard{t};
   PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[0], st));
-  if ((rc = stage_points(ctx, sc, points, true, &d))) return rc;
+  if (routed) {  // device-resident by contract
+    d.n = n;
+    d.routed.oct = reinterpret_cast<const uint8_t*>(routed->oct_rgb);  // byte 0 of every packed word
+    d.routed.oct_stride = 4;
+    d.routed.cx = routed->cx;
+    d.routed.cy = routed->cy;
+    d.routed.cz = routed->cz;
+    d.color = reinterpret_cast<const uint8_t*>(routed->oct_rgb) + 1;  // r, g, b follow the digit
+    d.color_stride = 4;
+    d.intensity = routed->intensity;
+  } else if ((rc = stage_points(ctx, sc, points, true, &d))) {
+    return rc;
+  }
 
   double bmin[3], bmax[3];
   if (params->flags & PCV_BUILD_COMPUTE_BBOX) {
@@ -579,6 +611,8 @@ extern "C" int pcv_build_begin(pcv_ctx* ctx, const pcv_build_params* params, con
   PcvLevels& lv = bs->lv;
   int max_level = 0;
   pcv_make_levels(bmin, bmax, params->resolution, 64, &lv, &max_level, nullptr, nullptr);
+  if (routed && (lv.nlevels < 1 || lv.enc[1] != PCV_ENC_FLOAT32))
+    return ctx->fail(PCV_E_INVALID, "routed points carry Float32 level-1 codes, but level 1 of this cube is not Float32-encoded");
 
   // ---- K2 keys, K3 sort, K4 node split — with depth speculation ----
   // The keys only have to cover the levels the tree really uses. A strided sample (2^18 points) gets full-depth
@@ -601,7 +635,7 @@ extern "C" int pcv_build_begin(pcv_ctx* ctx, const pcv_build_params* params, con
     uint32_t* d_max;
     if ((rc = sc.get(&d_max, 64))) return rc;
     PCV_HIP_CHECK(ctx, hipMemsetAsync(d_max, 0, 4, st));
-    pcv_launch_chain_keys(ctx, lv, ns, stride, d.x, d.y, d.z, keys_a, false);
+    pcv_launch_chain_keys(ctx, lv, ns, stride, d.x, d.y, d.z, keys_a, false, d.routed);
     bool s_in_a = true;
     if ((rc = pcv_radix_sort_u64(ctx, keys_a, keys_b, ns, 3 * (PCV_MAX_KEY_LEVELS - full_levels), 3 * PCV_MAX_KEY_LEVELS,
                                  nullptr, sort_scratch, &s_in_a)))
@@ -626,7 +660,7 @@ extern "C" int pcv_build_begin(pcv_ctx* ctx, const pcv_build_params* params, con
     ++attempts;
     lv.nlevels = spec_levels;
     keys32 = spec_levels <= 10;
-    pcv_launch_chain_keys(ctx, lv, n, 1, d.x, d.y, d.z, keys_a, keys32);
+    pcv_launch_chain_keys(ctx, lv, n, 1, d.x, d.y, d.z, keys_a, keys32, d.routed);
     PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[2], st));
     bool in_a = true;
     if (keys32)
@@ -947,7 +981,7 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
   }
   const int w_int = t->has_intensity ? 0 : -1;
   const int w_hi = wide ? (t->has_intensity ? 1 : 0) : -1;
-  pcv_launch_leaf_encode(ctx, lv, wt, n, d.x, d.y, d.z, d.color, d.color_stride, d.intensity, rank_a, pay_a,
+  pcv_launch_leaf_encode(ctx, lv, wt, n, d.x, d.y, d.z, d.routed, d.color, d.color_stride, d.intensity, rank_a, pay_a,
                          wide ? pl.in[w_hi] : nullptr, wide ? pl.in[w_hi + 1] : nullptr, wide ? pl.in[w_hi + 2] : nullptr,
                          w_int >= 0 ? pl.in[w_int] : nullptr);
   PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[6], st));

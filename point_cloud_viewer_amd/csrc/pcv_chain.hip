@@ -6,6 +6,8 @@
 //
 // Bounds: K1 is a pure HBM stream (24 B/point). K2 is f64-VALU bound by construction (two correctly rounded
 // f64 divisions per coordinate per level; parity forbids reciprocals) — it reads 24 B and writes 8 B/point.
+#include <cstring>
+
 #include "pcv_chain_dev.h"
 
 namespace {
@@ -102,21 +104,23 @@ __global__ __launch_bounds__(256) void aabb_final_kernel(int nblocks, const doub
 template <typename KeyT>
 __global__ __launch_bounds__(256) void chain_keys_kernel(PcvLevels lv, uint64_t n, uint64_t stride,
                                                           const double* __restrict__ x, const double* __restrict__ y,
-                                                          const double* __restrict__ z, KeyT* __restrict__ keys) {
+                                                          const double* __restrict__ z, PcvRouted routed,
+                                                          KeyT* __restrict__ keys) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const uint64_t src = i * stride;
-  double px = x[src], py = y[src], pz = z[src];
-  double mx = lv.root_min[0], my = lv.root_min[1], mz = lv.root_min[2];
-  uint64_t key = 0;
-  double cx, cy, cz;
+  double px, py, pz, mx, my, mz;
+  double cx = 0, cy = 0, cz = 0;
+  uint32_t d1;
+  const int k0 = pcv_chain_start(lv, routed, x, y, z, src, px, py, pz, mx, my, mz, cx, cy, cz, d1);
+  uint64_t key = (uint64_t)d1 << (3 * (PCV_MAX_KEY_LEVELS - 1));
   if (lv.fast_ok && pcv_point_is_tame(px, py, pz)) {
-    for (int k = 1; k <= lv.nlevels; ++k) {
+    for (int k = k0; k <= lv.nlevels; ++k) {
       const uint32_t d = pcv_chain_level<false>(lv.enc[k], lv.edge[k - 1], lv.edge[k], lv.inv_edge[k], px, py, pz, mx, my, mz, cx, cy, cz);
       key |= (uint64_t)d << (3 * (PCV_MAX_KEY_LEVELS - k));
     }
   } else {
-    for (int k = 1; k <= lv.nlevels; ++k) {
+    for (int k = k0; k <= lv.nlevels; ++k) {
       const uint32_t d = pcv_chain_level<true>(lv.enc[k], lv.edge[k - 1], lv.edge[k], lv.inv_edge[k], px, py, pz, mx, my, mz, cx, cy, cz);
       key |= (uint64_t)d << (3 * (PCV_MAX_KEY_LEVELS - k));
     }
@@ -149,7 +153,10 @@ __global__ __launch_bounds__(256) void depth_probe_kernel(const uint64_t* __rest
 __global__ __launch_bounds__(256) void route_bucket_kernel(PcvLevels lv, uint64_t n, const double* __restrict__ x,
                                                             const double* __restrict__ y, const double* __restrict__ z,
                                                             uint32_t* __restrict__ bucket,
-                                                            unsigned long long* __restrict__ counts /* [64] */) {
+                                                            unsigned long long* __restrict__ counts /* [64] */,
+                                                            uint32_t* __restrict__ st_orgb, uint32_t* __restrict__ st_cx,
+                                                            uint32_t* __restrict__ st_cy, uint32_t* __restrict__ st_cz,
+                                                            const uint8_t* __restrict__ color, uint32_t color_stride) {
   __shared__ uint32_t hist[64];
   if (threadIdx.x < 64) hist[threadIdx.x] = 0;
   __syncthreads();
@@ -163,8 +170,16 @@ __global__ __launch_bounds__(256) void route_bucket_kernel(PcvLevels lv, uint64_
       double px = x[i], py = y[i], pz = z[i];
       double mx = lv.root_min[0], my = lv.root_min[1], mz = lv.root_min[2];
       double cx, cy, cz;
-      for (int k = 1; k <= lv.nlevels; ++k)  // nlevels <= 2 here; always the guarded (exact for any input) variant
+      for (int k = 1; k <= lv.nlevels; ++k) {  // nlevels <= 2 here; always the guarded (exact for any input) variant
         b = (b << 3) | pcv_chain_level<true>(lv.enc[k], lv.edge[k - 1], lv.edge[k], lv.inv_edge[k], px, py, pz, mx, my, mz, cx, cy, cz);
+        if (k == 1 && st_orgb) {  // the level-1 state that crosses the exchange instead of the raw coordinates
+          const uint8_t* c = color + i * color_stride;
+          st_orgb[i] = b | ((uint32_t)c[0] << 8) | ((uint32_t)c[1] << 16) | ((uint32_t)c[2] << 24);
+          st_cx[i] = __float_as_uint((float)cx);  // value domain -> Float32 bit pattern (exact: cx is a float value)
+          st_cy[i] = __float_as_uint((float)cy);
+          st_cz[i] = __float_as_uint((float)cz);
+        }
+      }
       if (lv.nlevels < 2) b <<= 3;
       bucket[i] = b;
     }
@@ -246,24 +261,32 @@ __global__ __launch_bounds__(1024) void partition_scan_kernel(uint32_t* __restri
   }
 }
 
-struct PartDst {
-  double* x[8];
-  double* y[8];
-  double* z[8];
-  uint8_t* color[8];
-  float* intensity[8];
+constexpr int kMaxPlanes = 8;
+struct PartPlanes {
+  const uint8_t* src[kMaxPlanes];
+  uint32_t elem[kMaxPlanes];  // bytes per row: 1, 2, 3, 4, 8 or 16
+  uint8_t* dst[8][kMaxPlanes];
+  int nplanes;
 };
+
+__device__ __forceinline__ void copy_row(uint8_t* __restrict__ d, const uint8_t* __restrict__ s, uint32_t elem) {
+  switch (elem) {  // wave-uniform
+    case 8: *reinterpret_cast<uint64_t*>(d) = *reinterpret_cast<const uint64_t*>(s); break;
+    case 4: *reinterpret_cast<uint32_t*>(d) = *reinterpret_cast<const uint32_t*>(s); break;
+    case 2: *reinterpret_cast<uint16_t*>(d) = *reinterpret_cast<const uint16_t*>(s); break;
+    case 16: *reinterpret_cast<uint4*>(d) = *reinterpret_cast<const uint4*>(s); break;
+    default:
+      for (uint32_t b = 0; b < elem; ++b) d[b] = s[b];
+  }
+}
 
 __global__ __launch_bounds__(256) void partition_scatter_kernel(uint64_t n, const uint32_t* __restrict__ owner, uint32_t world,
                                                                  uint32_t ntiles, const uint32_t* __restrict__ tile_base,
-                                                                 const double* __restrict__ x, const double* __restrict__ y,
-                                                                 const double* __restrict__ z, const uint8_t* __restrict__ color,
-                                                                 uint32_t color_stride, const float* __restrict__ intensity,
-                                                                 PartDst dst, const uint8_t* __restrict__ remap) {
+                                                                 PartPlanes pl, const uint8_t* __restrict__ remap) {
   __shared__ uint32_t wave_cnt[4][8];
-  __shared__ PartDst sdst;  // per-lane owner indexes the pointer table: LDS lookup instead of a private copy
+  __shared__ uint8_t* sdst[8][kMaxPlanes];  // per-lane owner indexes the pointer table: LDS lookup, not a private copy
   __shared__ uint8_t rank_of[64];
-  if (threadIdx.x == 0) sdst = dst;
+  if (threadIdx.x < 8 * kMaxPlanes) sdst[threadIdx.x / kMaxPlanes][threadIdx.x % kMaxPlanes] = pl.dst[threadIdx.x / kMaxPlanes][threadIdx.x % kMaxPlanes];
   if (threadIdx.x < 64) rank_of[threadIdx.x] = remap ? remap[threadIdx.x] : (uint8_t)threadIdx.x;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -297,16 +320,10 @@ __global__ __launch_bounds__(256) void partition_scatter_kernel(uint64_t n, cons
       run[k] += (uint32_t)__popcll(m);
     }
     if (idx < n) {
-      sdst.x[o][pos] = x[idx];
-      sdst.y[o][pos] = y[idx];
-      sdst.z[o][pos] = z[idx];
-      const uint8_t* c = color + idx * color_stride;
-      uint8_t* d = sdst.color[o] + (uint64_t)pos * color_stride;
-      d[0] = c[0];
-      d[1] = c[1];
-      d[2] = c[2];
-      if (color_stride == 4) d[3] = c[3];
-      if (intensity) sdst.intensity[o][pos] = intensity[idx];
+      for (int p = 0; p < pl.nplanes; ++p) {
+        const uint32_t e = pl.elem[p];
+        copy_row(sdst[o][p] + (uint64_t)pos * e, pl.src[p] + idx * e, e);
+      }
     }
   }
 }
@@ -386,7 +403,7 @@ extern "C" int pcv_selftest_division(pcv_ctx* ctx, const double* divisors, int n
 }
 
 extern "C" int pcv_route_buckets(pcv_ctx* ctx, const pcv_build_params* params, const pcv_points* points, uint32_t* bucket,
-                                 uint64_t counts[64]) {
+                                 uint64_t counts[64], const pcv_route_state* state) {
   if (!ctx) return PCV_E_INVALID;
   if (!params || !points || !counts) return ctx->fail(PCV_E_INVALID, "null argument");
   for (int b = 0; b < 64; ++b) counts[b] = 0;
@@ -397,6 +414,13 @@ extern "C" int pcv_route_buckets(pcv_ctx* ctx, const pcv_build_params* params, c
   PcvLevels lv;
   int max_level;
   pcv_make_levels(params->bbox_min, params->bbox_max, params->resolution, 2, &lv, &max_level, nullptr, nullptr);
+  if (state) {
+    if (!state->oct_rgb || !state->cx || !state->cy || !state->cz) return ctx->fail(PCV_E_INVALID, "null plane in pcv_route_state");
+    if (!points->color || (points->color_stride != 3 && points->color_stride != 4))
+      return ctx->fail(PCV_E_INVALID, "the level-1 state packs the colour: points->color (stride 3 or 4) is required");
+    if (lv.nlevels < 1 || lv.enc[1] != PCV_ENC_FLOAT32)
+      return ctx->fail(PCV_E_INVALID, "the level-1 state is only defined for a Float32-encoded level 1: exchange raw coordinates");
+  }
   PcvScratch sc(ctx);
   unsigned long long* d_counts;
   int rc;
@@ -405,7 +429,9 @@ extern "C" int pcv_route_buckets(pcv_ctx* ctx, const pcv_build_params* params, c
   {
     PcvProf prof(ctx, PCV_K_ROUTE_BUCKET);
     hipLaunchKernelGGL(route_bucket_kernel, dim3((unsigned)std::min<uint64_t>((points->n + 255) / 256, 8192)), dim3(256), 0,
-                       ctx->stream, lv, points->n, points->x, points->y, points->z, bucket, d_counts);
+                       ctx->stream, lv, points->n, points->x, points->y, points->z, bucket, d_counts,
+                       state ? state->oct_rgb : nullptr, state ? state->cx : nullptr, state ? state->cy : nullptr,
+                       state ? state->cz : nullptr, points->color, points->color_stride);
   }
   PCV_HIP_CHECK(ctx, hipGetLastError());
   PCV_HIP_CHECK(ctx, hipMemcpyAsync(ctx->mailbox, d_counts, 64 * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -414,20 +440,28 @@ extern "C" int pcv_route_buckets(pcv_ctx* ctx, const pcv_build_params* params, c
   return PCV_OK;
 }
 
-extern "C" int pcv_partition_by_owner(pcv_ctx* ctx, const pcv_points* points, const uint32_t* owner, uint32_t world,
-                                      const pcv_route_dst* dst, const uint8_t* rank_of_bucket) {
+extern "C" int pcv_partition_by_owner(pcv_ctx* ctx, uint64_t n, const uint32_t* owner, uint32_t world,
+                                      const uint8_t* rank_of_bucket, uint32_t nplanes, const pcv_plane* planes,
+                                      void* const* dst) {
   if (!ctx) return PCV_E_INVALID;
-  if (!points || !dst) return ctx->fail(PCV_E_INVALID, "null argument");
+  if (!planes || !dst) return ctx->fail(PCV_E_INVALID, "null argument");
   if (world < 1 || world > 8) return ctx->fail(PCV_E_INVALID, "world must be 1..8");
-  if (points->n == 0) return PCV_OK;
+  if (nplanes < 1 || nplanes > (uint32_t)kMaxPlanes) return ctx->fail(PCV_E_INVALID, "1..8 planes");
+  if (n == 0) return PCV_OK;
   if (!owner) return ctx->fail(PCV_E_INVALID, "owner is null");
-  if (points->mem != PCV_MEM_DEVICE) return ctx->fail(PCV_E_INVALID, "pcv_partition_by_owner works on device-resident points");
-  if (points->color_stride != 3 && points->color_stride != 4) return ctx->fail(PCV_E_INVALID, "color_stride must be 3 or 4");
+  if (n >= 0xffffffffull) return ctx->fail(PCV_E_INVALID, "at most 2^32 - 2 rows per call");
   if (rank_of_bucket)
     for (int b = 0; b < 64; ++b)
       if (rank_of_bucket[b] >= world) return ctx->fail(PCV_E_INVALID, "rank_of_bucket entry out of range");
-  const uint64_t n = points->n;
-  if (n == 0) return PCV_OK;
+  PartPlanes pl{};
+  pl.nplanes = (int)nplanes;
+  for (uint32_t p = 0; p < nplanes; ++p) {
+    const uint32_t e = planes[p].elem_bytes;
+    if (!planes[p].src || e == 0 || e > 16) return ctx->fail(PCV_E_INVALID, "plane: null source or row size outside 1..16 bytes");
+    pl.src[p] = (const uint8_t*)planes[p].src;
+    pl.elem[p] = e;
+    for (uint32_t k = 0; k < world; ++k) pl.dst[k][p] = (uint8_t*)dst[(size_t)k * nplanes + p];
+  }
   PCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   PcvScratch sc(ctx);
   const uint32_t ntiles = (uint32_t)((n + kPartTile - 1) / kPartTile);
@@ -437,15 +471,8 @@ extern "C" int pcv_partition_by_owner(pcv_ctx* ctx, const pcv_points* points, co
   if ((rc = sc.get(&tile_counts, (size_t)world * ntiles))) return rc;
   if (rank_of_bucket) {
     if ((rc = sc.get(&d_remap, 64))) return rc;
-    PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_remap, rank_of_bucket, 64, hipMemcpyHostToDevice, ctx->stream));
-  }
-  PartDst pd{};
-  for (uint32_t k = 0; k < world; ++k) {
-    pd.x[k] = dst[k].x;
-    pd.y[k] = dst[k].y;
-    pd.z[k] = dst[k].z;
-    pd.color[k] = dst[k].color;
-    pd.intensity[k] = dst[k].intensity;
+    std::memcpy(ctx->mailbox, rank_of_bucket, 64);  // pinned source for the async upload
+    PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_remap, ctx->mailbox, 64, hipMemcpyHostToDevice, ctx->stream));
   }
   {
     PcvProf prof(ctx, PCV_K_PARTITION_COUNT);
@@ -456,8 +483,7 @@ extern "C" int pcv_partition_by_owner(pcv_ctx* ctx, const pcv_points* points, co
   {
     PcvProf prof(ctx, PCV_K_PARTITION_SCATTER);
     hipLaunchKernelGGL(partition_scatter_kernel, dim3(ntiles), dim3(256), 0, ctx->stream, n, owner, world, ntiles, tile_counts,
-                       points->x, points->y, points->z, points->color, points->color_stride, points->intensity, pd,
-                       (const uint8_t*)d_remap);
+                       pl, (const uint8_t*)d_remap);
   }
   PCV_HIP_CHECK(ctx, hipGetLastError());
   PCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -477,16 +503,16 @@ int pcv_launch_aabb(pcv_ctx* ctx, uint64_t n, const double* x, const double* y, 
 }
 
 void pcv_launch_chain_keys(pcv_ctx* ctx, const PcvLevels& lv, uint64_t n, uint64_t stride, const double* x,
-                           const double* y, const double* z, void* keys, bool keys32) {
+                           const double* y, const double* z, void* keys, bool keys32, const PcvRouted& routed) {
   if (n == 0) return;
   uint64_t blocks = (n + 255) / 256;
   PcvProf prof(ctx, PCV_K_CHAIN_KEYS);
   if (keys32)
     hipLaunchKernelGGL(chain_keys_kernel<uint32_t>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, lv, n, stride, x, y,
-                       z, (uint32_t*)keys);
+                       z, routed, (uint32_t*)keys);
   else
     hipLaunchKernelGGL(chain_keys_kernel<uint64_t>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, lv, n, stride, x, y,
-                       z, (uint64_t*)keys);
+                       z, routed, (uint64_t*)keys);
 }
 
 void pcv_launch_depth_probe(pcv_ctx* ctx, const uint64_t* sorted, uint32_t n, uint32_t gap, uint32_t* out) {

@@ -159,6 +159,34 @@ __device__ __forceinline__ uint32_t pcv_chain_level(uint32_t enc, double ep, dou
   }
 }
 
+// Start of a point's chain. Raw points start at the root (returns level 1). Routed points (PcvRouted) arrive as their
+// level-1 state: the octant digit selects the level-1 cube with the same `min += bit * edge` step the chain uses, the
+// Float32 codes decode to exactly the position the sending rank held after level 1 (returns level 2, digit in d1,
+// codes in the value domain in vx..vz).
+__device__ __forceinline__ int pcv_chain_start(const PcvLevels& lv, const PcvRouted& r, const double* __restrict__ x,
+                                               const double* __restrict__ y, const double* __restrict__ z, uint64_t src,
+                                               double& px, double& py, double& pz, double& mx, double& my, double& mz,
+                                               double& vx, double& vy, double& vz, uint32_t& d1) {
+  mx = lv.root_min[0], my = lv.root_min[1], mz = lv.root_min[2];
+  if (!r.oct) {
+    px = x[src], py = y[src], pz = z[src];
+    d1 = 0;
+    return 1;
+  }
+  d1 = r.oct[src * r.oct_stride] & 7u;
+  const double e1 = lv.edge[1];
+  mx = mx + ((d1 & 4u) ? e1 : 0.0);
+  my = my + ((d1 & 2u) ? e1 : 0.0);
+  mz = mz + ((d1 & 1u) ? e1 : 0.0);
+  vx = (double)__uint_as_float(r.cx[src]);
+  vy = (double)__uint_as_float(r.cy[src]);
+  vz = (double)__uint_as_float(r.cz[src]);
+  px = pcv_decode_val<PCV_ENC_FLOAT32>(vx, mx, e1);
+  py = pcv_decode_val<PCV_ENC_FLOAT32>(vy, my, e1);
+  pz = pcv_decode_val<PCV_ENC_FLOAT32>(vz, mz, e1);
+  return 2;
+}
+
 // One check per point instead of one per division: finite and |v| <= 2^500 keeps every p_k - m_k of the chain
 // finite and below 2^900 (cube mins and edges are bounded by PcvLevels::fast_ok on the host).
 __device__ __forceinline__ bool pcv_point_is_tame(double x, double y, double z) {

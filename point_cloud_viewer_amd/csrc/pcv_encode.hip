@@ -15,8 +15,8 @@ namespace {
 
 __global__ __launch_bounds__(256) void leaf_encode_kernel(
     PcvLevels lv, const uint64_t* __restrict__ walk, uint64_t n, const double* __restrict__ x,
-    const double* __restrict__ y, const double* __restrict__ z, const uint8_t* __restrict__ color, uint32_t color_stride,
-    const float* __restrict__ intensity, uint32_t* __restrict__ rank, uint4* __restrict__ payload,
+    const double* __restrict__ y, const double* __restrict__ z, PcvRouted routed, const uint8_t* __restrict__ color,
+    uint32_t color_stride, const float* __restrict__ intensity, uint32_t* __restrict__ rank, uint4* __restrict__ payload,
     uint32_t* __restrict__ cx_hi, uint32_t* __restrict__ cy_hi, uint32_t* __restrict__ cz_hi,
     uint32_t* __restrict__ inten_bits) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -25,24 +25,34 @@ __global__ __launch_bounds__(256) void leaf_encode_kernel(
   // (identical to K2's digit by construction), so no key has to be read back.
   // walk record = first_child | child_mask << 32 | leaf << 40 | level << 48 (leaves: low 32 bits = leaf rank)
   uint64_t rec = walk[0];
-  double px = x[i], py = y[i], pz = z[i];
-  double mx = lv.root_min[0], my = lv.root_min[1], mz = lv.root_min[2];
+  double px, py, pz, mx, my, mz;
   double vx = 0, vy = 0, vz = 0;
+  uint32_t d1;
   int L = 0;
-  if (lv.fast_ok && pcv_point_is_tame(px, py, pz)) {
-    do {
-      ++L;
-      const uint32_t d = pcv_chain_level<false>(lv.enc[L], lv.edge[L - 1], lv.edge[L], lv.inv_edge[L], px, py, pz, mx, my, mz, vx, vy, vz);
-      const uint32_t mask = (uint32_t)(rec >> 32) & 0xffu;
-      rec = walk[(uint32_t)rec + __popc(mask & ((1u << d) - 1u))];
-    } while (!((rec >> 40) & 1ull) && L < lv.nlevels);
-  } else {
-    do {
-      ++L;
-      const uint32_t d = pcv_chain_level<true>(lv.enc[L], lv.edge[L - 1], lv.edge[L], lv.inv_edge[L], px, py, pz, mx, my, mz, vx, vy, vz);
-      const uint32_t mask = (uint32_t)(rec >> 32) & 0xffu;
-      rec = walk[(uint32_t)rec + __popc(mask & ((1u << d) - 1u))];
-    } while (!((rec >> 40) & 1ull) && L < lv.nlevels);
+  bool done = false;
+  if (pcv_chain_start(lv, routed, x, y, z, i, px, py, pz, mx, my, mz, vx, vy, vz, d1) == 2) {
+    // routed input: level 1 is given (digit + codes), take the step through the node table only
+    L = 1;
+    const uint32_t mask = (uint32_t)(rec >> 32) & 0xffu;
+    rec = walk[(uint32_t)rec + __popc(mask & ((1u << d1) - 1u))];
+    done = ((rec >> 40) & 1ull) || L >= lv.nlevels;
+  }
+  if (!done) {
+    if (lv.fast_ok && pcv_point_is_tame(px, py, pz)) {
+      do {
+        ++L;
+        const uint32_t d = pcv_chain_level<false>(lv.enc[L], lv.edge[L - 1], lv.edge[L], lv.inv_edge[L], px, py, pz, mx, my, mz, vx, vy, vz);
+        const uint32_t mask = (uint32_t)(rec >> 32) & 0xffu;
+        rec = walk[(uint32_t)rec + __popc(mask & ((1u << d) - 1u))];
+      } while (!((rec >> 40) & 1ull) && L < lv.nlevels);
+    } else {
+      do {
+        ++L;
+        const uint32_t d = pcv_chain_level<true>(lv.enc[L], lv.edge[L - 1], lv.edge[L], lv.inv_edge[L], px, py, pz, mx, my, mz, vx, vy, vz);
+        const uint32_t mask = (uint32_t)(rec >> 32) & 0xffu;
+        rec = walk[(uint32_t)rec + __popc(mask & ((1u << d) - 1u))];
+      } while (!((rec >> 40) & 1ull) && L < lv.nlevels);
+    }
   }
   rank[i] = (uint32_t)rec;
   const uint32_t leaf_enc = lv.enc[L];
@@ -218,13 +228,13 @@ __global__ __launch_bounds__(256) void promote_climb_kernel(
 }  // namespace
 
 void pcv_launch_leaf_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvWalkTables& wt, uint64_t n, const double* x,
-                            const double* y, const double* z, const uint8_t* color, uint32_t color_stride,
-                            const float* intensity, uint32_t* rank, void* payload, uint32_t* cx_hi, uint32_t* cy_hi,
-                            uint32_t* cz_hi, uint32_t* inten_bits) {
+                            const double* y, const double* z, const PcvRouted& routed, const uint8_t* color,
+                            uint32_t color_stride, const float* intensity, uint32_t* rank, void* payload, uint32_t* cx_hi,
+                            uint32_t* cy_hi, uint32_t* cz_hi, uint32_t* inten_bits) {
   if (n == 0) return;
   PcvProf prof(ctx, PCV_K_LEAF_ENCODE);
   hipLaunchKernelGGL(leaf_encode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, lv, wt.walk, n, x,
-                     y, z, color, color_stride, intensity, rank, (uint4*)payload, cx_hi, cy_hi, cz_hi, inten_bits);
+                     y, z, routed, color, color_stride, intensity, rank, (uint4*)payload, cx_hi, cy_hi, cz_hi, inten_bits);
 }
 
 void pcv_launch_promote_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvPromoteTables& pt, uint64_t n,

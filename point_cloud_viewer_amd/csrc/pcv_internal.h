@@ -154,9 +154,19 @@ struct PcvScratch {
 // pcv_chain.hip
 int pcv_launch_aabb(pcv_ctx* ctx, uint64_t n, const double* x, const double* y, const double* z, double* partial,
                     double* out6 /* device: min xyz, max xyz */);
+// Routed input (multi-GPU build): instead of raw coordinates a point arrives as its level-1 chain state — the root
+// octant digit and the level-1 codes (Float32 bit patterns; the exchange falls back to raw f64 when level 1 is not
+// Float32-encoded). The chain continues at level 2 from decode(code) exactly as it would have on the sending rank.
+struct PcvRouted {
+  const uint8_t* oct = nullptr;  // null: raw points; the digit of point i is oct[i * oct_stride]
+  uint32_t oct_stride = 1;
+  const uint32_t* cx = nullptr;
+  const uint32_t* cy = nullptr;
+  const uint32_t* cz = nullptr;
+};
 // keys32: store the first 10 levels only as u32 (key >> 33); stride > 1: strided sample of the input.
 void pcv_launch_chain_keys(pcv_ctx* ctx, const PcvLevels& lv, uint64_t n, uint64_t stride, const double* x,
-                           const double* y, const double* z, void* keys, bool keys32);
+                           const double* y, const double* z, void* keys, bool keys32, const PcvRouted& routed = PcvRouted());
 void pcv_launch_depth_probe(pcv_ctx* ctx, const uint64_t* sorted, uint32_t n, uint32_t gap, uint32_t* out);
 
 // pcv_sort.hip — stable LSD radix sort, 8-bit digits, reduce-then-scan with LDS histograms.
@@ -202,8 +212,9 @@ struct PcvWalkTables {
 };
 // record = rank (u32) + payload uint4 {code x, code y, code z, rgba} [+ planes: intensity bits, Float64 high words]
 void pcv_launch_leaf_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvWalkTables& wt, uint64_t n, const double* x,
-                            const double* y, const double* z, const uint8_t* color, uint32_t color_stride,
-                            const float* intensity, uint32_t* rank, void* payload /* uint4[n] */, uint32_t* cx_hi,
+                            const double* y, const double* z, const PcvRouted& routed, const uint8_t* color,
+                            uint32_t color_stride, const float* intensity, uint32_t* rank, void* payload /* uint4[n] */,
+                            uint32_t* cx_hi,
                             uint32_t* cy_hi, uint32_t* cz_hi, uint32_t* inten_bits);
 
 // Everything K6 needs about a node in one 80-byte record, so a slot's dependent loads are rank -> record (-> the

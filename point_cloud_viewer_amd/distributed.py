@@ -116,16 +116,20 @@ class HipBackend:
         """(max_level, edges, encodings) of the global cube (PositionEncoding::new codec.rs:31-40)."""
         return _oct.level_table(bbox.min, bbox.max, resolution)
 
-    def buckets(self, resolution, bbox, x, y, z):
-        """(bucket per point, 64 counts): one HIP kernel (two chain levels + wave-aggregated histogram)."""
-        return self.ctx.route_buckets(resolution, bbox, x, y, z)
+    def buckets(self, resolution, bbox, x, y, z, rgb=None, with_state=False):
+        """(bucket per point, 64 counts[, level-1 chain state]): one HIP kernel (two chain levels + wave-aggregated
+        histogram; the state is four 4-byte planes: the Float32 level-1 codes and octant digit | rgb)."""
+        return self.ctx.route_buckets(resolution, bbox, x, y, z, rgb, with_state)
 
-    def partition(self, bucket, rank_of_bucket, x, y, z, rgb, intensity, dsts):
+    def partition(self, bucket, rank_of_bucket, planes, dsts):
         """Stable partition of the planes by owner straight into the destination views (count / scan / scatter)."""
-        self.ctx.partition_by_owner(bucket, x, y, z, rgb, intensity, dsts, rank_of_bucket)
+        self.ctx.partition_by_owner(bucket, planes, dsts, rank_of_bucket)
 
     def build_begin(self, resolution, bbox, x, y, z, rgb, intensity, max_points_per_node, force_split_level1):
         return self.ctx.build_begin(resolution, bbox, x, y, z, rgb, intensity, max_points_per_node, force_split_level1)
+
+    def build_begin_routed(self, resolution, bbox, state, intensity, max_points_per_node, force_split_level1):
+        return self.ctx.build_begin_routed(resolution, bbox, state, intensity, max_points_per_node, force_split_level1)
 
 
 class ShardedOctree:
@@ -214,10 +218,13 @@ class ShardedOctree:
 
 
 class ShardedOctreeBuilder:
-    def __init__(self, ctx, dist, device, backend=None):
+    def __init__(self, ctx, dist, device, backend=None, compress_exchange=True):
         import torch
         self.torch = torch
         self.dist = dist
+        # ship the level-1 chain state (Float32 codes + octant digit | rgb: four 4-byte planes, 16 B) instead of raw f64
+        # coordinates + rgb (27 B) whenever level 1 of the global cube is Float32-encoded; bit-identical either way
+        self.compress_exchange = compress_exchange
         self.device = device
         self.rank = dist.get_rank()
         self.world = dist.get_world_size()
@@ -245,9 +252,10 @@ class ShardedOctreeBuilder:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return t.cpu().numpy()
 
-    def _route(self, bucket, rank_of_bucket, send_counts, x, y, z, rgb, intensity):
+    def _route(self, bucket, rank_of_bucket, send_counts, planes):
         """Partition by owner and exchange: rows for rank r go to a send buffer, own rows directly into the receive
-        buffer; ONE grouped send/recv round moves everything else (RCCL: one ncclGroup == one all-to-all(v))."""
+        buffer; ONE grouped send/recv round moves everything else (RCCL: one ncclGroup == one all-to-all(v)).
+        planes: dict name -> row-aligned tensor; returns the received planes under the same names."""
         torch, dist = self.torch, self.dist
         world, rank = self.world, self.rank
         counts = torch.tensor(send_counts, dtype=torch.int64, device=self.device)
@@ -259,24 +267,20 @@ class ShardedOctreeBuilder:
         n_local = int(sum(send_counts))
         send_off = np.concatenate([[0], np.cumsum(send_counts)]).astype(np.int64)
         recv_off = np.concatenate([[0], np.cumsum(recv_counts)]).astype(np.int64)
-        planes = {"x": x, "y": y, "z": z, "color": rgb}
-        if intensity is not None:
-            planes["intensity"] = intensity
+        names = list(planes)
 
         def empty_like_rows(p, rows):
             return torch.empty((rows,) + tuple(p.shape[1:]), dtype=p.dtype, device=p.device)
 
-        send = {k: empty_like_rows(p, n_local) for k, p in planes.items()}
-        recv = {k: empty_like_rows(p, n_recv) for k, p in planes.items()}
+        send = {k: empty_like_rows(planes[k], n_local) for k in names}
+        recv = {k: empty_like_rows(planes[k], n_recv) for k in names}
         dsts = []
         for r in range(world):
             buf, off, cnt = (recv, recv_off[rank], send_counts[rank]) if r == rank else (send, send_off[r], send_counts[r])
-            d = {k: v[off:off + cnt] for k, v in buf.items()}
-            d.setdefault("intensity", None)
-            dsts.append(d)
-        self.backend.partition(bucket, rank_of_bucket, x, y, z, rgb, intensity, dsts)
+            dsts.append([buf[k][off:off + cnt] for k in names])
+        self.backend.partition(bucket, rank_of_bucket, [planes[k] for k in names], dsts)
         ops = []
-        for k in planes:
+        for k in names:
             for peer in range(world):
                 if peer == rank:
                     continue
@@ -306,17 +310,29 @@ class ShardedOctreeBuilder:
         max_level, edges, encodings = self.backend.level_table(resolution, bbox)
         can_split = max_level >= 2 and edges[1] > resolution
         # 1. buckets + global plan
-        bucket, counts = self.backend.buckets(resolution, bbox, x, y, z)
+        compressed = bool(self.compress_exchange and max_level >= 1 and int(encodings[1]) == 3)  # Float32 level 1
+        if compressed:
+            bucket, counts, state = self.backend.buckets(resolution, bbox, x, y, z, rgb, True)
+            planes = dict(state)
+        else:
+            bucket, counts = self.backend.buckets(resolution, bbox, x, y, z)
+            planes = {"x": x, "y": y, "z": z, "color": rgb}
+        if intensity is not None:
+            planes["intensity"] = intensity
         global_counts = self._sum_i64(counts)
         rank_of_bucket, split_mask = plan_buckets(global_counts, world, cap, can_split)
         send_counts = np.bincount(rank_of_bucket, weights=counts, minlength=world).astype(np.int64).tolist()
         # 2. the exchange
-        recv, matrix = self._route(bucket, rank_of_bucket, send_counts, x, y, z, rgb, intensity)
-        del bucket
+        recv, matrix = self._route(bucket, rank_of_bucket, send_counts, planes)
+        del bucket, planes
         mark()
         # 3. local topology, then the global streams of the top of the tree
-        pending = self.backend.build_begin(resolution, bbox, recv["x"], recv["y"], recv["z"], recv["color"],
-                                           recv.get("intensity"), cap, split_mask)
+        if compressed:
+            pending = self.backend.build_begin_routed(resolution, bbox, {k: recv[k] for k in ("cx", "cy", "cz", "oct_rgb")},
+                                                      recv.get("intensity"), cap, split_mask)
+        else:
+            pending = self.backend.build_begin(resolution, bbox, recv["x"], recv["y"], recv["z"], recv["color"],
+                                               recv.get("intensity"), cap, split_mask)
         l1, l2, _ = pending.top_streams()
         for c in range(8):
             if (split_mask >> c) & 1:

@@ -240,32 +240,57 @@ class Context:
                                                    int(samples_per_divisor), C.byref(bad)))
         return bad.value
 
-    def route_buckets(self, resolution, bounding_box, x, y, z):
-        """(bucket int32 tensor, 64 counts) for device-resident points: bucket = 8 * level-1 digit + level-2 digit."""
+    def route_buckets(self, resolution, bounding_box, x, y, z, color=None, with_state=False):
+        """(bucket int32 tensor, 64 counts[, state]) for device-resident points: bucket = 8 * level-1 digit + level-2
+        digit. with_state (needs color) also returns the level-1 chain state dict(cx, cy, cz = Float32 bits of the
+        level-1 codes, oct_rgb = digit | r << 8 | g << 16 | b << 24), all int32 tensors."""
         import torch
-        p, keep = self._points(x, y, z)
+        p, keep = self._points(x, y, z, color if with_state else None)
         if p.mem != L.MEM_DEVICE:
             raise ValueError("route_buckets needs device tensors")
         pr = self._params(resolution, bounding_box.min, bounding_box.max)
         bucket = torch.empty(p.n, dtype=torch.int32, device=x.device)
         counts = (C.c_uint64 * 64)()
-        self._check(self.lib.pcv_route_buckets(self.handle, C.byref(pr), C.byref(p), bucket.data_ptr(), counts))
-        return bucket, np.array(counts[:], dtype=np.int64)
+        st, state = None, None
+        if with_state:
+            state = {k: torch.empty(p.n, dtype=torch.int32, device=x.device) for k in ("cx", "cy", "cz", "oct_rgb")}
+            st = L.RouteState(state["cx"].data_ptr(), state["cy"].data_ptr(), state["cz"].data_ptr(), state["oct_rgb"].data_ptr())
+        self._check(self.lib.pcv_route_buckets(self.handle, C.byref(pr), C.byref(p), bucket.data_ptr(), counts,
+                                               C.byref(st) if st is not None else None))
+        counts = np.array(counts[:], dtype=np.int64)
+        return (bucket, counts, state) if with_state else (bucket, counts)
 
-    def partition_by_owner(self, owner, x, y, z, color, intensity, dsts, rank_of_bucket=None):
-        """Stable partition of device planes by owner. dsts: per owner a dict(x=, y=, z=, color=, intensity=) of
-        device tensors (views into send / receive buffers) that receive that owner's rows in input order. With
-        rank_of_bucket (64 entries) `owner` holds buckets and the table maps them to ranks."""
-        p, keep = self._points(x, y, z, color, intensity)
-        arr = (L.RouteDst * len(dsts))()
-        for k, d in enumerate(dsts):
-            arr[k].x, arr[k].y, arr[k].z = d["x"].data_ptr(), d["y"].data_ptr(), d["z"].data_ptr()
-            arr[k].color = d["color"].data_ptr()
-            arr[k].intensity = d["intensity"].data_ptr() if d.get("intensity") is not None else None
-        table = None
-        if rank_of_bucket is not None:
-            table = (C.c_uint8 * 64)(*[int(v) for v in rank_of_bucket])
-        self._check(self.lib.pcv_partition_by_owner(self.handle, C.byref(p), owner.data_ptr(), len(dsts), arr, table))
+    def partition_by_owner(self, owner, planes, dsts, rank_of_bucket=None):
+        """Stable partition of row-aligned device planes by owner. planes: list of tensors with the same number of rows;
+        dsts[r][p]: tensor (view into a send / receive buffer) that receives rank r's rows of plane p in input order.
+        With rank_of_bucket (64 entries) `owner` holds buckets and the table maps them to ranks."""
+        n = int(planes[0].shape[0])
+        world, npl = len(dsts), len(planes)
+        arr = (L.Plane * npl)()
+        for k, t in enumerate(planes):
+            if not t.is_contiguous() or int(t.shape[0]) != n:
+                raise ValueError("planes must be contiguous and row-aligned")
+            arr[k].src = t.data_ptr()
+            arr[k].elem_bytes = t.element_size() * (int(t.numel()) // n if n else 1)
+        dst = (C.c_void_p * (world * npl))()
+        for r, row in enumerate(dsts):
+            for k, t in enumerate(row):
+                dst[r * npl + k] = t.data_ptr()
+        table = (C.c_uint8 * 64)(*[int(v) for v in rank_of_bucket]) if rank_of_bucket is not None else None
+        self._check(self.lib.pcv_partition_by_owner(self.handle, n, owner.data_ptr(), world, table, npl, arr, dst))
+
+    def build_begin_routed(self, resolution, bounding_box, state, intensity=None, max_points_per_node=0,
+                           force_split_level1=0):
+        """build_begin for points that arrive as their level-1 chain state (route_buckets(with_state=True))."""
+        rp = L.RoutedPoints()
+        rp.n = int(state["oct_rgb"].shape[0])
+        rp.cx, rp.cy, rp.cz, rp.oct_rgb = (state[k].data_ptr() for k in ("cx", "cy", "cz", "oct_rgb"))
+        rp.intensity = intensity.data_ptr() if intensity is not None else None
+        flags = (int(force_split_level1) & 0xFF) << 8
+        pr = self._params(resolution, bounding_box.min, bounding_box.max, max_points_per_node, flags)
+        h = C.c_void_p()
+        self._check(self.lib.pcv_build_begin_routed(self.handle, C.byref(pr), C.byref(rp), C.byref(h)))
+        return PendingBuild(self, h, (state, intensity))
 
     def build_begin(self, resolution, bounding_box, x, y, z, color, intensity=None, max_points_per_node=0,
                     force_split_level1=0):

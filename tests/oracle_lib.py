@@ -213,19 +213,40 @@ def build_closed(resolution, bmin, bmax, x, y, z, rgb, intensity=None, threads=1
     return Octree(h)
 
 
-def build_closed_shard(resolution, bmin, bmax, x, y, z, rgb, intensity=None, threads=1, force_mask=0, layout=None):
+def chain_state1(bmin, bmax, resolution, x, y, z):
+    """Level-1 chain state of raw points: (octant uint8, cx, cy, cz uint32 raw level-1 codes)."""
+    x, y, z = (np.ascontiguousarray(a, dtype=np.float64) for a in (x, y, z))
+    bmin, bmax = _vec3(bmin), _vec3(bmax)
+    oct_ = np.zeros(x.size, dtype=np.uint8)
+    c = [np.zeros(x.size, dtype=np.uint32) for _ in range(3)]
+    f = lib().pcvo_chain_state1
+    f.restype = None
+    f.argtypes = [_dp, _dp, C.c_double, C.c_uint64, _dp, _dp, _dp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    f(_d(bmin), _d(bmax), resolution, x.size, _d(x), _d(y), _d(z), oct_.ctypes.data, c[0].ctypes.data, c[1].ctypes.data,
+      c[2].ctypes.data)
+    return oct_, c[0], c[1], c[2]
+
+
+def build_closed_shard(resolution, bmin, bmax, x, y, z, rgb, intensity=None, threads=1, force_mask=0, layout=None,
+                       routed=None):
     """One rank's share of a multi-rank build. Returns (Octree, streams[73]) — streams = 8 level-1 + 64 level-2 stream
     lengths + the local level-1 split mask. layout = array of 1 + 8 + 8 + 64 u64 (root_points, l1_stream, l1_offset,
     l2_offset) or None."""
+    ro = None
+    if routed is not None:  # (octant, cx, cy, cz) instead of coordinates
+        ro = [np.ascontiguousarray(routed[0], dtype=np.uint8)] + [np.ascontiguousarray(a, dtype=np.uint32) for a in routed[1:]]
+        x = y = z = np.zeros(ro[0].size)
     x, y, z, rgb, intensity, ip = _pts(x, y, z, rgb, intensity)
     bmin, bmax = _vec3(bmin), _vec3(bmax)
     streams = np.zeros(73, dtype=np.uint64)
     lay = None if layout is None else np.ascontiguousarray(layout, dtype=np.uint64)
     f = lib().pcvo_build_closed_shard
     f.restype = C.c_void_p
-    f.argtypes = [C.c_double, _dp, _dp, C.c_uint64, _dp, _dp, _dp, _u8p, _fp, C.c_int, C.c_uint, C.c_void_p, C.c_void_p]
+    f.argtypes = [C.c_double, _dp, _dp, C.c_uint64, _dp, _dp, _dp, _u8p, _fp, C.c_int, C.c_uint, C.c_void_p, C.c_void_p,
+                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rp = [None] * 4 if ro is None else [a.ctypes.data for a in ro]
     h = f(resolution, _d(bmin), _d(bmax), x.size, _d(x), _d(y), _d(z), rgb.ctypes.data_as(_u8p), ip, threads,
-          int(force_mask), None if lay is None else lay.ctypes.data, streams.ctypes.data)
+          int(force_mask), None if lay is None else lay.ctypes.data, streams.ctypes.data, *rp)
     return Octree(h), streams
 
 

@@ -53,12 +53,19 @@ class _HostTree:
 
 
 class _HostPending:
-    def __init__(self, O, cap, args, force_mask):
-        self.O, self.cap, self.args, self.force_mask = O, cap, args, force_mask
+    def __init__(self, O, cap, args, force_mask, routed=None):
+        self.O, self.cap, self.args, self.force_mask, self.routed = O, cap, args, force_mask, routed
 
     def _run(self, layout):
         resolution, bbox, x, y, z, rgb, intensity = self.args
         with self.O.max_points_per_node(self.cap):
+            if self.routed is not None:
+                packed = self.routed["oct_rgb"].numpy().view(np.uint32)
+                ro = [(packed & 7).astype(np.uint8)] + [self.routed[k].numpy().view(np.uint32) for k in ("cx", "cy", "cz")]
+                rgb = np.stack([(packed >> 8) & 255, (packed >> 16) & 255, packed >> 24], axis=1).astype(np.uint8)
+                return self.O.build_closed_shard(resolution, bbox.min, bbox.max, None, None, None, rgb,
+                                                 None if intensity is None else intensity.numpy(),
+                                                 force_mask=self.force_mask, layout=layout, routed=ro)
             return self.O.build_closed_shard(resolution, bbox.min, bbox.max, x.numpy(), y.numpy(), z.numpy(), rgb.numpy(),
                                              None if intensity is None else intensity.numpy(),
                                              force_mask=self.force_mask, layout=layout)
@@ -83,28 +90,37 @@ class HostBackend:
     def level_table(self, resolution, bbox):
         return self.O.level_table(bbox.min, bbox.max, resolution)
 
-    def buckets(self, resolution, bbox, x, y, z):
+    def buckets(self, resolution, bbox, x, y, z, rgb=None, with_state=False):
         keys = self.O.chain_keys64(bbox.min, bbox.max, resolution, 2, x.numpy(), y.numpy(), z.numpy())
         bucket = torch.from_numpy((keys >> np.uint64(57)).astype(np.int64) & 63)
-        return bucket, np.bincount(bucket.numpy(), minlength=64).astype(np.int64)
+        counts = np.bincount(bucket.numpy(), minlength=64).astype(np.int64)
+        if not with_state:
+            return bucket, counts
+        o, cx, cy, cz = self.O.chain_state1(bbox.min, bbox.max, resolution, x.numpy(), y.numpy(), z.numpy())
+        c = rgb.numpy().astype(np.uint32)
+        packed = o.astype(np.uint32) | (c[:, 0] << 8) | (c[:, 1] << 16) | (c[:, 2] << 24)
+        state = dict(cx=torch.from_numpy(cx.view(np.int32)), cy=torch.from_numpy(cy.view(np.int32)),
+                     cz=torch.from_numpy(cz.view(np.int32)), oct_rgb=torch.from_numpy(packed.view(np.int32)))
+        return bucket, counts, state
 
-    def partition(self, bucket, rank_of_bucket, x, y, z, rgb, intensity, dsts):
+    def partition(self, bucket, rank_of_bucket, planes, dsts):
         owner = torch.from_numpy(np.asarray(rank_of_bucket, dtype=np.int64))[bucket]
-        for k, d in enumerate(dsts):
+        for k, row in enumerate(dsts):
             sel = owner == k  # boolean-mask selection keeps input order
-            d["x"].copy_(x[sel])
-            d["y"].copy_(y[sel])
-            d["z"].copy_(z[sel])
-            d["color"].copy_(rgb[sel])
-            if intensity is not None:
-                d["intensity"].copy_(intensity[sel])
+            for src, dst in zip(planes, row):
+                dst.copy_(src[sel])
 
     def build_begin(self, resolution, bbox, x, y, z, rgb, intensity, max_points_per_node, force_split_level1):
         assert max_points_per_node == self.cap
         return _HostPending(self.O, self.cap, (resolution, bbox, x, y, z, rgb, intensity), force_split_level1)
 
+    def build_begin_routed(self, resolution, bbox, state, intensity, max_points_per_node, force_split_level1):
+        assert max_points_per_node == self.cap
+        return _HostPending(self.O, self.cap, (resolution, bbox, None, None, None, None, intensity), force_split_level1,
+                            routed=state)
 
-def _worker(rank, world, port, n, cap, with_intensity, out_path):
+
+def _worker(rank, world, port, n, cap, with_intensity, out_path, compress=True):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     import torch.distributed as dist
@@ -125,7 +141,7 @@ def _worker(rank, world, port, n, cap, with_intensity, out_path):
     tx, ty, tz = (torch.from_numpy(np.ascontiguousarray(a[sl])) for a in (x, y, z))
     trgb = torch.from_numpy(np.ascontiguousarray(rgb[sl]))
     tint = torch.from_numpy(np.ascontiguousarray(inten[sl])) if with_intensity else None
-    b = pdist.ShardedOctreeBuilder(None, dist, torch.device("cpu"), backend=HostBackend(O, cap))
+    b = pdist.ShardedOctreeBuilder(None, dist, torch.device("cpu"), backend=HostBackend(O, cap), compress_exchange=compress)
     bbox = b.global_bbox(tx, ty, tz)
     assert np.array_equal(bbox.min, bmin) and np.array_equal(bbox.max, bmax)
     res = b.build(0.001, bbox, tx, ty, tz, trgb, tint, max_points_per_node=cap)
@@ -151,10 +167,12 @@ def _worker(rank, world, port, n, cap, with_intensity, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,with_intensity", [(2, False), (2, True), (4, False)])
-def test_sharded_build_equals_single_build(tmp_path, world, with_intensity):
+@pytest.mark.parametrize("world,with_intensity,compress", [(2, False, True), (2, True, True), (4, False, True),
+                                                            (2, True, False)])
+def test_sharded_build_equals_single_build(tmp_path, world, with_intensity, compress):
+    """compress: the exchange carries the level-1 chain state (octant + Float32 codes) instead of raw f64 coordinates."""
     out = tmp_path / "result.txt"
-    mp.spawn(_worker, args=(world, _free_port(), 40_000, 700, with_intensity, str(out)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), 40_000, 700, with_intensity, str(out), compress), nprocs=world, join=True)
     assert out.read_text() == "OK", out.read_text()
 
 

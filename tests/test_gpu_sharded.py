@@ -57,27 +57,33 @@ def test_route_buckets_and_partition_kernels():
     bbox = pcv.Aabb(bmin, bmax)
     tx, ty, tz = (torch.from_numpy(a).cuda() for a in (x, y, z))
     trgb, tint = torch.from_numpy(rgb).cuda(), torch.from_numpy(inten).cuda()
-    bucket, counts = ctx.route_buckets(0.001, bbox, tx, ty, tz)
+    bucket, counts, state = ctx.route_buckets(0.001, bbox, tx, ty, tz, trgb, with_state=True)
     keys = O.chain_keys64(bmin, bmax, 0.001, 2, x, y, z)
     want = ((keys >> np.uint64(57)).astype(np.int64) & 63)
     assert np.array_equal(bucket.cpu().numpy(), want)
     assert np.array_equal(counts, np.bincount(want, minlength=64))
+    # the level-1 chain state that crosses the exchange: octant digit + raw Float32 codes
+    o, cx, cy, cz = O.chain_state1(bmin, bmax, 0.001, x, y, z)
+    c = rgb.astype(np.uint32)
+    assert np.array_equal(state["oct_rgb"].cpu().numpy().view(np.uint32), o | (c[:, 0] << 8) | (c[:, 1] << 16) | (c[:, 2] << 24))
+    for got, ref in ((state["cx"], cx), (state["cy"], cy), (state["cz"], cz)):
+        assert np.array_equal(got.cpu().numpy().view(np.uint32), ref)
+    planes = [tx, ty, tz, trgb, tint, state["oct_rgb"].view(torch.uint8)[::4].contiguous(), state["cx"]]
     for world in (1, 3, 8):
         rank_of, _ = pdist.plan_buckets(counts, world, 5000, True)
         owner = rank_of[want].astype(np.int64)
         cnt = np.bincount(owner, minlength=world)
-        dsts = [dict(x=torch.empty(c, dtype=torch.float64, device="cuda"), y=torch.empty(c, dtype=torch.float64, device="cuda"),
-                     z=torch.empty(c, dtype=torch.float64, device="cuda"), color=torch.empty((c, 3), dtype=torch.uint8, device="cuda"),
-                     intensity=torch.empty(c, dtype=torch.float32, device="cuda")) for c in cnt]
-        ctx.partition_by_owner(bucket, tx, ty, tz, trgb, tint, dsts, rank_of)
+        dsts = [[torch.empty((int(c),) + tuple(p.shape[1:]), dtype=p.dtype, device="cuda") for p in planes] for c in cnt]
+        ctx.partition_by_owner(bucket, planes, dsts, rank_of)
         for d in range(world):
             sel = torch.from_numpy(owner == d).cuda()
-            assert torch.equal(dsts[d]["x"], tx[sel]) and torch.equal(dsts[d]["y"], ty[sel]) and torch.equal(dsts[d]["z"], tz[sel])
-            assert torch.equal(dsts[d]["color"], trgb[sel]) and torch.equal(dsts[d]["intensity"], tint[sel])  # stable
+            for p, got in zip(planes, dsts[d]):
+                assert torch.equal(got, p[sel])  # stable, every plane (8-, 3-, 4- and 1-byte rows)
 
 
-@pytest.mark.parametrize("world,cap,with_intensity", [(2, 0, False), (4, 20_000, True), (8, 3_000, False)])
-def test_virtual_ranks_on_one_gpu(world, cap, with_intensity, tmp_path):
+@pytest.mark.parametrize("world,cap,with_intensity,compress", [(2, 0, False, True), (4, 20_000, True, True),
+                                                                (8, 3_000, False, True), (4, 20_000, True, False)])
+def test_virtual_ranks_on_one_gpu(world, cap, with_intensity, compress, tmp_path):
     """The real ShardedOctreeBuilder + HipBackend, N virtual ranks as threads on one GPU (tests/thread_dist.py)."""
     import torch
     from thread_dist import run_ranks
@@ -99,7 +105,7 @@ def test_virtual_ranks_on_one_gpu(world, cap, with_intensity, tmp_path):
         tx, ty, tz = (torch.from_numpy(np.ascontiguousarray(a[sl])).cuda() for a in (x, y, z))
         trgb = torch.from_numpy(np.ascontiguousarray(rgb[sl])).cuda()
         tint = torch.from_numpy(np.ascontiguousarray(inten[sl])).cuda() if with_intensity else None
-        b = pdist.ShardedOctreeBuilder(ctx, dist, dev)
+        b = pdist.ShardedOctreeBuilder(ctx, dist, dev, compress_exchange=compress)
         bbox = b.global_bbox(tx, ty, tz)
         assert np.array_equal(bbox.min, bmin) and np.array_equal(bbox.max, bmax)
         res = b.build(0.001, bbox, tx, ty, tz, trgb, tint, max_points_per_node=cap)
