@@ -346,7 +346,7 @@ struct RecPtrs {
 };
 
 template <bool kHasVec>
-__global__ __launch_bounds__(kBlock, 4) void downsweep_rec_kernel(const uint32_t* __restrict__ keys_in,
+__global__ __launch_bounds__(kBlock, kHasVec ? 3 : 4) void downsweep_rec_kernel(const uint32_t* __restrict__ keys_in,
                                                                   uint32_t* __restrict__ keys_out, uint64_t n,
                                                                   uint64_t chunk, int groups, int shift, int nbits,
                                                                   const uint32_t* __restrict__ offsets,
