@@ -252,3 +252,18 @@ def test_build_octree_from_file(ctx, tmp_path):
     bmin, bmax = O.aabb(px, py, pz)
     O.build_literal_dir(tmp_path / "cpu", 0.001, bmin, bmax, px, py, pz, rgb, inten, threads=4)
     assert not O.compare_octrees(O.load_dir(tmp_path / "gpu"), O.load_dir(tmp_path / "cpu"))
+
+
+def test_golden_fixtures(ctx):
+    """HIP build against the frozen fixtures of tests/golden/ (node table + SHA-256 of every node file)."""
+    import importlib.util
+    import json
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(here, "golden", "make_golden.py"))
+    G = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(G)
+    golden = json.load(open(os.path.join(here, "golden", "build_golden.json")))
+    for case in G.CASES:
+        x, y, z, rgb, inten, bmin, bmax, res, cap = G.make_case(case)
+        got = ctx.build(res, pcv.Aabb(bmin, bmax), x, y, z, rgb, inten, max_points_per_node=cap).to_dict()
+        assert G.digest(got) == golden[case[0]]["nodes"], case[0]
