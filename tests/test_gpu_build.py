@@ -254,6 +254,40 @@ def test_build_octree_from_file(ctx, tmp_path):
     assert not O.compare_octrees(O.load_dir(tmp_path / "gpu"), O.load_dir(tmp_path / "cpu"))
 
 
+def test_copy_node_and_write_nodes(ctx, tmp_path):
+    """pcv_octree_copy_node (device blob -> host / device buffer) and pcv_octree_write_nodes + pcv_write_meta, the pieces
+    the multi-GPU output is assembled from, on a single tree: together they must reproduce pcv_octree_write_dir."""
+    import torch
+    x, y, z, rgb, bmin, bmax = synthetic.gaussian_clusters(80_000, seed=13, num_clusters=4, extent=30.0, sigma_range=(0.05, 2.0))
+    inten = (np.arange(x.size) % 311).astype(np.float32)
+    t = ctx.build(0.001, pcv.Aabb(bmin, bmax), x, y, z, rgb, inten, max_points_per_node=2000)
+    nodes = t.to_dict()
+    for i in range(0, t.num_nodes, 7):
+        nd = t.node(i)
+        name = pcv.node_name(nd.id_high, nd.id_low)
+        for which, key in enumerate(("xyz", "rgb", "intensity")):
+            want = nodes[name][key]
+            host = np.zeros(len(want) + 5, dtype=np.uint8)
+            t.copy_node_into(i, which, host)
+            assert host[:len(want)].tobytes() == want and not host[len(want):].any()
+            dev = torch.zeros(len(want), dtype=torch.uint8, device="cuda")
+            t.copy_node_into(i, which, dev)
+            assert dev.cpu().numpy().tobytes() == want
+    with pytest.raises(pcv.PcvError):
+        t.copy_node_into(0, 0, np.zeros(1, dtype=np.uint8))  # too small
+    # write_nodes(level >= 1) + the root by hand + write_meta == write_dir
+    a, b = tmp_path / "whole", tmp_path / "pieces"
+    t.write_dir(str(a))
+    t.write_nodes(str(b), 1)
+    for ext in ("xyz", "rgb", "intensity"):
+        (b / f"r.{ext}").write_bytes(nodes["r"][ext])
+    table = [(t.node(i).id_high, t.node(i).id_low, t.node(i).num_points, t.node(i).encoding) for i in range(t.num_nodes)]
+    pcv.octree.write_meta(str(b), 0.001, bmin, bmax, table)
+    assert sorted(p.name for p in a.iterdir()) == sorted(p.name for p in b.iterdir())
+    for p in a.iterdir():
+        assert p.read_bytes() == (b / p.name).read_bytes(), p.name
+
+
 def test_golden_fixtures(ctx):
     """HIP build against the frozen fixtures of tests/golden/ (node table + SHA-256 of every node file)."""
     import importlib.util

@@ -90,6 +90,21 @@ def test_sort_keys64(ctx):
     assert np.array_equal(got, keys[np.argsort(m, kind="stable")])
 
 
+def test_sort_keys32(ctx):
+    """The 32-bit key sort the build uses when ten levels suffice: skewed digits (few distinct values in the upper
+    bytes, like path keys), ragged sizes, partial bit ranges."""
+    rng = np.random.default_rng(4)
+    for n in (0, 1, 63, 4095, 4097, 99_999, 2_000_003):
+        hi = rng.integers(0, 24, n, dtype=np.uint64) << np.uint64(24)  # 24 populated top buckets
+        keys = (hi | rng.integers(0, 2 ** 24, n, dtype=np.uint64)).astype(np.uint32)
+        if n > 100:
+            keys[::5] = keys[7]
+        assert np.array_equal(ctx.sort_keys32(keys.copy(), 0, 30), np.sort(keys)), n
+    keys = rng.integers(0, 2 ** 30, 300_000, dtype=np.uint64).astype(np.uint32)
+    got = ctx.sort_keys32(keys.copy(), 6, 30)  # the build sorts bits [3 * (10 - levels), 30)
+    assert np.array_equal(got, keys[np.argsort(keys >> np.uint32(6), kind="stable")])
+
+
 def test_sort_pairs32_is_stable(ctx):
     rng = np.random.default_rng(2)
     for n, bits in ((1, 1), (1000, 3), (123_457, 11), (1_000_000, 14), (300_000, 32)):
