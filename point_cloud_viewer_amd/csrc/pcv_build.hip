@@ -267,6 +267,8 @@ int pcv_make_levels(const double bmin[3], const double bmax[3], double resolutio
       lv->edge[j] = e[j];
       // IEEE division on the host: correctly rounded reciprocal; 0 = "use plain division" (pcv_div_const)
       lv->inv_edge[j] = (e[j] >= 0x1p-100 && e[j] <= 0x1p+100) ? 1.0 / e[j] : 0.0;
+      // low word of the double-double reciprocal: (1 - e * yh) is exact in one FMA, divided by e and rounded
+      lv->inv_edge_lo[j] = lv->inv_edge[j] != 0.0 ? std::fma(-e[j], lv->inv_edge[j], 1.0) / e[j] : 0.0;
       lv->enc[j] = (uint8_t)c[j];
       tame = tame && lv->inv_edge[j] != 0.0;
     }
@@ -939,10 +941,10 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
     nr.enc = lv.enc[u_level[i]];
     nr.edge = lv.edge[u_level[i]];
     nr.inv_edge = lv.inv_edge[u_level[i]];
+    nr.inv_edge_lo = lv.inv_edge_lo[u_level[i]];
     nr.xyz_off = u_xyz_off[i];
     nr.point_off = u_point_off[i];
     for (int a = 0; a < 3; ++a) nr.mn[a] = u_node_min[3 * (size_t)i + a];
-    nr.pad = 0;
   }
   for (uint32_t r = 0; r < num_leaves; ++r) u_leaf_rec[r] = u_node_rec[leaves[r]];
   const size_t walk_bytes = ((size_t)M * 8 + 255) & ~(size_t)255;

@@ -116,12 +116,12 @@ __global__ __launch_bounds__(256) void chain_keys_kernel(PcvLevels lv, uint64_t 
   uint64_t key = (uint64_t)d1 << (3 * (PCV_MAX_KEY_LEVELS - 1));
   if (lv.fast_ok && pcv_point_is_tame(px, py, pz)) {
     for (int k = k0; k <= lv.nlevels; ++k) {
-      const uint32_t d = pcv_chain_level<false>(lv.enc[k], lv.edge[k - 1], lv.edge[k], lv.inv_edge[k], px, py, pz, mx, my, mz, cx, cy, cz);
+      const uint32_t d = pcv_chain_level<false>(lv.enc[k], lv.edge[k - 1], lv.edge[k], PcvRecip{lv.inv_edge[k], lv.inv_edge_lo[k]}, px, py, pz, mx, my, mz, cx, cy, cz);
       key |= (uint64_t)d << (3 * (PCV_MAX_KEY_LEVELS - k));
     }
   } else {
     for (int k = k0; k <= lv.nlevels; ++k) {
-      const uint32_t d = pcv_chain_level<true>(lv.enc[k], lv.edge[k - 1], lv.edge[k], lv.inv_edge[k], px, py, pz, mx, my, mz, cx, cy, cz);
+      const uint32_t d = pcv_chain_level<true>(lv.enc[k], lv.edge[k - 1], lv.edge[k], PcvRecip{lv.inv_edge[k], lv.inv_edge_lo[k]}, px, py, pz, mx, my, mz, cx, cy, cz);
       key |= (uint64_t)d << (3 * (PCV_MAX_KEY_LEVELS - k));
     }
   }
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void route_bucket_kernel(PcvLevels lv, uint64_
       double mx = lv.root_min[0], my = lv.root_min[1], mz = lv.root_min[2];
       double cx, cy, cz;
       for (int k = 1; k <= lv.nlevels; ++k) {  // nlevels <= 2 here; always the guarded (exact for any input) variant
-        b = (b << 3) | pcv_chain_level<true>(lv.enc[k], lv.edge[k - 1], lv.edge[k], lv.inv_edge[k], px, py, pz, mx, my, mz, cx, cy, cz);
+        b = (b << 3) | pcv_chain_level<true>(lv.enc[k], lv.edge[k - 1], lv.edge[k], PcvRecip{lv.inv_edge[k], lv.inv_edge_lo[k]}, px, py, pz, mx, my, mz, cx, cy, cz);
         if (k == 1 && st_orgb) {  // the level-1 state that crosses the exchange instead of the raw coordinates
           const uint8_t* c = color + i * color_stride;
           st_orgb[i] = b | ((uint32_t)c[0] << 8) | ((uint32_t)c[1] << 16) | ((uint32_t)c[2] << 24);
@@ -344,12 +344,13 @@ __global__ __launch_bounds__(256) void selftest_division_kernel(const double* __
   unsigned long long bad = 0;
   if (gid < 65536) {
     const double v = (double)(uint32_t)gid;
-    bad += __double_as_longlong(pcv_div_code(v, 65535.0, 1.0 / 65535.0)) != __double_as_longlong(v / 65535.0);
-    if (gid < 256) bad += __double_as_longlong(pcv_div_code(v, 255.0, 1.0 / 255.0)) != __double_as_longlong(v / 255.0);
+    bad += __double_as_longlong(pcv_div_code(v, PCV_RECIP_65535)) != __double_as_longlong(v / 65535.0);
+    if (gid < 256) bad += __double_as_longlong(pcv_div_code(v, PCV_RECIP_255)) != __double_as_longlong(v / 255.0);
   }
   const uint64_t stride = (uint64_t)gridDim.x * 256;
   for (int d = 0; d < ndiv; ++d) {
-    const double e = divisors[d], y = (e >= 0x1p-100 && e <= 0x1p+100) ? 1.0 / e : 0.0;
+    const double e = divisors[d], yh = (e >= 0x1p-100 && e <= 0x1p+100) ? 1.0 / e : 0.0;
+    const PcvRecip y{yh, yh != 0.0 ? __fma_rn(-e, yh, 1.0) / e : 0.0};  // as pcv_make_levels builds it on the host
     for (uint64_t i = gid; i < samples_per_divisor; i += stride) {
       const uint64_t h = mix64(i * 0x100000001B3ull + (uint64_t)d);
       double x;

@@ -17,25 +17,27 @@
 #include "pcv_internal.h"
 
 // Correctly rounded x / e for a divisor that is constant across the grid, without the ~12-instruction IEEE
-// division expansion: y = RN(1/e) comes from the host; q0 = RN(x*y) is within 1.5 ulp; one residual correction
-// makes q1 faithful, and for a faithful q1 with exact residual r1 = x - e*q1 (one FMA) Markstein's theorem gives
-// RN(q1 + r1*y) == RN(x/e) (Markstein 1990; Muller et al., Handbook of Floating-Point Arithmetic, "division with
-// an FMA"). The theorem needs: y correctly rounded (it is), no overflow/underflow in the residuals. Outside
-// 2^-900 <= |x| <= 2^900 (also x == 0 for the sign of zero, inf, NaN) the IEEE division is used instead.
-// `pcv_selftest_division` checks the routine bit-for-bit against IEEE division on the device.
+// division expansion. The host supplies the reciprocal as a double-double: yh = RN(1/e), yl = RN(1/e - yh).
+//   q0 = RN(x*yh + RN(x*yl))   one rounding of x * (yh + yl) up to ~2^-105 relative: a faithful quotient (< 1 ulp)
+//   r  = x - e*q0              exact (one FMA), because q0 is faithful
+//   q  = RN(q0 + r*yh)         == RN(x/e) by Markstein's theorem (Markstein 1990; Muller et al., Handbook of
+//                              Floating-Point Arithmetic, "division with an FMA"): q0 faithful, yh correctly rounded
+// Four f64 operations. The theorem needs no overflow/underflow in the residual: outside 2^-900 <= |x| <= 2^900 (also
+// x == 0 for the sign of zero, inf, NaN) and for divisors outside [2^-100, 2^100] (yh == 0 from the host) the IEEE
+// division is used instead. `pcv_selftest_division` checks the routine bit-for-bit against IEEE division on the device.
 // GUARD = false drops the range check; only valid where the caller has established that x is finite with
-// |x| <= 2^900 and y != 0, and only for the integer encodings (where a zero or tiny x gives code 0 either way).
+// |x| <= 2^900 and yh != 0, and only for the integer encodings (where a zero or tiny x gives code 0 either way).
+struct PcvRecip {
+  double hi, lo;
+};
 template <bool GUARD = true>
-__device__ __forceinline__ double pcv_div_const(double x, double e, double y) {
-  const double q0 = x * y;
-  const double r0 = __fma_rn(-e, q0, x);
-  const double q1 = __fma_rn(r0, y, q0);
-  const double r1 = __fma_rn(-e, q1, x);
-  double q = __fma_rn(r1, y, q1);
+__device__ __forceinline__ double pcv_div_const(double x, double e, PcvRecip y) {
+  const double q0 = __fma_rn(x, y.hi, x * y.lo);
+  const double r = __fma_rn(-e, q0, x);
+  double q = __fma_rn(r, y.hi, q0);
   if (!GUARD) return q;
   const double ax = fabs(x);
-  // y == 0 marks a divisor outside [2^-100, 2^100] (host side), where the residuals could leave the normal range
-  if (__builtin_expect(!(ax >= 0x1p-900 && ax <= 0x1p+900) || y == 0.0, 0)) {
+  if (__builtin_expect(!(ax >= 0x1p-900 && ax <= 0x1p+900) || y.hi == 0.0, 0)) {
     // The empty volatile asm pins the IEEE division inside this (almost never taken) branch: without it the
     // compiler if-converts the branch and executes the full division expansion for every lane.
     double xs = x;
@@ -44,21 +46,19 @@ __device__ __forceinline__ double pcv_div_const(double x, double e, double y) {
   }
   return q;
 }
-// v / maxval for an integer code v in [0, maxval], maxval = 255 or 65535: one residual correction is already
-// bit-identical to IEEE division for every code (exhaustive: tests/test_oracle_kats.py on the host with exact
-// rational FMA emulation, pcv_selftest_division on the device).
-__device__ __forceinline__ double pcv_div_code(double v, double maxval, double y) {
-  const double q0 = v * y;
-  const double r0 = __fma_rn(-maxval, q0, v);
-  return __fma_rn(r0, y, q0);
-}
+// v / maxval for an integer code v in [0, maxval], maxval = 255 or 65535: RN(v*yh + RN(v*yl)) with the double-double
+// reciprocal of maxval is bit-identical to IEEE division for every code (exhaustive: tests/test_oracle_kats.py on the
+// host with exact rational FMA emulation, pcv_selftest_division on the device). Two f64 operations.
+#define PCV_RECIP_255 PcvRecip{0x1.0101010101010p-8, 0x1.0101010101010p-64}
+#define PCV_RECIP_65535 PcvRecip{0x1.0001000100010p-16, 0x1.0001000100010p-80}
+__device__ __forceinline__ double pcv_div_code(double v, PcvRecip y) { return __fma_rn(v, y.hi, v * y.lo); }
 
 // num::clamp semantics (NaN and -0.0 pass through) — needed verbatim for the float encodings.
 __device__ __forceinline__ double pcv_clamp01(double t) { return (t < 0.0) ? 0.0 : ((t > 1.0) ? 1.0 : t); }
 
 // Rust `as u8/u16` after the clamp: NaN -> 0, truncation toward zero; t <= 1 so no upper saturation.
 template <bool GUARD = true>
-__device__ __forceinline__ uint32_t pcv_fix_encode(double p, double mn, double edge, double inv_edge, double maxval) {
+__device__ __forceinline__ uint32_t pcv_fix_encode(double p, double mn, double edge, PcvRecip inv_edge, double maxval) {
   double t = pcv_div_const<GUARD>(p - mn, edge, inv_edge);
   // maxNum(t, 0) maps NaN (t is never a signalling NaN: it is an arithmetic result), -0.0 and negatives to a zero —
   // same integer code as num::clamp + `as` cast; minNum(t, 1) is the upper clamp. Two instructions instead of six.
@@ -69,7 +69,7 @@ __device__ __forceinline__ uint32_t pcv_fix_encode(double p, double mn, double e
 
 // Raw code (integer value or IEEE bit pattern) of one coordinate.
 template <bool GUARD = true>
-__device__ __forceinline__ uint64_t pcv_encode_coord(uint32_t enc, double p, double mn, double edge, double inv_edge) {
+__device__ __forceinline__ uint64_t pcv_encode_coord(uint32_t enc, double p, double mn, double edge, PcvRecip inv_edge) {
   switch (enc) {
     case PCV_ENC_UINT8: return pcv_fix_encode<GUARD>(p, mn, edge, inv_edge, 255.0);
     case PCV_ENC_UINT16: return pcv_fix_encode<GUARD>(p, mn, edge, inv_edge, 65535.0);
@@ -83,8 +83,8 @@ __device__ __forceinline__ uint64_t pcv_encode_coord(uint32_t enc, double p, dou
 
 __device__ __forceinline__ double pcv_decode_coord(uint32_t enc, uint64_t code, double mn, double edge) {
   switch (enc) {
-    case PCV_ENC_UINT8: return __fma_rn(pcv_div_code((double)(uint32_t)code, 255.0, 1.0 / 255.0), edge, mn);
-    case PCV_ENC_UINT16: return __fma_rn(pcv_div_code((double)(uint32_t)code, 65535.0, 1.0 / 65535.0), edge, mn);
+    case PCV_ENC_UINT8: return __fma_rn(pcv_div_code((double)(uint32_t)code, PCV_RECIP_255), edge, mn);
+    case PCV_ENC_UINT16: return __fma_rn(pcv_div_code((double)(uint32_t)code, PCV_RECIP_65535), edge, mn);
     case PCV_ENC_FLOAT32: return __fma_rn((double)__uint_as_float((uint32_t)code), edge, mn);
     default: return __fma_rn(__longlong_as_double((long long)code), edge, mn);
   }
@@ -93,7 +93,7 @@ __device__ __forceinline__ double pcv_decode_coord(uint32_t enc, uint64_t code, 
 // Inside the chain the code is kept in the value domain (a double): the integer value for u8/u16, (double)(float)t
 // for Float32, t for Float64 — no int conversions per level; pcv_val_to_code makes the raw bits once at the end.
 template <int ENC, bool GUARD>
-__device__ __forceinline__ double pcv_encode_val(double p, double mn, double edge, double inv_edge) {
+__device__ __forceinline__ double pcv_encode_val(double p, double mn, double edge, PcvRecip inv_edge) {
   if (ENC == PCV_ENC_UINT8 || ENC == PCV_ENC_UINT16) {
     const double maxval = ENC == PCV_ENC_UINT8 ? 255.0 : 65535.0;
     double t = pcv_div_const<GUARD>(p - mn, edge, inv_edge);
@@ -106,8 +106,8 @@ __device__ __forceinline__ double pcv_encode_val(double p, double mn, double edg
 }
 template <int ENC>
 __device__ __forceinline__ double pcv_decode_val(double cd, double mn, double edge) {
-  if (ENC == PCV_ENC_UINT8) return __fma_rn(pcv_div_code(cd, 255.0, 1.0 / 255.0), edge, mn);
-  if (ENC == PCV_ENC_UINT16) return __fma_rn(pcv_div_code(cd, 65535.0, 1.0 / 65535.0), edge, mn);
+  if (ENC == PCV_ENC_UINT8) return __fma_rn(pcv_div_code(cd, PCV_RECIP_255), edge, mn);
+  if (ENC == PCV_ENC_UINT16) return __fma_rn(pcv_div_code(cd, PCV_RECIP_65535), edge, mn);
   return __fma_rn(cd, edge, mn);
 }
 __device__ __forceinline__ uint64_t pcv_val_to_code(uint32_t enc, double cd) {
@@ -123,7 +123,7 @@ __device__ __forceinline__ uint64_t pcv_val_to_code(uint32_t enc, double cd) {
 // moves `mn` to the child cube, replaces `p` by its encode->decode image in the child cube and reports the code
 // (value domain).
 template <int ENC, bool GUARD>
-__device__ __forceinline__ uint32_t pcv_chain_coord_t(double e_parent, double e_child, double inv_e_child, double& p,
+__device__ __forceinline__ uint32_t pcv_chain_coord_t(double e_parent, double e_child, PcvRecip inv_e_child, double& p,
                                                       double& mn, double& cd) {
   const double mx = mn + e_parent;
   const double c = (mn + mx) / 2.0;
@@ -137,7 +137,7 @@ __device__ __forceinline__ uint32_t pcv_chain_coord_t(double e_parent, double e_
 // One level for all three coordinates as a single straight-line block (the encoding switch is taken once per
 // level and is wave-uniform, so the three dependency chains interleave). Returns the octant digit.
 template <int ENC, bool GUARD>
-__device__ __forceinline__ uint32_t pcv_chain_level_t(double ep, double ec, double ic, double& px, double& py, double& pz,
+__device__ __forceinline__ uint32_t pcv_chain_level_t(double ep, double ec, PcvRecip ic, double& px, double& py, double& pz,
                                                       double& mx, double& my, double& mz, double& cx, double& cy,
                                                       double& cz) {
   const uint32_t bx = pcv_chain_coord_t<ENC, GUARD>(ep, ec, ic, px, mx, cx);
@@ -148,7 +148,7 @@ __device__ __forceinline__ uint32_t pcv_chain_level_t(double ep, double ec, doub
 // GUARD = false: the caller checked once per point that the coordinates are finite and moderate (pcv_point_is_tame)
 // and the level table is tame (PcvLevels::fast_ok); the integer-encoded levels then run without per-division checks.
 template <bool GUARD>
-__device__ __forceinline__ uint32_t pcv_chain_level(uint32_t enc, double ep, double ec, double ic, double& px, double& py,
+__device__ __forceinline__ uint32_t pcv_chain_level(uint32_t enc, double ep, double ec, PcvRecip ic, double& px, double& py,
                                                     double& pz, double& mx, double& my, double& mz, double& cx,
                                                     double& cy, double& cz) {
   switch (enc) {

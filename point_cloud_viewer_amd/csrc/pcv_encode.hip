@@ -41,14 +41,14 @@ __global__ __launch_bounds__(256) void leaf_encode_kernel(
     if (lv.fast_ok && pcv_point_is_tame(px, py, pz)) {
       do {
         ++L;
-        const uint32_t d = pcv_chain_level<false>(lv.enc[L], lv.edge[L - 1], lv.edge[L], lv.inv_edge[L], px, py, pz, mx, my, mz, vx, vy, vz);
+        const uint32_t d = pcv_chain_level<false>(lv.enc[L], lv.edge[L - 1], lv.edge[L], PcvRecip{lv.inv_edge[L], lv.inv_edge_lo[L]}, px, py, pz, mx, my, mz, vx, vy, vz);
         const uint32_t mask = (uint32_t)(rec >> 32) & 0xffu;
         rec = walk[(uint32_t)rec + __popc(mask & ((1u << d) - 1u))];
       } while (!((rec >> 40) & 1ull) && L < lv.nlevels);
     } else {
       do {
         ++L;
-        const uint32_t d = pcv_chain_level<true>(lv.enc[L], lv.edge[L - 1], lv.edge[L], lv.inv_edge[L], px, py, pz, mx, my, mz, vx, vy, vz);
+        const uint32_t d = pcv_chain_level<true>(lv.enc[L], lv.edge[L - 1], lv.edge[L], PcvRecip{lv.inv_edge[L], lv.inv_edge_lo[L]}, px, py, pz, mx, my, mz, vx, vy, vz);
         const uint32_t mask = (uint32_t)(rec >> 32) & 0xffu;
         rec = walk[(uint32_t)rec + __popc(mask & ((1u << d) - 1u))];
       } while (!((rec >> 40) & 1ull) && L < lv.nlevels);
@@ -86,7 +86,7 @@ __device__ __forceinline__ void promote_one(const PcvPromoteTables& pt, uint64_t
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       const double q = pcv_decode_coord(cur.enc, code[a], cur.mn[a], cur.edge);
-      code[a] = pcv_encode_coord(par.enc, q, par.mn[a], par.edge, par.inv_edge);
+      code[a] = pcv_encode_coord(par.enc, q, par.mn[a], par.edge, PcvRecip{par.inv_edge, par.inv_edge_lo});
     }
     j = cur.child_off + (j >> 3);
     cur = par;
@@ -97,7 +97,7 @@ __device__ __forceinline__ void promote_one(const PcvPromoteTables& pt, uint64_t
     slot = j - (j >> 3) - 1u;
 #pragma unroll
     for (int a = 0; a < 3; ++a)
-      code[a] = pcv_encode_coord(enc, pcv_decode_coord(enc, code[a], cur.mn[a], cur.edge), cur.mn[a], cur.edge, cur.inv_edge);
+      code[a] = pcv_encode_coord(enc, pcv_decode_coord(enc, code[a], cur.mn[a], cur.edge), cur.mn[a], cur.edge, PcvRecip{cur.inv_edge, cur.inv_edge_lo});
   }
   uint8_t* dst = o.xyz_blob + cur.xyz_off;
   switch (enc) {

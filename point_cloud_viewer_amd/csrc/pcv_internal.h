@@ -20,7 +20,8 @@
 struct PcvLevels {
   double root_min[3];
   double edge[PCV_MAX_KEY_LEVELS + 2];
-  double inv_edge[PCV_MAX_KEY_LEVELS + 2];  // RN(1 / edge[k]) for the exact constant-divisor division
+  double inv_edge[PCV_MAX_KEY_LEVELS + 2];     // yh = RN(1 / edge[k]) for the exact constant-divisor division
+  double inv_edge_lo[PCV_MAX_KEY_LEVELS + 2];  // yl = RN(1 / edge[k] - yh): the reciprocal as a double-double
   uint8_t enc[PCV_MAX_KEY_LEVELS + 3];
   int32_t nlevels;  // number of digit levels materialised in the keys (<= PCV_MAX_KEY_LEVELS)
   int32_t fast_ok;  // root min and all edges are tame: unguarded exact division is valid for tame points
@@ -229,7 +230,7 @@ struct alignas(16) PcvNodeRec {
   double mn[3];        // cube min (NodeId::find_bounding_cube recurrence)
   double edge;         // cube edge of the node's level
   double inv_edge;     // RN(1 / edge), 0 when the exact-division fast path must not be used
-  uint64_t pad;
+  double inv_edge_lo;  // RN(1 / edge - inv_edge)
 };
 struct PcvPromoteTables {
   const PcvNodeRec* leaf_rec;  // per leaf rank

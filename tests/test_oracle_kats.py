@@ -123,18 +123,21 @@ def test_sum_of_num_points_equals_input():
     assert t.total_points() == n
 
 
-def test_one_step_reciprocal_division_is_exact_for_every_code():
-    """The HIP kernels decode with q0 = v * RN(1/max); q = fma(fma(-max, q0, v), RN(1/max), q0) instead of an IEEE
-    division (pcv_chain_dev.h pcv_div_code). Exhaustive proof for all u8 / u16 codes, FMA emulated exactly."""
+def test_double_double_reciprocal_division_is_exact_for_every_code():
+    """The HIP kernels decode with q = fma(v, yh, v * yl), (yh, yl) the double-double reciprocal of max, instead of an
+    IEEE division (pcv_chain_dev.h pcv_div_code, PCV_RECIP_255 / PCV_RECIP_65535). Exhaustive proof for all u8 / u16
+    codes, FMA emulated exactly; also pins the two constants."""
     from fractions import Fraction as F
 
     def fma(a, b, c):
         e = F(a) * F(b) + F(c)
         return float(e) if e != 0 else 0.0
 
-    for m in (255.0, 65535.0):
-        y = 1.0 / m
+    for m, want in ((255.0, (float.fromhex("0x1.0101010101010p-8"), float.fromhex("0x1.0101010101010p-64"))),
+                    (65535.0, (float.fromhex("0x1.0001000100010p-16"), float.fromhex("0x1.0001000100010p-80")))):
+        yh = 1.0 / m
+        yl = fma(-m, yh, 1.0) / m
+        assert (yh, yl) == want
         for v in range(int(m) + 1):
             v = float(v)
-            q0 = v * y
-            assert fma(fma(-m, q0, v), y, q0) == v / m, (m, v)
+            assert fma(v, yh, v * yl) == v / m, (m, v)
