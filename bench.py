@@ -178,11 +178,11 @@ def main():
         # HBM bytes per launch from the PMC passes of the same command (tools/profile_bench.sh -> profiles/): only
         # quoted for the workload those passes ran (default points, 1 GPU, plain build)
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01_bench_100M_kernel_stats_v4_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r01_bench_100M_kernel_stats_v5_traffic.json")
         if os.path.exists(tpath) and n == 100_000_000 and world == 1 and not args.force_sharded and not args.ecef:
             with open(tpath) as f:
                 traffic = json.load(f)["bytes_per_launch"].get(dom)
-            traffic_src = "profiles/r01_bench_100M_kernel_stats_v4_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
+            traffic_src = "profiles/r01_bench_100M_kernel_stats_v5_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 4),
                     "launches": launches, "algorithmic_bytes_per_launch": ALGO_BYTES.get(dom, 0.0) * n}

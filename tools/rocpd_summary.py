@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--fetch")
     ap.add_argument("--write")
     ap.add_argument("--keep", default="kernel", help="substring a kernel name must contain to be listed")
+    ap.add_argument("--sq", help="rocpd db of an SQ counter pass: writes <o>_sq.csv (per-kernel averages per launch)")
     ap.add_argument("--command", default="python bench.py (defaults: BASELINE config 2, 100 M points, 1 GPU)")
     ap.add_argument("-o", required=True)
     a = ap.parse_args()
@@ -56,6 +57,26 @@ def main():
                     f"{'' if fk is None else f'{fk * 2 * 1024 / 1e6:.1f}'},{'' if wk is None else f'{wk:.0f}'},"
                     f"{'' if wk is None else f'{wk * 1024 / 1e6:.1f}'}\n")
     print(open(a.o + ".csv").read())
+    if a.sq:
+        cur = sqlite3.connect(a.sq).cursor()
+        acc = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
+        for name, cn, val in cur.execute("select kernel_name,counter_name,value from counters_collection"):
+            c = acc[short(name)][cn]
+            c[0] += 1
+            c[1] += val
+        names = sorted({cn for k in acc.values() for cn in k})
+        rows = []
+        for k, c in acc.items():
+            avg = {cn: (c[cn][1] / c[cn][0] if cn in c and c[cn][0] else 0.0) for cn in names}
+            if avg.get("SQ_INSTS_VALU", 0) >= 1e6 and a.keep in k and not k.startswith("at::"):
+                rows.append((k, max(v[0] for v in c.values()), avg))
+        rows.sort(key=lambda r: -r[2].get("SQ_INSTS_VALU", 0))
+        with open(a.o + "_sq.csv", "w") as f:
+            f.write("kernel,launches," + ",".join(names) + ",valu_per_wave\n")
+            for k, launches, avg in rows:
+                per = avg.get("SQ_INSTS_VALU", 0) / max(avg.get("SQ_WAVES", 1), 1)
+                f.write(",".join([k, str(launches)] + [f"{avg[cn]:.0f}" for cn in names] + [f"{per:.1f}"]) + "\n")
+        print(open(a.o + "_sq.csv").read())
     # machine-readable HBM traffic per launch (bytes; FETCH_SIZE already doubled per the gfx950 correction) for bench.py
     import json
     traffic = {}
