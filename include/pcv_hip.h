@@ -56,6 +56,8 @@ int pcv_ctx_create(int device, void* stream, pcv_ctx** out);
 void pcv_ctx_destroy(pcv_ctx* ctx);
 const char* pcv_last_error(const pcv_ctx* ctx);
 int pcv_abi_version(void);
+/* Wait for everything queued on the context's stream (the few entry points documented as asynchronous). */
+int pcv_ctx_synchronize(pcv_ctx* ctx);
 /* Release cached device/host scratch held by the context. */
 int pcv_ctx_trim(pcv_ctx* ctx);
 
@@ -167,7 +169,9 @@ int pcv_octree_node_data(pcv_octree* t, uint64_t i, int which, const uint8_t** d
 /* Device-side blobs (no copy): which as above. */
 int pcv_octree_device_blob(const pcv_octree* t, int which, const void** dptr, uint64_t* len);
 /* Copy the bytes of node i (which: 0 .xyz, 1 .rgb, 2 .intensity) out of the device blob into `dst` (host or device
- * memory, `capacity` bytes) without staging the whole octree on the host. */
+ * memory, `capacity` bytes) without staging the whole octree on the host. A copy to device memory is only queued on
+ * the context's stream (follow with pcv_ctx_synchronize or stream-ordered work); a copy to host memory is complete on
+ * return. */
 int pcv_octree_copy_node(const pcv_octree* tree, uint64_t i, int which, void* dst, uint64_t capacity, int mem);
 /* Write `<NodeId>.xyz/.rgb/.intensity` + meta.pb (version 13) exactly as the reference lays them out
  * (src/read_write/raw.rs:374-449, node_writer.rs:78-89, generation.rs:390-402). */

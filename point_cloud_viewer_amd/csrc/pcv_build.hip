@@ -214,6 +214,13 @@ extern "C" void pcv_ctx_destroy(pcv_ctx* ctx) {
 
 extern "C" const char* pcv_last_error(const pcv_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
 
+extern "C" int pcv_ctx_synchronize(pcv_ctx* ctx) {
+  if (!ctx) return PCV_E_INVALID;
+  PCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  PCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return PCV_OK;
+}
+
 extern "C" int pcv_ctx_trim(pcv_ctx* ctx) {
   if (!ctx) return PCV_E_INVALID;
   (void)hipSetDevice(ctx->device);
@@ -516,7 +523,8 @@ extern "C" int pcv_octree_copy_node(const pcv_octree* t, uint64_t i, int which, 
   if (!dst) return ctx->fail(PCV_E_INVALID, "dst is null");
   PCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   PCV_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, len, mem == PCV_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
-  PCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  // device destinations stay asynchronous on the context's stream (pcv_ctx_synchronize, or stream order, completes them)
+  if (mem == PCV_MEM_HOST) PCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return PCV_OK;
 }
 

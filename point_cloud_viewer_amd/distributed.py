@@ -252,16 +252,14 @@ class ShardedOctreeBuilder:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return t.cpu().numpy()
 
-    def _route(self, bucket, rank_of_bucket, send_counts, planes):
+    def _route(self, bucket, rank_of_bucket, matrix, planes):
         """Partition by owner and exchange: rows for rank r go to a send buffer, own rows directly into the receive
         buffer; ONE grouped send/recv round moves everything else (RCCL: one ncclGroup == one all-to-all(v)).
-        planes: dict name -> row-aligned tensor; returns the received planes under the same names."""
+        matrix[src][dst] = rows src sends to dst; planes: dict name -> row-aligned tensor; returns the received planes
+        under the same names."""
         torch, dist = self.torch, self.dist
         world, rank = self.world, self.rank
-        counts = torch.tensor(send_counts, dtype=torch.int64, device=self.device)
-        allc = [torch.empty_like(counts) for _ in range(world)]
-        dist.all_gather(allc, counts)
-        matrix = torch.stack(allc).cpu().numpy()  # matrix[src][dst]
+        send_counts = [int(v) for v in matrix[rank]]
         recv_counts = matrix[:, rank]
         n_recv = int(recv_counts.sum())
         n_local = int(sum(send_counts))
@@ -291,7 +289,7 @@ class ShardedOctreeBuilder:
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
-        return recv, matrix
+        return recv
 
     def build(self, resolution, bbox, x, y, z, rgb, intensity=None, max_points_per_node=0):
         torch = self.torch
@@ -319,11 +317,16 @@ class ShardedOctreeBuilder:
             planes = {"x": x, "y": y, "z": z, "color": rgb}
         if intensity is not None:
             planes["intensity"] = intensity
-        global_counts = self._sum_i64(counts)
-        rank_of_bucket, split_mask = plan_buckets(global_counts, world, cap, can_split)
-        send_counts = np.bincount(rank_of_bucket, weights=counts, minlength=world).astype(np.int64).tolist()
+        # one all-gather of the 64 local counts gives every rank the global counts AND the whole send matrix
+        mine = torch.tensor(np.asarray(counts, dtype=np.int64), device=self.device)
+        every = [torch.empty_like(mine) for _ in range(world)]
+        self.dist.all_gather(every, mine)
+        per_rank = torch.stack(every).cpu().numpy()  # per_rank[src][bucket]
+        rank_of_bucket, split_mask = plan_buckets(per_rank.sum(axis=0), world, cap, can_split)
+        matrix = np.stack([np.bincount(rank_of_bucket, weights=per_rank[src], minlength=world) for src in range(world)])
+        matrix = matrix.astype(np.int64)  # matrix[src][dst]
         # 2. the exchange
-        recv, matrix = self._route(bucket, rank_of_bucket, send_counts, planes)
+        recv = self._route(bucket, rank_of_bucket, matrix, planes)
         del bucket, planes
         mark()
         # 3. local topology, then the global streams of the top of the tree
@@ -357,6 +360,8 @@ class ShardedOctreeBuilder:
                 off, length = nd[key]
                 if length:
                     tree.copy_node_into(i, which, top[off:off + length])
+        if hasattr(tree, "synchronize"):
+            tree.synchronize()  # the node copies are queued on the library's stream, the collective runs on torch's
         if world > 1:
             self.dist.all_reduce(top, op=self.dist.ReduceOp.SUM)
         mark()

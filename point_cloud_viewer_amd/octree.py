@@ -103,6 +103,10 @@ class Context:
             out[name.value.decode()] = (launches.value, ms.value)
         return out
 
+    def synchronize(self):
+        """Wait for the work queued on the context's stream."""
+        self._check(self.lib.pcv_ctx_synchronize(self.handle))
+
     def _check(self, rc):
         if rc != L.PCV_OK:
             raise L.PcvError(rc, self.lib.pcv_last_error(self.handle).decode())
@@ -533,6 +537,9 @@ class OctreeResult:
     def write_nodes(self, directory, min_level=0):
         """Node files of the nodes at level >= min_level, without meta.pb (multi-GPU output)."""
         self.ctx._check(self.lib.pcv_octree_write_nodes(self.handle, str(directory).encode(), int(min_level)))
+
+    def synchronize(self):
+        self.ctx.synchronize()
 
     def copy_node_into(self, i, which, dst):
         """Copy node i's bytes (0 xyz, 1 rgb, 2 intensity) from the device blob into a uint8 tensor/array view."""

@@ -271,7 +271,8 @@ def test_copy_node_and_write_nodes(ctx, tmp_path):
             t.copy_node_into(i, which, host)
             assert host[:len(want)].tobytes() == want and not host[len(want):].any()
             dev = torch.zeros(len(want), dtype=torch.uint8, device="cuda")
-            t.copy_node_into(i, which, dev)
+            t.copy_node_into(i, which, dev)  # queued on the context's stream
+            t.synchronize()
             assert dev.cpu().numpy().tobytes() == want
     with pytest.raises(pcv.PcvError):
         t.copy_node_into(0, 0, np.zeros(1, dtype=np.uint8))  # too small
