@@ -254,6 +254,17 @@ def test_build_octree_from_file(ctx, tmp_path):
     assert not O.compare_octrees(O.load_dir(tmp_path / "gpu"), O.load_dir(tmp_path / "cpu"))
 
 
+def test_ten_million_points_default_capacity_vs_oracle(ctx):
+    """The reference's own constants (capacity 100 000, 1 mm) on a cloud large enough to need them: 10 M points,
+    every node byte against the closed-form oracle."""
+    x, y, z, rgb, bmin, bmax = synthetic.gaussian_clusters(10_000_000, seed=77, num_clusters=16, extent=400.0,
+                                                           sigma_range=(0.5, 12.0))
+    want = O.build_closed(0.001, bmin, bmax, x, y, z, rgb, threads=min(64, O.num_procs()))
+    t = ctx.build(0.001, pcv.Aabb(bmin, bmax), x, y, z, rgb)
+    assert t.num_nodes > 300 and max(t.node(i).level for i in range(t.num_nodes)) >= 6
+    assert_same(t.to_dict(), want)
+
+
 def test_copy_node_and_write_nodes(ctx, tmp_path):
     """pcv_octree_copy_node (device blob -> host / device buffer) and pcv_octree_write_nodes + pcv_write_meta, the pieces
     the multi-GPU output is assembled from, on a single tree: together they must reproduce pcv_octree_write_dir."""
