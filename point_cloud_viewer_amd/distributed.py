@@ -347,6 +347,8 @@ class ShardedOctreeBuilder:
         # 4. finish the root and the level-1 nodes: sum of every rank's sparsely filled global-size nodes
         specs, nbytes = top_nodes(layout, encodings, intensity is not None)
         top = torch.zeros(max(nbytes, 16), dtype=torch.uint8, device=self.device)
+        if timed:
+            torch.cuda.current_stream().synchronize()  # the fill runs on torch's stream, the copies on the library's
         index_of = {}
         for i in range(min(tree.num_nodes, 9)):
             nd = tree.node(i)
