@@ -30,7 +30,7 @@ extern "C" {
 #define PCV_E_HIP (-2)     /* HIP runtime failure */
 #define PCV_E_IO (-3)      /* file system failure (ErrorKind::Io) */
 #define PCV_E_OOM (-4)     /* device or host allocation failed / node table capacity exceeded */
-#define PCV_E_DEPTH (-5)   /* a node deeper than PCV_MAX_KEY_LEVELS would still have to be split */
+#define PCV_E_DEPTH (-5)   /* a node at level 40 would still have to be split (the reference's NodeId ends there too) */
 #define PCV_E_NOT_FOUND (-6) /* ErrorKind::NodeNotFound */
 
 #define PCV_MEM_HOST 0
@@ -42,7 +42,8 @@ extern "C" {
 #define PCV_ENC_FLOAT32 3
 #define PCV_ENC_FLOAT64 4
 
-/* path digits kept per point: 3 bits per level in a 64-bit key */
+/* path digits kept per point: 3 bits per level in a 64-bit key word; deeper trees (up to 40 levels, all the
+ * reference's u128 NodeId can name) use a second word inside the library */
 #define PCV_MAX_KEY_LEVELS 21
 /* reference src/octree/generation.rs:37 */
 #define PCV_DEFAULT_MAX_POINTS_PER_NODE 100000u

@@ -269,8 +269,9 @@ int pcv_make_levels(const double bmin[3], const double bmax[3], double resolutio
     for (int a = 0; a < 3; ++a) lv->root_min[a] = bmin[a];
     int nl = k < PCV_MAX_KEY_LEVELS ? k : PCV_MAX_KEY_LEVELS;
     lv->nlevels = nl;
+    const int filled = k < PCV_MAX_LEVELS ? k : PCV_MAX_LEVELS;  // the tables cover the deep levels as well
     bool tame = std::fabs(bmin[0]) <= 0x1p+500 && std::fabs(bmin[1]) <= 0x1p+500 && std::fabs(bmin[2]) <= 0x1p+500;
-    for (int j = 0; j <= nl && j < (int)e.size(); ++j) {
+    for (int j = 0; j <= filled && j < (int)e.size(); ++j) {
       lv->edge[j] = e[j];
       // IEEE division on the host: correctly rounded reciprocal; 0 = "use plain division" (pcv_div_const)
       lv->inv_edge[j] = (e[j] >= 0x1p-100 && e[j] <= 0x1p+100) ? 1.0 / e[j] : 0.0;
@@ -404,6 +405,9 @@ struct PcvBuild {
   uint32_t M = 0;
   size_t host_bytes = 0;
   std::vector<uint64_t> pre;  // |pre(node)| stream lengths, bottom-up
+  bool deep = false;          // more than PCV_MAX_KEY_LEVELS levels: second key word, prefix_lo in the node table
+  int levels = 0;             // levels the level tables are valid for in K5/K6 (full depth, or the deep depth)
+  uint64_t* d_prefix_lo = nullptr;
   explicit PcvBuild(pcv_ctx* c) : ctx(c), sc(c) {}
 };
 
@@ -685,10 +689,12 @@ static int build_begin_impl(pcv_ctx* ctx, const pcv_build_params* params, const 
 
     // K4: every open node holds > max_points points and open nodes of one level are disjoint
     if (attempts == 1) {
-      uint64_t cap64 = 8ull * (uint64_t)(full_levels + 1) * (n / max_points + 1) + 64;
+      const int deepest = max_level < PCV_MAX_LEVELS ? max_level : PCV_MAX_LEVELS;  // incl. the deep retry
+      uint64_t cap64 = 8ull * (uint64_t)(deepest + 1) * (n / max_points + 1) + 64;
       if (cap64 > (1ull << 26)) cap64 = 1ull << 26;
       const uint32_t cap = (uint32_t)cap64;
       nt.capacity = cap;
+      nt.prefix_lo = nullptr;
       if ((rc = sc.get(&nt.prefix, cap)) || (rc = sc.get(&nt.lo, cap)) || (rc = sc.get(&nt.hi, cap)) ||
           (rc = sc.get(&nt.parent, cap)) || (rc = sc.get(&nt.first_child, cap)) || (rc = sc.get(&nt.level, cap)) ||
           (rc = sc.get(&nt.child_mask, cap)) || (rc = sc.get(&nt.open, cap)) ||
@@ -709,19 +715,66 @@ static int build_begin_impl(pcv_ctx* ctx, const pcv_build_params* params, const 
         spec_levels = full_levels;
         continue;
       }
+      if (max_level > PCV_MAX_KEY_LEVELS) {
+        // ---- deep tree: a second key word for levels 22..40 (heavy duplicates in a cube with edge/resolution > 2^21).
+        // Rare path, built from existing pieces: digits as four 32-bit words, four stable LSD sorts (one per word,
+        // least significant first, the other three travel as payload planes), then the split with both words.
+        ++attempts;
+        const int deep_levels = max_level < PCV_MAX_LEVELS ? max_level : PCV_MAX_LEVELS;
+        bs->deep = true;
+        lv.nlevels = deep_levels;
+        uint32_t* W[4][2];
+        for (int j = 0; j < 4; ++j)
+          for (int sd = 0; sd < 2; ++sd)
+            if ((rc = sc.get(&W[j][sd], n))) return rc;
+        uint32_t* first[4] = {W[0][0], W[1][0], W[2][0], W[3][0]};
+        pcv_launch_chain_keys_deep(ctx, lv, n, d.x, d.y, d.z, d.routed, first);
+        int side = 0;
+        for (int j = 3; j >= 0; --j) {
+          PcvSortPayload pl;
+          pl.nwords = 3;
+          int w = 0;
+          for (int o = 0; o < 4; ++o) {
+            if (o == j) continue;
+            pl.in[w] = W[o][side];
+            pl.out[w] = W[o][1 - side];
+            ++w;
+          }
+          bool in_a = true;
+          if ((rc = pcv_radix_sort_u32(ctx, W[j][side], W[j][1 - side], n, 0, 32, &pl, sort_scratch, &in_a))) return rc;
+          if (!in_a) side = 1 - side;
+        }
+        const uint32_t* sorted_words[4] = {W[0][side], W[1][side], W[2][side], W[3][side]};
+        pcv_launch_combine_words(ctx, n, sorted_words, keys_a, keys_b);  // keys_a = first word, keys_b = second word
+        if ((rc = sc.get(&nt.prefix_lo, nt.capacity))) return rc;
+        bs->d_prefix_lo = nt.prefix_lo;
+        pcv_launch_node_split(ctx, nt, keys_a, false, (uint32_t)n, lv, params->resolution, max_points,
+                              (params->flags >> 8) & 0xffu, keys_b);
+        PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[4], st));
+        PCV_HIP_CHECK(ctx, hipMemcpyAsync(ctx->mailbox, nt.counters, sizeof(counters), hipMemcpyDeviceToHost, st));
+        PCV_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        std::memcpy(counters, ctx->mailbox, sizeof(counters));
+        if (counters[1] & 2u) return ctx->fail(PCV_E_OOM, "node table capacity exceeded");
+        if (!(counters[1] & 1u)) {
+          spec_levels = deep_levels;
+          break;
+        }
+      }
       return ctx->fail(PCV_E_DEPTH, "a node at level " + std::to_string(lv.nlevels) +
                                         " still holds more than max_points_per_node points and is larger than the "
-                                        "resolution; PCV_MAX_KEY_LEVELS exhausted");
+                                        "resolution; the reference's NodeId cannot name deeper nodes either");
     }
     break;
   }
   t->key_levels = spec_levels;
   t->key_attempts = attempts;
-  lv.nlevels = full_levels;  // K5/K6 index the level tables by node level; the walk stops at leaves anyway
+  bs->levels = bs->deep ? lv.nlevels : full_levels;
+  lv.nlevels = bs->levels;  // K5/K6 index the level tables by node level; the walk stops at leaves anyway
   const uint32_t M = counters[0];
   bs->M = M;
   // pinned staging: prefix(8) lo hi parent first_child (4 each) level mask open (1 each)
-  const size_t host_bytes = (size_t)M * (8 + 4 * 4 + 3) + 64;
+  const size_t lo_off = (((size_t)M * (8 + 4 * 4 + 3) + 64) + 7) & ~(size_t)7;  // deep trees: second prefix word
+  const size_t host_bytes = lo_off + (bs->deep ? (size_t)M * 8 : 0);
   bs->host_bytes = host_bytes;
   if ((rc = ctx->pinned_reserve(host_bytes * 4 + (size_t)M * 64 + (size_t)M * 2 * sizeof(PcvNodeRec) + 512))) return rc;
   uint8_t* hp = (uint8_t*)ctx->pinned;
@@ -739,6 +792,8 @@ static int build_begin_impl(pcv_ctx* ctx, const pcv_build_params* params, const 
   PCV_HIP_CHECK(ctx, hipMemcpyAsync(h_level, nt.level, (size_t)M, hipMemcpyDeviceToHost, st));
   PCV_HIP_CHECK(ctx, hipMemcpyAsync(h_mask, nt.child_mask, (size_t)M, hipMemcpyDeviceToHost, st));
   PCV_HIP_CHECK(ctx, hipMemcpyAsync(h_open, nt.open, (size_t)M, hipMemcpyDeviceToHost, st));
+  if (bs->deep)
+    PCV_HIP_CHECK(ctx, hipMemcpyAsync(hp + lo_off, nt.prefix_lo, (size_t)M * 8, hipMemcpyDeviceToHost, st));
   PCV_HIP_CHECK(ctx, hipStreamSynchronize(st));
 
   // upload area (pinned, after the download area)
@@ -851,6 +906,7 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
   uint32_t* u_leaf_node = u_leaf_lo + M;             // <= M
   uint8_t* u_level = (uint8_t*)(u_leaf_node + M);    // M
   const size_t up_bytes = (size_t)M * (8 * 3 + 24 + 4 * 4 + 1);
+  const uint64_t* h_prefix_lo = (const uint64_t*)(hp + ((((size_t)M * (8 + 4 * 4 + 3) + 64) + 7) & ~(size_t)7));  // deep only
 
   uint32_t top_nodes = 0;  // nodes of level <= 1 hold GLOBAL streams when a layout is given (multi-GPU build)
   if (top) {
@@ -909,7 +965,9 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
       for (int a = 0; a < 3; ++a) u_node_min[a] = bmin[a];
     } else {
       const uint32_t p = u_parent[i];
-      const unsigned dgt = (unsigned)(h_prefix[i] >> (3 * (PCV_MAX_KEY_LEVELS - level))) & 7u;
+      const unsigned dgt = level <= PCV_MAX_KEY_LEVELS
+                               ? (unsigned)(h_prefix[i] >> (3 * (PCV_MAX_KEY_LEVELS - level))) & 7u
+                               : (unsigned)(h_prefix_lo[i] >> (3 * (2 * PCV_MAX_KEY_LEVELS - level))) & 7u;
       const double e = lv.edge[level];
       u_node_min[3 * (size_t)i + 0] = u_node_min[3 * (size_t)p + 0] + (double)((dgt >> 2) & 1) * e;
       u_node_min[3 * (size_t)i + 1] = u_node_min[3 * (size_t)p + 1] + (double)((dgt >> 1) & 1) * e;
@@ -917,9 +975,15 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
     }
     const uint64_t np = i == 0 ? pre[0] : pre[i] - ceil8(pre[i]);
     pcv_node_info& ni = t->nodes[i];
-    const uint64_t index = level ? (h_prefix[i] >> (3 * (PCV_MAX_KEY_LEVELS - level))) : 0;
-    ni.id_high = (uint64_t)level << 56;  // u128 = level << 120 | index ; index < 2^63 here
-    ni.id_low = index;
+    // u128 NodeId = level << 120 | index (node.rs:108-111); the index is the octal path, 3 bits per level
+    unsigned __int128 index = 0;
+    if (level > PCV_MAX_KEY_LEVELS)
+      index = ((unsigned __int128)h_prefix[i] << (3 * (level - PCV_MAX_KEY_LEVELS))) |
+              (h_prefix_lo[i] >> (3 * (2 * PCV_MAX_KEY_LEVELS - level)));
+    else if (level)
+      index = h_prefix[i] >> (3 * (PCV_MAX_KEY_LEVELS - level));
+    ni.id_high = ((uint64_t)level << 56) | (uint64_t)(index >> 64);
+    ni.id_low = (uint64_t)index;
     ni.num_points = (int64_t)np;
     ni.level = (uint32_t)level;
     ni.encoding = lv.enc[level];

@@ -128,6 +128,40 @@ __global__ __launch_bounds__(256) void chain_keys_kernel(PcvLevels lv, uint64_t 
   keys[i] = sizeof(KeyT) == 8 ? (KeyT)key : (KeyT)(key >> 33);
 }
 
+// Deep trees (more than PCV_MAX_KEY_LEVELS levels): the same chain, digits in two key words.
+struct DeepWords {
+  uint32_t* w[4];
+};
+__global__ __launch_bounds__(256) void chain_keys_deep_kernel(PcvLevels lv, uint64_t n, const double* __restrict__ x,
+                                                               const double* __restrict__ y, const double* __restrict__ z,
+                                                               PcvRouted routed, DeepWords out) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double px, py, pz, mx, my, mz;
+  double cx = 0, cy = 0, cz = 0;
+  uint32_t d1;
+  const int k0 = pcv_chain_start(lv, routed, x, y, z, i, px, py, pz, mx, my, mz, cx, cy, cz, d1);
+  uint64_t hi = (uint64_t)d1 << (3 * (PCV_MAX_KEY_LEVELS - 1)), lo = 0;
+  for (int k = k0; k <= lv.nlevels; ++k) {  // rare path: always the guarded variant
+    const uint64_t d = pcv_chain_level<true>(lv.enc[k], lv.edge[k - 1], lv.edge[k], PcvRecip{lv.inv_edge[k], lv.inv_edge_lo[k]}, px, py, pz, mx, my, mz, cx, cy, cz);
+    if (k <= PCV_MAX_KEY_LEVELS)
+      hi |= d << (3 * (PCV_MAX_KEY_LEVELS - k));
+    else
+      lo |= d << (3 * (2 * PCV_MAX_KEY_LEVELS - k));
+  }
+  out.w[0][i] = (uint32_t)(hi >> 32);
+  out.w[1][i] = (uint32_t)hi;
+  out.w[2][i] = (uint32_t)(lo >> 32);
+  out.w[3][i] = (uint32_t)lo;
+}
+__global__ __launch_bounds__(256) void combine_words_kernel(uint64_t n, DeepWords in, uint64_t* __restrict__ hi,
+                                                             uint64_t* __restrict__ lo) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  hi[i] = ((uint64_t)in.w[0][i] << 32) | in.w[1][i];
+  lo[i] = ((uint64_t)in.w[2][i] << 32) | in.w[3][i];
+}
+
 // Depth probe on a sorted sample: if two keys `gap` positions apart share their first l digits, the level-l node
 // holding them has more than `gap` sample points. The maximum such l over the sample bounds the deepest node that
 // the full input will have to split.
@@ -514,6 +548,20 @@ void pcv_launch_chain_keys(pcv_ctx* ctx, const PcvLevels& lv, uint64_t n, uint64
   else
     hipLaunchKernelGGL(chain_keys_kernel<uint64_t>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, lv, n, stride, x, y,
                        z, routed, (uint64_t*)keys);
+}
+
+void pcv_launch_chain_keys_deep(pcv_ctx* ctx, const PcvLevels& lv, uint64_t n, const double* x, const double* y,
+                                const double* z, const PcvRouted& routed, uint32_t* const words[4]) {
+  if (n == 0) return;
+  DeepWords dw{{words[0], words[1], words[2], words[3]}};
+  PcvProf prof(ctx, PCV_K_CHAIN_KEYS);
+  hipLaunchKernelGGL(chain_keys_deep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, lv, n, x, y, z, routed,
+                     dw);
+}
+void pcv_launch_combine_words(pcv_ctx* ctx, uint64_t n, const uint32_t* const words[4], uint64_t* hi, uint64_t* lo) {
+  if (n == 0) return;
+  DeepWords dw{{(uint32_t*)words[0], (uint32_t*)words[1], (uint32_t*)words[2], (uint32_t*)words[3]}};
+  hipLaunchKernelGGL(combine_words_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, dw, hi, lo);
 }
 
 void pcv_launch_depth_probe(pcv_ctx* ctx, const uint64_t* sorted, uint32_t n, uint32_t gap, uint32_t* out) {

@@ -17,13 +17,17 @@
 
 // Per-level constants handed to every kernel by value (lands in SGPRs; uniform across the grid).
 // edge[k], enc[k] for k = 0..nlevels: see pcv_level_table / reference codec.rs:31-40, node.rs:161.
+// A path key word holds PCV_MAX_KEY_LEVELS (21) levels. Trees that need more (heavy duplicates in a cube with
+// edge / resolution > 2^21) take the "deep" path: a second key word for levels 22..PCV_MAX_LEVELS. 40 levels is what the
+// reference's NodeId can name (u128: 8 bits of level + 120 bits of index, node.rs:101-111).
+#define PCV_MAX_LEVELS 40
 struct PcvLevels {
   double root_min[3];
-  double edge[PCV_MAX_KEY_LEVELS + 2];
-  double inv_edge[PCV_MAX_KEY_LEVELS + 2];     // yh = RN(1 / edge[k]) for the exact constant-divisor division
-  double inv_edge_lo[PCV_MAX_KEY_LEVELS + 2];  // yl = RN(1 / edge[k] - yh): the reciprocal as a double-double
-  uint8_t enc[PCV_MAX_KEY_LEVELS + 3];
-  int32_t nlevels;  // number of digit levels materialised in the keys (<= PCV_MAX_KEY_LEVELS)
+  double edge[PCV_MAX_LEVELS + 2];
+  double inv_edge[PCV_MAX_LEVELS + 2];     // yh = RN(1 / edge[k]) for the exact constant-divisor division
+  double inv_edge_lo[PCV_MAX_LEVELS + 2];  // yl = RN(1 / edge[k] - yh): the reciprocal as a double-double
+  uint8_t enc[PCV_MAX_LEVELS + 3];
+  int32_t nlevels;  // number of digit levels materialised in the keys (<= PCV_MAX_KEY_LEVELS; <= PCV_MAX_LEVELS deep)
   int32_t fast_ok;  // root min and all edges are tame: unguarded exact division is valid for tame points
 };
 
@@ -191,6 +195,7 @@ int pcv_radix_sort_u32(pcv_ctx* ctx, uint32_t* keys_a, uint32_t* keys_b, uint64_
 struct PcvNodeTableDev {
   uint32_t capacity;
   uint64_t* prefix;      // left-aligned path key (digits beyond `level` are zero)
+  uint64_t* prefix_lo;   // deep trees: digits of levels 22.. (level k at bits 3 * (42 - k)); null otherwise
   uint32_t* lo;          // [lo, hi) range in the sorted key array
   uint32_t* hi;
   uint32_t* parent;
@@ -199,11 +204,17 @@ struct PcvNodeTableDev {
   uint8_t* child_mask;   // bit c set = child c exists
   uint8_t* open;         // 1 = split further (inner node), 0 = leaf
   uint32_t* bounds;      // scratch: 9 bounds per node of the level being expanded
-  uint32_t* counters;    // [0] node_count, [1] error flag, [2..] level_start[k] (k = 0..PCV_MAX_KEY_LEVELS+1)
+  uint32_t* counters;    // [0] node_count, [1] error flag, [2..] level_start[k] (k = 0..PCV_MAX_LEVELS+1)
 };
+// sorted_lo (deep trees): second key word, sorted together with the first; levels > PCV_MAX_KEY_LEVELS search it
 void pcv_launch_node_split(pcv_ctx* ctx, const PcvNodeTableDev& t, const void* sorted_keys, bool keys32, uint32_t n,
                            const PcvLevels& lv, double resolution, uint32_t max_points_per_node,
-                           uint32_t force_split_level1_mask);
+                           uint32_t force_split_level1_mask, const uint64_t* sorted_lo = nullptr);
+// deep trees: digits of up to PCV_MAX_LEVELS levels as four 32-bit words (hi >> 32, hi, lo >> 32, lo); hi holds levels
+// 1..21 as in the ordinary key, lo holds level k > 21 at bits 3 * (42 - k)
+void pcv_launch_chain_keys_deep(pcv_ctx* ctx, const PcvLevels& lv, uint64_t n, const double* x, const double* y,
+                                const double* z, const PcvRouted& routed, uint32_t* const words[4]);
+void pcv_launch_combine_words(pcv_ctx* ctx, uint64_t n, const uint32_t* const words[4], uint64_t* hi, uint64_t* lo);
 
 // pcv_encode.hip — leaf lookup + leaf-level encode (input order), promotion + final encode (sorted order).
 struct PcvWalkTables {

@@ -42,6 +42,7 @@ __device__ __forceinline__ uint32_t wave_lower_bound(const KeyT* __restrict__ ke
 __global__ __launch_bounds__(256) void init_root_kernel(PcvNodeTableDev t, uint32_t n) {
   if (threadIdx.x == 0) {
     t.prefix[0] = 0;
+    if (t.prefix_lo) t.prefix_lo[0] = 0;
     t.lo[0] = 0;
     t.hi[0] = n;
     t.parent[0] = 0xffffffffu;
@@ -58,7 +59,8 @@ __global__ __launch_bounds__(256) void init_root_kernel(PcvNodeTableDev t, uint3
 
 // (A) child boundaries of every open node of level k-1.
 template <typename KeyT>
-__global__ __launch_bounds__(256) void split_search_kernel(PcvNodeTableDev t, const KeyT* __restrict__ keys, int k) {
+__global__ __launch_bounds__(256) void split_search_kernel(PcvNodeTableDev t, const KeyT* __restrict__ keys, int k,
+                                                            const uint64_t* __restrict__ keys_lo) {
   const uint32_t begin = t.counters[CNT_LEVEL_START + k - 1];
   const uint32_t end = t.counters[CNT_LEVEL_START + k];
   const int lane = threadIdx.x & 63;
@@ -71,9 +73,16 @@ __global__ __launch_bounds__(256) void split_search_kernel(PcvNodeTableDev t, co
     const uint32_t c = it % 7u + 1u;
     if (!t.open[node]) continue;  // wave-uniform
     const uint32_t lo = t.lo[node], hi = t.hi[node];
-    const uint64_t target64 = t.prefix[node] | ((uint64_t)c << shift);
-    const KeyT target = sizeof(KeyT) == 8 ? (KeyT)target64 : (KeyT)(target64 >> 33);  // u32 keys hold key >> 33
-    const uint32_t b = wave_lower_bound<KeyT>(keys, lo, hi, target, lane);
+    uint32_t b;
+    if (k > PCV_MAX_KEY_LEVELS) {
+      // deep tree: every key of this node has the same first word; the children are told apart by the second
+      const uint64_t target = t.prefix_lo[node] | ((uint64_t)c << (3 * (2 * PCV_MAX_KEY_LEVELS - k)));
+      b = wave_lower_bound<uint64_t>(keys_lo, lo, hi, target, lane);
+    } else {
+      const uint64_t target64 = t.prefix[node] | ((uint64_t)c << shift);
+      const KeyT target = sizeof(KeyT) == 8 ? (KeyT)target64 : (KeyT)(target64 >> 33);  // u32 keys hold key >> 33
+      b = wave_lower_bound<KeyT>(keys, lo, hi, target, lane);
+    }
     if (lane == 0) {
       uint32_t* bd = t.bounds + (uint64_t)(node - begin) * 9u;
       bd[c] = b;
@@ -135,6 +144,7 @@ __global__ __launch_bounds__(1024) void split_assign_kernel(PcvNodeTableDev t, P
       t.child_mask[node] = (uint8_t)mask;
       uint32_t j = first;
       const uint64_t pfx = t.prefix[node];
+      const uint64_t pfx_lo = t.prefix_lo ? t.prefix_lo[node] : 0ull;
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         if (!((mask >> c) & 1u)) continue;
@@ -150,7 +160,13 @@ __global__ __launch_bounds__(1024) void split_assign_kernel(PcvNodeTableDev t, P
             atomicOr(&t.counters[CNT_ERROR], 1u);
             open = false;
           }
-          t.prefix[j] = pfx | ((uint64_t)c << shift);
+          if (k > PCV_MAX_KEY_LEVELS) {
+            t.prefix[j] = pfx;
+            t.prefix_lo[j] = pfx_lo | ((uint64_t)c << (3 * (2 * PCV_MAX_KEY_LEVELS - k)));
+          } else {
+            t.prefix[j] = pfx | ((uint64_t)c << shift);
+            if (t.prefix_lo) t.prefix_lo[j] = 0;
+          }
           t.lo[j] = b[c];
           t.hi[j] = b[c + 1];
           t.parent[j] = node;
@@ -179,16 +195,18 @@ __global__ __launch_bounds__(1024) void split_assign_kernel(PcvNodeTableDev t, P
 
 void pcv_launch_node_split(pcv_ctx* ctx, const PcvNodeTableDev& t, const void* sorted_keys, bool keys32, uint32_t n,
                            const PcvLevels& lv, double resolution, uint32_t max_points_per_node,
-                           uint32_t force_split_level1_mask) {
+                           uint32_t force_split_level1_mask, const uint64_t* sorted_lo) {
   hipStream_t s = ctx->stream;
   hipLaunchKernelGGL(init_root_kernel, dim3(1), dim3(256), 0, s, t, n);
   for (int k = 1; k <= lv.nlevels; ++k) {
     {
       PcvProf prof(ctx, PCV_K_SPLIT_SEARCH);
       if (keys32)
-        hipLaunchKernelGGL(split_search_kernel<uint32_t>, dim3(512), dim3(256), 0, s, t, (const uint32_t*)sorted_keys, k);
+        hipLaunchKernelGGL(split_search_kernel<uint32_t>, dim3(512), dim3(256), 0, s, t, (const uint32_t*)sorted_keys, k,
+                           sorted_lo);
       else
-        hipLaunchKernelGGL(split_search_kernel<uint64_t>, dim3(512), dim3(256), 0, s, t, (const uint64_t*)sorted_keys, k);
+        hipLaunchKernelGGL(split_search_kernel<uint64_t>, dim3(512), dim3(256), 0, s, t, (const uint64_t*)sorted_keys, k,
+                           sorted_lo);
     }
     {
       PcvProf prof(ctx, PCV_K_SPLIT_ASSIGN);

@@ -109,9 +109,9 @@ def test_special_coordinates_take_the_guarded_chain(ctx):
         idx = rng.choice(n, 3000, replace=False)
         coords[idx] = rng.choice(special, idx.size)
     # the second box cuts the cloud in half: the outside points collapse onto its faces (clamped codes) and the tree gets
-    # deep — at 1e-7 m deeper than the 21 key levels, which test_depth_overflow_is_reported covers
+    # deep — at 1e-7 m 28 levels, i.e. the two-word key path
     for lo, hi, resolutions in ((bmin, bmax, (0.001, 1e-7)),
-                                (np.array([-8.0, -8.0, -8.0]), np.array([8.0, 8.0, 8.0]), (0.001,)),
+                                (np.array([-8.0, -8.0, -8.0]), np.array([8.0, 8.0, 8.0]), (0.001, 1e-7)),
                                 (np.array([0.0, -0.0, -8.0]), np.array([8.0, 8.0, 8.0]), (0.001, 1e-7))):
         for res in resolutions:
             with O.max_points_per_node(900):
@@ -150,13 +150,52 @@ def test_written_directory_equals_oracle_directory(ctx, tmp_path):
 
 
 def test_depth_overflow_is_reported(ctx):
-    # > capacity identical points and a resolution so fine that 21 levels cannot separate edge from resolution
+    # > capacity identical points and a resolution so fine that even 40 levels (all the reference's NodeId can name)
+    # cannot bring the edge down to it
     n = 300
     x = np.full(n, 0.123456789)
     rgb = np.zeros((n, 3), np.uint8)
     with pytest.raises(pcv.PcvError) as ei:
-        ctx.build(1e-12, pcv.Aabb([0, 0, 0], [1, 1, 1]), x, x, x, rgb, max_points_per_node=100)
+        ctx.build(1e-13, pcv.Aabb([0, 0, 0], [1, 1, 1]), x, x, x, rgb, max_points_per_node=100)
     assert ei.value.code == -5  # PCV_E_DEPTH
+
+
+def test_deep_trees_beyond_21_levels(ctx, tmp_path):
+    """Heavy duplicates in a cube with edge / resolution > 2^21: the tree needs more levels than one 63-bit key word
+    holds (second key word for levels 22..40). Node ids, counts and bytes against the oracle."""
+    rng = np.random.default_rng(19)
+    # (a) 8 km cube at 1 mm: 23 levels; two piles of duplicates 3 mm apart plus background
+    n_bg = 20_000
+    x = np.concatenate([rng.uniform(0, 8192, n_bg), np.full(3000, 1234.5678), np.full(2500, 1234.5678 + 0.003)])
+    y = np.concatenate([rng.uniform(0, 8192, n_bg), np.full(3000, 777.25), np.full(2500, 777.25)])
+    z = np.concatenate([rng.uniform(0, 8192, n_bg), np.full(3000, 4000.125), np.full(2500, 4000.125 - 0.002)])
+    perm = rng.permutation(x.size)
+    x, y, z = x[perm], y[perm], z[perm]
+    rgb = synthetic.hash_colors(x.size)
+    inten = (np.arange(x.size) % 113).astype(np.float32)
+    lo, hi = np.zeros(3), np.full(3, 8192.0)
+    with O.max_points_per_node(1000):
+        want = O.build_closed(0.001, lo, hi, x, y, z, rgb, inten, threads=4)
+    assert max(v["level"] for v in want.nodes.values()) > 21
+    t = ctx.build(0.001, pcv.Aabb(lo, hi), x, y, z, rgb, inten, max_points_per_node=1000)
+    assert t.build_info()["key_levels"] > 21
+    assert_same(t.to_dict(), want)
+    # node ids above 2^64 through meta.pb and the file names, read back by the oracle's loader and by open_dir
+    t.write_dir(str(tmp_path / "deep"))
+    with O.max_points_per_node(1000):
+        O.build_literal_dir(tmp_path / "deep_oracle", 0.001, lo, hi, x, y, z, rgb, inten, threads=4)
+    diffs = O.compare_octrees(O.load_dir(tmp_path / "deep"), O.load_dir(tmp_path / "deep_oracle"))
+    assert not diffs, diffs[:10]
+    reopened = ctx.open_dir(str(tmp_path / "deep"))
+    assert sorted(reopened.node_names()) == sorted(want.nodes)
+    # (b) identical points, unit cube, 1e-12: all 40 levels, then the edge is below the resolution and the leaf stays big
+    n = 300
+    x = np.full(n, 0.123456789)
+    rgb = synthetic.hash_colors(n)
+    with O.max_points_per_node(100):
+        want = O.build_closed(1e-12, np.zeros(3), np.ones(3), x, x, x, rgb)
+    assert max(v["level"] for v in want.nodes.values()) == 40
+    assert_same(ctx.build(1e-12, pcv.Aabb([0, 0, 0], [1, 1, 1]), x, x, x, rgb, max_points_per_node=100).to_dict(), want)
 
 
 def test_invalid_arguments(ctx):

@@ -158,3 +158,36 @@ def test_virtual_ranks_small_clouds_and_idle_ranks(world, n):
     _same(out[0][0], O.build_closed(0.001, bmin, bmax, x, y, z, rgb))
     if n == 3000:
         assert sum(1 for _, nodes in out if nodes == 0) >= 1  # at least one rank had nothing to build
+
+
+def test_virtual_ranks_deep_tree():
+    """More than 21 levels (two-word keys) through the sharded build: duplicates in an 8 km cube at 1 mm."""
+    import torch
+    from thread_dist import run_ranks
+    world = 3
+    rng = np.random.default_rng(23)
+    x = np.concatenate([rng.uniform(0, 8192, 15_000), np.full(2600, 5000.5), np.full(2400, 5000.5 + 0.004)])
+    y = np.concatenate([rng.uniform(0, 8192, 15_000), np.full(2600, 123.0), np.full(2400, 123.0)])
+    z = np.concatenate([rng.uniform(0, 8192, 15_000), np.full(2600, 8000.25), np.full(2400, 8000.25)])
+    perm = rng.permutation(x.size)
+    x, y, z = x[perm], y[perm], z[perm]
+    rgb = synthetic.hash_colors(x.size)
+    n = x.size
+    bmin, bmax = np.zeros(3), np.full(3, 8192.0)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def rank_main(rank, dist):
+        torch.cuda.set_device(0)
+        ctx = pcv.Context(0, stream=stream)
+        sl = slice(rank * n // world, (rank + 1) * n // world)
+        tx, ty, tz = (torch.from_numpy(np.ascontiguousarray(a[sl])).cuda() for a in (x, y, z))
+        trgb = torch.from_numpy(np.ascontiguousarray(rgb[sl])).cuda()
+        b = pdist.ShardedOctreeBuilder(ctx, dist, dev)
+        return b.build(0.001, pcv.Aabb(bmin, bmax), tx, ty, tz, trgb, max_points_per_node=1000).gather(0)
+
+    merged = run_ranks(world, rank_main)[0]
+    with O.max_points_per_node(1000):
+        want = O.build_closed(0.001, bmin, bmax, x, y, z, rgb, threads=4)
+    assert max(v["level"] for v in want.nodes.values()) > 21
+    _same(merged, want)
