@@ -186,6 +186,25 @@ def main():
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 4),
                     "launches": launches, "algorithmic_bytes_per_launch": ALGO_BYTES.get(dom, 0.0) * n}
+        # VALU-issue view of the two chain kernels, from the committed SQ counters of the same command
+        # (profiles/r01_bench_100M_sq_counters_v5.csv: SQ_INSTS_VALU / SQ_WAVES), the static f64 share of their ISA and
+        # the measured issue cost of a wave64 op on this part (tools/f64_rate.hip): an estimate, labelled as such
+        sq = os.path.join(ROOT, "profiles", "r01_bench_100M_sq_counters_v5.csv")
+        if dom in ("leaf_encode_kernel", "chain_keys_kernel") and os.path.exists(sq) and n == 100_000_000:
+            per_wave = None
+            for line in open(sq).read().splitlines()[1:]:
+                cols = line.split(",")
+                if cols[0].split("<")[0] == dom:
+                    per_wave = float(cols[-1])
+                    break
+            if per_wave:
+                f64_share = 0.68 if dom == "leaf_encode_kernel" else 0.70
+                cyc = per_wave * (f64_share * 5.3 + (1.0 - f64_share) * 2.5)
+                bound_ms = (n / 64.0) * cyc / (1024 * 2.4e9) * 1e3
+                roofline["valu_issue"] = {"insts_per_point": per_wave, "f64_share_static": f64_share,
+                                          "cycles_per_f64_wave_op": 5.3, "cycles_per_32bit_wave_op": 2.5,
+                                          "issue_bound_ms": round(bound_ms, 3), "frac": round(bound_ms / avg_ms, 3),
+                                          "kind": "estimate from profiles/r01_bench_100M_sq_counters_v5.csv + tools/f64_rate.hip"}
         if dom in ("leaf_encode_kernel", "chain_keys_kernel"):
             roofline["note"] = ("this kernel is f64-VALU bound by construction (two correctly rounded f64 divisions per "
                                 "coordinate and level; ~5 SIMD cycles per f64 wave-op measured by tools/f64_rate.hip), "
