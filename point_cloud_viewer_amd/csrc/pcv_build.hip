@@ -651,7 +651,10 @@ static int build_begin_impl(pcv_ctx* ctx, const pcv_build_params* params, const 
     PCV_HIP_CHECK(ctx, hipMemsetAsync(d_max, 0, 4, st));
     pcv_launch_chain_keys(ctx, lv, ns, stride, d.x, d.y, d.z, keys_a, false, d.routed);
     bool s_in_a = true;
-    if ((rc = pcv_radix_sort_u64(ctx, keys_a, keys_b, ns, 3 * (PCV_MAX_KEY_LEVELS - full_levels), 3 * PCV_MAX_KEY_LEVELS,
+    // the probe only has to tell depths up to kProbeLevels apart (deeper -> no speculation): sort those digits only
+    const int kProbeLevels = 14;
+    const int probe_levels = full_levels < kProbeLevels ? full_levels : kProbeLevels;
+    if ((rc = pcv_radix_sort_u64(ctx, keys_a, keys_b, ns, 3 * (PCV_MAX_KEY_LEVELS - probe_levels), 3 * PCV_MAX_KEY_LEVELS,
                                  nullptr, sort_scratch, &s_in_a)))
       return rc;
     double gapd = 0.6 * (double)max_points * (double)ns / (double)n;
@@ -660,8 +663,9 @@ static int build_begin_impl(pcv_ctx* ctx, const pcv_build_params* params, const 
     PCV_HIP_CHECK(ctx, hipMemcpyAsync(ctx->mailbox, d_max, 4, hipMemcpyDeviceToHost, st));
     PCV_HIP_CHECK(ctx, hipStreamSynchronize(st));
     const uint32_t shared = *(const uint32_t*)ctx->mailbox;
-    // a level-`shared` node is (probably) split -> nodes of level shared + 1 exist -> that many digits are needed
-    int want = (int)shared + 1;
+    // a level-`shared` node is (probably) split -> nodes of level shared + 1 exist -> that many digits are needed;
+    // a prefix shared down to the last sorted level says nothing about the levels below it
+    int want = (int)shared >= probe_levels ? full_levels : (int)shared + 1;
     if (want < 3) want = 3;
     if (want < full_levels) spec_levels = want;
   }

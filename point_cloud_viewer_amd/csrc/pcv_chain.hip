@@ -177,8 +177,14 @@ __global__ __launch_bounds__(256) void depth_probe_kernel(const uint64_t* __rest
     if (l > PCV_MAX_KEY_LEVELS) l = PCV_MAX_KEY_LEVELS;
   }
   for (int o = 32; o > 0; o >>= 1) l = max(l, (uint32_t)__shfl_xor((int)l, o, 64));
-  // one atomic per wave only when it would raise the maximum (a plain read first keeps 4096 waves off one address)
-  if ((threadIdx.x & 63) == 0 && l > *(volatile uint32_t*)max_shared_levels) atomicMax(max_shared_levels, l);
+  // one atomic per workgroup, and only when it would raise the maximum (a plain read first keeps the waves off one address)
+  __shared__ uint32_t wmax[4];
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = l;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t m = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+    if (m > *(volatile uint32_t*)max_shared_levels) atomicMax(max_shared_levels, m);
+  }
 }
 
 // Multi-GPU routing: the bucket of a point is its level-1 and level-2 octant digit (the first two steps of
