@@ -1,19 +1,25 @@
 #!/usr/bin/env python
 """bench.py — octree-build throughput on MI355X (BASELINE.json metric: octree-build Mpoints/sec + HBM GB/s).
 
-A "step" is one full pass of the hot path over one batch: pcv_build_octree on a device-resident cloud
-(chain keys -> key sort -> node split -> leaf encode -> record sort -> promotion/encode), producing the finished
-node table and node-contiguous .xyz/.rgb bytes in HBM. Inputs are resident in HBM when the timed region starts.
+A "step" is one full pass of the hot path over one batch: pcv_build_octree with PCV_BUILD_COMPUTE_BBOX on a
+device-resident cloud — K1 bounding box, path keys / topology, leaf encode, record sort, promotion/encode — producing
+the finished node table and node-contiguous .xyz/.rgb bytes in HBM. Inputs are resident in HBM when the timed region
+starts; nothing is read back except the node table.
 
 Workload at N=1: BASELINE config 2 — 100 M synthetic Gaussian-cluster points (64 clusters in a 1000 m cube,
 sigma in [1, 20] m), f64 SoA xyz + u8 rgb, resolution 1 mm. With --gpus N>1 every rank owns 100 M points of a
-N x 100 M cloud (weak scaling); points are routed to the rank that owns their root octant with ONE all-to-all
+N x 100 M cloud (weak scaling); points are routed to their owner with ONE all-to-all
 (point_cloud_viewer_amd/distributed.py) and each rank builds its subtrees.
+
+Other modes (never the driver's default): --verify adds a byte-for-byte parity record against the CPU oracle on the
+same cloud; --ecef is BASELINE config 5; --query is BASELINE config 4 (frustum path) with relation parity;
+--config1 is BASELINE config 1 (CPU plumbing line, no GPU work timed).
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -21,14 +27,16 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+F64_VALU_PEAK_GINST = 39300  # vector FP64 78.6 TFLOP/s = 39.3 T FMA-instructions/s (SURVEY 8d "Roofline bound")
+ROUND = "r02"
 
-# algorithmic HBM bytes per point and launch of the HBM-bound kernels (DESIGN.md "Kernels")
+# algorithmic HBM bytes per point and launch (DESIGN.md "Kernels"); kernels bound by f64 VALU issue are marked
 ALGO_BYTES = {
     "downsweep_kernel<u64>": 16.0,  # read 8 B key + write 8 B key
     "upsweep_kernel<u64>": 8.0,     # read 8 B key
     "aabb_partial_kernel": 24.0,    # read xyz f64
-    "chain_keys_kernel": 32.0,      # read xyz f64 + write 8 B key
+    "chain_keys_kernel": 28.0,      # read xyz f64 + write 4 B key (8 B when more than 10 levels are keyed)
     "leaf_encode_kernel": 24.0 + 3.0 + 20.0,  # read xyz + rgb, write rank + 16-byte payload
     "downsweep_kernel<u32>": 8.0,   # keys only: read 4 B + write 4 B
     "downsweep_rec_kernel": 2 * 4.0 + 2 * 16.0,  # rank r/w + 16-byte payload r/w
@@ -36,6 +44,7 @@ ALGO_BYTES = {
     "promote_settle_kernel": 20.0 + 7.0 / 8.0 * 9.0,  # read record; 7 of 8 points write ~6 B xyz + 3 B rgb
     "promote_climb_kernel": 4.0 + (16.0 + 9.0) / 8.0,  # read ranks; every 8th point: payload in, xyz + rgb out
 }
+VALU_F64_BOUND = ("leaf_encode_kernel", "chain_keys_kernel")
 
 
 def make_cloud(torch, n, seed, device, clusters=64, extent=1000.0, sigma=(1.0, 20.0), chunk=1 << 24,
@@ -58,11 +67,225 @@ def make_cloud(torch, n, seed, device, clusters=64, extent=1000.0, sigma=(1.0, 2
         p = torch.randn((m, 3), generator=g, dtype=torch.float64, device=device) * sigmas[which, None] + centres[which]
         x[s:s + m], y[s:s + m], z[s:s + m] = p[:, 0], p[:, 1], p[:, 2]
         del p, which
-    idx = torch.arange(n, device=device, dtype=torch.int64)
-    h = (idx * 2654435761) & 0xFFFFFF
-    rgb = torch.stack([(h >> 16) & 255, (h >> 8) & 255, h & 255], dim=1).to(torch.uint8).contiguous()
-    del idx, h
+    rgb = torch.empty((n, 3), dtype=torch.uint8, device=device)
+    for s in range(0, n, chunk):  # chunked: the int64 temporaries of 1 B points would not fit beside the cloud
+        m = min(chunk, n - s)
+        h = (torch.arange(s, s + m, device=device, dtype=torch.int64) * 2654435761) & 0xFFFFFF
+        rgb[s:s + m, 0], rgb[s:s + m, 1], rgb[s:s + m, 2] = (h >> 16) & 255, (h >> 8) & 255, h & 255
+        del h
+    torch.cuda.synchronize(device)  # the library runs on its own stream: the cloud must be complete before it is read
     return x, y, z, rgb
+
+
+def tree_digests(tree):
+    """{node name: (num_points, encoding, digest xyz, digest rgb, digest intensity)} of a built octree (host blobs)."""
+    import ctypes as C
+    import point_cloud_viewer_amd as pcv
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    out = {}
+    for i in range(tree.num_nodes):
+        nd = tree.node(i)
+        dig = []
+        for which in range(3):
+            ptr, ln = C.c_void_p(), C.c_uint64()
+            tree.ctx._check(tree.lib.pcv_octree_node_data(tree.handle, i, which, C.byref(ptr), C.byref(ln)))
+            dig.append(O.node_digest(ptr.value or 0, ln.value))
+        out[pcv.node_name(nd.id_high, nd.id_low)] = (nd.num_points, nd.encoding, dig[0], dig[1], dig[2])
+    return out
+
+
+def verify_build(ctx, resolution, x, y, z, rgb, threads=None):
+    """Byte-for-byte parity of one more build against the closed-form CPU oracle on the SAME cloud: node ids, point
+    counts, encodings and a digest of every node file (reference bar: point_cloud_test/tests/main.rs:10-23 sum of
+    num_points == N, src/octree/generation.rs:289-403 for the bytes)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    n = int(x.numel())
+    t0 = time.perf_counter()
+    tree = ctx.build(resolution, None, x, y, z, rgb)
+    meta = tree.meta()
+    got = tree_digests(tree)
+    info = tree.build_info()
+    tree.free()
+    t1 = time.perf_counter()
+    hx, hy, hz, hrgb = x.cpu().numpy(), y.cpu().numpy(), z.cpu().numpy(), rgb.cpu().numpy()
+    bbox_exact = bool(n == 0 or (np.array_equal(meta["bbox_min"], [hx.min(), hy.min(), hz.min()]) and
+                                 np.array_equal(meta["bbox_max"], [hx.max(), hy.max(), hz.max()])))
+    cores = threads or O.num_procs()
+    want, stats = O.build_closed_digests(resolution, meta["bbox_min"], meta["bbox_max"], hx, hy, hz, hrgb, threads=cores)
+    t2 = time.perf_counter()
+    missing = sorted(set(want) - set(got))
+    extra = sorted(set(got) - set(want))
+    bad = sorted(k for k in set(want) & set(got) if want[k] != got[k])
+    return {"oracle": "closed-form CPU restatement of the reference (oracle/pcv_oracle_build.cpp), not the Rust binary",
+            "points": n, "nodes": len(want), "nodes_gpu": len(got), "missing_nodes": len(missing), "extra_nodes": len(extra),
+            "mismatching_nodes": len(bad), "first_mismatches": (missing + extra + bad)[:5],
+            "sum_num_points_gpu": int(sum(v[0] for v in got.values())), "sum_num_points_oracle": stats["total_points"],
+            "bbox_equals_numpy_minmax": bbox_exact, "max_abs_position_error_m": stats["max_abs_position_error"],
+            "compared": "num_points, encoding, blake2b-128 of .xyz and .rgb of every node",
+            "key_levels": info.get("key_levels"), "attempts": info.get("attempts"),
+            "gpu_build_plus_d2h_s": round(t1 - t0, 2), "oracle_s": round(t2 - t1, 2), "oracle_threads": cores,
+            "ok": not missing and not extra and not bad and bbox_exact}
+
+
+def config1(args):
+    """BASELINE config 1 (plumbing): 1 M uniform points in a local frame placed in ECEF, CPU oracle only."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    n = 1_000_000
+    rng = np.random.Generator(np.random.PCG64(80293751232))
+    local = np.stack([rng.uniform(-100.0, 100.0, n), rng.uniform(-100.0, 100.0, n), rng.uniform(-10.0, 10.0, n)], axis=1)
+    lat, lon = math.radians(37.407204), math.radians(-122.147604)
+    # ENU -> ECEF rotation (columns east, north, up) and the WGS84 position of the origin (src/math/mod.rs:167-183)
+    east = np.array([-math.sin(lon), math.cos(lon), 0.0])
+    north = np.array([-math.sin(lat) * math.cos(lon), -math.sin(lat) * math.sin(lon), math.cos(lat)])
+    up = np.array([math.cos(lat) * math.cos(lon), math.cos(lat) * math.sin(lon), math.sin(lat)])
+    a, f = 6378137.0, 1.0 / 298.257223563
+    e2 = f * (2.0 - f)
+    nn = a / math.sqrt(1.0 - e2 * math.sin(lat) ** 2)
+    origin = np.array([nn * math.cos(lat) * math.cos(lon), nn * math.cos(lat) * math.sin(lon), nn * (1.0 - e2) * math.sin(lat)])
+    rot = np.stack([east, north, up], axis=1)
+    p = local @ rot.T + origin
+    corners = np.array([[sx, sy, sz] for sx in (-100.0, 100.0) for sy in (-100.0, 100.0) for sz in (-10.0, 10.0)]) @ rot.T + origin
+    bmin, bmax = corners.min(axis=0), corners.max(axis=0)  # loose box like synthetic_data.rs:46-50
+    idx = np.arange(n, dtype=np.int64)
+    rgb = np.stack([(idx >> 16) & 255, (idx >> 8) & 255, idx & 255], axis=1).astype(np.uint8)
+    x, y, z = (np.ascontiguousarray(p[:, k]) for k in range(3))
+    cores = O.num_procs()
+    import shutil
+    import tempfile
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    d = tempfile.mkdtemp(prefix="pcv_config1_", dir=base)
+    try:
+        t0 = time.perf_counter()
+        O.build_literal_dir(os.path.join(d, "octree"), 0.001, bmin, bmax, x, y, z, rgb, threads=cores)
+        dt = time.perf_counter() - t0
+        tree = O.load_dir(os.path.join(d, "octree"))
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    closed = O.build_closed(0.001, bmin, bmax, x, y, z, rgb, threads=cores)
+    same = closed.nodes == tree.nodes
+    levels = max(v["level"] for v in tree.nodes.values())
+    return {"metric": "octree-build Mpoints/sec", "value": round(n / dt / 1e6, 3), "unit": "Mpoints/s", "n_gpus": 0,
+            "steps": 1, "warmup": 0, "ms_per_step": round(dt * 1e3, 1), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE config 1: 1 M uniform points (200 x 200 x 20 m local frame placed in ECEF at "
+                                   "lat 37.407204, lon -122.147604), rgb = point index, loose bbox of the box corners, "
+                                   "resolution 1 mm — CPU restatement of the reference only (plumbing line)",
+                       "nodes": len(tree.nodes), "deepest_level": levels, "sum_num_points": tree.total_points(),
+                       "literal_equals_closed_form": bool(same)},
+            "cpu_baseline": {"value": round(n / dt / 1e6, 3), "unit": "Mpoints/s", "cores": cores, "kind": "port",
+                             "sample": f"the whole config-1 cloud, literal file-streaming restatement on tmpfs, {dt:.2f} s"}}
+
+
+def query_bench(args):
+    """BASELINE config 4: octree of the config-2 cloud, F random camera frusta — node relations (K7), visible-node
+    traversal (K7b), batched point query (K8) — with parity of the first --verify-frusta frusta against the oracle."""
+    import numpy as np
+    import torch
+    import point_cloud_viewer_amd as pcv
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+
+    dev = torch.device("cuda", 0)
+    x, y, z, rgb = make_cloud(torch, args.points, seed=1, device=dev)
+    ctx = pcv.Context(0)
+    tree = ctx.build(args.resolution, None, x, y, z, rgb)
+    meta = tree.meta()
+    bmin, bmax = meta["bbox_min"], meta["bbox_max"]
+    M = tree.num_nodes
+    del x, y, z, rgb
+
+    rng = np.random.default_rng(3)
+    persp = O.perspective3_new(1.0, 1.2, 0.1, 100.0)
+    mats = []
+    for _ in range(args.frusta):
+        eye = rng.uniform(bmin, bmax)
+        q = rng.normal(size=4)
+        q = q / math.sqrt(float(((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3]))
+        c, _ = O.frustum_new(eye, q, persp)
+        mats.append(c)
+    shapes = ctx.shapes([("frustum", m) for m in mats])
+    ctx.set_profiling(True)
+    for _ in range(max(1, args.warmup)):
+        rel, sizes = tree.cull_nodes(shapes, with_sizes=True)
+    ctx.reset_kernel_stats()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rel, sizes = tree.cull_nodes(shapes, with_sizes=True)
+    wall_a = (time.perf_counter() - t0) / args.steps
+    ks = ctx.kernel_stats()["cull_nodes_kernel"]
+    cull_ms = ks[1] / ks[0]
+    pairs = args.frusta * M
+
+    ctx.reset_kernel_stats()
+    vis, status = tree.visible_nodes(shapes)
+    ks = ctx.kernel_stats()["visible_nodes_kernel"]
+    vis_ms = ks[1] / ks[0]
+    nvis = np.array([len(v) for v in vis])
+
+    ctx.reset_kernel_stats()
+    kept = 0
+    for f in range(args.cull_frusta):
+        kept += tree.query_points(shapes, f, capacity=1 << 22)["count"]
+    st = ctx.kernel_stats()
+    q_ms = st["cull_points_kernel"][1] + st["query_compact_kernel"][1] + st["nodes_in_location_kernel"][1]
+    big = ctx.shapes([("aabb", bmin, bmin + (bmax - bmin) * 0.63)])
+    ctx.reset_kernel_stats()
+    r = tree.query_points(big, 0, capacity=1)
+    st = ctx.kernel_stats()
+    bpc = {1: 1, 2: 2, 3: 4, 4: 8}
+    visited = tree.nodes_in_location(big)[0]
+    tested = sum(tree.node(int(i)).num_points for i in visited)
+    enc_bytes = sum(tree.node(int(i)).num_points * 3 * bpc[tree.node(int(i)).encoding] for i in visited)
+    big_ms = st["cull_points_kernel"][1]
+    gbs = (enc_bytes + tested) / (big_ms * 1e-3) / 1e9
+
+    # parity + CPU baseline on the first V frusta: relation of every (frustum, node) pair, size on screen, visible lists
+    V = min(args.verify_frusta, args.frusta)
+    cubes = np.array([[*tree.node(i).cube_min, tree.node(i).cube_edge] for i in range(M)])
+    names = tree.node_names()
+    nodes = {names[i]: dict(id=(tree.node(i).id_high, tree.node(i).id_low), num_points=tree.node(i).num_points)
+             for i in range(M)}
+    rel_bad = size_bad = vis_bad = 0
+    t0 = time.perf_counter()
+    for f in range(V):
+        orel, osz = O.cull_cubes(O.SHAPE_FRUSTUM, mats[f], cubes, with_sizes=True)
+        rel_bad += int((orel != rel[f]).sum())
+        size_bad += int((~((osz == sizes[f]) | (np.isnan(osz) & np.isnan(sizes[f])))).sum())
+    cpu_a = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for f in range(V):
+        want = O.get_visible_nodes(bmin, bmax, nodes, mats[f])
+        got = None if status[f] != 0 else [names[int(i)] for i in vis[f]]
+        vis_bad += int(want != got)
+    cpu_b = time.perf_counter() - t0
+    return {"metric": "frustum-cull node pairs/sec", "value": round(pairs / (cull_ms * 1e-3) / 1e6, 1), "unit": "Mpairs/s",
+            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(cull_ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"BASELINE config 4: octree of {args.points / 1e6:g} M Gaussian-cluster points "
+                                   f"({M} nodes), {args.frusta} random camera frusta (Perspective3 aspect 1, fovy 1.2, "
+                                   "near 0.1, far 100), batched transform + cull on 1 GPU", "nodes": M, "frusta": args.frusta},
+            "cull_nodes": {"kernel_ms": round(cull_ms, 3), "wall_ms_incl_D2H": round(wall_a * 1e3, 1), "pairs": pairs,
+                           "relation_histogram": np.bincount(rel.ravel(), minlength=3).tolist()},
+            "visible_nodes": {"kernel_ms": round(vis_ms, 3), "frusta_per_s": round(args.frusta / (vis_ms * 1e-3), 1),
+                              "mean_visible": float(nvis.mean()), "max_visible": int(nvis.max()),
+                              "status_nonzero": int((status != 0).sum())},
+            "query_points": {"frusta": args.cull_frusta, "kept_points": int(kept), "kernel_ms": round(q_ms, 3)},
+            "roofline": {"bound": "hbm", "kernel": "cull_points_kernel", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(enc_bytes + tested), "avg_launch_ms": round(big_ms, 4),
+                         "points_tested": int(tested), "kept": r["count"],
+                         "note": "one AABB over 63 % of the cube per axis: encoded node bytes in, 1 flag byte per point out"},
+            "parity": {"oracle": "CPU restatement (oracle/pcv_oracle_query.cpp), not the Rust binary", "frusta_checked": V,
+                       "pairs_checked": V * M, "relation_mismatches": rel_bad, "size_on_screen_mismatches": size_bad,
+                       "visible_list_mismatches": vis_bad, "ok": rel_bad == 0 and size_bad == 0 and vis_bad == 0},
+            "cpu_baseline": {"value": round(V * M / cpu_a / 1e6, 3), "unit": "Mpairs/s", "cores": 1, "kind": "port",
+                             "sample": f"first {V} frusta x {M} nodes, SAT relation + size on screen, {cpu_a:.1f} s; "
+                                       f"get_visible_nodes: {V / cpu_b:.1f} frusta/s"}}
 
 
 def main():
@@ -77,10 +300,28 @@ def main():
                     help="BASELINE config 5: place the cloud at ECEF magnitudes (|p| ~ 6.4e6 m)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU code path (owner kernel, partition, exchange) even with one rank")
+    ap.add_argument("--shard-mode", choices=["buckets", "octants"], default="buckets",
+                    help="multi-GPU ownership: 64 level-2 buckets bin-packed onto ranks, or root octant c -> rank c % N")
+    ap.add_argument("--verify", action="store_true",
+                    help="after the timed region: one more build compared byte for byte with the CPU oracle")
+    ap.add_argument("--query", action="store_true", help="BASELINE config 4 (frustum path) instead of the build")
+    ap.add_argument("--frusta", type=int, default=10_000)
+    ap.add_argument("--cull-frusta", type=int, default=100)
+    ap.add_argument("--verify-frusta", type=int, default=1000)
+    ap.add_argument("--config1", action="store_true", help="BASELINE config 1 (CPU plumbing line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-to-files end-to-end leg (N=1 only)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with HIP events")
+    ap.add_argument("--fixed-bbox", action="store_true",
+                    help="take the bounding box as an argument (K1 outside the step), as round 1 measured")
     args = ap.parse_args()
+
+    if args.config1:
+        print(json.dumps(config1(args)), flush=True)
+        return
+    if args.query:
+        print(json.dumps(query_bench(args)), flush=True)
+        return
 
     import numpy as np
     import torch
@@ -107,30 +348,33 @@ def main():
 
     n = args.points
     offset = (-2.7e6, -4.3e6, 3.8e6) if args.ecef else (0.0, 0.0, 0.0)
-    x, y, z, rgb = make_cloud(torch, n, seed=1 + rank, device=dev, offset=offset)
-    ctx = pcv.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+    x, y, z, rgb = make_cloud(torch, n, seed=1 + rank, device=dev, offset=offset)  # ends with a device synchronize
+    ctx = pcv.Context(local_rank)  # the library's own stream; torch work is ordered explicitly (wait_torch)
 
-    if world == 1 and not args.force_sharded:
-        bmin, bmax = ctx.aabb_reduce(x, y, z)  # exact min/max bbox (config 2), outside the timed region
-        bbox = pcv.Aabb(bmin, bmax)
-        info = {}
+    sharded = world > 1 or args.force_sharded
+    info = {}
+    if not sharded:
+        bbox = None
+        if args.fixed_bbox:
+            bmin, bmax = ctx.aabb_reduce(x, y, z)
+            bbox = pcv.Aabb(bmin, bmax)
 
         def step():
-            t = ctx.build(args.resolution, bbox, x, y, z, rgb)
+            t = ctx.build(args.resolution, bbox, x, y, z, rgb)  # bbox None: K1 runs inside the step
             info["nodes"], info["stages"], info["build"] = t.num_nodes, t.stage_ms(), t.build_info()
             info.setdefault("gpu_ms", []).append(round(info["stages"]["total"], 3))
             info.setdefault("all_stages", []).append({k: round(v, 2) for k, v in info["stages"].items()})
             t.free()
     else:
         from point_cloud_viewer_amd import distributed as pdist
-        builder = pdist.ShardedOctreeBuilder(ctx, dist, dev)
+        builder = pdist.ShardedOctreeBuilder(ctx, dist, dev, shard_mode=args.shard_mode)
         bbox = builder.global_bbox(x, y, z)
-        info = {}
 
         def step():
             r = builder.build(args.resolution, bbox, x, y, z, rgb)
             info["nodes"], info["stages"] = r.num_nodes_local, r.stage_ms
             info["build"] = r.local.build_info() if hasattr(r.local, "build_info") else None
+            info["exchange"] = r.exchange_info()
             r.free()
 
     def barrier():
@@ -167,73 +411,86 @@ def main():
     total_points = n * world * args.steps
     value = total_points / elapsed / 1e6  # Mpoints/s, whole job
 
-    # dominant kernel by accumulated time (HIP events on the launch stream, inside the timed region)
-    roofline = None
+    roofline, encode_sort = None, None
     timed = {k: v for k, v in kstats.items() if v[0] > 0}
+    plain = n == 100_000_000 and world == 1 and not sharded and not args.ecef
     if timed:
-        dom = max(timed, key=lambda k: timed[k][1])
-        launches, ms = timed[dom]
-        avg_ms = ms / launches
-        gbs = ALGO_BYTES.get(dom, 0.0) * n / (avg_ms * 1e-3) / 1e9
-        # HBM bytes per launch from the PMC passes of the same command (tools/profile_bench.sh -> profiles/): only
-        # quoted for the workload those passes ran (default points, 1 GPU, plain build)
-        traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01_bench_100M_kernel_stats_v5_traffic.json")
-        if os.path.exists(tpath) and n == 100_000_000 and world == 1 and not args.force_sharded and not args.ecef:
-            with open(tpath) as f:
-                traffic = json.load(f)["bytes_per_launch"].get(dom)
-            traffic_src = "profiles/r01_bench_100M_kernel_stats_v5_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 4),
-                    "launches": launches, "algorithmic_bytes_per_launch": ALGO_BYTES.get(dom, 0.0) * n}
-        # VALU-issue view of the two chain kernels, from the committed SQ counters of the same command
-        # (profiles/r01_bench_100M_sq_counters_v5.csv: SQ_INSTS_VALU / SQ_WAVES), the static f64 share of their ISA and
-        # the measured issue cost of a wave64 op on this part (tools/f64_rate.hip): an estimate, labelled as such
-        sq = os.path.join(ROOT, "profiles", "r01_bench_100M_sq_counters_v5.csv")
-        if dom in ("leaf_encode_kernel", "chain_keys_kernel") and os.path.exists(sq) and n == 100_000_000:
-            per_wave = None
-            for line in open(sq).read().splitlines()[1:]:
-                cols = line.split(",")
-                if cols[0].split("<")[0] == dom:
-                    per_wave = float(cols[-1])
-                    break
-            if per_wave:
-                f64_share = 0.68 if dom == "leaf_encode_kernel" else 0.70
-                cyc = per_wave * (f64_share * 5.3 + (1.0 - f64_share) * 2.5)
-                bound_ms = (n / 64.0) * cyc / (1024 * 2.4e9) * 1e3
-                roofline["valu_issue"] = {"insts_per_point": per_wave, "f64_share_static": f64_share,
-                                          "cycles_per_f64_wave_op": 5.3, "cycles_per_32bit_wave_op": 2.5,
-                                          "issue_bound_ms": round(bound_ms, 3), "frac": round(bound_ms / avg_ms, 3),
-                                          "kind": "estimate from profiles/r01_bench_100M_sq_counters_v5.csv + tools/f64_rate.hip"}
-        if dom in ("leaf_encode_kernel", "chain_keys_kernel"):
-            roofline["note"] = ("this kernel is f64-VALU bound by construction (two correctly rounded f64 divisions per "
-                                "coordinate and level; ~5 SIMD cycles per f64 wave-op measured by tools/f64_rate.hip), "
-                                "not HBM bound: see DESIGN.md section 6; the largest HBM-bound kernels are "
-                                "downsweep_rec_kernel and promote_settle_kernel")
-        # encode+sort figure the BASELINE metric names: chain keys + key sort passes
-        # (stage times from the library's stage events: chain keys incl. the depth probe + the key sort)
+        def hbm_view(name):
+            launches, ms = timed[name]
+            avg_ms = ms / launches
+            gbs = ALGO_BYTES.get(name, 0.0) * n / (avg_ms * 1e-3) / 1e9
+            return {"kernel": name, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(gbs / HBM_PEAK_GBS, 4), "avg_launch_ms": round(avg_ms, 4), "launches": launches,
+                    "algorithmic_bytes_per_launch": ALGO_BYTES.get(name, 0.0) * n}
+
+        def pmc(name, key):
+            """Per-launch figure from this round's rocprofv3 PMC passes of the same command (tools/profile_bench.sh)."""
+            path = os.path.join(ROOT, "profiles", f"{ROUND}_bench_100M_{key}.json")
+            if not plain or not os.path.exists(path):
+                return None, None
+            with open(path) as f:
+                return json.load(f).get("per_launch", {}).get(name), os.path.relpath(path, ROOT)
+
+        dom = max(timed, key=lambda k: timed[k][1])  # dominant kernel by accumulated time inside the timed region
+        view = hbm_view(dom)
+        traffic, traffic_src = pmc(dom, "traffic")
+        if dom in VALU_F64_BOUND:
+            # f64-VALU bound by construction (two correctly rounded f64 divisions per coordinate and level): priced
+            # against the vector FP64 issue roof, instructions from the SQ counters of this round's profile of the same
+            # command, f64 share from the disassembly (tools/isa_mix.py)
+            insts, insts_src = pmc(dom, "valu")
+            roofline = {"bound": "valu_f64", "kernel": dom, "peak": F64_VALU_PEAK_GINST, "unit": "G f64-inst/s",
+                        "avg_launch_ms": view["avg_launch_ms"], "launches": view["launches"]}
+            if insts:
+                g = insts["f64_valu_insts_per_point"] * n / (view["avg_launch_ms"] * 1e-3) / 1e9
+                roofline.update({"achieved": round(g, 1), "frac": round(g / F64_VALU_PEAK_GINST, 4),
+                                 "valu_insts_per_point": insts["valu_insts_per_point"], "f64_share": insts["f64_share"],
+                                 "source": insts_src})
+            else:
+                roofline.update({"achieved": None, "frac": None,
+                                 "source": "no SQ-counter pass of this round found (tools/profile_bench.sh)"})
+            roofline["hbm_view"] = dict(view, traffic=traffic, traffic_source=traffic_src)
+            # the largest HBM-bound kernel next to it
+            rest = {k: v for k, v in timed.items() if k not in VALU_F64_BOUND and k in ALGO_BYTES}
+            if rest:
+                hk = max(rest, key=lambda k: rest[k][1])
+                ht, hs = pmc(hk, "traffic")
+                roofline["largest_hbm_kernel"] = dict(hbm_view(hk), bound="hbm", traffic=ht, traffic_source=hs)
+        else:
+            roofline = dict(view, bound="hbm", traffic=traffic, traffic_source=traffic_src)
+        # encode+sort figure the BASELINE metric names: K2 chain keys + key sort (stage events of the last step)
         st = info.get("stages") or {}
         es_ms = st.get("chain_keys", 0.0) + st.get("sort_keys", 0.0)
-        p64 = timed.get("downsweep_kernel<u64>", (0, 0))[0] / args.steps
-        rec_passes = timed.get("downsweep_rec_kernel", (0, 0))[0] / args.steps
-        p32 = timed.get("downsweep_kernel<u32>", (0, 0))[0] / args.steps
-        key32 = (info.get("build") or {}).get("key_levels", 21) <= 10  # the depth probe's own tiny sort is u64
+        key32 = (info.get("build") or {}).get("key_levels", 21) <= 10
         key_bytes = 4.0 if key32 else 8.0
-        passes = p32 if key32 else p64 - (8 if p32 == 0 and p64 > 8 else 0)
+        down = "downsweep_kernel<u32>" if key32 else "downsweep_kernel<u64>"
+        passes = timed.get(down, (0, 0))[0] / args.steps
+        if not key32:
+            passes = max(0.0, passes - 5)  # the depth probe's own tiny u64 sort
+        sort_ms = sum(timed.get(k, (0, 0.0))[1] for k in (down, down.replace("down", "up"), "scan_kernel")) / args.steps
         es_bytes_pp = 24.0 + key_bytes + passes * 3 * key_bytes
+        rec = timed.get("downsweep_rec_kernel")
         encode_sort = {"GB/s": round(n * es_bytes_pp / (es_ms * 1e-3) / 1e9, 1) if es_ms else None,
                        "ms": round(es_ms, 3), "key_bits": int(key_bytes * 8), "sort_passes": passes,
-                       "record_sort_passes": rec_passes, "algorithmic_bytes_per_point": es_bytes_pp}
-    else:
-        encode_sort = None
+                       "algorithmic_bytes_per_point": es_bytes_pp,
+                       "key_sort_only": {"ms": round(sort_ms, 3),
+                                         "GB/s": round(n * passes * 3 * key_bytes / (sort_ms * 1e-3) / 1e9, 1) if sort_ms else None},
+                       "record_sort": None if not rec else {
+                           "passes": rec[0] / args.steps, "ms": round(st.get("sort_records", 0.0), 3),
+                           "GB/s": round(n * (rec[0] / args.steps) * 44.0 / (st.get("sort_records", 1e9) * 1e-3) / 1e9, 1)}}
+
+    parity = None
+    if args.verify and rank == 0 and not sharded:
+        parity = verify_build(ctx, args.resolution, x, y, z, rgb)
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.force_sharded:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not sharded:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import shutil
         import tempfile
         import oracle_lib as O
         cores = O.num_procs()
+        bmin, bmax = ctx.aabb_reduce(x, y, z)
         base = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
         m, cdt = min(args.cpu_sample, n), None
         # the literal build keeps up to ~2 encoded copies of the cloud on the file system (<= 30 B/point) and, like the
@@ -246,7 +503,7 @@ def main():
             d = tempfile.mkdtemp(prefix="pcv_cpu_baseline_", dir=base)
             try:
                 c0 = time.perf_counter()
-                O.build_literal_dir(os.path.join(d, "octree"), args.resolution, bbox.min, bbox.max, hx, hy, hz, hrgb,
+                O.build_literal_dir(os.path.join(d, "octree"), args.resolution, bmin, bmax, hx, hy, hz, hrgb,
                                     threads=cores)
                 cdt = time.perf_counter() - c0
             except Exception as e:  # noqa: BLE001 - reported, then retried smaller
@@ -256,10 +513,12 @@ def main():
                 shutil.rmtree(d, ignore_errors=True)
         cpu = None if cdt is None else {"value": round(m / cdt / 1e6, 3), "unit": "Mpoints/s", "cores": cores, "kind": "port",
                "sample": f"first {m} points of the same cloud, literal file-streaming restatement of the reference "
-                         f"(oracle/pcv_oracle_build.cpp) on tmpfs, {cores} OpenMP threads, {cdt:.1f} s"}
+                         f"(oracle/pcv_oracle_build.cpp) incl. node-file writes on tmpfs, {cores} OpenMP threads, {cdt:.1f} s; "
+                         "scope differs from `value` (device-resident build without file writes) — the like-for-like "
+                         "figure is end_to_end.Mpoints_per_s_incl_files"}
 
     e2e = None
-    if rank == 0 and world == 1 and not args.no_e2e and not args.force_sharded:
+    if rank == 0 and world == 1 and not args.no_e2e and not sharded:
         # One untimed-region pass from HOST arrays to files on tmpfs: H2D staging + build, D2H of the node blobs,
         # threaded file writes. Never part of `value` (tier rule (4)); reported so the PCIe / file-system cost is visible.
         import shutil
@@ -272,7 +531,7 @@ def main():
                 shutil.rmtree(os.path.join(d, "octree"), ignore_errors=True)
                 torch.cuda.synchronize()
                 a0 = time.perf_counter()
-                t = ctx.build(args.resolution, bbox, hx, hy, hz, hrgb)
+                t = ctx.build(args.resolution, None, hx, hy, hz, hrgb)
                 a1 = time.perf_counter()
                 t.node_data(0, 0)  # forces the D2H of all node blobs (pinned host memory)
                 a2 = time.perf_counter()
@@ -286,7 +545,7 @@ def main():
                "write_files_tmpfs_ms": round((a3 - a2) * 1e3, 1), "files": files,
                "Mpoints_per_s_h2d_build_d2h": round(n / (a2 - a0) / 1e6, 1),
                "Mpoints_per_s_incl_files": round(n / (a3 - a0) / 1e6, 1),
-               "note": "pageable numpy inputs; not part of `value`"}
+               "note": "pageable numpy inputs, bounding box computed on the device; not part of `value`"}
 
     if rank == 0:
         out = {
@@ -297,11 +556,13 @@ def main():
             "config": {"workload": ("BASELINE config 5 (ECEF-offset f64 input): " if args.ecef else "BASELINE config 2: ") +
                                    f"{n / 1e6:g} M Gaussian-cluster points (64 clusters, 1000 m cube, "
                                    "sigma 1-20 m), f64 SoA xyz + u8 rgb, resolution 1 mm, full build + LOD promotion",
+                       "scope": "device-resident inputs -> bounding box (K1" + (" outside the step" if args.fixed_bbox else "") +
+                                ") + node table + node-contiguous .xyz/.rgb bytes in HBM; no D2H of the blobs, no file writes",
                        "points_per_gpu": n, "resolution": args.resolution, "nodes": info.get("nodes"),
                        "parallelism": "1 GPU" if world == 1 else
-                       f"{world} GPUs, one process each: 64 level-2 buckets bin-packed onto ranks, one all-to-all(v) over RCCL"},
-            "roofline": roofline, "encode_sort": encode_sort, "cpu_baseline": cpu, "end_to_end": e2e,
-            "build_info": info.get("build"),
+                       f"{world} GPUs, one process each, shard mode {args.shard_mode}: one all-to-all(v) over RCCL"},
+            "roofline": roofline, "encode_sort": encode_sort, "cpu_baseline": cpu, "parity": parity, "end_to_end": e2e,
+            "build_info": info.get("build"), "exchange": info.get("exchange"),
             "stage_ms": {k: round(v, 3) for k, v in (info.get("stages") or {}).items()},
             "wall_ms_each_step": per_step_ms, "gpu_ms_each_step": (info.get("gpu_ms") or [])[-args.steps:],
             "kernel_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in kstats.items() if v[0] > 0},

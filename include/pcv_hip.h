@@ -59,6 +59,16 @@ const char* pcv_last_error(const pcv_ctx* ctx);
 int pcv_abi_version(void);
 /* Wait for everything queued on the context's stream (the few entry points documented as asynchronous). */
 int pcv_ctx_synchronize(pcv_ctx* ctx);
+/* Stream hand-off with the caller's runtime (torch, RCCL, another library) without blocking the host:
+ * pcv_ctx_wait_stream   - everything queued on the context's stream AFTER this call runs after what is queued on
+ *                         `stream` now (the caller produced the inputs there);
+ * pcv_ctx_signal_stream - what is queued on `stream` after this call runs after the context's work queued so far
+ *                         (the caller consumes device-resident outputs there).
+ * `stream` is a hipStream_t of the context's device; NULL names the legacy default stream. Because NULL in
+ * pcv_ctx_create means "own stream", a caller whose work sits on the default stream MUST order it with these two
+ * calls (or synchronise the device) before handing buffers over. */
+int pcv_ctx_wait_stream(pcv_ctx* ctx, void* stream);
+int pcv_ctx_signal_stream(pcv_ctx* ctx, void* stream);
 /* Release cached device/host scratch held by the context. */
 int pcv_ctx_trim(pcv_ctx* ctx);
 
@@ -274,9 +284,11 @@ void pcv_ply_free(pcv_ply* ply);
 
 /* ---- octree loading (viewer side) ------------------------------------------------------------ */
 /* Replaces Octree::from_data_provider over an OnDiskDataProvider (src/octree/mod.rs:156-215,
- * src/data_provider/on_disk.rs): parses meta.pb (versions 9..13 are accepted by the reference; this loader
- * accepts 12/13 layouts written by the current tools) and derives every node's bounding cube
- * (NodeId::find_bounding_cube). Node files are read on demand by pcv_octree_node_data. */
+ * src/data_provider/on_disk.rs): parses meta.pb — versions 9..13 like the reference (9-11: top-level
+ * deprecated_resolution / deprecated_nodes, Vector3f boxes and level/index NodeIds where present; 12: the box inside
+ * OctreeMeta; 13: current), anything else is InvalidVersion — and derives every node's bounding cube
+ * (NodeId::find_bounding_cube). Node files are read on demand by pcv_octree_node_data; the first point query
+ * (pcv_query_points / pcv_cull_node_points) reads all node files once and keeps them device resident. */
 int pcv_octree_open_dir(pcv_ctx* ctx, const char* directory, pcv_octree** out);
 
 /* ---- queries: batched transform-and-cull ------------------------------------------------------ */
@@ -345,7 +357,9 @@ int pcv_cull_node_points(pcv_ctx* ctx, const pcv_shapes* shapes, uint32_t shape_
  * node's decoded positions, then `retain` — here as a stable compaction in (node traversal order, point order).
  * Outputs (capacity entries each; `mem` says where they live): decoded f64 x/y/z, rgb (3 B per point) and, when
  * non-null and the octree has it, intensity. *count = number of points that passed (may exceed capacity: only the
- * first `capacity` are written). Needs a built octree (device-resident node data). */
+ * first `capacity` are written). Works on built octrees and on octrees opened with pcv_octree_open_dir (the
+ * reference's use: stream_points_for_query_in_node -> points_in_node -> NodeIterator over node files,
+ * src/iterator.rs:185-223, src/octree/mod.rs:285-307, src/read_write/node_iterator.rs:24-119). */
 int pcv_query_points(pcv_ctx* ctx, const pcv_shapes* shapes, uint32_t shape_index, pcv_octree* tree, const double* interval,
                      uint64_t capacity, int mem, double* x, double* y, double* z, uint8_t* rgb, float* intensity,
                      uint64_t* count);

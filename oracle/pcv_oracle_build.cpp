@@ -596,6 +596,9 @@ struct Result {
   double resolution = 0;
   std::vector<ResultNode> nodes;
   std::string error;
+  // closed-form build only: max over all stored points and axes of |decode(stored code) - source coordinate|
+  // (the "max abs position error" BASELINE config 5 asks for); -1 when not computed
+  double max_abs_position_error = -1.0;
 };
 
 static void sort_nodes(Result* r) {
@@ -833,7 +836,9 @@ static Result* build_closed(const Aabb& bbox, double resolution, size_t n, const
     if (k0 > nlev) key = d1;
     keys[i] = key;
   }
-  // Top-down stable split of index lists (generation.rs:58-193 without the files).
+  // Top-down stable split of index lists (generation.rs:58-193 without the files). Level-synchronous so the nodes of a
+  // level split in parallel (they are independent); a big node is split by chunks (count, offsets, scatter), which keeps
+  // the order inside every child == the order inside the parent (the stable `retain` of generation.rs:84-90).
   std::vector<CNode> nodes;
   nodes.reserve(1024);
   {
@@ -844,29 +849,87 @@ static Result* build_closed(const Aabb& bbox, double resolution, size_t n, const
     root.parent = -1;
     for (int c = 0; c < 8; ++c) root.child[c] = -1;
     root.pre.resize(n);
+#pragma omp parallel for schedule(static) num_threads(num_threads)
     for (size_t i = 0; i < n; ++i) root.pre[i] = (uint32_t)i;
     nodes.push_back(std::move(root));
   }
-  for (size_t qi = 0; qi < nodes.size(); ++qi) {
-    if (nodes[qi].leaf) continue;
-    int lvl = nodes[qi].level + 1;
-    std::vector<uint32_t> lists[8];
-    for (uint32_t i : nodes[qi].pre) lists[(unsigned)((keys[i] >> (3 * (nlev - lvl))) & 7)].push_back(i);
-    nodes[qi].pre.clear();
-    nodes[qi].pre.shrink_to_fit();
-    for (int c = 0; c < 8; ++c) {
-      if (lists[c].empty()) continue;
-      CNode ch;
-      ch.id = nodes[qi].id.get_child_id((uint8_t)c);
-      ch.level = lvl;
-      ch.parent = (int)qi;
-      for (int k = 0; k < 8; ++k) ch.child[k] = -1;
-      ch.leaf = !((int64_t)lists[c].size() > MAX_POINTS_PER_NODE && t.edge[lvl] > resolution);
-      if (lvl == 1 && ((force_mask >> c) & 1u)) ch.leaf = false;
-      ch.pre = std::move(lists[c]);
-      nodes[qi].child[c] = (int)nodes.size();
-      nodes.push_back(std::move(ch));
+  auto split8 = [&](const std::vector<uint32_t>& pre, int lvl, std::vector<uint32_t>* lists /* [8] */, int threads) {
+    const int shift = 3 * (nlev - lvl);
+    const size_t m = pre.size();
+    if (threads <= 1 || m < (1u << 16)) {
+      for (uint32_t i : pre) lists[(unsigned)((keys[i] >> shift) & 7)].push_back(i);
+      return;
     }
+    const size_t chunks = (size_t)threads;
+    std::vector<size_t> cnt(chunks * 8, 0);
+#pragma omp parallel for schedule(static, 1) num_threads(threads)
+    for (size_t ch = 0; ch < chunks; ++ch) {
+      const size_t b = m * ch / chunks, e = m * (ch + 1) / chunks;
+      size_t local[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (size_t j = b; j < e; ++j) ++local[(unsigned)((keys[pre[j]] >> shift) & 7)];
+      for (int c = 0; c < 8; ++c) cnt[ch * 8 + (size_t)c] = local[c];
+    }
+    std::vector<size_t> off(chunks * 8, 0);
+    for (int c = 0; c < 8; ++c) {
+      size_t acc = 0;
+      for (size_t ch = 0; ch < chunks; ++ch) {
+        off[ch * 8 + (size_t)c] = acc;
+        acc += cnt[ch * 8 + (size_t)c];
+      }
+      lists[c].resize(acc);
+    }
+#pragma omp parallel for schedule(static, 1) num_threads(threads)
+    for (size_t ch = 0; ch < chunks; ++ch) {
+      const size_t b = m * ch / chunks, e = m * (ch + 1) / chunks;
+      size_t at[8];
+      for (int c = 0; c < 8; ++c) at[c] = off[ch * 8 + (size_t)c];
+      for (size_t j = b; j < e; ++j) {
+        const unsigned c = (unsigned)((keys[pre[j]] >> shift) & 7);
+        lists[c][at[c]++] = pre[j];
+      }
+    }
+  };
+  for (size_t level_begin = 0; level_begin < nodes.size();) {
+    const size_t level_end = nodes.size();
+    const size_t width = level_end - level_begin;
+    std::vector<std::vector<uint32_t>> kids(width * 8);
+    // few nodes: split each with all threads; many nodes: one thread per node
+    if (width < (size_t)num_threads) {
+      for (size_t w = 0; w < width; ++w) {
+        CNode& nd = nodes[level_begin + w];
+        if (nd.leaf) continue;
+        split8(nd.pre, nd.level + 1, &kids[w * 8], num_threads);
+      }
+    } else {
+#pragma omp parallel for schedule(dynamic, 1) num_threads(num_threads)
+      for (size_t w = 0; w < width; ++w) {
+        CNode& nd = nodes[level_begin + w];
+        if (nd.leaf) continue;
+        split8(nd.pre, nd.level + 1, &kids[w * 8], 1);
+      }
+    }
+    for (size_t w = 0; w < width; ++w) {
+      const size_t qi = level_begin + w;
+      if (nodes[qi].leaf) continue;
+      const int lvl = nodes[qi].level + 1;
+      nodes[qi].pre.clear();
+      nodes[qi].pre.shrink_to_fit();
+      for (int c = 0; c < 8; ++c) {
+        std::vector<uint32_t>& list = kids[w * 8 + (size_t)c];
+        if (list.empty()) continue;
+        CNode ch;
+        ch.id = nodes[qi].id.get_child_id((uint8_t)c);
+        ch.level = lvl;
+        ch.parent = (int)qi;
+        for (int k = 0; k < 8; ++k) ch.child[k] = -1;
+        ch.leaf = !((int64_t)list.size() > MAX_POINTS_PER_NODE && t.edge[lvl] > resolution);
+        if (lvl == 1 && ((force_mask >> c) & 1u)) ch.leaf = false;
+        ch.pre = std::move(list);
+        nodes[qi].child[c] = (int)nodes.size();
+        nodes.push_back(std::move(ch));
+      }
+    }
+    level_begin = level_end;
   }
   // Bottom-up promotion (generation.rs:195-253, 335-387): nodes[] is in BFS order, so reverse order
   // visits children before parents.
@@ -905,6 +968,7 @@ static Result* build_closed(const Aabb& bbox, double resolution, size_t n, const
       }
     }
   }
+#pragma omp parallel for schedule(dynamic, 16) num_threads(num_threads)
   for (size_t qi = 0; qi < nodes.size(); ++qi) {
     CNode& nd = nodes[qi];
     const bool global = layout && nd.level <= 1;
@@ -923,7 +987,8 @@ static Result* build_closed(const Aabb& bbox, double resolution, size_t n, const
   // Bytes: replay the chain down to the leaf level, then decode/encode upward, plus the one rewrite
   // every non-root node undergoes (generation.rs:230-238).
   r->nodes.resize(nodes.size());
-#pragma omp parallel for schedule(dynamic, 1) num_threads(num_threads)
+  double max_err = 0.0;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(num_threads) reduction(max : max_err)
   for (size_t qi = 0; qi < nodes.size(); ++qi) {
     const CNode& nd = nodes[qi];
     ResultNode& out = r->nodes[qi];
@@ -974,12 +1039,20 @@ static Result* build_closed(const Aabb& bbox, double resolution, size_t n, const
           code[a] = encode_coord(enc, q, mins[nd.level][a], t.edge[nd.level]);
         }
       for (int a = 0; a < 3; ++a) put_le(&out.xyz[(3 * s + (size_t)a) * (size_t)bpc], code[a], bpc);
+      if (!routed) {  // what a reader of this node file gets back (raw.rs:141-215) against the source coordinate
+        const double src[3] = {x[i], y[i], z[i]};
+        for (int a = 0; a < 3; ++a) {
+          const double err = std::fabs(decode_coord(enc, code[a], mins[nd.level][a], t.edge[nd.level]) - src[a]);
+          if (err > max_err) max_err = err;  // NaN sources compare false and are skipped
+        }
+      }
       out.rgb[3 * s] = rgb[3 * (size_t)i];
       out.rgb[3 * s + 1] = rgb[3 * (size_t)i + 1];
       out.rgb[3 * s + 2] = rgb[3 * (size_t)i + 2];
       if (intensity) std::memcpy(&out.intensity[4 * s], &intensity[i], 4);
     }
   }
+  r->max_abs_position_error = routed ? -1.0 : max_err;
   sort_nodes(r);
   return r;
 }
@@ -1179,6 +1252,7 @@ void* pcvo_load_dir(const char* dir) {
   return load_result(be);
 }
 
+double pcvo_result_max_abs_position_error(void* h) { return ((Result*)h)->max_abs_position_error; }
 const char* pcvo_result_error(void* h) { return ((Result*)h)->error.c_str(); }
 int pcvo_result_version(void* h) { return ((Result*)h)->version; }
 double pcvo_result_resolution(void* h) { return ((Result*)h)->resolution; }

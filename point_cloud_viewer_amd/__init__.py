@@ -4,7 +4,8 @@ The package is a thin host mirror of the reference's interface for this path; al
 libpcv_hip.so (point_cloud_viewer_amd/csrc). Importing does not require a GPU; calling does.
 """
 from . import _lib
-from ._lib import PcvError, load_library  # noqa: F401
+from ._lib import (PCV_E_DEPTH, PCV_E_HIP, PCV_E_INVALID, PCV_E_IO, PCV_E_NOT_FOUND, PCV_E_OOM, PCV_OK,  # noqa: F401
+                   PcvError, load_library)
 from .octree import (Aabb, Context, OctreeResult, Shapes, build_octree, build_octree_from_file, level_table,  # noqa: F401
                      node_name, read_ply)
 

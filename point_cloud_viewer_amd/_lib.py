@@ -84,6 +84,8 @@ _SIGNATURES = {
     "pcv_last_error": (C.c_char_p, [_vp]),
     "pcv_ctx_trim": (C.c_int, [_vp]),
     "pcv_ctx_synchronize": (C.c_int, [_vp]),
+    "pcv_ctx_wait_stream": (C.c_int, [_vp, _vp]),
+    "pcv_ctx_signal_stream": (C.c_int, [_vp, _vp]),
     "pcv_ctx_set_profiling": (C.c_int, [_vp, C.c_int]),
     "pcv_ctx_reset_kernel_stats": (C.c_int, [_vp]),
     "pcv_ctx_kernel_stats": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64),

@@ -187,6 +187,10 @@ extern "C" int pcv_ctx_create(int device, void* stream, pcv_ctx** out) {
       delete c;
       return PCV_E_HIP;
     }
+  if (hipEventCreateWithFlags(&c->xev, hipEventDisableTiming) != hipSuccess) {
+    delete c;
+    return PCV_E_HIP;
+  }
   *out = c;
   return PCV_OK;
 }
@@ -203,6 +207,7 @@ extern "C" void pcv_ctx_destroy(pcv_ctx* ctx) {
   for (auto& kv : ctx->host_live) (void)hipHostFree(kv.first);
   for (auto& e : ctx->ev)
     if (e) (void)hipEventDestroy(e);
+  if (ctx->xev) (void)hipEventDestroy(ctx->xev);
   for (auto& p : ctx->prof_pending) {
     (void)hipEventDestroy(p.a);
     (void)hipEventDestroy(p.b);
@@ -218,6 +223,25 @@ extern "C" int pcv_ctx_synchronize(pcv_ctx* ctx) {
   if (!ctx) return PCV_E_INVALID;
   PCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   PCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return PCV_OK;
+}
+
+// Stream hand-off with the caller's runtime (torch, RCCL): order the context's stream after / before another stream
+// of the same device without blocking the host. `stream` may be NULL: the legacy default stream (torch's default).
+extern "C" int pcv_ctx_wait_stream(pcv_ctx* ctx, void* stream) {
+  if (!ctx) return PCV_E_INVALID;
+  if ((hipStream_t)stream == ctx->stream) return PCV_OK;
+  PCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  PCV_HIP_CHECK(ctx, hipEventRecord(ctx->xev, (hipStream_t)stream));
+  PCV_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->xev, 0));
+  return PCV_OK;
+}
+extern "C" int pcv_ctx_signal_stream(pcv_ctx* ctx, void* stream) {
+  if (!ctx) return PCV_E_INVALID;
+  if ((hipStream_t)stream == ctx->stream) return PCV_OK;
+  PCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  PCV_HIP_CHECK(ctx, hipEventRecord(ctx->xev, ctx->stream));
+  PCV_HIP_CHECK(ctx, hipStreamWaitEvent((hipStream_t)stream, ctx->xev, 0));
   return PCV_OK;
 }
 

@@ -80,6 +80,7 @@ struct pcv_ctx {
   void* pinned = nullptr;
   size_t pinned_bytes = 0;
   hipEvent_t ev[PCV_NUM_STAGES + 2] = {};
+  hipEvent_t xev = nullptr;  // stream hand-off with the caller's runtime (pcv_ctx_wait_stream / _signal_stream)
 
   // per-launch profile: event pairs recorded on `stream`, resolved after the next stream sync
   bool profiling = false;
@@ -283,6 +284,7 @@ struct pcv_octree {
 int pcv_octree_prepare_query(pcv_octree* t);
 void pcv_octree_release_query(pcv_octree* t);
 int pcv_octree_fetch_host(pcv_octree* t);
+int pcv_octree_load_device(pcv_octree* t);  // directory octrees: read + upload all node files (pcv_io.cpp)
 int pcv_octree_read_node_file(pcv_octree* t, uint64_t i, int which, const uint8_t** data, uint64_t* len);
 int pcv_bytes_per_coordinate(uint32_t enc);
 

@@ -221,22 +221,44 @@ struct Reader {
   }
 };
 
+// Vector3d (fixed64 fields) or Vector3f (fixed32 fields, proto.proto:27-31) into doubles
 void read_vec3(Reader r, double v[3]) {
   v[0] = v[1] = v[2] = 0.;
   while (r.p < r.end && r.ok) {
     uint64_t t = r.varint();
     int f = (int)(t >> 3), w = (int)(t & 7);
     if (w == 1 && f >= 1 && f <= 3) v[f - 1] = r.f64();
-    else r.skip(w);
+    else if (w == 5 && f >= 1 && f <= 3 && r.end - r.p >= 4) {
+      uint32_t u = 0;
+      for (int i = 0; i < 4; ++i) u |= (uint32_t)r.p[i] << (8 * i);
+      r.p += 4;
+      float fl;
+      std::memcpy(&fl, &u, 4);
+      v[f - 1] = (double)fl;  // proto::Vector3d::from(Vector3f): plain widening
+    } else r.skip(w);
   }
 }
+// impl From<&proto::AxisAlignedCuboid> for Aabb (src/geometry/aabb.rs:69-84): min/max (fields 3/4, Vector3d), else the
+// deprecated Vector3f fields 1/2 of version <= 10
 void read_cuboid(Reader c, double mn[3], double mx[3]) {
+  bool have_min = false, have_max = false;
+  double dmn[3] = {0, 0, 0}, dmx[3] = {0, 0, 0};
   while (c.p < c.end && c.ok) {
     uint64_t t = c.varint();
     int f = (int)(t >> 3), w = (int)(t & 7);
-    if (f == 3 && w == 2) read_vec3(c.sub(), mn);
-    else if (f == 4 && w == 2) read_vec3(c.sub(), mx);
+    if (f == 3 && w == 2) {
+      read_vec3(c.sub(), mn);
+      have_min = true;
+    } else if (f == 4 && w == 2) {
+      read_vec3(c.sub(), mx);
+      have_max = true;
+    } else if (f == 1 && w == 2) read_vec3(c.sub(), dmn);
+    else if (f == 2 && w == 2) read_vec3(c.sub(), dmx);
     else c.skip(w);
+  }
+  for (int a = 0; a < 3; ++a) {
+    if (!have_min) mn[a] = dmn[a];
+    if (!have_max) mx[a] = dmx[a];
   }
 }
 
@@ -247,11 +269,20 @@ bool read_file(const std::string& path, std::vector<uint8_t>* out, bool* missing
     *missing = true;
     return false;
   }
-  fseek(f, 0, SEEK_END);
-  long sz = ftell(f);
-  fseek(f, 0, SEEK_SET);
-  out->resize((size_t)sz);
-  size_t got = sz ? fread(out->data(), 1, (size_t)sz, f) : 0;
+  long sz = -1;
+  if (fseek(f, 0, SEEK_END) == 0) sz = ftell(f);
+  if (sz < 0 || fseek(f, 0, SEEK_SET) != 0) {  // not seekable (a directory, a pipe): an I/O error, not a huge resize
+    fclose(f);
+    return false;
+  }
+  size_t got = 0;
+  try {
+    out->resize((size_t)sz);
+    got = sz ? fread(out->data(), 1, (size_t)sz, f) : 0;
+  } catch (...) {  // std::bad_alloc must not cross the C ABI
+    fclose(f);
+    return false;
+  }
   fclose(f);
   return got == (size_t)sz;
 }
@@ -269,48 +300,66 @@ extern "C" int pcv_octree_open_dir(pcv_ctx* ctx, const char* directory, pcv_octr
     return ctx->fail(missing ? PCV_E_NOT_FOUND : PCV_E_IO, "cannot read " + dir + "/meta.pb");
   int version = 0;
   double bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0}, resolution = 0;
+  double obmin[3] = {0, 0, 0}, obmax[3] = {0, 0, 0}, old_resolution = 0;  // version 12 / versions <= 11
   bool has_octree = false;
   struct RawNode {
     uint64_t hi, lo;
     int64_t num_points;
     uint32_t enc;
   };
-  std::vector<RawNode> raw;
+  std::vector<RawNode> raw, old_raw;
+  // proto::OctreeNode (proto.proto:90-94) incl. the NodeId of version 9 (deprecated_level / deprecated_index,
+  // NodeId::from_proto node.rs:89-99)
+  auto read_node = [](Reader n, RawNode* rn) {
+    *rn = RawNode{0, 0, 0, 0};
+    while (n.p < n.end && n.ok) {
+      uint64_t nt = n.varint();
+      int nf = (int)(nt >> 3), nw = (int)(nt & 7);
+      if (nf == 2 && nw == 0) rn->enc = (uint32_t)n.varint();
+      else if (nf == 3 && nw == 0) rn->num_points = (int64_t)n.varint();
+      else if (nf == 4 && nw == 2) {
+        Reader id = n.sub();
+        uint64_t dep_level = 0, dep_index = 0;
+        while (id.p < id.end && id.ok) {
+          uint64_t it = id.varint();
+          int idf = (int)(it >> 3), idw = (int)(it & 7);
+          if (idf == 3 && idw == 0) rn->hi = id.varint();
+          else if (idf == 4 && idw == 0) rn->lo = id.varint();
+          else if (idf == 1 && idw == 0) dep_level = id.varint() & 0xffu;  // `as u8`
+          else if (idf == 2 && idw == 0) dep_index = id.varint();
+          else id.skip(idw);
+        }
+        if (!id.ok) n.ok = false;
+        if (dep_level != 0 || dep_index != 0) {  // from_level_index(level, index as u128): i64 -> u128 sign-extends
+          rn->hi = (dep_level << 56) | (((int64_t)dep_index < 0) ? ~0ull : 0ull);
+          rn->lo = dep_index;
+        }
+      } else n.skip(nw);
+    }
+    return n.ok;
+  };
   Reader r{buf.data(), buf.data() + buf.size()};
   while (r.p < r.end && r.ok) {
     uint64_t t = r.varint();
     int f = (int)(t >> 3), w = (int)(t & 7);
     if (f == 1 && w == 0) version = (int)r.varint();
     else if (f == 4 && w == 2) read_cuboid(r.sub(), bmin, bmax);
-    else if (f == 6 && w == 2) {
+    else if (f == 3 && w == 1) old_resolution = r.f64();  // deprecated_resolution (versions <= 11)
+    else if (f == 5 && w == 2) {                          // deprecated_nodes (versions <= 11)
+      RawNode rn;
+      if (!read_node(r.sub(), &rn)) r.ok = false;
+      old_raw.push_back(rn);
+    } else if (f == 6 && w == 2) {
       has_octree = true;
       Reader o = r.sub();
       while (o.p < o.end && o.ok) {
         uint64_t ot = o.varint();
         int of = (int)(ot >> 3), ow = (int)(ot & 7);
         if (of == 2 && ow == 1) resolution = o.f64();
-        else if (of == 1 && ow == 2 && version == 12) read_cuboid(o.sub(), bmin, bmax);  // deprecated_bounding_box
+        else if (of == 1 && ow == 2) read_cuboid(o.sub(), obmin, obmax);  // deprecated_bounding_box (version 12)
         else if (of == 3 && ow == 2) {
-          Reader n = o.sub();
-          RawNode rn{0, 0, 0, 0};
-          while (n.p < n.end && n.ok) {
-            uint64_t nt = n.varint();
-            int nf = (int)(nt >> 3), nw = (int)(nt & 7);
-            if (nf == 2 && nw == 0) rn.enc = (uint32_t)n.varint();
-            else if (nf == 3 && nw == 0) rn.num_points = (int64_t)n.varint();
-            else if (nf == 4 && nw == 2) {
-              Reader id = n.sub();
-              while (id.p < id.end && id.ok) {
-                uint64_t it = id.varint();
-                int idf = (int)(it >> 3), idw = (int)(it & 7);
-                if (idf == 3 && idw == 0) rn.hi = id.varint();
-                else if (idf == 4 && idw == 0) rn.lo = id.varint();
-                else id.skip(idw);
-              }
-              if (!id.ok) n.ok = false;
-            } else n.skip(nw);
-          }
-          if (!n.ok) o.ok = false;
+          RawNode rn;
+          if (!read_node(o.sub(), &rn)) o.ok = false;
           raw.push_back(rn);
         } else o.skip(ow);
       }
@@ -318,8 +367,23 @@ extern "C" int pcv_octree_open_dir(pcv_ctx* ctx, const char* directory, pcv_octr
     } else r.skip(w);
   }
   if (!r.ok) return ctx->fail(PCV_E_INVALID, "Could not parse meta.pb");
-  if (version != 12 && version != 13) return ctx->fail(PCV_E_INVALID, "InvalidVersion(" + std::to_string(version) + ")");
-  if (!has_octree) return ctx->fail(PCV_E_INVALID, "No octree meta found");
+  // Octree::from_data_provider (octree/mod.rs:156-215): 9 | 10 | 11 read the top-level fields, 12 | 13 the OctreeMeta
+  if (version >= 9 && version <= 11) {
+    resolution = old_resolution;
+    raw.swap(old_raw);
+  } else if (version == 12 || version == 13) {
+    if (!has_octree) return ctx->fail(PCV_E_INVALID, "No octree meta found");
+    if (version == 12)
+      for (int a = 0; a < 3; ++a) {
+        bmin[a] = obmin[a];
+        bmax[a] = obmax[a];
+      }
+  } else {
+    return ctx->fail(PCV_E_INVALID, "InvalidVersion(" + std::to_string(version) + ")");
+  }
+  for (const RawNode& rn : raw)
+    if ((rn.hi >> 56) > (uint64_t)PCV_MAX_LEVELS)  // 120 index bits name 40 levels (node.rs:101-111); also keeps every shift below in range
+      return ctx->fail(PCV_E_INVALID, "meta.pb: node level " + std::to_string(rn.hi >> 56) + " exceeds what a NodeId can name");
 
   pcv_octree* t = new pcv_octree();
   t->ctx = ctx;
@@ -369,7 +433,7 @@ extern "C" int pcv_octree_open_dir(pcv_ctx* ctx, const char* directory, pcv_octr
     ni.point_offset = point_off;
     ni.xyz_offset = xyz_off;
     point_off += (uint64_t)ni.num_points;
-    xyz_off += (uint64_t)ni.num_points * 3 * (uint64_t)pcv_bytes_per_coordinate(ni.encoding);
+    xyz_off += ((uint64_t)ni.num_points * 3 * (uint64_t)pcv_bytes_per_coordinate(ni.encoding) + 15) & ~15ull;  // as built trees
   }
   // intensity is implied by the presence of the root's .intensity file (octree/mod.rs:57-74 hard-codes both)
   struct stat st;
@@ -396,5 +460,89 @@ int pcv_octree_read_node_file(pcv_octree* t, uint64_t i, int which, const uint8_
   }
   *data = it->second.data();
   *len = it->second.size();
+  return PCV_OK;
+}
+
+// N3 on an octree that lives on disk (src/iterator.rs:185-223 -> Octree::points_in_node, octree/mod.rs:285-307 ->
+// NodeIterator, read_write/node_iterator.rs:24-119): every node file is read once (pool of host threads, straight
+// into pinned blobs laid out like a built tree's) and uploaded; the cull / query kernels then decode on load exactly
+// as they do for a tree built in this process. File sizes are checked against meta.pb's num_points.
+int pcv_octree_load_device(pcv_octree* t) {
+  pcv_ctx* ctx = t->ctx;
+  if (t->d_xyz || t->directory.empty() || t->nodes.empty()) return PCV_OK;
+  const pcv_node_info& last = t->nodes.back();
+  t->xyz_bytes = last.xyz_offset + (((uint64_t)last.num_points * 3 * (uint64_t)pcv_bytes_per_coordinate(last.encoding) + 15) & ~15ull);
+  t->rgb_bytes = t->num_points * 3;
+  t->int_bytes = t->has_intensity ? t->num_points * 4 : 0;
+  if (t->num_points == 0) return PCV_OK;
+  PCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = ctx->host_alloc((void**)&t->h_xyz.p, t->xyz_bytes)) || (rc = ctx->host_alloc((void**)&t->h_rgb.p, t->rgb_bytes)) ||
+      (t->int_bytes && (rc = ctx->host_alloc((void**)&t->h_int.p, t->int_bytes))))
+    return rc;
+  const size_t count = t->nodes.size();
+  unsigned nthreads = std::thread::hardware_concurrency();
+  if (nthreads == 0) nthreads = 4;
+  if (nthreads > 32) nthreads = 32;
+  if (nthreads > count) nthreads = (unsigned)count;
+  std::atomic<size_t> next{0};
+  std::atomic<int> failed{0};
+  std::string first_error;
+  std::mutex err_mu;
+  auto read_into = [](const std::string& path, uint8_t* dst, uint64_t want) -> const char* {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return "cannot open ";
+    const size_t got = fread(dst, 1, (size_t)want, f);
+    uint8_t extra;
+    const bool longer = got == want && fread(&extra, 1, 1, f) == 1;
+    fclose(f);
+    if (got != want || longer) return "size does not match meta.pb's num_points: ";
+    return nullptr;
+  };
+  auto worker = [&]() {
+    for (;;) {
+      const size_t i = next.fetch_add(1);
+      if (i >= count || failed.load()) return;
+      const pcv_node_info& n = t->nodes[i];
+      if (n.num_points <= 0) continue;  // node_writer.rs:78-89: empty nodes have no files
+      const std::string stem = t->directory + "/" + node_name(n);
+      const uint64_t np = (uint64_t)n.num_points;
+      const uint64_t xb = np * 3 * (uint64_t)pcv_bytes_per_coordinate(n.encoding);
+      const char* bad = read_into(stem + ".xyz", t->h_xyz.p + n.xyz_offset, xb);
+      std::string which = ".xyz";
+      if (!bad) {
+        std::memset(t->h_xyz.p + n.xyz_offset + xb, 0, (size_t)(((xb + 15) & ~15ull) - xb));
+        bad = read_into(stem + ".rgb", t->h_rgb.p + n.point_offset * 3, np * 3);
+        which = ".rgb";
+      }
+      if (!bad && t->has_intensity) {
+        bad = read_into(stem + ".intensity", t->h_int.p + n.point_offset * 4, np * 4);
+        which = ".intensity";
+      }
+      if (bad) {
+        std::lock_guard<std::mutex> g(err_mu);
+        if (!failed.exchange(1)) first_error = std::string(bad) + stem + which;
+      }
+    }
+  };
+  std::vector<std::thread> pool;
+  for (unsigned k = 1; k < nthreads; ++k) pool.emplace_back(worker);
+  worker();
+  for (auto& th : pool) th.join();
+  if (failed.load()) return ctx->fail(PCV_E_IO, first_error);
+  void *dx = nullptr, *dr = nullptr, *di = nullptr;
+  if ((rc = ctx->dev_alloc(&dx, t->xyz_bytes))) return rc;
+  t->d_xyz = (uint8_t*)dx;
+  if ((rc = ctx->dev_alloc(&dr, t->rgb_bytes))) return rc;
+  t->d_rgb = (uint8_t*)dr;
+  if (t->int_bytes) {
+    if ((rc = ctx->dev_alloc(&di, t->int_bytes))) return rc;
+    t->d_int = (uint8_t*)di;
+  }
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(t->d_xyz, t->h_xyz.p, t->xyz_bytes, hipMemcpyHostToDevice, ctx->stream));
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(t->d_rgb, t->h_rgb.p, t->rgb_bytes, hipMemcpyHostToDevice, ctx->stream));
+  if (t->int_bytes) PCV_HIP_CHECK(ctx, hipMemcpyAsync(t->d_int, t->h_int.p, t->int_bytes, hipMemcpyHostToDevice, ctx->stream));
+  PCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  t->host_valid = true;
   return PCV_OK;
 }

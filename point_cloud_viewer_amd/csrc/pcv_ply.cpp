@@ -188,14 +188,30 @@ extern "C" int pcv_ply_read(const char* path, pcv_ply** out, char* err, uint64_t
   if (ply->has_color && (props[ir].type != T_U8 || props[ig].type != T_U8 || props[ib].type != T_U8))
     return bail(PCV_E_INVALID, "colour properties must be uchar");
   ply->has_intensity = ii >= 0;
+  // The header is untrusted: a vertex count that the rest of the file cannot hold (negative, absurd) is rejected
+  // before anything is sized by it, and no allocation failure may unwind across the C ABI.
+  if (vertex_count < 0) return bail(PCV_E_INVALID, "negative vertex count");
+  {
+    const long body = ftell(f);
+    long total = -1;
+    if (body >= 0 && fseek(f, 0, SEEK_END) == 0) total = ftell(f);
+    if (body < 0 || total < body || fseek(f, body, SEEK_SET) != 0) return bail(PCV_E_IO, "cannot measure the vertex data");
+    if (stride <= 0 || (unsigned long long)vertex_count > (unsigned long long)(total - body) / (unsigned long long)stride)
+      return bail(PCV_E_IO, "unexpected end of file in the vertex data");
+  }
   const size_t n = (size_t)vertex_count;
-  ply->x.resize(n);
-  ply->y.resize(n);
-  ply->z.resize(n);
-  if (ply->has_color) ply->rgb.resize(3 * n);
-  if (ply->has_intensity) ply->intensity.resize(n);
   const size_t chunk_pts = 1 << 16;
-  std::vector<uint8_t> buf(chunk_pts * (size_t)stride);
+  std::vector<uint8_t> buf;
+  try {
+    ply->x.resize(n);
+    ply->y.resize(n);
+    ply->z.resize(n);
+    if (ply->has_color) ply->rgb.resize(3 * n);
+    if (ply->has_intensity) ply->intensity.resize(n);
+    buf.resize(chunk_pts * (size_t)stride);
+  } catch (...) {
+    return bail(PCV_E_OOM, "out of host memory for " + std::to_string(n) + " points");
+  }
   for (size_t done = 0; done < n;) {
     const size_t m = std::min(chunk_pts, n - done);
     if (fread(buf.data(), (size_t)stride, m, f) != m) return bail(PCV_E_IO, "unexpected end of file in the vertex data");

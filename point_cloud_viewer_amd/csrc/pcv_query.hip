@@ -1017,7 +1017,10 @@ extern "C" int pcv_cull_node_points(pcv_ctx* ctx, const pcv_shapes* shapes, uint
                                     uint64_t node, const double* interval, uint8_t* keep, uint64_t* kept) {
   if (!ctx) return PCV_E_INVALID;
   if (!tree || node >= tree->nodes.size()) return ctx->fail(PCV_E_INVALID, "bad node");
-  if (!tree->d_xyz) return ctx->fail(PCV_E_INVALID, "octree has no device-resident node data (opened from a directory: use pcv_cull_points on decoded data)");
+  if (!tree->d_xyz) {  // an octree opened from a directory: node files are uploaded on first use
+    int lrc = pcv_octree_load_device(tree);
+    if (lrc) return lrc;
+  }
   const pcv_node_info& n = tree->nodes[node];
   PointsView v{};
   v.n = (uint64_t)n.num_points;
@@ -1107,7 +1110,10 @@ extern "C" int pcv_query_points(pcv_ctx* ctx, const pcv_shapes* shapes, uint32_t
   if (mem != PCV_MEM_HOST && mem != PCV_MEM_DEVICE) return ctx->fail(PCV_E_INVALID, "bad mem");
   *count = 0;
   if (tree->nodes.empty()) return PCV_OK;
-  if (!tree->d_xyz) return ctx->fail(PCV_E_INVALID, "octree has no device-resident node data (opened from a directory)");
+  if (!tree->d_xyz) {  // an octree opened from a directory: node files are uploaded on first use
+    int lrc = pcv_octree_load_device(tree);
+    if (lrc) return lrc;
+  }
   if (interval && !tree->has_intensity) return ctx->fail(PCV_E_INVALID, "octree has no intensity attribute to filter on");
   int rc = pcv_octree_prepare_query(tree);
   if (rc) return rc;

@@ -37,10 +37,12 @@ def _ceil8(v):
     return (int(v) + 7) // 8
 
 
-def plan_buckets(global_counts, world, max_points_per_node, level1_can_split):
+def plan_buckets(global_counts, world, max_points_per_node, level1_can_split, mode="buckets"):
     """(rank_of_bucket[64], split_mask) from the GLOBAL bucket counts — pure and deterministic, every rank computes the
-    same plan. Units are single buckets below level-1 nodes the global tree splits, whole octants otherwise; units go
-    largest-first to the least-loaded rank (ties: lower bucket, lower rank)."""
+    same plan. mode "buckets" (the skew remedy of SURVEY §8e): units are single buckets below level-1 nodes the global
+    tree splits, whole octants otherwise; units go largest-first to the least-loaded rank (ties: lower bucket, lower
+    rank). mode "octants" (BASELINE north_star: shard by the top-3-bit prefix): root octant c belongs to rank c % world,
+    whatever it holds. The finished octree is the same either way; only the load balance differs."""
     g = np.asarray(global_counts, dtype=np.int64).reshape(8, 8)
     octant = g.sum(axis=1)
     units, split_mask = [], 0
@@ -50,6 +52,10 @@ def plan_buckets(global_counts, world, max_points_per_node, level1_can_split):
             units += [(int(g[c, d]), [c * 8 + d]) for d in range(8) if g[c, d] > 0]
         elif octant[c] > 0:
             units.append((int(octant[c]), list(range(c * 8, c * 8 + 8))))
+    if mode == "octants":
+        return np.repeat(np.arange(8, dtype=np.uint8) % world, 8), split_mask
+    if mode != "buckets":
+        raise ValueError("shard mode must be 'buckets' or 'octants'")
     rank_of = np.zeros(64, dtype=np.uint8)
     loads = [0] * world
     for weight, buckets in sorted(units, key=lambda u: (-u[0], u[1][0])):
@@ -125,6 +131,15 @@ class HipBackend:
         """Stable partition of the planes by owner straight into the destination views (count / scan / scatter)."""
         self.ctx.partition_by_owner(bucket, planes, dsts, rank_of_bucket)
 
+    def after_torch(self):
+        """Order the library's stream after torch's current stream: the exchange (RCCL) and torch fills run there, and
+        `work.wait()` of an RCCL op only blocks that stream, not the host (the context owns a different stream)."""
+        self.ctx.wait_torch()
+
+    def before_torch(self):
+        """Order torch's current stream after the library's queued work (asynchronous node copies)."""
+        self.ctx.signal_torch()
+
     def build_begin(self, resolution, bbox, x, y, z, rgb, intensity, max_points_per_node, force_split_level1):
         return self.ctx.build_begin(resolution, bbox, x, y, z, rgb, intensity, max_points_per_node, force_split_level1)
 
@@ -145,6 +160,7 @@ class ShardedOctree:
         self._stage_ms = stage_ms
         self.counts = counts        # world x world matrix: counts[src][dst]
         self.plan = plan            # (rank_of_bucket, split_mask)
+        self.bytes_per_row = 0      # exchange payload per point (set by the builder)
 
     @property
     def num_nodes_local(self):
@@ -159,6 +175,21 @@ class ShardedOctree:
     def free(self):
         if hasattr(self.local, "free"):
             self.local.free()
+
+    def exchange_info(self):
+        """What this rank moved through the all-to-all(v): rows and bytes sent to / received from OTHER ranks, the
+        load balance of the plan (points owned per rank), and the stage times."""
+        m = np.asarray(self.counts, dtype=np.int64)
+        rank = self.builder.rank
+        bpr = self.bytes_per_row
+        sent = int(m[rank].sum() - m[rank, rank])
+        recv = int(m[:, rank].sum() - m[rank, rank])
+        owned = m.sum(axis=0)
+        return {"ranks": int(m.shape[0]), "shard_mode": self.builder.shard_mode, "bytes_per_row": bpr,
+                "rows_sent": sent, "rows_received": recv, "bytes_sent": sent * bpr, "bytes_received": recv * bpr,
+                "points_owned_per_rank": [int(v) for v in owned],
+                "imbalance_max_over_mean": round(float(owned.max() / max(owned.mean(), 1.0)), 4),
+                "ms": {k: round(float(v), 3) for k, v in self._stage_ms.items()}}
 
     def top_dict(self):
         """The finished root and level-1 nodes as {name: node dict} (host bytes)."""
@@ -218,10 +249,11 @@ class ShardedOctree:
 
 
 class ShardedOctreeBuilder:
-    def __init__(self, ctx, dist, device, backend=None, compress_exchange=True):
+    def __init__(self, ctx, dist, device, backend=None, compress_exchange=True, shard_mode="buckets"):
         import torch
         self.torch = torch
         self.dist = dist
+        self.shard_mode = shard_mode  # "buckets" (64 level-2 buckets bin-packed) or "octants" (octant c -> rank c % N)
         # ship the level-1 chain state (Float32 codes + octant digit | rgb: four 4-byte planes, 16 B) instead of raw f64
         # coordinates + rgb (27 B) whenever level 1 of the global cube is Float32-encoded; bit-identical either way
         self.compress_exchange = compress_exchange
@@ -235,6 +267,7 @@ class ShardedOctreeBuilder:
     # -- global bounding box (== find_bounding_box over the whole input, generation.rs:256-270) --
     def global_bbox(self, x, y, z):
         torch, dist = self.torch, self.dist
+        self._after_torch()
         bmin, bmax = self.backend.aabb(x, y, z)
         n_local = x.numel() if hasattr(x, "numel") else len(x)
         big = np.finfo(np.float64).max
@@ -245,6 +278,14 @@ class ShardedOctreeBuilder:
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         return _oct.Aabb(lo.cpu().numpy(), hi.cpu().numpy())
+
+    def _after_torch(self):
+        if hasattr(self.backend, "after_torch"):
+            self.backend.after_torch()
+
+    def _before_torch(self):
+        if hasattr(self.backend, "before_torch"):
+            self.backend.before_torch()
 
     def _sum_i64(self, values):
         """All-reduce(sum) of a small host vector of int64."""
@@ -289,6 +330,8 @@ class ShardedOctreeBuilder:
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
+        # RCCL's wait() orders torch's current stream only; the build reads `recv` on the library's own stream
+        self._after_torch()
         return recv
 
     def build(self, resolution, bbox, x, y, z, rgb, intensity=None, max_points_per_node=0):
@@ -305,6 +348,7 @@ class ShardedOctreeBuilder:
                 marks.append(e)
 
         mark()
+        self._after_torch()  # the caller's tensors were produced on torch's stream
         max_level, edges, encodings = self.backend.level_table(resolution, bbox)
         can_split = max_level >= 2 and edges[1] > resolution
         # 1. buckets + global plan
@@ -317,12 +361,14 @@ class ShardedOctreeBuilder:
             planes = {"x": x, "y": y, "z": z, "color": rgb}
         if intensity is not None:
             planes["intensity"] = intensity
+        row_bytes = sum(int(p.element_size()) * (int(p.numel()) // max(int(p.shape[0]), 1) if int(p.shape[0]) else
+                                                  int(np.prod(p.shape[1:], dtype=np.int64))) for p in planes.values())
         # one all-gather of the 64 local counts gives every rank the global counts AND the whole send matrix
         mine = torch.tensor(np.asarray(counts, dtype=np.int64), device=self.device)
         every = [torch.empty_like(mine) for _ in range(world)]
         self.dist.all_gather(every, mine)
         per_rank = torch.stack(every).cpu().numpy()  # per_rank[src][bucket]
-        rank_of_bucket, split_mask = plan_buckets(per_rank.sum(axis=0), world, cap, can_split)
+        rank_of_bucket, split_mask = plan_buckets(per_rank.sum(axis=0), world, cap, can_split, self.shard_mode)
         matrix = np.stack([np.bincount(rank_of_bucket, weights=per_rank[src], minlength=world) for src in range(world)])
         matrix = matrix.astype(np.int64)  # matrix[src][dst]
         # 2. the exchange
@@ -347,8 +393,7 @@ class ShardedOctreeBuilder:
         # 4. finish the root and the level-1 nodes: sum of every rank's sparsely filled global-size nodes
         specs, nbytes = top_nodes(layout, encodings, intensity is not None)
         top = torch.zeros(max(nbytes, 16), dtype=torch.uint8, device=self.device)
-        if timed:
-            torch.cuda.current_stream().synchronize()  # the fill runs on torch's stream, the copies on the library's
+        self._after_torch()  # the zero fill runs on torch's stream, the node copies on the library's
         index_of = {}
         for i in range(min(tree.num_nodes, 9)):
             nd = tree.node(i)
@@ -362,8 +407,7 @@ class ShardedOctreeBuilder:
                 off, length = nd[key]
                 if length:
                     tree.copy_node_into(i, which, top[off:off + length])
-        if hasattr(tree, "synchronize"):
-            tree.synchronize()  # the node copies are queued on the library's stream, the collective runs on torch's
+        self._before_torch()  # the node copies are queued on the library's stream, the collective runs on torch's
         if world > 1:
             self.dist.all_reduce(top, op=self.dist.ReduceOp.SUM)
         mark()
@@ -372,4 +416,6 @@ class ShardedOctreeBuilder:
             marks[-1].synchronize()
             ms = {"exchange": marks[0].elapsed_time(marks[1]), "local_build": marks[1].elapsed_time(marks[2]),
                   "top_merge": marks[2].elapsed_time(marks[3])}
-        return ShardedOctree(self, tree, specs, top, ms, matrix, (rank_of_bucket, split_mask), resolution, bbox)
+        out = ShardedOctree(self, tree, specs, top, ms, matrix, (rank_of_bucket, split_mask), resolution, bbox)
+        out.bytes_per_row = row_bytes
+        return out

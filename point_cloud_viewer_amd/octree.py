@@ -62,11 +62,19 @@ class _Buf:
 
 
 class Context:
-    """One pcv_ctx: bound to one HIP device and stream, not thread-safe (include/pcv_hip.h)."""
+    """One pcv_ctx: bound to one HIP device and stream, not thread-safe (include/pcv_hip.h).
+
+    stream=None (or handle 0, which the C ABI cannot tell from NULL) gives the context its OWN non-blocking stream.
+    Torch's default stream is handle 0 and therefore can never be shared: work queued by torch (or RCCL) that produces
+    the context's inputs must be ordered with `wait_torch()` / `wait_stream(handle)` before the first call that reads
+    it, and `signal_torch()` orders torch work after asynchronous context calls. Calls that return results to the host
+    end with a stream synchronisation of their own."""
 
     def __init__(self, device=0, stream=None):
         self.lib = L.load_library()
         h = C.c_void_p()
+        self.device = int(device)
+        self.shares_stream = bool(stream)
         rc = self.lib.pcv_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h))
         if rc != L.PCV_OK:
             raise L.PcvError(rc, f"pcv_ctx_create(device={device}) failed — is a HIP device visible?")
@@ -106,6 +114,24 @@ class Context:
     def synchronize(self):
         """Wait for the work queued on the context's stream."""
         self._check(self.lib.pcv_ctx_synchronize(self.handle))
+
+    def wait_stream(self, stream_handle):
+        """Order the context's stream after what is queued on `stream_handle` (0 = the default stream) right now."""
+        self._check(self.lib.pcv_ctx_wait_stream(self.handle, C.c_void_p(stream_handle) if stream_handle else None))
+
+    def signal_stream(self, stream_handle):
+        """Order work queued on `stream_handle` from now on after the context's work queued so far."""
+        self._check(self.lib.pcv_ctx_signal_stream(self.handle, C.c_void_p(stream_handle) if stream_handle else None))
+
+    def wait_torch(self):
+        """wait_stream on torch's current stream of this device: call after torch / torch.distributed produced
+        tensors the next context call reads."""
+        import torch
+        self.wait_stream(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def signal_torch(self):
+        import torch
+        self.signal_stream(torch.cuda.current_stream(self.device).cuda_stream)
 
     def _check(self, rc):
         if rc != L.PCV_OK:

@@ -124,6 +124,14 @@ def _vec3(v):
     return a
 
 
+def find_bounding_cube(hi, lo, root_min, root_edge):
+    """NodeId::find_bounding_cube (node.rs:157-172): (min xyz array, edge)."""
+    out = np.zeros(3)
+    edge = C.c_double()
+    lib().pcvo_find_bounding_cube(int(hi), int(lo), _d(_vec3(root_min)), float(root_edge), _d(out), C.byref(edge))
+    return out, edge.value
+
+
 def node_id_str(hi, lo):
     buf = C.create_string_buffer(64)
     lib().pcvo_node_id_to_string(int(hi), int(lo), buf, 64)
@@ -211,6 +219,46 @@ def build_closed(resolution, bmin, bmax, x, y, z, rgb, intensity=None, threads=1
     h = lib().pcvo_build_closed(resolution, _d(bmin), _d(bmax), x.size, _d(x), _d(y), _d(z),
                                 rgb.ctypes.data_as(_u8p), ip, threads)
     return Octree(h)
+
+
+def node_digest(ptr, length):
+    """blake2b-128 of `length` bytes at address `ptr` (no copy)."""
+    import hashlib
+    if not length:
+        return hashlib.blake2b(b"", digest_size=16).hexdigest()
+    return hashlib.blake2b((C.c_uint8 * length).from_address(ptr), digest_size=16).hexdigest()
+
+
+def build_closed_digests(resolution, bmin, bmax, x, y, z, rgb, intensity=None, threads=1):
+    """Closed-form oracle build of a LARGE cloud without copying node bytes into python: returns
+    ({node name: (num_points, encoding, digest xyz, digest rgb, digest intensity)}, stats) with
+    stats = dict(max_abs_position_error=..., total_points=...). Used by `bench.py --verify` at BASELINE sizes."""
+    x, y, z, rgb, intensity, ip = _pts(x, y, z, rgb, intensity)
+    bmin, bmax = _vec3(bmin), _vec3(bmax)
+    L = lib()
+    L.pcvo_result_max_abs_position_error.restype = C.c_double
+    L.pcvo_result_max_abs_position_error.argtypes = [C.c_void_p]
+    h = L.pcvo_build_closed(resolution, _d(bmin), _d(bmax), x.size, _d(x), _d(y), _d(z), rgb.ctypes.data_as(_u8p), ip,
+                            threads)
+    try:
+        err = L.pcvo_result_error(h)
+        if err:
+            raise RuntimeError("oracle: " + err.decode())
+        out, total = {}, 0
+        for i in range(L.pcvo_result_num_nodes(h)):
+            hi, lo, npnts = C.c_uint64(), C.c_uint64(), C.c_int64()
+            enc, lvl, has = C.c_int(), C.c_int(), C.c_int()
+            L.pcvo_result_node(h, i, C.byref(hi), C.byref(lo), C.byref(npnts), C.byref(enc), C.byref(lvl), C.byref(has))
+            dig = []
+            for which in range(3):
+                ln = C.c_uint64()
+                ptr = L.pcvo_result_node_data(h, i, which, C.byref(ln))
+                dig.append(node_digest(C.cast(ptr, C.c_void_p).value or 0, ln.value))
+            out[node_id_str(hi.value, lo.value)] = (npnts.value, enc.value, dig[0], dig[1], dig[2])
+            total += npnts.value
+        return out, dict(max_abs_position_error=L.pcvo_result_max_abs_position_error(h), total_points=total)
+    finally:
+        L.pcvo_result_free(h)
 
 
 def chain_state1(bmin, bmax, resolution, x, y, z):

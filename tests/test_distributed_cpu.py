@@ -120,7 +120,7 @@ class HostBackend:
                             routed=state)
 
 
-def _worker(rank, world, port, n, cap, with_intensity, out_path, compress=True):
+def _worker(rank, world, port, n, cap, with_intensity, out_path, compress=True, shard_mode="buckets"):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     import torch.distributed as dist
@@ -141,14 +141,21 @@ def _worker(rank, world, port, n, cap, with_intensity, out_path, compress=True):
     tx, ty, tz = (torch.from_numpy(np.ascontiguousarray(a[sl])) for a in (x, y, z))
     trgb = torch.from_numpy(np.ascontiguousarray(rgb[sl]))
     tint = torch.from_numpy(np.ascontiguousarray(inten[sl])) if with_intensity else None
-    b = pdist.ShardedOctreeBuilder(None, dist, torch.device("cpu"), backend=HostBackend(O, cap), compress_exchange=compress)
+    b = pdist.ShardedOctreeBuilder(None, dist, torch.device("cpu"), backend=HostBackend(O, cap), compress_exchange=compress,
+                                   shard_mode=shard_mode)
     bbox = b.global_bbox(tx, ty, tz)
     assert np.array_equal(bbox.min, bmin) and np.array_equal(bbox.max, bmax)
     res = b.build(0.001, bbox, tx, ty, tz, trgb, tint, max_points_per_node=cap)
     assert int(res.counts.sum()) == n
     rank_of, split_mask = res.plan
     assert split_mask != 0  # some level-1 node is split globally ...
-    assert any(len(set(rank_of[c * 8:c * 8 + 8].tolist())) > 1 for c in range(8) if (split_mask >> c) & 1)  # ... across ranks
+    if shard_mode == "buckets":
+        assert any(len(set(rank_of[c * 8:c * 8 + 8].tolist())) > 1 for c in range(8) if (split_mask >> c) & 1)  # ... across ranks
+    else:  # BASELINE north_star: the owner of root octant c is rank c (mod world)
+        assert rank_of.tolist() == [c % world for c in range(8) for _ in range(8)]
+    ex = res.exchange_info()
+    assert ex["shard_mode"] == shard_mode and sum(ex["points_owned_per_rank"]) == n
+    assert ex["bytes_sent"] == ex["rows_sent"] * ex["bytes_per_row"] and ex["bytes_per_row"] in (16, 20, 27, 31)
     merged = res.gather(dst=0)
     if rank == 0:
         with O.max_points_per_node(cap):
@@ -176,6 +183,14 @@ def test_sharded_build_equals_single_build(tmp_path, world, with_intensity, comp
     assert out.read_text() == "OK", out.read_text()
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_octant_ownership_mode_equals_single_build(tmp_path, world):
+    """north_star's sharding (top-3-bit prefix -> rank) next to the bucket mode: same finished octree."""
+    out = tmp_path / "result.txt"
+    mp.spawn(_worker, args=(world, _free_port(), 40_000, 700, True, str(out), True, "octants"), nprocs=world, join=True)
+    assert out.read_text() == "OK", out.read_text()
+
+
 def test_bucket_plan_is_balanced_and_keeps_unsplit_octants_whole():
     from point_cloud_viewer_amd.distributed import plan_buckets, top_layout
     rng = np.random.default_rng(5)
@@ -190,6 +205,8 @@ def test_bucket_plan_is_balanced_and_keeps_unsplit_octants_whole():
         assert loads.max() <= 1.1 * loads.mean() + 1
         again, _ = plan_buckets(g.copy(), world, 100_000, True)
         assert np.array_equal(rank_of, again)
+    rank_of, mask = plan_buckets(g, 8, 100_000, True, "octants")
+    assert mask == 0b11110101 and rank_of.tolist() == [c for c in range(8) for _ in range(8)]
     rank_of, mask = plan_buckets(g, 4, 100_000, False)  # level-1 nodes cannot split: whole octants only
     assert mask == 0 and all(len(set(rank_of[c * 8:c * 8 + 8])) == 1 for c in range(8))
     # layout: stream lengths follow |pre(inner)| = sum ceil(|pre(child)| / 8)

@@ -293,6 +293,33 @@ def test_build_octree_from_file(ctx, tmp_path):
     assert not O.compare_octrees(O.load_dir(tmp_path / "gpu"), O.load_dir(tmp_path / "cpu"))
 
 
+def test_c_host_binary_builds_the_same_directory(tmp_path):
+    """examples/build_octree.c (gcc -std=c11; the reference's src/bin/build_octree.rs:41-53 over the C ABI): PLY ->
+    directory in a separate non-Python process, compared with the oracle's literal build."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "bin", "build_octree")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "examples")])
+    x, y, z, rgb, _, _ = synthetic.gaussian_clusters(150_000, seed=43, num_clusters=4, extent=60.0, sigma_range=(0.05, 3.0))
+    inten = (np.arange(x.size) % 23).astype(np.float32)
+    with open(tmp_path / "cloud.ply", "wb") as f:
+        f.write((f"ply\nformat binary_little_endian 1.0\nelement vertex {x.size}\nproperty double x\nproperty double y\n"
+                 "property double z\nproperty uchar red\nproperty uchar green\nproperty uchar blue\nproperty float intensity\n"
+                 "end_header\n").encode())
+        rec = np.zeros(x.size, dtype=[("x", "<f8"), ("y", "<f8"), ("z", "<f8"), ("r", "u1"), ("g", "u1"), ("b", "u1"), ("i", "<f4")])
+        rec["x"], rec["y"], rec["z"], rec["r"], rec["g"], rec["b"], rec["i"] = x, y, z, rgb[:, 0], rgb[:, 1], rgb[:, 2], inten
+        f.write(rec.tobytes())
+    p = subprocess.run([exe, str(tmp_path / "cloud.ply"), "--output-directory", str(tmp_path / "c_out"), "--resolution", "0.001"],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    assert f"{x.size} points" in p.stdout
+    bmin, bmax = O.aabb(x, y, z)
+    O.build_literal_dir(tmp_path / "cpu", 0.001, bmin, bmax, x, y, z, rgb, inten, threads=4)
+    assert not O.compare_octrees(O.load_dir(tmp_path / "c_out"), O.load_dir(tmp_path / "cpu"))
+
+
 def test_ten_million_points_default_capacity_vs_oracle(ctx):
     """The reference's own constants (capacity 100 000, 1 mm) on a cloud large enough to need them: 10 M points,
     every node byte against the closed-form oracle."""
