@@ -1,0 +1,86 @@
+// pcv_spec.h — host logic of the single-chain ("speculative") build.
+//
+// The exact build runs the per-point quantise->decode chain twice: once for the path keys that give the topology
+// (K2 + key sort + node split) and once more to the leaf each point ends in (K5). The chain is f64-VALU bound and is
+// 44 % of the build. The single-chain build predicts the topology from a strided SAMPLE, walks every point down the
+// predicted tree in ONE chain pass, counts the points per predicted leaf exactly, and derives the TRUE tree from those
+// exact counts. Nothing about the result is approximate:
+//   * the predicted tree T'' only has to be at least as deep as the true tree wherever points go; every inner node has
+//     all eight children, so every point reaches exactly one predicted leaf;
+//   * a node whose sampled count is close to the capacity ("candidate") is split in T'', and every point passing
+//     through it also keeps the codes it had AT that node — so the point is ready both for "the node is a leaf" and for
+//     "the node is split";
+//   * the exact counts decide (should_split_node, reference src/octree/generation.rs:128-150); whenever the prediction
+//     does not cover the decision (a predicted leaf that must be split; a true leaf that is an inner node of T''
+//     without kept codes) the build is redone by the exact two-chain pipeline. Speculation can cost time, never
+//     correctness — the same contract as the depth speculation of the exact path.
+#pragma once
+#include <stdint.h>
+
+#include <vector>
+
+// Walk record of a T'' node (device): inner: first child index in bits 0..31 (the eight children are consecutive),
+// leaf: predicted-leaf rank in bits 0..31.
+#define PCV_SPEC_LEAF (1ull << 40)
+#define PCV_SPEC_CANDIDATE (1ull << 41)
+#define PCV_SPEC_LEVEL_SHIFT 48
+
+struct PcvSpecParams {
+  uint32_t cap = 0;         // max_points_per_node
+  double resolution = 0;
+  const double* edge = nullptr;  // edge[k], k = 0 .. nlevels
+  int nlevels = 0;          // digit levels of the sample keys (<= 21)
+  uint32_t force_mask = 0;  // level-1 nodes that are split whatever they hold (multi-GPU build)
+  double scale = 1;         // N / S: points per sample point
+  double delta = 0;         // relative half width of the candidate band around the capacity
+};
+
+// Node table of the SAMPLE tree as pcv_launch_node_split leaves it (BFS order, children contiguous in digit order).
+struct PcvSampleTable {
+  uint32_t num_nodes = 0;
+  const uint64_t* prefix = nullptr;
+  const uint32_t* lo = nullptr;
+  const uint32_t* hi = nullptr;
+  const uint32_t* first_child = nullptr;
+  const uint8_t* level = nullptr;
+  const uint8_t* child_mask = nullptr;
+  const uint8_t* open = nullptr;
+};
+
+struct PcvSpecTree {
+  std::vector<uint64_t> prefix;       // left-aligned path key, 3 bits per level, level 1 at bits 60..62
+  std::vector<uint8_t> level;
+  std::vector<uint8_t> inner;
+  std::vector<uint8_t> candidate;     // inner node whose sampled count is inside the band
+  std::vector<uint32_t> first_child;  // inner nodes: index of child 0 (children 0..7 follow each other)
+  std::vector<uint32_t> parent;
+  std::vector<uint32_t> leaf_rank;    // leaves: rank in key order (depth first, digits ascending)
+  std::vector<uint64_t> walk;         // device walk records, one per node
+  uint32_t num_leaves = 0;
+  bool any_candidate = false;
+};
+
+// Sample split threshold: a sample node is opened iff its sample count exceeds this (count * scale > cap * (1 - delta)).
+uint32_t pcv_spec_sample_threshold(const PcvSpecParams& p);
+
+void pcv_spec_build_tree(const PcvSpecParams& p, const PcvSampleTable& s, PcvSpecTree* out);
+
+enum PcvSpecStatus {
+  PCV_SPEC_OK = 0,
+  PCV_SPEC_TOO_SHALLOW = 1,  // a predicted leaf holds more than the capacity and may be split
+  PCV_SPEC_NO_CODES = 2,     // a true leaf is an inner node of T'' whose points did not keep their codes at that level
+};
+
+// The true tree in the layout the exact path downloads from the device after the node split (BFS order, children
+// contiguous in digit order, [lo, hi) = range in key-sorted order), plus the map predicted-leaf rank -> true leaf rank
+// (depth-first order, the same order pcv_build_finish assigns) with bit 31 set when the point takes the codes it kept at
+// its candidate node instead of the codes of its predicted leaf.
+struct PcvTrueTree {
+  std::vector<uint64_t> prefix;
+  std::vector<uint32_t> lo, hi, first_child;
+  std::vector<uint8_t> level, child_mask, open;
+  std::vector<uint32_t> spec_map;
+  uint32_t num_leaves = 0;
+  int deepest_level = 0;
+};
+PcvSpecStatus pcv_spec_resolve(const PcvSpecParams& p, const PcvSpecTree& t, const uint32_t* leaf_counts, PcvTrueTree* out);
