@@ -105,8 +105,15 @@ typedef struct pcv_build_params {
 /* Compute the bounding box on the device first (== build_octree_from_file's find_bounding_box pass,
  * generation.rs:256-287); bbox_min/max are then outputs. */
 #define PCV_BUILD_COMPUTE_BBOX 1u
-/* Always compute and sort full-depth path keys (disables the sampled depth speculation; same result, slower). */
+/* Exact two-chain pipeline with full-depth path keys: disables the single-chain build and the sampled depth
+ * speculation (same result, slower). */
 #define PCV_BUILD_NO_SPECULATION 2u
+/* Take the single-chain build (topology predicted from a strided sample, ONE chain pass, exact per-leaf counts decide
+ * the tree; see csrc/pcv_spec.h) whatever the input size; by default it is used from 2^22 points on. Same result: if
+ * the prediction does not cover the tree the exact pipeline redoes the build. */
+#define PCV_BUILD_FORCE_SINGLE_CHAIN 4u
+/* Never take the single-chain build (the exact pipeline with its depth speculation runs instead). */
+#define PCV_BUILD_NO_SINGLE_CHAIN 8u
 
 /* Multi-GPU build: level-1 nodes whose bit is set are split even if this rank's share of their points
  * is below the capacity — the split decision of the GLOBAL tree, made from the all-reduced bucket counts. */
@@ -208,9 +215,13 @@ void pcv_octree_free(pcv_octree* t);
 #define PCV_STAGE_TOTAL 8
 #define PCV_NUM_STAGES 9
 int pcv_octree_stage_ms(const pcv_octree* t, float* ms, int cap);
-/* How the last build sized its path keys: number of digit levels sorted and the number of attempts
- * (2 = the sampled depth estimate was too shallow and the build was redone at full depth). */
+/* How the last build went: attempts == 0: single-chain build (key_levels = levels the sample keys covered);
+ * attempts == 1: exact pipeline, the sampled depth estimate held (key_levels = digit levels sorted);
+ * attempts >= 2: something was redone (single-chain prediction too shallow and/or depth estimate too shallow). */
 void pcv_octree_build_info(const pcv_octree* t, int* key_levels, int* attempts);
+/* Single-chain build statistics of the last build (zeros otherwise): nodes and leaves of the predicted tree, points
+ * that took the codes kept at a candidate node, points that replayed the chain in the finalize kernel. */
+void pcv_octree_spec_stats(const pcv_octree* t, uint64_t stats[4]);
 
 /* ---- stage-level entry points (unit parity against the oracle) ------------------------------ */
 /* K1: find_bounding_box (generation.rs:256-270; Aabb::grow aabb.rs:41-44). n == 0 -> Aabb::zero(). */

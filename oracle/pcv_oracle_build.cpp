@@ -822,6 +822,14 @@ static Result* build_closed(const Aabb& bbox, double resolution, size_t n, const
   r->resolution = resolution;
   if (n == 0) return r;  // generation.rs:325-330: no leaves -> no finished nodes
   if (num_threads < 1) num_threads = 1;
+  const bool timing = std::getenv("PCVO_TIMING") != nullptr;
+  double t_last = omp_get_wtime();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    const double now = omp_get_wtime();
+    std::fprintf(stderr, "[oracle closed] %-10s %.2f s\n", what, now - t_last);
+    t_last = now;
+  };
   LevelTable t = make_level_table(bbox, resolution, 40);
   int nlev = t.max_level;
   std::vector<u128> keys(n);
@@ -836,6 +844,7 @@ static Result* build_closed(const Aabb& bbox, double resolution, size_t n, const
     if (k0 > nlev) key = d1;
     keys[i] = key;
   }
+  lap("keys");
   // Top-down stable split of index lists (generation.rs:58-193 without the files). Level-synchronous so the nodes of a
   // level split in parallel (they are independent); a big node is split by chunks (count, offsets, scatter), which keeps
   // the order inside every child == the order inside the parent (the stable `retain` of generation.rs:84-90).
@@ -931,6 +940,7 @@ static Result* build_closed(const Aabb& bbox, double resolution, size_t n, const
     }
     level_begin = level_end;
   }
+  lap("split");
   // Bottom-up promotion (generation.rs:195-253, 335-387): nodes[] is in BFS order, so reverse order
   // visits children before parents.
   for (size_t qi = 0; qi < nodes.size(); ++qi)
@@ -968,6 +978,7 @@ static Result* build_closed(const Aabb& bbox, double resolution, size_t n, const
       }
     }
   }
+  lap("promote");
 #pragma omp parallel for schedule(dynamic, 16) num_threads(num_threads)
   for (size_t qi = 0; qi < nodes.size(); ++qi) {
     CNode& nd = nodes[qi];
@@ -986,6 +997,7 @@ static Result* build_closed(const Aabb& bbox, double resolution, size_t n, const
   }
   // Bytes: replay the chain down to the leaf level, then decode/encode upward, plus the one rewrite
   // every non-root node undergoes (generation.rs:230-238).
+  lap("post");
   r->nodes.resize(nodes.size());
   double max_err = 0.0;
 #pragma omp parallel for schedule(dynamic, 1) num_threads(num_threads) reduction(max : max_err)
@@ -1052,6 +1064,7 @@ static Result* build_closed(const Aabb& bbox, double resolution, size_t n, const
       if (intensity) std::memcpy(&out.intensity[4 * s], &intensity[i], 4);
     }
   }
+  lap("bytes");
   r->max_abs_position_error = routed ? -1.0 : max_err;
   sort_nodes(r);
   return r;

@@ -14,6 +14,8 @@ MEM_HOST, MEM_DEVICE = 0, 1
 ENC_UINT8, ENC_UINT16, ENC_FLOAT32, ENC_FLOAT64 = 1, 2, 3, 4
 BUILD_COMPUTE_BBOX = 1
 BUILD_NO_SPECULATION = 2
+BUILD_FORCE_SINGLE_CHAIN = 4
+BUILD_NO_SINGLE_CHAIN = 8
 MAX_KEY_LEVELS = 21
 NUM_STAGES = 9
 STAGE_NAMES = ["aabb", "chain_keys", "sort_keys", "node_split", "table", "leaf_encode", "sort_records",
@@ -103,6 +105,7 @@ _SIGNATURES = {
     "pcv_octree_free": (None, [_vp]),
     "pcv_octree_stage_ms": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_int]),
     "pcv_octree_build_info": (None, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "pcv_octree_spec_stats": (None, [_vp, C.POINTER(C.c_uint64)]),
     "pcv_aabb_reduce": (C.c_int, [_vp, C.POINTER(Points), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "pcv_level_table": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_int,
                                   C.POINTER(C.c_double), C.POINTER(C.c_int32)]),

@@ -19,6 +19,7 @@
 #include <cstring>
 
 #include "pcv_internal.h"
+#include "pcv_spec.h"
 
 // ------------------------------------------------------------------------------------------------
 // context, pool
@@ -128,7 +129,7 @@ static const char* kKernelNames[PCV_K_COUNT] = {
     "upsweep_kernel<u32>", "downsweep_kernel<u32>", "promote_settle_kernel", "downsweep_rec_kernel", "cull_nodes_kernel",
     "visible_nodes_kernel", "nodes_in_location_kernel", "cull_points_kernel", "transform_points_kernel",
     "query_compact_kernel", "route_bucket_kernel", "partition_count_kernel", "partition_scatter_kernel",
-    "promote_climb_kernel"};
+    "promote_climb_kernel", "spec_encode_kernel", "rank_hist_kernel", "spec_finalize_kernel"};
 static_assert(sizeof(kKernelNames) / sizeof(kKernelNames[0]) == PCV_K_COUNT, "kernel name table out of sync");
 
 extern "C" int pcv_ctx_set_profiling(pcv_ctx* ctx, int enabled) {
@@ -187,6 +188,11 @@ extern "C" int pcv_ctx_create(int device, void* stream, pcv_ctx** out) {
       delete c;
       return PCV_E_HIP;
     }
+  for (int k = 0; k < PCV_NUM_STAGES; ++k)
+    if (hipEventCreate(&c->stage_b[k]) != hipSuccess || hipEventCreate(&c->stage_e[k]) != hipSuccess) {
+      delete c;
+      return PCV_E_HIP;
+    }
   if (hipEventCreateWithFlags(&c->xev, hipEventDisableTiming) != hipSuccess) {
     delete c;
     return PCV_E_HIP;
@@ -208,6 +214,10 @@ extern "C" void pcv_ctx_destroy(pcv_ctx* ctx) {
   for (auto& e : ctx->ev)
     if (e) (void)hipEventDestroy(e);
   if (ctx->xev) (void)hipEventDestroy(ctx->xev);
+  for (int k = 0; k < PCV_NUM_STAGES; ++k) {
+    if (ctx->stage_b[k]) (void)hipEventDestroy(ctx->stage_b[k]);
+    if (ctx->stage_e[k]) (void)hipEventDestroy(ctx->stage_e[k]);
+  }
   for (auto& p : ctx->prof_pending) {
     (void)hipEventDestroy(p.a);
     (void)hipEventDestroy(p.b);
@@ -432,6 +442,9 @@ struct PcvBuild {
   bool deep = false;          // more than PCV_MAX_KEY_LEVELS levels: second key word, prefix_lo in the node table
   int levels = 0;             // levels the level tables are valid for in K5/K6 (full depth, or the deep depth)
   uint64_t* d_prefix_lo = nullptr;
+  // single-chain build: the records (true-leaf rank, leaf codes + rgb[, intensity]) already exist when the topology does
+  bool spec = false;
+  void* spec_payload = nullptr;  // uint4[n]
   explicit PcvBuild(pcv_ctx* c) : ctx(c), sc(c) {}
 };
 
@@ -477,6 +490,10 @@ extern "C" void pcv_octree_build_info(const pcv_octree* t, int* key_levels, int*
   if (!t) return;
   if (key_levels) *key_levels = t->key_levels;
   if (attempts) *attempts = t->key_attempts;
+}
+extern "C" void pcv_octree_spec_stats(const pcv_octree* t, uint64_t stats[4]) {
+  if (!t || !stats) return;
+  for (int k = 0; k < 4; ++k) stats[k] = t->spec_stats[k];
 }
 extern "C" int pcv_octree_device_blob(const pcv_octree* t, int which, const void** dptr, uint64_t* len) {
   if (!t || !dptr || !len || which < 0 || which > 2) return PCV_E_INVALID;
@@ -585,6 +602,149 @@ extern "C" int pcv_build_begin_routed(pcv_ctx* ctx, const pcv_build_params* para
   if (params->flags & PCV_BUILD_COMPUTE_BBOX) return ctx->fail(PCV_E_INVALID, "routed points need the global bounding box");
   return build_begin_impl(ctx, params, nullptr, routed, out);
 }
+// The single-chain topology (pcv_spec.h): sample -> predicted tree T'' -> ONE chain pass for all points -> exact counts
+// per predicted leaf -> true tree on the host. On success (*used) the records (true-leaf rank in the first half of
+// keys_a, payload in bs->spec_payload, intensity bits in the second half of keys_a) are what K5 would have produced and
+// `tt` is the node table K4 would have produced. *used == false: the prediction did not cover the tree (or the sample
+// says the tree is deeper than one key word): the caller runs the exact pipeline; nothing of this attempt is kept.
+static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, const pcv_build_params* params,
+                                 uint32_t max_points, int full_levels, PcvNodeTableDev& nt, PcvTrueTree* tt, bool* used) {
+  *used = false;
+  hipStream_t st = ctx->stream;
+  PcvScratch& sc = bs->sc;
+  DevPoints& d = bs->d;
+  PcvLevels& lv = bs->lv;
+  const uint64_t n = bs->n;
+  int rc;
+  // sample stride: every 32nd point (>= 3 000 sample points per full node at the reference's capacity); small forced
+  // builds (tests) sample more densely
+  uint64_t stride = 32;
+  while (stride > 1 && n / stride < 4096) stride >>= 1;
+  const uint64_t ns = n / stride;
+  if (ns == 0) return PCV_OK;
+  PcvSpecParams sp;
+  sp.cap = max_points;
+  sp.resolution = params->resolution;
+  sp.edge = lv.edge;
+  sp.nlevels = full_levels;
+  sp.force_mask = (params->flags >> 8) & 0xffu;
+  sp.scale = (double)stride;
+  // band of five standard deviations of the scaled sample count of a node that holds exactly `cap` points
+  sp.delta = stride == 1 ? 0.0 : std::fmin(0.9, std::fmax(0.02, 5.0 * std::sqrt((double)stride / (double)max_points)));
+
+  ctx->stage_begin(PCV_STAGE_CHAIN_KEYS);
+  lv.nlevels = full_levels;
+  pcv_launch_chain_keys(ctx, lv, ns, stride, d.x, d.y, d.z, bs->keys_a, false, d.routed);
+  bool in_a = true;
+  if ((rc = pcv_radix_sort_u64(ctx, bs->keys_a, bs->keys_b, ns, 3 * (PCV_MAX_KEY_LEVELS - full_levels), 3 * PCV_MAX_KEY_LEVELS,
+                               nullptr, bs->sort_scratch, &in_a)))
+    return rc;
+  pcv_launch_node_split(ctx, nt, in_a ? bs->keys_a : bs->keys_b, false, (uint32_t)ns, lv, params->resolution,
+                        pcv_spec_sample_threshold(sp), sp.force_mask);
+  uint32_t counters[64];
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(ctx->mailbox, nt.counters, sizeof(counters), hipMemcpyDeviceToHost, st));
+  PCV_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  std::memcpy(counters, ctx->mailbox, sizeof(counters));
+  if (counters[1]) return PCV_OK;  // sample tree deeper than the key word, or table capacity: not this path's case
+  const uint32_t ms = counters[0];
+  if ((rc = ctx->pinned_reserve((size_t)ms * 32 + 512))) return rc;
+  uint8_t* hp = (uint8_t*)ctx->pinned;
+  uint64_t* s_prefix = (uint64_t*)hp;
+  uint32_t* s_lo = (uint32_t*)(s_prefix + ms);
+  uint32_t* s_hi = s_lo + ms;
+  uint32_t* s_first = s_hi + ms;
+  uint8_t* s_level = (uint8_t*)(s_first + ms);
+  uint8_t* s_mask = s_level + ms;
+  uint8_t* s_open = s_mask + ms;
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(s_prefix, nt.prefix, (size_t)ms * 8, hipMemcpyDeviceToHost, st));
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(s_lo, nt.lo, (size_t)ms * 4, hipMemcpyDeviceToHost, st));
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(s_hi, nt.hi, (size_t)ms * 4, hipMemcpyDeviceToHost, st));
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(s_first, nt.first_child, (size_t)ms * 4, hipMemcpyDeviceToHost, st));
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(s_level, nt.level, (size_t)ms, hipMemcpyDeviceToHost, st));
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(s_mask, nt.child_mask, (size_t)ms, hipMemcpyDeviceToHost, st));
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(s_open, nt.open, (size_t)ms, hipMemcpyDeviceToHost, st));
+  PCV_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  PcvSampleTable stab;
+  stab.num_nodes = ms;
+  stab.prefix = s_prefix;
+  stab.lo = s_lo;
+  stab.hi = s_hi;
+  stab.first_child = s_first;
+  stab.level = s_level;
+  stab.child_mask = s_mask;
+  stab.open = s_open;
+  PcvSpecTree tree;
+  pcv_spec_build_tree(sp, stab, &tree);
+  const size_t walk_bytes = tree.walk.size() * 8;
+  // one upload area: walk records now, the rank map (+ fix levels) later; one zeroed counter per predicted leaf
+  const size_t map_off = (walk_bytes + 255) & ~(size_t)255;
+  const size_t fix_off = map_off + (((size_t)tree.num_leaves * 4 + 255) & ~(size_t)255);
+  const size_t cnt_off = fix_off + (((size_t)tree.num_leaves + 255) & ~(size_t)255);
+  uint8_t* d_area;
+  if ((rc = sc.get(&d_area, cnt_off + (size_t)tree.num_leaves * 4 + 256))) return rc;
+  if ((rc = ctx->pinned_reserve(cnt_off + (size_t)tree.num_leaves * 4 + 512))) return rc;
+  hp = (uint8_t*)ctx->pinned;
+  std::memcpy(hp, tree.walk.data(), walk_bytes);
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_area, hp, walk_bytes, hipMemcpyHostToDevice, st));
+  uint32_t* d_counts = (uint32_t*)(d_area + cnt_off);
+  PCV_HIP_CHECK(ctx, hipMemsetAsync(d_counts, 0, (size_t)tree.num_leaves * 4, st));
+  ctx->stage_end(PCV_STAGE_CHAIN_KEYS);
+
+  // ---- the one chain pass ----
+  ctx->stage_begin(PCV_STAGE_LEAF_ENCODE);
+  uint32_t* rank = (uint32_t*)bs->keys_a;
+  uint4 *payload, *kept = nullptr;
+  if ((rc = sc.get(&payload, n))) return rc;
+  if (tree.any_candidate && (rc = sc.get(&kept, n))) return rc;
+  uint32_t* inten_bits = t->has_intensity ? (uint32_t*)bs->keys_a + n : nullptr;
+  // the sample keys are dead (the sample tree is on the host): the rank array takes their place in keys_a
+  pcv_launch_spec_encode(ctx, lv, (const uint64_t*)d_area, n, d.x, d.y, d.z, d.routed, d.color, d.color_stride, d.intensity,
+                         rank, payload, kept, inten_bits);
+  ctx->stage_end(PCV_STAGE_LEAF_ENCODE);
+
+  // ---- exact counts -> true tree ----
+  ctx->stage_begin(PCV_STAGE_NODE_SPLIT);
+  pcv_launch_rank_hist(ctx, rank, n, tree.num_leaves, d_counts);
+  PCV_HIP_CHECK(ctx, hipGetLastError());
+  uint32_t* h_counts = (uint32_t*)(hp + cnt_off);
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(h_counts, d_counts, (size_t)tree.num_leaves * 4, hipMemcpyDeviceToHost, st));
+  PCV_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  if (pcv_spec_resolve(sp, tree, h_counts, tt) != PCV_SPEC_OK) {
+    sc.detach(payload);
+    ctx->dev_free(payload);
+    if (kept) {
+      sc.detach(kept);
+      ctx->dev_free(kept);
+    }
+    return PCV_OK;  // *used stays false
+  }
+  if (tt->prefix.size() > (size_t)nt.capacity) return ctx->fail(PCV_E_OOM, "node table capacity exceeded");
+  std::memcpy(hp + map_off, tt->spec_map.data(), (size_t)tree.num_leaves * 4);
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_area + map_off, hp + map_off, (size_t)tree.num_leaves * 4, hipMemcpyHostToDevice, st));
+  if (tt->any_fix) {
+    std::memcpy(hp + fix_off, tt->fix_level.data(), (size_t)tree.num_leaves);
+    PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_area + fix_off, hp + fix_off, (size_t)tree.num_leaves, hipMemcpyHostToDevice, st));
+  }
+  pcv_launch_spec_finalize(ctx, lv, n, (const uint32_t*)(d_area + map_off), tt->any_fix ? d_area + fix_off : nullptr, d.x, d.y, d.z,
+                           d.routed, rank, payload, kept);
+  // the uploads above read the pinned block, which the caller is about to reuse for the node table: wait for them
+  PCV_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  ctx->stage_end(PCV_STAGE_NODE_SPLIT);
+  ctx->stage_begin(PCV_STAGE_TABLE);
+  if (kept) {  // consumed by the finalize kernel (the sync above)
+    sc.detach(kept);
+    ctx->dev_free(kept);
+  }
+  bs->spec = true;
+  bs->spec_payload = payload;
+  t->spec_stats[0] = tree.prefix.size();
+  t->spec_stats[1] = tree.num_leaves;
+  t->spec_stats[2] = tt->kept_points;
+  t->spec_stats[3] = tt->fix_points;
+  *used = true;
+  return PCV_OK;
+}
+
 static int build_begin_impl(pcv_ctx* ctx, const pcv_build_params* params, const pcv_points* points,
                             const pcv_routed_points* routed, pcv_octree** out) {
   int rc;
@@ -610,6 +770,8 @@ static int build_begin_impl(pcv_ctx* ctx, const pcv_build_params* params, const 
     }
   } guard{t};
   PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[0], st));
+  for (bool& on : ctx->stage_on) on = false;
+  ctx->stage_begin(PCV_STAGE_AABB);
   if (routed) {  // device-resident by contract
     d.n = n;
     d.routed.oct = reinterpret_cast<const uint8_t*>(routed->oct_rgb);  // byte 0 of every packed word
@@ -637,7 +799,7 @@ static int build_begin_impl(pcv_ctx* ctx, const pcv_build_params* params, const 
     t->bbox_min[a] = bmin[a];
     t->bbox_max[a] = bmax[a];
   }
-  PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[1], st));
+  ctx->stage_end(PCV_STAGE_AABB);
   if (n == 0) {  // generation.rs:325-330: no leaves, no finished nodes, meta without nodes
     delete t->pending;
     t->pending = nullptr;
@@ -652,6 +814,7 @@ static int build_begin_impl(pcv_ctx* ctx, const pcv_build_params* params, const 
   if (routed && (lv.nlevels < 1 || lv.enc[1] != PCV_ENC_FLOAT32))
     return ctx->fail(PCV_E_INVALID, "routed points carry Float32 level-1 codes, but level 1 of this cube is not Float32-encoded");
 
+  ctx->stage_begin(PCV_STAGE_CHAIN_KEYS);
   // ---- K2 keys, K3 sort, K4 node split — with depth speculation ----
   // The keys only have to cover the levels the tree really uses. A strided sample (2^18 points) gets full-depth
   // keys, is sorted, and depth_probe measures the deepest prefix still shared by sample keys `gap` apart
@@ -667,7 +830,42 @@ static int build_begin_impl(pcv_ctx* ctx, const pcv_build_params* params, const 
   sc.ptrs.push_back(sort_scratch);
   const int full_levels = lv.nlevels;
   int spec_levels = full_levels;
-  if (n >= (1ull << 22) && full_levels > 4 && !(params->flags & PCV_BUILD_NO_SPECULATION)) {
+
+  // device node table (the sample tree of the single-chain build, the tree itself in the exact build)
+  PcvNodeTableDev nt;
+  {
+    const int deepest = max_level < PCV_MAX_LEVELS ? max_level : PCV_MAX_LEVELS;  // incl. the deep retry
+    uint64_t cap64 = 8ull * (uint64_t)(deepest + 1) * (n / max_points + 1) + 64;
+    if (cap64 > (1ull << 26)) cap64 = 1ull << 26;
+    const uint32_t cap = (uint32_t)cap64;
+    nt.capacity = cap;
+    nt.prefix_lo = nullptr;
+    if ((rc = sc.get(&nt.prefix, cap)) || (rc = sc.get(&nt.lo, cap)) || (rc = sc.get(&nt.hi, cap)) ||
+        (rc = sc.get(&nt.parent, cap)) || (rc = sc.get(&nt.first_child, cap)) || (rc = sc.get(&nt.level, cap)) ||
+        (rc = sc.get(&nt.child_mask, cap)) || (rc = sc.get(&nt.open, cap)) ||
+        (rc = sc.get(&nt.bounds, (size_t)cap * 9)) || (rc = sc.get(&nt.counters, 64)))
+      return rc;
+  }
+  uint32_t counters[64];
+  bool keys32 = false;
+  int attempts = 0;
+
+  // ---- single-chain build (pcv_spec.h): ONE chain pass, topology from a sample + exact per-leaf counts ----
+  bool spec_used = false;
+  PcvTrueTree true_tree;
+  {
+    bool wide_level = false;  // a Float64-encoded level needs the high code words: left to the exact pipeline
+    for (int k = 0; k <= full_levels; ++k) wide_level = wide_level || lv.enc[k] == PCV_ENC_FLOAT64;
+    const bool forced = (params->flags & PCV_BUILD_FORCE_SINGLE_CHAIN) != 0;
+    const bool want = !(params->flags & (PCV_BUILD_NO_SPECULATION | PCV_BUILD_NO_SINGLE_CHAIN)) && (forced || n >= (1ull << 22));
+    if (want && !wide_level && full_levels >= 1) {
+      if ((rc = single_chain_topology(ctx, bs, t, params, max_points, full_levels, nt, &true_tree, &spec_used))) return rc;
+      if (spec_used) counters[0] = (uint32_t)true_tree.prefix.size();
+      else ++attempts;  // the prediction was too shallow somewhere: the exact pipeline redoes the build
+    }
+  }
+
+  if (!spec_used && n >= (1ull << 22) && full_levels > 4 && !(params->flags & PCV_BUILD_NO_SPECULATION)) {
     const uint32_t ns = 1u << 18;
     const uint64_t stride = n / ns;
     uint32_t* d_max;
@@ -694,16 +892,13 @@ static int build_begin_impl(pcv_ctx* ctx, const pcv_build_params* params, const 
     if (want < full_levels) spec_levels = want;
   }
 
-  PcvNodeTableDev nt;
-  uint32_t counters[64];
-  bool keys32 = false;
-  int attempts = 0;
-  for (;;) {
+  for (; !spec_used;) {
     ++attempts;
     lv.nlevels = spec_levels;
     keys32 = spec_levels <= 10;
     pcv_launch_chain_keys(ctx, lv, n, 1, d.x, d.y, d.z, keys_a, keys32, d.routed);
-    PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[2], st));
+    ctx->stage_end(PCV_STAGE_CHAIN_KEYS);
+    ctx->stage_begin(PCV_STAGE_SORT_KEYS);
     bool in_a = true;
     if (keys32)
       rc = pcv_radix_sort_u32(ctx, (uint32_t*)keys_a, (uint32_t*)keys_b, n, 3 * (10 - spec_levels), 30, nullptr,
@@ -713,25 +908,14 @@ static int build_begin_impl(pcv_ctx* ctx, const pcv_build_params* params, const 
                               nullptr, sort_scratch, &in_a);
     if (rc) return rc;
     const void* sorted_keys = in_a ? (const void*)keys_a : (const void*)keys_b;
-    PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[3], st));
+    ctx->stage_end(PCV_STAGE_SORT_KEYS);
+    ctx->stage_begin(PCV_STAGE_NODE_SPLIT);
 
     // K4: every open node holds > max_points points and open nodes of one level are disjoint
-    if (attempts == 1) {
-      const int deepest = max_level < PCV_MAX_LEVELS ? max_level : PCV_MAX_LEVELS;  // incl. the deep retry
-      uint64_t cap64 = 8ull * (uint64_t)(deepest + 1) * (n / max_points + 1) + 64;
-      if (cap64 > (1ull << 26)) cap64 = 1ull << 26;
-      const uint32_t cap = (uint32_t)cap64;
-      nt.capacity = cap;
-      nt.prefix_lo = nullptr;
-      if ((rc = sc.get(&nt.prefix, cap)) || (rc = sc.get(&nt.lo, cap)) || (rc = sc.get(&nt.hi, cap)) ||
-          (rc = sc.get(&nt.parent, cap)) || (rc = sc.get(&nt.first_child, cap)) || (rc = sc.get(&nt.level, cap)) ||
-          (rc = sc.get(&nt.child_mask, cap)) || (rc = sc.get(&nt.open, cap)) ||
-          (rc = sc.get(&nt.bounds, (size_t)cap * 9)) || (rc = sc.get(&nt.counters, 64)))
-        return rc;
-    }
     pcv_launch_node_split(ctx, nt, sorted_keys, keys32, (uint32_t)n, lv, params->resolution, max_points,
                           (params->flags >> 8) & 0xffu);
-    PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[4], st));
+    ctx->stage_end(PCV_STAGE_NODE_SPLIT);
+    ctx->stage_begin(PCV_STAGE_TABLE);
 
     // ---- node table to host ----
     PCV_HIP_CHECK(ctx, hipMemcpyAsync(ctx->mailbox, nt.counters, sizeof(counters), hipMemcpyDeviceToHost, st));
@@ -778,7 +962,8 @@ static int build_begin_impl(pcv_ctx* ctx, const pcv_build_params* params, const 
         bs->d_prefix_lo = nt.prefix_lo;
         pcv_launch_node_split(ctx, nt, keys_a, false, (uint32_t)n, lv, params->resolution, max_points,
                               (params->flags >> 8) & 0xffu, keys_b);
-        PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[4], st));
+        ctx->stage_end(PCV_STAGE_NODE_SPLIT);
+        ctx->stage_begin(PCV_STAGE_TABLE);
         PCV_HIP_CHECK(ctx, hipMemcpyAsync(ctx->mailbox, nt.counters, sizeof(counters), hipMemcpyDeviceToHost, st));
         PCV_HIP_CHECK(ctx, hipStreamSynchronize(st));
         std::memcpy(counters, ctx->mailbox, sizeof(counters));
@@ -813,16 +998,26 @@ static int build_begin_impl(pcv_ctx* ctx, const pcv_build_params* params, const 
   uint8_t* h_level = (uint8_t*)(h_first + M);
   uint8_t* h_mask = h_level + M;
   uint8_t* h_open = h_mask + M;
-  PCV_HIP_CHECK(ctx, hipMemcpyAsync(h_prefix, nt.prefix, (size_t)M * 8, hipMemcpyDeviceToHost, st));
-  PCV_HIP_CHECK(ctx, hipMemcpyAsync(h_lo, nt.lo, (size_t)M * 4, hipMemcpyDeviceToHost, st));
-  PCV_HIP_CHECK(ctx, hipMemcpyAsync(h_hi, nt.hi, (size_t)M * 4, hipMemcpyDeviceToHost, st));
-  PCV_HIP_CHECK(ctx, hipMemcpyAsync(h_first, nt.first_child, (size_t)M * 4, hipMemcpyDeviceToHost, st));
-  PCV_HIP_CHECK(ctx, hipMemcpyAsync(h_level, nt.level, (size_t)M, hipMemcpyDeviceToHost, st));
-  PCV_HIP_CHECK(ctx, hipMemcpyAsync(h_mask, nt.child_mask, (size_t)M, hipMemcpyDeviceToHost, st));
-  PCV_HIP_CHECK(ctx, hipMemcpyAsync(h_open, nt.open, (size_t)M, hipMemcpyDeviceToHost, st));
-  if (bs->deep)
-    PCV_HIP_CHECK(ctx, hipMemcpyAsync(hp + lo_off, nt.prefix_lo, (size_t)M * 8, hipMemcpyDeviceToHost, st));
-  PCV_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  if (spec_used) {  // the true tree was derived on the host from the exact per-leaf counts: same layout, no download
+    std::memcpy(h_prefix, true_tree.prefix.data(), (size_t)M * 8);
+    std::memcpy(h_lo, true_tree.lo.data(), (size_t)M * 4);
+    std::memcpy(h_hi, true_tree.hi.data(), (size_t)M * 4);
+    std::memcpy(h_first, true_tree.first_child.data(), (size_t)M * 4);
+    std::memcpy(h_level, true_tree.level.data(), (size_t)M);
+    std::memcpy(h_mask, true_tree.child_mask.data(), (size_t)M);
+    std::memcpy(h_open, true_tree.open.data(), (size_t)M);
+  } else {
+    PCV_HIP_CHECK(ctx, hipMemcpyAsync(h_prefix, nt.prefix, (size_t)M * 8, hipMemcpyDeviceToHost, st));
+    PCV_HIP_CHECK(ctx, hipMemcpyAsync(h_lo, nt.lo, (size_t)M * 4, hipMemcpyDeviceToHost, st));
+    PCV_HIP_CHECK(ctx, hipMemcpyAsync(h_hi, nt.hi, (size_t)M * 4, hipMemcpyDeviceToHost, st));
+    PCV_HIP_CHECK(ctx, hipMemcpyAsync(h_first, nt.first_child, (size_t)M * 4, hipMemcpyDeviceToHost, st));
+    PCV_HIP_CHECK(ctx, hipMemcpyAsync(h_level, nt.level, (size_t)M, hipMemcpyDeviceToHost, st));
+    PCV_HIP_CHECK(ctx, hipMemcpyAsync(h_mask, nt.child_mask, (size_t)M, hipMemcpyDeviceToHost, st));
+    PCV_HIP_CHECK(ctx, hipMemcpyAsync(h_open, nt.open, (size_t)M, hipMemcpyDeviceToHost, st));
+    if (bs->deep)
+      PCV_HIP_CHECK(ctx, hipMemcpyAsync(hp + lo_off, nt.prefix_lo, (size_t)M * 8, hipMemcpyDeviceToHost, st));
+    PCV_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  }
 
   // upload area (pinned, after the download area)
   uint8_t* up = hp + ((host_bytes + 255) & ~(size_t)255);
@@ -1059,7 +1254,7 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
   PcvPromoteTables pt;
   pt.node_rec = (const PcvNodeRec*)(d_up + walk_bytes);
   pt.leaf_rec = pt.node_rec + M;
-  PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[5], st));
+  ctx->stage_end(PCV_STAGE_TABLE);
 
   // ---- K5 leaf encode (input order) ----
   // record = rank (u32) + one 16-byte payload {code x, code y, code z, rgba}; optional 4-byte planes for the
@@ -1067,8 +1262,8 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
   // The key buffers are dead now: each (8n bytes) hosts one rank array; payloads get their own buffers.
   uint32_t* rank_a = (uint32_t*)keys_a;
   uint32_t* rank_b = (uint32_t*)keys_b;
-  uint4 *pay_a, *pay_b;
-  if ((rc = sc.get(&pay_a, n)) || (rc = sc.get(&pay_b, n))) return rc;
+  uint4 *pay_a = (uint4*)bs->spec_payload, *pay_b;
+  if ((!pay_a && (rc = sc.get(&pay_a, n))) || (rc = sc.get(&pay_b, n))) return rc;
   PcvSortPayload pl;
   pl.vec_in = pay_a;
   pl.vec_out = pay_b;
@@ -1083,10 +1278,14 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
   }
   const int w_int = t->has_intensity ? 0 : -1;
   const int w_hi = wide ? (t->has_intensity ? 1 : 0) : -1;
-  pcv_launch_leaf_encode(ctx, lv, wt, n, d.x, d.y, d.z, d.routed, d.color, d.color_stride, d.intensity, rank_a, pay_a,
-                         wide ? pl.in[w_hi] : nullptr, wide ? pl.in[w_hi + 1] : nullptr, wide ? pl.in[w_hi + 2] : nullptr,
-                         w_int >= 0 ? pl.in[w_int] : nullptr);
-  PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[6], st));
+  if (!bs->spec) {  // the single-chain build wrote (true-leaf rank, leaf codes, rgb[, intensity]) while it found the topology
+    ctx->stage_begin(PCV_STAGE_LEAF_ENCODE);
+    pcv_launch_leaf_encode(ctx, lv, wt, n, d.x, d.y, d.z, d.routed, d.color, d.color_stride, d.intensity, rank_a, pay_a,
+                           wide ? pl.in[w_hi] : nullptr, wide ? pl.in[w_hi + 1] : nullptr, wide ? pl.in[w_hi + 2] : nullptr,
+                           w_int >= 0 ? pl.in[w_int] : nullptr);
+    ctx->stage_end(PCV_STAGE_LEAF_ENCODE);
+  }
+  ctx->stage_begin(PCV_STAGE_SORT_RECORDS);
 
   // ---- K3 stable record sort by leaf rank ----
   int rank_bits = 1;
@@ -1096,7 +1295,8 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
   uint32_t* s_rank = rec_in_a ? rank_a : rank_b;
   const void* s_pay = rec_in_a ? (const void*)pay_a : (const void*)pay_b;
   uint32_t** s_plane = rec_in_a ? pl.in : pl.out;
-  PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[7], st));
+  ctx->stage_end(PCV_STAGE_SORT_RECORDS);
+  ctx->stage_begin(PCV_STAGE_PROMOTE_ENCODE);
 
   // ---- K6 promotion + final encode into node-contiguous blobs ----
   void *bx, *br, *bi = nullptr;
@@ -1118,11 +1318,15 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
   pcv_launch_promote_encode(ctx, lv, pt, n, s_rank, s_pay, wide ? s_plane[w_hi] : nullptr,
                             wide ? s_plane[w_hi + 1] : nullptr, wide ? s_plane[w_hi + 2] : nullptr,
                             w_int >= 0 ? s_plane[w_int] : nullptr, t->d_xyz, t->d_rgb, t->d_int);
+  ctx->stage_end(PCV_STAGE_PROMOTE_ENCODE);
   PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[8], st));
   PCV_HIP_CHECK(ctx, hipGetLastError());
   PCV_HIP_CHECK(ctx, hipStreamSynchronize(st));
   ctx->prof_resolve();
-  for (int sidx = 0; sidx < 8; ++sidx) (void)hipEventElapsedTime(&t->stage_ms[sidx], ctx->ev[sidx], ctx->ev[sidx + 1]);
+  for (int sidx = 0; sidx < PCV_STAGE_TOTAL; ++sidx) {
+    t->stage_ms[sidx] = 0.f;
+    if (ctx->stage_on[sidx]) (void)hipEventElapsedTime(&t->stage_ms[sidx], ctx->stage_b[sidx], ctx->stage_e[sidx]);
+  }
   (void)hipEventElapsedTime(&t->stage_ms[PCV_STAGE_TOTAL], ctx->ev[0], ctx->ev[8]);
   return PCV_OK;
 }

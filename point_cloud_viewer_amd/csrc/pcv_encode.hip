@@ -10,6 +10,7 @@
 //     (encode_k(decode_k(b))) at slot j - j/8 - 1; the root keeps everything it receives.
 //     Output is written node-contiguous: exactly the bytes of <node>.xyz/.rgb/.intensity.
 #include "pcv_chain_dev.h"
+#include "pcv_spec.h"
 
 namespace {
 
@@ -66,6 +67,138 @@ __global__ __launch_bounds__(256) void leaf_encode_kernel(
     cz_hi[i] = (uint32_t)(ccz >> 32);
   }
   if (inten_bits) inten_bits[i] = __float_as_uint(intensity[i]);
+}
+
+// ---- single-chain build (pcv_spec.h): ONE chain pass down the predicted tree T'' --------------------------------------
+// Every inner node of T'' has all eight children (consecutive walk records), so a digit indexes the child directly.
+// A point passing through a candidate node (sampled count close to the capacity) keeps the codes it has AT that node
+// (the first such node on its path): if the exact counts later say the node is a leaf, those are the point's leaf
+// codes; otherwise the codes of the predicted leaf are. Output: predicted-leaf rank, payload {codes, rgb} at the
+// predicted leaf, and — only for points that passed a candidate — the kept codes + their level.
+template <bool KEEP>
+__global__ __launch_bounds__(256) void spec_encode_kernel(
+    PcvLevels lv, const uint64_t* __restrict__ walk, uint64_t n, const double* __restrict__ x,
+    const double* __restrict__ y, const double* __restrict__ z, PcvRouted routed, const uint8_t* __restrict__ color,
+    uint32_t color_stride, const float* __restrict__ intensity, uint32_t* __restrict__ rank, uint4* __restrict__ payload,
+    uint4* __restrict__ kept, uint32_t* __restrict__ inten_bits) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint64_t rec = walk[0];
+  double px, py, pz, mx, my, mz;
+  double vx = 0, vy = 0, vz = 0;
+  double kx = 0, ky = 0, kz = 0;
+  int kl = 0;
+  uint32_t d1;
+  int L = 0;
+  if (pcv_chain_start(lv, routed, x, y, z, i, px, py, pz, mx, my, mz, vx, vy, vz, d1) == 2 && !(rec & PCV_SPEC_LEAF)) {
+    L = 1;  // routed input: level 1 is given (digit + codes)
+    rec = walk[(uint32_t)rec + d1];
+  }
+#define PCV_SPEC_WALK(GUARD)                                                                                          \
+  while (!(rec & PCV_SPEC_LEAF) && L < lv.nlevels) {                                                                    \
+    if (KEEP && (rec & PCV_SPEC_CANDIDATE) && kl == 0) {                                                                \
+      kx = vx, ky = vy, kz = vz;                                                                                        \
+      kl = L; /* candidates have level >= 1 */                                                                          \
+    }                                                                                                                   \
+    ++L;                                                                                                                \
+    const uint32_t d = pcv_chain_level<GUARD>(lv.enc[L], lv.edge[L - 1], lv.edge[L], PcvRecip{lv.inv_edge[L], lv.inv_edge_lo[L]}, \
+                                              px, py, pz, mx, my, mz, vx, vy, vz);                                      \
+    rec = walk[(uint32_t)rec + d];                                                                                      \
+  }
+  if (lv.fast_ok && pcv_point_is_tame(px, py, pz)) {
+    PCV_SPEC_WALK(false)
+  } else {
+    PCV_SPEC_WALK(true)
+  }
+#undef PCV_SPEC_WALK
+  rank[i] = (uint32_t)rec;
+  const uint32_t leaf_enc = lv.enc[L];
+  const uint8_t* c = color + i * color_stride;
+  payload[i] = make_uint4((uint32_t)pcv_val_to_code(leaf_enc, vx), (uint32_t)pcv_val_to_code(leaf_enc, vy),
+                          (uint32_t)pcv_val_to_code(leaf_enc, vz), (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16));
+  if (KEEP && kl) {
+    const uint32_t ke = lv.enc[kl];
+    kept[i] = make_uint4((uint32_t)pcv_val_to_code(ke, kx), (uint32_t)pcv_val_to_code(ke, ky), (uint32_t)pcv_val_to_code(ke, kz),
+                         (uint32_t)kl);
+  }
+  if (inten_bits) inten_bits[i] = __float_as_uint(intensity[i]);
+}
+
+// Exact number of points per predicted leaf: LDS-privatised histogram of the rank array over the bins
+// [bin_base, bin_base + nbins), nbins <= kHistBins; one flush of the non-zero bins per workgroup.
+constexpr int kHistBins = 12288;  // 48 KiB of LDS
+__global__ __launch_bounds__(1024) void rank_hist_kernel(const uint32_t* __restrict__ rank, uint64_t n, uint64_t chunk,
+                                                          uint32_t bin_base, uint32_t nbins, uint32_t* __restrict__ counts) {
+  __shared__ uint32_t hist[kHistBins];
+  for (uint32_t b = threadIdx.x; b < nbins; b += 1024) hist[b] = 0;
+  __syncthreads();
+  const uint64_t begin = (uint64_t)blockIdx.x * chunk;
+  uint64_t end = begin + chunk;
+  if (end > n) end = n;
+  // chunk is a multiple of 4 and the array comes from the pool (256-byte aligned): 16-byte loads
+  for (uint64_t i = begin + (uint64_t)threadIdx.x * 4; i < end; i += 4096) {
+    if (i + 4 <= end) {
+      const uint4 v = *reinterpret_cast<const uint4*>(rank + i);
+      const uint32_t r[4] = {v.x - bin_base, v.y - bin_base, v.z - bin_base, v.w - bin_base};
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (r[k] < nbins) atomicAdd(&hist[r[k]], 1u);
+    } else {
+      for (uint64_t j = i; j < end; ++j) {
+        const uint32_t r = rank[j] - bin_base;
+        if (r < nbins) atomicAdd(&hist[r], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < nbins; b += 1024) {
+    const uint32_t v = hist[b];
+    if (v) atomicAdd(&counts[bin_base + b], v);
+  }
+}
+
+// After the exact counts fixed the true tree: predicted-leaf rank -> true-leaf rank, and the payload takes the kept
+// codes where the true leaf is the candidate node (bit 31 of the map). FIX: predicted leaves whose true leaf is an
+// inner node of T'' WITHOUT kept codes (a candidate below a candidate, or a count far outside the band) carry the
+// level of that leaf in `fix_level`; their points replay the chain to that level — rare, and only the waves that
+// contain such a point pay for it.
+template <bool FIX>
+__global__ __launch_bounds__(256) void spec_finalize_kernel(
+    PcvLevels lv, uint64_t n, const uint32_t* __restrict__ spec_map, const uint8_t* __restrict__ fix_level,
+    const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ z, PcvRouted routed,
+    uint32_t* __restrict__ rank, uint4* __restrict__ payload, const uint4* __restrict__ kept) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t r = rank[i];
+  const uint32_t m = spec_map[r];
+  rank[i] = m & 0x7fffffffu;
+  if (FIX) {
+    const int target = fix_level[r];
+    if (target) {
+      double px, py, pz, mx, my, mz;
+      double vx = 0, vy = 0, vz = 0;
+      uint32_t d1;
+      int L = pcv_chain_start(lv, routed, x, y, z, i, px, py, pz, mx, my, mz, vx, vy, vz, d1) - 1;
+      while (L < target) {
+        ++L;
+        (void)pcv_chain_level<true>(lv.enc[L], lv.edge[L - 1], lv.edge[L], PcvRecip{lv.inv_edge[L], lv.inv_edge_lo[L]}, px, py, pz,
+                                    mx, my, mz, vx, vy, vz);
+      }
+      const uint32_t e = lv.enc[target];
+      uint4 p = payload[i];
+      p.x = (uint32_t)pcv_val_to_code(e, vx);
+      p.y = (uint32_t)pcv_val_to_code(e, vy);
+      p.z = (uint32_t)pcv_val_to_code(e, vz);
+      payload[i] = p;
+      return;
+    }
+  }
+  if (m >> 31) {
+    const uint4 k = kept[i];
+    uint4 p = payload[i];
+    p.x = k.x, p.y = k.y, p.z = k.z;
+    payload[i] = p;
+  }
 }
 
 struct PromoteOut {
@@ -235,6 +368,48 @@ void pcv_launch_leaf_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvWalkTabl
   PcvProf prof(ctx, PCV_K_LEAF_ENCODE);
   hipLaunchKernelGGL(leaf_encode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, lv, wt.walk, n, x,
                      y, z, routed, color, color_stride, intensity, rank, (uint4*)payload, cx_hi, cy_hi, cz_hi, inten_bits);
+}
+
+void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint64_t* walk, uint64_t n, const double* x,
+                            const double* y, const double* z, const PcvRouted& routed, const uint8_t* color,
+                            uint32_t color_stride, const float* intensity, uint32_t* rank, void* payload, void* kept,
+                            uint32_t* inten_bits) {
+  if (n == 0) return;
+  PcvProf prof(ctx, PCV_K_SPEC_ENCODE);
+  const dim3 grid((unsigned)((n + 255) / 256));
+  if (kept)
+    hipLaunchKernelGGL(spec_encode_kernel<true>, grid, dim3(256), 0, ctx->stream, lv, walk, n, x, y, z, routed, color,
+                       color_stride, intensity, rank, (uint4*)payload, (uint4*)kept, inten_bits);
+  else
+    hipLaunchKernelGGL(spec_encode_kernel<false>, grid, dim3(256), 0, ctx->stream, lv, walk, n, x, y, z, routed, color,
+                       color_stride, intensity, rank, (uint4*)payload, (uint4*)nullptr, inten_bits);
+}
+
+void pcv_launch_rank_hist(pcv_ctx* ctx, const uint32_t* rank, uint64_t n, uint32_t num_bins, uint32_t* counts) {
+  if (n == 0 || num_bins == 0) return;
+  // one workgroup per CU-ish: 512 workgroups of 1024 lanes; the chunk is a multiple of 4096 keys
+  uint64_t chunk = (n + 511) / 512;
+  chunk = (chunk + 4095) & ~(uint64_t)4095;
+  const unsigned groups = (unsigned)((n + chunk - 1) / chunk);
+  for (uint32_t base = 0; base < num_bins; base += kHistBins) {
+    const uint32_t nb = num_bins - base < (uint32_t)kHistBins ? num_bins - base : (uint32_t)kHistBins;
+    PcvProf prof(ctx, PCV_K_RANK_HIST);
+    hipLaunchKernelGGL(rank_hist_kernel, dim3(groups), dim3(1024), 0, ctx->stream, rank, n, chunk, base, nb, counts);
+  }
+}
+
+void pcv_launch_spec_finalize(pcv_ctx* ctx, const PcvLevels& lv, uint64_t n, const uint32_t* spec_map, const uint8_t* fix_level,
+                              const double* x, const double* y, const double* z, const PcvRouted& routed, uint32_t* rank,
+                              void* payload, const void* kept) {
+  if (n == 0) return;
+  PcvProf prof(ctx, PCV_K_SPEC_FINALIZE);
+  const dim3 grid((unsigned)((n + 255) / 256));
+  if (fix_level)
+    hipLaunchKernelGGL(spec_finalize_kernel<true>, grid, dim3(256), 0, ctx->stream, lv, n, spec_map, fix_level, x, y, z, routed,
+                       rank, (uint4*)payload, (const uint4*)kept);
+  else
+    hipLaunchKernelGGL(spec_finalize_kernel<false>, grid, dim3(256), 0, ctx->stream, lv, n, spec_map, fix_level, x, y, z, routed,
+                       rank, (uint4*)payload, (const uint4*)kept);
 }
 
 void pcv_launch_promote_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvPromoteTables& pt, uint64_t n,

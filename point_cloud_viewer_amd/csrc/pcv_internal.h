@@ -64,6 +64,9 @@ enum PcvKernelId {
   PCV_K_PARTITION_COUNT,
   PCV_K_PARTITION_SCATTER,
   PCV_K_PROMOTE_CLIMB,
+  PCV_K_SPEC_ENCODE,
+  PCV_K_RANK_HIST,
+  PCV_K_SPEC_FINALIZE,
   PCV_K_COUNT
 };
 
@@ -80,6 +83,17 @@ struct pcv_ctx {
   void* pinned = nullptr;
   size_t pinned_bytes = 0;
   hipEvent_t ev[PCV_NUM_STAGES + 2] = {};
+  // per-stage begin / end events of the build in flight (a stage may be recorded out of order or not at all)
+  hipEvent_t stage_b[PCV_NUM_STAGES] = {}, stage_e[PCV_NUM_STAGES] = {};
+  bool stage_on[PCV_NUM_STAGES] = {};
+  void stage_begin(int s) {
+    (void)hipEventRecord(stage_b[s], stream);
+    stage_on[s] = false;
+  }
+  void stage_end(int s) {
+    (void)hipEventRecord(stage_e[s], stream);
+    stage_on[s] = true;
+  }
   hipEvent_t xev = nullptr;  // stream hand-off with the caller's runtime (pcv_ctx_wait_stream / _signal_stream)
 
   // per-launch profile: event pairs recorded on `stream`, resolved after the next stream sync
@@ -230,6 +244,17 @@ void pcv_launch_leaf_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvWalkTabl
                             uint32_t* cx_hi,
                             uint32_t* cy_hi, uint32_t* cz_hi, uint32_t* inten_bits);
 
+// single-chain build (pcv_spec.h): the one chain pass down the predicted tree, the exact per-leaf counts, and the
+// rank / payload fix-up once the true tree is known
+void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint64_t* walk, uint64_t n, const double* x,
+                            const double* y, const double* z, const PcvRouted& routed, const uint8_t* color,
+                            uint32_t color_stride, const float* intensity, uint32_t* rank, void* payload /* uint4[n] */,
+                            void* kept /* uint4[n] or null */, uint32_t* inten_bits);
+void pcv_launch_rank_hist(pcv_ctx* ctx, const uint32_t* rank, uint64_t n, uint32_t num_bins, uint32_t* counts /* zeroed */);
+void pcv_launch_spec_finalize(pcv_ctx* ctx, const PcvLevels& lv, uint64_t n, const uint32_t* spec_map, const uint8_t* fix_level,
+                              const double* x, const double* y, const double* z, const PcvRouted& routed, uint32_t* rank,
+                              void* payload, const void* kept);
+
 // Everything K6 needs about a node in one 80-byte record, so a slot's dependent loads are rank -> record (-> the
 // parent's record per climb) instead of chained table lookups (node, level, per-level edge/encoding, offsets).
 struct alignas(16) PcvNodeRec {
@@ -275,7 +300,9 @@ struct pcv_octree {
   bool host_valid = false;
   float stage_ms[PCV_NUM_STAGES] = {};
   int key_levels = 0;    // digit levels the key sort covered (depth speculation)
-  int key_attempts = 0;  // 1 = speculation held (or was off), 2 = redone at full depth
+  int key_attempts = 0;  // 0 = single-chain build, 1 = depth speculation held (or was off), 2+ = redone
+  uint64_t spec_stats[4] = {};  // single-chain build: nodes / leaves of the predicted tree, points that took their kept
+                                // codes, points that replayed the chain
   PcvOctreeQuery* query = nullptr;
   // octrees opened from a directory: node files are read on demand
   std::string directory;

@@ -1,0 +1,297 @@
+// pcv_spec.cpp — host logic of the single-chain build (see pcv_spec.h). Plain C++, no HIP: unit-tested on the CPU
+// through pcv_spec_selftest (tests/test_spec_cpu.py) against the oracle's tree.
+#include "pcv_spec.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "../../include/pcv_hip.h"
+
+namespace {
+constexpr int kKeyLevels = PCV_MAX_KEY_LEVELS;  // 21 levels x 3 bits, level 1 at the top of the 63-bit key
+
+inline uint64_t digit_bits(unsigned c, int level) { return (uint64_t)c << (3 * (kKeyLevels - level)); }
+}  // namespace
+
+uint32_t pcv_spec_sample_threshold(const PcvSpecParams& p) {
+  // open a sample node iff count_s * scale > cap * (1 - delta)  <=>  count_s > floor(cap * (1 - delta) / scale)
+  const double t = std::floor((double)p.cap * (1.0 - p.delta) / p.scale);
+  return t <= 0.0 ? 0u : (t >= 4294967294.0 ? 4294967294u : (uint32_t)t);
+}
+
+void pcv_spec_build_tree(const PcvSpecParams& p, const PcvSampleTable& s, PcvSpecTree* out) {
+  PcvSpecTree& t = *out;
+  t = PcvSpecTree();
+  // a sample node inside the band: opened (count_s > lower threshold) but count_s * scale <= cap * (1 + delta)
+  const double upper = (double)p.cap * (1.0 + p.delta) / p.scale;
+  std::vector<int64_t> sample_of;  // T'' node -> sample node, -1 = no sample point fell in it
+  auto push = [&](uint64_t prefix, int level, uint32_t parent, int64_t sample_node) {
+    t.prefix.push_back(prefix);
+    t.level.push_back((uint8_t)level);
+    t.inner.push_back(0);
+    t.candidate.push_back(0);
+    t.first_child.push_back(0);
+    t.parent.push_back(parent);
+    t.leaf_rank.push_back(0);
+    sample_of.push_back(sample_node);
+  };
+  push(0, 0, 0xffffffffu, s.num_nodes ? 0 : -1);
+  for (size_t i = 0; i < t.prefix.size(); ++i) {  // breadth first: the vectors grow while we walk them
+    const int64_t sn = sample_of[i];
+    if (sn < 0 || !s.open[sn]) continue;
+    const int level = t.level[i];
+    t.inner[i] = 1;
+    t.first_child[i] = (uint32_t)t.prefix.size();
+    const double cnt = (double)(s.hi[sn] - s.lo[sn]);
+    const bool forced = level == 0 || (level == 1 && ((p.force_mask >> ((t.prefix[i] >> (3 * (kKeyLevels - 1))) & 7)) & 1u));
+    if (!forced && cnt <= upper) {
+      t.candidate[i] = 1;
+      t.any_candidate = true;
+    }
+    uint32_t next = s.first_child[sn];
+    const uint64_t pfx = t.prefix[i];
+    for (unsigned c = 0; c < 8; ++c) {
+      const bool present = (s.child_mask[sn] >> c) & 1;
+      push(pfx | digit_bits(c, level + 1), level + 1, (uint32_t)i, present ? (int64_t)next : -1);
+      if (present) ++next;
+    }
+  }
+  // predicted-leaf ranks in key order: depth first, digits ascending
+  std::vector<uint32_t> stack;
+  stack.push_back(0);
+  while (!stack.empty()) {
+    const uint32_t i = stack.back();
+    stack.pop_back();
+    if (!t.inner[i]) {
+      t.leaf_rank[i] = t.num_leaves++;
+      continue;
+    }
+    for (int c = 7; c >= 0; --c) stack.push_back(t.first_child[i] + (uint32_t)c);
+  }
+  t.walk.resize(t.prefix.size());
+  for (size_t i = 0; i < t.prefix.size(); ++i) {
+    uint64_t rec = (uint64_t)t.level[i] << PCV_SPEC_LEVEL_SHIFT;
+    if (t.inner[i]) rec |= (uint64_t)t.first_child[i] | (t.candidate[i] ? PCV_SPEC_CANDIDATE : 0ull);
+    else rec |= (uint64_t)t.leaf_rank[i] | PCV_SPEC_LEAF;
+    t.walk[i] = rec;
+  }
+}
+
+PcvSpecStatus pcv_spec_resolve(const PcvSpecParams& p, const PcvSpecTree& t, const uint32_t* leaf_counts, PcvTrueTree* out) {
+  PcvTrueTree& r = *out;
+  r = PcvTrueTree();
+  const size_t m = t.prefix.size();
+  // exact point count of every T'' node: children follow their parent in the (breadth-first) table
+  std::vector<uint64_t> cnt(m, 0);
+  for (size_t i = m; i-- > 0;) {
+    if (!t.inner[i]) cnt[i] = leaf_counts[t.leaf_rank[i]];
+    else
+      for (unsigned c = 0; c < 8; ++c) cnt[i] += cnt[t.first_child[i] + c];
+  }
+  r.spec_map.assign(t.num_leaves, 0);
+  r.fix_level.assign(t.num_leaves, 0);
+  if (cnt[0] == 0) return PCV_SPEC_OK;  // no points: no nodes (the caller handles n == 0 before it gets here)
+
+  // should_split_node (generation.rs:128-150) with the EXACT counts; the root is always split (generation.rs:312-323)
+  auto split = [&](uint32_t i) {
+    const int level = t.level[i];
+    if (level == 0) return true;
+    if (level == 1 && ((p.force_mask >> ((t.prefix[i] >> (3 * (kKeyLevels - 1))) & 7)) & 1u)) return true;
+    return cnt[i] > (uint64_t)p.cap && p.edge[level] > p.resolution;
+  };
+  // true tree, breadth first; src[k] = T'' node of true node k
+  std::vector<uint32_t> src;
+  std::vector<uint8_t> kept_above;  // a candidate ancestor already holds this path's kept codes
+  src.push_back(0);
+  kept_above.push_back(0);
+  for (size_t k = 0; k < src.size(); ++k) {
+    const uint32_t i = src[k];
+    r.prefix.push_back(t.prefix[i]);
+    r.level.push_back(t.level[i]);
+    r.lo.push_back(0);
+    r.hi.push_back(0);
+    r.first_child.push_back(0);
+    r.child_mask.push_back(0);
+    r.open.push_back(0);
+    if (t.level[i] > r.deepest_level) r.deepest_level = t.level[i];
+    if (!split(i)) continue;
+    if (!t.inner[i]) return PCV_SPEC_TOO_SHALLOW;  // the prediction stops above where the tree goes on
+    r.open[k] = 1;
+    r.first_child[k] = (uint32_t)src.size();
+    uint8_t mask = 0;
+    for (unsigned c = 0; c < 8; ++c) {
+      const uint32_t ch = t.first_child[i] + c;
+      if (cnt[ch] == 0) continue;  // a child exists iff a point lies in it
+      mask |= (uint8_t)(1u << c);
+      src.push_back(ch);
+      kept_above.push_back((uint8_t)(kept_above[k] | t.candidate[i]));
+    }
+    r.child_mask[k] = mask;
+  }
+  // leaves in key order (depth first, digits ascending — the order pcv_build_finish ranks them in): ranges in the
+  // sorted order and the predicted-leaf -> true-leaf map
+  std::vector<uint32_t> stack;
+  stack.push_back(0);
+  uint64_t run = 0;
+  std::vector<uint32_t> below;
+  while (!stack.empty()) {
+    const uint32_t k = stack.back();
+    stack.pop_back();
+    if (r.open[k]) {
+      const uint32_t nchild = (uint32_t)__builtin_popcount(r.child_mask[k]);
+      for (uint32_t c = nchild; c-- > 0;) stack.push_back(r.first_child[k] + c);
+      continue;
+    }
+    const uint32_t i = src[k];
+    const uint32_t rank = r.num_leaves++;
+    r.lo[k] = (uint32_t)run;
+    run += cnt[i];
+    r.hi[k] = (uint32_t)run;
+    if (!t.inner[i]) {
+      r.spec_map[t.leaf_rank[i]] = rank;  // the point's predicted leaf IS its leaf: codes of the predicted leaf
+      continue;
+    }
+    // a true leaf that the prediction split: its points kept their codes at this node iff it is the first candidate
+    // on their path; otherwise they replay the chain to this level
+    const bool has_codes = t.candidate[i] && !kept_above[k];
+    if (has_codes) r.kept_points += cnt[i];
+    else {
+      r.any_fix = true;
+      r.fix_points += cnt[i];
+    }
+    below.clear();
+    below.push_back(i);
+    while (!below.empty()) {
+      const uint32_t j = below.back();
+      below.pop_back();
+      if (!t.inner[j]) {
+        r.spec_map[t.leaf_rank[j]] = has_codes ? (rank | 0x80000000u) : rank;
+        if (!has_codes) r.fix_level[t.leaf_rank[j]] = t.level[i];
+      } else {
+        for (unsigned c = 0; c < 8; ++c) below.push_back(t.first_child[j] + c);
+      }
+    }
+  }
+  // inner nodes: [lo, hi) spans their leaves (children are contiguous and in digit order; bottom-up over the table)
+  for (size_t k = src.size(); k-- > 0;) {
+    if (!r.open[k]) continue;
+    const uint32_t nchild = (uint32_t)__builtin_popcount(r.child_mask[k]);
+    r.lo[k] = r.lo[r.first_child[k]];
+    r.hi[k] = r.hi[r.first_child[k] + nchild - 1];
+  }
+  return PCV_SPEC_OK;
+}
+
+// ---- CPU self-test hook (tests/test_spec_cpu.py) --------------------------------------------------------------------
+// Runs the whole host logic on given full-depth path keys (from the oracle): strided sample -> sample tree (a plain
+// CPU restatement of what the device node split produces) -> T'' -> walk every key down T'' -> exact counts -> true tree.
+// Returns the status; the true tree comes back as (prefix, level, point count before promotion, open) per node.
+extern "C" int pcv_spec_selftest(const uint64_t* keys, uint64_t n, uint32_t stride, uint32_t cap, double delta,
+                                 double resolution, const double* edge, int nlevels, uint32_t force_mask,
+                                 uint64_t node_capacity, uint64_t* out_prefix, uint8_t* out_level, uint64_t* out_count,
+                                 uint8_t* out_open, uint64_t* out_num_nodes, uint64_t* out_stats /* [4] */) {
+  PcvSpecParams p;
+  p.cap = cap;
+  p.resolution = resolution;
+  p.edge = edge;
+  p.nlevels = nlevels;
+  p.force_mask = force_mask;
+  p.scale = (double)stride;
+  p.delta = delta;
+  std::vector<uint64_t> sample;
+  for (uint64_t i = 0; i < n; i += stride) sample.push_back(keys[i]);
+  std::sort(sample.begin(), sample.end());
+  const uint32_t thr = pcv_spec_sample_threshold(p);
+  // sample tree exactly as pcv_launch_node_split lays it out
+  std::vector<uint64_t> prefix{0};
+  std::vector<uint32_t> lo{0}, hi{(uint32_t)sample.size()}, first{0};
+  std::vector<uint8_t> level{0}, mask{0}, open{(uint8_t)(sample.empty() ? 0 : 1)};
+  bool too_deep = false;
+  for (size_t i = 0; i < prefix.size(); ++i) {
+    if (!open[i]) continue;
+    const int k = level[i] + 1;
+    first[i] = (uint32_t)prefix.size();
+    uint32_t b = lo[i];
+    for (unsigned c = 0; c < 8; ++c) {
+      const uint64_t next = c == 7 ? 0 : (prefix[i] | digit_bits(c + 1, k));
+      const uint32_t e = c == 7 ? hi[i] : (uint32_t)(std::lower_bound(sample.begin() + b, sample.begin() + hi[i], next) - sample.begin());
+      if (e > b) {
+        mask[i] |= (uint8_t)(1u << c);
+        bool op = (e - b) > thr && edge[k] > resolution;
+        if (k == 1 && ((force_mask >> c) & 1u)) op = true;
+        if (op && k >= nlevels) {
+          too_deep = true;
+          op = false;
+        }
+        prefix.push_back(prefix[i] | digit_bits(c, k));
+        lo.push_back(b);
+        hi.push_back(e);
+        first.push_back(0);
+        level.push_back((uint8_t)k);
+        mask.push_back(0);
+        open.push_back(op ? 1 : 0);
+      }
+      b = e;
+    }
+  }
+  if (too_deep) return 100;
+  PcvSampleTable st;
+  st.num_nodes = (uint32_t)prefix.size();
+  st.prefix = prefix.data();
+  st.lo = lo.data();
+  st.hi = hi.data();
+  st.first_child = first.data();
+  st.level = level.data();
+  st.child_mask = mask.data();
+  st.open = open.data();
+  PcvSpecTree tree;
+  pcv_spec_build_tree(p, st, &tree);
+  std::vector<uint32_t> counts(tree.num_leaves, 0);
+  uint64_t kept = 0;
+  for (uint64_t i = 0; i < n; ++i) {  // what the fused kernel's walk does with the digits of the chain
+    uint64_t rec = tree.walk[0];
+    int l = 0;
+    bool have = false;
+    while (!(rec & PCV_SPEC_LEAF)) {
+      if ((rec & PCV_SPEC_CANDIDATE) && !have) have = true;
+      ++l;
+      rec = tree.walk[(uint32_t)rec + (unsigned)((keys[i] >> (3 * (kKeyLevels - l))) & 7)];
+    }
+    kept += have;
+    ++counts[(uint32_t)rec];
+  }
+  PcvTrueTree tt;
+  const PcvSpecStatus status = pcv_spec_resolve(p, tree, counts.data(), &tt);
+  if (out_stats) {
+    out_stats[0] = tree.prefix.size();
+    out_stats[1] = tree.num_leaves;
+    out_stats[2] = kept;          // points that passed a candidate (they write their kept codes)
+    out_stats[3] = tt.fix_points;  // points that replay the chain in the finalize kernel
+  }
+  if (status != PCV_SPEC_OK) return (int)status;
+  *out_num_nodes = tt.prefix.size();
+  if (tt.prefix.size() > node_capacity) return 101;
+  for (size_t k = 0; k < tt.prefix.size(); ++k) {
+    out_prefix[k] = tt.prefix[k];
+    out_level[k] = tt.level[k];
+    out_count[k] = tt.hi[k] - tt.lo[k];
+    out_open[k] = tt.open[k];
+  }
+  // the map must send every predicted leaf's points into the true leaf that spans them
+  std::vector<uint64_t> per_leaf(tt.num_leaves, 0);
+  for (uint32_t r = 0; r < tree.num_leaves; ++r) per_leaf[tt.spec_map[r] & 0x7fffffffu] += counts[r];
+  uint32_t rank = 0;
+  std::vector<uint32_t> stack{0};
+  while (!stack.empty()) {
+    const uint32_t k = stack.back();
+    stack.pop_back();
+    if (tt.open[k]) {
+      const uint32_t nchild = (uint32_t)__builtin_popcount(tt.child_mask[k]);
+      for (uint32_t c = nchild; c-- > 0;) stack.push_back(tt.first_child[k] + c);
+    } else if (per_leaf[rank++] != (uint64_t)(tt.hi[k] - tt.lo[k])) {
+      return 102;
+    }
+  }
+  return 0;
+}

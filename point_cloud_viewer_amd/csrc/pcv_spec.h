@@ -10,10 +10,11 @@
 //   * a node whose sampled count is close to the capacity ("candidate") is split in T'', and every point passing
 //     through it also keeps the codes it had AT that node — so the point is ready both for "the node is a leaf" and for
 //     "the node is split";
-//   * the exact counts decide (should_split_node, reference src/octree/generation.rs:128-150); whenever the prediction
-//     does not cover the decision (a predicted leaf that must be split; a true leaf that is an inner node of T''
-//     without kept codes) the build is redone by the exact two-chain pipeline. Speculation can cost time, never
-//     correctness — the same contract as the depth speculation of the exact path.
+//   * the exact counts decide (should_split_node, reference src/octree/generation.rs:128-150). A true leaf that is an
+//     inner node of T'' WITHOUT kept codes (rare: a candidate below a candidate, a count far outside the band) has its
+//     points replay the chain to its level; a predicted leaf that must be split (the prediction is too shallow there)
+//     sends the whole build to the exact two-chain pipeline. Speculation can cost time, never correctness — the same
+//     contract as the depth speculation of the exact path.
 #pragma once
 #include <stdint.h>
 
@@ -67,8 +68,7 @@ void pcv_spec_build_tree(const PcvSpecParams& p, const PcvSampleTable& s, PcvSpe
 
 enum PcvSpecStatus {
   PCV_SPEC_OK = 0,
-  PCV_SPEC_TOO_SHALLOW = 1,  // a predicted leaf holds more than the capacity and may be split
-  PCV_SPEC_NO_CODES = 2,     // a true leaf is an inner node of T'' whose points did not keep their codes at that level
+  PCV_SPEC_TOO_SHALLOW = 1,  // a predicted leaf holds more than the capacity and may be split: redo with the exact pipeline
 };
 
 // The true tree in the layout the exact path downloads from the device after the node split (BFS order, children
@@ -80,6 +80,12 @@ struct PcvTrueTree {
   std::vector<uint32_t> lo, hi, first_child;
   std::vector<uint8_t> level, child_mask, open;
   std::vector<uint32_t> spec_map;
+  // A true leaf that is an inner node of T'' whose points did NOT keep their codes there (a candidate below another
+  // candidate, or a sampled count outside the band): level of that leaf per predicted leaf below it, 0 = none. Those
+  // points replay the chain to that level in the finalize kernel (rare; any_fix says whether the table is needed).
+  std::vector<uint8_t> fix_level;
+  bool any_fix = false;
+  uint64_t fix_points = 0, kept_points = 0;  // points that replay the chain / take their kept codes
   uint32_t num_leaves = 0;
   int deepest_level = 0;
 };

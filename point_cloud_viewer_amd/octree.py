@@ -178,11 +178,17 @@ class Context:
 
     # ---- the build -------------------------------------------------------------------------------
     def build(self, resolution, bounding_box, x, y, z, color, intensity=None, max_points_per_node=0,
-              speculate_depth=True):
+              speculate_depth=True, single_chain=None):
         """build_octree up to (not including) the file writes. bounding_box=None computes it on the
-        device (== build_octree_from_file's find_bounding_box pass)."""
+        device (== build_octree_from_file's find_bounding_box pass). single_chain: None = the library decides (from
+        2^22 points on), True = force the single-chain build, False = exact two-chain pipeline; speculate_depth=False
+        additionally computes and sorts full-depth keys. The result is identical in every mode."""
         p, keep = self._points(x, y, z, color, intensity)
         flags = 0 if speculate_depth else L.BUILD_NO_SPECULATION
+        if single_chain is True:
+            flags |= L.BUILD_FORCE_SINGLE_CHAIN
+        elif single_chain is False:
+            flags |= L.BUILD_NO_SINGLE_CHAIN
         if bounding_box is None:
             pr = self._params(resolution, None, None, max_points_per_node, flags | L.BUILD_COMPUTE_BBOX)
         else:
@@ -486,9 +492,14 @@ class OctreeResult:
         return {L.STAGE_NAMES[i]: ms[i] for i in range(n)}
 
     def build_info(self):
+        """key_levels, attempts (0 = single-chain build, 1 = exact pipeline, >= 2 something was redone) and the
+        single-chain statistics (predicted nodes / leaves, points that took kept codes, points that replayed the chain)."""
         lv, at = C.c_int(), C.c_int()
         self.lib.pcv_octree_build_info(self.handle, C.byref(lv), C.byref(at))
-        return dict(key_levels=lv.value, attempts=at.value)
+        st = (C.c_uint64 * 4)()
+        self.lib.pcv_octree_spec_stats(self.handle, st)
+        return dict(key_levels=lv.value, attempts=at.value, single_chain=at.value == 0,
+                    predicted_nodes=st[0], predicted_leaves=st[1], kept_code_points=st[2], replayed_points=st[3])
 
     def write_dir(self, directory):
         self.ctx._check(self.lib.pcv_octree_write_dir(self.handle, str(directory).encode()))

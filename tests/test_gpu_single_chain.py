@@ -1,0 +1,113 @@
+"""The single-chain build (csrc/pcv_spec.h: topology predicted from a strided sample, ONE chain pass, exact per-leaf
+counts decide the tree) against the CPU oracle: byte-exact like every other build test, whatever the prediction did —
+held, took kept codes at candidate nodes, replayed the chain for a few points, or gave up and let the exact pipeline
+redo the build. The reference has one answer per input (src/octree/generation.rs:289-403); so do all of these paths."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import point_cloud_viewer_amd as pcv
+from point_cloud_viewer_amd import synthetic
+from test_gpu_build import assert_same
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = pcv.Context(0)
+    yield c
+    c.close()
+
+
+CASES = [  # n, capacity, resolution, clusters, extent, sigma range, intensity, seed
+    (600_000, 20_000, 0.001, 6, 200.0, (0.2, 8.0), False, 1),
+    (600_000, 20_000, 0.001, 6, 200.0, (0.2, 8.0), True, 2),
+    (800_000, 5_000, 0.001, 12, 300.0, (0.05, 5.0), False, 3),
+    (300_000, 2_000, 0.01, 5, 60.0, (0.01, 2.0), True, 4),
+    (200_000, 300, 0.001, 4, 40.0, (0.005, 1.0), False, 5),
+    (1_500_000, 100_000, 0.001, 3, 150.0, (0.5, 6.0), False, 6),
+]
+
+
+@pytest.mark.parametrize("n,cap,res,clusters,extent,sigma,with_int,seed", CASES)
+def test_forced_single_chain_equals_oracle(ctx, n, cap, res, clusters, extent, sigma, with_int, seed):
+    x, y, z, rgb, bmin, bmax = synthetic.gaussian_clusters(n, seed=seed, num_clusters=clusters, extent=extent, sigma_range=sigma)
+    inten = (np.arange(n) % 509).astype(np.float32) * 0.5 if with_int else None
+    with O.max_points_per_node(cap):
+        want = O.build_closed(res, bmin, bmax, x, y, z, rgb, inten, threads=8)
+    t = ctx.build(res, pcv.Aabb(bmin, bmax), x, y, z, rgb, inten, max_points_per_node=cap, single_chain=True)
+    info = t.build_info()
+    assert_same(t.to_dict(), want, check_intensity=with_int)
+    assert info["attempts"] in (0, 2, 3), info  # held, or redone by the exact pipeline (with or without its own retry)
+    if info["single_chain"]:
+        leaves = sum(1 for k in want.nodes if not any(c.startswith(k) and len(c) == len(k) + 1 for c in want.nodes))
+        assert info["predicted_leaves"] >= leaves
+    t.free()
+    # same input through the exact pipeline: the two must agree with each other, too
+    t2 = ctx.build(res, pcv.Aabb(bmin, bmax), x, y, z, rgb, inten, max_points_per_node=cap, single_chain=False)
+    assert t2.build_info()["attempts"] >= 1
+    assert_same(t2.to_dict(), want, check_intensity=with_int)
+
+
+def test_single_chain_is_the_default_from_4M_points_and_takes_kept_codes(ctx):
+    n = 6_000_000
+    x, y, z, rgb, bmin, bmax = synthetic.gaussian_clusters(n, seed=8, num_clusters=24, extent=500.0, sigma_range=(0.3, 9.0))
+    t = ctx.build(0.001, pcv.Aabb(bmin, bmax), x, y, z, rgb)
+    info = t.build_info()
+    assert info["single_chain"] and info["attempts"] == 0, info
+    assert info["kept_code_points"] > 0, info  # some node sat in the band and turned out to be a leaf
+    assert_same(t.to_dict(), O.build_closed(0.001, bmin, bmax, x, y, z, rgb, threads=8))
+    st = t.stage_ms()
+    assert st["sort_keys"] == 0.0 and st["leaf_encode"] > 0.0  # no key sort of the full input on this path
+
+
+def test_single_chain_with_computed_bbox_device_inputs_and_rgba(ctx):
+    import torch
+    n = 5_000_000
+    x, y, z, rgb, bmin, bmax = synthetic.gaussian_clusters(n, seed=9, num_clusters=10, extent=250.0, sigma_range=(0.2, 7.0))
+    rgba = np.concatenate([rgb, np.full((n, 1), 9, np.uint8)], axis=1)
+    dev = torch.device("cuda", 0)
+    dx, dy, dz = (torch.from_numpy(a).to(dev) for a in (x, y, z))
+    dc = torch.from_numpy(rgba).to(dev)
+    torch.cuda.synchronize()
+    t = ctx.build(0.001, None, dx, dy, dz, dc)
+    assert t.build_info()["single_chain"]
+    m = t.meta()
+    assert np.array_equal(m["bbox_min"], bmin) and np.array_equal(m["bbox_max"], bmax)
+    assert_same(t.to_dict(), O.build_closed(0.001, bmin, bmax, x, y, z, rgb, threads=8))
+
+
+def test_duplicates_and_resolution_limited_nodes(ctx):
+    rng = np.random.default_rng(11)
+    n = 700_000
+    x, y, z = rng.uniform(-30, 30, n), rng.uniform(-30, 30, n), rng.uniform(-3, 3, n)
+    x[: n // 3], y[: n // 3], z[: n // 3] = 1.25, -7.5, 0.5  # a third of the cloud is ONE point
+    perm = rng.permutation(n)
+    x, y, z = x[perm], y[perm], z[perm]
+    rgb = synthetic.index_colors(n)
+    bmin, bmax = np.array([-30.0, -30, -3]), np.array([30.0, 30, 3])
+    with O.max_points_per_node(10_000):
+        want = O.build_closed(0.01, bmin, bmax, x, y, z, rgb, threads=8)
+    t = ctx.build(0.01, pcv.Aabb(bmin, bmax), x, y, z, rgb, max_points_per_node=10_000, single_chain=True)
+    assert_same(t.to_dict(), want)
+
+
+def test_two_step_build_with_forced_level1_split(ctx):
+    """pcv_build_begin / pcv_build_finish (the multi-GPU halves) through the single-chain path, incl. a forced split of
+    level-1 nodes that hold few points."""
+    import torch
+    n = 5_000_000
+    x, y, z, rgb, bmin, bmax = synthetic.gaussian_clusters(n, seed=12, num_clusters=8, extent=400.0, sigma_range=(0.3, 8.0))
+    dev = torch.device("cuda", 0)
+    dx, dy, dz = (torch.from_numpy(a).to(dev) for a in (x, y, z))
+    dc = torch.from_numpy(rgb).to(dev)
+    torch.cuda.synchronize()
+    pend = ctx.build_begin(0.001, pcv.Aabb(bmin, bmax), dx, dy, dz, dc, force_split_level1=0xff)
+    l1, l2, mask = pend.top_streams()
+    tree = pend.finish(None)
+    assert tree.build_info()["single_chain"]
+    want, streams = O.build_closed_shard(0.001, bmin, bmax, x, y, z, rgb, threads=8, force_mask=0xff)
+    assert np.array_equal(l1, streams[:8].astype(np.int64)) and np.array_equal(l2, streams[8:72].astype(np.int64))
+    assert mask == int(streams[72])
+    assert_same(tree.to_dict(), want)
