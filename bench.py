@@ -43,8 +43,11 @@ ALGO_BYTES = {
     "upsweep_kernel<u32>": 4.0,
     "promote_settle_kernel": 20.0 + 7.0 / 8.0 * 9.0,  # read record; 7 of 8 points write ~6 B xyz + 3 B rgb
     "promote_climb_kernel": 4.0 + (16.0 + 9.0) / 8.0,  # read ranks; every 8th point: payload in, xyz + rgb out
+    "spec_encode_kernel": 24.0 + 3.0 + 20.0,  # single-chain pass: read xyz + rgb, write rank + 16-byte payload (+ kept codes of ~10 %)
+    "rank_hist_kernel": 4.0,        # read ranks
+    "spec_finalize_kernel": 8.0,    # rank read + write (+ payload patch of the points that take their kept codes)
 }
-VALU_F64_BOUND = ("leaf_encode_kernel", "chain_keys_kernel")
+VALU_F64_BOUND = ("leaf_encode_kernel", "chain_keys_kernel", "spec_encode_kernel")
 
 
 def make_cloud(torch, n, seed, device, clusters=64, extent=1000.0, sigma=(1.0, 20.0), chunk=1 << 24,
@@ -312,6 +315,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-to-files end-to-end leg (N=1 only)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with HIP events")
+    ap.add_argument("--exact-pipeline", action="store_true",
+                    help="force the exact two-chain pipeline (K2 keys + key sort + node split + K5) instead of the single-chain build")
     ap.add_argument("--fixed-bbox", action="store_true",
                     help="take the bounding box as an argument (K1 outside the step), as round 1 measured")
     args = ap.parse_args()
@@ -360,7 +365,8 @@ def main():
             bbox = pcv.Aabb(bmin, bmax)
 
         def step():
-            t = ctx.build(args.resolution, bbox, x, y, z, rgb)  # bbox None: K1 runs inside the step
+            t = ctx.build(args.resolution, bbox, x, y, z, rgb,  # bbox None: K1 runs inside the step
+                          single_chain=False if args.exact_pipeline else None)
             info["nodes"], info["stages"], info["build"] = t.num_nodes, t.stage_ms(), t.build_info()
             info.setdefault("gpu_ms", []).append(round(info["stages"]["total"], 3))
             info.setdefault("all_stages", []).append({k: round(v, 2) for k, v in info["stages"].items()})
@@ -458,26 +464,39 @@ def main():
                 roofline["largest_hbm_kernel"] = dict(hbm_view(hk), bound="hbm", traffic=ht, traffic_source=hs)
         else:
             roofline = dict(view, bound="hbm", traffic=traffic, traffic_source=traffic_src)
-        # encode+sort figure the BASELINE metric names: K2 chain keys + key sort (stage events of the last step)
+        # encode+sort figure the BASELINE metric names (stage events of the last step)
         st = info.get("stages") or {}
-        es_ms = st.get("chain_keys", 0.0) + st.get("sort_keys", 0.0)
-        key32 = (info.get("build") or {}).get("key_levels", 21) <= 10
-        key_bytes = 4.0 if key32 else 8.0
-        down = "downsweep_kernel<u32>" if key32 else "downsweep_kernel<u64>"
-        passes = timed.get(down, (0, 0))[0] / args.steps
-        if not key32:
-            passes = max(0.0, passes - 5)  # the depth probe's own tiny u64 sort
-        sort_ms = sum(timed.get(k, (0, 0.0))[1] for k in (down, down.replace("down", "up"), "scan_kernel")) / args.steps
-        es_bytes_pp = 24.0 + key_bytes + passes * 3 * key_bytes
+        binfo = info.get("build") or {}
         rec = timed.get("downsweep_rec_kernel")
-        encode_sort = {"GB/s": round(n * es_bytes_pp / (es_ms * 1e-3) / 1e9, 1) if es_ms else None,
-                       "ms": round(es_ms, 3), "key_bits": int(key_bytes * 8), "sort_passes": passes,
-                       "algorithmic_bytes_per_point": es_bytes_pp,
-                       "key_sort_only": {"ms": round(sort_ms, 3),
-                                         "GB/s": round(n * passes * 3 * key_bytes / (sort_ms * 1e-3) / 1e9, 1) if sort_ms else None},
-                       "record_sort": None if not rec else {
-                           "passes": rec[0] / args.steps, "ms": round(st.get("sort_records", 0.0), 3),
-                           "GB/s": round(n * (rec[0] / args.steps) * 44.0 / (st.get("sort_records", 1e9) * 1e-3) / 1e9, 1)}}
+        rec_passes = rec[0] / args.steps if rec else 0.0
+        rec_ms = st.get("sort_records", 0.0)
+        record_sort = None if not rec else {"passes": rec_passes, "ms": round(rec_ms, 3),
+                                            "GB/s": round(n * rec_passes * 44.0 / (rec_ms * 1e-3) / 1e9, 1) if rec_ms else None,
+                                            "algorithmic_bytes_per_point": rec_passes * 44.0}
+        if binfo.get("single_chain"):
+            # single-chain build: the encode is the one chain pass (read xyz + rgb, write rank + payload), the sort is the
+            # stable record sort by leaf rank (per pass: 4 B histogram read + 20 B read + 20 B write) — no key sort exists
+            es_ms = st.get("leaf_encode", 0.0) + rec_ms
+            es_bytes_pp = 47.0 + rec_passes * 44.0
+            encode_sort = {"GB/s": round(n * es_bytes_pp / (es_ms * 1e-3) / 1e9, 1) if es_ms else None, "ms": round(es_ms, 3),
+                           "pipeline": "single-chain: spec_encode + record sort", "algorithmic_bytes_per_point": es_bytes_pp,
+                           "record_sort": record_sort}
+        else:
+            es_ms = st.get("chain_keys", 0.0) + st.get("sort_keys", 0.0)
+            key32 = binfo.get("key_levels", 21) <= 10
+            key_bytes = 4.0 if key32 else 8.0
+            down = "downsweep_kernel<u32>" if key32 else "downsweep_kernel<u64>"
+            passes = timed.get(down, (0, 0))[0] / args.steps
+            if not key32:
+                passes = max(0.0, passes - 5)  # the depth probe's own tiny u64 sort
+            sort_ms = sum(timed.get(k, (0, 0.0))[1] for k in (down, down.replace("down", "up"), "scan_kernel")) / args.steps
+            es_bytes_pp = 24.0 + key_bytes + passes * 3 * key_bytes
+            encode_sort = {"GB/s": round(n * es_bytes_pp / (es_ms * 1e-3) / 1e9, 1) if es_ms else None,
+                           "ms": round(es_ms, 3), "pipeline": "exact: chain_keys + key sort", "key_bits": int(key_bytes * 8),
+                           "sort_passes": passes, "algorithmic_bytes_per_point": es_bytes_pp,
+                           "key_sort_only": {"ms": round(sort_ms, 3),
+                                             "GB/s": round(n * passes * 3 * key_bytes / (sort_ms * 1e-3) / 1e9, 1) if sort_ms else None},
+                           "record_sort": record_sort}
 
     parity = None
     if args.verify and rank == 0 and not sharded:

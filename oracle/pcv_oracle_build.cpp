@@ -845,11 +845,20 @@ static Result* build_closed(const Aabb& bbox, double resolution, size_t n, const
     keys[i] = key;
   }
   lap("keys");
-  // Top-down stable split of index lists (generation.rs:58-193 without the files). Level-synchronous so the nodes of a
-  // level split in parallel (they are independent); a big node is split by chunks (count, offsets, scatter), which keeps
-  // the order inside every child == the order inside the parent (the stable `retain` of generation.rs:84-90).
+  // Top-down stable split (generation.rs:58-193 without the files). The index lists of all nodes of a level live in ONE
+  // array, every node a contiguous range of it; a level is split by counting the next digit per range, laying the eight
+  // children out inside the parent's range and scattering into a second array (ping-pong per level) — no per-node
+  // allocation. The order inside every child == the order inside the parent (the stable `retain` of
+  // generation.rs:84-90). A leaf copies its range once; ranges are split in parallel over nodes, big ranges by chunks.
   std::vector<CNode> nodes;
   nodes.reserve(1024);
+  std::vector<uint32_t> buf_a(n), buf_b(n);
+#pragma omp parallel for schedule(static) num_threads(num_threads)
+  for (size_t i = 0; i < n; ++i) buf_a[i] = (uint32_t)i;
+  struct Range {
+    size_t lo, hi;
+  };
+  std::vector<Range> range;  // per node: its list inside the buffer of its level
   {
     CNode root;
     root.id = NodeId::root();
@@ -857,89 +866,90 @@ static Result* build_closed(const Aabb& bbox, double resolution, size_t n, const
     root.leaf = false;  // the root is always split (generation.rs:312-323)
     root.parent = -1;
     for (int c = 0; c < 8; ++c) root.child[c] = -1;
-    root.pre.resize(n);
-#pragma omp parallel for schedule(static) num_threads(num_threads)
-    for (size_t i = 0; i < n; ++i) root.pre[i] = (uint32_t)i;
     nodes.push_back(std::move(root));
+    range.push_back(Range{0, n});
   }
-  auto split8 = [&](const std::vector<uint32_t>& pre, int lvl, std::vector<uint32_t>* lists /* [8] */, int threads) {
-    const int shift = 3 * (nlev - lvl);
-    const size_t m = pre.size();
-    if (threads <= 1 || m < (1u << 16)) {
-      for (uint32_t i : pre) lists[(unsigned)((keys[i] >> shift) & 7)].push_back(i);
-      return;
-    }
-    const size_t chunks = (size_t)threads;
-    std::vector<size_t> cnt(chunks * 8, 0);
-#pragma omp parallel for schedule(static, 1) num_threads(threads)
-    for (size_t ch = 0; ch < chunks; ++ch) {
-      const size_t b = m * ch / chunks, e = m * (ch + 1) / chunks;
-      size_t local[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (size_t j = b; j < e; ++j) ++local[(unsigned)((keys[pre[j]] >> shift) & 7)];
-      for (int c = 0; c < 8; ++c) cnt[ch * 8 + (size_t)c] = local[c];
-    }
-    std::vector<size_t> off(chunks * 8, 0);
-    for (int c = 0; c < 8; ++c) {
-      size_t acc = 0;
-      for (size_t ch = 0; ch < chunks; ++ch) {
-        off[ch * 8 + (size_t)c] = acc;
-        acc += cnt[ch * 8 + (size_t)c];
-      }
-      lists[c].resize(acc);
-    }
-#pragma omp parallel for schedule(static, 1) num_threads(threads)
-    for (size_t ch = 0; ch < chunks; ++ch) {
-      const size_t b = m * ch / chunks, e = m * (ch + 1) / chunks;
-      size_t at[8];
-      for (int c = 0; c < 8; ++c) at[c] = off[ch * 8 + (size_t)c];
-      for (size_t j = b; j < e; ++j) {
-        const unsigned c = (unsigned)((keys[pre[j]] >> shift) & 7);
-        lists[c][at[c]++] = pre[j];
-      }
-    }
-  };
+  uint32_t* src = buf_a.data();
+  uint32_t* dst = buf_b.data();
   for (size_t level_begin = 0; level_begin < nodes.size();) {
     const size_t level_end = nodes.size();
     const size_t width = level_end - level_begin;
-    std::vector<std::vector<uint32_t>> kids(width * 8);
-    // few nodes: split each with all threads; many nodes: one thread per node
-    if (width < (size_t)num_threads) {
-      for (size_t w = 0; w < width; ++w) {
-        CNode& nd = nodes[level_begin + w];
-        if (nd.leaf) continue;
-        split8(nd.pre, nd.level + 1, &kids[w * 8], num_threads);
-      }
-    } else {
+    const int lvl = nodes[level_begin].level + 1;
+    const int shift = 3 * (nlev - lvl);
+    // work items: (node, chunk) — big ranges are cut into chunks so a handful of huge nodes still uses every thread
+    struct Item {
+      size_t node, lo, hi;
+    };
+    std::vector<Item> items;
+    const size_t grain = std::max<size_t>(1u << 16, n / (size_t)(8 * num_threads) + 1);
+    std::vector<size_t> first_item(width + 1, 0);
+    for (size_t w = 0; w < width; ++w) {
+      first_item[w] = items.size();
+      if (nodes[level_begin + w].leaf) continue;
+      const Range r = range[level_begin + w];
+      for (size_t b0 = r.lo; b0 < r.hi; b0 += grain) items.push_back(Item{w, b0, std::min(r.hi, b0 + grain)});
+    }
+    first_item[width] = items.size();
+    std::vector<size_t> cnt(items.size() * 8, 0);
 #pragma omp parallel for schedule(dynamic, 1) num_threads(num_threads)
-      for (size_t w = 0; w < width; ++w) {
-        CNode& nd = nodes[level_begin + w];
-        if (nd.leaf) continue;
-        split8(nd.pre, nd.level + 1, &kids[w * 8], 1);
+    for (size_t it = 0; it < items.size(); ++it) {
+      size_t local[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (size_t j = items[it].lo; j < items[it].hi; ++j) ++local[(unsigned)((keys[src[j]] >> shift) & 7)];
+      for (int c = 0; c < 8; ++c) cnt[it * 8 + (size_t)c] = local[c];
+    }
+    // child c of a node starts at range.lo + (points of children < c); inside it the chunks follow each other
+    std::vector<size_t> off(items.size() * 8, 0);
+    std::vector<size_t> child_size(width * 8, 0);
+    for (size_t w = 0; w < width; ++w) {
+      if (nodes[level_begin + w].leaf) continue;
+      size_t at = range[level_begin + w].lo;
+      for (int c = 0; c < 8; ++c) {
+        const size_t start = at;
+        for (size_t it = first_item[w]; it < first_item[w + 1]; ++it) {
+          off[it * 8 + (size_t)c] = at;
+          at += cnt[it * 8 + (size_t)c];
+        }
+        child_size[w * 8 + (size_t)c] = at - start;
+      }
+    }
+#pragma omp parallel for schedule(dynamic, 1) num_threads(num_threads)
+    for (size_t it = 0; it < items.size(); ++it) {
+      size_t at[8];
+      for (int c = 0; c < 8; ++c) at[c] = off[it * 8 + (size_t)c];
+      for (size_t j = items[it].lo; j < items[it].hi; ++j) {
+        const uint32_t i = src[j];
+        dst[at[(unsigned)((keys[i] >> shift) & 7)]++] = i;
       }
     }
     for (size_t w = 0; w < width; ++w) {
       const size_t qi = level_begin + w;
       if (nodes[qi].leaf) continue;
-      const int lvl = nodes[qi].level + 1;
-      nodes[qi].pre.clear();
-      nodes[qi].pre.shrink_to_fit();
+      size_t at = range[qi].lo;
       for (int c = 0; c < 8; ++c) {
-        std::vector<uint32_t>& list = kids[w * 8 + (size_t)c];
-        if (list.empty()) continue;
+        const size_t m = child_size[w * 8 + (size_t)c];
+        if (m == 0) continue;
         CNode ch;
         ch.id = nodes[qi].id.get_child_id((uint8_t)c);
         ch.level = lvl;
         ch.parent = (int)qi;
         for (int k = 0; k < 8; ++k) ch.child[k] = -1;
-        ch.leaf = !((int64_t)list.size() > MAX_POINTS_PER_NODE && t.edge[lvl] > resolution);
+        ch.leaf = !((int64_t)m > MAX_POINTS_PER_NODE && t.edge[lvl] > resolution);
         if (lvl == 1 && ((force_mask >> c) & 1u)) ch.leaf = false;
-        ch.pre = std::move(list);
         nodes[qi].child[c] = (int)nodes.size();
         nodes.push_back(std::move(ch));
+        range.push_back(Range{at, at + m});
+        at += m;
       }
     }
+    // the children that are leaves keep their list (it lives in `dst`, which the next level overwrites elsewhere only)
+#pragma omp parallel for schedule(dynamic, 8) num_threads(num_threads)
+    for (size_t qi = level_end; qi < nodes.size(); ++qi)
+      if (nodes[qi].leaf) nodes[qi].pre.assign(dst + range[qi].lo, dst + range[qi].hi);
+    std::swap(src, dst);
     level_begin = level_end;
   }
+  buf_a = std::vector<uint32_t>();
+  buf_b = std::vector<uint32_t>();
   lap("split");
   // Bottom-up promotion (generation.rs:195-253, 335-387): nodes[] is in BFS order, so reverse order
   // visits children before parents.
