@@ -99,6 +99,18 @@ int pcv_ctx::pinned_reserve(size_t bytes) {
   return PCV_OK;
 }
 
+int pcv_ctx::pinned_spec_reserve(size_t bytes) {
+  if (bytes <= pinned_spec_bytes) return PCV_OK;
+  bytes += bytes / 2;  // the size follows the node count of the input: leave room so that similar builds do not regrow it
+  if (pinned_spec) (void)hipHostFree(pinned_spec);  // waits for copies in flight
+  pinned_spec = nullptr;
+  pinned_spec_bytes = 0;
+  hipError_t e = hipHostMalloc(&pinned_spec, bytes, hipHostMallocDefault);
+  if (e != hipSuccess) return fail(PCV_E_OOM, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+  pinned_spec_bytes = bytes;
+  return PCV_OK;
+}
+
 hipEvent_t pcv_ctx::prof_event() {
   if (!prof_free.empty()) {
     hipEvent_t e = prof_free.back();
@@ -129,7 +141,7 @@ static const char* kKernelNames[PCV_K_COUNT] = {
     "upsweep_kernel<u32>", "downsweep_kernel<u32>", "promote_settle_kernel", "downsweep_rec_kernel", "cull_nodes_kernel",
     "visible_nodes_kernel", "nodes_in_location_kernel", "cull_points_kernel", "transform_points_kernel",
     "query_compact_kernel", "route_bucket_kernel", "partition_count_kernel", "partition_scatter_kernel",
-    "promote_climb_kernel", "spec_encode_kernel", "rank_hist_kernel", "spec_finalize_kernel"};
+    "promote_climb_kernel", "spec_encode_kernel", "rank_hist_kernel", "spec_finalize_kernel", "spec_replay_kernel"};
 static_assert(sizeof(kKernelNames) / sizeof(kKernelNames[0]) == PCV_K_COUNT, "kernel name table out of sync");
 
 extern "C" int pcv_ctx_set_profiling(pcv_ctx* ctx, int enabled) {
@@ -208,6 +220,7 @@ extern "C" void pcv_ctx_destroy(pcv_ctx* ctx) {
   ctx->pool.trim();
   for (auto& kv : ctx->pool.live) (void)hipFree(kv.first);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  if (ctx->pinned_spec) (void)hipHostFree(ctx->pinned_spec);
   if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
   for (auto& kv : ctx->host_free) (void)hipHostFree(kv.second);
   for (auto& kv : ctx->host_live) (void)hipHostFree(kv.first);
@@ -633,37 +646,72 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
   sp.delta = stride == 1 ? 0.0 : std::fmin(0.9, std::fmax(0.02, 5.0 * std::sqrt((double)stride / (double)max_points)));
 
   ctx->stage_begin(PCV_STAGE_CHAIN_KEYS);
+  // The sample keys cover 14 levels first (two radix passes and a third of the chain less than full depth); a sample
+  // tree that wants to go deeper is keyed again at full depth.
+  constexpr uint32_t kPackFirst = 8192;  // nodes fetched together with the counters in one copy
+  uint8_t* d_pack;
+  if ((rc = sc.get(&d_pack, kPcvPackHeader + ((size_t)nt.capacity + 8) * sizeof(PcvPackedNode)))) return rc;
+  if ((rc = ctx->pinned_spec_reserve(kPcvPackHeader + (size_t)nt.capacity * sizeof(PcvPackedNode)))) return rc;
+  uint32_t ms = 0;
+  const uint8_t* packed_host = nullptr;
+  int sample_levels = full_levels < 14 ? full_levels : 14;
+  for (;;) {
+    lv.nlevels = sample_levels;
+    pcv_launch_chain_keys(ctx, lv, ns, stride, d.x, d.y, d.z, bs->keys_a, false, d.routed);
+    bool in_a = true;
+    if ((rc = pcv_radix_sort_u64(ctx, bs->keys_a, bs->keys_b, ns, 3 * (PCV_MAX_KEY_LEVELS - sample_levels), 3 * PCV_MAX_KEY_LEVELS,
+                                 nullptr, bs->sort_scratch, &in_a)))
+      return rc;
+    pcv_launch_node_split(ctx, nt, in_a ? bs->keys_a : bs->keys_b, false, (uint32_t)ns, lv, params->resolution,
+                          pcv_spec_sample_threshold(sp), sp.force_mask);
+    pcv_launch_pack_node_table(ctx, nt, d_pack);
+    // counters + the first kPackFirst nodes in ONE copy and ONE synchronisation; the rest (big trees) in a second one
+    uint8_t* hs = (uint8_t*)ctx->pinned_spec;
+    const uint32_t first_nodes = nt.capacity < kPackFirst ? nt.capacity : kPackFirst;
+    PCV_HIP_CHECK(ctx, hipMemcpyAsync(hs, d_pack, kPcvPackHeader + (size_t)first_nodes * sizeof(PcvPackedNode),
+                                      hipMemcpyDeviceToHost, st));
+    PCV_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    uint32_t counters[64];
+    std::memcpy(counters, hs, sizeof(counters));
+    if (counters[1] & 2u) return PCV_OK;  // table capacity: let the exact pipeline report it
+    if (counters[1] & 1u) {               // deeper than the sample keys
+      if (sample_levels < full_levels) {
+        sample_levels = full_levels;
+        continue;
+      }
+      return PCV_OK;  // deeper than one key word: the exact pipeline (deep path) takes it
+    }
+    ms = counters[0];
+    if (ms > first_nodes) {
+      const size_t done = kPcvPackHeader + (size_t)first_nodes * sizeof(PcvPackedNode);
+      PCV_HIP_CHECK(ctx, hipMemcpyAsync(hs + done, d_pack + done, (size_t)(ms - first_nodes) * sizeof(PcvPackedNode),
+                                        hipMemcpyDeviceToHost, st));
+      PCV_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    }
+    packed_host = hs + kPcvPackHeader;
+    break;
+  }
+  sp.nlevels = sample_levels;
   lv.nlevels = full_levels;
-  pcv_launch_chain_keys(ctx, lv, ns, stride, d.x, d.y, d.z, bs->keys_a, false, d.routed);
-  bool in_a = true;
-  if ((rc = pcv_radix_sort_u64(ctx, bs->keys_a, bs->keys_b, ns, 3 * (PCV_MAX_KEY_LEVELS - full_levels), 3 * PCV_MAX_KEY_LEVELS,
-                               nullptr, bs->sort_scratch, &in_a)))
-    return rc;
-  pcv_launch_node_split(ctx, nt, in_a ? bs->keys_a : bs->keys_b, false, (uint32_t)ns, lv, params->resolution,
-                        pcv_spec_sample_threshold(sp), sp.force_mask);
-  uint32_t counters[64];
-  PCV_HIP_CHECK(ctx, hipMemcpyAsync(ctx->mailbox, nt.counters, sizeof(counters), hipMemcpyDeviceToHost, st));
-  PCV_HIP_CHECK(ctx, hipStreamSynchronize(st));
-  std::memcpy(counters, ctx->mailbox, sizeof(counters));
-  if (counters[1]) return PCV_OK;  // sample tree deeper than the key word, or table capacity: not this path's case
-  const uint32_t ms = counters[0];
-  if ((rc = ctx->pinned_reserve((size_t)ms * 32 + 512))) return rc;
-  uint8_t* hp = (uint8_t*)ctx->pinned;
-  uint64_t* s_prefix = (uint64_t*)hp;
-  uint32_t* s_lo = (uint32_t*)(s_prefix + ms);
-  uint32_t* s_hi = s_lo + ms;
-  uint32_t* s_first = s_hi + ms;
-  uint8_t* s_level = (uint8_t*)(s_first + ms);
-  uint8_t* s_mask = s_level + ms;
-  uint8_t* s_open = s_mask + ms;
-  PCV_HIP_CHECK(ctx, hipMemcpyAsync(s_prefix, nt.prefix, (size_t)ms * 8, hipMemcpyDeviceToHost, st));
-  PCV_HIP_CHECK(ctx, hipMemcpyAsync(s_lo, nt.lo, (size_t)ms * 4, hipMemcpyDeviceToHost, st));
-  PCV_HIP_CHECK(ctx, hipMemcpyAsync(s_hi, nt.hi, (size_t)ms * 4, hipMemcpyDeviceToHost, st));
-  PCV_HIP_CHECK(ctx, hipMemcpyAsync(s_first, nt.first_child, (size_t)ms * 4, hipMemcpyDeviceToHost, st));
-  PCV_HIP_CHECK(ctx, hipMemcpyAsync(s_level, nt.level, (size_t)ms, hipMemcpyDeviceToHost, st));
-  PCV_HIP_CHECK(ctx, hipMemcpyAsync(s_mask, nt.child_mask, (size_t)ms, hipMemcpyDeviceToHost, st));
-  PCV_HIP_CHECK(ctx, hipMemcpyAsync(s_open, nt.open, (size_t)ms, hipMemcpyDeviceToHost, st));
-  PCV_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  // unpack into the structure-of-arrays view pcv_spec_build_tree reads
+  std::vector<uint64_t> v_prefix(ms);
+  std::vector<uint32_t> v_lo(ms), v_hi(ms), v_first(ms);
+  std::vector<uint8_t> v_level(ms), v_mask(ms), v_open(ms);
+  {
+    const PcvPackedNode* pn = (const PcvPackedNode*)packed_host;
+    for (uint32_t k = 0; k < ms; ++k) {
+      v_prefix[k] = pn[k].prefix;
+      v_lo[k] = pn[k].lo;
+      v_hi[k] = pn[k].hi;
+      v_first[k] = pn[k].first_child;
+      v_level[k] = pn[k].level;
+      v_mask[k] = pn[k].child_mask;
+      v_open[k] = pn[k].open;
+    }
+  }
+  const uint64_t* s_prefix = v_prefix.data();
+  const uint32_t *s_lo = v_lo.data(), *s_hi = v_hi.data(), *s_first = v_first.data();
+  const uint8_t *s_level = v_level.data(), *s_mask = v_mask.data(), *s_open = v_open.data();
   PcvSampleTable stab;
   stab.num_nodes = ms;
   stab.prefix = s_prefix;
@@ -682,8 +730,8 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
   const size_t cnt_off = fix_off + (((size_t)tree.num_leaves + 255) & ~(size_t)255);
   uint8_t* d_area;
   if ((rc = sc.get(&d_area, cnt_off + (size_t)tree.num_leaves * 4 + 256))) return rc;
-  if ((rc = ctx->pinned_reserve(cnt_off + (size_t)tree.num_leaves * 4 + 512))) return rc;
-  hp = (uint8_t*)ctx->pinned;
+  if ((rc = ctx->pinned_spec_reserve(cnt_off + (size_t)tree.num_leaves * 4 + 512))) return rc;
+  uint8_t* hp = (uint8_t*)ctx->pinned_spec;  // the sample table has been unpacked: the block is free again
   std::memcpy(hp, tree.walk.data(), walk_bytes);
   PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_area, hp, walk_bytes, hipMemcpyHostToDevice, st));
   uint32_t* d_counts = (uint32_t*)(d_area + cnt_off);
@@ -725,13 +773,19 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
     std::memcpy(hp + fix_off, tt->fix_level.data(), (size_t)tree.num_leaves);
     PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_area + fix_off, hp + fix_off, (size_t)tree.num_leaves, hipMemcpyHostToDevice, st));
   }
+  uint32_t* replay_count = nullptr;
+  uint2* replay_list = nullptr;
+  if (tt->any_fix) {  // the points that replay the chain are known exactly: the list cannot overflow
+    if ((rc = sc.get(&replay_count, 64)) || (rc = sc.get(&replay_list, (size_t)tt->fix_points + 64))) return rc;
+    PCV_HIP_CHECK(ctx, hipMemsetAsync(replay_count, 0, 4, st));
+  }
   pcv_launch_spec_finalize(ctx, lv, n, (const uint32_t*)(d_area + map_off), tt->any_fix ? d_area + fix_off : nullptr, d.x, d.y, d.z,
-                           d.routed, rank, payload, kept);
-  // the uploads above read the pinned block, which the caller is about to reuse for the node table: wait for them
-  PCV_HIP_CHECK(ctx, hipStreamSynchronize(st));
+                           d.routed, rank, payload, kept, replay_count, replay_list, (uint32_t)tt->fix_points);
+  // no synchronisation here: the uploads read ctx->pinned_spec, the caller stages the node table in ctx->pinned, and
+  // the pool hands `kept` out again only to work queued on this same stream
   ctx->stage_end(PCV_STAGE_NODE_SPLIT);
   ctx->stage_begin(PCV_STAGE_TABLE);
-  if (kept) {  // consumed by the finalize kernel (the sync above)
+  if (kept) {
     sc.detach(kept);
     ctx->dev_free(kept);
   }
@@ -989,7 +1043,7 @@ static int build_begin_impl(pcv_ctx* ctx, const pcv_build_params* params, const 
   const size_t lo_off = (((size_t)M * (8 + 4 * 4 + 3) + 64) + 7) & ~(size_t)7;  // deep trees: second prefix word
   const size_t host_bytes = lo_off + (bs->deep ? (size_t)M * 8 : 0);
   bs->host_bytes = host_bytes;
-  if ((rc = ctx->pinned_reserve(host_bytes * 4 + (size_t)M * 64 + (size_t)M * 2 * sizeof(PcvNodeRec) + 512))) return rc;
+  if ((rc = ctx->pinned_reserve(host_bytes * 4 + (size_t)M * 72 + (size_t)M * 2 * sizeof(PcvNodeRec) + 1024))) return rc;
   uint8_t* hp = (uint8_t*)ctx->pinned;
   uint64_t* h_prefix = (uint64_t*)hp;
   uint32_t* h_lo = (uint32_t*)(h_prefix + M);
@@ -1242,12 +1296,20 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
     for (int a = 0; a < 3; ++a) nr.mn[a] = u_node_min[3 * (size_t)i + a];
   }
   for (uint32_t r = 0; r < num_leaves; ++r) u_leaf_rec[r] = u_node_rec[leaves[r]];
+  // climbers of K6 (every 8th point of every leaf; the root is never a leaf): dense index = climb_base[leaf] + j / 8
+  uint32_t* u_climb_base = (uint32_t*)(u_leaf_rec + num_leaves);
+  uint64_t num_climbers = 0;
+  for (uint32_t r = 0; r < num_leaves; ++r) {
+    u_climb_base[r] = (uint32_t)num_climbers;
+    if (u_leaf_rec[r].parent != 0xffffffffu) num_climbers += ceil8((uint64_t)h_hi[leaves[r]] - h_lo[leaves[r]]);
+  }
   const size_t walk_bytes = ((size_t)M * 8 + 255) & ~(size_t)255;
-  const size_t rec_bytes = (size_t)(M + num_leaves) * sizeof(PcvNodeRec);
+  const size_t rec_bytes = (size_t)(M + num_leaves) * sizeof(PcvNodeRec) + (size_t)num_leaves * 4;
   uint8_t* d_up;
   if ((rc = sc.get(&d_up, walk_bytes + rec_bytes + 256))) return rc;
-  PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_up, u_walk, (size_t)M * 8, hipMemcpyHostToDevice, st));
+  if (!bs->spec) PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_up, u_walk, (size_t)M * 8, hipMemcpyHostToDevice, st));  // K5 only
   PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_up + walk_bytes, u_node_rec, rec_bytes, hipMemcpyHostToDevice, st));
+  const uint32_t* d_climb_base = (const uint32_t*)(d_up + walk_bytes + (size_t)(M + num_leaves) * sizeof(PcvNodeRec));
   PcvWalkTables wt;
   wt.walk = (const uint64_t*)d_up;
   wt.num_nodes = M;
@@ -1315,9 +1377,16 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
     if (tp) PCV_HIP_CHECK(ctx, hipMemsetAsync(t->d_rgb, 0, tp * 3, st));
     if (tp && t->d_int) PCV_HIP_CHECK(ctx, hipMemsetAsync(t->d_int, 0, tp * 4, st));
   }
+  // the compact climber records live in the payload buffer the sort left unused (32 B x n / 8 < 16 B x n)
+  void* climbers = rec_in_a ? (void*)pay_b : (void*)pay_a;
+  if (pcv_climber_bytes(num_climbers) > (size_t)n * 16) {
+    if ((rc = ctx->dev_alloc(&climbers, pcv_climber_bytes(num_climbers)))) return rc;
+    sc.ptrs.push_back(climbers);
+  }
   pcv_launch_promote_encode(ctx, lv, pt, n, s_rank, s_pay, wide ? s_plane[w_hi] : nullptr,
                             wide ? s_plane[w_hi + 1] : nullptr, wide ? s_plane[w_hi + 2] : nullptr,
-                            w_int >= 0 ? s_plane[w_int] : nullptr, t->d_xyz, t->d_rgb, t->d_int);
+                            w_int >= 0 ? s_plane[w_int] : nullptr, d_climb_base, (uint32_t)num_climbers, climbers, t->d_xyz,
+                            t->d_rgb, t->d_int);
   ctx->stage_end(PCV_STAGE_PROMOTE_ENCODE);
   PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[8], st));
   PCV_HIP_CHECK(ctx, hipGetLastError());

@@ -9,6 +9,8 @@
 //     (generation.rs:222-238); a point that stays in a non-root node is rewritten once
 //     (encode_k(decode_k(b))) at slot j - j/8 - 1; the root keeps everything it receives.
 //     Output is written node-contiguous: exactly the bytes of <node>.xyz/.rgb/.intensity.
+#include <algorithm>
+
 #include "pcv_chain_dev.h"
 #include "pcv_spec.h"
 
@@ -160,43 +162,70 @@ __global__ __launch_bounds__(1024) void rank_hist_kernel(const uint32_t* __restr
 // After the exact counts fixed the true tree: predicted-leaf rank -> true-leaf rank, and the payload takes the kept
 // codes where the true leaf is the candidate node (bit 31 of the map). FIX: predicted leaves whose true leaf is an
 // inner node of T'' WITHOUT kept codes (a candidate below a candidate, or a count far outside the band) carry the
-// level of that leaf in `fix_level`; their points replay the chain to that level — rare, and only the waves that
-// contain such a point pay for it.
+// level of that leaf in `fix_level`; their points are appended to a replay list (one atomic per wave that holds any),
+// so that the chain replay runs over a dense list instead of dragging whole waves of the input through it.
 template <bool FIX>
-__global__ __launch_bounds__(256) void spec_finalize_kernel(
-    PcvLevels lv, uint64_t n, const uint32_t* __restrict__ spec_map, const uint8_t* __restrict__ fix_level,
-    const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ z, PcvRouted routed,
-    uint32_t* __restrict__ rank, uint4* __restrict__ payload, const uint4* __restrict__ kept) {
+__global__ __launch_bounds__(256) void spec_finalize_kernel(uint64_t n, const uint32_t* __restrict__ spec_map,
+                                                             const uint8_t* __restrict__ fix_level, uint32_t* __restrict__ rank,
+                                                             uint4* __restrict__ payload, const uint4* __restrict__ kept,
+                                                             uint32_t* __restrict__ replay_count, uint2* __restrict__ replay_list,
+                                                             uint32_t replay_capacity) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t r = rank[i];
-  const uint32_t m = spec_map[r];
-  rank[i] = m & 0x7fffffffu;
+  const bool in = i < n;
+  uint32_t r = 0, m = 0;
+  if (in) {
+    r = rank[i];
+    m = spec_map[r];
+    rank[i] = m & 0x7fffffffu;
+  }
   if (FIX) {
-    const int target = fix_level[r];
-    if (target) {
-      double px, py, pz, mx, my, mz;
-      double vx = 0, vy = 0, vz = 0;
-      uint32_t d1;
-      int L = pcv_chain_start(lv, routed, x, y, z, i, px, py, pz, mx, my, mz, vx, vy, vz, d1) - 1;
-      while (L < target) {
-        ++L;
-        (void)pcv_chain_level<true>(lv.enc[L], lv.edge[L - 1], lv.edge[L], PcvRecip{lv.inv_edge[L], lv.inv_edge_lo[L]}, px, py, pz,
-                                    mx, my, mz, vx, vy, vz);
+    const uint32_t target = in ? fix_level[r] : 0u;
+    const uint64_t who = __ballot(target != 0);
+    if (who) {  // wave-uniform
+      const int lane = threadIdx.x & 63;
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(replay_count, (uint32_t)__popcll(who));
+      base = __shfl(base, 0, 64);
+      if (target) {
+        const uint32_t slot = base + (uint32_t)__popcll(who & ((1ull << lane) - 1ull));
+        if (slot < replay_capacity) replay_list[slot] = make_uint2((uint32_t)i, target);
       }
-      const uint32_t e = lv.enc[target];
-      uint4 p = payload[i];
-      p.x = (uint32_t)pcv_val_to_code(e, vx);
-      p.y = (uint32_t)pcv_val_to_code(e, vy);
-      p.z = (uint32_t)pcv_val_to_code(e, vz);
-      payload[i] = p;
-      return;
     }
   }
-  if (m >> 31) {
+  if (in && (m >> 31)) {
     const uint4 k = kept[i];
     uint4 p = payload[i];
     p.x = k.x, p.y = k.y, p.z = k.z;
+    payload[i] = p;
+  }
+}
+
+// Chain replay of the listed points to the listed level (dense: every lane has work).
+__global__ __launch_bounds__(256) void spec_replay_kernel(PcvLevels lv, const uint32_t* __restrict__ replay_count,
+                                                           const uint2* __restrict__ replay_list, uint32_t replay_capacity,
+                                                           const double* __restrict__ x, const double* __restrict__ y,
+                                                           const double* __restrict__ z, PcvRouted routed,
+                                                           uint4* __restrict__ payload) {
+  uint32_t count = *replay_count;
+  if (count > replay_capacity) count = replay_capacity;
+  for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < count; j += gridDim.x * 256) {
+    const uint2 e = replay_list[j];
+    const uint64_t i = e.x;
+    const int target = (int)e.y;
+    double px, py, pz, mx, my, mz;
+    double vx = 0, vy = 0, vz = 0;
+    uint32_t d1;
+    int L = pcv_chain_start(lv, routed, x, y, z, i, px, py, pz, mx, my, mz, vx, vy, vz, d1) - 1;
+    while (L < target) {
+      ++L;
+      (void)pcv_chain_level<true>(lv.enc[L], lv.edge[L - 1], lv.edge[L], PcvRecip{lv.inv_edge[L], lv.inv_edge_lo[L]}, px, py, pz, mx,
+                                  my, mz, vx, vy, vz);
+    }
+    const uint32_t en = lv.enc[target];
+    uint4 p = payload[i];
+    p.x = (uint32_t)pcv_val_to_code(en, vx);
+    p.y = (uint32_t)pcv_val_to_code(en, vy);
+    p.z = (uint32_t)pcv_val_to_code(en, vz);
     payload[i] = p;
   }
 }
@@ -274,12 +303,20 @@ __device__ __forceinline__ void promote_one(const PcvPromoteTables& pt, uint64_t
 
 // K6 runs as two kernels over the sorted records. Seven of eight points stay in their leaf: `settle` streams over all
 // slots (two per lane, both record chains started before either is consumed) and finishes those with straight-line
-// code. The every-8th points climb a data-dependent number of levels (decode + encode per level): `climb` visits one
-// octet of slots per lane, so its waves are full of climbers instead of carrying seven idle lanes through the loop.
+// code. The every-8th points climb a data-dependent number of levels (decode + encode per level): `settle` copies
+// their records into a COMPACT array (climber k of leaf r sits at climb_base[r] + k, so the array is dense and in slot
+// order) and `climb` runs one lane per entry — its waves are full of climbers and it reads 32 bytes per climber instead
+// of touching every sector of the 16-byte payload array to use an eighth of it.
+struct alignas(16) PcvClimber {
+  uint4 pay;
+  uint32_t rank, slot, inten, pad;
+};
+
 __global__ __launch_bounds__(256) void promote_settle_kernel(
     PcvPromoteTables pt, uint64_t n, const uint32_t* __restrict__ rank, const uint4* __restrict__ payload,
     const uint32_t* __restrict__ cx_hi, const uint32_t* __restrict__ cy_hi, const uint32_t* __restrict__ cz_hi,
-    const uint32_t* __restrict__ inten_bits, PromoteOut o) {
+    const uint32_t* __restrict__ inten_bits, const uint32_t* __restrict__ climb_base, PcvClimber* __restrict__ climbers,
+    PromoteOut o) {
   const uint64_t s0 = (uint64_t)blockIdx.x * 512 + threadIdx.x;
   const uint64_t s1 = s0 + 256;
   if (s0 >= n) return;
@@ -305,57 +342,31 @@ __global__ __launch_bounds__(256) void promote_settle_kernel(
   }
   const PcvNodeRec c0 = pt.leaf_rec[r0];
   const PcvNodeRec c1 = pt.leaf_rec[r1];
-  const bool stay0 = c0.parent == 0xffffffffu || (((uint32_t)s0 - c0.lo) & 7u) != 0;
-  const bool stay1 = two && (c1.parent == 0xffffffffu || (((uint32_t)s1 - c1.lo) & 7u) != 0);
+  const uint32_t j0 = (uint32_t)s0 - c0.lo, j1 = (uint32_t)s1 - c1.lo;
+  const bool stay0 = c0.parent == 0xffffffffu || (j0 & 7u) != 0;
+  const bool stay1 = c1.parent == 0xffffffffu || (j1 & 7u) != 0;
   if (stay0) promote_one<false>(pt, s0, c0, p0, h0[0], h0[1], h0[2], i0, o);
-  if (stay1) promote_one<false>(pt, s1, c1, p1, h1[0], h1[1], h1[2], i1, o);
-}
-
-__device__ __forceinline__ void climb_slot(const PcvPromoteTables& pt, uint64_t s, const PcvNodeRec& rec,
-                                           const uint4* __restrict__ payload, const uint32_t* __restrict__ cx_hi,
-                                           const uint32_t* __restrict__ cy_hi, const uint32_t* __restrict__ cz_hi,
-                                           const uint32_t* __restrict__ inten_bits, const PromoteOut& o) {
-  const uint4 p = payload[s];
-  uint32_t h[3] = {0, 0, 0}, in = 0;
-  if (cx_hi) {
-    h[0] = cx_hi[s];
-    h[1] = cy_hi[s];
-    h[2] = cz_hi[s];
+  else climbers[climb_base[r0] + (j0 >> 3)] = PcvClimber{p0, r0, (uint32_t)s0, i0, 0u};
+  if (two) {
+    if (stay1) promote_one<false>(pt, s1, c1, p1, h1[0], h1[1], h1[2], i1, o);
+    else climbers[climb_base[r1] + (j1 >> 3)] = PcvClimber{p1, r1, (uint32_t)s1, i1, 0u};
   }
-  if (inten_bits) in = inten_bits[s];
-  promote_one<true>(pt, s, rec, p, h[0], h[1], h[2], in, o);
 }
 
 __global__ __launch_bounds__(256) void promote_climb_kernel(
-    PcvPromoteTables pt, uint64_t n, const uint32_t* __restrict__ rank, const uint4* __restrict__ payload,
-    const uint32_t* __restrict__ cx_hi, const uint32_t* __restrict__ cy_hi, const uint32_t* __restrict__ cz_hi,
-    const uint32_t* __restrict__ inten_bits, PromoteOut o) {
-  const uint64_t s0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 8;  // this lane's octet of sorted slots
-  if (s0 >= n) return;
-  uint32_t r[8];
-  if (s0 + 8 <= n) {  // rank comes from the pool (256-byte aligned) and s0 is a multiple of 8: two 16-byte loads
-    const uint4 a = *reinterpret_cast<const uint4*>(rank + s0);
-    const uint4 b = *reinterpret_cast<const uint4*>(rank + s0 + 4);
-    r[0] = a.x, r[1] = a.y, r[2] = a.z, r[3] = a.w, r[4] = b.x, r[5] = b.y, r[6] = b.z, r[7] = b.w;
-  } else {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) r[k] = s0 + k < n ? rank[s0 + k] : 0xffffffffu;
+    PcvPromoteTables pt, uint32_t num_climbers, const PcvClimber* __restrict__ climbers, const uint32_t* __restrict__ cx_hi,
+    const uint32_t* __restrict__ cy_hi, const uint32_t* __restrict__ cz_hi, PromoteOut o) {
+  const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= num_climbers) return;
+  const PcvClimber c = climbers[k];
+  const PcvNodeRec rec = pt.leaf_rec[c.rank];
+  uint32_t h[3] = {0, 0, 0};
+  if (cx_hi) {
+    h[0] = cx_hi[c.slot];
+    h[1] = cy_hi[c.slot];
+    h[2] = cz_hi[c.slot];
   }
-  const PcvNodeRec first = pt.leaf_rec[r[0]];
-  if (r[7] == r[0]) {  // ranks are sorted: the whole octet lies in one leaf, which holds exactly one climber of it
-    if (first.parent != 0xffffffffu)
-      climb_slot(pt, s0 + ((first.lo - (uint32_t)s0) & 7u), first, payload, cx_hi, cy_hi, cz_hi, inten_bits, o);
-    return;
-  }
-  // a leaf ends inside the octet (or the input ends): look at every slot
-#pragma unroll 1
-  for (int k = 0; k < 8; ++k) {
-    if (r[k] == 0xffffffffu) break;
-    const PcvNodeRec rec = r[k] == r[0] ? first : pt.leaf_rec[r[k]];
-    const uint64_t s = s0 + k;
-    if (rec.parent != 0xffffffffu && (((uint32_t)s - rec.lo) & 7u) == 0)
-      climb_slot(pt, s, rec, payload, cx_hi, cy_hi, cz_hi, inten_bits, o);
-  }
+  promote_one<true>(pt, c.slot, rec, c.pay, h[0], h[1], h[2], c.inten, o);
 }
 
 }  // namespace
@@ -400,32 +411,44 @@ void pcv_launch_rank_hist(pcv_ctx* ctx, const uint32_t* rank, uint64_t n, uint32
 
 void pcv_launch_spec_finalize(pcv_ctx* ctx, const PcvLevels& lv, uint64_t n, const uint32_t* spec_map, const uint8_t* fix_level,
                               const double* x, const double* y, const double* z, const PcvRouted& routed, uint32_t* rank,
-                              void* payload, const void* kept) {
+                              void* payload, const void* kept, uint32_t* replay_count, void* replay_list,
+                              uint32_t replay_capacity) {
   if (n == 0) return;
-  PcvProf prof(ctx, PCV_K_SPEC_FINALIZE);
   const dim3 grid((unsigned)((n + 255) / 256));
-  if (fix_level)
-    hipLaunchKernelGGL(spec_finalize_kernel<true>, grid, dim3(256), 0, ctx->stream, lv, n, spec_map, fix_level, x, y, z, routed,
-                       rank, (uint4*)payload, (const uint4*)kept);
-  else
-    hipLaunchKernelGGL(spec_finalize_kernel<false>, grid, dim3(256), 0, ctx->stream, lv, n, spec_map, fix_level, x, y, z, routed,
-                       rank, (uint4*)payload, (const uint4*)kept);
+  {
+    PcvProf prof(ctx, PCV_K_SPEC_FINALIZE);
+    if (fix_level)
+      hipLaunchKernelGGL(spec_finalize_kernel<true>, grid, dim3(256), 0, ctx->stream, n, spec_map, fix_level, rank, (uint4*)payload,
+                         (const uint4*)kept, replay_count, (uint2*)replay_list, replay_capacity);
+    else
+      hipLaunchKernelGGL(spec_finalize_kernel<false>, grid, dim3(256), 0, ctx->stream, n, spec_map, fix_level, rank, (uint4*)payload,
+                         (const uint4*)kept, replay_count, (uint2*)replay_list, replay_capacity);
+  }
+  if (fix_level) {
+    PcvProf prof(ctx, PCV_K_SPEC_REPLAY);
+    const unsigned blocks = (unsigned)std::min<uint64_t>(((uint64_t)replay_capacity + 255) / 256, 4096);
+    hipLaunchKernelGGL(spec_replay_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, ctx->stream, lv, replay_count,
+                       (const uint2*)replay_list, replay_capacity, x, y, z, routed, (uint4*)payload);
+  }
 }
+
+size_t pcv_climber_bytes(uint64_t num_climbers) { return (size_t)(num_climbers + 1) * sizeof(PcvClimber); }
 
 void pcv_launch_promote_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvPromoteTables& pt, uint64_t n,
                                const uint32_t* rank, const void* payload, const uint32_t* cx_hi, const uint32_t* cy_hi,
-                               const uint32_t* cz_hi, const uint32_t* inten_bits, uint8_t* xyz_blob, uint8_t* rgb_blob,
+                               const uint32_t* cz_hi, const uint32_t* inten_bits, const uint32_t* climb_base,
+                               uint32_t num_climbers, void* climbers, uint8_t* xyz_blob, uint8_t* rgb_blob,
                                uint8_t* inten_blob) {
   if (n == 0) return;
   PromoteOut o{xyz_blob, rgb_blob, inten_blob};
   {
     PcvProf prof(ctx, PCV_K_PROMOTE_ENCODE);
     hipLaunchKernelGGL(promote_settle_kernel, dim3((unsigned)((n + 511) / 512)), dim3(256), 0, ctx->stream, pt, n, rank,
-                       (const uint4*)payload, cx_hi, cy_hi, cz_hi, inten_bits, o);
+                       (const uint4*)payload, cx_hi, cy_hi, cz_hi, inten_bits, climb_base, (PcvClimber*)climbers, o);
   }
-  {
+  if (num_climbers) {
     PcvProf prof(ctx, PCV_K_PROMOTE_CLIMB);
-    hipLaunchKernelGGL(promote_climb_kernel, dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, ctx->stream, pt, n, rank,
-                       (const uint4*)payload, cx_hi, cy_hi, cz_hi, inten_bits, o);
+    hipLaunchKernelGGL(promote_climb_kernel, dim3((num_climbers + 255) / 256), dim3(256), 0, ctx->stream, pt, num_climbers,
+                       (const PcvClimber*)climbers, cx_hi, cy_hi, cz_hi, o);
   }
 }

@@ -67,6 +67,7 @@ enum PcvKernelId {
   PCV_K_SPEC_ENCODE,
   PCV_K_RANK_HIST,
   PCV_K_SPEC_FINALIZE,
+  PCV_K_SPEC_REPLAY,
   PCV_K_COUNT
 };
 
@@ -82,6 +83,11 @@ struct pcv_ctx {
   // pinned host staging, grown on demand
   void* pinned = nullptr;
   size_t pinned_bytes = 0;
+  // second pinned block: staging of the single-chain build (sample table down, walk records / rank map up), so that the
+  // node table can be staged in `pinned` while those uploads are still in flight
+  void* pinned_spec = nullptr;
+  size_t pinned_spec_bytes = 0;
+  int pinned_spec_reserve(size_t bytes);
   hipEvent_t ev[PCV_NUM_STAGES + 2] = {};
   // per-stage begin / end events of the build in flight (a stage may be recorded out of order or not at all)
   hipEvent_t stage_b[PCV_NUM_STAGES] = {}, stage_e[PCV_NUM_STAGES] = {};
@@ -221,6 +227,16 @@ struct PcvNodeTableDev {
   uint32_t* bounds;      // scratch: 9 bounds per node of the level being expanded
   uint32_t* counters;    // [0] node_count, [1] error flag, [2..] level_start[k] (k = 0..PCV_MAX_LEVELS+1)
 };
+// One node of the device table, packed for a single device-to-host copy (pcv_launch_pack_node_table): the copy starts
+// with the 64 counters (256 bytes), the nodes follow.
+struct PcvPackedNode {
+  uint64_t prefix;
+  uint32_t lo, hi, first_child;
+  uint8_t level, child_mask, open, pad;
+};
+static_assert(sizeof(PcvPackedNode) == 24, "packed node");
+constexpr size_t kPcvPackHeader = 256;
+void pcv_launch_pack_node_table(pcv_ctx* ctx, const PcvNodeTableDev& t, void* packed /* header + capacity nodes */);
 // sorted_lo (deep trees): second key word, sorted together with the first; levels > PCV_MAX_KEY_LEVELS search it
 void pcv_launch_node_split(pcv_ctx* ctx, const PcvNodeTableDev& t, const void* sorted_keys, bool keys32, uint32_t n,
                            const PcvLevels& lv, double resolution, uint32_t max_points_per_node,
@@ -251,9 +267,11 @@ void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint64_t* w
                             uint32_t color_stride, const float* intensity, uint32_t* rank, void* payload /* uint4[n] */,
                             void* kept /* uint4[n] or null */, uint32_t* inten_bits);
 void pcv_launch_rank_hist(pcv_ctx* ctx, const uint32_t* rank, uint64_t n, uint32_t num_bins, uint32_t* counts /* zeroed */);
+// replay_list: uint2[replay_capacity] (point index, level), replay_count: zeroed u32 — only used with fix_level
 void pcv_launch_spec_finalize(pcv_ctx* ctx, const PcvLevels& lv, uint64_t n, const uint32_t* spec_map, const uint8_t* fix_level,
                               const double* x, const double* y, const double* z, const PcvRouted& routed, uint32_t* rank,
-                              void* payload, const void* kept);
+                              void* payload, const void* kept, uint32_t* replay_count, void* replay_list,
+                              uint32_t replay_capacity);
 
 // Everything K6 needs about a node in one 80-byte record, so a slot's dependent loads are rank -> record (-> the
 // parent's record per climb) instead of chained table lookups (node, level, per-level edge/encoding, offsets).
@@ -273,10 +291,14 @@ struct PcvPromoteTables {
   const PcvNodeRec* leaf_rec;  // per leaf rank
   const PcvNodeRec* node_rec;  // per node index
 };
+// climb_base[leaf rank] = number of climbers (every 8th point of a non-root leaf) in the leaves before it; climbers:
+// pcv_climber_bytes(num_climbers) bytes of scratch that `settle` fills and `climb` consumes
+size_t pcv_climber_bytes(uint64_t num_climbers);
 void pcv_launch_promote_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvPromoteTables& pt, uint64_t n,
                                const uint32_t* rank, const void* payload /* uint4[n] */, const uint32_t* cx_hi,
                                const uint32_t* cy_hi, const uint32_t* cz_hi, const uint32_t* inten_bits,
-                               uint8_t* xyz_blob, uint8_t* rgb_blob, uint8_t* inten_blob);
+                               const uint32_t* climb_base, uint32_t num_climbers, void* climbers, uint8_t* xyz_blob,
+                               uint8_t* rgb_blob, uint8_t* inten_blob);
 
 struct PcvOctreeQuery;  // device-resident traversal tables (pcv_query.hip)
 

@@ -191,7 +191,30 @@ __global__ __launch_bounds__(1024) void split_assign_kernel(PcvNodeTableDev t, P
   }
 }
 
+// counters + nodes into one contiguous block (one D2H copy instead of eight)
+__global__ __launch_bounds__(256) void pack_node_table_kernel(PcvNodeTableDev t, uint8_t* __restrict__ packed) {
+  const uint32_t count = t.counters[CNT_NODES] < t.capacity ? t.counters[CNT_NODES] : t.capacity;
+  if (blockIdx.x == 0 && threadIdx.x < 64) reinterpret_cast<uint32_t*>(packed)[threadIdx.x] = t.counters[threadIdx.x];
+  PcvPackedNode* out = reinterpret_cast<PcvPackedNode*>(packed + kPcvPackHeader);
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < count; i += gridDim.x * 256) {
+    PcvPackedNode n;
+    n.prefix = t.prefix[i];
+    n.lo = t.lo[i];
+    n.hi = t.hi[i];
+    n.first_child = t.first_child[i];
+    n.level = t.level[i];
+    n.child_mask = t.child_mask[i];
+    n.open = t.open[i];
+    n.pad = 0;
+    out[i] = n;
+  }
+}
+
 }  // namespace
+
+void pcv_launch_pack_node_table(pcv_ctx* ctx, const PcvNodeTableDev& t, void* packed) {
+  hipLaunchKernelGGL(pack_node_table_kernel, dim3(64), dim3(256), 0, ctx->stream, t, (uint8_t*)packed);
+}
 
 void pcv_launch_node_split(pcv_ctx* ctx, const PcvNodeTableDev& t, const void* sorted_keys, bool keys32, uint32_t n,
                            const PcvLevels& lv, double resolution, uint32_t max_points_per_node,
