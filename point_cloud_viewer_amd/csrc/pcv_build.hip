@@ -458,6 +458,10 @@ struct PcvBuild {
   // single-chain build: the records (true-leaf rank, leaf codes + rgb[, intensity]) already exist when the topology does
   bool spec = false;
   void* spec_payload = nullptr;  // uint4[n]
+  struct FixRange {
+    uint32_t lo, count, level;
+  };
+  std::vector<FixRange> fix_ranges;  // sorted slots whose points replay the chain after the record sort
   explicit PcvBuild(pcv_ctx* c) : ctx(c), sc(c) {}
 };
 
@@ -773,14 +777,11 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
     std::memcpy(hp + fix_off, tt->fix_level.data(), (size_t)tree.num_leaves);
     PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_area + fix_off, hp + fix_off, (size_t)tree.num_leaves, hipMemcpyHostToDevice, st));
   }
-  uint32_t* replay_count = nullptr;
-  uint2* replay_list = nullptr;
-  if (tt->any_fix) {  // the points that replay the chain are known exactly: the list cannot overflow
-    if ((rc = sc.get(&replay_count, 64)) || (rc = sc.get(&replay_list, (size_t)tt->fix_points + 64))) return rc;
-    PCV_HIP_CHECK(ctx, hipMemsetAsync(replay_count, 0, 4, st));
-  }
-  pcv_launch_spec_finalize(ctx, lv, n, (const uint32_t*)(d_area + map_off), tt->any_fix ? d_area + fix_off : nullptr, d.x, d.y, d.z,
-                           d.routed, rank, payload, kept, replay_count, replay_list, (uint32_t)tt->fix_points);
+  pcv_launch_spec_finalize(ctx, n, (const uint32_t*)(d_area + map_off), tt->any_fix ? d_area + fix_off : nullptr, rank, payload,
+                           kept);
+  // leaves whose points still have to replay the chain: contiguous once the records are sorted ([lo, hi) of the leaf)
+  bs->fix_ranges.clear();
+  for (uint32_t k : tt->fix_nodes) bs->fix_ranges.push_back({tt->lo[k], tt->hi[k] - tt->lo[k], (uint32_t)tt->level[k]});
   // no synchronisation here: the uploads read ctx->pinned_spec, the caller stages the node table in ctx->pinned, and
   // the pool hands `kept` out again only to work queued on this same stream
   ctx->stage_end(PCV_STAGE_NODE_SPLIT);
@@ -1357,6 +1358,30 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
   uint32_t* s_rank = rec_in_a ? rank_a : rank_b;
   const void* s_pay = rec_in_a ? (const void*)pay_a : (const void*)pay_b;
   uint32_t** s_plane = rec_in_a ? pl.in : pl.out;
+  if (bs->spec && !bs->fix_ranges.empty()) {
+    // single-chain build: the few leaves whose points kept no codes replay their chain now that they are contiguous
+    const uint32_t nr = (uint32_t)bs->fix_ranges.size();
+    uint32_t* d_ranges;
+    if ((rc = sc.get(&d_ranges, (size_t)nr * 4 + 4))) return rc;
+    // staging: the pinned mailbox holds 32 ranges and nothing is in flight on it; more ranges (tiny capacities in
+    // tests) wait for the queued work and take the big block
+    uint32_t* h_ranges = (uint32_t*)ctx->mailbox;
+    if (nr > 32) {
+      PCV_HIP_CHECK(ctx, hipStreamSynchronize(st));
+      if ((rc = ctx->pinned_spec_reserve((size_t)nr * 16 + 64))) return rc;
+      h_ranges = (uint32_t*)ctx->pinned_spec;
+    }
+    uint32_t before = 0;
+    for (uint32_t k = 0; k < nr; ++k) {
+      h_ranges[4 * k + 0] = bs->fix_ranges[k].lo;
+      h_ranges[4 * k + 1] = before;
+      h_ranges[4 * k + 2] = bs->fix_ranges[k].level;
+      h_ranges[4 * k + 3] = 0;
+      before += bs->fix_ranges[k].count;
+    }
+    PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_ranges, h_ranges, (size_t)nr * 16, hipMemcpyHostToDevice, st));
+    pcv_launch_spec_replay(ctx, lv, d_ranges, nr, before, d.x, d.y, d.z, d.routed, (void*)s_pay);
+  }
   ctx->stage_end(PCV_STAGE_SORT_RECORDS);
   ctx->stage_begin(PCV_STAGE_PROMOTE_ENCODE);
 

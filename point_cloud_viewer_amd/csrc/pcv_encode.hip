@@ -161,38 +161,22 @@ __global__ __launch_bounds__(1024) void rank_hist_kernel(const uint32_t* __restr
 
 // After the exact counts fixed the true tree: predicted-leaf rank -> true-leaf rank, and the payload takes the kept
 // codes where the true leaf is the candidate node (bit 31 of the map). FIX: predicted leaves whose true leaf is an
-// inner node of T'' WITHOUT kept codes (a candidate below a candidate, or a count far outside the band) carry the
-// level of that leaf in `fix_level`; their points are appended to a replay list (one atomic per wave that holds any),
-// so that the chain replay runs over a dense list instead of dragging whole waves of the input through it.
+// inner node of T'' WITHOUT kept codes (a candidate below a candidate, or a count far outside the band) are flagged in
+// `fix_level`: their points have no valid codes yet. They leave their input index in the payload; the record sort makes
+// the points of such a leaf contiguous, and spec_replay_kernel then replays their chain over exactly those slots —
+// dense, without lists or atomics.
 template <bool FIX>
 __global__ __launch_bounds__(256) void spec_finalize_kernel(uint64_t n, const uint32_t* __restrict__ spec_map,
                                                              const uint8_t* __restrict__ fix_level, uint32_t* __restrict__ rank,
-                                                             uint4* __restrict__ payload, const uint4* __restrict__ kept,
-                                                             uint32_t* __restrict__ replay_count, uint2* __restrict__ replay_list,
-                                                             uint32_t replay_capacity) {
+                                                             uint4* __restrict__ payload, const uint4* __restrict__ kept) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  const bool in = i < n;
-  uint32_t r = 0, m = 0;
-  if (in) {
-    r = rank[i];
-    m = spec_map[r];
-    rank[i] = m & 0x7fffffffu;
-  }
-  if (FIX) {
-    const uint32_t target = in ? fix_level[r] : 0u;
-    const uint64_t who = __ballot(target != 0);
-    if (who) {  // wave-uniform
-      const int lane = threadIdx.x & 63;
-      uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(replay_count, (uint32_t)__popcll(who));
-      base = __shfl(base, 0, 64);
-      if (target) {
-        const uint32_t slot = base + (uint32_t)__popcll(who & ((1ull << lane) - 1ull));
-        if (slot < replay_capacity) replay_list[slot] = make_uint2((uint32_t)i, target);
-      }
-    }
-  }
-  if (in && (m >> 31)) {
+  if (i >= n) return;
+  const uint32_t r = rank[i];
+  const uint32_t m = spec_map[r];
+  rank[i] = m & 0x7fffffffu;
+  if (FIX && fix_level[r]) {
+    reinterpret_cast<uint32_t*>(payload + i)[0] = (uint32_t)i;  // n < 2^32
+  } else if (m >> 31) {
     const uint4 k = kept[i];
     uint4 p = payload[i];
     p.x = k.x, p.y = k.y, p.z = k.z;
@@ -200,18 +184,27 @@ __global__ __launch_bounds__(256) void spec_finalize_kernel(uint64_t n, const ui
   }
 }
 
-// Chain replay of the listed points to the listed level (dense: every lane has work).
-__global__ __launch_bounds__(256) void spec_replay_kernel(PcvLevels lv, const uint32_t* __restrict__ replay_count,
-                                                           const uint2* __restrict__ replay_list, uint32_t replay_capacity,
-                                                           const double* __restrict__ x, const double* __restrict__ y,
-                                                           const double* __restrict__ z, PcvRouted routed,
-                                                           uint4* __restrict__ payload) {
-  uint32_t count = *replay_count;
-  if (count > replay_capacity) count = replay_capacity;
-  for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < count; j += gridDim.x * 256) {
-    const uint2 e = replay_list[j];
-    const uint64_t i = e.x;
-    const int target = (int)e.y;
+// Chain replay over the sorted slots of the flagged leaves. ranges[k] = {first slot, slots before this range in the
+// flattened work list, level}; `total` = all flagged slots.
+struct PcvFixRange {
+  uint32_t lo, before, level, pad;
+};
+__global__ __launch_bounds__(256) void spec_replay_kernel(PcvLevels lv, const PcvFixRange* __restrict__ ranges, uint32_t num_ranges,
+                                                           uint32_t total, const double* __restrict__ x,
+                                                           const double* __restrict__ y, const double* __restrict__ z,
+                                                           PcvRouted routed, uint4* __restrict__ payload) {
+  for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < total; j += gridDim.x * 256) {
+    uint32_t a = 0, b = num_ranges;  // last range with before <= j
+    while (b - a > 1) {
+      const uint32_t mid = (a + b) >> 1;
+      if (ranges[mid].before <= j) a = mid;
+      else b = mid;
+    }
+    const PcvFixRange rg = ranges[a];
+    const uint64_t s = (uint64_t)rg.lo + (j - rg.before);
+    uint4 p = payload[s];
+    const uint64_t i = p.x;  // the input index the finalize kernel left here
+    const int target = (int)rg.level;
     double px, py, pz, mx, my, mz;
     double vx = 0, vy = 0, vz = 0;
     uint32_t d1;
@@ -222,11 +215,10 @@ __global__ __launch_bounds__(256) void spec_replay_kernel(PcvLevels lv, const ui
                                   my, mz, vx, vy, vz);
     }
     const uint32_t en = lv.enc[target];
-    uint4 p = payload[i];
     p.x = (uint32_t)pcv_val_to_code(en, vx);
     p.y = (uint32_t)pcv_val_to_code(en, vy);
     p.z = (uint32_t)pcv_val_to_code(en, vz);
-    payload[i] = p;
+    payload[s] = p;
   }
 }
 
@@ -409,27 +401,26 @@ void pcv_launch_rank_hist(pcv_ctx* ctx, const uint32_t* rank, uint64_t n, uint32
   }
 }
 
-void pcv_launch_spec_finalize(pcv_ctx* ctx, const PcvLevels& lv, uint64_t n, const uint32_t* spec_map, const uint8_t* fix_level,
-                              const double* x, const double* y, const double* z, const PcvRouted& routed, uint32_t* rank,
-                              void* payload, const void* kept, uint32_t* replay_count, void* replay_list,
-                              uint32_t replay_capacity) {
+void pcv_launch_spec_finalize(pcv_ctx* ctx, uint64_t n, const uint32_t* spec_map, const uint8_t* fix_level, uint32_t* rank,
+                              void* payload, const void* kept) {
   if (n == 0) return;
   const dim3 grid((unsigned)((n + 255) / 256));
-  {
-    PcvProf prof(ctx, PCV_K_SPEC_FINALIZE);
-    if (fix_level)
-      hipLaunchKernelGGL(spec_finalize_kernel<true>, grid, dim3(256), 0, ctx->stream, n, spec_map, fix_level, rank, (uint4*)payload,
-                         (const uint4*)kept, replay_count, (uint2*)replay_list, replay_capacity);
-    else
-      hipLaunchKernelGGL(spec_finalize_kernel<false>, grid, dim3(256), 0, ctx->stream, n, spec_map, fix_level, rank, (uint4*)payload,
-                         (const uint4*)kept, replay_count, (uint2*)replay_list, replay_capacity);
-  }
-  if (fix_level) {
-    PcvProf prof(ctx, PCV_K_SPEC_REPLAY);
-    const unsigned blocks = (unsigned)std::min<uint64_t>(((uint64_t)replay_capacity + 255) / 256, 4096);
-    hipLaunchKernelGGL(spec_replay_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, ctx->stream, lv, replay_count,
-                       (const uint2*)replay_list, replay_capacity, x, y, z, routed, (uint4*)payload);
-  }
+  PcvProf prof(ctx, PCV_K_SPEC_FINALIZE);
+  if (fix_level)
+    hipLaunchKernelGGL(spec_finalize_kernel<true>, grid, dim3(256), 0, ctx->stream, n, spec_map, fix_level, rank, (uint4*)payload,
+                       (const uint4*)kept);
+  else
+    hipLaunchKernelGGL(spec_finalize_kernel<false>, grid, dim3(256), 0, ctx->stream, n, spec_map, fix_level, rank, (uint4*)payload,
+                       (const uint4*)kept);
+}
+
+void pcv_launch_spec_replay(pcv_ctx* ctx, const PcvLevels& lv, const void* ranges, uint32_t num_ranges, uint32_t total,
+                            const double* x, const double* y, const double* z, const PcvRouted& routed, void* sorted_payload) {
+  if (total == 0 || num_ranges == 0) return;
+  PcvProf prof(ctx, PCV_K_SPEC_REPLAY);
+  const unsigned blocks = (unsigned)std::min<uint64_t>(((uint64_t)total + 255) / 256, 8192);
+  hipLaunchKernelGGL(spec_replay_kernel, dim3(blocks), dim3(256), 0, ctx->stream, lv, (const PcvFixRange*)ranges, num_ranges, total,
+                     x, y, z, routed, (uint4*)sorted_payload);
 }
 
 size_t pcv_climber_bytes(uint64_t num_climbers) { return (size_t)(num_climbers + 1) * sizeof(PcvClimber); }

@@ -267,11 +267,11 @@ void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint64_t* w
                             uint32_t color_stride, const float* intensity, uint32_t* rank, void* payload /* uint4[n] */,
                             void* kept /* uint4[n] or null */, uint32_t* inten_bits);
 void pcv_launch_rank_hist(pcv_ctx* ctx, const uint32_t* rank, uint64_t n, uint32_t num_bins, uint32_t* counts /* zeroed */);
-// replay_list: uint2[replay_capacity] (point index, level), replay_count: zeroed u32 — only used with fix_level
-void pcv_launch_spec_finalize(pcv_ctx* ctx, const PcvLevels& lv, uint64_t n, const uint32_t* spec_map, const uint8_t* fix_level,
-                              const double* x, const double* y, const double* z, const PcvRouted& routed, uint32_t* rank,
-                              void* payload, const void* kept, uint32_t* replay_count, void* replay_list,
-                              uint32_t replay_capacity);
+void pcv_launch_spec_finalize(pcv_ctx* ctx, uint64_t n, const uint32_t* spec_map, const uint8_t* fix_level, uint32_t* rank,
+                              void* payload, const void* kept);
+// ranges: device array of {first sorted slot, flagged slots before it, level, pad} (4 x u32), after the record sort
+void pcv_launch_spec_replay(pcv_ctx* ctx, const PcvLevels& lv, const void* ranges, uint32_t num_ranges, uint32_t total,
+                            const double* x, const double* y, const double* z, const PcvRouted& routed, void* sorted_payload);
 
 // Everything K6 needs about a node in one 80-byte record, so a slot's dependent loads are rank -> record (-> the
 // parent's record per climb) instead of chained table lookups (node, level, per-level edge/encoding, offsets).

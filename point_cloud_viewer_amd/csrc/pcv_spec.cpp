@@ -159,6 +159,7 @@ PcvSpecStatus pcv_spec_resolve(const PcvSpecParams& p, const PcvSpecTree& t, con
     else {
       r.any_fix = true;
       r.fix_points += cnt[i];
+      r.fix_nodes.push_back(k);
     }
     below.clear();
     below.push_back(i);

@@ -82,8 +82,10 @@ struct PcvTrueTree {
   std::vector<uint32_t> spec_map;
   // A true leaf that is an inner node of T'' whose points did NOT keep their codes there (a candidate below another
   // candidate, or a sampled count outside the band): level of that leaf per predicted leaf below it, 0 = none. Those
-  // points replay the chain to that level in the finalize kernel (rare; any_fix says whether the table is needed).
+  // points replay the chain to that level once the record sort has made them contiguous (rare; any_fix says whether the
+  // table is needed).
   std::vector<uint8_t> fix_level;
+  std::vector<uint32_t> fix_nodes;  // the true leaves (indices into this table) whose points replay the chain
   bool any_fix = false;
   uint64_t fix_points = 0, kept_points = 0;  // points that replay the chain / take their kept codes
   uint32_t num_leaves = 0;

@@ -20,6 +20,8 @@ def ctx():
     c.close()
 
 
+SEEN = {"held": 0, "fell_back": 0, "kept": 0, "replayed": 0}
+
 CASES = [  # n, capacity, resolution, clusters, extent, sigma range, intensity, seed
     (600_000, 20_000, 0.001, 6, 200.0, (0.2, 8.0), False, 1),
     (600_000, 20_000, 0.001, 6, 200.0, (0.2, 8.0), True, 2),
@@ -40,6 +42,9 @@ def test_forced_single_chain_equals_oracle(ctx, n, cap, res, clusters, extent, s
     info = t.build_info()
     assert_same(t.to_dict(), want, check_intensity=with_int)
     assert info["attempts"] in (0, 2, 3), info  # held, or redone by the exact pipeline (with or without its own retry)
+    SEEN["held" if info["single_chain"] else "fell_back"] += 1
+    SEEN["kept"] += info["kept_code_points"] > 0
+    SEEN["replayed"] += info["replayed_points"] > 0
     if info["single_chain"]:
         leaves = sum(1 for k in want.nodes if not any(c.startswith(k) and len(c) == len(k) + 1 for c in want.nodes))
         assert info["predicted_leaves"] >= leaves
@@ -48,6 +53,11 @@ def test_forced_single_chain_equals_oracle(ctx, n, cap, res, clusters, extent, s
     t2 = ctx.build(res, pcv.Aabb(bmin, bmax), x, y, z, rgb, inten, max_points_per_node=cap, single_chain=False)
     assert t2.build_info()["attempts"] >= 1
     assert_same(t2.to_dict(), want, check_intensity=with_int)
+
+
+def test_the_cases_above_covered_every_branch_of_the_prediction():
+    """held / took kept codes / replayed the chain after the sort must all have happened at least once above."""
+    assert SEEN["held"] >= 3 and SEEN["kept"] >= 2 and SEEN["replayed"] >= 1, SEEN
 
 
 def test_single_chain_is_the_default_from_4M_points_and_takes_kept_codes(ctx):
