@@ -727,7 +727,7 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
   stab.open = s_open;
   PcvSpecTree tree;
   pcv_spec_build_tree(sp, stab, &tree);
-  const size_t walk_bytes = tree.walk.size() * 8;
+  const size_t walk_bytes = tree.walk.size() * sizeof(uint32_t);
   // one upload area: walk records now, the rank map (+ fix levels) later; one zeroed counter per predicted leaf
   const size_t map_off = (walk_bytes + 255) & ~(size_t)255;
   const size_t fix_off = map_off + (((size_t)tree.num_leaves * 4 + 255) & ~(size_t)255);
@@ -750,7 +750,7 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
   if (tree.any_candidate && (rc = sc.get(&kept, n))) return rc;
   uint32_t* inten_bits = t->has_intensity ? (uint32_t*)bs->keys_a + n : nullptr;
   // the sample keys are dead (the sample tree is on the host): the rank array takes their place in keys_a
-  pcv_launch_spec_encode(ctx, lv, (const uint64_t*)d_area, n, d.x, d.y, d.z, d.routed, d.color, d.color_stride, d.intensity,
+  pcv_launch_spec_encode(ctx, lv, (const uint32_t*)d_area, n, d.x, d.y, d.z, d.routed, d.color, d.color_stride, d.intensity,
                          rank, payload, kept, inten_bits);
   ctx->stage_end(PCV_STAGE_LEAF_ENCODE);
 
@@ -773,12 +773,7 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
   if (tt->prefix.size() > (size_t)nt.capacity) return ctx->fail(PCV_E_OOM, "node table capacity exceeded");
   std::memcpy(hp + map_off, tt->spec_map.data(), (size_t)tree.num_leaves * 4);
   PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_area + map_off, hp + map_off, (size_t)tree.num_leaves * 4, hipMemcpyHostToDevice, st));
-  if (tt->any_fix) {
-    std::memcpy(hp + fix_off, tt->fix_level.data(), (size_t)tree.num_leaves);
-    PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_area + fix_off, hp + fix_off, (size_t)tree.num_leaves, hipMemcpyHostToDevice, st));
-  }
-  pcv_launch_spec_finalize(ctx, n, (const uint32_t*)(d_area + map_off), tt->any_fix ? d_area + fix_off : nullptr, rank, payload,
-                           kept);
+  pcv_launch_spec_finalize(ctx, n, (const uint32_t*)(d_area + map_off), rank, payload, kept);
   // leaves whose points still have to replay the chain: contiguous once the records are sorted ([lo, hi) of the leaf)
   bs->fix_ranges.clear();
   for (uint32_t k : tt->fix_nodes) bs->fix_ranges.push_back({tt->lo[k], tt->hi[k] - tt->lo[k], (uint32_t)tt->level[k]});

@@ -79,13 +79,13 @@ __global__ __launch_bounds__(256) void leaf_encode_kernel(
 // predicted leaf, and — only for points that passed a candidate — the kept codes + their level.
 template <bool KEEP>
 __global__ __launch_bounds__(256) void spec_encode_kernel(
-    PcvLevels lv, const uint64_t* __restrict__ walk, uint64_t n, const double* __restrict__ x,
+    PcvLevels lv, const uint32_t* __restrict__ walk, uint64_t n, const double* __restrict__ x,
     const double* __restrict__ y, const double* __restrict__ z, PcvRouted routed, const uint8_t* __restrict__ color,
     uint32_t color_stride, const float* __restrict__ intensity, uint32_t* __restrict__ rank, uint4* __restrict__ payload,
     uint4* __restrict__ kept, uint32_t* __restrict__ inten_bits) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  uint64_t rec = walk[0];
+  uint32_t rec = walk[0];
   double px, py, pz, mx, my, mz;
   double vx = 0, vy = 0, vz = 0;
   double kx = 0, ky = 0, kz = 0;
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void spec_encode_kernel(
   int L = 0;
   if (pcv_chain_start(lv, routed, x, y, z, i, px, py, pz, mx, my, mz, vx, vy, vz, d1) == 2 && !(rec & PCV_SPEC_LEAF)) {
     L = 1;  // routed input: level 1 is given (digit + codes)
-    rec = walk[(uint32_t)rec + d1];
+    rec = walk[(rec & PCV_SPEC_INDEX_MASK) + d1];
   }
 #define PCV_SPEC_WALK(GUARD)                                                                                          \
   while (!(rec & PCV_SPEC_LEAF) && L < lv.nlevels) {                                                                    \
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void spec_encode_kernel(
     ++L;                                                                                                                \
     const uint32_t d = pcv_chain_level<GUARD>(lv.enc[L], lv.edge[L - 1], lv.edge[L], PcvRecip{lv.inv_edge[L], lv.inv_edge_lo[L]}, \
                                               px, py, pz, mx, my, mz, vx, vy, vz);                                      \
-    rec = walk[(uint32_t)rec + d];                                                                                      \
+    rec = walk[(rec & PCV_SPEC_INDEX_MASK) + d];                                                                        \
   }
   if (lv.fast_ok && pcv_point_is_tame(px, py, pz)) {
     PCV_SPEC_WALK(false)
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void spec_encode_kernel(
     PCV_SPEC_WALK(true)
   }
 #undef PCV_SPEC_WALK
-  rank[i] = (uint32_t)rec;
+  rank[i] = rec & PCV_SPEC_INDEX_MASK;
   const uint32_t leaf_enc = lv.enc[L];
   const uint8_t* c = color + i * color_stride;
   payload[i] = make_uint4((uint32_t)pcv_val_to_code(leaf_enc, vx), (uint32_t)pcv_val_to_code(leaf_enc, vy),
@@ -162,21 +162,19 @@ __global__ __launch_bounds__(1024) void rank_hist_kernel(const uint32_t* __restr
 // After the exact counts fixed the true tree: predicted-leaf rank -> true-leaf rank, and the payload takes the kept
 // codes where the true leaf is the candidate node (bit 31 of the map). FIX: predicted leaves whose true leaf is an
 // inner node of T'' WITHOUT kept codes (a candidate below a candidate, or a count far outside the band) are flagged in
-// `fix_level`: their points have no valid codes yet. They leave their input index in the payload; the record sort makes
+// the map (PCV_SPEC_MAP_REPLAY): their points have no valid codes yet. They leave their input index in the payload; the record sort makes
 // the points of such a leaf contiguous, and spec_replay_kernel then replays their chain over exactly those slots —
 // dense, without lists or atomics.
-template <bool FIX>
 __global__ __launch_bounds__(256) void spec_finalize_kernel(uint64_t n, const uint32_t* __restrict__ spec_map,
-                                                             const uint8_t* __restrict__ fix_level, uint32_t* __restrict__ rank,
-                                                             uint4* __restrict__ payload, const uint4* __restrict__ kept) {
+                                                             uint32_t* __restrict__ rank, uint4* __restrict__ payload,
+                                                             const uint4* __restrict__ kept) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const uint32_t r = rank[i];
-  const uint32_t m = spec_map[r];
-  rank[i] = m & 0x7fffffffu;
-  if (FIX && fix_level[r]) {
+  const uint32_t m = spec_map[rank[i]];
+  rank[i] = m & PCV_SPEC_INDEX_MASK;
+  if (m & PCV_SPEC_MAP_REPLAY) {
     reinterpret_cast<uint32_t*>(payload + i)[0] = (uint32_t)i;  // n < 2^32
-  } else if (m >> 31) {
+  } else if (m & PCV_SPEC_MAP_KEPT) {
     const uint4 k = kept[i];
     uint4 p = payload[i];
     p.x = k.x, p.y = k.y, p.z = k.z;
@@ -373,7 +371,7 @@ void pcv_launch_leaf_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvWalkTabl
                      y, z, routed, color, color_stride, intensity, rank, (uint4*)payload, cx_hi, cy_hi, cz_hi, inten_bits);
 }
 
-void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint64_t* walk, uint64_t n, const double* x,
+void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* walk, uint64_t n, const double* x,
                             const double* y, const double* z, const PcvRouted& routed, const uint8_t* color,
                             uint32_t color_stride, const float* intensity, uint32_t* rank, void* payload, void* kept,
                             uint32_t* inten_bits) {
@@ -401,17 +399,11 @@ void pcv_launch_rank_hist(pcv_ctx* ctx, const uint32_t* rank, uint64_t n, uint32
   }
 }
 
-void pcv_launch_spec_finalize(pcv_ctx* ctx, uint64_t n, const uint32_t* spec_map, const uint8_t* fix_level, uint32_t* rank,
-                              void* payload, const void* kept) {
+void pcv_launch_spec_finalize(pcv_ctx* ctx, uint64_t n, const uint32_t* spec_map, uint32_t* rank, void* payload, const void* kept) {
   if (n == 0) return;
-  const dim3 grid((unsigned)((n + 255) / 256));
   PcvProf prof(ctx, PCV_K_SPEC_FINALIZE);
-  if (fix_level)
-    hipLaunchKernelGGL(spec_finalize_kernel<true>, grid, dim3(256), 0, ctx->stream, n, spec_map, fix_level, rank, (uint4*)payload,
-                       (const uint4*)kept);
-  else
-    hipLaunchKernelGGL(spec_finalize_kernel<false>, grid, dim3(256), 0, ctx->stream, n, spec_map, fix_level, rank, (uint4*)payload,
-                       (const uint4*)kept);
+  hipLaunchKernelGGL(spec_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, spec_map, rank,
+                     (uint4*)payload, (const uint4*)kept);
 }
 
 void pcv_launch_spec_replay(pcv_ctx* ctx, const PcvLevels& lv, const void* ranges, uint32_t num_ranges, uint32_t total,

@@ -262,13 +262,13 @@ void pcv_launch_leaf_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvWalkTabl
 
 // single-chain build (pcv_spec.h): the one chain pass down the predicted tree, the exact per-leaf counts, and the
 // rank / payload fix-up once the true tree is known
-void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint64_t* walk, uint64_t n, const double* x,
+void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* walk, uint64_t n, const double* x,
                             const double* y, const double* z, const PcvRouted& routed, const uint8_t* color,
                             uint32_t color_stride, const float* intensity, uint32_t* rank, void* payload /* uint4[n] */,
                             void* kept /* uint4[n] or null */, uint32_t* inten_bits);
 void pcv_launch_rank_hist(pcv_ctx* ctx, const uint32_t* rank, uint64_t n, uint32_t num_bins, uint32_t* counts /* zeroed */);
-void pcv_launch_spec_finalize(pcv_ctx* ctx, uint64_t n, const uint32_t* spec_map, const uint8_t* fix_level, uint32_t* rank,
-                              void* payload, const void* kept);
+void pcv_launch_spec_finalize(pcv_ctx* ctx, uint64_t n, const uint32_t* spec_map, uint32_t* rank, void* payload,
+                              const void* kept);
 // ranges: device array of {first sorted slot, flagged slots before it, level, pad} (4 x u32), after the record sort
 void pcv_launch_spec_replay(pcv_ctx* ctx, const PcvLevels& lv, const void* ranges, uint32_t num_ranges, uint32_t total,
                             const double* x, const double* y, const double* z, const PcvRouted& routed, void* sorted_payload);

@@ -70,12 +70,8 @@ void pcv_spec_build_tree(const PcvSpecParams& p, const PcvSampleTable& s, PcvSpe
     for (int c = 7; c >= 0; --c) stack.push_back(t.first_child[i] + (uint32_t)c);
   }
   t.walk.resize(t.prefix.size());
-  for (size_t i = 0; i < t.prefix.size(); ++i) {
-    uint64_t rec = (uint64_t)t.level[i] << PCV_SPEC_LEVEL_SHIFT;
-    if (t.inner[i]) rec |= (uint64_t)t.first_child[i] | (t.candidate[i] ? PCV_SPEC_CANDIDATE : 0ull);
-    else rec |= (uint64_t)t.leaf_rank[i] | PCV_SPEC_LEAF;
-    t.walk[i] = rec;
-  }
+  for (size_t i = 0; i < t.prefix.size(); ++i)
+    t.walk[i] = t.inner[i] ? (t.first_child[i] | (t.candidate[i] ? PCV_SPEC_CANDIDATE : 0u)) : (t.leaf_rank[i] | PCV_SPEC_LEAF);
 }
 
 PcvSpecStatus pcv_spec_resolve(const PcvSpecParams& p, const PcvSpecTree& t, const uint32_t* leaf_counts, PcvTrueTree* out) {
@@ -167,7 +163,7 @@ PcvSpecStatus pcv_spec_resolve(const PcvSpecParams& p, const PcvSpecTree& t, con
       const uint32_t j = below.back();
       below.pop_back();
       if (!t.inner[j]) {
-        r.spec_map[t.leaf_rank[j]] = has_codes ? (rank | 0x80000000u) : rank;
+        r.spec_map[t.leaf_rank[j]] = rank | (has_codes ? PCV_SPEC_MAP_KEPT : PCV_SPEC_MAP_REPLAY);
         if (!has_codes) r.fix_level[t.leaf_rank[j]] = t.level[i];
       } else {
         for (unsigned c = 0; c < 8; ++c) below.push_back(t.first_child[j] + c);
@@ -251,16 +247,16 @@ extern "C" int pcv_spec_selftest(const uint64_t* keys, uint64_t n, uint32_t stri
   std::vector<uint32_t> counts(tree.num_leaves, 0);
   uint64_t kept = 0;
   for (uint64_t i = 0; i < n; ++i) {  // what the fused kernel's walk does with the digits of the chain
-    uint64_t rec = tree.walk[0];
+    uint32_t rec = tree.walk[0];
     int l = 0;
     bool have = false;
     while (!(rec & PCV_SPEC_LEAF)) {
       if ((rec & PCV_SPEC_CANDIDATE) && !have) have = true;
       ++l;
-      rec = tree.walk[(uint32_t)rec + (unsigned)((keys[i] >> (3 * (kKeyLevels - l))) & 7)];
+      rec = tree.walk[(rec & PCV_SPEC_INDEX_MASK) + (unsigned)((keys[i] >> (3 * (kKeyLevels - l))) & 7)];
     }
     kept += have;
-    ++counts[(uint32_t)rec];
+    ++counts[rec & PCV_SPEC_INDEX_MASK];
   }
   PcvTrueTree tt;
   const PcvSpecStatus status = pcv_spec_resolve(p, tree, counts.data(), &tt);
@@ -281,7 +277,7 @@ extern "C" int pcv_spec_selftest(const uint64_t* keys, uint64_t n, uint32_t stri
   }
   // the map must send every predicted leaf's points into the true leaf that spans them
   std::vector<uint64_t> per_leaf(tt.num_leaves, 0);
-  for (uint32_t r = 0; r < tree.num_leaves; ++r) per_leaf[tt.spec_map[r] & 0x7fffffffu] += counts[r];
+  for (uint32_t r = 0; r < tree.num_leaves; ++r) per_leaf[tt.spec_map[r] & PCV_SPEC_INDEX_MASK] += counts[r];
   uint32_t rank = 0;
   std::vector<uint32_t> stack{0};
   while (!stack.empty()) {

@@ -20,11 +20,15 @@
 
 #include <vector>
 
-// Walk record of a T'' node (device): inner: first child index in bits 0..31 (the eight children are consecutive),
-// leaf: predicted-leaf rank in bits 0..31.
-#define PCV_SPEC_LEAF (1ull << 40)
-#define PCV_SPEC_CANDIDATE (1ull << 41)
-#define PCV_SPEC_LEVEL_SHIFT 48
+// Walk record of a T'' node (device, 32 bits so that the table of a 100 M-point tree fits the 32 KiB vector L1): inner:
+// first child index in bits 0..29 (the eight children are consecutive), leaf: predicted-leaf rank in bits 0..29.
+#define PCV_SPEC_LEAF (1u << 31)
+#define PCV_SPEC_CANDIDATE (1u << 30)
+#define PCV_SPEC_INDEX_MASK 0x3fffffffu
+// predicted-leaf -> true-leaf map entry: true rank in bits 0..29, bit 31: take the kept codes, bit 30: no codes yet
+// (the point leaves its input index in the payload and replays the chain after the record sort)
+#define PCV_SPEC_MAP_KEPT (1u << 31)
+#define PCV_SPEC_MAP_REPLAY (1u << 30)
 
 struct PcvSpecParams {
   uint32_t cap = 0;         // max_points_per_node
@@ -56,7 +60,7 @@ struct PcvSpecTree {
   std::vector<uint32_t> first_child;  // inner nodes: index of child 0 (children 0..7 follow each other)
   std::vector<uint32_t> parent;
   std::vector<uint32_t> leaf_rank;    // leaves: rank in key order (depth first, digits ascending)
-  std::vector<uint64_t> walk;         // device walk records, one per node
+  std::vector<uint32_t> walk;         // device walk records, one per node
   uint32_t num_leaves = 0;
   bool any_candidate = false;
 };
@@ -73,8 +77,8 @@ enum PcvSpecStatus {
 
 // The true tree in the layout the exact path downloads from the device after the node split (BFS order, children
 // contiguous in digit order, [lo, hi) = range in key-sorted order), plus the map predicted-leaf rank -> true leaf rank
-// (depth-first order, the same order pcv_build_finish assigns) with bit 31 set when the point takes the codes it kept at
-// its candidate node instead of the codes of its predicted leaf.
+// (depth-first order, the same order pcv_build_finish assigns) with PCV_SPEC_MAP_KEPT set when the point takes the codes
+// it kept at its candidate node instead of the codes of its predicted leaf, PCV_SPEC_MAP_REPLAY when it has to replay.
 struct PcvTrueTree {
   std::vector<uint64_t> prefix;
   std::vector<uint32_t> lo, hi, first_child;
