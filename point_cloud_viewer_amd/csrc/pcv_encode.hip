@@ -10,6 +10,7 @@
 //     (encode_k(decode_k(b))) at slot j - j/8 - 1; the root keeps everything it receives.
 //     Output is written node-contiguous: exactly the bytes of <node>.xyz/.rgb/.intensity.
 #include <algorithm>
+#include <cstdlib>
 
 #include "pcv_chain_dev.h"
 #include "pcv_spec.h"
@@ -77,24 +78,99 @@ __global__ __launch_bounds__(256) void leaf_encode_kernel(
 // (the first such node on its path): if the exact counts later say the node is a leaf, those are the point's leaf
 // codes; otherwise the codes of the predicted leaf are. Output: predicted-leaf rank, payload {codes, rgb} at the
 // predicted leaf, and — only for points that passed a candidate — the kept codes + their level.
-template <bool KEEP>
-__global__ __launch_bounds__(256) void spec_encode_kernel(
+//
+// Depth binning (BIN): lanes of one wave replay the chain until the DEEPEST of their 64 points reaches its leaf. In
+// input order that is 9.7 levels per wave for a mean leaf depth of 6.7 (config-2 cloud) — 45 % of the f64 work runs
+// with the lane already finished. So the workgroup first PREDICTS every point's leaf depth with a cheap walk of T''
+// along the digits of a 16-bit integer image of the coordinates (a hint: a wrong guess costs time, never changes a
+// result — the exact chain below still does all the work), then re-deals its points so that every wave gets points of
+// (nearly) the same depth, deepest waves first. Coordinates travel through LDS; outputs go to the point's own index.
+constexpr int kSpecClasses = 24;  // predicted depth 0..21 (+ padding lanes)
+
+template <bool KEEP, bool BIN, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void spec_encode_kernel(
     PcvLevels lv, const uint32_t* __restrict__ walk, uint64_t n, const double* __restrict__ x,
     const double* __restrict__ y, const double* __restrict__ z, PcvRouted routed, const uint8_t* __restrict__ color,
     uint32_t color_stride, const float* __restrict__ intensity, uint32_t* __restrict__ rank, uint4* __restrict__ payload,
-    uint4* __restrict__ kept, uint32_t* __restrict__ inten_bits) {
-  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  uint32_t rec = walk[0];
+    uint4* __restrict__ kept, uint32_t* __restrict__ inten_bits, float cells_per_unit /* 65536 / root edge */) {
+  constexpr int kWavesB = BLOCK / 64;
+  __shared__ double sx[BIN ? BLOCK : 1], sy[BIN ? BLOCK : 1], sz[BIN ? BLOCK : 1];
+  __shared__ uint16_t perm[BIN ? BLOCK : 1];
+  __shared__ uint16_t wcnt[BIN ? kWavesB : 1][kSpecClasses];
+  uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
   double px, py, pz, mx, my, mz;
   double vx = 0, vy = 0, vz = 0;
   double kx = 0, ky = 0, kz = 0;
   int kl = 0;
-  uint32_t d1;
+  uint32_t d1 = 0;
   int L = 0;
-  if (pcv_chain_start(lv, routed, x, y, z, i, px, py, pz, mx, my, mz, vx, vy, vz, d1) == 2 && !(rec & PCV_SPEC_LEAF)) {
-    L = 1;  // routed input: level 1 is given (digit + codes)
-    rec = walk[(rec & PCV_SPEC_INDEX_MASK) + d1];
+  uint32_t rec = walk[0];
+  if (BIN) {  // raw (not routed) input only
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool in = i < n;
+    uint32_t key = kSpecClasses - 1;  // padding lanes go last
+    if (in) {
+      const double qx = x[i], qy = y[i], qz = z[i];
+      sx[tid] = qx, sy[tid] = qy, sz[tid] = qz;
+      // 16-bit cell coordinates in the root cube (NaN -> 0, out of range clamps): the digits of level k are bit 16 - k
+      const int ix = (int)fminf(fmaxf((float)(qx - lv.root_min[0]) * cells_per_unit, 0.f), 65535.f);
+      const int iy = (int)fminf(fmaxf((float)(qy - lv.root_min[1]) * cells_per_unit, 0.f), 65535.f);
+      const int iz = (int)fminf(fmaxf((float)(qz - lv.root_min[2]) * cells_per_unit, 0.f), 65535.f);
+      uint32_t r = rec;
+      int l = 0;
+      while (!(r & PCV_SPEC_LEAF) && l < 16) {
+        ++l;
+        const uint32_t d = (((uint32_t)ix >> (16 - l)) & 1u) << 2 | (((uint32_t)iy >> (16 - l)) & 1u) << 1 | (((uint32_t)iz >> (16 - l)) & 1u);
+        r = walk[(r & PCV_SPEC_INDEX_MASK) + d];
+      }
+      key = (uint32_t)(kSpecClasses - 2 - l);  // deepest first
+    }
+    for (int k = tid; k < kWavesB * kSpecClasses; k += BLOCK) (&wcnt[0][0])[k] = 0;
+    __syncthreads();
+    // lanes of the wave with the same key: 5 ballots; the first of each group publishes the group size
+    uint64_t peers = ~0ull;
+#pragma unroll
+    for (int b = 0; b < 5; ++b) {
+      const bool bit = (key >> b) & 1u;
+      const uint64_t m = __ballot(bit);
+      peers &= bit ? m : ~m;
+    }
+    const uint32_t before = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+    if (before == 0) wcnt[wave][key] = (uint16_t)__popcll(peers);
+    __syncthreads();
+    if (tid < 64) {  // offsets: keys ascending, inside a key the waves ascending
+      uint32_t tot = 0;
+      if (tid < kSpecClasses)
+        for (int w = 0; w < kWavesB; ++w) tot += wcnt[w][tid];
+      uint32_t inc = tot;
+#pragma unroll
+      for (int o = 1; o < 32; o <<= 1) {
+        const uint32_t v = __shfl_up(inc, o, 64);
+        if (tid >= o) inc += v;
+      }
+      if (tid < kSpecClasses) {
+        uint32_t run = inc - tot;
+        for (int w = 0; w < kWavesB; ++w) {
+          const uint32_t c = wcnt[w][tid];
+          wcnt[w][tid] = (uint16_t)run;
+          run += c;
+        }
+      }
+    }
+    __syncthreads();
+    perm[wcnt[wave][key] + before] = (uint16_t)tid;
+    __syncthreads();
+    const int j = perm[tid];
+    i = (uint64_t)blockIdx.x * BLOCK + j;
+    if (i >= n) return;
+    px = sx[j], py = sy[j], pz = sz[j];
+    mx = lv.root_min[0], my = lv.root_min[1], mz = lv.root_min[2];
+  } else {
+    if (i >= n) return;
+    if (pcv_chain_start(lv, routed, x, y, z, i, px, py, pz, mx, my, mz, vx, vy, vz, d1) == 2 && !(rec & PCV_SPEC_LEAF)) {
+      L = 1;  // routed input: level 1 is given (digit + codes)
+      rec = walk[(rec & PCV_SPEC_INDEX_MASK) + d1];
+    }
   }
 #define PCV_SPEC_WALK(GUARD)                                                                                          \
   while (!(rec & PCV_SPEC_LEAF) && L < lv.nlevels) {                                                                    \
@@ -371,19 +447,41 @@ void pcv_launch_leaf_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvWalkTabl
                      y, z, routed, color, color_stride, intensity, rank, (uint4*)payload, cx_hi, cy_hi, cz_hi, inten_bits);
 }
 
+template <bool BIN, int BLOCK>
+static void launch_spec_encode_t(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* walk, uint64_t n, const double* x,
+                                 const double* y, const double* z, const PcvRouted& routed, const uint8_t* color,
+                                 uint32_t color_stride, const float* intensity, uint32_t* rank, void* payload, void* kept,
+                                 uint32_t* inten_bits) {
+  const dim3 grid((unsigned)((n + BLOCK - 1) / BLOCK));
+  const float cells = lv.edge[0] > 0.0 ? (float)(65536.0 / lv.edge[0]) : 0.f;
+  if (kept)
+    hipLaunchKernelGGL((spec_encode_kernel<true, BIN, BLOCK>), grid, dim3(BLOCK), 0, ctx->stream, lv, walk, n, x, y, z, routed, color,
+                       color_stride, intensity, rank, (uint4*)payload, (uint4*)kept, inten_bits, cells);
+  else
+    hipLaunchKernelGGL((spec_encode_kernel<false, BIN, BLOCK>), grid, dim3(BLOCK), 0, ctx->stream, lv, walk, n, x, y, z, routed,
+                       color, color_stride, intensity, rank, (uint4*)payload, (uint4*)nullptr, inten_bits, cells);
+}
+
 void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* walk, uint64_t n, const double* x,
                             const double* y, const double* z, const PcvRouted& routed, const uint8_t* color,
                             uint32_t color_stride, const float* intensity, uint32_t* rank, void* payload, void* kept,
                             uint32_t* inten_bits) {
   if (n == 0) return;
   PcvProf prof(ctx, PCV_K_SPEC_ENCODE);
-  const dim3 grid((unsigned)((n + 255) / 256));
-  if (kept)
-    hipLaunchKernelGGL(spec_encode_kernel<true>, grid, dim3(256), 0, ctx->stream, lv, walk, n, x, y, z, routed, color,
-                       color_stride, intensity, rank, (uint4*)payload, (uint4*)kept, inten_bits);
+  // PCV_SPEC_BIN (experiments): 0 = input order, 256 / 512 / 1024 = depth binning inside workgroups of that size
+  static const int bin_mode = [] {
+    const char* e = getenv("PCV_SPEC_BIN");
+    return e ? atoi(e) : 1024;
+  }();
+  const bool bin = bin_mode != 0 && !routed.oct;
+  if (!bin)
+    launch_spec_encode_t<false, 256>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, kept, inten_bits);
+  else if (bin_mode == 256)
+    launch_spec_encode_t<true, 256>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, kept, inten_bits);
+  else if (bin_mode == 512)
+    launch_spec_encode_t<true, 512>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, kept, inten_bits);
   else
-    hipLaunchKernelGGL(spec_encode_kernel<false>, grid, dim3(256), 0, ctx->stream, lv, walk, n, x, y, z, routed, color,
-                       color_stride, intensity, rank, (uint4*)payload, (uint4*)nullptr, inten_bits);
+    launch_spec_encode_t<true, 1024>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, kept, inten_bits);
 }
 
 void pcv_launch_rank_hist(pcv_ctx* ctx, const uint32_t* rank, uint64_t n, uint32_t num_bins, uint32_t* counts) {
