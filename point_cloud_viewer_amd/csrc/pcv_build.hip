@@ -750,8 +750,10 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
   if (tree.any_candidate && (rc = sc.get(&kept, n))) return rc;
   uint32_t* inten_bits = t->has_intensity ? (uint32_t*)bs->keys_a + n : nullptr;
   // the sample keys are dead (the sample tree is on the host): the rank array takes their place in keys_a
+  uint8_t* depth_grid = nullptr;
+  if (n >= (1u << 20) && (rc = sc.get(&depth_grid, pcv_spec_depth_grid_bytes()))) return rc;  // small builds: not worth a 2 MiB fill
   pcv_launch_spec_encode(ctx, lv, (const uint32_t*)d_area, n, d.x, d.y, d.z, d.routed, d.color, d.color_stride, d.intensity,
-                         rank, payload, kept, inten_bits);
+                         rank, payload, kept, inten_bits, depth_grid);
   ctx->stage_end(PCV_STAGE_LEAF_ENCODE);
 
   // ---- exact counts -> true tree ----

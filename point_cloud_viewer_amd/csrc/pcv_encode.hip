@@ -81,18 +81,34 @@ __global__ __launch_bounds__(256) void leaf_encode_kernel(
 //
 // Depth binning (BIN): lanes of one wave replay the chain until the DEEPEST of their 64 points reaches its leaf. In
 // input order that is 9.7 levels per wave for a mean leaf depth of 6.7 (config-2 cloud) — 45 % of the f64 work runs
-// with the lane already finished. So the workgroup first PREDICTS every point's leaf depth with a cheap walk of T''
-// along the digits of a 16-bit integer image of the coordinates (a hint: a wrong guess costs time, never changes a
-// result — the exact chain below still does all the work), then re-deals its points so that every wave gets points of
-// (nearly) the same depth, deepest waves first. Coordinates travel through LDS; outputs go to the point's own index.
+// with the lane already finished. So the workgroup first PREDICTS every point's leaf depth — one byte lookup in a
+// 128^3 grid over the root cube that spec_depth_grid_kernel fills from T'' (depth of the leaf that covers the cell, 8 =
+// "deeper than the grid") — and re-deals its points so that every wave gets points of (nearly) the same depth, deepest
+// waves first. The prediction is a hint: a wrong guess costs time, never changes a result — the exact chain below
+// still does all the work. Coordinates travel through LDS; outputs go to the point's own index.
 constexpr int kSpecClasses = 24;  // predicted depth 0..21 (+ padding lanes)
+constexpr int kGridBits = 7;      // 128^3 cells, 2 MiB: stays in L2
+
+__global__ __launch_bounds__(256) void spec_depth_grid_kernel(const uint32_t* __restrict__ walk, uint8_t* __restrict__ grid) {
+  const uint32_t c = blockIdx.x * 256 + threadIdx.x;  // grid is exactly 2^21 cells
+  const uint32_t ix = c & 127u, iy = (c >> 7) & 127u, iz = c >> 14;
+  uint32_t r = walk[0];
+  uint32_t l = 0;
+  while (!(r & PCV_SPEC_LEAF) && l < (uint32_t)kGridBits) {
+    ++l;
+    const uint32_t d = ((ix >> (kGridBits - l)) & 1u) << 2 | ((iy >> (kGridBits - l)) & 1u) << 1 | ((iz >> (kGridBits - l)) & 1u);
+    r = walk[(r & PCV_SPEC_INDEX_MASK) + d];
+  }
+  grid[c] = (uint8_t)((r & PCV_SPEC_LEAF) ? l : kGridBits + 1);
+}
 
 template <bool KEEP, bool BIN, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void spec_encode_kernel(
     PcvLevels lv, const uint32_t* __restrict__ walk, uint64_t n, const double* __restrict__ x,
     const double* __restrict__ y, const double* __restrict__ z, PcvRouted routed, const uint8_t* __restrict__ color,
     uint32_t color_stride, const float* __restrict__ intensity, uint32_t* __restrict__ rank, uint4* __restrict__ payload,
-    uint4* __restrict__ kept, uint32_t* __restrict__ inten_bits, float cells_per_unit /* 65536 / root edge */) {
+    uint4* __restrict__ kept, uint32_t* __restrict__ inten_bits, const uint8_t* __restrict__ depth_grid,
+    float cells_per_unit /* 128 / root edge */) {
   constexpr int kWavesB = BLOCK / 64;
   __shared__ double sx[BIN ? BLOCK : 1], sy[BIN ? BLOCK : 1], sz[BIN ? BLOCK : 1];
   __shared__ uint16_t perm[BIN ? BLOCK : 1];
@@ -112,17 +128,11 @@ __global__ __launch_bounds__(BLOCK) void spec_encode_kernel(
     if (in) {
       const double qx = x[i], qy = y[i], qz = z[i];
       sx[tid] = qx, sy[tid] = qy, sz[tid] = qz;
-      // 16-bit cell coordinates in the root cube (NaN -> 0, out of range clamps): the digits of level k are bit 16 - k
-      const int ix = (int)fminf(fmaxf((float)(qx - lv.root_min[0]) * cells_per_unit, 0.f), 65535.f);
-      const int iy = (int)fminf(fmaxf((float)(qy - lv.root_min[1]) * cells_per_unit, 0.f), 65535.f);
-      const int iz = (int)fminf(fmaxf((float)(qz - lv.root_min[2]) * cells_per_unit, 0.f), 65535.f);
-      uint32_t r = rec;
-      int l = 0;
-      while (!(r & PCV_SPEC_LEAF) && l < 16) {
-        ++l;
-        const uint32_t d = (((uint32_t)ix >> (16 - l)) & 1u) << 2 | (((uint32_t)iy >> (16 - l)) & 1u) << 1 | (((uint32_t)iz >> (16 - l)) & 1u);
-        r = walk[(r & PCV_SPEC_INDEX_MASK) + d];
-      }
+      // cell of the 128^3 grid over the root cube (NaN -> 0, out of range clamps) -> predicted depth (1..8, 8 = deeper)
+      const uint32_t ix = (uint32_t)fminf(fmaxf((float)(qx - lv.root_min[0]) * cells_per_unit, 0.f), 127.f);
+      const uint32_t iy = (uint32_t)fminf(fmaxf((float)(qy - lv.root_min[1]) * cells_per_unit, 0.f), 127.f);
+      const uint32_t iz = (uint32_t)fminf(fmaxf((float)(qz - lv.root_min[2]) * cells_per_unit, 0.f), 127.f);
+      const uint32_t l = depth_grid[ix | (iy << 7) | (iz << 14)];
       key = (uint32_t)(kSpecClasses - 2 - l);  // deepest first
     }
     for (int k = tid; k < kWavesB * kSpecClasses; k += BLOCK) (&wcnt[0][0])[k] = 0;
@@ -451,21 +461,22 @@ template <bool BIN, int BLOCK>
 static void launch_spec_encode_t(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* walk, uint64_t n, const double* x,
                                  const double* y, const double* z, const PcvRouted& routed, const uint8_t* color,
                                  uint32_t color_stride, const float* intensity, uint32_t* rank, void* payload, void* kept,
-                                 uint32_t* inten_bits) {
+                                 uint32_t* inten_bits, uint8_t* depth_grid) {
   const dim3 grid((unsigned)((n + BLOCK - 1) / BLOCK));
-  const float cells = lv.edge[0] > 0.0 ? (float)(65536.0 / lv.edge[0]) : 0.f;
+  const float cells = lv.edge[0] > 0.0 ? (float)(128.0 / lv.edge[0]) : 0.f;
+  if (BIN) hipLaunchKernelGGL(spec_depth_grid_kernel, dim3((1u << (3 * kGridBits)) / 256), dim3(256), 0, ctx->stream, walk, depth_grid);
   if (kept)
     hipLaunchKernelGGL((spec_encode_kernel<true, BIN, BLOCK>), grid, dim3(BLOCK), 0, ctx->stream, lv, walk, n, x, y, z, routed, color,
-                       color_stride, intensity, rank, (uint4*)payload, (uint4*)kept, inten_bits, cells);
+                       color_stride, intensity, rank, (uint4*)payload, (uint4*)kept, inten_bits, depth_grid, cells);
   else
     hipLaunchKernelGGL((spec_encode_kernel<false, BIN, BLOCK>), grid, dim3(BLOCK), 0, ctx->stream, lv, walk, n, x, y, z, routed,
-                       color, color_stride, intensity, rank, (uint4*)payload, (uint4*)nullptr, inten_bits, cells);
+                       color, color_stride, intensity, rank, (uint4*)payload, (uint4*)nullptr, inten_bits, depth_grid, cells);
 }
 
 void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* walk, uint64_t n, const double* x,
                             const double* y, const double* z, const PcvRouted& routed, const uint8_t* color,
                             uint32_t color_stride, const float* intensity, uint32_t* rank, void* payload, void* kept,
-                            uint32_t* inten_bits) {
+                            uint32_t* inten_bits, uint8_t* depth_grid /* pcv_spec_depth_grid_bytes() of scratch, or null */) {
   if (n == 0) return;
   PcvProf prof(ctx, PCV_K_SPEC_ENCODE);
   // PCV_SPEC_BIN (experiments): 0 = input order, 256 / 512 / 1024 = depth binning inside workgroups of that size
@@ -473,16 +484,22 @@ void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* w
     const char* e = getenv("PCV_SPEC_BIN");
     return e ? atoi(e) : 1024;
   }();
-  const bool bin = bin_mode != 0 && !routed.oct;
+  const bool bin = bin_mode != 0 && !routed.oct && depth_grid != nullptr;
   if (!bin)
-    launch_spec_encode_t<false, 256>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, kept, inten_bits);
+    launch_spec_encode_t<false, 256>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, kept, inten_bits,
+                                     depth_grid);
   else if (bin_mode == 256)
-    launch_spec_encode_t<true, 256>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, kept, inten_bits);
+    launch_spec_encode_t<true, 256>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, kept, inten_bits,
+                                     depth_grid);
   else if (bin_mode == 512)
-    launch_spec_encode_t<true, 512>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, kept, inten_bits);
+    launch_spec_encode_t<true, 512>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, kept, inten_bits,
+                                     depth_grid);
   else
-    launch_spec_encode_t<true, 1024>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, kept, inten_bits);
+    launch_spec_encode_t<true, 1024>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, kept, inten_bits,
+                                     depth_grid);
 }
+
+size_t pcv_spec_depth_grid_bytes() { return (size_t)1 << (3 * kGridBits); }
 
 void pcv_launch_rank_hist(pcv_ctx* ctx, const uint32_t* rank, uint64_t n, uint32_t num_bins, uint32_t* counts) {
   if (n == 0 || num_bins == 0) return;

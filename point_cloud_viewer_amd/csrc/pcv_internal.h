@@ -265,7 +265,8 @@ void pcv_launch_leaf_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvWalkTabl
 void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* walk, uint64_t n, const double* x,
                             const double* y, const double* z, const PcvRouted& routed, const uint8_t* color,
                             uint32_t color_stride, const float* intensity, uint32_t* rank, void* payload /* uint4[n] */,
-                            void* kept /* uint4[n] or null */, uint32_t* inten_bits);
+                            void* kept /* uint4[n] or null */, uint32_t* inten_bits, uint8_t* depth_grid);
+size_t pcv_spec_depth_grid_bytes();  // scratch for the depth-prediction grid of the binned pass
 void pcv_launch_rank_hist(pcv_ctx* ctx, const uint32_t* rank, uint64_t n, uint32_t num_bins, uint32_t* counts /* zeroed */);
 void pcv_launch_spec_finalize(pcv_ctx* ctx, uint64_t n, const uint32_t* spec_map, uint32_t* rank, void* payload,
                               const void* kept);
