@@ -780,9 +780,12 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
   if (tt->prefix.size() > (size_t)nt.capacity) return ctx->fail(PCV_E_OOM, "node table capacity exceeded");
   std::memcpy(hp + map_off, tt->spec_map.data(), (size_t)tree.num_leaves * 4);
   PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_area + map_off, hp + map_off, (size_t)tree.num_leaves * 4, hipMemcpyHostToDevice, st));
-  // the first record-sort pass translates the ranks and patches the payloads (no separate pass over the records)
-  bs->spec_map_dev = (const uint32_t*)(d_area + map_off);
-  bs->spec_kept = kept;
+  if (bs->onesweep) {  // the first record-sort pass translates the ranks and patches the payloads
+    bs->spec_map_dev = (const uint32_t*)(d_area + map_off);
+    bs->spec_kept = kept;
+  } else {
+    pcv_launch_spec_finalize(ctx, n, (const uint32_t*)(d_area + map_off), rank, payload, kept);
+  }
   // leaves whose points still have to replay the chain: contiguous once the records are sorted ([lo, hi) of the leaf)
   bs->fix_ranges.clear();
   for (uint32_t k : tt->fix_nodes) bs->fix_ranges.push_back({tt->lo[k], tt->hi[k] - tt->lo[k], (uint32_t)tt->level[k]});
@@ -790,7 +793,10 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
   // the pool hands `kept` out again only to work queued on this same stream
   ctx->stage_end(PCV_STAGE_NODE_SPLIT);
   ctx->stage_begin(PCV_STAGE_TABLE);
-
+  if (kept && !bs->onesweep) {
+    sc.detach(kept);
+    ctx->dev_free(kept);
+  }
   bs->spec = true;
   bs->spec_payload = payload;
   t->spec_stats[0] = tree.prefix.size();
@@ -1390,8 +1396,7 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
                                    &rec_in_a)))
       return rc;
     os_error = (uint32_t*)(os_scratch + pcv_onesweep_scratch_bytes(n) - 1024) + 1;
-  } else if ((rc = pcv_radix_sort_records_mapped(ctx, rank_a, rank_b, n, rank_bits, &pl, sort_scratch, bs->spec_map_dev,
-                                                 bs->spec_kept, &rec_in_a))) {
+  } else if ((rc = pcv_radix_sort_u32(ctx, rank_a, rank_b, n, 0, rank_bits, &pl, sort_scratch, &rec_in_a))) {
     return rc;
   }
   uint32_t* s_rank = rec_in_a ? rank_a : rank_b;

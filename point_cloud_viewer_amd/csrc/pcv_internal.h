@@ -212,9 +212,6 @@ int pcv_radix_sort_u64(pcv_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint64_
 int pcv_radix_sort_u32(pcv_ctx* ctx, uint32_t* keys_a, uint32_t* keys_b, uint64_t n, int begin_bit, int end_bit,
                        PcvSortPayload* payload, void* scratch, bool* result_in_a);
 
-int pcv_radix_sort_records_mapped(pcv_ctx* ctx, uint32_t* keys_a, uint32_t* keys_b, uint64_t n, int key_bits,
-                                  PcvSortPayload* payload, void* scratch, const uint32_t* map, const void* kept,
-                                  bool* result_in_a);
 // Onesweep record sort (decoupled look-back; digit offsets from the caller): see pcv_sort.hip
 size_t pcv_onesweep_scratch_bytes(uint64_t n);
 int pcv_onesweep_records(pcv_ctx* ctx, uint32_t* keys_a, uint32_t* keys_b, uint64_t n, int key_bits, PcvSortPayload* payload,

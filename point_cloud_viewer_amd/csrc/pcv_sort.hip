@@ -72,13 +72,10 @@ __device__ __forceinline__ void count_digit(uint32_t* __restrict__ wh, uint32_t 
   if (valid && below == 0) atomicAdd(&wh[d], (uint32_t)(__popc(plo) + __popc(phi)));
 }
 
-// `map` (u32 keys only, first record pass of the single-chain build): the key is a predicted-leaf rank, the sort key is
-// map[key] & PCV_SPEC_INDEX_MASK_SORT.
 template <typename KeyT>
 __global__ __launch_bounds__(kBlock) void upsweep_kernel(const KeyT* __restrict__ keys, uint64_t n, uint64_t chunk,
                                                           int groups, int shift, uint32_t mask,
-                                                          uint32_t* __restrict__ hist /* [256][groups] */,
-                                                          const uint32_t* __restrict__ map) {
+                                                          uint32_t* __restrict__ hist /* [256][groups] */) {
   __shared__ uint32_t wh[kWaves][kRadix];
   const int wave = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < kWaves * kRadix; i += kBlock) (&wh[0][0])[i] = 0;
@@ -96,12 +93,6 @@ __global__ __launch_bounds__(kBlock) void upsweep_kernel(const KeyT* __restrict_
     VecT v[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const VecT*>(keys + i + u * kStep);
-    if (sizeof(KeyT) == 4 && map) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int k = 0; k < kVec; ++k) v[u][k] = (KeyT)(map[(uint32_t)v[u][k]] & PCV_SPEC_INDEX_MASK_SORT);
-    }
     // the loop condition is not wave-uniform in the last iterations of a chunk: match only the lanes that are here
     const uint64_t here = __builtin_amdgcn_ballot_w64(true);
 #pragma unroll
@@ -111,19 +102,11 @@ __global__ __launch_bounds__(kBlock) void upsweep_kernel(const KeyT* __restrict_
   }
   for (; i + kVec <= end; i += kStep) {
     VecT v = *reinterpret_cast<const VecT*>(keys + i);
-    if (sizeof(KeyT) == 4 && map) {
-#pragma unroll
-      for (int k = 0; k < kVec; ++k) v[k] = (KeyT)(map[(uint32_t)v[k]] & PCV_SPEC_INDEX_MASK_SORT);
-    }
     const uint64_t here = __builtin_amdgcn_ballot_w64(true);
 #pragma unroll
     for (int k = 0; k < kVec; ++k) count_digit(wh[wave], (uint32_t)(v[k] >> shift) & mask, here, true);
   }
-  for (; i < end; ++i) {  // ragged tail (< kVec keys)
-    KeyT k = keys[i];
-    if (sizeof(KeyT) == 4 && map) k = (KeyT)(map[(uint32_t)k] & PCV_SPEC_INDEX_MASK_SORT);
-    atomicAdd(&wh[wave][(uint32_t)(k >> shift) & mask], 1u);
-  }
+  for (; i < end; ++i) atomicAdd(&wh[wave][(uint32_t)(keys[i] >> shift) & mask], 1u);  // ragged tail (< kVec keys)
   __syncthreads();
   for (int d = threadIdx.x; d < kRadix; d += kBlock) {
     uint32_t s = 0;
@@ -362,24 +345,9 @@ struct RecPtrs {
   int nplanes;          // extra u32 planes (0..8)
   const uint32_t* plane_in[8];
   uint32_t* plane_out[8];
-  const uint32_t* map;  // first record pass of the single-chain build: predicted-leaf rank -> PCV_SPEC_MAP_* entry
-  const uint4* kept;    // codes kept at candidate nodes (with map)
 };
 
-// key = map[key]; the payload takes the kept codes (bit 31) or, when the point has no codes yet (bit 30), its own input
-// index for the chain replay after the sort
-__device__ __forceinline__ void map_record(const RecPtrs& rp, uint64_t index, uint32_t& key, uint4& vec) {
-  const uint32_t m = rp.map[key];
-  key = m & PCV_SPEC_INDEX_MASK_SORT;
-  if (m & (1u << 30)) {
-    vec.x = (uint32_t)index;
-  } else if (m & (1u << 31)) {
-    const uint4 k = rp.kept[index];
-    vec.x = k.x, vec.y = k.y, vec.z = k.z;
-  }
-}
-
-template <bool kHasVec, bool kMapped = false>
+template <bool kHasVec>
 __global__ __launch_bounds__(kBlock, kHasVec ? 3 : 4) void downsweep_rec_kernel(const uint32_t* __restrict__ keys_in,
                                                                   uint32_t* __restrict__ keys_out, uint64_t n,
                                                                   uint64_t chunk, int groups, int shift, int nbits,
@@ -408,11 +376,6 @@ __global__ __launch_bounds__(kBlock, kHasVec ? 3 : 4) void downsweep_rec_kernel(
       const bool valid = li < tile_n;
       key[i] = valid ? keys_in[base + li] : 0u;
       if (kHasVec) vec[i] = valid ? rp.vec_in[base + li] : make_uint4(0, 0, 0, 0);
-    }
-    if (kHasVec && kMapped) {
-#pragma unroll
-      for (int i = 0; i < kKpt; ++i)
-        if (wbase + i * 64 < tile_n) map_record(rp, base + wbase + i * 64, key[i], vec[i]);
     }
     uint16_t lpos[kKpt];
     if (tile_n == (uint32_t)kTile)
@@ -486,6 +449,8 @@ struct OneSweepArgs {
   uint32_t* status;             // [tiles][256], zeroed
   uint32_t* tile_counter;       // zeroed
   uint32_t num_tiles;
+  const uint32_t* map;          // MAPPED only
+  const uint4* kept;            // MAPPED only, may be null
   uint32_t* error;              // set when a look-back gave up (never expected)
 };
 
@@ -497,34 +462,20 @@ __device__ __forceinline__ uint32_t os_lookback(uint32_t* __restrict__ status, u
     return global_base;
   }
   uint32_t excl = 0;
-  // a window of predecessors per round trip: with hundreds of tiles in flight the walk back to the nearest inclusive
-  // offset is tens of entries long, and one dependent load per entry would cost more than the tile itself
-  constexpr int kWindow = 8;
-  uint32_t t = tile;
-  bool done = false;
-  while (!done && t > 0) {
-    uint32_t v[kWindow];
-#pragma unroll
-    for (int u = 0; u < kWindow; ++u)
-      v[u] = (uint32_t)u < t ? __hip_atomic_load(status + (size_t)(t - 1 - u) * kRadix + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                             : kOsFlagInc;  // before tile 0: an inclusive offset of zero ends the walk
-#pragma unroll
-    for (int u = 0; u < kWindow; ++u) {
-      if (done) break;
-      uint32_t w = v[u];
-      uint32_t spins = 0;
-      while (!(w >> 30)) {  // not published yet: wait for this one (the later entries of the window stay valid)
-        if (++spins > (1u << 22)) {  // seconds: something is badly wrong; fail loudly instead of hanging the device
-          atomicOr(error, 1u);
-          return 0;
-        }
-        __builtin_amdgcn_s_sleep(2);
-        w = __hip_atomic_load(status + (size_t)(t - 1 - u) * kRadix + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (uint32_t t = tile; t-- > 0;) {
+    const uint32_t* theirs = status + (size_t)t * kRadix + d;
+    uint32_t v = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t spins = 0;
+    while (!(v >> 30)) {
+      if (++spins > (1u << 22)) {  // seconds: something is badly wrong; fail loudly instead of hanging the device
+        atomicOr(error, 1u);
+        return 0;
       }
-      excl += w & kOsValMask;
-      if (w >> 31) done = true;  // an inclusive offset: everything before it is accounted for
+      __builtin_amdgcn_s_sleep(2);
+      v = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    t = t > (uint32_t)kWindow ? t - kWindow : 0;
+    excl += v & kOsValMask;
+    if (v >> 31) break;  // an inclusive offset: everything before it is accounted for
   }
   __hip_atomic_store(mine, kOsFlagInc | (excl + count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return excl;
@@ -559,10 +510,23 @@ __global__ __launch_bounds__(kBlock, kHasVec ? 3 : 4) void onesweep_rec_kernel(O
       key[i] = valid ? a.keys_in[base + li] : 0u;
       if (kHasVec) vec[i] = valid ? rp.vec_in[base + li] : make_uint4(0, 0, 0, 0);
     }
-    if (kHasVec && kMapped) {
+    if (kMapped) {
 #pragma unroll
-      for (int i = 0; i < kKpt; ++i)
-        if (wbase + i * 64 < tile_n) map_record(rp, base + wbase + i * 64, key[i], vec[i]);
+      for (int i = 0; i < kKpt; ++i) {
+        const uint32_t li = wbase + i * 64;
+        if (li < tile_n) {
+          const uint32_t m = a.map[key[i]];
+          key[i] = m & PCV_SPEC_INDEX_MASK_SORT;
+          if (kHasVec) {
+            if (m & (1u << 30)) {
+              vec[i].x = (uint32_t)(base + li);  // replay after the sort: the record carries its input index
+            } else if (m & (1u << 31)) {
+              const uint4 k = a.kept[base + li];
+              vec[i].x = k.x, vec[i].y = k.y, vec[i].z = k.z;
+            }
+          }
+        }
+      }
     }
     uint16_t lpos[kKpt];
     if (tile_n == (uint32_t)kTile)
@@ -651,7 +615,7 @@ size_t pcv_onesweep_scratch_bytes_impl(uint64_t n) {
 
 template <typename KeyT>
 int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int end_bit, PcvSortPayload* payload,
-               void* scratch, bool* result_in_a, const uint32_t* map = nullptr, const void* kept = nullptr) {
+               void* scratch, bool* result_in_a) {
   *result_in_a = true;
   if (n == 0 || end_bit <= begin_bit) return PCV_OK;
   if (n >= 0xffffffffull) return ctx->fail(PCV_E_INVALID, "radix sort: n must be < 2^32 - 1");
@@ -669,7 +633,7 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
     {
       PcvProf prof(ctx, sizeof(KeyT) == 8 ? PCV_K_SORT_UPSWEEP64 : PCV_K_SORT_UPSWEEP32);
       hipLaunchKernelGGL(upsweep_kernel<KeyT>, dim3(g.groups), dim3(kBlock), 0, ctx->stream, src, n, g.chunk,
-                         g.groups, shift, mask, hist, shift == begin_bit ? map : nullptr);
+                         g.groups, shift, mask, hist);
     }
     {
       PcvProf prof(ctx, PCV_K_SORT_SCAN);
@@ -688,13 +652,8 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
         rp.plane_in[w] = in_a ? payload->in[w] : payload->out[w];
         rp.plane_out[w] = in_a ? payload->out[w] : payload->in[w];
       }
-      rp.map = shift == begin_bit ? map : nullptr;
-      rp.kept = shift == begin_bit ? (const uint4*)kept : nullptr;
       PcvProf prof(ctx, PCV_K_SORT_DOWNSWEEP_REC);
-      if (payload->vec_in && rp.map)
-        hipLaunchKernelGGL((downsweep_rec_kernel<true, true>), dim3(g.groups), dim3(kBlock), 0, ctx->stream, (const uint32_t*)src,
-                           (uint32_t*)dst, n, g.chunk, g.groups, shift, nbits, hist, totals, rp);
-      else if (payload->vec_in)
+      if (payload->vec_in)
         hipLaunchKernelGGL(downsweep_rec_kernel<true>, dim3(g.groups), dim3(kBlock), 0, ctx->stream, (const uint32_t*)src,
                            (uint32_t*)dst, n, g.chunk, g.groups, shift, nbits, hist, totals, rp);
       else
@@ -740,6 +699,8 @@ int pcv_onesweep_records(pcv_ctx* ctx, uint32_t* keys_a, uint32_t* keys_b, uint6
     a.status = status;
     a.tile_counter = counter;
     a.num_tiles = tiles;
+    a.map = pass == 0 ? map : nullptr;
+    a.kept = pass == 0 ? (const uint4*)kept : nullptr;
     a.error = counter + 1;
     RecPtrs rp{};
     rp.vec_in = (const uint4*)(in_a ? payload->vec_in : payload->vec_out);
@@ -749,12 +710,10 @@ int pcv_onesweep_records(pcv_ctx* ctx, uint32_t* keys_a, uint32_t* keys_b, uint6
       rp.plane_in[w] = in_a ? payload->in[w] : payload->out[w];
       rp.plane_out[w] = in_a ? payload->out[w] : payload->in[w];
     }
-    rp.map = pass == 0 ? map : nullptr;
-    rp.kept = pass == 0 ? (const uint4*)kept : nullptr;
     // persistent workgroups: as many as fit the device at the kernel's occupancy, each pulls tiles until none is left
     const unsigned groups = tiles < 256u * 3u ? tiles : 256u * 3u;
     PcvProf prof(ctx, PCV_K_SORT_ONESWEEP_REC);
-    if (rp.map)
+    if (a.map)
       hipLaunchKernelGGL((onesweep_rec_kernel<true, true>), dim3(groups), dim3(kBlock), 0, ctx->stream, a, rp);
     else
       hipLaunchKernelGGL((onesweep_rec_kernel<true, false>), dim3(groups), dim3(kBlock), 0, ctx->stream, a, rp);
@@ -774,11 +733,4 @@ int pcv_radix_sort_u64(pcv_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint64_
 int pcv_radix_sort_u32(pcv_ctx* ctx, uint32_t* keys_a, uint32_t* keys_b, uint64_t n, int begin_bit, int end_bit,
                        PcvSortPayload* payload, void* scratch, bool* result_in_a) {
   return radix_sort<uint32_t>(ctx, keys_a, keys_b, n, begin_bit, end_bit, payload, scratch, result_in_a);
-}
-// Record sort whose FIRST pass translates the keys through `map` (and patches the payload from `kept`): the
-// single-chain build's predicted-leaf ranks become true-leaf ranks without a separate pass over the records.
-int pcv_radix_sort_records_mapped(pcv_ctx* ctx, uint32_t* keys_a, uint32_t* keys_b, uint64_t n, int key_bits,
-                                  PcvSortPayload* payload, void* scratch, const uint32_t* map, const void* kept,
-                                  bool* result_in_a) {
-  return radix_sort<uint32_t>(ctx, keys_a, keys_b, n, 0, key_bits, payload, scratch, result_in_a, map, kept);
 }
