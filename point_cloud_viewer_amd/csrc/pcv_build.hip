@@ -141,7 +141,7 @@ static const char* kKernelNames[PCV_K_COUNT] = {
     "upsweep_kernel<u32>", "downsweep_kernel<u32>", "promote_settle_kernel", "downsweep_rec_kernel", "cull_nodes_kernel",
     "visible_nodes_kernel", "nodes_in_location_kernel", "cull_points_kernel", "transform_points_kernel",
     "query_compact_kernel", "route_bucket_kernel", "partition_count_kernel", "partition_scatter_kernel",
-    "promote_climb_kernel", "spec_encode_kernel", "rank_hist_kernel", "spec_finalize_kernel", "spec_replay_kernel", "onesweep_rec_kernel"};
+    "promote_climb_kernel", "spec_encode_kernel", "rank_hist_kernel", "spec_finalize_kernel", "spec_replay_kernel"};
 static_assert(sizeof(kKernelNames) / sizeof(kKernelNames[0]) == PCV_K_COUNT, "kernel name table out of sync");
 
 extern "C" int pcv_ctx_set_profiling(pcv_ctx* ctx, int enabled) {
@@ -462,11 +462,6 @@ struct PcvBuild {
     uint32_t lo, count, level;
   };
   std::vector<FixRange> fix_ranges;  // sorted slots whose points replay the chain after the record sort
-  // onesweep record sort (digit offsets from the leaf sizes, no histogram passes): with the single-chain build its first
-  // pass also applies the predicted-leaf -> true-leaf map (no separate finalize pass over the records)
-  bool onesweep = false;
-  const uint32_t* spec_map_dev = nullptr;
-  const void* spec_kept = nullptr;
   explicit PcvBuild(pcv_ctx* c) : ctx(c), sc(c) {}
 };
 
@@ -780,12 +775,7 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
   if (tt->prefix.size() > (size_t)nt.capacity) return ctx->fail(PCV_E_OOM, "node table capacity exceeded");
   std::memcpy(hp + map_off, tt->spec_map.data(), (size_t)tree.num_leaves * 4);
   PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_area + map_off, hp + map_off, (size_t)tree.num_leaves * 4, hipMemcpyHostToDevice, st));
-  if (bs->onesweep) {  // the first record-sort pass translates the ranks and patches the payloads
-    bs->spec_map_dev = (const uint32_t*)(d_area + map_off);
-    bs->spec_kept = kept;
-  } else {
-    pcv_launch_spec_finalize(ctx, n, (const uint32_t*)(d_area + map_off), rank, payload, kept);
-  }
+  pcv_launch_spec_finalize(ctx, n, (const uint32_t*)(d_area + map_off), rank, payload, kept);
   // leaves whose points still have to replay the chain: contiguous once the records are sorted ([lo, hi) of the leaf)
   bs->fix_ranges.clear();
   for (uint32_t k : tt->fix_nodes) bs->fix_ranges.push_back({tt->lo[k], tt->hi[k] - tt->lo[k], (uint32_t)tt->level[k]});
@@ -793,7 +783,7 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
   // the pool hands `kept` out again only to work queued on this same stream
   ctx->stage_end(PCV_STAGE_NODE_SPLIT);
   ctx->stage_begin(PCV_STAGE_TABLE);
-  if (kept && !bs->onesweep) {
+  if (kept) {
     sc.detach(kept);
     ctx->dev_free(kept);
   }
@@ -823,13 +813,6 @@ static int build_begin_impl(pcv_ctx* ctx, const pcv_build_params* params, const 
   PcvScratch& sc = bs->sc;
   DevPoints& d = bs->d;
   bs->n = n;
-  {
-    static const bool os_enabled = [] {
-      const char* e = getenv("PCV_ONESWEEP");
-      return !e || atoi(e) != 0;
-    }();
-    bs->onesweep = os_enabled && n < (1ull << 30);
-  }
   t->resolution = params->resolution;
   t->has_intensity = (routed ? routed->intensity : points->intensity) != nullptr;
   struct Guard {
@@ -1058,7 +1041,7 @@ static int build_begin_impl(pcv_ctx* ctx, const pcv_build_params* params, const 
   const size_t lo_off = (((size_t)M * (8 + 4 * 4 + 3) + 64) + 7) & ~(size_t)7;  // deep trees: second prefix word
   const size_t host_bytes = lo_off + (bs->deep ? (size_t)M * 8 : 0);
   bs->host_bytes = host_bytes;
-  if ((rc = ctx->pinned_reserve(host_bytes * 4 + (size_t)M * 72 + (size_t)M * 2 * sizeof(PcvNodeRec) + 8192))) return rc;
+  if ((rc = ctx->pinned_reserve(host_bytes * 4 + (size_t)M * 72 + (size_t)M * 2 * sizeof(PcvNodeRec) + 1024))) return rc;
   uint8_t* hp = (uint8_t*)ctx->pinned;
   uint64_t* h_prefix = (uint64_t*)hp;
   uint32_t* h_lo = (uint32_t*)(h_prefix + M);
@@ -1318,35 +1301,13 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
     u_climb_base[r] = (uint32_t)num_climbers;
     if (u_leaf_rec[r].parent != 0xffffffffu) num_climbers += ceil8((uint64_t)h_hi[leaves[r]] - h_lo[leaves[r]]);
   }
-  // onesweep record sort: first output position of every digit of every 8-bit pass over the leaf rank, from the leaf
-  // sizes (records of leaf r = its points; the sort is by r)
-  int rank_bits = 1;
-  while ((1ull << rank_bits) < num_leaves) ++rank_bits;
-  const int os_passes = (rank_bits + 7) / 8;
-  uint32_t* u_os_base = u_climb_base + num_leaves;
-  if (bs->onesweep) {
-    std::memset(u_os_base, 0, (size_t)os_passes * 256 * 4);
-    for (uint32_t r = 0; r < num_leaves; ++r) {
-      const uint32_t c = h_hi[leaves[r]] - h_lo[leaves[r]];
-      for (int p = 0; p < os_passes; ++p) u_os_base[p * 256 + ((r >> (8 * p)) & 255u)] += c;
-    }
-    for (int p = 0; p < os_passes; ++p) {
-      uint32_t run = 0;
-      for (int dgt = 0; dgt < 256; ++dgt) {
-        const uint32_t c = u_os_base[p * 256 + dgt];
-        u_os_base[p * 256 + dgt] = run;
-        run += c;
-      }
-    }
-  }
   const size_t walk_bytes = ((size_t)M * 8 + 255) & ~(size_t)255;
-  const size_t rec_bytes = (size_t)(M + num_leaves) * sizeof(PcvNodeRec) + (size_t)num_leaves * 4 + (size_t)os_passes * 1024;
+  const size_t rec_bytes = (size_t)(M + num_leaves) * sizeof(PcvNodeRec) + (size_t)num_leaves * 4;
   uint8_t* d_up;
   if ((rc = sc.get(&d_up, walk_bytes + rec_bytes + 256))) return rc;
   if (!bs->spec) PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_up, u_walk, (size_t)M * 8, hipMemcpyHostToDevice, st));  // K5 only
   PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_up + walk_bytes, u_node_rec, rec_bytes, hipMemcpyHostToDevice, st));
   const uint32_t* d_climb_base = (const uint32_t*)(d_up + walk_bytes + (size_t)(M + num_leaves) * sizeof(PcvNodeRec));
-  const uint32_t* d_os_base = d_climb_base + num_leaves;
   PcvWalkTables wt;
   wt.walk = (const uint64_t*)d_up;
   wt.num_nodes = M;
@@ -1387,18 +1348,10 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
   ctx->stage_begin(PCV_STAGE_SORT_RECORDS);
 
   // ---- K3 stable record sort by leaf rank ----
+  int rank_bits = 1;
+  while ((1ull << rank_bits) < num_leaves) ++rank_bits;
   bool rec_in_a = true;
-  uint32_t* os_error = nullptr;
-  if (bs->onesweep) {
-    uint8_t* os_scratch;
-    if ((rc = sc.get(&os_scratch, pcv_onesweep_scratch_bytes(n)))) return rc;
-    if ((rc = pcv_onesweep_records(ctx, rank_a, rank_b, n, rank_bits, &pl, d_os_base, os_scratch, bs->spec_map_dev, bs->spec_kept,
-                                   &rec_in_a)))
-      return rc;
-    os_error = (uint32_t*)(os_scratch + pcv_onesweep_scratch_bytes(n) - 1024) + 1;
-  } else if ((rc = pcv_radix_sort_u32(ctx, rank_a, rank_b, n, 0, rank_bits, &pl, sort_scratch, &rec_in_a))) {
-    return rc;
-  }
+  if ((rc = pcv_radix_sort_u32(ctx, rank_a, rank_b, n, 0, rank_bits, &pl, sort_scratch, &rec_in_a))) return rc;
   uint32_t* s_rank = rec_in_a ? rank_a : rank_b;
   const void* s_pay = rec_in_a ? (const void*)pay_a : (const void*)pay_b;
   uint32_t** s_plane = rec_in_a ? pl.in : pl.out;
@@ -1459,10 +1412,7 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
   ctx->stage_end(PCV_STAGE_PROMOTE_ENCODE);
   PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[8], st));
   PCV_HIP_CHECK(ctx, hipGetLastError());
-  if (os_error) PCV_HIP_CHECK(ctx, hipMemcpyAsync(ctx->mailbox, os_error, 4, hipMemcpyDeviceToHost, st));
   PCV_HIP_CHECK(ctx, hipStreamSynchronize(st));
-  if (os_error && *(const uint32_t*)ctx->mailbox)
-    return ctx->fail(PCV_E_HIP, "record sort: a tile gave up waiting for its predecessors (decoupled look-back)");
   ctx->prof_resolve();
   for (int sidx = 0; sidx < PCV_STAGE_TOTAL; ++sidx) {
     t->stage_ms[sidx] = 0.f;

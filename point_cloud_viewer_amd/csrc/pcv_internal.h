@@ -68,7 +68,6 @@ enum PcvKernelId {
   PCV_K_RANK_HIST,
   PCV_K_SPEC_FINALIZE,
   PCV_K_SPEC_REPLAY,
-  PCV_K_SORT_ONESWEEP_REC,
   PCV_K_COUNT
 };
 
@@ -211,12 +210,6 @@ int pcv_radix_sort_u64(pcv_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint64_
                        PcvSortPayload* payload, void* scratch, bool* result_in_a);
 int pcv_radix_sort_u32(pcv_ctx* ctx, uint32_t* keys_a, uint32_t* keys_b, uint64_t n, int begin_bit, int end_bit,
                        PcvSortPayload* payload, void* scratch, bool* result_in_a);
-
-// Onesweep record sort (decoupled look-back; digit offsets from the caller): see pcv_sort.hip
-size_t pcv_onesweep_scratch_bytes(uint64_t n);
-int pcv_onesweep_records(pcv_ctx* ctx, uint32_t* keys_a, uint32_t* keys_b, uint64_t n, int key_bits, PcvSortPayload* payload,
-                         const uint32_t* global_base /* device, [passes][256] */, void* scratch, const uint32_t* map,
-                         const void* kept, bool* result_in_a);
 
 // pcv_topology.hip — node split (topology from sorted keys).
 // Device node table, structure of arrays, BFS order (level-major, prefix-sorted inside a level).

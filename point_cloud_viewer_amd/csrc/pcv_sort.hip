@@ -15,8 +15,6 @@
 // HBM traffic per pass and key: sizeof(key) (upsweep) + 2 * sizeof(key) + 2 * payload bytes.
 #include "pcv_internal.h"
 
-#define PCV_SPEC_INDEX_MASK_SORT 0x3fffffffu  // == PCV_SPEC_INDEX_MASK (pcv_spec.h)
-
 namespace {
 
 constexpr int kBlock = 256;  // 4 waves
@@ -429,190 +427,6 @@ __global__ __launch_bounds__(kBlock, kHasVec ? 3 : 4) void downsweep_rec_kernel(
   }
 }
 
-// ---- onesweep record pass: one read, one write, no histogram pre-pass ---------------------------------------------------
-// Used where the digit totals are known before the sort starts — the leaf sizes come out of the topology, so the host
-// computes every pass's global digit offsets (`global_base`) and the sort needs neither the upsweep (a full re-read of
-// the keys) nor the scan. Tiles are handed out by an atomic counter; a tile publishes its digit counts, stages its
-// records through LDS and then looks back over its predecessors' published counts / inclusive offsets (decoupled
-// look-back, one lane per digit). A tile only ever waits for tiles with a smaller id, which were handed out earlier and
-// are therefore resident: the chain ends at tile 0, which never waits.
-// MAPPED (first pass of the single-chain build): the incoming key is a predicted-leaf rank; the true-leaf rank is
-// map[key] (PCV_SPEC_MAP_*: bit 31 = the payload takes the codes kept at the candidate node, bit 30 = no codes yet, the
-// record carries its input index for the replay after the sort).
-constexpr uint32_t kOsFlagAgg = 1u << 30, kOsFlagInc = 2u << 30, kOsValMask = (1u << 30) - 1u;
-struct OneSweepArgs {
-  const uint32_t* keys_in;
-  uint32_t* keys_out;
-  uint64_t n;
-  int shift, nbits;
-  const uint32_t* global_base;  // [256] first output position of every digit
-  uint32_t* status;             // [tiles][256], zeroed
-  uint32_t* tile_counter;       // zeroed
-  uint32_t num_tiles;
-  const uint32_t* map;          // MAPPED only
-  const uint4* kept;            // MAPPED only, may be null
-  uint32_t* error;              // set when a look-back gave up (never expected)
-};
-
-__device__ __forceinline__ uint32_t os_lookback(uint32_t* __restrict__ status, uint32_t tile, int d, uint32_t count,
-                                                uint32_t global_base, uint32_t* __restrict__ error) {
-  uint32_t* mine = status + (size_t)tile * kRadix + d;
-  if (tile == 0) {
-    __hip_atomic_store(mine, kOsFlagInc | (global_base + count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return global_base;
-  }
-  uint32_t excl = 0;
-  for (uint32_t t = tile; t-- > 0;) {
-    const uint32_t* theirs = status + (size_t)t * kRadix + d;
-    uint32_t v = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint32_t spins = 0;
-    while (!(v >> 30)) {
-      if (++spins > (1u << 22)) {  // seconds: something is badly wrong; fail loudly instead of hanging the device
-        atomicOr(error, 1u);
-        return 0;
-      }
-      __builtin_amdgcn_s_sleep(2);
-      v = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    excl += v & kOsValMask;
-    if (v >> 31) break;  // an inclusive offset: everything before it is accounted for
-  }
-  __hip_atomic_store(mine, kOsFlagInc | (excl + count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return excl;
-}
-
-template <bool kHasVec, bool kMapped>
-__global__ __launch_bounds__(kBlock, kHasVec ? 3 : 4) void onesweep_rec_kernel(OneSweepArgs a, RecPtrs rp) {
-  constexpr int kKpt = kKptRec, kTile = kBlock * kKpt;
-  __shared__ uint32_t skeys[kTile];
-  __shared__ uint4 svec[kHasVec ? kTile : 1];
-  __shared__ DigitState S;
-  __shared__ uint32_t s_tile;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const uint32_t mask = (1u << a.nbits) - 1u;
-  const uint32_t wbase = wave * 64 * kKpt + lane;
-  const uint32_t my_base = a.global_base[t];  // kBlock == kRadix
-  for (;;) {
-    if (t == 0) s_tile = atomicAdd(a.tile_counter, 1u);
-#pragma unroll
-    for (int w = 0; w < kWaves; ++w) S.whist[w][t] = 0;
-    __syncthreads();
-    const uint32_t tile = s_tile;
-    if (tile >= a.num_tiles) return;
-    const uint64_t base = (uint64_t)tile * kTile;
-    const uint32_t tile_n = (uint32_t)((a.n - base) < (uint64_t)kTile ? (a.n - base) : (uint64_t)kTile);
-    uint32_t key[kKpt];
-    uint4 vec[kHasVec ? kKpt : 1];
-#pragma unroll
-    for (int i = 0; i < kKpt; ++i) {
-      const uint32_t li = wbase + i * 64;
-      const bool valid = li < tile_n;
-      key[i] = valid ? a.keys_in[base + li] : 0u;
-      if (kHasVec) vec[i] = valid ? rp.vec_in[base + li] : make_uint4(0, 0, 0, 0);
-    }
-    if (kMapped) {
-#pragma unroll
-      for (int i = 0; i < kKpt; ++i) {
-        const uint32_t li = wbase + i * 64;
-        if (li < tile_n) {
-          const uint32_t m = a.map[key[i]];
-          key[i] = m & PCV_SPEC_INDEX_MASK_SORT;
-          if (kHasVec) {
-            if (m & (1u << 30)) {
-              vec[i].x = (uint32_t)(base + li);  // replay after the sort: the record carries its input index
-            } else if (m & (1u << 31)) {
-              const uint4 k = a.kept[base + li];
-              vec[i].x = k.x, vec[i].y = k.y, vec[i].z = k.z;
-            }
-          }
-        }
-      }
-    }
-    uint16_t lpos[kKpt];
-    if (tile_n == (uint32_t)kTile)
-      wave_rank_all<kKpt, uint32_t, true>(S, wave, wbase, tile_n, key, a.shift, mask, lpos);
-    else
-      wave_rank_all<kKpt, uint32_t, false>(S, wave, wbase, tile_n, key, a.shift, mask, lpos);
-    __syncthreads();
-    // digit t: count in the tile, start inside the tile, per-wave starts (as digit_scan, without the global part)
-    uint32_t pre[kWaves];
-    uint32_t acc = 0;
-#pragma unroll
-    for (int w = 0; w < kWaves; ++w) {
-      pre[w] = acc;
-      acc += S.whist[w][t];
-    }
-    // publish this tile's count of digit t right away: successors can already add it up
-    if (tile != 0)
-      __hip_atomic_store(a.status + (size_t)tile * kRadix + t, kOsFlagAgg | acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint32_t inc = acc;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      uint32_t v = __shfl_up(inc, o, 64);
-      if (lane >= o) inc += v;
-    }
-    if (lane == 63) S.wave_tot[wave] = inc;
-    __syncthreads();
-    uint32_t woff = 0;
-#pragma unroll
-    for (int w = 0; w < kWaves; ++w) woff += (w < wave) ? S.wave_tot[w] : 0u;
-    const uint32_t start = woff + inc - acc;
-#pragma unroll
-    for (int w = 0; w < kWaves; ++w) S.whist[w][t] = start + pre[w];
-    __syncthreads();
-    // stage the tile in digit order
-#pragma unroll
-    for (int i = 0; i < kKpt; ++i) {
-      if (wbase + i * 64 < tile_n) {
-        const uint32_t d = (key[i] >> a.shift) & mask;
-        const uint32_t p = S.whist[wave][d] + lpos[i];
-        lpos[i] = (uint16_t)p;
-        skeys[p] = key[i];
-        if (kHasVec) svec[p] = vec[i];
-      }
-    }
-    // global position of this tile's run of digit t (the predecessors had the whole staging phase to publish)
-    const uint32_t excl = os_lookback(a.status, tile, t, acc, my_base, a.error);
-    S.delta[t] = excl - start;
-    __syncthreads();
-    uint32_t gidx[kKpt];
-#pragma unroll
-    for (int j = 0; j < kKpt; ++j) {
-      const uint32_t p = j * kBlock + t;
-      if (p < tile_n) {
-        const uint32_t k = skeys[p];
-        const uint32_t d = (k >> a.shift) & mask;
-        const uint32_t g = S.delta[d] + p;
-        gidx[j] = g;
-        a.keys_out[g] = k;
-        if (kHasVec) rp.vec_out[g] = svec[p];
-      }
-    }
-    for (int w = 0; w < rp.nplanes; ++w) {  // rare: intensity / Float64 high words
-      const uint32_t* __restrict__ src = rp.plane_in[w];
-      uint32_t* __restrict__ dst = rp.plane_out[w];
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < kKpt; ++i) {
-        const uint32_t li = wbase + i * 64;
-        if (li < tile_n) skeys[lpos[i]] = src[base + li];
-      }
-      __syncthreads();
-#pragma unroll
-      for (int j = 0; j < kKpt; ++j) {
-        const uint32_t p = j * kBlock + t;
-        if (p < tile_n) dst[gidx[j]] = skeys[p];
-      }
-    }
-    __syncthreads();  // skeys / svec / S are reused by the next tile
-  }
-}
-
-size_t pcv_onesweep_scratch_bytes_impl(uint64_t n) {
-  const uint64_t tiles = (n + (uint64_t)kBlock * kKptRec - 1) / ((uint64_t)kBlock * kKptRec);
-  return (size_t)tiles * kRadix * sizeof(uint32_t) + 1024;
-}
-
 template <typename KeyT>
 int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int end_bit, PcvSortPayload* payload,
                void* scratch, bool* result_in_a) {
@@ -668,61 +482,6 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
 }
 
 }  // namespace
-
-size_t pcv_onesweep_scratch_bytes(uint64_t n) { return pcv_onesweep_scratch_bytes_impl(n); }
-
-// Stable LSD sort of (u32 key, 16-byte payload[, planes]) records on key bits [0, key_bits) in 8-bit passes, digit
-// offsets given by the caller: global_base[p * 256 + d] = first output position of digit d in pass p (device memory).
-// map/kept (nullable): first-pass key translation of the single-chain build (see onesweep_rec_kernel).
-int pcv_onesweep_records(pcv_ctx* ctx, uint32_t* keys_a, uint32_t* keys_b, uint64_t n, int key_bits, PcvSortPayload* payload,
-                         const uint32_t* global_base, void* scratch, const uint32_t* map, const void* kept, bool* result_in_a) {
-  *result_in_a = true;
-  if (n == 0 || key_bits <= 0) return PCV_OK;
-  if (n >= (1ull << 30)) return ctx->fail(PCV_E_INVALID, "onesweep record sort: n must be < 2^30");
-  if (!payload || !payload->vec_in) return ctx->fail(PCV_E_INVALID, "onesweep record sort needs the 16-byte payload");
-  constexpr uint64_t kTile = (uint64_t)kBlock * kKptRec;
-  const uint32_t tiles = (uint32_t)((n + kTile - 1) / kTile);
-  uint32_t* status = (uint32_t*)scratch;
-  uint32_t* counter = status + (size_t)tiles * kRadix;  // [0] tile counter, [1] error flag
-  bool in_a = true;
-  int pass = 0;
-  PCV_HIP_CHECK(ctx, hipMemsetAsync(counter + 1, 0, sizeof(uint32_t), ctx->stream));  // the error flag survives the passes
-  for (int shift = 0; shift < key_bits; shift += 8, ++pass) {
-    PCV_HIP_CHECK(ctx, hipMemsetAsync(status, 0, ((size_t)tiles * kRadix + 1) * sizeof(uint32_t), ctx->stream));
-    OneSweepArgs a{};
-    a.keys_in = in_a ? keys_a : keys_b;
-    a.keys_out = in_a ? keys_b : keys_a;
-    a.n = n;
-    a.shift = shift;
-    a.nbits = key_bits - shift < 8 ? key_bits - shift : 8;
-    a.global_base = global_base + (size_t)pass * kRadix;
-    a.status = status;
-    a.tile_counter = counter;
-    a.num_tiles = tiles;
-    a.map = pass == 0 ? map : nullptr;
-    a.kept = pass == 0 ? (const uint4*)kept : nullptr;
-    a.error = counter + 1;
-    RecPtrs rp{};
-    rp.vec_in = (const uint4*)(in_a ? payload->vec_in : payload->vec_out);
-    rp.vec_out = (uint4*)(in_a ? payload->vec_out : payload->vec_in);
-    rp.nplanes = payload->nwords;
-    for (int w = 0; w < payload->nwords; ++w) {
-      rp.plane_in[w] = in_a ? payload->in[w] : payload->out[w];
-      rp.plane_out[w] = in_a ? payload->out[w] : payload->in[w];
-    }
-    // persistent workgroups: as many as fit the device at the kernel's occupancy, each pulls tiles until none is left
-    const unsigned groups = tiles < 256u * 3u ? tiles : 256u * 3u;
-    PcvProf prof(ctx, PCV_K_SORT_ONESWEEP_REC);
-    if (a.map)
-      hipLaunchKernelGGL((onesweep_rec_kernel<true, true>), dim3(groups), dim3(kBlock), 0, ctx->stream, a, rp);
-    else
-      hipLaunchKernelGGL((onesweep_rec_kernel<true, false>), dim3(groups), dim3(kBlock), 0, ctx->stream, a, rp);
-    in_a = !in_a;
-  }
-  PCV_HIP_CHECK(ctx, hipGetLastError());
-  *result_in_a = in_a;
-  return PCV_OK;
-}
 
 size_t pcv_sort_scratch_bytes(uint64_t n) { return ((size_t)kRadix * kMaxGroups + kRadix) * sizeof(uint32_t); }
 
