@@ -482,7 +482,7 @@ void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* w
   // PCV_SPEC_BIN (experiments): 0 = input order, 256 / 512 / 1024 = depth binning inside workgroups of that size
   static const int bin_mode = [] {
     const char* e = getenv("PCV_SPEC_BIN");
-    return e ? atoi(e) : 1024;
+    return e ? atoi(e) : 512;
   }();
   const bool bin = bin_mode != 0 && !routed.oct && depth_grid != nullptr;
   if (!bin)

@@ -199,7 +199,8 @@ __device__ __forceinline__ void init_digit_base(DigitState& S, const uint32_t* _
 // one compare (the ballot), one three-input bit op per half (p & ~(ballot ^ m)), mbcnt for the lanes below.
 template <int kKpt, typename KeyT, bool kFull>
 __device__ __forceinline__ void wave_rank_all(DigitState& S, int wave, uint32_t wbase, uint32_t tile_n,
-                                              const KeyT (&key)[kKpt], int shift, uint32_t mask, uint16_t (&lpos)[kKpt]) {
+                                              const KeyT (&key)[kKpt], int shift, uint32_t mask, uint16_t (&lpos)[kKpt],
+                                              int nbits = 8) {
   constexpr int kBatch = 8;  // adds in flight; more costs registers the 16-keys-per-lane kernel does not have
   static_assert(kKpt % kBatch == 0, "keys per lane must be a multiple of the batch");
 #pragma unroll
@@ -218,6 +219,7 @@ __device__ __forceinline__ void wave_rank_all(DigitState& S, int wave, uint32_t 
       }
 #pragma unroll
       for (int b = 0; b < 8; ++b) {
+        if (b >= 5 && b >= nbits) break;  // narrow digits (wave-uniform): the upper bits are zero in every lane
         int m;  // all ones when bit b of the digit is set (asm: keep the optimiser from re-deriving it the long way)
         asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(d), "n"(b));
         const uint64_t bal = __builtin_amdgcn_ballot_w64(m != 0);
@@ -377,9 +379,9 @@ __global__ __launch_bounds__(kBlock, kHasVec ? 3 : 4) void downsweep_rec_kernel(
     }
     uint16_t lpos[kKpt];
     if (tile_n == (uint32_t)kTile)
-      wave_rank_all<kKpt, uint32_t, true>(S, wave, wbase, tile_n, key, shift, mask, lpos);
+      wave_rank_all<kKpt, uint32_t, true>(S, wave, wbase, tile_n, key, shift, mask, lpos, nbits);
     else
-      wave_rank_all<kKpt, uint32_t, false>(S, wave, wbase, tile_n, key, shift, mask, lpos);
+      wave_rank_all<kKpt, uint32_t, false>(S, wave, wbase, tile_n, key, shift, mask, lpos, nbits);
     digit_scan(S, t, lane, wave);
 #pragma unroll
     for (int i = 0; i < kKpt; ++i) {
@@ -439,8 +441,14 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
   uint32_t* hist = (uint32_t*)scratch;
   uint32_t* totals = hist + (size_t)kRadix * kMaxGroups;
   bool in_a = true;
-  for (int shift = begin_bit; shift < end_bit; shift += 8) {
-    int nbits = end_bit - shift < 8 ? end_bit - shift : 8;
+  // Records: as few passes as 8-bit digits allow, but of EQUAL width (13 bits -> 7 + 6, not 8 + 5): the run a digit gets
+  // inside a tile is tile / 2^width records, and the 4-byte key runs of an 8-bit pass (8 keys = 32 bytes) are partial
+  // sectors. Keys-only sorts keep full 8-bit digits (fewest passes is what counts there).
+  const int total_bits = end_bit - begin_bit;
+  const int passes = (total_bits + 7) / 8;
+  const int width = records ? (total_bits + passes - 1) / passes : 8;
+  for (int shift = begin_bit; shift < end_bit; shift += width) {
+    int nbits = end_bit - shift < width ? end_bit - shift : width;
     uint32_t mask = (1u << nbits) - 1u;
     KeyT* src = in_a ? a : b;
     KeyT* dst = in_a ? b : a;
