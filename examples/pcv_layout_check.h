@@ -39,5 +39,9 @@ PCV_SA(sizeof(pcv_routed_points) == 48 && offsetof(pcv_routed_points, oct_rgb) =
        "pcv_routed_points");
 PCV_SA(sizeof(pcv_route_state) == 32, "pcv_route_state");
 PCV_SA(sizeof(pcv_plane) == 16 && offsetof(pcv_plane, elem_bytes) == 8, "pcv_plane");
+PCV_SA(sizeof(pcv_split_node) == 56 && offsetof(pcv_split_node, first) == 16 && offsetof(pcv_split_node, level) == 32 &&
+           offsetof(pcv_split_node, is_leaf) == 48,
+       "pcv_split_node");
+PCV_SA(sizeof(pcv_promote_node) == 24 && offsetof(pcv_promote_node, child_offset) == 16, "pcv_promote_node");
 
 #endif

@@ -266,6 +266,46 @@ int pcv_partition_by_owner(pcv_ctx* ctx, uint64_t n, const uint32_t* owner, uint
                            const uint8_t* rank_of_bucket /* nullable host array of 64 */, uint32_t nplanes,
                            const pcv_plane* planes, void* const* dst /* [world][nplanes] */);
 
+/* K4: the octree topology from SORTED path keys (split / should_split_node / split_node, generation.rs:58-193): a child
+ * exists iff a key carries its prefix, a child is split iff count > max_points_per_node && child edge > resolution,
+ * the root is always split. keys: pcv_chain_keys layout, ascending, full depth of params' level table (<= 21 levels).
+ * nodes come back breadth first (level-major, prefix order inside a level), the children of a node consecutive in digit
+ * order. *num_nodes may exceed `capacity`: only the first `capacity` are written. PCV_E_DEPTH: a node at the last key
+ * level would still have to be split. */
+typedef struct pcv_split_node {
+  uint64_t id_high, id_low; /* NodeId halves (node.rs:101-111) */
+  uint64_t first, count;    /* the subtree's points: a contiguous range of the key-sorted order */
+  uint32_t level;
+  uint32_t parent;          /* index in this table, 0xffffffff for the root */
+  uint32_t first_child;     /* index of the first child (inner nodes) */
+  uint32_t child_mask;      /* bit c: child c exists */
+  uint32_t is_leaf;
+  uint32_t reserved;
+} pcv_split_node;
+int pcv_node_split(pcv_ctx* ctx, const pcv_build_params* params, const uint64_t* sorted_keys, uint64_t n, int mem,
+                   pcv_split_node* nodes, uint64_t capacity, uint64_t* num_nodes);
+
+/* K5 (table part): the closed form of subsample_children_into (generation.rs:195-253, 335-387) on a node
+ * table: stream_len = |pre(node)| (leaves: their points; inner: sum over children of ceil(|pre(child)| / 8)),
+ * num_points = what the node keeps (root: everything it receives; others: |pre| - ceil(|pre| / 8)), child_offset =
+ * where the node's promoted block starts inside its parent's stream. With node_of_slot / slot_in_node (nullable, n
+ * entries): the final home of the record at every position of the leaf-sorted order — it climbs while its position j in
+ * the current stream is a multiple of 8 (j' = child_offset + j / 8), otherwise it settles at slot j - j / 8 - 1
+ * (the root keeps slot j). Host only. */
+typedef struct pcv_promote_node {
+  uint64_t stream_len;
+  uint64_t num_points;
+  uint64_t child_offset;
+} pcv_promote_node;
+int pcv_promote_assign(const pcv_split_node* nodes, uint64_t num_nodes, pcv_promote_node* per_node, uint64_t n,
+                       uint32_t* node_of_slot, uint32_t* slot_in_node);
+
+/* K5 + K6: leaf encode, stable grouping by leaf, promotion and final encode for a GIVEN topology (a node table as
+ * pcv_node_split returns it, built for the same points / params): the finished octree, as pcv_build_octree returns it.
+ * With pcv_chain_keys + pcv_sort_keys64 + pcv_node_split this is the whole build, stage by stage. */
+int pcv_gather_encode(pcv_ctx* ctx, const pcv_build_params* params, const pcv_points* points, const pcv_split_node* nodes,
+                      uint64_t num_nodes, pcv_octree** out);
+
 /* K3: stable LSD radix sort of 64-bit keys on bits [begin_bit, end_bit), in place. */
 int pcv_sort_keys64(pcv_ctx* ctx, uint64_t* keys, uint64_t n, int begin_bit, int end_bit, int mem);
 /* K3: the 32-bit key variant the build uses when ten levels of path digits suffice. */

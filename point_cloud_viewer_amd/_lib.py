@@ -71,6 +71,16 @@ class TopLayout(C.Structure):
                 ("l2_offset", C.c_uint32 * 64)]
 
 
+class SplitNode(C.Structure):
+    _fields_ = [("id_high", C.c_uint64), ("id_low", C.c_uint64), ("first", C.c_uint64), ("count", C.c_uint64),
+                ("level", C.c_uint32), ("parent", C.c_uint32), ("first_child", C.c_uint32), ("child_mask", C.c_uint32),
+                ("is_leaf", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class PromoteNode(C.Structure):
+    _fields_ = [("stream_len", C.c_uint64), ("num_points", C.c_uint64), ("child_offset", C.c_uint64)]
+
+
 class NodeInfo(C.Structure):
     _fields_ = [("id_high", C.c_uint64), ("id_low", C.c_uint64), ("num_points", C.c_int64), ("level", C.c_uint32),
                 ("encoding", C.c_uint32), ("cube_min", C.c_double * 3), ("cube_edge", C.c_double),
@@ -122,6 +132,11 @@ _SIGNATURES = {
     "pcv_build_begin": (C.c_int, [_vp, C.POINTER(BuildParams), C.POINTER(Points), C.POINTER(_vp)]),
     "pcv_build_top_streams": (C.c_int, [_vp, C.POINTER(TopStreams)]),
     "pcv_build_finish": (C.c_int, [_vp, C.POINTER(TopLayout)]),
+    "pcv_node_split": (C.c_int, [_vp, C.POINTER(BuildParams), _vp, C.c_uint64, C.c_int, C.POINTER(SplitNode), C.c_uint64,
+                                 C.POINTER(C.c_uint64)]),
+    "pcv_promote_assign": (C.c_int, [C.POINTER(SplitNode), C.c_uint64, C.POINTER(PromoteNode), C.c_uint64, _vp, _vp]),
+    "pcv_gather_encode": (C.c_int, [_vp, C.POINTER(BuildParams), C.POINTER(Points), C.POINTER(SplitNode), C.c_uint64,
+                                    C.POINTER(_vp)]),
     "pcv_sort_keys64": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, C.c_int, C.c_int]),
     "pcv_sort_keys32": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, C.c_int, C.c_int]),
     "pcv_sort_pairs32": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.c_int, C.c_int, C.c_int]),

@@ -596,7 +596,7 @@ extern "C" int pcv_octree_copy_node(const pcv_octree* t, uint64_t i, int which, 
 static uint64_t ceil8(uint64_t v) { return (v + 7) / 8; }
 
 static int build_begin_impl(pcv_ctx* ctx, const pcv_build_params* params, const pcv_points* points,
-                            const pcv_routed_points* routed, pcv_octree** out);
+                            const pcv_routed_points* routed, pcv_octree** out, const PcvTrueTree* given_tree = nullptr);
 extern "C" int pcv_build_begin(pcv_ctx* ctx, const pcv_build_params* params, const pcv_points* points,
                                pcv_octree** out) {
   if (!ctx) return PCV_E_INVALID;
@@ -798,7 +798,7 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
 }
 
 static int build_begin_impl(pcv_ctx* ctx, const pcv_build_params* params, const pcv_points* points,
-                            const pcv_routed_points* routed, pcv_octree** out) {
+                            const pcv_routed_points* routed, pcv_octree** out, const PcvTrueTree* given_tree) {
   int rc;
   if (!(params->resolution > 0.0) || !std::isfinite(params->resolution)) return ctx->fail(PCV_E_INVALID, "resolution must be a positive finite number");
   const uint32_t max_points = params->max_points_per_node ? params->max_points_per_node : PCV_DEFAULT_MAX_POINTS_PER_NODE;
@@ -905,7 +905,11 @@ static int build_begin_impl(pcv_ctx* ctx, const pcv_build_params* params, const 
   // ---- single-chain build (pcv_spec.h): ONE chain pass, topology from a sample + exact per-leaf counts ----
   bool spec_used = false;
   PcvTrueTree true_tree;
-  {
+  if (given_tree) {  // pcv_gather_encode: the topology is an input; K5 / K6 run on it as they do after K4
+    true_tree = *given_tree;
+    spec_used = true;
+    counters[0] = (uint32_t)true_tree.prefix.size();
+  } else {
     bool wide_level = false;  // a Float64-encoded level needs the high code words: left to the exact pipeline
     for (int k = 0; k <= full_levels; ++k) wide_level = wide_level || lv.enc[k] == PCV_ENC_FLOAT64;
     const bool forced = (params->flags & PCV_BUILD_FORCE_SINGLE_CHAIN) != 0;
@@ -1522,4 +1526,169 @@ extern "C" int pcv_sort_pairs32(pcv_ctx* ctx, uint32_t* keys, uint32_t* values, 
                                 int mem) {
   if (ctx && !values) return ctx->fail(PCV_E_INVALID, "values is null");
   return sort_api<uint32_t>(ctx, keys, values, n, begin_bit, end_bit, mem);
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage-level entry points of the topology / promotion / encode stages
+// ------------------------------------------------------------------------------------------------
+extern "C" int pcv_node_split(pcv_ctx* ctx, const pcv_build_params* params, const uint64_t* sorted_keys, uint64_t n, int mem,
+                              pcv_split_node* nodes, uint64_t capacity, uint64_t* num_nodes) {
+  if (!ctx) return PCV_E_INVALID;
+  if (!params || !num_nodes || (capacity && !nodes)) return ctx->fail(PCV_E_INVALID, "null argument");
+  if (mem != PCV_MEM_HOST && mem != PCV_MEM_DEVICE) return ctx->fail(PCV_E_INVALID, "bad mem");
+  if (!(params->resolution > 0.0)) return ctx->fail(PCV_E_INVALID, "resolution must be positive");
+  if (n >= 0xffffffffull) return ctx->fail(PCV_E_INVALID, "at most 2^32 - 2 keys per call");
+  *num_nodes = 0;
+  if (n == 0) return PCV_OK;
+  if (!sorted_keys) return ctx->fail(PCV_E_INVALID, "sorted_keys is null");
+  PCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const uint32_t max_points = params->max_points_per_node ? params->max_points_per_node : PCV_DEFAULT_MAX_POINTS_PER_NODE;
+  PcvLevels lv;
+  int max_level = 0;
+  pcv_make_levels(params->bbox_min, params->bbox_max, params->resolution, 64, &lv, &max_level, nullptr, nullptr);
+  PcvScratch sc(ctx);
+  int rc;
+  const uint64_t* dk = sorted_keys;
+  if (mem == PCV_MEM_HOST) {
+    uint64_t* tmp;
+    if ((rc = sc.get(&tmp, n))) return rc;
+    PCV_HIP_CHECK(ctx, hipMemcpyAsync(tmp, sorted_keys, n * 8, hipMemcpyHostToDevice, st));
+    dk = tmp;
+  }
+  PcvNodeTableDev nt;
+  uint64_t cap64 = 8ull * (uint64_t)(lv.nlevels + 1) * (n / max_points + 1) + 64;
+  if (cap64 > (1ull << 26)) cap64 = 1ull << 26;
+  nt.capacity = (uint32_t)cap64;
+  nt.prefix_lo = nullptr;
+  if ((rc = sc.get(&nt.prefix, cap64)) || (rc = sc.get(&nt.lo, cap64)) || (rc = sc.get(&nt.hi, cap64)) ||
+      (rc = sc.get(&nt.parent, cap64)) || (rc = sc.get(&nt.first_child, cap64)) || (rc = sc.get(&nt.level, cap64)) ||
+      (rc = sc.get(&nt.child_mask, cap64)) || (rc = sc.get(&nt.open, cap64)) || (rc = sc.get(&nt.bounds, (size_t)cap64 * 9)) ||
+      (rc = sc.get(&nt.counters, 64)))
+    return rc;
+  uint8_t* d_pack;
+  if ((rc = sc.get(&d_pack, kPcvPackHeader + ((size_t)cap64 + 8) * sizeof(PcvPackedNode)))) return rc;
+  pcv_launch_node_split(ctx, nt, dk, false, (uint32_t)n, lv, params->resolution, max_points, (params->flags >> 8) & 0xffu);
+  pcv_launch_pack_node_table(ctx, nt, d_pack);
+  PCV_HIP_CHECK(ctx, hipGetLastError());
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(ctx->mailbox, d_pack, 256, hipMemcpyDeviceToHost, st));
+  PCV_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  uint32_t counters[64];
+  std::memcpy(counters, ctx->mailbox, sizeof(counters));
+  if (counters[1] & 2u) return ctx->fail(PCV_E_OOM, "node table capacity exceeded");
+  if (counters[1] & 1u) return ctx->fail(PCV_E_DEPTH, "a node at the last key level would still have to be split");
+  const uint32_t m = counters[0];
+  *num_nodes = m;
+  std::vector<PcvPackedNode> pk(m);
+  if (m) PCV_HIP_CHECK(ctx, hipMemcpy(pk.data(), d_pack + kPcvPackHeader, (size_t)m * sizeof(PcvPackedNode), hipMemcpyDeviceToHost));
+  std::vector<uint32_t> parent(m, 0xffffffffu);
+  for (uint32_t i = 0; i < m; ++i)
+    if (pk[i].open) {
+      const uint32_t nchild = (uint32_t)__builtin_popcount(pk[i].child_mask);
+      for (uint32_t c = 0; c < nchild; ++c) parent[pk[i].first_child + c] = i;
+    }
+  for (uint32_t i = 0; i < m && i < capacity; ++i) {
+    pcv_split_node& o = nodes[i];
+    const int level = pk[i].level;
+    const unsigned __int128 index = level ? (unsigned __int128)(pk[i].prefix >> (3 * (PCV_MAX_KEY_LEVELS - level))) : 0;
+    o.id_high = ((uint64_t)level << 56) | (uint64_t)(index >> 64);
+    o.id_low = (uint64_t)index;
+    o.first = pk[i].lo;
+    o.count = (uint64_t)pk[i].hi - pk[i].lo;
+    o.level = (uint32_t)level;
+    o.parent = parent[i];
+    o.first_child = pk[i].open ? pk[i].first_child : 0u;
+    o.child_mask = pk[i].child_mask;
+    o.is_leaf = pk[i].open ? 0u : 1u;
+    o.reserved = 0;
+  }
+  return PCV_OK;
+}
+
+extern "C" int pcv_promote_assign(const pcv_split_node* nodes, uint64_t num_nodes, pcv_promote_node* per_node, uint64_t n,
+                                  uint32_t* node_of_slot, uint32_t* slot_in_node) {
+  if ((num_nodes && (!nodes || !per_node)) || ((node_of_slot == nullptr) != (slot_in_node == nullptr))) return PCV_E_INVALID;
+  if (num_nodes == 0) return PCV_OK;
+  if (num_nodes > 0xfffffffeull) return PCV_E_INVALID;
+  const uint32_t m = (uint32_t)num_nodes;
+  for (uint32_t i = 0; i < m; ++i) {  // children must follow their parent (breadth-first table) and exist
+    if (nodes[i].is_leaf) continue;
+    const uint32_t nchild = (uint32_t)__builtin_popcount(nodes[i].child_mask & 0xffu);
+    if (nchild == 0 || nodes[i].first_child <= i || (uint64_t)nodes[i].first_child + nchild > m) return PCV_E_INVALID;
+  }
+  // bottom-up stream lengths: |pre(inner)| = sum ceil(|pre(child)| / 8)
+  for (uint32_t i = m; i-- > 0;) {
+    if (nodes[i].is_leaf) {
+      per_node[i].stream_len = nodes[i].count;
+    } else {
+      uint64_t acc = 0;
+      const uint32_t nchild = (uint32_t)__builtin_popcount(nodes[i].child_mask & 0xffu);
+      for (uint32_t c = 0; c < nchild; ++c) {
+        per_node[nodes[i].first_child + c].child_offset = acc;
+        acc += ceil8(per_node[nodes[i].first_child + c].stream_len);
+      }
+      per_node[i].stream_len = acc;
+    }
+  }
+  per_node[0].child_offset = 0;
+  for (uint32_t i = 0; i < m; ++i)
+    per_node[i].num_points = i == 0 ? per_node[0].stream_len : per_node[i].stream_len - ceil8(per_node[i].stream_len);
+  if (!node_of_slot) return PCV_OK;
+  for (uint32_t i = 0; i < m; ++i) {
+    if (!nodes[i].is_leaf) continue;
+    if (nodes[i].first + nodes[i].count > n) return PCV_E_INVALID;
+    for (uint64_t j0 = 0; j0 < nodes[i].count; ++j0) {
+      uint32_t node = i;
+      uint64_t j = j0;
+      while (node != 0 && (j & 7u) == 0) {  // an every-8th element of its stream climbs (generation.rs:222-238)
+        j = per_node[node].child_offset + (j >> 3);
+        node = nodes[node].parent;
+        if (node >= m) return PCV_E_INVALID;
+      }
+      node_of_slot[nodes[i].first + j0] = node;
+      slot_in_node[nodes[i].first + j0] = (uint32_t)(node == 0 ? j : j - (j >> 3) - 1);
+    }
+  }
+  return PCV_OK;
+}
+
+extern "C" int pcv_gather_encode(pcv_ctx* ctx, const pcv_build_params* params, const pcv_points* points,
+                                 const pcv_split_node* nodes, uint64_t num_nodes, pcv_octree** out) {
+  if (!ctx) return PCV_E_INVALID;
+  if (!out) return ctx->fail(PCV_E_INVALID, "out is null");
+  *out = nullptr;
+  if (!params) return ctx->fail(PCV_E_INVALID, "params is null");
+  int rc = validate_points(ctx, points, true);
+  if (rc) return rc;
+  if (params->flags & PCV_BUILD_COMPUTE_BBOX) return ctx->fail(PCV_E_INVALID, "the topology was built for a given bounding box: pass it");
+  if (points->n && (!nodes || num_nodes == 0)) return ctx->fail(PCV_E_INVALID, "no topology");
+  if (num_nodes > (1ull << 26)) return ctx->fail(PCV_E_INVALID, "too many nodes");
+  PcvTrueTree tt;
+  const uint32_t m = (uint32_t)num_nodes;
+  for (uint32_t i = 0; i < m && points->n; ++i) {
+    const pcv_split_node& nd = nodes[i];
+    if (nd.level > PCV_MAX_KEY_LEVELS) return ctx->fail(PCV_E_INVALID, "pcv_gather_encode takes trees of up to 21 levels");
+    if (nd.first + nd.count > points->n) return ctx->fail(PCV_E_INVALID, "node range outside the points");
+    const uint32_t nchild = (uint32_t)__builtin_popcount(nd.child_mask & 0xffu);
+    if (!nd.is_leaf && (nchild == 0 || nd.first_child <= i || (uint64_t)nd.first_child + nchild > m))
+      return ctx->fail(PCV_E_INVALID, "node table is not breadth first with consecutive children");
+    const unsigned __int128 index = ((unsigned __int128)(nd.id_high & 0x00ffffffffffffffull) << 64) | nd.id_low;
+    tt.prefix.push_back(nd.level ? (uint64_t)(index << (3 * (PCV_MAX_KEY_LEVELS - nd.level))) : 0ull);
+    tt.lo.push_back((uint32_t)nd.first);
+    tt.hi.push_back((uint32_t)(nd.first + nd.count));
+    tt.first_child.push_back(nd.is_leaf ? 0u : nd.first_child);
+    tt.level.push_back((uint8_t)nd.level);
+    tt.child_mask.push_back((uint8_t)nd.child_mask);
+    tt.open.push_back(nd.is_leaf ? 0 : 1);
+  }
+  if (points->n && (tt.lo[0] != 0 || tt.hi[0] != points->n || tt.level[0] != 0))
+    return ctx->fail(PCV_E_INVALID, "the first node must be the root and span all points");
+  pcv_octree* t = nullptr;
+  rc = build_begin_impl(ctx, params, points, nullptr, &t, &tt);
+  if (rc == PCV_OK && (rc = pcv_build_finish(t, nullptr)) != PCV_OK) {
+    pcv_octree_free(t);
+    t = nullptr;
+  }
+  *out = t;
+  return rc;
 }

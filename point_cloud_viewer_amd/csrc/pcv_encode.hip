@@ -251,13 +251,8 @@ __global__ __launch_bounds__(1024) void rank_hist_kernel(const uint32_t* __restr
 // the map (PCV_SPEC_MAP_REPLAY): their points have no valid codes yet. They leave their input index in the payload; the record sort makes
 // the points of such a leaf contiguous, and spec_replay_kernel then replays their chain over exactly those slots —
 // dense, without lists or atomics.
-__global__ __launch_bounds__(256) void spec_finalize_kernel(uint64_t n, const uint32_t* __restrict__ spec_map,
-                                                             uint32_t* __restrict__ rank, uint4* __restrict__ payload,
-                                                             const uint4* __restrict__ kept) {
-  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t m = spec_map[rank[i]];
-  rank[i] = m & PCV_SPEC_INDEX_MASK;
+__device__ __forceinline__ uint32_t spec_finalize_one(uint64_t i, uint32_t m, uint4* __restrict__ payload,
+                                                       const uint4* __restrict__ kept) {
   if (m & PCV_SPEC_MAP_REPLAY) {
     reinterpret_cast<uint32_t*>(payload + i)[0] = (uint32_t)i;  // n < 2^32
   } else if (m & PCV_SPEC_MAP_KEPT) {
@@ -265,6 +260,25 @@ __global__ __launch_bounds__(256) void spec_finalize_kernel(uint64_t n, const ui
     uint4 p = payload[i];
     p.x = k.x, p.y = k.y, p.z = k.z;
     payload[i] = p;
+  }
+  return m & PCV_SPEC_INDEX_MASK;
+}
+// four ranks per lane (one 16-byte load / store; the map lookups and the rare payload patches of all four in flight)
+__global__ __launch_bounds__(256) void spec_finalize_kernel(uint64_t n, const uint32_t* __restrict__ spec_map,
+                                                             uint32_t* __restrict__ rank, uint4* __restrict__ payload,
+                                                             const uint4* __restrict__ kept) {
+  const uint64_t i = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  if (i + 4 <= n) {  // rank comes from the pool: 16-byte aligned
+    uint4 r = *reinterpret_cast<const uint4*>(rank + i);
+    const uint32_t m0 = spec_map[r.x], m1 = spec_map[r.y], m2 = spec_map[r.z], m3 = spec_map[r.w];
+    r.x = spec_finalize_one(i, m0, payload, kept);
+    r.y = spec_finalize_one(i + 1, m1, payload, kept);
+    r.z = spec_finalize_one(i + 2, m2, payload, kept);
+    r.w = spec_finalize_one(i + 3, m3, payload, kept);
+    *reinterpret_cast<uint4*>(rank + i) = r;
+  } else {
+    for (uint64_t j = i; j < n; ++j) rank[j] = spec_finalize_one(j, spec_map[rank[j]], payload, kept);
   }
 }
 
@@ -517,7 +531,7 @@ void pcv_launch_rank_hist(pcv_ctx* ctx, const uint32_t* rank, uint64_t n, uint32
 void pcv_launch_spec_finalize(pcv_ctx* ctx, uint64_t n, const uint32_t* spec_map, uint32_t* rank, void* payload, const void* kept) {
   if (n == 0) return;
   PcvProf prof(ctx, PCV_K_SPEC_FINALIZE);
-  hipLaunchKernelGGL(spec_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, spec_map, rank,
+  hipLaunchKernelGGL(spec_finalize_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, ctx->stream, n, spec_map, rank,
                      (uint4*)payload, (const uint4*)kept);
 }
 

@@ -268,6 +268,27 @@ class Context:
         self._check(self.lib.pcv_chain_keys(self.handle, C.byref(pr), C.byref(p), nlevels, keys.ctypes.data))
         return keys
 
+    def node_split(self, resolution, bounding_box, sorted_keys, max_points_per_node=0, capacity=1 << 16):
+        """K4 on sorted full-depth path keys: ctypes array of SplitNode (breadth first, children consecutive)."""
+        b = _Buf(sorted_keys, np.uint64, "sorted_keys")
+        pr = self._params(resolution, bounding_box.min, bounding_box.max, max_points_per_node)
+        nodes = (L.SplitNode * capacity)()
+        num = C.c_uint64()
+        self._check(self.lib.pcv_node_split(self.handle, C.byref(pr), b.ptr, b.size, L.MEM_DEVICE if b.device else L.MEM_HOST,
+                                            nodes, capacity, C.byref(num)))
+        if num.value > capacity:
+            return self.node_split(resolution, bounding_box, sorted_keys, max_points_per_node, int(num.value))
+        return nodes, int(num.value)
+
+    def gather_encode(self, resolution, bounding_box, x, y, z, color, nodes, num_nodes, intensity=None, max_points_per_node=0):
+        """K5 + K6 for a given topology (node_split's table): the finished octree."""
+        p, keep = self._points(x, y, z, color, intensity)
+        pr = self._params(resolution, bounding_box.min, bounding_box.max, max_points_per_node)
+        h = C.c_void_p()
+        self._check(self.lib.pcv_gather_encode(self.handle, C.byref(pr), C.byref(p), nodes, num_nodes, C.byref(h)))
+        del keep
+        return OctreeResult(self, h)
+
     def selftest_division(self, divisors, samples_per_divisor=1 << 22):
         """Number of inputs for which the exact constant-divisor division differs from IEEE division (must be 0)."""
         d = np.ascontiguousarray(divisors, dtype=np.float64)
@@ -358,6 +379,23 @@ class Context:
         self._check(self.lib.pcv_sort_pairs32(self.handle, k.ptr, v.ptr, k.size, begin_bit, end_bit,
                                               L.MEM_DEVICE if k.device else L.MEM_HOST))
         return k.keep, v.keep
+
+
+def promote_assign(nodes, num_nodes, n=0, with_slots=False):
+    """Closed form of the every-8th promotion on a node table: (stream_len, num_points, child_offset) arrays and, with
+    with_slots, (node_of_slot, slot_in_node) for every position of the leaf-sorted order."""
+    lib = L.load_library()
+    per = (L.PromoteNode * max(1, num_nodes))()
+    node_of = np.zeros(n if with_slots else 0, dtype=np.uint32)
+    slot_in = np.zeros(n if with_slots else 0, dtype=np.uint32)
+    rc = lib.pcv_promote_assign(nodes, num_nodes, per, n, node_of.ctypes.data if with_slots else None,
+                                slot_in.ctypes.data if with_slots else None)
+    if rc != L.PCV_OK:
+        raise L.PcvError(rc, "pcv_promote_assign: inconsistent node table")
+    stream = np.array([per[i].stream_len for i in range(num_nodes)], dtype=np.int64)
+    kept = np.array([per[i].num_points for i in range(num_nodes)], dtype=np.int64)
+    off = np.array([per[i].child_offset for i in range(num_nodes)], dtype=np.int64)
+    return (stream, kept, off, node_of, slot_in) if with_slots else (stream, kept, off)
 
 
 def level_table(bbox_min, bbox_max, resolution, cap=64):

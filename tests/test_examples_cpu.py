@@ -31,3 +31,4 @@ def test_ctypes_mirrors_have_the_asserted_layouts():
     assert C.sizeof(L.NodeInfo) == 80 and L.NodeInfo.cube_edge.offset == 56 and L.NodeInfo.point_offset.offset == 72
     assert C.sizeof(L.Shape) == 264 and C.sizeof(L.TopStreams) == 584 and C.sizeof(L.TopLayout) == 360
     assert C.sizeof(L.RoutedPoints) == 48 and C.sizeof(L.RouteState) == 32 and C.sizeof(L.Plane) == 16
+    assert C.sizeof(L.SplitNode) == 56 and L.SplitNode.is_leaf.offset == 48 and C.sizeof(L.PromoteNode) == 24

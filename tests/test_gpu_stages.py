@@ -128,3 +128,52 @@ def test_exact_constant_divisor_division_selftest(ctx):
     divisors += [3.0, 7.0, 1.0 / 3.0, 0.1, 1e-30, 1e30, 1e-40, 1e200, 5e-324, 2.0 ** 52 - 1, 1.9999999999999998,
                  1.0000000000000002]
     assert ctx.selftest_division(divisors, 1 << 22) == 0
+
+
+def test_node_split_promote_assign_gather_encode_stage_by_stage(ctx):
+    """The build stage by stage through the C ABI: pcv_chain_keys -> pcv_sort_keys64 -> pcv_node_split ->
+    pcv_promote_assign -> pcv_gather_encode, every stage against the oracle (generation.rs:58-253)."""
+    from point_cloud_viewer_amd import octree
+    n, cap = 250_000, 1500
+    x, y, z, rgb, bmin, bmax = synthetic.gaussian_clusters(n, seed=23, num_clusters=5, extent=90.0, sigma_range=(0.01, 4.0))
+    inten = (np.arange(n) % 101).astype(np.float32)
+    box = pcv.Aabb(bmin, bmax)
+    with O.max_points_per_node(cap):
+        want = O.build_closed(0.001, bmin, bmax, x, y, z, rgb, inten, threads=4)
+    keys = ctx.chain_keys(0.001, box, x, y, z)
+    assert np.array_equal(keys, O.chain_keys64(bmin, bmax, 0.001, 21, x, y, z, threads=4))
+    skeys = ctx.sort_keys64(keys.copy(), 0, 63)
+    assert np.array_equal(skeys, np.sort(keys))
+    nodes, m = ctx.node_split(0.001, box, skeys, max_points_per_node=cap)
+    names = [pcv.node_name(nodes[i].id_high, nodes[i].id_low) for i in range(m)]
+    assert set(names) == set(want.nodes) and len(names) == len(set(names))
+    for i, k in enumerate(names):
+        children = [c for c in want.nodes if len(c) == len(k) + 1 and c.startswith(k)]
+        assert bool(nodes[i].is_leaf) == (not children), k
+        assert nodes[i].level == len(k) - 1
+        if children:
+            got = [names[nodes[i].first_child + c] for c in range(bin(nodes[i].child_mask).count("1"))]
+            assert got == sorted(children), k  # consecutive, digit order
+            assert all(nodes[nodes[i].first_child + c].parent == i for c in range(len(got)))
+        pfx = sum(int(d) << (3 * (21 - j)) for j, d in enumerate(k[1:], start=1))
+        lo = int(np.searchsorted(skeys, np.uint64(pfx), "left"))
+        hi = int(np.searchsorted(skeys, np.uint64(pfx + (1 << (3 * (21 - nodes[i].level))) - 1), "right")) if nodes[i].level else n
+        assert (nodes[i].first, nodes[i].count) == (lo, hi - lo), k
+    stream, kept, off = octree.promote_assign(nodes, m)
+    for i, k in enumerate(names):
+        assert kept[i] == want.nodes[k]["num_points"], k
+    tree = ctx.gather_encode(0.001, box, x, y, z, rgb, nodes, m, intensity=inten, max_points_per_node=cap)
+    got = tree.to_dict()
+    assert set(got) == set(want.nodes)
+    for k, nd in want.nodes.items():
+        assert (got[k]["num_points"], got[k]["xyz"], got[k]["rgb"], got[k]["intensity"]) == \\
+               (nd["num_points"], nd["xyz"], nd["rgb"], nd["intensity"]), k
+    # a topology that does not belong to the points is refused, not encoded
+    with pytest.raises(pcv.PcvError):
+        ctx.gather_encode(0.001, box, x[:1000], y[:1000], z[:1000], rgb[:1000], nodes, m, max_points_per_node=cap)
+    # depth overflow of the stage call (keys end at level 21)
+    dup = np.zeros(5000)
+    kz = ctx.chain_keys(1e-9, pcv.Aabb([0, 0, 0], [1, 1, 1]), dup, dup, dup)
+    with pytest.raises(pcv.PcvError) as e:
+        ctx.node_split(1e-9, pcv.Aabb([0, 0, 0], [1, 1, 1]), np.sort(kz), max_points_per_node=100)
+    assert e.value.code == pcv.PCV_E_DEPTH
