@@ -166,8 +166,8 @@ def test_node_split_promote_assign_gather_encode_stage_by_stage(ctx):
     got = tree.to_dict()
     assert set(got) == set(want.nodes)
     for k, nd in want.nodes.items():
-        assert (got[k]["num_points"], got[k]["xyz"], got[k]["rgb"], got[k]["intensity"]) == \\
-               (nd["num_points"], nd["xyz"], nd["rgb"], nd["intensity"]), k
+        g = got[k]
+        assert (g["num_points"], g["xyz"], g["rgb"], g["intensity"]) == (nd["num_points"], nd["xyz"], nd["rgb"], nd["intensity"]), k
     # a topology that does not belong to the points is refused, not encoded
     with pytest.raises(pcv.PcvError):
         ctx.gather_encode(0.001, box, x[:1000], y[:1000], z[:1000], rgb[:1000], nodes, m, max_points_per_node=cap)
