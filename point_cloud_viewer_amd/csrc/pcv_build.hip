@@ -823,6 +823,7 @@ static int build_begin_impl(pcv_ctx* ctx, const pcv_build_params* params, const 
   } guard{t};
   PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[0], st));
   for (bool& on : ctx->stage_on) on = false;
+  for (bool& open : ctx->stage_open) open = false;
   ctx->stage_begin(PCV_STAGE_AABB);
   if (routed) {  // device-resident by contract
     d.n = n;
@@ -909,6 +910,7 @@ static int build_begin_impl(pcv_ctx* ctx, const pcv_build_params* params, const 
     true_tree = *given_tree;
     spec_used = true;
     counters[0] = (uint32_t)true_tree.prefix.size();
+    ctx->stage_begin(PCV_STAGE_TABLE);
   } else {
     bool wide_level = false;  // a Float64-encoded level needs the high code words: left to the exact pipeline
     for (int k = 0; k <= full_levels; ++k) wide_level = wide_level || lv.enc[k] == PCV_ENC_FLOAT64;

@@ -91,14 +91,17 @@ struct pcv_ctx {
   hipEvent_t ev[PCV_NUM_STAGES + 2] = {};
   // per-stage begin / end events of the build in flight (a stage may be recorded out of order or not at all)
   hipEvent_t stage_b[PCV_NUM_STAGES] = {}, stage_e[PCV_NUM_STAGES] = {};
-  bool stage_on[PCV_NUM_STAGES] = {};
+  bool stage_on[PCV_NUM_STAGES] = {}, stage_open[PCV_NUM_STAGES] = {};
   void stage_begin(int s) {
     (void)hipEventRecord(stage_b[s], stream);
     stage_on[s] = false;
+    stage_open[s] = true;
   }
-  void stage_end(int s) {
+  void stage_end(int s) {  // a stage that was never begun in this build stays unmeasured
+    if (!stage_open[s]) return;
     (void)hipEventRecord(stage_e[s], stream);
     stage_on[s] = true;
+    stage_open[s] = false;
   }
   hipEvent_t xev = nullptr;  // stream hand-off with the caller's runtime (pcv_ctx_wait_stream / _signal_stream)
 
