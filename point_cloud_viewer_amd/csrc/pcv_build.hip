@@ -111,6 +111,93 @@ int pcv_ctx::pinned_spec_reserve(size_t bytes) {
   return PCV_OK;
 }
 
+void PcvHostPool::start(unsigned n) {
+  if (!threads.empty()) return;
+  for (unsigned k = 0; k < n; ++k)
+    threads.emplace_back([this] {
+      uint64_t seen = 0;
+      for (;;) {
+        std::unique_lock<std::mutex> lk(mu);
+        wake.wait(lk, [&] { return stop || (generation != seen && next < count); });
+        if (stop) return;
+        while (next < count) {
+          const size_t i = next++;
+          lk.unlock();
+          job(i);
+          lk.lock();
+          if (++finished == count) done.notify_all();
+        }
+        seen = generation;
+      }
+    });
+}
+void PcvHostPool::run(size_t n, const std::function<void(size_t)>& fn) {
+  if (n == 0) return;
+  if (threads.empty() || n == 1) {
+    for (size_t i = 0; i < n; ++i) fn(i);
+    return;
+  }
+  std::unique_lock<std::mutex> lk(mu);
+  job = fn;
+  next = 0;
+  count = n;
+  finished = 0;
+  ++generation;
+  wake.notify_all();
+  while (next < count) {  // the caller works too
+    const size_t i = next++;
+    lk.unlock();
+    fn(i);
+    lk.lock();
+    ++finished;
+  }
+  done.wait(lk, [&] { return finished == count; });
+  count = 0;
+}
+PcvHostPool::~PcvHostPool() {
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    stop = true;
+  }
+  wake.notify_all();
+  for (auto& th : threads) th.join();
+}
+
+// Pageable caller memory -> device: the runtime's own staging of a pageable hipMemcpy runs on one thread (~45 GB/s
+// here); several host threads filling a ring of pinned chunks keep the link busy instead (every chunk is one DMA).
+int pcv_ctx::h2d(void* dst, const void* src, size_t bytes) {
+  if (bytes == 0) return PCV_OK;
+  if (bytes < (4u << 20)) {  // small arrays: not worth the ring
+    PCV_HIP_CHECK(this, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
+    return PCV_OK;
+  }
+  if (!ring[0]) {
+    for (int k = 0; k < kRingSlots; ++k) {
+      if (hipHostMalloc(&ring[k], kRingChunk, hipHostMallocDefault) != hipSuccess) return fail(PCV_E_OOM, "hipHostMalloc (staging ring)");
+      if (hipEventCreateWithFlags(&ring_ev[k], hipEventDisableTiming) != hipSuccess) return fail(PCV_E_HIP, "hipEventCreate");
+    }
+    unsigned hw = std::thread::hardware_concurrency();
+    host_pool.start(hw >= 16 ? 7 : (hw > 2 ? hw / 2 - 1 : 0));
+  }
+  constexpr size_t kPart = 2u << 20;
+  for (size_t off = 0; off < bytes; off += kRingChunk) {
+    const size_t len = bytes - off < kRingChunk ? bytes - off : kRingChunk;
+    const int slot = ring_next;
+    ring_next = (ring_next + 1) % kRingSlots;
+    if (ring_busy[slot]) PCV_HIP_CHECK(this, hipEventSynchronize(ring_ev[slot]));  // its previous DMA has left the chunk
+    uint8_t* chunk = (uint8_t*)ring[slot];
+    const uint8_t* from = (const uint8_t*)src + off;
+    host_pool.run((len + kPart - 1) / kPart, [&](size_t p) {
+      const size_t b = p * kPart, e = b + kPart < len ? b + kPart : len;
+      std::memcpy(chunk + b, from + b, e - b);
+    });
+    PCV_HIP_CHECK(this, hipMemcpyAsync((uint8_t*)dst + off, chunk, len, hipMemcpyHostToDevice, stream));
+    PCV_HIP_CHECK(this, hipEventRecord(ring_ev[slot], stream));
+    ring_busy[slot] = true;
+  }
+  return PCV_OK;
+}
+
 hipEvent_t pcv_ctx::prof_event() {
   if (!prof_free.empty()) {
     hipEvent_t e = prof_free.back();
@@ -221,6 +308,10 @@ extern "C" void pcv_ctx_destroy(pcv_ctx* ctx) {
   for (auto& kv : ctx->pool.live) (void)hipFree(kv.first);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->pinned_spec) (void)hipHostFree(ctx->pinned_spec);
+  for (int k = 0; k < pcv_ctx::kRingSlots; ++k) {
+    if (ctx->ring[k]) (void)hipHostFree(ctx->ring[k]);
+    if (ctx->ring_ev[k]) (void)hipEventDestroy(ctx->ring_ev[k]);
+  }
   if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
   for (auto& kv : ctx->host_free) (void)hipHostFree(kv.second);
   for (auto& kv : ctx->host_live) (void)hipHostFree(kv.first);
@@ -385,21 +476,19 @@ static int stage_points(pcv_ctx* ctx, PcvScratch& sc, const pcv_points* p, bool 
   double *x, *y, *z;
   int rc;
   if ((rc = sc.get(&x, p->n)) || (rc = sc.get(&y, p->n)) || (rc = sc.get(&z, p->n))) return rc;
-  PCV_HIP_CHECK(ctx, hipMemcpyAsync(x, p->x, p->n * 8, hipMemcpyHostToDevice, ctx->stream));
-  PCV_HIP_CHECK(ctx, hipMemcpyAsync(y, p->y, p->n * 8, hipMemcpyHostToDevice, ctx->stream));
-  PCV_HIP_CHECK(ctx, hipMemcpyAsync(z, p->z, p->n * 8, hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = ctx->h2d(x, p->x, p->n * 8)) || (rc = ctx->h2d(y, p->y, p->n * 8)) || (rc = ctx->h2d(z, p->z, p->n * 8))) return rc;
   d->x = x;
   d->y = y;
   d->z = z;
   if (with_attrs) {
     uint8_t* c;
     if ((rc = sc.get(&c, p->n * p->color_stride))) return rc;
-    PCV_HIP_CHECK(ctx, hipMemcpyAsync(c, p->color, p->n * p->color_stride, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = ctx->h2d(c, p->color, p->n * p->color_stride))) return rc;
     d->color = c;
     if (p->intensity) {
       float* f;
       if ((rc = sc.get(&f, p->n))) return rc;
-      PCV_HIP_CHECK(ctx, hipMemcpyAsync(f, p->intensity, p->n * 4, hipMemcpyHostToDevice, ctx->stream));
+      if ((rc = ctx->h2d(f, p->intensity, p->n * 4))) return rc;
       d->intensity = f;
     }
   }

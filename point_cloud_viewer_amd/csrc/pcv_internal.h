@@ -3,8 +3,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <condition_variable>
+#include <functional>
 #include <map>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/pcv_hip.h"
@@ -29,6 +33,21 @@ struct PcvLevels {
   uint8_t enc[PCV_MAX_LEVELS + 3];
   int32_t nlevels;  // number of digit levels materialised in the keys (<= PCV_MAX_KEY_LEVELS; <= PCV_MAX_LEVELS deep)
   int32_t fast_ok;  // root min and all edges are tame: unguarded exact division is valid for tame points
+};
+
+// A few persistent host threads for memory-bound host work next to the GPU (staging copies into pinned memory): a
+// parallel-for over [0, count) that returns when every index is done. One per context, created on first use.
+struct PcvHostPool {
+  std::vector<std::thread> threads;
+  std::mutex mu;
+  std::condition_variable wake, done;
+  std::function<void(size_t)> job;
+  size_t next = 0, count = 0, finished = 0;
+  uint64_t generation = 0;
+  bool stop = false;
+  void start(unsigned n);
+  void run(size_t n, const std::function<void(size_t)>& fn);
+  ~PcvHostPool();
 };
 
 // Caching device allocator + pinned host scratch, one per context. Steady-state builds allocate nothing.
@@ -88,6 +107,15 @@ struct pcv_ctx {
   void* pinned_spec = nullptr;
   size_t pinned_spec_bytes = 0;
   int pinned_spec_reserve(size_t bytes);
+  // host -> device staging of pageable caller memory: ring of pinned chunks filled by the host pool, DMA per chunk
+  static constexpr size_t kRingChunk = 32u << 20;
+  static constexpr int kRingSlots = 3;
+  void* ring[kRingSlots] = {};
+  hipEvent_t ring_ev[kRingSlots] = {};
+  bool ring_busy[kRingSlots] = {};
+  int ring_next = 0;
+  PcvHostPool host_pool;
+  int h2d(void* dst, const void* src, size_t bytes);  // asynchronous on `stream` from the device's point of view
   hipEvent_t ev[PCV_NUM_STAGES + 2] = {};
   // per-stage begin / end events of the build in flight (a stage may be recorded out of order or not at all)
   hipEvent_t stage_b[PCV_NUM_STAGES] = {}, stage_e[PCV_NUM_STAGES] = {};

@@ -6,7 +6,9 @@
 //   files of a node with zero points do not exist                          src/read_write/node_writer.rs:78-89
 //   meta.pb             proto3 `Meta`, version 13                          point_viewer_proto_rust/src/proto.proto:136-149
 // NodeId Display: "r" + index in octal, zero-padded to `level` digits      src/octree/node.rs:73-86
+#include <fcntl.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cmath>
@@ -62,6 +64,22 @@ bool write_file(const std::string& path, const uint8_t* data, uint64_t len) {
   if (!f) return false;
   bool ok = len == 0 || fwrite(data, 1, len, f) == len;
   return fclose(f) == 0 && ok;
+}
+// one file of a node: open relative to the directory handle (no path walk), one write, close
+bool write_file_at(int dirfd, const std::string& name, const uint8_t* data, uint64_t len) {
+  const int fd = openat(dirfd, name.c_str(), O_CREAT | O_WRONLY | O_TRUNC | O_CLOEXEC, 0666);
+  if (fd < 0) return false;
+  bool ok = true;
+  while (len) {
+    const ssize_t w = ::write(fd, data, (size_t)len);
+    if (w <= 0) {
+      ok = false;
+      break;
+    }
+    data += w;
+    len -= (uint64_t)w;
+  }
+  return ::close(fd) == 0 && ok;
 }
 
 }  // namespace
@@ -122,14 +140,64 @@ extern "C" int pcv_octree_write_nodes(pcv_octree* t, const char* directory, uint
 static int write_nodes(pcv_octree* t, const char* directory, uint32_t min_level, bool with_meta) {
   if (!t || !directory) return PCV_E_INVALID;
   pcv_ctx* ctx = t->ctx;
-  int rc = pcv_octree_fetch_host(t);
-  if (rc) return rc;
   std::string dir(directory);
   ::mkdir(dir.c_str(), 0777);  // generation.rs:308 "Ignore errors, maybe directory is already there."
   struct stat st;
   if (stat(dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return ctx->fail(PCV_E_IO, "cannot create directory " + dir);
-  // thousands of small files — written by a pool of host threads (the node blobs are already
-  // contiguous in host memory, so every file is one write()).
+  const int dirfd = open(dir.c_str(), O_RDONLY | O_DIRECTORY | O_CLOEXEC);
+  if (dirfd < 0) return ctx->fail(PCV_E_IO, "cannot open directory " + dir);
+  // thousands of small files — written by a pool of host threads while the node blobs are still coming
+  // down: the D2H is queued in chunks with an event each, a writer only waits for the chunks its node ends in (the
+  // blobs are node-contiguous and in table order, so the copy runs ahead of the writers).
+  constexpr uint64_t kChunk = 16ull << 20;
+  struct Blob {
+    const uint8_t* dev;
+    uint8_t* host;
+    uint64_t bytes;
+    std::vector<hipEvent_t> ev;
+  } blobs[3] = {{t->d_xyz, nullptr, t->xyz_bytes, {}}, {t->d_rgb, nullptr, t->rgb_bytes, {}}, {t->d_int, nullptr, t->int_bytes, {}}};
+  int rc = PCV_OK;
+  const bool stream_down = !t->host_valid && t->directory.empty();
+  if (stream_down) {
+    if (hipSetDevice(ctx->device) != hipSuccess) rc = ctx->fail(PCV_E_HIP, "hipSetDevice");
+    if (!rc && t->xyz_bytes) rc = ctx->host_alloc((void**)&t->h_xyz.p, t->xyz_bytes);
+    if (!rc && t->rgb_bytes) rc = ctx->host_alloc((void**)&t->h_rgb.p, t->rgb_bytes);
+    if (!rc && t->int_bytes) rc = ctx->host_alloc((void**)&t->h_int.p, t->int_bytes);
+    blobs[0].host = t->h_xyz.p, blobs[1].host = t->h_rgb.p, blobs[2].host = t->h_int.p;
+    // interleave the chunks of the three blobs so that all of a node's files become writable at about the same time
+    const uint64_t most = std::max(std::max(blobs[0].bytes, blobs[1].bytes), blobs[2].bytes);
+    for (uint64_t off = 0; !rc && off < most; off += kChunk)
+      for (Blob& b : blobs) {
+        const uint64_t boff = b.bytes * (off / kChunk) / ((most + kChunk - 1) / kChunk);  // proportional progress
+        const uint64_t bend = b.bytes * (off / kChunk + 1) / ((most + kChunk - 1) / kChunk);
+        hipEvent_t e = nullptr;  // one event per chunk index and blob, also where the blob has nothing in this chunk
+        if ((bend > boff && hipMemcpyAsync(b.host + boff, b.dev + boff, bend - boff, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) ||
+            hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess || hipEventRecord(e, ctx->stream) != hipSuccess) {
+          rc = ctx->fail(PCV_E_HIP, "queueing the blob download failed");
+          break;
+        }
+        b.ev.push_back(e);
+      }
+  } else if (!t->host_valid) {
+    rc = ctx->fail(PCV_E_INVALID, "this octree was opened from a directory and its node files were not loaded; there is nothing to write");
+  }
+  // event k of a blob covers bytes [bytes * k / chunks, bytes * (k + 1) / chunks)
+  const uint64_t chunks = std::max<uint64_t>(1, blobs[0].ev.size());
+  std::vector<std::atomic<int>> arrived(3 * chunks);
+  for (auto& a : arrived) a.store(0);
+  auto wait_for = [&](int which, uint64_t end_byte) -> bool {  // everything before end_byte of blob `which` is on the host
+    if (!stream_down || end_byte == 0) return true;
+    const Blob& b = blobs[which];
+    if (b.ev.empty()) return true;
+    uint64_t k = 0;
+    while (k + 1 < b.ev.size() && b.bytes * (k + 1) / b.ev.size() < end_byte) ++k;
+    for (uint64_t j = 0; j <= k; ++j) {
+      if (arrived[which * chunks + j].load(std::memory_order_acquire)) continue;
+      if (hipEventSynchronize(b.ev[j]) != hipSuccess) return false;
+      arrived[which * chunks + j].store(1, std::memory_order_release);
+    }
+    return true;
+  };
   const size_t count = t->nodes.size();
   unsigned nthreads = std::thread::hardware_concurrency();
   if (nthreads == 0) nthreads = 4;
@@ -140,30 +208,45 @@ static int write_nodes(pcv_octree* t, const char* directory, uint32_t min_level,
   std::string first_error;
   std::mutex err_mu;
   auto worker = [&]() {
+    (void)hipSetDevice(ctx->device);
     for (;;) {
       const size_t i = next.fetch_add(1);
       if (i >= count || failed.load()) return;
       const pcv_node_info& n = t->nodes[i];
       if (n.num_points == 0 || n.level < min_level) continue;  // node_writer.rs:78-89: empty nodes have no files
-      const std::string stem = dir + "/" + node_name(n);
+      const std::string stem = node_name(n);
       const uint64_t np = (uint64_t)n.num_points;
+      const uint64_t xb = np * 3 * (uint64_t)pcv_bytes_per_coordinate(n.encoding);
       const char* bad = nullptr;
-      if (!write_file(stem + ".xyz", t->h_xyz.data() + n.xyz_offset, np * 3 * (uint64_t)pcv_bytes_per_coordinate(n.encoding)))
+      if (!wait_for(0, n.xyz_offset + xb) || !wait_for(1, (n.point_offset + np) * 3) ||
+          (t->has_intensity && !wait_for(2, (n.point_offset + np) * 4)))
+        bad = " (download)";
+      else if (!write_file_at(dirfd, stem + ".xyz", t->h_xyz.data() + n.xyz_offset, xb))
         bad = ".xyz";
-      else if (!write_file(stem + ".rgb", t->h_rgb.data() + n.point_offset * 3, np * 3))
+      else if (!write_file_at(dirfd, stem + ".rgb", t->h_rgb.data() + n.point_offset * 3, np * 3))
         bad = ".rgb";
-      else if (t->has_intensity && !write_file(stem + ".intensity", t->h_int.data() + n.point_offset * 4, np * 4))
+      else if (t->has_intensity && !write_file_at(dirfd, stem + ".intensity", t->h_int.data() + n.point_offset * 4, np * 4))
         bad = ".intensity";
       if (bad) {
         std::lock_guard<std::mutex> g(err_mu);
-        if (!failed.exchange(1)) first_error = "cannot write " + stem + bad;
+        if (!failed.exchange(1)) first_error = "cannot write " + dir + "/" + stem + bad;
       }
     }
   };
-  std::vector<std::thread> pool;
-  for (unsigned k = 1; k < nthreads; ++k) pool.emplace_back(worker);
-  worker();
-  for (auto& th : pool) th.join();
+  if (!rc) {
+    std::vector<std::thread> pool;
+    for (unsigned k = 1; k < nthreads; ++k) pool.emplace_back(worker);
+    worker();
+    for (auto& th : pool) th.join();
+  }
+  if (stream_down) {
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && !rc) rc = ctx->fail(PCV_E_HIP, "blob download failed");
+    for (Blob& b : blobs)
+      for (hipEvent_t e : b.ev) (void)hipEventDestroy(e);
+    if (!rc) t->host_valid = true;
+  }
+  ::close(dirfd);
+  if (rc) return rc;
   if (failed.load()) return ctx->fail(PCV_E_IO, first_error);
   if (!with_meta) return PCV_OK;
   std::vector<uint8_t> meta = pcv_encode_meta(t);
