@@ -549,22 +549,31 @@ def main():
             for attempt in range(2):  # the first pass pays one-time costs (pinned host blocks, staging buffers)
                 shutil.rmtree(os.path.join(d, "octree"), ignore_errors=True)
                 torch.cuda.synchronize()
+                # (a) host arrays -> host blobs: pinned-ring H2D + build, then one D2H of the node blobs
                 a0 = time.perf_counter()
                 t = ctx.build(args.resolution, None, hx, hy, hz, hrgb)
                 a1 = time.perf_counter()
                 t.node_data(0, 0)  # forces the D2H of all node blobs (pinned host memory)
                 a2 = time.perf_counter()
+                t.free()
+                # (b) host arrays -> files: the node files are written while the blobs are still coming down
+                b0 = time.perf_counter()
+                t = ctx.build(args.resolution, None, hx, hy, hz, hrgb)
+                b1 = time.perf_counter()
                 t.write_dir(os.path.join(d, "octree"))
-                a3 = time.perf_counter()
+                b2 = time.perf_counter()
                 files = len(os.listdir(os.path.join(d, "octree")))
                 t.free()
         finally:
             shutil.rmtree(d, ignore_errors=True)
         e2e = {"h2d_plus_build_ms": round((a1 - a0) * 1e3, 1), "d2h_blobs_ms": round((a2 - a1) * 1e3, 1),
-               "write_files_tmpfs_ms": round((a3 - a2) * 1e3, 1), "files": files,
+               "d2h_overlapped_with_file_writes_tmpfs_ms": round((b2 - b1) * 1e3, 1), "files": files,
                "Mpoints_per_s_h2d_build_d2h": round(n / (a2 - a0) / 1e6, 1),
-               "Mpoints_per_s_incl_files": round(n / (a3 - a0) / 1e6, 1),
-               "note": "pageable numpy inputs, bounding box computed on the device; not part of `value`"}
+               "Mpoints_per_s_incl_files": round(n / (b2 - b0) / 1e6, 1),
+               "input_bytes_per_point": 27, "h2d_GBps": round(27.0 * n / max(a1 - a0 - value and (n / (value * 1e6)), 1e-9) / 1e9, 1),
+               "note": "pageable numpy inputs staged through a pinned ring (one DMA per 32 MiB chunk), bounding box computed "
+                       "on the device; creating the node files in ONE directory serialises on the directory lock "
+                       "(reference layout); not part of `value`"}
 
     if rank == 0:
         out = {
