@@ -570,7 +570,7 @@ def main():
                "d2h_overlapped_with_file_writes_tmpfs_ms": round((b2 - b1) * 1e3, 1), "files": files,
                "Mpoints_per_s_h2d_build_d2h": round(n / (a2 - a0) / 1e6, 1),
                "Mpoints_per_s_incl_files": round(n / (b2 - b0) / 1e6, 1),
-               "input_bytes_per_point": 27, "h2d_GBps": round(27.0 * n / max(a1 - a0 - value and (n / (value * 1e6)), 1e-9) / 1e9, 1),
+               "input_bytes_per_point": 27, "h2d_GBps": round(27.0 * n / max((a1 - a0) - elapsed / args.steps, 1e-9) / 1e9, 1),
                "note": "pageable numpy inputs staged through a pinned ring (one DMA per 32 MiB chunk), bounding box computed "
                        "on the device; creating the node files in ONE directory serialises on the directory lock "
                        "(reference layout); not part of `value`"}
