@@ -415,6 +415,13 @@ int pcv_query_points(pcv_ctx* ctx, const pcv_shapes* shapes, uint32_t shape_inde
                      uint64_t capacity, int mem, double* x, double* y, double* z, uint8_t* rgb, float* intensity,
                      uint64_t* count);
 
+/* The same for ONE node: PointCloud::stream_points_for_query_in_node (src/iterator.rs:185-205) — the points of node
+ * `node` (index as pcv_octree_node) that pass the shape and the interval, in file order. ParallelIterator hands the nodes
+ * of nodes_in_location to its workers one by one; a veneer that keeps that structure calls this per node. */
+int pcv_query_node_points(pcv_ctx* ctx, const pcv_shapes* shapes, uint32_t shape_index, pcv_octree* tree, uint64_t node,
+                          const double* interval, uint64_t capacity, int mem, double* x, double* y, double* z, uint8_t* rgb,
+                          float* intensity, uint64_t* count);
+
 /* The `/nodes_data` reply blob of octree_web_viewer (octree_web_viewer/src/backend.rs:90-177) for a list of nodes:
  * per node min xyz (3 x f64 LE), edge (f64), num_points (u32), bytes per coordinate (u8), pad to 8, raw .xyz, pad
  * to 8, raw .rgb, pad to 8. *needed = blob size; the blob is written when out != NULL and capacity >= *needed. */

@@ -160,6 +160,8 @@ _SIGNATURES = {
                                        C.POINTER(C.c_uint64)]),
     "pcv_query_points": (C.c_int, [_vp, _vp, C.c_uint32, _vp, C.POINTER(C.c_double), C.c_uint64, C.c_int, _vp, _vp, _vp, _vp,
                                    _vp, C.POINTER(C.c_uint64)]),
+    "pcv_query_node_points": (C.c_int, [_vp, _vp, C.c_uint32, _vp, C.c_uint64, C.POINTER(C.c_double), C.c_uint64, C.c_int, _vp, _vp,
+                                        _vp, _vp, _vp, C.POINTER(C.c_uint64)]),
     "pcv_octree_nodes_blob": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.c_uint64, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
     "pcv_transform_points": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(Points), _vp, _vp, _vp]),
 }

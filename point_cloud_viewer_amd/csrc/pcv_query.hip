@@ -1101,9 +1101,11 @@ extern "C" int pcv_transform_points(pcv_ctx* ctx, const double iso[7], const pcv
 }
 
 // N3: nodes_in_location + per-point culling + stable compaction for one location in a handful of launches.
-extern "C" int pcv_query_points(pcv_ctx* ctx, const pcv_shapes* shapes, uint32_t shape_index, pcv_octree* tree,
-                                const double* interval, uint64_t capacity, int mem, double* x, double* y, double* z,
-                                uint8_t* rgb, float* intensity, uint64_t* count) {
+// only_node == nullptr: every node PointCloud::nodes_in_location reports for the shape; otherwise that one node
+// (stream_points_for_query_in_node, src/iterator.rs:185-205: the node's points through the FilteredIterator)
+static int query_points_impl(pcv_ctx* ctx, const pcv_shapes* shapes, uint32_t shape_index, pcv_octree* tree,
+                             const uint64_t* only_node, const double* interval, uint64_t capacity, int mem, double* x, double* y,
+                             double* z, uint8_t* rgb, float* intensity, uint64_t* count) {
   if (!ctx) return PCV_E_INVALID;
   if (!shapes || shape_index >= shapes->count || !tree || !count) return ctx->fail(PCV_E_INVALID, "bad argument");
   if (capacity && (!x || !y || !z || !rgb)) return ctx->fail(PCV_E_INVALID, "null output");
@@ -1120,6 +1122,11 @@ extern "C" int pcv_query_points(pcv_ctx* ctx, const pcv_shapes* shapes, uint32_t
   PCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   PcvScratch sc(ctx);
   const uint32_t m = tree->query->m;
+  std::vector<uint32_t> nodes;
+  if (only_node) {
+    if (*only_node >= tree->nodes.size()) return ctx->fail(PCV_E_INVALID, "bad node");
+    nodes.push_back((uint32_t)*only_node);
+  } else {
   // 1. PointCloud::nodes_in_location for this one shape: the Relation of every node cube in one dense launch
   //    (same sat() as the traversal kernel), then the breadth-first walk of NodeIdsIterator on the host.
   uint8_t* d_rel;
@@ -1132,7 +1139,6 @@ extern "C" int pcv_query_points(pcv_ctx* ctx, const pcv_shapes* shapes, uint32_t
   std::vector<uint8_t> rel(m);
   PCV_HIP_CHECK(ctx, hipMemcpyAsync(rel.data(), d_rel, m, hipMemcpyDeviceToHost, ctx->stream));
   PCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  std::vector<uint32_t> nodes;
   nodes.reserve(m);
   {
     std::vector<uint32_t> queue;
@@ -1146,6 +1152,7 @@ extern "C" int pcv_query_points(pcv_ctx* ctx, const pcv_shapes* shapes, uint32_t
         if ((tree->query->h_child_mask[cur] >> ci) & 1) queue.push_back(c++);
       nodes.push_back(cur);
     }
+  }
   }
   const uint32_t nn = (uint32_t)nodes.size();
   // 2. one job per non-empty node, in traversal order
@@ -1213,6 +1220,17 @@ extern "C" int pcv_query_points(pcv_ctx* ctx, const pcv_shapes* shapes, uint32_t
   }
   ctx->prof_resolve();
   return PCV_OK;
+}
+
+extern "C" int pcv_query_points(pcv_ctx* ctx, const pcv_shapes* shapes, uint32_t shape_index, pcv_octree* tree,
+                                const double* interval, uint64_t capacity, int mem, double* x, double* y, double* z,
+                                uint8_t* rgb, float* intensity, uint64_t* count) {
+  return query_points_impl(ctx, shapes, shape_index, tree, nullptr, interval, capacity, mem, x, y, z, rgb, intensity, count);
+}
+extern "C" int pcv_query_node_points(pcv_ctx* ctx, const pcv_shapes* shapes, uint32_t shape_index, pcv_octree* tree,
+                                     uint64_t node, const double* interval, uint64_t capacity, int mem, double* x, double* y,
+                                     double* z, uint8_t* rgb, float* intensity, uint64_t* count) {
+  return query_points_impl(ctx, shapes, shape_index, tree, &node, interval, capacity, mem, x, y, z, rgb, intensity, count);
 }
 
 // N4: the /nodes_data reply blob of octree_web_viewer (octree_web_viewer/src/backend.rs:90-177): per node

@@ -583,19 +583,24 @@ class OctreeResult:
                                                       keep.ctypes.data, C.byref(kept)))
         return keep, kept.value
 
-    def query_points(self, shapes, shape_index, interval=None, capacity=None):
+    def query_points(self, shapes, shape_index, interval=None, capacity=None, node=None):
         """All points of the octree inside shape `shape_index` (and the intensity interval): dict of numpy arrays
-        x, y, z (decoded f64), rgb (n x 3), intensity (or None), in (node traversal, point) order."""
-        cap = self.num_points if capacity is None else int(capacity)
+        x, y, z (decoded f64), rgb (n x 3), intensity (or None), in (node traversal, point) order. With `node` only
+        that node's points (stream_points_for_query_in_node)."""
+        cap = (self.num_points if node is None else self.node(node).num_points) if capacity is None else int(capacity)
         x, y, z = np.zeros(cap), np.zeros(cap), np.zeros(cap)
         rgb = np.zeros((cap, 3), dtype=np.uint8)
         has_int = bool(self.lib.pcv_octree_has_intensity(self.handle))
         inten = np.zeros(cap, dtype=np.float32) if has_int else None
         iv = (C.c_double * 2)(*[float(v) for v in interval]) if interval is not None else None
         count = C.c_uint64()
-        self.ctx._check(self.lib.pcv_query_points(self.ctx.handle, shapes.handle, shape_index, self.handle, iv, cap,
-                                                  L.MEM_HOST, x.ctypes.data, y.ctypes.data, z.ctypes.data, rgb.ctypes.data,
-                                                  inten.ctypes.data if has_int else None, C.byref(count)))
+        outs = (cap, L.MEM_HOST, x.ctypes.data, y.ctypes.data, z.ctypes.data, rgb.ctypes.data,
+                inten.ctypes.data if has_int else None, C.byref(count))
+        if node is None:
+            self.ctx._check(self.lib.pcv_query_points(self.ctx.handle, shapes.handle, shape_index, self.handle, iv, *outs))
+        else:
+            self.ctx._check(self.lib.pcv_query_node_points(self.ctx.handle, shapes.handle, shape_index, self.handle, int(node),
+                                                           iv, *outs))
         n = min(count.value, cap)
         return dict(count=count.value, x=x[:n], y=y[:n], z=z[:n], rgb=rgb[:n], intensity=inten[:n] if has_int else None)
 

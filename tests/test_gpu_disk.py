@@ -94,6 +94,13 @@ def test_query_points_on_an_octree_opened_from_disk(ctx, disk_scene):
     keep, kept = tree.cull_node_points(prepared, 6, big)
     want = O.cull_points(kinds[6][0], kinds[6][1], px, py, pz)
     assert np.array_equal(keep, want) and kept == int(want.sum())
+    # stream_points_for_query_in_node: that node's points through the FilteredIterator, with an interval
+    inten = np.frombuffer(nd["intensity"], dtype=np.float32)
+    wi = O.cull_points(kinds[6][0], kinds[6][1], px, py, pz, inten, (15.0, 150.0)).astype(bool)
+    got = tree.query_points(prepared, 6, interval=(15.0, 150.0), node=big)
+    assert got["count"] == int(wi.sum()) and np.array_equal(got["x"], px[wi]) and np.array_equal(got["z"], pz[wi])
+    assert np.array_equal(got["rgb"].reshape(-1, 3), np.frombuffer(nd["rgb"], dtype=np.uint8).reshape(-1, 3)[wi])
+    assert np.array_equal(got["intensity"], inten[wi])
     tree.free()
 
 
