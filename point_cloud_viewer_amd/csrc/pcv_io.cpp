@@ -11,8 +11,10 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <atomic>
 #include <cstring>
 #include <mutex>
@@ -181,20 +183,21 @@ static int write_nodes(pcv_octree* t, const char* directory, uint32_t min_level,
   } else if (!t->host_valid) {
     rc = ctx->fail(PCV_E_INVALID, "this octree was opened from a directory and its node files were not loaded; there is nothing to write");
   }
-  // event k of a blob covers bytes [bytes * k / chunks, bytes * (k + 1) / chunks)
+  // chunk k of a blob covers bytes [bytes * k / chunks, bytes * (k + 1) / chunks). The calling thread waits for the
+  // events in order and publishes how many chunks have arrived; the writers only read that counter (no HIP call in a
+  // writer thread: the first HIP call of a new thread costs milliseconds of runtime set-up).
   const uint64_t chunks = std::max<uint64_t>(1, blobs[0].ev.size());
-  std::vector<std::atomic<int>> arrived(3 * chunks);
-  for (auto& a : arrived) a.store(0);
+  std::atomic<uint64_t> arrived{stream_down ? 0 : chunks};
+  std::atomic<int> download_failed{0};
   auto wait_for = [&](int which, uint64_t end_byte) -> bool {  // everything before end_byte of blob `which` is on the host
     if (!stream_down || end_byte == 0) return true;
     const Blob& b = blobs[which];
-    if (b.ev.empty()) return true;
-    uint64_t k = 0;
-    while (k + 1 < b.ev.size() && b.bytes * (k + 1) / b.ev.size() < end_byte) ++k;
-    for (uint64_t j = 0; j <= k; ++j) {
-      if (arrived[which * chunks + j].load(std::memory_order_acquire)) continue;
-      if (hipEventSynchronize(b.ev[j]) != hipSuccess) return false;
-      arrived[which * chunks + j].store(1, std::memory_order_release);
+    uint64_t need = 1;  // chunks that must have arrived
+    while (need < chunks && b.bytes * need / chunks < end_byte) ++need;
+    for (int spin = 0; arrived.load(std::memory_order_acquire) < need; ++spin) {
+      if (download_failed.load()) return false;
+      if (spin > 64) std::this_thread::sleep_for(std::chrono::microseconds(20));
+      else std::this_thread::yield();
     }
     return true;
   };
@@ -202,13 +205,13 @@ static int write_nodes(pcv_octree* t, const char* directory, uint32_t min_level,
   unsigned nthreads = std::thread::hardware_concurrency();
   if (nthreads == 0) nthreads = 4;
   if (nthreads > 32) nthreads = 32;
+  if (const char* e = getenv("PCV_WRITER_THREADS")) nthreads = (unsigned)std::max(1, atoi(e));  // experiments
   if (nthreads > count) nthreads = count ? (unsigned)count : 1;
   std::atomic<size_t> next{0};
   std::atomic<int> failed{0};
   std::string first_error;
   std::mutex err_mu;
   auto worker = [&]() {
-    (void)hipSetDevice(ctx->device);
     for (;;) {
       const size_t i = next.fetch_add(1);
       if (i >= count || failed.load()) return;
@@ -235,9 +238,23 @@ static int write_nodes(pcv_octree* t, const char* directory, uint32_t min_level,
   };
   if (!rc) {
     std::vector<std::thread> pool;
-    for (unsigned k = 1; k < nthreads; ++k) pool.emplace_back(worker);
-    worker();
+    for (unsigned k = stream_down ? 0 : 1; k < nthreads; ++k) pool.emplace_back(worker);
+    if (stream_down) {  // this thread follows the download and publishes its progress
+      for (uint64_t k = 0; k < chunks; ++k) {
+        bool ok = true;
+        for (Blob& b : blobs)
+          if (k < b.ev.size() && hipEventSynchronize(b.ev[k]) != hipSuccess) ok = false;
+        if (!ok) {
+          download_failed.store(1);
+          break;
+        }
+        arrived.store(k + 1, std::memory_order_release);
+      }
+    } else {
+      worker();
+    }
     for (auto& th : pool) th.join();
+    if (download_failed.load()) rc = ctx->fail(PCV_E_HIP, "blob download failed");
   }
   if (stream_down) {
     if (hipStreamSynchronize(ctx->stream) != hipSuccess && !rc) rc = ctx->fail(PCV_E_HIP, "blob download failed");
