@@ -39,6 +39,6 @@ if len(sys.argv) > 2 and sys.argv[1] == "--child":
           f"download_and_write_ms={best[2] * 1e3:.1f} Mpts/s={n / best[0] / 1e6:.1f}")
 else:
     n = sys.argv[1] if len(sys.argv) > 1 else "100000000"
-    for th in ("8", "16", "32", "64", "128"):
+    for th in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("2", "4", "6", "8", "12", "32")):
         env = dict(os.environ, PCV_WRITER_THREADS=th)
         subprocess.run([sys.executable, os.path.abspath(__file__), "--child", n], env=env)
