@@ -450,11 +450,18 @@ def main():
             if insts:
                 g = insts["f64_valu_insts_per_point"] * n / (view["avg_launch_ms"] * 1e-3) / 1e9
                 roofline.update({"achieved": round(g, 1), "frac": round(g / F64_VALU_PEAK_GINST, 4),
-                                 "valu_insts_per_point": insts["valu_insts_per_point"], "f64_share": insts["f64_share"],
-                                 "source": insts_src})
+                                 "valu_insts_per_point": insts["valu_insts_per_point"],
+                                 "f64_arithmetic_insts_per_point": insts["f64_valu_insts_per_point"],
+                                 "f64_arithmetic_share_of_valu": insts["f64_share"],
+                                 "f64_pipe_share_static_isa": insts.get("f64_share_static_isa"),
+                                 "source": insts_src + " (SQ_INSTS_VALU_{ADD,MUL,FMA}_F64 of a rocprofv3 --pmc pass of "
+                                                       "the same command; compares / min / max / conversions also issue "
+                                                       "on the f64 pipe and are only in the static share)"})
             else:
                 roofline.update({"achieved": None, "frac": None,
                                  "source": "no SQ-counter pass of this round found (tools/profile_bench.sh)"})
+            roofline["traffic"] = traffic
+            roofline["traffic_source"] = traffic_src
             roofline["hbm_view"] = dict(view, traffic=traffic, traffic_source=traffic_src)
             # the largest HBM-bound kernel next to it
             rest = {k: v for k, v in timed.items() if k not in VALU_F64_BOUND and k in ALGO_BYTES}

@@ -29,7 +29,15 @@ def main():
                    stdout=subprocess.DEVNULL)
     mix = json.load(open(mix_path))["kernels"] if os.path.exists(mix_path) else {}
     per = {}
-    for row in csv.DictReader(open(a.tag + "_f64.csv")):
+    def rows(path):
+        """kernel names may contain commas (template arguments): split the numeric columns off from the right"""
+        lines = open(path).read().splitlines()
+        head = lines[0].split(",")
+        for line in lines[1:]:
+            parts = line.rsplit(",", len(head) - 1)
+            yield dict(zip(head, parts))
+
+    for row in rows(a.tag + "_f64.csv"):
         name = row["kernel"].split("<")[0]
         waves = float(row["SQ_WAVES"]) or 1.0
         valu = float(row["SQ_INSTS_VALU"])
