@@ -725,6 +725,7 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
   // sample stride: every 32nd point (>= 3 000 sample points per full node at the reference's capacity); small forced
   // builds (tests) sample more densely
   uint64_t stride = 32;
+  if (const char* e = getenv("PCV_SPEC_STRIDE")) stride = (uint64_t)std::max(1, atoi(e));  // experiments
   while (stride > 1 && n / stride < 4096) stride >>= 1;
   const uint64_t ns = n / stride;
   if (ns == 0) return PCV_OK;

@@ -121,13 +121,20 @@ __global__ __launch_bounds__(BLOCK) void spec_encode_kernel(
   uint32_t d1 = 0;
   int L = 0;
   uint32_t rec = walk[0];
-  if (BIN) {  // raw (not routed) input only
+  if (BIN) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool in = i < n;
     uint32_t key = kSpecClasses - 1;  // padding lanes go last
     if (in) {
-      const double qx = x[i], qy = y[i], qz = z[i];
-      sx[tid] = qx, sy[tid] = qy, sz[tid] = qz;
+      double qx, qy, qz;
+      if (routed.oct) {  // routed input: the position the sending rank held after level 1 (decode of the level-1 codes)
+        double t0, t1, t2, t3, t4, t5;
+        uint32_t dd;
+        (void)pcv_chain_start(lv, routed, x, y, z, i, qx, qy, qz, t0, t1, t2, t3, t4, t5, dd);
+      } else {
+        qx = x[i], qy = y[i], qz = z[i];
+        sx[tid] = qx, sy[tid] = qy, sz[tid] = qz;
+      }
       // cell of the 128^3 grid over the root cube (NaN -> 0, out of range clamps) -> predicted depth (1..8, 8 = deeper)
       const uint32_t ix = (uint32_t)fminf(fmaxf((float)(qx - lv.root_min[0]) * cells_per_unit, 0.f), 127.f);
       const uint32_t iy = (uint32_t)fminf(fmaxf((float)(qy - lv.root_min[1]) * cells_per_unit, 0.f), 127.f);
@@ -173,8 +180,15 @@ __global__ __launch_bounds__(BLOCK) void spec_encode_kernel(
     const int j = perm[tid];
     i = (uint64_t)blockIdx.x * BLOCK + j;
     if (i >= n) return;
-    px = sx[j], py = sy[j], pz = sz[j];
-    mx = lv.root_min[0], my = lv.root_min[1], mz = lv.root_min[2];
+    if (routed.oct) {  // wave-uniform
+      if (pcv_chain_start(lv, routed, x, y, z, i, px, py, pz, mx, my, mz, vx, vy, vz, d1) == 2 && !(rec & PCV_SPEC_LEAF)) {
+        L = 1;
+        rec = walk[(rec & PCV_SPEC_INDEX_MASK) + d1];
+      }
+    } else {
+      px = sx[j], py = sy[j], pz = sz[j];
+      mx = lv.root_min[0], my = lv.root_min[1], mz = lv.root_min[2];
+    }
   } else {
     if (i >= n) return;
     if (pcv_chain_start(lv, routed, x, y, z, i, px, py, pz, mx, my, mz, vx, vy, vz, d1) == 2 && !(rec & PCV_SPEC_LEAF)) {
@@ -498,7 +512,7 @@ void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* w
     const char* e = getenv("PCV_SPEC_BIN");
     return e ? atoi(e) : 512;
   }();
-  const bool bin = bin_mode != 0 && !routed.oct && depth_grid != nullptr;
+  const bool bin = bin_mode != 0 && depth_grid != nullptr;
   if (!bin)
     launch_spec_encode_t<false, 256>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, kept, inten_bits,
                                      depth_grid);

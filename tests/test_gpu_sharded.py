@@ -44,6 +44,22 @@ def test_world_size_one_over_rccl():
         r = b.build(0.001, bbox, tx, ty, tz, trgb)
         _same(r.gather(0), O.build_closed(0.001, bmin, bmax, x, y, z, rgb, threads=4))
         assert r.stage_ms["exchange"] >= 0
+        # 5 M points: the routed input takes the single-chain build (level-1 chain state in, depth-binned chain pass),
+        # once per ownership mode
+        x, y, z, rgb, bmin, bmax = synthetic.gaussian_clusters(5_000_000, seed=29, num_clusters=12, extent=500.0,
+                                                               sigma_range=(0.3, 9.0))
+        want = O.build_closed(0.001, bmin, bmax, x, y, z, rgb, threads=8)
+        tx, ty, tz = (torch.from_numpy(a).cuda() for a in (x, y, z))
+        trgb = torch.from_numpy(rgb).cuda()
+        for mode in ("buckets", "octants"):
+            b = pdist.ShardedOctreeBuilder(ctx, dist, dev, shard_mode=mode)
+            bbox = b.global_bbox(tx, ty, tz)
+            r = b.build(0.001, bbox, tx, ty, tz, trgb)
+            assert r.local.build_info()["single_chain"], r.local.build_info()
+            ex = r.exchange_info()
+            assert ex["shard_mode"] == mode and ex["bytes_per_row"] == 16 and ex["points_owned_per_rank"] == [5_000_000]
+            _same(r.gather(0), want)
+            r.free()
     finally:
         dist.destroy_process_group()
 
