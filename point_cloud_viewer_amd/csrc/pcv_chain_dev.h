@@ -159,6 +159,38 @@ __device__ __forceinline__ uint32_t pcv_chain_level(uint32_t enc, double ep, dou
   }
 }
 
+// The same level in two halves, for callers that want the digit BEFORE the (long) encode/decode arithmetic — the
+// single-chain pass issues the load of the child's walk record right after the digit, so that its latency hides behind
+// the ~55 f64 operations of the rest of the level. Same operations, same order per coordinate, same results.
+__device__ __forceinline__ uint32_t pcv_chain_digit(double e_parent, double px, double py, double pz, double mx, double my,
+                                                    double mz) {
+  const double cx = (mx + (mx + e_parent)) / 2.0, cy = (my + (my + e_parent)) / 2.0, cz = (mz + (mz + e_parent)) / 2.0;
+  return (px > cx ? 4u : 0u) | (py > cy ? 2u : 0u) | (pz > cz ? 1u : 0u);
+}
+template <int ENC, bool GUARD>
+__device__ __forceinline__ void pcv_chain_apply_t(uint32_t d, double ec, PcvRecip ic, double& px, double& py, double& pz, double& mx,
+                                                  double& my, double& mz, double& cx, double& cy, double& cz) {
+  mx = mx + ((d & 4u) ? ec : 0.0);  // `bit as f64 * edge` is exactly e or +0.0
+  my = my + ((d & 2u) ? ec : 0.0);
+  mz = mz + ((d & 1u) ? ec : 0.0);
+  cx = pcv_encode_val<ENC, GUARD>(px, mx, ec, ic);
+  cy = pcv_encode_val<ENC, GUARD>(py, my, ec, ic);
+  cz = pcv_encode_val<ENC, GUARD>(pz, mz, ec, ic);
+  px = pcv_decode_val<ENC>(cx, mx, ec);
+  py = pcv_decode_val<ENC>(cy, my, ec);
+  pz = pcv_decode_val<ENC>(cz, mz, ec);
+}
+template <bool GUARD>
+__device__ __forceinline__ void pcv_chain_apply(uint32_t enc, uint32_t d, double ec, PcvRecip ic, double& px, double& py, double& pz,
+                                                double& mx, double& my, double& mz, double& cx, double& cy, double& cz) {
+  switch (enc) {
+    case PCV_ENC_UINT8: return pcv_chain_apply_t<PCV_ENC_UINT8, GUARD>(d, ec, ic, px, py, pz, mx, my, mz, cx, cy, cz);
+    case PCV_ENC_UINT16: return pcv_chain_apply_t<PCV_ENC_UINT16, GUARD>(d, ec, ic, px, py, pz, mx, my, mz, cx, cy, cz);
+    case PCV_ENC_FLOAT32: return pcv_chain_apply_t<PCV_ENC_FLOAT32, true>(d, ec, ic, px, py, pz, mx, my, mz, cx, cy, cz);
+    default: return pcv_chain_apply_t<PCV_ENC_FLOAT64, true>(d, ec, ic, px, py, pz, mx, my, mz, cx, cy, cz);
+  }
+}
+
 // Start of a point's chain. Raw points start at the root (returns level 1). Routed points (PcvRouted) arrive as their
 // level-1 state: the octant digit selects the level-1 cube with the same `min += bit * edge` step the chain uses, the
 // Float32 codes decode to exactly the position the sending rank held after level 1 (returns level 2, digit in d1,

@@ -203,9 +203,12 @@ __global__ __launch_bounds__(BLOCK) void spec_encode_kernel(
       kl = L; /* candidates have level >= 1 */                                                                          \
     }                                                                                                                   \
     ++L;                                                                                                                \
-    const uint32_t d = pcv_chain_level<GUARD>(lv.enc[L], lv.edge[L - 1], lv.edge[L], PcvRecip{lv.inv_edge[L], lv.inv_edge_lo[L]}, \
-                                              px, py, pz, mx, my, mz, vx, vy, vz);                                      \
-    rec = walk[(rec & PCV_SPEC_INDEX_MASK) + d];                                                                        \
+    /* the digit first, the child's record in flight while the level's encode / decode arithmetic runs */             \
+    const uint32_t d = pcv_chain_digit(lv.edge[L - 1], px, py, pz, mx, my, mz);                                         \
+    const uint32_t next = walk[(rec & PCV_SPEC_INDEX_MASK) + d];                                                        \
+    pcv_chain_apply<GUARD>(lv.enc[L], d, lv.edge[L], PcvRecip{lv.inv_edge[L], lv.inv_edge_lo[L]}, px, py, pz, mx, my, mz, vx, \
+                           vy, vz);                                                                                     \
+    rec = next;                                                                                                         \
   }
   if (lv.fast_ok && pcv_point_is_tame(px, py, pz)) {
     PCV_SPEC_WALK(false)
