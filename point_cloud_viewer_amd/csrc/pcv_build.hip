@@ -551,6 +551,8 @@ struct PcvBuild {
     uint32_t lo, count, level;
   };
   std::vector<FixRange> fix_ranges;  // sorted slots whose points replay the chain after the record sort
+  const uint32_t* spec_map_dev = nullptr;  // set: the record sort's first upsweep applies the rank map / payload patch
+  const void* spec_kept = nullptr;
   explicit PcvBuild(pcv_ctx* c) : ctx(c), sc(c) {}
 };
 
@@ -865,7 +867,18 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
   if (tt->prefix.size() > (size_t)nt.capacity) return ctx->fail(PCV_E_OOM, "node table capacity exceeded");
   std::memcpy(hp + map_off, tt->spec_map.data(), (size_t)tree.num_leaves * 4);
   PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_area + map_off, hp + map_off, (size_t)tree.num_leaves * 4, hipMemcpyHostToDevice, st));
-  pcv_launch_spec_finalize(ctx, n, (const uint32_t*)(d_area + map_off), rank, payload, kept);
+  // the rank map and the payload patch are applied by the first upsweep of the record sort (one pass over the ranks
+  // instead of two); PCV_SPEC_FUSE=0 keeps the separate finalize kernel (experiments)
+  static const bool fuse = [] {
+    const char* e = getenv("PCV_SPEC_FUSE");
+    return !e || atoi(e) != 0;
+  }();
+  if (fuse) {
+    bs->spec_map_dev = (const uint32_t*)(d_area + map_off);
+    bs->spec_kept = kept;
+  } else {
+    pcv_launch_spec_finalize(ctx, n, (const uint32_t*)(d_area + map_off), rank, payload, kept);
+  }
   // leaves whose points still have to replay the chain: contiguous once the records are sorted ([lo, hi) of the leaf)
   bs->fix_ranges.clear();
   for (uint32_t k : tt->fix_nodes) bs->fix_ranges.push_back({tt->lo[k], tt->hi[k] - tt->lo[k], (uint32_t)tt->level[k]});
@@ -873,7 +886,7 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
   // the pool hands `kept` out again only to work queued on this same stream
   ctx->stage_end(PCV_STAGE_NODE_SPLIT);
   ctx->stage_begin(PCV_STAGE_TABLE);
-  if (kept) {
+  if (kept && !bs->spec_kept) {
     sc.detach(kept);
     ctx->dev_free(kept);
   }
@@ -1447,7 +1460,11 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
   int rank_bits = 1;
   while ((1ull << rank_bits) < num_leaves) ++rank_bits;
   bool rec_in_a = true;
-  if ((rc = pcv_radix_sort_u32(ctx, rank_a, rank_b, n, 0, rank_bits, &pl, sort_scratch, &rec_in_a))) return rc;
+  if (bs->spec_map_dev)
+    rc = pcv_radix_sort_records_mapped(ctx, rank_a, rank_b, n, rank_bits, &pl, sort_scratch, bs->spec_map_dev, bs->spec_kept, &rec_in_a);
+  else
+    rc = pcv_radix_sort_u32(ctx, rank_a, rank_b, n, 0, rank_bits, &pl, sort_scratch, &rec_in_a);
+  if (rc) return rc;
   uint32_t* s_rank = rec_in_a ? rank_a : rank_b;
   const void* s_pay = rec_in_a ? (const void*)pay_a : (const void*)pay_b;
   uint32_t** s_plane = rec_in_a ? pl.in : pl.out;

@@ -15,6 +15,8 @@
 // HBM traffic per pass and key: sizeof(key) (upsweep) + 2 * sizeof(key) + 2 * payload bytes.
 #include "pcv_internal.h"
 
+#define PCV_SPEC_INDEX_MASK_SORT 0x3fffffffu  // == PCV_SPEC_INDEX_MASK (pcv_spec.h)
+
 namespace {
 
 constexpr int kBlock = 256;  // 4 waves
@@ -111,6 +113,73 @@ __global__ __launch_bounds__(kBlock) void upsweep_kernel(const KeyT* __restrict_
 #pragma unroll
     for (int w = 0; w < kWaves; ++w) s += wh[w][d];
     hist[(uint64_t)d * groups + blockIdx.x] = s;
+  }
+}
+
+// First record pass of the single-chain build: the upsweep reads every rank anyway, so it also does the "finalize"
+// work on the way — rank := map[rank] (written back in place), payload := kept codes where the map says so (bit 31),
+// payload.x := own index where the point has to replay its chain after the sort (bit 30) — and counts the digits of
+// the MAPPED ranks. One pass over the ranks instead of two (finalize + upsweep); the downsweep is the ordinary one.
+__global__ __launch_bounds__(kBlock) void upsweep_map_kernel(uint32_t* __restrict__ keys, uint64_t n, uint64_t chunk, int groups,
+                                                              int shift, uint32_t mask, uint32_t* __restrict__ hist,
+                                                              const uint32_t* __restrict__ map, uint4* __restrict__ payload,
+                                                              const uint4* __restrict__ kept) {
+  __shared__ uint32_t wh[kWaves][kRadix];
+  const int wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < kWaves * kRadix; i += kBlock) (&wh[0][0])[i] = 0;
+  __syncthreads();
+  const uint64_t begin = (uint64_t)blockIdx.x * chunk;
+  uint64_t end = begin + chunk;
+  if (end > n) end = n;
+  auto one = [&](uint64_t idx, uint32_t m) -> uint32_t {
+    if (m & (1u << 30)) {
+      reinterpret_cast<uint32_t*>(payload + idx)[0] = (uint32_t)idx;
+    } else if (m & (1u << 31)) {
+      const uint4 k = kept[idx];
+      uint4 p = payload[idx];
+      p.x = k.x, p.y = k.y, p.z = k.z;
+      payload[idx] = p;
+    }
+    return m & PCV_SPEC_INDEX_MASK_SORT;
+  };
+  uint64_t i = begin + (uint64_t)threadIdx.x * 4;
+  constexpr uint64_t kStep = (uint64_t)kBlock * 4;
+  for (; i + kStep + 4 <= end; i += 2 * kStep) {  // two 16-byte loads and their eight map lookups in flight per lane
+    uint4 v[2];
+    v[0] = *reinterpret_cast<const uint4*>(keys + i);
+    v[1] = *reinterpret_cast<const uint4*>(keys + i + kStep);
+    uint32_t m[8] = {map[v[0].x], map[v[0].y], map[v[0].z], map[v[0].w], map[v[1].x], map[v[1].y], map[v[1].z], map[v[1].w]};
+    uint32_t r[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r[k] = one(i + (k >> 2) * kStep + (k & 3), m[k]);
+    *reinterpret_cast<uint4*>(keys + i) = make_uint4(r[0], r[1], r[2], r[3]);
+    *reinterpret_cast<uint4*>(keys + i + kStep) = make_uint4(r[4], r[5], r[6], r[7]);
+    const uint64_t here = __builtin_amdgcn_ballot_w64(true);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) count_digit(wh[wave], (r[k] >> shift) & mask, here, true);
+  }
+  for (; i + 4 <= end; i += kStep) {
+    const uint4 v = *reinterpret_cast<const uint4*>(keys + i);
+    const uint32_t m[4] = {map[v.x], map[v.y], map[v.z], map[v.w]};
+    uint32_t r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = one(i + k, m[k]);
+    *reinterpret_cast<uint4*>(keys + i) = make_uint4(r[0], r[1], r[2], r[3]);
+    const uint64_t here = __builtin_amdgcn_ballot_w64(true);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) count_digit(wh[wave], (r[k] >> shift) & mask, here, true);
+  }
+  for (; i < end; ++i) {  // ragged tail (< 4 keys per lane)
+    const uint32_t r = one(i, map[keys[i]]);
+    keys[i] = r;
+    atomicAdd(&wh[wave][(r >> shift) & mask], 1u);
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < kRadix; d += kBlock) {
+    uint32_t s2 = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) s2 += wh[w][d];
+    hist[(uint64_t)d * groups + blockIdx.x] = s2;
   }
 }
 
@@ -431,7 +500,7 @@ __global__ __launch_bounds__(kBlock, kHasVec ? 3 : 4) void downsweep_rec_kernel(
 
 template <typename KeyT>
 int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int end_bit, PcvSortPayload* payload,
-               void* scratch, bool* result_in_a) {
+               void* scratch, bool* result_in_a, const uint32_t* map = nullptr, const void* kept = nullptr) {
   *result_in_a = true;
   if (n == 0 || end_bit <= begin_bit) return PCV_OK;
   if (n >= 0xffffffffull) return ctx->fail(PCV_E_INVALID, "radix sort: n must be < 2^32 - 1");
@@ -452,7 +521,11 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
     uint32_t mask = (1u << nbits) - 1u;
     KeyT* src = in_a ? a : b;
     KeyT* dst = in_a ? b : a;
-    {
+    if (map && shift == begin_bit && sizeof(KeyT) == 4 && payload && payload->vec_in) {
+      PcvProf prof(ctx, PCV_K_SPEC_FINALIZE);  // finalize fused into the first upsweep
+      hipLaunchKernelGGL(upsweep_map_kernel, dim3(g.groups), dim3(kBlock), 0, ctx->stream, (uint32_t*)src, n, g.chunk, g.groups,
+                         shift, mask, hist, map, (uint4*)(in_a ? payload->vec_in : payload->vec_out), (const uint4*)kept);
+    } else {
       PcvProf prof(ctx, sizeof(KeyT) == 8 ? PCV_K_SORT_UPSWEEP64 : PCV_K_SORT_UPSWEEP32);
       hipLaunchKernelGGL(upsweep_kernel<KeyT>, dim3(g.groups), dim3(kBlock), 0, ctx->stream, src, n, g.chunk,
                          g.groups, shift, mask, hist);
@@ -500,4 +573,10 @@ int pcv_radix_sort_u64(pcv_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint64_
 int pcv_radix_sort_u32(pcv_ctx* ctx, uint32_t* keys_a, uint32_t* keys_b, uint64_t n, int begin_bit, int end_bit,
                        PcvSortPayload* payload, void* scratch, bool* result_in_a) {
   return radix_sort<uint32_t>(ctx, keys_a, keys_b, n, begin_bit, end_bit, payload, scratch, result_in_a);
+}
+// Record sort whose first upsweep also translates the ranks through `map` and patches the payloads (single-chain build)
+int pcv_radix_sort_records_mapped(pcv_ctx* ctx, uint32_t* keys_a, uint32_t* keys_b, uint64_t n, int key_bits,
+                                  PcvSortPayload* payload, void* scratch, const uint32_t* map, const void* kept,
+                                  bool* result_in_a) {
+  return radix_sort<uint32_t>(ctx, keys_a, keys_b, n, 0, key_bits, payload, scratch, result_in_a, map, kept);
 }
