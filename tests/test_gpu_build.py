@@ -92,9 +92,10 @@ def test_degenerate_inputs(ctx):
         x = np.full(n, 2.5)
         rgb = np.arange(3 * n, dtype=np.uint8).reshape(n, 3)
         for bmin, bmax in (([0, 0, 0], [10, 10, 10]), ([2.5, 2.5, 2.5], [2.5, 2.5, 2.5])):
-            got = ctx.build(0.001, pcv.Aabb(bmin, bmax), x, x, x, rgb).to_dict()
             want = O.build_closed(0.001, np.array(bmin, float), np.array(bmax, float), x, x, x, rgb)
-            assert_same(got, want)
+            for single_chain in (None, True):  # the forced single-chain build must cope with (or hand back) the same corners
+                got = ctx.build(0.001, pcv.Aabb(bmin, bmax), x, x, x, rgb, single_chain=single_chain).to_dict()
+                assert_same(got, want)
 
 
 def test_special_coordinates_take_the_guarded_chain(ctx):
@@ -116,8 +117,9 @@ def test_special_coordinates_take_the_guarded_chain(ctx):
         for res in resolutions:
             with O.max_points_per_node(900):
                 want = O.build_closed(res, lo, hi, x, y, z, rgb, threads=4)
-            got = ctx.build(res, pcv.Aabb(lo, hi), x, y, z, rgb, max_points_per_node=900).to_dict()
-            assert_same(got, want)
+            for single_chain in (None, True):
+                got = ctx.build(res, pcv.Aabb(lo, hi), x, y, z, rgb, max_points_per_node=900, single_chain=single_chain).to_dict()
+                assert_same(got, want)
 
 
 def test_device_resident_inputs_and_computed_bbox(ctx):

@@ -29,6 +29,7 @@ CASES = [  # n, capacity, resolution, clusters, extent, sigma range, intensity, 
     (300_000, 2_000, 0.01, 5, 60.0, (0.01, 2.0), True, 4),
     (200_000, 300, 0.001, 4, 40.0, (0.005, 1.0), False, 5),
     (1_500_000, 100_000, 0.001, 3, 150.0, (0.5, 6.0), False, 6),
+    (1_300_000, 30_000, 0.001, 7, 220.0, (0.1, 7.0), True, 7),   # >= 2^20 points: depth-binned pass, with intensity
 ]
 
 
