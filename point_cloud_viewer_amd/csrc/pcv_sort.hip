@@ -13,6 +13,8 @@
 // Two downsweep kernels: keys only (u32/u64, 16 keys per lane, next tile prefetched into registers) and records
 // (u32 key + one 16-byte payload word per key, 8 per lane, + optional extra 4-byte planes).
 // HBM traffic per pass and key: sizeof(key) (upsweep) + 2 * sizeof(key) + 2 * payload bytes.
+#include <cstdlib>
+
 #include "pcv_internal.h"
 
 #define PCV_SPEC_INDEX_MASK_SORT 0x3fffffffu  // == PCV_SPEC_INDEX_MASK (pcv_spec.h)
@@ -416,7 +418,9 @@ struct RecPtrs {
   uint32_t* plane_out[8];
 };
 
-template <bool kHasVec>
+// kPrefetch: the next tile's keys and payloads are loaded into the registers the LDS staging just freed, so that the
+// loads are in flight while this tile drains through LDS to memory (as the keys-only kernel does).
+template <bool kHasVec, bool kPrefetch = false>
 __global__ __launch_bounds__(kBlock, kHasVec ? 3 : 4) void downsweep_rec_kernel(const uint32_t* __restrict__ keys_in,
                                                                   uint32_t* __restrict__ keys_out, uint64_t n,
                                                                   uint64_t chunk, int groups, int shift, int nbits,
@@ -435,10 +439,9 @@ __global__ __launch_bounds__(kBlock, kHasVec ? 3 : 4) void downsweep_rec_kernel(
   if (end > n) end = n;
   const uint32_t wbase = wave * 64 * kKpt + lane;
 
-  for (uint64_t base = begin; base < end; base += kTile) {
-    const uint32_t tile_n = (uint32_t)((end - base) < (uint64_t)kTile ? (end - base) : (uint64_t)kTile);
-    uint32_t key[kKpt];
-    uint4 vec[kHasVec ? kKpt : 1];
+  uint32_t key[kKpt];
+  uint4 vec[kHasVec ? kKpt : 1];
+  auto load_tile = [&](uint64_t base, uint32_t tile_n) {
 #pragma unroll
     for (int i = 0; i < kKpt; ++i) {
       const uint32_t li = wbase + i * 64;
@@ -446,6 +449,11 @@ __global__ __launch_bounds__(kBlock, kHasVec ? 3 : 4) void downsweep_rec_kernel(
       key[i] = valid ? keys_in[base + li] : 0u;
       if (kHasVec) vec[i] = valid ? rp.vec_in[base + li] : make_uint4(0, 0, 0, 0);
     }
+  };
+  if (kPrefetch && begin < end) load_tile(begin, (uint32_t)((end - begin) < (uint64_t)kTile ? (end - begin) : (uint64_t)kTile));
+  for (uint64_t base = begin; base < end; base += kTile) {
+    const uint32_t tile_n = (uint32_t)((end - base) < (uint64_t)kTile ? (end - base) : (uint64_t)kTile);
+    if (!kPrefetch) load_tile(base, tile_n);
     uint16_t lpos[kKpt];
     if (tile_n == (uint32_t)kTile)
       wave_rank_all<kKpt, uint32_t, true>(S, wave, wbase, tile_n, key, shift, mask, lpos, nbits);
@@ -461,6 +469,10 @@ __global__ __launch_bounds__(kBlock, kHasVec ? 3 : 4) void downsweep_rec_kernel(
         skeys[p] = key[i];
         if (kHasVec) svec[p] = vec[i];
       }
+    }
+    if (kPrefetch) {  // the key / payload registers are free: fetch the next tile while this one drains
+      const uint64_t nbase = base + kTile;
+      if (nbase < end) load_tile(nbase, (uint32_t)((end - nbase) < (uint64_t)kTile ? (end - nbase) : (uint64_t)kTile));
     }
     __syncthreads();
     uint32_t gidx[kKpt];
@@ -547,8 +559,15 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
         rp.plane_in[w] = in_a ? payload->in[w] : payload->out[w];
         rp.plane_out[w] = in_a ? payload->out[w] : payload->in[w];
       }
+      static const bool prefetch = [] {
+        const char* e = getenv("PCV_REC_PREFETCH");
+        return e && atoi(e) != 0;
+      }();
       PcvProf prof(ctx, PCV_K_SORT_DOWNSWEEP_REC);
-      if (payload->vec_in)
+      if (payload->vec_in && prefetch)
+        hipLaunchKernelGGL((downsweep_rec_kernel<true, true>), dim3(g.groups), dim3(kBlock), 0, ctx->stream, (const uint32_t*)src,
+                           (uint32_t*)dst, n, g.chunk, g.groups, shift, nbits, hist, totals, rp);
+      else if (payload->vec_in)
         hipLaunchKernelGGL(downsweep_rec_kernel<true>, dim3(g.groups), dim3(kBlock), 0, ctx->stream, (const uint32_t*)src,
                            (uint32_t*)dst, n, g.chunk, g.groups, shift, nbits, hist, totals, rp);
       else
