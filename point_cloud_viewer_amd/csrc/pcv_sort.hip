@@ -560,8 +560,8 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
         rp.plane_out[w] = in_a ? payload->out[w] : payload->in[w];
       }
       static const bool prefetch = [] {
-        const char* e = getenv("PCV_REC_PREFETCH");
-        return e && atoi(e) != 0;
+        const char* e = getenv("PCV_REC_PREFETCH");  // 0 = the unpipelined kernel (experiments)
+        return !e || atoi(e) != 0;
       }();
       PcvProf prof(ctx, PCV_K_SORT_DOWNSWEEP_REC);
       if (payload->vec_in && prefetch)
