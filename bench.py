@@ -46,6 +46,7 @@ ALGO_BYTES = {
     "spec_encode_kernel": 24.0 + 3.0 + 20.0,  # single-chain pass: read xyz + rgb, write rank + 16-byte payload (+ kept codes of ~10 %)
     "rank_hist_kernel": 4.0,        # read ranks
     "spec_finalize_kernel": 8.0,    # rank read + write (+ payload patch of the points that take their kept codes)
+    "upsweep_map_kernel": 8.0,      # the same fused into the record sort's first histogram pass
 }
 VALU_F64_BOUND = ("leaf_encode_kernel", "chain_keys_kernel", "spec_encode_kernel")
 

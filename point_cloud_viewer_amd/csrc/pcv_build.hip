@@ -228,7 +228,7 @@ static const char* kKernelNames[PCV_K_COUNT] = {
     "upsweep_kernel<u32>", "downsweep_kernel<u32>", "promote_settle_kernel", "downsweep_rec_kernel", "cull_nodes_kernel",
     "visible_nodes_kernel", "nodes_in_location_kernel", "cull_points_kernel", "transform_points_kernel",
     "query_compact_kernel", "route_bucket_kernel", "partition_count_kernel", "partition_scatter_kernel",
-    "promote_climb_kernel", "spec_encode_kernel", "rank_hist_kernel", "spec_finalize_kernel", "spec_replay_kernel"};
+    "promote_climb_kernel", "spec_encode_kernel", "rank_hist_kernel", "spec_finalize_kernel", "spec_replay_kernel", "upsweep_map_kernel"};
 static_assert(sizeof(kKernelNames) / sizeof(kKernelNames[0]) == PCV_K_COUNT, "kernel name table out of sync");
 
 extern "C" int pcv_ctx_set_profiling(pcv_ctx* ctx, int enabled) {

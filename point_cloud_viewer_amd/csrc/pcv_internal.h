@@ -87,6 +87,7 @@ enum PcvKernelId {
   PCV_K_RANK_HIST,
   PCV_K_SPEC_FINALIZE,
   PCV_K_SPEC_REPLAY,
+  PCV_K_SORT_UPSWEEP_MAP,
   PCV_K_COUNT
 };
 

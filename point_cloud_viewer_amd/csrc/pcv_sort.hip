@@ -534,7 +534,7 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
     KeyT* src = in_a ? a : b;
     KeyT* dst = in_a ? b : a;
     if (map && shift == begin_bit && sizeof(KeyT) == 4 && payload && payload->vec_in) {
-      PcvProf prof(ctx, PCV_K_SPEC_FINALIZE);  // finalize fused into the first upsweep
+      PcvProf prof(ctx, PCV_K_SORT_UPSWEEP_MAP);  // finalize fused into the first upsweep
       hipLaunchKernelGGL(upsweep_map_kernel, dim3(g.groups), dim3(kBlock), 0, ctx->stream, (uint32_t*)src, n, g.chunk, g.groups,
                          shift, mask, hist, map, (uint4*)(in_a ? payload->vec_in : payload->vec_out), (const uint4*)kept);
     } else {
