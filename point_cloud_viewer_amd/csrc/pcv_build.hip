@@ -292,6 +292,10 @@ extern "C" int pcv_ctx_create(int device, void* stream, pcv_ctx** out) {
       delete c;
       return PCV_E_HIP;
     }
+  if (hipEventCreateWithFlags(&c->spec_ev, hipEventDisableTiming) != hipSuccess) {
+    delete c;
+    return PCV_E_HIP;
+  }
   if (hipEventCreateWithFlags(&c->xev, hipEventDisableTiming) != hipSuccess) {
     delete c;
     return PCV_E_HIP;
@@ -318,6 +322,7 @@ extern "C" void pcv_ctx_destroy(pcv_ctx* ctx) {
   for (auto& e : ctx->ev)
     if (e) (void)hipEventDestroy(e);
   if (ctx->xev) (void)hipEventDestroy(ctx->xev);
+  if (ctx->spec_ev) (void)hipEventDestroy(ctx->spec_ev);
   for (int k = 0; k < PCV_NUM_STAGES; ++k) {
     if (ctx->stage_b[k]) (void)hipEventDestroy(ctx->stage_b[k]);
     if (ctx->stage_e[k]) (void)hipEventDestroy(ctx->stage_e[k]);
@@ -744,129 +749,117 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
   ctx->stage_begin(PCV_STAGE_CHAIN_KEYS);
   // The sample keys cover 14 levels first (two radix passes and a third of the chain less than full depth); a sample
   // tree that wants to go deeper is keyed again at full depth.
-  constexpr uint32_t kPackFirst = 8192;  // nodes fetched together with the counters in one copy
-  uint8_t* d_pack;
-  if ((rc = sc.get(&d_pack, kPcvPackHeader + ((size_t)nt.capacity + 8) * sizeof(PcvPackedNode)))) return rc;
-  if ((rc = ctx->pinned_spec_reserve(kPcvPackHeader + (size_t)nt.capacity * sizeof(PcvPackedNode)))) return rc;
-  uint32_t ms = 0;
-  const uint8_t* packed_host = nullptr;
+  // The predicted tree is built on the device (sample split -> spec_tree kernels): the one chain pass starts without a
+  // host round trip, and the host mirrors the tree (one small asynchronous copy) while that pass runs.
+  constexpr uint32_t kFirst = 16384;  // T'' nodes mirrored by the first copy (a 100 M-point tree has ~7 500)
+  const size_t tcap = 1 + 8 * (size_t)nt.capacity;  // T'' nodes at most
+  uint32_t *d_ord, *d_walk, *d_sparent, *d_info, *d_counts, *d_map;
+  uint8_t* d_slevel;
+  if ((rc = sc.get(&d_ord, nt.capacity)) || (rc = sc.get(&d_walk, tcap)) || (rc = sc.get(&d_sparent, tcap)) ||
+      (rc = sc.get(&d_slevel, tcap)) || (rc = sc.get(&d_info, 64)) || (rc = sc.get(&d_counts, tcap)) || (rc = sc.get(&d_map, tcap)))
+    return rc;
+  uint32_t* rank = (uint32_t*)bs->keys_a;
+  uint4 *payload, *kept;  // kept codes: always provided (whether any node is a candidate is only known on the device)
+  if ((rc = sc.get(&payload, n)) || (rc = sc.get(&kept, n))) return rc;
+  uint32_t* inten_bits = t->has_intensity ? (uint32_t*)bs->keys_a + n : nullptr;
+  uint8_t* depth_grid = nullptr;
+  if (n >= (1u << 20) && (rc = sc.get(&depth_grid, pcv_spec_depth_grid_bytes()))) return rc;  // small builds: not worth a 2 MiB fill
+  const size_t h_walk = 256, h_parent = h_walk + (size_t)kFirst * 4, h_level = h_parent + (size_t)kFirst * 4;
+  const size_t h_first_bytes = h_level + kFirst;
+  if ((rc = ctx->pinned_spec_reserve(h_first_bytes + 256))) return rc;
+  const double upper = (double)sp.cap * (1.0 + sp.delta) / sp.scale;
+  PcvSpecTree tree;
+  uint32_t info[4] = {0, 0, 0, 0};
+  uint64_t* small_partner = nullptr;
   int sample_levels = full_levels < 14 ? full_levels : 14;
   for (;;) {
+    // The sample keys cover 14 levels first (two radix passes and a third of the chain less than full depth); a sample
+    // tree that wants to go deeper is keyed again at full depth.
     lv.nlevels = sample_levels;
-    pcv_launch_chain_keys(ctx, lv, ns, stride, d.x, d.y, d.z, bs->keys_a, false, d.routed);
+    // keys_a doubles as the rank array of the chain pass below: a second round must not start before the first
+    // round's pass is done with it — same stream, so it is ordered
+    uint64_t* skeys_a = bs->keys_b;  // the sample keys (and their sort partner) live in keys_b: 2 x n / 32 x 8 B of its 8 n
+    const uint64_t soff = ((ns + 31) & ~31ull) + 32;  // keeps the partner 256-byte aligned
+    uint64_t* skeys_b = bs->keys_b + soff;
+    if (soff + ns > n) {  // tiny forced builds sample every point: the partner gets its own buffer
+      if (!small_partner && (rc = sc.get(&small_partner, ns + 32))) return rc;
+      skeys_b = small_partner;
+    }
+    pcv_launch_chain_keys(ctx, lv, ns, stride, d.x, d.y, d.z, skeys_a, false, d.routed);
     bool in_a = true;
-    if ((rc = pcv_radix_sort_u64(ctx, bs->keys_a, bs->keys_b, ns, 3 * (PCV_MAX_KEY_LEVELS - sample_levels), 3 * PCV_MAX_KEY_LEVELS,
+    if ((rc = pcv_radix_sort_u64(ctx, skeys_a, skeys_b, ns, 3 * (PCV_MAX_KEY_LEVELS - sample_levels), 3 * PCV_MAX_KEY_LEVELS,
                                  nullptr, bs->sort_scratch, &in_a)))
       return rc;
-    pcv_launch_node_split(ctx, nt, in_a ? bs->keys_a : bs->keys_b, false, (uint32_t)ns, lv, params->resolution,
+    pcv_launch_node_split(ctx, nt, in_a ? skeys_a : skeys_b, false, (uint32_t)ns, lv, params->resolution,
                           pcv_spec_sample_threshold(sp), sp.force_mask);
-    pcv_launch_pack_node_table(ctx, nt, d_pack);
-    // counters + the first kPackFirst nodes in ONE copy and ONE synchronisation; the rest (big trees) in a second one
+    pcv_launch_spec_tree(ctx, nt, upper, sp.force_mask, d_ord, d_walk, d_sparent, d_slevel, d_info);
     uint8_t* hs = (uint8_t*)ctx->pinned_spec;
-    const uint32_t first_nodes = nt.capacity < kPackFirst ? nt.capacity : kPackFirst;
-    PCV_HIP_CHECK(ctx, hipMemcpyAsync(hs, d_pack, kPcvPackHeader + (size_t)first_nodes * sizeof(PcvPackedNode),
-                                      hipMemcpyDeviceToHost, st));
-    PCV_HIP_CHECK(ctx, hipStreamSynchronize(st));
-    uint32_t counters[64];
-    std::memcpy(counters, hs, sizeof(counters));
-    if (counters[1] & 2u) return PCV_OK;  // table capacity: let the exact pipeline report it
-    if (counters[1] & 1u) {               // deeper than the sample keys
+    const size_t first = tcap < kFirst ? tcap : kFirst;
+    PCV_HIP_CHECK(ctx, hipMemcpyAsync(hs, d_info, 16, hipMemcpyDeviceToHost, st));
+    PCV_HIP_CHECK(ctx, hipMemcpyAsync(hs + h_walk, d_walk, first * 4, hipMemcpyDeviceToHost, st));
+    PCV_HIP_CHECK(ctx, hipMemcpyAsync(hs + h_parent, d_sparent, first * 4, hipMemcpyDeviceToHost, st));
+    PCV_HIP_CHECK(ctx, hipMemcpyAsync(hs + h_level, d_slevel, first, hipMemcpyDeviceToHost, st));
+    PCV_HIP_CHECK(ctx, hipEventRecord(ctx->spec_ev, st));
+    PCV_HIP_CHECK(ctx, hipMemsetAsync(d_counts, 0, tcap * 4, st));
+    ctx->stage_end(PCV_STAGE_CHAIN_KEYS);
+
+    // ---- the one chain pass (queued before the host has seen the tree) ----
+    ctx->stage_begin(PCV_STAGE_LEAF_ENCODE);
+    lv.nlevels = full_levels;
+    pcv_launch_spec_encode(ctx, lv, d_walk, n, d.x, d.y, d.z, d.routed, d.color, d.color_stride, d.intensity, rank, payload, kept,
+                           inten_bits, depth_grid);
+    ctx->stage_end(PCV_STAGE_LEAF_ENCODE);
+
+    // ---- meanwhile: the host's view of the tree ----
+    PCV_HIP_CHECK(ctx, hipEventSynchronize(ctx->spec_ev));
+    std::memcpy(info, hs, sizeof(info));
+    if (info[1] & 2u) return PCV_OK;  // table capacity: let the exact pipeline report it
+    if (info[1] & 1u) {               // deeper than the sample keys
       if (sample_levels < full_levels) {
         sample_levels = full_levels;
+        ctx->stage_begin(PCV_STAGE_CHAIN_KEYS);
         continue;
       }
       return PCV_OK;  // deeper than one key word: the exact pipeline (deep path) takes it
     }
-    ms = counters[0];
-    if (ms > first_nodes) {
-      const size_t done = kPcvPackHeader + (size_t)first_nodes * sizeof(PcvPackedNode);
-      PCV_HIP_CHECK(ctx, hipMemcpyAsync(hs + done, d_pack + done, (size_t)(ms - first_nodes) * sizeof(PcvPackedNode),
-                                        hipMemcpyDeviceToHost, st));
+    const uint32_t tn = info[0];
+    if (tn <= first) {
+      if (!pcv_spec_tree_from_walk((const uint32_t*)(hs + h_walk), (const uint32_t*)(hs + h_parent), hs + h_level, tn, &tree))
+        return ctx->fail(PCV_E_HIP, "single-chain build: inconsistent predicted tree");
+    } else {  // a big tree: fetch all of it (queued behind the chain pass; 500 M+ points)
+      std::vector<uint32_t> w(tn), pr(tn);
+      std::vector<uint8_t> lvl(tn);
+      PCV_HIP_CHECK(ctx, hipMemcpyAsync(w.data(), d_walk, (size_t)tn * 4, hipMemcpyDeviceToHost, st));
+      PCV_HIP_CHECK(ctx, hipMemcpyAsync(pr.data(), d_sparent, (size_t)tn * 4, hipMemcpyDeviceToHost, st));
+      PCV_HIP_CHECK(ctx, hipMemcpyAsync(lvl.data(), d_slevel, (size_t)tn, hipMemcpyDeviceToHost, st));
       PCV_HIP_CHECK(ctx, hipStreamSynchronize(st));
+      if (!pcv_spec_tree_from_walk(w.data(), pr.data(), lvl.data(), tn, &tree))
+        return ctx->fail(PCV_E_HIP, "single-chain build: inconsistent predicted tree");
     }
-    packed_host = hs + kPcvPackHeader;
     break;
   }
   sp.nlevels = sample_levels;
-  lv.nlevels = full_levels;
-  // unpack into the structure-of-arrays view pcv_spec_build_tree reads
-  std::vector<uint64_t> v_prefix(ms);
-  std::vector<uint32_t> v_lo(ms), v_hi(ms), v_first(ms);
-  std::vector<uint8_t> v_level(ms), v_mask(ms), v_open(ms);
-  {
-    const PcvPackedNode* pn = (const PcvPackedNode*)packed_host;
-    for (uint32_t k = 0; k < ms; ++k) {
-      v_prefix[k] = pn[k].prefix;
-      v_lo[k] = pn[k].lo;
-      v_hi[k] = pn[k].hi;
-      v_first[k] = pn[k].first_child;
-      v_level[k] = pn[k].level;
-      v_mask[k] = pn[k].child_mask;
-      v_open[k] = pn[k].open;
-    }
-  }
-  const uint64_t* s_prefix = v_prefix.data();
-  const uint32_t *s_lo = v_lo.data(), *s_hi = v_hi.data(), *s_first = v_first.data();
-  const uint8_t *s_level = v_level.data(), *s_mask = v_mask.data(), *s_open = v_open.data();
-  PcvSampleTable stab;
-  stab.num_nodes = ms;
-  stab.prefix = s_prefix;
-  stab.lo = s_lo;
-  stab.hi = s_hi;
-  stab.first_child = s_first;
-  stab.level = s_level;
-  stab.child_mask = s_mask;
-  stab.open = s_open;
-  PcvSpecTree tree;
-  pcv_spec_build_tree(sp, stab, &tree);
-  const size_t walk_bytes = tree.walk.size() * sizeof(uint32_t);
-  // one upload area: walk records now, the rank map (+ fix levels) later; one zeroed counter per predicted leaf
-  const size_t map_off = (walk_bytes + 255) & ~(size_t)255;
-  const size_t fix_off = map_off + (((size_t)tree.num_leaves * 4 + 255) & ~(size_t)255);
-  const size_t cnt_off = fix_off + (((size_t)tree.num_leaves + 255) & ~(size_t)255);
-  uint8_t* d_area;
-  if ((rc = sc.get(&d_area, cnt_off + (size_t)tree.num_leaves * 4 + 256))) return rc;
-  if ((rc = ctx->pinned_spec_reserve(cnt_off + (size_t)tree.num_leaves * 4 + 512))) return rc;
-  uint8_t* hp = (uint8_t*)ctx->pinned_spec;  // the sample table has been unpacked: the block is free again
-  std::memcpy(hp, tree.walk.data(), walk_bytes);
-  PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_area, hp, walk_bytes, hipMemcpyHostToDevice, st));
-  uint32_t* d_counts = (uint32_t*)(d_area + cnt_off);
-  PCV_HIP_CHECK(ctx, hipMemsetAsync(d_counts, 0, (size_t)tree.num_leaves * 4, st));
-  ctx->stage_end(PCV_STAGE_CHAIN_KEYS);
-
-  // ---- the one chain pass ----
-  ctx->stage_begin(PCV_STAGE_LEAF_ENCODE);
-  uint32_t* rank = (uint32_t*)bs->keys_a;
-  uint4 *payload, *kept = nullptr;
-  if ((rc = sc.get(&payload, n))) return rc;
-  if (tree.any_candidate && (rc = sc.get(&kept, n))) return rc;
-  uint32_t* inten_bits = t->has_intensity ? (uint32_t*)bs->keys_a + n : nullptr;
-  // the sample keys are dead (the sample tree is on the host): the rank array takes their place in keys_a
-  uint8_t* depth_grid = nullptr;
-  if (n >= (1u << 20) && (rc = sc.get(&depth_grid, pcv_spec_depth_grid_bytes()))) return rc;  // small builds: not worth a 2 MiB fill
-  pcv_launch_spec_encode(ctx, lv, (const uint32_t*)d_area, n, d.x, d.y, d.z, d.routed, d.color, d.color_stride, d.intensity,
-                         rank, payload, kept, inten_bits, depth_grid);
-  ctx->stage_end(PCV_STAGE_LEAF_ENCODE);
 
   // ---- exact counts -> true tree ----
   ctx->stage_begin(PCV_STAGE_NODE_SPLIT);
   pcv_launch_rank_hist(ctx, rank, n, tree.num_leaves, d_counts);
   PCV_HIP_CHECK(ctx, hipGetLastError());
-  uint32_t* h_counts = (uint32_t*)(hp + cnt_off);
+  if ((rc = ctx->pinned_spec_reserve((size_t)tree.num_leaves * 8 + 512))) return rc;
+  uint8_t* hp = (uint8_t*)ctx->pinned_spec;
+  uint32_t* h_counts = (uint32_t*)hp;
+  const size_t map_off = ((size_t)tree.num_leaves * 4 + 255) & ~(size_t)255;
   PCV_HIP_CHECK(ctx, hipMemcpyAsync(h_counts, d_counts, (size_t)tree.num_leaves * 4, hipMemcpyDeviceToHost, st));
   PCV_HIP_CHECK(ctx, hipStreamSynchronize(st));
   if (pcv_spec_resolve(sp, tree, h_counts, tt) != PCV_SPEC_OK) {
     sc.detach(payload);
     ctx->dev_free(payload);
-    if (kept) {
-      sc.detach(kept);
-      ctx->dev_free(kept);
-    }
+    sc.detach(kept);
+    ctx->dev_free(kept);
     return PCV_OK;  // *used stays false
   }
   if (tt->prefix.size() > (size_t)nt.capacity) return ctx->fail(PCV_E_OOM, "node table capacity exceeded");
   std::memcpy(hp + map_off, tt->spec_map.data(), (size_t)tree.num_leaves * 4);
-  PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_area + map_off, hp + map_off, (size_t)tree.num_leaves * 4, hipMemcpyHostToDevice, st));
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_map, hp + map_off, (size_t)tree.num_leaves * 4, hipMemcpyHostToDevice, st));
   // the rank map and the payload patch are applied by the first upsweep of the record sort (one pass over the ranks
   // instead of two); PCV_SPEC_FUSE=0 keeps the separate finalize kernel (experiments)
   static const bool fuse = [] {
@@ -874,10 +867,10 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
     return !e || atoi(e) != 0;
   }();
   if (fuse) {
-    bs->spec_map_dev = (const uint32_t*)(d_area + map_off);
+    bs->spec_map_dev = d_map;
     bs->spec_kept = kept;
   } else {
-    pcv_launch_spec_finalize(ctx, n, (const uint32_t*)(d_area + map_off), rank, payload, kept);
+    pcv_launch_spec_finalize(ctx, n, d_map, rank, payload, kept);
   }
   // leaves whose points still have to replay the chain: contiguous once the records are sorted ([lo, hi) of the leaf)
   bs->fix_ranges.clear();
@@ -893,7 +886,7 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
   bs->spec = true;
   bs->spec_payload = payload;
   t->spec_stats[0] = tree.prefix.size();
-  t->spec_stats[1] = tree.num_leaves;
+  t->spec_stats[1] = (uint64_t)std::count(tree.inner.begin(), tree.inner.end(), (uint8_t)0);
   t->spec_stats[2] = tt->kept_points;
   t->spec_stats[3] = tt->fix_points;
   *used = true;

@@ -133,6 +133,7 @@ struct pcv_ctx {
     stage_open[s] = false;
   }
   hipEvent_t xev = nullptr;  // stream hand-off with the caller's runtime (pcv_ctx_wait_stream / _signal_stream)
+  hipEvent_t spec_ev = nullptr;  // single-chain build: "the predicted tree has reached the host"
 
   // per-launch profile: event pairs recorded on `stream`, resolved after the next stream sync
   bool profiling = false;
@@ -273,6 +274,11 @@ struct PcvPackedNode {
 static_assert(sizeof(PcvPackedNode) == 24, "packed node");
 constexpr size_t kPcvPackHeader = 256;
 void pcv_launch_pack_node_table(pcv_ctx* ctx, const PcvNodeTableDev& t, void* packed /* header + capacity nodes */);
+// single-chain build: predicted tree on the device from the sample's node table. ord: capacity u32 of scratch; walk /
+// sparent: 1 + 8 x capacity u32; slevel: 1 + 8 x capacity bytes; info: 4 u32 (nodes, split error flags, sample nodes,
+// any candidate)
+void pcv_launch_spec_tree(pcv_ctx* ctx, const PcvNodeTableDev& t, double upper, uint32_t force_mask, uint32_t* ord, uint32_t* walk,
+                          uint32_t* sparent, uint8_t* slevel, uint32_t* info);
 // sorted_lo (deep trees): second key word, sorted together with the first; levels > PCV_MAX_KEY_LEVELS search it
 void pcv_launch_node_split(pcv_ctx* ctx, const PcvNodeTableDev& t, const void* sorted_keys, bool keys32, uint32_t n,
                            const PcvLevels& lv, double resolution, uint32_t max_points_per_node,

@@ -57,21 +57,55 @@ void pcv_spec_build_tree(const PcvSpecParams& p, const PcvSampleTable& s, PcvSpe
       if (present) ++next;
     }
   }
-  // predicted-leaf ranks in key order: depth first, digits ascending
-  std::vector<uint32_t> stack;
-  stack.push_back(0);
-  while (!stack.empty()) {
-    const uint32_t i = stack.back();
-    stack.pop_back();
-    if (!t.inner[i]) {
-      t.leaf_rank[i] = t.num_leaves++;
-      continue;
-    }
-    for (int c = 7; c >= 0; --c) stack.push_back(t.first_child[i] + (uint32_t)c);
-  }
+  // a predicted leaf is named by its node index (the rank map takes any unique name); every node gets a counter bin
+  t.num_leaves = (uint32_t)t.prefix.size();
   t.walk.resize(t.prefix.size());
-  for (size_t i = 0; i < t.prefix.size(); ++i)
-    t.walk[i] = t.inner[i] ? (t.first_child[i] | (t.candidate[i] ? PCV_SPEC_CANDIDATE : 0u)) : (t.leaf_rank[i] | PCV_SPEC_LEAF);
+  for (size_t i = 0; i < t.prefix.size(); ++i) {
+    t.leaf_rank[i] = (uint32_t)i;
+    t.walk[i] = t.inner[i] ? (t.first_child[i] | (t.candidate[i] ? PCV_SPEC_CANDIDATE : 0u)) : ((uint32_t)i | PCV_SPEC_LEAF);
+  }
+}
+
+// The host's view of a predicted tree that was built on the DEVICE (spec_tree_emit_kernel): walk records, parent and
+// level per node. Children follow their parent (the k-th inner node's children sit at 1 + 8 k .. 1 + 8 k + 7).
+bool pcv_spec_tree_from_walk(const uint32_t* walk, const uint32_t* parent, const uint8_t* level, uint32_t count, PcvSpecTree* out) {
+  PcvSpecTree& t = *out;
+  t = PcvSpecTree();
+  t.prefix.assign(count, 0);
+  t.level.assign(level, level + count);
+  t.inner.assign(count, 0);
+  t.candidate.assign(count, 0);
+  t.first_child.assign(count, 0);
+  t.parent.assign(parent, parent + count);
+  t.leaf_rank.resize(count);
+  t.walk.assign(walk, walk + count);
+  t.num_leaves = count;
+  for (uint32_t i = 0; i < count; ++i) {
+    t.leaf_rank[i] = i;
+    const uint32_t rec = walk[i];
+    if (!(rec & PCV_SPEC_LEAF)) {
+      const uint32_t first = rec & PCV_SPEC_INDEX_MASK;
+      if (first <= i || (uint64_t)first + 8 > count) return false;  // children must follow their parent and exist
+      t.inner[i] = 1;
+      t.first_child[i] = first;
+      if (rec & PCV_SPEC_CANDIDATE) {
+        t.candidate[i] = 1;
+        t.any_candidate = true;
+      }
+    } else if ((rec & PCV_SPEC_INDEX_MASK) != i) {
+      return false;
+    }
+    if (i) {
+      const uint32_t p = parent[i];
+      if (p >= i || !t.inner[p] || i < t.first_child[p] || i >= t.first_child[p] + 8 || level[i] != level[p] + 1 ||
+          level[i] > kKeyLevels)
+        return false;
+      t.prefix[i] = t.prefix[p] | digit_bits(i - t.first_child[p], level[i]);
+    } else if (level[0] != 0) {
+      return false;
+    }
+  }
+  return true;
 }
 
 PcvSpecStatus pcv_spec_resolve(const PcvSpecParams& p, const PcvSpecTree& t, const uint32_t* leaf_counts, PcvTrueTree* out) {

@@ -59,11 +59,13 @@ struct PcvSpecTree {
   std::vector<uint8_t> candidate;     // inner node whose sampled count is inside the band
   std::vector<uint32_t> first_child;  // inner nodes: index of child 0 (children 0..7 follow each other)
   std::vector<uint32_t> parent;
-  std::vector<uint32_t> leaf_rank;    // leaves: rank in key order (depth first, digits ascending)
+  std::vector<uint32_t> leaf_rank;    // the name a predicted leaf writes into the rank array: its node index
   std::vector<uint32_t> walk;         // device walk records, one per node
-  uint32_t num_leaves = 0;
+  uint32_t num_leaves = 0;            // number of counter bins (== number of nodes)
   bool any_candidate = false;
 };
+// Host view of a predicted tree built on the device (walk records + parent + level per node); false: inconsistent.
+bool pcv_spec_tree_from_walk(const uint32_t* walk, const uint32_t* parent, const uint8_t* level, uint32_t count, PcvSpecTree* out);
 
 // Sample split threshold: a sample node is opened iff its sample count exceeds this (count * scale > cap * (1 - delta)).
 uint32_t pcv_spec_sample_threshold(const PcvSpecParams& p);

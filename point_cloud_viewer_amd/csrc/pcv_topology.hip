@@ -11,6 +11,7 @@
 // (B) one workgroup scans the child counts and appends the new level to the node table in (parent, digit)
 // order, so the table is deterministic and BFS-ordered.
 #include "pcv_internal.h"
+#include "pcv_spec.h"
 
 namespace {
 
@@ -210,7 +211,97 @@ __global__ __launch_bounds__(256) void pack_node_table_kernel(PcvNodeTableDev t,
   }
 }
 
+// ---- single-chain build: the predicted tree T'' built ON THE DEVICE from the sample's node table ------------------------
+// (what pcv_spec_build_tree does on the host, same numbering: the k-th open sample node — table order — owns the T''
+// nodes 1 + 8 k .. 1 + 8 k + 7, a leaf is named by its own index). With the walk table on the device the one chain
+// pass starts without a host round trip; the host mirrors the tree (pcv_spec_tree_from_walk) while that pass runs.
+// info: [0] number of T'' nodes, [1] error flags of the sample split, [2] sample nodes, [3] any candidate
+__global__ __launch_bounds__(1024) void spec_tree_scan_kernel(PcvNodeTableDev t, uint32_t* __restrict__ ord,
+                                                               uint32_t* __restrict__ info) {
+  __shared__ uint32_t wave_tot[16];
+  __shared__ uint32_t running;
+  const uint32_t count = t.counters[CNT_NODES] < t.capacity ? t.counters[CNT_NODES] : t.capacity;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) running = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < count; base += 1024) {
+    const uint32_t idx = base + threadIdx.x;
+    const uint32_t v = idx < count ? (uint32_t)t.open[idx] : 0u;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t u = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += u;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      woff += (w < wave) ? wave_tot[w] : 0u;
+      tot += wave_tot[w];
+    }
+    if (idx < count) ord[idx] = running + woff + inc - v;
+    __syncthreads();
+    if (threadIdx.x == 0) running += tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    info[0] = 1u + 8u * running;
+    info[1] = t.counters[CNT_ERROR];
+    info[2] = count;
+    info[3] = 0;
+  }
+}
+
+__global__ __launch_bounds__(256) void spec_tree_emit_kernel(PcvNodeTableDev t, const uint32_t* __restrict__ ord, double upper,
+                                                              uint32_t force_mask, uint32_t* __restrict__ walk,
+                                                              uint32_t* __restrict__ sparent, uint8_t* __restrict__ slevel,
+                                                              uint32_t* __restrict__ info) {
+  const uint32_t count = t.counters[CNT_NODES] < t.capacity ? t.counters[CNT_NODES] : t.capacity;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < count; i += gridDim.x * 256) {
+    if (!t.open[i]) continue;
+    const uint32_t level = t.level[i];
+    const uint32_t digit = level ? (uint32_t)(t.prefix[i] >> (3 * (PCV_MAX_KEY_LEVELS - level))) & 7u : 0u;
+    const uint32_t id = i == 0 ? 0u : 1u + 8u * ord[t.parent[i]] + digit;
+    const uint32_t base = 1u + 8u * ord[i];
+    if (i == 0) {  // the root is always split and never a candidate
+      walk[0] = base;
+      sparent[0] = 0xffffffffu;
+      slevel[0] = 0;
+    }
+    const uint32_t mask = t.child_mask[i];
+    uint32_t next = t.first_child[i];
+    bool cand_seen = false;
+#pragma unroll
+    for (uint32_t c = 0; c < 8; ++c) {
+      const uint32_t child = base + c;
+      uint32_t rec = child | PCV_SPEC_LEAF;
+      if ((mask >> c) & 1u) {
+        const uint32_t j = next++;
+        if (t.open[j]) {
+          const bool forced = level == 0 && ((force_mask >> c) & 1u);  // level-1 nodes the global tree splits anyway
+          const bool cand = !forced && (double)(t.hi[j] - t.lo[j]) <= upper;
+          rec = (1u + 8u * ord[j]) | (cand ? PCV_SPEC_CANDIDATE : 0u);
+          cand_seen = cand_seen || cand;
+        }
+      }
+      walk[child] = rec;
+      sparent[child] = id;
+      slevel[child] = (uint8_t)(level + 1);
+    }
+    if (cand_seen) atomicOr(&info[3], 1u);
+  }
+}
+
 }  // namespace
+
+void pcv_launch_spec_tree(pcv_ctx* ctx, const PcvNodeTableDev& t, double upper, uint32_t force_mask, uint32_t* ord, uint32_t* walk,
+                          uint32_t* sparent, uint8_t* slevel, uint32_t* info) {
+  hipLaunchKernelGGL(spec_tree_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, t, ord, info);
+  hipLaunchKernelGGL(spec_tree_emit_kernel, dim3(64), dim3(256), 0, ctx->stream, t, ord, upper, force_mask, walk, sparent, slevel,
+                     info);
+}
 
 void pcv_launch_pack_node_table(pcv_ctx* ctx, const PcvNodeTableDev& t, void* packed) {
   hipLaunchKernelGGL(pack_node_table_kernel, dim3(64), dim3(256), 0, ctx->stream, t, (uint8_t*)packed);
