@@ -237,6 +237,8 @@ def query_bench(args):
         kept += tree.query_points(shapes, f, capacity=1 << 22)["count"]
     st = ctx.kernel_stats()
     q_ms = st["cull_points_kernel"][1] + st["query_compact_kernel"][1] + st["nodes_in_location_kernel"][1]
+    q_split = {k.replace("_kernel", ""): round(st[k][1], 3) for k in ("cull_points_kernel", "query_compact_kernel",
+                                                                      "nodes_in_location_kernel")}
     big = ctx.shapes([("aabb", bmin, bmin + (bmax - bmin) * 0.63)])
     ctx.reset_kernel_stats()
     r = tree.query_points(big, 0, capacity=1)
@@ -278,7 +280,8 @@ def query_bench(args):
             "visible_nodes": {"kernel_ms": round(vis_ms, 3), "frusta_per_s": round(args.frusta / (vis_ms * 1e-3), 1),
                               "mean_visible": float(nvis.mean()), "max_visible": int(nvis.max()),
                               "status_nonzero": int((status != 0).sum())},
-            "query_points": {"frusta": args.cull_frusta, "kept_points": int(kept), "kernel_ms": round(q_ms, 3)},
+            "query_points": {"frusta": args.cull_frusta, "kept_points": int(kept), "kernel_ms": round(q_ms, 3),
+                             "kernel_ms_split": q_split},
             "roofline": {"bound": "hbm", "kernel": "cull_points_kernel", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
                          "algorithmic_bytes_per_launch": int(enc_bytes + tested), "avg_launch_ms": round(big_ms, 4),

@@ -5,7 +5,7 @@
 //   K7  cull_nodes       sat() of every (shape, node cube) pair (sat.rs:174-205) + relative_size_on_screen
 //                        (src/octree/mod.rs:119-139)
 //   K7b visible_nodes    Octree::get_visible_nodes — best-first traversal with Rust's BinaryHeap order
-//                        (octree/mod.rs:228-283,360-404), one lane per frustum
+//                        (octree/mod.rs:228-283,360-404), one wave per frustum
 //   K7c nodes_in_location  NodeIdsIterator BFS (src/octree/octree_iterator.rs, octree/mod.rs:309-323)
 //   K8  cull_points      FilteredIterator keep mask (src/iterator.rs:96-119; frustum.rs:120-125, obb.rs:83-90,
 //                        aabb.rs:46-48), on raw f64 positions or on a node's encoded bytes decoded on the fly
@@ -107,6 +107,7 @@ struct pcv_shapes {
   pcv_ctx* ctx;
   uint32_t count;
   PcvShapeDev* dev;
+  std::vector<int32_t> kinds;  // host copy: the point kernels are compiled per shape kind
 };
 
 namespace {
@@ -312,92 +313,131 @@ struct QTree {
   const uint8_t* empty;        // num_points == 0
 };
 
-// K7b: one lane per frustum; the heap lives in global scratch (capacity m entries per frustum).
+// K7b: one wave per frustum. Lanes 0..7 run the SAT + size_on_screen of the popped node's children side by side;
+// lane 0 owns the BinaryHeap (std's pop / push sift order restated, so the pop order is the reference's). The first
+// kHeapLds heap slots live in LDS, anything deeper in the frustum's global scratch (m entries).
 struct HeapEntry {
   double size;
   uint32_t node;
   uint32_t relation;
 };
-__device__ __forceinline__ void heap_sift_up(HeapEntry* d, uint32_t start, uint32_t pos) {
-  HeapEntry elt = d[pos];
+constexpr uint32_t kHeapLds = 384;  // 16 B entries: 4 waves x 6 KiB per workgroup
+struct WaveHeap {
+  HeapEntry* lds;
+  HeapEntry* glb;  // indexed by heap slot too (its first kHeapLds slots stay unused)
+  __device__ __forceinline__ HeapEntry get(uint32_t i) const { return i < kHeapLds ? lds[i] : glb[i]; }
+  __device__ __forceinline__ void set(uint32_t i, const HeapEntry& e) const {
+    if (i < kHeapLds) lds[i] = e;
+    else glb[i] = e;
+  }
+};
+__device__ __forceinline__ void heap_sift_up(const WaveHeap& d, uint32_t start, uint32_t pos) {
+  HeapEntry elt = d.get(pos);
   while (pos > start) {
     uint32_t parent = (pos - 1) / 2;
-    if (elt.size <= d[parent].size) break;
-    d[pos] = d[parent];
+    HeapEntry pe = d.get(parent);
+    if (elt.size <= pe.size) break;
+    d.set(pos, pe);
     pos = parent;
   }
-  d[pos] = elt;
+  d.set(pos, elt);
 }
-__global__ __launch_bounds__(64) void visible_nodes_kernel(const PcvShapeDev* __restrict__ shapes, uint32_t first_shape,
-                                                            uint32_t nshapes, QTree t, HeapEntry* __restrict__ heaps,
-                                                            uint32_t capacity, uint32_t* __restrict__ counts,
-                                                            uint32_t* __restrict__ out, int32_t* __restrict__ status) {
-  const uint32_t li = blockIdx.x * 64 + threadIdx.x;
-  if (li >= nshapes) return;
+// BinaryHeap::pop: swap the last element in, sift_down_to_bottom, sift_up
+__device__ __forceinline__ HeapEntry heap_pop(const WaveHeap& d, uint32_t& len) {
+  HeapEntry item = d.get(len - 1);
+  --len;
+  if (len > 0) {
+    HeapEntry top = d.get(0);
+    d.set(0, item);
+    item = top;
+    const uint32_t end = len;
+    uint32_t pos = 0, child = 1;
+    HeapEntry elt = d.get(0);
+    while (child + 1 < end) {
+      HeapEntry l = d.get(child), r = d.get(child + 1);
+      const bool right = l.size <= r.size;
+      child += right ? 1u : 0u;
+      d.set(pos, right ? r : l);
+      pos = child;
+      child = 2 * pos + 1;
+    }
+    if (child == end - 1) {
+      d.set(pos, d.get(child));
+      pos = child;
+    }
+    d.set(pos, elt);
+    heap_sift_up(d, 0, pos);
+  }
+  return item;
+}
+__global__ __launch_bounds__(256) void visible_nodes_kernel(const PcvShapeDev* __restrict__ shapes, uint32_t first_shape,
+                                                             uint32_t nshapes, QTree t, HeapEntry* __restrict__ heaps,
+                                                             uint32_t capacity, uint32_t* __restrict__ counts,
+                                                             uint32_t* __restrict__ out, int32_t* __restrict__ status) {
+  __shared__ HeapEntry lds_heap[4][kHeapLds];
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t li = blockIdx.x * 4 + wave;
+  if (li >= nshapes) return;  // wave-uniform
   const uint32_t f = first_shape + li;
   const PcvShapeDev* s = shapes + f;
-  HeapEntry* d = heaps + (uint64_t)li * t.m;
+  const WaveHeap d{lds_heap[wave], heaps + (uint64_t)li * t.m};
   uint32_t* o = out + (uint64_t)f * capacity;
-  uint32_t len = 0, nout = 0;
+  uint32_t len = 0, nout = 0;  // lane 0's
   int32_t st = 0;
   if (!s->valid) {  // .expect("Invalid projection matrix.")
-    counts[f] = 0;
-    status[f] = 1;
+    if (lane == 0) {
+      counts[f] = 0;
+      status[f] = 1;
+    }
     return;
   }
-  if (t.m > 0) {  // maybe_push_node(root, Cross)
+  if (t.m > 0 && lane == 0) {  // maybe_push_node(root, Cross)
     double sz = size_on_screen(s->clip_from_query, t.cubes[0], t.cubes[1], t.cubes[2], t.cubes[3]);
     if (sz != sz) st = 2;
-    d[0] = HeapEntry{sz, 0u, 1u};
+    d.set(0, HeapEntry{sz, 0u, 1u});
     len = 1;
   }
-  while (len > 0 && st == 0) {
-    // BinaryHeap::pop
-    HeapEntry item = d[len - 1];
-    --len;
-    if (len > 0) {
-      HeapEntry top = d[0];
-      d[0] = item;
-      item = top;
-      uint32_t end = len, pos = 0, child = 1;
-      HeapEntry elt = d[0];
-      while (child + 1 < end) {
-        child += (d[child].size <= d[child + 1].size) ? 1u : 0u;
-        d[pos] = d[child];
-        pos = child;
-        child = 2 * pos + 1;
-      }
-      if (child == end - 1) {
-        d[pos] = d[child];
-        pos = child;
-      }
-      d[pos] = elt;
-      heap_sift_up(d, 0, pos);
+  for (;;) {
+    if (!__shfl((int)(len > 0 && st == 0), 0)) break;
+    uint32_t node = 0, relation = 0;
+    if (lane == 0) {
+      const HeapEntry item = heap_pop(d, len);
+      node = item.node;
+      relation = item.relation;
     }
-    const uint32_t mask = t.child_mask[item.node];
-    uint32_t cidx = t.first_child[item.node];
-    for (uint32_t ci = 0; ci < 8; ++ci) {
-      if (!((mask >> ci) & 1u)) continue;  // maybe_push_node: only nodes that exist
-      const uint32_t c = cidx++;
+    node = (uint32_t)__shfl((int)node, 0);
+    relation = (uint32_t)__shfl((int)relation, 0);
+    const uint32_t mask = t.child_mask[node];
+    // maybe_push_node on the children that exist: one lane per child
+    const uint32_t c = t.first_child[node] + (uint32_t)__popc(mask & ((1u << (lane & 7)) - 1u));
+    uint32_t rel = 2;
+    double sz = 0.0;
+    if (lane < 8 && ((mask >> lane) & 1u)) {
       const double* cb = t.cubes + 4 * (uint64_t)c;
-      uint32_t rel = 0;
-      if (item.relation == 1u) {
-        rel = (uint32_t)sat_cube(s, cb[0], cb[1], cb[2], cb[3]);
-        if (rel == 2u) continue;
-      }
-      double sz = size_on_screen(s->clip_from_query, cb[0], cb[1], cb[2], cb[3]);
-      if (sz != sz) st = 2;
-      d[len] = HeapEntry{sz, c, rel};
-      heap_sift_up(d, 0, len);
-      ++len;
+      rel = 0;
+      if (relation == 1u) rel = (uint32_t)sat_cube(s, cb[0], cb[1], cb[2], cb[3]);
+      if (rel != 2u) sz = size_on_screen(s->clip_from_query, cb[0], cb[1], cb[2], cb[3]);
     }
-    if (!t.empty[item.node]) {
-      if (nout < capacity) o[nout] = item.node;
+    for (int ci = 0; ci < 8; ++ci) {  // pushes in child order, like the reference's loop
+      const uint32_t r = (uint32_t)__shfl((int)rel, ci);
+      const double z = __shfl(sz, ci);
+      const uint32_t cc = (uint32_t)__shfl((int)c, ci);
+      if (lane == 0 && r != 2u) {
+        if (z != z) st = 2;
+        d.set(len, HeapEntry{z, cc, r});
+        heap_sift_up(d, 0, len);
+        ++len;
+      }
+    }
+    if (lane == 0 && !t.empty[node]) {
+      if (nout < capacity) o[nout] = node;
       ++nout;
     }
   }
-  counts[f] = nout;
-  status[f] = st;
+  if (lane == 0) {
+    counts[f] = nout;
+    status[f] = st;
+  }
 }
 
 // K7c: BFS of NodeIdsIterator; queue in global scratch.
@@ -477,39 +517,248 @@ __device__ __forceinline__ V3d load_point(const PointsView& v, uint64_t i) {
           pcv_decode_coord(v.enc, c[2], v.cube_min[2], v.cube_edge)};
 }
 
-__global__ __launch_bounds__(256) void cull_points_kernel(const PcvShapeDev* __restrict__ shape, PointsView v,
-                                                           uint8_t* __restrict__ keep, unsigned long long* __restrict__ kept) {
-  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  bool k = false;
-  if (i < v.n) {
-    const V3d p = load_point(v, i);
-    switch (shape->kind) {
-      case PCV_SHAPE_AABB:  // aabb.rs:46-48: mins <= p < maxs
-        k = shape->bmin[0] <= p.x && shape->bmin[1] <= p.y && shape->bmin[2] <= p.z && p.x < shape->bmax[0] &&
-            p.y < shape->bmax[1] && p.z < shape->bmax[2];
-        break;
-      case PCV_SHAPE_FRUSTUM:
-      case PCV_SHAPE_FRUSTUM_WITH_INVERSE: {  // frustum.rs:120-125
-        const V3d c = m4_transform_point(shape->clip_from_query, p);
-        const double mn = fmin(fmin(c.x, c.y), c.z), mx = fmax(fmax(c.x, c.y), c.z);
-        k = mn > -1.0 && mx < 1.0;
-        break;
-      }
-      case PCV_SHAPE_OBB: {  // obb.rs:83-90
-        const V3d q = v_add(quat_rotate(shape->iso + 3, p), V3d{shape->iso[0], shape->iso[1], shape->iso[2]});
-        k = fabs(q.x) <= shape->half[0] && fabs(q.y) <= shape->half[1] && fabs(q.z) <= shape->half[2];
-        break;
-      }
-      default: k = true;  // AllPoints
+// What contains() needs of a shape, fetched once per wave (wave-uniform: it lives in scalar registers) instead of
+// once per point: the clip matrix (frustum), mins / maxs (AABB) or isometry + half extents (OBB). The point kernels
+// are compiled per KIND (PCV_SHAPE_FRUSTUM stands for both frustum kinds), so the inner loops carry no shape switch.
+template <int KIND>
+struct ContainParams {
+  double p[KIND == PCV_SHAPE_FRUSTUM ? 16 : KIND == PCV_SHAPE_OBB ? 10 : KIND == PCV_SHAPE_AABB ? 6 : 1];
+};
+template <int KIND>
+__device__ __forceinline__ ContainParams<KIND> load_contain(const PcvShapeDev* __restrict__ shape) {
+  ContainParams<KIND> c;
+  if (KIND == PCV_SHAPE_AABB) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      c.p[i] = shape->bmin[i];
+      c.p[3 + i] = shape->bmax[i];
     }
-    if (v.has_interval) {  // iterator.rs:82-91 + math/mod.rs:86-88
-      const double a = (double)v.attr[i];
-      k = k && (v.lo <= a && a <= v.hi);
-    }
-    keep[i] = k ? 1 : 0;
+  } else if (KIND == PCV_SHAPE_FRUSTUM) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) c.p[i] = shape->clip_from_query[i];
+  } else if (KIND == PCV_SHAPE_OBB) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) c.p[i] = shape->iso[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) c.p[7 + i] = shape->half[i];
+  } else {
+    c.p[0] = 0.0;
   }
-  const unsigned long long b = __ballot(k);
-  if ((threadIdx.x & 63) == 0 && b) atomicAdd(kept, (unsigned long long)__popcll(b));
+  return c;
+}
+template <int KIND>
+__device__ __forceinline__ bool shape_contains(const ContainParams<KIND>& s, V3d p) {
+  if (KIND == PCV_SHAPE_AABB) {  // aabb.rs:46-48: mins <= p < maxs
+    return s.p[0] <= p.x && s.p[1] <= p.y && s.p[2] <= p.z && p.x < s.p[3] && p.y < s.p[4] && p.z < s.p[5];
+  } else if (KIND == PCV_SHAPE_FRUSTUM) {  // frustum.rs:120-125
+    const V3d c = m4_transform_point(s.p, p);
+    const double mn = fmin(fmin(c.x, c.y), c.z), mx = fmax(fmax(c.x, c.y), c.z);
+    return mn > -1.0 && mx < 1.0;
+  } else if (KIND == PCV_SHAPE_OBB) {  // obb.rs:83-90
+    const V3d q = v_add(quat_rotate(s.p + 3, p), V3d{s.p[0], s.p[1], s.p[2]});
+    return fabs(q.x) <= s.p[7] && fabs(q.y) <= s.p[8] && fabs(q.z) <= s.p[9];
+  }
+  return true;  // AllPoints
+}
+// the kernel instance of a shape kind
+#define PCV_DISPATCH_KIND(kind, CALL)                                  \
+  switch (kind) {                                                      \
+    case PCV_SHAPE_AABB: CALL(PCV_SHAPE_AABB); break;                  \
+    case PCV_SHAPE_FRUSTUM:                                            \
+    case PCV_SHAPE_FRUSTUM_WITH_INVERSE: CALL(PCV_SHAPE_FRUSTUM); break; \
+    case PCV_SHAPE_OBB: CALL(PCV_SHAPE_OBB); break;                    \
+    default: CALL(PCV_SHAPE_ALL); break;                               \
+  }
+
+// ---- wave chunks -------------------------------------------------------------------------------------------------
+// A wave owns one chunk of consecutive points: kGroup x m of them, m chosen on the host so that the chunk's encoded
+// bytes (3, 6, 12 or 24 per point; 16-byte aligned per node in the blob) fill at most kStageSlots 16-byte LDS slots.
+// When the chunk lies in one node, those bytes are fetched with aligned 16-byte loads, all issued before the first is
+// used (6 KiB in flight per wave — the kernel is latency bound, so bytes in flight are what buy bandwidth), and
+// decoded from LDS; the keep flags leave as one dword store per lane and group of 256 points.
+constexpr uint32_t kGroup = 256;                       // points per keep-store group (4 ballots)
+constexpr uint32_t kStageSlots = kGroup * 24 / 16 + 1;  // uint4 slots per wave: 6 KiB of codes + the alignment skew
+constexpr uint32_t kStageLoads = (kStageSlots + 63) / 64;
+
+static inline uint32_t enc_stride_host(uint32_t enc) { return 3u * (uint32_t)pcv_bytes_per_coordinate(enc); }
+// points per wave for nodes of at most `max_stride` encoded bytes per point
+static inline uint32_t chunk_points(uint32_t max_stride) { return kGroup * (24u / max_stride); }
+
+// The chunk's aligned 16-byte pieces, in registers between stage_issue (all loads in flight) and stage_commit (LDS).
+// src = blob + off: the pointer keeps the blob's (global) address space, so the loads are global_load_dwordx4.
+struct StageRegs {
+  uint4 t0, t1, t2, t3, t4, t5, t6;
+  uint32_t skew, n16;
+};
+static_assert(kStageLoads == 7, "the staging loads are written out by hand");
+__device__ __forceinline__ StageRegs stage_issue(const uint8_t* __restrict__ blob, uint64_t off, uint32_t nbytes, uint32_t lane) {
+  StageRegs r;
+  r.skew = (uint32_t)((reinterpret_cast<uintptr_t>(blob) + off) & 15u);
+  const uint4* g = reinterpret_cast<const uint4*>(blob + (off - r.skew));
+  r.n16 = (r.skew + nbytes + 15u) >> 4;
+  const uint32_t last = r.n16 - 1;  // slots past the end re-read the last one: no branches between the loads
+  r.t0 = g[min(lane, last)];
+  r.t1 = g[min(lane + 64u, last)];
+  r.t2 = g[min(lane + 128u, last)];
+  r.t3 = g[min(lane + 192u, last)];
+  r.t4 = g[min(lane + 256u, last)];
+  r.t5 = g[min(lane + 320u, last)];
+  r.t6 = g[min(lane + 384u, last)];
+  return r;
+}
+__device__ __forceinline__ void stage_commit(const StageRegs& r, uint4* stage, uint32_t lane) {
+  if (lane < r.n16) stage[lane] = r.t0;
+  if (lane + 64u < r.n16) stage[lane + 64u] = r.t1;
+  if (lane + 128u < r.n16) stage[lane + 128u] = r.t2;
+  if (lane + 192u < r.n16) stage[lane + 192u] = r.t3;
+  if (lane + 256u < r.n16) stage[lane + 256u] = r.t4;
+  if (lane + 320u < r.n16) stage[lane + 320u] = r.t5;
+  if (lane + 384u < r.n16) stage[lane + 384u] = r.t6;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int ENC>
+__device__ __forceinline__ V3d staged_point(const uint8_t* at, const double* cube_min, double cube_edge) {
+  uint64_t c[3];
+  if (ENC == PCV_ENC_UINT8) {
+    c[0] = at[0];
+    c[1] = at[1];
+    c[2] = at[2];
+  } else if (ENC == PCV_ENC_UINT16) {
+    const uint16_t* q = reinterpret_cast<const uint16_t*>(at);
+    c[0] = q[0];
+    c[1] = q[1];
+    c[2] = q[2];
+  } else if (ENC == PCV_ENC_FLOAT32) {
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(at);
+    c[0] = q[0];
+    c[1] = q[1];
+    c[2] = q[2];
+  } else {
+    const uint64_t* q = reinterpret_cast<const uint64_t*>(at);
+    c[0] = q[0];
+    c[1] = q[1];
+    c[2] = q[2];
+  }
+  return {pcv_decode_coord(ENC, c[0], cube_min[0], cube_edge), pcv_decode_coord(ENC, c[1], cube_min[1], cube_edge),
+          pcv_decode_coord(ENC, c[2], cube_min[2], cube_edge)};
+}
+
+__device__ __forceinline__ uint32_t enc_stride(uint32_t enc) {
+  return enc == PCV_ENC_UINT8 ? 3u : enc == PCV_ENC_UINT16 ? 6u : enc == PCV_ENC_FLOAT32 ? 12u : 24u;
+}
+
+// a group's keep flags from its 4 ballots (lane l of ballot r = point 64 r + l): lane l writes points 4 l .. 4 l + 3
+__device__ __forceinline__ void store_keep(uint8_t* __restrict__ keep, uint32_t cnt, const unsigned long long b[4],
+                                           uint32_t lane) {
+  const uint32_t r = lane >> 4;
+  const unsigned long long sel = r == 0 ? b[0] : r == 1 ? b[1] : r == 2 ? b[2] : b[3];
+  const uint32_t bits = (uint32_t)(sel >> ((lane & 15u) * 4u)) & 0xfu;
+  const uint32_t word = (bits * 0x00204081u) & 0x01010101u;  // bit j -> byte j
+  const uint32_t q = lane * 4;
+  if ((reinterpret_cast<uintptr_t>(keep) & 3u) == 0 && q + 3 < cnt) {
+    *reinterpret_cast<uint32_t*>(keep + q) = word;
+  } else {
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j)
+      if (q + j < cnt) keep[q + j] = (uint8_t)((word >> (8 * j)) & 1u);
+  }
+}
+
+// keep flags of one chunk of `cnt` points of ONE node whose encoded bytes sit in the wave's LDS slice at `skew`
+// (attr = the chunk's first attribute or null); returns how many were kept
+template <int KIND, int ENC>
+__device__ __forceinline__ uint32_t staged_keep_enc(const ContainParams<KIND>& shape, const uint4* stage, uint32_t skew,
+                                                    const double* cube_min, double cube_edge, uint32_t cnt,
+                                                    const float* __restrict__ attr, double lo, double hi, uint32_t lane,
+                                                    uint8_t* __restrict__ keep) {
+  constexpr uint32_t stride = ENC == PCV_ENC_UINT8 ? 3u : ENC == PCV_ENC_UINT16 ? 6u : ENC == PCV_ENC_FLOAT32 ? 12u : 24u;
+  const uint8_t* bytes = reinterpret_cast<const uint8_t*>(stage) + skew;
+  uint32_t tot = 0;
+  for (uint32_t g0 = 0; g0 < cnt; g0 += kGroup) {
+    unsigned long long b[4];
+#pragma unroll
+    for (uint32_t r = 0; r < 4; ++r) {
+      const uint32_t q = g0 + r * 64 + lane;
+      bool k = false;
+      if (q < cnt) {
+        k = shape_contains<KIND>(shape, staged_point<ENC>(bytes + q * stride, cube_min, cube_edge));
+        if (attr) {  // iterator.rs:82-91 + math/mod.rs:86-88
+          const double a = (double)attr[q];
+          k = k && (lo <= a && a <= hi);
+        }
+      }
+      b[r] = __ballot(k);
+    }
+    store_keep(keep + g0, cnt - g0, b, lane);
+    tot += (uint32_t)(__popcll(b[0]) + __popcll(b[1]) + __popcll(b[2]) + __popcll(b[3]));
+  }
+  return tot;
+}
+template <int KIND>
+__device__ __forceinline__ uint32_t staged_keep(const ContainParams<KIND>& shape, const uint4* stage, uint32_t skew,
+                                                uint32_t enc, const double* cube_min, double cube_edge, uint32_t cnt,
+                                                const float* __restrict__ attr, double lo, double hi, uint32_t lane,
+                                                uint8_t* __restrict__ keep) {
+  switch (enc) {  // wave-uniform
+    case PCV_ENC_UINT8:
+      return staged_keep_enc<KIND, PCV_ENC_UINT8>(shape, stage, skew, cube_min, cube_edge, cnt, attr, lo, hi, lane, keep);
+    case PCV_ENC_UINT16:
+      return staged_keep_enc<KIND, PCV_ENC_UINT16>(shape, stage, skew, cube_min, cube_edge, cnt, attr, lo, hi, lane, keep);
+    case PCV_ENC_FLOAT32:
+      return staged_keep_enc<KIND, PCV_ENC_FLOAT32>(shape, stage, skew, cube_min, cube_edge, cnt, attr, lo, hi, lane, keep);
+    default:
+      return staged_keep_enc<KIND, PCV_ENC_FLOAT64>(shape, stage, skew, cube_min, cube_edge, cnt, attr, lo, hi, lane, keep);
+  }
+}
+
+// K8 on one view (raw f64 SoA, or one node's encoded bytes): a wave per `chunk` points, one counter update per workgroup
+template <int KIND>
+__global__ __launch_bounds__(256) void cull_points_kernel(const PcvShapeDev* __restrict__ shape_dev, PointsView v, uint32_t chunk,
+                                                           uint8_t* __restrict__ keep, unsigned long long* __restrict__ kept) {
+  __shared__ uint4 stage[4][kStageSlots];
+  __shared__ uint32_t wave_cnt[4];
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const uint64_t base = ((uint64_t)blockIdx.x * 4 + wave) * chunk;
+  uint32_t tot = 0;
+  if (base < v.n) {
+    const ContainParams<KIND> shape = load_contain<KIND>(shape_dev);
+    const uint32_t cnt = (uint32_t)(v.n - base < chunk ? v.n - base : chunk);
+    if (v.encoded) {
+      const StageRegs sr = stage_issue(v.encoded, base * enc_stride(v.enc), cnt * enc_stride(v.enc), lane);
+      stage_commit(sr, stage[wave], lane);
+      tot = staged_keep<KIND>(shape, stage[wave], sr.skew, v.enc, v.cube_min, v.cube_edge, cnt,
+                        v.has_interval ? v.attr + base : nullptr, v.lo, v.hi, lane, keep + base);
+    } else {
+      for (uint32_t g0 = 0; g0 < cnt; g0 += kGroup) {
+        unsigned long long b[4];
+#pragma unroll
+        for (uint32_t r = 0; r < 4; ++r) {
+          const uint32_t q = g0 + r * 64 + lane;
+          bool k = false;
+          if (q < cnt) {
+            const uint64_t i = base + q;
+            k = shape_contains<KIND>(shape, V3d{v.x[i], v.y[i], v.z[i]});
+            if (v.has_interval) {
+              const double a = (double)v.attr[i];
+              k = k && (v.lo <= a && a <= v.hi);
+            }
+          }
+          b[r] = __ballot(k);
+        }
+        store_keep(keep + base + g0, cnt - g0, b, lane);
+        tot += (uint32_t)(__popcll(b[0]) + __popcll(b[1]) + __popcll(b[2]) + __popcll(b[3]));
+      }
+    }
+  }
+  if (lane == 0) wave_cnt[wave] = tot;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t t = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    if (t) atomicAdd(kept, (unsigned long long)t);
+  }
 }
 
 // K9
@@ -528,148 +777,216 @@ __global__ __launch_bounds__(256) void transform_points_kernel(uint64_t n, const
 }
 
 // ---- batched point query (the work of ParallelIterator + FilteredIterator for one location) -------
+// One job per visited node, in traversal order. Every job is cut into chunks of its own size — as many points as
+// fill a wave's LDS slice at the node's encoding (256 f64, 512 f32, 1024 u16, 2048 u8 points) — so a chunk never
+// spans two nodes and the keep flags of a chunk start on a 4-byte boundary of the (internal) flag array.
 struct QueryJob {
-  uint64_t xyz_off;    // byte offset of the node's encoded positions in the xyz blob
-  uint64_t point_off;  // point offset in the rgb / intensity blobs
-  uint64_t first;      // index of the node's first point in the concatenated job space
+  uint64_t xyz_off;     // byte offset of the node's encoded positions in the xyz blob
+  uint64_t point_off;   // point offset in the rgb / intensity blobs
+  uint64_t keep_first;  // offset of the node's first flag (jobs are padded to 4 flags)
   uint32_t n;
   uint32_t enc;
   double cube_min[3];
   double cube_edge;
+  uint32_t chunk_first;  // index of the node's first chunk
+  uint32_t pad;
 };
 
-__device__ __forceinline__ uint32_t find_job(const QueryJob* __restrict__ jobs, uint32_t njobs, uint64_t i) {
-  uint32_t lo = 0, hi = njobs;  // last job with first <= i
+// pass 0 writes one descriptor per chunk, so that pass 1 has a single scalar load between "which chunk" and the
+// staging loads
+struct ChunkDesc {
+  uint64_t src;         // offset of the chunk's first encoded byte in the xyz blob
+  uint64_t attr_index;  // index of its first point in the rgb / intensity blobs
+  double cube_min[3];
+  double cube_edge;
+  uint64_t keep_off;  // offset of its first flag
+  uint32_t enc;
+  uint32_t cnt;  // points
+};
+static_assert(sizeof(ChunkDesc) == 64, "one descriptor per s_load_dwordx16");
+
+// the descriptor of chunk c, which belongs to job jb; chunks hold (LDS slice / stride) >> shift points
+__host__ __device__ inline ChunkDesc make_chunk_desc(const QueryJob& jb, uint32_t c, uint32_t shift) {
+  const uint32_t stride = jb.enc == PCV_ENC_UINT8 ? 3u : jb.enc == PCV_ENC_UINT16 ? 6u : jb.enc == PCV_ENC_FLOAT32 ? 12u : 24u;
+  const uint32_t per = (kGroup * (24u / stride)) >> shift;
+  const uint64_t kk = (uint64_t)(c - jb.chunk_first) * per;
+  ChunkDesc d;
+  d.src = jb.xyz_off + kk * stride;
+  d.attr_index = jb.point_off + kk;
+  d.cube_min[0] = jb.cube_min[0];
+  d.cube_min[1] = jb.cube_min[1];
+  d.cube_min[2] = jb.cube_min[2];
+  d.cube_edge = jb.cube_edge;
+  d.keep_off = jb.keep_first + kk;
+  d.enc = jb.enc;
+  d.cnt = (uint32_t)(jb.n - kk < per ? jb.n - kk : per);
+  return d;
+}
+
+__global__ __launch_bounds__(256) void query_chunks_kernel(const QueryJob* __restrict__ jobs, uint32_t njobs, uint32_t nchunks,
+                                                            uint32_t shift, ChunkDesc* __restrict__ desc) {
+  const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= nchunks) return;
+  uint32_t lo = 0, hi = njobs;  // last job with chunk_first <= c
   while (hi - lo > 1) {
     const uint32_t mid = (lo + hi) >> 1;
-    if (jobs[mid].first <= i) lo = mid;
+    if (jobs[mid].chunk_first <= c) lo = mid;
     else hi = mid;
   }
-  return lo;
+  desc[c] = make_chunk_desc(jobs[lo], c, shift);
 }
 
-__device__ __forceinline__ V3d job_point(const QueryJob& jb, const uint8_t* __restrict__ xyz_blob, uint64_t k) {
-  PointsView v{};
-  v.encoded = xyz_blob + jb.xyz_off;
-  v.enc = jb.enc;
-  v.cube_min[0] = jb.cube_min[0];
-  v.cube_min[1] = jb.cube_min[1];
-  v.cube_min[2] = jb.cube_min[2];
-  v.cube_edge = jb.cube_edge;
-  return load_point(v, k);
-}
-
-__device__ __forceinline__ bool shape_contains(const PcvShapeDev* __restrict__ shape, V3d p) {
-  switch (shape->kind) {
-    case PCV_SHAPE_AABB:
-      return shape->bmin[0] <= p.x && shape->bmin[1] <= p.y && shape->bmin[2] <= p.z && p.x < shape->bmax[0] &&
-             p.y < shape->bmax[1] && p.z < shape->bmax[2];
-    case PCV_SHAPE_FRUSTUM:
-    case PCV_SHAPE_FRUSTUM_WITH_INVERSE: {
-      const V3d c = m4_transform_point(shape->clip_from_query, p);
-      const double mn = fmin(fmin(c.x, c.y), c.z), mx = fmax(fmax(c.x, c.y), c.z);
-      return mn > -1.0 && mx < 1.0;
-    }
-    case PCV_SHAPE_OBB: {
-      const V3d q = v_add(quat_rotate(shape->iso + 3, p), V3d{shape->iso[0], shape->iso[1], shape->iso[2]});
-      return fabs(q.x) <= shape->half[0] && fabs(q.y) <= shape->half[1] && fabs(q.z) <= shape->half[2];
-    }
-    default: return true;
-  }
-}
-
-// pass 1: keep flag per point of every job + kept count per workgroup
-__global__ __launch_bounds__(256) void query_flags_kernel(const PcvShapeDev* __restrict__ shape,
-                                                           const QueryJob* __restrict__ jobs, uint32_t njobs, uint64_t total,
+// pass 1: keep flag per point of every chunk + kept count per chunk. Persistent waves: wave w takes chunks w, w + W,
+// ... and has the next chunk's encoded bytes in flight (registers) and the descriptor after that on its way while it
+// decodes the current chunk from LDS, so a chunk's memory latency hides behind the f64 work of the one before.
+template <int KIND>
+__global__ __launch_bounds__(256) void query_flags_kernel(const PcvShapeDev* __restrict__ shape_dev,
+                                                           const ChunkDesc* __restrict__ desc, uint32_t nchunks,
                                                            const uint8_t* __restrict__ xyz_blob,
                                                            const float* __restrict__ inten_blob, int has_interval, double lo,
                                                            double hi, uint8_t* __restrict__ keep,
-                                                           uint32_t* __restrict__ block_counts) {
-  __shared__ uint32_t wave_cnt[4];
-  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  bool k = false;
-  if (i < total) {
-    const QueryJob jb = jobs[find_job(jobs, njobs, i)];
-    const uint64_t kk = i - jb.first;
-    k = shape_contains(shape, job_point(jb, xyz_blob, kk));
-    if (has_interval) {
-      const double a = (double)inten_blob[jb.point_off + kk];
-      k = k && (lo <= a && a <= hi);
-    }
-    keep[i] = k ? 1 : 0;
+                                                           uint32_t* __restrict__ chunk_counts) {
+  __shared__ uint4 stage_all[4][kStageSlots];
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  uint4* stage = stage_all[wave];
+  const uint32_t nwaves = gridDim.x * 4;
+  uint32_t c = blockIdx.x * 4 + wave;
+  if (c >= nchunks) return;
+  const ContainParams<KIND> shape = load_contain<KIND>(shape_dev);
+  ChunkDesc d = desc[c];  // wave-uniform: scalar loads
+  ChunkDesc dn = desc[min(c + nwaves, nchunks - 1)];
+  StageRegs sr = stage_issue(xyz_blob, d.src, d.cnt * enc_stride(d.enc), lane);
+  for (;;) {
+    const uint32_t skew = sr.skew;
+    stage_commit(sr, stage, lane);
+    const uint32_t cn = c + nwaves;
+    if (cn < nchunks) sr = stage_issue(xyz_blob, dn.src, dn.cnt * enc_stride(dn.enc), lane);
+    const ChunkDesc dnn = desc[min(cn + nwaves, nchunks - 1)];
+    const uint32_t tot = staged_keep<KIND>(shape, stage, skew, d.enc, d.cube_min, d.cube_edge, d.cnt,
+                                           has_interval ? inten_blob + d.attr_index : nullptr, lo, hi, lane, keep + d.keep_off);
+    if (lane == 0) chunk_counts[c] = tot;
+    if (cn >= nchunks) break;
+    // the LDS slice is rewritten by the next commit: every lane must be done reading it
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    c = cn;
+    d = dn;
+    dn = dnn;
   }
-  const unsigned long long b = __ballot(k);
-  if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = (uint32_t)__popcll(b);
-  __syncthreads();
-  if (threadIdx.x == 0) block_counts[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
 }
 
-// exclusive scan of nb counters by one workgroup; total to out_total
+// exclusive scan of nb counters (16-byte aligned, allocated up to a multiple of 4) by one workgroup, in place; total to
+// out_total.
+// Up to 65 536 counters per pass sit in registers: thread t holds the uint4 of counters 4 (1024 j + t) .. + 3 for
+// j < 16, all loads in flight at once; wave scans per j, one scan of the 256 (j, wave) totals, coalesced write-back.
 __global__ __launch_bounds__(1024) void query_scan_kernel(uint32_t* __restrict__ counts, uint32_t nb,
                                                            unsigned long long* __restrict__ out_total) {
-  __shared__ unsigned long long wave_tot[16];
-  __shared__ unsigned long long running;
-  if (threadIdx.x == 0) running = 0;
-  __syncthreads();
+  constexpr int R = 16;
+  __shared__ uint32_t tot[R * 16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (uint32_t base = 0; base < nb; base += 1024) {
-    const uint32_t idx = base + threadIdx.x;
-    const unsigned long long v = idx < nb ? counts[idx] : 0ull;
-    unsigned long long inc = v;
+  uint4* c4 = reinterpret_cast<uint4*>(counts);
+  const uint32_t n4 = (nb + 3) / 4;
+  unsigned long long running = 0;
+  for (uint32_t base = 0; base < n4; base += R * 1024) {
+    uint4 v[R];
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      unsigned long long t = __shfl_up(inc, o, 64);
-      if (lane >= o) inc += t;
+    for (int j = 0; j < R; ++j) {
+      const uint32_t idx = base + j * 1024 + threadIdx.x;
+      v[j] = idx < n4 ? c4[idx] : make_uint4(0, 0, 0, 0);
+      if (4 * idx + 1 >= nb) v[j].y = 0;  // the allocation's tail past nb holds no counters
+      if (4 * idx + 2 >= nb) v[j].z = 0;
+      if (4 * idx + 3 >= nb) v[j].w = 0;
     }
-    if (lane == 63) wave_tot[wave] = inc;
-    __syncthreads();
-    unsigned long long woff = 0, tot = 0;
+    uint32_t inc[R];
 #pragma unroll
-    for (int w = 0; w < 16; ++w) {
-      woff += (w < wave) ? wave_tot[w] : 0ull;
-      tot += wave_tot[w];
+    for (int j = 0; j < R; ++j) {
+      uint32_t x = v[j].x + v[j].y + v[j].z + v[j].w;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(x, o, 64);
+        if (lane >= o) x += t;
+      }
+      inc[j] = x;
+      if (lane == 63) tot[j * 16 + wave] = x;
     }
-    // positions fit u32 per octree (n < 2^32); keep the exclusive prefix in place
-    if (idx < nb) counts[idx] = (uint32_t)(running + woff + inc - v);
     __syncthreads();
-    if (threadIdx.x == 0) running += tot;
+    if (wave == 0) {  // exclusive scan of the 256 totals, 4 per lane, (j, wave) order
+      uint32_t a0 = tot[4 * lane], a1 = tot[4 * lane + 1], a2 = tot[4 * lane + 2], a3 = tot[4 * lane + 3];
+      uint32_t x = a0 + a1 + a2 + a3;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(x, o, 64);
+        if (lane >= o) x += t;
+      }
+      uint32_t e = x - (a0 + a1 + a2 + a3);
+      tot[4 * lane] = e;
+      tot[4 * lane + 1] = e + a0;
+      tot[4 * lane + 2] = e + a0 + a1;
+      tot[4 * lane + 3] = e + a0 + a1 + a2;
+    }
+    __syncthreads();
+    // positions fit u32 per octree (n < 2^32)
+    uint32_t pass_total = 0;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const uint32_t idx = base + j * 1024 + threadIdx.x;
+      const uint32_t s4 = v[j].x + v[j].y + v[j].z + v[j].w;
+      const uint32_t e = (uint32_t)running + tot[j * 16 + wave] + inc[j] - s4;
+      if (idx < n4) c4[idx] = make_uint4(e, e + v[j].x, e + v[j].x + v[j].y, e + v[j].x + v[j].y + v[j].z);
+      if (j == R - 1 && threadIdx.x == 1023) pass_total = tot[j * 16 + wave] + inc[j];
+    }
+    // the pass total is known to the last thread only: broadcast it through LDS
+    __syncthreads();
+    if (threadIdx.x == 1023) tot[0] = pass_total;
+    __syncthreads();
+    running += tot[0];
     __syncthreads();
   }
   if (threadIdx.x == 0) *out_total = running;
 }
 
-// pass 2: stable compaction — decoded f64 positions, colours and intensity of the kept points, in job order
-__global__ __launch_bounds__(256) void query_compact_kernel(const QueryJob* __restrict__ jobs, uint32_t njobs, uint64_t total,
+// pass 2: stable compaction — decoded f64 positions, colours and intensity of the kept points, in job order; a wave
+// per chunk, output position = the scanned chunk count + the rank among the chunk's kept points
+__global__ __launch_bounds__(256) void query_compact_kernel(const ChunkDesc* __restrict__ desc, uint32_t nchunks,
                                                              const uint8_t* __restrict__ xyz_blob,
                                                              const uint8_t* __restrict__ rgb_blob,
                                                              const float* __restrict__ inten_blob,
                                                              const uint8_t* __restrict__ keep,
-                                                             const uint32_t* __restrict__ block_offsets, uint64_t capacity,
+                                                             const uint32_t* __restrict__ chunk_offsets, uint64_t capacity,
                                                              double* __restrict__ ox, double* __restrict__ oy,
                                                              double* __restrict__ oz, uint8_t* __restrict__ orgb,
                                                              float* __restrict__ ointen) {
-  __shared__ uint32_t wave_cnt[4];
-  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  const bool k = i < total && keep[i];
-  const unsigned long long b = __ballot(k);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(b);
-  __syncthreads();
-  if (!k) return;
-  uint32_t pos = block_offsets[blockIdx.x] + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
-  for (int w = 0; w < wave; ++w) pos += wave_cnt[w];
-  if (pos >= capacity) return;
-  const QueryJob jb = jobs[find_job(jobs, njobs, i)];
-  const uint64_t kk = i - jb.first;
-  const V3d p = job_point(jb, xyz_blob, kk);
-  ox[pos] = p.x;
-  oy[pos] = p.y;
-  oz[pos] = p.z;
-  const uint8_t* c = rgb_blob + 3 * (jb.point_off + kk);
-  orgb[3 * (uint64_t)pos] = c[0];
-  orgb[3 * (uint64_t)pos + 1] = c[1];
-  orgb[3 * (uint64_t)pos + 2] = c[2];
-  if (ointen) ointen[pos] = inten_blob[jb.point_off + kk];
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const uint32_t ci = blockIdx.x * 4 + wave;
+  if (ci >= nchunks) return;
+  uint32_t pos0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)chunk_offsets[ci]);
+  if (pos0 >= capacity) return;  // everything from here on is past the caller's buffers
+  const ChunkDesc& d = desc[ci];
+  PointsView v{};
+  v.encoded = xyz_blob + d.src;
+  v.enc = d.enc;
+  v.cube_min[0] = d.cube_min[0];
+  v.cube_min[1] = d.cube_min[1];
+  v.cube_min[2] = d.cube_min[2];
+  v.cube_edge = d.cube_edge;
+  const uint8_t* kp = keep + d.keep_off;
+  for (uint32_t q0 = 0; q0 < d.cnt; q0 += 64) {
+    const uint32_t q = q0 + lane;
+    const unsigned long long b = __ballot(q < d.cnt && kp[q]);
+    const uint32_t pos = pos0 + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+    if (((b >> lane) & 1ull) && pos < capacity) {
+      const V3d p = load_point(v, q);
+      ox[pos] = p.x;
+      oy[pos] = p.y;
+      oz[pos] = p.z;
+      const uint8_t* c = rgb_blob + 3 * (d.attr_index + q);
+      orgb[3 * (uint64_t)pos] = c[0];
+      orgb[3 * (uint64_t)pos + 1] = c[1];
+      orgb[3 * (uint64_t)pos + 2] = c[2];
+      if (ointen) ointen[pos] = inten_blob[d.attr_index + q];
+    }
+    pos0 += (uint32_t)__popcll(b);
+  }
 }
 
 }  // namespace
@@ -716,6 +1033,8 @@ extern "C" int pcv_shapes_create(pcv_ctx* ctx, const pcv_shape* shapes, uint32_t
   r->ctx = ctx;
   r->count = count;
   r->dev = nullptr;
+  r->kinds.resize(count);
+  for (uint32_t i = 0; i < count; ++i) r->kinds[i] = shapes[i].kind;
   void* p = nullptr;
   int rc = ctx->dev_alloc(&p, sizeof(PcvShapeDev) * (count ? count : 1));
   if (rc) {
@@ -922,7 +1241,7 @@ static int traverse(pcv_ctx* ctx, const pcv_shapes* shapes, pcv_octree* tree, ui
     const uint32_t nb = std::min(batch, f - first);
     PcvProf prof(ctx, visible ? PCV_K_VISIBLE_NODES : PCV_K_NODES_IN_LOCATION);
     if (visible)
-      hipLaunchKernelGGL(visible_nodes_kernel, dim3((nb + 63) / 64), dim3(64), 0, ctx->stream, shapes->dev, first, nb, qt,
+      hipLaunchKernelGGL(visible_nodes_kernel, dim3((nb + 3) / 4), dim3(256), 0, ctx->stream, shapes->dev, first, nb, qt,
                          (HeapEntry*)scratch, capacity, d_counts, d_out, d_status);
     else
       hipLaunchKernelGGL(nodes_in_location_kernel, dim3((nb + 63) / 64), dim3(64), 0, ctx->stream, shapes->dev, first, nb,
@@ -975,8 +1294,12 @@ static int run_cull_points(pcv_ctx* ctx, const pcv_shapes* shapes, uint32_t shap
   PCV_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
   {
     PcvProf prof(ctx, PCV_K_CULL_POINTS);
-    hipLaunchKernelGGL(cull_points_kernel, dim3((unsigned)((v.n + 255) / 256)), dim3(256), 0, ctx->stream,
-                       shapes->dev + shape_index, v, d_keep, d_cnt);
+    const uint32_t chunk = v.encoded ? chunk_points(enc_stride_host(v.enc)) : kGroup;
+#define PCV_CALL(K)                                                                                                     \
+  hipLaunchKernelGGL(cull_points_kernel<K>, dim3((unsigned)((v.n + 4ull * chunk - 1) / (4ull * chunk))), dim3(256), 0, \
+                     ctx->stream, shapes->dev + shape_index, v, chunk, d_keep, d_cnt)
+    PCV_DISPATCH_KIND(shapes->kinds[shape_index], PCV_CALL)
+#undef PCV_CALL
   }
   PCV_HIP_CHECK(ctx, hipGetLastError());
   if (mem == PCV_MEM_HOST) PCV_HIP_CHECK(ctx, hipMemcpyAsync(keep, d_keep, v.n, hipMemcpyDeviceToHost, ctx->stream));
@@ -1049,8 +1372,12 @@ extern "C" int pcv_cull_node_points(pcv_ctx* ctx, const pcv_shapes* shapes, uint
   PCV_HIP_CHECK(ctx, hipMemsetAsync(d_cnt, 0, 8, ctx->stream));
   {
     PcvProf prof(ctx, PCV_K_CULL_POINTS);
-    hipLaunchKernelGGL(cull_points_kernel, dim3((unsigned)((v.n + 255) / 256)), dim3(256), 0, ctx->stream,
-                       shapes->dev + shape_index, v, d_keep, d_cnt);
+    const uint32_t chunk = v.encoded ? chunk_points(enc_stride_host(v.enc)) : kGroup;
+#define PCV_CALL(K)                                                                                                     \
+  hipLaunchKernelGGL(cull_points_kernel<K>, dim3((unsigned)((v.n + 4ull * chunk - 1) / (4ull * chunk))), dim3(256), 0, \
+                     ctx->stream, shapes->dev + shape_index, v, chunk, d_keep, d_cnt)
+    PCV_DISPATCH_KIND(shapes->kinds[shape_index], PCV_CALL)
+#undef PCV_CALL
   }
   PCV_HIP_CHECK(ctx, hipGetLastError());
   PCV_HIP_CHECK(ctx, hipMemcpyAsync(keep, d_keep, v.n, hipMemcpyDeviceToHost, ctx->stream));
@@ -1155,40 +1482,77 @@ static int query_points_impl(pcv_ctx* ctx, const pcv_shapes* shapes, uint32_t sh
   }
   }
   const uint32_t nn = (uint32_t)nodes.size();
-  // 2. one job per non-empty node, in traversal order
-  std::vector<QueryJob> jobs;
+  // 2. one job per non-empty node, in traversal order. Small queries get smaller chunks (more waves, each with less
+  //    serial work) and their descriptors straight from the host (no pass 0).
   uint64_t total = 0;
+  for (uint32_t k = 0; k < nn; ++k) total += (uint64_t)std::max<int64_t>(tree->nodes[nodes[k]].num_points, 0);
+  if (total == 0) return PCV_OK;
+  const uint32_t shift = total < (1u << 19) ? 2u : total < (1u << 22) ? 1u : 0u;
+  std::vector<QueryJob> jobs;
+  uint64_t keep_total = 0;
+  uint32_t nchunks = 0;
   for (uint32_t k = 0; k < nn; ++k) {
     const pcv_node_info& nd = tree->nodes[nodes[k]];
     if (nd.num_points <= 0) continue;
     QueryJob jb;
     jb.xyz_off = nd.xyz_offset;
     jb.point_off = nd.point_offset;
-    jb.first = total;
+    jb.keep_first = keep_total;
     jb.n = (uint32_t)nd.num_points;
     jb.enc = nd.encoding;
     for (int a = 0; a < 3; ++a) jb.cube_min[a] = nd.cube_min[a];
     jb.cube_edge = nd.cube_edge;
+    jb.chunk_first = nchunks;
+    jb.pad = 0;
     jobs.push_back(jb);
-    total += (uint64_t)nd.num_points;
+    const uint32_t per = chunk_points(enc_stride_host(nd.encoding)) >> shift;
+    nchunks += (uint32_t)(((uint64_t)nd.num_points + per - 1) / per);
+    keep_total += ((uint64_t)nd.num_points + 3) & ~3ull;
   }
-  if (total == 0) return PCV_OK;
   const uint32_t njobs = (uint32_t)jobs.size();
-  const uint32_t nb = (uint32_t)((total + 255) / 256);
-  QueryJob* d_jobs;
+  const bool host_desc = nchunks <= 2048;
+  std::vector<ChunkDesc> h_desc;
+  if (host_desc) {
+    h_desc.reserve(nchunks);
+    for (const QueryJob& jb : jobs) {
+      const uint32_t per = chunk_points(enc_stride_host(jb.enc)) >> shift;
+      const uint32_t nc = (jb.n + per - 1) / per;
+      for (uint32_t c = 0; c < nc; ++c) h_desc.push_back(make_chunk_desc(jb, jb.chunk_first + c, shift));
+    }
+  }
+  const uint32_t nb = (nchunks + 3) / 4;
+  int cus = 0, per_cu = 0;
+  PCV_HIP_CHECK(ctx, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
+  // persistent pass 1: as many workgroups as are resident at once
+#define PCV_CALL(K) PCV_HIP_CHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, query_flags_kernel<K>, 256, 0))
+  PCV_DISPATCH_KIND(shapes->kinds[shape_index], PCV_CALL)
+#undef PCV_CALL
+  const uint32_t nb_flags = std::min<uint32_t>(nb, (uint32_t)std::max(cus, 1) * (uint32_t)std::max(per_cu, 1));
+  QueryJob* d_jobs = nullptr;
+  ChunkDesc* d_desc;
   uint8_t* d_keep;
-  uint32_t* d_bc;
+  uint32_t* d_cc;
   unsigned long long* d_total;
-  if ((rc = sc.get(&d_jobs, njobs)) || (rc = sc.get(&d_keep, total)) || (rc = sc.get(&d_bc, nb)) || (rc = sc.get(&d_total, 1)))
+  if ((!host_desc && (rc = sc.get(&d_jobs, njobs))) || (rc = sc.get(&d_keep, keep_total)) ||
+      (rc = sc.get(&d_cc, ((size_t)nchunks + 3) & ~(size_t)3)) || (rc = sc.get(&d_total, 1)) || (rc = sc.get(&d_desc, nchunks)))
     return rc;
-  PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_jobs, jobs.data(), sizeof(QueryJob) * njobs, hipMemcpyHostToDevice, ctx->stream));
+  if (host_desc)
+    PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_desc, h_desc.data(), sizeof(ChunkDesc) * nchunks, hipMemcpyHostToDevice, ctx->stream));
+  else
+    PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_jobs, jobs.data(), sizeof(QueryJob) * njobs, hipMemcpyHostToDevice, ctx->stream));
   {
     PcvProf prof(ctx, PCV_K_CULL_POINTS);
-    hipLaunchKernelGGL(query_flags_kernel, dim3(nb), dim3(256), 0, ctx->stream, shapes->dev + shape_index, d_jobs, njobs, total,
-                       tree->d_xyz, (const float*)tree->d_int, interval ? 1 : 0, interval ? interval[0] : 0.0,
-                       interval ? interval[1] : 0.0, d_keep, d_bc);
+    if (!host_desc)
+      hipLaunchKernelGGL(query_chunks_kernel, dim3((nchunks + 255) / 256), dim3(256), 0, ctx->stream, d_jobs, njobs, nchunks, shift,
+                         d_desc);
+#define PCV_CALL(K)                                                                                                      \
+  hipLaunchKernelGGL(query_flags_kernel<K>, dim3(nb_flags), dim3(256), 0, ctx->stream, shapes->dev + shape_index, d_desc, \
+                     nchunks, tree->d_xyz, (const float*)tree->d_int, interval ? 1 : 0, interval ? interval[0] : 0.0,      \
+                     interval ? interval[1] : 0.0, d_keep, d_cc)
+    PCV_DISPATCH_KIND(shapes->kinds[shape_index], PCV_CALL)
+#undef PCV_CALL
   }
-  hipLaunchKernelGGL(query_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_bc, nb, d_total);
+  hipLaunchKernelGGL(query_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_cc, nchunks, d_total);
   PCV_HIP_CHECK(ctx, hipMemcpyAsync(ctx->mailbox, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
   PCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // also keeps `jobs` alive until the copy is done
   const unsigned long long kept = ctx->mailbox[0];
@@ -1205,8 +1569,8 @@ static int query_points_impl(pcv_ctx* ctx, const pcv_shapes* shapes, uint32_t sh
     }
     {
       PcvProf prof(ctx, PCV_K_QUERY_COMPACT);
-      hipLaunchKernelGGL(query_compact_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_jobs, njobs, total, tree->d_xyz,
-                         tree->d_rgb, (const float*)tree->d_int, d_keep, d_bc, nout, dx, dy, dz, drgb, want_int ? dint : nullptr);
+      hipLaunchKernelGGL(query_compact_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_desc, nchunks, tree->d_xyz, tree->d_rgb,
+                         (const float*)tree->d_int, d_keep, d_cc, nout, dx, dy, dz, drgb, want_int ? dint : nullptr);
     }
     PCV_HIP_CHECK(ctx, hipGetLastError());
     if (mem == PCV_MEM_HOST) {

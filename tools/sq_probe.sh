@@ -1,11 +1,12 @@
 #!/bin/bash
 # One rocprofv3 SQ-counter pass over a short bench.py run (own run, --kernel-trace only, as gpurun requires):
 #   gpurun -- 'ENV=... bash tools/sq_probe.sh TAG [bench flags]'  ->  gpurun_out/TAG_sq.csv (per-kernel averages per launch)
+#   PROBE_CMD="python tools/query_probe.py" profiles another command from the repo root instead of bench.py
 TAG=${1:-sq}; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace -d $OUT/${TAG}_sqdb -o r -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-e2e --no-kernel-events "$@" > $OUT/${TAG}_sq.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace -d $OUT/${TAG}_sqdb -o r -- ${PROBE_CMD:-python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-e2e --no-kernel-events} "$@" > $OUT/${TAG}_sq.log 2>&1
 cd $GRAFT_REPO_ROOT && python - "$OUT/${TAG}_sqdb/r_results.db" "$OUT/${TAG}_sq.csv" <<'PY'
 import sqlite3, sys
 from collections import defaultdict
