@@ -237,8 +237,14 @@ __global__ __launch_bounds__(64) void shape_setup_kernel(PcvShapeDev* shapes, ui
     project8(s->corners, V3d{s->axes[3 * a], s->axes[3 * a + 1], s->axes[3 * a + 2]}, &s->amin[a], &s->amax[a]);
 }
 
-// sat() of one cube against one prepared shape. Evaluating every axis gives the same Relation as the reference's
-// early return: Out if any axis separates, else Cross if B sticks out on any axis, else In (sat.rs:174-194).
+// sat() of one cube against one prepared shape: Out if any axis separates, else Cross if B sticks out on any axis,
+// else In (sat.rs:174-194) — so the walk over the axes stops at the first separating one, like the reference's early
+// return, and the Relation does not depend on where it stops.
+// The interval of the cube's 8 corners on an axis: each corner is fl(fl(x a_x + y a_y) + z a_z) with x, y, z the low or
+// high bound; rounding is monotone, so the least (greatest) corner is the one built from the three least (greatest)
+// products — 6 min/max + 4 adds instead of 16 adds + 16 min/max. Only when a bound comes out non-finite (inf / NaN
+// inputs) are the 8 corners folded literally, in aabb.rs:114-125 order, so that f64::min / max skip NaNs as they do
+// in the reference.
 __device__ __forceinline__ int sat_cube(const PcvShapeDev* __restrict__ s, double mnx, double mny, double mnz, double edge) {
   if (s->kind == PCV_SHAPE_ALL) return 1;  // AllPoints intersects everything (math/mod.rs:139-160) -> "not Out"
   // Cube::to_aabb: Aabb::new(min, min + edge) (inf / sup)
@@ -246,21 +252,25 @@ __device__ __forceinline__ int sat_cube(const PcvShapeDev* __restrict__ s, doubl
   const double lx = fmin(mnx, ax_), hx = fmax(mnx, ax_);
   const double ly = fmin(mny, ay_), hy = fmax(mny, ay_);
   const double lz = fmin(mnz, az_), hz = fmax(mnz, az_);
-  bool out = false, cross = false;
+  bool cross = false;
   const int na = s->naxes;
   for (int a = 0; a < na; ++a) {
     const double ax = s->axes[3 * a], ay = s->axes[3 * a + 1], az = s->axes[3 * a + 2];
     const double plx = lx * ax, phx = hx * ax, ply = ly * ay, phy = hy * ay, plz = lz * az, phz = hz * az;
-    // corners in aabb.rs:114-125 order: (l,l,l) (h,l,l) (l,h,l) (h,h,l) (l,l,h) (h,l,h) (l,h,h) (h,h,h)
-    double c0 = (plx + ply) + plz, c1 = (phx + ply) + plz, c2 = (plx + phy) + plz, c3 = (phx + phy) + plz;
-    double c4 = (plx + ply) + phz, c5 = (phx + ply) + phz, c6 = (plx + phy) + phz, c7 = (phx + phy) + phz;
-    double bmin = fmin(fmin(fmin(fmin(fmin(fmin(fmin(fmin(1.7976931348623157e308, c0), c1), c2), c3), c4), c5), c6), c7);
-    double bmax = fmax(fmax(fmax(fmax(fmax(fmax(fmax(fmax(-1.7976931348623157e308, c0), c1), c2), c3), c4), c5), c6), c7);
+    double bmin = (fmin(plx, phx) + fmin(ply, phy)) + fmin(plz, phz);
+    double bmax = (fmax(plx, phx) + fmax(ply, phy)) + fmax(plz, phz);
+    if (!(fabs(bmin) <= 1.7976931348623157e308 && fabs(bmax) <= 1.7976931348623157e308)) {
+      // corners in aabb.rs:114-125 order: (l,l,l) (h,l,l) (l,h,l) (h,h,l) (l,l,h) (h,l,h) (l,h,h) (h,h,h)
+      double c0 = (plx + ply) + plz, c1 = (phx + ply) + plz, c2 = (plx + phy) + plz, c3 = (phx + phy) + plz;
+      double c4 = (plx + ply) + phz, c5 = (phx + ply) + phz, c6 = (plx + phy) + phz, c7 = (phx + phy) + phz;
+      bmin = fmin(fmin(fmin(fmin(fmin(fmin(fmin(fmin(1.7976931348623157e308, c0), c1), c2), c3), c4), c5), c6), c7);
+      bmax = fmax(fmax(fmax(fmax(fmax(fmax(fmax(fmax(-1.7976931348623157e308, c0), c1), c2), c3), c4), c5), c6), c7);
+    }
     const double amin = s->amin[a], amax = s->amax[a];
-    out = out || (bmin > amax || bmax < amin);
+    if (bmin > amax || bmax < amin) return 2;
     cross = cross || (amin > bmin || bmax > amax);
   }
-  return out ? 2 : (cross ? 1 : 0);
+  return cross ? 1 : 0;
 }
 
 __device__ __forceinline__ double clamp_num(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }

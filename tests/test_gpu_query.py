@@ -192,29 +192,22 @@ def test_open_dir_round_trip_and_query(ctx, scene, tmp_path):
         ctx.open_dir(tmp_path / "missing")
 
 
-def test_query_points_batched(ctx, scene):
-    """pcv_query_points == for node in nodes_in_location: decode, FilteredIterator keep mask, retain (iterator.rs)."""
-    rng = np.random.default_rng(9)
-    fr = random_frusta(rng, scene["bmin"], scene["bmax"], 6)
-    obb = (scene["bmin"] + 45, O.quat_from_axis_angle([1.0, 0.0, 0.0], 0.5), [30.0, 20.0, 15.0])
-    shapes = [("frustum2", *fr[i]) for i in range(6)] + [("obb", *obb), ("aabb", scene["bmin"] + 10, scene["bmin"] + 60), ("all",)]
-    kinds = [(O.SHAPE_FRUSTUM2, np.concatenate(fr[i])) for i in range(6)]
-    kinds += [(O.SHAPE_OBB, list(obb[0]) + list(obb[1]) + list(obb[2])),
-              (O.SHAPE_AABB, list(scene["bmin"] + 10) + list(scene["bmin"] + 60)), (O.SHAPE_ALL, None)]
-    prepared = ctx.shapes(shapes)
+def check_query_points(scene, prepared, kinds, intervals=(None, (20.0, 180.0)), only=None):
+    """pcv_query_points against: for node in nodes_in_location: decode, FilteredIterator keep mask, retain."""
     tree, on = scene["tree"], scene["oracle"].nodes
+    index_of = {name: i for i, name in enumerate(scene["names"])}
     nonempty = 0
     for i, (kind, params) in enumerate(kinds):
-        for interval in (None, (20.0, 180.0)):
+        if only is not None and i not in only:
+            continue
+        for interval in intervals:
             got = tree.query_points(prepared, i, interval=interval)
             wx, wy, wz, wrgb, wint = [], [], [], [], []
             for name in O.nodes_in_location(scene["bmin"], scene["bmax"], on, kind, params):
                 nd = on[name]
                 if nd["num_points"] == 0:
                     continue
-                hi, lo = nd["id"]
-                idx = scene["names"].index(name)
-                info = tree.node(idx)
+                info = tree.node(index_of[name])
                 px, py, pz = O.decode_positions(nd["encoding"], info.cube_min, info.cube_edge, nd["xyz"])
                 inten = np.frombuffer(nd["intensity"], dtype=np.float32)
                 keep = O.cull_points(kind, params, px, py, pz, inten if interval else None, interval).astype(bool)
@@ -228,11 +221,50 @@ def test_query_points_batched(ctx, scene):
             assert np.array_equal(got["rgb"].reshape(-1, 3), cat(wrgb, np.uint8).reshape(-1, 3))
             assert np.array_equal(got["intensity"], cat(wint, np.float32))
             nonempty += got["count"] > 0
-    assert nonempty >= 6
+    return nonempty
+
+
+def test_query_points_batched(ctx, scene):
+    """pcv_query_points == for node in nodes_in_location: decode, FilteredIterator keep mask, retain (iterator.rs)."""
+    rng = np.random.default_rng(9)
+    fr = random_frusta(rng, scene["bmin"], scene["bmax"], 6)
+    obb = (scene["bmin"] + 45, O.quat_from_axis_angle([1.0, 0.0, 0.0], 0.5), [30.0, 20.0, 15.0])
+    shapes = [("frustum2", *fr[i]) for i in range(6)] + [("obb", *obb), ("aabb", scene["bmin"] + 10, scene["bmin"] + 60), ("all",)]
+    kinds = [(O.SHAPE_FRUSTUM2, np.concatenate(fr[i])) for i in range(6)]
+    kinds += [(O.SHAPE_OBB, list(obb[0]) + list(obb[1]) + list(obb[2])),
+              (O.SHAPE_AABB, list(scene["bmin"] + 10) + list(scene["bmin"] + 60)), (O.SHAPE_ALL, None)]
+    prepared = ctx.shapes(shapes)
+    tree = scene["tree"]
+    assert check_query_points(scene, prepared, kinds) >= 6
     everything = tree.query_points(prepared, 8)
     assert everything["count"] == tree.num_points  # AllPoints returns the whole cloud
     small = tree.query_points(prepared, 8, capacity=1000)  # capacity smaller than the result
     assert small["count"] == tree.num_points and len(small["x"]) == 1000 and np.array_equal(small["x"], everything["x"][:1000])
+
+
+def test_query_points_large(ctx):
+    """The same parity on a cloud big enough for full-size chunks written by the device pre-pass (the small scene takes
+    quarter-size chunks with host-built descriptors), with u8 / u16 / f32 nodes in one query and many partial chunks."""
+    x, y, z, rgb, bmin, bmax = synthetic.gaussian_clusters(5_000_000, seed=4, num_clusters=5, extent=400.0,
+                                                           sigma_range=(1.0, 30.0))
+    inten = (np.arange(x.size) % 251).astype(np.float32)
+    tree = ctx.build(0.001, pcv.Aabb(bmin, bmax), x, y, z, rgb, inten, max_points_per_node=20000)
+    with O.max_points_per_node(20000):
+        want = O.build_closed(0.001, bmin, bmax, x, y, z, rgb, inten, threads=8)
+    scene = dict(bmin=bmin, bmax=bmax, tree=tree, oracle=want, names=tree.node_names())
+    encodings = {tree.node(i).encoding for i in range(tree.num_nodes)}
+    assert len(encodings) >= 2
+    rng = np.random.default_rng(10)
+    fr = random_frusta(rng, bmin, bmax, 1)
+    lo, hi = bmin + (bmax - bmin) * 0.05, bmin + (bmax - bmin) * 0.9
+    obb = ((bmin + bmax) / 2, O.quat_from_axis_angle([0.0, 0.0, 1.0], 0.3), list((bmax - bmin) * 0.3))
+    shapes = [("all",), ("aabb", lo, hi), ("obb", *obb), ("frustum2", *fr[0])]
+    kinds = [(O.SHAPE_ALL, None), (O.SHAPE_AABB, list(lo) + list(hi)),
+             (O.SHAPE_OBB, list(obb[0]) + list(obb[1]) + list(obb[2])), (O.SHAPE_FRUSTUM2, np.concatenate(fr[0]))]
+    prepared = ctx.shapes(shapes)
+    assert check_query_points(scene, prepared, kinds, intervals=(None,), only=(0,)) == 1  # 5 M points: device descriptors
+    assert check_query_points(scene, prepared, kinds, intervals=((20.0, 180.0),), only=(1, 2, 3)) >= 2
+    assert tree.query_points(prepared, 0, capacity=1)["count"] == tree.num_points
 
 
 def test_nodes_blob_matches_web_viewer_wire_format(ctx, scene):
