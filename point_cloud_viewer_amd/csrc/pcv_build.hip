@@ -558,6 +558,10 @@ struct PcvBuild {
   std::vector<FixRange> fix_ranges;  // sorted slots whose points replay the chain after the record sort
   const uint32_t* spec_map_dev = nullptr;  // set: the record sort's first upsweep applies the rank map / payload patch
   const void* spec_kept = nullptr;
+  // the record sort (queue_record_sort): buffers and where the sorted records ended up
+  bool sort_queued = false, rec_in_a = true;
+  void *pay_a = nullptr, *pay_b = nullptr;
+  PcvSortPayload pl;
   explicit PcvBuild(pcv_ctx* c) : ctx(c), sc(c) {}
 };
 
@@ -720,6 +724,87 @@ extern "C" int pcv_build_begin_routed(pcv_ctx* ctx, const pcv_build_params* para
 // keys_a, payload in bs->spec_payload, intensity bits in the second half of keys_a) are what K5 would have produced and
 // `tt` is the node table K4 would have produced. *used == false: the prediction did not cover the tree (or the sample
 // says the tree is deeper than one key word): the caller runs the exact pipeline; nothing of this attempt is kept.
+// K5 (exact pipeline only: `wt` set) + K3 stable record sort by leaf rank (+ the single-chain build's replay of the
+// leaves that kept no codes), queued on the stream; the outcome is left in the build state for K6.
+// record = rank (u32) + one 16-byte payload {code x, code y, code z, rgba}; optional 4-byte planes for the intensity
+// and, when some leaf level is Float64-encoded, the high words of the codes. The key buffers are dead by now: each
+// (8n bytes) hosts one rank array; payloads get their own buffers.
+static int queue_record_sort(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, const PcvWalkTables* wt, uint32_t num_leaves, bool wide) {
+  hipStream_t st = ctx->stream;
+  PcvScratch& sc = bs->sc;
+  DevPoints& d = bs->d;
+  PcvLevels& lv = bs->lv;
+  const uint64_t n = bs->n;
+  int rc;
+  uint32_t* rank_a = (uint32_t*)bs->keys_a;
+  uint32_t* rank_b = (uint32_t*)bs->keys_b;
+  uint4 *pay_a = (uint4*)bs->spec_payload, *pay_b;
+  if ((!pay_a && (rc = sc.get(&pay_a, n))) || (rc = sc.get(&pay_b, n))) return rc;
+  PcvSortPayload& pl = bs->pl;
+  pl = PcvSortPayload();
+  pl.vec_in = pay_a;
+  pl.vec_out = pay_b;
+  pl.nwords = (t->has_intensity ? 1 : 0) + (wide ? 3 : 0);
+  for (int w = 0; w < pl.nwords; ++w) {
+    if (w == 0) {  // first plane fits in the second half of the key buffers
+      pl.in[0] = (uint32_t*)bs->keys_a + n;
+      pl.out[0] = (uint32_t*)bs->keys_b + n;
+    } else if ((rc = sc.get(&pl.in[w], n)) || (rc = sc.get(&pl.out[w], n))) {
+      return rc;
+    }
+  }
+  const int w_int = t->has_intensity ? 0 : -1;
+  const int w_hi = wide ? (t->has_intensity ? 1 : 0) : -1;
+  if (!bs->spec) {  // the single-chain build wrote (true-leaf rank, leaf codes, rgb[, intensity]) while it found the topology
+    ctx->stage_begin(PCV_STAGE_LEAF_ENCODE);
+    pcv_launch_leaf_encode(ctx, lv, *wt, n, d.x, d.y, d.z, d.routed, d.color, d.color_stride, d.intensity, rank_a, pay_a,
+                           wide ? pl.in[w_hi] : nullptr, wide ? pl.in[w_hi + 1] : nullptr, wide ? pl.in[w_hi + 2] : nullptr,
+                           w_int >= 0 ? pl.in[w_int] : nullptr);
+    ctx->stage_end(PCV_STAGE_LEAF_ENCODE);
+  }
+  ctx->stage_begin(PCV_STAGE_SORT_RECORDS);
+  int rank_bits = 1;
+  while ((1ull << rank_bits) < num_leaves) ++rank_bits;
+  bool rec_in_a = true;
+  if (bs->spec_map_dev)
+    rc = pcv_radix_sort_records_mapped(ctx, rank_a, rank_b, n, rank_bits, &pl, bs->sort_scratch, bs->spec_map_dev, bs->spec_kept,
+                                       &rec_in_a);
+  else
+    rc = pcv_radix_sort_u32(ctx, rank_a, rank_b, n, 0, rank_bits, &pl, bs->sort_scratch, &rec_in_a);
+  if (rc) return rc;
+  const void* s_pay = rec_in_a ? (const void*)pay_a : (const void*)pay_b;
+  if (bs->spec && !bs->fix_ranges.empty()) {
+    // single-chain build: the few leaves whose points kept no codes replay their chain now that they are contiguous
+    const uint32_t nr = (uint32_t)bs->fix_ranges.size();
+    uint32_t* d_ranges;
+    if ((rc = sc.get(&d_ranges, (size_t)nr * 4 + 4))) return rc;
+    // staging: the pinned mailbox holds 32 ranges and nothing is in flight on it; more ranges (tiny capacities in
+    // tests) wait for the queued work and take the big block
+    uint32_t* h_ranges = (uint32_t*)ctx->mailbox;
+    if (nr > 32) {
+      PCV_HIP_CHECK(ctx, hipStreamSynchronize(st));
+      if ((rc = ctx->pinned_spec_reserve((size_t)nr * 16 + 64))) return rc;
+      h_ranges = (uint32_t*)ctx->pinned_spec;
+    }
+    uint32_t before = 0;
+    for (uint32_t k = 0; k < nr; ++k) {
+      h_ranges[4 * k + 0] = bs->fix_ranges[k].lo;
+      h_ranges[4 * k + 1] = before;
+      h_ranges[4 * k + 2] = bs->fix_ranges[k].level;
+      h_ranges[4 * k + 3] = 0;
+      before += bs->fix_ranges[k].count;
+    }
+    PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_ranges, h_ranges, (size_t)nr * 16, hipMemcpyHostToDevice, st));
+    pcv_launch_spec_replay(ctx, lv, d_ranges, nr, before, d.x, d.y, d.z, d.routed, (void*)s_pay);
+  }
+  ctx->stage_end(PCV_STAGE_SORT_RECORDS);
+  bs->sort_queued = true;
+  bs->rec_in_a = rec_in_a;
+  bs->pay_a = pay_a;
+  bs->pay_b = pay_b;
+  return PCV_OK;
+}
+
 static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, const pcv_build_params* params,
                                  uint32_t max_points, int full_levels, PcvNodeTableDev& nt, PcvTrueTree* tt, bool* used) {
   *used = false;
@@ -878,13 +963,17 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
   // no synchronisation here: the uploads read ctx->pinned_spec, the caller stages the node table in ctx->pinned, and
   // the pool hands `kept` out again only to work queued on this same stream
   ctx->stage_end(PCV_STAGE_NODE_SPLIT);
-  ctx->stage_begin(PCV_STAGE_TABLE);
   if (kept && !bs->spec_kept) {
     sc.detach(kept);
     ctx->dev_free(kept);
   }
   bs->spec = true;
   bs->spec_payload = payload;
+  // the record sort needs nothing but the rank map: it starts now, and every table the host still has to build (here,
+  // in the caller and in pcv_build_finish) is built while it runs. A mis-staged mailbox is the one thing to avoid:
+  // with more than 32 replay ranges the staging synchronises first.
+  if (fuse && (rc = queue_record_sort(ctx, bs, t, nullptr, tt->num_leaves, false))) return rc;
+  ctx->stage_begin(PCV_STAGE_TABLE);
   t->spec_stats[0] = tree.prefix.size();
   t->spec_stats[1] = (uint64_t)std::count(tree.inner.begin(), tree.inner.end(), (uint8_t)0);
   t->spec_stats[2] = tt->kept_points;
@@ -1258,6 +1347,7 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
   const uint64_t n = bs->n;
   const uint32_t M = bs->M;
   const size_t host_bytes = bs->host_bytes;
+
   uint64_t* keys_a = bs->keys_a;
   uint64_t* keys_b = bs->keys_b;
   void* sort_scratch = bs->sort_scratch;
@@ -1329,6 +1419,15 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
     u_leaf_lo[r] = h_lo[i];
     u_leaf_node[r] = i;
     if (lv.enc[h_level[i]] == PCV_ENC_FLOAT64) wide = true;
+  }
+  // The single-chain build queued its record sort as soon as the rank map was on the device (queue_record_sort): the
+  // host work from here to K6 — node tables and their upload — hides behind the two sort passes.
+  const int w_int = t->has_intensity ? 0 : -1;
+  const int w_hi = wide ? (t->has_intensity ? 1 : 0) : -1;
+  PcvWalkTables wt;
+  if (bs->spec && !bs->sort_queued) {
+    ctx->stage_end(PCV_STAGE_TABLE);
+    if ((rc = queue_record_sort(ctx, bs, t, nullptr, num_leaves, wide))) return rc;
   }
   t->nodes.resize(M);
   uint64_t xyz_off = 0, point_off = 0;
@@ -1410,82 +1509,20 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
   if (!bs->spec) PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_up, u_walk, (size_t)M * 8, hipMemcpyHostToDevice, st));  // K5 only
   PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_up + walk_bytes, u_node_rec, rec_bytes, hipMemcpyHostToDevice, st));
   const uint32_t* d_climb_base = (const uint32_t*)(d_up + walk_bytes + (size_t)(M + num_leaves) * sizeof(PcvNodeRec));
-  PcvWalkTables wt;
   wt.walk = (const uint64_t*)d_up;
   wt.num_nodes = M;
   PcvPromoteTables pt;
   pt.node_rec = (const PcvNodeRec*)(d_up + walk_bytes);
   pt.leaf_rec = pt.node_rec + M;
-  ctx->stage_end(PCV_STAGE_TABLE);
+  ctx->stage_end(PCV_STAGE_TABLE);  // single-chain build: what is left of the table work once the sort has drained
 
-  // ---- K5 leaf encode (input order) ----
-  // record = rank (u32) + one 16-byte payload {code x, code y, code z, rgba}; optional 4-byte planes for the
-  // intensity and, when some leaf level is Float64-encoded, the high words of the codes.
-  // The key buffers are dead now: each (8n bytes) hosts one rank array; payloads get their own buffers.
-  uint32_t* rank_a = (uint32_t*)keys_a;
-  uint32_t* rank_b = (uint32_t*)keys_b;
-  uint4 *pay_a = (uint4*)bs->spec_payload, *pay_b;
-  if ((!pay_a && (rc = sc.get(&pay_a, n))) || (rc = sc.get(&pay_b, n))) return rc;
-  PcvSortPayload pl;
-  pl.vec_in = pay_a;
-  pl.vec_out = pay_b;
-  pl.nwords = (t->has_intensity ? 1 : 0) + (wide ? 3 : 0);
-  for (int w = 0; w < pl.nwords; ++w) {
-    if (w == 0) {  // first plane fits in the second half of the key buffers
-      pl.in[0] = (uint32_t*)keys_a + n;
-      pl.out[0] = (uint32_t*)keys_b + n;
-    } else if ((rc = sc.get(&pl.in[w], n)) || (rc = sc.get(&pl.out[w], n))) {
-      return rc;
-    }
-  }
-  const int w_int = t->has_intensity ? 0 : -1;
-  const int w_hi = wide ? (t->has_intensity ? 1 : 0) : -1;
-  if (!bs->spec) {  // the single-chain build wrote (true-leaf rank, leaf codes, rgb[, intensity]) while it found the topology
-    ctx->stage_begin(PCV_STAGE_LEAF_ENCODE);
-    pcv_launch_leaf_encode(ctx, lv, wt, n, d.x, d.y, d.z, d.routed, d.color, d.color_stride, d.intensity, rank_a, pay_a,
-                           wide ? pl.in[w_hi] : nullptr, wide ? pl.in[w_hi + 1] : nullptr, wide ? pl.in[w_hi + 2] : nullptr,
-                           w_int >= 0 ? pl.in[w_int] : nullptr);
-    ctx->stage_end(PCV_STAGE_LEAF_ENCODE);
-  }
-  ctx->stage_begin(PCV_STAGE_SORT_RECORDS);
-
-  // ---- K3 stable record sort by leaf rank ----
-  int rank_bits = 1;
-  while ((1ull << rank_bits) < num_leaves) ++rank_bits;
-  bool rec_in_a = true;
-  if (bs->spec_map_dev)
-    rc = pcv_radix_sort_records_mapped(ctx, rank_a, rank_b, n, rank_bits, &pl, sort_scratch, bs->spec_map_dev, bs->spec_kept, &rec_in_a);
-  else
-    rc = pcv_radix_sort_u32(ctx, rank_a, rank_b, n, 0, rank_bits, &pl, sort_scratch, &rec_in_a);
-  if (rc) return rc;
-  uint32_t* s_rank = rec_in_a ? rank_a : rank_b;
+  if (!bs->spec && (rc = queue_record_sort(ctx, bs, t, &wt, num_leaves, wide))) return rc;
+  const bool rec_in_a = bs->rec_in_a;
+  uint4 *pay_a = (uint4*)bs->pay_a, *pay_b = (uint4*)bs->pay_b;
+  PcvSortPayload& pl = bs->pl;
+  uint32_t* s_rank = rec_in_a ? (uint32_t*)keys_a : (uint32_t*)keys_b;
   const void* s_pay = rec_in_a ? (const void*)pay_a : (const void*)pay_b;
   uint32_t** s_plane = rec_in_a ? pl.in : pl.out;
-  if (bs->spec && !bs->fix_ranges.empty()) {
-    // single-chain build: the few leaves whose points kept no codes replay their chain now that they are contiguous
-    const uint32_t nr = (uint32_t)bs->fix_ranges.size();
-    uint32_t* d_ranges;
-    if ((rc = sc.get(&d_ranges, (size_t)nr * 4 + 4))) return rc;
-    // staging: the pinned mailbox holds 32 ranges and nothing is in flight on it; more ranges (tiny capacities in
-    // tests) wait for the queued work and take the big block
-    uint32_t* h_ranges = (uint32_t*)ctx->mailbox;
-    if (nr > 32) {
-      PCV_HIP_CHECK(ctx, hipStreamSynchronize(st));
-      if ((rc = ctx->pinned_spec_reserve((size_t)nr * 16 + 64))) return rc;
-      h_ranges = (uint32_t*)ctx->pinned_spec;
-    }
-    uint32_t before = 0;
-    for (uint32_t k = 0; k < nr; ++k) {
-      h_ranges[4 * k + 0] = bs->fix_ranges[k].lo;
-      h_ranges[4 * k + 1] = before;
-      h_ranges[4 * k + 2] = bs->fix_ranges[k].level;
-      h_ranges[4 * k + 3] = 0;
-      before += bs->fix_ranges[k].count;
-    }
-    PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_ranges, h_ranges, (size_t)nr * 16, hipMemcpyHostToDevice, st));
-    pcv_launch_spec_replay(ctx, lv, d_ranges, nr, before, d.x, d.y, d.z, d.routed, (void*)s_pay);
-  }
-  ctx->stage_end(PCV_STAGE_SORT_RECORDS);
   ctx->stage_begin(PCV_STAGE_PROMOTE_ENCODE);
 
   // ---- K6 promotion + final encode into node-contiguous blobs ----

@@ -133,6 +133,15 @@ PcvSpecStatus pcv_spec_resolve(const PcvSpecParams& p, const PcvSpecTree& t, con
   // true tree, breadth first; src[k] = T'' node of true node k
   std::vector<uint32_t> src;
   std::vector<uint8_t> kept_above;  // a candidate ancestor already holds this path's kept codes
+  src.reserve(m);  // the true tree is a subtree of T'': no reallocation on the build's critical path
+  kept_above.reserve(m);
+  r.prefix.reserve(m);
+  r.level.reserve(m);
+  r.lo.reserve(m);
+  r.hi.reserve(m);
+  r.first_child.reserve(m);
+  r.child_mask.reserve(m);
+  r.open.reserve(m);
   src.push_back(0);
   kept_above.push_back(0);
   for (size_t k = 0; k < src.size(); ++k) {
