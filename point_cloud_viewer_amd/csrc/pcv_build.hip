@@ -99,6 +99,22 @@ int pcv_ctx::pinned_reserve(size_t bytes) {
   return PCV_OK;
 }
 
+int pcv_ctx::table_dev_reserve(size_t bytes) {
+  if (bytes <= table_dev_bytes) return PCV_OK;
+  // the old block may still be read by work in flight: drain both streams before it goes away
+  if (table_dev) {
+    (void)hipStreamSynchronize(stream);
+    (void)hipStreamSynchronize(side);
+    (void)hipFree(table_dev);
+    table_dev = nullptr;
+    table_dev_bytes = 0;
+  }
+  const size_t want = (bytes + (bytes >> 1) + 4095) & ~(size_t)4095;
+  if (hipMalloc(&table_dev, want) != hipSuccess) return fail(PCV_E_OOM, "out of device memory (node tables)");
+  table_dev_bytes = want;
+  return PCV_OK;
+}
+
 int pcv_ctx::pinned_spec_reserve(size_t bytes) {
   if (bytes <= pinned_spec_bytes) return PCV_OK;
   bytes += bytes / 2;  // the size follows the node count of the input: leave room so that similar builds do not regrow it
@@ -300,6 +316,12 @@ extern "C" int pcv_ctx_create(int device, void* stream, pcv_ctx** out) {
     delete c;
     return PCV_E_HIP;
   }
+  if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->side_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->side_join, hipEventDisableTiming) != hipSuccess) {
+    delete c;
+    return PCV_E_HIP;
+  }
   *out = c;
   return PCV_OK;
 }
@@ -323,6 +345,13 @@ extern "C" void pcv_ctx_destroy(pcv_ctx* ctx) {
     if (e) (void)hipEventDestroy(e);
   if (ctx->xev) (void)hipEventDestroy(ctx->xev);
   if (ctx->spec_ev) (void)hipEventDestroy(ctx->spec_ev);
+  if (ctx->side) {
+    (void)hipStreamSynchronize(ctx->side);
+    (void)hipStreamDestroy(ctx->side);
+  }
+  if (ctx->side_fork) (void)hipEventDestroy(ctx->side_fork);
+  if (ctx->side_join) (void)hipEventDestroy(ctx->side_join);
+  if (ctx->table_dev) (void)hipFree(ctx->table_dev);
   for (int k = 0; k < PCV_NUM_STAGES; ++k) {
     if (ctx->stage_b[k]) (void)hipEventDestroy(ctx->stage_b[k]);
     if (ctx->stage_e[k]) (void)hipEventDestroy(ctx->stage_e[k]);
@@ -880,12 +909,11 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
     pcv_launch_spec_tree(ctx, nt, upper, sp.force_mask, d_ord, d_walk, d_sparent, d_slevel, d_info);
     uint8_t* hs = (uint8_t*)ctx->pinned_spec;
     const size_t first = tcap < kFirst ? tcap : kFirst;
-    PCV_HIP_CHECK(ctx, hipMemcpyAsync(hs, d_info, 16, hipMemcpyDeviceToHost, st));
-    PCV_HIP_CHECK(ctx, hipMemcpyAsync(hs + h_walk, d_walk, first * 4, hipMemcpyDeviceToHost, st));
-    PCV_HIP_CHECK(ctx, hipMemcpyAsync(hs + h_parent, d_sparent, first * 4, hipMemcpyDeviceToHost, st));
-    PCV_HIP_CHECK(ctx, hipMemcpyAsync(hs + h_level, d_slevel, first, hipMemcpyDeviceToHost, st));
-    PCV_HIP_CHECK(ctx, hipEventRecord(ctx->spec_ev, st));
-    PCV_HIP_CHECK(ctx, hipMemsetAsync(d_counts, 0, tcap * 4, st));
+    // The host's mirror of the tree and the zeroed counters travel on the side stream: on `stream` each of these small
+    // operations would sit (with its ~12 us hand-over) between the tree kernels and the chain pass. The fork point is
+    // recorded now, the chain pass is queued next (the GPU has caught up with the host by here, so every API call
+    // before that launch is idle GPU time), and only then is the side stream fed.
+    PCV_HIP_CHECK(ctx, hipEventRecord(ctx->side_fork, st));
     ctx->stage_end(PCV_STAGE_CHAIN_KEYS);
 
     // ---- the one chain pass (queued before the host has seen the tree) ----
@@ -895,8 +923,20 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
                            inten_bits, depth_grid);
     ctx->stage_end(PCV_STAGE_LEAF_ENCODE);
 
+    PCV_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->side, ctx->side_fork, 0));
+    PCV_HIP_CHECK(ctx, hipMemcpyAsync(hs, d_info, 16, hipMemcpyDeviceToHost, ctx->side));
+    PCV_HIP_CHECK(ctx, hipMemcpyAsync(hs + h_walk, d_walk, first * 4, hipMemcpyDeviceToHost, ctx->side));
+    PCV_HIP_CHECK(ctx, hipMemcpyAsync(hs + h_parent, d_sparent, first * 4, hipMemcpyDeviceToHost, ctx->side));
+    PCV_HIP_CHECK(ctx, hipMemcpyAsync(hs + h_level, d_slevel, first, hipMemcpyDeviceToHost, ctx->side));
+    PCV_HIP_CHECK(ctx, hipEventRecord(ctx->spec_ev, ctx->side));
+    PCV_HIP_CHECK(ctx, hipMemsetAsync(d_counts, 0, tcap * 4, ctx->side));
+    PCV_HIP_CHECK(ctx, hipEventRecord(ctx->side_join, ctx->side));  // `stream` waits for it below
+
     // ---- meanwhile: the host's view of the tree ----
     PCV_HIP_CHECK(ctx, hipEventSynchronize(ctx->spec_ev));
+    // whatever is queued on `stream` from here on (the counting pass, a second round, the exact pipeline) comes after
+    // the side stream's zero fill of the counters
+    PCV_HIP_CHECK(ctx, hipStreamWaitEvent(st, ctx->side_join, 0));
     std::memcpy(info, hs, sizeof(info));
     if (info[1] & 2u) return PCV_OK;  // table capacity: let the exact pipeline report it
     if (info[1] & 1u) {               // deeper than the sample keys
@@ -1504,10 +1544,15 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
   }
   const size_t walk_bytes = ((size_t)M * 8 + 255) & ~(size_t)255;
   const size_t rec_bytes = (size_t)(M + num_leaves) * sizeof(PcvNodeRec) + (size_t)num_leaves * 4;
-  uint8_t* d_up;
-  if ((rc = sc.get(&d_up, walk_bytes + rec_bytes + 256))) return rc;
-  if (!bs->spec) PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_up, u_walk, (size_t)M * 8, hipMemcpyHostToDevice, st));  // K5 only
-  PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_up + walk_bytes, u_node_rec, rec_bytes, hipMemcpyHostToDevice, st));
+  // the tables live in a context-owned block; with the record sort already running they go up on the side stream (the
+  // copy would otherwise queue behind the sort and sit, with its hand-over, between the sort and K6)
+  if ((rc = ctx->table_dev_reserve(walk_bytes + rec_bytes + 256))) return rc;
+  uint8_t* d_up = (uint8_t*)ctx->table_dev;
+  const bool up_side = bs->spec && bs->sort_queued;
+  hipStream_t up_st = up_side ? ctx->side : st;
+  if (!bs->spec) PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_up, u_walk, (size_t)M * 8, hipMemcpyHostToDevice, up_st));  // K5 only
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_up + walk_bytes, u_node_rec, rec_bytes, hipMemcpyHostToDevice, up_st));
+  if (up_side && (rc = ctx->side_end())) return ctx->fail(rc, "side stream");
   const uint32_t* d_climb_base = (const uint32_t*)(d_up + walk_bytes + (size_t)(M + num_leaves) * sizeof(PcvNodeRec));
   wt.walk = (const uint64_t*)d_up;
   wt.num_nodes = M;

@@ -134,6 +134,24 @@ struct pcv_ctx {
   }
   hipEvent_t xev = nullptr;  // stream hand-off with the caller's runtime (pcv_ctx_wait_stream / _signal_stream)
   hipEvent_t spec_ev = nullptr;  // single-chain build: "the predicted tree has reached the host"
+  // side stream for small copies that must not sit between two kernels of `stream` (the predicted tree going down
+  // while the chain pass starts; the node tables going up while the record sort runs). fork: side waits for what
+  // `stream` has queued so far; join: `stream` waits for what the side stream has queued so far.
+  hipStream_t side = nullptr;
+  hipEvent_t side_fork = nullptr, side_join = nullptr;
+  int side_begin() {
+    if (hipEventRecord(side_fork, stream) != hipSuccess || hipStreamWaitEvent(side, side_fork, 0) != hipSuccess) return PCV_E_HIP;
+    return PCV_OK;
+  }
+  int side_end() {
+    if (hipEventRecord(side_join, side) != hipSuccess || hipStreamWaitEvent(stream, side_join, 0) != hipSuccess) return PCV_E_HIP;
+    return PCV_OK;
+  }
+  // node / leaf records of K6: a context-owned device block (never recycled through the pool, so the side stream can
+  // fill it while `stream` still runs kernels that use pool memory)
+  void* table_dev = nullptr;
+  size_t table_dev_bytes = 0;
+  int table_dev_reserve(size_t bytes);
 
   // per-launch profile: event pairs recorded on `stream`, resolved after the next stream sync
   bool profiling = false;
