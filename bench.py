@@ -282,11 +282,12 @@ def query_bench(args):
                               "status_nonzero": int((status != 0).sum())},
             "query_points": {"frusta": args.cull_frusta, "kept_points": int(kept), "kernel_ms": round(q_ms, 3),
                              "kernel_ms_split": q_split},
-            "roofline": {"bound": "hbm", "kernel": "cull_points_kernel", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "query_flags_kernel", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
                          "algorithmic_bytes_per_launch": int(enc_bytes + tested), "avg_launch_ms": round(big_ms, 4),
                          "points_tested": int(tested), "kept": r["count"],
-                         "note": "one AABB over 63 % of the cube per axis: encoded node bytes in, 1 flag byte per point out"},
+                         "note": "pcv_query_points, one AABB over 63 % of the cube per axis: encoded node bytes in, 1 flag byte per "
+                                 "point out; avg_launch_ms = query_chunks_kernel (descriptors) + query_flags_kernel, HIP events"},
             "parity": {"oracle": "CPU restatement (oracle/pcv_oracle_query.cpp), not the Rust binary", "frusta_checked": V,
                        "pairs_checked": V * M, "relation_mismatches": rel_bad, "size_on_screen_mismatches": size_bad,
                        "visible_list_mismatches": vis_bad, "ok": rel_bad == 0 and size_bad == 0 and vis_bad == 0},

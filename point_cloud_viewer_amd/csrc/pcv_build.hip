@@ -753,6 +753,18 @@ extern "C" int pcv_build_begin_routed(pcv_ctx* ctx, const pcv_build_params* para
 // keys_a, payload in bs->spec_payload, intensity bits in the second half of keys_a) are what K5 would have produced and
 // `tt` is the node table K4 would have produced. *used == false: the prediction did not cover the tree (or the sample
 // says the tree is deeper than one key word): the caller runs the exact pipeline; nothing of this attempt is kept.
+// PCV_HOST_TIMING=1: host-side lap times of the single-chain build's critical section (counts on the host -> first
+// sort kernel queued), printed to stderr
+#include <chrono>
+static void host_lap(const char* what, bool reset = false) {
+  static const bool on = getenv("PCV_HOST_TIMING") != nullptr;
+  static std::chrono::steady_clock::time_point t0;
+  if (!on) return;
+  const auto now = std::chrono::steady_clock::now();
+  if (!reset) fprintf(stderr, "[host] %-24s %8.1f us\n", what, std::chrono::duration<double, std::micro>(now - t0).count());
+  t0 = now;
+}
+
 // K5 (exact pipeline only: `wt` set) + K3 stable record sort by leaf rank (+ the single-chain build's replay of the
 // leaves that kept no codes), queued on the stream; the outcome is left in the build state for K6.
 // record = rank (u32) + one 16-byte payload {code x, code y, code z, rgba}; optional 4-byte planes for the intensity
@@ -975,7 +987,10 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
   const size_t map_off = ((size_t)tree.num_leaves * 4 + 255) & ~(size_t)255;
   PCV_HIP_CHECK(ctx, hipMemcpyAsync(h_counts, d_counts, (size_t)tree.num_leaves * 4, hipMemcpyDeviceToHost, st));
   PCV_HIP_CHECK(ctx, hipStreamSynchronize(st));
-  if (pcv_spec_resolve(sp, tree, h_counts, tt) != PCV_SPEC_OK) {
+  host_lap("", true);
+  const PcvSpecStatus resolved = pcv_spec_resolve(sp, tree, h_counts, tt);
+  host_lap("resolve");
+  if (resolved != PCV_SPEC_OK) {
     sc.detach(payload);
     ctx->dev_free(payload);
     sc.detach(kept);
@@ -1012,7 +1027,9 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
   // the record sort needs nothing but the rank map: it starts now, and every table the host still has to build (here,
   // in the caller and in pcv_build_finish) is built while it runs. A mis-staged mailbox is the one thing to avoid:
   // with more than 32 replay ranges the staging synchronises first.
+  host_lap("map upload, fix ranges");
   if (fuse && (rc = queue_record_sort(ctx, bs, t, nullptr, tt->num_leaves, false))) return rc;
+  host_lap("record sort queued");
   ctx->stage_begin(PCV_STAGE_TABLE);
   t->spec_stats[0] = tree.prefix.size();
   t->spec_stats[1] = (uint64_t)std::count(tree.inner.begin(), tree.inner.end(), (uint8_t)0);

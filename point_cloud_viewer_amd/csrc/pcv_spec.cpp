@@ -2,6 +2,10 @@
 // through pcv_spec_selftest (tests/test_spec_cpu.py) against the oracle's tree.
 #include "pcv_spec.h"
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -109,19 +113,23 @@ bool pcv_spec_tree_from_walk(const uint32_t* walk, const uint32_t* parent, const
 }
 
 PcvSpecStatus pcv_spec_resolve(const PcvSpecParams& p, const PcvSpecTree& t, const uint32_t* leaf_counts, PcvTrueTree* out) {
+  // This runs with the GPU idle (exact counts in, rank map out): flat pre-sized arrays, no allocation inside the loops.
   PcvTrueTree& r = *out;
   r = PcvTrueTree();
   const size_t m = t.prefix.size();
   // exact point count of every T'' node: children follow their parent in the (breadth-first) table
-  std::vector<uint64_t> cnt(m, 0);
+  std::vector<uint64_t> cnt(m);
   for (size_t i = m; i-- > 0;) {
-    if (!t.inner[i]) cnt[i] = leaf_counts[t.leaf_rank[i]];
-    else
-      for (unsigned c = 0; c < 8; ++c) cnt[i] += cnt[t.first_child[i] + c];
+    if (!t.inner[i]) {
+      cnt[i] = leaf_counts[t.leaf_rank[i]];
+    } else {
+      const uint64_t* c = cnt.data() + t.first_child[i];
+      cnt[i] = ((c[0] + c[1]) + (c[2] + c[3])) + ((c[4] + c[5]) + (c[6] + c[7]));
+    }
   }
   r.spec_map.assign(t.num_leaves, 0);
   r.fix_level.assign(t.num_leaves, 0);
-  if (cnt[0] == 0) return PCV_SPEC_OK;  // no points: no nodes (the caller handles n == 0 before it gets here)
+  if (m == 0 || cnt[0] == 0) return PCV_SPEC_OK;  // no points: no nodes (the caller handles n == 0 before it gets here)
 
   // should_split_node (generation.rs:128-150) with the EXACT counts; the root is always split (generation.rs:312-323)
   auto split = [&](uint32_t i) {
@@ -130,56 +138,58 @@ PcvSpecStatus pcv_spec_resolve(const PcvSpecParams& p, const PcvSpecTree& t, con
     if (level == 1 && ((p.force_mask >> ((t.prefix[i] >> (3 * (kKeyLevels - 1))) & 7)) & 1u)) return true;
     return cnt[i] > (uint64_t)p.cap && p.edge[level] > p.resolution;
   };
-  // true tree, breadth first; src[k] = T'' node of true node k
-  std::vector<uint32_t> src;
-  std::vector<uint8_t> kept_above;  // a candidate ancestor already holds this path's kept codes
-  src.reserve(m);  // the true tree is a subtree of T'': no reallocation on the build's critical path
-  kept_above.reserve(m);
-  r.prefix.reserve(m);
-  r.level.reserve(m);
-  r.lo.reserve(m);
-  r.hi.reserve(m);
-  r.first_child.reserve(m);
-  r.child_mask.reserve(m);
-  r.open.reserve(m);
-  src.push_back(0);
-  kept_above.push_back(0);
-  for (size_t k = 0; k < src.size(); ++k) {
+  // true tree, breadth first (a subtree of T'': at most m nodes); src[k] = T'' node of true node k
+  std::vector<uint32_t> src(m);
+  std::vector<uint8_t> kept_above(m);  // a candidate ancestor already holds this path's kept codes
+  r.prefix.resize(m);
+  r.level.resize(m);
+  r.lo.resize(m);
+  r.hi.resize(m);
+  r.first_child.resize(m);
+  r.child_mask.resize(m);
+  r.open.resize(m);
+  size_t nk = 1;
+  src[0] = 0;
+  kept_above[0] = 0;
+  for (size_t k = 0; k < nk; ++k) {
     const uint32_t i = src[k];
-    r.prefix.push_back(t.prefix[i]);
-    r.level.push_back(t.level[i]);
-    r.lo.push_back(0);
-    r.hi.push_back(0);
-    r.first_child.push_back(0);
-    r.child_mask.push_back(0);
-    r.open.push_back(0);
+    r.prefix[k] = t.prefix[i];
+    r.level[k] = t.level[i];
     if (t.level[i] > r.deepest_level) r.deepest_level = t.level[i];
     if (!split(i)) continue;
     if (!t.inner[i]) return PCV_SPEC_TOO_SHALLOW;  // the prediction stops above where the tree goes on
     r.open[k] = 1;
-    r.first_child[k] = (uint32_t)src.size();
+    r.first_child[k] = (uint32_t)nk;
     uint8_t mask = 0;
+    const uint8_t ka = (uint8_t)(kept_above[k] | t.candidate[i]);
     for (unsigned c = 0; c < 8; ++c) {
       const uint32_t ch = t.first_child[i] + c;
       if (cnt[ch] == 0) continue;  // a child exists iff a point lies in it
       mask |= (uint8_t)(1u << c);
-      src.push_back(ch);
-      kept_above.push_back((uint8_t)(kept_above[k] | t.candidate[i]));
+      src[nk] = ch;
+      kept_above[nk] = ka;
+      ++nk;
     }
     r.child_mask[k] = mask;
   }
+  r.prefix.resize(nk);
+  r.level.resize(nk);
+  r.lo.resize(nk);
+  r.hi.resize(nk);
+  r.first_child.resize(nk);
+  r.child_mask.resize(nk);
+  r.open.resize(nk);
   // leaves in key order (depth first, digits ascending — the order pcv_build_finish ranks them in): ranges in the
   // sorted order and the predicted-leaf -> true-leaf map
-  std::vector<uint32_t> stack;
-  stack.push_back(0);
+  std::vector<uint32_t> stack(8 * (size_t)(kKeyLevels + 2)), below(8 * (size_t)(kKeyLevels + 2));
+  size_t sp = 0;
+  stack[sp++] = 0;
   uint64_t run = 0;
-  std::vector<uint32_t> below;
-  while (!stack.empty()) {
-    const uint32_t k = stack.back();
-    stack.pop_back();
+  while (sp) {
+    const uint32_t k = stack[--sp];
     if (r.open[k]) {
       const uint32_t nchild = (uint32_t)__builtin_popcount(r.child_mask[k]);
-      for (uint32_t c = nchild; c-- > 0;) stack.push_back(r.first_child[k] + c);
+      for (uint32_t c = nchild; c-- > 0;) stack[sp++] = r.first_child[k] + c;
       continue;
     }
     const uint32_t i = src[k];
@@ -200,21 +210,21 @@ PcvSpecStatus pcv_spec_resolve(const PcvSpecParams& p, const PcvSpecTree& t, con
       r.fix_points += cnt[i];
       r.fix_nodes.push_back(k);
     }
-    below.clear();
-    below.push_back(i);
-    while (!below.empty()) {
-      const uint32_t j = below.back();
-      below.pop_back();
+    const uint32_t mapped = rank | (has_codes ? PCV_SPEC_MAP_KEPT : PCV_SPEC_MAP_REPLAY);
+    size_t bp = 0;
+    below[bp++] = i;
+    while (bp) {
+      const uint32_t j = below[--bp];
       if (!t.inner[j]) {
-        r.spec_map[t.leaf_rank[j]] = rank | (has_codes ? PCV_SPEC_MAP_KEPT : PCV_SPEC_MAP_REPLAY);
+        r.spec_map[t.leaf_rank[j]] = mapped;
         if (!has_codes) r.fix_level[t.leaf_rank[j]] = t.level[i];
       } else {
-        for (unsigned c = 0; c < 8; ++c) below.push_back(t.first_child[j] + c);
+        for (unsigned c = 0; c < 8; ++c) below[bp++] = t.first_child[j] + c;
       }
     }
   }
   // inner nodes: [lo, hi) spans their leaves (children are contiguous and in digit order; bottom-up over the table)
-  for (size_t k = src.size(); k-- > 0;) {
+  for (size_t k = nk; k-- > 0;) {
     if (!r.open[k]) continue;
     const uint32_t nchild = (uint32_t)__builtin_popcount(r.child_mask[k]);
     r.lo[k] = r.lo[r.first_child[k]];
@@ -303,6 +313,16 @@ extern "C" int pcv_spec_selftest(const uint64_t* keys, uint64_t n, uint32_t stri
   }
   PcvTrueTree tt;
   const PcvSpecStatus status = pcv_spec_resolve(p, tree, counts.data(), &tt);
+  if (getenv("PCV_SPEC_TIME")) {  // host cost of the build's critical section (tools/spec_resolve_time.py)
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int rep = 0; rep < 200; ++rep) {
+      PcvTrueTree again;
+      pcv_spec_resolve(p, tree, counts.data(), &again);
+    }
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / 200;
+    fprintf(stderr, "pcv_spec_resolve: %.1f us (T'' %zu nodes, %u leaves, true tree %zu nodes)\n", us, tree.prefix.size(),
+            tree.num_leaves, tt.prefix.size());
+  }
   if (out_stats) {
     out_stats[0] = tree.prefix.size();
     out_stats[1] = tree.num_leaves;
