@@ -419,44 +419,54 @@ struct alignas(16) PcvClimber {
   uint32_t rank, slot, inten, pad;
 };
 
+// one sorted slot of `settle`: finish it in its leaf, or hand it to `climb`
+__device__ __forceinline__ void settle_one(const PcvPromoteTables& pt, uint64_t s, const PcvNodeRec& c, uint32_t r, uint4 p,
+                                           const uint32_t h[3], uint32_t inten, const uint32_t* __restrict__ climb_base,
+                                           PcvClimber* __restrict__ climbers, const PromoteOut& o) {
+  const uint32_t j = (uint32_t)s - c.lo;
+  if (c.parent == 0xffffffffu || (j & 7u) != 0) promote_one<false>(pt, s, c, p, h[0], h[1], h[2], inten, o);
+  else climbers[climb_base[r] + (j >> 3)] = PcvClimber{p, r, (uint32_t)s, inten, 0u};
+}
+
+// kSettleSlots sorted slots per lane: every record load of the tile is in flight before the first is used
+template <int kSettleSlots>
 __global__ __launch_bounds__(256) void promote_settle_kernel(
     PcvPromoteTables pt, uint64_t n, const uint32_t* __restrict__ rank, const uint4* __restrict__ payload,
     const uint32_t* __restrict__ cx_hi, const uint32_t* __restrict__ cy_hi, const uint32_t* __restrict__ cz_hi,
     const uint32_t* __restrict__ inten_bits, const uint32_t* __restrict__ climb_base, PcvClimber* __restrict__ climbers,
     PromoteOut o) {
-  const uint64_t s0 = (uint64_t)blockIdx.x * 512 + threadIdx.x;
-  const uint64_t s1 = s0 + 256;
-  if (s0 >= n) return;
-  const bool two = s1 < n;
-  const uint32_t r0 = rank[s0];
-  const uint32_t r1 = two ? rank[s1] : 0u;
-  const uint4 p0 = payload[s0];
-  const uint4 p1 = two ? payload[s1] : make_uint4(0, 0, 0, 0);
-  uint32_t h0[3] = {0, 0, 0}, h1[3] = {0, 0, 0}, i0 = 0, i1 = 0;
-  if (cx_hi) {
-    h0[0] = cx_hi[s0];
-    h0[1] = cy_hi[s0];
-    h0[2] = cz_hi[s0];
-    if (two) {
-      h1[0] = cx_hi[s1];
-      h1[1] = cy_hi[s1];
-      h1[2] = cz_hi[s1];
+  const uint64_t base = (uint64_t)blockIdx.x * (256 * kSettleSlots) + threadIdx.x;
+  uint32_t r[kSettleSlots];
+  uint4 p[kSettleSlots];
+  uint32_t h[kSettleSlots][3], in[kSettleSlots];
+#pragma unroll
+  for (int k = 0; k < kSettleSlots; ++k) {
+    const uint64_t s = base + 256 * k;
+    const bool live = s < n;
+    r[k] = live ? rank[s] : 0u;
+    p[k] = live ? payload[s] : make_uint4(0, 0, 0, 0);
+    h[k][0] = h[k][1] = h[k][2] = 0;
+    in[k] = 0;
+    if (cx_hi && live) {
+      h[k][0] = cx_hi[s];
+      h[k][1] = cy_hi[s];
+      h[k][2] = cz_hi[s];
     }
+    if (inten_bits && live) in[k] = inten_bits[s];
   }
-  if (inten_bits) {
-    i0 = inten_bits[s0];
-    if (two) i1 = inten_bits[s1];
-  }
-  const PcvNodeRec c0 = pt.leaf_rec[r0];
-  const PcvNodeRec c1 = pt.leaf_rec[r1];
-  const uint32_t j0 = (uint32_t)s0 - c0.lo, j1 = (uint32_t)s1 - c1.lo;
-  const bool stay0 = c0.parent == 0xffffffffu || (j0 & 7u) != 0;
-  const bool stay1 = c1.parent == 0xffffffffu || (j1 & 7u) != 0;
-  if (stay0) promote_one<false>(pt, s0, c0, p0, h0[0], h0[1], h0[2], i0, o);
-  else climbers[climb_base[r0] + (j0 >> 3)] = PcvClimber{p0, r0, (uint32_t)s0, i0, 0u};
-  if (two) {
-    if (stay1) promote_one<false>(pt, s1, c1, p1, h1[0], h1[1], h1[2], i1, o);
-    else climbers[climb_base[r1] + (j1 >> 3)] = PcvClimber{p1, r1, (uint32_t)s1, i1, 0u};
+#pragma unroll
+  for (int k = 0; k < kSettleSlots; ++k) {
+    const uint64_t s = base + 256 * k;
+    const bool live = s < n;
+    if (!__any(live)) break;
+    // 64 consecutive sorted slots almost always lie in one leaf (a leaf of the bench cloud spans 250 waves): its
+    // 80-byte record then comes through the scalar cache into SGPRs instead of being gathered into 20 VGPRs per lane
+    const uint32_t u = (uint32_t)__builtin_amdgcn_readfirstlane((int)r[k]);
+    if (__all(!live || r[k] == u)) {
+      if (live) settle_one(pt, s, pt.leaf_rec[u], r[k], p[k], h[k], in[k], climb_base, climbers, o);
+    } else if (live) {
+      settle_one(pt, s, pt.leaf_rec[r[k]], r[k], p[k], h[k], in[k], climb_base, climbers, o);
+    }
   }
 }
 
@@ -572,8 +582,17 @@ void pcv_launch_promote_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvPromo
   PromoteOut o{xyz_blob, rgb_blob, inten_blob};
   {
     PcvProf prof(ctx, PCV_K_PROMOTE_ENCODE);
-    hipLaunchKernelGGL(promote_settle_kernel, dim3((unsigned)((n + 511) / 512)), dim3(256), 0, ctx->stream, pt, n, rank,
-                       (const uint4*)payload, cx_hi, cy_hi, cz_hi, inten_bits, climb_base, (PcvClimber*)climbers, o);
+    static const int slots = [] {  // PCV_SETTLE_SLOTS (experiments): 1, 2 or 4 sorted slots per lane
+      const char* e = getenv("PCV_SETTLE_SLOTS");
+      return e ? atoi(e) : 2;
+    }();
+#define PCV_SETTLE(S)                                                                                                    \
+  hipLaunchKernelGGL(promote_settle_kernel<S>, dim3((unsigned)((n + 256 * S - 1) / (256 * S))), dim3(256), 0, ctx->stream, pt, n, \
+                     rank, (const uint4*)payload, cx_hi, cy_hi, cz_hi, inten_bits, climb_base, (PcvClimber*)climbers, o)
+    if (slots == 1) PCV_SETTLE(1);
+    else if (slots == 4) PCV_SETTLE(4);
+    else PCV_SETTLE(2);
+#undef PCV_SETTLE
   }
   if (num_climbers) {
     PcvProf prof(ctx, PCV_K_PROMOTE_CLIMB);
