@@ -913,12 +913,16 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
     }
     pcv_launch_chain_keys(ctx, lv, ns, stride, d.x, d.y, d.z, skeys_a, false, d.routed);
     bool in_a = true;
+    host_lap("", true);
     if ((rc = pcv_radix_sort_u64(ctx, skeys_a, skeys_b, ns, 3 * (PCV_MAX_KEY_LEVELS - sample_levels), 3 * PCV_MAX_KEY_LEVELS,
                                  nullptr, bs->sort_scratch, &in_a)))
       return rc;
+    host_lap("sample sort queued");
     pcv_launch_node_split(ctx, nt, in_a ? skeys_a : skeys_b, false, (uint32_t)ns, lv, params->resolution,
                           pcv_spec_sample_threshold(sp), sp.force_mask);
+    host_lap("sample split queued");
     pcv_launch_spec_tree(ctx, nt, upper, sp.force_mask, d_ord, d_walk, d_sparent, d_slevel, d_info);
+    host_lap("spec tree queued");
     uint8_t* hs = (uint8_t*)ctx->pinned_spec;
     const size_t first = tcap < kFirst ? tcap : kFirst;
     // The host's mirror of the tree and the zeroed counters travel on the side stream: on `stream` each of these small
@@ -934,6 +938,7 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
     pcv_launch_spec_encode(ctx, lv, d_walk, n, d.x, d.y, d.z, d.routed, d.color, d.color_stride, d.intensity, rank, payload, kept,
                            inten_bits, depth_grid);
     ctx->stage_end(PCV_STAGE_LEAF_ENCODE);
+    host_lap("chain pass queued");
 
     PCV_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->side, ctx->side_fork, 0));
     PCV_HIP_CHECK(ctx, hipMemcpyAsync(hs, d_info, 16, hipMemcpyDeviceToHost, ctx->side));
