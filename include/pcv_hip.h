@@ -52,7 +52,10 @@ typedef struct pcv_ctx pcv_ctx;
 typedef struct pcv_octree pcv_octree;
 
 /* ---- context -------------------------------------------------------------------------------- */
-/* `stream` is a hipStream_t (may be NULL = a stream owned by the context). */
+/* `stream` is a hipStream_t (may be NULL = a stream owned by the context). The context also owns a small side stream
+ * for copies that would otherwise sit between two kernels (the build's host mirror of the predicted tree, the upload
+ * of the node tables); everything queued there is joined back into `stream` before a kernel that depends on it, so
+ * the caller only ever orders itself against `stream` (pcv_ctx_wait_stream / pcv_ctx_signal_stream). */
 int pcv_ctx_create(int device, void* stream, pcv_ctx** out);
 void pcv_ctx_destroy(pcv_ctx* ctx);
 const char* pcv_last_error(const pcv_ctx* ctx);

@@ -122,3 +122,40 @@ def test_two_step_build_with_forced_level1_split(ctx):
     assert np.array_equal(l1, streams[:8].astype(np.int64)) and np.array_equal(l2, streams[8:72].astype(np.int64))
     assert mask == int(streams[72])
     assert_same(tree.to_dict(), want)
+
+
+def test_back_to_back_builds_are_identical_and_survive_interleaved_queries(ctx):
+    """The single-chain build forks small copies onto a side stream, queues its record sort before the host has built
+    the node tables and keeps those tables in a context-owned block: repeated builds of alternating sizes on ONE context,
+    with queries on the trees that are still alive in between, must give the same bytes every time."""
+    import hashlib
+
+    def digest(t):
+        h = hashlib.blake2b(digest_size=16)
+        for name, nd in sorted(t.to_dict().items()):
+            h.update(name.encode())
+            h.update(nd["xyz"])
+            h.update(nd["rgb"])
+        return h.hexdigest()
+
+    clouds = []
+    for n, seed in ((700_000, 21), (2_300_000, 22)):
+        x, y, z, rgb, bmin, bmax = synthetic.gaussian_clusters(n, seed=seed, num_clusters=7, extent=250.0, sigma_range=(0.1, 9.0))
+        clouds.append((x, y, z, rgb, bmin, bmax))
+    first, alive = {}, []
+    for it in range(8):
+        k = it % 2
+        x, y, z, rgb, bmin, bmax = clouds[k]
+        t = ctx.build(0.001, None if it % 3 == 0 else pcv.Aabb(bmin, bmax), x, y, z, rgb, max_points_per_node=25_000,
+                      single_chain=True)
+        d = digest(t)
+        assert first.setdefault(k, d) == d, it
+        alive.append((t, bmin, bmax))
+        if len(alive) > 2:
+            alive.pop(0)[0].free()
+        for tr, lo, hi in alive:  # a point query on every tree that is still alive: a box around everything, half of it
+            shapes = ctx.shapes([("aabb", lo - 1.0, hi + 1.0), ("aabb", lo - 1.0, (lo + hi) / 2)])
+            assert tr.query_points(shapes, 0, capacity=1)["count"] == tr.num_points
+            assert tr.query_points(shapes, 1, capacity=1)["count"] < tr.num_points
+    for t, _, _ in alive:
+        t.free()
