@@ -911,7 +911,13 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
       if (!small_partner && (rc = sc.get(&small_partner, ns + 32))) return rc;
       skeys_b = small_partner;
     }
-    pcv_launch_chain_keys(ctx, lv, ns, stride, d.x, d.y, d.z, skeys_a, false, d.routed);
+    // The sample is taken in clumps of 8 consecutive points (one clump every 8 x stride): read one by one, every
+    // sampled coordinate costs a full cache line (1.2 GB and 0.23 ms for the 3.1 M sample points of a 100 M cloud)
+    static const uint32_t clump_shift = [] {
+      const char* e = getenv("PCV_SAMPLE_CLUMP_SHIFT");  // experiments: 0 = single points
+      return e ? (uint32_t)std::min(6, std::max(0, atoi(e))) : 3u;
+    }();
+    pcv_launch_chain_keys(ctx, lv, ns, stride, d.x, d.y, d.z, skeys_a, false, d.routed, stride > 1 ? clump_shift : 0u);
     bool in_a = true;
     host_lap("", true);
     if ((rc = pcv_radix_sort_u64(ctx, skeys_a, skeys_b, ns, 3 * (PCV_MAX_KEY_LEVELS - sample_levels), 3 * PCV_MAX_KEY_LEVELS,

@@ -102,13 +102,15 @@ __global__ __launch_bounds__(256) void aabb_final_kernel(int nblocks, const doub
 // arguments in SGPRs), so the encoding switch is a scalar branch. `stride` > 1 evaluates a strided sample of the
 // input (depth probe); KeyT = u32 stores the top 10 levels only (key >> 33).
 template <typename KeyT>
-__global__ __launch_bounds__(256) void chain_keys_kernel(PcvLevels lv, uint64_t n, uint64_t stride,
+__global__ __launch_bounds__(256) void chain_keys_kernel(PcvLevels lv, uint64_t n, uint64_t stride, uint32_t clump_shift,
                                                           const double* __restrict__ x, const double* __restrict__ y,
                                                           const double* __restrict__ z, PcvRouted routed,
                                                           KeyT* __restrict__ keys) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const uint64_t src = i * stride;
+  // sample i of a strided sample taken in clumps of 2^clump_shift consecutive points (same density: one clump every
+  // stride x clump points): a lone 8-byte coordinate costs a whole cache line, a clump uses the line it fetches
+  const uint64_t src = (((i >> clump_shift) * stride) << clump_shift) + (i & ((1ull << clump_shift) - 1ull));
   double px, py, pz, mx, my, mz;
   double cx = 0, cy = 0, cz = 0;
   uint32_t d1;
@@ -544,16 +546,17 @@ int pcv_launch_aabb(pcv_ctx* ctx, uint64_t n, const double* x, const double* y, 
 }
 
 void pcv_launch_chain_keys(pcv_ctx* ctx, const PcvLevels& lv, uint64_t n, uint64_t stride, const double* x,
-                           const double* y, const double* z, void* keys, bool keys32, const PcvRouted& routed) {
+                           const double* y, const double* z, void* keys, bool keys32, const PcvRouted& routed,
+                           uint32_t clump_shift) {
   if (n == 0) return;
   uint64_t blocks = (n + 255) / 256;
   PcvProf prof(ctx, PCV_K_CHAIN_KEYS);
   if (keys32)
-    hipLaunchKernelGGL(chain_keys_kernel<uint32_t>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, lv, n, stride, x, y,
-                       z, routed, (uint32_t*)keys);
+    hipLaunchKernelGGL(chain_keys_kernel<uint32_t>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, lv, n, stride,
+                       clump_shift, x, y, z, routed, (uint32_t*)keys);
   else
-    hipLaunchKernelGGL(chain_keys_kernel<uint64_t>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, lv, n, stride, x, y,
-                       z, routed, (uint64_t*)keys);
+    hipLaunchKernelGGL(chain_keys_kernel<uint64_t>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, lv, n, stride,
+                       clump_shift, x, y, z, routed, (uint64_t*)keys);
 }
 
 void pcv_launch_chain_keys_deep(pcv_ctx* ctx, const PcvLevels& lv, uint64_t n, const double* x, const double* y,

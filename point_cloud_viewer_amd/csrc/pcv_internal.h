@@ -242,8 +242,10 @@ struct PcvRouted {
   const uint32_t* cz = nullptr;
 };
 // keys32: store the first 10 levels only as u32 (key >> 33); stride > 1: strided sample of the input.
+// clump_shift: the strided sample is taken in clumps of 2^clump_shift consecutive points (0 = single points).
 void pcv_launch_chain_keys(pcv_ctx* ctx, const PcvLevels& lv, uint64_t n, uint64_t stride, const double* x,
-                           const double* y, const double* z, void* keys, bool keys32, const PcvRouted& routed = PcvRouted());
+                           const double* y, const double* z, void* keys, bool keys32, const PcvRouted& routed = PcvRouted(),
+                           uint32_t clump_shift = 0);
 void pcv_launch_depth_probe(pcv_ctx* ctx, const uint64_t* sorted, uint32_t n, uint32_t gap, uint32_t* out);
 
 // pcv_sort.hip — stable LSD radix sort, 8-bit digits, reduce-then-scan with LDS histograms.

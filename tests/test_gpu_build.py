@@ -261,7 +261,10 @@ def test_depth_speculation_failure_falls_back_to_full_depth(ctx):
     x = rng.uniform(0.0, 500.0, n)
     y = rng.uniform(0.0, 500.0, n)
     z = rng.uniform(0.0, 500.0, n)
-    hidden = (np.arange(n) % stride) != 0
+    # visible to the exact pipeline's depth probe: every 16th point; to the single-chain build's sample: clumps of 8
+    # consecutive points every 256 (every 32nd point on average)
+    idx = np.arange(n)
+    hidden = ((idx % stride) != 0) & ((idx % 256) >= 8)
     m = int(hidden.sum())
     x[hidden] = 250.0 + rng.normal(0.0, 0.01, m)
     y[hidden] = 125.0 + rng.normal(0.0, 0.01, m)
@@ -274,7 +277,7 @@ def test_depth_speculation_failure_falls_back_to_full_depth(ctx):
     assert info["attempts"] == 2, info
     assert_same(t.to_dict(), want)
     t.free()
-    # the single-chain build samples every 32nd point and is fooled the same way: its prediction is too shallow, the
+    # the single-chain build samples one point in 32 (in clumps) and is fooled the same way: its prediction is too shallow, the
     # exact counts notice, the exact pipeline (whose depth probe is fooled too) redoes the build
     t = ctx.build(0.001, pcv.Aabb(bmin, bmax), x, y, z, rgb)
     info = t.build_info()
