@@ -586,6 +586,7 @@ struct PcvBuild {
   };
   std::vector<FixRange> fix_ranges;  // sorted slots whose points replay the chain after the record sort
   const uint32_t* spec_map_dev = nullptr;  // set: the record sort's first upsweep applies the rank map / payload patch
+  uint32_t spec_map_entries = 0;
   const void* spec_kept = nullptr;
   // the record sort (queue_record_sort): buffers and where the sorted records ended up
   bool sort_queued = false, rec_in_a = true;
@@ -808,8 +809,8 @@ static int queue_record_sort(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, const Pc
   while ((1ull << rank_bits) < num_leaves) ++rank_bits;
   bool rec_in_a = true;
   if (bs->spec_map_dev)
-    rc = pcv_radix_sort_records_mapped(ctx, rank_a, rank_b, n, rank_bits, &pl, bs->sort_scratch, bs->spec_map_dev, bs->spec_kept,
-                                       &rec_in_a);
+    rc = pcv_radix_sort_records_mapped(ctx, rank_a, rank_b, n, rank_bits, &pl, bs->sort_scratch, bs->spec_map_dev,
+                                       bs->spec_map_entries, bs->spec_kept, &rec_in_a);
   else
     rc = pcv_radix_sort_u32(ctx, rank_a, rank_b, n, 0, rank_bits, &pl, bs->sort_scratch, &rec_in_a);
   if (rc) return rc;
@@ -1019,6 +1020,7 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
   }();
   if (fuse) {
     bs->spec_map_dev = d_map;
+    bs->spec_map_entries = tree.num_leaves;
     bs->spec_kept = kept;
   } else {
     pcv_launch_spec_finalize(ctx, n, d_map, rank, payload, kept);

@@ -265,8 +265,8 @@ int pcv_radix_sort_u32(pcv_ctx* ctx, uint32_t* keys_a, uint32_t* keys_b, uint64_
                        PcvSortPayload* payload, void* scratch, bool* result_in_a);
 
 int pcv_radix_sort_records_mapped(pcv_ctx* ctx, uint32_t* keys_a, uint32_t* keys_b, uint64_t n, int key_bits,
-                                  PcvSortPayload* payload, void* scratch, const uint32_t* map, const void* kept,
-                                  bool* result_in_a);
+                                  PcvSortPayload* payload, void* scratch, const uint32_t* map, uint32_t map_entries,
+                                  const void* kept, bool* result_in_a);
 
 // pcv_topology.hip — node split (topology from sorted keys).
 // Device node table, structure of arrays, BFS order (level-major, prefix-sorted inside a level).

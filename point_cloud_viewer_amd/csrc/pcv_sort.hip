@@ -137,13 +137,22 @@ __global__ __launch_bounds__(kBlock) void upsweep_kernel(const KeyT* __restrict_
 // work on the way — rank := map[rank] (written back in place), payload := kept codes where the map says so (bit 31),
 // payload.x := own index where the point has to replay its chain after the sort (bit 30) — and counts the digits of
 // the MAPPED ranks. One pass over the ranks instead of two (finalize + upsweep); the downsweep is the ordinary one.
+// kMapLds: the map (one entry per predicted leaf; 26 KB for a 100 M-point tree) is copied into LDS first — eight
+// dependent lookups per lane and iteration then cost LDS latency instead of a trip to the vector L1 / L2 that the
+// streaming keys keep evicting it from.
+constexpr uint32_t kMapLdsEntries = 24576;  // 96 KB
+template <bool kMapLds>
 __global__ __launch_bounds__(kBlock) void upsweep_map_kernel(uint32_t* __restrict__ keys, uint64_t n, uint64_t chunk, int groups,
                                                               int shift, uint32_t mask, uint32_t* __restrict__ hist,
-                                                              const uint32_t* __restrict__ map, uint4* __restrict__ payload,
-                                                              const uint4* __restrict__ kept) {
+                                                              const uint32_t* __restrict__ gmap, uint32_t map_entries,
+                                                              uint4* __restrict__ payload, const uint4* __restrict__ kept) {
   __shared__ uint32_t wh[kWaves][kRadix];
+  extern __shared__ uint32_t smap[];  // kMapLds: map_entries words (dynamic, so small maps keep the occupancy)
   const int wave = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < kWaves * kRadix; i += kBlock) (&wh[0][0])[i] = 0;
+  if (kMapLds)
+    for (uint32_t i = threadIdx.x; i < map_entries; i += kBlock) smap[i] = gmap[i];
+  const uint32_t* map = kMapLds ? smap : gmap;
   __syncthreads();
   const uint64_t begin = (uint64_t)blockIdx.x * chunk;
   uint64_t end = begin + chunk;
@@ -151,11 +160,12 @@ __global__ __launch_bounds__(kBlock) void upsweep_map_kernel(uint32_t* __restric
   auto one = [&](uint64_t idx, uint32_t m) -> uint32_t {
     if (m & (1u << 30)) {
       reinterpret_cast<uint32_t*>(payload + idx)[0] = (uint32_t)idx;
-    } else if (m & (1u << 31)) {
+    } else if (m & (1u << 31)) {  // the three code words only: the colour word stays, so the payload is not read
       const uint4 k = kept[idx];
-      uint4 p = payload[idx];
-      p.x = k.x, p.y = k.y, p.z = k.z;
-      payload[idx] = p;
+      uint32_t* p = reinterpret_cast<uint32_t*>(payload + idx);
+      p[0] = k.x;
+      p[1] = k.y;
+      p[2] = k.z;
     }
     return m & PCV_SPEC_INDEX_MASK_SORT;
   };
@@ -527,7 +537,8 @@ __global__ __launch_bounds__(kBlock, kHasVec ? 3 : 4) void downsweep_rec_kernel(
 
 template <typename KeyT>
 int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int end_bit, PcvSortPayload* payload,
-               void* scratch, bool* result_in_a, const uint32_t* map = nullptr, const void* kept = nullptr) {
+               void* scratch, bool* result_in_a, const uint32_t* map = nullptr, const void* kept = nullptr,
+               uint32_t map_entries = 0) {
   *result_in_a = true;
   if (n == 0 || end_bit <= begin_bit) return PCV_OK;
   if (n >= 0xffffffffull) return ctx->fail(PCV_E_INVALID, "radix sort: n must be < 2^32 - 1");
@@ -550,8 +561,14 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
     KeyT* dst = in_a ? b : a;
     if (map && shift == begin_bit && sizeof(KeyT) == 4 && payload && payload->vec_in) {
       PcvProf prof(ctx, PCV_K_SORT_UPSWEEP_MAP);  // finalize fused into the first upsweep
-      hipLaunchKernelGGL(upsweep_map_kernel, dim3(g.groups), dim3(kBlock), 0, ctx->stream, (uint32_t*)src, n, g.chunk, g.groups,
-                         shift, mask, hist, map, (uint4*)(in_a ? payload->vec_in : payload->vec_out), (const uint4*)kept);
+      if (map_entries && map_entries <= kMapLdsEntries)
+        hipLaunchKernelGGL(upsweep_map_kernel<true>, dim3(g.groups), dim3(kBlock), (size_t)map_entries * 4, ctx->stream, (uint32_t*)src, n, g.chunk,
+                           g.groups, shift, mask, hist, map, map_entries, (uint4*)(in_a ? payload->vec_in : payload->vec_out),
+                           (const uint4*)kept);
+      else
+        hipLaunchKernelGGL(upsweep_map_kernel<false>, dim3(g.groups), dim3(kBlock), 0, ctx->stream, (uint32_t*)src, n, g.chunk,
+                           g.groups, shift, mask, hist, map, map_entries, (uint4*)(in_a ? payload->vec_in : payload->vec_out),
+                           (const uint4*)kept);
     } else {
       PcvProf prof(ctx, sizeof(KeyT) == 8 ? PCV_K_SORT_UPSWEEP64 : PCV_K_SORT_UPSWEEP32);
       hipLaunchKernelGGL(upsweep_kernel<KeyT>, dim3(g.groups), dim3(kBlock), 0, ctx->stream, src, n, g.chunk,
@@ -610,7 +627,7 @@ int pcv_radix_sort_u32(pcv_ctx* ctx, uint32_t* keys_a, uint32_t* keys_b, uint64_
 }
 // Record sort whose first upsweep also translates the ranks through `map` and patches the payloads (single-chain build)
 int pcv_radix_sort_records_mapped(pcv_ctx* ctx, uint32_t* keys_a, uint32_t* keys_b, uint64_t n, int key_bits,
-                                  PcvSortPayload* payload, void* scratch, const uint32_t* map, const void* kept,
-                                  bool* result_in_a) {
-  return radix_sort<uint32_t>(ctx, keys_a, keys_b, n, 0, key_bits, payload, scratch, result_in_a, map, kept);
+                                  PcvSortPayload* payload, void* scratch, const uint32_t* map, uint32_t map_entries,
+                                  const void* kept, bool* result_in_a) {
+  return radix_sort<uint32_t>(ctx, keys_a, keys_b, n, 0, key_bits, payload, scratch, result_in_a, map, kept, map_entries);
 }
