@@ -285,3 +285,30 @@ def test_nodes_blob_matches_web_viewer_wire_format(ctx, scene):
         want = pad(want + tree.node_data(i, 0))
         want = pad(want + tree.node_data(i, 1))
     assert tree.nodes_blob(picks) == want
+
+
+def test_query_points_all_four_encodings(ctx):
+    """City-scale extent at 1 mm: Float64 root / level 1, Float32, UInt16 and UInt8 levels below (codec.rs:31-40), a small
+    capacity so that every encoding holds points; every chunk size of the staged decode (256 / 512 / 1 024 / 2 048
+    points, quartered for this small query) against the oracle's decode + contains + retain."""
+    x, y, z, rgb, bmin, bmax = synthetic.gaussian_clusters(340_000, seed=12, num_clusters=6, extent=30000.0,
+                                                           sigma_range=(5.0, 400.0), offset=(-2.7e6, -4.3e6, 3.8e6))
+    rng = np.random.default_rng(13)  # one tight cluster: deep UInt8 levels
+    c = np.array([x[0], y[0], z[0]])
+    x = np.concatenate([x, c[0] + rng.normal(0.0, 0.03, 60_000)])
+    y = np.concatenate([y, c[1] + rng.normal(0.0, 0.03, 60_000)])
+    z = np.concatenate([z, c[2] + rng.normal(0.0, 0.03, 60_000)])
+    rgb = synthetic.index_colors(x.size)
+    bmin, bmax = np.array([x.min(), y.min(), z.min()]), np.array([x.max(), y.max(), z.max()])
+    inten = (np.arange(x.size) % 251).astype(np.float32)
+    tree = ctx.build(0.001, pcv.Aabb(bmin, bmax), x, y, z, rgb, inten, max_points_per_node=1500)
+    with O.max_points_per_node(1500):
+        want = O.build_closed(0.001, bmin, bmax, x, y, z, rgb, inten, threads=8)
+    scene = dict(bmin=bmin, bmax=bmax, tree=tree, oracle=want, names=tree.node_names())
+    encodings = {tree.node(i).encoding for i in range(tree.num_nodes) if tree.node(i).num_points > 0}
+    assert encodings == {1, 2, 3, 4}, encodings
+    lo, hi = bmin + (bmax - bmin) * 0.1, bmin + (bmax - bmin) * 0.8
+    shapes = [("all",), ("aabb", lo, hi)]
+    kinds = [(O.SHAPE_ALL, None), (O.SHAPE_AABB, list(lo) + list(hi))]
+    prepared = ctx.shapes(shapes)
+    assert check_query_points(scene, prepared, kinds) >= 3
