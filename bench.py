@@ -426,6 +426,12 @@ def main():
     timed = {k: v for k, v in kstats.items() if v[0] > 0}
     plain = n == 100_000_000 and world == 1 and not sharded and not args.ecef
     if timed:
+        # packed 12-byte records (single-chain build, build_info record_bytes == 12): u32 key + uint2 payload
+        rec_b = float((info.get("build") or {}).get("record_bytes") or 20)
+        if rec_b == 12.0:
+            ALGO_BYTES.update({"downsweep_rec_kernel": 2 * 12.0, "promote_settle_kernel": 12.0 + 7.0 / 8.0 * 9.0,
+                               "spec_encode_kernel": 24.0 + 3.0 + 12.0})
+
         def hbm_view(name):
             launches, ms = timed[name]
             avg_ms = ms / launches
@@ -482,14 +488,15 @@ def main():
         rec = timed.get("downsweep_rec_kernel")
         rec_passes = rec[0] / args.steps if rec else 0.0
         rec_ms = st.get("sort_records", 0.0)
-        record_sort = None if not rec else {"passes": rec_passes, "ms": round(rec_ms, 3),
-                                            "GB/s": round(n * rec_passes * 44.0 / (rec_ms * 1e-3) / 1e9, 1) if rec_ms else None,
-                                            "algorithmic_bytes_per_point": rec_passes * 44.0}
+        pass_b = 4.0 + 2 * rec_b  # per pass: 4 B histogram read + record read + record write
+        record_sort = None if not rec else {"passes": rec_passes, "ms": round(rec_ms, 3), "record_bytes": rec_b,
+                                            "GB/s": round(n * rec_passes * pass_b / (rec_ms * 1e-3) / 1e9, 1) if rec_ms else None,
+                                            "algorithmic_bytes_per_point": rec_passes * pass_b}
         if binfo.get("single_chain"):
             # single-chain build: the encode is the one chain pass (read xyz + rgb, write rank + payload), the sort is the
-            # stable record sort by leaf rank (per pass: 4 B histogram read + 20 B read + 20 B write) — no key sort exists
+            # stable record sort by leaf rank (per pass: 4 B histogram read + record read + record write) — no key sort exists
             es_ms = st.get("leaf_encode", 0.0) + rec_ms
-            es_bytes_pp = 47.0 + rec_passes * 44.0
+            es_bytes_pp = 27.0 + rec_b + rec_passes * pass_b
             encode_sort = {"GB/s": round(n * es_bytes_pp / (es_ms * 1e-3) / 1e9, 1) if es_ms else None, "ms": round(es_ms, 3),
                            "pipeline": "single-chain: spec_encode + record sort", "algorithmic_bytes_per_point": es_bytes_pp,
                            "record_sort": record_sort}

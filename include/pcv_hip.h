@@ -225,6 +225,9 @@ void pcv_octree_build_info(const pcv_octree* t, int* key_levels, int* attempts);
 /* Single-chain build statistics of the last build (zeros otherwise): nodes and leaves of the predicted tree, points
  * that took the codes kept at a candidate node, points that replayed the chain in the finalize kernel. */
 void pcv_octree_spec_stats(const pcv_octree* t, uint64_t stats[4]);
+/* Bytes of one record of the last build's record sort (rank + leaf codes + colour): 20, or 12 when the single-chain
+ * build packed the record (16-bit codes; the points of Float32-coded leaves travel as their input index). */
+int pcv_octree_record_bytes(const pcv_octree* t);
 
 /* ---- stage-level entry points (unit parity against the oracle) ------------------------------ */
 /* K1: find_bounding_box (generation.rs:256-270; Aabb::grow aabb.rs:41-44). n == 0 -> Aabb::zero(). */

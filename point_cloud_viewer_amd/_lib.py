@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpcv_hip.so")
+# PCV_HIP_LIBRARY: an alternative in-tree build of the same sources (tools/build_variants.sh, experiments only)
+LIB_PATH = os.environ.get("PCV_HIP_LIBRARY") or os.path.join(_HERE, "libpcv_hip.so")
 
 PCV_OK = 0
 PCV_E_INVALID, PCV_E_HIP, PCV_E_IO, PCV_E_OOM, PCV_E_DEPTH, PCV_E_NOT_FOUND = -1, -2, -3, -4, -5, -6
@@ -116,6 +117,7 @@ _SIGNATURES = {
     "pcv_octree_stage_ms": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_int]),
     "pcv_octree_build_info": (None, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pcv_octree_spec_stats": (None, [_vp, C.POINTER(C.c_uint64)]),
+    "pcv_octree_record_bytes": (C.c_int, [_vp]),
     "pcv_aabb_reduce": (C.c_int, [_vp, C.POINTER(Points), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "pcv_level_table": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_int,
                                   C.POINTER(C.c_double), C.POINTER(C.c_int32)]),

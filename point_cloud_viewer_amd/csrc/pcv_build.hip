@@ -449,7 +449,7 @@ int pcv_make_levels(const double bmin[3], const double bmax[3], double resolutio
       lv->inv_edge[j] = (e[j] >= 0x1p-100 && e[j] <= 0x1p+100) ? 1.0 / e[j] : 0.0;
       // low word of the double-double reciprocal: (1 - e * yh) is exact in one FMA, divided by e and rounded
       lv->inv_edge_lo[j] = lv->inv_edge[j] != 0.0 ? std::fma(-e[j], lv->inv_edge[j], 1.0) / e[j] : 0.0;
-      lv->enc[j] = (uint8_t)c[j];
+      lv->enc[j] = (uint32_t)c[j];
       tame = tame && lv->inv_edge[j] != 0.0;
     }
     lv->fast_ok = tame ? 1 : 0;
@@ -580,7 +580,9 @@ struct PcvBuild {
   uint64_t* d_prefix_lo = nullptr;
   // single-chain build: the records (true-leaf rank, leaf codes + rgb[, intensity]) already exist when the topology does
   bool spec = false;
-  void* spec_payload = nullptr;  // uint4[n]
+  void* spec_payload = nullptr;  // uint4[n]; uint2[n] with 12-byte records
+  void* spec_wide = nullptr;     // set: 12-byte records (pcv_internal.h); uint4[n], the codes of Float32-coded leaves
+  uint64_t wide_levels = 0;      // bit k: level k is Float32-coded
   struct FixRange {
     uint32_t lo, count, level;
   };
@@ -642,6 +644,7 @@ extern "C" void pcv_octree_spec_stats(const pcv_octree* t, uint64_t stats[4]) {
   if (!t || !stats) return;
   for (int k = 0; k < 4; ++k) stats[k] = t->spec_stats[k];
 }
+extern "C" int pcv_octree_record_bytes(const pcv_octree* t) { return t ? t->record_bytes : 0; }
 extern "C" int pcv_octree_device_blob(const pcv_octree* t, int which, const void** dptr, uint64_t* len) {
   if (!t || !dptr || !len || which < 0 || which > 2) return PCV_E_INVALID;
   *dptr = which == 0 ? t->d_xyz : (which == 1 ? t->d_rgb : t->d_int);
@@ -780,12 +783,21 @@ static int queue_record_sort(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, const Pc
   int rc;
   uint32_t* rank_a = (uint32_t*)bs->keys_a;
   uint32_t* rank_b = (uint32_t*)bs->keys_b;
+  const bool compact = bs->spec_wide != nullptr;  // 12-byte records: uint2 payloads
   uint4 *pay_a = (uint4*)bs->spec_payload, *pay_b;
-  if ((!pay_a && (rc = sc.get(&pay_a, n))) || (rc = sc.get(&pay_b, n))) return rc;
+  if (compact) {
+    uint2* b2;
+    if ((rc = sc.get(&b2, n))) return rc;
+    pay_b = (uint4*)b2;
+  } else if ((!pay_a && (rc = sc.get(&pay_a, n))) || (rc = sc.get(&pay_b, n))) {
+    return rc;
+  }
   PcvSortPayload& pl = bs->pl;
   pl = PcvSortPayload();
   pl.vec_in = pay_a;
   pl.vec_out = pay_b;
+  pl.vec_bytes = compact ? 8 : 16;
+  t->record_bytes = compact ? 12 : 20;
   pl.nwords = (t->has_intensity ? 1 : 0) + (wide ? 3 : 0);
   for (int w = 0; w < pl.nwords; ++w) {
     if (w == 0) {  // first plane fits in the second half of the key buffers
@@ -810,7 +822,7 @@ static int queue_record_sort(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, const Pc
   bool rec_in_a = true;
   if (bs->spec_map_dev)
     rc = pcv_radix_sort_records_mapped(ctx, rank_a, rank_b, n, rank_bits, &pl, bs->sort_scratch, bs->spec_map_dev,
-                                       bs->spec_map_entries, bs->spec_kept, &rec_in_a);
+                                       bs->spec_map_entries, bs->spec_kept, &rec_in_a, bs->spec_wide, bs->wide_levels);
   else
     rc = pcv_radix_sort_u32(ctx, rank_a, rank_b, n, 0, rank_bits, &pl, bs->sort_scratch, &rec_in_a);
   if (rc) return rc;
@@ -837,7 +849,7 @@ static int queue_record_sort(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, const Pc
       before += bs->fix_ranges[k].count;
     }
     PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_ranges, h_ranges, (size_t)nr * 16, hipMemcpyHostToDevice, st));
-    pcv_launch_spec_replay(ctx, lv, d_ranges, nr, before, d.x, d.y, d.z, d.routed, (void*)s_pay);
+    pcv_launch_spec_replay(ctx, lv, d_ranges, nr, before, d.x, d.y, d.z, d.routed, (void*)s_pay, bs->spec_wide);
   }
   ctx->stage_end(PCV_STAGE_SORT_RECORDS);
   bs->sort_queued = true;
@@ -887,7 +899,25 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
     return rc;
   uint32_t* rank = (uint32_t*)bs->keys_a;
   uint4 *payload, *kept;  // kept codes: always provided (whether any node is a candidate is only known on the device)
-  if ((rc = sc.get(&payload, n)) || (rc = sc.get(&kept, n))) return rc;
+  // 12-byte records (pcv_internal.h) unless switched off (PCV_COMPACT_RECORDS=0, experiments) or the predicted tree could
+  // outgrow the 24 rank bits of the key
+  static const bool compact_on = [] {
+    const char* e = getenv("PCV_COMPACT_RECORDS");
+    return !e || atoi(e) != 0;
+  }();
+  const bool compact = compact_on && tcap <= (1u << 24);
+  uint4* wide = nullptr;
+  uint64_t wide_levels = 0;
+  for (int k = 0; k <= full_levels && k < 64; ++k)
+    if (lv.enc[k] > PCV_ENC_UINT16) wide_levels |= 1ull << k;
+  if (compact) {
+    uint2* p2;
+    if ((rc = sc.get(&p2, n)) || (rc = sc.get(&wide, n))) return rc;
+    payload = (uint4*)p2;
+    if ((rc = sc.get(&kept, n))) return rc;
+  } else if ((rc = sc.get(&payload, n)) || (rc = sc.get(&kept, n))) {
+    return rc;
+  }
   uint32_t* inten_bits = t->has_intensity ? (uint32_t*)bs->keys_a + n : nullptr;
   uint8_t* depth_grid = nullptr;
   if (n >= (1u << 20) && (rc = sc.get(&depth_grid, pcv_spec_depth_grid_bytes()))) return rc;  // small builds: not worth a 2 MiB fill
@@ -943,7 +973,7 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
     ctx->stage_begin(PCV_STAGE_LEAF_ENCODE);
     lv.nlevels = full_levels;
     pcv_launch_spec_encode(ctx, lv, d_walk, n, d.x, d.y, d.z, d.routed, d.color, d.color_stride, d.intensity, rank, payload, kept,
-                           inten_bits, depth_grid);
+                           inten_bits, depth_grid, wide);
     ctx->stage_end(PCV_STAGE_LEAF_ENCODE);
     host_lap("chain pass queued");
 
@@ -991,7 +1021,7 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
 
   // ---- exact counts -> true tree ----
   ctx->stage_begin(PCV_STAGE_NODE_SPLIT);
-  pcv_launch_rank_hist(ctx, rank, n, tree.num_leaves, d_counts);
+  pcv_launch_rank_hist(ctx, rank, n, tree.num_leaves, d_counts, compact ? 8 : 0);
   PCV_HIP_CHECK(ctx, hipGetLastError());
   if ((rc = ctx->pinned_spec_reserve((size_t)tree.num_leaves * 8 + 512))) return rc;
   uint8_t* hp = (uint8_t*)ctx->pinned_spec;
@@ -1007,6 +1037,10 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
     ctx->dev_free(payload);
     sc.detach(kept);
     ctx->dev_free(kept);
+    if (wide) {
+      sc.detach(wide);
+      ctx->dev_free(wide);
+    }
     return PCV_OK;  // *used stays false
   }
   if (tt->prefix.size() > (size_t)nt.capacity) return ctx->fail(PCV_E_OOM, "node table capacity exceeded");
@@ -1018,7 +1052,9 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
     const char* e = getenv("PCV_SPEC_FUSE");
     return !e || atoi(e) != 0;
   }();
-  if (fuse) {
+  bs->spec_wide = wide;
+  bs->wide_levels = wide_levels;
+  if (fuse || compact) {  // 12-byte records are only patched by the fused pass
     bs->spec_map_dev = d_map;
     bs->spec_map_entries = tree.num_leaves;
     bs->spec_kept = kept;
@@ -1041,7 +1077,7 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
   // in the caller and in pcv_build_finish) is built while it runs. A mis-staged mailbox is the one thing to avoid:
   // with more than 32 replay ranges the staging synchronises first.
   host_lap("map upload, fix ranges");
-  if (fuse && (rc = queue_record_sort(ctx, bs, t, nullptr, tt->num_leaves, false))) return rc;
+  if ((fuse || compact) && (rc = queue_record_sort(ctx, bs, t, nullptr, tt->num_leaves, false))) return rc;
   host_lap("record sort queued");
   ctx->stage_begin(PCV_STAGE_TABLE);
   t->spec_stats[0] = tree.prefix.size();
@@ -1619,14 +1655,14 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
   }
   // the compact climber records live in the payload buffer the sort left unused (32 B x n / 8 < 16 B x n)
   void* climbers = rec_in_a ? (void*)pay_b : (void*)pay_a;
-  if (pcv_climber_bytes(num_climbers) > (size_t)n * 16) {
+  if (pcv_climber_bytes(num_climbers) > (size_t)n * (bs->spec_wide ? 8 : 16)) {
     if ((rc = ctx->dev_alloc(&climbers, pcv_climber_bytes(num_climbers)))) return rc;
     sc.ptrs.push_back(climbers);
   }
   pcv_launch_promote_encode(ctx, lv, pt, n, s_rank, s_pay, wide ? s_plane[w_hi] : nullptr,
                             wide ? s_plane[w_hi + 1] : nullptr, wide ? s_plane[w_hi + 2] : nullptr,
                             w_int >= 0 ? s_plane[w_int] : nullptr, d_climb_base, (uint32_t)num_climbers, climbers, t->d_xyz,
-                            t->d_rgb, t->d_int);
+                            t->d_rgb, t->d_int, bs->spec_wide);
   ctx->stage_end(PCV_STAGE_PROMOTE_ENCODE);
   PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[8], st));
   PCV_HIP_CHECK(ctx, hipGetLastError());

@@ -119,6 +119,12 @@ __device__ __forceinline__ uint64_t pcv_val_to_code(uint32_t enc, double cd) {
   }
 }
 
+// `min += bit as f64 * edge` (node.rs:161-170): the product is exactly `edge` or +0.0, so a single FMA with the bit as
+// 1.0 / 0.0 rounds identically (one select for the high word of the factor + the FMA instead of two selects + an add).
+__device__ __forceinline__ double pcv_step_min(double mn, bool bit, double ec) {
+  return __fma_rn(__hiloint2double(bit ? 0x3ff00000 : 0, 0), ec, mn);
+}
+
 // One level of the chain for one coordinate with the encoding known at compile time: returns the octant bit,
 // moves `mn` to the child cube, replaces `p` by its encode->decode image in the child cube and reports the code
 // (value domain).
@@ -128,7 +134,7 @@ __device__ __forceinline__ uint32_t pcv_chain_coord_t(double e_parent, double e_
   const double mx = mn + e_parent;
   const double c = (mn + mx) / 2.0;
   const uint32_t bit = p > c ? 1u : 0u;
-  mn = mn + (bit ? e_child : 0.0);  // `bit as f64 * edge` is exactly e or +0.0
+  mn = pcv_step_min(mn, bit != 0u, e_child);
   cd = pcv_encode_val<ENC, GUARD>(p, mn, e_child, inv_e_child);
   p = pcv_decode_val<ENC>(cd, mn, e_child);
   return bit;
@@ -170,9 +176,9 @@ __device__ __forceinline__ uint32_t pcv_chain_digit(double e_parent, double px, 
 template <int ENC, bool GUARD>
 __device__ __forceinline__ void pcv_chain_apply_t(uint32_t d, double ec, PcvRecip ic, double& px, double& py, double& pz, double& mx,
                                                   double& my, double& mz, double& cx, double& cy, double& cz) {
-  mx = mx + ((d & 4u) ? ec : 0.0);  // `bit as f64 * edge` is exactly e or +0.0
-  my = my + ((d & 2u) ? ec : 0.0);
-  mz = mz + ((d & 1u) ? ec : 0.0);
+  mx = pcv_step_min(mx, (d & 4u) != 0u, ec);
+  my = pcv_step_min(my, (d & 2u) != 0u, ec);
+  mz = pcv_step_min(mz, (d & 1u) != 0u, ec);
   cx = pcv_encode_val<ENC, GUARD>(px, mx, ec, ic);
   cy = pcv_encode_val<ENC, GUARD>(py, my, ec, ic);
   cz = pcv_encode_val<ENC, GUARD>(pz, mz, ec, ic);
@@ -207,9 +213,9 @@ __device__ __forceinline__ int pcv_chain_start(const PcvLevels& lv, const PcvRou
   }
   d1 = r.oct[src * r.oct_stride] & 7u;
   const double e1 = lv.edge[1];
-  mx = mx + ((d1 & 4u) ? e1 : 0.0);
-  my = my + ((d1 & 2u) ? e1 : 0.0);
-  mz = mz + ((d1 & 1u) ? e1 : 0.0);
+  mx = pcv_step_min(mx, (d1 & 4u) != 0u, e1);
+  my = pcv_step_min(my, (d1 & 2u) != 0u, e1);
+  mz = pcv_step_min(mz, (d1 & 1u) != 0u, e1);
   vx = (double)__uint_as_float(r.cx[src]);
   vy = (double)__uint_as_float(r.cy[src]);
   vz = (double)__uint_as_float(r.cz[src]);

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(BLOCK) void spec_encode_kernel(
     const double* __restrict__ y, const double* __restrict__ z, PcvRouted routed, const uint8_t* __restrict__ color,
     uint32_t color_stride, const float* __restrict__ intensity, uint32_t* __restrict__ rank, uint4* __restrict__ payload,
     uint4* __restrict__ kept, uint32_t* __restrict__ inten_bits, const uint8_t* __restrict__ depth_grid,
-    float cells_per_unit /* 128 / root edge */) {
+    float cells_per_unit /* 128 / root edge */, uint4* __restrict__ wide /* set: 12-byte records */) {
   constexpr int kWavesB = BLOCK / 64;
   __shared__ double sx[BIN ? BLOCK : 1], sy[BIN ? BLOCK : 1], sz[BIN ? BLOCK : 1];
   __shared__ uint16_t perm[BIN ? BLOCK : 1];
@@ -216,11 +216,25 @@ __global__ __launch_bounds__(BLOCK) void spec_encode_kernel(
     PCV_SPEC_WALK(true)
   }
 #undef PCV_SPEC_WALK
-  rank[i] = rec & PCV_SPEC_INDEX_MASK;
   const uint32_t leaf_enc = lv.enc[L];
   const uint8_t* c = color + i * color_stride;
-  payload[i] = make_uint4((uint32_t)pcv_val_to_code(leaf_enc, vx), (uint32_t)pcv_val_to_code(leaf_enc, vy),
-                          (uint32_t)pcv_val_to_code(leaf_enc, vz), (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16));
+  const uint32_t ccx = (uint32_t)pcv_val_to_code(leaf_enc, vx), ccy = (uint32_t)pcv_val_to_code(leaf_enc, vy),
+                 ccz = (uint32_t)pcv_val_to_code(leaf_enc, vz);
+  if (wide) {
+    // 12-byte record: key = rank << 8 | blue, payload = {cx | cy << 16, cz | red << 16 | green << 24}. The codes of a
+    // Float32-coded leaf level do not fit: they go to the point's `wide` entry and the record carries the input index.
+    rank[i] = ((rec & PCV_SPEC_INDEX_MASK) << 8) | (uint32_t)c[2];
+    const uint32_t rg = ((uint32_t)c[0] << 16) | ((uint32_t)c[1] << 24);
+    if (leaf_enc <= PCV_ENC_UINT16) {
+      reinterpret_cast<uint2*>(payload)[i] = make_uint2(ccx | (ccy << 16), ccz | rg);
+    } else {
+      reinterpret_cast<uint2*>(payload)[i] = make_uint2((uint32_t)i, rg);
+      wide[i] = make_uint4(ccx, ccy, ccz, 0u);
+    }
+  } else {
+    rank[i] = rec & PCV_SPEC_INDEX_MASK;
+    payload[i] = make_uint4(ccx, ccy, ccz, (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16));
+  }
   if (KEEP && kl) {
     const uint32_t ke = lv.enc[kl];
     kept[i] = make_uint4((uint32_t)pcv_val_to_code(ke, kx), (uint32_t)pcv_val_to_code(ke, ky), (uint32_t)pcv_val_to_code(ke, kz),
@@ -233,7 +247,8 @@ __global__ __launch_bounds__(BLOCK) void spec_encode_kernel(
 // [bin_base, bin_base + nbins), nbins <= kHistBins; one flush of the non-zero bins per workgroup.
 constexpr int kHistBins = 12288;  // 48 KiB of LDS
 __global__ __launch_bounds__(1024) void rank_hist_kernel(const uint32_t* __restrict__ rank, uint64_t n, uint64_t chunk,
-                                                          uint32_t bin_base, uint32_t nbins, uint32_t* __restrict__ counts) {
+                                                          uint32_t bin_base, uint32_t nbins, uint32_t* __restrict__ counts,
+                                                          int shift /* 8: 12-byte records, the rank sits above the blue byte */) {
   __shared__ uint32_t hist[kHistBins];
   for (uint32_t b = threadIdx.x; b < nbins; b += 1024) hist[b] = 0;
   __syncthreads();
@@ -244,13 +259,14 @@ __global__ __launch_bounds__(1024) void rank_hist_kernel(const uint32_t* __restr
   for (uint64_t i = begin + (uint64_t)threadIdx.x * 4; i < end; i += 4096) {
     if (i + 4 <= end) {
       const uint4 v = *reinterpret_cast<const uint4*>(rank + i);
-      const uint32_t r[4] = {v.x - bin_base, v.y - bin_base, v.z - bin_base, v.w - bin_base};
+      const uint32_t r[4] = {(v.x >> shift) - bin_base, (v.y >> shift) - bin_base, (v.z >> shift) - bin_base,
+                             (v.w >> shift) - bin_base};
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         if (r[k] < nbins) atomicAdd(&hist[r[k]], 1u);
     } else {
       for (uint64_t j = i; j < end; ++j) {
-        const uint32_t r = rank[j] - bin_base;
+        const uint32_t r = (rank[j] >> shift) - bin_base;
         if (r < nbins) atomicAdd(&hist[r], 1u);
       }
     }
@@ -307,7 +323,8 @@ struct PcvFixRange {
 __global__ __launch_bounds__(256) void spec_replay_kernel(PcvLevels lv, const PcvFixRange* __restrict__ ranges, uint32_t num_ranges,
                                                            uint32_t total, const double* __restrict__ x,
                                                            const double* __restrict__ y, const double* __restrict__ z,
-                                                           PcvRouted routed, uint4* __restrict__ payload) {
+                                                           PcvRouted routed, uint4* __restrict__ payload,
+                                                           uint4* __restrict__ wide /* set: 12-byte records */) {
   for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < total; j += gridDim.x * 256) {
     uint32_t a = 0, b = num_ranges;  // last range with before <= j
     while (b - a > 1) {
@@ -317,7 +334,14 @@ __global__ __launch_bounds__(256) void spec_replay_kernel(PcvLevels lv, const Pc
     }
     const PcvFixRange rg = ranges[a];
     const uint64_t s = (uint64_t)rg.lo + (j - rg.before);
-    uint4 p = payload[s];
+    uint4 p = make_uint4(0, 0, 0, 0);
+    uint2 q = make_uint2(0, 0);
+    if (wide) {
+      q = reinterpret_cast<const uint2*>(payload)[s];
+      p.x = q.x;
+    } else {
+      p = payload[s];
+    }
     const uint64_t i = p.x;  // the input index the finalize kernel left here
     const int target = (int)rg.level;
     double px, py, pz, mx, my, mz;
@@ -333,7 +357,13 @@ __global__ __launch_bounds__(256) void spec_replay_kernel(PcvLevels lv, const Pc
     p.x = (uint32_t)pcv_val_to_code(en, vx);
     p.y = (uint32_t)pcv_val_to_code(en, vy);
     p.z = (uint32_t)pcv_val_to_code(en, vz);
-    payload[s] = p;
+    if (!wide) {
+      payload[s] = p;
+    } else if (en <= PCV_ENC_UINT16) {
+      reinterpret_cast<uint2*>(payload)[s] = make_uint2(p.x | (p.y << 16), (q.y & 0xffff0000u) | p.z);
+    } else {  // the record keeps the input index, the codes go where `settle` looks for those of a Float32-coded leaf
+      wide[i] = make_uint4(p.x, p.y, p.z, 0u);
+    }
   }
 }
 
@@ -420,21 +450,34 @@ struct alignas(16) PcvClimber {
 };
 
 // one sorted slot of `settle`: finish it in its leaf, or hand it to `climb`
+template <bool kCompact>
 __device__ __forceinline__ void settle_one(const PcvPromoteTables& pt, uint64_t s, const PcvNodeRec& c, uint32_t r, uint4 p,
                                            const uint32_t h[3], uint32_t inten, const uint32_t* __restrict__ climb_base,
-                                           PcvClimber* __restrict__ climbers, const PromoteOut& o) {
+                                           PcvClimber* __restrict__ climbers, const PromoteOut& o,
+                                           const uint4* __restrict__ wide) {
+  if (kCompact) {
+    if (c.enc <= PCV_ENC_UINT16) {
+      p.y = p.x >> 16;
+      p.x &= 0xffffu;
+    } else {  // Float32-coded leaf: p.x is the input index
+      const uint4 w = wide[p.x];
+      p.x = w.x, p.y = w.y, p.z = w.z;
+    }
+  }
   const uint32_t j = (uint32_t)s - c.lo;
   if (c.parent == 0xffffffffu || (j & 7u) != 0) promote_one<false>(pt, s, c, p, h[0], h[1], h[2], inten, o);
   else climbers[climb_base[r] + (j >> 3)] = PcvClimber{p, r, (uint32_t)s, inten, 0u};
 }
 
 // kSettleSlots sorted slots per lane: every record load of the tile is in flight before the first is used
-template <int kSettleSlots>
+// kCompact: 12-byte records (key = rank << 8 | blue, uint2 payload); `wide` holds the codes of the points whose leaf
+// level is Float32-coded, by input index (the record's first word).
+template <int kSettleSlots, bool kCompact>
 __global__ __launch_bounds__(256) void promote_settle_kernel(
     PcvPromoteTables pt, uint64_t n, const uint32_t* __restrict__ rank, const uint4* __restrict__ payload,
     const uint32_t* __restrict__ cx_hi, const uint32_t* __restrict__ cy_hi, const uint32_t* __restrict__ cz_hi,
     const uint32_t* __restrict__ inten_bits, const uint32_t* __restrict__ climb_base, PcvClimber* __restrict__ climbers,
-    PromoteOut o) {
+    PromoteOut o, const uint4* __restrict__ wide) {
   const uint64_t base = (uint64_t)blockIdx.x * (256 * kSettleSlots) + threadIdx.x;
   uint32_t r[kSettleSlots];
   uint4 p[kSettleSlots];
@@ -444,7 +487,13 @@ __global__ __launch_bounds__(256) void promote_settle_kernel(
     const uint64_t s = base + 256 * k;
     const bool live = s < n;
     r[k] = live ? rank[s] : 0u;
-    p[k] = live ? payload[s] : make_uint4(0, 0, 0, 0);
+    if (kCompact) {
+      const uint2 q = live ? reinterpret_cast<const uint2*>(payload)[s] : make_uint2(0, 0);
+      p[k] = make_uint4(q.x, 0u, q.y & 0xffffu, (q.y >> 16) | ((r[k] & 0xffu) << 16));  // x: both codes, or the input index
+      r[k] >>= 8;
+    } else {
+      p[k] = live ? payload[s] : make_uint4(0, 0, 0, 0);
+    }
     h[k][0] = h[k][1] = h[k][2] = 0;
     in[k] = 0;
     if (cx_hi && live) {
@@ -463,9 +512,9 @@ __global__ __launch_bounds__(256) void promote_settle_kernel(
     // 80-byte record then comes through the scalar cache into SGPRs instead of being gathered into 20 VGPRs per lane
     const uint32_t u = (uint32_t)__builtin_amdgcn_readfirstlane((int)r[k]);
     if (__all(!live || r[k] == u)) {
-      if (live) settle_one(pt, s, pt.leaf_rec[u], r[k], p[k], h[k], in[k], climb_base, climbers, o);
+      if (live) settle_one<kCompact>(pt, s, pt.leaf_rec[u], r[k], p[k], h[k], in[k], climb_base, climbers, o, wide);
     } else if (live) {
-      settle_one(pt, s, pt.leaf_rec[r[k]], r[k], p[k], h[k], in[k], climb_base, climbers, o);
+      settle_one<kCompact>(pt, s, pt.leaf_rec[r[k]], r[k], p[k], h[k], in[k], climb_base, climbers, o, wide);
     }
   }
 }
@@ -502,22 +551,23 @@ template <bool BIN, int BLOCK>
 static void launch_spec_encode_t(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* walk, uint64_t n, const double* x,
                                  const double* y, const double* z, const PcvRouted& routed, const uint8_t* color,
                                  uint32_t color_stride, const float* intensity, uint32_t* rank, void* payload, void* kept,
-                                 uint32_t* inten_bits, uint8_t* depth_grid) {
+                                 uint32_t* inten_bits, uint8_t* depth_grid, void* wide) {
   const dim3 grid((unsigned)((n + BLOCK - 1) / BLOCK));
   const float cells = lv.edge[0] > 0.0 ? (float)(128.0 / lv.edge[0]) : 0.f;
   if (BIN) hipLaunchKernelGGL(spec_depth_grid_kernel, dim3((1u << (3 * kGridBits)) / 256), dim3(256), 0, ctx->stream, walk, depth_grid);
   if (kept)
     hipLaunchKernelGGL((spec_encode_kernel<true, BIN, BLOCK>), grid, dim3(BLOCK), 0, ctx->stream, lv, walk, n, x, y, z, routed, color,
-                       color_stride, intensity, rank, (uint4*)payload, (uint4*)kept, inten_bits, depth_grid, cells);
+                       color_stride, intensity, rank, (uint4*)payload, (uint4*)kept, inten_bits, depth_grid, cells, (uint4*)wide);
   else
     hipLaunchKernelGGL((spec_encode_kernel<false, BIN, BLOCK>), grid, dim3(BLOCK), 0, ctx->stream, lv, walk, n, x, y, z, routed,
-                       color, color_stride, intensity, rank, (uint4*)payload, (uint4*)nullptr, inten_bits, depth_grid, cells);
+                       color, color_stride, intensity, rank, (uint4*)payload, (uint4*)nullptr, inten_bits, depth_grid, cells, (uint4*)wide);
 }
 
 void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* walk, uint64_t n, const double* x,
                             const double* y, const double* z, const PcvRouted& routed, const uint8_t* color,
                             uint32_t color_stride, const float* intensity, uint32_t* rank, void* payload, void* kept,
-                            uint32_t* inten_bits, uint8_t* depth_grid /* pcv_spec_depth_grid_bytes() of scratch, or null */) {
+                            uint32_t* inten_bits, uint8_t* depth_grid /* pcv_spec_depth_grid_bytes() of scratch, or null */,
+                            void* wide) {
   if (n == 0) return;
   PcvProf prof(ctx, PCV_K_SPEC_ENCODE);
   // PCV_SPEC_BIN (experiments): 0 = input order, 256 / 512 / 1024 = depth binning inside workgroups of that size
@@ -528,21 +578,21 @@ void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* w
   const bool bin = bin_mode != 0 && depth_grid != nullptr;
   if (!bin)
     launch_spec_encode_t<false, 256>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, kept, inten_bits,
-                                     depth_grid);
+                                     depth_grid, wide);
   else if (bin_mode == 256)
     launch_spec_encode_t<true, 256>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, kept, inten_bits,
-                                     depth_grid);
+                                     depth_grid, wide);
   else if (bin_mode == 512)
     launch_spec_encode_t<true, 512>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, kept, inten_bits,
-                                     depth_grid);
+                                     depth_grid, wide);
   else
     launch_spec_encode_t<true, 1024>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, kept, inten_bits,
-                                     depth_grid);
+                                     depth_grid, wide);
 }
 
 size_t pcv_spec_depth_grid_bytes() { return (size_t)1 << (3 * kGridBits); }
 
-void pcv_launch_rank_hist(pcv_ctx* ctx, const uint32_t* rank, uint64_t n, uint32_t num_bins, uint32_t* counts) {
+void pcv_launch_rank_hist(pcv_ctx* ctx, const uint32_t* rank, uint64_t n, uint32_t num_bins, uint32_t* counts, int shift) {
   if (n == 0 || num_bins == 0) return;
   // one workgroup per CU-ish: 512 workgroups of 1024 lanes; the chunk is a multiple of 4096 keys
   uint64_t chunk = (n + 511) / 512;
@@ -551,7 +601,7 @@ void pcv_launch_rank_hist(pcv_ctx* ctx, const uint32_t* rank, uint64_t n, uint32
   for (uint32_t base = 0; base < num_bins; base += kHistBins) {
     const uint32_t nb = num_bins - base < (uint32_t)kHistBins ? num_bins - base : (uint32_t)kHistBins;
     PcvProf prof(ctx, PCV_K_RANK_HIST);
-    hipLaunchKernelGGL(rank_hist_kernel, dim3(groups), dim3(1024), 0, ctx->stream, rank, n, chunk, base, nb, counts);
+    hipLaunchKernelGGL(rank_hist_kernel, dim3(groups), dim3(1024), 0, ctx->stream, rank, n, chunk, base, nb, counts, shift);
   }
 }
 
@@ -563,12 +613,13 @@ void pcv_launch_spec_finalize(pcv_ctx* ctx, uint64_t n, const uint32_t* spec_map
 }
 
 void pcv_launch_spec_replay(pcv_ctx* ctx, const PcvLevels& lv, const void* ranges, uint32_t num_ranges, uint32_t total,
-                            const double* x, const double* y, const double* z, const PcvRouted& routed, void* sorted_payload) {
+                            const double* x, const double* y, const double* z, const PcvRouted& routed, void* sorted_payload,
+                            void* wide) {
   if (total == 0 || num_ranges == 0) return;
   PcvProf prof(ctx, PCV_K_SPEC_REPLAY);
   const unsigned blocks = (unsigned)std::min<uint64_t>(((uint64_t)total + 255) / 256, 8192);
   hipLaunchKernelGGL(spec_replay_kernel, dim3(blocks), dim3(256), 0, ctx->stream, lv, (const PcvFixRange*)ranges, num_ranges, total,
-                     x, y, z, routed, (uint4*)sorted_payload);
+                     x, y, z, routed, (uint4*)sorted_payload, (uint4*)wide);
 }
 
 size_t pcv_climber_bytes(uint64_t num_climbers) { return (size_t)(num_climbers + 1) * sizeof(PcvClimber); }
@@ -577,7 +628,7 @@ void pcv_launch_promote_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvPromo
                                const uint32_t* rank, const void* payload, const uint32_t* cx_hi, const uint32_t* cy_hi,
                                const uint32_t* cz_hi, const uint32_t* inten_bits, const uint32_t* climb_base,
                                uint32_t num_climbers, void* climbers, uint8_t* xyz_blob, uint8_t* rgb_blob,
-                               uint8_t* inten_blob) {
+                               uint8_t* inten_blob, const void* wide) {
   if (n == 0) return;
   PromoteOut o{xyz_blob, rgb_blob, inten_blob};
   {
@@ -586,12 +637,16 @@ void pcv_launch_promote_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvPromo
       const char* e = getenv("PCV_SETTLE_SLOTS");
       return e ? atoi(e) : 2;
     }();
-#define PCV_SETTLE(S)                                                                                                    \
-  hipLaunchKernelGGL(promote_settle_kernel<S>, dim3((unsigned)((n + 256 * S - 1) / (256 * S))), dim3(256), 0, ctx->stream, pt, n, \
-                     rank, (const uint4*)payload, cx_hi, cy_hi, cz_hi, inten_bits, climb_base, (PcvClimber*)climbers, o)
-    if (slots == 1) PCV_SETTLE(1);
-    else if (slots == 4) PCV_SETTLE(4);
-    else PCV_SETTLE(2);
+#define PCV_SETTLE(S, C)                                                                                                 \
+  hipLaunchKernelGGL((promote_settle_kernel<S, C>), dim3((unsigned)((n + 256 * S - 1) / (256 * S))), dim3(256), 0, ctx->stream, pt, \
+                     n, rank, (const uint4*)payload, cx_hi, cy_hi, cz_hi, inten_bits, climb_base, (PcvClimber*)climbers, o,       \
+                     (const uint4*)wide)
+    if (wide && slots == 1) PCV_SETTLE(1, true);
+    else if (wide && slots == 4) PCV_SETTLE(4, true);
+    else if (wide) PCV_SETTLE(2, true);
+    else if (slots == 1) PCV_SETTLE(1, false);
+    else if (slots == 4) PCV_SETTLE(4, false);
+    else PCV_SETTLE(2, false);
 #undef PCV_SETTLE
   }
   if (num_climbers) {

@@ -30,7 +30,7 @@ struct PcvLevels {
   double edge[PCV_MAX_LEVELS + 2];
   double inv_edge[PCV_MAX_LEVELS + 2];     // yh = RN(1 / edge[k]) for the exact constant-divisor division
   double inv_edge_lo[PCV_MAX_LEVELS + 2];  // yl = RN(1 / edge[k] - yh): the reciprocal as a double-double
-  uint8_t enc[PCV_MAX_LEVELS + 3];
+  uint32_t enc[PCV_MAX_LEVELS + 3];  // 32-bit entries: a wave-uniform lv.enc[L] is a scalar load (a byte would be a vector load)
   int32_t nlevels;  // number of digit levels materialised in the keys (<= PCV_MAX_KEY_LEVELS; <= PCV_MAX_LEVELS deep)
   int32_t fast_ok;  // root min and all edges are tame: unguarded exact division is valid for tame points
 };
@@ -252,6 +252,7 @@ void pcv_launch_depth_probe(pcv_ctx* ctx, const uint64_t* sorted, uint32_t n, ui
 struct PcvSortPayload {
   void* vec_in = nullptr;   // optional 16-byte payload word per key (uint4), ping-pong partner in vec_out
   void* vec_out = nullptr;
+  int vec_bytes = 16;       // 8: 12-byte records (uint2 payload, key = rank << 8 | blue), single-chain build only
   int nwords = 0;           // extra 32-bit payload planes that travel with the key (0..8)
   uint32_t* in[8] = {};
   uint32_t* out[8] = {};
@@ -266,7 +267,7 @@ int pcv_radix_sort_u32(pcv_ctx* ctx, uint32_t* keys_a, uint32_t* keys_b, uint64_
 
 int pcv_radix_sort_records_mapped(pcv_ctx* ctx, uint32_t* keys_a, uint32_t* keys_b, uint64_t n, int key_bits,
                                   PcvSortPayload* payload, void* scratch, const uint32_t* map, uint32_t map_entries,
-                                  const void* kept, bool* result_in_a);
+                                  const void* kept, bool* result_in_a, void* wide = nullptr, uint64_t wide_levels = 0);
 
 // pcv_topology.hip — node split (topology from sorted keys).
 // Device node table, structure of arrays, BFS order (level-major, prefix-sorted inside a level).
@@ -323,18 +324,25 @@ void pcv_launch_leaf_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvWalkTabl
                             uint32_t* cy_hi, uint32_t* cz_hi, uint32_t* inten_bits);
 
 // single-chain build (pcv_spec.h): the one chain pass down the predicted tree, the exact per-leaf counts, and the
-// rank / payload fix-up once the true tree is known
+// rank / payload fix-up once the true tree is known.
+// 12-byte records (`wide` set, u32 + uint2 per point instead of u32 + uint4): key = rank << 8 | blue, payload =
+// {code x | code y << 16, code z | red << 16 | green << 24} for u8 / u16-coded leaf levels; a point whose leaf level is
+// Float32-coded keeps its INPUT INDEX in the first payload word and its three 32-bit codes in wide[index] (uint4[n],
+// touched only by those points) — 24 instead of 40 bytes per point and pass through the record sort.
 void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* walk, uint64_t n, const double* x,
                             const double* y, const double* z, const PcvRouted& routed, const uint8_t* color,
                             uint32_t color_stride, const float* intensity, uint32_t* rank, void* payload /* uint4[n] */,
-                            void* kept /* uint4[n] or null */, uint32_t* inten_bits, uint8_t* depth_grid);
+                            void* kept /* uint4[n] or null */, uint32_t* inten_bits, uint8_t* depth_grid,
+                            void* wide = nullptr);
 size_t pcv_spec_depth_grid_bytes();  // scratch for the depth-prediction grid of the binned pass
-void pcv_launch_rank_hist(pcv_ctx* ctx, const uint32_t* rank, uint64_t n, uint32_t num_bins, uint32_t* counts /* zeroed */);
+void pcv_launch_rank_hist(pcv_ctx* ctx, const uint32_t* rank, uint64_t n, uint32_t num_bins, uint32_t* counts /* zeroed */,
+                          int shift = 0);
 void pcv_launch_spec_finalize(pcv_ctx* ctx, uint64_t n, const uint32_t* spec_map, uint32_t* rank, void* payload,
                               const void* kept);
 // ranges: device array of {first sorted slot, flagged slots before it, level, pad} (4 x u32), after the record sort
 void pcv_launch_spec_replay(pcv_ctx* ctx, const PcvLevels& lv, const void* ranges, uint32_t num_ranges, uint32_t total,
-                            const double* x, const double* y, const double* z, const PcvRouted& routed, void* sorted_payload);
+                            const double* x, const double* y, const double* z, const PcvRouted& routed, void* sorted_payload,
+                            void* wide = nullptr);
 
 // Everything K6 needs about a node in one 80-byte record, so a slot's dependent loads are rank -> record (-> the
 // parent's record per climb) instead of chained table lookups (node, level, per-level edge/encoding, offsets).
@@ -361,7 +369,7 @@ void pcv_launch_promote_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvPromo
                                const uint32_t* rank, const void* payload /* uint4[n] */, const uint32_t* cx_hi,
                                const uint32_t* cy_hi, const uint32_t* cz_hi, const uint32_t* inten_bits,
                                const uint32_t* climb_base, uint32_t num_climbers, void* climbers, uint8_t* xyz_blob,
-                               uint8_t* rgb_blob, uint8_t* inten_blob);
+                               uint8_t* rgb_blob, uint8_t* inten_blob, const void* wide = nullptr);
 
 struct PcvOctreeQuery;  // device-resident traversal tables (pcv_query.hip)
 
@@ -386,6 +394,7 @@ struct pcv_octree {
   float stage_ms[PCV_NUM_STAGES] = {};
   int key_levels = 0;    // digit levels the key sort covered (depth speculation)
   int key_attempts = 0;  // 0 = single-chain build, 1 = depth speculation held (or was off), 2+ = redone
+  int record_bytes = 0;  // bytes per record in the record sort (20, or 12 packed)
   uint64_t spec_stats[4] = {};  // single-chain build: nodes / leaves of the predicted tree, points that took their kept
                                 // codes, points that replayed the chain
   PcvOctreeQuery* query = nullptr;

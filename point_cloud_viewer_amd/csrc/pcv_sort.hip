@@ -141,11 +141,17 @@ __global__ __launch_bounds__(kBlock) void upsweep_kernel(const KeyT* __restrict_
 // dependent lookups per lane and iteration then cost LDS latency instead of a trip to the vector L1 / L2 that the
 // streaming keys keep evicting it from.
 constexpr uint32_t kMapLdsEntries = 24576;  // 96 KB
-template <bool kMapLds>
+// kCompact (12-byte records, pcv_internal.h): key = rank << 8 | blue, payload = uint2; a kept code set of a
+// Float32-coded level does not fit 16 bits per coordinate and goes to the point's `wide` entry instead (the record keeps
+// the input index); `shift` is the digit's position inside the KEY (8 + its position inside the rank).
+template <bool kMapLds, bool kCompact>
 __global__ __launch_bounds__(kBlock) void upsweep_map_kernel(uint32_t* __restrict__ keys, uint64_t n, uint64_t chunk, int groups,
                                                               int shift, uint32_t mask, uint32_t* __restrict__ hist,
                                                               const uint32_t* __restrict__ gmap, uint32_t map_entries,
-                                                              uint4* __restrict__ payload, const uint4* __restrict__ kept) {
+                                                              void* __restrict__ payload_v, const uint4* __restrict__ kept,
+                                                              uint4* __restrict__ wide, uint64_t wide_levels) {
+  uint4* __restrict__ payload = reinterpret_cast<uint4*>(payload_v);
+  uint2* __restrict__ pay2 = reinterpret_cast<uint2*>(payload_v);
   __shared__ uint32_t wh[kWaves][kRadix];
   extern __shared__ uint32_t smap[];  // kMapLds: map_entries words (dynamic, so small maps keep the occupancy)
   const int wave = threadIdx.x >> 6;
@@ -157,7 +163,22 @@ __global__ __launch_bounds__(kBlock) void upsweep_map_kernel(uint32_t* __restric
   const uint64_t begin = (uint64_t)blockIdx.x * chunk;
   uint64_t end = begin + chunk;
   if (end > n) end = n;
-  auto one = [&](uint64_t idx, uint32_t m) -> uint32_t {
+  auto one = [&](uint64_t idx, uint32_t old, uint32_t m) -> uint32_t {
+    if (kCompact) {
+      if (m & (1u << 30)) {
+        reinterpret_cast<uint32_t*>(pay2 + idx)[0] = (uint32_t)idx;
+      } else if (m & (1u << 31)) {  // the code fields only: the colour bytes stay, so the payload is not read
+        const uint4 k = kept[idx];
+        if ((wide_levels >> (k.w & 63u)) & 1ull) {
+          reinterpret_cast<uint32_t*>(pay2 + idx)[0] = (uint32_t)idx;
+          wide[idx] = k;
+        } else {
+          reinterpret_cast<uint32_t*>(pay2 + idx)[0] = k.x | (k.y << 16);
+          reinterpret_cast<uint16_t*>(pay2 + idx)[2] = (uint16_t)k.z;
+        }
+      }
+      return ((m & PCV_SPEC_INDEX_MASK_SORT) << 8) | (old & 0xffu);
+    }
     if (m & (1u << 30)) {
       reinterpret_cast<uint32_t*>(payload + idx)[0] = (uint32_t)idx;
     } else if (m & (1u << 31)) {  // the three code words only: the colour word stays, so the payload is not read
@@ -169,16 +190,20 @@ __global__ __launch_bounds__(kBlock) void upsweep_map_kernel(uint32_t* __restric
     }
     return m & PCV_SPEC_INDEX_MASK_SORT;
   };
+  constexpr int kKeyShift = kCompact ? 8 : 0;  // position of the predicted-leaf rank inside the key
   uint64_t i = begin + (uint64_t)threadIdx.x * 4;
   constexpr uint64_t kStep = (uint64_t)kBlock * 4;
   for (; i + kStep + 4 <= end; i += 2 * kStep) {  // two 16-byte loads and their eight map lookups in flight per lane
     uint4 v[2];
     v[0] = *reinterpret_cast<const uint4*>(keys + i);
     v[1] = *reinterpret_cast<const uint4*>(keys + i + kStep);
-    uint32_t m[8] = {map[v[0].x], map[v[0].y], map[v[0].z], map[v[0].w], map[v[1].x], map[v[1].y], map[v[1].z], map[v[1].w]};
+    const uint32_t o[8] = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w};
+    uint32_t m[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m[k] = map[o[k] >> kKeyShift];
     uint32_t r[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) r[k] = one(i + (k >> 2) * kStep + (k & 3), m[k]);
+    for (int k = 0; k < 8; ++k) r[k] = one(i + (k >> 2) * kStep + (k & 3), o[k], m[k]);
     *reinterpret_cast<uint4*>(keys + i) = make_uint4(r[0], r[1], r[2], r[3]);
     *reinterpret_cast<uint4*>(keys + i + kStep) = make_uint4(r[4], r[5], r[6], r[7]);
     const uint64_t here = __builtin_amdgcn_ballot_w64(true);
@@ -187,17 +212,21 @@ __global__ __launch_bounds__(kBlock) void upsweep_map_kernel(uint32_t* __restric
   }
   for (; i + 4 <= end; i += kStep) {
     const uint4 v = *reinterpret_cast<const uint4*>(keys + i);
-    const uint32_t m[4] = {map[v.x], map[v.y], map[v.z], map[v.w]};
+    const uint32_t o[4] = {v.x, v.y, v.z, v.w};
+    uint32_t m[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) m[k] = map[o[k] >> kKeyShift];
     uint32_t r[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) r[k] = one(i + k, m[k]);
+    for (int k = 0; k < 4; ++k) r[k] = one(i + k, o[k], m[k]);
     *reinterpret_cast<uint4*>(keys + i) = make_uint4(r[0], r[1], r[2], r[3]);
     const uint64_t here = __builtin_amdgcn_ballot_w64(true);
 #pragma unroll
     for (int k = 0; k < 4; ++k) count_digit(wh[wave], (r[k] >> shift) & mask, here, true);
   }
   for (; i < end; ++i) {  // ragged tail (< 4 keys per lane)
-    const uint32_t r = one(i, map[keys[i]]);
+    const uint32_t o = keys[i];
+    const uint32_t r = one(i, o, map[o >> kKeyShift]);
     keys[i] = r;
     atomicAdd(&wh[wave][(r >> shift) & mask], 1u);
   }
@@ -436,8 +465,8 @@ __global__ __launch_bounds__(kBlock, PCV_KEYS_WAVES) void downsweep_keys_kernel(
 
 // ---- records: u32 key + optional 16-byte payload + extra 4-byte planes -----------------------------
 struct RecPtrs {
-  const uint4* vec_in;  // may be null
-  uint4* vec_out;
+  const void* vec_in;  // may be null; uint4 (20-byte records) or uint2 (12-byte records) per key
+  void* vec_out;
   int nplanes;          // extra u32 planes (0..8)
   const uint32_t* plane_in[8];
   uint32_t* plane_out[8];
@@ -445,7 +474,7 @@ struct RecPtrs {
 
 // kPrefetch: the next tile's keys and payloads are loaded into the registers the LDS staging just freed, so that the
 // loads are in flight while this tile drains through LDS to memory (as the keys-only kernel does).
-template <bool kHasVec, bool kPrefetch = false>
+template <bool kHasVec, bool kPrefetch = false, typename VecT = uint4>
 __global__ __launch_bounds__(kBlock, kHasVec ? 3 : 4) void downsweep_rec_kernel(const uint32_t* __restrict__ keys_in,
                                                                   uint32_t* __restrict__ keys_out, uint64_t n,
                                                                   uint64_t chunk, int groups, int shift, int nbits,
@@ -453,11 +482,13 @@ __global__ __launch_bounds__(kBlock, kHasVec ? 3 : 4) void downsweep_rec_kernel(
                                                                   const uint32_t* __restrict__ totals, RecPtrs rp) {
   constexpr int kKpt = kKptRec, kTile = kBlock * kKpt;
   __shared__ uint32_t skeys[kTile];
-  __shared__ uint4 svec[kHasVec ? kTile : 1];
+  __shared__ VecT svec[kHasVec ? kTile : 1];
   __shared__ DigitState S;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const uint32_t mask = (1u << nbits) - 1u;
   init_digit_base(S, offsets, totals, groups, t, lane, wave);
+  const VecT* __restrict__ vec_in = reinterpret_cast<const VecT*>(rp.vec_in);
+  VecT* __restrict__ vec_out = reinterpret_cast<VecT*>(rp.vec_out);
 
   const uint64_t begin = (uint64_t)blockIdx.x * chunk;
   uint64_t end = begin + chunk;
@@ -465,14 +496,14 @@ __global__ __launch_bounds__(kBlock, kHasVec ? 3 : 4) void downsweep_rec_kernel(
   const uint32_t wbase = wave * 64 * kKpt + lane;
 
   uint32_t key[kKpt];
-  uint4 vec[kHasVec ? kKpt : 1];
+  VecT vec[kHasVec ? kKpt : 1];
   auto load_tile = [&](uint64_t base, uint32_t tile_n) {
 #pragma unroll
     for (int i = 0; i < kKpt; ++i) {
       const uint32_t li = wbase + i * 64;
       const bool valid = li < tile_n;
       key[i] = valid ? keys_in[base + li] : 0u;
-      if (kHasVec) vec[i] = valid ? rp.vec_in[base + li] : make_uint4(0, 0, 0, 0);
+      if (kHasVec) vec[i] = valid ? vec_in[base + li] : VecT{};
     }
   };
   if (kPrefetch && begin < end) load_tile(begin, (uint32_t)((end - begin) < (uint64_t)kTile ? (end - begin) : (uint64_t)kTile));
@@ -510,7 +541,7 @@ __global__ __launch_bounds__(kBlock, kHasVec ? 3 : 4) void downsweep_rec_kernel(
         const uint32_t g = S.delta[d] + p;
         gidx[j] = g;
         keys_out[g] = k;
-        if (kHasVec) rp.vec_out[g] = svec[p];
+        if (kHasVec) vec_out[g] = svec[p];
       }
     }
     for (int w = 0; w < rp.nplanes; ++w) {  // rare: intensity / Float64 high words / generic pairs API
@@ -538,12 +569,13 @@ __global__ __launch_bounds__(kBlock, kHasVec ? 3 : 4) void downsweep_rec_kernel(
 template <typename KeyT>
 int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int end_bit, PcvSortPayload* payload,
                void* scratch, bool* result_in_a, const uint32_t* map = nullptr, const void* kept = nullptr,
-               uint32_t map_entries = 0) {
+               uint32_t map_entries = 0, void* wide = nullptr, uint64_t wide_levels = 0) {
   *result_in_a = true;
   if (n == 0 || end_bit <= begin_bit) return PCV_OK;
   if (n >= 0xffffffffull) return ctx->fail(PCV_E_INVALID, "radix sort: n must be < 2^32 - 1");
   const bool records = payload && (payload->vec_in || payload->nwords > 0);
   if (records && sizeof(KeyT) != 4) return ctx->fail(PCV_E_INVALID, "record sort needs 32-bit keys");
+  const bool compact = records && payload->vec_in && payload->vec_bytes == 8;  // 12-byte records
   SortGeom g = make_geom(n);
   uint32_t* hist = (uint32_t*)scratch;
   uint32_t* totals = hist + (size_t)kRadix * kMaxGroups;
@@ -561,14 +593,17 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
     KeyT* dst = in_a ? b : a;
     if (map && shift == begin_bit && sizeof(KeyT) == 4 && payload && payload->vec_in) {
       PcvProf prof(ctx, PCV_K_SORT_UPSWEEP_MAP);  // finalize fused into the first upsweep
-      if (map_entries && map_entries <= kMapLdsEntries)
-        hipLaunchKernelGGL(upsweep_map_kernel<true>, dim3(g.groups), dim3(kBlock), (size_t)map_entries * 4, ctx->stream, (uint32_t*)src, n, g.chunk,
-                           g.groups, shift, mask, hist, map, map_entries, (uint4*)(in_a ? payload->vec_in : payload->vec_out),
-                           (const uint4*)kept);
-      else
-        hipLaunchKernelGGL(upsweep_map_kernel<false>, dim3(g.groups), dim3(kBlock), 0, ctx->stream, (uint32_t*)src, n, g.chunk,
-                           g.groups, shift, mask, hist, map, map_entries, (uint4*)(in_a ? payload->vec_in : payload->vec_out),
-                           (const uint4*)kept);
+      const bool lds = map_entries && map_entries <= kMapLdsEntries;
+      const size_t dyn = lds ? (size_t)map_entries * 4 : 0;
+      void* pay = in_a ? payload->vec_in : payload->vec_out;
+#define PCV_UPSWEEP_MAP(L, C)                                                                                                    \
+  hipLaunchKernelGGL((upsweep_map_kernel<L, C>), dim3(g.groups), dim3(kBlock), dyn, ctx->stream, (uint32_t*)src, n, g.chunk, g.groups, \
+                     shift, mask, hist, map, map_entries, pay, (const uint4*)kept, (uint4*)wide, wide_levels)
+      if (lds && compact) PCV_UPSWEEP_MAP(true, true);
+      else if (lds) PCV_UPSWEEP_MAP(true, false);
+      else if (compact) PCV_UPSWEEP_MAP(false, true);
+      else PCV_UPSWEEP_MAP(false, false);
+#undef PCV_UPSWEEP_MAP
     } else {
       PcvProf prof(ctx, sizeof(KeyT) == 8 ? PCV_K_SORT_UPSWEEP64 : PCV_K_SORT_UPSWEEP32);
       hipLaunchKernelGGL(upsweep_kernel<KeyT>, dim3(g.groups), dim3(kBlock), 0, ctx->stream, src, n, g.chunk,
@@ -584,8 +619,8 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
                          g.groups, shift, nbits, hist, totals);
     } else {
       RecPtrs rp{};
-      rp.vec_in = (const uint4*)(in_a ? payload->vec_in : payload->vec_out);
-      rp.vec_out = (uint4*)(in_a ? payload->vec_out : payload->vec_in);
+      rp.vec_in = in_a ? payload->vec_in : payload->vec_out;
+      rp.vec_out = in_a ? payload->vec_out : payload->vec_in;
       rp.nplanes = payload->nwords;
       for (int w = 0; w < payload->nwords; ++w) {
         rp.plane_in[w] = in_a ? payload->in[w] : payload->out[w];
@@ -596,7 +631,10 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
         return !e || atoi(e) != 0;
       }();
       PcvProf prof(ctx, PCV_K_SORT_DOWNSWEEP_REC);
-      if (payload->vec_in && prefetch)
+      if (compact)
+        hipLaunchKernelGGL((downsweep_rec_kernel<true, true, uint2>), dim3(g.groups), dim3(kBlock), 0, ctx->stream, (const uint32_t*)src,
+                           (uint32_t*)dst, n, g.chunk, g.groups, shift, nbits, hist, totals, rp);
+      else if (payload->vec_in && prefetch)
         hipLaunchKernelGGL((downsweep_rec_kernel<true, true>), dim3(g.groups), dim3(kBlock), 0, ctx->stream, (const uint32_t*)src,
                            (uint32_t*)dst, n, g.chunk, g.groups, shift, nbits, hist, totals, rp);
       else if (payload->vec_in)
@@ -626,8 +664,12 @@ int pcv_radix_sort_u32(pcv_ctx* ctx, uint32_t* keys_a, uint32_t* keys_b, uint64_
   return radix_sort<uint32_t>(ctx, keys_a, keys_b, n, begin_bit, end_bit, payload, scratch, result_in_a);
 }
 // Record sort whose first upsweep also translates the ranks through `map` and patches the payloads (single-chain build)
+// 12-byte records (payload->vec_bytes == 8): the rank sits in bits 8.. of the key, `wide` / `wide_levels` as in
+// upsweep_map_kernel
 int pcv_radix_sort_records_mapped(pcv_ctx* ctx, uint32_t* keys_a, uint32_t* keys_b, uint64_t n, int key_bits,
                                   PcvSortPayload* payload, void* scratch, const uint32_t* map, uint32_t map_entries,
-                                  const void* kept, bool* result_in_a) {
-  return radix_sort<uint32_t>(ctx, keys_a, keys_b, n, 0, key_bits, payload, scratch, result_in_a, map, kept, map_entries);
+                                  const void* kept, bool* result_in_a, void* wide, uint64_t wide_levels) {
+  const int base = payload && payload->vec_bytes == 8 ? 8 : 0;
+  return radix_sort<uint32_t>(ctx, keys_a, keys_b, n, base, base + key_bits, payload, scratch, result_in_a, map, kept, map_entries,
+                              wide, wide_levels);
 }

@@ -30,6 +30,11 @@ CASES = [  # n, capacity, resolution, clusters, extent, sigma range, intensity, 
     (200_000, 300, 0.001, 4, 40.0, (0.005, 1.0), False, 5),
     (1_500_000, 100_000, 0.001, 3, 150.0, (0.5, 6.0), False, 6),
     (1_300_000, 30_000, 0.001, 7, 220.0, (0.1, 7.0), True, 7),   # >= 2^20 points: depth-binned pass, with intensity
+    # finer resolutions: levels 1..5 are Float32-coded, so most leaves (and the candidates whose kept codes are taken,
+    # and the replayed leaves) are "wide" for the packed 12-byte records — their codes travel through the side array
+    (600_000, 20_000, 0.0001, 6, 200.0, (0.2, 8.0), True, 21),
+    (800_000, 5_000, 0.0002, 12, 300.0, (0.05, 5.0), False, 22),
+    (1_200_000, 60_000, 0.0001, 5, 180.0, (0.3, 9.0), False, 23),
 ]
 
 
@@ -47,6 +52,7 @@ def test_forced_single_chain_equals_oracle(ctx, n, cap, res, clusters, extent, s
     SEEN["kept"] += info["kept_code_points"] > 0
     SEEN["replayed"] += info["replayed_points"] > 0
     if info["single_chain"]:
+        assert info["record_bytes"] == 12, info  # packed records are what ships on this path
         leaves = sum(1 for k in want.nodes if not any(c.startswith(k) and len(c) == len(k) + 1 for c in want.nodes))
         assert info["predicted_leaves"] >= leaves
     t.free()
