@@ -443,6 +443,10 @@ int pcv_make_levels(const double bmin[3], const double bmax[3], double resolutio
     lv->nlevels = nl;
     const int filled = k < PCV_MAX_LEVELS ? k : PCV_MAX_LEVELS;  // the tables cover the deep levels as well
     bool tame = std::fabs(bmin[0]) <= 0x1p+500 && std::fabs(bmin[1]) <= 0x1p+500 && std::fabs(bmin[2]) <= 0x1p+500;
+    // largest |coordinate| of any cube min / max in the tree (every cube lies inside the root cube)
+    double amax = 0.0;
+    for (int a = 0; a < 3; ++a) amax = std::fmax(amax, std::fmax(std::fabs(bmin[a]), std::fabs(bmin[a] + e[0])));
+    for (int j = 0; j < PCV_MAX_LEVELS + 2; ++j) lv->digit_half[j] = -1.0;
     for (int j = 0; j <= filled && j < (int)e.size(); ++j) {
       lv->edge[j] = e[j];
       // IEEE division on the host: correctly rounded reciprocal; 0 = "use plain division" (pcv_div_const)
@@ -451,6 +455,12 @@ int pcv_make_levels(const double bmin[3], const double bmax[3], double resolutio
       lv->inv_edge_lo[j] = lv->inv_edge[j] != 0.0 ? std::fma(-e[j], lv->inv_edge[j], 1.0) / e[j] : 0.0;
       lv->enc[j] = (uint32_t)c[j];
       tame = tame && lv->inv_edge[j] != 0.0;
+      // pcv_digit_from_codes: valid where 1.01 u (2.5 A / e + 3) < 1 / (2 M) (u = 2^-53); required here with a factor
+      // of two in hand. Level 0 has no codes (the chain starts from the raw position).
+      if (j >= 1 && (c[j] == PCV_ENC_UINT8 || c[j] == PCV_ENC_UINT16) && std::isfinite(amax) && e[j] > 0.0) {
+        const double m = c[j] == PCV_ENC_UINT8 ? 255.0 : 65535.0;
+        if ((2.5 * amax / e[j] + 3.0) * 4.04 * m < 0x1p+53) lv->digit_half[j] = c[j] == PCV_ENC_UINT8 ? 127.0 : 32767.0;
+      }
     }
     lv->fast_ok = tame ? 1 : 0;
   }

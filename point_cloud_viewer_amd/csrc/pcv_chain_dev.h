@@ -173,6 +173,20 @@ __device__ __forceinline__ uint32_t pcv_chain_digit(double e_parent, double px, 
   const double cx = (mx + (mx + e_parent)) / 2.0, cy = (my + (my + e_parent)) / 2.0, cz = (mz + (mz + e_parent)) / 2.0;
   return (px > cx ? 4u : 0u) | (py > cy ? 2u : 0u) | (pz > cz ? 1u : 0u);
 }
+// The same digit from the integer codes of the parent level, without touching the cube: for a u8 / u16-coded level k
+// with codes c in [0, M] (M = 255 / 65535, odd) the position the next comparison sees is p = fma(RN(c / M), e, mn) and
+// the centre is c0 = fl(fl(mn + fl(mn + e)) / 2). Exactly, P* = mn + (c / M) e and C* = mn + e / 2 differ by
+// e |c / M - 1 / 2| >= e / (2 M) — there is no tie, M is odd. Rounding moves p by at most u (|mn| + 2 e) and c0 by at
+// most u (1.5 |mn| + e) (u = 2^-53, standard model, no under/overflow for tame tables). So wherever
+//     1.01 u (2.5 A / e + 3) < 1 / (2 M),     A = the largest |coordinate| of the root cube,
+// (p > c0) == (c > M / 2) == (c > 127 resp. 32767) for every point: one compare per coordinate instead of two
+// additions, a multiplication and a compare. pcv_make_levels checks the inequality per level with a factor of two in
+// hand (PcvLevels::digit_half; ECEF coordinates with millimetre cubes pass) and tests/test_oracle_kats.py replays the
+// boundary codes at the admitted |mn| / e ratios in exact rational arithmetic. Only used on the unguarded path (finite,
+// moderate inputs); Float32 / Float64-coded parents (ties at t = 0.5) and the root keep the comparison above.
+__device__ __forceinline__ uint32_t pcv_digit_from_codes(double half, double vx, double vy, double vz) {
+  return (vx > half ? 4u : 0u) | (vy > half ? 2u : 0u) | (vz > half ? 1u : 0u);
+}
 template <int ENC, bool GUARD>
 __device__ __forceinline__ void pcv_chain_apply_t(uint32_t d, double ec, PcvRecip ic, double& px, double& py, double& pz, double& mx,
                                                   double& my, double& mz, double& cx, double& cy, double& cz) {

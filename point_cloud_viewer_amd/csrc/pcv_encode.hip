@@ -15,6 +15,10 @@
 #include "pcv_chain_dev.h"
 #include "pcv_spec.h"
 
+#ifndef PCV_SETTLE_DIAG
+#define PCV_SETTLE_DIAG 0
+#endif
+
 namespace {
 
 __global__ __launch_bounds__(256) void leaf_encode_kernel(
@@ -197,6 +201,8 @@ __global__ __launch_bounds__(BLOCK) void spec_encode_kernel(
     }
   }
 #define PCV_SPEC_WALK(GUARD)                                                                                          \
+  /* >= 0: the next digit comes from this level's integer codes (fetched with the level's other constants) */          \
+  double half = lv.digit_half[L];                                                                                       \
   while (!(rec & PCV_SPEC_LEAF) && L < lv.nlevels) {                                                                    \
     if (KEEP && (rec & PCV_SPEC_CANDIDATE) && kl == 0) {                                                                \
       kx = vx, ky = vy, kz = vz;                                                                                        \
@@ -204,8 +210,10 @@ __global__ __launch_bounds__(BLOCK) void spec_encode_kernel(
     }                                                                                                                   \
     ++L;                                                                                                                \
     /* the digit first, the child's record in flight while the level's encode / decode arithmetic runs */             \
-    const uint32_t d = pcv_chain_digit(lv.edge[L - 1], px, py, pz, mx, my, mz);                                         \
+    const uint32_t d = (!GUARD && half >= 0.0) ? pcv_digit_from_codes(half, vx, vy, vz)                                 \
+                                               : pcv_chain_digit(lv.edge[L - 1], px, py, pz, mx, my, mz);                \
     const uint32_t next = walk[(rec & PCV_SPEC_INDEX_MASK) + d];                                                        \
+    half = lv.digit_half[L];                                                                                            \
     pcv_chain_apply<GUARD>(lv.enc[L], d, lv.edge[L], PcvRecip{lv.inv_edge[L], lv.inv_edge_lo[L]}, px, py, pz, mx, my, mz, vx, \
                            vy, vz);                                                                                     \
     rec = next;                                                                                                         \
@@ -394,10 +402,15 @@ __device__ __forceinline__ void promote_one(const PcvPromoteTables& pt, uint64_t
   const uint32_t enc = cur.enc;
   if (cur.parent != 0xffffffffu) {
     slot = j - (j >> 3) - 1u;
+#if PCV_SETTLE_DIAG != 2  // (timing experiments, tools/build_variants.sh: 2 = no re-encode, 1 = no stores; never shipped)
 #pragma unroll
     for (int a = 0; a < 3; ++a)
       code[a] = pcv_encode_coord(enc, pcv_decode_coord(enc, code[a], cur.mn[a], cur.edge), cur.mn[a], cur.edge, PcvRecip{cur.inv_edge, cur.inv_edge_lo});
+#endif
   }
+#if PCV_SETTLE_DIAG == 1
+  if (!CLIMB && code[0] != 0x7fffffffffffull) return;
+#endif
   uint8_t* dst = o.xyz_blob + cur.xyz_off;
   switch (enc) {
     case PCV_ENC_UINT8: {

@@ -31,6 +31,9 @@ struct PcvLevels {
   double inv_edge[PCV_MAX_LEVELS + 2];     // yh = RN(1 / edge[k]) for the exact constant-divisor division
   double inv_edge_lo[PCV_MAX_LEVELS + 2];  // yl = RN(1 / edge[k] - yh): the reciprocal as a double-double
   uint32_t enc[PCV_MAX_LEVELS + 3];  // 32-bit entries: a wave-uniform lv.enc[L] is a scalar load (a byte would be a vector load)
+  // Octant digit of level k + 1 straight from the integer codes of level k (pcv_chain_dev.h, pcv_digit_from_codes):
+  // digit_half[k] = 127 / 32767 when level k is u8 / u16-coded and the rounding-error bound holds there, else -1
+  double digit_half[PCV_MAX_LEVELS + 2];
   int32_t nlevels;  // number of digit levels materialised in the keys (<= PCV_MAX_KEY_LEVELS; <= PCV_MAX_LEVELS deep)
   int32_t fast_ok;  // root min and all edges are tame: unguarded exact division is valid for tame points
 };

@@ -141,3 +141,30 @@ def test_double_double_reciprocal_division_is_exact_for_every_code():
         for v in range(int(m) + 1):
             v = float(v)
             assert fma(v, yh, v * yl) == v / m, (m, v)
+
+
+def test_octant_digit_from_integer_codes_at_the_admitted_ratio():
+    """csrc/pcv_chain_dev.h pcv_digit_from_codes: for a u8 / u16-coded level the next octant digit (node.rs:34-42,
+    strict > against aabb.rs:175-192's centre) of the decoded position fma(RN(c / M), e, mn) (codec.rs:124-139) equals
+    c > M // 2 wherever pcv_make_levels admits the shortcut: (2.5 A / e + 3) * 4.04 * M < 2^53. Replayed in exact
+    rational arithmetic (Fraction -> float is correctly rounded, i.e. the FMA) for the two codes next to the centre and
+    random ones, with |mn| / e right at the admitted bound (and at easy ratios)."""
+    from fractions import Fraction
+    import math
+    import random
+    rnd = random.Random(7)
+    for M, half in ((255, 127), (65535, 32767)):
+        limit = (2.0 ** 53 / (4.04 * M) - 3.0) / 2.5  # largest admitted A / e
+        for trial in range(4000):
+            e = math.ldexp(rnd.uniform(1.0, 2.0), rnd.randint(-20, 12))
+            ratio = limit * (1.0 - 1e-9) if trial % 2 == 0 else rnd.uniform(0.0, limit)
+            # cube min with |mn| + e <= A = ratio * e, either sign, arbitrary low bits
+            mag = max(0.0, ratio * e - e) * (1.0 if trial % 4 < 2 else rnd.uniform(0.0, 1.0))
+            mn = math.copysign(mag, rnd.choice((-1.0, 1.0)))
+            if mn < 0:
+                mn = -(mag + e) if mag + e <= ratio * e else mn  # keep |mn + e| inside A as well
+            centre = (mn + (mn + e)) / 2.0
+            for c in (half, half + 1, 0, M, rnd.randint(0, M), rnd.randint(0, M)):
+                q = c / M  # IEEE division == pcv_div_code (test_exact_code_division above)
+                p = float(Fraction(mn) + Fraction(q) * Fraction(e))  # one rounding: the FMA
+                assert (p > centre) == (c > half), (M, c, mn, e, p, centre)
