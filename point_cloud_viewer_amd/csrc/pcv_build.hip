@@ -457,7 +457,11 @@ int pcv_make_levels(const double bmin[3], const double bmax[3], double resolutio
       tame = tame && lv->inv_edge[j] != 0.0;
       // pcv_digit_from_codes: valid where 1.01 u (2.5 A / e + 3) < 1 / (2 M) (u = 2^-53); required here with a factor
       // of two in hand. Level 0 has no codes (the chain starts from the raw position).
-      if (j >= 1 && (c[j] == PCV_ENC_UINT8 || c[j] == PCV_ENC_UINT16) && std::isfinite(amax) && e[j] > 0.0) {
+      static const bool digit_shortcut = [] {  // PCV_DIGIT_SHORTCUT=0: always compare against the centre (experiments)
+        const char* ev = getenv("PCV_DIGIT_SHORTCUT");
+        return !ev || atoi(ev) != 0;
+      }();
+      if (digit_shortcut && j >= 1 && (c[j] == PCV_ENC_UINT8 || c[j] == PCV_ENC_UINT16) && std::isfinite(amax) && e[j] > 0.0) {
         const double m = c[j] == PCV_ENC_UINT8 ? 255.0 : 65535.0;
         if ((2.5 * amax / e[j] + 3.0) * 4.04 * m < 0x1p+53) lv->digit_half[j] = c[j] == PCV_ENC_UINT8 ? 127.0 : 32767.0;
       }
@@ -1348,7 +1352,9 @@ static int build_begin_impl(pcv_ctx* ctx, const pcv_build_params* params, const 
   const size_t lo_off = (((size_t)M * (8 + 4 * 4 + 3) + 64) + 7) & ~(size_t)7;  // deep trees: second prefix word
   const size_t host_bytes = lo_off + (bs->deep ? (size_t)M * 8 : 0);
   bs->host_bytes = host_bytes;
-  if ((rc = ctx->pinned_reserve(host_bytes * 4 + (size_t)M * 72 + (size_t)M * 2 * sizeof(PcvNodeRec) + 1024))) return rc;
+  if ((rc = ctx->pinned_reserve(host_bytes * 4 + (size_t)M * 72 + (size_t)M * 2 * sizeof(PcvNodeRec) + 1024 +
+                                (bs->n / kPcvSettleTile + M + 2) * sizeof(PcvSettleItem))))
+    return rc;
   uint8_t* hp = (uint8_t*)ctx->pinned;
   uint64_t* h_prefix = (uint64_t*)hp;
   uint32_t* h_lo = (uint32_t*)(h_prefix + M);
@@ -1618,8 +1624,24 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
     u_climb_base[r] = (uint32_t)num_climbers;
     if (u_leaf_rec[r].parent != 0xffffffffu) num_climbers += ceil8((uint64_t)h_hi[leaves[r]] - h_lo[leaves[r]]);
   }
+  // work list of the leaf-wise settle kernel: tiles of <= 512 consecutive slots of one leaf (PCV_SETTLE_BY_LEAF=0: the
+  // slot-wise kernel, experiments)
+  static const bool by_leaf = [] {
+    const char* e = getenv("PCV_SETTLE_BY_LEAF");
+    return !e || atoi(e) != 0;
+  }();
+  const size_t items_off = (((size_t)(M + num_leaves) * sizeof(PcvNodeRec) + (size_t)num_leaves * 4) + 15) & ~(size_t)15;
+  PcvSettleItem* u_items = (PcvSettleItem*)((uint8_t*)u_node_rec + items_off);
+  uint32_t num_items = 0;
+  if (by_leaf) {
+    for (uint32_t r = 0; r < num_leaves; ++r) {
+      const uint32_t lo = h_lo[leaves[r]], hi = h_hi[leaves[r]];
+      for (uint64_t b = lo; b < hi; b += kPcvSettleTile)
+        u_items[num_items++] = PcvSettleItem{r, (uint32_t)b, (uint32_t)std::min<uint64_t>(b + kPcvSettleTile, hi), 0u};
+    }
+  }
   const size_t walk_bytes = ((size_t)M * 8 + 255) & ~(size_t)255;
-  const size_t rec_bytes = (size_t)(M + num_leaves) * sizeof(PcvNodeRec) + (size_t)num_leaves * 4;
+  const size_t rec_bytes = items_off + (size_t)num_items * sizeof(PcvSettleItem);
   // the tables live in a context-owned block; with the record sort already running they go up on the side stream (the
   // copy would otherwise queue behind the sort and sit, with its hand-over, between the sort and K6)
   if ((rc = ctx->table_dev_reserve(walk_bytes + rec_bytes + 256))) return rc;
@@ -1672,7 +1694,8 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
   pcv_launch_promote_encode(ctx, lv, pt, n, s_rank, s_pay, wide ? s_plane[w_hi] : nullptr,
                             wide ? s_plane[w_hi + 1] : nullptr, wide ? s_plane[w_hi + 2] : nullptr,
                             w_int >= 0 ? s_plane[w_int] : nullptr, d_climb_base, (uint32_t)num_climbers, climbers, t->d_xyz,
-                            t->d_rgb, t->d_int, bs->spec_wide);
+                            t->d_rgb, t->d_int, bs->spec_wide,
+                            by_leaf ? (const PcvSettleItem*)(d_up + walk_bytes + items_off) : nullptr, num_items);
   ctx->stage_end(PCV_STAGE_PROMOTE_ENCODE);
   PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[8], st));
   PCV_HIP_CHECK(ctx, hipGetLastError());

@@ -532,6 +532,56 @@ __global__ __launch_bounds__(256) void promote_settle_kernel(
   }
 }
 
+// Leaf-wise settle: one workgroup per work item (<= 512 consecutive slots of one leaf). The item and the leaf's record
+// are wave-uniform scalar loads that do not depend on the records, so they run beside the record loads (in the slot-wise
+// kernel above the leaf is only known once the rank has arrived: load -> readfirstlane -> scalar load, a wave lived
+// 7 us, three quarters of it waiting); no divergent "two leaves in one wave" path either. The rank array is only read
+// for the blue byte of the packed records.
+template <bool kCompact>
+__global__ __launch_bounds__(256) void promote_settle_leaf_kernel(
+    PcvPromoteTables pt, const PcvSettleItem* __restrict__ items, const uint32_t* __restrict__ rank,
+    const uint4* __restrict__ payload, const uint32_t* __restrict__ cx_hi, const uint32_t* __restrict__ cy_hi,
+    const uint32_t* __restrict__ cz_hi, const uint32_t* __restrict__ inten_bits, const uint32_t* __restrict__ climb_base,
+    PcvClimber* __restrict__ climbers, PromoteOut o, const uint4* __restrict__ wide) {
+  constexpr int kSlots = (int)kPcvSettleTile / 256;
+  const PcvSettleItem it = items[blockIdx.x];
+  // every record load is issued before anything is consumed; dead lanes of the leaf's last tile re-read the tile's
+  // first slot (an item is never empty) so that no load sits behind a branch
+  uint32_t key[kSlots], h[kSlots][3], in[kSlots];
+  uint2 q[kSlots];
+  uint4 p[kSlots];
+#pragma unroll
+  for (int k = 0; k < kSlots; ++k) {
+    const uint32_t s = it.begin + threadIdx.x + 256 * k;
+    const uint32_t sl = s < it.end ? s : it.begin;
+    key[k] = 0;
+    q[k] = make_uint2(0, 0);
+    p[k] = make_uint4(0, 0, 0, 0);
+    if (kCompact) {
+      key[k] = rank[sl];
+      q[k] = reinterpret_cast<const uint2*>(payload)[sl];
+    } else {
+      p[k] = payload[sl];
+    }
+    h[k][0] = h[k][1] = h[k][2] = 0;
+    in[k] = 0;
+    if (cx_hi) {
+      h[k][0] = cx_hi[sl];
+      h[k][1] = cy_hi[sl];
+      h[k][2] = cz_hi[sl];
+    }
+    if (inten_bits) in[k] = inten_bits[sl];
+  }
+  const PcvNodeRec c = pt.leaf_rec[it.rank];
+#pragma unroll
+  for (int k = 0; k < kSlots; ++k) {
+    const uint32_t s = it.begin + threadIdx.x + 256 * k;
+    if (kCompact)  // x: both codes, or the input index
+      p[k] = make_uint4(q[k].x, 0u, q[k].y & 0xffffu, (q[k].y >> 16) | ((key[k] & 0xffu) << 16));
+    if (s < it.end) settle_one<kCompact>(pt, s, c, it.rank, p[k], h[k], in[k], climb_base, climbers, o, wide);
+  }
+}
+
 __global__ __launch_bounds__(256) void promote_climb_kernel(
     PcvPromoteTables pt, uint32_t num_climbers, const PcvClimber* __restrict__ climbers, const uint32_t* __restrict__ cx_hi,
     const uint32_t* __restrict__ cy_hi, const uint32_t* __restrict__ cz_hi, PromoteOut o) {
@@ -641,10 +691,18 @@ void pcv_launch_promote_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvPromo
                                const uint32_t* rank, const void* payload, const uint32_t* cx_hi, const uint32_t* cy_hi,
                                const uint32_t* cz_hi, const uint32_t* inten_bits, const uint32_t* climb_base,
                                uint32_t num_climbers, void* climbers, uint8_t* xyz_blob, uint8_t* rgb_blob,
-                               uint8_t* inten_blob, const void* wide) {
+                               uint8_t* inten_blob, const void* wide, const PcvSettleItem* items, uint32_t num_items) {
   if (n == 0) return;
   PromoteOut o{xyz_blob, rgb_blob, inten_blob};
-  {
+  if (items) {
+    PcvProf prof(ctx, PCV_K_PROMOTE_ENCODE);
+    if (num_items && wide)
+      hipLaunchKernelGGL((promote_settle_leaf_kernel<true>), dim3(num_items), dim3(256), 0, ctx->stream, pt, items, rank,
+                         (const uint4*)payload, cx_hi, cy_hi, cz_hi, inten_bits, climb_base, (PcvClimber*)climbers, o, (const uint4*)wide);
+    else if (num_items)
+      hipLaunchKernelGGL((promote_settle_leaf_kernel<false>), dim3(num_items), dim3(256), 0, ctx->stream, pt, items, rank,
+                         (const uint4*)payload, cx_hi, cy_hi, cz_hi, inten_bits, climb_base, (PcvClimber*)climbers, o, (const uint4*)nullptr);
+  } else {
     PcvProf prof(ctx, PCV_K_PROMOTE_ENCODE);
     static const int slots = [] {  // PCV_SETTLE_SLOTS (experiments): 1, 2 or 4 sorted slots per lane
       const char* e = getenv("PCV_SETTLE_SLOTS");

@@ -365,6 +365,13 @@ struct PcvPromoteTables {
   const PcvNodeRec* leaf_rec;  // per leaf rank
   const PcvNodeRec* node_rec;  // per node index
 };
+// One workgroup of the leaf-wise `settle`: up to 512 consecutive sorted slots [begin, end) of ONE leaf. The work list is
+// built by the host with the node tables (it knows every leaf's slot range), so a workgroup gets its leaf record through
+// two scalar loads that run beside its record loads instead of behind them.
+struct alignas(16) PcvSettleItem {
+  uint32_t rank, begin, end, pad;
+};
+constexpr uint32_t kPcvSettleTile = 512;
 // climb_base[leaf rank] = number of climbers (every 8th point of a non-root leaf) in the leaves before it; climbers:
 // pcv_climber_bytes(num_climbers) bytes of scratch that `settle` fills and `climb` consumes
 size_t pcv_climber_bytes(uint64_t num_climbers);
@@ -372,7 +379,8 @@ void pcv_launch_promote_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvPromo
                                const uint32_t* rank, const void* payload /* uint4[n] */, const uint32_t* cx_hi,
                                const uint32_t* cy_hi, const uint32_t* cz_hi, const uint32_t* inten_bits,
                                const uint32_t* climb_base, uint32_t num_climbers, void* climbers, uint8_t* xyz_blob,
-                               uint8_t* rgb_blob, uint8_t* inten_blob, const void* wide = nullptr);
+                               uint8_t* rgb_blob, uint8_t* inten_blob, const void* wide = nullptr,
+                               const PcvSettleItem* items = nullptr, uint32_t num_items = 0);
 
 struct PcvOctreeQuery;  // device-resident traversal tables (pcv_query.hip)
 

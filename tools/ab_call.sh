@@ -1,15 +1,23 @@
-# one gpurun call: GPU tests, the bench with full-size parity, then timing-only A/B variants (tools/build_variants.sh)
+# one gpurun call: GPU tests, the bench with full-size parity, then timing-only A/B runs.
+# VARIANTS: space-separated "name" (library built by tools/build_variants.sh) or "name:ENV=VALUE" (environment switch)
 mkdir -p gpurun_out
 T=${TAG:-ab}
 timeout 400 python -m pytest tests -m gpu -x -q > gpurun_out/${T}_gputest.log 2>&1; echo "pytest rc=$?"
 B="python bench.py --steps 10 --warmup 3 --no-e2e --no-cpu-baseline"
 timeout 300 python bench.py --steps 10 --warmup 3 --no-e2e --verify > gpurun_out/${T}_bench_main.json 2> gpurun_out/${T}_bench_main.err; echo "rc=$?"
+NAMES=""
 for v in $VARIANTS; do
-  PCV_HIP_LIBRARY=$PWD/point_cloud_viewer_amd/libpcv_hip_$v.so timeout 200 $B > gpurun_out/${T}_bench_$v.json 2> gpurun_out/${T}_bench_$v.err; echo "$v rc=$?"
+  name=${v%%:*}; NAMES="$NAMES $name"
+  if [ "$name" != "$v" ]; then
+    env "${v#*:}" timeout 200 $B > gpurun_out/${T}_bench_$name.json 2> gpurun_out/${T}_bench_$name.err
+  else
+    PCV_HIP_LIBRARY=$PWD/point_cloud_viewer_amd/libpcv_hip_$name.so timeout 200 $B > gpurun_out/${T}_bench_$name.json 2> gpurun_out/${T}_bench_$name.err
+  fi
+  echo "$name rc=$?"
 done
 timeout 200 $B > gpurun_out/${T}_bench_main2.json 2> gpurun_out/${T}_bench_main2.err; echo "rc=$?"
 tail -4 gpurun_out/${T}_gputest.log
-for f in main $VARIANTS main2; do python - <<PY
+for f in main $NAMES main2; do python - <<PY
 import json
 try:
     d=json.loads(open('gpurun_out/${T}_bench_$f.json').read().strip().splitlines()[-1])
