@@ -467,6 +467,20 @@ int pcv_make_levels(const double bmin[3], const double bmax[3], double resolutio
       }
     }
     lv->fast_ok = tame ? 1 : 0;
+    {
+      const int never = 1 << 20;
+      int f16 = never, f8 = never;
+      bool monotone = true;
+      const int last = filled < (int)e.size() - 1 ? filled : (int)e.size() - 1;
+      for (int j = 1; j <= last; ++j) {
+        if (c[j] <= PCV_ENC_UINT16 && f16 == never) f16 = j;
+        if (c[j] == PCV_ENC_UINT8 && f8 == never) f8 = j;
+        if (j > 1 && c[j] > c[j - 1]) monotone = false;
+      }
+      if (f8 != never && f16 == never) f16 = f8;
+      lv->first_u16 = monotone ? f16 : never;
+      lv->first_u8 = monotone ? f8 : never;
+    }
   }
   if (edges) *edges = e;
   if (encs) *encs = c;

@@ -18,6 +18,12 @@
 #ifndef PCV_SETTLE_DIAG
 #define PCV_SETTLE_DIAG 0
 #endif
+#ifndef PCV_KEEP_BRANCH
+#define PCV_KEEP_BRANCH 0
+#endif
+#ifndef PCV_ENC_SEGMENTS
+#define PCV_ENC_SEGMENTS 1
+#endif
 
 namespace {
 
@@ -91,11 +97,15 @@ __global__ __launch_bounds__(256) void leaf_encode_kernel(
 // waves first. The prediction is a hint: a wrong guess costs time, never changes a result — the exact chain below
 // still does all the work. Coordinates travel through LDS; outputs go to the point's own index.
 constexpr int kSpecClasses = 24;  // predicted depth 0..21 (+ padding lanes)
-constexpr int kGridBits = 7;      // 128^3 cells, 2 MiB: stays in L2
+#ifndef PCV_GRID_BITS
+#define PCV_GRID_BITS 7
+#endif
+constexpr int kGridBits = PCV_GRID_BITS;  // 128^3 cells, 2 MiB: stays in L2
 
 __global__ __launch_bounds__(256) void spec_depth_grid_kernel(const uint32_t* __restrict__ walk, uint8_t* __restrict__ grid) {
   const uint32_t c = blockIdx.x * 256 + threadIdx.x;  // grid is exactly 2^21 cells
-  const uint32_t ix = c & 127u, iy = (c >> 7) & 127u, iz = c >> 14;
+  constexpr uint32_t kM = (1u << kGridBits) - 1u;
+  const uint32_t ix = c & kM, iy = (c >> kGridBits) & kM, iz = c >> (2 * kGridBits);
   uint32_t r = walk[0];
   uint32_t l = 0;
   while (!(r & PCV_SPEC_LEAF) && l < (uint32_t)kGridBits) {
@@ -140,10 +150,11 @@ __global__ __launch_bounds__(BLOCK) void spec_encode_kernel(
         sx[tid] = qx, sy[tid] = qy, sz[tid] = qz;
       }
       // cell of the 128^3 grid over the root cube (NaN -> 0, out of range clamps) -> predicted depth (1..8, 8 = deeper)
-      const uint32_t ix = (uint32_t)fminf(fmaxf((float)(qx - lv.root_min[0]) * cells_per_unit, 0.f), 127.f);
-      const uint32_t iy = (uint32_t)fminf(fmaxf((float)(qy - lv.root_min[1]) * cells_per_unit, 0.f), 127.f);
-      const uint32_t iz = (uint32_t)fminf(fmaxf((float)(qz - lv.root_min[2]) * cells_per_unit, 0.f), 127.f);
-      const uint32_t l = depth_grid[ix | (iy << 7) | (iz << 14)];
+      constexpr float kTop = (float)((1 << kGridBits) - 1);
+      const uint32_t ix = (uint32_t)fminf(fmaxf((float)(qx - lv.root_min[0]) * cells_per_unit, 0.f), kTop);
+      const uint32_t iy = (uint32_t)fminf(fmaxf((float)(qy - lv.root_min[1]) * cells_per_unit, 0.f), kTop);
+      const uint32_t iz = (uint32_t)fminf(fmaxf((float)(qz - lv.root_min[2]) * cells_per_unit, 0.f), kTop);
+      const uint32_t l = depth_grid[ix | (iy << kGridBits) | (iz << (2 * kGridBits))];
       key = (uint32_t)(kSpecClasses - 2 - l);  // deepest first
     }
     for (int k = tid; k < kWavesB * kSpecClasses; k += BLOCK) (&wcnt[0][0])[k] = 0;
@@ -200,30 +211,75 @@ __global__ __launch_bounds__(BLOCK) void spec_encode_kernel(
       rec = walk[(rec & PCV_SPEC_INDEX_MASK) + d1];
     }
   }
+#if PCV_KEEP_BRANCH  /* (experiment) a real branch around the copies: most waves have no lane at its first candidate */
+#define PCV_KEEP_STEP                                                                                                   \
+  if (KEEP) {                                                                                                           \
+    const bool take = (rec & PCV_SPEC_CANDIDATE) && kl == 0;                                                            \
+    if (__builtin_amdgcn_ballot_w64(take) != 0ull) {                                                                    \
+      asm volatile("" ::: "memory");                                                                                    \
+      if (take) {                                                                                                       \
+        kx = vx, ky = vy, kz = vz;                                                                                      \
+        kl = U;                                                                                                         \
+      }                                                                                                                 \
+    }                                                                                                                   \
+  }
+#else
+#define PCV_KEEP_STEP                                                                                                   \
+  if (KEEP && (rec & PCV_SPEC_CANDIDATE) && kl == 0) {                                                                  \
+    kx = vx, ky = vy, kz = vz;                                                                                          \
+    kl = U; /* candidates have level >= 1 */                                                                            \
+  }
+#endif
+/* Levels U + 1 .. LEND of the lanes that have not reached a leaf. U is the wave's level counter: every live lane is at
+   level U (they start together and step together), so it — and with it the level constants and `half` — stays in scalar
+   registers across the loops; L is the lane's own last level. Per level: the digit first, the child's record in flight
+   while the level's encode / decode arithmetic runs. */
+#define PCV_SPEC_LOOP(GUARD, LEND, APPLY)                                                                               \
+  while (U < (LEND)) {                                                                                                  \
+    const bool live = !(rec & PCV_SPEC_LEAF);                                                                           \
+    if (!__any(live)) break;                                                                                            \
+    const double half_next = lv.digit_half[U + 1];                                                                      \
+    if (live) {                                                                                                         \
+      PCV_KEEP_STEP                                                                                                     \
+      const uint32_t d = (!GUARD && half >= 0.0) ? pcv_digit_from_codes(half, vx, vy, vz)                               \
+                                                 : pcv_chain_digit(lv.edge[U], px, py, pz, mx, my, mz);                  \
+      const uint32_t next = walk[(rec & PCV_SPEC_INDEX_MASK) + d];                                                      \
+      const double ec = lv.edge[U + 1];                                                                                 \
+      const PcvRecip ic{lv.inv_edge[U + 1], lv.inv_edge_lo[U + 1]};                                                     \
+      APPLY;                                                                                                            \
+      rec = next;                                                                                                       \
+      L = U + 1;                                                                                                        \
+    }                                                                                                                   \
+    half = half_next;                                                                                                   \
+    ++U;                                                                                                                \
+  }
+#if PCV_ENC_SEGMENTS
+/* one loop per encoding range (PcvLevels::first_u16 / first_u8): Float32 / Float64-coded levels through the per-level   \
+   switch, then the u16-coded and the u8-coded levels as straight-line loops */                                         \
 #define PCV_SPEC_WALK(GUARD)                                                                                          \
   /* >= 0: the next digit comes from this level's integer codes (fetched with the level's other constants) */          \
-  double half = lv.digit_half[L];                                                                                       \
-  while (!(rec & PCV_SPEC_LEAF) && L < lv.nlevels) {                                                                    \
-    if (KEEP && (rec & PCV_SPEC_CANDIDATE) && kl == 0) {                                                                \
-      kx = vx, ky = vy, kz = vz;                                                                                        \
-      kl = L; /* candidates have level >= 1 */                                                                          \
-    }                                                                                                                   \
-    ++L;                                                                                                                \
-    /* the digit first, the child's record in flight while the level's encode / decode arithmetic runs */             \
-    const uint32_t d = (!GUARD && half >= 0.0) ? pcv_digit_from_codes(half, vx, vy, vz)                                 \
-                                               : pcv_chain_digit(lv.edge[L - 1], px, py, pz, mx, my, mz);                \
-    const uint32_t next = walk[(rec & PCV_SPEC_INDEX_MASK) + d];                                                        \
-    half = lv.digit_half[L];                                                                                            \
-    pcv_chain_apply<GUARD>(lv.enc[L], d, lv.edge[L], PcvRecip{lv.inv_edge[L], lv.inv_edge_lo[L]}, px, py, pz, mx, my, mz, vx, \
-                           vy, vz);                                                                                     \
-    rec = next;                                                                                                         \
+  double half = lv.digit_half[U];                                                                                       \
+  {                                                                                                                     \
+    const int e0 = lv.first_u16 - 1 < lv.nlevels ? lv.first_u16 - 1 : lv.nlevels;                                       \
+    const int e1 = lv.first_u8 - 1 < lv.nlevels ? lv.first_u8 - 1 : lv.nlevels;                                         \
+    PCV_SPEC_LOOP(GUARD, e0, pcv_chain_apply<GUARD>(lv.enc[U + 1], d, ec, ic, px, py, pz, mx, my, mz, vx, vy, vz))          \
+    PCV_SPEC_LOOP(GUARD, e1, (pcv_chain_apply_t<PCV_ENC_UINT16, GUARD>(d, ec, ic, px, py, pz, mx, my, mz, vx, vy, vz))) \
+    PCV_SPEC_LOOP(GUARD, lv.nlevels, (pcv_chain_apply_t<PCV_ENC_UINT8, GUARD>(d, ec, ic, px, py, pz, mx, my, mz, vx, vy, vz))) \
   }
+#else
+#define PCV_SPEC_WALK(GUARD)                                                                                          \
+  double half = lv.digit_half[U];                                                                                       \
+  PCV_SPEC_LOOP(GUARD, lv.nlevels, pcv_chain_apply<GUARD>(lv.enc[U + 1], d, ec, ic, px, py, pz, mx, my, mz, vx, vy, vz))
+#endif
+  // the wave's level counter (all lanes start at the same level: 0, or 1 for routed input)
+  int U = __builtin_amdgcn_readfirstlane(L);
   if (lv.fast_ok && pcv_point_is_tame(px, py, pz)) {
     PCV_SPEC_WALK(false)
   } else {
     PCV_SPEC_WALK(true)
   }
 #undef PCV_SPEC_WALK
+#undef PCV_SPEC_LOOP
   const uint32_t leaf_enc = lv.enc[L];
   const uint8_t* c = color + i * color_stride;
   const uint32_t ccx = (uint32_t)pcv_val_to_code(leaf_enc, vx), ccy = (uint32_t)pcv_val_to_code(leaf_enc, vy),
@@ -616,7 +672,7 @@ static void launch_spec_encode_t(pcv_ctx* ctx, const PcvLevels& lv, const uint32
                                  uint32_t color_stride, const float* intensity, uint32_t* rank, void* payload, void* kept,
                                  uint32_t* inten_bits, uint8_t* depth_grid, void* wide) {
   const dim3 grid((unsigned)((n + BLOCK - 1) / BLOCK));
-  const float cells = lv.edge[0] > 0.0 ? (float)(128.0 / lv.edge[0]) : 0.f;
+  const float cells = lv.edge[0] > 0.0 ? (float)((double)(1 << kGridBits) / lv.edge[0]) : 0.f;
   if (BIN) hipLaunchKernelGGL(spec_depth_grid_kernel, dim3((1u << (3 * kGridBits)) / 256), dim3(256), 0, ctx->stream, walk, depth_grid);
   if (kept)
     hipLaunchKernelGGL((spec_encode_kernel<true, BIN, BLOCK>), grid, dim3(BLOCK), 0, ctx->stream, lv, walk, n, x, y, z, routed, color,

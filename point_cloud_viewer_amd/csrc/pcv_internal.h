@@ -34,6 +34,10 @@ struct PcvLevels {
   // Octant digit of level k + 1 straight from the integer codes of level k (pcv_chain_dev.h, pcv_digit_from_codes):
   // digit_half[k] = 127 / 32767 when level k is u8 / u16-coded and the rounding-error bound holds there, else -1
   double digit_half[PCV_MAX_LEVELS + 2];
+  // Encodings narrow with depth (the edge halves per level): levels [first_u16, first_u8) are u16-coded, levels from
+  // first_u8 on u8-coded; both are "never" (a huge level) when the table is not monotone. The single chain pass runs one
+  // straight-line loop per range instead of a switch per level.
+  int32_t first_u16, first_u8;
   int32_t nlevels;  // number of digit levels materialised in the keys (<= PCV_MAX_KEY_LEVELS; <= PCV_MAX_LEVELS deep)
   int32_t fast_ok;  // root min and all edges are tame: unguarded exact division is valid for tame points
 };

@@ -285,17 +285,21 @@ __global__ __launch_bounds__(256) void scan_kernel(uint32_t* __restrict__ hist, 
 
 // ---- shared pieces of the two downsweep kernels -------------------------------------------------
 
+// R: digit values the pass can produce (256, or 128 for digits of <= 7 bits: 3 KB less LDS, which is what lets three
+// workgroups of the 12-byte record kernel share a CU); thread t serves digit t, threads >= R only keep the barriers
+template <int R = kRadix>
 struct DigitState {
-  uint32_t whist[kWaves][kRadix];  // per-wave digit counters, then exclusive prefix over the waves
-  uint32_t digit_base[kRadix];     // global position of the next key of each digit for this workgroup
-  uint32_t delta[kRadix];          // digit_base - (digit's start inside the tile): LDS slot p goes to delta[digit] + p
+  uint32_t whist[kWaves][R];  // per-wave digit counters, then exclusive prefix over the waves
+  uint32_t digit_base[R];     // global position of the next key of each digit for this workgroup
+  uint32_t delta[R];          // digit_base - (digit's start inside the tile): LDS slot p goes to delta[digit] + p
   uint32_t wave_tot[kWaves];
 };
 
 // global base of digit t for this workgroup = (keys with a smaller digit) + (same digit, earlier workgroups)
-__device__ __forceinline__ void init_digit_base(DigitState& S, const uint32_t* __restrict__ offsets,
+template <int R>
+__device__ __forceinline__ void init_digit_base(DigitState<R>& S, const uint32_t* __restrict__ offsets,
                                                 const uint32_t* __restrict__ totals, int groups, int t, int lane, int wave) {
-  const uint32_t tot = totals[t];  // kBlock == kRadix
+  const uint32_t tot = t < R ? totals[t] : 0u;  // kBlock == kRadix >= R
   uint32_t inc = tot;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -307,9 +311,11 @@ __device__ __forceinline__ void init_digit_base(DigitState& S, const uint32_t* _
   uint32_t woff = 0;
 #pragma unroll
   for (int w = 0; w < kWaves; ++w) woff += (w < wave) ? S.wave_tot[w] : 0u;
-  S.digit_base[t] = woff + inc - tot + offsets[(uint64_t)t * groups + blockIdx.x];
+  if (t < R) {
+    S.digit_base[t] = woff + inc - tot + offsets[(uint64_t)t * groups + blockIdx.x];
 #pragma unroll
-  for (int w = 0; w < kWaves; ++w) S.whist[w][t] = 0;
+    for (int w = 0; w < kWaves; ++w) S.whist[w][t] = 0;
+  }
   __syncthreads();
 }
 
@@ -322,8 +328,8 @@ __device__ __forceinline__ void init_digit_base(DigitState& S, const uint32_t* _
 // The kernel is VALU-issue bound (a wave64 op takes 4 clocks on a 16-lane SIMD), so the mask arithmetic is written
 // on 32-bit halves in the shape the ISA has single instructions for: one sign-extracting bit-field op per digit bit,
 // one compare (the ballot), one three-input bit op per half (p & ~(ballot ^ m)), mbcnt for the lanes below.
-template <int kKpt, typename KeyT, bool kFull>
-__device__ __forceinline__ void wave_rank_all(DigitState& S, int wave, uint32_t wbase, uint32_t tile_n,
+template <int kKpt, typename KeyT, bool kFull, int R>
+__device__ __forceinline__ void wave_rank_all(DigitState<R>& S, int wave, uint32_t wbase, uint32_t tile_n,
                                               const KeyT (&key)[kKpt], int shift, uint32_t mask, uint16_t (&lpos)[kKpt],
                                               int nbits = 8) {
   constexpr int kBatch = 8;  // adds in flight; more costs registers the 16-keys-per-lane kernel does not have
@@ -365,14 +371,15 @@ __device__ __forceinline__ void wave_rank_all(DigitState& S, int wave, uint32_t 
 // After all waves ranked their slices: per digit t the exclusive prefix over the waves (folded together with the
 // digit's start inside the tile, so the LDS slot of a key is whist[wave][d] + its rank), the global position of the
 // digit's run (delta) and the advance of digit_base. Starts and ends with a barrier.
-__device__ __forceinline__ void digit_scan(DigitState& S, int t, int lane, int wave) {
+template <int R>
+__device__ __forceinline__ void digit_scan(DigitState<R>& S, int t, int lane, int wave) {
   __syncthreads();
   uint32_t pre[kWaves];
   uint32_t acc = 0;
 #pragma unroll
   for (int w = 0; w < kWaves; ++w) {
     pre[w] = acc;
-    acc += S.whist[w][t];
+    acc += t < R ? S.whist[w][t] : 0u;
   }
   uint32_t inc = acc;
 #pragma unroll
@@ -386,11 +393,13 @@ __device__ __forceinline__ void digit_scan(DigitState& S, int t, int lane, int w
 #pragma unroll
   for (int w = 0; w < kWaves; ++w) woff += (w < wave) ? S.wave_tot[w] : 0u;
   const uint32_t start = woff + inc - acc;
+  if (t < R) {
 #pragma unroll
-  for (int w = 0; w < kWaves; ++w) S.whist[w][t] = start + pre[w];
-  const uint32_t base = S.digit_base[t];
-  S.delta[t] = base - start;
-  S.digit_base[t] = base + acc;
+    for (int w = 0; w < kWaves; ++w) S.whist[w][t] = start + pre[w];
+    const uint32_t base = S.digit_base[t];
+    S.delta[t] = base - start;
+    S.digit_base[t] = base + acc;
+  }
   __syncthreads();
 }
 
@@ -403,7 +412,7 @@ __global__ __launch_bounds__(kBlock, PCV_KEYS_WAVES) void downsweep_keys_kernel(
                                                                    const uint32_t* __restrict__ totals) {
   constexpr int kKpt = kKptKeys, kTile = kBlock * kKpt;
   __shared__ KeyT skeys[kTile];
-  __shared__ DigitState S;
+  __shared__ DigitState<kRadix> S;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const uint32_t mask = (1u << nbits) - 1u;
   init_digit_base(S, offsets, totals, groups, t, lane, wave);
@@ -426,9 +435,9 @@ __global__ __launch_bounds__(kBlock, PCV_KEYS_WAVES) void downsweep_keys_kernel(
     const uint32_t tile_n = (uint32_t)((end - base) < (uint64_t)kTile ? (end - base) : (uint64_t)kTile);
     uint16_t lpos[kKpt];
     if (tile_n == (uint32_t)kTile)
-      wave_rank_all<kKpt, KeyT, true>(S, wave, wbase, tile_n, key, shift, mask, lpos);
+      wave_rank_all<kKpt, KeyT, true, kRadix>(S, wave, wbase, tile_n, key, shift, mask, lpos);
     else
-      wave_rank_all<kKpt, KeyT, false>(S, wave, wbase, tile_n, key, shift, mask, lpos);
+      wave_rank_all<kKpt, KeyT, false, kRadix>(S, wave, wbase, tile_n, key, shift, mask, lpos);
     digit_scan(S, t, lane, wave);
 #pragma unroll
     for (int i = 0; i < kKpt; ++i) {
@@ -474,7 +483,7 @@ struct RecPtrs {
 
 // kPrefetch: the next tile's keys and payloads are loaded into the registers the LDS staging just freed, so that the
 // loads are in flight while this tile drains through LDS to memory (as the keys-only kernel does).
-template <bool kHasVec, bool kPrefetch = false, typename VecT = uint4>
+template <bool kHasVec, bool kPrefetch = false, typename VecT = uint4, int R = kRadix>
 __global__ __launch_bounds__(kBlock, kHasVec ? 3 : 4) void downsweep_rec_kernel(const uint32_t* __restrict__ keys_in,
                                                                   uint32_t* __restrict__ keys_out, uint64_t n,
                                                                   uint64_t chunk, int groups, int shift, int nbits,
@@ -483,7 +492,7 @@ __global__ __launch_bounds__(kBlock, kHasVec ? 3 : 4) void downsweep_rec_kernel(
   constexpr int kKpt = kKptRec, kTile = kBlock * kKpt;
   __shared__ uint32_t skeys[kTile];
   __shared__ VecT svec[kHasVec ? kTile : 1];
-  __shared__ DigitState S;
+  __shared__ DigitState<R> S;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const uint32_t mask = (1u << nbits) - 1u;
   init_digit_base(S, offsets, totals, groups, t, lane, wave);
@@ -512,9 +521,9 @@ __global__ __launch_bounds__(kBlock, kHasVec ? 3 : 4) void downsweep_rec_kernel(
     if (!kPrefetch) load_tile(base, tile_n);
     uint16_t lpos[kKpt];
     if (tile_n == (uint32_t)kTile)
-      wave_rank_all<kKpt, uint32_t, true>(S, wave, wbase, tile_n, key, shift, mask, lpos, nbits);
+      wave_rank_all<kKpt, uint32_t, true, R>(S, wave, wbase, tile_n, key, shift, mask, lpos, nbits);
     else
-      wave_rank_all<kKpt, uint32_t, false>(S, wave, wbase, tile_n, key, shift, mask, lpos, nbits);
+      wave_rank_all<kKpt, uint32_t, false, R>(S, wave, wbase, tile_n, key, shift, mask, lpos, nbits);
     digit_scan(S, t, lane, wave);
 #pragma unroll
     for (int i = 0; i < kKpt; ++i) {
@@ -560,8 +569,10 @@ __global__ __launch_bounds__(kBlock, kHasVec ? 3 : 4) void downsweep_rec_kernel(
         if (p < tile_n) dst[gidx[j]] = skeys[p];
       }
     }
+    if (t < R) {
 #pragma unroll
-    for (int w = 0; w < kWaves; ++w) S.whist[w][t] = 0;  // last read before the barrier after the LDS scatter
+      for (int w = 0; w < kWaves; ++w) S.whist[w][t] = 0;  // last read before the barrier after the LDS scatter
+    }
     __syncthreads();
   }
 }
@@ -631,7 +642,14 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
         return !e || atoi(e) != 0;
       }();
       PcvProf prof(ctx, PCV_K_SORT_DOWNSWEEP_REC);
-      if (compact)
+      static const bool narrow_state = [] {
+        const char* e = getenv("PCV_REC_RADIX128");  // 0 = always the 256-entry digit state (experiments)
+        return !e || atoi(e) != 0;
+      }();
+      if (compact && nbits <= 7 && narrow_state)
+        hipLaunchKernelGGL((downsweep_rec_kernel<true, true, uint2, 128>), dim3(g.groups), dim3(kBlock), 0, ctx->stream, (const uint32_t*)src,
+                           (uint32_t*)dst, n, g.chunk, g.groups, shift, nbits, hist, totals, rp);
+      else if (compact)
         hipLaunchKernelGGL((downsweep_rec_kernel<true, true, uint2>), dim3(g.groups), dim3(kBlock), 0, ctx->stream, (const uint32_t*)src,
                            (uint32_t*)dst, n, g.chunk, g.groups, shift, nbits, hist, totals, rp);
       else if (payload->vec_in && prefetch)
