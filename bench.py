@@ -41,8 +41,8 @@ ALGO_BYTES = {
     "downsweep_kernel<u32>": 8.0,   # keys only: read 4 B + write 4 B
     "downsweep_rec_kernel": 2 * 4.0 + 2 * 16.0,  # rank r/w + 16-byte payload r/w
     "upsweep_kernel<u32>": 4.0,
-    "promote_settle_kernel": 20.0 + 63.0 / 64.0 * 9.0 + 48.0 / 64.0,  # read record; 63 of 64 points write ~6 B xyz + 3 B rgb (leaf or its parent), the rest a 48-byte climber
-    "promote_climb_kernel": (48.0 + 9.0) / 64.0,  # every 64th point: climber in, xyz + rgb out
+    "promote_settle_kernel": 20.0 + 7.0 / 8.0 * 9.0,  # read record; 7 of 8 points write ~6 B xyz + 3 B rgb
+    "promote_climb_kernel": 4.0 + (16.0 + 9.0) / 8.0,  # read ranks; every 8th point: payload in, xyz + rgb out
     "spec_encode_kernel": 24.0 + 3.0 + 20.0,  # single-chain pass: read xyz + rgb, write rank + 16-byte payload (+ kept codes of ~10 %)
     "rank_hist_kernel": 4.0,        # read ranks
     "spec_finalize_kernel": 8.0,    # rank read + write (+ payload patch of the points that take their kept codes)
@@ -429,7 +429,7 @@ def main():
         # packed 12-byte records (single-chain build, build_info record_bytes == 12): u32 key + uint2 payload
         rec_b = float((info.get("build") or {}).get("record_bytes") or 20)
         if rec_b == 12.0:
-            ALGO_BYTES.update({"downsweep_rec_kernel": 2 * 12.0, "promote_settle_kernel": 12.0 + 63.0 / 64.0 * 9.0 + 48.0 / 64.0,
+            ALGO_BYTES.update({"downsweep_rec_kernel": 2 * 12.0, "promote_settle_kernel": 12.0 + 7.0 / 8.0 * 9.0,
                                "spec_encode_kernel": 24.0 + 3.0 + 12.0})
 
         def hbm_view(name):

@@ -1631,18 +1631,12 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
     for (int a = 0; a < 3; ++a) nr.mn[a] = u_node_min[3 * (size_t)i + a];
   }
   for (uint32_t r = 0; r < num_leaves; ++r) u_leaf_rec[r] = u_node_rec[leaves[r]];
-  // climbers of K6: `settle` finishes a leaf's every-8th points in the leaf's parent; those that are an every-8th element
-  // of the PARENT's stream too (climber k = j / 8 of the leaf with (k + o) % 8 == 0, o = child_off & 7) climb on in the
-  // climb kernel: dense index = climb_base[leaf] + ((k + o) >> 3) - (o != 0). Parents that are the root keep everything.
+  // climbers of K6 (every 8th point of every leaf; the root is never a leaf): dense index = climb_base[leaf] + j / 8
   uint32_t* u_climb_base = (uint32_t*)(u_leaf_rec + num_leaves);
   uint64_t num_climbers = 0;
   for (uint32_t r = 0; r < num_leaves; ++r) {
     u_climb_base[r] = (uint32_t)num_climbers;
-    const uint32_t par = u_leaf_rec[r].parent;
-    if (par == 0xffffffffu || u_node_rec[par].parent == 0xffffffffu) continue;
-    const uint64_t k8 = ceil8((uint64_t)h_hi[leaves[r]] - h_lo[leaves[r]]);  // climbers of the leaf
-    const uint64_t off = u_leaf_rec[r].child_off & 7u;
-    if (k8) num_climbers += (k8 - 1 + off) / 8 + (off ? 0 : 1);
+    if (u_leaf_rec[r].parent != 0xffffffffu) num_climbers += ceil8((uint64_t)h_hi[leaves[r]] - h_lo[leaves[r]]);
   }
   // work list of the leaf-wise settle kernel: tiles of <= 512 consecutive slots of one leaf (PCV_SETTLE_BY_LEAF=0: the
   // slot-wise kernel, experiments)
@@ -1705,7 +1699,7 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
     if (tp) PCV_HIP_CHECK(ctx, hipMemsetAsync(t->d_rgb, 0, tp * 3, st));
     if (tp && t->d_int) PCV_HIP_CHECK(ctx, hipMemsetAsync(t->d_int, 0, tp * 4, st));
   }
-  // the compact climber records live in the payload buffer the sort left unused (48 B x ~n / 64)
+  // the compact climber records live in the payload buffer the sort left unused (32 B x n / 8 < 16 B x n)
   void* climbers = rec_in_a ? (void*)pay_b : (void*)pay_a;
   if (pcv_climber_bytes(num_climbers) > (size_t)n * (bs->spec_wide ? 8 : 16)) {
     if ((rc = ctx->dev_alloc(&climbers, pcv_climber_bytes(num_climbers)))) return rc;

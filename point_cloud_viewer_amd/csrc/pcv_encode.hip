@@ -437,12 +437,12 @@ struct PromoteOut {
   uint8_t* inten_blob;
 };
 
-// One point at position j of node `cur`'s stream, codes at cur's level: climb (CLIMB), final encode, store.
-// CLIMB = false: the caller knows the point stays in `cur`.
+// One sorted slot: climb, final encode, store. CLIMB = false: the caller knows the point stays in its leaf.
 template <bool CLIMB>
-__device__ __forceinline__ void promote_one(const PcvPromoteTables& pt, uint32_t j, PcvNodeRec cur, uint64_t cx, uint64_t cy,
-                                            uint64_t cz, uint32_t rgb, uint32_t inten, const PromoteOut& o) {
-  uint64_t code[3] = {cx, cy, cz};
+__device__ __forceinline__ void promote_one(const PcvPromoteTables& pt, uint64_t s, PcvNodeRec cur, uint4 pay,
+                                            uint32_t hx, uint32_t hy, uint32_t hz, uint32_t inten, const PromoteOut& o) {
+  uint32_t j = (uint32_t)s - cur.lo;
+  uint64_t code[3] = {pay.x | ((uint64_t)hx << 32), pay.y | ((uint64_t)hy << 32), pay.z | ((uint64_t)hz << 32)};
   // climb while this point is an every-8th element of its node's stream
   while (CLIMB && cur.parent != 0xffffffffu && (j & 7u) == 0) {
     const PcvNodeRec par = pt.node_rec[cur.parent];
@@ -499,7 +499,7 @@ __device__ __forceinline__ void promote_one(const PcvPromoteTables& pt, uint32_t
     }
   }
   const uint64_t pidx = cur.point_off + slot;
-  const uint32_t c = rgb;
+  const uint32_t c = pay.w;
   uint8_t* cd = o.rgb_blob + pidx * 3;
   cd[0] = (uint8_t)c;
   cd[1] = (uint8_t)(c >> 8);
@@ -507,20 +507,18 @@ __device__ __forceinline__ void promote_one(const PcvPromoteTables& pt, uint32_t
   if (o.inten_blob) reinterpret_cast<uint32_t*>(o.inten_blob)[pidx] = inten;
 }
 
-// K6 runs as two kernels over the sorted records. Seven of eight points stay in their leaf, and seven of eight of the
-// rest stay in the leaf's PARENT: `settle` streams over all slots and finishes both kinds with straight-line code — the
-// first climb step runs inline, the parent's record is one more (wave-uniform) record load. Only the points that are an
-// every-8th element of the parent's stream as well (one point in 64) climb a data-dependent number of further levels:
-// `settle` leaves them — already re-encoded into the parent — in a COMPACT array and `climb` runs one lane per entry.
-// Entry of leaf r's climber k = j / 8 (k + o a multiple of 8, o = child_off & 7): climb_base[r] + ((k + o) >> 3) - (o != 0).
+// K6 runs as two kernels over the sorted records. Seven of eight points stay in their leaf: `settle` streams over all
+// slots (two per lane, both record chains started before either is consumed) and finishes those with straight-line
+// code. The every-8th points climb a data-dependent number of levels (decode + encode per level): `settle` copies
+// their records into a COMPACT array (climber k of leaf r sits at climb_base[r] + k, so the array is dense and in slot
+// order) and `climb` runs one lane per entry — its waves are full of climbers and it reads 32 bytes per climber instead
+// of touching every sector of the 16-byte payload array to use an eighth of it.
 struct alignas(16) PcvClimber {
-  uint64_t code[3];  // codes at the level of `node`
-  uint32_t rgb, node, j, inten;  // position j of node `node`'s stream ((j & 7) == 0: it climbs on)
-  uint32_t pad[2];
+  uint4 pay;
+  uint32_t rank, slot, inten, pad;
 };
-static_assert(sizeof(PcvClimber) == 48, "climber record");
 
-// one sorted slot of `settle`: finish it in its leaf or in the leaf's parent, or hand it to `climb`
+// one sorted slot of `settle`: finish it in its leaf, or hand it to `climb`
 template <bool kCompact>
 __device__ __forceinline__ void settle_one(const PcvPromoteTables& pt, uint64_t s, const PcvNodeRec& c, uint32_t r, uint4 p,
                                            const uint32_t h[3], uint32_t inten, const uint32_t* __restrict__ climb_base,
@@ -536,26 +534,8 @@ __device__ __forceinline__ void settle_one(const PcvPromoteTables& pt, uint64_t 
     }
   }
   const uint32_t j = (uint32_t)s - c.lo;
-  uint64_t code[3] = {p.x | ((uint64_t)h[0] << 32), p.y | ((uint64_t)h[1] << 32), p.z | ((uint64_t)h[2] << 32)};
-  if (c.parent == 0xffffffffu || (j & 7u) != 0) {
-    promote_one<false>(pt, j, c, code[0], code[1], code[2], p.w, inten, o);
-    return;
-  }
-  // every 8th point of the leaf: into the parent (generation.rs:222-238: decode at the child's level, encode at the parent's)
-  const PcvNodeRec par = pt.node_rec[c.parent];
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    const double q = pcv_decode_coord(c.enc, code[a], c.mn[a], c.edge);
-    code[a] = pcv_encode_coord(par.enc, q, par.mn[a], par.edge, PcvRecip{par.inv_edge, par.inv_edge_lo});
-  }
-  const uint32_t jp = c.child_off + (j >> 3);
-  if (par.parent == 0xffffffffu || (jp & 7u) != 0) {
-    promote_one<false>(pt, jp, par, code[0], code[1], code[2], p.w, inten, o);
-  } else {
-    const uint32_t off = c.child_off & 7u;
-    climbers[climb_base[r] + (((j >> 3) + off) >> 3) - (off ? 1u : 0u)] =
-        PcvClimber{{code[0], code[1], code[2]}, p.w, c.parent, jp, inten, {0u, 0u}};
-  }
+  if (c.parent == 0xffffffffu || (j & 7u) != 0) promote_one<false>(pt, s, c, p, h[0], h[1], h[2], inten, o);
+  else climbers[climb_base[r] + (j >> 3)] = PcvClimber{p, r, (uint32_t)s, inten, 0u};
 }
 
 // kSettleSlots sorted slots per lane: every record load of the tile is in flight before the first is used
@@ -658,12 +638,20 @@ __global__ __launch_bounds__(256) void promote_settle_leaf_kernel(
   }
 }
 
-__global__ __launch_bounds__(256) void promote_climb_kernel(PcvPromoteTables pt, uint32_t num_climbers,
-                                                             const PcvClimber* __restrict__ climbers, PromoteOut o) {
+__global__ __launch_bounds__(256) void promote_climb_kernel(
+    PcvPromoteTables pt, uint32_t num_climbers, const PcvClimber* __restrict__ climbers, const uint32_t* __restrict__ cx_hi,
+    const uint32_t* __restrict__ cy_hi, const uint32_t* __restrict__ cz_hi, PromoteOut o) {
   const uint32_t k = blockIdx.x * 256 + threadIdx.x;
   if (k >= num_climbers) return;
   const PcvClimber c = climbers[k];
-  promote_one<true>(pt, c.j, pt.node_rec[c.node], c.code[0], c.code[1], c.code[2], c.rgb, c.inten, o);
+  const PcvNodeRec rec = pt.leaf_rec[c.rank];
+  uint32_t h[3] = {0, 0, 0};
+  if (cx_hi) {
+    h[0] = cx_hi[c.slot];
+    h[1] = cy_hi[c.slot];
+    h[2] = cz_hi[c.slot];
+  }
+  promote_one<true>(pt, c.slot, rec, c.pay, h[0], h[1], h[2], c.inten, o);
 }
 
 }  // namespace
@@ -791,6 +779,6 @@ void pcv_launch_promote_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvPromo
   if (num_climbers) {
     PcvProf prof(ctx, PCV_K_PROMOTE_CLIMB);
     hipLaunchKernelGGL(promote_climb_kernel, dim3((num_climbers + 255) / 256), dim3(256), 0, ctx->stream, pt, num_climbers,
-                       (const PcvClimber*)climbers, o);
+                       (const PcvClimber*)climbers, cx_hi, cy_hi, cz_hi, o);
   }
 }

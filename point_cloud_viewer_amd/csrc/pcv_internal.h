@@ -376,8 +376,7 @@ struct alignas(16) PcvSettleItem {
   uint32_t rank, begin, end, pad;
 };
 constexpr uint32_t kPcvSettleTile = 512;
-// climb_base[leaf rank] = number of climber records (points that are an every-8th element of their leaf's stream AND of
-// the leaf's parent's stream, the parent not being the root) in the leaves before it; climbers:
+// climb_base[leaf rank] = number of climbers (every 8th point of a non-root leaf) in the leaves before it; climbers:
 // pcv_climber_bytes(num_climbers) bytes of scratch that `settle` fills and `climb` consumes
 size_t pcv_climber_bytes(uint64_t num_climbers);
 void pcv_launch_promote_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvPromoteTables& pt, uint64_t n,
