@@ -1624,8 +1624,9 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
     nr.child_off = u_child_off[i];
     nr.enc = lv.enc[u_level[i]];
     nr.edge = lv.edge[u_level[i]];
-    nr.inv_edge = lv.inv_edge[u_level[i]];
-    nr.inv_edge_lo = lv.inv_edge_lo[u_level[i]];
+    // 0 = "no unchecked exact division here": also when the root cube's min is not tame (PcvLevels::fast_ok)
+    nr.inv_edge = lv.fast_ok ? lv.inv_edge[u_level[i]] : 0.0;
+    nr.inv_edge_lo = lv.fast_ok ? lv.inv_edge_lo[u_level[i]] : 0.0;
     nr.xyz_off = u_xyz_off[i];
     nr.point_off = u_point_off[i];
     for (int a = 0; a < 3; ++a) nr.mn[a] = u_node_min[3 * (size_t)i + a];

@@ -437,6 +437,64 @@ struct PromoteOut {
   uint8_t* inten_blob;
 };
 
+// The point at position j of node `cur`'s stream stays there: final rewrite (encode(decode(code)) at the node's own level —
+// not idempotent, SURVEY F5 — unless the node is the root, which keeps what it receives) and the stores, as straight-line
+// code for one encoding.
+template <int ENC, bool CLIMB>
+__device__ __forceinline__ void promote_final(const PcvNodeRec& cur, uint32_t j, uint64_t (&code)[3], uint32_t rgb,
+                                              uint32_t inten, const PromoteOut& o) {
+  uint32_t slot = j;
+  if (cur.parent != 0xffffffffu) {
+    slot = j - (j >> 3) - 1u;
+#if PCV_SETTLE_DIAG != 2  // (timing experiments, tools/build_variants.sh: 2 = no re-encode, 1 = no stores; never shipped)
+    if ((ENC == PCV_ENC_UINT8 || ENC == PCV_ENC_UINT16) && cur.inv_edge != 0.0) {
+      // integer codes in a tame cube (the host zeroes inv_edge otherwise): the decoded position lies inside the cube, so
+      // the exact constant-divisor division needs no range check (pcv_div_const<false>)
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+        code[a] = pcv_fix_encode<false>(pcv_decode_coord(ENC, code[a], cur.mn[a], cur.edge), cur.mn[a], cur.edge,
+                                        PcvRecip{cur.inv_edge, cur.inv_edge_lo}, ENC == PCV_ENC_UINT8 ? 255.0 : 65535.0);
+    } else {
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+        code[a] = pcv_encode_coord(ENC, pcv_decode_coord(ENC, code[a], cur.mn[a], cur.edge), cur.mn[a], cur.edge,
+                                   PcvRecip{cur.inv_edge, cur.inv_edge_lo});
+    }
+#endif
+  }
+#if PCV_SETTLE_DIAG == 1
+  if (!CLIMB && code[0] != 0x7fffffffffffull) return;
+#endif
+  uint8_t* dst = o.xyz_blob + cur.xyz_off;
+  if (ENC == PCV_ENC_UINT8) {
+    uint8_t* d = dst + (uint64_t)slot * 3;
+    d[0] = (uint8_t)code[0];
+    d[1] = (uint8_t)code[1];
+    d[2] = (uint8_t)code[2];
+  } else if (ENC == PCV_ENC_UINT16) {
+    uint16_t* d = reinterpret_cast<uint16_t*>(dst) + (uint64_t)slot * 3;
+    d[0] = (uint16_t)code[0];
+    d[1] = (uint16_t)code[1];
+    d[2] = (uint16_t)code[2];
+  } else if (ENC == PCV_ENC_FLOAT32) {
+    uint32_t* d = reinterpret_cast<uint32_t*>(dst) + (uint64_t)slot * 3;
+    d[0] = (uint32_t)code[0];
+    d[1] = (uint32_t)code[1];
+    d[2] = (uint32_t)code[2];
+  } else {
+    uint64_t* d = reinterpret_cast<uint64_t*>(dst) + (uint64_t)slot * 3;
+    d[0] = code[0];
+    d[1] = code[1];
+    d[2] = code[2];
+  }
+  const uint64_t pidx = cur.point_off + slot;
+  uint8_t* cd = o.rgb_blob + pidx * 3;
+  cd[0] = (uint8_t)rgb;
+  cd[1] = (uint8_t)(rgb >> 8);
+  cd[2] = (uint8_t)(rgb >> 16);
+  if (o.inten_blob) reinterpret_cast<uint32_t*>(o.inten_blob)[pidx] = inten;
+}
+
 // One sorted slot: climb, final encode, store. CLIMB = false: the caller knows the point stays in its leaf.
 template <bool CLIMB>
 __device__ __forceinline__ void promote_one(const PcvPromoteTables& pt, uint64_t s, PcvNodeRec cur, uint4 pay,
@@ -454,57 +512,12 @@ __device__ __forceinline__ void promote_one(const PcvPromoteTables& pt, uint64_t
     j = cur.child_off + (j >> 3);
     cur = par;
   }
-  uint32_t slot = j;
-  const uint32_t enc = cur.enc;
-  if (cur.parent != 0xffffffffu) {
-    slot = j - (j >> 3) - 1u;
-#if PCV_SETTLE_DIAG != 2  // (timing experiments, tools/build_variants.sh: 2 = no re-encode, 1 = no stores; never shipped)
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-      code[a] = pcv_encode_coord(enc, pcv_decode_coord(enc, code[a], cur.mn[a], cur.edge), cur.mn[a], cur.edge, PcvRecip{cur.inv_edge, cur.inv_edge_lo});
-#endif
+  switch (cur.enc) {  // the node's encoding is wave-uniform in `settle` (one leaf per workgroup): one scalar branch
+    case PCV_ENC_UINT8: return promote_final<PCV_ENC_UINT8, CLIMB>(cur, j, code, pay.w, inten, o);
+    case PCV_ENC_UINT16: return promote_final<PCV_ENC_UINT16, CLIMB>(cur, j, code, pay.w, inten, o);
+    case PCV_ENC_FLOAT32: return promote_final<PCV_ENC_FLOAT32, CLIMB>(cur, j, code, pay.w, inten, o);
+    default: return promote_final<PCV_ENC_FLOAT64, CLIMB>(cur, j, code, pay.w, inten, o);
   }
-#if PCV_SETTLE_DIAG == 1
-  if (!CLIMB && code[0] != 0x7fffffffffffull) return;
-#endif
-  uint8_t* dst = o.xyz_blob + cur.xyz_off;
-  switch (enc) {
-    case PCV_ENC_UINT8: {
-      uint8_t* d = dst + (uint64_t)slot * 3;
-      d[0] = (uint8_t)code[0];
-      d[1] = (uint8_t)code[1];
-      d[2] = (uint8_t)code[2];
-      break;
-    }
-    case PCV_ENC_UINT16: {
-      uint16_t* d = reinterpret_cast<uint16_t*>(dst) + (uint64_t)slot * 3;
-      d[0] = (uint16_t)code[0];
-      d[1] = (uint16_t)code[1];
-      d[2] = (uint16_t)code[2];
-      break;
-    }
-    case PCV_ENC_FLOAT32: {
-      uint32_t* d = reinterpret_cast<uint32_t*>(dst) + (uint64_t)slot * 3;
-      d[0] = (uint32_t)code[0];
-      d[1] = (uint32_t)code[1];
-      d[2] = (uint32_t)code[2];
-      break;
-    }
-    default: {
-      uint64_t* d = reinterpret_cast<uint64_t*>(dst) + (uint64_t)slot * 3;
-      d[0] = code[0];
-      d[1] = code[1];
-      d[2] = code[2];
-      break;
-    }
-  }
-  const uint64_t pidx = cur.point_off + slot;
-  const uint32_t c = pay.w;
-  uint8_t* cd = o.rgb_blob + pidx * 3;
-  cd[0] = (uint8_t)c;
-  cd[1] = (uint8_t)(c >> 8);
-  cd[2] = (uint8_t)(c >> 16);
-  if (o.inten_blob) reinterpret_cast<uint32_t*>(o.inten_blob)[pidx] = inten;
 }
 
 // K6 runs as two kernels over the sorted records. Seven of eight points stay in their leaf: `settle` streams over all

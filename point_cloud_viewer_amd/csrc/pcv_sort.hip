@@ -483,8 +483,11 @@ struct RecPtrs {
 
 // kPrefetch: the next tile's keys and payloads are loaded into the registers the LDS staging just freed, so that the
 // loads are in flight while this tile drains through LDS to memory (as the keys-only kernel does).
+#ifndef PCV_REC_WAVES
+#define PCV_REC_WAVES 3
+#endif
 template <bool kHasVec, bool kPrefetch = false, typename VecT = uint4, int R = kRadix>
-__global__ __launch_bounds__(kBlock, kHasVec ? 3 : 4) void downsweep_rec_kernel(const uint32_t* __restrict__ keys_in,
+__global__ __launch_bounds__(kBlock, kHasVec ? PCV_REC_WAVES : 4) void downsweep_rec_kernel(const uint32_t* __restrict__ keys_in,
                                                                   uint32_t* __restrict__ keys_out, uint64_t n,
                                                                   uint64_t chunk, int groups, int shift, int nbits,
                                                                   const uint32_t* __restrict__ offsets,
@@ -642,15 +645,22 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
         return !e || atoi(e) != 0;
       }();
       PcvProf prof(ctx, PCV_K_SORT_DOWNSWEEP_REC);
+      // (experiment, off: PCV_REC_RADIX128=1) the 128-entry digit state fits THREE workgroups of the 12-byte kernel on a CU
+      // — and makes both passes 2.3 x slower (2.49 vs 1.10 ms at 100 M): more concurrent scatter streams, not fewer, is
+      // what hurts this kernel
       static const bool narrow_state = [] {
-        const char* e = getenv("PCV_REC_RADIX128");  // 0 = always the 256-entry digit state (experiments)
-        return !e || atoi(e) != 0;
+        const char* e = getenv("PCV_REC_RADIX128");
+        return e && atoi(e) != 0;
+      }();
+      static const size_t lds_pad = [] {  // (experiment) unused dynamic LDS: fewer workgroups per CU
+        const char* e = getenv("PCV_REC_LDS_PAD");
+        return e ? (size_t)atoi(e) : (size_t)0;
       }();
       if (compact && nbits <= 7 && narrow_state)
         hipLaunchKernelGGL((downsweep_rec_kernel<true, true, uint2, 128>), dim3(g.groups), dim3(kBlock), 0, ctx->stream, (const uint32_t*)src,
                            (uint32_t*)dst, n, g.chunk, g.groups, shift, nbits, hist, totals, rp);
       else if (compact)
-        hipLaunchKernelGGL((downsweep_rec_kernel<true, true, uint2>), dim3(g.groups), dim3(kBlock), 0, ctx->stream, (const uint32_t*)src,
+        hipLaunchKernelGGL((downsweep_rec_kernel<true, true, uint2>), dim3(g.groups), dim3(kBlock), lds_pad, ctx->stream, (const uint32_t*)src,
                            (uint32_t*)dst, n, g.chunk, g.groups, shift, nbits, hist, totals, rp);
       else if (payload->vec_in && prefetch)
         hipLaunchKernelGGL((downsweep_rec_kernel<true, true>), dim3(g.groups), dim3(kBlock), 0, ctx->stream, (const uint32_t*)src,
