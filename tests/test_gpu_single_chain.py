@@ -165,3 +165,41 @@ def test_back_to_back_builds_are_identical_and_survive_interleaved_queries(ctx):
             assert tr.query_points(shapes, 1, capacity=1)["count"] < tr.num_points
     for t, _, _ in alive:
         t.free()
+
+
+_ALT_PATH_SCRIPT = r"""
+import sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import numpy as np
+import oracle_lib as O
+import point_cloud_viewer_amd as pcv
+from point_cloud_viewer_amd import synthetic
+from test_gpu_build import assert_same
+want_bytes = int(sys.argv[2])
+ctx = pcv.Context(0)
+for n, cap, res, clusters, extent, sigma, with_int, seed in ((600_000, 20_000, 0.001, 6, 200.0, (0.2, 8.0), True, 2),
+                                                              (600_000, 20_000, 0.0001, 6, 200.0, (0.2, 8.0), False, 21)):
+    x, y, z, rgb, bmin, bmax = synthetic.gaussian_clusters(n, seed=seed, num_clusters=clusters, extent=extent, sigma_range=sigma)
+    inten = (np.arange(n) % 509).astype(np.float32) * 0.5 if with_int else None
+    with O.max_points_per_node(cap):
+        want = O.build_closed(res, bmin, bmax, x, y, z, rgb, inten, threads=8)
+    t = ctx.build(res, pcv.Aabb(bmin, bmax), x, y, z, rgb, inten, max_points_per_node=cap, single_chain=True)
+    info = t.build_info()
+    assert info["single_chain"] and info["record_bytes"] == want_bytes, info
+    assert_same(t.to_dict(), want, check_intensity=with_int)
+print("alt-path ok")
+"""
+
+
+@pytest.mark.parametrize("env,record_bytes", [({"PCV_COMPACT_RECORDS": "0"}, 20), ({"PCV_SETTLE_BY_LEAF": "0"}, 12),
+                                              ({"PCV_COMPACT_RECORDS": "0", "PCV_SETTLE_BY_LEAF": "0"}, 20)])
+def test_alternative_kernels_behind_the_switches_are_byte_exact_too(env, record_bytes):
+    """The 20-byte record format (what a predicted tree of more than 2^24 nodes falls back to) and the slot-wise settle
+    kernel are selected by switches that are read once per process: run them in a child process against the oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", _ALT_PATH_SCRIPT, root, str(record_bytes)], env=dict(os.environ, **env),
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "alt-path ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
