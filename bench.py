@@ -460,7 +460,12 @@ def main():
                         "avg_launch_ms": view["avg_launch_ms"], "launches": view["launches"]}
             if insts:
                 g = insts["f64_valu_insts_per_point"] * n / (view["avg_launch_ms"] * 1e-3) / 1e9
+                # every wave64 VALU instruction (f64 or not) holds its SIMD for the same 4 clocks, so all of them compete for
+                # the one issue roof: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = the same 39.3 T lane-instructions/s
+                gv = insts["valu_insts_per_point"] * n / (view["avg_launch_ms"] * 1e-3) / 1e9
                 roofline.update({"achieved": round(g, 1), "frac": round(g / F64_VALU_PEAK_GINST, 4),
+                                 "valu_issue": {"achieved": round(gv, 1), "peak": F64_VALU_PEAK_GINST, "unit": "G VALU lane-inst/s",
+                                                "frac": round(gv / F64_VALU_PEAK_GINST, 4)},
                                  "valu_insts_per_point": insts["valu_insts_per_point"],
                                  "f64_arithmetic_insts_per_point": insts["f64_valu_insts_per_point"],
                                  "f64_arithmetic_share_of_valu": insts["f64_share"],
