@@ -299,8 +299,10 @@ def query_bench(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    # defaults: 20 timed builds after 5 untimed ones — the first builds of a process run 5-8 % slower (clocks ramp up,
+    # the pool fills), a step is 7 ms, so the whole timed region is still 0.15 s
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points", type=int, default=100_000_000, help="points per GPU")
     ap.add_argument("--resolution", type=float, default=0.001)
     ap.add_argument("--cpu-sample", type=int, default=100_000_000, help="points of the workload timed on the CPU")
