@@ -56,6 +56,23 @@ __device__ __forceinline__ double pcv_div_code(double v, PcvRecip y) { return __
 // num::clamp semantics (NaN and -0.0 pass through) — needed verbatim for the float encodings.
 __device__ __forceinline__ double pcv_clamp01(double t) { return (t < 0.0) ? 0.0 : ((t > 1.0) ? 1.0 : t); }
 
+// t = num::clamp((p - mn) / edge, 0, 1) for the float encodings, where the exact t matters down to the sign of zero.
+// Wherever x = p - mn is nonzero, finite and moderate (2^-900 <= |x| <= 2^900, tame divisor) the exact constant-divisor
+// division applies and its quotient is finite and NONZERO — and for such t num::clamp is min(max(t, 0), 1): two
+// instructions (the compiler folds them into the clamp modifier of the division's last FMA) instead of two compares
+// and four selects per coordinate. Zeros (sign!), denormals, infinities, NaN and untamed divisors take the IEEE
+// division and the literal clamp, out of line.
+__device__ __forceinline__ double pcv_unit_quotient(double p, double mn, double edge, PcvRecip inv_edge) {
+  const double x = p - mn;
+  const double ax = fabs(x);
+  if (__builtin_expect(!(ax >= 0x1p-900 && ax <= 0x1p+900) || inv_edge.hi == 0.0, 0)) {
+    double xs = x;
+    asm volatile("" : "+v"(xs));  // pins the division expansion inside this (almost never taken) branch
+    return pcv_clamp01(xs / edge);
+  }
+  return fmin(fmax(pcv_div_const<false>(x, edge, inv_edge), 0.0), 1.0);
+}
+
 // Rust `as u8/u16` after the clamp: NaN -> 0, truncation toward zero; t <= 1 so no upper saturation.
 template <bool GUARD = true>
 __device__ __forceinline__ uint32_t pcv_fix_encode(double p, double mn, double edge, PcvRecip inv_edge, double maxval) {
@@ -74,10 +91,10 @@ __device__ __forceinline__ uint64_t pcv_encode_coord(uint32_t enc, double p, dou
     case PCV_ENC_UINT8: return pcv_fix_encode<GUARD>(p, mn, edge, inv_edge, 255.0);
     case PCV_ENC_UINT16: return pcv_fix_encode<GUARD>(p, mn, edge, inv_edge, 65535.0);
     case PCV_ENC_FLOAT32: {
-      float f = (float)pcv_clamp01(pcv_div_const(p - mn, edge, inv_edge));  // round-to-nearest-even
+      float f = (float)pcv_unit_quotient(p, mn, edge, inv_edge);  // round-to-nearest-even
       return (uint64_t)__float_as_uint(f);
     }
-    default: return (uint64_t)__double_as_longlong(pcv_clamp01(pcv_div_const(p - mn, edge, inv_edge)));
+    default: return (uint64_t)__double_as_longlong(pcv_unit_quotient(p, mn, edge, inv_edge));
   }
 }
 
@@ -101,7 +118,7 @@ __device__ __forceinline__ double pcv_encode_val(double p, double mn, double edg
     t = fmin(t, 1.0);
     return trunc(maxval * t);  // Rust `as u8/u16`: truncation toward zero, exact in f64
   }
-  const double t = pcv_clamp01(pcv_div_const<true>(p - mn, edge, inv_edge));
+  const double t = pcv_unit_quotient(p, mn, edge, inv_edge);
   return ENC == PCV_ENC_FLOAT32 ? (double)(float)t : t;
 }
 template <int ENC>
