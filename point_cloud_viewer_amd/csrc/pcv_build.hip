@@ -1367,7 +1367,7 @@ static int build_begin_impl(pcv_ctx* ctx, const pcv_build_params* params, const 
   const size_t host_bytes = lo_off + (bs->deep ? (size_t)M * 8 : 0);
   bs->host_bytes = host_bytes;
   if ((rc = ctx->pinned_reserve(host_bytes * 4 + (size_t)M * 72 + (size_t)M * 2 * sizeof(PcvNodeRec) + 1024 +
-                                (bs->n / kPcvSettleTile + M + 2) * sizeof(PcvSettleItem))))
+                                (bs->n / kPcvSettleTile + bs->n / (8 * kPcvClimbTile) + 2 * (size_t)M + 4) * sizeof(PcvSettleItem))))
     return rc;
   uint8_t* hp = (uint8_t*)ctx->pinned;
   uint64_t* h_prefix = (uint64_t*)hp;
@@ -1655,8 +1655,19 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
         u_items[num_items++] = PcvSettleItem{r, (uint32_t)b, (uint32_t)std::min<uint64_t>(b + kPcvSettleTile, hi), 0u};
     }
   }
+  // ... and of the leaf-wise climb kernel: <= 256 consecutive climber records of one leaf
+  PcvSettleItem* u_citems = u_items + num_items;
+  uint32_t num_citems = 0;
+  if (by_leaf) {
+    for (uint32_t r = 0; r < num_leaves; ++r) {
+      if (u_leaf_rec[r].parent == 0xffffffffu) continue;
+      const uint64_t k8 = ceil8((uint64_t)h_hi[leaves[r]] - h_lo[leaves[r]]), base = u_climb_base[r];
+      for (uint64_t b = 0; b < k8; b += kPcvClimbTile)
+        u_citems[num_citems++] = PcvSettleItem{r, (uint32_t)(base + b), (uint32_t)(base + std::min<uint64_t>(b + kPcvClimbTile, k8)), 0u};
+    }
+  }
   const size_t walk_bytes = ((size_t)M * 8 + 255) & ~(size_t)255;
-  const size_t rec_bytes = items_off + (size_t)num_items * sizeof(PcvSettleItem);
+  const size_t rec_bytes = items_off + (size_t)(num_items + num_citems) * sizeof(PcvSettleItem);
   // the tables live in a context-owned block; with the record sort already running they go up on the side stream (the
   // copy would otherwise queue behind the sort and sit, with its hand-over, between the sort and K6)
   if ((rc = ctx->table_dev_reserve(walk_bytes + rec_bytes + 256))) return rc;
@@ -1710,7 +1721,8 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
                             wide ? s_plane[w_hi + 1] : nullptr, wide ? s_plane[w_hi + 2] : nullptr,
                             w_int >= 0 ? s_plane[w_int] : nullptr, d_climb_base, (uint32_t)num_climbers, climbers, t->d_xyz,
                             t->d_rgb, t->d_int, bs->spec_wide,
-                            by_leaf ? (const PcvSettleItem*)(d_up + walk_bytes + items_off) : nullptr, num_items);
+                            by_leaf ? (const PcvSettleItem*)(d_up + walk_bytes + items_off) : nullptr, num_items,
+                            by_leaf ? (const PcvSettleItem*)(d_up + walk_bytes + items_off) + num_items : nullptr, num_citems);
   ctx->stage_end(PCV_STAGE_PROMOTE_ENCODE);
   PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[8], st));
   PCV_HIP_CHECK(ctx, hipGetLastError());

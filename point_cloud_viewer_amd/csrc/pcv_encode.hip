@@ -667,6 +667,39 @@ __global__ __launch_bounds__(256) void promote_climb_kernel(
   promote_one<true>(pt, c.slot, rec, c.pay, h[0], h[1], h[2], c.inten, o);
 }
 
+// Leaf-wise climb: one workgroup per <= 256 consecutive climber records of ONE leaf (they are dense per leaf). Every
+// climber climbs at least once, from its leaf into the leaf's parent: both records are wave-uniform scalar loads that
+// run beside the climber loads, and that first step is straight-line code; only the every-8th climbers go on with
+// per-lane parent records.
+__global__ __launch_bounds__(256) void promote_climb_leaf_kernel(PcvPromoteTables pt, const PcvSettleItem* __restrict__ items,
+                                                                  const PcvClimber* __restrict__ climbers,
+                                                                  const uint32_t* __restrict__ cx_hi,
+                                                                  const uint32_t* __restrict__ cy_hi,
+                                                                  const uint32_t* __restrict__ cz_hi, PromoteOut o) {
+  const PcvSettleItem it = items[blockIdx.x];
+  const uint32_t k = it.begin + threadIdx.x;
+  const bool live = k < it.end;
+  const PcvClimber c = climbers[live ? k : it.begin];
+  uint32_t h[3] = {0, 0, 0};
+  if (cx_hi) {
+    h[0] = cx_hi[c.slot];
+    h[1] = cy_hi[c.slot];
+    h[2] = cz_hi[c.slot];
+  }
+  const PcvNodeRec leaf = pt.leaf_rec[it.rank];
+  const PcvNodeRec par = pt.node_rec[leaf.parent];  // a leaf with climbers is not the root
+  if (!live) return;
+  uint64_t code[3] = {c.pay.x | ((uint64_t)h[0] << 32), c.pay.y | ((uint64_t)h[1] << 32), c.pay.z | ((uint64_t)h[2] << 32)};
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const double q = pcv_decode_coord(leaf.enc, code[a], leaf.mn[a], leaf.edge);
+    code[a] = pcv_encode_coord(par.enc, q, par.mn[a], par.edge, PcvRecip{par.inv_edge, par.inv_edge_lo});
+  }
+  const uint32_t j = leaf.child_off + ((c.slot - leaf.lo) >> 3);  // position in the parent's stream
+  promote_one<true>(pt, (uint64_t)par.lo + j, par, make_uint4((uint32_t)code[0], (uint32_t)code[1], (uint32_t)code[2], c.pay.w),
+                    (uint32_t)(code[0] >> 32), (uint32_t)(code[1] >> 32), (uint32_t)(code[2] >> 32), c.inten, o);
+}
+
 }  // namespace
 
 void pcv_launch_leaf_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvWalkTables& wt, uint64_t n, const double* x,
@@ -760,7 +793,8 @@ void pcv_launch_promote_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvPromo
                                const uint32_t* rank, const void* payload, const uint32_t* cx_hi, const uint32_t* cy_hi,
                                const uint32_t* cz_hi, const uint32_t* inten_bits, const uint32_t* climb_base,
                                uint32_t num_climbers, void* climbers, uint8_t* xyz_blob, uint8_t* rgb_blob,
-                               uint8_t* inten_blob, const void* wide, const PcvSettleItem* items, uint32_t num_items) {
+                               uint8_t* inten_blob, const void* wide, const PcvSettleItem* items, uint32_t num_items,
+                               const PcvSettleItem* climb_items, uint32_t num_climb_items) {
   if (n == 0) return;
   PromoteOut o{xyz_blob, rgb_blob, inten_blob};
   if (items) {
@@ -789,7 +823,12 @@ void pcv_launch_promote_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvPromo
     else PCV_SETTLE(2, false);
 #undef PCV_SETTLE
   }
-  if (num_climbers) {
+  if (num_climbers && climb_items) {
+    PcvProf prof(ctx, PCV_K_PROMOTE_CLIMB);
+    if (num_climb_items)
+      hipLaunchKernelGGL(promote_climb_leaf_kernel, dim3(num_climb_items), dim3(256), 0, ctx->stream, pt, climb_items,
+                         (const PcvClimber*)climbers, cx_hi, cy_hi, cz_hi, o);
+  } else if (num_climbers) {
     PcvProf prof(ctx, PCV_K_PROMOTE_CLIMB);
     hipLaunchKernelGGL(promote_climb_kernel, dim3((num_climbers + 255) / 256), dim3(256), 0, ctx->stream, pt, num_climbers,
                        (const PcvClimber*)climbers, cx_hi, cy_hi, cz_hi, o);

@@ -376,6 +376,7 @@ struct alignas(16) PcvSettleItem {
   uint32_t rank, begin, end, pad;
 };
 constexpr uint32_t kPcvSettleTile = 512;
+constexpr uint32_t kPcvClimbTile = 256;  // the same for the climb kernel: [begin, end) are indices of one leaf's climber records
 // climb_base[leaf rank] = number of climbers (every 8th point of a non-root leaf) in the leaves before it; climbers:
 // pcv_climber_bytes(num_climbers) bytes of scratch that `settle` fills and `climb` consumes
 size_t pcv_climber_bytes(uint64_t num_climbers);
@@ -384,7 +385,8 @@ void pcv_launch_promote_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvPromo
                                const uint32_t* cy_hi, const uint32_t* cz_hi, const uint32_t* inten_bits,
                                const uint32_t* climb_base, uint32_t num_climbers, void* climbers, uint8_t* xyz_blob,
                                uint8_t* rgb_blob, uint8_t* inten_blob, const void* wide = nullptr,
-                               const PcvSettleItem* items = nullptr, uint32_t num_items = 0);
+                               const PcvSettleItem* items = nullptr, uint32_t num_items = 0,
+                               const PcvSettleItem* climb_items = nullptr, uint32_t num_climb_items = 0);
 
 struct PcvOctreeQuery;  // device-resident traversal tables (pcv_query.hip)
 
