@@ -1632,39 +1632,28 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
     for (int a = 0; a < 3; ++a) nr.mn[a] = u_node_min[3 * (size_t)i + a];
   }
   for (uint32_t r = 0; r < num_leaves; ++r) u_leaf_rec[r] = u_node_rec[leaves[r]];
-  // climbers of K6 (every 8th point of every leaf; the root is never a leaf): dense index = climb_base[leaf] + j / 8
-  uint32_t* u_climb_base = (uint32_t*)(u_leaf_rec + num_leaves);
-  uint64_t num_climbers = 0;
-  for (uint32_t r = 0; r < num_leaves; ++r) {
-    u_climb_base[r] = (uint32_t)num_climbers;
-    if (u_leaf_rec[r].parent != 0xffffffffu) num_climbers += ceil8((uint64_t)h_hi[leaves[r]] - h_lo[leaves[r]]);
-  }
-  // work list of the leaf-wise settle kernel: tiles of <= 512 consecutive slots of one leaf (PCV_SETTLE_BY_LEAF=0: the
-  // slot-wise kernel, experiments)
+  // climbers of K6 (every 8th point of every leaf; the root is never a leaf): dense index = climb_base[leaf] + j / 8,
+  // and the work lists of the leaf-wise settle / climb kernels (pcv_spec.h; PCV_SETTLE_BY_LEAF=0: the slot-wise settle
+  // kernel and the flat climb launch, experiments)
   static const bool by_leaf = [] {
     const char* e = getenv("PCV_SETTLE_BY_LEAF");
     return !e || atoi(e) != 0;
   }();
+  uint32_t* u_climb_base = (uint32_t*)(u_leaf_rec + num_leaves);
   const size_t items_off = (((size_t)(M + num_leaves) * sizeof(PcvNodeRec) + (size_t)num_leaves * 4) + 15) & ~(size_t)15;
   PcvSettleItem* u_items = (PcvSettleItem*)((uint8_t*)u_node_rec + items_off);
-  uint32_t num_items = 0;
-  if (by_leaf) {
+  uint32_t num_items = 0, num_citems = 0;
+  uint64_t num_climbers = 0;
+  {
+    std::vector<uint32_t> cnt(num_leaves);
+    std::vector<uint8_t> climbs(num_leaves);
     for (uint32_t r = 0; r < num_leaves; ++r) {
-      const uint32_t lo = h_lo[leaves[r]], hi = h_hi[leaves[r]];
-      for (uint64_t b = lo; b < hi; b += kPcvSettleTile)
-        u_items[num_items++] = PcvSettleItem{r, (uint32_t)b, (uint32_t)std::min<uint64_t>(b + kPcvSettleTile, hi), 0u};
+      cnt[r] = h_hi[leaves[r]] - h_lo[leaves[r]];
+      climbs[r] = u_leaf_rec[r].parent != 0xffffffffu;
     }
-  }
-  // ... and of the leaf-wise climb kernel: <= 256 consecutive climber records of one leaf
-  PcvSettleItem* u_citems = u_items + num_items;
-  uint32_t num_citems = 0;
-  if (by_leaf) {
-    for (uint32_t r = 0; r < num_leaves; ++r) {
-      if (u_leaf_rec[r].parent == 0xffffffffu) continue;
-      const uint64_t k8 = ceil8((uint64_t)h_hi[leaves[r]] - h_lo[leaves[r]]), base = u_climb_base[r];
-      for (uint64_t b = 0; b < k8; b += kPcvClimbTile)
-        u_citems[num_citems++] = PcvSettleItem{r, (uint32_t)(base + b), (uint32_t)(base + std::min<uint64_t>(b + kPcvClimbTile, k8)), 0u};
-    }
+    if (by_leaf) num_items = pcv_settle_items(u_leaf_lo, cnt.data(), num_leaves, u_items);
+    num_climbers = pcv_climb_layout(cnt.data(), climbs.data(), num_leaves, u_climb_base, u_items + num_items, &num_citems);
+    if (!by_leaf) num_citems = 0;
   }
   const size_t walk_bytes = ((size_t)M * 8 + 255) & ~(size_t)255;
   const size_t rec_bytes = items_off + (size_t)(num_items + num_citems) * sizeof(PcvSettleItem);

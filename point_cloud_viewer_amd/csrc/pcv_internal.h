@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/pcv_hip.h"
+#include "pcv_spec.h"
 
 #define PCV_HIP_CHECK(ctx, expr)                                                                   \
   do {                                                                                             \
@@ -369,14 +370,6 @@ struct PcvPromoteTables {
   const PcvNodeRec* leaf_rec;  // per leaf rank
   const PcvNodeRec* node_rec;  // per node index
 };
-// One workgroup of the leaf-wise `settle`: up to 512 consecutive sorted slots [begin, end) of ONE leaf. The work list is
-// built by the host with the node tables (it knows every leaf's slot range), so a workgroup gets its leaf record through
-// two scalar loads that run beside its record loads instead of behind them.
-struct alignas(16) PcvSettleItem {
-  uint32_t rank, begin, end, pad;
-};
-constexpr uint32_t kPcvSettleTile = 512;
-constexpr uint32_t kPcvClimbTile = 256;  // the same for the climb kernel: [begin, end) are indices of one leaf's climber records
 // climb_base[leaf rank] = number of climbers (every 8th point of a non-root leaf) in the leaves before it; climbers:
 // pcv_climber_bytes(num_climbers) bytes of scratch that `settle` fills and `climb` consumes
 size_t pcv_climber_bytes(uint64_t num_climbers);

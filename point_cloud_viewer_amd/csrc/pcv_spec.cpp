@@ -233,6 +233,45 @@ PcvSpecStatus pcv_spec_resolve(const PcvSpecParams& p, const PcvSpecTree& t, con
   return PCV_SPEC_OK;
 }
 
+// ---- K6 work lists ---------------------------------------------------------------------------------------------------
+uint32_t pcv_settle_items(const uint32_t* lo, const uint32_t* count, uint32_t num_leaves, PcvSettleItem* out) {
+  uint32_t n = 0;
+  for (uint32_t r = 0; r < num_leaves; ++r) {
+    const uint64_t b0 = lo[r], e = b0 + count[r];
+    for (uint64_t b = b0; b < e; b += kPcvSettleTile)
+      out[n++] = PcvSettleItem{r, (uint32_t)b, (uint32_t)std::min<uint64_t>(b + kPcvSettleTile, e), 0u};
+  }
+  return n;
+}
+
+uint64_t pcv_climb_layout(const uint32_t* count, const uint8_t* climbs, uint32_t num_leaves, uint32_t* climb_base,
+                          PcvSettleItem* out, uint32_t* num_items) {
+  uint64_t total = 0;
+  uint32_t n = 0;
+  for (uint32_t r = 0; r < num_leaves; ++r) {
+    climb_base[r] = (uint32_t)total;
+    if (!climbs[r]) continue;
+    const uint64_t k8 = ((uint64_t)count[r] + 7) / 8;
+    for (uint64_t b = 0; b < k8; b += kPcvClimbTile)
+      out[n++] = PcvSettleItem{r, (uint32_t)(total + b), (uint32_t)(total + std::min<uint64_t>(b + kPcvClimbTile, k8)), 0u};
+    total += k8;
+  }
+  *num_items = n;
+  return total;
+}
+
+// CPU test hook (tests/test_spec_cpu.py): both lists for given leaf sizes; items come back as 4 x u32 each.
+extern "C" int pcv_worklist_selftest(const uint32_t* lo, const uint32_t* count, const uint8_t* climbs, uint32_t num_leaves,
+                                     uint32_t* settle_items, uint64_t* num_settle, uint32_t* climb_base, uint32_t* climb_items,
+                                     uint64_t* num_climb, uint64_t* total_climbers) {
+  static_assert(sizeof(PcvSettleItem) == 16, "work item");
+  *num_settle = pcv_settle_items(lo, count, num_leaves, reinterpret_cast<PcvSettleItem*>(settle_items));
+  uint32_t nc = 0;
+  *total_climbers = pcv_climb_layout(count, climbs, num_leaves, climb_base, reinterpret_cast<PcvSettleItem*>(climb_items), &nc);
+  *num_climb = nc;
+  return 0;
+}
+
 // ---- CPU self-test hook (tests/test_spec_cpu.py) --------------------------------------------------------------------
 // Runs the whole host logic on given full-depth path keys (from the oracle): strided sample -> sample tree (a plain
 // CPU restatement of what the device node split produces) -> T'' -> walk every key down T'' -> exact counts -> true tree.

@@ -98,3 +98,22 @@ struct PcvTrueTree {
   int deepest_level = 0;
 };
 PcvSpecStatus pcv_spec_resolve(const PcvSpecParams& p, const PcvSpecTree& t, const uint32_t* leaf_counts, PcvTrueTree* out);
+
+// ---- K6 work lists (host) ----------------------------------------------------------------------------------------------
+// One workgroup of the leaf-wise `settle` / `climb` kernels: up to kPcvSettleTile consecutive sorted slots — resp. up to
+// kPcvClimbTile consecutive climber records — [begin, end) of ONE leaf. The host knows every leaf's slot range when it
+// builds the node tables, so a workgroup gets its leaf's record through scalar loads that run beside its record loads
+// instead of behind them.
+struct alignas(16) PcvSettleItem {
+  uint32_t rank, begin, end, pad;
+};
+constexpr uint32_t kPcvSettleTile = 512;
+constexpr uint32_t kPcvClimbTile = 256;
+// Leaves in rank order: leaf r holds the sorted slots [lo[r], lo[r] + count[r]). Writes the settle items (in slot order)
+// and returns their number (<= n / kPcvSettleTile + num_leaves).
+uint32_t pcv_settle_items(const uint32_t* lo, const uint32_t* count, uint32_t num_leaves, PcvSettleItem* out);
+// Climbers: every 8th point (j % 8 == 0) of a leaf whose node is not the root (climbs[r] != 0) — ceil(count / 8) records,
+// dense from climb_base[r] (filled here: exclusive prefix sum in rank order). Writes the climb items, stores their number
+// in *num_items (<= total / kPcvClimbTile + num_leaves) and returns the total number of climber records.
+uint64_t pcv_climb_layout(const uint32_t* count, const uint8_t* climbs, uint32_t num_leaves, uint32_t* climb_base,
+                          PcvSettleItem* out, uint32_t* num_items);

@@ -98,3 +98,48 @@ def test_forced_level1_split_and_duplicates():
             for c in range(8):
                 if (force >> c) & 1 and f"r{c}" in got:
                     assert any(k.startswith(f"r{c}") and len(k) == 3 for k in got)  # split although small
+
+
+def test_settle_and_climb_work_lists_partition_every_leaf_exactly_once():
+    """K6 work lists (csrc/pcv_spec.cpp pcv_settle_items / pcv_climb_layout): the leaf-wise kernels rely on every sorted slot
+    lying in exactly one settle item of its own leaf (<= 512 slots) and every climber record — every 8th point of a leaf
+    whose node is not the root (generation.rs:222-238: `i % 8 == 0`), dense per leaf from climb_base — in exactly one
+    climb item of its own leaf (<= 256 records)."""
+    lib = pcv.load_library()
+    f = lib.pcv_worklist_selftest
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p] * 5 + [C.c_void_p] + [C.c_void_p] * 4
+    rng = np.random.default_rng(5)
+    special = [0, 1, 7, 8, 9, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 2047, 2048, 2049, 100_000, 100_003]
+    count = np.array(special + list(rng.integers(0, 5000, 300)) + list(rng.integers(0, 200_000, 40)), dtype=np.uint32)
+    rng.shuffle(count)
+    nl = count.size
+    lo = np.concatenate([[0], np.cumsum(count.astype(np.uint64))[:-1]]).astype(np.uint32)
+    climbs = (rng.random(nl) < 0.9).astype(np.uint8)
+    n = int(count.astype(np.uint64).sum())
+    settle = np.zeros((n // 512 + nl + 1, 4), dtype=np.uint32)
+    climb = np.zeros((n // 8 // 256 + nl + 1, 4), dtype=np.uint32)
+    base = np.zeros(nl, dtype=np.uint32)
+    ns, nc, total = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    assert f(lo.ctypes.data, count.ctypes.data, climbs.ctypes.data, nl, settle.ctypes.data, C.byref(ns), base.ctypes.data,
+             climb.ctypes.data, C.byref(nc), C.byref(total)) == 0
+    settle, climb = settle[:ns.value], climb[:nc.value]
+    # settle: in slot order, back to back, one leaf each, <= 512 slots, nothing for empty leaves
+    assert ns.value == int(np.sum((count.astype(np.int64) + 511) // 512))
+    assert np.all(settle[:, 2] > settle[:, 1]) and np.all(settle[:, 2] - settle[:, 1] <= 512)
+    nz = np.flatnonzero(count)
+    assert settle[0, 1] == lo[nz[0]] and settle[-1, 2] == n and np.all(settle[1:, 1] == settle[:-1, 2])
+    r = settle[:, 0]
+    assert np.all(settle[:, 1] >= lo[r]) and np.all(settle[:, 2].astype(np.uint64) <= lo[r].astype(np.uint64) + count[r])
+    # climbers: ceil(count / 8) per climbing leaf, dense in rank order
+    k8 = np.where(climbs != 0, (count.astype(np.int64) + 7) // 8, 0)
+    assert total.value == int(k8.sum())
+    assert np.array_equal(base.astype(np.int64), np.concatenate([[0], np.cumsum(k8)[:-1]]))
+    assert nc.value == int(np.sum((k8 + 255) // 256))
+    if nc.value:
+        rc_ = climb[:, 0]
+        assert np.all(climb[:, 2] > climb[:, 1]) and np.all(climb[:, 2] - climb[:, 1] <= 256)
+        assert climb[0, 1] == base[np.flatnonzero(k8)[0]] and climb[-1, 2] == total.value
+        assert np.all(climb[1:, 1] == climb[:-1, 2])
+        assert np.all(climb[:, 1] >= base[rc_]) and np.all(climb[:, 2].astype(np.int64) <= base[rc_].astype(np.int64) + k8[rc_])
+        assert np.all(climbs[rc_] != 0)
