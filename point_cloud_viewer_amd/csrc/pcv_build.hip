@@ -1478,7 +1478,6 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
     }
   } done{t};
   PcvScratch& sc = bs->sc;
-  DevPoints& d = bs->d;
   PcvLevels& lv = bs->lv;
   const uint64_t n = bs->n;
   const uint32_t M = bs->M;
@@ -1486,7 +1485,6 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
 
   uint64_t* keys_a = bs->keys_a;
   uint64_t* keys_b = bs->keys_b;
-  void* sort_scratch = bs->sort_scratch;
   std::vector<uint64_t>& pre = bs->pre;
   double bmin[3] = {t->bbox_min[0], t->bbox_min[1], t->bbox_min[2]};
   uint8_t* hp = (uint8_t*)ctx->pinned;
