@@ -7,13 +7,18 @@ the finished node table and node-contiguous .xyz/.rgb bytes in HBM. Inputs are r
 starts; nothing is read back except the node table.
 
 Workload at N=1: BASELINE config 2 — 100 M synthetic Gaussian-cluster points (64 clusters in a 1000 m cube,
-sigma in [1, 20] m), f64 SoA xyz + u8 rgb, resolution 1 mm. With --gpus N>1 every rank owns 100 M points of a
-N x 100 M cloud (weak scaling); points are routed to their owner with ONE all-to-all
-(point_cloud_viewer_amd/distributed.py) and each rank builds its subtrees.
+sigma in [1, 20] m), f64 SoA xyz + u8 rgb, resolution 1 mm; after the timed region the closed-form CPU oracle builds
+the same cloud and every node of one more GPU build is compared with it byte for byte (`parity`).
+With --gpus N>1: BASELINE config 3 — ONE cloud of 1 B points of the same distribution (seed 2), rank r holds the
+contiguous slice [r, r + 1) * 1e9 / N of it (strong scaling; --points P gives every rank P points instead), points are
+routed to their owner with ONE all-to-all (point_cloud_viewer_amd/distributed.py) and each rank builds its subtrees.
+--virtual-ranks V runs that same path with V thread-ranks on ONE GPU (tests/thread_dist.py stands in for
+torch.distributed) and compares the merged octree with a single-GPU build of the whole cloud (and, with --verify, with
+the CPU oracle): the config-3 dress rehearsal for boxes with one GPU.
 
-Other modes (never the driver's default): --verify adds a byte-for-byte parity record against the CPU oracle on the
-same cloud; --ecef is BASELINE config 5; --query is BASELINE config 4 (frustum path) with relation parity;
---config1 is BASELINE config 1 (CPU plumbing line, no GPU work timed).
+Other modes (never the driver's default): --verify forces the oracle comparison wherever it is off by default
+(sharded path, --ecef ...); --ecef is BASELINE config 5; --query is BASELINE config 4 (frustum path) with parity of all
+frusta; --config1 is BASELINE config 1 (CPU plumbing line, no GPU work timed).
 
 Prints ONE JSON line on rank 0.
 """
@@ -29,7 +34,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 F64_VALU_PEAK_GINST = 39300  # vector FP64 78.6 TFLOP/s = 39.3 T FMA-instructions/s (SURVEY 8d "Roofline bound")
-ROUND = "r02"
+ROUND = "r03"
 
 # algorithmic HBM bytes per point and launch (DESIGN.md "Kernels"); kernels bound by f64 VALU issue are marked
 ALGO_BYTES = {
@@ -46,7 +51,7 @@ ALGO_BYTES = {
     "spec_encode_kernel": 24.0 + 3.0 + 20.0,  # single-chain pass: read xyz + rgb, write rank + 16-byte payload (+ kept codes of ~10 %)
     "rank_hist_kernel": 4.0,        # read ranks
     "spec_finalize_kernel": 8.0,    # rank read + write (+ payload patch of the points that take their kept codes)
-    "upsweep_map_kernel": 8.0,      # the same fused into the record sort's first histogram pass
+    "upsweep_map_kernel": 8.0,      # rank read + mapped rank written back (+ the rare replay marks)
 }
 VALU_F64_BOUND = ("leaf_encode_kernel", "chain_keys_kernel", "spec_encode_kernel")
 
@@ -81,31 +86,133 @@ def make_cloud(torch, n, seed, device, clusters=64, extent=1000.0, sigma=(1.0, 2
     return x, y, z, rgb
 
 
-def tree_digests(tree):
+CLOUD_BLOCK = 1 << 22  # config-3 cloud: generated in blocks of 4 M points, block b from seed (seed, b)
+
+
+def make_cloud_slice(torch, total, start, count, seed, device, clusters=64, extent=1000.0, sigma=(1.0, 20.0)):
+    """Points [start, start + count) of the config-3 cloud of `total` points: the same 64 Gaussian clusters as config 2,
+    generated block-wise (block b of CLOUD_BLOCK points from its own generator seed), so that any rank can produce any
+    slice of the ONE global cloud without producing the rest; rgb = hash of the global point index."""
+    import numpy as np
+    rng = np.random.Generator(np.random.PCG64(12345))
+    centres = torch.tensor(rng.uniform(0.0, extent, (clusters, 3)), dtype=torch.float64, device=device)
+    sigmas = torch.tensor(rng.uniform(sigma[0], sigma[1], clusters), dtype=torch.float64, device=device)
+    x = torch.empty(count, dtype=torch.float64, device=device)
+    y = torch.empty_like(x)
+    z = torch.empty_like(x)
+    rgb = torch.empty((count, 3), dtype=torch.uint8, device=device)
+    end = min(start + count, total)
+    g = torch.Generator(device=device)
+    b = start // CLOUD_BLOCK
+    while b * CLOUD_BLOCK < end:
+        b0 = b * CLOUD_BLOCK
+        m = min(CLOUD_BLOCK, total - b0)
+        g.manual_seed(seed * 1_000_003 + b)
+        which = torch.randint(0, clusters, (m,), generator=g, device=device)
+        p = torch.randn((m, 3), generator=g, dtype=torch.float64, device=device) * sigmas[which, None] + centres[which]
+        lo, hi = max(start, b0), min(end, b0 + m)  # the part of this block inside the slice
+        dst = slice(lo - start, hi - start)
+        src = slice(lo - b0, hi - b0)
+        x[dst], y[dst], z[dst] = p[src, 0], p[src, 1], p[src, 2]
+        h = (torch.arange(lo, hi, device=device, dtype=torch.int64) * 2654435761) & 0xFFFFFF
+        rgb[dst, 0], rgb[dst, 1], rgb[dst, 2] = (h >> 16) & 255, (h >> 8) & 255, h & 255
+        del p, which, h
+        b += 1
+    torch.cuda.synchronize(device)
+    return x, y, z, rgb
+
+
+def build_hash():
+    """sha256 (16 hex digits) over the sources libpcv_hip.so is built from: what ties a rocprofv3 profile under
+    profiles/ to the library that is running (tools/make_bench_profile_json.py stamps the same value)."""
+    import hashlib
+    d = os.path.join(ROOT, "point_cloud_viewer_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp")) or name == "Makefile":
+            h.update(name.encode())
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def _digest(ptr, length):
+    """blake2b-128 of `length` bytes at address `ptr` (no copy)."""
+    import ctypes as C
+    import hashlib
+    if not length:
+        return hashlib.blake2b(b"", digest_size=16).hexdigest()
+    return hashlib.blake2b((C.c_uint8 * length).from_address(ptr), digest_size=16).hexdigest()
+
+
+def tree_digests(tree, min_level=0):
     """{node name: (num_points, encoding, digest xyz, digest rgb, digest intensity)} of a built octree (host blobs)."""
     import ctypes as C
     import point_cloud_viewer_amd as pcv
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_lib as O
     out = {}
     for i in range(tree.num_nodes):
         nd = tree.node(i)
+        if nd.level < min_level:
+            continue
         dig = []
         for which in range(3):
             ptr, ln = C.c_void_p(), C.c_uint64()
             tree.ctx._check(tree.lib.pcv_octree_node_data(tree.handle, i, which, C.byref(ptr), C.byref(ln)))
-            dig.append(O.node_digest(ptr.value or 0, ln.value))
+            dig.append(_digest(ptr.value or 0, ln.value))
         out[pcv.node_name(nd.id_high, nd.id_low)] = (nd.num_points, nd.encoding, dig[0], dig[1], dig[2])
     return out
+
+
+def sharded_digests(result):
+    """This rank's share of a sharded build in the same shape: its subtrees (level >= 2); the finished root / level-1
+    nodes (every rank holds them after the top all-reduce) are added by rank 0 only."""
+    import hashlib
+    out = tree_digests(result.local, min_level=2)
+    if result.builder.rank == 0:
+        for name, nd in result.top_dict().items():
+            out[name] = (nd["num_points"], nd["encoding"]) + tuple(
+                hashlib.blake2b(nd[k], digest_size=16).hexdigest() for k in ("xyz", "rgb", "intensity"))
+    return out
+
+
+def digest_of_digests(digests):
+    """One hash over a digest table (order-independent): equal iff the two octrees are byte-identical."""
+    import hashlib
+    h = hashlib.blake2b(digest_size=16)
+    for name in sorted(digests):
+        h.update(repr((name, digests[name])).encode())
+    return h.hexdigest()
+
+
+def compare_digests(want, got):
+    missing = sorted(set(want) - set(got))
+    extra = sorted(set(got) - set(want))
+    bad = sorted(k for k in set(want) & set(got) if want[k] != got[k])
+    return {"nodes": len(want), "nodes_gpu": len(got), "missing_nodes": len(missing), "extra_nodes": len(extra),
+            "mismatching_nodes": len(bad), "first_mismatches": (missing + extra + bad)[:5],
+            "ok": not missing and not extra and not bad}
+
+
+def oracle_digests(resolution, bmin, bmax, x, y, z, rgb, threads=None):
+    """Closed-form CPU oracle on the same cloud (host copies of the device tensors): digest table + stats."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    hx, hy, hz, hrgb = x.cpu().numpy(), y.cpu().numpy(), z.cpu().numpy(), rgb.cpu().numpy()
+    cores = threads or O.num_procs()
+    t0 = time.perf_counter()
+    want, stats = O.build_closed_digests(resolution, bmin, bmax, hx, hy, hz, hrgb, threads=cores)
+    stats = dict(stats, oracle_s=round(time.perf_counter() - t0, 2), oracle_threads=cores)
+    import numpy as np
+    n = int(x.numel())
+    stats["bbox_equals_numpy_minmax"] = bool(n == 0 or (np.array_equal(bmin, [hx.min(), hy.min(), hz.min()]) and
+                                                        np.array_equal(bmax, [hx.max(), hy.max(), hz.max()])))
+    return want, stats
 
 
 def verify_build(ctx, resolution, x, y, z, rgb, threads=None):
     """Byte-for-byte parity of one more build against the closed-form CPU oracle on the SAME cloud: node ids, point
     counts, encodings and a digest of every node file (reference bar: point_cloud_test/tests/main.rs:10-23 sum of
     num_points == N, src/octree/generation.rs:289-403 for the bytes)."""
-    import numpy as np
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_lib as O
     n = int(x.numel())
     t0 = time.perf_counter()
     tree = ctx.build(resolution, None, x, y, z, rgb)
@@ -114,24 +221,18 @@ def verify_build(ctx, resolution, x, y, z, rgb, threads=None):
     info = tree.build_info()
     tree.free()
     t1 = time.perf_counter()
-    hx, hy, hz, hrgb = x.cpu().numpy(), y.cpu().numpy(), z.cpu().numpy(), rgb.cpu().numpy()
-    bbox_exact = bool(n == 0 or (np.array_equal(meta["bbox_min"], [hx.min(), hy.min(), hz.min()]) and
-                                 np.array_equal(meta["bbox_max"], [hx.max(), hy.max(), hz.max()])))
-    cores = threads or O.num_procs()
-    want, stats = O.build_closed_digests(resolution, meta["bbox_min"], meta["bbox_max"], hx, hy, hz, hrgb, threads=cores)
-    t2 = time.perf_counter()
-    missing = sorted(set(want) - set(got))
-    extra = sorted(set(got) - set(want))
-    bad = sorted(k for k in set(want) & set(got) if want[k] != got[k])
-    return {"oracle": "closed-form CPU restatement of the reference (oracle/pcv_oracle_build.cpp), not the Rust binary",
-            "points": n, "nodes": len(want), "nodes_gpu": len(got), "missing_nodes": len(missing), "extra_nodes": len(extra),
-            "mismatching_nodes": len(bad), "first_mismatches": (missing + extra + bad)[:5],
-            "sum_num_points_gpu": int(sum(v[0] for v in got.values())), "sum_num_points_oracle": stats["total_points"],
-            "bbox_equals_numpy_minmax": bbox_exact, "max_abs_position_error_m": stats["max_abs_position_error"],
-            "compared": "num_points, encoding, blake2b-128 of .xyz and .rgb of every node",
-            "key_levels": info.get("key_levels"), "attempts": info.get("attempts"),
-            "gpu_build_plus_d2h_s": round(t1 - t0, 2), "oracle_s": round(t2 - t1, 2), "oracle_threads": cores,
-            "ok": not missing and not extra and not bad and bbox_exact}
+    want, stats = oracle_digests(resolution, meta["bbox_min"], meta["bbox_max"], x, y, z, rgb, threads)
+    out = {"oracle": "closed-form CPU restatement of the reference (oracle/pcv_oracle_build.cpp), not the Rust binary", "points": n}
+    out.update(compare_digests(want, got))
+    out.update({"sum_num_points_gpu": int(sum(v[0] for v in got.values())), "sum_num_points_oracle": stats["total_points"],
+                "bbox_equals_numpy_minmax": stats["bbox_equals_numpy_minmax"],
+                "max_abs_position_error_m": stats["max_abs_position_error"],
+                "compared": "num_points, encoding, blake2b-128 of .xyz and .rgb of every node",
+                "tree_digest": digest_of_digests(got),
+                "key_levels": info.get("key_levels"), "attempts": info.get("attempts"),
+                "gpu_build_plus_d2h_s": round(t1 - t0, 2), "oracle_s": stats["oracle_s"], "oracle_threads": stats["oracle_threads"]})
+    out["ok"] = bool(out["ok"] and stats["bbox_equals_numpy_minmax"])
+    return out
 
 
 def config1(args):
@@ -187,7 +288,8 @@ def config1(args):
 
 def query_bench(args):
     """BASELINE config 4: octree of the config-2 cloud, F random camera frusta — node relations (K7), visible-node
-    traversal (K7b), batched point query (K8) — with parity of the first --verify-frusta frusta against the oracle."""
+    traversal (K7b), batched point query (K8) — with parity of the first --verify-frusta frusta (default: all) and of the
+    points of the --verify-cull-frusta culled frusta against the oracle."""
     import numpy as np
     import torch
     import point_cloud_viewer_amd as pcv
@@ -233,8 +335,10 @@ def query_bench(args):
 
     ctx.reset_kernel_stats()
     kept = 0
+    kept_each = []
     for f in range(args.cull_frusta):
-        kept += tree.query_points(shapes, f, capacity=1 << 22)["count"]
+        kept_each.append(tree.query_points(shapes, f, capacity=1 << 22)["count"])
+        kept += kept_each[-1]
     st = ctx.kernel_stats()
     q_ms = st["cull_points_kernel"][1] + st["query_compact_kernel"][1] + st["nodes_in_location_kernel"][1]
     q_split = {k.replace("_kernel", ""): round(st[k][1], 3) for k in ("cull_points_kernel", "query_compact_kernel",
@@ -269,6 +373,33 @@ def query_bench(args):
         got = None if status[f] != 0 else [names[int(i)] for i in vis[f]]
         vis_bad += int(want != got)
     cpu_b = time.perf_counter() - t0
+    # K8 parity (reference bar point_cloud_test/tests/main.rs:104-127): the points pcv_query_points returns for each of
+    # the culled frusta == for node in nodes_in_location: decode, contains, retain — positions, colours and order
+    pts_bad = cnt_bad = 0
+    pts_checked = 0
+    index_of = {nm: i for i, nm in enumerate(names)}
+    t0 = time.perf_counter()
+    for f in range(min(args.cull_frusta, args.verify_cull_frusta)):
+        got = tree.query_points(shapes, f, capacity=max(kept_each[f], 1))
+        wx, wy, wz, wc = [], [], [], []
+        for nm in O.nodes_in_location(bmin, bmax, nodes, O.SHAPE_FRUSTUM, mats[f]):
+            i = index_of[nm]
+            nd = tree.node(i)
+            if nd.num_points == 0:
+                continue
+            px, py, pz = O.decode_positions(nd.encoding, nd.cube_min, nd.cube_edge, tree.node_data(i, 0))
+            keep = O.cull_points(O.SHAPE_FRUSTUM, mats[f], px, py, pz).astype(bool)
+            wx.append(px[keep]), wy.append(py[keep]), wz.append(pz[keep])
+            wc.append(np.frombuffer(tree.node_data(i, 1), dtype=np.uint8).reshape(-1, 3)[keep])
+        cat = lambda parts, dt: np.concatenate(parts) if parts else np.zeros(0, dtype=dt)
+        ex, ey, ez, ec = cat(wx, np.float64), cat(wy, np.float64), cat(wz, np.float64), cat(wc, np.uint8).reshape(-1, 3)
+        pts_checked += int(ex.size)
+        if got["count"] != ex.size:
+            cnt_bad += 1
+        elif not (np.array_equal(got["x"], ex) and np.array_equal(got["y"], ey) and np.array_equal(got["z"], ez) and
+                  np.array_equal(got["rgb"].reshape(-1, 3), ec)):
+            pts_bad += 1
+    cpu_c = time.perf_counter() - t0
     return {"metric": "frustum-cull node pairs/sec", "value": round(pairs / (cull_ms * 1e-3) / 1e6, 1), "unit": "Mpairs/s",
             "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(cull_ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -290,10 +421,115 @@ def query_bench(args):
                                  "point out; avg_launch_ms = query_chunks_kernel (descriptors) + query_flags_kernel, HIP events"},
             "parity": {"oracle": "CPU restatement (oracle/pcv_oracle_query.cpp), not the Rust binary", "frusta_checked": V,
                        "pairs_checked": V * M, "relation_mismatches": rel_bad, "size_on_screen_mismatches": size_bad,
-                       "visible_list_mismatches": vis_bad, "ok": rel_bad == 0 and size_bad == 0 and vis_bad == 0},
+                       "visible_list_mismatches": vis_bad,
+                       "query_points_frusta_checked": min(args.cull_frusta, args.verify_cull_frusta),
+                       "query_points_points_checked": pts_checked, "query_points_count_mismatches": cnt_bad,
+                       "query_points_content_mismatches": pts_bad, "query_points_check_s": round(cpu_c, 1),
+                       "ok": rel_bad == 0 and size_bad == 0 and vis_bad == 0 and cnt_bad == 0 and pts_bad == 0},
             "cpu_baseline": {"value": round(V * M / cpu_a / 1e6, 3), "unit": "Mpairs/s", "cores": 1, "kind": "port",
                              "sample": f"first {V} frusta x {M} nodes, SAT relation + size on screen, {cpu_a:.1f} s; "
                                        f"get_visible_nodes: {V / cpu_b:.1f} frusta/s"}}
+
+
+def run_virtual_ranks(args, torch, pcv, dev):
+    """BASELINE config 3 on ONE GPU: V thread-ranks (tests/thread_dist.py in place of torch.distributed — RCCL refuses
+    two ranks on one device), each with its own context and stream, rank r holding slice r of ONE cloud; the real
+    ShardedOctreeBuilder / HipBackend in every shard mode asked for. The merged octree (every rank's subtrees + the
+    all-reduced top nodes) is compared node by node with a single-GPU build of the whole cloud and, with --verify, with
+    the closed-form CPU oracle."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from thread_dist import run_ranks
+    from point_cloud_viewer_amd import distributed as pdist
+    V = args.virtual_ranks
+    total = args.points * V if args.points else 1_000_000_000
+    x, y, z, rgb = make_cloud_slice(torch, total, 0, total, seed=args.seed3, device=dev)
+    out = {"metric": "octree-build Mpoints/sec", "unit": "Mpoints/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic"}
+    # the single-GPU build of the whole cloud: the reference the merged shards are compared with
+    ctx = pcv.Context(0)
+    t0 = time.perf_counter()
+    tree = ctx.build(args.resolution, None, x, y, z, rgb)
+    single_ms = (time.perf_counter() - t0) * 1e3
+    meta = tree.meta()
+    single = tree_digests(tree)
+    single_info = tree.build_info()
+    single_stage = tree.stage_ms()
+    tree.free()
+    ctx.close()  # its pool holds ~95 bytes per point: give it back before the ranks allocate theirs
+    oracle = None
+    if args.verify:
+        want, stats = oracle_digests(args.resolution, meta["bbox_min"], meta["bbox_max"], x, y, z, rgb)
+        oracle = dict(compare_digests(want, single), max_abs_position_error_m=stats["max_abs_position_error"],
+                      oracle_s=stats["oracle_s"], oracle_threads=stats["oracle_threads"],
+                      bbox_equals_numpy_minmax=stats["bbox_equals_numpy_minmax"])
+    modes = ["octants", "buckets"] if args.shard_mode == "both" else [args.shard_mode]
+    records = {}
+    value = ms = None
+    for mode in modes:
+        def rank_main(rank, dist, mode=mode):
+            torch.cuda.set_device(dev)
+            rctx = pcv.Context(dev.index or 0)
+            lo, hi = rank * total // V, (rank + 1) * total // V
+            sx, sy, sz, srgb = x[lo:hi], y[lo:hi], z[lo:hi], rgb[lo:hi]
+            builder = pdist.ShardedOctreeBuilder(rctx, dist, dev, shard_mode=mode)
+            bbox = builder.global_bbox(sx, sy, sz)
+            times = []
+            res = None
+            for it in range(args.warmup + args.steps):
+                if res is not None:
+                    res.free()
+                dist.barrier()
+                torch.cuda.synchronize()
+                a = time.perf_counter()
+                res = builder.build(args.resolution, bbox, sx, sy, sz, srgb)
+                torch.cuda.synchronize()
+                dist.barrier()
+                if it >= args.warmup:
+                    times.append(time.perf_counter() - a)
+            dig = sharded_digests(res)
+            info = dict(exchange=res.exchange_info(), build=res.local.build_info(), nodes_local=res.num_nodes_local,
+                        bbox=(bbox.min.tolist(), bbox.max.tolist()))
+            res.free()
+            rctx.close()
+            return dig, times, info
+
+        results = run_ranks(V, rank_main)
+        merged, dup = {}, 0
+        for dig, _, _ in results:
+            for k, v in dig.items():
+                dup += k in merged
+                merged[k] = v
+        cmp_single = compare_digests(single, merged)
+        step_s = [max(r[1][i] for r in results) for i in range(args.steps)]  # slowest rank per step
+        ms = sum(step_s) / max(len(step_s), 1) * 1e3
+        value = total / (ms * 1e-3) / 1e6
+        records[mode] = {"vs_single_gpu_build": cmp_single, "nodes_built_twice": dup,
+                         "tree_digest": digest_of_digests(merged), "ms_per_step_slowest_rank": round(ms, 3),
+                         "bbox_equals_single_gpu": results[0][2]["bbox"] == (meta["bbox_min"].tolist(), meta["bbox_max"].tolist()),
+                         "exchange_rank0": results[0][2]["exchange"],
+                         "single_chain_per_rank": [r[2]["build"].get("single_chain") for r in results],
+                         "nodes_local_per_rank": [r[2]["nodes_local"] for r in results]}
+        if oracle is not None:
+            records[mode]["vs_oracle"] = compare_digests(want, merged)
+    ok = all(r["vs_single_gpu_build"]["ok"] and r["nodes_built_twice"] == 0 and r["bbox_equals_single_gpu"] for r in records.values())
+    if oracle is not None:
+        ok = ok and oracle["ok"] and all(r["vs_oracle"]["ok"] for r in records.values())
+    out.update({"value": round(value, 2), "ms_per_step": round(ms, 3),
+                "config": {"workload": f"BASELINE config 3 dress rehearsal: ONE cloud of {total / 1e6:g} M Gaussian-cluster points "
+                                       f"(64 clusters, 1000 m cube, sigma 1-20 m, seed {args.seed3}), {V} VIRTUAL ranks (threads, one "
+                                       f"context + stream each) on ONE GPU, contiguous slices of {total // V} points, shard "
+                                       f"mode(s) {'+'.join(modes)}, resolution 1 mm; `value` is the last mode's, the ranks share "
+                                       "one device, so it is NOT a scaling number",
+                           "virtual_ranks": V, "points_total": total, "resolution": args.resolution},
+                "single_gpu_build": {"nodes": len(single), "tree_digest": digest_of_digests(single), "build_info": single_info,
+                                     "first_build_wall_ms": round(single_ms, 1), "stage_ms": {k: round(v, 3) for k, v in single_stage.items()},
+                                     "vs_oracle": oracle},
+                "shard_modes": records,
+                "parity": {"ok": bool(ok), "compared": "every node: num_points, encoding, blake2b-128 of .xyz / .rgb; merged shards vs "
+                                                        "the single-GPU build" + (" and vs the closed-form CPU oracle" if oracle else ""),
+                           "mismatching_nodes": sum(r["vs_single_gpu_build"]["mismatching_nodes"] + r["vs_single_gpu_build"]["missing_nodes"] +
+                                                    r["vs_single_gpu_build"]["extra_nodes"] for r in records.values())}})
+    return out
 
 
 def main():
@@ -303,35 +539,51 @@ def main():
     # the pool fills), a step is 7 ms, so the whole timed region is still 0.15 s
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--points", type=int, default=100_000_000, help="points per GPU")
+    ap.add_argument("--points", type=int, default=0,
+                    help="points per GPU (default: 100 M on one GPU = config 2; 1e9 / N on N GPUs = config 3)")
     ap.add_argument("--resolution", type=float, default=0.001)
     ap.add_argument("--cpu-sample", type=int, default=100_000_000, help="points of the workload timed on the CPU")
     ap.add_argument("--ecef", action="store_true",
                     help="BASELINE config 5: place the cloud at ECEF magnitudes (|p| ~ 6.4e6 m)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU code path (owner kernel, partition, exchange) even with one rank")
-    ap.add_argument("--shard-mode", choices=["buckets", "octants"], default="buckets",
-                    help="multi-GPU ownership: 64 level-2 buckets bin-packed onto ranks, or root octant c -> rank c % N")
+    ap.add_argument("--shard-mode", choices=["buckets", "octants", "both"], default="octants",
+                    help="multi-GPU ownership: root octant c -> rank c %% N (BASELINE north_star), or 64 level-2 buckets "
+                         "bin-packed onto ranks (the skew remedy); both: --virtual-ranks only")
+    ap.add_argument("--virtual-ranks", type=int, default=0,
+                    help="config 3 with V thread-ranks on ONE GPU, merged octree compared with the single-GPU build")
+    ap.add_argument("--seed3", type=int, default=2, help="seed of the config-3 cloud")
     ap.add_argument("--verify", action="store_true",
-                    help="after the timed region: one more build compared byte for byte with the CPU oracle")
+                    help="after the timed region: one more build compared byte for byte with the CPU oracle (default at N=1 "
+                         "on the plain config-2 run; this flag forces it elsewhere, incl. the sharded path)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the default oracle comparison of the N=1 run (A/B timing runs)")
+    ap.add_argument("--digest", action="store_true", help="print a digest of the built octree (no oracle): A/B runs compare it")
     ap.add_argument("--query", action="store_true", help="BASELINE config 4 (frustum path) instead of the build")
     ap.add_argument("--frusta", type=int, default=10_000)
     ap.add_argument("--cull-frusta", type=int, default=100)
-    ap.add_argument("--verify-frusta", type=int, default=1000)
+    ap.add_argument("--verify-frusta", type=int, default=10_000, help="frusta whose relations / sizes / visible lists are compared with the oracle")
+    ap.add_argument("--verify-cull-frusta", type=int, default=100, help="culled frusta whose query_points result is compared with the oracle")
     ap.add_argument("--config1", action="store_true", help="BASELINE config 1 (CPU plumbing line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-to-files end-to-end leg (N=1 only)")
-    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with HIP events")
+    ap.add_argument("--kernel-events", choices=["major", "all", "none"], default="major",
+                    help="HIP events around kernel launches inside the timed region: the kernels that pass over the whole "
+                         "cloud (default), every launch (~100 per build, costs the step a few percent), or none")
+    ap.add_argument("--no-kernel-events", action="store_true", help="same as --kernel-events none")
     ap.add_argument("--exact-pipeline", action="store_true",
                     help="force the exact two-chain pipeline (K2 keys + key sort + node split + K5) instead of the single-chain build")
     ap.add_argument("--fixed-bbox", action="store_true",
                     help="take the bounding box as an argument (K1 outside the step), as round 1 measured")
     args = ap.parse_args()
+    if args.no_kernel_events:
+        args.kernel_events = "none"
 
     if args.config1:
         print(json.dumps(config1(args)), flush=True)
         return
     if args.query:
+        if not args.points:
+            args.points = 100_000_000
         print(json.dumps(query_bench(args)), flush=True)
         return
 
@@ -348,6 +600,17 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if args.virtual_ranks:
+        out = run_virtual_ranks(args, torch, pcv, dev)
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(out), flush=True)
+        return
+    if args.shard_mode == "both":
+        raise SystemExit("--shard-mode both needs --virtual-ranks")
     dist = None
     if world > 1 or args.force_sharded:
         import torch.distributed as dist
@@ -358,12 +621,21 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    n = args.points
+    sharded = world > 1 or args.force_sharded
     offset = (-2.7e6, -4.3e6, 3.8e6) if args.ecef else (0.0, 0.0, 0.0)
-    x, y, z, rgb = make_cloud(torch, n, seed=1 + rank, device=dev, offset=offset)  # ends with a device synchronize
+    config3 = world > 1 and not args.ecef
+    if config3:
+        # BASELINE config 3: ONE cloud (1 B points unless --points gives every rank its share), rank r holds slice r
+        total = args.points * world if args.points else 1_000_000_000
+        lo, hi = rank * total // world, (rank + 1) * total // world
+        n = hi - lo
+        x, y, z, rgb = make_cloud_slice(torch, total, lo, n, seed=args.seed3, device=dev)
+    else:
+        n = args.points or 100_000_000
+        total = n * world
+        x, y, z, rgb = make_cloud(torch, n, seed=1 + rank, device=dev, offset=offset)  # ends with a device synchronize
     ctx = pcv.Context(local_rank)  # the library's own stream; torch work is ordered explicitly (wait_torch)
 
-    sharded = world > 1 or args.force_sharded
     info = {}
     if not sharded:
         bbox = None
@@ -395,11 +667,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if not args.no_kernel_events:
-        ctx.set_profiling(True)  # already during warmup, so that the event pool exists before the timed region
+    if args.kernel_events != "none":
+        ctx.set_profiling("major" if args.kernel_events == "major" else True)  # during warmup: the event pool exists before the timed region
     for _ in range(args.warmup):
         step()
-    if not args.no_kernel_events:
+    if args.kernel_events != "none":
         ctx.reset_kernel_stats()
     import gc
     gc.collect()
@@ -421,12 +693,13 @@ def main():
     ctx.set_profiling(False)
     kstats = ctx.kernel_stats()
 
-    total_points = n * world * args.steps
+    total_points = total * args.steps
     value = total_points / elapsed / 1e6  # Mpoints/s, whole job
 
     roofline, encode_sort = None, None
     timed = {k: v for k, v in kstats.items() if v[0] > 0}
-    plain = n == 100_000_000 and world == 1 and not sharded and not args.ecef
+    plain = n == 100_000_000 and world == 1 and not sharded and not args.ecef and not args.exact_pipeline
+    bhash = build_hash()
     if timed:
         # packed 12-byte records (single-chain build, build_info record_bytes == 12): u32 key + uint2 payload
         rec_b = float((info.get("build") or {}).get("record_bytes") or 20)
@@ -442,13 +715,24 @@ def main():
                     "frac": round(gbs / HBM_PEAK_GBS, 4), "avg_launch_ms": round(avg_ms, 4), "launches": launches,
                     "algorithmic_bytes_per_launch": ALGO_BYTES.get(name, 0.0) * n}
 
+        profile_state = {"matches": None}
+
         def pmc(name, key):
-            """Per-launch figure from this round's rocprofv3 PMC passes of the same command (tools/profile_bench.sh)."""
+            """Per-launch figure from this round's rocprofv3 PMC passes of the same command (tools/profile_bench.sh) — only
+            when the profile was taken from the library that is running (build_hash stamped into the file)."""
             path = os.path.join(ROOT, "profiles", f"{ROUND}_bench_100M_{key}.json")
             if not plain or not os.path.exists(path):
                 return None, None
             with open(path) as f:
-                return json.load(f).get("per_launch", {}).get(name), os.path.relpath(path, ROOT)
+                prof = json.load(f)
+            same = prof.get("build_hash") == bhash
+            profile_state["matches"] = same if profile_state["matches"] is None else (profile_state["matches"] and same)
+            if not same:
+                return None, os.path.relpath(path, ROOT) + f" (STALE: taken from build {prof.get('build_hash')}, running {bhash})"
+            per = prof.get("per_launch", {})
+            # the library's event names and the rocprof kernel names differ for two kernels
+            alias = {"promote_settle_kernel": "promote_settle_leaf_kernel", "promote_climb_kernel": "promote_climb_leaf_kernel"}
+            return per.get(name, per.get(alias.get(name, name))), os.path.relpath(path, ROOT)
 
         dom = max(timed, key=lambda k: timed[k][1])  # dominant kernel by accumulated time inside the timed region
         view = hbm_view(dom)
@@ -473,11 +757,11 @@ def main():
                                  "f64_arithmetic_share_of_valu": insts["f64_share"],
                                  "f64_pipe_share_static_isa": insts.get("f64_share_static_isa"),
                                  "source": insts_src + " (SQ_INSTS_VALU_{ADD,MUL,FMA}_F64 of a rocprofv3 --pmc pass of "
-                                                       "the same command; compares / min / max / conversions also issue "
-                                                       "on the f64 pipe and are only in the static share)"})
+                                                       "the same command and the same build; compares / min / max / conversions "
+                                                       "also issue on the f64 pipe and are only in the static share)"})
             else:
                 roofline.update({"achieved": None, "frac": None,
-                                 "source": "no SQ-counter pass of this round found (tools/profile_bench.sh)"})
+                                 "source": insts_src or "no SQ-counter pass of this round found (tools/profile_bench.sh)"})
             roofline["traffic"] = traffic
             roofline["traffic_source"] = traffic_src
             roofline["hbm_view"] = dict(view, traffic=traffic, traffic_source=traffic_src)
@@ -487,8 +771,12 @@ def main():
                 hk = max(rest, key=lambda k: rest[k][1])
                 ht, hs = pmc(hk, "traffic")
                 roofline["largest_hbm_kernel"] = dict(hbm_view(hk), bound="hbm", traffic=ht, traffic_source=hs)
+                roofline["hbm_kernels"] = {k: dict(GBps=hbm_view(k)["achieved"], frac=hbm_view(k)["frac"], avg_launch_ms=hbm_view(k)["avg_launch_ms"],
+                                                   traffic=pmc(k, "traffic")[0]) for k in rest}
         else:
             roofline = dict(view, bound="hbm", traffic=traffic, traffic_source=traffic_src)
+        roofline["build_hash"] = bhash
+        roofline["profile_matches_build"] = profile_state["matches"]
         # encode+sort figure the BASELINE metric names (stage events of the last step)
         st = info.get("stages") or {}
         binfo = info.get("build") or {}
@@ -524,9 +812,48 @@ def main():
                                              "GB/s": round(n * passes * 3 * key_bytes / (sort_ms * 1e-3) / 1e9, 1) if sort_ms else None},
                            "record_sort": record_sort}
 
+    # ---- parity: one more build compared with the CPU oracle on the same cloud (default on the plain N=1 run) ----
     parity = None
-    if args.verify and rank == 0 and not sharded:
+    tree_digest = None
+    if not sharded and rank == 0 and (args.verify or (plain and not args.no_parity)):
         parity = verify_build(ctx, args.resolution, x, y, z, rgb)
+        tree_digest = parity.get("tree_digest")
+    elif sharded and (args.verify or args.digest):
+        # sharded path: every rank hashes its subtrees, rank 0 merges them with the all-reduced top nodes; --verify:
+        # rank 0 regenerates the whole cloud (the block generator makes any slice reproducible) for the oracle
+        r = builder.build(args.resolution, bbox, x, y, z, rgb)
+        mine = sharded_digests(r)
+        r.free()
+        gathered = [None] * world if rank == 0 else None
+        dist.gather_object(mine, gathered, dst=0)
+        if rank == 0:
+            merged, dup = {}, 0
+            for part in gathered:
+                for k, v in part.items():
+                    dup += k in merged
+                    merged[k] = v
+            tree_digest = digest_of_digests(merged)
+            if args.verify:
+                if config3:
+                    wx, wy, wz, wrgb = make_cloud_slice(torch, total, 0, total, seed=args.seed3, device=dev)
+                elif world == 1:
+                    wx, wy, wz, wrgb = x, y, z, rgb
+                else:
+                    raise SystemExit("--verify on the sharded path needs the config-3 cloud (or one rank)")
+                want, stats = oracle_digests(args.resolution, bbox.min, bbox.max, wx, wy, wz, wrgb)
+                parity = {"oracle": "closed-form CPU restatement of the reference (oracle/pcv_oracle_build.cpp), not the Rust binary",
+                          "points": total, "sharded": True, "ranks": world, "nodes_built_twice": dup}
+                parity.update(compare_digests(want, merged))
+                parity.update({"bbox_equals_numpy_minmax": stats["bbox_equals_numpy_minmax"], "tree_digest": tree_digest,
+                               "max_abs_position_error_m": stats["max_abs_position_error"], "oracle_s": stats["oracle_s"],
+                               "oracle_threads": stats["oracle_threads"],
+                               "compared": "num_points, encoding, blake2b-128 of .xyz and .rgb of every node (merged over the ranks)"})
+                parity["ok"] = bool(parity["ok"] and dup == 0 and stats["bbox_equals_numpy_minmax"])
+                del wx, wy, wz, wrgb
+    elif args.digest and rank == 0:
+        t = ctx.build(args.resolution, None, x, y, z, rgb, single_chain=False if args.exact_pipeline else None)
+        tree_digest = digest_of_digests(tree_digests(t))
+        t.free()
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not sharded:
@@ -602,20 +929,29 @@ def main():
                        "(reference layout); not part of `value`"}
 
     if rank == 0:
+        if config3:
+            workload = (f"BASELINE config 3: ONE cloud of {total / 1e6:g} M Gaussian-cluster points (64 clusters, 1000 m cube, "
+                        f"sigma 1-20 m, seed {args.seed3}), rank r holds the contiguous slice r of {n} points, sharded by "
+                        f"{'root octant (top-3-bit prefix): octant c -> rank c % N' if args.shard_mode == 'octants' else '64 level-2 buckets bin-packed onto the ranks'}"
+                        ", ONE all-to-all(v) over RCCL, f64 SoA xyz + u8 rgb, resolution 1 mm, full build + LOD promotion")
+        else:
+            workload = (("BASELINE config 5 (ECEF-offset f64 input): " if args.ecef else "BASELINE config 2: ") +
+                        f"{n / 1e6:g} M Gaussian-cluster points (64 clusters, 1000 m cube, "
+                        "sigma 1-20 m), f64 SoA xyz + u8 rgb, resolution 1 mm, full build + LOD promotion")
         out = {
             "metric": "octree-build Mpoints/sec", "value": round(value, 2), "unit": "Mpoints/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": ("BASELINE config 5 (ECEF-offset f64 input): " if args.ecef else "BASELINE config 2: ") +
-                                   f"{n / 1e6:g} M Gaussian-cluster points (64 clusters, 1000 m cube, "
-                                   "sigma 1-20 m), f64 SoA xyz + u8 rgb, resolution 1 mm, full build + LOD promotion",
+            "higher_is_better": True, "scaling": "strong" if (config3 and not args.points) else "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": workload,
                        "scope": "device-resident inputs -> bounding box (K1" + (" outside the step" if args.fixed_bbox else "") +
                                 ") + node table + node-contiguous .xyz/.rgb bytes in HBM; no D2H of the blobs, no file writes",
-                       "points_per_gpu": n, "resolution": args.resolution, "nodes": info.get("nodes"),
+                       "points_per_gpu": n, "points_total": total, "resolution": args.resolution, "nodes": info.get("nodes"),
+                       "kernel_events_in_timed_region": args.kernel_events,
                        "parallelism": "1 GPU" if world == 1 else
                        f"{world} GPUs, one process each, shard mode {args.shard_mode}: one all-to-all(v) over RCCL"},
-            "roofline": roofline, "encode_sort": encode_sort, "cpu_baseline": cpu, "parity": parity, "end_to_end": e2e,
+            "roofline": roofline, "encode_sort": encode_sort, "cpu_baseline": cpu, "parity": parity, "tree_digest": tree_digest,
+            "end_to_end": e2e,
             "build_info": info.get("build"), "exchange": info.get("exchange"),
             "stage_ms": {k: round(v, 3) for k, v in (info.get("stages") or {}).items()},
             "wall_ms_each_step": per_step_ms, "gpu_ms_each_step": (info.get("gpu_ms") or [])[-args.steps:],

@@ -75,9 +75,10 @@ int pcv_ctx_signal_stream(pcv_ctx* ctx, void* stream);
 /* Release cached device/host scratch held by the context. */
 int pcv_ctx_trim(pcv_ctx* ctx);
 
-/* Optional per-launch profile: when enabled every kernel launch of this context is bracketed by HIP events on
- * the context's stream; pcv_ctx_kernel_stats returns, per kernel id (0 .. return value - 1), the kernel's name,
- * the number of launches and their summed duration since the last reset. */
+/* Optional per-launch profile: enabled = 1 brackets every kernel launch of this context with HIP events on the
+ * context's stream, enabled = 2 only the kernels that pass over the whole cloud (an event pair costs the stream a few
+ * microseconds; a build makes ~100 small launches); pcv_ctx_kernel_stats returns, per kernel id (0 .. return value - 1),
+ * the kernel's name, the number of launches and their summed duration since the last reset. */
 int pcv_ctx_set_profiling(pcv_ctx* ctx, int enabled);
 int pcv_ctx_reset_kernel_stats(pcv_ctx* ctx);
 int pcv_ctx_kernel_stats(pcv_ctx* ctx, int kernel_id, const char** name, uint64_t* launches, double* total_ms);

@@ -249,7 +249,7 @@ static_assert(sizeof(kKernelNames) / sizeof(kKernelNames[0]) == PCV_K_COUNT, "ke
 
 extern "C" int pcv_ctx_set_profiling(pcv_ctx* ctx, int enabled) {
   if (!ctx) return PCV_E_INVALID;
-  ctx->profiling = enabled != 0;
+  ctx->profiling = enabled == 2 ? 2 : (enabled != 0 ? 1 : 0);
   return PCV_OK;
 }
 extern "C" int pcv_ctx_reset_kernel_stats(pcv_ctx* ctx) {
@@ -285,7 +285,7 @@ extern "C" int pcv_ctx_create(int device, void* stream, pcv_ctx** out) {
   if (hipSetDevice(device) != hipSuccess) return PCV_E_HIP;
   pcv_ctx* c = new pcv_ctx();
   c->device = device;
-  if (hipHostMalloc((void**)&c->mailbox, 64 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) {
+  if (hipHostMalloc((void**)&c->mailbox, 128 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) {
     delete c;
     return PCV_E_OOM;
   }
@@ -860,9 +860,11 @@ static int queue_record_sort(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, const Pc
     const uint32_t nr = (uint32_t)bs->fix_ranges.size();
     uint32_t* d_ranges;
     if ((rc = sc.get(&d_ranges, (size_t)nr * 4 + 4))) return rc;
-    // staging: the pinned mailbox holds 32 ranges and nothing is in flight on it; more ranges (tiny capacities in
-    // tests) wait for the queued work and take the big block
-    uint32_t* h_ranges = (uint32_t*)ctx->mailbox;
+    // staging: the second half of the pinned mailbox block is reserved for these ranges (32 of them) — the upload is
+    // queued behind the record sort and the caller gets control back before it has run, so the slot must not be one that
+    // other entry points of the context write (they use the first half); more ranges (tiny capacities in tests) wait
+    // for the queued work and take the big block
+    uint32_t* h_ranges = (uint32_t*)(ctx->mailbox + 64);
     if (nr > 32) {
       PCV_HIP_CHECK(ctx, hipStreamSynchronize(st));
       if ((rc = ctx->pinned_spec_reserve((size_t)nr * 16 + 64))) return rc;

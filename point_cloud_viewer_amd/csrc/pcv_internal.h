@@ -107,7 +107,7 @@ struct pcv_ctx {
   PcvPool pool;
   // small pinned mailbox for scalar read-backs (counters, flags): a D2H copy into pageable memory (a stack variable)
   // makes the runtime pin pages on the fly, which now and then costs milliseconds in the middle of a build
-  uint64_t* mailbox = nullptr;  // 64 x u64
+  uint64_t* mailbox = nullptr;  // 64 x u64 for read-backs + 64 x u64 reserved for the replay ranges of a build in flight
   // pinned host staging, grown on demand
   void* pinned = nullptr;
   size_t pinned_bytes = 0;
@@ -161,8 +161,10 @@ struct pcv_ctx {
   size_t table_dev_bytes = 0;
   int table_dev_reserve(size_t bytes);
 
-  // per-launch profile: event pairs recorded on `stream`, resolved after the next stream sync
-  bool profiling = false;
+  // per-launch profile: event pairs recorded on `stream`, resolved after the next stream sync. 0 = off, 1 = every
+  // launch, 2 = the kernels that move the whole cloud only (pcv_prof_is_major): an event pair costs the stream a few
+  // microseconds, and the ~70 tiny launches of the sample phase are better read off the stage events
+  int profiling = 0;
   struct ProfPending {
     int id;
     hipEvent_t a, b;
@@ -188,13 +190,33 @@ struct pcv_ctx {
   int pinned_reserve(size_t bytes);
 };
 
+// Kernels whose launches touch every point of the cloud (profiling level 2 brackets only these).
+inline bool pcv_prof_is_major(int id) {
+  switch (id) {
+    case PCV_K_AABB:
+    case PCV_K_LEAF_ENCODE:
+    case PCV_K_PROMOTE_ENCODE:
+    case PCV_K_SORT_DOWNSWEEP_REC:
+    case PCV_K_PROMOTE_CLIMB:
+    case PCV_K_SPEC_ENCODE:
+    case PCV_K_RANK_HIST:
+    case PCV_K_SORT_UPSWEEP_MAP:
+    case PCV_K_SORT_UPSWEEP32:
+    case PCV_K_ROUTE_BUCKET:
+    case PCV_K_PARTITION_COUNT:
+    case PCV_K_PARTITION_SCATTER:
+      return true;
+    default:
+      return false;
+  }
+}
 // Brackets one kernel launch with HIP events on the ctx stream when profiling is on.
 struct PcvProf {
   pcv_ctx* ctx;
   int id;
   hipEvent_t a = nullptr;
   PcvProf(pcv_ctx* c, int kernel_id) : ctx(c), id(kernel_id) {
-    if (ctx->profiling) {
+    if (ctx->profiling == 1 || (ctx->profiling == 2 && pcv_prof_is_major(kernel_id))) {
       a = ctx->prof_event();
       (void)hipEventRecord(a, ctx->stream);
     }

@@ -175,6 +175,7 @@ static int write_nodes(pcv_octree* t, const char* directory, uint32_t min_level,
         hipEvent_t e = nullptr;  // one event per chunk index and blob, also where the blob has nothing in this chunk
         if ((bend > boff && hipMemcpyAsync(b.host + boff, b.dev + boff, bend - boff, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) ||
             hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess || hipEventRecord(e, ctx->stream) != hipSuccess) {
+          if (e) (void)hipEventDestroy(e);  // created but never pushed
           rc = ctx->fail(PCV_E_HIP, "queueing the blob download failed");
           break;
         }
@@ -262,7 +263,14 @@ static int write_nodes(pcv_octree* t, const char* directory, uint32_t min_level,
     if (hipStreamSynchronize(ctx->stream) != hipSuccess && !rc) rc = ctx->fail(PCV_E_HIP, "blob download failed");
     for (Blob& b : blobs)
       for (hipEvent_t e : b.ev) (void)hipEventDestroy(e);
-    if (!rc) t->host_valid = true;
+    if (!rc) {
+      t->host_valid = true;
+    } else {  // a failed download leaves no half-filled host blobs attached to the tree (a retry would allocate over them)
+      if (t->h_xyz.p) ctx->host_release(t->h_xyz.p);
+      if (t->h_rgb.p) ctx->host_release(t->h_rgb.p);
+      if (t->h_int.p) ctx->host_release(t->h_int.p);
+      t->h_xyz.p = t->h_rgb.p = t->h_int.p = nullptr;
+    }
   }
   ::close(dirfd);
   if (rc) return rc;
@@ -483,9 +491,21 @@ extern "C" int pcv_octree_open_dir(pcv_ctx* ctx, const char* directory, pcv_octr
   } else {
     return ctx->fail(PCV_E_INVALID, "InvalidVersion(" + std::to_string(version) + ")");
   }
-  for (const RawNode& rn : raw)
-    if ((rn.hi >> 56) > (uint64_t)PCV_MAX_LEVELS)  // 120 index bits name 40 levels (node.rs:101-111); also keeps every shift below in range
-      return ctx->fail(PCV_E_INVALID, "meta.pb: node level " + std::to_string(rn.hi >> 56) + " exceeds what a NodeId can name");
+  {
+    // meta.pb is untrusted input: the offsets derived from num_points become raw write targets when the node files are
+    // loaded (pcv_octree_load_device), so a negative count or a sum that wraps must never get that far. 2^56 bytes of
+    // blob is far beyond any device and keeps every product below (x 3 coordinates x 8 bytes + padding) inside 64 bits.
+    constexpr uint64_t kMaxBlob = 1ull << 56;
+    uint64_t total_bytes = 0;
+    for (const RawNode& rn : raw) {
+      if ((rn.hi >> 56) > (uint64_t)PCV_MAX_LEVELS)  // 120 index bits name 40 levels (node.rs:101-111); also keeps every shift below in range
+        return ctx->fail(PCV_E_INVALID, "meta.pb: node level " + std::to_string(rn.hi >> 56) + " exceeds what a NodeId can name");
+      if (rn.num_points < 0) return ctx->fail(PCV_E_INVALID, "meta.pb: negative num_points");
+      if ((uint64_t)rn.num_points > kMaxBlob / 32) return ctx->fail(PCV_E_INVALID, "meta.pb: num_points out of range");
+      total_bytes += (uint64_t)rn.num_points * 24 + 16;  // widest encoding + the 16-byte padding of a node's xyz block
+      if (total_bytes > kMaxBlob) return ctx->fail(PCV_E_INVALID, "meta.pb: the nodes' num_points add up to more than 2^56 bytes");
+    }
+  }
 
   pcv_octree* t = new pcv_octree();
   t->ctx = ctx;
@@ -579,9 +599,17 @@ int pcv_octree_load_device(pcv_octree* t) {
   if (t->num_points == 0) return PCV_OK;
   PCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   int rc;
+  auto drop_host = [&]() {  // a failed attempt leaves nothing behind: the next query starts from scratch
+    if (t->h_xyz.p) ctx->host_release(t->h_xyz.p);
+    if (t->h_rgb.p) ctx->host_release(t->h_rgb.p);
+    if (t->h_int.p) ctx->host_release(t->h_int.p);
+    t->h_xyz.p = t->h_rgb.p = t->h_int.p = nullptr;
+  };
   if ((rc = ctx->host_alloc((void**)&t->h_xyz.p, t->xyz_bytes)) || (rc = ctx->host_alloc((void**)&t->h_rgb.p, t->rgb_bytes)) ||
-      (t->int_bytes && (rc = ctx->host_alloc((void**)&t->h_int.p, t->int_bytes))))
+      (t->int_bytes && (rc = ctx->host_alloc((void**)&t->h_int.p, t->int_bytes)))) {
+    drop_host();
     return rc;
+  }
   const size_t count = t->nodes.size();
   unsigned nthreads = std::thread::hardware_concurrency();
   if (nthreads == 0) nthreads = 4;
@@ -631,20 +659,33 @@ int pcv_octree_load_device(pcv_octree* t) {
   for (unsigned k = 1; k < nthreads; ++k) pool.emplace_back(worker);
   worker();
   for (auto& th : pool) th.join();
-  if (failed.load()) return ctx->fail(PCV_E_IO, first_error);
-  void *dx = nullptr, *dr = nullptr, *di = nullptr;
-  if ((rc = ctx->dev_alloc(&dx, t->xyz_bytes))) return rc;
-  t->d_xyz = (uint8_t*)dx;
-  if ((rc = ctx->dev_alloc(&dr, t->rgb_bytes))) return rc;
-  t->d_rgb = (uint8_t*)dr;
-  if (t->int_bytes) {
-    if ((rc = ctx->dev_alloc(&di, t->int_bytes))) return rc;
-    t->d_int = (uint8_t*)di;
+  if (failed.load()) {
+    drop_host();
+    return ctx->fail(PCV_E_IO, first_error);
   }
-  PCV_HIP_CHECK(ctx, hipMemcpyAsync(t->d_xyz, t->h_xyz.p, t->xyz_bytes, hipMemcpyHostToDevice, ctx->stream));
-  PCV_HIP_CHECK(ctx, hipMemcpyAsync(t->d_rgb, t->h_rgb.p, t->rgb_bytes, hipMemcpyHostToDevice, ctx->stream));
-  if (t->int_bytes) PCV_HIP_CHECK(ctx, hipMemcpyAsync(t->d_int, t->h_int.p, t->int_bytes, hipMemcpyHostToDevice, ctx->stream));
-  PCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  // device blobs: into locals first — t->d_xyz is what "already loaded" is read off, so it is only set once every
+  // allocation and upload has succeeded
+  void *dx = nullptr, *dr = nullptr, *di = nullptr;
+  auto fail_dev = [&](int code, const char* what) {
+    if (dx) ctx->dev_free(dx);
+    if (dr) ctx->dev_free(dr);
+    if (di) ctx->dev_free(di);
+    drop_host();
+    return what ? ctx->fail(code, what) : code;
+  };
+  if ((rc = ctx->dev_alloc(&dx, t->xyz_bytes)) || (rc = ctx->dev_alloc(&dr, t->rgb_bytes)) ||
+      (t->int_bytes && (rc = ctx->dev_alloc(&di, t->int_bytes))))
+    return fail_dev(rc, nullptr);
+  if (hipMemcpyAsync(dx, t->h_xyz.p, t->xyz_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+      hipMemcpyAsync(dr, t->h_rgb.p, t->rgb_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+      (t->int_bytes && hipMemcpyAsync(di, t->h_int.p, t->int_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) ||
+      hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    (void)hipStreamSynchronize(ctx->stream);  // nothing may still be reading the pinned blocks when they go back
+    return fail_dev(PCV_E_HIP, "uploading the node files failed");
+  }
+  t->d_xyz = (uint8_t*)dx;
+  t->d_rgb = (uint8_t*)dr;
+  t->d_int = (uint8_t*)di;
   t->host_valid = true;
   return PCV_OK;
 }

@@ -59,13 +59,13 @@ struct SortGeom {
   int groups;
 };
 
-SortGeom make_geom(uint64_t n) {
+SortGeom make_geom(uint64_t n, uint64_t unit = kTileUnit) {
   SortGeom g;
   g.n = n;
-  uint64_t tiles = (n + kTileUnit - 1) / kTileUnit;
+  uint64_t tiles = (n + unit - 1) / unit;
   uint64_t tiles_per_group = (tiles + kMaxGroups - 1) / kMaxGroups;
   if (tiles_per_group == 0) tiles_per_group = 1;
-  g.chunk = tiles_per_group * kTileUnit;
+  g.chunk = tiles_per_group * unit;
   g.groups = (int)((n + g.chunk - 1) / g.chunk);
   if (g.groups < 1) g.groups = 1;
   return g;
@@ -580,6 +580,231 @@ __global__ __launch_bounds__(kBlock, kHasVec ? PCV_REC_WAVES : 4) void downsweep
   }
 }
 
+// ---- 12-byte records, generalised geometry ---------------------------------------------------------------------------
+// The same reduce-then-scan downsweep for the packed records of the single-chain build (u32 key + uint2 payload), with
+// the workgroup size, the records per lane and the digit-state size as template parameters, so that the occupancy can
+// be chosen: the 256-lane / 16-per-lane kernel above needs 235 VGPRs and 54 KB of LDS (two workgroups = 8 waves per CU).
+//   BLOCK x KPT = tile (records staged through LDS per round); R = digit values (128 for digits of <= 7 bits);
+//   WPE = waves per SIMD the register allocation is asked to admit; NT: non-temporal global stores.
+// The output phase runs in groups of four LDS reads + four stores (a scheduling barrier between the groups keeps the
+// compiler from hoisting all reads of the tile into registers), with the next tile's loads already in flight.
+template <int NW, int R>
+struct DigitStateN {
+  uint32_t whist[NW][R];
+  uint32_t digit_base[R];
+  uint32_t delta[R];
+  uint32_t wave_tot[NW];
+};
+
+template <int BLOCK, int KPT, int R, int WPE, bool NT>
+__global__ __launch_bounds__(BLOCK, WPE) void downsweep_rec12_kernel(const uint32_t* __restrict__ keys_in,
+                                                                     uint32_t* __restrict__ keys_out, uint64_t n, uint64_t chunk,
+                                                                     int groups, int shift, int nbits,
+                                                                     const uint32_t* __restrict__ offsets,
+                                                                     const uint32_t* __restrict__ totals,
+                                                                     const uint2* __restrict__ vec_in, uint2* __restrict__ vec_out) {
+  constexpr int NW = BLOCK / 64, kTile = BLOCK * KPT, RW = R / 64;
+  static_assert(BLOCK >= R && R % 64 == 0 && KPT % 8 == 0, "geometry");
+  __shared__ uint32_t skeys[kTile];
+  __shared__ uint2 svec[kTile];
+  __shared__ DigitStateN<NW, R> S;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const uint32_t mask = (1u << nbits) - 1u;
+  {  // global base of digit t for this workgroup = (keys with a smaller digit) + (same digit, earlier workgroups)
+    const uint32_t tot = t < R ? totals[t] : 0u;
+    uint32_t inc = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t v = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += v;
+    }
+    if (lane == 63 && wave < RW) S.wave_tot[wave] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+#pragma unroll
+    for (int w = 0; w < RW; ++w) woff += (w < wave) ? S.wave_tot[w] : 0u;
+    if (t < R) S.digit_base[t] = woff + inc - tot + offsets[(uint64_t)t * groups + blockIdx.x];
+    for (int k = t; k < NW * R; k += BLOCK) (&S.whist[0][0])[k] = 0;
+    __syncthreads();
+  }
+  const uint64_t begin = (uint64_t)blockIdx.x * chunk;
+  uint64_t end = begin + chunk;
+  if (end > n) end = n;
+  const uint32_t wbase = wave * 64 * KPT + lane;
+
+  uint32_t key[KPT];
+  uint2 vec[KPT];
+  auto load_tile = [&](uint64_t base, uint32_t tile_n) {
+    const uint32_t* __restrict__ kp = keys_in + base + wbase;
+    const uint2* __restrict__ vp = vec_in + base + wbase;
+    if (tile_n == (uint32_t)kTile) {  // full tile: straight-line loads off one base address each
+#pragma unroll
+      for (int i = 0; i < KPT; ++i) {
+        key[i] = kp[i * 64];
+        vec[i] = vp[i * 64];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < KPT; ++i) {
+        const bool valid = wbase + i * 64 < tile_n;
+        key[i] = valid ? kp[i * 64] : 0u;
+        vec[i] = valid ? vp[i * 64] : make_uint2(0u, 0u);
+      }
+    }
+  };
+  if (begin < end) load_tile(begin, (uint32_t)((end - begin) < (uint64_t)kTile ? (end - begin) : (uint64_t)kTile));
+  for (uint64_t base = begin; base < end; base += kTile) {
+    const uint32_t tile_n = (uint32_t)((end - base) < (uint64_t)kTile ? (end - base) : (uint64_t)kTile);
+    const bool full = tile_n == (uint32_t)kTile;
+    // rank of every record among the earlier records of the same digit inside the wave's slice (see wave_rank_all)
+    uint16_t lpos[KPT];
+#pragma unroll
+    for (int i0 = 0; i0 < KPT; i0 += 8) {
+      uint32_t pre[8], rank_in[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = i0 + j;
+        const bool valid = full || wbase + i * 64 < tile_n;
+        const uint32_t d = (key[i] >> shift) & mask;
+        uint32_t plo = 0xffffffffu, phi = 0xffffffffu;
+        if (!full) {
+          const uint64_t vm = __ballot(valid);
+          plo = (uint32_t)vm;
+          phi = (uint32_t)(vm >> 32);
+        }
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+          if (b >= 5 && b >= nbits) break;
+          int m;
+          asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(d), "n"(b));
+          const uint64_t bal = __builtin_amdgcn_ballot_w64(m != 0);
+          plo = __builtin_amdgcn_bitop3_b32(plo, (uint32_t)bal, (uint32_t)m, 0x90);
+          phi = __builtin_amdgcn_bitop3_b32(phi, (uint32_t)(bal >> 32), (uint32_t)m, 0x90);
+        }
+        rank_in[j] = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+        uint32_t* slot = &S.whist[wave][d];
+        pre[j] = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (valid && rank_in[j] == 0)
+          (void)__hip_atomic_fetch_add(slot, (uint32_t)(__popc(plo) + __popc(phi)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) lpos[i0 + j] = (uint16_t)(pre[j] + rank_in[j]);
+    }
+    // per digit: exclusive prefix over the waves + the digit's start inside the tile; global position of the digit's run
+    __syncthreads();
+    {
+      uint32_t pre[NW];
+      uint32_t acc = 0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        pre[w] = acc;
+        acc += t < R ? S.whist[w][t] : 0u;
+      }
+      uint32_t inc = acc;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += v;
+      }
+      if (lane == 63 && wave < RW) S.wave_tot[wave] = inc;
+      __syncthreads();
+      uint32_t woff = 0;
+#pragma unroll
+      for (int w = 0; w < RW; ++w) woff += (w < wave) ? S.wave_tot[w] : 0u;
+      const uint32_t start = woff + inc - acc;
+      if (t < R) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) S.whist[w][t] = start + pre[w];
+        const uint32_t gb = S.digit_base[t];
+        S.delta[t] = gb - start;
+        S.digit_base[t] = gb + acc;
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      if (full || wbase + i * 64 < tile_n) {
+        const uint32_t d = (key[i] >> shift) & mask;
+        const uint32_t p = S.whist[wave][d] + lpos[i];
+        skeys[p] = key[i];
+        svec[p] = vec[i];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);  // the loads below must not be hoisted over the LDS scatter (twice the registers)
+    {  // the key / payload registers are free: fetch the next tile while this one drains
+      const uint64_t nbase = base + kTile;
+      if (nbase < end) load_tile(nbase, (uint32_t)((end - nbase) < (uint64_t)kTile ? (end - nbase) : (uint64_t)kTile));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j0 = 0; j0 < KPT; j0 += 4) {
+      uint32_t k4[4];
+      uint2 v4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t p = (j0 + j) * BLOCK + t;
+        k4[j] = skeys[p];
+        v4[j] = svec[p];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t p = (j0 + j) * BLOCK + t;
+        if (full || p < tile_n) {
+          const uint32_t g = S.delta[(k4[j] >> shift) & mask] + p;
+          if (NT) {
+            __builtin_nontemporal_store(k4[j], keys_out + g);
+            __builtin_nontemporal_store((uint64_t)v4[j].x | ((uint64_t)v4[j].y << 32), reinterpret_cast<uint64_t*>(vec_out + g));
+          } else {
+            keys_out[g] = k4[j];
+            vec_out[g] = v4[j];
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    for (int k = t; k < NW * R; k += BLOCK) (&S.whist[0][0])[k] = 0;  // last read before the barrier above
+    __syncthreads();
+  }
+}
+
+
+// PCV_REC_VARIANT (experiments): 1 = 256 lanes x 16, three workgroups per CU where the digit state allows (<= 7-bit digits);
+// 2 = 512 x 8 (two workgroups = 16 waves per CU); 3 = 1024 x 8 (tiles of 8 192, one workgroup per CU); 4 = 512 x 16 (tiles
+// of 8 192); 5 = 256 x 16 with non-temporal stores; 6 = 512 x 8 with non-temporal stores
+static void rec12_launch(pcv_ctx* ctx, int variant, const SortGeom& g, const uint32_t* src, uint32_t* dst, uint64_t n, int shift,
+                         int nbits, const uint32_t* hist, const uint32_t* totals, const uint2* vin, uint2* vout) {
+#define PCV_REC12(B, K, R, W, NT)                                                                                              \
+  hipLaunchKernelGGL((downsweep_rec12_kernel<B, K, R, W, NT>), dim3(g.groups), dim3(B), 0, ctx->stream, src, dst, n, g.chunk, g.groups, \
+                     shift, nbits, hist, totals, vin, vout)
+  const bool narrow = nbits <= 7;
+  switch (variant) {
+    case 1:
+      if (narrow) PCV_REC12(256, 16, 128, 3, false);
+      else PCV_REC12(256, 16, 256, 3, false);
+      break;
+    case 2:
+      if (narrow) PCV_REC12(512, 8, 128, 4, false);
+      else PCV_REC12(512, 8, 256, 4, false);
+      break;
+    case 3:
+      if (narrow) PCV_REC12(1024, 8, 128, 4, false);
+      else PCV_REC12(1024, 8, 256, 4, false);
+      break;
+    case 4:
+      if (narrow) PCV_REC12(512, 16, 128, 2, false);
+      else PCV_REC12(512, 16, 256, 2, false);
+      break;
+    case 5:
+      if (narrow) PCV_REC12(256, 16, 128, 3, true);
+      else PCV_REC12(256, 16, 256, 3, true);
+      break;
+    default:
+      if (narrow) PCV_REC12(512, 8, 128, 4, true);
+      else PCV_REC12(512, 8, 256, 4, true);
+  }
+#undef PCV_REC12
+}
+
 template <typename KeyT>
 int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int end_bit, PcvSortPayload* payload,
                void* scratch, bool* result_in_a, const uint32_t* map = nullptr, const void* kept = nullptr,
@@ -590,7 +815,13 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
   const bool records = payload && (payload->vec_in || payload->nwords > 0);
   if (records && sizeof(KeyT) != 4) return ctx->fail(PCV_E_INVALID, "record sort needs 32-bit keys");
   const bool compact = records && payload->vec_in && payload->vec_bytes == 8;  // 12-byte records
-  SortGeom g = make_geom(n);
+  // geometry of the 12-byte record downsweep (experiments: PCV_REC_VARIANT, see rec12_launch)
+  static const int rec_variant = [] {
+    const char* e = getenv("PCV_REC_VARIANT");
+    return e ? atoi(e) : 0;
+  }();
+  const bool rec12 = compact && payload->nwords == 0 && rec_variant > 0;
+  SortGeom g = make_geom(n, rec12 && (rec_variant == 3 || rec_variant == 4) ? 8192 : kTileUnit);
   uint32_t* hist = (uint32_t*)scratch;
   uint32_t* totals = hist + (size_t)kRadix * kMaxGroups;
   bool in_a = true;
@@ -656,7 +887,10 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
         const char* e = getenv("PCV_REC_LDS_PAD");
         return e ? (size_t)atoi(e) : (size_t)0;
       }();
-      if (compact && nbits <= 7 && narrow_state)
+      if (rec12)
+        rec12_launch(ctx, rec_variant, g, (const uint32_t*)src, (uint32_t*)dst, n, shift, nbits, hist, totals, (const uint2*)rp.vec_in,
+                     (uint2*)rp.vec_out);
+      else if (compact && nbits <= 7 && narrow_state)
         hipLaunchKernelGGL((downsweep_rec_kernel<true, true, uint2, 128>), dim3(g.groups), dim3(kBlock), 0, ctx->stream, (const uint32_t*)src,
                            (uint32_t*)dst, n, g.chunk, g.groups, shift, nbits, hist, totals, rp);
       else if (compact)

@@ -95,8 +95,10 @@ class Context:
             pass
 
     def set_profiling(self, enabled=True):
-        """Bracket every kernel launch with HIP events on the ctx stream (see kernel_stats)."""
-        self._check(self.lib.pcv_ctx_set_profiling(self.handle, 1 if enabled else 0))
+        """Bracket kernel launches with HIP events on the ctx stream (see kernel_stats): True / 1 = every launch,
+        "major" / 2 = only the kernels that pass over the whole cloud, False / 0 = off."""
+        level = 2 if enabled in ("major", 2) else (1 if enabled else 0)
+        self._check(self.lib.pcv_ctx_set_profiling(self.handle, level))
 
     def reset_kernel_stats(self):
         self._check(self.lib.pcv_ctx_reset_kernel_stats(self.handle))

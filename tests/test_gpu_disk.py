@@ -209,6 +209,13 @@ def test_open_dir_rejects_what_the_reference_rejects(ctx, tmp_path):
     with pytest.raises(pcv.PcvError) as e:
         ctx.open_dir(tmp_path / "deep")
     assert e.value.code == pcv.PCV_E_INVALID
+    # num_points is untrusted: a negative count or counts that add up past any addressable blob would turn into raw
+    # write offsets when the node files are loaded (safe Rust cannot do that; here it must be refused at open time)
+    for tag, counts in (("neg", [-2, 7]), ("huge", [1 << 62, 5]), ("sum", [(1 << 56) // 40] * 3)):
+        _write_meta_version(tmp_path / tag, 13, bmin, bmax, 0.1, [(0, 0, counts[0], 1)] + [(1, k, c, 1) for k, c in enumerate(counts[1:])])
+        with pytest.raises(pcv.PcvError) as e:
+            ctx.open_dir(tmp_path / tag)
+        assert e.value.code == pcv.PCV_E_INVALID and "num_points" in str(e.value), tag
     # garbage
     os.makedirs(tmp_path / "junk")
     (tmp_path / "junk" / "meta.pb").write_bytes(b"\xff" * 37)

@@ -3,7 +3,7 @@
 mkdir -p gpurun_out
 T=${TAG:-ab}
 timeout 400 python -m pytest tests -m gpu -x -q > gpurun_out/${T}_gputest.log 2>&1; echo "pytest rc=$?"
-B="python bench.py --steps 10 --warmup 3 --no-e2e --no-cpu-baseline"
+B="python bench.py --steps 10 --warmup 3 --no-e2e --no-cpu-baseline --no-parity --digest"
 timeout 300 python bench.py --steps 10 --warmup 3 --no-e2e --verify > gpurun_out/${T}_bench_main.json 2> gpurun_out/${T}_bench_main.err; echo "rc=$?"
 NAMES=""
 for v in $VARIANTS; do

@@ -1,7 +1,7 @@
 # timing-only A/B in one gpurun call: RUNS="name[:ENV=VAL|lib] ..." each run = one short bench; prints the kernel table
 mkdir -p gpurun_out
 T=${TAG:-abq}
-B="python bench.py --steps ${STEPS:-10} --warmup 3 --no-e2e --no-cpu-baseline"
+B="python bench.py --steps ${STEPS:-10} --warmup 3 --no-e2e --no-cpu-baseline --no-parity --digest"
 i=0
 for v in $RUNS; do
   i=$((i+1)); name=${v%%:*}; arg=${v#*:}

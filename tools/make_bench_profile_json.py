@@ -20,10 +20,14 @@ def main():
     ap.add_argument("--tag", required=True)
     ap.add_argument("--points", type=int, default=100_000_000)
     a, _ = ap.parse_known_args()
+    sys.path.insert(0, ROOT)
+    from bench import build_hash  # the same hash bench.py recomputes: ties the profile to the library it was taken from
+    stamp = {"build_hash": build_hash(),
+             "git_head": subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None}
     with open(a.tag + "_kernel_stats_traffic.json") as f:
         tr = json.load(f)
     with open(a.tag + "_bench_traffic.json", "w") as f:
-        json.dump({"note": tr["note"], "per_launch": tr["bytes_per_launch"]}, f, indent=1)
+        json.dump(dict(stamp, note=tr["note"], per_launch=tr["bytes_per_launch"]), f, indent=1)
     mix_path = a.tag + "_isa_mix.json"
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_mix.py"), "-o", mix_path], check=False,
                    stdout=subprocess.DEVNULL)
@@ -57,9 +61,9 @@ def main():
     for v in per.values():
         v.pop("_valu")
     with open(a.tag + "_bench_valu.json", "w") as f:
-        json.dump({"note": "per launch: SQ_INSTS_VALU and SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 of one rocprofv3 --pmc pass "
-                           "(wave instructions x 64 lanes / points); f64_share_static_isa from tools/isa_mix.py",
-                   "points": a.points, "per_launch": per}, f, indent=1)
+        json.dump(dict(stamp, note="per launch: SQ_INSTS_VALU and SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 of one rocprofv3 --pmc pass "
+                                    "(wave instructions x 64 lanes / points); f64_share_static_isa from tools/isa_mix.py",
+                       points=a.points, per_launch=per), f, indent=1)
     print(json.dumps(per, indent=1)[:1500])
 
 

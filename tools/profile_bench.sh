@@ -11,7 +11,7 @@ TAG=${1:-prof}; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-e2e --no-kernel-events"
+B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-e2e --no-kernel-events --no-parity"
 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_stats -o r -- $B --steps 5 --warmup 2 "$@" > $OUT/${TAG}_stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/${TAG}_fetch -o r -- $B --steps 1 --warmup 0 "$@" > $OUT/${TAG}_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/${TAG}_write -o r -- $B --steps 1 --warmup 0 "$@" > $OUT/${TAG}_write.log 2>&1
