@@ -224,8 +224,11 @@ int pcv_octree_stage_ms(const pcv_octree* t, float* ms, int cap);
  * attempts >= 2: something was redone (single-chain prediction too shallow and/or depth estimate too shallow). */
 void pcv_octree_build_info(const pcv_octree* t, int* key_levels, int* attempts);
 /* Single-chain build statistics of the last build (zeros otherwise): nodes and leaves of the predicted tree, points
- * that took the codes kept at a candidate node, points that replayed the chain in the finalize kernel. */
+ * whose leaf is an unsplit candidate node (the codes they kept there are their leaf codes), points that replayed the
+ * chain from their coordinates. pcv_octree_spec_continued: points whose chain was continued from the codes kept at a
+ * candidate node that turned out to be split. */
 void pcv_octree_spec_stats(const pcv_octree* t, uint64_t stats[4]);
+uint64_t pcv_octree_spec_continued(const pcv_octree* t);
 /* Bytes of one record of the last build's record sort (rank + leaf codes + colour): 20, or 12 when the single-chain
  * build packed the record (16-bit codes; the points of Float32-coded leaves travel as their input index). */
 int pcv_octree_record_bytes(const pcv_octree* t);

@@ -244,7 +244,7 @@ static const char* kKernelNames[PCV_K_COUNT] = {
     "upsweep_kernel<u32>", "downsweep_kernel<u32>", "promote_settle_kernel", "downsweep_rec_kernel", "cull_nodes_kernel",
     "visible_nodes_kernel", "nodes_in_location_kernel", "cull_points_kernel", "transform_points_kernel",
     "query_compact_kernel", "route_bucket_kernel", "partition_count_kernel", "partition_scatter_kernel",
-    "promote_climb_kernel", "spec_encode_kernel", "rank_hist_kernel", "spec_finalize_kernel", "spec_replay_kernel", "upsweep_map_kernel"};
+    "promote_climb_kernel", "spec_encode_kernel", "rank_hist_kernel", "spec_continue_kernel", "spec_replay_kernel", "upsweep_map_kernel"};
 static_assert(sizeof(kKernelNames) / sizeof(kKernelNames[0]) == PCV_K_COUNT, "kernel name table out of sync");
 
 extern "C" int pcv_ctx_set_profiling(pcv_ctx* ctx, int enabled) {
@@ -615,9 +615,10 @@ struct PcvBuild {
     uint32_t lo, count, level;
   };
   std::vector<FixRange> fix_ranges;  // sorted slots whose points replay the chain after the record sort
-  const uint32_t* spec_map_dev = nullptr;  // set: the record sort's first upsweep applies the rank map / payload patch
+  const uint32_t* spec_map_dev = nullptr;  // set: the record sort's first upsweep applies the rank map
   uint32_t spec_map_entries = 0;
-  const void* spec_kept = nullptr;
+  // true leaves below a split first candidate (PcvTrueTree::cont_nodes / cont_from): their chain is continued after the sort
+  std::vector<uint32_t> cont_nodes, cont_from;
   // the record sort (queue_record_sort): buffers and where the sorted records ended up
   bool sort_queued = false, rec_in_a = true;
   void *pay_a = nullptr, *pay_b = nullptr;
@@ -673,6 +674,7 @@ extern "C" void pcv_octree_spec_stats(const pcv_octree* t, uint64_t stats[4]) {
   for (int k = 0; k < 4; ++k) stats[k] = t->spec_stats[k];
 }
 extern "C" int pcv_octree_record_bytes(const pcv_octree* t) { return t ? t->record_bytes : 0; }
+extern "C" uint64_t pcv_octree_spec_continued(const pcv_octree* t) { return t ? t->spec_continued : 0; }
 extern "C" int pcv_octree_device_blob(const pcv_octree* t, int which, const void** dptr, uint64_t* len) {
   if (!t || !dptr || !len || which < 0 || which > 2) return PCV_E_INVALID;
   *dptr = which == 0 ? t->d_xyz : (which == 1 ? t->d_rgb : t->d_int);
@@ -850,7 +852,7 @@ static int queue_record_sort(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, const Pc
   bool rec_in_a = true;
   if (bs->spec_map_dev)
     rc = pcv_radix_sort_records_mapped(ctx, rank_a, rank_b, n, rank_bits, &pl, bs->sort_scratch, bs->spec_map_dev,
-                                       bs->spec_map_entries, bs->spec_kept, &rec_in_a, bs->spec_wide, bs->wide_levels);
+                                       bs->spec_map_entries, &rec_in_a);
   else
     rc = pcv_radix_sort_u32(ctx, rank_a, rank_b, n, 0, rank_bits, &pl, bs->sort_scratch, &rec_in_a);
   if (rc) return rc;
@@ -928,7 +930,7 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
       (rc = sc.get(&d_slevel, tcap)) || (rc = sc.get(&d_info, 64)) || (rc = sc.get(&d_counts, tcap)) || (rc = sc.get(&d_map, tcap)))
     return rc;
   uint32_t* rank = (uint32_t*)bs->keys_a;
-  uint4 *payload, *kept;  // kept codes: always provided (whether any node is a candidate is only known on the device)
+  uint4* payload;
   // 12-byte records (pcv_internal.h) unless switched off (PCV_COMPACT_RECORDS=0, experiments) or the predicted tree could
   // outgrow the 24 rank bits of the key
   static const bool compact_on = [] {
@@ -944,8 +946,7 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
     uint2* p2;
     if ((rc = sc.get(&p2, n)) || (rc = sc.get(&wide, n))) return rc;
     payload = (uint4*)p2;
-    if ((rc = sc.get(&kept, n))) return rc;
-  } else if ((rc = sc.get(&payload, n)) || (rc = sc.get(&kept, n))) {
+  } else if ((rc = sc.get(&payload, n))) {
     return rc;
   }
   uint32_t* inten_bits = t->has_intensity ? (uint32_t*)bs->keys_a + n : nullptr;
@@ -1002,7 +1003,7 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
     // ---- the one chain pass (queued before the host has seen the tree) ----
     ctx->stage_begin(PCV_STAGE_LEAF_ENCODE);
     lv.nlevels = full_levels;
-    pcv_launch_spec_encode(ctx, lv, d_walk, n, d.x, d.y, d.z, d.routed, d.color, d.color_stride, d.intensity, rank, payload, kept,
+    pcv_launch_spec_encode(ctx, lv, d_walk, n, d.x, d.y, d.z, d.routed, d.color, d.color_stride, d.intensity, rank, payload,
                            inten_bits, depth_grid, wide);
     ctx->stage_end(PCV_STAGE_LEAF_ENCODE);
     host_lap("chain pass queued");
@@ -1065,8 +1066,6 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
   if (resolved != PCV_SPEC_OK) {
     sc.detach(payload);
     ctx->dev_free(payload);
-    sc.detach(kept);
-    ctx->dev_free(kept);
     if (wide) {
       sc.detach(wide);
       ctx->dev_free(wide);
@@ -1076,44 +1075,31 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
   if (tt->prefix.size() > (size_t)nt.capacity) return ctx->fail(PCV_E_OOM, "node table capacity exceeded");
   std::memcpy(hp + map_off, tt->spec_map.data(), (size_t)tree.num_leaves * 4);
   PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_map, hp + map_off, (size_t)tree.num_leaves * 4, hipMemcpyHostToDevice, st));
-  // the rank map and the payload patch are applied by the first upsweep of the record sort (one pass over the ranks
-  // instead of two); PCV_SPEC_FUSE=0 keeps the separate finalize kernel (experiments)
-  static const bool fuse = [] {
-    const char* e = getenv("PCV_SPEC_FUSE");
-    return !e || atoi(e) != 0;
-  }();
+  // the rank map is applied by the first upsweep of the record sort (one pass over the ranks instead of two)
   bs->spec_wide = wide;
   bs->wide_levels = wide_levels;
-  if (fuse || compact) {  // 12-byte records are only patched by the fused pass
-    bs->spec_map_dev = d_map;
-    bs->spec_map_entries = tree.num_leaves;
-    bs->spec_kept = kept;
-  } else {
-    pcv_launch_spec_finalize(ctx, n, d_map, rank, payload, kept);
-  }
+  bs->spec_map_dev = d_map;
+  bs->spec_map_entries = tree.num_leaves;
+  bs->cont_nodes = tt->cont_nodes;
+  bs->cont_from = tt->cont_from;
   // leaves whose points still have to replay the chain: contiguous once the records are sorted ([lo, hi) of the leaf)
   bs->fix_ranges.clear();
   for (uint32_t k : tt->fix_nodes) bs->fix_ranges.push_back({tt->lo[k], tt->hi[k] - tt->lo[k], (uint32_t)tt->level[k]});
-  // no synchronisation here: the uploads read ctx->pinned_spec, the caller stages the node table in ctx->pinned, and
-  // the pool hands `kept` out again only to work queued on this same stream
+  // no synchronisation here: the uploads read ctx->pinned_spec, the caller stages the node table in ctx->pinned
   ctx->stage_end(PCV_STAGE_NODE_SPLIT);
-  if (kept && !bs->spec_kept) {
-    sc.detach(kept);
-    ctx->dev_free(kept);
-  }
   bs->spec = true;
   bs->spec_payload = payload;
   // the record sort needs nothing but the rank map: it starts now, and every table the host still has to build (here,
-  // in the caller and in pcv_build_finish) is built while it runs. A mis-staged mailbox is the one thing to avoid:
-  // with more than 32 replay ranges the staging synchronises first.
+  // in the caller and in pcv_build_finish) is built while it runs.
   host_lap("map upload, fix ranges");
-  if ((fuse || compact) && (rc = queue_record_sort(ctx, bs, t, nullptr, tt->num_leaves, false))) return rc;
+  if ((rc = queue_record_sort(ctx, bs, t, nullptr, tt->num_leaves, false))) return rc;
   host_lap("record sort queued");
   ctx->stage_begin(PCV_STAGE_TABLE);
   t->spec_stats[0] = tree.prefix.size();
   t->spec_stats[1] = (uint64_t)std::count(tree.inner.begin(), tree.inner.end(), (uint8_t)0);
   t->spec_stats[2] = tt->kept_points;
   t->spec_stats[3] = tt->fix_points;
+  t->spec_continued = tt->cont_points;
   *used = true;
   return PCV_OK;
 }
@@ -1369,7 +1355,8 @@ static int build_begin_impl(pcv_ctx* ctx, const pcv_build_params* params, const 
   const size_t host_bytes = lo_off + (bs->deep ? (size_t)M * 8 : 0);
   bs->host_bytes = host_bytes;
   if ((rc = ctx->pinned_reserve(host_bytes * 4 + (size_t)M * 72 + (size_t)M * 2 * sizeof(PcvNodeRec) + 1024 +
-                                (bs->n / kPcvSettleTile + bs->n / (8 * kPcvClimbTile) + 2 * (size_t)M + 4) * sizeof(PcvSettleItem))))
+                                (2 * (bs->n / kPcvSettleTile) + bs->n / (8 * kPcvClimbTile) + 3 * (size_t)M + 8) * sizeof(PcvSettleItem) +
+                                (size_t)M * pcv_cont_range_bytes())))
     return rc;
   uint8_t* hp = (uint8_t*)ctx->pinned;
   uint64_t* h_prefix = (uint64_t*)hp;
@@ -1655,8 +1642,22 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
     num_climbers = pcv_climb_layout(cnt.data(), climbs.data(), num_leaves, u_climb_base, u_items + num_items, &num_citems);
     if (!by_leaf) num_citems = 0;
   }
+  // single-chain build: leaves below a split first candidate continue their chain from the candidate's codes
+  // (spec_continue_kernel): one range per leaf (levels + the candidate's cube min) and one item per <= 512 of its slots
+  const size_t cont_off = items_off + (size_t)(num_items + num_citems) * sizeof(PcvSettleItem);
+  const uint32_t num_cont = bs->spec ? (uint32_t)bs->cont_nodes.size() : 0u;
+  uint8_t* u_cont_ranges = (uint8_t*)u_node_rec + cont_off;
+  const size_t cont_items_off = cont_off + (((size_t)num_cont * pcv_cont_range_bytes() + 15) & ~(size_t)15);
+  PcvSettleItem* u_cont_items = (PcvSettleItem*)((uint8_t*)u_node_rec + cont_items_off);
+  uint32_t num_cont_items = 0;
+  for (uint32_t k = 0; k < num_cont; ++k) {
+    const uint32_t leaf = bs->cont_nodes[k], from = bs->cont_from[k];
+    pcv_fill_cont_range(u_cont_ranges + (size_t)k * pcv_cont_range_bytes(), h_level[from], h_level[leaf], u_node_min + 3 * (size_t)from);
+    for (uint64_t b = h_lo[leaf]; b < h_hi[leaf]; b += kPcvSettleTile)
+      u_cont_items[num_cont_items++] = PcvSettleItem{k, (uint32_t)b, (uint32_t)std::min<uint64_t>(b + kPcvSettleTile, h_hi[leaf]), 0u};
+  }
   const size_t walk_bytes = ((size_t)M * 8 + 255) & ~(size_t)255;
-  const size_t rec_bytes = items_off + (size_t)(num_items + num_citems) * sizeof(PcvSettleItem);
+  const size_t rec_bytes = cont_items_off + (size_t)num_cont_items * sizeof(PcvSettleItem);
   // the tables live in a context-owned block; with the record sort already running they go up on the side stream (the
   // copy would otherwise queue behind the sort and sit, with its hand-over, between the sort and K6)
   if ((rc = ctx->table_dev_reserve(walk_bytes + rec_bytes + 256))) return rc;
@@ -1706,6 +1707,9 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
     if ((rc = ctx->dev_alloc(&climbers, pcv_climber_bytes(num_climbers)))) return rc;
     sc.ptrs.push_back(climbers);
   }
+  if (num_cont_items)
+    pcv_launch_spec_continue(ctx, lv, d_up + walk_bytes + cont_off, (const PcvSettleItem*)(d_up + walk_bytes + cont_items_off), num_cont_items,
+                             (void*)s_pay, bs->spec_wide);
   pcv_launch_promote_encode(ctx, lv, pt, n, s_rank, s_pay, wide ? s_plane[w_hi] : nullptr,
                             wide ? s_plane[w_hi + 1] : nullptr, wide ? s_plane[w_hi + 2] : nullptr,
                             w_int >= 0 ? s_plane[w_int] : nullptr, d_climb_base, (uint32_t)num_climbers, climbers, t->d_xyz,

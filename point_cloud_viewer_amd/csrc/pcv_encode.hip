@@ -84,10 +84,11 @@ __global__ __launch_bounds__(256) void leaf_encode_kernel(
 
 // ---- single-chain build (pcv_spec.h): ONE chain pass down the predicted tree T'' --------------------------------------
 // Every inner node of T'' has all eight children (consecutive walk records), so a digit indexes the child directly.
-// A point passing through a candidate node (sampled count close to the capacity) keeps the codes it has AT that node
-// (the first such node on its path): if the exact counts later say the node is a leaf, those are the point's leaf
-// codes; otherwise the codes of the predicted leaf are. Output: predicted-leaf rank, payload {codes, rgb} at the
-// predicted leaf, and — only for points that passed a candidate — the kept codes + their level.
+// A point passing through a candidate node (sampled count close to the capacity) leaves this pass with the codes it has
+// AT that node (the first such node on its path) instead of those of its predicted leaf: a point's chain from level k on
+// is a function of its level-k codes alone, so if the exact counts later say the candidate is a leaf those ARE the leaf
+// codes, and if it is split the chain is continued from them (spec_continue_kernel) once the record sort has made the
+// true leaves contiguous. Output: predicted-leaf rank (the exact counts need it either way) + payload {codes, rgb}.
 //
 // Depth binning (BIN): lanes of one wave replay the chain until the DEEPEST of their 64 points reaches its leaf. In
 // input order that is 9.7 levels per wave for a mean leaf depth of 6.7 (config-2 cloud) — 45 % of the f64 work runs
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(BLOCK) void spec_encode_kernel(
     PcvLevels lv, const uint32_t* __restrict__ walk, uint64_t n, const double* __restrict__ x,
     const double* __restrict__ y, const double* __restrict__ z, PcvRouted routed, const uint8_t* __restrict__ color,
     uint32_t color_stride, const float* __restrict__ intensity, uint32_t* __restrict__ rank, uint4* __restrict__ payload,
-    uint4* __restrict__ kept, uint32_t* __restrict__ inten_bits, const uint8_t* __restrict__ depth_grid,
+    uint32_t* __restrict__ inten_bits, const uint8_t* __restrict__ depth_grid,
     float cells_per_unit /* 128 / root edge */, uint4* __restrict__ wide /* set: 12-byte records */) {
   constexpr int kWavesB = BLOCK / 64;
   __shared__ double sx[BIN ? BLOCK : 1], sy[BIN ? BLOCK : 1], sz[BIN ? BLOCK : 1];
@@ -280,13 +281,18 @@ __global__ __launch_bounds__(BLOCK) void spec_encode_kernel(
   }
 #undef PCV_SPEC_WALK
 #undef PCV_SPEC_LOOP
+  // the record carries the codes of the first candidate on the path where there is one, else those of the predicted leaf
+  if (KEEP && kl) {
+    vx = kx, vy = ky, vz = kz;
+    L = kl;
+  }
   const uint32_t leaf_enc = lv.enc[L];
   const uint8_t* c = color + i * color_stride;
   const uint32_t ccx = (uint32_t)pcv_val_to_code(leaf_enc, vx), ccy = (uint32_t)pcv_val_to_code(leaf_enc, vy),
                  ccz = (uint32_t)pcv_val_to_code(leaf_enc, vz);
   if (wide) {
     // 12-byte record: key = rank << 8 | blue, payload = {cx | cy << 16, cz | red << 16 | green << 24}. The codes of a
-    // Float32-coded leaf level do not fit: they go to the point's `wide` entry and the record carries the input index.
+    // Float32-coded level do not fit: they go to the point's `wide` entry and the record carries the input index.
     rank[i] = ((rec & PCV_SPEC_INDEX_MASK) << 8) | (uint32_t)c[2];
     const uint32_t rg = ((uint32_t)c[0] << 16) | ((uint32_t)c[1] << 24);
     if (leaf_enc <= PCV_ENC_UINT16) {
@@ -298,11 +304,6 @@ __global__ __launch_bounds__(BLOCK) void spec_encode_kernel(
   } else {
     rank[i] = rec & PCV_SPEC_INDEX_MASK;
     payload[i] = make_uint4(ccx, ccy, ccz, (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16));
-  }
-  if (KEEP && kl) {
-    const uint32_t ke = lv.enc[kl];
-    kept[i] = make_uint4((uint32_t)pcv_val_to_code(ke, kx), (uint32_t)pcv_val_to_code(ke, ky), (uint32_t)pcv_val_to_code(ke, kz),
-                         (uint32_t)kl);
   }
   if (inten_bits) inten_bits[i] = __float_as_uint(intensity[i]);
 }
@@ -342,40 +343,60 @@ __global__ __launch_bounds__(1024) void rank_hist_kernel(const uint32_t* __restr
   }
 }
 
-// After the exact counts fixed the true tree: predicted-leaf rank -> true-leaf rank, and the payload takes the kept
-// codes where the true leaf is the candidate node (bit 31 of the map). FIX: predicted leaves whose true leaf is an
-// inner node of T'' WITHOUT kept codes (a candidate below a candidate, or a count far outside the band) are flagged in
-// the map (PCV_SPEC_MAP_REPLAY): their points have no valid codes yet. They leave their input index in the payload; the record sort makes
-// the points of such a leaf contiguous, and spec_replay_kernel then replays their chain over exactly those slots —
-// dense, without lists or atomics.
-__device__ __forceinline__ uint32_t spec_finalize_one(uint64_t i, uint32_t m, uint4* __restrict__ payload,
-                                                       const uint4* __restrict__ kept) {
-  if (m & PCV_SPEC_MAP_REPLAY) {
-    reinterpret_cast<uint32_t*>(payload + i)[0] = (uint32_t)i;  // n < 2^32
-  } else if (m & PCV_SPEC_MAP_KEPT) {
-    const uint4 k = kept[i];
-    uint4 p = payload[i];
-    p.x = k.x, p.y = k.y, p.z = k.z;
-    payload[i] = p;
-  }
-  return m & PCV_SPEC_INDEX_MASK;
-}
-// four ranks per lane (one 16-byte load / store; the map lookups and the rare payload patches of all four in flight)
-__global__ __launch_bounds__(256) void spec_finalize_kernel(uint64_t n, const uint32_t* __restrict__ spec_map,
-                                                             uint32_t* __restrict__ rank, uint4* __restrict__ payload,
-                                                             const uint4* __restrict__ kept) {
-  const uint64_t i = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-  if (i >= n) return;
-  if (i + 4 <= n) {  // rank comes from the pool: 16-byte aligned
-    uint4 r = *reinterpret_cast<const uint4*>(rank + i);
-    const uint32_t m0 = spec_map[r.x], m1 = spec_map[r.y], m2 = spec_map[r.z], m3 = spec_map[r.w];
-    r.x = spec_finalize_one(i, m0, payload, kept);
-    r.y = spec_finalize_one(i + 1, m1, payload, kept);
-    r.z = spec_finalize_one(i + 2, m2, payload, kept);
-    r.w = spec_finalize_one(i + 3, m3, payload, kept);
-    *reinterpret_cast<uint4*>(rank + i) = r;
-  } else {
-    for (uint64_t j = i; j < n; ++j) rank[j] = spec_finalize_one(j, spec_map[rank[j]], payload, kept);
+// Chain continuation over the sorted slots of the true leaves that lie BELOW the first candidate node of their path (the
+// candidate was split): their records carry the codes of the candidate's level, and a point's chain from that level on
+// is a function of those codes alone — decode in the candidate's cube, then the ordinary level steps down to the leaf
+// (the digits come out of the chain itself and are the ones the chain pass walked with). One workgroup per <= 512 slots
+// of one leaf; range and levels are wave-uniform, so the level loop and its encoding switch are scalar.
+struct alignas(16) PcvContRange {
+  uint32_t from_level, to_level, pad0, pad1;
+  double mn[3];  // cube min of the candidate node (NodeId::find_bounding_cube recurrence, as the node records carry it)
+  double pad2;
+};
+static_assert(sizeof(PcvContRange) == 48, "continue range");
+template <bool kCompact>
+__global__ __launch_bounds__(256) void spec_continue_kernel(PcvLevels lv, const PcvContRange* __restrict__ ranges,
+                                                             const PcvSettleItem* __restrict__ items, uint4* __restrict__ payload,
+                                                             uint4* __restrict__ wide /* kCompact: codes of Float32-coded levels */) {
+  const PcvSettleItem it = items[blockIdx.x];
+  const PcvContRange rg = ranges[it.rank];
+  const int from = (int)rg.from_level, to = (int)rg.to_level;
+  const uint32_t fe = lv.enc[from], te = lv.enc[to];
+  uint2* __restrict__ pay2 = reinterpret_cast<uint2*>(payload);
+  for (uint32_t s = it.begin + threadIdx.x; s < it.end; s += 256) {
+    uint4 p = make_uint4(0, 0, 0, 0);
+    uint2 q = make_uint2(0, 0);
+    uint32_t idx = 0;
+    if (kCompact) {
+      q = pay2[s];
+      if (fe <= PCV_ENC_UINT16) {
+        p.x = q.x & 0xffffu, p.y = q.x >> 16, p.z = q.y & 0xffffu;
+      } else {
+        idx = q.x;
+        const uint4 w = wide[idx];
+        p.x = w.x, p.y = w.y, p.z = w.z;
+      }
+    } else {
+      p = payload[s];
+    }
+    double mx = rg.mn[0], my = rg.mn[1], mz = rg.mn[2];
+    const double e = lv.edge[from];
+    double px = pcv_decode_coord(fe, p.x, mx, e), py = pcv_decode_coord(fe, p.y, my, e), pz = pcv_decode_coord(fe, p.z, mz, e);
+    double vx = 0, vy = 0, vz = 0;
+    for (int L = from + 1; L <= to; ++L)
+      (void)pcv_chain_level<true>(lv.enc[L], lv.edge[L - 1], lv.edge[L], PcvRecip{lv.inv_edge[L], lv.inv_edge_lo[L]}, px, py, pz, mx,
+                                  my, mz, vx, vy, vz);
+    p.x = (uint32_t)pcv_val_to_code(te, vx);
+    p.y = (uint32_t)pcv_val_to_code(te, vy);
+    p.z = (uint32_t)pcv_val_to_code(te, vz);
+    if (!kCompact) {
+      payload[s] = p;
+    } else if (te <= PCV_ENC_UINT16) {
+      pay2[s] = make_uint2(p.x | (p.y << 16), (q.y & 0xffff0000u) | p.z);
+    } else {  // encodings narrow with depth: a Float32-coded leaf level means the candidate's level was Float32-coded too,
+              // so the record already carries the input index
+      wide[idx] = make_uint4(p.x, p.y, p.z, 0u);
+    }
   }
 }
 
@@ -715,22 +736,18 @@ void pcv_launch_leaf_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvWalkTabl
 template <bool BIN, int BLOCK>
 static void launch_spec_encode_t(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* walk, uint64_t n, const double* x,
                                  const double* y, const double* z, const PcvRouted& routed, const uint8_t* color,
-                                 uint32_t color_stride, const float* intensity, uint32_t* rank, void* payload, void* kept,
+                                 uint32_t color_stride, const float* intensity, uint32_t* rank, void* payload,
                                  uint32_t* inten_bits, uint8_t* depth_grid, void* wide) {
   const dim3 grid((unsigned)((n + BLOCK - 1) / BLOCK));
   const float cells = lv.edge[0] > 0.0 ? (float)((double)(1 << kGridBits) / lv.edge[0]) : 0.f;
   if (BIN) hipLaunchKernelGGL(spec_depth_grid_kernel, dim3((1u << (3 * kGridBits)) / 256), dim3(256), 0, ctx->stream, walk, depth_grid);
-  if (kept)
-    hipLaunchKernelGGL((spec_encode_kernel<true, BIN, BLOCK>), grid, dim3(BLOCK), 0, ctx->stream, lv, walk, n, x, y, z, routed, color,
-                       color_stride, intensity, rank, (uint4*)payload, (uint4*)kept, inten_bits, depth_grid, cells, (uint4*)wide);
-  else
-    hipLaunchKernelGGL((spec_encode_kernel<false, BIN, BLOCK>), grid, dim3(BLOCK), 0, ctx->stream, lv, walk, n, x, y, z, routed,
-                       color, color_stride, intensity, rank, (uint4*)payload, (uint4*)nullptr, inten_bits, depth_grid, cells, (uint4*)wide);
+  hipLaunchKernelGGL((spec_encode_kernel<true, BIN, BLOCK>), grid, dim3(BLOCK), 0, ctx->stream, lv, walk, n, x, y, z, routed, color,
+                     color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide);
 }
 
 void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* walk, uint64_t n, const double* x,
                             const double* y, const double* z, const PcvRouted& routed, const uint8_t* color,
-                            uint32_t color_stride, const float* intensity, uint32_t* rank, void* payload, void* kept,
+                            uint32_t color_stride, const float* intensity, uint32_t* rank, void* payload,
                             uint32_t* inten_bits, uint8_t* depth_grid /* pcv_spec_depth_grid_bytes() of scratch, or null */,
                             void* wide) {
   if (n == 0) return;
@@ -742,16 +759,16 @@ void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* w
   }();
   const bool bin = bin_mode != 0 && depth_grid != nullptr;
   if (!bin)
-    launch_spec_encode_t<false, 256>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, kept, inten_bits,
+    launch_spec_encode_t<false, 256>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, inten_bits,
                                      depth_grid, wide);
   else if (bin_mode == 256)
-    launch_spec_encode_t<true, 256>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, kept, inten_bits,
+    launch_spec_encode_t<true, 256>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, inten_bits,
                                      depth_grid, wide);
   else if (bin_mode == 512)
-    launch_spec_encode_t<true, 512>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, kept, inten_bits,
+    launch_spec_encode_t<true, 512>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, inten_bits,
                                      depth_grid, wide);
   else
-    launch_spec_encode_t<true, 1024>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, kept, inten_bits,
+    launch_spec_encode_t<true, 1024>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, inten_bits,
                                      depth_grid, wide);
 }
 
@@ -770,11 +787,21 @@ void pcv_launch_rank_hist(pcv_ctx* ctx, const uint32_t* rank, uint64_t n, uint32
   }
 }
 
-void pcv_launch_spec_finalize(pcv_ctx* ctx, uint64_t n, const uint32_t* spec_map, uint32_t* rank, void* payload, const void* kept) {
-  if (n == 0) return;
-  PcvProf prof(ctx, PCV_K_SPEC_FINALIZE);
-  hipLaunchKernelGGL(spec_finalize_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, ctx->stream, n, spec_map, rank,
-                     (uint4*)payload, (const uint4*)kept);
+size_t pcv_cont_range_bytes() { return sizeof(PcvContRange); }
+void pcv_fill_cont_range(void* dst, uint32_t from_level, uint32_t to_level, const double mn[3]) {
+  PcvContRange* r = reinterpret_cast<PcvContRange*>(dst);
+  *r = PcvContRange{from_level, to_level, 0u, 0u, {mn[0], mn[1], mn[2]}, 0.0};
+}
+void pcv_launch_spec_continue(pcv_ctx* ctx, const PcvLevels& lv, const void* ranges, const PcvSettleItem* items, uint32_t num_items,
+                              void* sorted_payload, void* wide) {
+  if (num_items == 0) return;
+  PcvProf prof(ctx, PCV_K_SPEC_CONTINUE);
+  if (wide)
+    hipLaunchKernelGGL((spec_continue_kernel<true>), dim3(num_items), dim3(256), 0, ctx->stream, lv, (const PcvContRange*)ranges, items,
+                       (uint4*)sorted_payload, (uint4*)wide);
+  else
+    hipLaunchKernelGGL((spec_continue_kernel<false>), dim3(num_items), dim3(256), 0, ctx->stream, lv, (const PcvContRange*)ranges, items,
+                       (uint4*)sorted_payload, (uint4*)nullptr);
 }
 
 void pcv_launch_spec_replay(pcv_ctx* ctx, const PcvLevels& lv, const void* ranges, uint32_t num_ranges, uint32_t total,

@@ -93,7 +93,7 @@ enum PcvKernelId {
   PCV_K_PROMOTE_CLIMB,
   PCV_K_SPEC_ENCODE,
   PCV_K_RANK_HIST,
-  PCV_K_SPEC_FINALIZE,
+  PCV_K_SPEC_CONTINUE,
   PCV_K_SPEC_REPLAY,
   PCV_K_SORT_UPSWEEP_MAP,
   PCV_K_COUNT
@@ -202,6 +202,7 @@ inline bool pcv_prof_is_major(int id) {
     case PCV_K_RANK_HIST:
     case PCV_K_SORT_UPSWEEP_MAP:
     case PCV_K_SORT_UPSWEEP32:
+    case PCV_K_SPEC_CONTINUE:
     case PCV_K_ROUTE_BUCKET:
     case PCV_K_PARTITION_COUNT:
     case PCV_K_PARTITION_SCATTER:
@@ -297,7 +298,7 @@ int pcv_radix_sort_u32(pcv_ctx* ctx, uint32_t* keys_a, uint32_t* keys_b, uint64_
 
 int pcv_radix_sort_records_mapped(pcv_ctx* ctx, uint32_t* keys_a, uint32_t* keys_b, uint64_t n, int key_bits,
                                   PcvSortPayload* payload, void* scratch, const uint32_t* map, uint32_t map_entries,
-                                  const void* kept, bool* result_in_a, void* wide = nullptr, uint64_t wide_levels = 0);
+                                  bool* result_in_a);
 
 // pcv_topology.hip — node split (topology from sorted keys).
 // Device node table, structure of arrays, BFS order (level-major, prefix-sorted inside a level).
@@ -362,13 +363,17 @@ void pcv_launch_leaf_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvWalkTabl
 void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* walk, uint64_t n, const double* x,
                             const double* y, const double* z, const PcvRouted& routed, const uint8_t* color,
                             uint32_t color_stride, const float* intensity, uint32_t* rank, void* payload /* uint4[n] */,
-                            void* kept /* uint4[n] or null */, uint32_t* inten_bits, uint8_t* depth_grid,
-                            void* wide = nullptr);
+                            uint32_t* inten_bits, uint8_t* depth_grid, void* wide = nullptr);
 size_t pcv_spec_depth_grid_bytes();  // scratch for the depth-prediction grid of the binned pass
 void pcv_launch_rank_hist(pcv_ctx* ctx, const uint32_t* rank, uint64_t n, uint32_t num_bins, uint32_t* counts /* zeroed */,
                           int shift = 0);
-void pcv_launch_spec_finalize(pcv_ctx* ctx, uint64_t n, const uint32_t* spec_map, uint32_t* rank, void* payload,
-                              const void* kept);
+// Chain continuation of the true leaves below a split first candidate (pcv_spec.h): `ranges` = device array of
+// pcv_cont_range_bytes()-sized records filled by pcv_fill_cont_range (levels + cube min of the candidate), `items` = one
+// entry per <= kPcvSettleTile sorted slots of one such leaf (rank = index of its range); rewrites the codes in place.
+size_t pcv_cont_range_bytes();
+void pcv_fill_cont_range(void* dst, uint32_t from_level, uint32_t to_level, const double mn[3]);
+void pcv_launch_spec_continue(pcv_ctx* ctx, const PcvLevels& lv, const void* ranges, const PcvSettleItem* items, uint32_t num_items,
+                              void* sorted_payload, void* wide = nullptr);
 // ranges: device array of {first sorted slot, flagged slots before it, level, pad} (4 x u32), after the record sort
 void pcv_launch_spec_replay(pcv_ctx* ctx, const PcvLevels& lv, const void* ranges, uint32_t num_ranges, uint32_t total,
                             const double* x, const double* y, const double* z, const PcvRouted& routed, void* sorted_payload,
@@ -427,8 +432,9 @@ struct pcv_octree {
   int key_levels = 0;    // digit levels the key sort covered (depth speculation)
   int key_attempts = 0;  // 0 = single-chain build, 1 = depth speculation held (or was off), 2+ = redone
   int record_bytes = 0;  // bytes per record in the record sort (20, or 12 packed)
-  uint64_t spec_stats[4] = {};  // single-chain build: nodes / leaves of the predicted tree, points that took their kept
-                                // codes, points that replayed the chain
+  uint64_t spec_stats[4] = {};  // single-chain build: nodes / leaves of the predicted tree, points in an unsplit first
+                                // candidate (their kept codes are their leaf codes), points that replayed the chain
+  uint64_t spec_continued = 0;  // points whose chain was continued from the codes of a split candidate
   PcvOctreeQuery* query = nullptr;
   // octrees opened from a directory: node files are read on demand
   std::string directory;

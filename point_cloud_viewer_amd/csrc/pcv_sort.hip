@@ -133,25 +133,22 @@ __global__ __launch_bounds__(kBlock) void upsweep_kernel(const KeyT* __restrict_
   }
 }
 
-// First record pass of the single-chain build: the upsweep reads every rank anyway, so it also does the "finalize"
-// work on the way — rank := map[rank] (written back in place), payload := kept codes where the map says so (bit 31),
-// payload.x := own index where the point has to replay its chain after the sort (bit 30) — and counts the digits of
-// the MAPPED ranks. One pass over the ranks instead of two (finalize + upsweep); the downsweep is the ordinary one.
-// kMapLds: the map (one entry per predicted leaf; 26 KB for a 100 M-point tree) is copied into LDS first — eight
+// First record pass of the single-chain build: the upsweep reads every rank anyway, so it also translates it on the way
+// — rank := map[rank], written back in place — and counts the digits of the MAPPED ranks: one pass over the ranks
+// instead of two; the downsweep is the ordinary one. The payloads are not touched: a record already carries the codes
+// its true leaf needs (pcv_spec.h), except for the rare leaves the map flags PCV_SPEC_MAP_REPLAY (bit 30), whose points
+// leave their input index in the first payload word for the replay after the sort.
+// kMapLds: the map (one entry per predicted leaf; 30 KB for a 100 M-point tree) is copied into LDS first — eight
 // dependent lookups per lane and iteration then cost LDS latency instead of a trip to the vector L1 / L2 that the
-// streaming keys keep evicting it from.
-constexpr uint32_t kMapLdsEntries = 24576;  // 96 KB
-// kCompact (12-byte records, pcv_internal.h): key = rank << 8 | blue, payload = uint2; a kept code set of a
-// Float32-coded level does not fit 16 bits per coordinate and goes to the point's `wide` entry instead (the record keeps
-// the input index); `shift` is the digit's position inside the KEY (8 + its position inside the rank).
+// streaming keys keep evicting it from. Static + dynamic LDS stay inside the 64 KB a kernel gets without opting in.
+constexpr uint32_t kMapLdsEntries = 15360;  // 60 KB
+// kCompact (12-byte records, pcv_internal.h): key = rank << 8 | blue, payload = uint2; `shift` is the digit's position
+// inside the KEY (8 + its position inside the rank).
 template <bool kMapLds, bool kCompact>
 __global__ __launch_bounds__(kBlock) void upsweep_map_kernel(uint32_t* __restrict__ keys, uint64_t n, uint64_t chunk, int groups,
                                                               int shift, uint32_t mask, uint32_t* __restrict__ hist,
                                                               const uint32_t* __restrict__ gmap, uint32_t map_entries,
-                                                              void* __restrict__ payload_v, const uint4* __restrict__ kept,
-                                                              uint4* __restrict__ wide, uint64_t wide_levels) {
-  uint4* __restrict__ payload = reinterpret_cast<uint4*>(payload_v);
-  uint2* __restrict__ pay2 = reinterpret_cast<uint2*>(payload_v);
+                                                              void* __restrict__ payload_v) {
   __shared__ uint32_t wh[kWaves][kRadix];
   extern __shared__ uint32_t smap[];  // kMapLds: map_entries words (dynamic, so small maps keep the occupancy)
   const int wave = threadIdx.x >> 6;
@@ -164,51 +161,35 @@ __global__ __launch_bounds__(kBlock) void upsweep_map_kernel(uint32_t* __restric
   uint64_t end = begin + chunk;
   if (end > n) end = n;
   auto one = [&](uint64_t idx, uint32_t old, uint32_t m) -> uint32_t {
-    if (kCompact) {
-      if (m & (1u << 30)) {
-        reinterpret_cast<uint32_t*>(pay2 + idx)[0] = (uint32_t)idx;
-      } else if (m & (1u << 31)) {  // the code fields only: the colour bytes stay, so the payload is not read
-        const uint4 k = kept[idx];
-        if ((wide_levels >> (k.w & 63u)) & 1ull) {
-          reinterpret_cast<uint32_t*>(pay2 + idx)[0] = (uint32_t)idx;
-          wide[idx] = k;
-        } else {
-          reinterpret_cast<uint32_t*>(pay2 + idx)[0] = k.x | (k.y << 16);
-          reinterpret_cast<uint16_t*>(pay2 + idx)[2] = (uint16_t)k.z;
-        }
-      }
-      return ((m & PCV_SPEC_INDEX_MASK_SORT) << 8) | (old & 0xffu);
+    if (__builtin_expect((m & (1u << 30)) != 0u, 0)) {  // replay: the first payload word becomes the input index
+      if (kCompact) reinterpret_cast<uint32_t*>(reinterpret_cast<uint2*>(payload_v) + idx)[0] = (uint32_t)idx;
+      else reinterpret_cast<uint32_t*>(reinterpret_cast<uint4*>(payload_v) + idx)[0] = (uint32_t)idx;
     }
-    if (m & (1u << 30)) {
-      reinterpret_cast<uint32_t*>(payload + idx)[0] = (uint32_t)idx;
-    } else if (m & (1u << 31)) {  // the three code words only: the colour word stays, so the payload is not read
-      const uint4 k = kept[idx];
-      uint32_t* p = reinterpret_cast<uint32_t*>(payload + idx);
-      p[0] = k.x;
-      p[1] = k.y;
-      p[2] = k.z;
-    }
-    return m & PCV_SPEC_INDEX_MASK_SORT;
+    return kCompact ? (((m & PCV_SPEC_INDEX_MASK_SORT) << 8) | (old & 0xffu)) : (m & PCV_SPEC_INDEX_MASK_SORT);
   };
   constexpr int kKeyShift = kCompact ? 8 : 0;  // position of the predicted-leaf rank inside the key
   uint64_t i = begin + (uint64_t)threadIdx.x * 4;
   constexpr uint64_t kStep = (uint64_t)kBlock * 4;
-  for (; i + kStep + 4 <= end; i += 2 * kStep) {  // two 16-byte loads and their eight map lookups in flight per lane
-    uint4 v[2];
-    v[0] = *reinterpret_cast<const uint4*>(keys + i);
-    v[1] = *reinterpret_cast<const uint4*>(keys + i + kStep);
-    const uint32_t o[8] = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w};
-    uint32_t m[8];
+  for (; i + 3 * kStep + 4 <= end; i += 4 * kStep) {  // four 16-byte loads and their sixteen map lookups in flight per lane
+    uint4 v[4];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) m[k] = map[o[k] >> kKeyShift];
-    uint32_t r[8];
+    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const uint4*>(keys + i + u * kStep);
+    uint32_t r[16];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) r[k] = one(i + (k >> 2) * kStep + (k & 3), o[k], m[k]);
-    *reinterpret_cast<uint4*>(keys + i) = make_uint4(r[0], r[1], r[2], r[3]);
-    *reinterpret_cast<uint4*>(keys + i + kStep) = make_uint4(r[4], r[5], r[6], r[7]);
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t o[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+      uint32_t m[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) m[k] = map[o[k] >> kKeyShift];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) r[4 * u + k] = one(i + u * kStep + k, o[k], m[k]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      *reinterpret_cast<uint4*>(keys + i + u * kStep) = make_uint4(r[4 * u], r[4 * u + 1], r[4 * u + 2], r[4 * u + 3]);
     const uint64_t here = __builtin_amdgcn_ballot_w64(true);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) count_digit(wh[wave], (r[k] >> shift) & mask, here, true);
+    for (int k = 0; k < 16; ++k) count_digit(wh[wave], (r[k] >> shift) & mask, here, true);
   }
   for (; i + 4 <= end; i += kStep) {
     const uint4 v = *reinterpret_cast<const uint4*>(keys + i);
@@ -807,18 +788,20 @@ static void rec12_launch(pcv_ctx* ctx, int variant, const SortGeom& g, const uin
 
 template <typename KeyT>
 int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int end_bit, PcvSortPayload* payload,
-               void* scratch, bool* result_in_a, const uint32_t* map = nullptr, const void* kept = nullptr,
-               uint32_t map_entries = 0, void* wide = nullptr, uint64_t wide_levels = 0) {
+               void* scratch, bool* result_in_a, const uint32_t* map = nullptr, uint32_t map_entries = 0) {
   *result_in_a = true;
   if (n == 0 || end_bit <= begin_bit) return PCV_OK;
   if (n >= 0xffffffffull) return ctx->fail(PCV_E_INVALID, "radix sort: n must be < 2^32 - 1");
   const bool records = payload && (payload->vec_in || payload->nwords > 0);
   if (records && sizeof(KeyT) != 4) return ctx->fail(PCV_E_INVALID, "record sort needs 32-bit keys");
   const bool compact = records && payload->vec_in && payload->vec_bytes == 8;  // 12-byte records
-  // geometry of the 12-byte record downsweep (experiments: PCV_REC_VARIANT, see rec12_launch)
+  // geometry of the 12-byte record downsweep: 1 024 lanes x 8 records, tiles of 8 192 (PCV_REC_VARIANT: the other
+  // geometries of rec12_launch; 0 = the 256-lane kernel that also carries extra planes). What moves this kernel is the
+  // length of the write runs, not the occupancy: tiles of 4 096 at 8 / 12 / 16 waves per CU all take 0.68-0.70 ms per pass
+  // at 100 M records, tiles of 8 192 0.60-0.63 (r03a A/B, one box); non-temporal stores cost 35 %
   static const int rec_variant = [] {
     const char* e = getenv("PCV_REC_VARIANT");
-    return e ? atoi(e) : 0;
+    return e ? atoi(e) : 3;
   }();
   const bool rec12 = compact && payload->nwords == 0 && rec_variant > 0;
   SortGeom g = make_geom(n, rec12 && (rec_variant == 3 || rec_variant == 4) ? 8192 : kTileUnit);
@@ -843,7 +826,7 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
       void* pay = in_a ? payload->vec_in : payload->vec_out;
 #define PCV_UPSWEEP_MAP(L, C)                                                                                                    \
   hipLaunchKernelGGL((upsweep_map_kernel<L, C>), dim3(g.groups), dim3(kBlock), dyn, ctx->stream, (uint32_t*)src, n, g.chunk, g.groups, \
-                     shift, mask, hist, map, map_entries, pay, (const uint4*)kept, (uint4*)wide, wide_levels)
+                     shift, mask, hist, map, map_entries, pay)
       if (lds && compact) PCV_UPSWEEP_MAP(true, true);
       else if (lds) PCV_UPSWEEP_MAP(true, false);
       else if (compact) PCV_UPSWEEP_MAP(false, true);
@@ -925,13 +908,11 @@ int pcv_radix_sort_u32(pcv_ctx* ctx, uint32_t* keys_a, uint32_t* keys_b, uint64_
                        PcvSortPayload* payload, void* scratch, bool* result_in_a) {
   return radix_sort<uint32_t>(ctx, keys_a, keys_b, n, begin_bit, end_bit, payload, scratch, result_in_a);
 }
-// Record sort whose first upsweep also translates the ranks through `map` and patches the payloads (single-chain build)
-// 12-byte records (payload->vec_bytes == 8): the rank sits in bits 8.. of the key, `wide` / `wide_levels` as in
-// upsweep_map_kernel
+// Record sort whose first upsweep also translates the ranks through `map` (single-chain build); 12-byte records
+// (payload->vec_bytes == 8): the rank sits in bits 8.. of the key
 int pcv_radix_sort_records_mapped(pcv_ctx* ctx, uint32_t* keys_a, uint32_t* keys_b, uint64_t n, int key_bits,
                                   PcvSortPayload* payload, void* scratch, const uint32_t* map, uint32_t map_entries,
-                                  const void* kept, bool* result_in_a, void* wide, uint64_t wide_levels) {
+                                  bool* result_in_a) {
   const int base = payload && payload->vec_bytes == 8 ? 8 : 0;
-  return radix_sort<uint32_t>(ctx, keys_a, keys_b, n, base, base + key_bits, payload, scratch, result_in_a, map, kept, map_entries,
-                              wide, wide_levels);
+  return radix_sort<uint32_t>(ctx, keys_a, keys_b, n, base, base + key_bits, payload, scratch, result_in_a, map, map_entries);
 }

@@ -140,7 +140,10 @@ PcvSpecStatus pcv_spec_resolve(const PcvSpecParams& p, const PcvSpecTree& t, con
   };
   // true tree, breadth first (a subtree of T'': at most m nodes); src[k] = T'' node of true node k
   std::vector<uint32_t> src(m);
-  std::vector<uint8_t> kept_above(m);  // a candidate ancestor already holds this path's kept codes
+  // first candidate node on the path from the root to (but excluding) this node, as an index into the true tree;
+  // kNone: no candidate above. The chain pass left every point below it with the codes of THAT node's level.
+  constexpr uint32_t kNone = 0xffffffffu;
+  std::vector<uint32_t> first_cand(m);
   r.prefix.resize(m);
   r.level.resize(m);
   r.lo.resize(m);
@@ -150,7 +153,7 @@ PcvSpecStatus pcv_spec_resolve(const PcvSpecParams& p, const PcvSpecTree& t, con
   r.open.resize(m);
   size_t nk = 1;
   src[0] = 0;
-  kept_above[0] = 0;
+  first_cand[0] = kNone;
   for (size_t k = 0; k < nk; ++k) {
     const uint32_t i = src[k];
     r.prefix[k] = t.prefix[i];
@@ -161,13 +164,13 @@ PcvSpecStatus pcv_spec_resolve(const PcvSpecParams& p, const PcvSpecTree& t, con
     r.open[k] = 1;
     r.first_child[k] = (uint32_t)nk;
     uint8_t mask = 0;
-    const uint8_t ka = (uint8_t)(kept_above[k] | t.candidate[i]);
+    const uint32_t fc = first_cand[k] != kNone ? first_cand[k] : (t.candidate[i] ? (uint32_t)k : kNone);
     for (unsigned c = 0; c < 8; ++c) {
       const uint32_t ch = t.first_child[i] + c;
       if (cnt[ch] == 0) continue;  // a child exists iff a point lies in it
       mask |= (uint8_t)(1u << c);
       src[nk] = ch;
-      kept_above[nk] = ka;
+      first_cand[nk] = fc;
       ++nk;
     }
     r.child_mask[k] = mask;
@@ -197,27 +200,35 @@ PcvSpecStatus pcv_spec_resolve(const PcvSpecParams& p, const PcvSpecTree& t, con
     r.lo[k] = (uint32_t)run;
     run += cnt[i];
     r.hi[k] = (uint32_t)run;
-    if (!t.inner[i]) {
-      r.spec_map[t.leaf_rank[i]] = rank;  // the point's predicted leaf IS its leaf: codes of the predicted leaf
-      continue;
-    }
-    // a true leaf that the prediction split: its points kept their codes at this node iff it is the first candidate
-    // on their path; otherwise they replay the chain to this level
-    const bool has_codes = t.candidate[i] && !kept_above[k];
-    if (has_codes) r.kept_points += cnt[i];
-    else {
+    // which level do the codes in this leaf's records belong to?
+    //   a candidate above (it was split, or this node would not exist): that candidate's level -> continue the chain;
+    //   else this node is a predicted leaf, or an unsplit (first) candidate: its own level -> nothing to do;
+    //   else (a non-candidate inner node of T'': the codes may belong to a candidate BELOW it): replay from the coordinates
+    const bool cont = first_cand[k] != kNone;
+    const bool replay = !cont && t.inner[i] && !t.candidate[i];
+    if (cont) {
+      r.cont_nodes.push_back(k);
+      r.cont_from.push_back(first_cand[k]);
+      r.cont_points += cnt[i];
+    } else if (replay) {
       r.any_fix = true;
       r.fix_points += cnt[i];
       r.fix_nodes.push_back(k);
+    } else if (t.inner[i]) {
+      r.kept_points += cnt[i];
     }
-    const uint32_t mapped = rank | (has_codes ? PCV_SPEC_MAP_KEPT : PCV_SPEC_MAP_REPLAY);
+    if (!t.inner[i]) {
+      r.spec_map[t.leaf_rank[i]] = rank;  // the point's predicted leaf IS its leaf
+      continue;
+    }
+    const uint32_t mapped = rank | (replay ? PCV_SPEC_MAP_REPLAY : 0u);
     size_t bp = 0;
     below[bp++] = i;
     while (bp) {
       const uint32_t j = below[--bp];
       if (!t.inner[j]) {
         r.spec_map[t.leaf_rank[j]] = mapped;
-        if (!has_codes) r.fix_level[t.leaf_rank[j]] = t.level[i];
+        if (replay) r.fix_level[t.leaf_rank[j]] = t.level[i];
       } else {
         for (unsigned c = 0; c < 8; ++c) below[bp++] = t.first_child[j] + c;
       }
@@ -337,18 +348,21 @@ extern "C" int pcv_spec_selftest(const uint64_t* keys, uint64_t n, uint32_t stri
   PcvSpecTree tree;
   pcv_spec_build_tree(p, st, &tree);
   std::vector<uint32_t> counts(tree.num_leaves, 0);
+  std::vector<uint8_t> code_level(n);  // level of the codes the chain pass leaves in the point's record
+  std::vector<uint32_t> pred_leaf(n);
   uint64_t kept = 0;
-  for (uint64_t i = 0; i < n; ++i) {  // what the fused kernel's walk does with the digits of the chain
+  for (uint64_t i = 0; i < n; ++i) {  // what the one chain pass does with the digits of the chain
     uint32_t rec = tree.walk[0];
-    int l = 0;
-    bool have = false;
+    int l = 0, kl = 0;
     while (!(rec & PCV_SPEC_LEAF)) {
-      if ((rec & PCV_SPEC_CANDIDATE) && !have) have = true;
+      if ((rec & PCV_SPEC_CANDIDATE) && kl == 0) kl = l;  // the first candidate on the path: its codes are what is kept
       ++l;
       rec = tree.walk[(rec & PCV_SPEC_INDEX_MASK) + (unsigned)((keys[i] >> (3 * (kKeyLevels - l))) & 7)];
     }
-    kept += have;
-    ++counts[rec & PCV_SPEC_INDEX_MASK];
+    kept += kl != 0;
+    code_level[i] = (uint8_t)(kl ? kl : l);
+    pred_leaf[i] = rec & PCV_SPEC_INDEX_MASK;
+    ++counts[pred_leaf[i]];
   }
   PcvTrueTree tt;
   const PcvSpecStatus status = pcv_spec_resolve(p, tree, counts.data(), &tt);
@@ -365,10 +379,53 @@ extern "C" int pcv_spec_selftest(const uint64_t* keys, uint64_t n, uint32_t stri
   if (out_stats) {
     out_stats[0] = tree.prefix.size();
     out_stats[1] = tree.num_leaves;
-    out_stats[2] = kept;          // points that passed a candidate (they write their kept codes)
-    out_stats[3] = tt.fix_points;  // points that replay the chain in the finalize kernel
+    out_stats[2] = kept;          // points that passed a candidate (their records carry that candidate's codes)
+    out_stats[3] = tt.fix_points;  // points that replay the chain from their coordinates
   }
   if (status != PCV_SPEC_OK) return (int)status;
+  {  // every point's record must carry codes the build knows how to turn into its leaf's codes
+    std::vector<uint32_t> leaf_node;  // true-leaf rank -> node (depth-first order, as in pcv_spec_resolve)
+    std::vector<uint32_t> st{0};
+    while (!st.empty()) {
+      const uint32_t k = st.back();
+      st.pop_back();
+      if (tt.open[k]) {
+        const uint32_t nchild = (uint32_t)__builtin_popcount(tt.child_mask[k]);
+        for (uint32_t c = nchild; c-- > 0;) st.push_back(tt.first_child[k] + c);
+      } else {
+        leaf_node.push_back(k);
+      }
+    }
+    std::vector<int> from_level(tt.prefix.size(), -1);  // leaf node -> level the chain is continued from
+    std::vector<uint8_t> replays(tt.prefix.size(), 0);
+    for (size_t j = 0; j < tt.cont_nodes.size(); ++j) {
+      const uint32_t leaf = tt.cont_nodes[j], from = tt.cont_from[j];
+      if (!tt.open[from] || tt.level[from] >= tt.level[leaf]) return 103;
+      // the candidate must be an ancestor of the leaf
+      const int sh = 3 * (kKeyLevels - tt.level[from]);
+      if (tt.level[from] && (tt.prefix[leaf] >> sh) != (tt.prefix[from] >> sh)) return 103;
+      from_level[leaf] = tt.level[from];
+    }
+    for (uint32_t k : tt.fix_nodes) replays[k] = 1;
+    uint64_t cont_seen = 0, fix_seen = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+      const uint32_t m = tt.spec_map[pred_leaf[i]];
+      const uint32_t leaf = leaf_node[m & PCV_SPEC_INDEX_MASK];
+      // the point really lies in that leaf
+      const int sh = 3 * (kKeyLevels - tt.level[leaf]);
+      if (tt.level[leaf] && (keys[i] >> sh) != (tt.prefix[leaf] >> sh)) return 104;
+      if (((m & PCV_SPEC_MAP_REPLAY) != 0) != (replays[leaf] != 0)) return 105;
+      if (replays[leaf]) {
+        ++fix_seen;  // codes ignored: replayed from the coordinates
+      } else if (from_level[leaf] >= 0) {
+        if ((int)code_level[i] != from_level[leaf]) return 106;  // continued from exactly the level the record holds
+        ++cont_seen;
+      } else if (code_level[i] != tt.level[leaf]) {
+        return 107;  // nothing is done to this leaf: the record must already hold its level's codes
+      }
+    }
+    if (cont_seen != tt.cont_points || fix_seen != tt.fix_points) return 108;
+  }
   *out_num_nodes = tt.prefix.size();
   if (tt.prefix.size() > node_capacity) return 101;
   for (size_t k = 0; k < tt.prefix.size(); ++k) {

@@ -7,14 +7,18 @@
 // exact counts. Nothing about the result is approximate:
 //   * the predicted tree T'' only has to be at least as deep as the true tree wherever points go; every inner node has
 //     all eight children, so every point reaches exactly one predicted leaf;
-//   * a node whose sampled count is close to the capacity ("candidate") is split in T'', and every point passing
-//     through it also keeps the codes it had AT that node — so the point is ready both for "the node is a leaf" and for
-//     "the node is split";
-//   * the exact counts decide (should_split_node, reference src/octree/generation.rs:128-150). A true leaf that is an
-//     inner node of T'' WITHOUT kept codes (rare: a candidate below a candidate, a count far outside the band) has its
-//     points replay the chain to its level; a predicted leaf that must be split (the prediction is too shallow there)
-//     sends the whole build to the exact two-chain pipeline. Speculation can cost time, never correctness — the same
-//     contract as the depth speculation of the exact path.
+//   * a node whose sampled count is close to the capacity ("candidate") is split in T''; a point passing through one
+//     leaves the chain pass with the codes it had AT the FIRST candidate on its path (the walk still goes on to the
+//     predicted leaf, whose exact count the split decisions need). The chain of a point from level k on is a function
+//     of its level-k codes alone (every level re-decodes the position from the codes, generation.rs:78-99), so those codes
+//     serve both outcomes: if the candidate is a true leaf they ARE the leaf codes — nothing to patch —, and if it is
+//     split the chain is CONTINUED from them, leaf by leaf, once the record sort has made each true leaf contiguous;
+//   * the exact counts decide (should_split_node, reference src/octree/generation.rs:128-150). A true leaf that is a
+//     non-candidate inner node of T'' with no candidate above it (a count far outside the band: rare) has no usable
+//     codes — they may belong to a level BELOW it — and its points replay the chain from their coordinates; a
+//     predicted leaf that must be split (the prediction is too shallow there) sends the whole build to the exact
+//     two-chain pipeline. Speculation can cost time, never correctness — the same contract as the depth speculation of
+//     the exact path.
 #pragma once
 #include <stdint.h>
 
@@ -25,9 +29,8 @@
 #define PCV_SPEC_LEAF (1u << 31)
 #define PCV_SPEC_CANDIDATE (1u << 30)
 #define PCV_SPEC_INDEX_MASK 0x3fffffffu
-// predicted-leaf -> true-leaf map entry: true rank in bits 0..29, bit 31: take the kept codes, bit 30: no codes yet
-// (the point leaves its input index in the payload and replays the chain after the record sort)
-#define PCV_SPEC_MAP_KEPT (1u << 31)
+// predicted-leaf -> true-leaf map entry: true rank in bits 0..29, bit 30: no usable codes (the point leaves its input
+// index in the payload and replays the chain from its coordinates after the record sort)
 #define PCV_SPEC_MAP_REPLAY (1u << 30)
 
 struct PcvSpecParams {
@@ -79,21 +82,24 @@ enum PcvSpecStatus {
 
 // The true tree in the layout the exact path downloads from the device after the node split (BFS order, children
 // contiguous in digit order, [lo, hi) = range in key-sorted order), plus the map predicted-leaf rank -> true leaf rank
-// (depth-first order, the same order pcv_build_finish assigns) with PCV_SPEC_MAP_KEPT set when the point takes the codes
-// it kept at its candidate node instead of the codes of its predicted leaf, PCV_SPEC_MAP_REPLAY when it has to replay.
+// (depth-first order, the same order pcv_build_finish assigns) with PCV_SPEC_MAP_REPLAY set when the points have to
+// replay their chain from the coordinates.
 struct PcvTrueTree {
   std::vector<uint64_t> prefix;
   std::vector<uint32_t> lo, hi, first_child;
   std::vector<uint8_t> level, child_mask, open;
   std::vector<uint32_t> spec_map;
-  // A true leaf that is an inner node of T'' whose points did NOT keep their codes there (a candidate below another
-  // candidate, or a sampled count outside the band): level of that leaf per predicted leaf below it, 0 = none. Those
-  // points replay the chain to that level once the record sort has made them contiguous (rare; any_fix says whether the
-  // table is needed).
+  // A true leaf that is a non-candidate inner node of T'' without a candidate above it: level of that leaf per predicted
+  // leaf below it, 0 = none. Those points replay the chain to that level once the record sort has made them contiguous
+  // (rare; any_fix says whether the table is needed).
   std::vector<uint8_t> fix_level;
   std::vector<uint32_t> fix_nodes;  // the true leaves (indices into this table) whose points replay the chain
   bool any_fix = false;
-  uint64_t fix_points = 0, kept_points = 0;  // points that replay the chain / take their kept codes
+  // True leaves BELOW the first candidate of their path (the candidate was split): their records carry the codes of the
+  // candidate's level. cont_nodes[j] = the leaf, cont_from[j] = that candidate (both indices into this table); the chain
+  // is continued from the one level to the other over the leaf's sorted slots.
+  std::vector<uint32_t> cont_nodes, cont_from;
+  uint64_t fix_points = 0, kept_points = 0, cont_points = 0;  // replayed / in an unsplit first candidate / continued
   uint32_t num_leaves = 0;
   int deepest_level = 0;
 };

@@ -533,14 +533,16 @@ class OctreeResult:
 
     def build_info(self):
         """key_levels, attempts (0 = single-chain build, 1 = exact pipeline, >= 2 something was redone) and the
-        single-chain statistics (predicted nodes / leaves, points that took kept codes, points that replayed the chain);
+        single-chain statistics (predicted nodes / leaves, points whose leaf is an unsplit candidate, points whose chain
+        was continued from a split candidate's codes, points that replayed the chain from their coordinates);
         record_bytes: bytes per record of the record sort (20, or 12 packed)."""
         lv, at = C.c_int(), C.c_int()
         self.lib.pcv_octree_build_info(self.handle, C.byref(lv), C.byref(at))
         st = (C.c_uint64 * 4)()
         self.lib.pcv_octree_spec_stats(self.handle, st)
         return dict(key_levels=lv.value, attempts=at.value, single_chain=at.value == 0,
-                    record_bytes=int(self.lib.pcv_octree_record_bytes(self.handle)), predicted_nodes=st[0], predicted_leaves=st[1], kept_code_points=st[2], replayed_points=st[3])
+                    record_bytes=int(self.lib.pcv_octree_record_bytes(self.handle)), predicted_nodes=st[0], predicted_leaves=st[1], kept_code_points=st[2], replayed_points=st[3],
+                    continued_points=int(self.lib.pcv_octree_spec_continued(self.handle)))
 
     def write_dir(self, directory):
         self.ctx._check(self.lib.pcv_octree_write_dir(self.handle, str(directory).encode()))
