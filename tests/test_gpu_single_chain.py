@@ -1,7 +1,7 @@
 """The single-chain build (csrc/pcv_spec.h: topology predicted from a strided sample, ONE chain pass, exact per-leaf
 counts decide the tree) against the CPU oracle: byte-exact like every other build test, whatever the prediction did —
-held, took kept codes at candidate nodes, replayed the chain for a few points, or gave up and let the exact pipeline
-redo the build. The reference has one answer per input (src/octree/generation.rs:289-403); so do all of these paths."""
+held, kept a candidate's codes as leaf codes, continued the chain from a split candidate's codes, replayed the chain
+from the coordinates for a few points, or gave up and let the exact pipeline redo the build. The reference has one answer per input (src/octree/generation.rs:289-403); so do all of these paths."""
 import numpy as np
 import pytest
 
@@ -20,7 +20,7 @@ def ctx():
     c.close()
 
 
-SEEN = {"held": 0, "fell_back": 0, "kept": 0, "replayed": 0}
+SEEN = {"held": 0, "fell_back": 0, "kept": 0, "continued": 0, "replayed": 0}
 
 CASES = [  # n, capacity, resolution, clusters, extent, sigma range, intensity, seed
     (600_000, 20_000, 0.001, 6, 200.0, (0.2, 8.0), False, 1),
@@ -51,6 +51,7 @@ def test_forced_single_chain_equals_oracle(ctx, n, cap, res, clusters, extent, s
     SEEN["held" if info["single_chain"] else "fell_back"] += 1
     SEEN["kept"] += info["kept_code_points"] > 0
     SEEN["replayed"] += info["replayed_points"] > 0
+    SEEN["continued"] += info["continued_points"] > 0
     if info["single_chain"]:
         assert info["record_bytes"] == 12, info  # packed records are what ships on this path
         leaves = sum(1 for k in want.nodes if not any(c.startswith(k) and len(c) == len(k) + 1 for c in want.nodes))
@@ -63,17 +64,43 @@ def test_forced_single_chain_equals_oracle(ctx, n, cap, res, clusters, extent, s
 
 
 def test_the_cases_above_covered_every_branch_of_the_prediction():
-    """held / took kept codes / replayed the chain after the sort must all have happened at least once above."""
-    assert SEEN["held"] >= 3 and SEEN["kept"] >= 2 and SEEN["replayed"] >= 1, SEEN
+    """held / a candidate's codes were the leaf codes / the chain was continued from a split candidate's codes must all
+    have happened above (the replay from coordinates needs a sample that OVER-counts a node: next test)."""
+    assert SEEN["held"] >= 3 and SEEN["kept"] >= 2 and SEEN["continued"] >= 2, SEEN
 
 
-def test_single_chain_is_the_default_from_4M_points_and_takes_kept_codes(ctx):
+def test_oversampled_clusters_replay_the_chain_from_their_coordinates(ctx):
+    """A sample that over-counts: six tight clusters of 2 500 points sit exactly at the sampled input positions (8
+    consecutive points every 256), so the prediction splits their level-2 nodes many levels deep — far outside the
+    candidate band — while the exact counts (11-12 k < capacity 20 k) make those nodes LEAVES. Their points went down
+    to candidates below the leaf, so their records hold codes of a deeper level: the one case that still needs the
+    coordinates (PCV_SPEC_MAP_REPLAY). Byte-exact against the oracle like everything else."""
+    rng = np.random.default_rng(77)
+    n, cap, k = 600_000, 20_000, 2_500
+    x, y, z = rng.uniform(0.0, 200.0, n), rng.uniform(0.0, 200.0, n), rng.uniform(0.0, 200.0, n)
+    sampled = np.flatnonzero(np.arange(n) % 256 < 8)
+    slots = rng.permutation(sampled)[: 6 * k].reshape(6, k)
+    for c, centre in enumerate([(30.0, 30.0, 30.0), (170.0, 40.0, 35.0), (45.0, 160.0, 30.0), (160.0, 165.0, 40.0),
+                                (35.0, 40.0, 170.0), (165.0, 160.0, 165.0)]):
+        x[slots[c]], y[slots[c]], z[slots[c]] = (centre[a] + rng.normal(0.0, 0.05, k) for a in range(3))
+    rgb = synthetic.index_colors(n)
+    bmin, bmax = np.array([0.0, 0.0, 0.0]), np.array([200.0, 200.0, 200.0])
+    with O.max_points_per_node(cap):
+        want = O.build_closed(0.001, bmin, bmax, x, y, z, rgb, threads=8)
+    t = ctx.build(0.001, pcv.Aabb(bmin, bmax), x, y, z, rgb, max_points_per_node=cap, single_chain=True)
+    info = t.build_info()
+    assert_same(t.to_dict(), want)
+    assert info["single_chain"] and info["replayed_points"] >= 6 * k, info
+
+
+def test_single_chain_is_the_default_from_4M_points_and_keeps_candidate_codes(ctx):
     n = 6_000_000
     x, y, z, rgb, bmin, bmax = synthetic.gaussian_clusters(n, seed=8, num_clusters=24, extent=500.0, sigma_range=(0.3, 9.0))
     t = ctx.build(0.001, pcv.Aabb(bmin, bmax), x, y, z, rgb)
     info = t.build_info()
     assert info["single_chain"] and info["attempts"] == 0, info
     assert info["kept_code_points"] > 0, info  # some node sat in the band and turned out to be a leaf
+    assert info["continued_points"] > 0, info  # and some node in the band was split: its points continued their chain
     assert_same(t.to_dict(), O.build_closed(0.001, bmin, bmax, x, y, z, rgb, threads=8))
     st = t.stage_ms()
     assert st["sort_keys"] == 0.0 and st["leaf_encode"] > 0.0  # no key sort of the full input on this path
