@@ -6,8 +6,11 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# PCV_HIP_LIBRARY: an alternative in-tree build of the same sources (tools/build_variants.sh, experiments only)
-LIB_PATH = os.environ.get("PCV_HIP_LIBRARY") or os.path.join(_HERE, "libpcv_hip.so")
+# PCV_HIP_LIBRARY: an alternative in-tree build of the same sources — "exp" = libpcv_hip_exp.so, the build with
+# -DPCV_EXPERIMENTS whose environment switches are live (A/B scripts under tools/, tests of the alternative kernels), or
+# a path (tools/build_variants.sh). The default library reads no environment variable.
+_alt = os.environ.get("PCV_HIP_LIBRARY")
+LIB_PATH = os.path.join(_HERE, "libpcv_hip_exp.so") if _alt == "exp" else (_alt or os.path.join(_HERE, "libpcv_hip.so"))
 
 PCV_OK = 0
 PCV_E_INVALID, PCV_E_HIP, PCV_E_IO, PCV_E_OOM, PCV_E_DEPTH, PCV_E_NOT_FOUND = -1, -2, -3, -4, -5, -6

@@ -458,7 +458,7 @@ int pcv_make_levels(const double bmin[3], const double bmax[3], double resolutio
       // pcv_digit_from_codes: valid where 1.01 u (2.5 A / e + 3) < 1 / (2 M) (u = 2^-53); required here with a factor
       // of two in hand. Level 0 has no codes (the chain starts from the raw position).
       static const bool digit_shortcut = [] {  // PCV_DIGIT_SHORTCUT=0: always compare against the centre (experiments)
-        const char* ev = getenv("PCV_DIGIT_SHORTCUT");
+        const char* ev = pcv_experiment("PCV_DIGIT_SHORTCUT");
         return !ev || atoi(ev) != 0;
       }();
       if (digit_shortcut && j >= 1 && (c[j] == PCV_ENC_UINT8 || c[j] == PCV_ENC_UINT16) && std::isfinite(amax) && e[j] > 0.0) {
@@ -791,7 +791,7 @@ extern "C" int pcv_build_begin_routed(pcv_ctx* ctx, const pcv_build_params* para
 // sort kernel queued), printed to stderr
 #include <chrono>
 static void host_lap(const char* what, bool reset = false) {
-  static const bool on = getenv("PCV_HOST_TIMING") != nullptr;
+  static const bool on = pcv_experiment("PCV_HOST_TIMING") != nullptr;
   static std::chrono::steady_clock::time_point t0;
   if (!on) return;
   const auto now = std::chrono::steady_clock::now();
@@ -903,7 +903,7 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
   // sample stride: every 32nd point (>= 3 000 sample points per full node at the reference's capacity); small forced
   // builds (tests) sample more densely
   uint64_t stride = 32;
-  if (const char* e = getenv("PCV_SPEC_STRIDE")) stride = (uint64_t)std::max(1, atoi(e));  // experiments
+  if (const char* e = pcv_experiment("PCV_SPEC_STRIDE")) stride = (uint64_t)std::max(1, atoi(e));  // experiments
   while (stride > 1 && n / stride < 4096) stride >>= 1;
   const uint64_t ns = n / stride;
   if (ns == 0) return PCV_OK;
@@ -934,7 +934,7 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
   // 12-byte records (pcv_internal.h) unless switched off (PCV_COMPACT_RECORDS=0, experiments) or the predicted tree could
   // outgrow the 24 rank bits of the key
   static const bool compact_on = [] {
-    const char* e = getenv("PCV_COMPACT_RECORDS");
+    const char* e = pcv_experiment("PCV_COMPACT_RECORDS");
     return !e || atoi(e) != 0;
   }();
   const bool compact = compact_on && tcap <= (1u << 24);
@@ -976,7 +976,7 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
     // The sample is taken in clumps of 8 consecutive points (one clump every 8 x stride): read one by one, every
     // sampled coordinate costs a full cache line (1.2 GB and 0.23 ms for the 3.1 M sample points of a 100 M cloud)
     static const uint32_t clump_shift = [] {
-      const char* e = getenv("PCV_SAMPLE_CLUMP_SHIFT");  // experiments: 0 = single points
+      const char* e = pcv_experiment("PCV_SAMPLE_CLUMP_SHIFT");  // experiments: 0 = single points
       return e ? (uint32_t)std::min(6, std::max(0, atoi(e))) : 3u;
     }();
     pcv_launch_chain_keys(ctx, lv, ns, stride, d.x, d.y, d.z, skeys_a, false, d.routed, stride > 1 ? clump_shift : 0u);
@@ -1623,7 +1623,7 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
   // and the work lists of the leaf-wise settle / climb kernels (pcv_spec.h; PCV_SETTLE_BY_LEAF=0: the slot-wise settle
   // kernel and the flat climb launch, experiments)
   static const bool by_leaf = [] {
-    const char* e = getenv("PCV_SETTLE_BY_LEAF");
+    const char* e = pcv_experiment("PCV_SETTLE_BY_LEAF");
     return !e || atoi(e) != 0;
   }();
   uint32_t* u_climb_base = (uint32_t*)(u_leaf_rec + num_leaves);

@@ -538,7 +538,7 @@ int pcv_launch_aabb(pcv_ctx* ctx, uint64_t n, const double* x, const double* y, 
   uint64_t want = (n + (uint64_t)kAabbBlock * 2 * 8 - 1) / ((uint64_t)kAabbBlock * 2 * 8);
   // two resident workgroups per CU stream best: 512 blocks read 100 M points at 6.3 TB/s, 2048 at 5.5, 256 at 4.6
   static const int maxb = [] {
-    if (const char* e = getenv("PCV_AABB_BLOCKS")) return std::min(2048, std::max(1, atoi(e)));  // experiments
+    if (const char* e = pcv_experiment("PCV_AABB_BLOCKS")) return std::min(2048, std::max(1, atoi(e)));  // experiments
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
       cus = 256;

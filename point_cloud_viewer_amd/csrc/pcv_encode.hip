@@ -754,7 +754,7 @@ void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* w
   PcvProf prof(ctx, PCV_K_SPEC_ENCODE);
   // PCV_SPEC_BIN (experiments): 0 = input order, 256 / 512 / 1024 = depth binning inside workgroups of that size
   static const int bin_mode = [] {
-    const char* e = getenv("PCV_SPEC_BIN");
+    const char* e = pcv_experiment("PCV_SPEC_BIN");
     return e ? atoi(e) : 512;
   }();
   const bool bin = bin_mode != 0 && depth_grid != nullptr;
@@ -835,7 +835,7 @@ void pcv_launch_promote_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvPromo
   } else {
     PcvProf prof(ctx, PCV_K_PROMOTE_ENCODE);
     static const int slots = [] {  // PCV_SETTLE_SLOTS (experiments): 1, 2 or 4 sorted slots per lane
-      const char* e = getenv("PCV_SETTLE_SLOTS");
+      const char* e = pcv_experiment("PCV_SETTLE_SLOTS");
       return e ? atoi(e) : 2;
     }();
 #define PCV_SETTLE(S, C)                                                                                                 \

@@ -208,7 +208,7 @@ static int write_nodes(pcv_octree* t, const char* directory, uint32_t min_level,
   // creating files in ONE directory serialises on the directory lock: past ~8 writers the lock convoy costs more than
   // the extra copies gain (measured on tmpfs: 8 threads 40 ms, 32 threads 50 ms, 64 threads 144 ms for 12 009 files)
   if (nthreads > 8) nthreads = 8;
-  if (const char* e = getenv("PCV_WRITER_THREADS")) nthreads = (unsigned)std::max(1, atoi(e));  // experiments
+  if (const char* e = pcv_experiment("PCV_WRITER_THREADS")) nthreads = (unsigned)std::max(1, atoi(e));  // experiments
   if (nthreads > count) nthreads = count ? (unsigned)count : 1;
   std::atomic<size_t> next{0};
   std::atomic<int> failed{0};

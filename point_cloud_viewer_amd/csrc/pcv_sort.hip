@@ -566,7 +566,7 @@ __global__ __launch_bounds__(kBlock, kHasVec ? PCV_REC_WAVES : 4) void downsweep
 // the workgroup size, the records per lane and the digit-state size as template parameters, so that the occupancy can
 // be chosen: the 256-lane / 16-per-lane kernel above needs 235 VGPRs and 54 KB of LDS (two workgroups = 8 waves per CU).
 //   BLOCK x KPT = tile (records staged through LDS per round); R = digit values (128 for digits of <= 7 bits);
-//   WPE = waves per SIMD the register allocation is asked to admit; NT: non-temporal global stores.
+//   WPE = waves per SIMD the register allocation is asked to admit; NT (unused): non-temporal stores cost 35 %.
 // The output phase runs in groups of four LDS reads + four stores (a scheduling barrier between the groups keeps the
 // compiler from hoisting all reads of the tile into registers), with the next tile's loads already in flight.
 template <int NW, int R>
@@ -732,13 +732,8 @@ __global__ __launch_bounds__(BLOCK, WPE) void downsweep_rec12_kernel(const uint3
         const uint32_t p = (j0 + j) * BLOCK + t;
         if (full || p < tile_n) {
           const uint32_t g = S.delta[(k4[j] >> shift) & mask] + p;
-          if (NT) {
-            __builtin_nontemporal_store(k4[j], keys_out + g);
-            __builtin_nontemporal_store((uint64_t)v4[j].x | ((uint64_t)v4[j].y << 32), reinterpret_cast<uint64_t*>(vec_out + g));
-          } else {
-            keys_out[g] = k4[j];
-            vec_out[g] = v4[j];
-          }
+          keys_out[g] = k4[j];
+          vec_out[g] = v4[j];
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -749,9 +744,14 @@ __global__ __launch_bounds__(BLOCK, WPE) void downsweep_rec12_kernel(const uint3
 }
 
 
-// PCV_REC_VARIANT (experiments): 1 = 256 lanes x 16, three workgroups per CU where the digit state allows (<= 7-bit digits);
-// 2 = 512 x 8 (two workgroups = 16 waves per CU); 3 = 1024 x 8 (tiles of 8 192, one workgroup per CU); 4 = 512 x 16 (tiles
-// of 8 192); 5 = 256 x 16 with non-temporal stores; 6 = 512 x 8 with non-temporal stores
+// Geometry of the 12-byte record downsweep. What moves this kernel is the length of the write runs (tile / digit
+// values), not the occupancy (r03a / r03d A/B at 100 M records, both passes together, one box per line):
+//   tiles of 4 096: 256 lanes x 16 at 8 waves per CU 1.36-1.40 ms, at 12 waves per CU 1.40, 512 x 8 at 16 waves per CU 1.36
+//   tiles of 8 192: 1 024 x 8 1.20 ms (ships), 512 x 16 1.25; non-temporal stores +35 %
+//   tiles of 16 384 by staging keys and payloads one after the other through the same LDS: 1.27-1.29 against 1.01-1.11
+//   (two more barriers per tile, one workgroup per CU) — dropped
+// PCV_REC_VARIANT (libpcv_hip_exp.so): 3 = 1 024 x 8 (default), 4 = 512 x 16, 2 = 512 x 8 (tiles of 4 096), 0 = the
+// 256-lane kernel above
 static void rec12_launch(pcv_ctx* ctx, int variant, const SortGeom& g, const uint32_t* src, uint32_t* dst, uint64_t n, int shift,
                          int nbits, const uint32_t* hist, const uint32_t* totals, const uint2* vin, uint2* vout) {
 #define PCV_REC12(B, K, R, W, NT)                                                                                              \
@@ -759,29 +759,17 @@ static void rec12_launch(pcv_ctx* ctx, int variant, const SortGeom& g, const uin
                      shift, nbits, hist, totals, vin, vout)
   const bool narrow = nbits <= 7;
   switch (variant) {
-    case 1:
-      if (narrow) PCV_REC12(256, 16, 128, 3, false);
-      else PCV_REC12(256, 16, 256, 3, false);
-      break;
     case 2:
       if (narrow) PCV_REC12(512, 8, 128, 4, false);
       else PCV_REC12(512, 8, 256, 4, false);
-      break;
-    case 3:
-      if (narrow) PCV_REC12(1024, 8, 128, 4, false);
-      else PCV_REC12(1024, 8, 256, 4, false);
       break;
     case 4:
       if (narrow) PCV_REC12(512, 16, 128, 2, false);
       else PCV_REC12(512, 16, 256, 2, false);
       break;
-    case 5:
-      if (narrow) PCV_REC12(256, 16, 128, 3, true);
-      else PCV_REC12(256, 16, 256, 3, true);
-      break;
     default:
-      if (narrow) PCV_REC12(512, 8, 128, 4, true);
-      else PCV_REC12(512, 8, 256, 4, true);
+      if (narrow) PCV_REC12(1024, 8, 128, 4, false);
+      else PCV_REC12(1024, 8, 256, 4, false);
   }
 #undef PCV_REC12
 }
@@ -795,16 +783,13 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
   const bool records = payload && (payload->vec_in || payload->nwords > 0);
   if (records && sizeof(KeyT) != 4) return ctx->fail(PCV_E_INVALID, "record sort needs 32-bit keys");
   const bool compact = records && payload->vec_in && payload->vec_bytes == 8;  // 12-byte records
-  // geometry of the 12-byte record downsweep: 1 024 lanes x 8 records, tiles of 8 192 (PCV_REC_VARIANT: the other
-  // geometries of rec12_launch; 0 = the 256-lane kernel that also carries extra planes). What moves this kernel is the
-  // length of the write runs, not the occupancy: tiles of 4 096 at 8 / 12 / 16 waves per CU all take 0.68-0.70 ms per pass
-  // at 100 M records, tiles of 8 192 0.60-0.63 (r03a A/B, one box); non-temporal stores cost 35 %
+  // geometry of the 12-byte record downsweep: 1 024 lanes x 8 records, tiles of 8 192 (rec12_launch)
   static const int rec_variant = [] {
-    const char* e = getenv("PCV_REC_VARIANT");
+    const char* e = pcv_experiment("PCV_REC_VARIANT");
     return e ? atoi(e) : 3;
   }();
   const bool rec12 = compact && payload->nwords == 0 && rec_variant > 0;
-  SortGeom g = make_geom(n, rec12 && (rec_variant == 3 || rec_variant == 4) ? 8192 : kTileUnit);
+  SortGeom g = make_geom(n, rec12 && rec_variant != 2 ? 8192 : kTileUnit);
   uint32_t* hist = (uint32_t*)scratch;
   uint32_t* totals = hist + (size_t)kRadix * kMaxGroups;
   bool in_a = true;
@@ -855,29 +840,15 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
         rp.plane_out[w] = in_a ? payload->out[w] : payload->in[w];
       }
       static const bool prefetch = [] {
-        const char* e = getenv("PCV_REC_PREFETCH");  // 0 = the unpipelined kernel (experiments)
+        const char* e = pcv_experiment("PCV_REC_PREFETCH");  // 0 = the unpipelined kernel (experiments)
         return !e || atoi(e) != 0;
       }();
       PcvProf prof(ctx, PCV_K_SORT_DOWNSWEEP_REC);
-      // (experiment, off: PCV_REC_RADIX128=1) the 128-entry digit state fits THREE workgroups of the 12-byte kernel on a CU
-      // — and makes both passes 2.3 x slower (2.49 vs 1.10 ms at 100 M): more concurrent scatter streams, not fewer, is
-      // what hurts this kernel
-      static const bool narrow_state = [] {
-        const char* e = getenv("PCV_REC_RADIX128");
-        return e && atoi(e) != 0;
-      }();
-      static const size_t lds_pad = [] {  // (experiment) unused dynamic LDS: fewer workgroups per CU
-        const char* e = getenv("PCV_REC_LDS_PAD");
-        return e ? (size_t)atoi(e) : (size_t)0;
-      }();
       if (rec12)
         rec12_launch(ctx, rec_variant, g, (const uint32_t*)src, (uint32_t*)dst, n, shift, nbits, hist, totals, (const uint2*)rp.vec_in,
                      (uint2*)rp.vec_out);
-      else if (compact && nbits <= 7 && narrow_state)
-        hipLaunchKernelGGL((downsweep_rec_kernel<true, true, uint2, 128>), dim3(g.groups), dim3(kBlock), 0, ctx->stream, (const uint32_t*)src,
-                           (uint32_t*)dst, n, g.chunk, g.groups, shift, nbits, hist, totals, rp);
       else if (compact)
-        hipLaunchKernelGGL((downsweep_rec_kernel<true, true, uint2>), dim3(g.groups), dim3(kBlock), lds_pad, ctx->stream, (const uint32_t*)src,
+        hipLaunchKernelGGL((downsweep_rec_kernel<true, true, uint2>), dim3(g.groups), dim3(kBlock), 0, ctx->stream, (const uint32_t*)src,
                            (uint32_t*)dst, n, g.chunk, g.groups, shift, nbits, hist, totals, rp);
       else if (payload->vec_in && prefetch)
         hipLaunchKernelGGL((downsweep_rec_kernel<true, true>), dim3(g.groups), dim3(kBlock), 0, ctx->stream, (const uint32_t*)src,

@@ -366,7 +366,7 @@ extern "C" int pcv_spec_selftest(const uint64_t* keys, uint64_t n, uint32_t stri
   }
   PcvTrueTree tt;
   const PcvSpecStatus status = pcv_spec_resolve(p, tree, counts.data(), &tt);
-  if (getenv("PCV_SPEC_TIME")) {  // host cost of the build's critical section (tools/spec_resolve_time.py)
+  if (pcv_experiment("PCV_SPEC_TIME")) {  // host cost of the build's critical section (tools/spec_resolve_time.py)
     const auto t0 = std::chrono::steady_clock::now();
     for (int rep = 0; rep < 200; ++rep) {
       PcvTrueTree again;

@@ -21,6 +21,19 @@
 //     the exact path.
 #pragma once
 #include <stdint.h>
+#include <stdlib.h>
+
+// Experiment switches (environment variables, each read once per process) exist only in libpcv_hip_exp.so, the build made
+// with -DPCV_EXPERIMENTS for the A/B scripts under tools/ and for the tests of the alternative kernels. The shipped
+// library reads no environment variable.
+inline const char* pcv_experiment(const char* name) {
+#ifdef PCV_EXPERIMENTS
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
 
 #include <vector>
 

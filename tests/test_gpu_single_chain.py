@@ -70,13 +70,14 @@ def test_the_cases_above_covered_every_branch_of_the_prediction():
 
 
 def test_oversampled_clusters_replay_the_chain_from_their_coordinates(ctx):
-    """A sample that over-counts: six tight clusters of 2 500 points sit exactly at the sampled input positions (8
-    consecutive points every 256), so the prediction splits their level-2 nodes many levels deep — far outside the
-    candidate band — while the exact counts (11-12 k < capacity 20 k) make those nodes LEAVES. Their points went down
-    to candidates below the leaf, so their records hold codes of a deeper level: the one case that still needs the
-    coordinates (PCV_SPEC_MAP_REPLAY). Byte-exact against the oracle like everything else."""
+    """A sample that over-counts: six tight clusters of 700 points sit exactly at the sampled input positions (8
+    consecutive points every 256), so their level-2 nodes look like 30 k points to the prediction — above the candidate
+    band, split without kept codes — while the exact counts (~10 k < capacity 20 k) make those nodes LEAVES. Their points
+    went down to candidates below the leaf, so their records hold codes of a deeper level: the one case that still needs
+    the coordinates (PCV_SPEC_MAP_REPLAY). (The clusters take a fifth of the sampled slots; more would starve the sample
+    of background points and send the whole build to the exact pipeline.) Byte-exact like everything else."""
     rng = np.random.default_rng(77)
-    n, cap, k = 600_000, 20_000, 2_500
+    n, cap, k = 600_000, 20_000, 700
     x, y, z = rng.uniform(0.0, 200.0, n), rng.uniform(0.0, 200.0, n), rng.uniform(0.0, 200.0, n)
     sampled = np.flatnonzero(np.arange(n) % 256 < 8)
     slots = rng.permutation(sampled)[: 6 * k].reshape(6, k)
@@ -227,6 +228,8 @@ def test_alternative_kernels_behind_the_switches_are_byte_exact_too(env, record_
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, "-c", _ALT_PATH_SCRIPT, root, str(record_bytes)], env=dict(os.environ, **env),
+    # the switches only exist in the experiment build of the library (libpcv_hip_exp.so, -DPCV_EXPERIMENTS)
+    out = subprocess.run([sys.executable, "-c", _ALT_PATH_SCRIPT, root, str(record_bytes)],
+                         env=dict(os.environ, PCV_HIP_LIBRARY="exp", **env),
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "alt-path ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]

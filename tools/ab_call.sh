@@ -9,7 +9,7 @@ NAMES=""
 for v in $VARIANTS; do
   name=${v%%:*}; NAMES="$NAMES $name"
   if [ "$name" != "$v" ]; then
-    env "${v#*:}" timeout 200 $B > gpurun_out/${T}_bench_$name.json 2> gpurun_out/${T}_bench_$name.err
+    env PCV_HIP_LIBRARY=exp "${v#*:}" timeout 200 $B > gpurun_out/${T}_bench_$name.json 2> gpurun_out/${T}_bench_$name.err
   else
     PCV_HIP_LIBRARY=$PWD/point_cloud_viewer_amd/libpcv_hip_$name.so timeout 200 $B > gpurun_out/${T}_bench_$name.json 2> gpurun_out/${T}_bench_$name.err
   fi

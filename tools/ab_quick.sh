@@ -9,7 +9,7 @@ for v in $RUNS; do
   if [ -f "$PWD/point_cloud_viewer_amd/libpcv_hip_$arg.so" ]; then
     PCV_HIP_LIBRARY=$PWD/point_cloud_viewer_amd/libpcv_hip_$arg.so timeout 200 $B > gpurun_out/${T}_$i.json 2> gpurun_out/${T}_$i.err
   elif [ -n "$arg" ]; then
-    env "$arg" timeout 200 $B > gpurun_out/${T}_$i.json 2> gpurun_out/${T}_$i.err
+    env PCV_HIP_LIBRARY=exp "$arg" timeout 200 $B > gpurun_out/${T}_$i.json 2> gpurun_out/${T}_$i.err
   else
     timeout 200 $B > gpurun_out/${T}_$i.json 2> gpurun_out/${T}_$i.err
   fi

@@ -2,6 +2,7 @@
 """Host arrays -> octree directory on tmpfs with different writer-thread counts (PCV_WRITER_THREADS): where the file
 side of the end-to-end path saturates. usage (GPU box): python tools/e2e_probe.py [points]"""
 import os
+os.environ.setdefault("PCV_HIP_LIBRARY", "exp")  # the switches live in the experiment build
 import shutil
 import subprocess
 import sys

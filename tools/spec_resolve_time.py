@@ -2,6 +2,7 @@
 8 M Gaussian-cluster points with capacity 8 000 give about the node counts of the 100 M-point bench cloud at 100 000.
     PCV_SPEC_TIME=1 python tools/spec_resolve_time.py"""
 import os
+os.environ.setdefault("PCV_HIP_LIBRARY", "exp")  # the switches live in the experiment build
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
