@@ -692,6 +692,10 @@ def main():
         elapsed = float(tt.item())
     ctx.set_profiling(False)
     kstats = ctx.kernel_stats()
+    per_rank = None
+    if dist is not None:  # every rank's view of its last step: rows / bytes moved and the stage times (exchange, local build, merge)
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, info.get("exchange"))
 
     total_points = total * args.steps
     value = total_points / elapsed / 1e6  # Mpoints/s, whole job
@@ -917,6 +921,27 @@ def main():
                 b2 = time.perf_counter()
                 files = len(os.listdir(os.path.join(d, "octree")))
                 t.free()
+            # (c) the reference's own entry: build_octree_from_file on a binary PLY (float x y z + uchar r g b = 15 bytes per
+            # point) — the vertex records go up as they are and are decoded on the device (pcv_build_octree_from_ply)
+            rec = np.empty(n, dtype=[("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("r", "u1"), ("g", "u1"), ("b", "u1")])
+            rec["x"], rec["y"], rec["z"] = hx, hy, hz
+            rec["r"], rec["g"], rec["b"] = hrgb[:, 0], hrgb[:, 1], hrgb[:, 2]
+            ply_path = os.path.join(d, "cloud.ply")
+            with open(ply_path, "wb") as f:
+                f.write((f"ply\nformat binary_little_endian 1.0\nelement vertex {n}\nproperty float x\nproperty float y\n"
+                         "property float z\nproperty uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n").encode())
+                rec.tofile(f)
+            del rec
+            for attempt in range(2):
+                shutil.rmtree(os.path.join(d, "octree"), ignore_errors=True)
+                torch.cuda.synchronize()
+                c0 = time.perf_counter()
+                t = ctx.build_from_ply(args.resolution, ply_path)
+                c1 = time.perf_counter()
+                t.write_dir(os.path.join(d, "octree"))
+                c2 = time.perf_counter()
+                ply_nodes = t.num_nodes
+                t.free()
         finally:
             shutil.rmtree(d, ignore_errors=True)
         e2e = {"h2d_plus_build_ms": round((a1 - a0) * 1e3, 1), "d2h_blobs_ms": round((a2 - a1) * 1e3, 1),
@@ -924,6 +949,12 @@ def main():
                "Mpoints_per_s_h2d_build_d2h": round(n / (a2 - a0) / 1e6, 1),
                "Mpoints_per_s_incl_files": round(n / (b2 - b0) / 1e6, 1),
                "input_bytes_per_point": 27, "h2d_GBps": round(27.0 * n / max((a1 - a0) - elapsed / args.steps, 1e-9) / 1e9, 1),
+               "from_ply_file": {"input_bytes_per_point": 15, "read_upload_decode_build_ms": round((c1 - c0) * 1e3, 1),
+                                 "d2h_overlapped_with_file_writes_tmpfs_ms": round((c2 - c1) * 1e3, 1),
+                                 "Mpoints_per_s_incl_files": round(n / (c2 - c0) / 1e6, 1), "nodes": ply_nodes,
+                                 "note": "build_octree_from_file on a binary PLY on tmpfs (float x y z + uchar r g b): vertex records "
+                                         "pread into the pinned ring and uploaded as they are, cast to f64 on the device (ply.rs:488-493); "
+                                         "the f32 coordinates make this a different (coarser) cloud than the one `value` is measured on"},
                "note": "pageable numpy inputs staged through a pinned ring (one DMA per 32 MiB chunk), bounding box computed "
                        "on the device; creating the node files in ONE directory serialises on the directory lock "
                        "(reference layout); not part of `value`"}
@@ -953,6 +984,11 @@ def main():
             "roofline": roofline, "encode_sort": encode_sort, "cpu_baseline": cpu, "parity": parity, "tree_digest": tree_digest,
             "end_to_end": e2e,
             "build_info": info.get("build"), "exchange": info.get("exchange"),
+            "exchange_per_rank": None if per_rank is None else [
+                None if e is None else {"rank": r, "rows_sent": e["rows_sent"], "rows_received": e["rows_received"],
+                                        "bytes_sent": e["bytes_sent"], "bytes_received": e["bytes_received"], "ms": e["ms"]}
+                for r, e in enumerate(per_rank)],
+            "rccl_ranks": world if dist is not None else None,
             "stage_ms": {k: round(v, 3) for k, v in (info.get("stages") or {}).items()},
             "wall_ms_each_step": per_step_ms, "gpu_ms_each_step": (info.get("gpu_ms") or [])[-args.steps:],
             "kernel_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in kstats.items() if v[0] > 0},

@@ -1,6 +1,6 @@
 /* build_octree.c — the reference's `build_octree` binary (src/bin/build_octree.rs:41-53) on top of the C ABI, in plain
  * C11: PLY -> octree directory. Proves that include/pcv_hip.h is a C header and shows the call sequence a non-Python
- * host uses:  pcv_ply_read -> pcv_build_octree(PCV_BUILD_COMPUTE_BBOX) -> pcv_octree_write_dir
+ * host uses:  pcv_build_octree_from_ply (decode + bounding box on the device) -> pcv_octree_write_dir
  * == build_octree_from_file(output_directory, resolution, input, &["color", "intensity"]) (generation.rs:272-287).
  *
  *   build_octree <input.ply> --output-directory <dir> [--resolution 0.001] [--num-threads N (ignored: GPU build)]
@@ -29,44 +29,26 @@ int main(int argc, char** argv) {
   }
   if (!input || !outdir) return usage();
 
-  char err[512] = {0};
-  pcv_ply* ply = NULL;
-  int rc = pcv_ply_read(input, &ply, err, sizeof(err));
-  if (rc != PCV_OK) {
-    fprintf(stderr, "cannot read %s: %s\n", input, err);
-    return 1;
-  }
-  pcv_points pts;
-  pcv_ply_points(ply, &pts);
-  if (!pts.color) { /* on_disk.rs:20-22: the octree format always carries colour */
-    fprintf(stderr, "%s has no red/green/blue properties\n", input);
-    pcv_ply_free(ply);
-    return 1;
-  }
-  if (!pts.intensity) { /* the reference binary asks for "intensity" and panics without it */
-    fprintf(stderr, "%s has no 'intensity' property (the reference build_octree requires it)\n", input);
-    pcv_ply_free(ply);
-    return 1;
-  }
   pcv_ctx* ctx = NULL;
+  int rc;
   if ((rc = pcv_ctx_create(0, NULL, &ctx)) != PCV_OK) {
     fprintf(stderr, "no HIP device (pcv_ctx_create: %d); there is no CPU fallback\n", rc);
-    pcv_ply_free(ply);
     return 1;
   }
   pcv_build_params params;
   memset(&params, 0, sizeof(params));
   params.resolution = resolution;
-  params.flags = PCV_BUILD_COMPUTE_BBOX; /* find_bounding_box on the device (generation.rs:256-270) */
+  /* build_octree_from_file (generation.rs:272-287): the vertex records go to the device as they are in the file and
+   * are decoded there; find_bounding_box runs on the device too. Like the reference binary (src/bin/build_octree.rs:47-52)
+   * this asks for "intensity" and fails on a file without it. */
   pcv_octree* tree = NULL;
-  rc = pcv_build_octree(ctx, &params, &pts, &tree);
+  rc = pcv_build_octree_from_ply(ctx, &params, input, 1, &tree);
   if (rc == PCV_OK) rc = pcv_octree_write_dir(tree, outdir);
-  if (rc != PCV_OK) fprintf(stderr, "build failed (%d): %s\n", rc, pcv_last_error(ctx));
+  if (rc != PCV_OK) fprintf(stderr, "build of %s failed (%d): %s\n", input, rc, pcv_last_error(ctx));
   else
     printf("%llu points -> %llu nodes in %s\n", (unsigned long long)pcv_octree_num_points(tree),
            (unsigned long long)pcv_octree_num_nodes(tree), outdir);
   pcv_octree_free(tree);
-  pcv_ply_free(ply);
   pcv_ctx_destroy(ctx);
   return rc == PCV_OK ? 0 : 1;
 }

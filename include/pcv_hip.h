@@ -195,6 +195,14 @@ int pcv_octree_device_blob(const pcv_octree* t, int which, const void** dptr, ui
  * the context's stream (follow with pcv_ctx_synchronize or stream-ordered work); a copy to host memory is complete on
  * return. */
 int pcv_octree_copy_node(const pcv_octree* tree, uint64_t i, int which, void* dst, uint64_t capacity, int mem);
+/* The same for a list of nodes into ONE destination buffer: copies[k].dst_offset[which] is where node copies[k].node's
+ * .xyz / .rgb / .intensity bytes go (UINT64_MAX: skip that file kind). The multi-GPU build uses it to lay its share of
+ * the root / level-1 nodes out for the top all-reduce in one call. Same completion rules as pcv_octree_copy_node. */
+typedef struct pcv_node_copy {
+  uint64_t node;
+  uint64_t dst_offset[3];
+} pcv_node_copy;
+int pcv_octree_copy_nodes(const pcv_octree* tree, const pcv_node_copy* copies, uint64_t count, void* dst, uint64_t capacity, int mem);
 /* Write `<NodeId>.xyz/.rgb/.intensity` + meta.pb (version 13) exactly as the reference lays them out
  * (src/read_write/raw.rs:374-449, node_writer.rs:78-89, generation.rs:390-402). */
 int pcv_octree_write_dir(pcv_octree* t, const char* directory);
@@ -342,6 +350,13 @@ uint64_t pcv_ply_num_points(const pcv_ply* ply);
 /* Fills `out` with host pointers owned by `ply` (color / intensity are NULL when the file has none). */
 int pcv_ply_points(const pcv_ply* ply, pcv_points* out);
 void pcv_ply_free(pcv_ply* ply);
+/* build_octree_from_file (src/octree/generation.rs:272-287) with the decode on the device: the vertex records of the
+ * file go up as they are (15 bytes per point for float x y z + uchar r g b instead of the 27 of f64 SoA arrays), one HIP
+ * kernel casts x / y / z to f64 and adds the header offset like ply.rs:488-493, then the build runs with
+ * PCV_BUILD_COMPUTE_BBOX (params->bbox_* are ignored). Same files as pcv_ply_read + pcv_build_octree; the PLY must
+ * have colour, and `intensity` (float) when with_intensity != 0. */
+int pcv_build_octree_from_ply(pcv_ctx* ctx, const pcv_build_params* params, const char* path, int with_intensity,
+                              pcv_octree** out);
 
 /* ---- octree loading (viewer side) ------------------------------------------------------------ */
 /* Replaces Octree::from_data_provider over an OnDiskDataProvider (src/octree/mod.rs:156-215,

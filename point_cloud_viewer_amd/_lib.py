@@ -40,6 +40,10 @@ class Points(C.Structure):
                 ("color_stride", C.c_uint32), ("intensity", C.c_void_p), ("mem", C.c_int32)]
 
 
+class NodeCopy(C.Structure):
+    _fields_ = [("node", C.c_uint64), ("dst_offset", C.c_uint64 * 3)]
+
+
 class BuildParams(C.Structure):
     _fields_ = [("resolution", C.c_double), ("bbox_min", C.c_double * 3), ("bbox_max", C.c_double * 3),
                 ("max_points_per_node", C.c_uint32), ("flags", C.c_uint32)]
@@ -135,6 +139,7 @@ _SIGNATURES = {
     "pcv_write_meta": (C.c_int, [C.c_char_p, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(NodeInfo),
                                  C.c_uint64]),
     "pcv_octree_copy_node": (C.c_int, [_vp, C.c_uint64, C.c_int, _vp, C.c_uint64, C.c_int]),
+    "pcv_octree_copy_nodes": (C.c_int, [_vp, C.POINTER(NodeCopy), C.c_uint64, _vp, C.c_uint64, C.c_int]),
     "pcv_build_begin": (C.c_int, [_vp, C.POINTER(BuildParams), C.POINTER(Points), C.POINTER(_vp)]),
     "pcv_build_top_streams": (C.c_int, [_vp, C.POINTER(TopStreams)]),
     "pcv_build_finish": (C.c_int, [_vp, C.POINTER(TopLayout)]),
@@ -151,6 +156,7 @@ _SIGNATURES = {
     "pcv_ply_num_points": (C.c_uint64, [_vp]),
     "pcv_ply_points": (C.c_int, [_vp, C.POINTER(Points)]),
     "pcv_ply_free": (None, [_vp]),
+    "pcv_build_octree_from_ply": (C.c_int, [_vp, C.POINTER(BuildParams), C.c_char_p, C.c_int, C.POINTER(_vp)]),
     "pcv_octree_open_dir": (C.c_int, [_vp, C.c_char_p, C.POINTER(_vp)]),
     "pcv_shapes_create": (C.c_int, [_vp, C.POINTER(Shape), C.c_uint32, C.POINTER(_vp)]),
     "pcv_shapes_free": (None, [_vp]),

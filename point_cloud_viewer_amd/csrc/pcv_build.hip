@@ -14,6 +14,7 @@
 //
 // Everything between the first and last kernel stays in HBM; the only host round trip is the (small) node
 // table. No CPU fallback exists: if HIP fails the call fails.
+#include <atomic>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -187,6 +188,18 @@ int pcv_ctx::h2d(void* dst, const void* src, size_t bytes) {
     PCV_HIP_CHECK(this, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
     return PCV_OK;
   }
+  const uint8_t* from = (const uint8_t*)src;
+  return h2d_fill(dst, bytes, [from](uint8_t* to, size_t off, size_t len) {
+    std::memcpy(to, from + off, len);
+    return true;
+  });
+}
+
+// Host -> device through the ring of pinned chunks: `fill(to, off, len)` produces bytes [off, off + len) of the source
+// into pinned memory (a memcpy from pageable memory, a pread from a file) and is called from the context's host threads,
+// 2 MiB per call, several calls in parallel; one DMA per 32 MiB chunk follows. false from `fill` -> PCV_E_IO.
+int pcv_ctx::h2d_fill(void* dst, size_t bytes, const std::function<bool(uint8_t*, size_t, size_t)>& fill) {
+  if (bytes == 0) return PCV_OK;
   if (!ring[0]) {
     for (int k = 0; k < kRingSlots; ++k) {
       if (hipHostMalloc(&ring[k], kRingChunk, hipHostMallocDefault) != hipSuccess) return fail(PCV_E_OOM, "hipHostMalloc (staging ring)");
@@ -196,17 +209,18 @@ int pcv_ctx::h2d(void* dst, const void* src, size_t bytes) {
     host_pool.start(hw >= 16 ? 7 : (hw > 2 ? hw / 2 - 1 : 0));
   }
   constexpr size_t kPart = 2u << 20;
+  std::atomic<int> bad{0};
   for (size_t off = 0; off < bytes; off += kRingChunk) {
     const size_t len = bytes - off < kRingChunk ? bytes - off : kRingChunk;
     const int slot = ring_next;
     ring_next = (ring_next + 1) % kRingSlots;
     if (ring_busy[slot]) PCV_HIP_CHECK(this, hipEventSynchronize(ring_ev[slot]));  // its previous DMA has left the chunk
     uint8_t* chunk = (uint8_t*)ring[slot];
-    const uint8_t* from = (const uint8_t*)src + off;
     host_pool.run((len + kPart - 1) / kPart, [&](size_t p) {
       const size_t b = p * kPart, e = b + kPart < len ? b + kPart : len;
-      std::memcpy(chunk + b, from + b, e - b);
+      if (!fill(chunk + b, off + b, e - b)) bad.store(1);
     });
+    if (bad.load()) return fail(PCV_E_IO, "reading the source of a host-to-device copy failed");
     PCV_HIP_CHECK(this, hipMemcpyAsync((uint8_t*)dst + off, chunk, len, hipMemcpyHostToDevice, stream));
     PCV_HIP_CHECK(this, hipEventRecord(ring_ev[slot], stream));
     ring_busy[slot] = true;
@@ -753,6 +767,34 @@ extern "C" int pcv_octree_copy_node(const pcv_octree* t, uint64_t i, int which, 
   return PCV_OK;
 }
 
+// Batch form of pcv_octree_copy_node for the multi-GPU top merge: every rank copies its (sparsely filled, global-size)
+// root / level-1 nodes into one buffer that is then all-reduced — one call instead of one per node and file kind.
+extern "C" int pcv_octree_copy_nodes(const pcv_octree* t, const pcv_node_copy* copies, uint64_t count, void* dst, uint64_t capacity,
+                                     int mem) {
+  if (!t || (count && !copies) || (mem != PCV_MEM_HOST && mem != PCV_MEM_DEVICE)) return PCV_E_INVALID;
+  pcv_ctx* ctx = t->ctx;
+  if (!t->directory.empty()) return ctx->fail(PCV_E_INVALID, "pcv_octree_copy_nodes works on built octrees (device blobs)");
+  PCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const hipMemcpyKind kind = mem == PCV_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  for (uint64_t k = 0; k < count; ++k) {
+    const pcv_node_copy& c = copies[k];
+    if (c.node >= t->nodes.size()) return ctx->fail(PCV_E_INVALID, "pcv_octree_copy_nodes: node index out of range");
+    const pcv_node_info& nd = t->nodes[c.node];
+    const uint64_t np = (uint64_t)nd.num_points;
+    const uint8_t* src[3] = {t->d_xyz + nd.xyz_offset, t->d_rgb + nd.point_offset * 3, t->has_intensity ? t->d_int + nd.point_offset * 4 : nullptr};
+    const uint64_t len[3] = {np * 3 * (uint64_t)pcv_bytes_per_coordinate(nd.encoding), np * 3, t->has_intensity ? np * 4 : 0};
+    for (int w = 0; w < 3; ++w) {
+      if (c.dst_offset[w] == UINT64_MAX || len[w] == 0) continue;
+      if (c.dst_offset[w] > capacity || len[w] > capacity - c.dst_offset[w])
+        return ctx->fail(PCV_E_INVALID, "pcv_octree_copy_nodes: destination too small for a node's bytes");
+      if (!dst) return ctx->fail(PCV_E_INVALID, "dst is null");
+      PCV_HIP_CHECK(ctx, hipMemcpyAsync((uint8_t*)dst + c.dst_offset[w], src[w], len[w], kind, ctx->stream));
+    }
+  }
+  if (mem == PCV_MEM_HOST) PCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return PCV_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // the build
 // ------------------------------------------------------------------------------------------------
@@ -789,6 +831,7 @@ extern "C" int pcv_build_begin_routed(pcv_ctx* ctx, const pcv_build_params* para
 // says the tree is deeper than one key word): the caller runs the exact pipeline; nothing of this attempt is kept.
 // PCV_HOST_TIMING=1: host-side lap times of the single-chain build's critical section (counts on the host -> first
 // sort kernel queued), printed to stderr
+#include <atomic>
 #include <chrono>
 static void host_lap(const char* what, bool reset = false) {
   static const bool on = pcv_experiment("PCV_HOST_TIMING") != nullptr;

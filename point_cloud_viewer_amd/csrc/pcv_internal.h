@@ -125,6 +125,7 @@ struct pcv_ctx {
   int ring_next = 0;
   PcvHostPool host_pool;
   int h2d(void* dst, const void* src, size_t bytes);  // asynchronous on `stream` from the device's point of view
+  int h2d_fill(void* dst, size_t bytes, const std::function<bool(uint8_t* to, size_t off, size_t len)>& fill);
   hipEvent_t ev[PCV_NUM_STAGES + 2] = {};
   // per-stage begin / end events of the build in flight (a stage may be recorded out of order or not at all)
   hipEvent_t stage_b[PCV_NUM_STAGES] = {}, stage_e[PCV_NUM_STAGES] = {};

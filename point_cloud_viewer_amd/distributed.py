@@ -399,14 +399,19 @@ class ShardedOctreeBuilder:
             nd = tree.node(i)
             if nd.level <= 1:
                 index_of[_oct.node_name(nd.id_high, nd.id_low)] = i
+        copies = []
         for nd in specs:
             i = index_of.get(nd["name"])
-            if i is None:
-                continue
-            for which, key in enumerate(("xyz", "rgb", "intensity")):
-                off, length = nd[key]
-                if length:
-                    tree.copy_node_into(i, which, top[off:off + length])
+            if i is not None:
+                copies.append((i, [nd[key] if nd[key][1] else None for key in ("xyz", "rgb", "intensity")]))
+        if copies and hasattr(tree, "copy_nodes_into"):
+            # one ABI call for all top nodes and file kinds
+            tree.copy_nodes_into([(i, tuple(None if r is None else r[0] for r in ranges)) for i, ranges in copies], top)
+        else:  # host test backends
+            for i, ranges in copies:
+                for which, r in enumerate(ranges):
+                    if r is not None:
+                        tree.copy_node_into(i, which, top[r[0]:r[0] + r[1]])
         self._before_torch()  # the node copies are queued on the library's stream, the collective runs on torch's
         if world > 1:
             self.dist.all_reduce(top, op=self.dist.ReduceOp.SUM)

@@ -200,6 +200,16 @@ class Context:
         del keep
         return OctreeResult(self, h)
 
+    def build_from_ply(self, resolution, filename, with_intensity=False, max_points_per_node=0):
+        """build_octree_from_file (generation.rs:272-287) with the decode on the device: the file's vertex records go up as
+        they are, a HIP kernel casts x / y / z to f64 and adds the header offset (ply.rs:488-493), the bounding box is
+        computed on the device."""
+        pr = self._params(resolution, None, None, max_points_per_node, L.BUILD_COMPUTE_BBOX)
+        h = C.c_void_p()
+        self._check(self.lib.pcv_build_octree_from_ply(self.handle, C.byref(pr), str(filename).encode(), 1 if with_intensity else 0,
+                                                       C.byref(h)))
+        return OctreeResult(self, h)
+
     # ---- loading + queries -----------------------------------------------------------------------
     def open_dir(self, directory):
         """Octree::from_data_provider over a directory (octree/mod.rs:156-215)."""
@@ -634,6 +644,20 @@ class OctreeResult:
             ptr, cap, mem = dst.ctypes.data, dst.nbytes, L.MEM_HOST
         self.ctx._check(self.lib.pcv_octree_copy_node(self.handle, i, which, ptr, cap, mem))
 
+    def copy_nodes_into(self, copies, dst):
+        """Batch form of copy_node_into: copies = [(node index, (xyz offset, rgb offset, intensity offset))] with None for
+        a file kind to skip; everything lands in the one uint8 tensor / array `dst` (one ABI call)."""
+        arr = (L.NodeCopy * max(1, len(copies)))()
+        for k, (node, offs) in enumerate(copies):
+            arr[k].node = int(node)
+            for w in range(3):
+                arr[k].dst_offset[w] = 0xFFFFFFFFFFFFFFFF if offs[w] is None else int(offs[w])
+        if hasattr(dst, "data_ptr"):
+            ptr, cap, mem = dst.data_ptr(), dst.numel() * dst.element_size(), (L.MEM_DEVICE if dst.is_cuda else L.MEM_HOST)
+        else:
+            ptr, cap, mem = dst.ctypes.data, dst.nbytes, L.MEM_HOST
+        self.ctx._check(self.lib.pcv_octree_copy_nodes(self.handle, arr, len(copies), ptr, cap, mem))
+
     def to_dict(self):
         """{node name: dict(id, num_points, encoding, level, xyz, rgb, intensity)} — same shape the test-side
         oracle wrapper uses, so parity tests are plain dict comparisons."""
@@ -692,10 +716,28 @@ def read_ply(path):
         lib.pcv_ply_free(h)
 
 
-def build_octree_from_file(output_directory, resolution, filename, attributes=("color", "intensity"), ctx=None):
-    """Drop-in for reference `build_octree_from_file` (generation.rs:272-287): one parsing pass, bounding box on the
+def build_octree_from_file(output_directory, resolution, filename, attributes=("color", "intensity"), ctx=None,
+                           host_decode=False):
+    """Drop-in for reference `build_octree_from_file` (generation.rs:272-287): the vertex records of the file go to the
+    device as they are and are decoded there (host_decode=True: the one-pass host parser instead), bounding box on the
     device, build, directory write. Like the reference binary (src/bin/build_octree.rs:47-52) the default attribute
     list asks for intensity; a PLY without it raises (the reference panics)."""
+    attributes = tuple(attributes)
+    if not host_decode:
+        if "color" not in attributes:
+            raise ValueError("the octree format requires the 'color' attribute (on_disk.rs:20-22)")
+        for a in attributes:
+            if a not in ("color", "intensity"):
+                raise ValueError(f"unsupported attribute {a!r} (octree/mod.rs:62-74 implies color and intensity)")
+        ctx = ctx or default_context()
+        try:
+            tree = ctx.build_from_ply(resolution, filename, with_intensity="intensity" in attributes)
+        except L.PcvError as e:
+            if "requested but the PLY has none" in str(e) or "requires colour" in str(e):
+                raise ValueError(str(e)) from None
+            raise
+        tree.write_dir(output_directory)
+        return tree
     pts = read_ply(filename)
     if pts["color"] is None:
         raise ValueError("the PLY has no red/green/blue properties; the octree format requires colour")

@@ -299,11 +299,66 @@ def test_build_octree_from_file(ctx, tmp_path):
         rec = np.zeros(x.size, dtype=[("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("r", "u1"), ("g", "u1"), ("b", "u1"), ("i", "<f4")])
         rec["x"], rec["y"], rec["z"], rec["r"], rec["g"], rec["b"], rec["i"] = xf, yf, zf, rgb[:, 0], rgb[:, 1], rgb[:, 2], inten
         f.write(rec.tobytes())
-    pcv.build_octree_from_file(tmp_path / "gpu", 0.001, tmp_path / "cloud.ply", ctx=ctx)
+    pcv.build_octree_from_file(tmp_path / "gpu", 0.001, tmp_path / "cloud.ply", ctx=ctx)  # decode on the device
+    pcv.build_octree_from_file(tmp_path / "gpu_host", 0.001, tmp_path / "cloud.ply", ctx=ctx, host_decode=True)
     px, py, pz = xf.astype(np.float64) + off[0], yf.astype(np.float64) + off[1], zf.astype(np.float64) + off[2]
     bmin, bmax = O.aabb(px, py, pz)
     O.build_literal_dir(tmp_path / "cpu", 0.001, bmin, bmax, px, py, pz, rgb, inten, threads=4)
     assert not O.compare_octrees(O.load_dir(tmp_path / "gpu"), O.load_dir(tmp_path / "cpu"))
+    assert not O.compare_octrees(O.load_dir(tmp_path / "gpu_host"), O.load_dir(tmp_path / "cpu"))
+
+
+def test_device_ply_decode_equals_host_decode(ctx, tmp_path):
+    """pcv_build_octree_from_ply (vertex records uploaded as they are, cast + `comment offset` on the device,
+    ply.rs:488-493) against the host parser + pcv_build_octree on the same file: x / y / z of different scalar types at
+    unaligned offsets inside a 23-byte record, properties that are skipped, a trailing element; and the reference's own
+    fixture files when the checkout is there."""
+    import os
+    rng = np.random.default_rng(5)
+    n = 60_000
+    rec = np.zeros(n, dtype=[("pad", "u1"), ("x", "<i2"), ("r", "u1"), ("y", "<f8"), ("g", "u1"), ("z", "<u4"), ("b", "u1"),
+                             ("a", "u1"), ("i", "<f4")])
+    rec["x"], rec["y"], rec["z"] = rng.integers(-3000, 3000, n), rng.normal(0.0, 40.0, n), rng.integers(0, 5000, n)
+    rec["r"], rec["g"], rec["b"], rec["a"] = rng.integers(0, 256, n), rng.integers(0, 256, n), rng.integers(0, 256, n), 7
+    rec["i"] = rng.uniform(0, 100, n).astype(np.float32)
+    with open(tmp_path / "mixed.ply", "wb") as f:
+        f.write((f"ply\nformat binary_little_endian 1.0\ncomment offset: 0.125 -2000000.5 1e-3\nelement vertex {n}\n"
+                 "property uchar pad\nproperty short x\nproperty uchar red\nproperty double y\nproperty uchar green\n"
+                 "property uint z\nproperty uchar blue\nproperty uchar alpha\nproperty float intensity\n"
+                 "element face 0\nproperty list uchar int vertex_indices\nend_header\n").encode())
+        f.write(rec.tobytes())
+    files = [(tmp_path / "mixed.ply", True)]
+    for name, has_int in (("xyz_f32_rgb_u8_le.ply", False), ("xyz_f32_rgba_u8_le.ply", False), ("xyz_f32_rgb_u8_intensity_f32.ply", True)):
+        if os.path.exists(os.path.join("/root/reference/src/test_data", name)):
+            files.append((os.path.join("/root/reference/src/test_data", name), has_int))
+    for path, has_int in files:
+        dev = ctx.build_from_ply(0.01, path, with_intensity=has_int, max_points_per_node=2000)
+        pts = pcv.read_ply(path)
+        host = ctx.build(0.01, None, pts["x"], pts["y"], pts["z"], pts["color"], pts["intensity"] if has_int else None,
+                         max_points_per_node=2000)
+        assert dev.meta()["bbox_min"].tolist() == host.meta()["bbox_min"].tolist()
+        a, b = dev.to_dict(), host.to_dict()
+        assert set(a) == set(b) and dev.num_points == pts["x"].size
+        for name in a:
+            for key in ("num_points", "encoding", "xyz", "rgb"):
+                assert a[name][key] == b[name][key], (path, name, key)
+            ia, ib = np.frombuffer(a[name]["intensity"], np.float32), np.frombuffer(b[name]["intensity"], np.float32)
+            assert np.array_equal(ia, ib, equal_nan=True), (path, name)  # the fixture's intensities are NaN
+    # intensity asked for, none in the file (the reference panics, SURVEY F8); a missing file
+    small = np.zeros(4, dtype=[("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("r", "u1"), ("g", "u1"), ("b", "u1")])
+    with open(tmp_path / "noint.ply", "wb") as f:
+        f.write(b"ply\nformat binary_little_endian 1.0\nelement vertex 4\nproperty float x\nproperty float y\nproperty float z\n"
+                b"property uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n" + small.tobytes())
+    with pytest.raises(pcv.PcvError, match="requested but the PLY has none"):
+        ctx.build_from_ply(0.01, tmp_path / "noint.ply", with_intensity=True)
+    assert ctx.build_from_ply(0.01, tmp_path / "noint.ply").num_points == 4
+    with pytest.raises(pcv.PcvError, match="Could not open"):
+        ctx.build_from_ply(0.01, tmp_path / "missing.ply")
+    with open(tmp_path / "short.ply", "wb") as f:  # the header promises more records than the file holds
+        f.write(b"ply\nformat binary_little_endian 1.0\nelement vertex 400\nproperty float x\nproperty float y\nproperty float z\n"
+                b"property uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n" + small.tobytes())
+    with pytest.raises(pcv.PcvError, match="unexpected end of file"):
+        ctx.build_from_ply(0.01, tmp_path / "short.ply")
 
 
 def test_c_host_binary_builds_the_same_directory(tmp_path):

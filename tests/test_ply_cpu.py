@@ -93,3 +93,31 @@ def test_rejects_what_the_reference_rejects(tmp_path):
     (tmp_path / "short.ply").write_bytes(data[:-5])
     with pytest.raises(pcv.PcvError, match="unexpected end of file"):
         pcv.read_ply(tmp_path / "short.ply")
+
+
+REFERENCE_FIXTURES = "/root/reference/src/test_data"
+
+
+@pytest.mark.parametrize("name,last_red,has_intensity", [("xyz_f32_rgb_u8_le.ply", 234, False), ("xyz_f32_rgba_u8_le.ply", 227, False),
+                                                          ("xyz_f32_rgb_u8_intensity_f32.ply", 234, True)])
+def test_the_reference_own_fixture_files(name, last_red, has_intensity):
+    """The three byte fixtures the reference ships, read FROM the reference checkout when it is there (build container;
+    the GPU box has no /root/reference), against exactly what src/read_write/ply.rs:753-797 asserts: 4 batches of 2 = 8
+    points, first x == 1, last x == 22, first red == 255, last red == 234 / 227, NaN intensities present."""
+    import os
+    path = os.path.join(REFERENCE_FIXTURES, name)
+    if not os.path.exists(path):
+        pytest.skip("reference checkout not present")
+    p = pcv.read_ply(path)
+    assert p["x"].size == 8                       # NUM_BATCHES * BATCH_SIZE
+    assert p["x"][0] == 1.0 and p["x"][-1] == 22.0
+    assert p["color"][0, 0] == 255 and p["color"][-1, 0] == last_red
+    if has_intensity:
+        assert p["intensity"] is not None and p["intensity"].size == 8 and np.all(np.isnan(p["intensity"]))
+    else:
+        assert p["intensity"] is None
+    # and they are the files the generated fixtures above stand in for (apart from the alpha values, which are skipped)
+    want = np.array(_reference_rows())
+    assert np.array_equal(np.stack([p["x"], p["y"], p["z"]], axis=1), want[:, :3])
+    if name != "xyz_f32_rgba_u8_le.ply":
+        assert np.array_equal(p["color"], want[:, 3:6].astype(np.uint8))
