@@ -206,7 +206,8 @@ int pcv_ctx::h2d_fill(void* dst, size_t bytes, const std::function<bool(uint8_t*
       if (hipEventCreateWithFlags(&ring_ev[k], hipEventDisableTiming) != hipSuccess) return fail(PCV_E_HIP, "hipEventCreate");
     }
     unsigned hw = std::thread::hardware_concurrency();
-    host_pool.start(hw >= 16 ? 7 : (hw > 2 ? hw / 2 - 1 : 0));
+    // copies into pinned memory saturate the link with 7 threads; preads from a file (pcv_build_octree_from_ply) want more
+    host_pool.start(hw >= 64 ? 15 : (hw >= 16 ? 7 : (hw > 2 ? hw / 2 - 1 : 0)));
   }
   constexpr size_t kPart = 2u << 20;
   std::atomic<int> bad{0};

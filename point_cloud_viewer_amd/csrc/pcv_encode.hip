@@ -279,8 +279,6 @@ __global__ __launch_bounds__(BLOCK) void spec_encode_kernel(
   } else {
     PCV_SPEC_WALK(true)
   }
-#undef PCV_SPEC_WALK
-#undef PCV_SPEC_LOOP
   // the record carries the codes of the first candidate on the path where there is one, else those of the predicted leaf
   if (KEEP && kl) {
     vx = kx, vy = ky, vz = kz;
@@ -307,6 +305,152 @@ __global__ __launch_bounds__(BLOCK) void spec_encode_kernel(
   }
   if (inten_bits) inten_bits[i] = __float_as_uint(intensity[i]);
 }
+
+// Persistent form of the binned pass for raw (not routed) input. The kernel above starts one workgroup per 512 points:
+// its eight waves load coordinates, look the depth up, sort themselves through five barriers — and only then have
+// arithmetic to issue; with four such workgroups per CU the SIMDs idle a quarter of the time (VALU issue 71 %, half of
+// every wave's life in s_waitcnt). Here a workgroup stays and walks tile after tile:
+//   * a tile is 2 x BLOCK points, re-dealt by predicted depth into 2 x (BLOCK / 64) groups of 64; wave w walks group w
+//     (the deep end) and then group 2 x waves - 1 - w (the shallow end), so the waves of a workgroup finish together and
+//     the barrier that opens the next tile costs nobody a wait;
+//   * the NEXT tile's coordinates are loaded into registers before the walks start and land while they run.
+// Same arithmetic, same outputs as the kernel above (the deal only decides which lane walks which point).
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void spec_encode_persist_kernel(
+    PcvLevels lv, const uint32_t* __restrict__ walk, uint64_t n, uint32_t num_tiles, const double* __restrict__ x,
+    const double* __restrict__ y, const double* __restrict__ z, const uint8_t* __restrict__ color, uint32_t color_stride,
+    const float* __restrict__ intensity, uint32_t* __restrict__ rank, uint4* __restrict__ payload, uint32_t* __restrict__ inten_bits,
+    const uint8_t* __restrict__ depth_grid, float cells_per_unit, uint4* __restrict__ wide) {
+  constexpr bool KEEP = true;
+  constexpr int TILE = 2 * BLOCK, kWavesB = BLOCK / 64, kGroups = 2 * kWavesB;
+  __shared__ double sx[TILE], sy[TILE], sz[TILE];
+  __shared__ uint16_t perm[TILE];
+  __shared__ uint16_t wcnt[kGroups][kSpecClasses];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const PcvRouted routed{};  // raw points only
+  double qx[2], qy[2], qz[2];
+  auto load_tile = [&](uint32_t tile) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const uint64_t i = (uint64_t)tile * TILE + (uint64_t)h * BLOCK + tid;
+      const bool in = i < n;
+      qx[h] = in ? x[i] : 0.0;
+      qy[h] = in ? y[i] : 0.0;
+      qz[h] = in ? z[i] : 0.0;
+    }
+  };
+  uint32_t tile = blockIdx.x;
+  if (tile < num_tiles) load_tile(tile);
+  for (; tile < num_tiles; tile += gridDim.x) {
+    const uint64_t base = (uint64_t)tile * TILE;
+    uint32_t key[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      key[h] = kSpecClasses - 1;  // padding lanes go last
+      if (base + (uint64_t)h * BLOCK + tid < n) {
+        constexpr float kTop = (float)((1 << kGridBits) - 1);
+        const uint32_t ix = (uint32_t)fminf(fmaxf((float)(qx[h] - lv.root_min[0]) * cells_per_unit, 0.f), kTop);
+        const uint32_t iy = (uint32_t)fminf(fmaxf((float)(qy[h] - lv.root_min[1]) * cells_per_unit, 0.f), kTop);
+        const uint32_t iz = (uint32_t)fminf(fmaxf((float)(qz[h] - lv.root_min[2]) * cells_per_unit, 0.f), kTop);
+        key[h] = (uint32_t)(kSpecClasses - 2 - depth_grid[ix | (iy << kGridBits) | (iz << (2 * kGridBits))]);  // deepest first
+      }
+    }
+    __syncthreads();  // every wave is done with the previous tile's coordinates and deal
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      sx[h * BLOCK + tid] = qx[h];
+      sy[h * BLOCK + tid] = qy[h];
+      sz[h * BLOCK + tid] = qz[h];
+    }
+    for (int k = tid; k < kGroups * kSpecClasses; k += BLOCK) (&wcnt[0][0])[k] = 0;
+    __syncthreads();
+    // lanes of a 64-point row with the same key: 5 ballots; the first of each group publishes the group size
+    uint32_t before[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      uint64_t peers = ~0ull;
+#pragma unroll
+      for (int b = 0; b < 5; ++b) {
+        const bool bit = (key[h] >> b) & 1u;
+        const uint64_t m = __ballot(bit);
+        peers &= bit ? m : ~m;
+      }
+      before[h] = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+      if (before[h] == 0) wcnt[h * kWavesB + wave][key[h]] = (uint16_t)__popcll(peers);
+    }
+    __syncthreads();
+    if (tid < 64) {  // offsets: keys ascending, inside a key the rows ascending
+      uint32_t tot = 0;
+      if (tid < kSpecClasses)
+        for (int w = 0; w < kGroups; ++w) tot += wcnt[w][tid];
+      uint32_t inc = tot;
+#pragma unroll
+      for (int o = 1; o < 32; o <<= 1) {
+        const uint32_t v = __shfl_up(inc, o, 64);
+        if (tid >= o) inc += v;
+      }
+      if (tid < kSpecClasses) {
+        uint32_t run = inc - tot;
+        for (int w = 0; w < kGroups; ++w) {
+          const uint32_t c = wcnt[w][tid];
+          wcnt[w][tid] = (uint16_t)run;
+          run += c;
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) perm[wcnt[h * kWavesB + wave][key[h]] + before[h]] = (uint16_t)(h * BLOCK + tid);
+    __syncthreads();
+    {  // the next tile's coordinates travel while this one is walked
+      const uint32_t next = tile + gridDim.x;
+      if (next < num_tiles) load_tile(next);
+    }
+    for (int task = 0; task < 2; ++task) {
+      const int group = task == 0 ? wave : kGroups - 1 - wave;
+      const int j = perm[group * 64 + lane];
+      const uint64_t i = base + j;
+      if (i >= n) continue;
+      double px = sx[j], py = sy[j], pz = sz[j];
+      double mx = lv.root_min[0], my = lv.root_min[1], mz = lv.root_min[2];
+      double vx = 0, vy = 0, vz = 0;
+      double kx = 0, ky = 0, kz = 0;
+      int kl = 0;
+      int L = 0;
+      uint32_t rec = walk[0];
+      int U = 0;  // the wave's level counter: every lane starts at the root
+      if (lv.fast_ok && pcv_point_is_tame(px, py, pz)) {
+        PCV_SPEC_WALK(false)
+      } else {
+        PCV_SPEC_WALK(true)
+      }
+      if (kl) {
+        vx = kx, vy = ky, vz = kz;
+        L = kl;
+      }
+      const uint32_t leaf_enc = lv.enc[L];
+      const uint8_t* c = color + i * color_stride;
+      const uint32_t ccx = (uint32_t)pcv_val_to_code(leaf_enc, vx), ccy = (uint32_t)pcv_val_to_code(leaf_enc, vy),
+                     ccz = (uint32_t)pcv_val_to_code(leaf_enc, vz);
+      if (wide) {
+        rank[i] = ((rec & PCV_SPEC_INDEX_MASK) << 8) | (uint32_t)c[2];
+        const uint32_t rg = ((uint32_t)c[0] << 16) | ((uint32_t)c[1] << 24);
+        if (leaf_enc <= PCV_ENC_UINT16) {
+          reinterpret_cast<uint2*>(payload)[i] = make_uint2(ccx | (ccy << 16), ccz | rg);
+        } else {
+          reinterpret_cast<uint2*>(payload)[i] = make_uint2((uint32_t)i, rg);
+          wide[i] = make_uint4(ccx, ccy, ccz, 0u);
+        }
+      } else {
+        rank[i] = rec & PCV_SPEC_INDEX_MASK;
+        payload[i] = make_uint4(ccx, ccy, ccz, (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16));
+      }
+      if (inten_bits) inten_bits[i] = __float_as_uint(intensity[i]);
+    }
+  }
+}
+#undef PCV_SPEC_WALK
+#undef PCV_SPEC_LOOP
 
 // Exact number of points per predicted leaf: LDS-privatised histogram of the rank array over the bins
 // [bin_base, bin_base + nbins), nbins <= kHistBins; one flush of the non-zero bins per workgroup.
@@ -758,6 +902,27 @@ void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* w
     return e ? atoi(e) : 512;
   }();
   const bool bin = bin_mode != 0 && depth_grid != nullptr;
+  // raw input: the persistent kernel (PCV_SPEC_PERSIST=0, libpcv_hip_exp.so: one workgroup per 512 points as before;
+  // PCV_SPEC_PERSIST=k: k workgroups per CU)
+  static const int persist = [] {
+    const char* e = pcv_experiment("PCV_SPEC_PERSIST");
+    return e ? atoi(e) : 3;
+  }();
+  if (bin && persist > 0 && !routed.oct && bin_mode == 512) {
+    constexpr int kTile = 1024;
+    const uint32_t num_tiles = (uint32_t)((n + kTile - 1) / kTile);
+    static const int cus = [] {
+      int dev = 0, c = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) c = 256;
+      return c;
+    }();
+    const uint32_t groups = std::min<uint32_t>(num_tiles, (uint32_t)(cus * persist));
+    const float cells = lv.edge[0] > 0.0 ? (float)((double)(1 << kGridBits) / lv.edge[0]) : 0.f;
+    hipLaunchKernelGGL(spec_depth_grid_kernel, dim3((1u << (3 * kGridBits)) / 256), dim3(256), 0, ctx->stream, walk, depth_grid);
+    hipLaunchKernelGGL((spec_encode_persist_kernel<512>), dim3(groups), dim3(512), 0, ctx->stream, lv, walk, n, num_tiles, x, y, z, color,
+                       color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide);
+    return;
+  }
   if (!bin)
     launch_spec_encode_t<false, 256>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, inten_bits,
                                      depth_grid, wide);
