@@ -949,6 +949,9 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
   uint64_t stride = 32;
   if (const char* e = pcv_experiment("PCV_SPEC_STRIDE")) stride = (uint64_t)std::max(1, atoi(e));  // experiments
   while (stride > 1 && n / stride < 4096) stride >>= 1;
+  // a node at the capacity must still hold a few dozen sample points, or the band around the capacity (five standard
+  // deviations of the scaled count) swallows every node and the prediction opens all of them (tiny capacities in tests)
+  while (stride > 1 && (uint64_t)max_points / stride < 64) stride >>= 1;
   const uint64_t ns = n / stride;
   if (ns == 0) return PCV_OK;
   PcvSpecParams sp;
@@ -962,8 +965,8 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
   sp.delta = stride == 1 ? 0.0 : std::fmin(0.9, std::fmax(0.02, 5.0 * std::sqrt((double)stride / (double)max_points)));
 
   ctx->stage_begin(PCV_STAGE_CHAIN_KEYS);
-  // The sample keys cover 14 levels first (two radix passes and a third of the chain less than full depth); a sample
-  // tree that wants to go deeper is keyed again at full depth.
+  // The sample keys cover `sample_levels` levels first (below); a sample tree that wants to go deeper is keyed again at
+  // full depth.
   // The predicted tree is built on the device (sample split -> spec_tree kernels): the one chain pass starts without a
   // host round trip, and the host mirrors the tree (one small asynchronous copy) while that pass runs.
   constexpr uint32_t kFirst = 16384;  // T'' nodes mirrored by the first copy (a 100 M-point tree has ~7 500)
@@ -1003,10 +1006,19 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
   PcvSpecTree tree;
   uint32_t info[4] = {0, 0, 0, 0};
   uint64_t* small_partner = nullptr;
-  int sample_levels = full_levels < 14 ? full_levels : 14;
+  // Levels the sample keys cover first: a uniform cloud reaches the capacity at level log8(n / capacity); clustered clouds
+  // go deeper, so eight levels on top (12 levels for the 100 M bench cloud whose deepest leaf sits at level 10, 13 for
+  // 1 B points), at most 14. Every level less is a tenth of the sample's chain, three bits of its key sort and two
+  // launches of its split; a sample tree that wants to go deeper is keyed again at full depth (below).
+  int sample_levels;
+  {
+    int uniform = 0;
+    for (uint64_t per_node = n / (uint64_t)max_points + 1; per_node > 1; per_node = (per_node + 7) / 8) ++uniform;
+    sample_levels = std::min(14, std::max(10, uniform + 8));
+    if (const char* e = pcv_experiment("PCV_SAMPLE_LEVELS")) sample_levels = std::max(1, atoi(e));
+    if (sample_levels > full_levels) sample_levels = full_levels;
+  }
   for (;;) {
-    // The sample keys cover 14 levels first (two radix passes and a third of the chain less than full depth); a sample
-    // tree that wants to go deeper is keyed again at full depth.
     lv.nlevels = sample_levels;
     // keys_a doubles as the rank array of the chain pass below: a second round must not start before the first
     // round's pass is done with it — same stream, so it is ordered
@@ -1694,11 +1706,19 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
   const size_t cont_items_off = cont_off + (((size_t)num_cont * pcv_cont_range_bytes() + 15) & ~(size_t)15);
   PcvSettleItem* u_cont_items = (PcvSettleItem*)((uint8_t*)u_node_rec + cont_items_off);
   uint32_t num_cont_items = 0;
-  for (uint32_t k = 0; k < num_cont; ++k) {
-    const uint32_t leaf = bs->cont_nodes[k], from = bs->cont_from[k];
-    pcv_fill_cont_range(u_cont_ranges + (size_t)k * pcv_cont_range_bytes(), h_level[from], h_level[leaf], u_node_min + 3 * (size_t)from);
-    for (uint64_t b = h_lo[leaf]; b < h_hi[leaf]; b += kPcvSettleTile)
-      u_cont_items[num_cont_items++] = PcvSettleItem{k, (uint32_t)b, (uint32_t)std::min<uint64_t>(b + kPcvSettleTile, h_hi[leaf]), 0u};
+  {
+    std::vector<uint32_t> cont_of_rank;
+    if (num_cont && by_leaf) cont_of_rank.assign(num_leaves, 0u);
+    for (uint32_t k = 0; k < num_cont; ++k) {
+      const uint32_t leaf = bs->cont_nodes[k], from = bs->cont_from[k];
+      pcv_fill_cont_range(u_cont_ranges + (size_t)k * pcv_cont_range_bytes(), h_level[from], h_level[leaf], u_node_min + 3 * (size_t)from);
+      if (by_leaf) cont_of_rank[rank_of[leaf]] = k + 1;
+      for (uint64_t b = h_lo[leaf]; b < h_hi[leaf]; b += kPcvSettleTile)
+        u_cont_items[num_cont_items++] = PcvSettleItem{k, (uint32_t)b, (uint32_t)std::min<uint64_t>(b + kPcvSettleTile, h_hi[leaf]), 0u};
+    }
+    if (num_cont && by_leaf)  // the leaf-wise settle kernel continues these leaves' chains itself (it ignores the mark when it
+                              // is launched without the ranges)
+      for (uint32_t j = 0; j < num_items; ++j) u_items[j].pad = cont_of_rank[u_items[j].rank];
   }
   const size_t walk_bytes = ((size_t)M * 8 + 255) & ~(size_t)255;
   const size_t rec_bytes = cont_items_off + (size_t)num_cont_items * sizeof(PcvSettleItem);
@@ -1751,7 +1771,14 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
     if ((rc = ctx->dev_alloc(&climbers, pcv_climber_bytes(num_climbers)))) return rc;
     sc.ptrs.push_back(climbers);
   }
-  if (num_cont_items)
+  // leaves below a split first candidate: the leaf-wise settle kernel continues their chain itself (its items name the
+  // range); the slot-wise kernel (experiments) gets the codes rewritten by a pass of its own first
+  static const bool fuse_cont = [] {  // PCV_CONT_IN_SETTLE=0 (libpcv_hip_exp.so): the stand-alone continuation kernel
+    const char* e = pcv_experiment("PCV_CONT_IN_SETTLE");
+    return !e || atoi(e) != 0;
+  }();
+  const bool cont_in_settle = by_leaf && fuse_cont && num_cont_items > 0;
+  if (num_cont_items && !cont_in_settle)
     pcv_launch_spec_continue(ctx, lv, d_up + walk_bytes + cont_off, (const PcvSettleItem*)(d_up + walk_bytes + cont_items_off), num_cont_items,
                              (void*)s_pay, bs->spec_wide);
   pcv_launch_promote_encode(ctx, lv, pt, n, s_rank, s_pay, wide ? s_plane[w_hi] : nullptr,
@@ -1759,7 +1786,8 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
                             w_int >= 0 ? s_plane[w_int] : nullptr, d_climb_base, (uint32_t)num_climbers, climbers, t->d_xyz,
                             t->d_rgb, t->d_int, bs->spec_wide,
                             by_leaf ? (const PcvSettleItem*)(d_up + walk_bytes + items_off) : nullptr, num_items,
-                            by_leaf ? (const PcvSettleItem*)(d_up + walk_bytes + items_off) + num_items : nullptr, num_citems);
+                            by_leaf ? (const PcvSettleItem*)(d_up + walk_bytes + items_off) + num_items : nullptr, num_citems,
+                            cont_in_settle ? (const void*)(d_up + walk_bytes + cont_off) : nullptr);
   ctx->stage_end(PCV_STAGE_PROMOTE_ENCODE);
   PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[8], st));
   PCV_HIP_CHECK(ctx, hipGetLastError());

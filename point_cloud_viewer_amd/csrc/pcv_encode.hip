@@ -315,8 +315,8 @@ __global__ __launch_bounds__(BLOCK) void spec_encode_kernel(
 //     the barrier that opens the next tile costs nobody a wait;
 //   * the NEXT tile's coordinates are loaded into registers before the walks start and land while they run.
 // Same arithmetic, same outputs as the kernel above (the deal only decides which lane walks which point).
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void spec_encode_persist_kernel(
+template <int BLOCK, bool PREFETCH>
+__global__ __launch_bounds__(BLOCK, PREFETCH ? 6 : 8) void spec_encode_persist_kernel(
     PcvLevels lv, const uint32_t* __restrict__ walk, uint64_t n, uint32_t num_tiles, const double* __restrict__ x,
     const double* __restrict__ y, const double* __restrict__ z, const uint8_t* __restrict__ color, uint32_t color_stride,
     const float* __restrict__ intensity, uint32_t* __restrict__ rank, uint4* __restrict__ payload, uint32_t* __restrict__ inten_bits,
@@ -340,9 +340,10 @@ __global__ __launch_bounds__(BLOCK) void spec_encode_persist_kernel(
     }
   };
   uint32_t tile = blockIdx.x;
-  if (tile < num_tiles) load_tile(tile);
+  if (PREFETCH && tile < num_tiles) load_tile(tile);
   for (; tile < num_tiles; tile += gridDim.x) {
     const uint64_t base = (uint64_t)tile * TILE;
+    if (!PREFETCH) load_tile(tile);  // (variant without the registers that carry the next tile across the walks)
     uint32_t key[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -402,7 +403,7 @@ __global__ __launch_bounds__(BLOCK) void spec_encode_persist_kernel(
 #pragma unroll
     for (int h = 0; h < 2; ++h) perm[wcnt[h * kWavesB + wave][key[h]] + before[h]] = (uint16_t)(h * BLOCK + tid);
     __syncthreads();
-    {  // the next tile's coordinates travel while this one is walked
+    if (PREFETCH) {  // the next tile's coordinates travel while this one is walked
       const uint32_t next = tile + gridDim.x;
       if (next < num_tiles) load_tile(next);
     }
@@ -498,14 +499,30 @@ struct alignas(16) PcvContRange {
   double pad2;
 };
 static_assert(sizeof(PcvContRange) == 48, "continue range");
+// raw codes of level rg.from_level in the candidate's cube -> raw codes of level rg.to_level down the point's own path
+__device__ __forceinline__ void pcv_continue_codes(const PcvLevels& lv, const PcvContRange& rg, uint32_t& cx, uint32_t& cy, uint32_t& cz) {
+  const int from = (int)rg.from_level, to = (int)rg.to_level;
+  const uint32_t fe = lv.enc[from], te = lv.enc[to];
+  double mx = rg.mn[0], my = rg.mn[1], mz = rg.mn[2];
+  const double e = lv.edge[from];
+  double px = pcv_decode_coord(fe, cx, mx, e), py = pcv_decode_coord(fe, cy, my, e), pz = pcv_decode_coord(fe, cz, mz, e);
+  double vx = 0, vy = 0, vz = 0;
+  for (int L = from + 1; L <= to; ++L)
+    (void)pcv_chain_level<true>(lv.enc[L], lv.edge[L - 1], lv.edge[L], PcvRecip{lv.inv_edge[L], lv.inv_edge_lo[L]}, px, py, pz, mx, my,
+                                mz, vx, vy, vz);
+  cx = (uint32_t)pcv_val_to_code(te, vx);
+  cy = (uint32_t)pcv_val_to_code(te, vy);
+  cz = (uint32_t)pcv_val_to_code(te, vz);
+}
+// Stand-alone form (the slot-wise settle kernel and the 20-byte records of the exact geometry use it; the leaf-wise settle
+// kernel continues the chain itself, see promote_settle_leaf_kernel): rewrites the codes in place.
 template <bool kCompact>
 __global__ __launch_bounds__(256) void spec_continue_kernel(PcvLevels lv, const PcvContRange* __restrict__ ranges,
                                                              const PcvSettleItem* __restrict__ items, uint4* __restrict__ payload,
                                                              uint4* __restrict__ wide /* kCompact: codes of Float32-coded levels */) {
   const PcvSettleItem it = items[blockIdx.x];
   const PcvContRange rg = ranges[it.rank];
-  const int from = (int)rg.from_level, to = (int)rg.to_level;
-  const uint32_t fe = lv.enc[from], te = lv.enc[to];
+  const uint32_t fe = lv.enc[rg.from_level], te = lv.enc[rg.to_level];
   uint2* __restrict__ pay2 = reinterpret_cast<uint2*>(payload);
   for (uint32_t s = it.begin + threadIdx.x; s < it.end; s += 256) {
     uint4 p = make_uint4(0, 0, 0, 0);
@@ -523,16 +540,7 @@ __global__ __launch_bounds__(256) void spec_continue_kernel(PcvLevels lv, const 
     } else {
       p = payload[s];
     }
-    double mx = rg.mn[0], my = rg.mn[1], mz = rg.mn[2];
-    const double e = lv.edge[from];
-    double px = pcv_decode_coord(fe, p.x, mx, e), py = pcv_decode_coord(fe, p.y, my, e), pz = pcv_decode_coord(fe, p.z, mz, e);
-    double vx = 0, vy = 0, vz = 0;
-    for (int L = from + 1; L <= to; ++L)
-      (void)pcv_chain_level<true>(lv.enc[L], lv.edge[L - 1], lv.edge[L], PcvRecip{lv.inv_edge[L], lv.inv_edge_lo[L]}, px, py, pz, mx,
-                                  my, mz, vx, vy, vz);
-    p.x = (uint32_t)pcv_val_to_code(te, vx);
-    p.y = (uint32_t)pcv_val_to_code(te, vy);
-    p.z = (uint32_t)pcv_val_to_code(te, vz);
+    pcv_continue_codes(lv, rg, p.x, p.y, p.z);
     if (!kCompact) {
       payload[s] = p;
     } else if (te <= PCV_ENC_UINT16) {
@@ -771,12 +779,16 @@ __global__ __launch_bounds__(256) void promote_settle_kernel(
 // kernel above the leaf is only known once the rank has arrived: load -> readfirstlane -> scalar load, a wave lived
 // 7 us, three quarters of it waiting); no divergent "two leaves in one wave" path either. The rank array is only read
 // for the blue byte of the packed records.
+// A leaf below a split first candidate (pcv_spec.h) arrives with the candidate level's codes: its items carry the index of
+// the leaf's continuation range (PcvSettleItem::pad = 1 + index), and the workgroup continues the chain to the leaf's
+// level in registers before it settles the slot — no separate pass over those records, no launch.
 template <bool kCompact>
 __global__ __launch_bounds__(256) void promote_settle_leaf_kernel(
     PcvPromoteTables pt, const PcvSettleItem* __restrict__ items, const uint32_t* __restrict__ rank,
     const uint4* __restrict__ payload, const uint32_t* __restrict__ cx_hi, const uint32_t* __restrict__ cy_hi,
     const uint32_t* __restrict__ cz_hi, const uint32_t* __restrict__ inten_bits, const uint32_t* __restrict__ climb_base,
-    PcvClimber* __restrict__ climbers, PromoteOut o, const uint4* __restrict__ wide) {
+    PcvClimber* __restrict__ climbers, PromoteOut o, const uint4* __restrict__ wide, PcvLevels lv,
+    const PcvContRange* __restrict__ cont_ranges) {
   constexpr int kSlots = (int)kPcvSettleTile / 256;
   const PcvSettleItem it = items[blockIdx.x];
   // every record load is issued before anything is consumed; dead lanes of the leaf's last tile re-read the tile's
@@ -807,6 +819,28 @@ __global__ __launch_bounds__(256) void promote_settle_leaf_kernel(
     if (inten_bits) in[k] = inten_bits[sl];
   }
   const PcvNodeRec c = pt.leaf_rec[it.rank];
+  if (it.pad != 0 && cont_ranges) {  // workgroup-uniform: this leaf continues its chain first
+    const PcvContRange rg = cont_ranges[it.pad - 1];
+    const uint32_t fe = lv.enc[rg.from_level];
+#pragma unroll
+    for (int k = 0; k < kSlots; ++k) {
+      const uint32_t s = it.begin + threadIdx.x + 256 * k;
+      if (s >= it.end) continue;
+      uint4 u = p[k];  // codes of the candidate's level, unpacked with ITS encoding
+      if (kCompact) {
+        u.w = (q[k].y >> 16) | ((key[k] & 0xffu) << 16);
+        if (fe <= PCV_ENC_UINT16) {
+          u.x = q[k].x & 0xffffu, u.y = q[k].x >> 16, u.z = q[k].y & 0xffffu;
+        } else {
+          const uint4 w = wide[q[k].x];
+          u.x = w.x, u.y = w.y, u.z = w.z;
+        }
+      }
+      pcv_continue_codes(lv, rg, u.x, u.y, u.z);
+      settle_one<false>(pt, s, c, it.rank, u, h[k], in[k], climb_base, climbers, o, nullptr);  // codes are unpacked already
+    }
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < kSlots; ++k) {
     const uint32_t s = it.begin + threadIdx.x + 256 * k;
@@ -906,7 +940,7 @@ void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* w
   // PCV_SPEC_PERSIST=k: k workgroups per CU)
   static const int persist = [] {
     const char* e = pcv_experiment("PCV_SPEC_PERSIST");
-    return e ? atoi(e) : 3;
+    return e ? atoi(e) : 0;
   }();
   if (bin && persist > 0 && !routed.oct && bin_mode == 512) {
     constexpr int kTile = 1024;
@@ -916,11 +950,16 @@ void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* w
       if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) c = 256;
       return c;
     }();
-    const uint32_t groups = std::min<uint32_t>(num_tiles, (uint32_t)(cus * persist));
     const float cells = lv.edge[0] > 0.0 ? (float)((double)(1 << kGridBits) / lv.edge[0]) : 0.f;
     hipLaunchKernelGGL(spec_depth_grid_kernel, dim3((1u << (3 * kGridBits)) / 256), dim3(256), 0, ctx->stream, walk, depth_grid);
-    hipLaunchKernelGGL((spec_encode_persist_kernel<512>), dim3(groups), dim3(512), 0, ctx->stream, lv, walk, n, num_tiles, x, y, z, color,
-                       color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide);
+    if (persist >= 100) {  // one tile of 1 024 points per workgroup, no prefetch registers: just the paired deal
+      hipLaunchKernelGGL((spec_encode_persist_kernel<512, false>), dim3(num_tiles), dim3(512), 0, ctx->stream, lv, walk, n, num_tiles, x, y, z,
+                         color, color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide);
+    } else {
+      const uint32_t groups = std::min<uint32_t>(num_tiles, (uint32_t)(cus * persist));
+      hipLaunchKernelGGL((spec_encode_persist_kernel<512, true>), dim3(groups), dim3(512), 0, ctx->stream, lv, walk, n, num_tiles, x, y, z,
+                         color, color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide);
+    }
     return;
   }
   if (!bin)
@@ -986,17 +1025,19 @@ void pcv_launch_promote_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvPromo
                                const uint32_t* cz_hi, const uint32_t* inten_bits, const uint32_t* climb_base,
                                uint32_t num_climbers, void* climbers, uint8_t* xyz_blob, uint8_t* rgb_blob,
                                uint8_t* inten_blob, const void* wide, const PcvSettleItem* items, uint32_t num_items,
-                               const PcvSettleItem* climb_items, uint32_t num_climb_items) {
+                               const PcvSettleItem* climb_items, uint32_t num_climb_items, const void* cont_ranges) {
   if (n == 0) return;
   PromoteOut o{xyz_blob, rgb_blob, inten_blob};
   if (items) {
     PcvProf prof(ctx, PCV_K_PROMOTE_ENCODE);
     if (num_items && wide)
       hipLaunchKernelGGL((promote_settle_leaf_kernel<true>), dim3(num_items), dim3(256), 0, ctx->stream, pt, items, rank,
-                         (const uint4*)payload, cx_hi, cy_hi, cz_hi, inten_bits, climb_base, (PcvClimber*)climbers, o, (const uint4*)wide);
+                         (const uint4*)payload, cx_hi, cy_hi, cz_hi, inten_bits, climb_base, (PcvClimber*)climbers, o, (const uint4*)wide, lv,
+                         (const PcvContRange*)cont_ranges);
     else if (num_items)
       hipLaunchKernelGGL((promote_settle_leaf_kernel<false>), dim3(num_items), dim3(256), 0, ctx->stream, pt, items, rank,
-                         (const uint4*)payload, cx_hi, cy_hi, cz_hi, inten_bits, climb_base, (PcvClimber*)climbers, o, (const uint4*)nullptr);
+                         (const uint4*)payload, cx_hi, cy_hi, cz_hi, inten_bits, climb_base, (PcvClimber*)climbers, o, (const uint4*)nullptr, lv,
+                         (const PcvContRange*)cont_ranges);
   } else {
     PcvProf prof(ctx, PCV_K_PROMOTE_ENCODE);
     static const int slots = [] {  // PCV_SETTLE_SLOTS (experiments): 1, 2 or 4 sorted slots per lane

@@ -407,7 +407,9 @@ void pcv_launch_promote_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvPromo
                                const uint32_t* climb_base, uint32_t num_climbers, void* climbers, uint8_t* xyz_blob,
                                uint8_t* rgb_blob, uint8_t* inten_blob, const void* wide = nullptr,
                                const PcvSettleItem* items = nullptr, uint32_t num_items = 0,
-                               const PcvSettleItem* climb_items = nullptr, uint32_t num_climb_items = 0);
+                               const PcvSettleItem* climb_items = nullptr, uint32_t num_climb_items = 0,
+                               const void* cont_ranges = nullptr /* leaf-wise settle: items with pad != 0 continue their chain
+                                                                    from range pad - 1 (pcv_fill_cont_range) */);
 
 struct PcvOctreeQuery;  // device-resident traversal tables (pcv_query.hip)
 

@@ -94,6 +94,22 @@ def test_oversampled_clusters_replay_the_chain_from_their_coordinates(ctx):
     assert info["single_chain"] and info["replayed_points"] >= 6 * k, info
 
 
+def test_many_small_leaves_take_8_bit_digits_and_the_global_rank_map(ctx):
+    """27 000+ leaves: the record sort runs two 8-bit passes (256 digit values: the wide digit state of the 12-byte
+    downsweep) and the predicted tree has more nodes than the rank map's LDS copy holds (the first upsweep then reads the
+    map from memory) — the geometry a 1 B-point build has, at test size."""
+    n, cap = 2_000_000, 150
+    x, y, z, rgb, bmin, bmax = synthetic.gaussian_clusters(n, seed=31, num_clusters=9, extent=250.0, sigma_range=(0.3, 7.0))
+    with O.max_points_per_node(cap):
+        want = O.build_closed(0.001, bmin, bmax, x, y, z, rgb, threads=8)
+    leaves = len(want.nodes) - len({k[:-1] for k in want.nodes if len(k) > 1})  # nodes that are nobody's parent
+    assert 16_384 < leaves <= 65_536, leaves  # 15 or 16 rank bits -> two passes of 8
+    t = ctx.build(0.001, pcv.Aabb(bmin, bmax), x, y, z, rgb, max_points_per_node=cap, single_chain=True)
+    info = t.build_info()
+    assert_same(t.to_dict(), want)
+    assert info["single_chain"] and info["record_bytes"] == 12 and info["predicted_nodes"] > 15_360, info
+
+
 def test_single_chain_is_the_default_from_4M_points_and_keeps_candidate_codes(ctx):
     n = 6_000_000
     x, y, z, rgb, bmin, bmax = synthetic.gaussian_clusters(n, seed=8, num_clusters=24, extent=500.0, sigma_range=(0.3, 9.0))
