@@ -843,13 +843,12 @@ static void host_lap(const char* what, bool reset = false) {
   t0 = now;
 }
 
-// K5 (exact pipeline only: `wt` set) + K3 stable record sort by leaf rank (+ the single-chain build's replay of the
-// leaves that kept no codes), queued on the stream; the outcome is left in the build state for K6.
+// K5 (exact pipeline only: `wt` set) + K3 stable record sort by leaf rank, queued on the stream; the outcome is left in
+// the build state for K6. num_leaves only sizes the digits: any upper bound of the number of true leaves will do.
 // record = rank (u32) + one 16-byte payload {code x, code y, code z, rgba}; optional 4-byte planes for the intensity
 // and, when some leaf level is Float64-encoded, the high words of the codes. The key buffers are dead by now: each
 // (8n bytes) hosts one rank array; payloads get their own buffers.
 static int queue_record_sort(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, const PcvWalkTables* wt, uint32_t num_leaves, bool wide) {
-  hipStream_t st = ctx->stream;
   PcvScratch& sc = bs->sc;
   DevPoints& d = bs->d;
   PcvLevels& lv = bs->lv;
@@ -900,38 +899,45 @@ static int queue_record_sort(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, const Pc
   else
     rc = pcv_radix_sort_u32(ctx, rank_a, rank_b, n, 0, rank_bits, &pl, bs->sort_scratch, &rec_in_a);
   if (rc) return rc;
-  const void* s_pay = rec_in_a ? (const void*)pay_a : (const void*)pay_b;
-  if (bs->spec && !bs->fix_ranges.empty()) {
-    // single-chain build: the few leaves whose points kept no codes replay their chain now that they are contiguous
-    const uint32_t nr = (uint32_t)bs->fix_ranges.size();
-    uint32_t* d_ranges;
-    if ((rc = sc.get(&d_ranges, (size_t)nr * 4 + 4))) return rc;
-    // staging: the second half of the pinned mailbox block is reserved for these ranges (32 of them) — the upload is
-    // queued behind the record sort and the caller gets control back before it has run, so the slot must not be one that
-    // other entry points of the context write (they use the first half); more ranges (tiny capacities in tests) wait
-    // for the queued work and take the big block
-    uint32_t* h_ranges = (uint32_t*)(ctx->mailbox + 64);
-    if (nr > 32) {
-      PCV_HIP_CHECK(ctx, hipStreamSynchronize(st));
-      if ((rc = ctx->pinned_spec_reserve((size_t)nr * 16 + 64))) return rc;
-      h_ranges = (uint32_t*)ctx->pinned_spec;
-    }
-    uint32_t before = 0;
-    for (uint32_t k = 0; k < nr; ++k) {
-      h_ranges[4 * k + 0] = bs->fix_ranges[k].lo;
-      h_ranges[4 * k + 1] = before;
-      h_ranges[4 * k + 2] = bs->fix_ranges[k].level;
-      h_ranges[4 * k + 3] = 0;
-      before += bs->fix_ranges[k].count;
-    }
-    PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_ranges, h_ranges, (size_t)nr * 16, hipMemcpyHostToDevice, st));
-    pcv_launch_spec_replay(ctx, lv, d_ranges, nr, before, d.x, d.y, d.z, d.routed, (void*)s_pay, bs->spec_wide);
-  }
   ctx->stage_end(PCV_STAGE_SORT_RECORDS);
   bs->sort_queued = true;
   bs->rec_in_a = rec_in_a;
   bs->pay_a = pay_a;
   bs->pay_b = pay_b;
+  return PCV_OK;
+}
+
+// single-chain build: the few leaves whose records hold no usable codes (bs->fix_ranges, PCV_SPEC_MAP_REPLAY) replay their
+// chain from the coordinates now that the record sort has made them contiguous; queued behind the sort.
+static int queue_replay(pcv_ctx* ctx, PcvBuild* bs) {
+  if (!bs->spec || bs->fix_ranges.empty()) return PCV_OK;
+  hipStream_t st = ctx->stream;
+  DevPoints& d = bs->d;
+  int rc;
+  const void* s_pay = bs->rec_in_a ? (const void*)bs->pay_a : (const void*)bs->pay_b;
+  const uint32_t nr = (uint32_t)bs->fix_ranges.size();
+  uint32_t* d_ranges;
+  if ((rc = bs->sc.get(&d_ranges, (size_t)nr * 4 + 4))) return rc;
+  // staging: the second half of the pinned mailbox block is reserved for these ranges (32 of them) — the upload is
+  // queued behind the record sort and the caller gets control back before it has run, so the slot must not be one that
+  // other entry points of the context write (they use the first half); more ranges (tiny capacities in tests) wait
+  // for the queued work and take the big block
+  uint32_t* h_ranges = (uint32_t*)(ctx->mailbox + 64);
+  if (nr > 32) {
+    PCV_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    if ((rc = ctx->pinned_spec_reserve((size_t)nr * 16 + 64))) return rc;
+    h_ranges = (uint32_t*)ctx->pinned_spec;
+  }
+  uint32_t before = 0;
+  for (uint32_t k = 0; k < nr; ++k) {
+    h_ranges[4 * k + 0] = bs->fix_ranges[k].lo;
+    h_ranges[4 * k + 1] = before;
+    h_ranges[4 * k + 2] = bs->fix_ranges[k].level;
+    h_ranges[4 * k + 3] = 0;
+    before += bs->fix_ranges[k].count;
+  }
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_ranges, h_ranges, (size_t)nr * 16, hipMemcpyHostToDevice, st));
+  pcv_launch_spec_replay(ctx, bs->lv, d_ranges, nr, before, d.x, d.y, d.z, d.routed, (void*)s_pay, bs->spec_wide);
   return PCV_OK;
 }
 
@@ -1106,7 +1112,7 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
   }
   sp.nlevels = sample_levels;
 
-  // ---- exact counts -> true tree ----
+  // ---- exact counts -> rank map (device) and true tree (host) ----
   ctx->stage_begin(PCV_STAGE_NODE_SPLIT);
   pcv_launch_rank_hist(ctx, rank, n, tree.num_leaves, d_counts, compact ? 8 : 0);
   PCV_HIP_CHECK(ctx, hipGetLastError());
@@ -1115,41 +1121,69 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
   uint32_t* h_counts = (uint32_t*)hp;
   const size_t map_off = ((size_t)tree.num_leaves * 4 + 255) & ~(size_t)255;
   PCV_HIP_CHECK(ctx, hipMemcpyAsync(h_counts, d_counts, (size_t)tree.num_leaves * 4, hipMemcpyDeviceToHost, st));
-  PCV_HIP_CHECK(ctx, hipStreamSynchronize(st));
-  host_lap("", true);
-  const PcvSpecStatus resolved = pcv_spec_resolve(sp, tree, h_counts, tt);
-  host_lap("resolve");
-  if (resolved != PCV_SPEC_OK) {
+  PCV_HIP_CHECK(ctx, hipEventRecord(ctx->spec_ev, st));  // the counts are on their way to the host
+  // The map the record sort needs is computed on the device (spec_resolve_kernel), and the sort is queued behind it right
+  // away: the counts' trip to the host, the host's own resolve and the table building all happen beside the sort instead
+  // of in front of it. The sort's digit widths come from the number of PREDICTED leaves (an upper bound of the true
+  // leaves, known since the host mirrored T''). PCV_DEVICE_RESOLVE=0 (libpcv_hip_exp.so): the map comes from the host.
+  static const bool device_resolve = [] {
+    const char* e = pcv_experiment("PCV_DEVICE_RESOLVE");
+    return !e || atoi(e) != 0;
+  }();
+  bs->spec_wide = wide;
+  bs->wide_levels = wide_levels;
+  bs->spec_map_dev = d_map;
+  bs->spec_map_entries = tree.num_leaves;
+  bs->spec = true;
+  bs->spec_payload = payload;
+  bs->fix_ranges.clear();
+  auto give_up = [&]() {  // nothing of this attempt is kept; queued work on the scratch buffers drains harmlessly
+    bs->spec = false;
+    bs->spec_payload = nullptr;
+    bs->spec_wide = nullptr;
+    bs->spec_map_dev = nullptr;
+    bs->sort_queued = false;
     sc.detach(payload);
     ctx->dev_free(payload);
     if (wide) {
       sc.detach(wide);
       ctx->dev_free(wide);
     }
+  };
+  if (device_resolve) {
+    uint32_t *d_nst, *d_base, *d_out;
+    const uint32_t tn = (uint32_t)tree.prefix.size();
+    if ((rc = sc.get(&d_nst, tn)) || (rc = sc.get(&d_base, tn)) || (rc = sc.get(&d_out, 64))) return rc;
+    pcv_launch_spec_resolve(ctx, lv, params->resolution, sp.cap, sp.force_mask, d_walk, d_slevel, tn, d_counts, d_nst, d_base, d_map, d_out);
+    ctx->stage_end(PCV_STAGE_NODE_SPLIT);
+    const uint32_t predicted_leaves = (uint32_t)std::count(tree.inner.begin(), tree.inner.end(), (uint8_t)0);
+    if ((rc = queue_record_sort(ctx, bs, t, nullptr, predicted_leaves, false))) return rc;
+    host_lap("record sort queued");
+  }
+  PCV_HIP_CHECK(ctx, hipEventSynchronize(ctx->spec_ev));
+  host_lap("", true);
+  const PcvSpecStatus resolved = pcv_spec_resolve(sp, tree, h_counts, tt);
+  host_lap("resolve");
+  if (resolved != PCV_SPEC_OK) {
+    give_up();
     return PCV_OK;  // *used stays false
   }
   if (tt->prefix.size() > (size_t)nt.capacity) return ctx->fail(PCV_E_OOM, "node table capacity exceeded");
-  std::memcpy(hp + map_off, tt->spec_map.data(), (size_t)tree.num_leaves * 4);
-  PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_map, hp + map_off, (size_t)tree.num_leaves * 4, hipMemcpyHostToDevice, st));
-  // the rank map is applied by the first upsweep of the record sort (one pass over the ranks instead of two)
-  bs->spec_wide = wide;
-  bs->wide_levels = wide_levels;
-  bs->spec_map_dev = d_map;
-  bs->spec_map_entries = tree.num_leaves;
   bs->cont_nodes = tt->cont_nodes;
   bs->cont_from = tt->cont_from;
   // leaves whose points still have to replay the chain: contiguous once the records are sorted ([lo, hi) of the leaf)
-  bs->fix_ranges.clear();
   for (uint32_t k : tt->fix_nodes) bs->fix_ranges.push_back({tt->lo[k], tt->hi[k] - tt->lo[k], (uint32_t)tt->level[k]});
-  // no synchronisation here: the uploads read ctx->pinned_spec, the caller stages the node table in ctx->pinned
-  ctx->stage_end(PCV_STAGE_NODE_SPLIT);
-  bs->spec = true;
-  bs->spec_payload = payload;
-  // the record sort needs nothing but the rank map: it starts now, and every table the host still has to build (here,
-  // in the caller and in pcv_build_finish) is built while it runs.
-  host_lap("map upload, fix ranges");
-  if ((rc = queue_record_sort(ctx, bs, t, nullptr, tt->num_leaves, false))) return rc;
-  host_lap("record sort queued");
+  if (!device_resolve) {
+    // the host's map goes up and is applied by the first upsweep of the record sort; no synchronisation: the upload reads
+    // ctx->pinned_spec, the caller stages the node table in ctx->pinned
+    std::memcpy(hp + map_off, tt->spec_map.data(), (size_t)tree.num_leaves * 4);
+    PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_map, hp + map_off, (size_t)tree.num_leaves * 4, hipMemcpyHostToDevice, st));
+    ctx->stage_end(PCV_STAGE_NODE_SPLIT);
+    host_lap("map upload, fix ranges");
+    if ((rc = queue_record_sort(ctx, bs, t, nullptr, tt->num_leaves, false))) return rc;
+    host_lap("record sort queued");
+  }
+  if ((rc = queue_replay(ctx, bs))) return rc;
   ctx->stage_begin(PCV_STAGE_TABLE);
   t->spec_stats[0] = tree.prefix.size();
   t->spec_stats[1] = (uint64_t)std::count(tree.inner.begin(), tree.inner.end(), (uint8_t)0);

@@ -327,7 +327,6 @@ __global__ __launch_bounds__(BLOCK, PREFETCH ? 6 : 8) void spec_encode_persist_k
   __shared__ uint16_t perm[TILE];
   __shared__ uint16_t wcnt[kGroups][kSpecClasses];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const PcvRouted routed{};  // raw points only
   double qx[2], qy[2], qz[2];
   auto load_tile = [&](uint32_t tile) {
 #pragma unroll

@@ -332,6 +332,13 @@ void pcv_launch_pack_node_table(pcv_ctx* ctx, const PcvNodeTableDev& t, void* pa
 // any candidate)
 void pcv_launch_spec_tree(pcv_ctx* ctx, const PcvNodeTableDev& t, double upper, uint32_t force_mask, uint32_t* ord, uint32_t* walk,
                           uint32_t* sparent, uint8_t* slevel, uint32_t* info);
+// single-chain build: the predicted-leaf -> true-leaf rank map on the device, from the exact counts (`counts`: one u32 per
+// T'' node, leaf entries filled by pcv_launch_rank_hist, inner entries zero). tn = number of T'' nodes (the host knows it
+// from its mirror of the tree); nst / base: tn u32 of scratch each; out: [0] number of true leaves, [1] 1 = prediction too
+// shallow
+void pcv_launch_spec_resolve(pcv_ctx* ctx, const PcvLevels& lv, double resolution, uint32_t cap, uint32_t force_mask, const uint32_t* walk,
+                             const uint8_t* slevel, uint32_t tn, uint32_t* counts, uint32_t* nst, uint32_t* base, uint32_t* map,
+                             uint32_t* out);
 // sorted_lo (deep trees): second key word, sorted together with the first; levels > PCV_MAX_KEY_LEVELS search it
 void pcv_launch_node_split(pcv_ctx* ctx, const PcvNodeTableDev& t, const void* sorted_keys, bool keys32, uint32_t n,
                            const PcvLevels& lv, double resolution, uint32_t max_points_per_node,

@@ -294,7 +294,161 @@ __global__ __launch_bounds__(256) void spec_tree_emit_kernel(PcvNodeTableDev t, 
   }
 }
 
+
+// ---- single-chain build: the rank map ON THE DEVICE (what pcv_spec_resolve computes on the host, pcv_spec.cpp) ----------
+// Exact counts per predicted leaf in, predicted-leaf -> true-leaf map out, so that the record sort can start without the
+// counts travelling to the host and the map travelling back (the host still derives the true tree from the same counts
+// — it needs the node tables — but beside the sort, not in front of it). One workgroup; T'' is level-major (the children
+// of the k-th open sample node, table order, sit at 1 + 8 k ..), so every level is a contiguous index range:
+//   bottom-up: exact count of every node, "would split" (should_split_node, generation.rs:128-150, with the exact count),
+//              true leaves in the subtree;
+//   top-down : depth-first rank of every true leaf = rank base of its parent + leaves of its earlier siblings (children in
+//              digit order: the order pcv_spec_resolve and pcv_build_finish rank them in); everything below a true leaf
+//              inherits its rank; PCV_SPEC_MAP_REPLAY where the leaf is a non-candidate inner node of T'' with no
+//              candidate above it.
+// Both sides apply the same integer rules to the same counts; a disagreement would surface as a parity failure (the
+// device map drives the sort, the host's tree the tables).
+// kLds: the four per-node arrays (walk record, count, leaves + state, rank base) live in LDS — a predicted tree of up to
+// ~10 000 nodes (100-150 M points at the default capacity) fits the 160 KB, and each of the ~26 level steps then costs
+// LDS latency instead of two or three dependent trips to L2 (88 us -> ~20 us for the 7 489 nodes of the bench tree).
+template <bool kLds>
+__global__ __launch_bounds__(1024) void spec_resolve_kernel(PcvLevels lv, double resolution, uint32_t cap, uint32_t force_mask,
+                                                             const uint32_t* __restrict__ g_walk, const uint8_t* __restrict__ slevel,
+                                                             uint32_t tn, uint32_t* __restrict__ g_cnt, uint32_t* __restrict__ g_nst,
+                                                             uint32_t* __restrict__ g_base, uint32_t* __restrict__ map,
+                                                             uint32_t* __restrict__ out /* [0] true leaves, [1] 1 = too shallow */) {
+  extern __shared__ uint32_t dyn[];
+  __shared__ uint32_t lstart[PCV_MAX_KEY_LEVELS + 3];
+  __shared__ uint32_t too_shallow;
+  // generic pointers: LDS (flat access) or global memory
+  const uint32_t* walk = kLds ? dyn : g_walk;
+  uint32_t* cnt = kLds ? dyn + tn : g_cnt;
+  uint32_t* nst = kLds ? dyn + 2 * (size_t)tn : g_nst;   // leaves in the subtree (bits 0..27) | state (bits 28..30, see below)
+  uint32_t* base = kLds ? dyn + 3 * (size_t)tn : g_base;
+  const uint32_t t = threadIdx.x;
+  if (t < PCV_MAX_KEY_LEVELS + 3) lstart[t] = tn;
+  if (t == 0) too_shallow = 0;
+  if (kLds)
+    for (uint32_t i = t; i < tn; i += 1024) {
+      dyn[i] = g_walk[i];
+      dyn[tn + i] = g_cnt[i];
+    }
+  __syncthreads();
+  for (uint32_t i = t; i < tn; i += 1024)
+    if (i == 0 || slevel[i] != slevel[i - 1]) lstart[slevel[i]] = i;
+  __syncthreads();
+  int maxl = 0;
+  for (int l = 0; l <= PCV_MAX_KEY_LEVELS; ++l)
+    if (lstart[l] < tn) maxl = l;
+  const uint32_t l1_first = walk[0] & PCV_SPEC_INDEX_MASK;  // the root's children (level 1) start here
+  auto would_split = [&](uint32_t i, int level, uint32_t c) -> bool {
+    if (level == 0) return true;  // the root is always split (generation.rs:312-323)
+    if (level == 1 && ((force_mask >> ((i - l1_first) & 7u)) & 1u)) return true;  // multi-GPU build: the global tree splits it
+    return c > cap && lv.edge[level] > resolution;
+  };
+  constexpr uint32_t kLeavesMask = 0x0fffffffu;
+  for (int L = maxl; L >= 0; --L) {  // bottom-up
+    const uint32_t b = lstart[L], e = lstart[L + 1];
+    for (uint32_t i = b + t; i < e; i += 1024) {
+      const uint32_t rec = walk[i];
+      uint32_t c, nl;
+      if (rec & PCV_SPEC_LEAF) {
+        c = cnt[i];
+        if (would_split(i, L, c)) atomicOr(&too_shallow, 1u);  // the prediction stops above where the tree goes on
+        nl = c > 0 ? 1u : 0u;
+      } else {
+        const uint32_t first = rec & PCV_SPEC_INDEX_MASK;
+        uint32_t cs[8], ns[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          cs[k] = cnt[first + k];
+          ns[k] = nst[first + k] & kLeavesMask;
+        }
+        c = ((cs[0] + cs[1]) + (cs[2] + cs[3])) + ((cs[4] + cs[5]) + (cs[6] + cs[7]));
+        cnt[i] = c;
+        nl = would_split(i, L, c) ? ((ns[0] + ns[1]) + (ns[2] + ns[3])) + ((ns[4] + ns[5]) + (ns[6] + ns[7])) : (c > 0 ? 1u : 0u);
+      }
+      nst[i] = nl;
+    }
+    __syncthreads();
+  }
+  // top-down. state (bits 28..29 of nst): 0 = no point below (or under such a node), 1 = inner node of the true tree,
+  // 2 = a true leaf or below one; bit 30: a candidate node lies above on the path
+  if (t == 0) {
+    nst[0] = (nst[0] & kLeavesMask) | (1u << 28);
+    base[0] = 0;
+  }
+  __syncthreads();
+  for (int L = 0; L <= maxl; ++L) {
+    const uint32_t b = lstart[L], e = lstart[L + 1];
+    for (uint32_t i = b + t; i < e; i += 1024) {
+      const uint32_t rec = walk[i];
+      const uint32_t s = nst[i] >> 28;
+      if (rec & PCV_SPEC_LEAF) {
+        map[i] = (s & 3u) == 2u ? base[i] : 0u;
+        continue;
+      }
+      const uint32_t first = rec & PCV_SPEC_INDEX_MASK;
+      if ((s & 3u) == 1u) {
+        uint32_t run = base[i];
+        const uint32_t ca = ((s >> 2) & 1u) | ((rec & PCV_SPEC_CANDIDATE) ? 1u : 0u);
+        uint32_t cs[8], ns[8], ws[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {  // every load of the eight children before anything depends on one
+          cs[k] = cnt[first + k];
+          ns[k] = nst[first + k] & kLeavesMask;
+          ws[k] = walk[first + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const uint32_t ch = first + k;
+          if (cs[k] == 0) {
+            nst[ch] = ns[k];  // state 0
+          } else if (would_split(ch, L + 1, cs[k])) {
+            nst[ch] = ns[k] | ((1u | (ca << 2)) << 28);
+            base[ch] = run;
+            run += ns[k];
+          } else {
+            const bool replay = !ca && !(ws[k] & PCV_SPEC_LEAF) && !(ws[k] & PCV_SPEC_CANDIDATE);
+            nst[ch] = ns[k] | (2u << 28);
+            base[ch] = run | (replay ? PCV_SPEC_MAP_REPLAY : 0u);
+            run += 1;
+          }
+        }
+      } else {  // nothing to decide below a true leaf (or below an empty node): the children inherit
+        const uint32_t v = base[i];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          nst[first + k] = (nst[first + k] & kLeavesMask) | (s << 28);
+          base[first + k] = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    out[0] = nst[0] & kLeavesMask;
+    out[1] = too_shallow;
+  }
+}
+
 }  // namespace
+
+void pcv_launch_spec_resolve(pcv_ctx* ctx, const PcvLevels& lv, double resolution, uint32_t cap, uint32_t force_mask, const uint32_t* walk,
+                             const uint8_t* slevel, uint32_t tn, uint32_t* counts, uint32_t* nst, uint32_t* base, uint32_t* map,
+                             uint32_t* out) {
+  // small trees: the per-node arrays in LDS (16 bytes per node; the opt-in for more than 64 KB of dynamic LDS is made once)
+  constexpr size_t kLdsBudget = 156 * 1024;
+  static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&spec_resolve_kernel<true>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget) == hipSuccess;
+  const size_t need = (size_t)tn * 16;
+  if (lds_ok && need <= kLdsBudget)
+    hipLaunchKernelGGL((spec_resolve_kernel<true>), dim3(1), dim3(1024), need, ctx->stream, lv, resolution, cap, force_mask, walk, slevel, tn,
+                       counts, nst, base, map, out);
+  else
+    hipLaunchKernelGGL((spec_resolve_kernel<false>), dim3(1), dim3(1024), 0, ctx->stream, lv, resolution, cap, force_mask, walk, slevel, tn,
+                       counts, nst, base, map, out);
+}
 
 void pcv_launch_spec_tree(pcv_ctx* ctx, const PcvNodeTableDev& t, double upper, uint32_t force_mask, uint32_t* ord, uint32_t* walk,
                           uint32_t* sparent, uint8_t* slevel, uint32_t* info) {

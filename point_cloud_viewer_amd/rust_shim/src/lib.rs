@@ -73,6 +73,7 @@ extern "C" {
     fn pcv_ctx_destroy(ctx: *mut pcv_ctx);
     fn pcv_last_error(ctx: *const pcv_ctx) -> *const c_char;
     fn pcv_build_octree(ctx: *mut pcv_ctx, params: *const PcvBuildParams, points: *const PcvPoints, out: *mut *mut pcv_octree) -> c_int;
+    fn pcv_build_octree_from_ply(ctx: *mut pcv_ctx, params: *const PcvBuildParams, path: *const c_char, with_intensity: c_int, out: *mut *mut pcv_octree) -> c_int;
     fn pcv_octree_write_dir(t: *mut pcv_octree, directory: *const c_char) -> c_int;
     fn pcv_octree_open_dir(ctx: *mut pcv_ctx, directory: *const c_char, out: *mut *mut pcv_octree) -> c_int;
     fn pcv_octree_num_nodes(t: *const pcv_octree) -> u64;
@@ -172,6 +173,24 @@ pub fn build_octree(
     let dir = CString::new(output_directory.as_ref().to_str().unwrap()).unwrap();
     ctx.check(unsafe { pcv_octree_write_dir(tree, dir.as_ptr()) });
     unsafe { pcv_octree_free(tree) };
+    });
+}
+
+/// Same signature and behaviour as `point_viewer::octree::build_octree_from_file` (generation.rs:272-287), which is what
+/// `src/bin/build_octree.rs:47-52` calls: the PLY's vertex records go to the device as they are in the file and are
+/// decoded there (cast to f64 + `comment offset`, ply.rs:488-493), the bounding box is computed on the device
+/// (find_bounding_box, generation.rs:256-270), then build + directory write. Panics like the reference on any error,
+/// including a PLY without the `intensity` the attribute list asks for.
+pub fn build_octree_from_file(output_directory: impl AsRef<Path>, resolution: f64, filename: impl AsRef<Path>, attributes: &[&str]) {
+    CONTEXT.with(|ctx| {
+        let params = PcvBuildParams { resolution, bbox_min: [0.0; 3], bbox_max: [0.0; 3], max_points_per_node: 0, flags: 0 };
+        let file = CString::new(filename.as_ref().to_str().unwrap()).unwrap();
+        let mut tree = std::ptr::null_mut();
+        let with_intensity = attributes.contains(&"intensity") as c_int;
+        ctx.check(unsafe { pcv_build_octree_from_ply(ctx.0, &params, file.as_ptr(), with_intensity, &mut tree) });
+        let dir = CString::new(output_directory.as_ref().to_str().unwrap()).unwrap();
+        ctx.check(unsafe { pcv_octree_write_dir(tree, dir.as_ptr()) });
+        unsafe { pcv_octree_free(tree) };
     });
 }
 

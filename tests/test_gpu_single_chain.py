@@ -95,10 +95,12 @@ def test_oversampled_clusters_replay_the_chain_from_their_coordinates(ctx):
 
 
 def test_many_small_leaves_take_8_bit_digits_and_the_global_rank_map(ctx):
-    """27 000+ leaves: the record sort runs two 8-bit passes (256 digit values: the wide digit state of the 12-byte
-    downsweep) and the predicted tree has more nodes than the rank map's LDS copy holds (the first upsweep then reads the
-    map from memory) — the geometry a 1 B-point build has, at test size."""
-    n, cap = 2_000_000, 150
+    """28 000 leaves: the record sort runs two 8-bit passes (256 digit values: the wide digit state of the 12-byte
+    downsweep), the predicted tree has more nodes than the rank map's LDS copy holds (the first upsweep then reads the
+    map from memory) and more than the device-side resolve keeps in LDS — the geometry a 1 B-point build has, at test
+    size. (A capacity of 150 would push the predicted tree's bound past the 24 rank bits of the packed key: that build
+    takes the 20-byte records and is byte-exact as well.)"""
+    n, cap = 2_000_000, 250
     x, y, z, rgb, bmin, bmax = synthetic.gaussian_clusters(n, seed=31, num_clusters=9, extent=250.0, sigma_range=(0.3, 7.0))
     with O.max_points_per_node(cap):
         want = O.build_closed(0.001, bmin, bmax, x, y, z, rgb, threads=8)
@@ -108,6 +110,13 @@ def test_many_small_leaves_take_8_bit_digits_and_the_global_rank_map(ctx):
     info = t.build_info()
     assert_same(t.to_dict(), want)
     assert info["single_chain"] and info["record_bytes"] == 12 and info["predicted_nodes"] > 15_360, info
+    t.free()
+    t = ctx.build(0.001, pcv.Aabb(bmin, bmax), x[:1_200_000], y[:1_200_000], z[:1_200_000], rgb[:1_200_000], max_points_per_node=90,
+                  single_chain=True)
+    with O.max_points_per_node(90):
+        want = O.build_closed(0.001, bmin, bmax, x[:1_200_000], y[:1_200_000], z[:1_200_000], rgb[:1_200_000], threads=8)
+    assert_same(t.to_dict(), want)
+    assert t.build_info()["record_bytes"] == 20, t.build_info()  # the predicted tree could outgrow 24 rank bits
 
 
 def test_single_chain_is_the_default_from_4M_points_and_keeps_candidate_codes(ctx):
