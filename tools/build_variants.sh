@@ -8,6 +8,6 @@ cd "$(dirname "$0")/../point_cloud_viewer_amd/csrc"
 FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math --offload-arch=gfx950 -Wall -Wno-unused-result"
 OBJ=/tmp/pcv_variant_${TAG}.o
 /opt/rocm/bin/hipcc $FLAGS $DEFS -c $SRC -o $OBJ
-OTHERS=$(ls *.o | grep -v "^${SRC%.hip}.o$")
+OTHERS=$(ls *.o | grep -v "^exp_" | grep -v "^${SRC%.hip}.o$")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libpcv_hip_${TAG}.so $OTHERS $OBJ -lpthread
 ls -la ../libpcv_hip_${TAG}.so
