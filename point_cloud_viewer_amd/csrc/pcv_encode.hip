@@ -704,7 +704,10 @@ struct alignas(16) PcvClimber {
 };
 
 // one sorted slot of `settle`: finish it in its leaf, or hand it to `climb`
-template <bool kCompact>
+// kClimb16: the climber record is the 16-byte payload alone {code x, code y, code z, rgb} — leaf, slot and position in the
+// parent follow from the record's index (climbers are dense per leaf, in slot order: index = climb_base[leaf] + j / 8);
+// used by the leaf-wise kernels when there is no intensity and no Float64 level (half the climber traffic)
+template <bool kCompact, bool kClimb16 = false>
 __device__ __forceinline__ void settle_one(const PcvPromoteTables& pt, uint64_t s, const PcvNodeRec& c, uint32_t r, uint4 p,
                                            const uint32_t h[3], uint32_t inten, const uint32_t* __restrict__ climb_base,
                                            PcvClimber* __restrict__ climbers, const PromoteOut& o,
@@ -720,6 +723,7 @@ __device__ __forceinline__ void settle_one(const PcvPromoteTables& pt, uint64_t 
   }
   const uint32_t j = (uint32_t)s - c.lo;
   if (c.parent == 0xffffffffu || (j & 7u) != 0) promote_one<false>(pt, s, c, p, h[0], h[1], h[2], inten, o);
+  else if (kClimb16) reinterpret_cast<uint4*>(climbers)[climb_base[r] + (j >> 3)] = p;
   else climbers[climb_base[r] + (j >> 3)] = PcvClimber{p, r, (uint32_t)s, inten, 0u};
 }
 
@@ -781,7 +785,7 @@ __global__ __launch_bounds__(256) void promote_settle_kernel(
 // A leaf below a split first candidate (pcv_spec.h) arrives with the candidate level's codes: its items carry the index of
 // the leaf's continuation range (PcvSettleItem::pad = 1 + index), and the workgroup continues the chain to the leaf's
 // level in registers before it settles the slot — no separate pass over those records, no launch.
-template <bool kCompact>
+template <bool kCompact, bool kClimb16>
 __global__ __launch_bounds__(256) void promote_settle_leaf_kernel(
     PcvPromoteTables pt, const PcvSettleItem* __restrict__ items, const uint32_t* __restrict__ rank,
     const uint4* __restrict__ payload, const uint32_t* __restrict__ cx_hi, const uint32_t* __restrict__ cy_hi,
@@ -836,7 +840,7 @@ __global__ __launch_bounds__(256) void promote_settle_leaf_kernel(
         }
       }
       pcv_continue_codes(lv, rg, u.x, u.y, u.z);
-      settle_one<false>(pt, s, c, it.rank, u, h[k], in[k], climb_base, climbers, o, nullptr);  // codes are unpacked already
+      settle_one<false, kClimb16>(pt, s, c, it.rank, u, h[k], in[k], climb_base, climbers, o, nullptr);  // codes are unpacked already
     }
     return;
   }
@@ -845,7 +849,7 @@ __global__ __launch_bounds__(256) void promote_settle_leaf_kernel(
     const uint32_t s = it.begin + threadIdx.x + 256 * k;
     if (kCompact)  // x: both codes, or the input index
       p[k] = make_uint4(q[k].x, 0u, q[k].y & 0xffffu, (q[k].y >> 16) | ((key[k] & 0xffu) << 16));
-    if (s < it.end) settle_one<kCompact>(pt, s, c, it.rank, p[k], h[k], in[k], climb_base, climbers, o, wide);
+    if (s < it.end) settle_one<kCompact, kClimb16>(pt, s, c, it.rank, p[k], h[k], in[k], climb_base, climbers, o, wide);
   }
 }
 
@@ -869,6 +873,9 @@ __global__ __launch_bounds__(256) void promote_climb_kernel(
 // climber climbs at least once, from its leaf into the leaf's parent: both records are wave-uniform scalar loads that
 // run beside the climber loads, and that first step is straight-line code; only the every-8th climbers go on with
 // per-lane parent records.
+// kClimb16: 16-byte climber records (the payload alone); the item's pad holds the leaf's first climber index, so the
+// record's own index gives its slot (lo + 8 q) and its place in the parent's stream (child_off + q).
+template <bool kClimb16>
 __global__ __launch_bounds__(256) void promote_climb_leaf_kernel(PcvPromoteTables pt, const PcvSettleItem* __restrict__ items,
                                                                   const PcvClimber* __restrict__ climbers,
                                                                   const uint32_t* __restrict__ cx_hi,
@@ -877,25 +884,36 @@ __global__ __launch_bounds__(256) void promote_climb_leaf_kernel(PcvPromoteTable
   const PcvSettleItem it = items[blockIdx.x];
   const uint32_t k = it.begin + threadIdx.x;
   const bool live = k < it.end;
-  const PcvClimber c = climbers[live ? k : it.begin];
-  uint32_t h[3] = {0, 0, 0};
-  if (cx_hi) {
-    h[0] = cx_hi[c.slot];
-    h[1] = cy_hi[c.slot];
-    h[2] = cz_hi[c.slot];
-  }
+  const uint32_t kk = live ? k : it.begin;
+  uint4 pay;
+  uint32_t slot_rel, inten = 0;
   const PcvNodeRec leaf = pt.leaf_rec[it.rank];
+  if (kClimb16) {
+    pay = reinterpret_cast<const uint4*>(climbers)[kk];
+    slot_rel = (kk - it.pad) << 3;  // j of the climber inside its leaf's stream
+  } else {
+    const PcvClimber c = climbers[kk];
+    pay = c.pay;
+    slot_rel = c.slot - leaf.lo;
+    inten = c.inten;
+  }
+  uint32_t h[3] = {0, 0, 0};
+  if (!kClimb16 && cx_hi) {
+    h[0] = cx_hi[leaf.lo + slot_rel];
+    h[1] = cy_hi[leaf.lo + slot_rel];
+    h[2] = cz_hi[leaf.lo + slot_rel];
+  }
   const PcvNodeRec par = pt.node_rec[leaf.parent];  // a leaf with climbers is not the root
   if (!live) return;
-  uint64_t code[3] = {c.pay.x | ((uint64_t)h[0] << 32), c.pay.y | ((uint64_t)h[1] << 32), c.pay.z | ((uint64_t)h[2] << 32)};
+  uint64_t code[3] = {pay.x | ((uint64_t)h[0] << 32), pay.y | ((uint64_t)h[1] << 32), pay.z | ((uint64_t)h[2] << 32)};
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     const double q = pcv_decode_coord(leaf.enc, code[a], leaf.mn[a], leaf.edge);
     code[a] = pcv_encode_coord(par.enc, q, par.mn[a], par.edge, PcvRecip{par.inv_edge, par.inv_edge_lo});
   }
-  const uint32_t j = leaf.child_off + ((c.slot - leaf.lo) >> 3);  // position in the parent's stream
-  promote_one<true>(pt, (uint64_t)par.lo + j, par, make_uint4((uint32_t)code[0], (uint32_t)code[1], (uint32_t)code[2], c.pay.w),
-                    (uint32_t)(code[0] >> 32), (uint32_t)(code[1] >> 32), (uint32_t)(code[2] >> 32), c.inten, o);
+  const uint32_t j = leaf.child_off + (slot_rel >> 3);  // position in the parent's stream
+  promote_one<true>(pt, (uint64_t)par.lo + j, par, make_uint4((uint32_t)code[0], (uint32_t)code[1], (uint32_t)code[2], pay.w),
+                    (uint32_t)(code[0] >> 32), (uint32_t)(code[1] >> 32), (uint32_t)(code[2] >> 32), inten, o);
 }
 
 }  // namespace
@@ -1027,16 +1045,23 @@ void pcv_launch_promote_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvPromo
                                const PcvSettleItem* climb_items, uint32_t num_climb_items, const void* cont_ranges) {
   if (n == 0) return;
   PromoteOut o{xyz_blob, rgb_blob, inten_blob};
+  // 16-byte climbers: leaf-wise kernels, no intensity plane, no Float64 high words
+  static const bool climb16_on = [] {  // PCV_CLIMB16=0 (libpcv_hip_exp.so): 32-byte climber records everywhere
+    const char* e = pcv_experiment("PCV_CLIMB16");
+    return !e || atoi(e) != 0;
+  }();
+  const bool climb16 = climb16_on && items && climb_items && !inten_bits && !cx_hi;
   if (items) {
     PcvProf prof(ctx, PCV_K_PROMOTE_ENCODE);
-    if (num_items && wide)
-      hipLaunchKernelGGL((promote_settle_leaf_kernel<true>), dim3(num_items), dim3(256), 0, ctx->stream, pt, items, rank,
-                         (const uint4*)payload, cx_hi, cy_hi, cz_hi, inten_bits, climb_base, (PcvClimber*)climbers, o, (const uint4*)wide, lv,
-                         (const PcvContRange*)cont_ranges);
-    else if (num_items)
-      hipLaunchKernelGGL((promote_settle_leaf_kernel<false>), dim3(num_items), dim3(256), 0, ctx->stream, pt, items, rank,
-                         (const uint4*)payload, cx_hi, cy_hi, cz_hi, inten_bits, climb_base, (PcvClimber*)climbers, o, (const uint4*)nullptr, lv,
-                         (const PcvContRange*)cont_ranges);
+#define PCV_SETTLE_LEAF(C, K, W)                                                                                              \
+  hipLaunchKernelGGL((promote_settle_leaf_kernel<C, K>), dim3(num_items), dim3(256), 0, ctx->stream, pt, items, rank,           \
+                     (const uint4*)payload, cx_hi, cy_hi, cz_hi, inten_bits, climb_base, (PcvClimber*)climbers, o, (const uint4*)(W), lv, \
+                     (const PcvContRange*)cont_ranges)
+    if (num_items && wide && climb16) PCV_SETTLE_LEAF(true, true, wide);
+    else if (num_items && wide) PCV_SETTLE_LEAF(true, false, wide);
+    else if (num_items && climb16) PCV_SETTLE_LEAF(false, true, nullptr);
+    else if (num_items) PCV_SETTLE_LEAF(false, false, nullptr);
+#undef PCV_SETTLE_LEAF
   } else {
     PcvProf prof(ctx, PCV_K_PROMOTE_ENCODE);
     static const int slots = [] {  // PCV_SETTLE_SLOTS (experiments): 1, 2 or 4 sorted slots per lane
@@ -1057,8 +1082,11 @@ void pcv_launch_promote_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvPromo
   }
   if (num_climbers && climb_items) {
     PcvProf prof(ctx, PCV_K_PROMOTE_CLIMB);
-    if (num_climb_items)
-      hipLaunchKernelGGL(promote_climb_leaf_kernel, dim3(num_climb_items), dim3(256), 0, ctx->stream, pt, climb_items,
+    if (num_climb_items && climb16)
+      hipLaunchKernelGGL(promote_climb_leaf_kernel<true>, dim3(num_climb_items), dim3(256), 0, ctx->stream, pt, climb_items,
+                         (const PcvClimber*)climbers, cx_hi, cy_hi, cz_hi, o);
+    else if (num_climb_items)
+      hipLaunchKernelGGL(promote_climb_leaf_kernel<false>, dim3(num_climb_items), dim3(256), 0, ctx->stream, pt, climb_items,
                          (const PcvClimber*)climbers, cx_hi, cy_hi, cz_hi, o);
   } else if (num_climbers) {
     PcvProf prof(ctx, PCV_K_PROMOTE_CLIMB);

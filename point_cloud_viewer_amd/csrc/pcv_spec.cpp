@@ -264,7 +264,8 @@ uint64_t pcv_climb_layout(const uint32_t* count, const uint8_t* climbs, uint32_t
     if (!climbs[r]) continue;
     const uint64_t k8 = ((uint64_t)count[r] + 7) / 8;
     for (uint64_t b = 0; b < k8; b += kPcvClimbTile)
-      out[n++] = PcvSettleItem{r, (uint32_t)(total + b), (uint32_t)(total + std::min<uint64_t>(b + kPcvClimbTile, k8)), 0u};
+      out[n++] = PcvSettleItem{r, (uint32_t)(total + b), (uint32_t)(total + std::min<uint64_t>(b + kPcvClimbTile, k8)),
+                               (uint32_t)total /* == climb_base[r]: the leaf's first climber record */};
     total += k8;
   }
   *num_items = n;

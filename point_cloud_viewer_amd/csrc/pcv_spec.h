@@ -133,6 +133,7 @@ constexpr uint32_t kPcvClimbTile = 256;
 uint32_t pcv_settle_items(const uint32_t* lo, const uint32_t* count, uint32_t num_leaves, PcvSettleItem* out);
 // Climbers: every 8th point (j % 8 == 0) of a leaf whose node is not the root (climbs[r] != 0) — ceil(count / 8) records,
 // dense from climb_base[r] (filled here: exclusive prefix sum in rank order). Writes the climb items, stores their number
-// in *num_items (<= total / kPcvClimbTile + num_leaves) and returns the total number of climber records.
+// in *num_items (<= total / kPcvClimbTile + num_leaves) and returns the total number of climber records. A climb item's
+// pad is its leaf's climb_base (with 16-byte climber records a record's index is all that says which slot it came from).
 uint64_t pcv_climb_layout(const uint32_t* count, const uint8_t* climbs, uint32_t num_leaves, uint32_t* climb_base,
                           PcvSettleItem* out, uint32_t* num_items);

@@ -143,3 +143,4 @@ def test_settle_and_climb_work_lists_partition_every_leaf_exactly_once():
         assert np.all(climb[1:, 1] == climb[:-1, 2])
         assert np.all(climb[:, 1] >= base[rc_]) and np.all(climb[:, 2].astype(np.int64) <= base[rc_].astype(np.int64) + k8[rc_])
         assert np.all(climbs[rc_] != 0)
+        assert np.array_equal(climb[:, 3], base[rc_])  # pad = the leaf's first climber record
