@@ -426,9 +426,10 @@ def query_bench(args):
                        "query_points_points_checked": pts_checked, "query_points_count_mismatches": cnt_bad,
                        "query_points_content_mismatches": pts_bad, "query_points_check_s": round(cpu_c, 1),
                        "ok": rel_bad == 0 and size_bad == 0 and vis_bad == 0 and cnt_bad == 0 and pts_bad == 0},
-            "cpu_baseline": {"value": round(V * M / cpu_a / 1e6, 3), "unit": "Mpairs/s", "cores": 1, "kind": "port",
-                             "sample": f"first {V} frusta x {M} nodes, SAT relation + size on screen, {cpu_a:.1f} s; "
-                                       f"get_visible_nodes: {V / cpu_b:.1f} frusta/s"}}
+            "cpu_baseline": None if V == 0 else {
+                "value": round(V * M / cpu_a / 1e6, 3), "unit": "Mpairs/s", "cores": 1, "kind": "port",
+                "sample": f"first {V} frusta x {M} nodes, SAT relation + size on screen, {cpu_a:.1f} s; "
+                          f"get_visible_nodes: {V / cpu_b:.1f} frusta/s"}}
 
 
 def run_virtual_ranks(args, torch, pcv, dev):
