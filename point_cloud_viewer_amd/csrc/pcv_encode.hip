@@ -306,6 +306,8 @@ __global__ __launch_bounds__(BLOCK) void spec_encode_kernel(
   if (inten_bits) inten_bits[i] = __float_as_uint(intensity[i]);
 }
 
+#ifdef PCV_EXPERIMENTS
+// (libpcv_hip_exp.so only: measured slower than the kernel above — DESIGN.md §6, profiles/r03h_*)
 // Persistent form of the binned pass for raw (not routed) input. The kernel above starts one workgroup per 512 points:
 // its eight waves load coordinates, look the depth up, sort themselves through five barriers — and only then have
 // arithmetic to issue; with four such workgroups per CU the SIMDs idle a quarter of the time (VALU issue 71 %, half of
@@ -449,6 +451,7 @@ __global__ __launch_bounds__(BLOCK, PREFETCH ? 6 : 8) void spec_encode_persist_k
     }
   }
 }
+#endif  // PCV_EXPERIMENTS
 #undef PCV_SPEC_WALK
 #undef PCV_SPEC_LOOP
 
@@ -953,6 +956,7 @@ void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* w
     return e ? atoi(e) : 512;
   }();
   const bool bin = bin_mode != 0 && depth_grid != nullptr;
+#ifdef PCV_EXPERIMENTS
   // raw input: the persistent kernel (PCV_SPEC_PERSIST=0, libpcv_hip_exp.so: one workgroup per 512 points as before;
   // PCV_SPEC_PERSIST=k: k workgroups per CU)
   static const int persist = [] {
@@ -979,6 +983,7 @@ void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* w
     }
     return;
   }
+#endif
   if (!bin)
     launch_spec_encode_t<false, 256>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, inten_bits,
                                      depth_grid, wide);

@@ -27,6 +27,9 @@ struct pcv_ply {
 namespace {
 
 enum Type { T_I8, T_U8, T_I16, T_U16, T_I32, T_U32, T_F32, T_F64, T_BAD };  // == PcvPlyType (pcv_ply_layout.h)
+static_assert(T_I8 == (int)PCV_PLY_I8 && T_U8 == (int)PCV_PLY_U8 && T_I16 == (int)PCV_PLY_I16 && T_U16 == (int)PCV_PLY_U16 &&
+                  T_I32 == (int)PCV_PLY_I32 && T_U32 == (int)PCV_PLY_U32 && T_F32 == (int)PCV_PLY_F32 && T_F64 == (int)PCV_PLY_F64,
+              "the host parser and the device decode share the type numbering");
 Type parse_type(const std::string& s) {  // ply.rs:62-80 DataType::from_str
   if (s == "char" || s == "int8") return T_I8;
   if (s == "uchar" || s == "uint8") return T_U8;

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(kBlock) void upsweep_kernel(const KeyT* __restrict_
 // kMapLds: the map (one entry per predicted leaf; 30 KB for a 100 M-point tree) is copied into LDS first — eight
 // dependent lookups per lane and iteration then cost LDS latency instead of a trip to the vector L1 / L2 that the
 // streaming keys keep evicting it from. Static + dynamic LDS stay inside the 64 KB a kernel gets without opting in.
-constexpr uint32_t kMapLdsEntries = 15360;  // 60 KB
+constexpr uint32_t kMapLdsEntries = 15000;  // 60 000 bytes next to the 4 KB of counters
 // kCompact (12-byte records, pcv_internal.h): key = rank << 8 | blue, payload = uint2; `shift` is the digit's position
 // inside the KEY (8 + its position inside the rank).
 template <bool kMapLds, bool kCompact>
