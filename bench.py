@@ -554,6 +554,9 @@ def main():
     ap.add_argument("--virtual-ranks", type=int, default=0,
                     help="config 3 with V thread-ranks on ONE GPU, merged octree compared with the single-GPU build")
     ap.add_argument("--seed3", type=int, default=2, help="seed of the config-3 cloud")
+    ap.add_argument("--config3", action="store_true",
+                    help="take the config-3 cloud (block-wise generator, --points per rank or 1e9 / N) even with one rank: with "
+                         "--force-sharded this is the --gpus N code path at world size 1")
     ap.add_argument("--verify", action="store_true",
                     help="after the timed region: one more build compared byte for byte with the CPU oracle (default at N=1 "
                          "on the plain config-2 run; this flag forces it elsewhere, incl. the sharded path)")
@@ -624,7 +627,7 @@ def main():
 
     sharded = world > 1 or args.force_sharded
     offset = (-2.7e6, -4.3e6, 3.8e6) if args.ecef else (0.0, 0.0, 0.0)
-    config3 = world > 1 and not args.ecef
+    config3 = (world > 1 or args.config3) and not args.ecef
     if config3:
         # BASELINE config 3: ONE cloud (1 B points unless --points gives every rank its share), rank r holds slice r
         total = args.points * world if args.points else 1_000_000_000
@@ -735,8 +738,10 @@ def main():
             if not same:
                 return None, os.path.relpath(path, ROOT) + f" (STALE: taken from build {prof.get('build_hash')}, running {bhash})"
             per = prof.get("per_launch", {})
-            # the library's event names and the rocprof kernel names differ for two kernels
-            alias = {"promote_settle_kernel": "promote_settle_leaf_kernel", "promote_climb_kernel": "promote_climb_leaf_kernel"}
+            # the library's event names and the rocprof kernel names differ for some kernels (the profile lists the larger
+            # launch where one kernel runs with several key widths: the u32 upsweep, not the sample's u64 one)
+            alias = {"promote_settle_kernel": "promote_settle_leaf_kernel", "promote_climb_kernel": "promote_climb_leaf_kernel",
+                     "downsweep_rec_kernel": "downsweep_rec12_kernel", "upsweep_kernel<u32>": "upsweep_kernel"}
             return per.get(name, per.get(alias.get(name, name))), os.path.relpath(path, ROOT)
 
         dom = max(timed, key=lambda k: timed[k][1])  # dominant kernel by accumulated time inside the timed region
