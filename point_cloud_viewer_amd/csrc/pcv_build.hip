@@ -207,25 +207,48 @@ int pcv_ctx::h2d_fill(void* dst, size_t bytes, const std::function<bool(uint8_t*
     }
     unsigned hw = std::thread::hardware_concurrency();
     // copies into pinned memory saturate the link with 7 threads; preads from a file (pcv_build_octree_from_ply) want more
-    host_pool.start(hw >= 64 ? 15 : (hw >= 16 ? 7 : (hw > 2 ? hw / 2 - 1 : 0)));
+    unsigned workers = hw >= 64 ? 15 : (hw >= 16 ? 7 : (hw > 2 ? hw / 2 - 1 : 0));
+    if (const char* e = pcv_experiment("PCV_H2D_THREADS")) workers = (unsigned)std::max(0, atoi(e));
+    host_pool.start(workers);
   }
-  constexpr size_t kPart = 2u << 20;
+  // one part per worker (the caller works too) and chunk, not less than 256 KiB
+  const size_t nworkers = host_pool.threads.size() + 1;
+  const size_t kPart = std::max<size_t>(256u << 10, ((kRingChunk + nworkers - 1) / nworkers + 4095) & ~(size_t)4095);
   std::atomic<int> bad{0};
+#ifdef PCV_EXPERIMENTS
+  static const bool trace = pcv_experiment("PCV_H2D_TRACE") != nullptr;
+  double t_wait = 0, t_fill = 0, t_issue = 0;
+  const auto t_begin = std::chrono::steady_clock::now();
+#define PCV_H2D_T(acc, stmt)                                                                          \
+  {                                                                                                   \
+    const auto t0_ = std::chrono::steady_clock::now();                                                \
+    stmt;                                                                                             \
+    acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0_).count(); \
+  }
+#else
+#define PCV_H2D_T(acc, stmt) stmt;
+#endif
   for (size_t off = 0; off < bytes; off += kRingChunk) {
     const size_t len = bytes - off < kRingChunk ? bytes - off : kRingChunk;
     const int slot = ring_next;
     ring_next = (ring_next + 1) % kRingSlots;
-    if (ring_busy[slot]) PCV_HIP_CHECK(this, hipEventSynchronize(ring_ev[slot]));  // its previous DMA has left the chunk
+    if (ring_busy[slot]) PCV_H2D_T(t_wait, PCV_HIP_CHECK(this, hipEventSynchronize(ring_ev[slot])))  // its previous DMA has left the chunk
     uint8_t* chunk = (uint8_t*)ring[slot];
-    host_pool.run((len + kPart - 1) / kPart, [&](size_t p) {
+    PCV_H2D_T(t_fill, host_pool.run((len + kPart - 1) / kPart, [&](size_t p) {
       const size_t b = p * kPart, e = b + kPart < len ? b + kPart : len;
       if (!fill(chunk + b, off + b, e - b)) bad.store(1);
-    });
+    }))
     if (bad.load()) return fail(PCV_E_IO, "reading the source of a host-to-device copy failed");
-    PCV_HIP_CHECK(this, hipMemcpyAsync((uint8_t*)dst + off, chunk, len, hipMemcpyHostToDevice, stream));
-    PCV_HIP_CHECK(this, hipEventRecord(ring_ev[slot], stream));
+    PCV_H2D_T(t_issue, PCV_HIP_CHECK(this, hipMemcpyAsync((uint8_t*)dst + off, chunk, len, hipMemcpyHostToDevice, stream));
+              PCV_HIP_CHECK(this, hipEventRecord(ring_ev[slot], stream)))
     ring_busy[slot] = true;
   }
+#undef PCV_H2D_T
+#ifdef PCV_EXPERIMENTS
+  if (trace)
+    fprintf(stderr, "[pcv h2d] %.1f MB: total %.2f ms (waiting for a ring slot %.2f, filling %.2f, issuing %.2f)\n", bytes / 1e6,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(), t_wait, t_fill, t_issue);
+#endif
   return PCV_OK;
 }
 

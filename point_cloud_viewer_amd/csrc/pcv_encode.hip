@@ -701,6 +701,17 @@ __device__ __forceinline__ void promote_one(const PcvPromoteTables& pt, uint64_t
 // their records into a COMPACT array (climber k of leaf r sits at climb_base[r] + k, so the array is dense and in slot
 // order) and `climb` runs one lane per entry — its waves are full of climbers and it reads 32 bytes per climber instead
 // of touching every sector of the 16-byte payload array to use an eighth of it.
+#ifdef PCV_EXPERIMENTS
+// (libpcv_hip_exp.so, PCV_WIDE_MASK=m) the wide-code gathers of `settle` fold onto the first m + 1 entries: WRONG output,
+// it only times the kernel without the line fetches the sparse gather costs (the bound of any fix for them)
+__constant__ uint32_t pcv_exp_wide_mask = 0xffffffffu;
+// (PCV_SETTLE_XCD=1) number of settle items when workgroup b takes item (b % 8) * ceil(items / 8) + b / 8: workgroups go
+// round-robin over the 8 XCDs, so consecutive items (slices of one leaf, neighbouring leaves) then share one L2
+__constant__ uint32_t pcv_exp_settle_items = 0;
+#define PCV_WIDE_INDEX(i) ((i) & pcv_exp_wide_mask)
+#else
+#define PCV_WIDE_INDEX(i) (i)
+#endif
 struct alignas(16) PcvClimber {
   uint4 pay;
   uint32_t rank, slot, inten, pad;
@@ -720,7 +731,7 @@ __device__ __forceinline__ void settle_one(const PcvPromoteTables& pt, uint64_t 
       p.y = p.x >> 16;
       p.x &= 0xffffu;
     } else {  // Float32-coded leaf: p.x is the input index
-      const uint4 w = wide[p.x];
+      const uint4 w = wide[PCV_WIDE_INDEX(p.x)];
       p.x = w.x, p.y = w.y, p.z = w.z;
     }
   }
@@ -796,7 +807,14 @@ __global__ __launch_bounds__(256) void promote_settle_leaf_kernel(
     PcvClimber* __restrict__ climbers, PromoteOut o, const uint4* __restrict__ wide, PcvLevels lv,
     const PcvContRange* __restrict__ cont_ranges) {
   constexpr int kSlots = (int)kPcvSettleTile / 256;
-  const PcvSettleItem it = items[blockIdx.x];
+  uint32_t item = blockIdx.x;
+#ifdef PCV_EXPERIMENTS
+  if (pcv_exp_settle_items) {
+    item = (blockIdx.x & 7u) * ((pcv_exp_settle_items + 7u) / 8u) + (blockIdx.x >> 3);
+    if (item >= pcv_exp_settle_items) return;
+  }
+#endif
+  const PcvSettleItem it = items[item];
   // every record load is issued before anything is consumed; dead lanes of the leaf's last tile re-read the tile's
   // first slot (an item is never empty) so that no load sits behind a branch
   uint32_t key[kSlots], h[kSlots][3], in[kSlots];
@@ -838,7 +856,7 @@ __global__ __launch_bounds__(256) void promote_settle_leaf_kernel(
         if (fe <= PCV_ENC_UINT16) {
           u.x = q[k].x & 0xffffu, u.y = q[k].x >> 16, u.z = q[k].y & 0xffffu;
         } else {
-          const uint4 w = wide[q[k].x];
+          const uint4 w = wide[PCV_WIDE_INDEX(q[k].x)];
           u.x = w.x, u.y = w.y, u.z = w.z;
         }
       }
@@ -1051,15 +1069,36 @@ void pcv_launch_promote_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvPromo
   if (n == 0) return;
   PromoteOut o{xyz_blob, rgb_blob, inten_blob};
   // 16-byte climbers: leaf-wise kernels, no intensity plane, no Float64 high words
+#ifdef PCV_EXPERIMENTS
+  static const bool wide_mask_set = [] {
+    if (const char* e = pcv_experiment("PCV_WIDE_MASK")) {
+      const uint32_t m = (uint32_t)strtoul(e, nullptr, 0);
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(pcv_exp_wide_mask), &m, sizeof(m));
+    }
+    return true;
+  }();
+  (void)wide_mask_set;
+#endif
   static const bool climb16_on = [] {  // PCV_CLIMB16=0 (libpcv_hip_exp.so): 32-byte climber records everywhere
     const char* e = pcv_experiment("PCV_CLIMB16");
     return !e || atoi(e) != 0;
   }();
   const bool climb16 = climb16_on && items && climb_items && !inten_bits && !cx_hi;
   if (items) {
+    uint32_t settle_grid = num_items;
+#ifdef PCV_EXPERIMENTS
+    static const bool xcd = [] {
+      const char* e = pcv_experiment("PCV_SETTLE_XCD");
+      return e && atoi(e) != 0;
+    }();
+    if (xcd) {
+      settle_grid = (num_items + 7u) / 8u * 8u;
+      (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(pcv_exp_settle_items), &num_items, sizeof(num_items), 0, hipMemcpyHostToDevice, ctx->stream);
+    }
+#endif
     PcvProf prof(ctx, PCV_K_PROMOTE_ENCODE);
 #define PCV_SETTLE_LEAF(C, K, W)                                                                                              \
-  hipLaunchKernelGGL((promote_settle_leaf_kernel<C, K>), dim3(num_items), dim3(256), 0, ctx->stream, pt, items, rank,           \
+  hipLaunchKernelGGL((promote_settle_leaf_kernel<C, K>), dim3(settle_grid), dim3(256), 0, ctx->stream, pt, items, rank,         \
                      (const uint4*)payload, cx_hi, cy_hi, cz_hi, inten_bits, climb_base, (PcvClimber*)climbers, o, (const uint4*)(W), lv, \
                      (const PcvContRange*)cont_ranges)
     if (num_items && wide && climb16) PCV_SETTLE_LEAF(true, true, wide);

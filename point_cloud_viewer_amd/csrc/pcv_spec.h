@@ -126,7 +126,12 @@ PcvSpecStatus pcv_spec_resolve(const PcvSpecParams& p, const PcvSpecTree& t, con
 struct alignas(16) PcvSettleItem {
   uint32_t rank, begin, end, pad;
 };
-constexpr uint32_t kPcvSettleTile = 512;
+// Four slots per lane: `settle` lives on the record loads it has in flight (r03t A/B at 100 M points, one box: 512 slots per
+// workgroup 0.680-0.683 ms, 1 024 0.637-0.639, 2 048 0.663 — 124 VGPRs, four waves per SIMD)
+#ifndef PCV_SETTLE_TILE
+#define PCV_SETTLE_TILE 1024
+#endif
+constexpr uint32_t kPcvSettleTile = PCV_SETTLE_TILE;
 constexpr uint32_t kPcvClimbTile = 256;
 // Leaves in rank order: leaf r holds the sorted slots [lo[r], lo[r] + count[r]). Writes the settle items (in slot order)
 // and returns their number (<= n / kPcvSettleTile + num_leaves).

@@ -102,7 +102,7 @@ def test_forced_level1_split_and_duplicates():
 
 def test_settle_and_climb_work_lists_partition_every_leaf_exactly_once():
     """K6 work lists (csrc/pcv_spec.cpp pcv_settle_items / pcv_climb_layout): the leaf-wise kernels rely on every sorted slot
-    lying in exactly one settle item of its own leaf (<= 512 slots) and every climber record — every 8th point of a leaf
+    lying in exactly one settle item of its own leaf (<= kPcvSettleTile = 1 024 slots) and every climber record — every 8th point of a leaf
     whose node is not the root (generation.rs:222-238: `i % 8 == 0`), dense per leaf from climb_base — in exactly one
     climb item of its own leaf (<= 256 records)."""
     lib = pcv.load_library()
@@ -117,16 +117,17 @@ def test_settle_and_climb_work_lists_partition_every_leaf_exactly_once():
     lo = np.concatenate([[0], np.cumsum(count.astype(np.uint64))[:-1]]).astype(np.uint32)
     climbs = (rng.random(nl) < 0.9).astype(np.uint8)
     n = int(count.astype(np.uint64).sum())
-    settle = np.zeros((n // 512 + nl + 1, 4), dtype=np.uint32)
+    TILE = 1024  # kPcvSettleTile (csrc/pcv_spec.h)
+    settle = np.zeros((n // TILE + nl + 1, 4), dtype=np.uint32)
     climb = np.zeros((n // 8 // 256 + nl + 1, 4), dtype=np.uint32)
     base = np.zeros(nl, dtype=np.uint32)
     ns, nc, total = C.c_uint64(), C.c_uint64(), C.c_uint64()
     assert f(lo.ctypes.data, count.ctypes.data, climbs.ctypes.data, nl, settle.ctypes.data, C.byref(ns), base.ctypes.data,
              climb.ctypes.data, C.byref(nc), C.byref(total)) == 0
     settle, climb = settle[:ns.value], climb[:nc.value]
-    # settle: in slot order, back to back, one leaf each, <= 512 slots, nothing for empty leaves
-    assert ns.value == int(np.sum((count.astype(np.int64) + 511) // 512))
-    assert np.all(settle[:, 2] > settle[:, 1]) and np.all(settle[:, 2] - settle[:, 1] <= 512)
+    # settle: in slot order, back to back, one leaf each, <= TILE slots, nothing for empty leaves
+    assert ns.value == int(np.sum((count.astype(np.int64) + TILE - 1) // TILE))
+    assert np.all(settle[:, 2] > settle[:, 1]) and np.all(settle[:, 2] - settle[:, 1] <= TILE)
     nz = np.flatnonzero(count)
     assert settle[0, 1] == lo[nz[0]] and settle[-1, 2] == n and np.all(settle[1:, 1] == settle[:-1, 2])
     r = settle[:, 0]
