@@ -90,6 +90,23 @@ def test_sort_keys64(ctx):
     assert np.array_equal(got, keys[np.argsort(m, kind="stable")])
 
 
+def test_sort_keys64_top_bit_ranges(ctx):
+    """Key sorts over the top 25-42 bits of the word, like the path keys of the sample (30-42 significant bits, noise
+    below): ragged sizes around the tiles and chunks, skewed upper digits, long runs of equal keys — stable."""
+    rng = np.random.default_rng(11)
+    for n, bits in ((1, 33), (63, 33), (8191, 33), (8192, 30), (8193, 36), (16_385, 39), (100_003, 42), (3_125_000, 33),
+                    (1_000_003, 25), ((1 << 24), 33)):
+        lo = 63 - bits
+        body = rng.integers(0, 2 ** bits, n, dtype=np.uint64)
+        body[: n // 3] &= np.uint64((1 << (bits - 9)) - 1)  # a third of the keys share the upper digit
+        keys = (body << np.uint64(lo)) | rng.integers(0, 2 ** lo, n, dtype=np.uint64)  # noise below the sorted bits
+        if n > 100:
+            keys[::5] = keys[7]
+        got = ctx.sort_keys64(keys.copy(), lo, 63)
+        order = np.argsort(keys >> np.uint64(lo), kind="stable")
+        assert np.array_equal(got, keys[order]), (n, bits)
+
+
 def test_sort_keys32(ctx):
     """The 32-bit key sort the build uses when ten levels suffice: skewed digits (few distinct values in the upper
     bytes, like path keys), ragged sizes, partial bit ranges."""

@@ -1,0 +1,21 @@
+# round-3 call 29: sample key sort with digits of up to 11 bits (3 passes for 33 bits) against 8-bit digits (5 passes)
+mkdir -p gpurun_out
+T=r03A
+timeout 900 python -m pytest tests/test_gpu_stages.py tests/test_gpu_single_chain.py tests/test_gpu_build.py tests/test_gpu_fuzz.py -m gpu -x -q > gpurun_out/${T}_gputest.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/${T}_gputest.log
+B="python bench.py --steps 10 --warmup 3 --no-e2e --no-cpu-baseline --no-parity --digest"
+run() { name=$1; shift; env "$@" timeout 200 $B $EXTRA > gpurun_out/${T}_ab_$name.json 2> gpurun_out/${T}_ab_$name.err; echo "$name rc=$?"; }
+run main A=1
+run digits8 PCV_HIP_LIBRARY=exp PCV_SORT_WIDE_DIGITS=0
+run main2 A=1
+run digits8b PCV_HIP_LIBRARY=exp PCV_SORT_WIDE_DIGITS=0
+bash tools/step_timeline.sh ${T} --no-parity > /dev/null 2>&1; echo "timeline rc=$?"
+python - <<'PY'
+import json, glob
+for f in sorted(glob.glob('gpurun_out/r03A_*.json')):
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        print(f.split('/')[-1], d['value'], d['ms_per_step'], 'digest', d.get('tree_digest'), {k: round(v, 3) for k, v in d['stage_ms'].items()})
+    except Exception as e:
+        print(f, 'ERR', e)
+PY
+sed -n 5,22p gpurun_out/${T}_timeline.txt
