@@ -794,14 +794,19 @@ def main():
         rec_passes = rec[0] / args.steps if rec else 0.0
         rec_ms = st.get("sort_records", 0.0)
         pass_b = 4.0 + 2 * rec_b  # per pass: 4 B histogram read + record read + record write
+        # single-chain build with the first histogram taken from the rank counts (no upsweep_map launch): that pass does not
+        # read the keys an extra time; with upsweep_map it reads them and writes the mapped keys back (4 B more)
+        rows_path = bool(binfo.get("single_chain")) and rec_b == 12.0 and "upsweep_map_kernel" not in timed
+        sort_b = rec_passes * pass_b + (-4.0 if rows_path else (4.0 if "upsweep_map_kernel" in timed else 0.0))
         record_sort = None if not rec else {"passes": rec_passes, "ms": round(rec_ms, 3), "record_bytes": rec_b,
-                                            "GB/s": round(n * rec_passes * pass_b / (rec_ms * 1e-3) / 1e9, 1) if rec_ms else None,
-                                            "algorithmic_bytes_per_point": rec_passes * pass_b}
+                                            "GB/s": round(n * sort_b / (rec_ms * 1e-3) / 1e9, 1) if rec_ms else None,
+                                            "algorithmic_bytes_per_point": sort_b,
+                                            "first_histogram": "from the rank counts" if rows_path else "own pass over the keys"}
         if binfo.get("single_chain"):
             # single-chain build: the encode is the one chain pass (read xyz + rgb, write rank + payload), the sort is the
             # stable record sort by leaf rank (per pass: 4 B histogram read + record read + record write) — no key sort exists
             es_ms = st.get("leaf_encode", 0.0) + rec_ms
-            es_bytes_pp = 27.0 + rec_b + rec_passes * pass_b
+            es_bytes_pp = 27.0 + rec_b + sort_b
             encode_sort = {"GB/s": round(n * es_bytes_pp / (es_ms * 1e-3) / 1e9, 1) if es_ms else None, "ms": round(es_ms, 3),
                            "pipeline": "single-chain: spec_encode + record sort", "algorithmic_bytes_per_point": es_bytes_pp,
                            "record_sort": record_sort}

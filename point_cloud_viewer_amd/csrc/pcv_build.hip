@@ -282,7 +282,8 @@ static const char* kKernelNames[PCV_K_COUNT] = {
     "upsweep_kernel<u32>", "downsweep_kernel<u32>", "promote_settle_kernel", "downsweep_rec_kernel", "cull_nodes_kernel",
     "visible_nodes_kernel", "nodes_in_location_kernel", "cull_points_kernel", "transform_points_kernel",
     "query_compact_kernel", "route_bucket_kernel", "partition_count_kernel", "partition_scatter_kernel",
-    "promote_climb_kernel", "spec_encode_kernel", "rank_hist_kernel", "spec_continue_kernel", "spec_replay_kernel", "upsweep_map_kernel"};
+    "promote_climb_kernel", "spec_encode_kernel", "rank_hist_kernel", "spec_continue_kernel", "spec_replay_kernel", "upsweep_map_kernel",
+    "hist_from_rows_kernel"};
 static_assert(sizeof(kKernelNames) / sizeof(kKernelNames[0]) == PCV_K_COUNT, "kernel name table out of sync");
 
 extern "C" int pcv_ctx_set_profiling(pcv_ctx* ctx, int enabled) {
@@ -648,6 +649,7 @@ struct PcvBuild {
   bool spec = false;
   void* spec_payload = nullptr;  // uint4[n]; uint2[n] with 12-byte records
   void* spec_wide = nullptr;     // set: 12-byte records (pcv_internal.h); uint4[n], the codes of Float32-coded leaves
+  const uint32_t* spec_rows = nullptr;  // rank counts per sort workgroup (pcv_launch_rank_hist_rows), or null
   uint64_t wide_levels = 0;      // bit k: level k is Float32-coded
   struct FixRange {
     uint32_t lo, count, level;
@@ -918,7 +920,7 @@ static int queue_record_sort(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, const Pc
   bool rec_in_a = true;
   if (bs->spec_map_dev)
     rc = pcv_radix_sort_records_mapped(ctx, rank_a, rank_b, n, rank_bits, &pl, bs->sort_scratch, bs->spec_map_dev,
-                                       bs->spec_map_entries, &rec_in_a);
+                                       bs->spec_map_entries, &rec_in_a, compact && pl.nwords == 0 ? bs->spec_rows : nullptr);
   else
     rc = pcv_radix_sort_u32(ctx, rank_a, rank_b, n, 0, rank_bits, &pl, bs->sort_scratch, &rec_in_a);
   if (rc) return rc;
@@ -1137,7 +1139,26 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
 
   // ---- exact counts -> rank map (device) and true tree (host) ----
   ctx->stage_begin(PCV_STAGE_NODE_SPLIT);
-  pcv_launch_rank_hist(ctx, rank, n, tree.num_leaves, d_counts, compact ? 8 : 0);
+  // 12-byte records and a predicted tree whose counters fit one LDS histogram and whose map fits beside the sort's staging:
+  // the count runs over the record sort's own workgroups and keeps every workgroup's histogram, from which the sort's first
+  // pass derives its digit histogram (the keys are then read by its downsweep only, which applies the map itself).
+  // PCV_SORT_ROWS=0 (libpcv_hip_exp.so): the first pass counts (and maps) the keys in a pass of its own.
+  static const bool rows_on = [] {
+    const char* e = pcv_experiment("PCV_SORT_ROWS");
+    return !e || atoi(e) != 0;
+  }();
+  bs->spec_rows = nullptr;
+  if (rows_on && compact && tree.num_leaves <= 8192 && tree.num_leaves <= pcv_rank_hist_max_bins()) {
+    int sgroups;
+    uint64_t schunk;
+    pcv_sort_rec12_geometry(n, &sgroups, &schunk);
+    uint32_t* rows;
+    if ((rc = sc.get(&rows, (size_t)sgroups * tree.num_leaves))) return rc;
+    pcv_launch_rank_hist_rows(ctx, rank, n, tree.num_leaves, d_counts, 8, sgroups, schunk, rows);
+    bs->spec_rows = rows;
+  } else {
+    pcv_launch_rank_hist(ctx, rank, n, tree.num_leaves, d_counts, compact ? 8 : 0);
+  }
   PCV_HIP_CHECK(ctx, hipGetLastError());
   if ((rc = ctx->pinned_spec_reserve((size_t)tree.num_leaves * 8 + 512))) return rc;
   uint8_t* hp = (uint8_t*)ctx->pinned_spec;
@@ -1165,6 +1186,7 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
     bs->spec_payload = nullptr;
     bs->spec_wide = nullptr;
     bs->spec_map_dev = nullptr;
+    bs->spec_rows = nullptr;
     bs->sort_queued = false;
     sc.detach(payload);
     ctx->dev_free(payload);

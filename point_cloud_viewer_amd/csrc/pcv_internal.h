@@ -96,6 +96,7 @@ enum PcvKernelId {
   PCV_K_SPEC_CONTINUE,
   PCV_K_SPEC_REPLAY,
   PCV_K_SORT_UPSWEEP_MAP,
+  PCV_K_SORT_HIST_ROWS,
   PCV_K_COUNT
 };
 
@@ -297,9 +298,11 @@ int pcv_radix_sort_u64(pcv_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint64_
 int pcv_radix_sort_u32(pcv_ctx* ctx, uint32_t* keys_a, uint32_t* keys_b, uint64_t n, int begin_bit, int end_bit,
                        PcvSortPayload* payload, void* scratch, bool* result_in_a);
 
+// rows (pcv_launch_rank_hist_rows, map_entries counters per sort workgroup): the first pass takes its histogram from them and
+// applies the map inside its downsweep — the keys are not read an extra time
 int pcv_radix_sort_records_mapped(pcv_ctx* ctx, uint32_t* keys_a, uint32_t* keys_b, uint64_t n, int key_bits,
                                   PcvSortPayload* payload, void* scratch, const uint32_t* map, uint32_t map_entries,
-                                  bool* result_in_a);
+                                  bool* result_in_a, const uint32_t* rows = nullptr);
 
 // pcv_topology.hip — node split (topology from sorted keys).
 // Device node table, structure of arrays, BFS order (level-major, prefix-sorted inside a level).
@@ -375,6 +378,11 @@ void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* w
 size_t pcv_spec_depth_grid_bytes();  // scratch for the depth-prediction grid of the binned pass
 void pcv_launch_rank_hist(pcv_ctx* ctx, const uint32_t* rank, uint64_t n, uint32_t num_bins, uint32_t* counts /* zeroed */,
                           int shift = 0);
+uint32_t pcv_rank_hist_max_bins();
+void pcv_launch_rank_hist_rows(pcv_ctx* ctx, const uint32_t* rank, uint64_t n, uint32_t num_bins, uint32_t* counts /* zeroed */,
+                               int shift, int groups, uint64_t chunk, uint32_t* rows /* groups x num_bins */);
+// workgroups and keys per workgroup of the 12-byte record sort (tiles of 8 192)
+void pcv_sort_rec12_geometry(uint64_t n, int* groups, uint64_t* chunk);
 // Chain continuation of the true leaves below a split first candidate (pcv_spec.h): `ranges` = device array of
 // pcv_cont_range_bytes()-sized records filled by pcv_fill_cont_range (levels + cube min of the candidate), `items` = one
 // entry per <= kPcvSettleTile sorted slots of one such leaf (rank = index of its range); rewrites the codes in place.

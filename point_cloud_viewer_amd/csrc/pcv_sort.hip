@@ -586,20 +586,28 @@ struct DigitStateN {
   uint32_t wave_tot[NW];
 };
 
-template <int BLOCK, int KPT, int R, int WPE, bool NT>
+// MAP (first pass of the single-chain build's record sort when the histogram came from the rank counts, hist_from_rows_kernel):
+// the keys still carry PREDICTED leaf ranks; they are translated through the rank map (a copy in dynamic LDS) as they are
+// loaded — rank := map[rank], and where the map flags a replayed leaf (bit 30) the record's first payload word becomes its
+// input index — which is what upsweep_map_kernel does in a pass of its own otherwise.
+template <int BLOCK, int KPT, int R, int WPE, bool NT, bool MAP = false>
 __global__ __launch_bounds__(BLOCK, WPE) void downsweep_rec12_kernel(const uint32_t* __restrict__ keys_in,
                                                                      uint32_t* __restrict__ keys_out, uint64_t n, uint64_t chunk,
                                                                      int groups, int shift, int nbits,
                                                                      const uint32_t* __restrict__ offsets,
                                                                      const uint32_t* __restrict__ totals,
-                                                                     const uint2* __restrict__ vec_in, uint2* __restrict__ vec_out) {
+                                                                     const uint2* __restrict__ vec_in, uint2* __restrict__ vec_out,
+                                                                     const uint32_t* __restrict__ gmap = nullptr, uint32_t map_entries = 0) {
   constexpr int NW = BLOCK / 64, kTile = BLOCK * KPT, RW = R / 64;
   static_assert(BLOCK >= R && R % 64 == 0 && KPT % 8 == 0, "geometry");
   __shared__ uint32_t skeys[kTile];
   __shared__ uint2 svec[kTile];
   __shared__ DigitStateN<NW, R> S;
+  extern __shared__ uint32_t smap_dyn[];  // MAP: map_entries words
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const uint32_t mask = (1u << nbits) - 1u;
+  if (MAP)
+    for (uint32_t i = t; i < map_entries; i += BLOCK) smap_dyn[i] = gmap[i];  // visible after the first barrier below
   {  // global base of digit t for this workgroup = (keys with a smaller digit) + (same digit, earlier workgroups)
     const uint32_t tot = t < R ? totals[t] : 0u;
     uint32_t inc = tot;
@@ -641,7 +649,17 @@ __global__ __launch_bounds__(BLOCK, WPE) void downsweep_rec12_kernel(const uint3
         vec[i] = valid ? vp[i * 64] : make_uint2(0u, 0u);
       }
     }
+    if (MAP) {
+#pragma unroll
+      for (int i = 0; i < KPT; ++i) {
+        const uint32_t pr = key[i] >> 8;
+        const uint32_t m = smap_dyn[pr < map_entries ? pr : 0u];
+        if (__builtin_expect((m & (1u << 30)) != 0u, 0)) vec[i].x = (uint32_t)(base + wbase + i * 64);  // replay: the input index
+        key[i] = ((m & PCV_SPEC_INDEX_MASK_SORT) << 8) | (key[i] & 0xffu);
+      }
+    }
   };
+  // (MAP: the copy of the map above is complete: the digit-base prologue ended with a barrier)
   if (begin < end) load_tile(begin, (uint32_t)((end - begin) < (uint64_t)kTile ? (end - begin) : (uint64_t)kTile));
   for (uint64_t base = begin; base < end; base += kTile) {
     const uint32_t tile_n = (uint32_t)((end - base) < (uint64_t)kTile ? (end - base) : (uint64_t)kTile);
@@ -753,6 +771,24 @@ __global__ __launch_bounds__(BLOCK, WPE) void downsweep_rec12_kernel(const uint3
 }
 
 
+// First-pass histogram of the record sort from the per-workgroup rank counts (rank_hist rows, pcv_encode.hip) and the rank map:
+// workgroup g's count of digit d = sum over the predicted leaves b whose TRUE rank has digit d of rows[g][b]. One workgroup
+// per sort workgroup; the keys are not read.
+__global__ __launch_bounds__(256) void hist_from_rows_kernel(const uint32_t* __restrict__ rows, uint32_t nbins,
+                                                              const uint32_t* __restrict__ map, int rank_shift, uint32_t mask, int groups,
+                                                              uint32_t* __restrict__ hist /* [digit][groups] */) {
+  __shared__ uint32_t h[kRadix];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t* row = rows + (uint64_t)blockIdx.x * nbins;
+  for (uint32_t b = threadIdx.x; b < nbins; b += 256) {
+    const uint32_t c = row[b];
+    if (c) atomicAdd(&h[((map[b] & PCV_SPEC_INDEX_MASK_SORT) >> rank_shift) & mask], c);
+  }
+  __syncthreads();
+  if (threadIdx.x <= mask) hist[(uint64_t)threadIdx.x * groups + blockIdx.x] = h[threadIdx.x];
+}
+
 // Geometry of the 12-byte record downsweep. What moves this kernel is the length of the write runs (tile / digit
 // values), not the occupancy (r03a / r03d A/B at 100 M records, both passes together, one box per line):
 //   tiles of 4 096: 256 lanes x 16 at 8 waves per CU 1.36-1.40 ms, at 12 waves per CU 1.40, 512 x 8 at 16 waves per CU 1.36
@@ -785,7 +821,8 @@ static void rec12_launch(pcv_ctx* ctx, int variant, const SortGeom& g, const uin
 
 template <typename KeyT>
 int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int end_bit, PcvSortPayload* payload,
-               void* scratch, bool* result_in_a, const uint32_t* map = nullptr, uint32_t map_entries = 0) {
+               void* scratch, bool* result_in_a, const uint32_t* map = nullptr, uint32_t map_entries = 0,
+               const uint32_t* rows = nullptr) {
   *result_in_a = true;
   if (n == 0 || end_bit <= begin_bit) return PCV_OK;
   if (n >= 0xffffffffull) return ctx->fail(PCV_E_INVALID, "radix sort: n must be < 2^32 - 1");
@@ -813,6 +850,39 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
     uint32_t mask = (1u << nbits) - 1u;
     KeyT* src = in_a ? a : b;
     KeyT* dst = in_a ? b : a;
+    // the histogram from the rank counts, the map applied inside the downsweep (12-byte records in tiles of 8 192; the map in
+    // dynamic LDS next to the kernel's 107-117 KB: up to 8 192 entries)
+    const bool from_rows = map && rows && shift == begin_bit && rec12 && rec_variant == 3 && map_entries <= 8192 && nbits <= 8;
+    if (from_rows) {
+      {
+        PcvProf prof(ctx, PCV_K_SORT_HIST_ROWS);
+        hipLaunchKernelGGL(hist_from_rows_kernel, dim3(g.groups), dim3(256), 0, ctx->stream, rows, map_entries, map, shift - begin_bit, mask,
+                           g.groups, hist);
+      }
+      {
+        PcvProf prof(ctx, PCV_K_SORT_SCAN);
+        hipLaunchKernelGGL(scan_kernel, dim3(kRadix), dim3(256), 0, ctx->stream, hist, g.groups, totals);
+      }
+      PcvProf prof(ctx, PCV_K_SORT_DOWNSWEEP_REC);
+      const size_t dyn = (size_t)map_entries * 4;
+      const uint2* vin = (const uint2*)(in_a ? payload->vec_in : payload->vec_out);
+      uint2* vout = (uint2*)(in_a ? payload->vec_out : payload->vec_in);
+      if (nbits <= 7) {
+        static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&downsweep_rec12_kernel<1024, 8, 128, 4, false, true>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 32768) == hipSuccess;
+        (void)ok;
+        hipLaunchKernelGGL((downsweep_rec12_kernel<1024, 8, 128, 4, false, true>), dim3(g.groups), dim3(1024), dyn, ctx->stream,
+                           (const uint32_t*)src, (uint32_t*)dst, n, g.chunk, g.groups, shift, nbits, hist, totals, vin, vout, map, map_entries);
+      } else {
+        static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&downsweep_rec12_kernel<1024, 8, 256, 4, false, true>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 32768) == hipSuccess;
+        (void)ok;
+        hipLaunchKernelGGL((downsweep_rec12_kernel<1024, 8, 256, 4, false, true>), dim3(g.groups), dim3(1024), dyn, ctx->stream,
+                           (const uint32_t*)src, (uint32_t*)dst, n, g.chunk, g.groups, shift, nbits, hist, totals, vin, vout, map, map_entries);
+      }
+      in_a = !in_a;
+      continue;
+    }
     if (map && shift == begin_bit && sizeof(KeyT) == 4 && payload && payload->vec_in) {
       PcvProf prof(ctx, PCV_K_SORT_UPSWEEP_MAP);  // finalize fused into the first upsweep
       const bool lds = map_entries && map_entries <= kMapLdsEntries;
@@ -900,7 +970,12 @@ int pcv_radix_sort_u32(pcv_ctx* ctx, uint32_t* keys_a, uint32_t* keys_b, uint64_
 // (payload->vec_bytes == 8): the rank sits in bits 8.. of the key
 int pcv_radix_sort_records_mapped(pcv_ctx* ctx, uint32_t* keys_a, uint32_t* keys_b, uint64_t n, int key_bits,
                                   PcvSortPayload* payload, void* scratch, const uint32_t* map, uint32_t map_entries,
-                                  bool* result_in_a) {
+                                  bool* result_in_a, const uint32_t* rows) {
   const int base = payload && payload->vec_bytes == 8 ? 8 : 0;
-  return radix_sort<uint32_t>(ctx, keys_a, keys_b, n, base, base + key_bits, payload, scratch, result_in_a, map, map_entries);
+  return radix_sort<uint32_t>(ctx, keys_a, keys_b, n, base, base + key_bits, payload, scratch, result_in_a, map, map_entries, rows);
+}
+void pcv_sort_rec12_geometry(uint64_t n, int* groups, uint64_t* chunk) {
+  const SortGeom g = make_geom(n, 8192);
+  *groups = g.groups;
+  *chunk = g.chunk;
 }
