@@ -797,11 +797,14 @@ def main():
         # single-chain build with the first histogram taken from the rank counts (no upsweep_map launch): that pass does not
         # read the keys an extra time; with upsweep_map it reads them and writes the mapped keys back (4 B more)
         rows_path = bool(binfo.get("single_chain")) and rec_b == 12.0 and "upsweep_map_kernel" not in timed
-        sort_b = rec_passes * pass_b + (-4.0 if rows_path else (4.0 if "upsweep_map_kernel" in timed else 0.0))
+        # ... and with the second pass cut into whole first-pass runs, its histogram comes from the same counts: no
+        # upsweep<u32> launch either
+        rows_both = rows_path and "upsweep_kernel<u32>" not in timed
+        sort_b = rec_passes * pass_b + (-4.0 * rec_passes if rows_both else -4.0 if rows_path else (4.0 if "upsweep_map_kernel" in timed else 0.0))
         record_sort = None if not rec else {"passes": rec_passes, "ms": round(rec_ms, 3), "record_bytes": rec_b,
                                             "GB/s": round(n * sort_b / (rec_ms * 1e-3) / 1e9, 1) if rec_ms else None,
                                             "algorithmic_bytes_per_point": sort_b,
-                                            "first_histogram": "from the rank counts" if rows_path else "own pass over the keys"}
+                                            "histograms": "both from the rank counts" if rows_both else "first from the rank counts" if rows_path else "own passes over the keys"}
         if binfo.get("single_chain"):
             # single-chain build: the encode is the one chain pass (read xyz + rgb, write rank + payload), the sort is the
             # stable record sort by leaf rank (per pass: 4 B histogram read + record read + record write) — no key sort exists

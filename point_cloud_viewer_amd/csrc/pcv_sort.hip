@@ -597,8 +597,13 @@ __global__ __launch_bounds__(BLOCK, WPE) void downsweep_rec12_kernel(const uint3
                                                                      const uint32_t* __restrict__ offsets,
                                                                      const uint32_t* __restrict__ totals,
                                                                      const uint2* __restrict__ vec_in, uint2* __restrict__ vec_out,
-                                                                     const uint32_t* __restrict__ gmap = nullptr, uint32_t map_entries = 0) {
+                                                                     const uint32_t* __restrict__ gmap = nullptr, uint32_t map_entries = 0,
+                                                                     const uint2* __restrict__ ranges = nullptr /* set: piece k
+                                                                     = the records [ranges[k].x, ranges[k].y) instead of chunk k */,
+                                                                     const uint32_t* __restrict__ order = nullptr /* set: workgroup
+                                                                     b takes piece order[b] (largest pieces first) */) {
   constexpr int NW = BLOCK / 64, kTile = BLOCK * KPT, RW = R / 64;
+  const uint32_t piece = order ? order[blockIdx.x] : blockIdx.x;
   static_assert(BLOCK >= R && R % 64 == 0 && KPT % 8 == 0, "geometry");
   __shared__ uint32_t skeys[kTile];
   __shared__ uint2 svec[kTile];
@@ -621,13 +626,17 @@ __global__ __launch_bounds__(BLOCK, WPE) void downsweep_rec12_kernel(const uint3
     uint32_t woff = 0;
 #pragma unroll
     for (int w = 0; w < RW; ++w) woff += (w < wave) ? S.wave_tot[w] : 0u;
-    if (t < R) S.digit_base[t] = woff + inc - tot + offsets[(uint64_t)t * groups + blockIdx.x];
+    if (t < R) S.digit_base[t] = woff + inc - tot + offsets[(uint64_t)t * groups + piece];
     for (int k = t; k < NW * R; k += BLOCK) (&S.whist[0][0])[k] = 0;
     __syncthreads();
   }
-  const uint64_t begin = (uint64_t)blockIdx.x * chunk;
+  uint64_t begin = (uint64_t)piece * chunk;
   uint64_t end = begin + chunk;
   if (end > n) end = n;
+  if (ranges) {
+    begin = ranges[piece].x;
+    end = ranges[piece].y;
+  }
   const uint32_t wbase = wave * 64 * KPT + lane;
 
   uint32_t key[KPT];
@@ -786,7 +795,76 @@ __global__ __launch_bounds__(256) void hist_from_rows_kernel(const uint32_t* __r
     if (c) atomicAdd(&h[((map[b] & PCV_SPEC_INDEX_MASK_SORT) >> rank_shift) & mask], c);
   }
   __syncthreads();
-  if (threadIdx.x <= mask) hist[(uint64_t)threadIdx.x * groups + blockIdx.x] = h[threadIdx.x];
+  hist[(uint64_t)threadIdx.x * groups + blockIdx.x] = threadIdx.x <= mask ? h[threadIdx.x] : 0u;  // all kRadix rows are scanned
+}
+
+// Two-pass sorts: BOTH histograms from the rank counts. Per sort workgroup g the counts are re-indexed by TRUE rank, lower
+// digit major — tr[d1 * D2 + d2] — and kept (rows_true[g][.]); the first pass's histogram is their sum over d2. The first
+// pass writes its output ordered by (d1, g); the second pass cuts THAT sequence into pieces of whole runs — piece k = digit
+// d1 = k / blocks, workgroups [blk * gpb, (blk + 1) * gpb) of the first pass — so a piece's digit counts are sums of
+// rows_true entries and its record range follows from the first pass's offsets: the second pass needs no counting pass over
+// the keys either (pass2_layout_kernel). Pieces differ in size (by the popularity of d1) instead of being equal chunks.
+__global__ __launch_bounds__(256) void hist12_from_rows_kernel(const uint32_t* __restrict__ rows, uint32_t nbins,
+                                                                const uint32_t* __restrict__ map, int nbits1, int nbits2, int groups,
+                                                                uint32_t* __restrict__ hist1 /* [d1][groups] */,
+                                                                uint32_t* __restrict__ rows_true /* [groups][D1 * D2] */) {
+  __shared__ uint32_t tr[8192];
+  const uint32_t D1 = 1u << nbits1, D2 = 1u << nbits2, TB = D1 * D2;
+  for (uint32_t i = threadIdx.x; i < TB; i += 256) tr[i] = 0;
+  __syncthreads();
+  const uint32_t* row = rows + (uint64_t)blockIdx.x * nbins;
+  for (uint32_t b = threadIdx.x; b < nbins; b += 256) {
+    const uint32_t c = row[b];
+    if (c) {
+      const uint32_t r = map[b] & PCV_SPEC_INDEX_MASK_SORT;
+      atomicAdd(&tr[(r & (D1 - 1u)) * D2 + ((r >> nbits1) & (D2 - 1u))], c);
+    }
+  }
+  __syncthreads();
+  uint32_t* out = rows_true + (uint64_t)blockIdx.x * TB;
+  for (uint32_t i = threadIdx.x; i < TB; i += 256) out[i] = tr[i];
+  uint32_t s = 0;
+  if (threadIdx.x < D1)
+    for (uint32_t d2 = 0; d2 < D2; ++d2) s += tr[threadIdx.x * D2 + ((d2 + threadIdx.x) & (D2 - 1u))];  // skewed: no bank conflict
+  hist1[(uint64_t)threadIdx.x * groups + blockIdx.x] = s;  // all kRadix rows are scanned
+}
+// piece k of the second pass (see above): its digit counts and its record range. offsets1 / totals1: the first pass's scanned
+// histogram. One workgroup of 256 lanes per piece.
+__global__ __launch_bounds__(256) void pass2_layout_kernel(const uint32_t* __restrict__ rows_true, int nbits1, int nbits2, int groups,
+                                                            int blocks, int gpb, const uint32_t* __restrict__ offsets1,
+                                                            const uint32_t* __restrict__ totals1, int pieces,
+                                                            uint32_t* __restrict__ hist2 /* [d2][pieces] */, uint2* __restrict__ ranges,
+                                                            uint32_t* __restrict__ order /* pieces by falling size of their digit */) {
+  __shared__ uint32_t part[4][256];
+  const uint32_t D1 = 1u << nbits1, D2 = 1u << nbits2, TB = D1 * D2;
+  const int k = blockIdx.x, d1 = k / blocks, blk = k % blocks;
+  const int g_lo = blk * gpb, g_hi = (g_lo + gpb < groups) ? g_lo + gpb : groups;
+  const uint32_t d2 = threadIdx.x & (D2 - 1u), lanes_per_g = 256u / D2, sub = threadIdx.x / D2;  // D2 <= 256
+  uint32_t s = 0;
+  for (int g = g_lo + (int)sub; g < g_hi; g += (int)lanes_per_g) s += rows_true[(uint64_t)g * TB + (uint32_t)d1 * D2 + d2];
+  (&part[0][0])[threadIdx.x] = s;
+  __syncthreads();
+  {
+    uint32_t tot = 0;
+    if (threadIdx.x < D2)
+      for (uint32_t q = 0; q < lanes_per_g; ++q) tot += (&part[0][0])[q * D2 + threadIdx.x];
+    hist2[(uint64_t)threadIdx.x * pieces + k] = tot;  // all kRadix rows are scanned
+  }
+  if (threadIdx.x == 0) {
+    uint32_t start = 0;  // records with a smaller first digit
+    for (int d = 0; d < d1; ++d) start += totals1[d];
+    const uint32_t b = g_lo < groups ? start + offsets1[(uint64_t)d1 * groups + g_lo] : start + totals1[d1];
+    const uint32_t e = g_hi < groups ? start + offsets1[(uint64_t)d1 * groups + g_hi] : start + totals1[d1];
+    ranges[k] = make_uint2(b, e);
+    // launch order: the pieces of the most popular first digits first (a piece's size follows its digit's total)
+    const uint32_t mine = totals1[d1];
+    uint32_t before = 0;
+    for (int d = 0; d < (int)D1; ++d) {
+      const uint32_t o = totals1[d];
+      before += (o > mine || (o == mine && d < d1)) ? 1u : 0u;
+    }
+    order[before * (uint32_t)blocks + (uint32_t)blk] = (uint32_t)k;
+  }
 }
 
 // Geometry of the 12-byte record downsweep. What moves this kernel is the length of the write runs (tile / digit
@@ -854,34 +932,87 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
     // dynamic LDS next to the kernel's 107-117 KB: up to 8 192 entries)
     const bool from_rows = map && rows && shift == begin_bit && rec12 && rec_variant == 3 && map_entries <= 8192 && nbits <= 8;
     if (from_rows) {
+      static const bool pass2_rows_on = [] {
+        const char* e = pcv_experiment("PCV_SORT_ROWS2");  // 0 = the second pass counts its keys itself (experiments)
+        return !e || atoi(e) != 0;
+      }();
+      const int nbits2 = end_bit - (shift + width) < width ? end_bit - (shift + width) : width;
+      const bool two = pass2_rows_on && shift + width < end_bit && shift + 2 * width >= end_bit && total_bits <= 13 && nbits2 >= 1 &&
+                       g.groups >= 8;
+      uint32_t* hist2 = totals + kRadix;
+      uint32_t* totals2 = hist2 + (size_t)kRadix * kMaxGroups;
+      uint2* ranges = reinterpret_cast<uint2*>(totals2 + kRadix);
+      uint32_t* order = reinterpret_cast<uint32_t*>(ranges + kMaxGroups);
+      uint32_t* rows_true = order + kMaxGroups;
       {
         PcvProf prof(ctx, PCV_K_SORT_HIST_ROWS);
-        hipLaunchKernelGGL(hist_from_rows_kernel, dim3(g.groups), dim3(256), 0, ctx->stream, rows, map_entries, map, shift - begin_bit, mask,
-                           g.groups, hist);
+        if (two)
+          hipLaunchKernelGGL(hist12_from_rows_kernel, dim3(g.groups), dim3(256), 0, ctx->stream, rows, map_entries, map, nbits, nbits2,
+                             g.groups, hist, rows_true);
+        else
+          hipLaunchKernelGGL(hist_from_rows_kernel, dim3(g.groups), dim3(256), 0, ctx->stream, rows, map_entries, map, shift - begin_bit,
+                             mask, g.groups, hist);
       }
       {
         PcvProf prof(ctx, PCV_K_SORT_SCAN);
         hipLaunchKernelGGL(scan_kernel, dim3(kRadix), dim3(256), 0, ctx->stream, hist, g.groups, totals);
       }
-      PcvProf prof(ctx, PCV_K_SORT_DOWNSWEEP_REC);
       const size_t dyn = (size_t)map_entries * 4;
       const uint2* vin = (const uint2*)(in_a ? payload->vec_in : payload->vec_out);
       uint2* vout = (uint2*)(in_a ? payload->vec_out : payload->vec_in);
-      if (nbits <= 7) {
-        static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&downsweep_rec12_kernel<1024, 8, 128, 4, false, true>),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 32768) == hipSuccess;
-        (void)ok;
-        hipLaunchKernelGGL((downsweep_rec12_kernel<1024, 8, 128, 4, false, true>), dim3(g.groups), dim3(1024), dyn, ctx->stream,
-                           (const uint32_t*)src, (uint32_t*)dst, n, g.chunk, g.groups, shift, nbits, hist, totals, vin, vout, map, map_entries);
-      } else {
-        static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&downsweep_rec12_kernel<1024, 8, 256, 4, false, true>),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 32768) == hipSuccess;
-        (void)ok;
-        hipLaunchKernelGGL((downsweep_rec12_kernel<1024, 8, 256, 4, false, true>), dim3(g.groups), dim3(1024), dyn, ctx->stream,
-                           (const uint32_t*)src, (uint32_t*)dst, n, g.chunk, g.groups, shift, nbits, hist, totals, vin, vout, map, map_entries);
+      {
+        PcvProf prof(ctx, PCV_K_SORT_DOWNSWEEP_REC);
+        if (nbits <= 7) {
+          static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&downsweep_rec12_kernel<1024, 8, 128, 4, false, true>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 32768) == hipSuccess;
+          (void)ok;
+          hipLaunchKernelGGL((downsweep_rec12_kernel<1024, 8, 128, 4, false, true>), dim3(g.groups), dim3(1024), dyn, ctx->stream,
+                             (const uint32_t*)src, (uint32_t*)dst, n, g.chunk, g.groups, shift, nbits, hist, totals, vin, vout, map,
+                             map_entries, (const uint2*)nullptr);
+        } else {
+          static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&downsweep_rec12_kernel<1024, 8, 256, 4, false, true>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 32768) == hipSuccess;
+          (void)ok;
+          hipLaunchKernelGGL((downsweep_rec12_kernel<1024, 8, 256, 4, false, true>), dim3(g.groups), dim3(1024), dyn, ctx->stream,
+                             (const uint32_t*)src, (uint32_t*)dst, n, g.chunk, g.groups, shift, nbits, hist, totals, vin, vout, map,
+                             map_entries, (const uint2*)nullptr);
+        }
       }
       in_a = !in_a;
-      continue;
+      if (!two) continue;
+      // second pass: pieces of whole first-pass runs, digit counts and ranges from rows_true and the first pass's offsets
+      const int D1 = 1 << nbits;
+      int blocks = kMaxGroups / D1;
+      if (blocks > g.groups) blocks = g.groups;
+      if (blocks < 1) blocks = 1;
+      const int gpb = (g.groups + blocks - 1) / blocks;
+      const int pieces = D1 * blocks;
+      {
+        PcvProf prof(ctx, PCV_K_SORT_HIST_ROWS);
+        hipLaunchKernelGGL(pass2_layout_kernel, dim3(pieces), dim3(256), 0, ctx->stream, rows_true, nbits, nbits2, g.groups, blocks, gpb, hist,
+                           totals, pieces, hist2, ranges, order);
+      }
+      {
+        PcvProf prof(ctx, PCV_K_SORT_SCAN);
+        hipLaunchKernelGGL(scan_kernel, dim3(kRadix), dim3(256), 0, ctx->stream, hist2, pieces, totals2);
+      }
+      {
+        PcvProf prof(ctx, PCV_K_SORT_DOWNSWEEP_REC);
+        const uint32_t* src2 = (const uint32_t*)(in_a ? a : b);
+        uint32_t* dst2 = (uint32_t*)(in_a ? b : a);
+        const uint2* vin2 = (const uint2*)(in_a ? payload->vec_in : payload->vec_out);
+        uint2* vout2 = (uint2*)(in_a ? payload->vec_out : payload->vec_in);
+        if (nbits2 <= 7)
+          hipLaunchKernelGGL((downsweep_rec12_kernel<1024, 8, 128, 4, false, false>), dim3(pieces), dim3(1024), 0, ctx->stream, src2, dst2, n,
+                             g.chunk, pieces, shift + width, nbits2, hist2, totals2, vin2, vout2, (const uint32_t*)nullptr, 0u,
+                             (const uint2*)ranges, (const uint32_t*)order);
+        else
+          hipLaunchKernelGGL((downsweep_rec12_kernel<1024, 8, 256, 4, false, false>), dim3(pieces), dim3(1024), 0, ctx->stream, src2, dst2, n,
+                             g.chunk, pieces, shift + width, nbits2, hist2, totals2, vin2, vout2, (const uint32_t*)nullptr, 0u,
+                             (const uint2*)ranges, (const uint32_t*)order);
+      }
+      in_a = !in_a;
+      break;
     }
     if (map && shift == begin_bit && sizeof(KeyT) == 4 && payload && payload->vec_in) {
       PcvProf prof(ctx, PCV_K_SORT_UPSWEEP_MAP);  // finalize fused into the first upsweep
@@ -956,7 +1087,10 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
 
 }  // namespace
 
-size_t pcv_sort_scratch_bytes(uint64_t n) { return ((size_t)kRadix * kMaxGroups + kRadix) * sizeof(uint32_t); }
+// two histograms + totals, the second pass's piece ranges, and the rank counts re-indexed by true rank (8 192 per sort workgroup)
+size_t pcv_sort_scratch_bytes(uint64_t n) {
+  return (2 * ((size_t)kRadix * kMaxGroups + kRadix) + 3 * (size_t)kMaxGroups + 8192 * (size_t)kMaxGroups) * sizeof(uint32_t) + 256;
+}
 
 int pcv_radix_sort_u64(pcv_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint64_t n, int begin_bit, int end_bit,
                        PcvSortPayload* payload, void* scratch, bool* result_in_a) {

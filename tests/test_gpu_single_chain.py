@@ -248,7 +248,10 @@ print("alt-path ok")
                                               ({"PCV_COMPACT_RECORDS": "0", "PCV_SETTLE_BY_LEAF": "0"}, 20),
                                               # the first sort pass counting and mapping the keys in a pass of its own (what
                                               # trees of more than 8 192 predicted nodes take)
-                                              ({"PCV_SORT_ROWS": "0"}, 12)])
+                                              ({"PCV_SORT_ROWS": "0"}, 12),
+                                              # the second pass counting its keys itself (equal chunks instead of pieces of
+                                              # whole first-pass runs)
+                                              ({"PCV_SORT_ROWS2": "0"}, 12)])
 def test_alternative_kernels_behind_the_switches_are_byte_exact_too(env, record_bytes):
     """The 20-byte record format (what a predicted tree of more than 2^24 nodes falls back to) and the slot-wise settle
     kernel are selected by switches that are read once per process: run them in a child process against the oracle."""
