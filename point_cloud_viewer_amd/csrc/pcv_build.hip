@@ -1139,7 +1139,8 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
 
   // ---- exact counts -> rank map (device) and true tree (host) ----
   ctx->stage_begin(PCV_STAGE_NODE_SPLIT);
-  // 12-byte records and a predicted tree whose counters fit one LDS histogram and whose map fits beside the sort's staging:
+  // 12-byte records and a predicted tree whose counters fit one LDS histogram and whose map fits beside the sort's staging
+  // (up to 16 384 nodes: clouds of up to ~250 M points at the default capacity):
   // the count runs over the record sort's own workgroups and keeps every workgroup's histogram, from which the sort's first
   // pass derives its digit histogram (the keys are then read by its downsweep only, which applies the map itself).
   // PCV_SORT_ROWS=0 (libpcv_hip_exp.so): the first pass counts (and maps) the keys in a pass of its own.
@@ -1148,7 +1149,7 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
     return !e || atoi(e) != 0;
   }();
   bs->spec_rows = nullptr;
-  if (rows_on && compact && tree.num_leaves <= 8192 && tree.num_leaves <= pcv_rank_hist_max_bins()) {
+  if (rows_on && compact && tree.num_leaves <= 16384 && tree.num_leaves <= pcv_rank_hist_max_bins()) {
     int sgroups;
     uint64_t schunk;
     pcv_sort_rec12_geometry(n, &sgroups, &schunk);

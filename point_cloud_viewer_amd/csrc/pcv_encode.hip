@@ -457,7 +457,7 @@ __global__ __launch_bounds__(BLOCK, PREFETCH ? 6 : 8) void spec_encode_persist_k
 
 // Exact number of points per predicted leaf: LDS-privatised histogram of the rank array over the bins
 // [bin_base, bin_base + nbins), nbins <= kHistBins; one flush of the non-zero bins per workgroup.
-constexpr int kHistBins = 12288;  // 48 KiB of LDS
+constexpr int kHistBins = 16384;  // 64 KiB of LDS
 __global__ __launch_bounds__(1024) void rank_hist_kernel(const uint32_t* __restrict__ rank, uint64_t n, uint64_t chunk,
                                                           uint32_t bin_base, uint32_t nbins, uint32_t* __restrict__ counts,
                                                           int shift /* 8: 12-byte records, the rank sits above the blue byte */,

@@ -608,11 +608,14 @@ __global__ __launch_bounds__(BLOCK, WPE) void downsweep_rec12_kernel(const uint3
   __shared__ uint32_t skeys[kTile];
   __shared__ uint2 svec[kTile];
   __shared__ DigitStateN<NW, R> S;
-  extern __shared__ uint32_t smap_dyn[];  // MAP: map_entries words
+  extern __shared__ uint16_t smap_dyn[];  // MAP: map_entries half words: true rank (< 2^15) | replay mark << 15
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const uint32_t mask = (1u << nbits) - 1u;
   if (MAP)
-    for (uint32_t i = t; i < map_entries; i += BLOCK) smap_dyn[i] = gmap[i];  // visible after the first barrier below
+    for (uint32_t i = t; i < map_entries; i += BLOCK) {  // visible after the first barrier below
+      const uint32_t m = gmap[i];
+      smap_dyn[i] = (uint16_t)((m & 0x7fffu) | (((m >> 30) & 1u) << 15));
+    }
   {  // global base of digit t for this workgroup = (keys with a smaller digit) + (same digit, earlier workgroups)
     const uint32_t tot = t < R ? totals[t] : 0u;
     uint32_t inc = tot;
@@ -663,8 +666,8 @@ __global__ __launch_bounds__(BLOCK, WPE) void downsweep_rec12_kernel(const uint3
       for (int i = 0; i < KPT; ++i) {
         const uint32_t pr = key[i] >> 8;
         const uint32_t m = smap_dyn[pr < map_entries ? pr : 0u];
-        if (__builtin_expect((m & (1u << 30)) != 0u, 0)) vec[i].x = (uint32_t)(base + wbase + i * 64);  // replay: the input index
-        key[i] = ((m & PCV_SPEC_INDEX_MASK_SORT) << 8) | (key[i] & 0xffu);
+        if (__builtin_expect((m & 0x8000u) != 0u, 0)) vec[i].x = (uint32_t)(base + wbase + i * 64);  // replay: the input index
+        key[i] = ((m & 0x7fffu) << 8) | (key[i] & 0xffu);
       }
     }
   };
@@ -808,7 +811,7 @@ __global__ __launch_bounds__(256) void hist12_from_rows_kernel(const uint32_t* _
                                                                 const uint32_t* __restrict__ map, int nbits1, int nbits2, int groups,
                                                                 uint32_t* __restrict__ hist1 /* [d1][groups] */,
                                                                 uint32_t* __restrict__ rows_true /* [groups][D1 * D2] */) {
-  __shared__ uint32_t tr[8192];
+  __shared__ uint32_t tr[16384];  // 64 KB: ranks of up to 14 bits
   const uint32_t D1 = 1u << nbits1, D2 = 1u << nbits2, TB = D1 * D2;
   for (uint32_t i = threadIdx.x; i < TB; i += 256) tr[i] = 0;
   __syncthreads();
@@ -929,15 +932,15 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
     KeyT* src = in_a ? a : b;
     KeyT* dst = in_a ? b : a;
     // the histogram from the rank counts, the map applied inside the downsweep (12-byte records in tiles of 8 192; the map in
-    // dynamic LDS next to the kernel's 107-117 KB: up to 8 192 entries)
-    const bool from_rows = map && rows && shift == begin_bit && rec12 && rec_variant == 3 && map_entries <= 8192 && nbits <= 8;
+    // dynamic LDS next to the kernel's 107-117 KB: up to 16 384 half-word entries)
+    const bool from_rows = map && rows && shift == begin_bit && rec12 && rec_variant == 3 && map_entries <= 16384 && nbits <= 8;
     if (from_rows) {
       static const bool pass2_rows_on = [] {
         const char* e = pcv_experiment("PCV_SORT_ROWS2");  // 0 = the second pass counts its keys itself (experiments)
         return !e || atoi(e) != 0;
       }();
       const int nbits2 = end_bit - (shift + width) < width ? end_bit - (shift + width) : width;
-      const bool two = pass2_rows_on && shift + width < end_bit && shift + 2 * width >= end_bit && total_bits <= 13 && nbits2 >= 1 &&
+      const bool two = pass2_rows_on && shift + width < end_bit && shift + 2 * width >= end_bit && total_bits <= 14 && nbits2 >= 1 &&
                        g.groups >= 8;
       uint32_t* hist2 = totals + kRadix;
       uint32_t* totals2 = hist2 + (size_t)kRadix * kMaxGroups;
@@ -957,7 +960,7 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
         PcvProf prof(ctx, PCV_K_SORT_SCAN);
         hipLaunchKernelGGL(scan_kernel, dim3(kRadix), dim3(256), 0, ctx->stream, hist, g.groups, totals);
       }
-      const size_t dyn = (size_t)map_entries * 4;
+      const size_t dyn = ((size_t)map_entries * 2 + 15) & ~(size_t)15;
       const uint2* vin = (const uint2*)(in_a ? payload->vec_in : payload->vec_out);
       uint2* vout = (uint2*)(in_a ? payload->vec_out : payload->vec_in);
       {
@@ -1087,9 +1090,9 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
 
 }  // namespace
 
-// two histograms + totals, the second pass's piece ranges, and the rank counts re-indexed by true rank (8 192 per sort workgroup)
+// two histograms + totals, the second pass's piece ranges, and the rank counts re-indexed by true rank (16 384 per sort workgroup)
 size_t pcv_sort_scratch_bytes(uint64_t n) {
-  return (2 * ((size_t)kRadix * kMaxGroups + kRadix) + 3 * (size_t)kMaxGroups + 8192 * (size_t)kMaxGroups) * sizeof(uint32_t) + 256;
+  return (2 * ((size_t)kRadix * kMaxGroups + kRadix) + 3 * (size_t)kMaxGroups + 16384 * (size_t)kMaxGroups) * sizeof(uint32_t) + 256;
 }
 
 int pcv_radix_sort_u64(pcv_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint64_t n, int begin_bit, int end_bit,
