@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 F64_VALU_PEAK_GINST = 39300  # vector FP64 78.6 TFLOP/s = 39.3 T FMA-instructions/s (SURVEY 8d "Roofline bound")
-ROUND = "r03"
+ROUND = "r04"
 
 # algorithmic HBM bytes per point and launch (DESIGN.md "Kernels"); kernels bound by f64 VALU issue are marked
 ALGO_BYTES = {
@@ -286,24 +286,19 @@ def config1(args):
                              "sample": f"the whole config-1 cloud, literal file-streaming restatement on tmpfs, {dt:.2f} s"}}
 
 
-def query_bench(args):
-    """BASELINE config 4: octree of the config-2 cloud, F random camera frusta — node relations (K7), visible-node
-    traversal (K7b), batched point query (K8) — with parity of the first --verify-frusta frusta (default: all) and of the
-    points of the --verify-cull-frusta culled frusta against the oracle."""
+def query_leg(args, ctx, tree):
+    """BASELINE config 4 on a built octree: F random camera frusta — node relations (K7), visible-node traversal (K7b),
+    batched point query (K8) — with parity of the first --verify-frusta frusta (default: all) and of the points of the
+    --verify-cull-frusta culled frusta against the oracle (reference bars: sat.rs:174-205 relation tests,
+    point_cloud_test/tests/main.rs:104-127 points in a frustum)."""
     import numpy as np
-    import torch
-    import point_cloud_viewer_amd as pcv
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
 
-    dev = torch.device("cuda", 0)
-    x, y, z, rgb = make_cloud(torch, args.points, seed=1, device=dev)
-    ctx = pcv.Context(0)
-    tree = ctx.build(args.resolution, None, x, y, z, rgb)
     meta = tree.meta()
     bmin, bmax = meta["bbox_min"], meta["bbox_max"]
     M = tree.num_nodes
-    del x, y, z, rgb
+    npoints = tree.num_points
 
     rng = np.random.default_rng(3)
     persp = O.perspective3_new(1.0, 1.2, 0.1, 100.0)
@@ -316,13 +311,14 @@ def query_bench(args):
         mats.append(c)
     shapes = ctx.shapes([("frustum", m) for m in mats])
     ctx.set_profiling(True)
-    for _ in range(max(1, args.warmup)):
+    qsteps = max(1, args.query_steps)
+    for _ in range(max(1, min(args.warmup, 2))):
         rel, sizes = tree.cull_nodes(shapes, with_sizes=True)
     ctx.reset_kernel_stats()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(qsteps):
         rel, sizes = tree.cull_nodes(shapes, with_sizes=True)
-    wall_a = (time.perf_counter() - t0) / args.steps
+    wall_a = (time.perf_counter() - t0) / qsteps
     ks = ctx.kernel_stats()["cull_nodes_kernel"]
     cull_ms = ks[1] / ks[0]
     pairs = args.frusta * M
@@ -401,9 +397,9 @@ def query_bench(args):
             pts_bad += 1
     cpu_c = time.perf_counter() - t0
     return {"metric": "frustum-cull node pairs/sec", "value": round(pairs / (cull_ms * 1e-3) / 1e6, 1), "unit": "Mpairs/s",
-            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(cull_ms, 3),
+            "n_gpus": 1, "steps": qsteps, "warmup": max(1, min(args.warmup, 2)), "ms_per_step": round(cull_ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"BASELINE config 4: octree of {args.points / 1e6:g} M Gaussian-cluster points "
+            "config": {"workload": f"BASELINE config 4: octree of {npoints / 1e6:g} M Gaussian-cluster points "
                                    f"({M} nodes), {args.frusta} random camera frusta (Perspective3 aspect 1, fovy 1.2, "
                                    "near 0.1, far 100), batched transform + cull on 1 GPU", "nodes": M, "frusta": args.frusta},
             "cull_nodes": {"kernel_ms": round(cull_ms, 3), "wall_ms_incl_D2H": round(wall_a * 1e3, 1), "pairs": pairs,
@@ -430,6 +426,73 @@ def query_bench(args):
                 "value": round(V * M / cpu_a / 1e6, 3), "unit": "Mpairs/s", "cores": 1, "kind": "port",
                 "sample": f"first {V} frusta x {M} nodes, SAT relation + size on screen, {cpu_a:.1f} s; "
                           f"get_visible_nodes: {V / cpu_b:.1f} frusta/s"}}
+
+
+def query_profile(bhash):
+    """Counters of the query kernels from this round's rocprofv3 passes of `bench.py --query` (tools/profile_query.sh ->
+    profiles/<round>_query_counters.json), quoted only when they were taken from the library that is running."""
+    path = os.path.join(ROOT, "profiles", f"{ROUND}_query_counters.json")
+    if not os.path.exists(path):
+        return {"source": None, "note": "no rocprofv3 pass of the query path recorded for this round"}
+    with open(path) as f:
+        prof = json.load(f)
+    if prof.get("build_hash") != bhash:
+        return {"source": os.path.relpath(path, ROOT), "profile_matches_build": False,
+                "note": f"STALE: taken from build {prof.get('build_hash')}, running {bhash}"}
+    return dict(prof.get("kernels", {}), source=os.path.relpath(path, ROOT), profile_matches_build=True)
+
+
+def query_bench(args):
+    """`bench.py --query`: BASELINE config 4 on its own (the default line carries the same leg as `query`)."""
+    import torch
+    import point_cloud_viewer_amd as pcv
+    dev = torch.device("cuda", 0)
+    x, y, z, rgb = make_cloud(torch, args.points, seed=1, device=dev)
+    ctx = pcv.Context(0)
+    tree = ctx.build(args.resolution, None, x, y, z, rgb)
+    del x, y, z, rgb
+    out = query_leg(args, ctx, tree)
+    out["roofline"]["profile"] = query_profile(build_hash())
+    return out
+
+
+def config5_leg(args, torch, pcv, ctx, dev, points):
+    """BASELINE config 5 inside the default line: `points` (500 M) Gaussian-cluster points at ECEF magnitudes (|p| ~ 6.4e6 m,
+    f64 input; leaf levels Float32 / u16 / u8-coded, codec.rs:115-121), timed builds + byte parity of every node against
+    the closed-form CPU oracle. This is the size at which the SHIPPED library's big-tree record sort (more than 16 384
+    predicted nodes) runs."""
+    offset = (-2.7e6, -4.3e6, 3.8e6)
+    t_gen = time.perf_counter()
+    x, y, z, rgb = make_cloud(torch, points, seed=1, device=dev, offset=offset)
+    t_gen = time.perf_counter() - t_gen
+    steps, warmup = max(1, args.config5_steps), 1
+    ctx.set_profiling("major")
+    info = {}
+    for _ in range(warmup):
+        ctx.build(args.resolution, None, x, y, z, rgb).free()
+    ctx.reset_kernel_stats()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        t = ctx.build(args.resolution, None, x, y, z, rgb)
+        info["nodes"], info["stages"], info["build"] = t.num_nodes, t.stage_ms(), t.build_info()
+        t.free()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ctx.set_profiling(False)
+    kstats = ctx.kernel_stats()
+    parity = verify_build(ctx, args.resolution, x, y, z, rgb)
+    del x, y, z, rgb
+    ms = elapsed / steps * 1e3
+    return {"metric": "octree-build Mpoints/sec", "value": round(points / (ms * 1e-3) / 1e6, 2), "unit": "Mpoints/s",
+            "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 3), "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"BASELINE config 5 (ECEF-offset f64 input): {points / 1e6:g} M Gaussian-cluster points (64 clusters, "
+                                   f"1000 m cube, sigma 1-20 m) offset by {offset} m, f64 SoA xyz + u8 rgb, resolution 1 mm, full "
+                                   "build + LOD promotion, K1 inside the step",
+                       "points": points, "nodes": info.get("nodes"), "cloud_generation_s": round(t_gen, 1)},
+            "parity": parity, "tree_digest": parity.get("tree_digest"), "build_info": info.get("build"),
+            "stage_ms": {k: round(v, 3) for k, v in (info.get("stages") or {}).items()},
+            "kernel_ms_per_step": {k: round(v[1] / steps, 3) for k, v in kstats.items() if v[0] > 0}}
 
 
 def run_virtual_ranks(args, torch, pcv, dev):
@@ -567,7 +630,12 @@ def main():
     ap.add_argument("--cull-frusta", type=int, default=100)
     ap.add_argument("--verify-frusta", type=int, default=10_000, help="frusta whose relations / sizes / visible lists are compared with the oracle")
     ap.add_argument("--verify-cull-frusta", type=int, default=100, help="culled frusta whose query_points result is compared with the oracle")
+    ap.add_argument("--query-steps", type=int, default=5, help="timed repetitions of the node-cull launch sequence (config 4)")
     ap.add_argument("--config1", action="store_true", help="BASELINE config 1 (CPU plumbing line)")
+    ap.add_argument("--no-legs", action="store_true",
+                    help="default N=1 line only: skip the config-4 (`query`) and config-5 (`config5`) legs after the timed region")
+    ap.add_argument("--config5-points", type=int, default=500_000_000)
+    ap.add_argument("--config5-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-to-files end-to-end leg (N=1 only)")
     ap.add_argument("--kernel-events", choices=["major", "all", "none"], default="major",
@@ -973,6 +1041,23 @@ def main():
                        "on the device; creating the node files in ONE directory serialises on the directory lock "
                        "(reference layout); not part of `value`"}
 
+    # ---- the other single-GPU BASELINE configs, after the timed region of the default line: config 4 (frustum path on the
+    # octree of this cloud) and config 5 (500 M ECEF points), each with its own timing and oracle parity ----
+    query, config5 = None, None
+    if plain and rank == 0 and not args.no_parity and not args.no_legs:
+        try:
+            qt = ctx.build(args.resolution, None, x, y, z, rgb)
+            query = query_leg(args, ctx, qt)
+            query["roofline"]["profile"] = query_profile(bhash)
+            qt.free()
+        except Exception as e:  # noqa: BLE001 - the leg reports its failure, the line of record still prints
+            query = {"error": f"{type(e).__name__}: {e}", "parity": {"ok": False}}
+        del x, y, z, rgb
+        try:
+            config5 = config5_leg(args, torch, pcv, ctx, dev, args.config5_points)
+        except Exception as e:  # noqa: BLE001
+            config5 = {"error": f"{type(e).__name__}: {e}", "parity": {"ok": False, "mismatching_nodes": None}}
+
     if rank == 0:
         if config3:
             workload = (f"BASELINE config 3: ONE cloud of {total / 1e6:g} M Gaussian-cluster points (64 clusters, 1000 m cube, "
@@ -996,7 +1081,7 @@ def main():
                        "parallelism": "1 GPU" if world == 1 else
                        f"{world} GPUs, one process each, shard mode {args.shard_mode}: one all-to-all(v) over RCCL"},
             "roofline": roofline, "encode_sort": encode_sort, "cpu_baseline": cpu, "parity": parity, "tree_digest": tree_digest,
-            "end_to_end": e2e,
+            "end_to_end": e2e, "query": query, "config5": config5,
             "build_info": info.get("build"), "exchange": info.get("exchange"),
             "exchange_per_rank": None if per_rank is None else [
                 None if e is None else {"rank": r, "rows_sent": e["rows_sent"], "rows_received": e["rows_received"],

@@ -118,6 +118,11 @@ typedef struct pcv_build_params {
 #define PCV_BUILD_FORCE_SINGLE_CHAIN 4u
 /* Never take the single-chain build (the exact pipeline with its depth speculation runs instead). */
 #define PCV_BUILD_NO_SINGLE_CHAIN 8u
+/* Single-chain build, diagnostics: the device's predicted-leaf -> true-leaf rank map (which drives the record sort) is
+ * downloaded and compared entry by entry with the host's (which the node tables come from) before the octree is handed
+ * out; PCV_E_HIP on a difference. Without the flag only the number of true leaves and the "too shallow" verdict of the two
+ * resolves are compared (always, for free). */
+#define PCV_BUILD_CHECK_RESOLVE 16u
 
 /* Multi-GPU build: level-1 nodes whose bit is set are split even if this rank's share of their points
  * is below the capacity — the split decision of the GLOBAL tree, made from the all-reduced bucket counts. */
@@ -237,8 +242,11 @@ void pcv_octree_build_info(const pcv_octree* t, int* key_levels, int* attempts);
  * candidate node that turned out to be split. */
 void pcv_octree_spec_stats(const pcv_octree* t, uint64_t stats[4]);
 uint64_t pcv_octree_spec_continued(const pcv_octree* t);
+/* Single-chain build with 12-byte records: number of points whose record left the chain pass with the codes of a
+ * Float32-coded level (they wait in a dense side pool, the record names the entry); 0 otherwise. */
+uint64_t pcv_octree_wide_pool_entries(const pcv_octree* t);
 /* Bytes of one record of the last build's record sort (rank + leaf codes + colour): 20, or 12 when the single-chain
- * build packed the record (16-bit codes; the points of Float32-coded leaves travel as their input index). */
+ * build packed the record (16-bit codes; the points of Float32-coded levels travel as the index of their pool entry). */
 int pcv_octree_record_bytes(const pcv_octree* t);
 
 /* ---- stage-level entry points (unit parity against the oracle) ------------------------------ */

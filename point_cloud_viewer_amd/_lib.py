@@ -20,6 +20,7 @@ BUILD_COMPUTE_BBOX = 1
 BUILD_NO_SPECULATION = 2
 BUILD_FORCE_SINGLE_CHAIN = 4
 BUILD_NO_SINGLE_CHAIN = 8
+BUILD_CHECK_RESOLVE = 16
 MAX_KEY_LEVELS = 21
 NUM_STAGES = 9
 STAGE_NAMES = ["aabb", "chain_keys", "sort_keys", "node_split", "table", "leaf_encode", "sort_records",
@@ -126,6 +127,7 @@ _SIGNATURES = {
     "pcv_octree_spec_stats": (None, [_vp, C.POINTER(C.c_uint64)]),
     "pcv_octree_record_bytes": (C.c_int, [_vp]),
     "pcv_octree_spec_continued": (C.c_uint64, [_vp]),
+    "pcv_octree_wide_pool_entries": (C.c_uint64, [_vp]),
     "pcv_aabb_reduce": (C.c_int, [_vp, C.POINTER(Points), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "pcv_level_table": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_int,
                                   C.POINTER(C.c_double), C.POINTER(C.c_int32)]),

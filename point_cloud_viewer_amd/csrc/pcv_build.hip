@@ -324,7 +324,7 @@ extern "C" int pcv_ctx_create(int device, void* stream, pcv_ctx** out) {
   if (hipSetDevice(device) != hipSuccess) return PCV_E_HIP;
   pcv_ctx* c = new pcv_ctx();
   c->device = device;
-  if (hipHostMalloc((void**)&c->mailbox, 128 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) {
+  if (hipHostMalloc((void**)&c->mailbox, 136 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) {
     delete c;
     return PCV_E_OOM;
   }
@@ -502,21 +502,33 @@ int pcv_make_levels(const double bmin[3], const double bmax[3], double resolutio
       }();
       if (digit_shortcut && j >= 1 && (c[j] == PCV_ENC_UINT8 || c[j] == PCV_ENC_UINT16) && std::isfinite(amax) && e[j] > 0.0) {
         const double m = c[j] == PCV_ENC_UINT8 ? 255.0 : 65535.0;
-        if ((2.5 * amax / e[j] + 3.0) * 4.04 * m < 0x1p+53) lv->digit_half[j] = c[j] == PCV_ENC_UINT8 ? 127.0 : 32767.0;
+        if ((2.5 * amax / e[j] + 3.0) * 4.04 * m < 0x1p+53) {
+          lv->digit_half[j] = c[j] == PCV_ENC_UINT8 ? 127.0 : 32767.0;
+          lv->digit_mode[j] = 1;
+        }
+      }
+      // pcv_f32 codes (pcv_chain_dev.h, pcv_bits_from_codes / pcv_f32_code_tie): the same inequality with M = 2^24 — the
+      // floats next to 1/2 are 2^-25 away; only the single chain pass looks at digit_mode
+      if (digit_shortcut && j >= 1 && c[j] == PCV_ENC_FLOAT32 && std::isfinite(amax) && e[j] > 0.0 &&
+          (2.5 * amax / e[j] + 3.0) * 4.04 * 0x1p+24 < 0x1p+53) {
+        lv->digit_half[j] = 0.5;
+        lv->digit_mode[j] = 2;
       }
     }
     lv->fast_ok = tame ? 1 : 0;
     {
       const int never = 1 << 20;
-      int f16 = never, f8 = never;
+      int f16 = never, f8 = never, f32 = never;
       bool monotone = true;
       const int last = filled < (int)e.size() - 1 ? filled : (int)e.size() - 1;
       for (int j = 1; j <= last; ++j) {
+        if (c[j] <= PCV_ENC_FLOAT32 && f32 == never) f32 = j;
         if (c[j] <= PCV_ENC_UINT16 && f16 == never) f16 = j;
         if (c[j] == PCV_ENC_UINT8 && f8 == never) f8 = j;
         if (j > 1 && c[j] > c[j - 1]) monotone = false;
       }
       if (f8 != never && f16 == never) f16 = f8;
+      lv->first_f32 = monotone ? f32 : never;
       lv->first_u16 = monotone ? f16 : never;
       lv->first_u8 = monotone ? f8 : never;
     }
@@ -631,6 +643,7 @@ static int device_aabb(pcv_ctx* ctx, PcvScratch& sc, const DevPoints& d, double 
 // octree object
 // ------------------------------------------------------------------------------------------------
 // State of a build between pcv_build_begin (through the topology) and pcv_build_finish (encode + promotion).
+constexpr int kMailboxResolve = 128;  // u64 slot of the pinned mailbox (pcv_internal.h: 0..63 read-backs, 64..127 replay ranges)
 struct PcvBuild {
   pcv_ctx* ctx;
   PcvScratch sc;
@@ -662,6 +675,13 @@ struct PcvBuild {
   // the record sort (queue_record_sort): buffers and where the sorted records ended up
   bool sort_queued = false, rec_in_a = true;
   void *pay_a = nullptr, *pay_b = nullptr;
+  // device resolve (spec_resolve_kernel drives the record sort) vs host resolve (pcv_spec_resolve builds the tables): what the
+  // device reported — {true leaves, too shallow} — lands in mailbox[kMailboxResolve] and pcv_build_finish compares it with
+  // the host's tree before anything of the build is handed out; check_map: the whole rank map is compared too
+  bool resolve_on_device = false, resolve_check_map = false;
+  uint32_t resolve_host_leaves = 0;
+  std::vector<uint32_t> resolve_host_map;
+  std::vector<uint8_t> resolve_host_inner;  // T'' node is an inner node: its map entry is never read (the device leaves it unwritten)
   PcvSortPayload pl;
   explicit PcvBuild(pcv_ctx* c) : ctx(c), sc(c) {}
 };
@@ -715,6 +735,7 @@ extern "C" void pcv_octree_spec_stats(const pcv_octree* t, uint64_t stats[4]) {
 }
 extern "C" int pcv_octree_record_bytes(const pcv_octree* t) { return t ? t->record_bytes : 0; }
 extern "C" uint64_t pcv_octree_spec_continued(const pcv_octree* t) { return t ? t->spec_continued : 0; }
+extern "C" uint64_t pcv_octree_wide_pool_entries(const pcv_octree* t) { return t ? t->wide_pool_entries : 0; }
 extern "C" int pcv_octree_device_blob(const pcv_octree* t, int which, const void** dptr, uint64_t* len) {
   if (!t || !dptr || !len || which < 0 || which > 2) return PCV_E_INVALID;
   *dptr = which == 0 ? t->d_xyz : (which == 1 ? t->d_rgb : t->d_int);
@@ -962,7 +983,8 @@ static int queue_replay(pcv_ctx* ctx, PcvBuild* bs) {
     before += bs->fix_ranges[k].count;
   }
   PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_ranges, h_ranges, (size_t)nr * 16, hipMemcpyHostToDevice, st));
-  pcv_launch_spec_replay(ctx, bs->lv, d_ranges, nr, before, d.x, d.y, d.z, d.routed, (void*)s_pay, bs->spec_wide);
+  pcv_launch_spec_replay(ctx, bs->lv, d_ranges, nr, before, d.x, d.y, d.z, d.routed, (void*)s_pay, bs->spec_wide,
+                         (uint32_t)(bs->n - 1));
   return PCV_OK;
 }
 
@@ -1091,7 +1113,7 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
     ctx->stage_begin(PCV_STAGE_LEAF_ENCODE);
     lv.nlevels = full_levels;
     pcv_launch_spec_encode(ctx, lv, d_walk, n, d.x, d.y, d.z, d.routed, d.color, d.color_stride, d.intensity, rank, payload,
-                           inten_bits, depth_grid, wide);
+                           inten_bits, depth_grid, wide, d_info + 8 /* pool counter: zeroed by the spec_tree kernels */);
     ctx->stage_end(PCV_STAGE_LEAF_ENCODE);
     host_lap("chain pass queued");
 
@@ -1166,6 +1188,9 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
   uint32_t* h_counts = (uint32_t*)hp;
   const size_t map_off = ((size_t)tree.num_leaves * 4 + 255) & ~(size_t)255;
   PCV_HIP_CHECK(ctx, hipMemcpyAsync(h_counts, d_counts, (size_t)tree.num_leaves * 4, hipMemcpyDeviceToHost, st));
+  // ... and with them the number of `wide` pool entries the chain pass handed out (pcv_spec_emit)
+  uint32_t* h_pool = (uint32_t*)(hp + (((size_t)tree.num_leaves * 8 + 256 + 63) & ~(size_t)63));
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(h_pool, d_info + 8, 4, hipMemcpyDeviceToHost, st));
   PCV_HIP_CHECK(ctx, hipEventRecord(ctx->spec_ev, st));  // the counts are on their way to the host
   // The map the record sort needs is computed on the device (spec_resolve_kernel), and the sort is queued behind it right
   // away: the counts' trip to the host, the host's own resolve and the table building all happen beside the sort instead
@@ -1183,12 +1208,25 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
   bs->spec_payload = payload;
   bs->fix_ranges.clear();
   auto give_up = [&]() {  // nothing of this attempt is kept; queued work on the scratch buffers drains harmlessly
+    // (the pool is stream-ordered: a freed block is only handed to work queued later on the same stream). The record sort
+    // that was queued ahead of the verdict leaves its second payload buffer and the rank-count rows behind: without this
+    // the fallback — which allocates its own record buffers — would be the build's memory peak
+    if (bs->sort_queued && bs->pay_b && bs->pay_b != (void*)payload) {
+      sc.detach(bs->pay_b);
+      ctx->dev_free(bs->pay_b);
+    }
+    if (bs->spec_rows) {
+      sc.detach((void*)bs->spec_rows);
+      ctx->dev_free((void*)bs->spec_rows);
+    }
+    bs->pay_a = bs->pay_b = nullptr;
     bs->spec = false;
     bs->spec_payload = nullptr;
     bs->spec_wide = nullptr;
     bs->spec_map_dev = nullptr;
     bs->spec_rows = nullptr;
     bs->sort_queued = false;
+    bs->resolve_on_device = false;
     sc.detach(payload);
     ctx->dev_free(payload);
     if (wide) {
@@ -1201,6 +1239,12 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
     const uint32_t tn = (uint32_t)tree.prefix.size();
     if ((rc = sc.get(&d_nst, tn)) || (rc = sc.get(&d_base, tn)) || (rc = sc.get(&d_out, 64))) return rc;
     pcv_launch_spec_resolve(ctx, lv, params->resolution, sp.cap, sp.force_mask, d_walk, d_slevel, tn, d_counts, d_nst, d_base, d_map, d_out);
+    PCV_HIP_CHECK(ctx, hipGetLastError());  // before the sort is queued behind it
+    // {true leaves, too shallow} as the device sees them: read by pcv_build_finish (which synchronises anyway) and held
+    // against the host's resolve — the device map drives the sort, the host's tree the tables
+    ctx->mailbox[kMailboxResolve] = ~0ull;
+    PCV_HIP_CHECK(ctx, hipMemcpyAsync(ctx->mailbox + kMailboxResolve, d_out, 8, hipMemcpyDeviceToHost, st));
+    bs->resolve_on_device = true;
     ctx->stage_end(PCV_STAGE_NODE_SPLIT);
     const uint32_t predicted_leaves = (uint32_t)std::count(tree.inner.begin(), tree.inner.end(), (uint8_t)0);
     if ((rc = queue_record_sort(ctx, bs, t, nullptr, predicted_leaves, false))) return rc;
@@ -1213,6 +1257,25 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
   if (resolved != PCV_SPEC_OK) {
     give_up();
     return PCV_OK;  // *used stays false
+  }
+  // the rare replay takes its pool entries from the top of `wide` (spec_replay_kernel): they must not reach down to the
+  // entries the chain pass handed out from the bottom. A point has at most one live entry, but a replayed point may have used
+  // one in the chain pass already — on an adversarial cloud the two can add up to more than n: the exact pipeline takes it
+  if (wide) {
+    uint64_t replay_wide = 0;
+    for (uint32_t k : tt->fix_nodes)
+      if ((wide_levels >> tt->level[k]) & 1ull) replay_wide += tt->hi[k] - tt->lo[k];
+    if ((uint64_t)*h_pool + replay_wide > n) {
+      give_up();
+      return PCV_OK;
+    }
+    t->wide_pool_entries = *h_pool;
+  }
+  bs->resolve_host_leaves = tt->num_leaves;
+  bs->resolve_check_map = (params->flags & PCV_BUILD_CHECK_RESOLVE) != 0;
+  if (bs->resolve_check_map) {
+    bs->resolve_host_map = tt->spec_map;
+    bs->resolve_host_inner = tree.inner;
   }
   if (tt->prefix.size() > (size_t)nt.capacity) return ctx->fail(PCV_E_OOM, "node table capacity exceeded");
   bs->cont_nodes = tt->cont_nodes;
@@ -1872,6 +1935,23 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
   PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[8], st));
   PCV_HIP_CHECK(ctx, hipGetLastError());
   PCV_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  if (bs->spec && bs->resolve_on_device) {
+    // the record sort ran on the device's rank map, the tables above come from the host's resolve: both apply the same
+    // integer rules to the same counts, so a difference is a bug — reported, never handed out as an octree
+    uint32_t dev[2];
+    std::memcpy(dev, ctx->mailbox + kMailboxResolve, sizeof(dev));
+    bool same = dev[0] == bs->resolve_host_leaves && dev[1] == 0u;
+    if (same && bs->resolve_check_map && !bs->resolve_host_map.empty()) {
+      std::vector<uint32_t> dm(bs->resolve_host_map.size());
+      PCV_HIP_CHECK(ctx, hipMemcpy(dm.data(), bs->spec_map_dev, dm.size() * 4, hipMemcpyDeviceToHost));
+      for (size_t k = 0; same && k < dm.size(); ++k) same = bs->resolve_host_inner[k] || dm[k] == bs->resolve_host_map[k];
+    }
+    if (!same) {
+      t->nodes.clear();
+      t->num_points = 0;
+      return ctx->fail(PCV_E_HIP, "single-chain build: the device's resolve of the predicted tree disagrees with the host's");
+    }
+  }
   ctx->prof_resolve();
   for (int sidx = 0; sidx < PCV_STAGE_TOTAL; ++sidx) {
     t->stage_ms[sidx] = 0.f;

@@ -62,15 +62,25 @@ __device__ __forceinline__ double pcv_clamp01(double t) { return (t < 0.0) ? 0.0
 // instructions (the compiler folds them into the clamp modifier of the division's last FMA) instead of two compares
 // and four selects per coordinate. Zeros (sign!), denormals, infinities, NaN and untamed divisors take the IEEE
 // division and the literal clamp, out of line.
-__device__ __forceinline__ double pcv_unit_quotient(double p, double mn, double edge, PcvRecip inv_edge) {
+// TAME: the caller has established once per point that the coordinates are finite with |v| <= 2^500 and that the level
+// table is tame (PcvLevels::fast_ok: every inv_edge.hi != 0, |cube min| <= 2^500 + edges): |x| <= 2^900 and the divisor
+// check then hold by construction and ONE comparison — "not (|x| >= 2^-900)", which also catches the zeros whose sign the
+// Markstein step would lose — is all that guards the fast path (round 4: a Float32-coded level spent 9 of its 48 f64-pipe
+// instructions on the three-part range test).
+template <bool TAME>
+__device__ __forceinline__ double pcv_unit_quotient_t(double p, double mn, double edge, PcvRecip inv_edge) {
   const double x = p - mn;
   const double ax = fabs(x);
-  if (__builtin_expect(!(ax >= 0x1p-900 && ax <= 0x1p+900) || inv_edge.hi == 0.0, 0)) {
+  const bool slow = TAME ? !(ax >= 0x1p-900) : (!(ax >= 0x1p-900 && ax <= 0x1p+900) || inv_edge.hi == 0.0);
+  if (__builtin_expect(slow, 0)) {
     double xs = x;
     asm volatile("" : "+v"(xs));  // pins the division expansion inside this (almost never taken) branch
     return pcv_clamp01(xs / edge);
   }
   return fmin(fmax(pcv_div_const<false>(x, edge, inv_edge), 0.0), 1.0);
+}
+__device__ __forceinline__ double pcv_unit_quotient(double p, double mn, double edge, PcvRecip inv_edge) {
+  return pcv_unit_quotient_t<false>(p, mn, edge, inv_edge);
 }
 
 // Rust `as u8/u16` after the clamp: NaN -> 0, truncation toward zero; t <= 1 so no upper saturation.
@@ -118,7 +128,7 @@ __device__ __forceinline__ double pcv_encode_val(double p, double mn, double edg
     t = fmin(t, 1.0);
     return trunc(maxval * t);  // Rust `as u8/u16`: truncation toward zero, exact in f64
   }
-  const double t = pcv_unit_quotient(p, mn, edge, inv_edge);
+  const double t = pcv_unit_quotient_t<!GUARD>(p, mn, edge, inv_edge);  // GUARD = false: tame point, tame table
   return ENC == PCV_ENC_FLOAT32 ? (double)(float)t : t;
 }
 template <int ENC>
@@ -177,8 +187,8 @@ __device__ __forceinline__ uint32_t pcv_chain_level(uint32_t enc, double ep, dou
   switch (enc) {
     case PCV_ENC_UINT8: return pcv_chain_level_t<PCV_ENC_UINT8, GUARD>(ep, ec, ic, px, py, pz, mx, my, mz, cx, cy, cz);
     case PCV_ENC_UINT16: return pcv_chain_level_t<PCV_ENC_UINT16, GUARD>(ep, ec, ic, px, py, pz, mx, my, mz, cx, cy, cz);
-    case PCV_ENC_FLOAT32: return pcv_chain_level_t<PCV_ENC_FLOAT32, true>(ep, ec, ic, px, py, pz, mx, my, mz, cx, cy, cz);
-    default: return pcv_chain_level_t<PCV_ENC_FLOAT64, true>(ep, ec, ic, px, py, pz, mx, my, mz, cx, cy, cz);
+    case PCV_ENC_FLOAT32: return pcv_chain_level_t<PCV_ENC_FLOAT32, GUARD>(ep, ec, ic, px, py, pz, mx, my, mz, cx, cy, cz);
+    default: return pcv_chain_level_t<PCV_ENC_FLOAT64, GUARD>(ep, ec, ic, px, py, pz, mx, my, mz, cx, cy, cz);
   }
 }
 
@@ -223,8 +233,83 @@ __device__ __forceinline__ void pcv_chain_apply(uint32_t enc, uint32_t d, double
   switch (enc) {
     case PCV_ENC_UINT8: return pcv_chain_apply_t<PCV_ENC_UINT8, GUARD>(d, ec, ic, px, py, pz, mx, my, mz, cx, cy, cz);
     case PCV_ENC_UINT16: return pcv_chain_apply_t<PCV_ENC_UINT16, GUARD>(d, ec, ic, px, py, pz, mx, my, mz, cx, cy, cz);
-    case PCV_ENC_FLOAT32: return pcv_chain_apply_t<PCV_ENC_FLOAT32, true>(d, ec, ic, px, py, pz, mx, my, mz, cx, cy, cz);
-    default: return pcv_chain_apply_t<PCV_ENC_FLOAT64, true>(d, ec, ic, px, py, pz, mx, my, mz, cx, cy, cz);
+    case PCV_ENC_FLOAT32: return pcv_chain_apply_t<PCV_ENC_FLOAT32, GUARD>(d, ec, ic, px, py, pz, mx, my, mz, cx, cy, cz);
+    default: return pcv_chain_apply_t<PCV_ENC_FLOAT64, GUARD>(d, ec, ic, px, py, pz, mx, my, mz, cx, cy, cz);
+  }
+}
+
+// ---- the same level with the octant bits kept as three booleans (round 4) ------------------------------------------
+// The digit only exists to index the child: the three comparisons produce lane masks, `min += bit * edge` selects the
+// high word of its 1.0 / 0.0 factor straight from the mask (one v_cndmask per coordinate) and the child index is assembled
+// from the same masks — instead of packing the digit and taking it apart again (six more integer instructions per level).
+struct PcvOctBits {
+  bool x, y, z;
+  __device__ __forceinline__ uint32_t digit() const { return (x ? 4u : 0u) | (y ? 2u : 0u) | (z ? 1u : 0u); }
+};
+__device__ __forceinline__ PcvOctBits pcv_chain_bits(double e_parent, double px, double py, double pz, double mx, double my, double mz) {
+  const double cx = (mx + (mx + e_parent)) / 2.0, cy = (my + (my + e_parent)) / 2.0, cz = (mz + (mz + e_parent)) / 2.0;
+  return PcvOctBits{px > cx, py > cy, pz > cz};
+}
+// Integer codes of a u8 / u16-coded parent level: see pcv_digit_from_codes.
+__device__ __forceinline__ PcvOctBits pcv_bits_from_codes(double half, double vx, double vy, double vz) {
+  return PcvOctBits{vx > half, vy > half, vz > half};
+}
+// Float32 codes of the parent level (round 4). The position the comparison sees is p = fma(v, e, mn) with v = (double)(float)t,
+// the centre c0 = fl(fl(mn + fl(mn + e)) / 2). Exactly, P* - C* = (v - 1/2) e, and the floats next to 1/2 are 1/2 - 2^-25 and
+// 1/2 + 2^-24: unless v == 1/2, |P* - C*| >= 2^-25 e. Rounding moves p by at most u (|mn| + e) and c0 by at most
+// u (1.5 |mn| + e) (u = 2^-53), so wherever
+//     1.01 u (2.5 A / e + 3) < 2^-25,     A = the largest |coordinate| of the root cube,
+// (p > c0) == (v > 1/2) for every v != 1/2 — the same inequality as pcv_digit_from_codes with M = 2^24, checked per level by
+// pcv_make_levels with a factor of two in hand (PcvLevels::digit_mode == 2). A code of exactly 1/2 is a genuine tie of the
+// exact values: there the rounded comparison decides, so a wave that holds such a lane takes the comparison against the
+// centre for that level (wave-uniform branch; one point in 2^24 per coordinate for smooth data).
+__device__ __forceinline__ bool pcv_f32_code_tie(double vx, double vy, double vz) { return vx == 0.5 || vy == 0.5 || vz == 0.5; }
+
+template <int ENC, bool GUARD>
+__device__ __forceinline__ void pcv_chain_apply_bits_t(PcvOctBits b, double ec, PcvRecip ic, double& px, double& py, double& pz, double& mx,
+                                                       double& my, double& mz, double& cx, double& cy, double& cz) {
+  mx = pcv_step_min(mx, b.x, ec);
+  my = pcv_step_min(my, b.y, ec);
+  mz = pcv_step_min(mz, b.z, ec);
+  if constexpr (!GUARD && (ENC == PCV_ENC_FLOAT32 || ENC == PCV_ENC_FLOAT64)) {
+    // float encodings of a tame point in a tame table (pcv_unit_quotient_t<true>), the three coordinates behind ONE branch:
+    // a lane whose dividends are all >= 2^-900 in magnitude takes the constant-divisor division for all three; any other
+    // lane (a zero whose sign matters, a denormal) takes the IEEE division for all three — it is correct everywhere, and
+    // one branch scaffold per level replaces three
+    const double x = px - mx, y = py - my, z = pz - mz;
+    double tx, ty, tz;
+    if (__builtin_expect(!(fabs(x) >= 0x1p-900 && fabs(y) >= 0x1p-900 && fabs(z) >= 0x1p-900), 0)) {
+      double xs = x, ys = y, zs = z;
+      asm volatile("" : "+v"(xs), "+v"(ys), "+v"(zs));  // pins the division expansions inside this (almost never taken) branch
+      tx = pcv_clamp01(xs / ec), ty = pcv_clamp01(ys / ec), tz = pcv_clamp01(zs / ec);
+    } else {
+      tx = fmin(fmax(pcv_div_const<false>(x, ec, ic), 0.0), 1.0);
+      ty = fmin(fmax(pcv_div_const<false>(y, ec, ic), 0.0), 1.0);
+      tz = fmin(fmax(pcv_div_const<false>(z, ec, ic), 0.0), 1.0);
+    }
+    cx = ENC == PCV_ENC_FLOAT32 ? (double)(float)tx : tx;
+    cy = ENC == PCV_ENC_FLOAT32 ? (double)(float)ty : ty;
+    cz = ENC == PCV_ENC_FLOAT32 ? (double)(float)tz : tz;
+    px = pcv_decode_val<ENC>(cx, mx, ec);
+    py = pcv_decode_val<ENC>(cy, my, ec);
+    pz = pcv_decode_val<ENC>(cz, mz, ec);
+    return;
+  }
+  cx = pcv_encode_val<ENC, GUARD>(px, mx, ec, ic);
+  cy = pcv_encode_val<ENC, GUARD>(py, my, ec, ic);
+  cz = pcv_encode_val<ENC, GUARD>(pz, mz, ec, ic);
+  px = pcv_decode_val<ENC>(cx, mx, ec);
+  py = pcv_decode_val<ENC>(cy, my, ec);
+  pz = pcv_decode_val<ENC>(cz, mz, ec);
+}
+template <bool GUARD>
+__device__ __forceinline__ void pcv_chain_apply_bits(uint32_t enc, PcvOctBits b, double ec, PcvRecip ic, double& px, double& py, double& pz,
+                                                     double& mx, double& my, double& mz, double& cx, double& cy, double& cz) {
+  switch (enc) {
+    case PCV_ENC_UINT8: return pcv_chain_apply_bits_t<PCV_ENC_UINT8, GUARD>(b, ec, ic, px, py, pz, mx, my, mz, cx, cy, cz);
+    case PCV_ENC_UINT16: return pcv_chain_apply_bits_t<PCV_ENC_UINT16, GUARD>(b, ec, ic, px, py, pz, mx, my, mz, cx, cy, cz);
+    case PCV_ENC_FLOAT32: return pcv_chain_apply_bits_t<PCV_ENC_FLOAT32, GUARD>(b, ec, ic, px, py, pz, mx, my, mz, cx, cy, cz);
+    default: return pcv_chain_apply_bits_t<PCV_ENC_FLOAT64, GUARD>(b, ec, ic, px, py, pz, mx, my, mz, cx, cy, cz);
   }
 }
 

@@ -82,6 +82,61 @@ __global__ __launch_bounds__(256) void leaf_encode_kernel(
   if (inten_bits) inten_bits[i] = __float_as_uint(intensity[i]);
 }
 
+// ---- the record a point leaves the chain pass with (both forms of the pass) -----------------------------------------------
+// 12-byte record: key = predicted leaf << 8 | blue, payload = {cx | cy << 16, cz | red << 16 | green << 24}. The codes of a
+// Float32-coded level do not fit 16 bits: they go to an entry of the dense `wide` POOL and the record names that entry.
+// Pool entries are handed out per WAVE (round 4): the lanes whose record level is Float32-coded are counted with one
+// ballot, the wave's first such lane reserves that many consecutive entries with ONE returning atomic on the pool counter,
+// and lane k of them takes entry base + k. Waves without such a lane (most of them: the deal below groups points by depth,
+// and only the shallow levels are Float32-coded) pay a ballot and a scalar branch. A leaf's records meet `settle` in input
+// order, i.e. in runs of entries that one wave wrote side by side: the 4.7 M entries of the bench cloud are 75 MB
+// (Infinity-Cache resident) read in runs, where round 3 gathered one 16-byte entry per HBM line out of a 1.6 GB array indexed
+// by input position (settle: 1.55 x its algorithmic traffic). Which entry a point gets depends on the order the waves reach
+// the atomic — it does not matter: the record names its entry, nothing else refers to it.
+__device__ __forceinline__ uint32_t pcv_load_rgb(const uint8_t* __restrict__ c, bool room) {
+  // r | g << 8 | b << 16: one unaligned 32-bit load where a fourth byte exists behind the colour (every point but the last)
+  if (room) {
+    uint32_t w;
+    __builtin_memcpy(&w, c, 4);
+    return w & 0xffffffu;
+  }
+  return (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16);
+}
+__device__ __forceinline__ void pcv_spec_emit(uint64_t i, uint64_t n, uint32_t rec, uint32_t leaf_enc, double vx, double vy, double vz,
+                                              const uint8_t* __restrict__ color, uint32_t color_stride,
+                                              const float* __restrict__ intensity, uint32_t* __restrict__ rank,
+                                              uint4* __restrict__ payload, uint32_t* __restrict__ inten_bits,
+                                              uint4* __restrict__ wide, uint32_t* __restrict__ pool_counter) {
+  const uint32_t rgb = pcv_load_rgb(color + i * color_stride, i + 1 < n);
+  const bool is_wide = leaf_enc > PCV_ENC_UINT16;
+  // value domain -> raw code: the integer itself (u8 / u16), the IEEE bits of the float (Float32); single-chain builds have
+  // no Float64-coded level (build_begin_impl sends those to the exact pipeline)
+  const uint32_t ccx = is_wide ? __float_as_uint((float)vx) : (uint32_t)vx, ccy = is_wide ? __float_as_uint((float)vy) : (uint32_t)vy,
+                 ccz = is_wide ? __float_as_uint((float)vz) : (uint32_t)vz;
+  if (wide) {
+    rank[i] = ((rec & PCV_SPEC_INDEX_MASK) << 8) | (rgb >> 16);
+    const uint32_t rg = (rgb & 0xffffu) << 16;
+    uint2 out = make_uint2(ccx | (ccy << 16), ccz | rg);
+    const uint64_t wm = __ballot(is_wide);
+    if (wm != 0ull) {  // wave-uniform
+      uint32_t base = 0;
+      if (is_wide && (wm & ((1ull << (threadIdx.x & 63)) - 1ull)) == 0ull)
+        base = __hip_atomic_fetch_add(pool_counter, (uint32_t)__popcll(wm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)__builtin_ctzll(wm));
+      if (is_wide) {
+        const uint32_t e = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(wm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wm, 0u));
+        wide[e] = make_uint4(ccx, ccy, ccz, 0u);
+        out = make_uint2(e, rg);
+      }
+    }
+    reinterpret_cast<uint2*>(payload)[i] = out;
+  } else {  // 20-byte records (a predicted tree that could outgrow 24 rank bits): the codes travel in full
+    rank[i] = rec & PCV_SPEC_INDEX_MASK;
+    payload[i] = make_uint4(ccx, ccy, ccz, rgb);
+  }
+  if (inten_bits) inten_bits[i] = __float_as_uint(intensity[i]);
+}
+
 // ---- single-chain build (pcv_spec.h): ONE chain pass down the predicted tree T'' --------------------------------------
 // Every inner node of T'' has all eight children (consecutive walk records), so a digit indexes the child directly.
 // A point passing through a candidate node (sampled count close to the capacity) leaves this pass with the codes it has
@@ -123,7 +178,8 @@ __global__ __launch_bounds__(BLOCK) void spec_encode_kernel(
     const double* __restrict__ y, const double* __restrict__ z, PcvRouted routed, const uint8_t* __restrict__ color,
     uint32_t color_stride, const float* __restrict__ intensity, uint32_t* __restrict__ rank, uint4* __restrict__ payload,
     uint32_t* __restrict__ inten_bits, const uint8_t* __restrict__ depth_grid,
-    float cells_per_unit /* 128 / root edge */, uint4* __restrict__ wide /* set: 12-byte records */) {
+    float cells_per_unit /* 128 / root edge */, uint4* __restrict__ wide /* set: 12-byte records */,
+    uint32_t* __restrict__ pool_counter) {
   constexpr int kWavesB = BLOCK / 64;
   __shared__ double sx[BIN ? BLOCK : 1], sy[BIN ? BLOCK : 1], sz[BIN ? BLOCK : 1];
   __shared__ uint16_t perm[BIN ? BLOCK : 1];
@@ -242,7 +298,7 @@ __global__ __launch_bounds__(BLOCK) void spec_encode_kernel(
     const double half_next = lv.digit_half[U + 1];                                                                      \
     if (live) {                                                                                                         \
       PCV_KEEP_STEP                                                                                                     \
-      const uint32_t d = (!GUARD && half >= 0.0) ? pcv_digit_from_codes(half, vx, vy, vz)                               \
+      const uint32_t d = (!GUARD && half >= 1.0) ? pcv_digit_from_codes(half, vx, vy, vz)                               \
                                                  : pcv_chain_digit(lv.edge[U], px, py, pz, mx, my, mz);                  \
       const uint32_t next = walk[(rec & PCV_SPEC_INDEX_MASK) + d];                                                      \
       const double ec = lv.edge[U + 1];                                                                                 \
@@ -258,7 +314,7 @@ __global__ __launch_bounds__(BLOCK) void spec_encode_kernel(
 /* one loop per encoding range (PcvLevels::first_u16 / first_u8): Float32 / Float64-coded levels through the per-level   \
    switch, then the u16-coded and the u8-coded levels as straight-line loops */                                         \
 #define PCV_SPEC_WALK(GUARD)                                                                                          \
-  /* >= 0: the next digit comes from this level's integer codes (fetched with the level's other constants) */          \
+  /* >= 1: the next digit comes from this level's integer codes (fetched with the level's other constants) */          \
   double half = lv.digit_half[U];                                                                                       \
   {                                                                                                                     \
     const int e0 = lv.first_u16 - 1 < lv.nlevels ? lv.first_u16 - 1 : lv.nlevels;                                       \
@@ -284,27 +340,179 @@ __global__ __launch_bounds__(BLOCK) void spec_encode_kernel(
     vx = kx, vy = ky, vz = kz;
     L = kl;
   }
-  const uint32_t leaf_enc = lv.enc[L];
-  const uint8_t* c = color + i * color_stride;
-  const uint32_t ccx = (uint32_t)pcv_val_to_code(leaf_enc, vx), ccy = (uint32_t)pcv_val_to_code(leaf_enc, vy),
-                 ccz = (uint32_t)pcv_val_to_code(leaf_enc, vz);
-  if (wide) {
-    // 12-byte record: key = rank << 8 | blue, payload = {cx | cy << 16, cz | red << 16 | green << 24}. The codes of a
-    // Float32-coded level do not fit: they go to the point's `wide` entry and the record carries the input index.
-    rank[i] = ((rec & PCV_SPEC_INDEX_MASK) << 8) | (uint32_t)c[2];
-    const uint32_t rg = ((uint32_t)c[0] << 16) | ((uint32_t)c[1] << 24);
-    if (leaf_enc <= PCV_ENC_UINT16) {
-      reinterpret_cast<uint2*>(payload)[i] = make_uint2(ccx | (ccy << 16), ccz | rg);
-    } else {
-      reinterpret_cast<uint2*>(payload)[i] = make_uint2((uint32_t)i, rg);
-      wide[i] = make_uint4(ccx, ccy, ccz, 0u);
-    }
-  } else {
-    rank[i] = rec & PCV_SPEC_INDEX_MASK;
-    payload[i] = make_uint4(ccx, ccy, ccz, (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16));
-  }
-  if (inten_bits) inten_bits[i] = __float_as_uint(intensity[i]);
+  pcv_spec_emit(i, n, rec, lv.enc[L], vx, vy, vz, color, color_stride, intensity, rank, payload, inten_bits, wide, pool_counter);
 }
+
+// ---- the chain pass, round 4 ------------------------------------------------------------------------------------------------
+// Same walk, same arithmetic, same records as spec_encode_kernel above; what changed is everything AROUND the level steps —
+// by round 3's counters 242 of the 654 VALU instructions per point were not chain arithmetic:
+//   * the deal by predicted depth takes ONE returning LDS atomic per point (its rank among the points of its depth class in
+//     the workgroup) instead of five ballots and a two-level prefix over per-wave counts; every wave scans the 32 class
+//     counters itself in registers (DPP), and the coordinates go straight to their dealt LDS slot: three barriers, no
+//     permutation array;
+//   * Float32-coded levels — 4 of the 6.5 levels a point of the bench cloud walks — test the dividend's range with one
+//     comparison instead of three (pcv_unit_quotient_t<TAME>) and take the next digit from their codes (v > 1/2, ties to
+//     the exact comparison; pcv_chain_dev.h) instead of three additions, a halving and a comparison per coordinate: 48 -> 36
+//     f64-pipe instructions per level; they have a loop of their own (no per-level switch);
+//   * the octant bits stay lane masks (PcvOctBits): `min += bit * edge` and the child index read the comparison results
+//     directly;
+//   * the copy of the first candidate's codes sits behind a wave-uniform branch (most level steps of most waves meet no
+//     candidate): two compares instead of two compares + four moves per level;
+//   * one 32-bit colour load; pool entries for the Float32 codes (pcv_spec_emit).
+__device__ __forceinline__ uint32_t pcv_wave_incl_scan32(uint32_t v) {  // inclusive prefix over lanes 0..31 (DPP rows 0 and 1)
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1 and 3
+  return v;
+}
+
+#ifndef PCV4_KEEP_BRANCH
+#define PCV4_KEEP_BRANCH 1
+#endif
+#if PCV4_KEEP_BRANCH
+#define PCV4_KEEP_STEP                                                                                                  \
+  if (KEEP) {                                                                                                           \
+    const bool take = (rec & PCV_SPEC_CANDIDATE) && kl == 0;                                                            \
+    if (__builtin_amdgcn_ballot_w64(take) != 0ull) {                                                                    \
+      asm volatile(""); /* keeps the copies inside the branch (the compiler would if-convert them into every level) */  \
+      if (take) {                                                                                                       \
+        kx = vx, ky = vy, kz = vz;                                                                                      \
+        kl = U; /* candidates have level >= 1 */                                                                        \
+      }                                                                                                                 \
+    }                                                                                                                   \
+  }
+#else
+#define PCV4_KEEP_STEP                                                                                                  \
+  if (KEEP && (rec & PCV_SPEC_CANDIDATE) && kl == 0) {                                                                  \
+    kx = vx, ky = vy, kz = vz;                                                                                          \
+    kl = U;                                                                                                             \
+  }
+#endif
+/* Levels U + 1 .. LEND of the lanes that have not reached a leaf (U: the wave's level counter, see spec_encode_kernel).
+   mode / half: how the digit of level U + 1 is taken from level U's codes (PcvLevels::digit_mode), scalar. */
+#define PCV4_LOOP(GUARD, LEND, APPLY)                                                                                   \
+  while (U < (LEND)) {                                                                                                  \
+    const bool live = !(rec & PCV_SPEC_LEAF);                                                                           \
+    if (!__any(live)) break;                                                                                            \
+    const double half_next = lv.digit_half[U + 1];                                                                      \
+    const uint32_t mode_next = lv.digit_mode[U + 1];                                                                    \
+    if (live) {                                                                                                         \
+      PCV4_KEEP_STEP                                                                                                    \
+      PcvOctBits b;                                                                                                     \
+      if (!GUARD && mode == 1u) {                                                                                       \
+        b = pcv_bits_from_codes(half, vx, vy, vz);                                                                      \
+      } else if (!GUARD && mode == 2u) {                                                                                \
+        b = pcv_bits_from_codes(0.5, vx, vy, vz);                                                                       \
+        if (__builtin_expect(__any(pcv_f32_code_tie(vx, vy, vz)), 0)) b = pcv_chain_bits(lv.edge[U], px, py, pz, mx, my, mz); \
+      } else {                                                                                                          \
+        b = pcv_chain_bits(lv.edge[U], px, py, pz, mx, my, mz);                                                         \
+      }                                                                                                                 \
+      const uint32_t next = walk[(rec & PCV_SPEC_INDEX_MASK) + b.digit()];                                              \
+      const double ec = lv.edge[U + 1];                                                                                 \
+      const PcvRecip ic{lv.inv_edge[U + 1], lv.inv_edge_lo[U + 1]};                                                     \
+      APPLY;                                                                                                            \
+      rec = next;                                                                                                       \
+      L = U + 1;                                                                                                        \
+    }                                                                                                                   \
+    half = half_next;                                                                                                   \
+    mode = mode_next;                                                                                                   \
+    ++U;                                                                                                                \
+  }
+/* one loop per encoding range: Float64-coded levels (and tables that are not monotone) through the per-level switch, then
+   the Float32-, the u16- and the u8-coded levels as straight-line loops */
+#define PCV4_WALK(GUARD)                                                                                                \
+  {                                                                                                                     \
+    double half = lv.digit_half[U];                                                                                     \
+    uint32_t mode = lv.digit_mode[U];                                                                                   \
+    const int e0 = lv.first_f32 - 1 < lv.nlevels ? lv.first_f32 - 1 : lv.nlevels;                                       \
+    const int e1 = lv.first_u16 - 1 < lv.nlevels ? lv.first_u16 - 1 : lv.nlevels;                                       \
+    const int e2 = lv.first_u8 - 1 < lv.nlevels ? lv.first_u8 - 1 : lv.nlevels;                                         \
+    PCV4_LOOP(GUARD, e0, pcv_chain_apply_bits<GUARD>(lv.enc[U + 1], b, ec, ic, px, py, pz, mx, my, mz, vx, vy, vz))     \
+    PCV4_LOOP(GUARD, e1, (pcv_chain_apply_bits_t<PCV_ENC_FLOAT32, GUARD>(b, ec, ic, px, py, pz, mx, my, mz, vx, vy, vz))) \
+    PCV4_LOOP(GUARD, e2, (pcv_chain_apply_bits_t<PCV_ENC_UINT16, GUARD>(b, ec, ic, px, py, pz, mx, my, mz, vx, vy, vz))) \
+    PCV4_LOOP(GUARD, lv.nlevels, (pcv_chain_apply_bits_t<PCV_ENC_UINT8, GUARD>(b, ec, ic, px, py, pz, mx, my, mz, vx, vy, vz))) \
+  }
+
+template <bool KEEP, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void spec_encode4_kernel(
+    PcvLevels lv, const uint32_t* __restrict__ walk, uint64_t n, const double* __restrict__ x, const double* __restrict__ y,
+    const double* __restrict__ z, PcvRouted routed, const uint8_t* __restrict__ color, uint32_t color_stride,
+    const float* __restrict__ intensity, uint32_t* __restrict__ rank, uint4* __restrict__ payload, uint32_t* __restrict__ inten_bits,
+    const uint8_t* __restrict__ depth_grid, float cells_per_unit /* 128 / root edge */, uint4* __restrict__ wide /* set: 12-byte records */,
+    uint32_t* __restrict__ pool_counter) {
+  __shared__ double sx[BLOCK], sy[BLOCK], sz[BLOCK];
+  __shared__ uint16_t sidx[BLOCK];
+  __shared__ uint32_t kcnt[32];  // points of the workgroup per depth class
+  const int tid = threadIdx.x, lane = tid & 63;
+  uint64_t i = (uint64_t)blockIdx.x * BLOCK + tid;
+  const bool raw = routed.oct == nullptr;  // grid-uniform
+  if (tid < 32) kcnt[tid] = 0;
+  const bool in = i < n;
+  double qx = 0.0, qy = 0.0, qz = 0.0;
+  if (in) {
+    if (raw) {
+      qx = x[i], qy = y[i], qz = z[i];
+    } else {  // routed input: the position the sending rank held after level 1 (decode of the level-1 codes)
+      double t0, t1, t2, t3, t4, t5;
+      uint32_t dd;
+      (void)pcv_chain_start(lv, routed, x, y, z, i, qx, qy, qz, t0, t1, t2, t3, t4, t5, dd);
+    }
+  }
+  __syncthreads();  // the counters are zero (the coordinate loads are in flight)
+  uint32_t key = kSpecClasses - 1;  // padding lanes go last
+  if (in) {
+    // cell of the 128^3 grid over the root cube (NaN -> 0, out of range clamps) -> predicted depth (1..8, 8 = deeper)
+    constexpr float kTop = (float)((1 << kGridBits) - 1);
+    const uint32_t ix = (uint32_t)fminf(fmaxf((float)(qx - lv.root_min[0]) * cells_per_unit, 0.f), kTop);
+    const uint32_t iy = (uint32_t)fminf(fmaxf((float)(qy - lv.root_min[1]) * cells_per_unit, 0.f), kTop);
+    const uint32_t iz = (uint32_t)fminf(fmaxf((float)(qz - lv.root_min[2]) * cells_per_unit, 0.f), kTop);
+    key = (uint32_t)(kSpecClasses - 2) - depth_grid[ix | (iy << kGridBits) | (iz << (2 * kGridBits))];  // deepest first
+  }
+  // rank of the point among the workgroup's points of its class (any order inside a class will do: the deal only decides
+  // which lane walks which point)
+  const uint32_t pos = __hip_atomic_fetch_add(&kcnt[key], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  __syncthreads();  // the counts are final
+  const uint32_t cnt = kcnt[lane & 31];
+  const uint32_t inc = pcv_wave_incl_scan32(lane < 32 ? cnt : 0u);
+  const uint32_t slot = (uint32_t)__shfl((int)(inc - cnt), (int)key, 64) + pos;  // classes ascending = deepest first
+  if (raw) sx[slot] = qx, sy[slot] = qy, sz[slot] = qz;
+  sidx[slot] = (uint16_t)tid;
+  __syncthreads();
+  const int j = sidx[tid];
+  i = (uint64_t)blockIdx.x * BLOCK + j;
+  if (i >= n) return;  // (no barrier below)
+  double px, py, pz, mx, my, mz;
+  double vx = 0, vy = 0, vz = 0;
+  double kx = 0, ky = 0, kz = 0;
+  int kl = 0;
+  uint32_t d1 = 0;
+  int L = 0;
+  uint32_t rec = walk[0];
+  if (raw) {
+    px = sx[tid], py = sy[tid], pz = sz[tid];
+    mx = lv.root_min[0], my = lv.root_min[1], mz = lv.root_min[2];
+  } else if (pcv_chain_start(lv, routed, x, y, z, i, px, py, pz, mx, my, mz, vx, vy, vz, d1) == 2 && !(rec & PCV_SPEC_LEAF)) {
+    L = 1;  // level 1 is given (digit + codes)
+    rec = walk[(rec & PCV_SPEC_INDEX_MASK) + d1];
+  }
+  int U = __builtin_amdgcn_readfirstlane(L);  // the wave's level counter (all lanes start at the same level: 0, or 1 for routed input)
+  if (lv.fast_ok && pcv_point_is_tame(px, py, pz)) {
+    PCV4_WALK(false)
+  } else {
+    PCV4_WALK(true)
+  }
+  // the record carries the codes of the first candidate on the path where there is one, else those of the predicted leaf
+  if (KEEP && kl) {
+    vx = kx, vy = ky, vz = kz;
+    L = kl;
+  }
+  pcv_spec_emit(i, n, rec, lv.enc[L], vx, vy, vz, color, color_stride, intensity, rank, payload, inten_bits, wide, pool_counter);
+}
+#undef PCV4_WALK
+#undef PCV4_LOOP
+#undef PCV4_KEEP_STEP
 
 #ifdef PCV_EXPERIMENTS
 // (libpcv_hip_exp.so only: measured slower than the kernel above — DESIGN.md §6, profiles/r03h_*)
@@ -322,7 +530,7 @@ __global__ __launch_bounds__(BLOCK, PREFETCH ? 6 : 8) void spec_encode_persist_k
     PcvLevels lv, const uint32_t* __restrict__ walk, uint64_t n, uint32_t num_tiles, const double* __restrict__ x,
     const double* __restrict__ y, const double* __restrict__ z, const uint8_t* __restrict__ color, uint32_t color_stride,
     const float* __restrict__ intensity, uint32_t* __restrict__ rank, uint4* __restrict__ payload, uint32_t* __restrict__ inten_bits,
-    const uint8_t* __restrict__ depth_grid, float cells_per_unit, uint4* __restrict__ wide) {
+    const uint8_t* __restrict__ depth_grid, float cells_per_unit, uint4* __restrict__ wide, uint32_t* __restrict__ pool_counter) {
   constexpr bool KEEP = true;
   constexpr int TILE = 2 * BLOCK, kWavesB = BLOCK / 64, kGroups = 2 * kWavesB;
   __shared__ double sx[TILE], sy[TILE], sz[TILE];
@@ -430,24 +638,7 @@ __global__ __launch_bounds__(BLOCK, PREFETCH ? 6 : 8) void spec_encode_persist_k
         vx = kx, vy = ky, vz = kz;
         L = kl;
       }
-      const uint32_t leaf_enc = lv.enc[L];
-      const uint8_t* c = color + i * color_stride;
-      const uint32_t ccx = (uint32_t)pcv_val_to_code(leaf_enc, vx), ccy = (uint32_t)pcv_val_to_code(leaf_enc, vy),
-                     ccz = (uint32_t)pcv_val_to_code(leaf_enc, vz);
-      if (wide) {
-        rank[i] = ((rec & PCV_SPEC_INDEX_MASK) << 8) | (uint32_t)c[2];
-        const uint32_t rg = ((uint32_t)c[0] << 16) | ((uint32_t)c[1] << 24);
-        if (leaf_enc <= PCV_ENC_UINT16) {
-          reinterpret_cast<uint2*>(payload)[i] = make_uint2(ccx | (ccy << 16), ccz | rg);
-        } else {
-          reinterpret_cast<uint2*>(payload)[i] = make_uint2((uint32_t)i, rg);
-          wide[i] = make_uint4(ccx, ccy, ccz, 0u);
-        }
-      } else {
-        rank[i] = rec & PCV_SPEC_INDEX_MASK;
-        payload[i] = make_uint4(ccx, ccy, ccz, (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16));
-      }
-      if (inten_bits) inten_bits[i] = __float_as_uint(intensity[i]);
+      pcv_spec_emit(i, n, rec, lv.enc[L], vx, vy, vz, color, color_stride, intensity, rank, payload, inten_bits, wide, pool_counter);
     }
   }
 }
@@ -566,7 +757,8 @@ __global__ __launch_bounds__(256) void spec_replay_kernel(PcvLevels lv, const Pc
                                                            uint32_t total, const double* __restrict__ x,
                                                            const double* __restrict__ y, const double* __restrict__ z,
                                                            PcvRouted routed, uint4* __restrict__ payload,
-                                                           uint4* __restrict__ wide /* set: 12-byte records */) {
+                                                           uint4* __restrict__ wide /* set: 12-byte records */,
+                                                           uint32_t wide_top /* the pool's last entry (n - 1) */) {
   for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < total; j += gridDim.x * 256) {
     uint32_t a = 0, b = num_ranges;  // last range with before <= j
     while (b - a > 1) {
@@ -603,8 +795,12 @@ __global__ __launch_bounds__(256) void spec_replay_kernel(PcvLevels lv, const Pc
       payload[s] = p;
     } else if (en <= PCV_ENC_UINT16) {
       reinterpret_cast<uint2*>(payload)[s] = make_uint2(p.x | (p.y << 16), (q.y & 0xffff0000u) | p.z);
-    } else {  // the record keeps the input index, the codes go where `settle` looks for those of a Float32-coded leaf
-      wide[i] = make_uint4(p.x, p.y, p.z, 0u);
+    } else {  // the codes go where `settle` looks for those of a Float32-coded leaf: a pool entry, named by the record. The
+              // chain pass hands entries out from the bottom of the pool; replayed points take them from the TOP (entry
+              // wide_top - j for the j-th replayed slot) — the host has checked that the two cannot meet (queue_replay)
+      const uint32_t e = wide_top - j;
+      wide[e] = make_uint4(p.x, p.y, p.z, 0u);
+      reinterpret_cast<uint2*>(payload)[s] = make_uint2(e, q.y);
     }
   }
 }
@@ -956,21 +1152,30 @@ template <bool BIN, int BLOCK>
 static void launch_spec_encode_t(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* walk, uint64_t n, const double* x,
                                  const double* y, const double* z, const PcvRouted& routed, const uint8_t* color,
                                  uint32_t color_stride, const float* intensity, uint32_t* rank, void* payload,
-                                 uint32_t* inten_bits, uint8_t* depth_grid, void* wide) {
+                                 uint32_t* inten_bits, uint8_t* depth_grid, void* wide, uint32_t* pool_counter, bool v4) {
   const dim3 grid((unsigned)((n + BLOCK - 1) / BLOCK));
   const float cells = lv.edge[0] > 0.0 ? (float)((double)(1 << kGridBits) / lv.edge[0]) : 0.f;
   if (BIN) hipLaunchKernelGGL(spec_depth_grid_kernel, dim3((1u << (3 * kGridBits)) / 256), dim3(256), 0, ctx->stream, walk, depth_grid);
-  hipLaunchKernelGGL((spec_encode_kernel<true, BIN, BLOCK>), grid, dim3(BLOCK), 0, ctx->stream, lv, walk, n, x, y, z, routed, color,
-                     color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide);
+  if (BIN && v4)
+    hipLaunchKernelGGL((spec_encode4_kernel<true, BLOCK>), grid, dim3(BLOCK), 0, ctx->stream, lv, walk, n, x, y, z, routed, color,
+                       color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_counter);
+  else
+    hipLaunchKernelGGL((spec_encode_kernel<true, BIN, BLOCK>), grid, dim3(BLOCK), 0, ctx->stream, lv, walk, n, x, y, z, routed, color,
+                       color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_counter);
 }
 
 void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* walk, uint64_t n, const double* x,
                             const double* y, const double* z, const PcvRouted& routed, const uint8_t* color,
                             uint32_t color_stride, const float* intensity, uint32_t* rank, void* payload,
                             uint32_t* inten_bits, uint8_t* depth_grid /* pcv_spec_depth_grid_bytes() of scratch, or null */,
-                            void* wide) {
+                            void* wide, uint32_t* pool_counter /* zero; counts the entries of `wide` handed out */) {
   if (n == 0) return;
   PcvProf prof(ctx, PCV_K_SPEC_ENCODE);
+  // PCV_CHAIN_V (experiments): 3 = round 3's kernel (ballot deal, packed digit), default 4
+  static const bool v4 = [] {
+    const char* e = pcv_experiment("PCV_CHAIN_V");
+    return !e || atoi(e) != 3;
+  }();
   // PCV_SPEC_BIN (experiments): 0 = input order, 256 / 512 / 1024 = depth binning inside workgroups of that size
   static const int bin_mode = [] {
     const char* e = pcv_experiment("PCV_SPEC_BIN");
@@ -996,27 +1201,27 @@ void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* w
     hipLaunchKernelGGL(spec_depth_grid_kernel, dim3((1u << (3 * kGridBits)) / 256), dim3(256), 0, ctx->stream, walk, depth_grid);
     if (persist >= 100) {  // one tile of 1 024 points per workgroup, no prefetch registers: just the paired deal
       hipLaunchKernelGGL((spec_encode_persist_kernel<512, false>), dim3(num_tiles), dim3(512), 0, ctx->stream, lv, walk, n, num_tiles, x, y, z,
-                         color, color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide);
+                         color, color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_counter);
     } else {
       const uint32_t groups = std::min<uint32_t>(num_tiles, (uint32_t)(cus * persist));
       hipLaunchKernelGGL((spec_encode_persist_kernel<512, true>), dim3(groups), dim3(512), 0, ctx->stream, lv, walk, n, num_tiles, x, y, z,
-                         color, color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide);
+                         color, color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_counter);
     }
     return;
   }
 #endif
   if (!bin)
     launch_spec_encode_t<false, 256>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, inten_bits,
-                                     depth_grid, wide);
+                                     depth_grid, wide, pool_counter, v4);
   else if (bin_mode == 256)
     launch_spec_encode_t<true, 256>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, inten_bits,
-                                     depth_grid, wide);
+                                     depth_grid, wide, pool_counter, v4);
   else if (bin_mode == 512)
     launch_spec_encode_t<true, 512>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, inten_bits,
-                                     depth_grid, wide);
+                                     depth_grid, wide, pool_counter, v4);
   else
     launch_spec_encode_t<true, 1024>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, inten_bits,
-                                     depth_grid, wide);
+                                     depth_grid, wide, pool_counter, v4);
 }
 
 size_t pcv_spec_depth_grid_bytes() { return (size_t)1 << (3 * kGridBits); }
@@ -1065,12 +1270,12 @@ void pcv_launch_spec_continue(pcv_ctx* ctx, const PcvLevels& lv, const void* ran
 
 void pcv_launch_spec_replay(pcv_ctx* ctx, const PcvLevels& lv, const void* ranges, uint32_t num_ranges, uint32_t total,
                             const double* x, const double* y, const double* z, const PcvRouted& routed, void* sorted_payload,
-                            void* wide) {
+                            void* wide, uint32_t wide_top) {
   if (total == 0 || num_ranges == 0) return;
   PcvProf prof(ctx, PCV_K_SPEC_REPLAY);
   const unsigned blocks = (unsigned)std::min<uint64_t>(((uint64_t)total + 255) / 256, 8192);
   hipLaunchKernelGGL(spec_replay_kernel, dim3(blocks), dim3(256), 0, ctx->stream, lv, (const PcvFixRange*)ranges, num_ranges, total,
-                     x, y, z, routed, (uint4*)sorted_payload, (uint4*)wide);
+                     x, y, z, routed, (uint4*)sorted_payload, (uint4*)wide, wide_top);
 }
 
 size_t pcv_climber_bytes(uint64_t num_climbers) { return (size_t)(num_climbers + 1) * sizeof(PcvClimber); }

@@ -35,10 +35,15 @@ struct PcvLevels {
   // Octant digit of level k + 1 straight from the integer codes of level k (pcv_chain_dev.h, pcv_digit_from_codes):
   // digit_half[k] = 127 / 32767 when level k is u8 / u16-coded and the rounding-error bound holds there, else -1
   double digit_half[PCV_MAX_LEVELS + 2];
+  // how the single chain pass gets the digit of level k + 1 (pcv_chain_dev.h): 0 = comparison against the cube centre,
+  // 1 = from the integer codes of level k (digit_half[k] = 127 / 32767), 2 = from the Float32 codes of level k
+  // (digit_half[k] = 0.5; a code of exactly 0.5 falls back to the comparison) — an integer so that the test is scalar
+  uint32_t digit_mode[PCV_MAX_LEVELS + 2];
   // Encodings narrow with depth (the edge halves per level): levels [first_u16, first_u8) are u16-coded, levels from
   // first_u8 on u8-coded; both are "never" (a huge level) when the table is not monotone. The single chain pass runs one
   // straight-line loop per range instead of a switch per level.
   int32_t first_u16, first_u8;
+  int32_t first_f32;  // levels [first_f32, first_u16) are Float32-coded ("never" when the table is not monotone)
   int32_t nlevels;  // number of digit levels materialised in the keys (<= PCV_MAX_KEY_LEVELS; <= PCV_MAX_LEVELS deep)
   int32_t fast_ok;  // root min and all edges are tame: unguarded exact division is valid for tame points
 };
@@ -369,12 +374,13 @@ void pcv_launch_leaf_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvWalkTabl
 // rank / payload fix-up once the true tree is known.
 // 12-byte records (`wide` set, u32 + uint2 per point instead of u32 + uint4): key = rank << 8 | blue, payload =
 // {code x | code y << 16, code z | red << 16 | green << 24} for u8 / u16-coded leaf levels; a point whose leaf level is
-// Float32-coded keeps its INPUT INDEX in the first payload word and its three 32-bit codes in wide[index] (uint4[n],
-// touched only by those points) — 24 instead of 40 bytes per point and pass through the record sort.
+// Float32-coded names an entry of the `wide` POOL in the first payload word and keeps its three 32-bit codes there (uint4[n];
+// entries are handed out densely from 0 by the chain pass — one reservation per wave on *pool_counter — and from n - 1
+// downwards by the rare replay) — 24 instead of 40 bytes per point and pass through the record sort.
 void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* walk, uint64_t n, const double* x,
                             const double* y, const double* z, const PcvRouted& routed, const uint8_t* color,
                             uint32_t color_stride, const float* intensity, uint32_t* rank, void* payload /* uint4[n] */,
-                            uint32_t* inten_bits, uint8_t* depth_grid, void* wide = nullptr);
+                            uint32_t* inten_bits, uint8_t* depth_grid, void* wide, uint32_t* pool_counter);
 size_t pcv_spec_depth_grid_bytes();  // scratch for the depth-prediction grid of the binned pass
 void pcv_launch_rank_hist(pcv_ctx* ctx, const uint32_t* rank, uint64_t n, uint32_t num_bins, uint32_t* counts /* zeroed */,
                           int shift = 0);
@@ -393,7 +399,7 @@ void pcv_launch_spec_continue(pcv_ctx* ctx, const PcvLevels& lv, const void* ran
 // ranges: device array of {first sorted slot, flagged slots before it, level, pad} (4 x u32), after the record sort
 void pcv_launch_spec_replay(pcv_ctx* ctx, const PcvLevels& lv, const void* ranges, uint32_t num_ranges, uint32_t total,
                             const double* x, const double* y, const double* z, const PcvRouted& routed, void* sorted_payload,
-                            void* wide = nullptr);
+                            void* wide = nullptr, uint32_t wide_top = 0);
 
 // Everything K6 needs about a node in one 80-byte record, so a slot's dependent loads are rank -> record (-> the
 // parent's record per climb) instead of chained table lookups (node, level, per-level edge/encoding, offsets).
@@ -452,6 +458,7 @@ struct pcv_octree {
   int record_bytes = 0;  // bytes per record in the record sort (20, or 12 packed)
   uint64_t spec_stats[4] = {};  // single-chain build: nodes / leaves of the predicted tree, points in an unsplit first
                                 // candidate (their kept codes are their leaf codes), points that replayed the chain
+  uint64_t wide_pool_entries = 0;  // single-chain build, 12-byte records: entries of the Float32-code pool the chain pass used
   uint64_t spec_continued = 0;  // points whose chain was continued from the codes of a split candidate
   PcvOctreeQuery* query = nullptr;
   // octrees opened from a directory: node files are read on demand

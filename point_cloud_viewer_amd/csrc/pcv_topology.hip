@@ -251,6 +251,7 @@ __global__ __launch_bounds__(1024) void spec_tree_scan_kernel(PcvNodeTableDev t,
     info[1] = t.counters[CNT_ERROR];
     info[2] = count;
     info[3] = 0;
+    info[8] = 0;  // the chain pass's pool counter (entries of `wide` handed out, pcv_encode.hip pcv_spec_emit): zero before every pass
   }
 }
 

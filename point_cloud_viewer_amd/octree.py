@@ -180,13 +180,16 @@ class Context:
 
     # ---- the build -------------------------------------------------------------------------------
     def build(self, resolution, bounding_box, x, y, z, color, intensity=None, max_points_per_node=0,
-              speculate_depth=True, single_chain=None):
+              speculate_depth=True, single_chain=None, check_resolve=False):
         """build_octree up to (not including) the file writes. bounding_box=None computes it on the
         device (== build_octree_from_file's find_bounding_box pass). single_chain: None = the library decides (from
         2^22 points on), True = force the single-chain build, False = exact two-chain pipeline; speculate_depth=False
-        additionally computes and sorts full-depth keys. The result is identical in every mode."""
+        additionally computes and sorts full-depth keys. The result is identical in every mode. check_resolve: the
+        single-chain build compares the device's rank map with the host's entry by entry (PCV_BUILD_CHECK_RESOLVE)."""
         p, keep = self._points(x, y, z, color, intensity)
         flags = 0 if speculate_depth else L.BUILD_NO_SPECULATION
+        if check_resolve:
+            flags |= L.BUILD_CHECK_RESOLVE
         if single_chain is True:
             flags |= L.BUILD_FORCE_SINGLE_CHAIN
         elif single_chain is False:
@@ -552,7 +555,8 @@ class OctreeResult:
         self.lib.pcv_octree_spec_stats(self.handle, st)
         return dict(key_levels=lv.value, attempts=at.value, single_chain=at.value == 0,
                     record_bytes=int(self.lib.pcv_octree_record_bytes(self.handle)), predicted_nodes=st[0], predicted_leaves=st[1], kept_code_points=st[2], replayed_points=st[3],
-                    continued_points=int(self.lib.pcv_octree_spec_continued(self.handle)))
+                    continued_points=int(self.lib.pcv_octree_spec_continued(self.handle)),
+                    wide_pool_entries=int(self.lib.pcv_octree_wide_pool_entries(self.handle)))
 
     def write_dir(self, directory):
         self.ctx._check(self.lib.pcv_octree_write_dir(self.handle, str(directory).encode()))

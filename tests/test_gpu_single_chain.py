@@ -44,7 +44,7 @@ def test_forced_single_chain_equals_oracle(ctx, n, cap, res, clusters, extent, s
     inten = (np.arange(n) % 509).astype(np.float32) * 0.5 if with_int else None
     with O.max_points_per_node(cap):
         want = O.build_closed(res, bmin, bmax, x, y, z, rgb, inten, threads=8)
-    t = ctx.build(res, pcv.Aabb(bmin, bmax), x, y, z, rgb, inten, max_points_per_node=cap, single_chain=True)
+    t = ctx.build(res, pcv.Aabb(bmin, bmax), x, y, z, rgb, inten, max_points_per_node=cap, single_chain=True, check_resolve=True)
     info = t.build_info()
     assert_same(t.to_dict(), want, check_intensity=with_int)
     assert info["attempts"] in (0, 2, 3), info  # held, or redone by the exact pipeline (with or without its own retry)
@@ -88,7 +88,7 @@ def test_oversampled_clusters_replay_the_chain_from_their_coordinates(ctx):
     bmin, bmax = np.array([0.0, 0.0, 0.0]), np.array([200.0, 200.0, 200.0])
     with O.max_points_per_node(cap):
         want = O.build_closed(0.001, bmin, bmax, x, y, z, rgb, threads=8)
-    t = ctx.build(0.001, pcv.Aabb(bmin, bmax), x, y, z, rgb, max_points_per_node=cap, single_chain=True)
+    t = ctx.build(0.001, pcv.Aabb(bmin, bmax), x, y, z, rgb, max_points_per_node=cap, single_chain=True, check_resolve=True)
     info = t.build_info()
     assert_same(t.to_dict(), want)
     assert info["single_chain"] and info["replayed_points"] >= 6 * k, info
@@ -106,13 +106,13 @@ def test_many_small_leaves_take_8_bit_digits_and_the_global_rank_map(ctx):
         want = O.build_closed(0.001, bmin, bmax, x, y, z, rgb, threads=8)
     leaves = len(want.nodes) - len({k[:-1] for k in want.nodes if len(k) > 1})  # nodes that are nobody's parent
     assert 16_384 < leaves <= 65_536, leaves  # 15 or 16 rank bits -> two passes of 8
-    t = ctx.build(0.001, pcv.Aabb(bmin, bmax), x, y, z, rgb, max_points_per_node=cap, single_chain=True)
+    t = ctx.build(0.001, pcv.Aabb(bmin, bmax), x, y, z, rgb, max_points_per_node=cap, single_chain=True, check_resolve=True)
     info = t.build_info()
     assert_same(t.to_dict(), want)
     assert info["single_chain"] and info["record_bytes"] == 12 and info["predicted_nodes"] > 15_360, info
     t.free()
     t = ctx.build(0.001, pcv.Aabb(bmin, bmax), x[:1_200_000], y[:1_200_000], z[:1_200_000], rgb[:1_200_000], max_points_per_node=90,
-                  single_chain=True)
+                  single_chain=True, check_resolve=True)
     with O.max_points_per_node(90):
         want = O.build_closed(0.001, bmin, bmax, x[:1_200_000], y[:1_200_000], z[:1_200_000], rgb[:1_200_000], threads=8)
     assert_same(t.to_dict(), want)
@@ -159,7 +159,7 @@ def test_duplicates_and_resolution_limited_nodes(ctx):
     bmin, bmax = np.array([-30.0, -30, -3]), np.array([30.0, 30, 3])
     with O.max_points_per_node(10_000):
         want = O.build_closed(0.01, bmin, bmax, x, y, z, rgb, threads=8)
-    t = ctx.build(0.01, pcv.Aabb(bmin, bmax), x, y, z, rgb, max_points_per_node=10_000, single_chain=True)
+    t = ctx.build(0.01, pcv.Aabb(bmin, bmax), x, y, z, rgb, max_points_per_node=10_000, single_chain=True, check_resolve=True)
     assert_same(t.to_dict(), want)
 
 
@@ -206,7 +206,7 @@ def test_back_to_back_builds_are_identical_and_survive_interleaved_queries(ctx):
         k = it % 2
         x, y, z, rgb, bmin, bmax = clouds[k]
         t = ctx.build(0.001, None if it % 3 == 0 else pcv.Aabb(bmin, bmax), x, y, z, rgb, max_points_per_node=25_000,
-                      single_chain=True)
+                      single_chain=True, check_resolve=True)
         d = digest(t)
         assert first.setdefault(k, d) == d, it
         alive.append((t, bmin, bmax))
@@ -236,7 +236,7 @@ for n, cap, res, clusters, extent, sigma, with_int, seed in ((600_000, 20_000, 0
     inten = (np.arange(n) % 509).astype(np.float32) * 0.5 if with_int else None
     with O.max_points_per_node(cap):
         want = O.build_closed(res, bmin, bmax, x, y, z, rgb, inten, threads=8)
-    t = ctx.build(res, pcv.Aabb(bmin, bmax), x, y, z, rgb, inten, max_points_per_node=cap, single_chain=True)
+    t = ctx.build(res, pcv.Aabb(bmin, bmax), x, y, z, rgb, inten, max_points_per_node=cap, single_chain=True, check_resolve=True)
     info = t.build_info()
     assert info["single_chain"] and info["record_bytes"] == want_bytes, info
     assert_same(t.to_dict(), want, check_intensity=with_int)

@@ -168,3 +168,38 @@ def test_octant_digit_from_integer_codes_at_the_admitted_ratio():
                 q = c / M  # IEEE division == pcv_div_code (test_exact_code_division above)
                 p = float(Fraction(mn) + Fraction(q) * Fraction(e))  # one rounding: the FMA
                 assert (p > centre) == (c > half), (M, c, mn, e, p, centre)
+
+
+def test_octant_digit_from_float32_codes_at_the_admitted_ratio():
+    """csrc/pcv_chain_dev.h pcv_bits_from_codes / pcv_f32_code_tie (round 4): for a Float32-coded level the next octant
+    digit (node.rs:34-42, strict > against aabb.rs:175-192's centre) of the decoded position fma((double)(float)t, e, mn)
+    (codec.rs:115-121, 131-135) equals v > 0.5 for every code v != 0.5 wherever pcv_make_levels admits the shortcut:
+    (2.5 A / e + 3) * 4.04 * 2^24 < 2^53 (PcvLevels::digit_mode == 2). A code of exactly 0.5 is a tie of the exact values —
+    there the rounded comparison decides, which is why the kernel falls back to it; the test shows that both outcomes
+    occur. Replayed in exact rational arithmetic for the floats next to 0.5 and random ones, |mn| / e at the admitted bound."""
+    from fractions import Fraction
+    import math
+    import random
+    import numpy as np
+    rnd = random.Random(11)
+    limit = (2.0 ** 53 / (4.04 * 2.0 ** 24) - 3.0) / 2.5  # largest admitted A / e
+    below, above = float(np.nextafter(np.float32(0.5), np.float32(0.0))), float(np.nextafter(np.float32(0.5), np.float32(1.0)))
+    assert below == 0.5 - 2.0 ** -25 and above == 0.5 + 2.0 ** -24
+    tie_outcomes = set()
+    for trial in range(6000):
+        e = math.ldexp(rnd.uniform(1.0, 2.0), rnd.randint(-10, 14))
+        ratio = limit * (1.0 - 1e-9) if trial % 2 == 0 else rnd.uniform(0.0, limit)
+        mag = max(0.0, ratio * e - e) * (1.0 if trial % 4 < 2 else rnd.uniform(0.0, 1.0))
+        mn = math.copysign(mag, rnd.choice((-1.0, 1.0)))
+        if mn < 0:
+            mn = -(mag + e) if mag + e <= ratio * e else mn  # keep |mn + e| inside A as well
+        centre = (mn + (mn + e)) / 2.0
+        codes = [below, above, 0.0, 1.0, float(np.float32(rnd.random())), float(np.float32(rnd.uniform(0.49999, 0.50001)))]
+        for v in codes:
+            p = float(Fraction(mn) + Fraction(v) * Fraction(e))  # one rounding: the FMA of the decode
+            if v == 0.5:
+                continue
+            assert (p > centre) == (v > 0.5), (v, mn, e, p, centre)
+        p = float(Fraction(mn) + Fraction(0.5) * Fraction(e))
+        tie_outcomes.add(p > centre)
+    assert tie_outcomes == {False, True} or tie_outcomes == {False}, tie_outcomes  # the tie is decided by rounding, not by the code
