@@ -1,0 +1,29 @@
+#!/bin/bash
+# Round-4 GPU-box recipe, ONE gpurun call: stages picked by name, in the order given.
+#   usage: gpurun -- 'bash tools/r04_run.sh TAG stage [stage ...]'
+#   tests     pytest -m gpu                               probes    tools/f64_rate.sh + scatter_probe runs
+#   bench     the default line (config 2 + legs 4 / 5)     quick     the default line without the legs (--no-legs)
+#   ab        timing-only A/B runs, RUNS="name[:ENV=VAL|libtag] ..." (tools/ab_quick.sh)
+#   profile   rocprofv3 passes of the build (tools/profile_bench.sh) -> profiles-ready JSON / CSV in gpurun_out/
+#   qprofile  rocprofv3 passes of bench.py --query (tools/profile_query.sh)
+#   smoke     __graft_entry__.smoke()
+TAG=${1:-r04}; shift
+mkdir -p gpurun_out
+for stage in "$@"; do
+  t0=$(date +%s)
+  case $stage in
+    tests) timeout 900 python -m pytest tests -m gpu -q --tb=line > gpurun_out/${TAG}_gputest.log 2>&1; echo "pytest rc=$?"; tail -25 gpurun_out/${TAG}_gputest.log;;
+    smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${TAG}_smoke.log 2>&1; echo "smoke rc=$?"; tail -2 gpurun_out/${TAG}_smoke.log;;
+    probes) bash tools/f64_rate.sh ${TAG} > gpurun_out/${TAG}_f64_rate.log 2>&1; echo "f64_rate rc=$?"; tail -25 gpurun_out/${TAG}_f64_rate.log
+            timeout 300 tools/scatter_probe.bin runs 100000000 > gpurun_out/${TAG}_scatter_runs.jsonl 2> gpurun_out/${TAG}_scatter_runs.err; echo "scatter rc=$?"; cat gpurun_out/${TAG}_scatter_runs.jsonl;;
+    bench) timeout 900 python bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err; echo "bench rc=$?"; tail -3 gpurun_out/${TAG}_bench_default.err
+           python tools/bench_brief.py gpurun_out/${TAG}_bench_default.json;;
+    quick) timeout 600 python bench.py --no-legs > gpurun_out/${TAG}_bench_quick.json 2> gpurun_out/${TAG}_bench_quick.err; echo "quick rc=$?"; tail -3 gpurun_out/${TAG}_bench_quick.err
+           python tools/bench_brief.py gpurun_out/${TAG}_bench_quick.json;;
+    ab) TAG=${TAG}_ab bash tools/ab_quick.sh;;
+    profile) bash tools/profile_bench.sh ${TAG}_prof > gpurun_out/${TAG}_prof.log 2>&1; echo "profile rc=$?"; tail -5 gpurun_out/${TAG}_prof.log;;
+    qprofile) bash tools/profile_query.sh ${TAG} > gpurun_out/${TAG}_qprof.log 2>&1; echo "qprofile rc=$?"; tail -12 gpurun_out/${TAG}_qprof.log;;
+    *) echo "unknown stage $stage";;
+  esac
+  echo "== $stage took $(( $(date +%s) - t0 )) s"
+done
