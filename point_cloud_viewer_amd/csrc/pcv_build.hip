@@ -984,7 +984,7 @@ static int queue_replay(pcv_ctx* ctx, PcvBuild* bs) {
   }
   PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_ranges, h_ranges, (size_t)nr * 16, hipMemcpyHostToDevice, st));
   pcv_launch_spec_replay(ctx, bs->lv, d_ranges, nr, before, d.x, d.y, d.z, d.routed, (void*)s_pay, bs->spec_wide,
-                         (uint32_t)(bs->n - 1));
+                         (uint32_t)pcv_pool_region_entries(bs->n));
   return PCV_OK;
 }
 
@@ -1024,10 +1024,11 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
   // host round trip, and the host mirrors the tree (one small asynchronous copy) while that pass runs.
   constexpr uint32_t kFirst = 16384;  // T'' nodes mirrored by the first copy (a 100 M-point tree has ~7 500)
   const size_t tcap = 1 + 8 * (size_t)nt.capacity;  // T'' nodes at most
-  uint32_t *d_ord, *d_walk, *d_sparent, *d_info, *d_counts, *d_map;
+  uint32_t *d_ord, *d_walk, *d_sparent, *d_info, *d_counts, *d_map, *d_pool_ctr;
   uint8_t* d_slevel;
   if ((rc = sc.get(&d_ord, nt.capacity)) || (rc = sc.get(&d_walk, tcap)) || (rc = sc.get(&d_sparent, tcap)) ||
-      (rc = sc.get(&d_slevel, tcap)) || (rc = sc.get(&d_info, 64)) || (rc = sc.get(&d_counts, tcap)) || (rc = sc.get(&d_map, tcap)))
+      (rc = sc.get(&d_slevel, tcap)) || (rc = sc.get(&d_info, 64)) || (rc = sc.get(&d_counts, tcap)) || (rc = sc.get(&d_map, tcap)) ||
+      (rc = sc.get(&d_pool_ctr, kPcvPoolRegions)))
     return rc;
   uint32_t* rank = (uint32_t*)bs->keys_a;
   uint4* payload;
@@ -1037,14 +1038,16 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
     const char* e = pcv_experiment("PCV_COMPACT_RECORDS");
     return !e || atoi(e) != 0;
   }();
-  const bool compact = compact_on && tcap <= (1u << 24);
+  // ... or the pool of Float32 codes (kPcvPoolRegions regions, pcv_internal.h) could outgrow 32-bit entry numbers
+  const uint64_t pool_cap = pcv_pool_region_entries(n), pool_entries = pool_cap * kPcvPoolRegions;
+  const bool compact = compact_on && tcap <= (1u << 24) && pool_entries <= 0xffffffffull;
   uint4* wide = nullptr;
   uint64_t wide_levels = 0;
   for (int k = 0; k <= full_levels && k < 64; ++k)
     if (lv.enc[k] > PCV_ENC_UINT16) wide_levels |= 1ull << k;
   if (compact) {
     uint2* p2;
-    if ((rc = sc.get(&p2, n)) || (rc = sc.get(&wide, n))) return rc;
+    if ((rc = sc.get(&p2, n)) || (rc = sc.get(&wide, pool_entries))) return rc;
     payload = (uint4*)p2;
   } else if ((rc = sc.get(&payload, n))) {
     return rc;
@@ -1098,7 +1101,7 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
     pcv_launch_node_split(ctx, nt, in_a ? skeys_a : skeys_b, false, (uint32_t)ns, lv, params->resolution,
                           pcv_spec_sample_threshold(sp), sp.force_mask);
     host_lap("sample split queued");
-    pcv_launch_spec_tree(ctx, nt, upper, sp.force_mask, d_ord, d_walk, d_sparent, d_slevel, d_info);
+    pcv_launch_spec_tree(ctx, nt, upper, sp.force_mask, d_ord, d_walk, d_sparent, d_slevel, d_info, d_pool_ctr);
     host_lap("spec tree queued");
     uint8_t* hs = (uint8_t*)ctx->pinned_spec;
     const size_t first = tcap < kFirst ? tcap : kFirst;
@@ -1113,7 +1116,7 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
     ctx->stage_begin(PCV_STAGE_LEAF_ENCODE);
     lv.nlevels = full_levels;
     pcv_launch_spec_encode(ctx, lv, d_walk, n, d.x, d.y, d.z, d.routed, d.color, d.color_stride, d.intensity, rank, payload,
-                           inten_bits, depth_grid, wide, d_info + 8 /* pool counter: zeroed by the spec_tree kernels */);
+                           inten_bits, depth_grid, wide, d_pool_ctr /* zeroed by the spec_tree kernels */);
     ctx->stage_end(PCV_STAGE_LEAF_ENCODE);
     host_lap("chain pass queued");
 
@@ -1183,14 +1186,14 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
     pcv_launch_rank_hist(ctx, rank, n, tree.num_leaves, d_counts, compact ? 8 : 0);
   }
   PCV_HIP_CHECK(ctx, hipGetLastError());
-  if ((rc = ctx->pinned_spec_reserve((size_t)tree.num_leaves * 8 + 512))) return rc;
+  if ((rc = ctx->pinned_spec_reserve((size_t)tree.num_leaves * 8 + 512 + kPcvPoolRegions * 4))) return rc;
   uint8_t* hp = (uint8_t*)ctx->pinned_spec;
   uint32_t* h_counts = (uint32_t*)hp;
   const size_t map_off = ((size_t)tree.num_leaves * 4 + 255) & ~(size_t)255;
   PCV_HIP_CHECK(ctx, hipMemcpyAsync(h_counts, d_counts, (size_t)tree.num_leaves * 4, hipMemcpyDeviceToHost, st));
-  // ... and with them the number of `wide` pool entries the chain pass handed out (pcv_spec_emit)
+  // ... and with them the number of `wide` pool entries the chain pass handed out per region (pcv_spec_emit)
   uint32_t* h_pool = (uint32_t*)(hp + (((size_t)tree.num_leaves * 8 + 256 + 63) & ~(size_t)63));
-  PCV_HIP_CHECK(ctx, hipMemcpyAsync(h_pool, d_info + 8, 4, hipMemcpyDeviceToHost, st));
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(h_pool, d_pool_ctr, kPcvPoolRegions * 4, hipMemcpyDeviceToHost, st));
   PCV_HIP_CHECK(ctx, hipEventRecord(ctx->spec_ev, st));  // the counts are on their way to the host
   // The map the record sort needs is computed on the device (spec_resolve_kernel), and the sort is queued behind it right
   // away: the counts' trip to the host, the host's own resolve and the table building all happen beside the sort instead
@@ -1258,18 +1261,22 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
     give_up();
     return PCV_OK;  // *used stays false
   }
-  // the rare replay takes its pool entries from the top of `wide` (spec_replay_kernel): they must not reach down to the
-  // entries the chain pass handed out from the bottom. A point has at most one live entry, but a replayed point may have used
-  // one in the chain pass already — on an adversarial cloud the two can add up to more than n: the exact pipeline takes it
+  // the rare replay takes its pool entries from the TOPS of the pool regions (spec_replay_kernel: slot j of the flattened
+  // replay list -> region j % regions): they must not reach down to what the chain pass filled from the bottoms. A point
+  // has at most one live entry, but a replayed point may have used one in the chain pass already — on an adversarial
+  // cloud a region can run out: the exact pipeline takes the build
   if (wide) {
-    uint64_t replay_wide = 0;
-    for (uint32_t k : tt->fix_nodes)
-      if ((wide_levels >> tt->level[k]) & 1ull) replay_wide += tt->hi[k] - tt->lo[k];
-    if ((uint64_t)*h_pool + replay_wide > n) {
+    uint64_t replay_slots = 0, used = 0, most = 0;
+    for (uint32_t k : tt->fix_nodes) replay_slots += tt->hi[k] - tt->lo[k];
+    for (uint32_t r = 0; r < kPcvPoolRegions; ++r) {
+      used += h_pool[r];
+      most = std::max<uint64_t>(most, h_pool[r]);
+    }
+    if (most + (replay_slots + kPcvPoolRegions - 1) / kPcvPoolRegions > pool_cap) {
       give_up();
       return PCV_OK;
     }
-    t->wide_pool_entries = *h_pool;
+    t->wide_pool_entries = used;
   }
   bs->resolve_host_leaves = tt->num_leaves;
   bs->resolve_check_map = (params->flags & PCV_BUILD_CHECK_RESOLVE) != 0;

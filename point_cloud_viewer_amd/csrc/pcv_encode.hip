@@ -86,8 +86,9 @@ __global__ __launch_bounds__(256) void leaf_encode_kernel(
 // 12-byte record: key = predicted leaf << 8 | blue, payload = {cx | cy << 16, cz | red << 16 | green << 24}. The codes of a
 // Float32-coded level do not fit 16 bits: they go to an entry of the dense `wide` POOL and the record names that entry.
 // Pool entries are handed out per WAVE (round 4): the lanes whose record level is Float32-coded are counted with one
-// ballot, the wave's first such lane reserves that many consecutive entries with ONE returning atomic on the pool counter,
-// and lane k of them takes entry base + k. Waves without such a lane (most of them: the deal below groups points by depth,
+// ballot, the wave's first such lane reserves that many consecutive entries with ONE returning atomic on the counter of the
+// pool region its input slice belongs to (pcv_internal.h: kPcvPoolRegions regions — one counter for everything serialises
+// the whole pass), and lane k of them takes entry base + k. Waves without such a lane (most of them: the deal below groups points by depth,
 // and only the shallow levels are Float32-coded) pay a ballot and a scalar branch. A leaf's records meet `settle` in input
 // order, i.e. in runs of entries that one wave wrote side by side: the 4.7 M entries of the bench cloud are 75 MB
 // (Infinity-Cache resident) read in runs, where round 3 gathered one 16-byte entry per HBM line out of a 1.6 GB array indexed
@@ -106,7 +107,7 @@ __device__ __forceinline__ void pcv_spec_emit(uint64_t i, uint64_t n, uint32_t r
                                               const uint8_t* __restrict__ color, uint32_t color_stride,
                                               const float* __restrict__ intensity, uint32_t* __restrict__ rank,
                                               uint4* __restrict__ payload, uint32_t* __restrict__ inten_bits,
-                                              uint4* __restrict__ wide, uint32_t* __restrict__ pool_counter) {
+                                              uint4* __restrict__ wide, uint32_t* __restrict__ pool_ctr, uint32_t pool_cap) {
   const uint32_t rgb = pcv_load_rgb(color + i * color_stride, i + 1 < n);
   const bool is_wide = leaf_enc > PCV_ENC_UINT16;
   // value domain -> raw code: the integer itself (u8 / u16), the IEEE bits of the float (Float32); single-chain builds have
@@ -119,10 +120,13 @@ __device__ __forceinline__ void pcv_spec_emit(uint64_t i, uint64_t n, uint32_t r
     uint2 out = make_uint2(ccx | (ccy << 16), ccz | rg);
     const uint64_t wm = __ballot(is_wide);
     if (wm != 0ull) {  // wave-uniform
+      // every lane of a wave holds points of ONE slice of 1 024 input points (the deal stays inside the workgroup's points,
+      // and workgroups of 256 / 512 / 1 024 points start on multiples of their size)
+      const uint32_t region = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(i >> 10)) & (kPcvPoolRegions - 1u);
       uint32_t base = 0;
       if (is_wide && (wm & ((1ull << (threadIdx.x & 63)) - 1ull)) == 0ull)
-        base = __hip_atomic_fetch_add(pool_counter, (uint32_t)__popcll(wm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)__builtin_ctzll(wm));
+        base = __hip_atomic_fetch_add(pool_ctr + region, (uint32_t)__popcll(wm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      base = region * pool_cap + (uint32_t)__builtin_amdgcn_readlane((int)base, (int)__builtin_ctzll(wm));
       if (is_wide) {
         const uint32_t e = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(wm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wm, 0u));
         wide[e] = make_uint4(ccx, ccy, ccz, 0u);
@@ -179,7 +183,7 @@ __global__ __launch_bounds__(BLOCK) void spec_encode_kernel(
     uint32_t color_stride, const float* __restrict__ intensity, uint32_t* __restrict__ rank, uint4* __restrict__ payload,
     uint32_t* __restrict__ inten_bits, const uint8_t* __restrict__ depth_grid,
     float cells_per_unit /* 128 / root edge */, uint4* __restrict__ wide /* set: 12-byte records */,
-    uint32_t* __restrict__ pool_counter) {
+    uint32_t* __restrict__ pool_ctr, uint32_t pool_cap) {
   constexpr int kWavesB = BLOCK / 64;
   __shared__ double sx[BIN ? BLOCK : 1], sy[BIN ? BLOCK : 1], sz[BIN ? BLOCK : 1];
   __shared__ uint16_t perm[BIN ? BLOCK : 1];
@@ -340,7 +344,7 @@ __global__ __launch_bounds__(BLOCK) void spec_encode_kernel(
     vx = kx, vy = ky, vz = kz;
     L = kl;
   }
-  pcv_spec_emit(i, n, rec, lv.enc[L], vx, vy, vz, color, color_stride, intensity, rank, payload, inten_bits, wide, pool_counter);
+  pcv_spec_emit(i, n, rec, lv.enc[L], vx, vy, vz, color, color_stride, intensity, rank, payload, inten_bits, wide, pool_ctr, pool_cap);
 }
 
 // ---- the chain pass, round 4 ------------------------------------------------------------------------------------------------
@@ -441,7 +445,7 @@ __global__ __launch_bounds__(BLOCK) void spec_encode4_kernel(
     const double* __restrict__ z, PcvRouted routed, const uint8_t* __restrict__ color, uint32_t color_stride,
     const float* __restrict__ intensity, uint32_t* __restrict__ rank, uint4* __restrict__ payload, uint32_t* __restrict__ inten_bits,
     const uint8_t* __restrict__ depth_grid, float cells_per_unit /* 128 / root edge */, uint4* __restrict__ wide /* set: 12-byte records */,
-    uint32_t* __restrict__ pool_counter) {
+    uint32_t* __restrict__ pool_ctr, uint32_t pool_cap) {
   __shared__ double sx[BLOCK], sy[BLOCK], sz[BLOCK];
   __shared__ uint16_t sidx[BLOCK];
   __shared__ uint32_t kcnt[32];  // points of the workgroup per depth class
@@ -508,7 +512,7 @@ __global__ __launch_bounds__(BLOCK) void spec_encode4_kernel(
     vx = kx, vy = ky, vz = kz;
     L = kl;
   }
-  pcv_spec_emit(i, n, rec, lv.enc[L], vx, vy, vz, color, color_stride, intensity, rank, payload, inten_bits, wide, pool_counter);
+  pcv_spec_emit(i, n, rec, lv.enc[L], vx, vy, vz, color, color_stride, intensity, rank, payload, inten_bits, wide, pool_ctr, pool_cap);
 }
 #undef PCV4_WALK
 #undef PCV4_LOOP
@@ -530,7 +534,7 @@ __global__ __launch_bounds__(BLOCK, PREFETCH ? 6 : 8) void spec_encode_persist_k
     PcvLevels lv, const uint32_t* __restrict__ walk, uint64_t n, uint32_t num_tiles, const double* __restrict__ x,
     const double* __restrict__ y, const double* __restrict__ z, const uint8_t* __restrict__ color, uint32_t color_stride,
     const float* __restrict__ intensity, uint32_t* __restrict__ rank, uint4* __restrict__ payload, uint32_t* __restrict__ inten_bits,
-    const uint8_t* __restrict__ depth_grid, float cells_per_unit, uint4* __restrict__ wide, uint32_t* __restrict__ pool_counter) {
+    const uint8_t* __restrict__ depth_grid, float cells_per_unit, uint4* __restrict__ wide, uint32_t* __restrict__ pool_ctr, uint32_t pool_cap) {
   constexpr bool KEEP = true;
   constexpr int TILE = 2 * BLOCK, kWavesB = BLOCK / 64, kGroups = 2 * kWavesB;
   __shared__ double sx[TILE], sy[TILE], sz[TILE];
@@ -638,7 +642,7 @@ __global__ __launch_bounds__(BLOCK, PREFETCH ? 6 : 8) void spec_encode_persist_k
         vx = kx, vy = ky, vz = kz;
         L = kl;
       }
-      pcv_spec_emit(i, n, rec, lv.enc[L], vx, vy, vz, color, color_stride, intensity, rank, payload, inten_bits, wide, pool_counter);
+      pcv_spec_emit(i, n, rec, lv.enc[L], vx, vy, vz, color, color_stride, intensity, rank, payload, inten_bits, wide, pool_ctr, pool_cap);
     }
   }
 }
@@ -758,7 +762,7 @@ __global__ __launch_bounds__(256) void spec_replay_kernel(PcvLevels lv, const Pc
                                                            const double* __restrict__ y, const double* __restrict__ z,
                                                            PcvRouted routed, uint4* __restrict__ payload,
                                                            uint4* __restrict__ wide /* set: 12-byte records */,
-                                                           uint32_t wide_top /* the pool's last entry (n - 1) */) {
+                                                           uint32_t pool_cap /* entries per pool region */) {
   for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < total; j += gridDim.x * 256) {
     uint32_t a = 0, b = num_ranges;  // last range with before <= j
     while (b - a > 1) {
@@ -796,9 +800,9 @@ __global__ __launch_bounds__(256) void spec_replay_kernel(PcvLevels lv, const Pc
     } else if (en <= PCV_ENC_UINT16) {
       reinterpret_cast<uint2*>(payload)[s] = make_uint2(p.x | (p.y << 16), (q.y & 0xffff0000u) | p.z);
     } else {  // the codes go where `settle` looks for those of a Float32-coded leaf: a pool entry, named by the record. The
-              // chain pass hands entries out from the bottom of the pool; replayed points take them from the TOP (entry
-              // wide_top - j for the j-th replayed slot) — the host has checked that the two cannot meet (queue_replay)
-      const uint32_t e = wide_top - j;
+              // chain pass fills every pool region from its bottom; the j-th replayed slot takes an entry from the TOP of
+              // region j % regions — the host has checked that the two cannot meet (single_chain_topology)
+      const uint32_t e = (j & (kPcvPoolRegions - 1u)) * pool_cap + pool_cap - 1u - j / kPcvPoolRegions;
       wide[e] = make_uint4(p.x, p.y, p.z, 0u);
       reinterpret_cast<uint2*>(payload)[s] = make_uint2(e, q.y);
     }
@@ -1152,23 +1156,24 @@ template <bool BIN, int BLOCK>
 static void launch_spec_encode_t(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* walk, uint64_t n, const double* x,
                                  const double* y, const double* z, const PcvRouted& routed, const uint8_t* color,
                                  uint32_t color_stride, const float* intensity, uint32_t* rank, void* payload,
-                                 uint32_t* inten_bits, uint8_t* depth_grid, void* wide, uint32_t* pool_counter, bool v4) {
+                                 uint32_t* inten_bits, uint8_t* depth_grid, void* wide, uint32_t* pool_ctr, bool v4) {
+  const uint32_t pool_cap = (uint32_t)pcv_pool_region_entries(n);
   const dim3 grid((unsigned)((n + BLOCK - 1) / BLOCK));
   const float cells = lv.edge[0] > 0.0 ? (float)((double)(1 << kGridBits) / lv.edge[0]) : 0.f;
   if (BIN) hipLaunchKernelGGL(spec_depth_grid_kernel, dim3((1u << (3 * kGridBits)) / 256), dim3(256), 0, ctx->stream, walk, depth_grid);
   if (BIN && v4)
     hipLaunchKernelGGL((spec_encode4_kernel<true, BLOCK>), grid, dim3(BLOCK), 0, ctx->stream, lv, walk, n, x, y, z, routed, color,
-                       color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_counter);
+                       color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr, pool_cap);
   else
     hipLaunchKernelGGL((spec_encode_kernel<true, BIN, BLOCK>), grid, dim3(BLOCK), 0, ctx->stream, lv, walk, n, x, y, z, routed, color,
-                       color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_counter);
+                       color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr, pool_cap);
 }
 
 void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* walk, uint64_t n, const double* x,
                             const double* y, const double* z, const PcvRouted& routed, const uint8_t* color,
                             uint32_t color_stride, const float* intensity, uint32_t* rank, void* payload,
                             uint32_t* inten_bits, uint8_t* depth_grid /* pcv_spec_depth_grid_bytes() of scratch, or null */,
-                            void* wide, uint32_t* pool_counter /* zero; counts the entries of `wide` handed out */) {
+                            void* wide, uint32_t* pool_ctr /* kPcvPoolRegions zeroed counters: entries of `wide` handed out per region */) {
   if (n == 0) return;
   PcvProf prof(ctx, PCV_K_SPEC_ENCODE);
   // PCV_CHAIN_V (experiments): 3 = round 3's kernel (ballot deal, packed digit), default 4
@@ -1176,6 +1181,8 @@ void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* w
     const char* e = pcv_experiment("PCV_CHAIN_V");
     return !e || atoi(e) != 3;
   }();
+  const uint32_t pool_cap = (uint32_t)pcv_pool_region_entries(n);
+  (void)pool_cap;
   // PCV_SPEC_BIN (experiments): 0 = input order, 256 / 512 / 1024 = depth binning inside workgroups of that size
   static const int bin_mode = [] {
     const char* e = pcv_experiment("PCV_SPEC_BIN");
@@ -1201,27 +1208,27 @@ void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* w
     hipLaunchKernelGGL(spec_depth_grid_kernel, dim3((1u << (3 * kGridBits)) / 256), dim3(256), 0, ctx->stream, walk, depth_grid);
     if (persist >= 100) {  // one tile of 1 024 points per workgroup, no prefetch registers: just the paired deal
       hipLaunchKernelGGL((spec_encode_persist_kernel<512, false>), dim3(num_tiles), dim3(512), 0, ctx->stream, lv, walk, n, num_tiles, x, y, z,
-                         color, color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_counter);
+                         color, color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr, pool_cap);
     } else {
       const uint32_t groups = std::min<uint32_t>(num_tiles, (uint32_t)(cus * persist));
       hipLaunchKernelGGL((spec_encode_persist_kernel<512, true>), dim3(groups), dim3(512), 0, ctx->stream, lv, walk, n, num_tiles, x, y, z,
-                         color, color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_counter);
+                         color, color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr, pool_cap);
     }
     return;
   }
 #endif
   if (!bin)
     launch_spec_encode_t<false, 256>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, inten_bits,
-                                     depth_grid, wide, pool_counter, v4);
+                                     depth_grid, wide, pool_ctr, v4);
   else if (bin_mode == 256)
     launch_spec_encode_t<true, 256>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, inten_bits,
-                                     depth_grid, wide, pool_counter, v4);
+                                     depth_grid, wide, pool_ctr, v4);
   else if (bin_mode == 512)
     launch_spec_encode_t<true, 512>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, inten_bits,
-                                     depth_grid, wide, pool_counter, v4);
+                                     depth_grid, wide, pool_ctr, v4);
   else
     launch_spec_encode_t<true, 1024>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, inten_bits,
-                                     depth_grid, wide, pool_counter, v4);
+                                     depth_grid, wide, pool_ctr, v4);
 }
 
 size_t pcv_spec_depth_grid_bytes() { return (size_t)1 << (3 * kGridBits); }
@@ -1270,12 +1277,12 @@ void pcv_launch_spec_continue(pcv_ctx* ctx, const PcvLevels& lv, const void* ran
 
 void pcv_launch_spec_replay(pcv_ctx* ctx, const PcvLevels& lv, const void* ranges, uint32_t num_ranges, uint32_t total,
                             const double* x, const double* y, const double* z, const PcvRouted& routed, void* sorted_payload,
-                            void* wide, uint32_t wide_top) {
+                            void* wide, uint32_t pool_cap) {
   if (total == 0 || num_ranges == 0) return;
   PcvProf prof(ctx, PCV_K_SPEC_REPLAY);
   const unsigned blocks = (unsigned)std::min<uint64_t>(((uint64_t)total + 255) / 256, 8192);
   hipLaunchKernelGGL(spec_replay_kernel, dim3(blocks), dim3(256), 0, ctx->stream, lv, (const PcvFixRange*)ranges, num_ranges, total,
-                     x, y, z, routed, (uint4*)sorted_payload, (uint4*)wide, wide_top);
+                     x, y, z, routed, (uint4*)sorted_payload, (uint4*)wide, pool_cap);
 }
 
 size_t pcv_climber_bytes(uint64_t num_climbers) { return (size_t)(num_climbers + 1) * sizeof(PcvClimber); }

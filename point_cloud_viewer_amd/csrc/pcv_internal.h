@@ -339,7 +339,7 @@ void pcv_launch_pack_node_table(pcv_ctx* ctx, const PcvNodeTableDev& t, void* pa
 // sparent: 1 + 8 x capacity u32; slevel: 1 + 8 x capacity bytes; info: 4 u32 (nodes, split error flags, sample nodes,
 // any candidate)
 void pcv_launch_spec_tree(pcv_ctx* ctx, const PcvNodeTableDev& t, double upper, uint32_t force_mask, uint32_t* ord, uint32_t* walk,
-                          uint32_t* sparent, uint8_t* slevel, uint32_t* info);
+                          uint32_t* sparent, uint8_t* slevel, uint32_t* info, uint32_t* pool_ctr /* kPcvPoolRegions counters, zeroed here; may be null */);
 // single-chain build: the predicted-leaf -> true-leaf rank map on the device, from the exact counts (`counts`: one u32 per
 // T'' node, leaf entries filled by pcv_launch_rank_hist, inner entries zero). tn = number of T'' nodes (the host knows it
 // from its mirror of the tree); nst / base: tn u32 of scratch each; out: [0] number of true leaves, [1] 1 = prediction too
@@ -374,13 +374,19 @@ void pcv_launch_leaf_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvWalkTabl
 // rank / payload fix-up once the true tree is known.
 // 12-byte records (`wide` set, u32 + uint2 per point instead of u32 + uint4): key = rank << 8 | blue, payload =
 // {code x | code y << 16, code z | red << 16 | green << 24} for u8 / u16-coded leaf levels; a point whose leaf level is
-// Float32-coded names an entry of the `wide` POOL in the first payload word and keeps its three 32-bit codes there (uint4[n];
-// entries are handed out densely from 0 by the chain pass — one reservation per wave on *pool_counter — and from n - 1
-// downwards by the rare replay) — 24 instead of 40 bytes per point and pass through the record sort.
+// Float32-coded names an entry of the `wide` POOL in the first payload word and keeps its three 32-bit codes there — 24
+// instead of 40 bytes per point and pass through the record sort. The pool has kPcvPoolRegions regions of
+// pcv_pool_region_entries(n) entries; the points of input slice s (1 024 consecutive points) use region s % kPcvPoolRegions,
+// filled from its first entry upwards by ONE reservation per wave on the region's counter (a single counter for the whole
+// pool serialises: 7.3 instead of 2.2 ms for the pass at 100 M points) — so the used part of the pool is kPcvPoolRegions
+// dense prefixes (100 MB for the 6.3 M entries of the bench cloud); the rare replay takes entries from the regions' tops.
 void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* walk, uint64_t n, const double* x,
                             const double* y, const double* z, const PcvRouted& routed, const uint8_t* color,
                             uint32_t color_stride, const float* intensity, uint32_t* rank, void* payload /* uint4[n] */,
-                            uint32_t* inten_bits, uint8_t* depth_grid, void* wide, uint32_t* pool_counter);
+                            uint32_t* inten_bits, uint8_t* depth_grid, void* wide, uint32_t* pool_ctr);
+constexpr uint32_t kPcvPoolRegions = 1024;
+// entries per region: every slice of 1 024 points could be all Float32-coded
+inline uint64_t pcv_pool_region_entries(uint64_t n) { return (((n + 1023) / 1024 + kPcvPoolRegions - 1) / kPcvPoolRegions) * 1024; }
 size_t pcv_spec_depth_grid_bytes();  // scratch for the depth-prediction grid of the binned pass
 void pcv_launch_rank_hist(pcv_ctx* ctx, const uint32_t* rank, uint64_t n, uint32_t num_bins, uint32_t* counts /* zeroed */,
                           int shift = 0);
@@ -399,7 +405,7 @@ void pcv_launch_spec_continue(pcv_ctx* ctx, const PcvLevels& lv, const void* ran
 // ranges: device array of {first sorted slot, flagged slots before it, level, pad} (4 x u32), after the record sort
 void pcv_launch_spec_replay(pcv_ctx* ctx, const PcvLevels& lv, const void* ranges, uint32_t num_ranges, uint32_t total,
                             const double* x, const double* y, const double* z, const PcvRouted& routed, void* sorted_payload,
-                            void* wide = nullptr, uint32_t wide_top = 0);
+                            void* wide = nullptr, uint32_t pool_cap = 0 /* pcv_pool_region_entries(n) */);
 
 // Everything K6 needs about a node in one 80-byte record, so a slot's dependent loads are rank -> record (-> the
 // parent's record per climb) instead of chained table lookups (node, level, per-level edge/encoding, offsets).

@@ -217,7 +217,10 @@ __global__ __launch_bounds__(256) void pack_node_table_kernel(PcvNodeTableDev t,
 // pass starts without a host round trip; the host mirrors the tree (pcv_spec_tree_from_walk) while that pass runs.
 // info: [0] number of T'' nodes, [1] error flags of the sample split, [2] sample nodes, [3] any candidate
 __global__ __launch_bounds__(1024) void spec_tree_scan_kernel(PcvNodeTableDev t, uint32_t* __restrict__ ord,
-                                                               uint32_t* __restrict__ info) {
+                                                               uint32_t* __restrict__ info, uint32_t* __restrict__ pool_ctr) {
+  static_assert(kPcvPoolRegions <= 1024, "one counter per lane");
+  // the chain pass's pool counters (entries of `wide` handed out per region, pcv_encode.hip pcv_spec_emit): zero before every pass
+  if (pool_ctr && threadIdx.x < kPcvPoolRegions) pool_ctr[threadIdx.x] = 0;
   __shared__ uint32_t wave_tot[16];
   __shared__ uint32_t running;
   const uint32_t count = t.counters[CNT_NODES] < t.capacity ? t.counters[CNT_NODES] : t.capacity;
@@ -251,7 +254,6 @@ __global__ __launch_bounds__(1024) void spec_tree_scan_kernel(PcvNodeTableDev t,
     info[1] = t.counters[CNT_ERROR];
     info[2] = count;
     info[3] = 0;
-    info[8] = 0;  // the chain pass's pool counter (entries of `wide` handed out, pcv_encode.hip pcv_spec_emit): zero before every pass
   }
 }
 
@@ -355,7 +357,9 @@ __global__ __launch_bounds__(1024) void spec_resolve_kernel(PcvLevels lv, double
       uint32_t c, nl;
       if (rec & PCV_SPEC_LEAF) {
         c = cnt[i];
-        if (would_split(i, L, c)) atomicOr(&too_shallow, 1u);  // the prediction stops above where the tree goes on
+        // the prediction stops above where the tree goes on (an empty octant is no node at all, forced or not: the host's
+        // resolve never visits it, pcv_spec.cpp)
+        if (c > 0 && would_split(i, L, c)) atomicOr(&too_shallow, 1u);
         nl = c > 0 ? 1u : 0u;
       } else {
         const uint32_t first = rec & PCV_SPEC_INDEX_MASK;
@@ -452,8 +456,8 @@ void pcv_launch_spec_resolve(pcv_ctx* ctx, const PcvLevels& lv, double resolutio
 }
 
 void pcv_launch_spec_tree(pcv_ctx* ctx, const PcvNodeTableDev& t, double upper, uint32_t force_mask, uint32_t* ord, uint32_t* walk,
-                          uint32_t* sparent, uint8_t* slevel, uint32_t* info) {
-  hipLaunchKernelGGL(spec_tree_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, t, ord, info);
+                          uint32_t* sparent, uint8_t* slevel, uint32_t* info, uint32_t* pool_ctr) {
+  hipLaunchKernelGGL(spec_tree_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, t, ord, info, pool_ctr);
   hipLaunchKernelGGL(spec_tree_emit_kernel, dim3(64), dim3(256), 0, ctx->stream, t, ord, upper, force_mask, walk, sparent, slevel,
                      info);
 }
