@@ -4,9 +4,10 @@
 TAG=${1:-r04}
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT
+source $GRAFT_REPO_ROOT/tools/run_limited.sh
 cd /tmp && export TMPDIR=/tmp
 $GRAFT_REPO_ROOT/tools/f64_rate.bin > $OUT/${TAG}_f64_rate_plain.jsonl 2> $OUT/${TAG}_f64_rate.err
 rm -rf /tmp/${TAG}_f64clk
-rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace -d /tmp/${TAG}_f64clk -o r -- $GRAFT_REPO_ROOT/tools/f64_rate.bin > $OUT/${TAG}_f64_rate_pmc.jsonl 2>> $OUT/${TAG}_f64_rate.err
+run_limited 200 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace -d /tmp/${TAG}_f64clk -o r -- $GRAFT_REPO_ROOT/tools/f64_rate.bin > $OUT/${TAG}_f64_rate_pmc.jsonl 2>> $OUT/${TAG}_f64_rate.err
 cd $GRAFT_REPO_ROOT
 python tools/f64_rate_merge.py $OUT/${TAG}_f64_rate_plain.jsonl /tmp/${TAG}_f64clk/r_results.db $OUT/${TAG}_f64_rate.json

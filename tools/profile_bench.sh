@@ -10,13 +10,14 @@
 TAG=${1:-prof}; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT
+source $GRAFT_REPO_ROOT/tools/run_limited.sh
 cd /tmp && export TMPDIR=/tmp
 B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-e2e --no-kernel-events --no-parity"
-rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_stats -o r -- $B --steps 5 --warmup 2 "$@" > $OUT/${TAG}_stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/${TAG}_fetch -o r -- $B --steps 1 --warmup 0 "$@" > $OUT/${TAG}_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/${TAG}_write -o r -- $B --steps 1 --warmup 0 "$@" > $OUT/${TAG}_write.log 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace -d $OUT/${TAG}_sq -o r -- $B --steps 1 --warmup 0 "$@" > $OUT/${TAG}_sq.log 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 --kernel-trace -d $OUT/${TAG}_f64 -o r -- $B --steps 1 --warmup 0 "$@" > $OUT/${TAG}_f64.log 2>&1
+run_limited 200 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_stats -o r -- $B --steps 5 --warmup 2 "$@" > $OUT/${TAG}_stats.log 2>&1
+run_limited 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/${TAG}_fetch -o r -- $B --steps 1 --warmup 0 "$@" > $OUT/${TAG}_fetch.log 2>&1
+run_limited 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/${TAG}_write -o r -- $B --steps 1 --warmup 0 "$@" > $OUT/${TAG}_write.log 2>&1
+run_limited 200 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace -d $OUT/${TAG}_sq -o r -- $B --steps 1 --warmup 0 "$@" > $OUT/${TAG}_sq.log 2>&1
+run_limited 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 --kernel-trace -d $OUT/${TAG}_f64 -o r -- $B --steps 1 --warmup 0 "$@" > $OUT/${TAG}_f64.log 2>&1
 tail -1 $OUT/${TAG}_stats.log
 cd $GRAFT_REPO_ROOT
 python tools/rocpd_summary.py --stats $OUT/${TAG}_stats/r_results.db --fetch $OUT/${TAG}_fetch/r_results.db --write $OUT/${TAG}_write/r_results.db --sq $OUT/${TAG}_sq/r_results.db -o $OUT/${TAG}_kernel_stats > /dev/null
