@@ -1116,7 +1116,7 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
     ctx->stage_begin(PCV_STAGE_LEAF_ENCODE);
     lv.nlevels = full_levels;
     pcv_launch_spec_encode(ctx, lv, d_walk, n, d.x, d.y, d.z, d.routed, d.color, d.color_stride, d.intensity, rank, payload,
-                           inten_bits, depth_grid, wide, d_pool_ctr /* zeroed by the spec_tree kernels */);
+                           inten_bits, depth_grid, wide, d_pool_ctr /* zeroed by the spec_tree kernels */, d_info);
     ctx->stage_end(PCV_STAGE_LEAF_ENCODE);
     host_lap("chain pass queued");
 

@@ -375,6 +375,11 @@ __device__ __forceinline__ uint32_t pcv_wave_incl_scan32(uint32_t v) {  // inclu
 #ifndef PCV4_KEEP_BRANCH
 #define PCV4_KEEP_BRANCH 1
 #endif
+/* walk record of T'' node `idx`: the first lds_nodes records (T'' is level-major: the top of the tree) are mirrored in LDS */
+#define PCV4_WALK_AT(idx) pcv4_walk_at(walk, swalk, lds_nodes, (idx))
+__device__ __forceinline__ uint32_t pcv4_walk_at(const uint32_t* __restrict__ walk, const uint32_t* swalk, uint32_t lds_nodes, uint32_t idx) {
+  return idx < lds_nodes ? swalk[idx] : walk[idx];
+}
 #if PCV4_KEEP_BRANCH
 #define PCV4_KEEP_STEP                                                                                                  \
   if (KEEP) {                                                                                                           \
@@ -413,7 +418,7 @@ __device__ __forceinline__ uint32_t pcv_wave_incl_scan32(uint32_t v) {  // inclu
       } else {                                                                                                          \
         b = pcv_chain_bits(lv.edge[U], px, py, pz, mx, my, mz);                                                         \
       }                                                                                                                 \
-      const uint32_t next = walk[(rec & PCV_SPEC_INDEX_MASK) + b.digit()];                                              \
+      const uint32_t next = PCV4_WALK_AT((rec & PCV_SPEC_INDEX_MASK) + b.digit());                                      \
       const double ec = lv.edge[U + 1];                                                                                 \
       const PcvRecip ic{lv.inv_edge[U + 1], lv.inv_edge_lo[U + 1]};                                                     \
       APPLY;                                                                                                            \
@@ -440,19 +445,30 @@ __device__ __forceinline__ uint32_t pcv_wave_incl_scan32(uint32_t v) {  // inclu
   }
 
 template <bool KEEP, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void spec_encode4_kernel(
+__global__ __launch_bounds__(BLOCK, 8) void spec_encode4_kernel(
     PcvLevels lv, const uint32_t* __restrict__ walk, uint64_t n, const double* __restrict__ x, const double* __restrict__ y,
     const double* __restrict__ z, PcvRouted routed, const uint8_t* __restrict__ color, uint32_t color_stride,
     const float* __restrict__ intensity, uint32_t* __restrict__ rank, uint4* __restrict__ payload, uint32_t* __restrict__ inten_bits,
     const uint8_t* __restrict__ depth_grid, float cells_per_unit /* 128 / root edge */, uint4* __restrict__ wide /* set: 12-byte records */,
-    uint32_t* __restrict__ pool_ctr, uint32_t pool_cap) {
+    uint32_t* __restrict__ pool_ctr, uint32_t pool_cap, uint32_t lds_cap /* walk records the dynamic LDS has room for (a multiple of 4) */,
+    const uint32_t* __restrict__ tree_info /* [0] = number of T'' nodes (spec_tree_scan_kernel) */) {
   __shared__ double sx[BLOCK], sy[BLOCK], sz[BLOCK];
   __shared__ uint16_t sidx[BLOCK];
   __shared__ uint32_t kcnt[32];  // points of the workgroup per depth class
+  extern __shared__ uint32_t swalk[];  // the first lds_nodes walk records
+  const uint32_t tn4 = (tree_info[0] + 3u) & ~3u;  // (the table's allocation is a multiple of 256 bytes)
+  const uint32_t lds_nodes = tn4 < lds_cap ? tn4 : lds_cap;
   const int tid = threadIdx.x, lane = tid & 63;
   uint64_t i = (uint64_t)blockIdx.x * BLOCK + tid;
   const bool raw = routed.oct == nullptr;  // grid-uniform
   if (tid < 32) kcnt[tid] = 0;
+  // The walk table's top in LDS. By round 4's counters this pass is bound by the vector L1, not by its arithmetic: 858 M tag
+  // look-ups per launch = one in 70 % of all cycles of every CU's TCP (+ 11 % tag-conflict stalls), 549 per wave — 290 of
+  // them for the per-level gathers of walk records (64 lanes, ~40 different lines), 64 for the depth grid, the rest for the
+  // coordinates, the colour and the scattered record stores (profiles/r04_chain_pass_v4_before_lds_walk_counters.json). A
+  // workgroup copies the table once (30 KB for the 7 489 nodes of the bench tree: 234 lines) and its waves then gather from LDS.
+  for (uint32_t k = (uint32_t)tid * 4u; k < lds_nodes; k += (uint32_t)BLOCK * 4u)
+    *reinterpret_cast<uint4*>(swalk + k) = *reinterpret_cast<const uint4*>(walk + k);
   const bool in = i < n;
   double qx = 0.0, qy = 0.0, qz = 0.0;
   if (in) {
@@ -499,7 +515,7 @@ __global__ __launch_bounds__(BLOCK) void spec_encode4_kernel(
     mx = lv.root_min[0], my = lv.root_min[1], mz = lv.root_min[2];
   } else if (pcv_chain_start(lv, routed, x, y, z, i, px, py, pz, mx, my, mz, vx, vy, vz, d1) == 2 && !(rec & PCV_SPEC_LEAF)) {
     L = 1;  // level 1 is given (digit + codes)
-    rec = walk[(rec & PCV_SPEC_INDEX_MASK) + d1];
+    rec = PCV4_WALK_AT((rec & PCV_SPEC_INDEX_MASK) + d1);
   }
   int U = __builtin_amdgcn_readfirstlane(L);  // the wave's level counter (all lanes start at the same level: 0, or 1 for routed input)
   if (lv.fast_ok && pcv_point_is_tame(px, py, pz)) {
@@ -517,6 +533,7 @@ __global__ __launch_bounds__(BLOCK) void spec_encode4_kernel(
 #undef PCV4_WALK
 #undef PCV4_LOOP
 #undef PCV4_KEEP_STEP
+#undef PCV4_WALK_AT
 
 #ifdef PCV_EXPERIMENTS
 // (libpcv_hip_exp.so only: measured slower than the kernel above — DESIGN.md §6, profiles/r03h_*)
@@ -1156,24 +1173,37 @@ template <bool BIN, int BLOCK>
 static void launch_spec_encode_t(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* walk, uint64_t n, const double* x,
                                  const double* y, const double* z, const PcvRouted& routed, const uint8_t* color,
                                  uint32_t color_stride, const float* intensity, uint32_t* rank, void* payload,
-                                 uint32_t* inten_bits, uint8_t* depth_grid, void* wide, uint32_t* pool_ctr, bool v4) {
-  const uint32_t pool_cap = (uint32_t)pcv_pool_region_entries(n);
+                                 uint32_t* inten_bits, uint8_t* depth_grid, void* wide, uint32_t* pool_ctr, bool v4, const uint32_t* tree_info) {
   const dim3 grid((unsigned)((n + BLOCK - 1) / BLOCK));
   const float cells = lv.edge[0] > 0.0 ? (float)((double)(1 << kGridBits) / lv.edge[0]) : 0.f;
+  const uint32_t pool_cap = (uint32_t)pcv_pool_region_entries(n);
   if (BIN) hipLaunchKernelGGL(spec_depth_grid_kernel, dim3((1u << (3 * kGridBits)) / 256), dim3(256), 0, ctx->stream, walk, depth_grid);
-  if (BIN && v4)
-    hipLaunchKernelGGL((spec_encode4_kernel<true, BLOCK>), grid, dim3(BLOCK), 0, ctx->stream, lv, walk, n, x, y, z, routed, color,
-                       color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr, pool_cap);
-  else
+  if (BIN && v4) {
+    // walk records mirrored in LDS: as many as fit beside the deal's staging with the CU still full (8 waves per SIMD):
+    // workgroups of 512 -> 3 per CU hold 13.4 + 32 KB each, workgroups of 1 024 -> 2 per CU hold 26.8 + 48 KB each
+    static const uint32_t lds_cap = [] {
+      const char* e = pcv_experiment("PCV_CHAIN_LDS");  // experiments: entries (0 = the table stays in global memory)
+      return e ? (uint32_t)atoi(e) : (BLOCK >= 1024 ? 12288u : 8192u);
+    }();
+    const uint32_t lds_nodes = lds_cap & ~3u;
+    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&spec_encode4_kernel<true, BLOCK>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
+    (void)ok;
+    hipLaunchKernelGGL((spec_encode4_kernel<true, BLOCK>), grid, dim3(BLOCK), (size_t)lds_nodes * 4, ctx->stream, lv, walk, n, x, y, z, routed,
+                       color, color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr, pool_cap,
+                       lds_nodes, tree_info);
+  } else {
     hipLaunchKernelGGL((spec_encode_kernel<true, BIN, BLOCK>), grid, dim3(BLOCK), 0, ctx->stream, lv, walk, n, x, y, z, routed, color,
                        color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr, pool_cap);
+  }
 }
 
 void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* walk, uint64_t n, const double* x,
                             const double* y, const double* z, const PcvRouted& routed, const uint8_t* color,
                             uint32_t color_stride, const float* intensity, uint32_t* rank, void* payload,
                             uint32_t* inten_bits, uint8_t* depth_grid /* pcv_spec_depth_grid_bytes() of scratch, or null */,
-                            void* wide, uint32_t* pool_ctr /* kPcvPoolRegions zeroed counters: entries of `wide` handed out per region */) {
+                            void* wide, uint32_t* pool_ctr /* kPcvPoolRegions zeroed counters: entries of `wide` handed out per region */,
+                            const uint32_t* tree_info /* device: [0] = number of T'' nodes (spec_tree_scan_kernel's info block) */) {
   if (n == 0) return;
   PcvProf prof(ctx, PCV_K_SPEC_ENCODE);
   // PCV_CHAIN_V (experiments): 3 = round 3's kernel (ballot deal, packed digit), default 4
@@ -1219,16 +1249,16 @@ void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* w
 #endif
   if (!bin)
     launch_spec_encode_t<false, 256>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, inten_bits,
-                                     depth_grid, wide, pool_ctr, v4);
+                                     depth_grid, wide, pool_ctr, v4, tree_info);
   else if (bin_mode == 256)
     launch_spec_encode_t<true, 256>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, inten_bits,
-                                     depth_grid, wide, pool_ctr, v4);
+                                     depth_grid, wide, pool_ctr, v4, tree_info);
   else if (bin_mode == 512)
     launch_spec_encode_t<true, 512>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, inten_bits,
-                                     depth_grid, wide, pool_ctr, v4);
+                                     depth_grid, wide, pool_ctr, v4, tree_info);
   else
     launch_spec_encode_t<true, 1024>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, inten_bits,
-                                     depth_grid, wide, pool_ctr, v4);
+                                     depth_grid, wide, pool_ctr, v4, tree_info);
 }
 
 size_t pcv_spec_depth_grid_bytes() { return (size_t)1 << (3 * kGridBits); }

@@ -383,7 +383,7 @@ void pcv_launch_leaf_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvWalkTabl
 void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* walk, uint64_t n, const double* x,
                             const double* y, const double* z, const PcvRouted& routed, const uint8_t* color,
                             uint32_t color_stride, const float* intensity, uint32_t* rank, void* payload /* uint4[n] */,
-                            uint32_t* inten_bits, uint8_t* depth_grid, void* wide, uint32_t* pool_ctr);
+                            uint32_t* inten_bits, uint8_t* depth_grid, void* wide, uint32_t* pool_ctr, const uint32_t* tree_info);
 constexpr uint32_t kPcvPoolRegions = 1024;
 // entries per region: every slice of 1 024 points could be all Float32-coded
 inline uint64_t pcv_pool_region_entries(uint64_t n) { return (((n + 1023) / 1024 + kPcvPoolRegions - 1) / kPcvPoolRegions) * 1024; }

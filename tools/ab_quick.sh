@@ -1,4 +1,4 @@
-# timing-only A/B in one gpurun call: RUNS="name[:ENV=VAL|lib] ..." each run = one short bench; prints the kernel table
+# timing-only A/B in one gpurun call: RUNS="name[:ENV=VAL[,ENV2=VAL2]|lib] ..." each run = one short bench; prints the kernel table
 mkdir -p gpurun_out
 T=${TAG:-abq}
 B="python bench.py --steps ${STEPS:-10} --warmup 3 --no-e2e --no-cpu-baseline --no-parity --digest"
@@ -9,7 +9,7 @@ for v in $RUNS; do
   if [ -f "$PWD/point_cloud_viewer_amd/libpcv_hip_$arg.so" ]; then
     PCV_HIP_LIBRARY=$PWD/point_cloud_viewer_amd/libpcv_hip_$arg.so timeout 200 $B > gpurun_out/${T}_$i.json 2> gpurun_out/${T}_$i.err
   elif [ -n "$arg" ]; then
-    env PCV_HIP_LIBRARY=exp "$arg" timeout 200 $B > gpurun_out/${T}_$i.json 2> gpurun_out/${T}_$i.err
+    env PCV_HIP_LIBRARY=exp ${arg//,/ } timeout 200 $B > gpurun_out/${T}_$i.json 2> gpurun_out/${T}_$i.err
   else
     timeout 200 $B > gpurun_out/${T}_$i.json 2> gpurun_out/${T}_$i.err
   fi
