@@ -451,7 +451,8 @@ __global__ __launch_bounds__(BLOCK, 8) void spec_encode4_kernel(
     const float* __restrict__ intensity, uint32_t* __restrict__ rank, uint4* __restrict__ payload, uint32_t* __restrict__ inten_bits,
     const uint8_t* __restrict__ depth_grid, float cells_per_unit /* 128 / root edge */, uint4* __restrict__ wide /* set: 12-byte records */,
     uint32_t* __restrict__ pool_ctr, uint32_t pool_cap, uint32_t lds_cap /* walk records the dynamic LDS has room for (a multiple of 4) */,
-    const uint32_t* __restrict__ tree_info /* [0] = number of T'' nodes (spec_tree_scan_kernel) */) {
+    const uint32_t* __restrict__ tree_info /* [0] = number of T'' nodes (spec_tree_scan_kernel) */,
+    uint32_t diag /* 0; libpcv_hip_exp.so PCV_CHAIN_DIAG (timing only, wrong records): 1 = no walk, 4 = no record stores */) {
   __shared__ double sx[BLOCK], sy[BLOCK], sz[BLOCK];
   __shared__ uint16_t sidx[BLOCK];
   __shared__ uint32_t kcnt[32];  // points of the workgroup per depth class
@@ -518,7 +519,9 @@ __global__ __launch_bounds__(BLOCK, 8) void spec_encode4_kernel(
     rec = PCV4_WALK_AT((rec & PCV_SPEC_INDEX_MASK) + d1);
   }
   int U = __builtin_amdgcn_readfirstlane(L);  // the wave's level counter (all lanes start at the same level: 0, or 1 for routed input)
-  if (lv.fast_ok && pcv_point_is_tame(px, py, pz)) {
+  if (diag & 1u) {
+    vx = px, vy = py, vz = pz;
+  } else if (lv.fast_ok && pcv_point_is_tame(px, py, pz)) {
     PCV4_WALK(false)
   } else {
     PCV4_WALK(true)
@@ -528,6 +531,7 @@ __global__ __launch_bounds__(BLOCK, 8) void spec_encode4_kernel(
     vx = kx, vy = ky, vz = kz;
     L = kl;
   }
+  if ((diag & 4u) && vx != 12345.678) return;
   pcv_spec_emit(i, n, rec, lv.enc[L], vx, vy, vz, color, color_stride, intensity, rank, payload, inten_bits, wide, pool_ctr, pool_cap);
 }
 #undef PCV4_WALK
@@ -1186,12 +1190,16 @@ static void launch_spec_encode_t(pcv_ctx* ctx, const PcvLevels& lv, const uint32
       return e ? (uint32_t)atoi(e) : (BLOCK >= 1024 ? 12288u : 8192u);
     }();
     const uint32_t lds_nodes = lds_cap & ~3u;
+    static const uint32_t diag = [] {
+      const char* e = pcv_experiment("PCV_CHAIN_DIAG");
+      return e ? (uint32_t)atoi(e) : 0u;
+    }();
     static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&spec_encode4_kernel<true, BLOCK>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
     (void)ok;
     hipLaunchKernelGGL((spec_encode4_kernel<true, BLOCK>), grid, dim3(BLOCK), (size_t)lds_nodes * 4, ctx->stream, lv, walk, n, x, y, z, routed,
                        color, color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr, pool_cap,
-                       lds_nodes, tree_info);
+                       lds_nodes, tree_info, diag);
   } else {
     hipLaunchKernelGGL((spec_encode_kernel<true, BIN, BLOCK>), grid, dim3(BLOCK), 0, ctx->stream, lv, walk, n, x, y, z, routed, color,
                        color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr, pool_cap);
