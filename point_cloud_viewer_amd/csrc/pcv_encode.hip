@@ -452,7 +452,8 @@ __global__ __launch_bounds__(BLOCK, 8) void spec_encode4_kernel(
     const uint8_t* __restrict__ depth_grid, float cells_per_unit /* 128 / root edge */, uint4* __restrict__ wide /* set: 12-byte records */,
     uint32_t* __restrict__ pool_ctr, uint32_t pool_cap, uint32_t lds_cap /* walk records the dynamic LDS has room for (a multiple of 4) */,
     const uint32_t* __restrict__ tree_info /* [0] = number of T'' nodes (spec_tree_scan_kernel) */,
-    uint32_t diag /* 0; libpcv_hip_exp.so PCV_CHAIN_DIAG (timing only, wrong records): 1 = no walk, 4 = no record stores */) {
+    uint32_t diag /* 0; libpcv_hip_exp.so PCV_CHAIN_DIAG (timing only, wrong records — the launcher runs the real pass afterwards):
+                     1 = no walk, 2 = stop after the deal, 4 = no record stores, 8 = stop after the coordinate loads */) {
   __shared__ double sx[BLOCK], sy[BLOCK], sz[BLOCK];
   __shared__ uint16_t sidx[BLOCK];
   __shared__ uint32_t kcnt[32];  // points of the workgroup per depth class
@@ -481,6 +482,7 @@ __global__ __launch_bounds__(BLOCK, 8) void spec_encode4_kernel(
       (void)pcv_chain_start(lv, routed, x, y, z, i, qx, qy, qz, t0, t1, t2, t3, t4, t5, dd);
     }
   }
+  if ((diag & 8u) && qx != 12345.678) return;
   __syncthreads();  // the counters are zero (the coordinate loads are in flight)
   uint32_t key = kSpecClasses - 1;  // padding lanes go last
   if (in) {
@@ -504,6 +506,7 @@ __global__ __launch_bounds__(BLOCK, 8) void spec_encode4_kernel(
   const int j = sidx[tid];
   i = (uint64_t)blockIdx.x * BLOCK + j;
   if (i >= n) return;  // (no barrier below)
+  if ((diag & 2u) && j != 70000) return;
   double px, py, pz, mx, my, mz;
   double vx = 0, vy = 0, vz = 0;
   double kx = 0, ky = 0, kz = 0;
@@ -1197,9 +1200,30 @@ static void launch_spec_encode_t(pcv_ctx* ctx, const PcvLevels& lv, const uint32
     static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&spec_encode4_kernel<true, BLOCK>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
     (void)ok;
+#ifdef PCV_EXPERIMENTS
+    if (diag) {  // timing only: the cut-down pass runs first and is timed on its own, then the real pass overwrites what it wrote
+      for (uint32_t d : {0u, diag}) {
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        (void)hipEventRecord(e0, ctx->stream);
+        hipLaunchKernelGGL((spec_encode4_kernel<true, BLOCK>), grid, dim3(BLOCK), (size_t)lds_nodes * 4, ctx->stream, lv, walk, n, x, y, z, routed,
+                           color, color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr,
+                           pool_cap, lds_nodes, tree_info, d);
+        (void)hipEventRecord(e1, ctx->stream);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        fprintf(stderr, "PCV_CHAIN_DIAG=%u block=%d lds=%u: %.3f ms\n", d, BLOCK, lds_nodes, ms);
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        (void)hipMemsetAsync(pool_ctr, 0, kPcvPoolRegions * 4, ctx->stream);
+      }
+    }
+#endif
     hipLaunchKernelGGL((spec_encode4_kernel<true, BLOCK>), grid, dim3(BLOCK), (size_t)lds_nodes * 4, ctx->stream, lv, walk, n, x, y, z, routed,
                        color, color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr, pool_cap,
-                       lds_nodes, tree_info, diag);
+                       lds_nodes, tree_info, 0u);
   } else {
     hipLaunchKernelGGL((spec_encode_kernel<true, BIN, BLOCK>), grid, dim3(BLOCK), 0, ctx->stream, lv, walk, n, x, y, z, routed, color,
                        color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr, pool_cap);
