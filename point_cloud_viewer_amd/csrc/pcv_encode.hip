@@ -107,7 +107,9 @@ __device__ __forceinline__ void pcv_spec_emit(uint64_t i, uint64_t n, uint32_t r
                                               const uint8_t* __restrict__ color, uint32_t color_stride,
                                               const float* __restrict__ intensity, uint32_t* __restrict__ rank,
                                               uint4* __restrict__ payload, uint32_t* __restrict__ inten_bits,
-                                              uint4* __restrict__ wide, uint32_t* __restrict__ pool_ctr, uint32_t pool_cap) {
+                                              uint4* __restrict__ wide, uint32_t* __restrict__ pool_ctr, uint32_t pool_cap,
+                                              uint32_t* stage_key = nullptr /* LDS: the workgroup stores its 12-byte records itself */,
+                                              uint2* stage_pay = nullptr, uint32_t stage_slot = 0) {
   const uint32_t rgb = pcv_load_rgb(color + i * color_stride, i + 1 < n);
   const bool is_wide = leaf_enc > PCV_ENC_UINT16;
   // value domain -> raw code: the integer itself (u8 / u16), the IEEE bits of the float (Float32); single-chain builds have
@@ -115,7 +117,7 @@ __device__ __forceinline__ void pcv_spec_emit(uint64_t i, uint64_t n, uint32_t r
   const uint32_t ccx = is_wide ? __float_as_uint((float)vx) : (uint32_t)vx, ccy = is_wide ? __float_as_uint((float)vy) : (uint32_t)vy,
                  ccz = is_wide ? __float_as_uint((float)vz) : (uint32_t)vz;
   if (wide) {
-    rank[i] = ((rec & PCV_SPEC_INDEX_MASK) << 8) | (rgb >> 16);
+    const uint32_t key = ((rec & PCV_SPEC_INDEX_MASK) << 8) | (rgb >> 16);
     const uint32_t rg = (rgb & 0xffffu) << 16;
     uint2 out = make_uint2(ccx | (ccy << 16), ccz | rg);
     const uint64_t wm = __ballot(is_wide);
@@ -133,7 +135,13 @@ __device__ __forceinline__ void pcv_spec_emit(uint64_t i, uint64_t n, uint32_t r
         out = make_uint2(e, rg);
       }
     }
-    reinterpret_cast<uint2*>(payload)[i] = out;
+    if (stage_key) {
+      stage_key[stage_slot] = key;
+      stage_pay[stage_slot] = out;
+    } else {
+      rank[i] = key;
+      reinterpret_cast<uint2*>(payload)[i] = out;
+    }
   } else {  // 20-byte records (a predicted tree that could outgrow 24 rank bits): the codes travel in full
     rank[i] = rec & PCV_SPEC_INDEX_MASK;
     payload[i] = make_uint4(ccx, ccy, ccz, rgb);
@@ -454,9 +462,17 @@ __global__ __launch_bounds__(BLOCK, 8) void spec_encode4_kernel(
     const uint32_t* __restrict__ tree_info /* [0] = number of T'' nodes (spec_tree_scan_kernel) */,
     uint32_t diag /* 0; libpcv_hip_exp.so PCV_CHAIN_DIAG (timing only, wrong records — the launcher runs the real pass afterwards):
                      1 = no walk, 2 = stop after the deal, 4 = no record stores, 8 = stop after the coordinate loads */) {
-  __shared__ double sx[BLOCK], sy[BLOCK], sz[BLOCK];
+  __shared__ double sxyz[3 * BLOCK];
+  double *const sx = sxyz, *const sy = sxyz + BLOCK, *const sz = sxyz + 2 * BLOCK;
   __shared__ uint16_t sidx[BLOCK];
   __shared__ uint32_t kcnt[32];  // points of the workgroup per depth class
+  // the records leave through LDS (12-byte records): after the deal a wave's 64 points are scattered over the workgroup's
+  // slice, and stored straight from the lanes every wave writes a few bytes into each of the slice's 16 + 32 lines — 384
+  // partial-line write requests per workgroup where 48 full lines do (round 4: the pass without its walk took 2.0 ms with
+  // these stores and 1.05 without, tools/chain_diag.sh)
+  // (in the coordinates' staging area, which is dead once every wave has fetched its dealt points: a barrier says so)
+  uint32_t* const okey = reinterpret_cast<uint32_t*>(sxyz);
+  uint2* const opay = reinterpret_cast<uint2*>(sxyz + BLOCK);
   extern __shared__ uint32_t swalk[];  // the first lds_nodes walk records
   const uint32_t tn4 = (tree_info[0] + 3u) & ~3u;  // (the table's allocation is a multiple of 256 bytes)
   const uint32_t lds_nodes = tn4 < lds_cap ? tn4 : lds_cap;
@@ -505,37 +521,54 @@ __global__ __launch_bounds__(BLOCK, 8) void spec_encode4_kernel(
   __syncthreads();
   const int j = sidx[tid];
   i = (uint64_t)blockIdx.x * BLOCK + j;
-  if (i >= n) return;  // (no barrier below)
+  const bool stage = wide != nullptr;  // grid-uniform: 12-byte records
   if ((diag & 2u) && j != 70000) return;
-  double px, py, pz, mx, my, mz;
-  double vx = 0, vy = 0, vz = 0;
-  double kx = 0, ky = 0, kz = 0;
-  int kl = 0;
-  uint32_t d1 = 0;
-  int L = 0;
-  uint32_t rec = walk[0];
-  if (raw) {
-    px = sx[tid], py = sy[tid], pz = sz[tid];
-    mx = lv.root_min[0], my = lv.root_min[1], mz = lv.root_min[2];
-  } else if (pcv_chain_start(lv, routed, x, y, z, i, px, py, pz, mx, my, mz, vx, vy, vz, d1) == 2 && !(rec & PCV_SPEC_LEAF)) {
-    L = 1;  // level 1 is given (digit + codes)
-    rec = PCV4_WALK_AT((rec & PCV_SPEC_INDEX_MASK) + d1);
+  double px = 0, py = 0, pz = 0;
+  if (raw) px = sx[tid], py = sy[tid], pz = sz[tid];
+  if (stage) __syncthreads();  // the staging area now belongs to the records (the waves are still in step here)
+  if (i < n) {
+    double mx, my, mz;
+    double vx = 0, vy = 0, vz = 0;
+    double kx = 0, ky = 0, kz = 0;
+    int kl = 0;
+    uint32_t d1 = 0;
+    int L = 0;
+    uint32_t rec = walk[0];
+    if (raw) {
+      mx = lv.root_min[0], my = lv.root_min[1], mz = lv.root_min[2];
+    } else if (pcv_chain_start(lv, routed, x, y, z, i, px, py, pz, mx, my, mz, vx, vy, vz, d1) == 2 && !(rec & PCV_SPEC_LEAF)) {
+      L = 1;  // level 1 is given (digit + codes)
+      rec = PCV4_WALK_AT((rec & PCV_SPEC_INDEX_MASK) + d1);
+    }
+    int U = __builtin_amdgcn_readfirstlane(L);  // the wave's level counter (all lanes start at the same level: 0, or 1 for routed input)
+    if (diag & 1u) {
+      vx = px, vy = py, vz = pz;
+    } else if (lv.fast_ok && pcv_point_is_tame(px, py, pz)) {
+      PCV4_WALK(false)
+    } else {
+      PCV4_WALK(true)
+    }
+    // the record carries the codes of the first candidate on the path where there is one, else those of the predicted leaf
+    if (KEEP && kl) {
+      vx = kx, vy = ky, vz = kz;
+      L = kl;
+    }
+    // the point's index again, from its 9 / 10-bit slot: keeping the 64-bit index alive across the loops costs a spill
+    uint32_t jj = (uint32_t)j;
+    asm volatile("" : "+v"(jj));
+    const uint64_t i2 = (uint64_t)blockIdx.x * BLOCK + jj;
+    if (!((diag & 4u) && vx != 12345.678))
+      pcv_spec_emit(i2, n, rec, lv.enc[L], vx, vy, vz, color, color_stride, intensity, rank, payload, inten_bits, wide, pool_ctr, pool_cap,
+                    stage ? okey : nullptr, opay, jj);
   }
-  int U = __builtin_amdgcn_readfirstlane(L);  // the wave's level counter (all lanes start at the same level: 0, or 1 for routed input)
-  if (diag & 1u) {
-    vx = px, vy = py, vz = pz;
-  } else if (lv.fast_ok && pcv_point_is_tame(px, py, pz)) {
-    PCV4_WALK(false)
-  } else {
-    PCV4_WALK(true)
+  if (stage) {  // input order again: full lines
+    __syncthreads();
+    const uint64_t o = (uint64_t)blockIdx.x * BLOCK + tid;
+    if (o < n && !(diag & 4u)) {
+      rank[o] = okey[tid];
+      reinterpret_cast<uint2*>(payload)[o] = opay[tid];
+    }
   }
-  // the record carries the codes of the first candidate on the path where there is one, else those of the predicted leaf
-  if (KEEP && kl) {
-    vx = kx, vy = ky, vz = kz;
-    L = kl;
-  }
-  if ((diag & 4u) && vx != 12345.678) return;
-  pcv_spec_emit(i, n, rec, lv.enc[L], vx, vy, vz, color, color_stride, intensity, rank, payload, inten_bits, wide, pool_ctr, pool_cap);
 }
 #undef PCV4_WALK
 #undef PCV4_LOOP
