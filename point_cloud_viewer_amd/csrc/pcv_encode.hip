@@ -110,7 +110,9 @@ __device__ __forceinline__ void pcv_spec_emit(uint64_t i, uint64_t n, uint32_t r
                                               uint4* __restrict__ wide, uint32_t* __restrict__ pool_ctr, uint32_t pool_cap,
                                               uint32_t* stage_key = nullptr /* LDS: the workgroup stores its 12-byte records itself */,
                                               uint2* stage_pay = nullptr, uint32_t stage_slot = 0) {
-  const uint32_t rgb = pcv_load_rgb(color + i * color_stride, i + 1 < n);
+  // staged records: the colour is OR-ed in by the lane that stores the record (input order: a coalesced load off the wave's
+  // critical path); otherwise it is fetched here
+  const uint32_t rgb = stage_key ? 0u : pcv_load_rgb(color + i * color_stride, i + 1 < n);
   const bool is_wide = leaf_enc > PCV_ENC_UINT16;
   // value domain -> raw code: the integer itself (u8 / u16), the IEEE bits of the float (Float32); single-chain builds have
   // no Float64-coded level (build_begin_impl sends those to the exact pipeline)
@@ -557,16 +559,26 @@ __global__ __launch_bounds__(BLOCK, 8) void spec_encode4_kernel(
     uint32_t jj = (uint32_t)j;
     asm volatile("" : "+v"(jj));
     const uint64_t i2 = (uint64_t)blockIdx.x * BLOCK + jj;
+    // encoding of the record's level: the table is monotone (Float64 -> Float32 -> u16 -> u8 with depth) unless first_f32 says
+    // "never" — three compares instead of a gather from the level table at the very end of the wave's critical path
+    uint32_t leaf_enc;
+    if (lv.first_f32 < (1 << 20))
+      leaf_enc = L >= lv.first_u8 ? PCV_ENC_UINT8 : L >= lv.first_u16 ? PCV_ENC_UINT16 : L >= lv.first_f32 ? PCV_ENC_FLOAT32 : lv.enc[0];
+    else
+      leaf_enc = lv.enc[L];
     if (!((diag & 4u) && vx != 12345.678))
-      pcv_spec_emit(i2, n, rec, lv.enc[L], vx, vy, vz, color, color_stride, intensity, rank, payload, inten_bits, wide, pool_ctr, pool_cap,
+      pcv_spec_emit(i2, n, rec, leaf_enc, vx, vy, vz, color, color_stride, intensity, rank, payload, inten_bits, wide, pool_ctr, pool_cap,
                     stage ? okey : nullptr, opay, jj);
   }
-  if (stage) {  // input order again: full lines
-    __syncthreads();
+  if (stage) {  // input order again: full lines; the colour joins here
     const uint64_t o = (uint64_t)blockIdx.x * BLOCK + tid;
+    uint32_t rgb = 0;
+    if (o < n) rgb = pcv_load_rgb(color + o * color_stride, o + 1 < n);
+    __syncthreads();
     if (o < n && !(diag & 4u)) {
-      rank[o] = okey[tid];
-      reinterpret_cast<uint2*>(payload)[o] = opay[tid];
+      const uint2 q = opay[tid];
+      rank[o] = okey[tid] | (rgb >> 16);
+      reinterpret_cast<uint2*>(payload)[o] = make_uint2(q.x, q.y | ((rgb & 0xffffu) << 16));
     }
   }
 }
