@@ -462,6 +462,7 @@ __global__ __launch_bounds__(BLOCK, 8) void spec_encode4_kernel(
     const uint8_t* __restrict__ depth_grid, float cells_per_unit /* 128 / root edge */, uint4* __restrict__ wide /* set: 12-byte records */,
     uint32_t* __restrict__ pool_ctr, uint32_t pool_cap, uint32_t lds_cap /* walk records the dynamic LDS has room for (a multiple of 4) */,
     const uint32_t* __restrict__ tree_info /* [0] = number of T'' nodes (spec_tree_scan_kernel) */,
+    uint32_t stagger /* see below */,
     uint32_t diag /* 0; libpcv_hip_exp.so PCV_CHAIN_DIAG (timing only, wrong records — the launcher runs the real pass afterwards):
                      1 = no walk, 2 = stop after the deal, 4 = no record stores, 8 = stop after the coordinate loads */) {
   __shared__ double sxyz[3 * BLOCK];
@@ -476,6 +477,15 @@ __global__ __launch_bounds__(BLOCK, 8) void spec_encode4_kernel(
   uint32_t* const okey = reinterpret_cast<uint32_t*>(sxyz);
   uint2* const opay = reinterpret_cast<uint2*>(sxyz + BLOCK);
   extern __shared__ uint32_t swalk[];  // the first lds_nodes walk records
+  // Phase stagger. A workgroup's life is a memory phase (coordinates, depth grid, the deal: nothing to issue) followed by an
+  // arithmetic phase (the walk). The four workgroups a CU holds start together at launch, take the same time, are replaced
+  // together — and stay in step: the phases of the pass ADD (tools/chain_diag.sh: 0.74 ms without the walk, 1.94 with it and
+  // without stores) where they should overlap. The first generation of workgroups therefore starts k quarters of a workgroup's
+  // life late (k = its slot on the CU, as far as the dispatch order lets us guess it); the shift then carries itself forward.
+  if (stagger && blockIdx.x < 1024u * 4u) {
+    const uint32_t k = (stagger >> 16) & 1u ? (blockIdx.x & 3u) : ((blockIdx.x >> 8) & 3u);
+    for (uint32_t w = k * (stagger & 0xffffu); w > 0; --w) __builtin_amdgcn_s_sleep(64);  // 64 x 64 clocks each
+  }
   const uint32_t tn4 = (tree_info[0] + 3u) & ~3u;  // (the table's allocation is a multiple of 256 bytes)
   const uint32_t lds_nodes = tn4 < lds_cap ? tn4 : lds_cap;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1242,6 +1252,10 @@ static void launch_spec_encode_t(pcv_ctx* ctx, const PcvLevels& lv, const uint32
       const char* e = pcv_experiment("PCV_CHAIN_DIAG");
       return e ? (uint32_t)atoi(e) : 0u;
     }();
+    static const uint32_t stagger = [] {
+      const char* e = pcv_experiment("PCV_CHAIN_STAGGER");  // units of 4 096 clocks per slot | mode << 16 (experiments)
+      return e ? (uint32_t)atoi(e) : 0u;
+    }();
     static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&spec_encode4_kernel<true, BLOCK>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
     (void)ok;
@@ -1254,7 +1268,7 @@ static void launch_spec_encode_t(pcv_ctx* ctx, const PcvLevels& lv, const uint32
         (void)hipEventRecord(e0, ctx->stream);
         hipLaunchKernelGGL((spec_encode4_kernel<true, BLOCK>), grid, dim3(BLOCK), (size_t)lds_nodes * 4, ctx->stream, lv, walk, n, x, y, z, routed,
                            color, color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr,
-                           pool_cap, lds_nodes, tree_info, d);
+                           pool_cap, lds_nodes, tree_info, stagger, d);
         (void)hipEventRecord(e1, ctx->stream);
         (void)hipEventSynchronize(e1);
         float ms = 0.f;
@@ -1268,7 +1282,7 @@ static void launch_spec_encode_t(pcv_ctx* ctx, const PcvLevels& lv, const uint32
 #endif
     hipLaunchKernelGGL((spec_encode4_kernel<true, BLOCK>), grid, dim3(BLOCK), (size_t)lds_nodes * 4, ctx->stream, lv, walk, n, x, y, z, routed,
                        color, color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr, pool_cap,
-                       lds_nodes, tree_info, 0u);
+                       lds_nodes, tree_info, stagger, 0u);
   } else {
     hipLaunchKernelGGL((spec_encode_kernel<true, BIN, BLOCK>), grid, dim3(BLOCK), 0, ctx->stream, lv, walk, n, x, y, z, routed, color,
                        color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr, pool_cap);
