@@ -462,7 +462,6 @@ __global__ __launch_bounds__(BLOCK, 8) void spec_encode4_kernel(
     const uint8_t* __restrict__ depth_grid, float cells_per_unit /* 128 / root edge */, uint4* __restrict__ wide /* set: 12-byte records */,
     uint32_t* __restrict__ pool_ctr, uint32_t pool_cap, uint32_t lds_cap /* walk records the dynamic LDS has room for (a multiple of 4) */,
     const uint32_t* __restrict__ tree_info /* [0] = number of T'' nodes (spec_tree_scan_kernel) */,
-    uint32_t stagger /* see below */,
     uint32_t diag /* 0; libpcv_hip_exp.so PCV_CHAIN_DIAG (timing only, wrong records — the launcher runs the real pass afterwards):
                      1 = no walk, 2 = stop after the deal, 4 = no record stores, 8 = stop after the coordinate loads */) {
   __shared__ double sxyz[3 * BLOCK];
@@ -477,15 +476,6 @@ __global__ __launch_bounds__(BLOCK, 8) void spec_encode4_kernel(
   uint32_t* const okey = reinterpret_cast<uint32_t*>(sxyz);
   uint2* const opay = reinterpret_cast<uint2*>(sxyz + BLOCK);
   extern __shared__ uint32_t swalk[];  // the first lds_nodes walk records
-  // Phase stagger. A workgroup's life is a memory phase (coordinates, depth grid, the deal: nothing to issue) followed by an
-  // arithmetic phase (the walk). The four workgroups a CU holds start together at launch, take the same time, are replaced
-  // together — and stay in step: the phases of the pass ADD (tools/chain_diag.sh: 0.74 ms without the walk, 1.94 with it and
-  // without stores) where they should overlap. The first generation of workgroups therefore starts k quarters of a workgroup's
-  // life late (k = its slot on the CU, as far as the dispatch order lets us guess it); the shift then carries itself forward.
-  if (stagger && blockIdx.x < 1024u * 4u) {
-    const uint32_t k = (stagger >> 16) & 1u ? (blockIdx.x & 3u) : ((blockIdx.x >> 8) & 3u);
-    for (uint32_t w = k * (stagger & 0xffffu); w > 0; --w) __builtin_amdgcn_s_sleep(64);  // 64 x 64 clocks each
-  }
   const uint32_t tn4 = (tree_info[0] + 3u) & ~3u;  // (the table's allocation is a multiple of 256 bytes)
   const uint32_t lds_nodes = tn4 < lds_cap ? tn4 : lds_cap;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1241,19 +1231,17 @@ static void launch_spec_encode_t(pcv_ctx* ctx, const PcvLevels& lv, const uint32
   const uint32_t pool_cap = (uint32_t)pcv_pool_region_entries(n);
   if (BIN) hipLaunchKernelGGL(spec_depth_grid_kernel, dim3((1u << (3 * kGridBits)) / 256), dim3(256), 0, ctx->stream, walk, depth_grid);
   if (BIN && v4) {
-    // walk records mirrored in LDS: as many as fit beside the deal's staging with the CU still full (8 waves per SIMD):
-    // workgroups of 512 -> 3 per CU hold 13.4 + 32 KB each, workgroups of 1 024 -> 2 per CU hold 26.8 + 48 KB each
+    // walk records mirrored in LDS (PCV_CHAIN_LDS=entries, libpcv_hip_exp.so): measured and NOT shipped — with 4 096 / 6 144 /
+    // 8 192 entries per workgroup of 512 (12 288 per 1 024) the pass takes 2.12-2.35 ms against 2.04 without: copying the
+    // table (30 KB per 512 points) costs the prologue what the LDS gathers save the walk, and above 5 000 entries a CU holds
+    // three workgroups instead of four (profiles/r04_chain_pass_breakdown.json)
     static const uint32_t lds_cap = [] {
-      const char* e = pcv_experiment("PCV_CHAIN_LDS");  // experiments: entries (0 = the table stays in global memory)
-      return e ? (uint32_t)atoi(e) : (BLOCK >= 1024 ? 12288u : 8192u);
+      const char* e = pcv_experiment("PCV_CHAIN_LDS");
+      return e ? (uint32_t)atoi(e) : 0u;
     }();
     const uint32_t lds_nodes = lds_cap & ~3u;
     static const uint32_t diag = [] {
       const char* e = pcv_experiment("PCV_CHAIN_DIAG");
-      return e ? (uint32_t)atoi(e) : 0u;
-    }();
-    static const uint32_t stagger = [] {
-      const char* e = pcv_experiment("PCV_CHAIN_STAGGER");  // units of 4 096 clocks per slot | mode << 16 (experiments)
       return e ? (uint32_t)atoi(e) : 0u;
     }();
     static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&spec_encode4_kernel<true, BLOCK>),
@@ -1268,7 +1256,7 @@ static void launch_spec_encode_t(pcv_ctx* ctx, const PcvLevels& lv, const uint32
         (void)hipEventRecord(e0, ctx->stream);
         hipLaunchKernelGGL((spec_encode4_kernel<true, BLOCK>), grid, dim3(BLOCK), (size_t)lds_nodes * 4, ctx->stream, lv, walk, n, x, y, z, routed,
                            color, color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr,
-                           pool_cap, lds_nodes, tree_info, stagger, d);
+                           pool_cap, lds_nodes, tree_info, d);
         (void)hipEventRecord(e1, ctx->stream);
         (void)hipEventSynchronize(e1);
         float ms = 0.f;
@@ -1282,7 +1270,7 @@ static void launch_spec_encode_t(pcv_ctx* ctx, const PcvLevels& lv, const uint32
 #endif
     hipLaunchKernelGGL((spec_encode4_kernel<true, BLOCK>), grid, dim3(BLOCK), (size_t)lds_nodes * 4, ctx->stream, lv, walk, n, x, y, z, routed,
                        color, color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr, pool_cap,
-                       lds_nodes, tree_info, stagger, 0u);
+                       lds_nodes, tree_info, 0u);
   } else {
     hipLaunchKernelGGL((spec_encode_kernel<true, BIN, BLOCK>), grid, dim3(BLOCK), 0, ctx->stream, lv, walk, n, x, y, z, routed, color,
                        color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr, pool_cap);
