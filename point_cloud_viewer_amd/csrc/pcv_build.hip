@@ -1174,7 +1174,7 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
     return !e || atoi(e) != 0;
   }();
   bs->spec_rows = nullptr;
-  if (rows_on && compact && tree.num_leaves <= 16384 && tree.num_leaves <= pcv_rank_hist_max_bins()) {
+  if (rows_on && compact && tree.num_leaves <= pcv_rank_hist_max_bins()) {
     int sgroups;
     uint64_t schunk;
     pcv_sort_rec12_geometry(n, &sgroups, &schunk);

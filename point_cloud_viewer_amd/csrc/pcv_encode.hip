@@ -721,13 +721,15 @@ __global__ __launch_bounds__(BLOCK, PREFETCH ? 6 : 8) void spec_encode_persist_k
 
 // Exact number of points per predicted leaf: LDS-privatised histogram of the rank array over the bins
 // [bin_base, bin_base + nbins), nbins <= kHistBins; one flush of the non-zero bins per workgroup.
-constexpr int kHistBins = 16384;  // 64 KiB of LDS
+constexpr int kHistBins = 16384;      // 64 KiB of LDS: the plain count (512 workgroups, two to a CU)
+constexpr int kHistBinsRows = 32768;  // 128 KiB: the count over the record sort's workgroups with the rows kept (one to a CU)
 __global__ __launch_bounds__(1024) void rank_hist_kernel(const uint32_t* __restrict__ rank, uint64_t n, uint64_t chunk,
                                                           uint32_t bin_base, uint32_t nbins, uint32_t* __restrict__ counts,
                                                           int shift /* 8: 12-byte records, the rank sits above the blue byte */,
                                                           uint32_t* __restrict__ rows /* set: this workgroup's histogram is kept,
-                                                                                         rows[blockIdx.x * nbins + b] */) {
-  __shared__ uint32_t hist[kHistBins];
+                                                                                         rows[blockIdx.x * row_stride + bin_base + b] */,
+                                                          uint32_t row_stride) {
+  extern __shared__ uint32_t hist[];  // nbins counters
   for (uint32_t b = threadIdx.x; b < nbins; b += 1024) hist[b] = 0;
   __syncthreads();
   const uint64_t begin = (uint64_t)blockIdx.x * chunk;
@@ -753,7 +755,7 @@ __global__ __launch_bounds__(1024) void rank_hist_kernel(const uint32_t* __restr
   for (uint32_t b = threadIdx.x; b < nbins; b += 1024) {
     const uint32_t v = hist[b];
     if (v) atomicAdd(&counts[bin_base + b], v);
-    if (rows) rows[(uint64_t)blockIdx.x * nbins + b] = v;
+    if (rows) rows[(uint64_t)blockIdx.x * row_stride + bin_base + b] = v;
   }
 }
 
@@ -1351,20 +1353,28 @@ void pcv_launch_rank_hist(pcv_ctx* ctx, const uint32_t* rank, uint64_t n, uint32
   for (uint32_t base = 0; base < num_bins; base += kHistBins) {
     const uint32_t nb = num_bins - base < (uint32_t)kHistBins ? num_bins - base : (uint32_t)kHistBins;
     PcvProf prof(ctx, PCV_K_RANK_HIST);
-    hipLaunchKernelGGL(rank_hist_kernel, dim3(groups), dim3(1024), 0, ctx->stream, rank, n, chunk, base, nb, counts, shift,
-                       (uint32_t*)nullptr);
+    hipLaunchKernelGGL(rank_hist_kernel, dim3(groups), dim3(1024), (size_t)nb * 4, ctx->stream, rank, n, chunk, base, nb, counts, shift,
+                       (uint32_t*)nullptr, 0u);
   }
 }
 
 // The same count over the workgroups and chunks of the record sort (pcv_sort_rec12_geometry), every workgroup's histogram kept
 // as a row: the sort's first pass derives its digit histogram from the rows and the rank map (pcv_sort.hip) instead of
-// reading the keys once more. num_bins <= pcv_rank_hist_max_bins().
-uint32_t pcv_rank_hist_max_bins() { return (uint32_t)kHistBins; }
+// reading the keys once more. Up to 32 768 bins per launch (128 KB of LDS, one workgroup per CU: the sort's own occupancy);
+// bigger trees (1 B points: ~50 000 predicted nodes) take one launch per 32 768 bins. num_bins <= pcv_rank_hist_max_bins().
+uint32_t pcv_rank_hist_max_bins() { return 1u << 18; }
 void pcv_launch_rank_hist_rows(pcv_ctx* ctx, const uint32_t* rank, uint64_t n, uint32_t num_bins, uint32_t* counts, int shift,
                                int groups, uint64_t chunk, uint32_t* rows) {
   if (n == 0 || num_bins == 0) return;
-  PcvProf prof(ctx, PCV_K_RANK_HIST);
-  hipLaunchKernelGGL(rank_hist_kernel, dim3(groups), dim3(1024), 0, ctx->stream, rank, n, chunk, 0u, num_bins, counts, shift, rows);
+  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&rank_hist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             kHistBinsRows * 4) == hipSuccess;
+  (void)ok;
+  for (uint32_t base = 0; base < num_bins; base += kHistBinsRows) {
+    const uint32_t nb = num_bins - base < (uint32_t)kHistBinsRows ? num_bins - base : (uint32_t)kHistBinsRows;
+    PcvProf prof(ctx, PCV_K_RANK_HIST);
+    hipLaunchKernelGGL(rank_hist_kernel, dim3(groups), dim3(1024), (size_t)nb * 4, ctx->stream, rank, n, chunk, base, nb, counts, shift, rows,
+                       num_bins);
+  }
 }
 
 size_t pcv_cont_range_bytes() { return sizeof(PcvContRange); }

@@ -590,7 +590,7 @@ struct DigitStateN {
 // the keys still carry PREDICTED leaf ranks; they are translated through the rank map (a copy in dynamic LDS) as they are
 // loaded — rank := map[rank], and where the map flags a replayed leaf (bit 30) the record's first payload word becomes its
 // input index — which is what upsweep_map_kernel does in a pass of its own otherwise.
-template <int BLOCK, int KPT, int R, int WPE, bool NT, bool MAP = false>
+template <int BLOCK, int KPT, int R, int WPE, bool NT, int MAP = 0 /* 1: the map in LDS (half words), 2: in global memory */>
 __global__ __launch_bounds__(BLOCK, WPE) void downsweep_rec12_kernel(const uint32_t* __restrict__ keys_in,
                                                                      uint32_t* __restrict__ keys_out, uint64_t n, uint64_t chunk,
                                                                      int groups, int shift, int nbits,
@@ -611,7 +611,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void downsweep_rec12_kernel(const uint3
   extern __shared__ uint16_t smap_dyn[];  // MAP: map_entries half words: true rank (< 2^15) | replay mark << 15
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const uint32_t mask = (1u << nbits) - 1u;
-  if (MAP)
+  if (MAP == 1)
     for (uint32_t i = t; i < map_entries; i += BLOCK) {  // visible after the first barrier below
       const uint32_t m = gmap[i];
       smap_dyn[i] = (uint16_t)((m & 0x7fffu) | (((m >> 30) & 1u) << 15));
@@ -661,13 +661,26 @@ __global__ __launch_bounds__(BLOCK, WPE) void downsweep_rec12_kernel(const uint3
         vec[i] = valid ? vp[i * 64] : make_uint2(0u, 0u);
       }
     }
-    if (MAP) {
+    if (MAP == 1) {
 #pragma unroll
       for (int i = 0; i < KPT; ++i) {
         const uint32_t pr = key[i] >> 8;
         const uint32_t m = smap_dyn[pr < map_entries ? pr : 0u];
         if (__builtin_expect((m & 0x8000u) != 0u, 0)) vec[i].x = (uint32_t)(base + wbase + i * 64);  // replay: the input index
         key[i] = ((m & 0x7fffu) << 8) | (key[i] & 0xffu);
+      }
+    }
+    if (MAP == 2) {  // trees of more than 16 384 predicted nodes: the map (4 bytes per node, L2-resident) is gathered as it is
+      uint32_t m[KPT];
+#pragma unroll
+      for (int i = 0; i < KPT; ++i) {
+        const uint32_t pr = key[i] >> 8;
+        m[i] = gmap[pr < map_entries ? pr : 0u];
+      }
+#pragma unroll
+      for (int i = 0; i < KPT; ++i) {
+        if (__builtin_expect((m[i] & (1u << 30)) != 0u, 0)) vec[i].x = (uint32_t)(base + wbase + i * 64);  // replay: the input index
+        key[i] = ((m[i] & PCV_SPEC_INDEX_MASK_SORT) << 8) | (key[i] & 0xffu);
       }
     }
   };
@@ -933,15 +946,16 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
     KeyT* dst = in_a ? b : a;
     // the histogram from the rank counts, the map applied inside the downsweep (12-byte records in tiles of 8 192; the map in
     // dynamic LDS next to the kernel's 107-117 KB: up to 16 384 half-word entries)
-    const bool from_rows = map && rows && shift == begin_bit && rec12 && rec_variant == 3 && map_entries <= 16384 && nbits <= 8;
+    const bool from_rows = map && rows && shift == begin_bit && rec12 && rec_variant == 3 && nbits <= 8;
+    const bool map_in_lds = map_entries <= 16384;  // half words in <= 32 KB beside the kernel's 107-117 KB
     if (from_rows) {
       static const bool pass2_rows_on = [] {
         const char* e = pcv_experiment("PCV_SORT_ROWS2");  // 0 = the second pass counts its keys itself (experiments)
         return !e || atoi(e) != 0;
       }();
       const int nbits2 = end_bit - (shift + width) < width ? end_bit - (shift + width) : width;
-      const bool two = pass2_rows_on && shift + width < end_bit && shift + 2 * width >= end_bit && total_bits <= 14 && nbits2 >= 1 &&
-                       g.groups >= 8;
+      const bool two = pass2_rows_on && map_in_lds && shift + width < end_bit && shift + 2 * width >= end_bit && total_bits <= 14 &&
+                       nbits2 >= 1 && g.groups >= 8;
       uint32_t* hist2 = totals + kRadix;
       uint32_t* totals2 = hist2 + (size_t)kRadix * kMaxGroups;
       uint2* ranges = reinterpret_cast<uint2*>(totals2 + kRadix);
@@ -960,26 +974,25 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
         PcvProf prof(ctx, PCV_K_SORT_SCAN);
         hipLaunchKernelGGL(scan_kernel, dim3(kRadix), dim3(256), 0, ctx->stream, hist, g.groups, totals);
       }
-      const size_t dyn = ((size_t)map_entries * 2 + 15) & ~(size_t)15;
+      const size_t dyn = map_in_lds ? (((size_t)map_entries * 2 + 15) & ~(size_t)15) : 0;
       const uint2* vin = (const uint2*)(in_a ? payload->vec_in : payload->vec_out);
       uint2* vout = (uint2*)(in_a ? payload->vec_out : payload->vec_in);
       {
         PcvProf prof(ctx, PCV_K_SORT_DOWNSWEEP_REC);
-        if (nbits <= 7) {
-          static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&downsweep_rec12_kernel<1024, 8, 128, 4, false, true>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 32768) == hipSuccess;
-          (void)ok;
-          hipLaunchKernelGGL((downsweep_rec12_kernel<1024, 8, 128, 4, false, true>), dim3(g.groups), dim3(1024), dyn, ctx->stream,
-                             (const uint32_t*)src, (uint32_t*)dst, n, g.chunk, g.groups, shift, nbits, hist, totals, vin, vout, map,
-                             map_entries, (const uint2*)nullptr);
-        } else {
-          static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&downsweep_rec12_kernel<1024, 8, 256, 4, false, true>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 32768) == hipSuccess;
-          (void)ok;
-          hipLaunchKernelGGL((downsweep_rec12_kernel<1024, 8, 256, 4, false, true>), dim3(g.groups), dim3(1024), dyn, ctx->stream,
-                             (const uint32_t*)src, (uint32_t*)dst, n, g.chunk, g.groups, shift, nbits, hist, totals, vin, vout, map,
-                             map_entries, (const uint2*)nullptr);
-        }
+#define PCV_REC12_MAP(R, M)                                                                                                              \
+  {                                                                                                                                      \
+    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&downsweep_rec12_kernel<1024, 8, R, 4, false, M>),           \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 32768) == hipSuccess;                          \
+    (void)ok;                                                                                                                            \
+    hipLaunchKernelGGL((downsweep_rec12_kernel<1024, 8, R, 4, false, M>), dim3(g.groups), dim3(1024), dyn, ctx->stream,                   \
+                       (const uint32_t*)src, (uint32_t*)dst, n, g.chunk, g.groups, shift, nbits, hist, totals, vin, vout, map, map_entries, \
+                       (const uint2*)nullptr);                                                                                            \
+  }
+        if (nbits <= 7 && map_in_lds) PCV_REC12_MAP(128, 1)
+        else if (map_in_lds) PCV_REC12_MAP(256, 1)
+        else if (nbits <= 7) PCV_REC12_MAP(128, 2)
+        else PCV_REC12_MAP(256, 2)
+#undef PCV_REC12_MAP
       }
       in_a = !in_a;
       if (!two) continue;
@@ -1006,11 +1019,11 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
         const uint2* vin2 = (const uint2*)(in_a ? payload->vec_in : payload->vec_out);
         uint2* vout2 = (uint2*)(in_a ? payload->vec_out : payload->vec_in);
         if (nbits2 <= 7)
-          hipLaunchKernelGGL((downsweep_rec12_kernel<1024, 8, 128, 4, false, false>), dim3(pieces), dim3(1024), 0, ctx->stream, src2, dst2, n,
+          hipLaunchKernelGGL((downsweep_rec12_kernel<1024, 8, 128, 4, false, 0>), dim3(pieces), dim3(1024), 0, ctx->stream, src2, dst2, n,
                              g.chunk, pieces, shift + width, nbits2, hist2, totals2, vin2, vout2, (const uint32_t*)nullptr, 0u,
                              (const uint2*)ranges, (const uint32_t*)order);
         else
-          hipLaunchKernelGGL((downsweep_rec12_kernel<1024, 8, 256, 4, false, false>), dim3(pieces), dim3(1024), 0, ctx->stream, src2, dst2, n,
+          hipLaunchKernelGGL((downsweep_rec12_kernel<1024, 8, 256, 4, false, 0>), dim3(pieces), dim3(1024), 0, ctx->stream, src2, dst2, n,
                              g.chunk, pieces, shift + width, nbits2, hist2, totals2, vin2, vout2, (const uint32_t*)nullptr, 0u,
                              (const uint2*)ranges, (const uint32_t*)order);
       }
