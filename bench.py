@@ -56,6 +56,44 @@ ALGO_BYTES = {
 VALU_F64_BOUND = ("leaf_encode_kernel", "chain_keys_kernel", "spec_encode_kernel")
 
 
+def valu_issue_model(insts, n, launch_ms):
+    """VALU issue time of one launch from DYNAMIC counters x MEASURED issue costs: per instruction class the
+    wave-instruction count of the rocprofv3 pass (f64 add / mul / fma; conversions; the rest, split by the static mix of the
+    kernel text into f64-pipe compares / min / max / trunc, 32-bit compares and plain 32-bit instructions) x the SIMD cycles one
+    wave64 instruction of that class holds its SIMD (tools/f64_rate.hip -> profiles/<round>_f64_rate.json, measured at the clock
+    the part sustained under that class), summed and divided by the SIMD cycles the launch had: 1 024 SIMDs x the clock the part
+    sustained DURING THIS KERNEL (GRBM_GUI_ACTIVE / duration of the counter pass) x the launch time measured here."""
+    path = os.path.join(ROOT, "profiles", f"{ROUND}_f64_rate.json")
+    if not os.path.exists(path):
+        return {"frac": None, "note": "no f64-rate probe recorded for this round (tools/f64_rate.sh)"}
+    with open(path) as f:
+        rate = json.load(f)
+    by = {r["inst"]: r["cycles_at_sustained_clock"] or r["cycles_at_2.4GHz"] for r in rate["per_instruction"]}
+    mean = lambda names: sum(by[k] for k in names) / len(names)
+    cyc = {"f64_add_mul_fma": mean(["v_fma_f64", "v_add_f64", "v_mul_f64"]),
+           "f64_convert": mean(["v_cvt_f32_f64", "v_cvt_f64_f32", "v_cvt_u32_f64", "v_cvt_f64_u32"]),
+           "f64_compare_minmax_trunc": mean(["v_trunc_f64", "v_max_f64", "v_cmp_gt_f64"]),
+           "b32_compare": by["v_cmp_lt_u32"],
+           "b32_plain": mean(["v_add_u32", "v_and_b32", "v_mov_b32", "v_fma_f32"])}
+    rest = insts.get("rest_insts_per_point")
+    if rest is None:
+        return {"frac": None, "note": "the profile predates the per-class counters"}
+    s64, s32 = insts.get("rest_static_share_f64_other") or 0.0, insts.get("rest_static_share_cmp32") or 0.0
+    per_point = {"f64_add_mul_fma": insts["f64_arith_insts_per_point"], "f64_convert": insts["cvt_insts_per_point"],
+                 "f64_compare_minmax_trunc": rest * s64, "b32_compare": rest * s32, "b32_plain": rest * (1.0 - s64 - s32)}
+    clock = insts.get("sustained_clock_GHz") or 2.4
+    cycles_per_point = sum(per_point[k] * cyc[k] for k in cyc)  # lane-instructions x cycles per wave64 instruction
+    simd_cycles = cycles_per_point * n / 64.0                    # wave instructions = lane instructions / 64
+    have = 1024 * clock * 1e9 * launch_ms * 1e-3
+    return {"frac": round(simd_cycles / have, 4), "sustained_clock_GHz": clock,
+            "cycles_per_class": {k: round(v, 3) for k, v in cyc.items()},
+            "lane_insts_per_point_per_class": {k: round(v, 2) for k, v in per_point.items()},
+            "simd_cycles_per_wave": round(cycles_per_point, 1), "simds": 1024,
+            "source": os.path.relpath(path, ROOT) + " (issue costs) x the SQ_INSTS_VALU_* counters and GRBM_GUI_ACTIVE of this round's "
+                      "rocprofv3 passes; the split of the instructions that are neither f64 add / mul / fma nor conversions follows the "
+                      "static mix of the kernel text (tools/isa_mix.py)"}
+
+
 def make_cloud(torch, n, seed, device, clusters=64, extent=1000.0, sigma=(1.0, 20.0), chunk=1 << 24,
                offset=(0.0, 0.0, 0.0)):
     """Config-2 distribution generated on the device (centres/sigmas from a host generator so every rank
@@ -809,7 +847,8 @@ def main():
             # the library's event names and the rocprof kernel names differ for some kernels (the profile lists the larger
             # launch where one kernel runs with several key widths: the u32 upsweep, not the sample's u64 one)
             alias = {"promote_settle_kernel": "promote_settle_leaf_kernel", "promote_climb_kernel": "promote_climb_leaf_kernel",
-                     "downsweep_rec_kernel": "downsweep_rec12_kernel", "upsweep_kernel<u32>": "upsweep_kernel"}
+                     "downsweep_rec_kernel": "downsweep_rec12_kernel", "upsweep_kernel<u32>": "upsweep_kernel",
+                     "spec_encode_kernel": "spec_encode4_kernel"}
             return per.get(name, per.get(alias.get(name, name))), os.path.relpath(path, ROOT)
 
         dom = max(timed, key=lambda k: timed[k][1])  # dominant kernel by accumulated time inside the timed region
@@ -824,12 +863,8 @@ def main():
                         "avg_launch_ms": view["avg_launch_ms"], "launches": view["launches"]}
             if insts:
                 g = insts["f64_valu_insts_per_point"] * n / (view["avg_launch_ms"] * 1e-3) / 1e9
-                # every wave64 VALU instruction (f64 or not) holds its SIMD for the same 4 clocks, so all of them compete for
-                # the one issue roof: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = the same 39.3 T lane-instructions/s
-                gv = insts["valu_insts_per_point"] * n / (view["avg_launch_ms"] * 1e-3) / 1e9
                 roofline.update({"achieved": round(g, 1), "frac": round(g / F64_VALU_PEAK_GINST, 4),
-                                 "valu_issue": {"achieved": round(gv, 1), "peak": F64_VALU_PEAK_GINST, "unit": "G VALU lane-inst/s",
-                                                "frac": round(gv / F64_VALU_PEAK_GINST, 4)},
+                                 "valu_issue": valu_issue_model(insts, n, view["avg_launch_ms"]),
                                  "valu_insts_per_point": insts["valu_insts_per_point"],
                                  "f64_arithmetic_insts_per_point": insts["f64_valu_insts_per_point"],
                                  "f64_arithmetic_share_of_valu": insts["f64_share"],

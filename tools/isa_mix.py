@@ -20,6 +20,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "point_cloud_viewer_amd", "csrc")
 FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "--offload-arch=gfx950", "--cuda-device-only", "-S"]
 F64 = re.compile(r"^v_\w*f64\w*|^v_cvt_\w*f64|^v_cvt_f64_\w+|^v_ldexp_f64|^v_frexp_\w*f64|^v_rcp_f64|^v_div_\w*f64|^v_trig_preop_f64")
+# classes of the issue-cost model (tools/f64_rate.hip measures one representative of each): f64 add / mul / fma; conversions
+# from / to f64; the other f64-pipe instructions (compare, min / max, trunc ...); 32-bit compares (they write a lane mask: as
+# slow as an f64 instruction); everything else (32-bit ALU, moves, selects)
+F64_ARITH = re.compile(r"^v_(add|mul|fma|fmac)_f64")
+CVT = re.compile(r"^v_cvt_")
+CMP32 = re.compile(r"^v_cmpx?_\w+_(u32|i32|u16|i16|f32|u64|i64)")
 
 
 def demangle(name):
@@ -43,7 +49,7 @@ def mix_of(source):
         m = re.match(r"^(_Z\w+):", line)
         if m:
             cur = demangle(m.group(1))
-            out[cur] = {"valu": 0, "f64_valu": 0}
+            out[cur] = {"valu": 0, "f64_valu": 0, "f64_arith": 0, "cvt": 0, "f64_other": 0, "cmp32": 0}
             continue
         if cur is None:
             continue
@@ -56,6 +62,14 @@ def mix_of(source):
             out[cur]["valu"] += 1
             if F64.match(op):
                 out[cur]["f64_valu"] += 1
+            if F64_ARITH.match(op):
+                out[cur]["f64_arith"] += 1
+            elif CVT.match(op):
+                out[cur]["cvt"] += 1
+            elif F64.match(op):
+                out[cur]["f64_other"] += 1
+            elif CMP32.match(op):
+                out[cur]["cmp32"] += 1
     for name, meta in re.findall(r"\.name:\s+(_Z\w+)\n((?:\s+\.\w+:.*\n)+)", text):
         k = demangle(name)
         if k in out:

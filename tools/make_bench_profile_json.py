@@ -45,16 +45,32 @@ def main():
         name = row["kernel"].split("<")[0]
         waves = float(row["SQ_WAVES"]) or 1.0
         valu = float(row["SQ_INSTS_VALU"])
-        f64 = sum(float(row.get(k, 0) or 0) for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64",
-                                                      "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"))
+        arith = sum(float(row.get(k, 0) or 0) for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64"))
+        trans = float(row.get("SQ_INSTS_VALU_TRANS_F64", 0) or 0)
+        cvt = float(row.get("SQ_INSTS_VALU_CVT", 0) or 0)
+        f64 = arith + trans
         if name in per and per[name]["_valu"] >= valu:
             continue  # several launches with different shapes: keep the big one
         static = next((v for k, v in mix.items() if k.split("<")[0] == name and k == row["kernel"].replace("unsigned int", "unsigned int")), None)
         if static is None:
             static = next((v for k, v in mix.items() if k.split("<")[0] == name), {})
+        # sustained clock during THIS dispatch: GRBM_GUI_ACTIVE (summed over the 8 XCDs by the rocpd view) / its duration
+        gui, ns = float(row.get("GRBM_GUI_ACTIVE", 0) or 0), float(row.get("ns_under_counters", 0) or 0)
+        clock = (gui / ns) if gui and ns else None
+        if clock and clock > 4.0:
+            clock /= 8.0
+        # the instructions that are neither f64 add / mul / fma nor conversions, split by the static mix of the kernel text into
+        # f64-pipe ones (compare, min / max, trunc), 32-bit compares and plain 32-bit instructions
+        rest_static = max(1, static.get("valu", 0) - static.get("f64_arith", 0) - static.get("cvt", 0)) if static else 1
         per[name] = {"_valu": valu, "kernel": row["kernel"],
                      "valu_insts_per_point": round(valu * 64.0 / a.points, 2),
                      "f64_valu_insts_per_point": round(f64 * 64.0 / a.points, 2),
+                     "f64_arith_insts_per_point": round(arith * 64.0 / a.points, 2),
+                     "cvt_insts_per_point": round(cvt * 64.0 / a.points, 2),
+                     "rest_insts_per_point": round((valu - arith - trans - cvt) * 64.0 / a.points, 2),
+                     "rest_static_share_f64_other": round(static.get("f64_other", 0) / rest_static, 4) if static else None,
+                     "rest_static_share_cmp32": round(static.get("cmp32", 0) / rest_static, 4) if static else None,
+                     "sustained_clock_GHz": None if clock is None else round(clock, 3),
                      "f64_share": round(f64 / valu, 4) if valu else 0.0,
                      "f64_share_static_isa": static.get("f64_share"),
                      "valu_per_wave": round(valu / waves, 1)}

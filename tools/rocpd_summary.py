@@ -60,10 +60,14 @@ def main():
     if a.sq:
         cur = sqlite3.connect(a.sq).cursor()
         acc = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
-        for name, cn, val in cur.execute("select kernel_name,counter_name,value from counters_collection"):
+        for name, cn, val, dur in cur.execute("select kernel_name,counter_name,value,duration from counters_collection"):
             c = acc[short(name)][cn]
             c[0] += 1
             c[1] += val
+            d = acc[short(name)]["ns_under_counters"]  # the dispatch's own duration in this pass (for GRBM_GUI_ACTIVE -> clock)
+            if cn == "SQ_WAVES":
+                d[0] += 1
+                d[1] += dur or 0.0
         names = sorted({cn for k in acc.values() for cn in k})
         rows = []
         for k, c in acc.items():
