@@ -889,21 +889,9 @@ struct PromoteOut {
 // The point at position j of node `cur`'s stream stays there: final rewrite (encode(decode(code)) at the node's own level —
 // not idempotent, SURVEY F5 — unless the node is the root, which keeps what it receives) and the stores, as straight-line
 // code for one encoding.
-// Leaf-wise settle: the finished bytes of a workgroup (<= 1 024 consecutive slots of ONE leaf -> one contiguous piece of the
-// leaf's .xyz and of its .rgb) are collected in LDS and leave as 16-byte stores. Written straight from the lanes they are
-// six byte / half-word stores per point, every one of them a wave-instruction that touches two or three lines with a
-// byte mask: by round 4's counters the kernel spent 64 % of its cycles on L1 tag look-ups and 86 % stalled on pending
-// ones (7.7 M store instructions for 3.3 M loads, profiles/r04_chain_pass_v4_before_lds_walk_counters.json) at 45 % of the
-// HBM roof. The LDS image starts at the skew of the global address (mod 16), so aligned 16-byte chunks of one are aligned
-// chunks of the other.
-struct PcvStage {
-  uint8_t* xyz;  // LDS
-  uint8_t* rgb;  // LDS
-  uint32_t slot_base;  // first output slot of the workgroup inside the leaf's blob
-};
 template <int ENC, bool CLIMB>
 __device__ __forceinline__ void promote_final(const PcvNodeRec& cur, uint32_t j, uint64_t (&code)[3], uint32_t rgb,
-                                              uint32_t inten, const PromoteOut& o, const PcvStage* st = nullptr) {
+                                              uint32_t inten, const PromoteOut& o) {
   uint32_t slot = j;
   if (cur.parent != 0xffffffffu) {
     slot = j - (j >> 3) - 1u;
@@ -926,23 +914,6 @@ __device__ __forceinline__ void promote_final(const PcvNodeRec& cur, uint32_t j,
 #if PCV_SETTLE_DIAG == 1
   if (!CLIMB && code[0] != 0x7fffffffffffull) return;
 #endif
-  if (!CLIMB && st && ENC != PCV_ENC_FLOAT64) {  // (the caller has put the images at the skew of their global addresses)
-    const uint32_t local = slot - st->slot_base;
-    if (ENC == PCV_ENC_UINT8) {
-      uint8_t* d = st->xyz + local * 3u;
-      d[0] = (uint8_t)code[0], d[1] = (uint8_t)code[1], d[2] = (uint8_t)code[2];
-    } else if (ENC == PCV_ENC_UINT16) {
-      uint16_t* d = reinterpret_cast<uint16_t*>(st->xyz + local * 6u);
-      d[0] = (uint16_t)code[0], d[1] = (uint16_t)code[1], d[2] = (uint16_t)code[2];
-    } else {
-      uint32_t* d = reinterpret_cast<uint32_t*>(st->xyz + local * 12u);
-      d[0] = (uint32_t)code[0], d[1] = (uint32_t)code[1], d[2] = (uint32_t)code[2];
-    }
-    uint8_t* cd = st->rgb + local * 3u;
-    cd[0] = (uint8_t)rgb, cd[1] = (uint8_t)(rgb >> 8), cd[2] = (uint8_t)(rgb >> 16);
-    if (o.inten_blob) reinterpret_cast<uint32_t*>(o.inten_blob)[cur.point_off + slot] = inten;
-    return;
-  }
   uint8_t* dst = o.xyz_blob + cur.xyz_off;
   if (ENC == PCV_ENC_UINT8) {
     uint8_t* d = dst + (uint64_t)slot * 3;
@@ -976,8 +947,7 @@ __device__ __forceinline__ void promote_final(const PcvNodeRec& cur, uint32_t j,
 // One sorted slot: climb, final encode, store. CLIMB = false: the caller knows the point stays in its leaf.
 template <bool CLIMB>
 __device__ __forceinline__ void promote_one(const PcvPromoteTables& pt, uint64_t s, PcvNodeRec cur, uint4 pay,
-                                            uint32_t hx, uint32_t hy, uint32_t hz, uint32_t inten, const PromoteOut& o,
-                                            const PcvStage* st = nullptr) {
+                                            uint32_t hx, uint32_t hy, uint32_t hz, uint32_t inten, const PromoteOut& o) {
   uint32_t j = (uint32_t)s - cur.lo;
   uint64_t code[3] = {pay.x | ((uint64_t)hx << 32), pay.y | ((uint64_t)hy << 32), pay.z | ((uint64_t)hz << 32)};
   // climb while this point is an every-8th element of its node's stream
@@ -992,10 +962,10 @@ __device__ __forceinline__ void promote_one(const PcvPromoteTables& pt, uint64_t
     cur = par;
   }
   switch (cur.enc) {  // the node's encoding is wave-uniform in `settle` (one leaf per workgroup): one scalar branch
-    case PCV_ENC_UINT8: return promote_final<PCV_ENC_UINT8, CLIMB>(cur, j, code, pay.w, inten, o, st);
-    case PCV_ENC_UINT16: return promote_final<PCV_ENC_UINT16, CLIMB>(cur, j, code, pay.w, inten, o, st);
-    case PCV_ENC_FLOAT32: return promote_final<PCV_ENC_FLOAT32, CLIMB>(cur, j, code, pay.w, inten, o, st);
-    default: return promote_final<PCV_ENC_FLOAT64, CLIMB>(cur, j, code, pay.w, inten, o, st);
+    case PCV_ENC_UINT8: return promote_final<PCV_ENC_UINT8, CLIMB>(cur, j, code, pay.w, inten, o);
+    case PCV_ENC_UINT16: return promote_final<PCV_ENC_UINT16, CLIMB>(cur, j, code, pay.w, inten, o);
+    case PCV_ENC_FLOAT32: return promote_final<PCV_ENC_FLOAT32, CLIMB>(cur, j, code, pay.w, inten, o);
+    default: return promote_final<PCV_ENC_FLOAT64, CLIMB>(cur, j, code, pay.w, inten, o);
   }
 }
 
@@ -1029,7 +999,7 @@ template <bool kCompact, bool kClimb16 = false>
 __device__ __forceinline__ void settle_one(const PcvPromoteTables& pt, uint64_t s, const PcvNodeRec& c, uint32_t r, uint4 p,
                                            const uint32_t h[3], uint32_t inten, const uint32_t* __restrict__ climb_base,
                                            PcvClimber* __restrict__ climbers, const PromoteOut& o,
-                                           const uint4* __restrict__ wide, const PcvStage* st = nullptr) {
+                                           const uint4* __restrict__ wide) {
   if (kCompact) {
     if (c.enc <= PCV_ENC_UINT16) {
       p.y = p.x >> 16;
@@ -1040,7 +1010,7 @@ __device__ __forceinline__ void settle_one(const PcvPromoteTables& pt, uint64_t 
     }
   }
   const uint32_t j = (uint32_t)s - c.lo;
-  if (c.parent == 0xffffffffu || (j & 7u) != 0) promote_one<false>(pt, s, c, p, h[0], h[1], h[2], inten, o, st);
+  if (c.parent == 0xffffffffu || (j & 7u) != 0) promote_one<false>(pt, s, c, p, h[0], h[1], h[2], inten, o);
   else if (kClimb16) reinterpret_cast<uint4*>(climbers)[climb_base[r] + (j >> 3)] = p;
   else climbers[climb_base[r] + (j >> 3)] = PcvClimber{p, r, (uint32_t)s, inten, 0u};
 }
@@ -1147,22 +1117,6 @@ __global__ __launch_bounds__(256) void promote_settle_leaf_kernel(
     if (inten_bits) in[k] = inten_bits[sl];
   }
   const PcvNodeRec c = pt.leaf_rec[it.rank];
-  // staging of the finished bytes (PcvStage): outputs of the slots [begin, end) of this leaf are the blob slots
-  // [g(begin - lo), g(end - lo)), g(j) = number of points below j that stay (all of them in a root leaf, else the ones
-  // that are not every-8th)
-  constexpr uint32_t kStageXyz = kPcvSettleTile * 12u + 32u, kStageRgb = kPcvSettleTile * 3u + 32u;
-  __shared__ __attribute__((aligned(16))) uint8_t stage_xyz[kStageXyz];
-  __shared__ __attribute__((aligned(16))) uint8_t stage_rgb[kStageRgb];
-  const bool is_root = c.parent == 0xffffffffu;
-  const uint32_t jb = it.begin - c.lo, je = it.end - c.lo;
-  const uint32_t out_b = is_root ? jb : jb - ((jb + 7u) >> 3), out_e = is_root ? je : je - ((je + 7u) >> 3);
-  const uint32_t bpp = c.enc == PCV_ENC_UINT8 ? 3u : c.enc == PCV_ENC_UINT16 ? 6u : 12u;  // .xyz bytes per point
-  const bool staged = c.enc != PCV_ENC_FLOAT64;  // workgroup-uniform (Float64-coded leaves store straight from the lanes)
-  uint8_t* const gx = o.xyz_blob + c.xyz_off + (uint64_t)out_b * bpp;  // first output byte of the workgroup
-  uint8_t* const gc = o.rgb_blob + (c.point_off + (uint64_t)out_b) * 3u;
-  const uint32_t skew_x = (uint32_t)(reinterpret_cast<uintptr_t>(gx) & 15u), skew_c = (uint32_t)(reinterpret_cast<uintptr_t>(gc) & 15u);
-  const PcvStage stage{stage_xyz + skew_x, stage_rgb + skew_c, out_b};
-  const PcvStage* const st = staged ? &stage : nullptr;
   if (it.pad != 0 && cont_ranges) {  // workgroup-uniform: this leaf continues its chain first
     const PcvContRange rg = cont_ranges[it.pad - 1];
     const uint32_t fe = lv.enc[rg.from_level];
@@ -1181,35 +1135,17 @@ __global__ __launch_bounds__(256) void promote_settle_leaf_kernel(
         }
       }
       pcv_continue_codes(lv, rg, u.x, u.y, u.z);
-      settle_one<false, kClimb16>(pt, s, c, it.rank, u, h[k], in[k], climb_base, climbers, o, nullptr, st);  // codes are unpacked already
+      settle_one<false, kClimb16>(pt, s, c, it.rank, u, h[k], in[k], climb_base, climbers, o, nullptr);  // codes are unpacked already
     }
-  } else {
-#pragma unroll
-    for (int k = 0; k < kSlots; ++k) {
-      const uint32_t s = it.begin + threadIdx.x + 256 * k;
-      if (kCompact)  // x: both codes, or the input index
-        p[k] = make_uint4(q[k].x, 0u, q[k].y & 0xffffu, (q[k].y >> 16) | ((key[k] & 0xffu) << 16));
-      if (s < it.end) settle_one<kCompact, kClimb16>(pt, s, c, it.rank, p[k], h[k], in[k], climb_base, climbers, o, wide, st);
-    }
+    return;
   }
-  if (!staged) return;
-  __syncthreads();
-  // LDS -> blob: whole aligned 16-byte chunks where the piece covers them, single bytes at its two ends (the neighbouring
-  // bytes belong to other workgroups)
-  auto flush = [&](const uint8_t* lds /* 16-byte aligned image, the piece starts at `skew` */, uint8_t* g /* first byte of the piece */,
-                   uint32_t skew, uint32_t bytes) {
-    uint8_t* const g0 = g - skew;  // 16-byte aligned
-    const uint32_t lo = skew, hi = skew + bytes;
-    for (uint32_t c16 = threadIdx.x * 16u; c16 < hi; c16 += 256u * 16u) {
-      if (c16 >= lo && c16 + 16u <= hi) {
-        *reinterpret_cast<uint4*>(g0 + c16) = *reinterpret_cast<const uint4*>(lds + c16);
-      } else {
-        for (uint32_t b = c16 < lo ? lo : c16; b < c16 + 16u && b < hi; ++b) g0[b] = lds[b];
-      }
-    }
-  };
-  flush(stage_xyz, gx, skew_x, (out_e - out_b) * bpp);
-  flush(stage_rgb, gc, skew_c, (out_e - out_b) * 3u);
+#pragma unroll
+  for (int k = 0; k < kSlots; ++k) {
+    const uint32_t s = it.begin + threadIdx.x + 256 * k;
+    if (kCompact)  // x: both codes, or the input index
+      p[k] = make_uint4(q[k].x, 0u, q[k].y & 0xffffu, (q[k].y >> 16) | ((key[k] & 0xffu) << 16));
+    if (s < it.end) settle_one<kCompact, kClimb16>(pt, s, c, it.rank, p[k], h[k], in[k], climb_base, climbers, o, wide);
+  }
 }
 
 __global__ __launch_bounds__(256) void promote_climb_kernel(
