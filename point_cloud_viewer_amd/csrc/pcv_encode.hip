@@ -762,7 +762,7 @@ __global__ __launch_bounds__(1024) void rank_hist_kernel(const uint32_t* __restr
 // Chain continuation over the sorted slots of the true leaves that lie BELOW the first candidate node of their path (the
 // candidate was split): their records carry the codes of the candidate's level, and a point's chain from that level on
 // is a function of those codes alone — decode in the candidate's cube, then the ordinary level steps down to the leaf
-// (the digits come out of the chain itself and are the ones the chain pass walked with). One workgroup per <= 512 slots
+// (the digits come out of the chain itself and are the ones the chain pass walked with). One workgroup per <= kPcvSettleTile (1 024) slots
 // of one leaf; range and levels are wave-uniform, so the level loop and its encoding switch are scalar.
 struct alignas(16) PcvContRange {
   uint32_t from_level, to_level, pad0, pad1;

@@ -124,6 +124,11 @@ extern "C" int pcv_build_octree_from_ply(pcv_ctx* ctx, const pcv_build_params* p
                     lay.i_off, {lay.offset[0], lay.offset[1], lay.offset[2]}};
     hipLaunchKernelGGL(ply_decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a, n, raw, x, y, z, rgb, inten);
     PCV_HIP_CHECK(ctx, hipGetLastError());
+    // the raw vertex records are dead once the decode kernel is queued: the pool is stream-ordered, so the build below may
+    // recycle the block (stride x n bytes: 15 B/pt of a float xyz + uchar rgb file) instead of holding it next to the
+    // decoded arrays for its whole run
+    sc.detach(raw);
+    ctx->dev_free(raw);
     pts.x = x, pts.y = y, pts.z = z;
     pts.color = rgb;
     pts.intensity = inten;

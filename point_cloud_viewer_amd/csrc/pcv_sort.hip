@@ -1103,9 +1103,12 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
 
 }  // namespace
 
-// two histograms + totals, the second pass's piece ranges, and the rank counts re-indexed by true rank (16 384 per sort workgroup)
+// two histograms + totals, the second pass's piece ranges, and the rank counts re-indexed by true rank (16 384 per sort
+// workgroup, 64 MB) — the last only for inputs whose record sort can take the two-pass rows path at all (12-byte records in
+// tiles of 8 192, i.e. >= 8 sort workgroups: n >= 65 536); small builds (tests, virtual ranks) get by with 2 MB
 size_t pcv_sort_scratch_bytes(uint64_t n) {
-  return (2 * ((size_t)kRadix * kMaxGroups + kRadix) + 3 * (size_t)kMaxGroups + 16384 * (size_t)kMaxGroups) * sizeof(uint32_t) + 256;
+  const size_t rows_true = make_geom(n, 8192).groups >= 8 ? 16384 * (size_t)kMaxGroups : 0;
+  return (2 * ((size_t)kRadix * kMaxGroups + kRadix) + 3 * (size_t)kMaxGroups + rows_true) * sizeof(uint32_t) + 256;
 }
 
 int pcv_radix_sort_u64(pcv_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint64_t n, int begin_bit, int end_bit,

@@ -400,9 +400,19 @@ class ShardedOctreeBuilder:
             if nd.level <= 1:
                 index_of[_oct.node_name(nd.id_high, nd.id_low)] = i
         copies = []
+        bytes_per_code = {1: 1, 2: 2, 3: 4, 4: 8}
         for nd in specs:
             i = index_of.get(nd["name"])
             if i is not None:
+                # a local top node must fill exactly its slot of the global layout: the batched copy below only knows offsets,
+                # a node longer than its slot would overwrite its neighbours in the all-reduce buffer
+                info = tree.node(i)
+                have = {"xyz": info.num_points * 3 * bytes_per_code[int(info.encoding)], "rgb": info.num_points * 3,
+                        "intensity": info.num_points * 4 if intensity is not None else 0}
+                for key in ("xyz", "rgb", "intensity"):
+                    if nd[key][1] and have[key] != nd[key][1]:
+                        raise RuntimeError(f"sharded build: local top node {nd['name']} has {have[key]} {key} bytes, "
+                                           f"its slot in the global layout {nd[key][1]}")
                 copies.append((i, [nd[key] if nd[key][1] else None for key in ("xyz", "rgb", "intensity")]))
         if copies and hasattr(tree, "copy_nodes_into"):
             # one ABI call for all top nodes and file kinds

@@ -24,8 +24,8 @@ def _free_port():
 
 
 class _Node:
-    def __init__(self, level, id_high, id_low):
-        self.level, self.id_high, self.id_low = level, id_high, id_low
+    def __init__(self, level, id_high, id_low, num_points=0, encoding=1):
+        self.level, self.id_high, self.id_low, self.num_points, self.encoding = level, id_high, id_low, num_points, encoding
 
 
 class _HostTree:
@@ -38,7 +38,7 @@ class _HostTree:
 
     def node(self, i):
         nd = self.oct.nodes[self.names[i]]
-        return _Node(nd["level"], nd["id"][0], nd["id"][1])
+        return _Node(nd["level"], nd["id"][0], nd["id"][1], nd["num_points"], nd["encoding"])
 
     def copy_node_into(self, i, which, dst):
         data = self.oct.nodes[self.names[i]][("xyz", "rgb", "intensity")[which]]

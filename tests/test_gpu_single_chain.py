@@ -247,7 +247,7 @@ print("alt-path ok")
 @pytest.mark.parametrize("env,record_bytes", [({"PCV_COMPACT_RECORDS": "0"}, 20), ({"PCV_SETTLE_BY_LEAF": "0"}, 12),
                                               ({"PCV_COMPACT_RECORDS": "0", "PCV_SETTLE_BY_LEAF": "0"}, 20),
                                               # the first sort pass counting and mapping the keys in a pass of its own (what
-                                              # trees of more than 8 192 predicted nodes take)
+                                              # trees of more than 16 384 predicted nodes took before round 4)
                                               ({"PCV_SORT_ROWS": "0"}, 12),
                                               # the second pass counting its keys itself (equal chunks instead of pieces of
                                               # whole first-pass runs)
