@@ -385,11 +385,7 @@ __device__ __forceinline__ uint32_t pcv_wave_incl_scan32(uint32_t v) {  // inclu
 #ifndef PCV4_KEEP_BRANCH
 #define PCV4_KEEP_BRANCH 1
 #endif
-/* PCV4_NT (bit mask): non-temporal hints on the accesses that touch every byte once — 1: the coordinate loads, 2: the depth-grid
-   gather, 4: the record stores — so that the walk table (30 KB for the bench tree) is what stays in the 32 KB vector L1 */
-#ifndef PCV4_NT
-#define PCV4_NT 0
-#endif
+
 /* walk record of T'' node `idx`: the first lds_nodes records (T'' is level-major: the top of the tree) are mirrored in LDS */
 #define PCV4_WALK_AT(idx) pcv4_walk_at(walk, swalk, lds_nodes, (idx))
 __device__ __forceinline__ uint32_t pcv4_walk_at(const uint32_t* __restrict__ walk, const uint32_t* swalk, uint32_t lds_nodes, uint32_t idx) {
@@ -416,18 +412,12 @@ __device__ __forceinline__ uint32_t pcv4_walk_at(const uint32_t* __restrict__ wa
 #endif
 /* Levels U + 1 .. LEND of the lanes that have not reached a leaf (U: the wave's level counter, see spec_encode_kernel).
    mode / half: how the digit of level U + 1 is taken from level U's codes (PcvLevels::digit_mode), scalar. */
-/* The level constants run ONE LEVEL AHEAD (ecN, ihN, ilN: edge and double-double reciprocal of level U + 1, fetched while
-   level U's arithmetic ran): round 4's phase timing showed a level step taking ~1 300 clocks of a wave's life for ~200 of
-   issue — the scalar loads of the constants and the child record's gather were waited for where they were issued. */  \
 #define PCV4_LOOP(GUARD, LEND, APPLY)                                                                                   \
   while (U < (LEND)) {                                                                                                  \
     const bool live = !(rec & PCV_SPEC_LEAF);                                                                           \
     if (!__any(live)) break;                                                                                            \
-    const double ec = ecN;                                                                                              \
-    const PcvRecip ic{ihN, ilN};                                                                                        \
     const double half_next = lv.digit_half[U + 1];                                                                      \
     const uint32_t mode_next = lv.digit_mode[U + 1];                                                                    \
-    ecN = lv.edge[U + 2], ihN = lv.inv_edge[U + 2], ilN = lv.inv_edge_lo[U + 2]; /* (tables hold PCV_MAX_LEVELS + 2 entries) */ \
     if (live) {                                                                                                         \
       PCV4_KEEP_STEP                                                                                                    \
       PcvOctBits b;                                                                                                     \
@@ -435,16 +425,17 @@ __device__ __forceinline__ uint32_t pcv4_walk_at(const uint32_t* __restrict__ wa
         b = pcv_bits_from_codes(half, vx, vy, vz);                                                                      \
       } else if (!GUARD && mode == 2u) {                                                                                \
         b = pcv_bits_from_codes(0.5, vx, vy, vz);                                                                       \
-        if (__builtin_expect(__any(pcv_f32_code_tie(vx, vy, vz)), 0)) b = pcv_chain_bits(ep, px, py, pz, mx, my, mz);     \
+        if (__builtin_expect(__any(pcv_f32_code_tie(vx, vy, vz)), 0)) b = pcv_chain_bits(lv.edge[U], px, py, pz, mx, my, mz);     \
       } else {                                                                                                          \
-        b = pcv_chain_bits(ep, px, py, pz, mx, my, mz);                                                                 \
+        b = pcv_chain_bits(lv.edge[U], px, py, pz, mx, my, mz);                                                                 \
       }                                                                                                                 \
       const uint32_t next = PCV4_WALK_AT((rec & PCV_SPEC_INDEX_MASK) + b.digit());                                      \
+      const double ec = lv.edge[U + 1];                                                                                 \
+      const PcvRecip ic{lv.inv_edge[U + 1], lv.inv_edge_lo[U + 1]};                                                     \
       APPLY;                                                                                                            \
       rec = next;                                                                                                       \
       L = U + 1;                                                                                                        \
     }                                                                                                                   \
-    ep = ec;                                                                                                            \
     half = half_next;                                                                                                   \
     mode = mode_next;                                                                                                   \
     ++U;                                                                                                                \
@@ -455,8 +446,6 @@ __device__ __forceinline__ uint32_t pcv4_walk_at(const uint32_t* __restrict__ wa
   {                                                                                                                     \
     double half = lv.digit_half[U];                                                                                     \
     uint32_t mode = lv.digit_mode[U];                                                                                   \
-    double ep = lv.edge[U]; /* edge of the level the lanes stand on */                                                  \
-    double ecN = lv.edge[U + 1], ihN = lv.inv_edge[U + 1], ilN = lv.inv_edge_lo[U + 1];                                 \
     const int e0 = lv.first_f32 - 1 < lv.nlevels ? lv.first_f32 - 1 : lv.nlevels;                                       \
     const int e1 = lv.first_u16 - 1 < lv.nlevels ? lv.first_u16 - 1 : lv.nlevels;                                       \
     const int e2 = lv.first_u8 - 1 < lv.nlevels ? lv.first_u8 - 1 : lv.nlevels;                                         \
@@ -505,8 +494,7 @@ __global__ __launch_bounds__(BLOCK, 8) void spec_encode4_kernel(
   double qx = 0.0, qy = 0.0, qz = 0.0;
   if (in) {
     if (raw) {
-      if (PCV4_NT & 1) qx = __builtin_nontemporal_load(x + i), qy = __builtin_nontemporal_load(y + i), qz = __builtin_nontemporal_load(z + i);
-      else qx = x[i], qy = y[i], qz = z[i];
+      qx = x[i], qy = y[i], qz = z[i];
     } else {  // routed input: the position the sending rank held after level 1 (decode of the level-1 codes)
       double t0, t1, t2, t3, t4, t5;
       uint32_t dd;
@@ -522,8 +510,7 @@ __global__ __launch_bounds__(BLOCK, 8) void spec_encode4_kernel(
     const uint32_t ix = (uint32_t)fminf(fmaxf((float)(qx - lv.root_min[0]) * cells_per_unit, 0.f), kTop);
     const uint32_t iy = (uint32_t)fminf(fmaxf((float)(qy - lv.root_min[1]) * cells_per_unit, 0.f), kTop);
     const uint32_t iz = (uint32_t)fminf(fmaxf((float)(qz - lv.root_min[2]) * cells_per_unit, 0.f), kTop);
-    const uint8_t* cell = depth_grid + (ix | (iy << kGridBits) | (iz << (2 * kGridBits)));
-    key = (uint32_t)(kSpecClasses - 2) - ((PCV4_NT & 2) ? __builtin_nontemporal_load(cell) : *cell);  // deepest first
+    key = (uint32_t)(kSpecClasses - 2) - depth_grid[ix | (iy << kGridBits) | (iz << (2 * kGridBits))];  // deepest first
   }
   // rank of the point among the workgroup's points of its class (any order inside a class will do: the deal only decides
   // which lane walks which point)
@@ -591,14 +578,8 @@ __global__ __launch_bounds__(BLOCK, 8) void spec_encode4_kernel(
     __syncthreads();
     if (o < n && !(diag & 4u)) {
       const uint2 q = opay[tid];
-      if (PCV4_NT & 4) {
-        __builtin_nontemporal_store(okey[tid] | (rgb >> 16), rank + o);
-        __builtin_nontemporal_store(q.x, &reinterpret_cast<uint2*>(payload)[o].x);
-        __builtin_nontemporal_store(q.y | ((rgb & 0xffffu) << 16), &reinterpret_cast<uint2*>(payload)[o].y);
-      } else {
-        rank[o] = okey[tid] | (rgb >> 16);
-        reinterpret_cast<uint2*>(payload)[o] = make_uint2(q.x, q.y | ((rgb & 0xffffu) << 16));
-      }
+      rank[o] = okey[tid] | (rgb >> 16);
+      reinterpret_cast<uint2*>(payload)[o] = make_uint2(q.x, q.y | ((rgb & 0xffffu) << 16));
     }
   }
 }
