@@ -280,6 +280,28 @@ typedef struct pcv_route_state {  /* optional outputs of pcv_route_buckets: the 
 int pcv_route_buckets(pcv_ctx* ctx, const pcv_build_params* params, const pcv_points* points, uint32_t* bucket,
                       uint64_t counts[64], const pcv_route_state* state /* nullable; needs a Float32-encoded level 1 */);
 
+/* The same routing in two passes that never write the level-1 state in input order (69 instead of 87 bytes of traffic per
+ * point; a Float32-encoded level 1 is required, as for pcv_route_state):
+ *   pcv_route_plan     bucket BYTE of every point (device, n bytes), the bucket histogram of every tile of 4 096 points
+ *                      (device, pcv_route_tiles(n) x 64 x u16) and the 64 counts the ranks all-gather;
+ *   pcv_route_scatter  once the plan (bucket -> owning rank) is known: the level-1 state of every point — the four planes of
+ *                      pcv_route_state, plus points->intensity when set — computed from the coordinates again and written
+ *                      straight to the point's place in its owner's buffer: row k (in input order) of the rows owned by rank
+ *                      r goes to row k of dst[r]'s planes. Replaces ChildIndex::from_bounding_cube (node.rs:34-42) + the
+ *                      first encode step (codec.rs:102-121) of generation.rs:78-99 for the multi-GPU exchange. */
+typedef struct pcv_route_dst {
+  uint32_t* oct_rgb;
+  uint32_t* cx;
+  uint32_t* cy;
+  uint32_t* cz;
+  float* intensity; /* nullable */
+} pcv_route_dst;
+uint64_t pcv_route_tiles(uint64_t n);
+int pcv_route_plan(pcv_ctx* ctx, const pcv_build_params* params, const pcv_points* points, uint8_t* bucket, uint16_t* tile_hist,
+                   uint64_t counts[64]);
+int pcv_route_scatter(pcv_ctx* ctx, const pcv_build_params* params, const pcv_points* points, const uint8_t* bucket,
+                      const uint16_t* tile_hist, uint32_t world, const uint8_t rank_of_bucket[64], const pcv_route_dst* dst /* [world] */);
+
 /* Stable partition of up to 8 row-aligned planes by owner (owner[i] is a rank, or a bucket when rank_of_bucket maps the
  * 64 buckets to ranks): row k (in input order) of the rows owned by rank r goes to row k of dst[r * nplanes + p] for
  * every plane p. The caller points dst[r * nplanes + p] at its send buffer for rank r, and the own rank's entries

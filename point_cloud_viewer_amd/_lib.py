@@ -62,6 +62,10 @@ class RouteState(C.Structure):
     _fields_ = [("cx", C.c_void_p), ("cy", C.c_void_p), ("cz", C.c_void_p), ("oct_rgb", C.c_void_p)]
 
 
+class RouteDst(C.Structure):
+    _fields_ = [("oct_rgb", C.c_void_p), ("cx", C.c_void_p), ("cy", C.c_void_p), ("cz", C.c_void_p), ("intensity", C.c_void_p)]
+
+
 class Plane(C.Structure):
     _fields_ = [("src", C.c_void_p), ("elem_bytes", C.c_uint32)]
 
@@ -134,6 +138,9 @@ _SIGNATURES = {
     "pcv_chain_keys": (C.c_int, [_vp, C.POINTER(BuildParams), C.POINTER(Points), C.c_int, _vp]),
     "pcv_route_buckets": (C.c_int, [_vp, C.POINTER(BuildParams), C.POINTER(Points), _vp, C.POINTER(C.c_uint64),
                                     C.POINTER(RouteState)]),
+    "pcv_route_tiles": (C.c_uint64, [C.c_uint64]),
+    "pcv_route_plan": (C.c_int, [_vp, C.POINTER(BuildParams), C.POINTER(Points), _vp, _vp, C.POINTER(C.c_uint64)]),
+    "pcv_route_scatter": (C.c_int, [_vp, C.POINTER(BuildParams), C.POINTER(Points), _vp, _vp, C.c_uint32, _vp, C.POINTER(RouteDst)]),
     "pcv_partition_by_owner": (C.c_int, [_vp, C.c_uint64, _vp, C.c_uint32, _vp, C.c_uint32, C.POINTER(Plane),
                                          C.POINTER(C.c_void_p)]),
     "pcv_build_begin_routed": (C.c_int, [_vp, C.POINTER(BuildParams), C.POINTER(RoutedPoints), C.POINTER(_vp)]),

@@ -370,6 +370,154 @@ __global__ __launch_bounds__(256) void partition_scatter_kernel(uint64_t n, cons
   }
 }
 
+// ---- routing in two passes (round 4) ---------------------------------------------------------------------------------------
+// route_bucket + partition_count + partition_scatter above move 47 + 4 + 36 bytes per point: the first writes the 16-byte
+// level-1 state of every point next to its bucket, the last reads it back to scatter it. Here the state never exists in
+// input order:
+//   pass 1 (route_plan):    coordinates -> bucket BYTE per point + the bucket histogram of every tile of 4 096 points + the 64
+//                           counts the ranks all-gather (24 B read + 1 B written per point);
+//   pass 2 (route_scatter): the plan (bucket -> owner) is known; owner counts per tile = sums of the tile's histogram, scanned;
+//                           then coordinates + colour + bucket byte -> the level-1 state, computed in registers (the octant
+//                           digit is the bucket's upper three bits, so the step is one `min += bit * edge` and one Float32
+//                           encode per coordinate — the operations pass 1 ran, on the same operands) and stored straight at
+//                           the point's stable place in its owner's send buffer (28 B read + 16 B written per point).
+// 69 instead of 87 bytes per point, no partition_count pass.
+constexpr int kRouteTile = kPartTile;  // 4 096 points: 256 lanes x 16 rows, wave-striped
+
+__global__ __launch_bounds__(256) void route_plan_kernel(PcvLevels lv, uint64_t n, const double* __restrict__ x,
+                                                          const double* __restrict__ y, const double* __restrict__ z,
+                                                          uint8_t* __restrict__ bucket, uint16_t* __restrict__ tile_hist /* [tiles][64] */,
+                                                          unsigned long long* __restrict__ counts /* [64] */) {
+  __shared__ uint32_t hist[64];
+  if (threadIdx.x < 64) hist[threadIdx.x] = 0;
+  __syncthreads();
+  const uint64_t base = (uint64_t)blockIdx.x * kRouteTile + threadIdx.x;
+#pragma unroll 4
+  for (int k = 0; k < kRouteTile / 256; ++k) {
+    const uint64_t i = base + (uint64_t)k * 256;
+    if (i < n) {
+      double px = x[i], py = y[i], pz = z[i];
+      double mx = lv.root_min[0], my = lv.root_min[1], mz = lv.root_min[2];
+      double cx, cy, cz;
+      uint32_t b = 0;
+      for (int l = 1; l <= lv.nlevels; ++l)  // nlevels <= 2 here; always the guarded (exact for any input) variant
+        b = (b << 3) | pcv_chain_level<true>(lv.enc[l], lv.edge[l - 1], lv.edge[l], PcvRecip{lv.inv_edge[l], lv.inv_edge_lo[l]}, px, py, pz, mx, my, mz, cx, cy, cz);
+      if (lv.nlevels < 2) b <<= 3;
+      bucket[i] = (uint8_t)b;
+      atomicAdd(&hist[b], 1u);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const uint32_t v = hist[threadIdx.x];
+    tile_hist[(uint64_t)blockIdx.x * 64 + threadIdx.x] = (uint16_t)v;  // <= 4 096
+    if (v) atomicAdd(&counts[threadIdx.x], (unsigned long long)v);
+  }
+}
+
+// owner counts per tile from the tiles' bucket histograms: tile_counts[owner][tile]
+__global__ __launch_bounds__(256) void route_owner_counts_kernel(const uint16_t* __restrict__ tile_hist, uint32_t ntiles,
+                                                                  const uint8_t* __restrict__ remap, uint32_t world,
+                                                                  uint32_t* __restrict__ tile_counts) {
+  __shared__ uint8_t rank_of[64];
+  if (threadIdx.x < 64) rank_of[threadIdx.x] = remap[threadIdx.x];
+  __syncthreads();
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= ntiles) return;
+  uint32_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const uint4* h4 = reinterpret_cast<const uint4*>(tile_hist + (uint64_t)t * 64);  // 128 bytes per tile
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const uint4 v = h4[q];
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t b0 = (uint32_t)(q * 8 + e * 2);
+      const uint32_t r0 = rank_of[b0], r1 = rank_of[b0 + 1];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) c[k] += (r0 == (uint32_t)k ? (w[e] & 0xffffu) : 0u) + (r1 == (uint32_t)k ? (w[e] >> 16) : 0u);
+    }
+  }
+  for (uint32_t k = 0; k < world; ++k) tile_counts[(uint64_t)k * ntiles + t] = c[k];
+}
+
+struct RouteDst {
+  uint32_t* orgb[8];
+  uint32_t* cx[8];
+  uint32_t* cy[8];
+  uint32_t* cz[8];
+  float* inten[8];
+};
+
+__global__ __launch_bounds__(256) void route_scatter_kernel(PcvLevels lv, uint64_t n, const double* __restrict__ x,
+                                                             const double* __restrict__ y, const double* __restrict__ z,
+                                                             const uint8_t* __restrict__ color, uint32_t color_stride,
+                                                             const float* __restrict__ intensity, const uint8_t* __restrict__ bucket,
+                                                             const uint8_t* __restrict__ remap, uint32_t world, uint32_t ntiles,
+                                                             const uint32_t* __restrict__ tile_base, RouteDst dst) {
+  __shared__ uint32_t wave_cnt[4][8];
+  __shared__ uint8_t rank_of[64];
+  __shared__ uint32_t* sp[5][8];  // per-lane owner indexes the pointer tables: LDS lookup, not a private copy
+  if (threadIdx.x < 64) rank_of[threadIdx.x] = remap[threadIdx.x];
+  if (threadIdx.x < 8) {
+    sp[0][threadIdx.x] = dst.orgb[threadIdx.x];
+    sp[1][threadIdx.x] = dst.cx[threadIdx.x];
+    sp[2][threadIdx.x] = dst.cy[threadIdx.x];
+    sp[3][threadIdx.x] = dst.cz[threadIdx.x];
+    sp[4][threadIdx.x] = reinterpret_cast<uint32_t*>(dst.inten[threadIdx.x]);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint64_t lane_lt = (1ull << lane) - 1ull;
+  const uint64_t base = (uint64_t)blockIdx.x * kRouteTile + (uint64_t)wave * 1024 + lane;
+  uint32_t own[16], d1[16];
+  uint32_t wcount[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // wave-uniform
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const uint64_t idx = base + (uint64_t)i * 64;
+    const uint32_t b = idx < n ? (uint32_t)bucket[idx] : 0xffu;
+    own[i] = b < 64u ? (uint32_t)rank_of[b] : 0xffu;
+    d1[i] = (b >> 3) & 7u;
+    for (uint32_t k = 0; k < world; ++k) wcount[k] += (uint32_t)__popcll(__ballot(own[i] == k));
+  }
+  if (lane == 0)
+    for (uint32_t k = 0; k < world; ++k) wave_cnt[wave][k] = wcount[k];
+  __syncthreads();
+  uint32_t run[8];  // next free row of each owner for this wave
+  for (uint32_t k = 0; k < world; ++k) {
+    uint32_t r = tile_base[(uint64_t)k * ntiles + blockIdx.x];
+    for (int w = 0; w < wave; ++w) r += wave_cnt[w][k];
+    run[k] = r;
+  }
+  const double e1 = lv.edge[1];
+  const PcvRecip r1{lv.inv_edge[1], lv.inv_edge_lo[1]};
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const uint64_t idx = base + (uint64_t)i * 64;
+    const uint32_t o = own[i];
+    uint32_t pos = 0;
+    for (uint32_t k = 0; k < world; ++k) {
+      const uint64_t m = __ballot(o == k);
+      if (o == k) pos = run[k] + (uint32_t)__popcll(m & lane_lt);
+      run[k] += (uint32_t)__popcll(m);
+    }
+    if (idx < n) {
+      // the level-1 step of the chain for a known digit (pcv_chain_coord_t: min += bit * edge, Float32 encode, guarded variant)
+      const uint32_t d = d1[i];
+      const double mx = pcv_step_min(lv.root_min[0], (d & 4u) != 0u, e1), my = pcv_step_min(lv.root_min[1], (d & 2u) != 0u, e1),
+                   mz = pcv_step_min(lv.root_min[2], (d & 1u) != 0u, e1);
+      const double cx = pcv_encode_val<PCV_ENC_FLOAT32, true>(x[idx], mx, e1, r1), cy = pcv_encode_val<PCV_ENC_FLOAT32, true>(y[idx], my, e1, r1),
+                   cz = pcv_encode_val<PCV_ENC_FLOAT32, true>(z[idx], mz, e1, r1);
+      const uint8_t* c = color + idx * color_stride;
+      sp[0][o][pos] = d | ((uint32_t)c[0] << 8) | ((uint32_t)c[1] << 16) | ((uint32_t)c[2] << 24);
+      sp[1][o][pos] = __float_as_uint((float)cx);  // value domain -> Float32 bit pattern (exact: cx is a float value)
+      sp[2][o][pos] = __float_as_uint((float)cy);
+      sp[3][o][pos] = __float_as_uint((float)cz);
+      if (intensity) reinterpret_cast<float*>(sp[4][o])[pos] = intensity[idx];
+    }
+  }
+}
+
 // Division self-test: pcv_div_code against IEEE division for every code and both divisors (exhaustive), and
 // pcv_div_const against IEEE division for pseudo-random numerators (full exponent/mantissa spread, plus values
 // straddling rounding boundaries of the quotient) over a list of divisors.
@@ -527,6 +675,88 @@ extern "C" int pcv_partition_by_owner(pcv_ctx* ctx, uint64_t n, const uint32_t* 
     PcvProf prof(ctx, PCV_K_PARTITION_SCATTER);
     hipLaunchKernelGGL(partition_scatter_kernel, dim3(ntiles), dim3(256), 0, ctx->stream, n, owner, world, ntiles, tile_counts,
                        pl, (const uint8_t*)d_remap);
+  }
+  PCV_HIP_CHECK(ctx, hipGetLastError());
+  PCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return PCV_OK;
+}
+
+extern "C" uint64_t pcv_route_tiles(uint64_t n) { return (n + kRouteTile - 1) / kRouteTile; }
+
+extern "C" int pcv_route_plan(pcv_ctx* ctx, const pcv_build_params* params, const pcv_points* points, uint8_t* bucket,
+                              uint16_t* tile_hist, uint64_t counts[64]) {
+  if (!ctx) return PCV_E_INVALID;
+  if (!params || !points || !counts) return ctx->fail(PCV_E_INVALID, "null argument");
+  for (int b = 0; b < 64; ++b) counts[b] = 0;
+  if (points->n == 0) return PCV_OK;  // an empty input slice (a rank without points) is fine
+  if (!bucket || !tile_hist) return ctx->fail(PCV_E_INVALID, "bucket / tile_hist is null");
+  if (points->mem != PCV_MEM_DEVICE) return ctx->fail(PCV_E_INVALID, "pcv_route_plan works on device-resident points");
+  if (points->n >= 0xffffffffull) return ctx->fail(PCV_E_INVALID, "at most 2^32 - 2 points per call");
+  PCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  PcvLevels lv;
+  int max_level;
+  pcv_make_levels(params->bbox_min, params->bbox_max, params->resolution, 2, &lv, &max_level, nullptr, nullptr);
+  PcvScratch sc(ctx);
+  unsigned long long* d_counts;
+  int rc;
+  if ((rc = sc.get(&d_counts, 64))) return rc;
+  PCV_HIP_CHECK(ctx, hipMemsetAsync(d_counts, 0, 64 * 8, ctx->stream));
+  {
+    PcvProf prof(ctx, PCV_K_ROUTE_BUCKET);
+    hipLaunchKernelGGL(route_plan_kernel, dim3((unsigned)pcv_route_tiles(points->n)), dim3(256), 0, ctx->stream, lv, points->n, points->x,
+                       points->y, points->z, bucket, tile_hist, d_counts);
+  }
+  PCV_HIP_CHECK(ctx, hipGetLastError());
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(ctx->mailbox, d_counts, 64 * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  for (int b = 0; b < 64; ++b) counts[b] = ctx->mailbox[b];
+  return PCV_OK;
+}
+
+extern "C" int pcv_route_scatter(pcv_ctx* ctx, const pcv_build_params* params, const pcv_points* points, const uint8_t* bucket,
+                                 const uint16_t* tile_hist, uint32_t world, const uint8_t rank_of_bucket[64],
+                                 const pcv_route_dst* dst) {
+  if (!ctx) return PCV_E_INVALID;
+  if (!params || !points || !rank_of_bucket || !dst) return ctx->fail(PCV_E_INVALID, "null argument");
+  if (world < 1 || world > 8) return ctx->fail(PCV_E_INVALID, "world must be 1..8");
+  const uint64_t n = points->n;
+  if (n == 0) return PCV_OK;
+  if (!bucket || !tile_hist) return ctx->fail(PCV_E_INVALID, "bucket / tile_hist is null");
+  if (points->mem != PCV_MEM_DEVICE) return ctx->fail(PCV_E_INVALID, "pcv_route_scatter works on device-resident points");
+  if (n >= 0xffffffffull) return ctx->fail(PCV_E_INVALID, "at most 2^32 - 2 points per call");
+  if (!points->color || (points->color_stride != 3 && points->color_stride != 4))
+    return ctx->fail(PCV_E_INVALID, "the level-1 state packs the colour: points->color (stride 3 or 4) is required");
+  for (int b = 0; b < 64; ++b)
+    if (rank_of_bucket[b] >= world) return ctx->fail(PCV_E_INVALID, "rank_of_bucket entry out of range");
+  PcvLevels lv;
+  int max_level;
+  pcv_make_levels(params->bbox_min, params->bbox_max, params->resolution, 2, &lv, &max_level, nullptr, nullptr);
+  if (lv.nlevels < 1 || lv.enc[1] != PCV_ENC_FLOAT32)
+    return ctx->fail(PCV_E_INVALID, "the level-1 state is only defined for a Float32-encoded level 1: exchange raw coordinates");
+  RouteDst rd{};
+  for (uint32_t k = 0; k < world; ++k) {
+    rd.orgb[k] = dst[k].oct_rgb, rd.cx[k] = dst[k].cx, rd.cy[k] = dst[k].cy, rd.cz[k] = dst[k].cz, rd.inten[k] = dst[k].intensity;
+    // (an owner that receives no row may have null planes)
+  }
+  PCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  PcvScratch sc(ctx);
+  const uint32_t ntiles = (uint32_t)pcv_route_tiles(n);
+  uint32_t* tile_counts;
+  uint8_t* d_remap;
+  int rc;
+  if ((rc = sc.get(&tile_counts, (size_t)world * ntiles)) || (rc = sc.get(&d_remap, 64))) return rc;
+  std::memcpy(ctx->mailbox, rank_of_bucket, 64);  // pinned source for the async upload
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_remap, ctx->mailbox, 64, hipMemcpyHostToDevice, ctx->stream));
+  {
+    PcvProf prof(ctx, PCV_K_PARTITION_COUNT);
+    hipLaunchKernelGGL(route_owner_counts_kernel, dim3((ntiles + 255) / 256), dim3(256), 0, ctx->stream, tile_hist, ntiles,
+                       (const uint8_t*)d_remap, world, tile_counts);
+  }
+  hipLaunchKernelGGL(partition_scan_kernel, dim3(world), dim3(1024), 0, ctx->stream, tile_counts, ntiles);
+  {
+    PcvProf prof(ctx, PCV_K_PARTITION_SCATTER);
+    hipLaunchKernelGGL(route_scatter_kernel, dim3(ntiles), dim3(256), 0, ctx->stream, lv, n, points->x, points->y, points->z, points->color,
+                       points->color_stride, points->intensity, bucket, (const uint8_t*)d_remap, world, ntiles, tile_counts, rd);
   }
   PCV_HIP_CHECK(ctx, hipGetLastError());
   PCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));

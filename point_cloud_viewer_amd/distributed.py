@@ -127,6 +127,14 @@ class HipBackend:
         histogram; the state is four 4-byte planes: the Float32 level-1 codes and octant digit | rgb)."""
         return self.ctx.route_buckets(resolution, bbox, x, y, z, rgb, with_state)
 
+    def route_plan(self, resolution, bbox, x, y, z):
+        """Two-pass routing, first pass: (bucket bytes, per-tile bucket histograms, 64 counts) — no state is written."""
+        return self.ctx.route_plan(resolution, bbox, x, y, z)
+
+    def route_scatter(self, resolution, bbox, x, y, z, rgb, intensity, bucket, tile_hist, rank_of_bucket, dsts):
+        """Second pass: the level-1 state computed again and stored straight into the owners' buffers."""
+        self.ctx.route_scatter(resolution, bbox, x, y, z, rgb, bucket, tile_hist, rank_of_bucket, dsts, intensity)
+
     def partition(self, bucket, rank_of_bucket, planes, dsts):
         """Stable partition of the planes by owner straight into the destination views (count / scan / scatter)."""
         self.ctx.partition_by_owner(bucket, planes, dsts, rank_of_bucket)
@@ -293,7 +301,7 @@ class ShardedOctreeBuilder:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return t.cpu().numpy()
 
-    def _route(self, bucket, rank_of_bucket, matrix, planes):
+    def _route(self, bucket, rank_of_bucket, matrix, planes, scatter=None):
         """Partition by owner and exchange: rows for rank r go to a send buffer, own rows directly into the receive
         buffer; ONE grouped send/recv round moves everything else (RCCL: one ncclGroup == one all-to-all(v)).
         matrix[src][dst] = rows src sends to dst; planes: dict name -> row-aligned tensor; returns the received planes
@@ -317,7 +325,10 @@ class ShardedOctreeBuilder:
         for r in range(world):
             buf, off, cnt = (recv, recv_off[rank], send_counts[rank]) if r == rank else (send, send_off[r], send_counts[r])
             dsts.append([buf[k][off:off + cnt] for k in names])
-        self.backend.partition(bucket, rank_of_bucket, [planes[k] for k in names], dsts)
+        if scatter is not None:  # two-pass routing: the planes do not exist yet, `scatter` computes them into the buffers
+            scatter(rank_of_bucket, [dict(zip(names, row)) for row in dsts])
+        else:
+            self.backend.partition(bucket, rank_of_bucket, [planes[k] for k in names], dsts)
         ops = []
         for k in names:
             for peer in range(world):
@@ -353,13 +364,25 @@ class ShardedOctreeBuilder:
         can_split = max_level >= 2 and edges[1] > resolution
         # 1. buckets + global plan
         compressed = bool(self.compress_exchange and max_level >= 1 and int(encodings[1]) == 3)  # Float32 level 1
-        if compressed:
+        two_pass = compressed and hasattr(self.backend, "route_plan") and int(x.shape[0]) > 0
+        scatter = None
+        if two_pass:
+            # the state never exists in input order: pass 1 leaves bucket bytes + tile histograms, pass 2 (inside _route, once
+            # the plan is known) writes every point's state straight into its owner's buffer; `planes` only describes the rows
+            bucket, tile_hist, counts = self.backend.route_plan(resolution, bbox, x, y, z)
+            planes = {k: torch.empty(0, dtype=torch.int32, device=self.device) for k in ("cx", "cy", "cz", "oct_rgb")}
+            if intensity is not None:
+                planes["intensity"] = torch.empty(0, dtype=intensity.dtype, device=self.device)
+
+            def scatter(rank_of, dsts):
+                self.backend.route_scatter(resolution, bbox, x, y, z, rgb, intensity, bucket, tile_hist, rank_of, dsts)
+        elif compressed:
             bucket, counts, state = self.backend.buckets(resolution, bbox, x, y, z, rgb, True)
             planes = dict(state)
         else:
             bucket, counts = self.backend.buckets(resolution, bbox, x, y, z)
             planes = {"x": x, "y": y, "z": z, "color": rgb}
-        if intensity is not None:
+        if intensity is not None and not two_pass:
             planes["intensity"] = intensity
         row_bytes = sum(int(p.element_size()) * (int(p.numel()) // max(int(p.shape[0]), 1) if int(p.shape[0]) else
                                                   int(np.prod(p.shape[1:], dtype=np.int64))) for p in planes.values())
@@ -372,8 +395,8 @@ class ShardedOctreeBuilder:
         matrix = np.stack([np.bincount(rank_of_bucket, weights=per_rank[src], minlength=world) for src in range(world)])
         matrix = matrix.astype(np.int64)  # matrix[src][dst]
         # 2. the exchange
-        recv = self._route(bucket, rank_of_bucket, matrix, planes)
-        del bucket, planes
+        recv = self._route(bucket, rank_of_bucket, matrix, planes, scatter)
+        del bucket, planes, scatter
         mark()
         # 3. local topology, then the global streams of the top of the tree
         if compressed:

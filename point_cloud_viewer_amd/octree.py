@@ -332,6 +332,37 @@ class Context:
         counts = np.array(counts[:], dtype=np.int64)
         return (bucket, counts, state) if with_state else (bucket, counts)
 
+    def route_plan(self, resolution, bounding_box, x, y, z):
+        """First pass of the two-pass routing (pcv_route_plan): (bucket uint8 tensor, per-tile bucket histograms, 64 counts)
+        for device-resident points; the histograms are what pcv_route_scatter derives every owner's row offsets from."""
+        import torch
+        p, keep = self._points(x, y, z, None)
+        if p.mem != L.MEM_DEVICE:
+            raise ValueError("route_plan needs device tensors")
+        pr = self._params(resolution, bounding_box.min, bounding_box.max)
+        bucket = torch.empty(p.n, dtype=torch.uint8, device=x.device)
+        tiles = int(self.lib.pcv_route_tiles(p.n))
+        tile_hist = torch.empty((max(tiles, 1), 64), dtype=torch.int16, device=x.device)
+        counts = (C.c_uint64 * 64)()
+        self._check(self.lib.pcv_route_plan(self.handle, C.byref(pr), C.byref(p), bucket.data_ptr(), tile_hist.data_ptr(), counts))
+        return bucket, tile_hist, np.array(counts[:], dtype=np.int64)
+
+    def route_scatter(self, resolution, bounding_box, x, y, z, color, bucket, tile_hist, rank_of_bucket, dsts, intensity=None):
+        """Second pass (pcv_route_scatter): the level-1 state of every point written straight to its owner's planes.
+        dsts[r] = dict(oct_rgb, cx, cy, cz[, intensity]) of int32 (float32) device tensors (views into send / receive buffers)."""
+        p, keep = self._points(x, y, z, color, intensity)
+        pr = self._params(resolution, bounding_box.min, bounding_box.max)
+        world = len(dsts)
+        arr = (L.RouteDst * world)()
+        for r, d in enumerate(dsts):
+            for k in ("oct_rgb", "cx", "cy", "cz"):
+                setattr(arr[r], k, d[k].data_ptr() if d[k].numel() else None)
+            arr[r].intensity = d["intensity"].data_ptr() if intensity is not None and d["intensity"].numel() else None
+        table = (C.c_uint8 * 64)(*[int(v) for v in rank_of_bucket])
+        self._check(self.lib.pcv_route_scatter(self.handle, C.byref(pr), C.byref(p), bucket.data_ptr(), tile_hist.data_ptr(), world,
+                                               table, arr))
+        del keep
+
     def partition_by_owner(self, owner, planes, dsts, rank_of_bucket=None):
         """Stable partition of row-aligned device planes by owner. planes: list of tensors with the same number of rows;
         dsts[r][p]: tensor (view into a send / receive buffer) that receives rank r's rows of plane p in input order.

@@ -97,6 +97,45 @@ def test_route_buckets_and_partition_kernels():
                 assert torch.equal(got, p[sel])  # stable, every plane (8-, 3-, 4- and 1-byte rows)
 
 
+def test_two_pass_routing_equals_state_plus_partition():
+    """pcv_route_plan + pcv_route_scatter (the level-1 state computed in the scatter pass, never stored in input order) deliver
+    exactly what pcv_route_buckets(state) + pcv_partition_by_owner deliver: bucket, counts, and every owner's rows of the four
+    state planes (+ intensity) in input order — checked against the oracle's level-1 state (codec.rs:102-121 Float32 arm,
+    node.rs:34-42) for 1, 3 and 8 owners, an odd point count and an input that ends inside a tile."""
+    import torch
+    n = 300_001
+    x, y, z, rgb, bmin, bmax = synthetic.gaussian_clusters(n, seed=32, num_clusters=9, extent=200.0, sigma_range=(0.02, 9.0))
+    inten = (np.arange(n) % 241).astype(np.float32)
+    ctx = pcv.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    bbox = pcv.Aabb(bmin, bmax)
+    tx, ty, tz = (torch.from_numpy(a).cuda() for a in (x, y, z))
+    trgb, tint = torch.from_numpy(rgb).cuda(), torch.from_numpy(inten).cuda()
+    bucket, tile_hist, counts = ctx.route_plan(0.001, bbox, tx, ty, tz)
+    keys = O.chain_keys64(bmin, bmax, 0.001, 2, x, y, z)
+    want = ((keys >> np.uint64(57)).astype(np.int64) & 63)
+    assert np.array_equal(bucket.cpu().numpy().astype(np.int64), want)
+    assert np.array_equal(counts, np.bincount(want, minlength=64))
+    th = tile_hist.cpu().numpy().astype(np.int64)
+    assert th.shape == ((n + 4095) // 4096, 64)
+    for t in (0, 7, th.shape[0] - 1):
+        assert np.array_equal(th[t], np.bincount(want[t * 4096:(t + 1) * 4096], minlength=64))
+    o, cx, cy, cz = O.chain_state1(bmin, bmax, 0.001, x, y, z)
+    c = rgb.astype(np.uint32)
+    ref = {"oct_rgb": o | (c[:, 0] << 8) | (c[:, 1] << 16) | (c[:, 2] << 24), "cx": cx, "cy": cy, "cz": cz}
+    for world in (1, 3, 8):
+        rank_of, _ = pdist.plan_buckets(counts, world, 5000, True)
+        owner = rank_of[want].astype(np.int64)
+        cnt = np.bincount(owner, minlength=world)
+        dsts = [dict({k: torch.empty(int(q), dtype=torch.int32, device="cuda") for k in ("oct_rgb", "cx", "cy", "cz")},
+                     intensity=torch.empty(int(q), dtype=torch.float32, device="cuda")) for q in cnt]
+        ctx.route_scatter(0.001, bbox, tx, ty, tz, trgb, bucket, tile_hist, rank_of, dsts, intensity=tint)
+        for d in range(world):
+            sel = owner == d
+            for k in ("oct_rgb", "cx", "cy", "cz"):
+                assert np.array_equal(dsts[d][k].cpu().numpy().view(np.uint32), ref[k][sel]), (world, d, k)
+            assert np.array_equal(dsts[d]["intensity"].cpu().numpy(), inten[sel])
+
+
 @pytest.mark.parametrize("world,cap,with_intensity,compress", [(2, 0, False, True), (4, 20_000, True, True),
                                                                 (8, 3_000, False, True), (4, 20_000, True, False)])
 def test_virtual_ranks_on_one_gpu(world, cap, with_intensity, compress, tmp_path):
