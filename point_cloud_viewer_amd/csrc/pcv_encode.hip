@@ -465,6 +465,9 @@ __global__ __launch_bounds__(BLOCK, 8) void spec_encode4_kernel(
     const uint32_t* __restrict__ tree_info /* [0] = number of T'' nodes (spec_tree_scan_kernel) */,
     uint32_t diag /* 0; libpcv_hip_exp.so PCV_CHAIN_DIAG (timing only, wrong records — the launcher runs the real pass afterwards):
                      1 = no walk, 2 = stop after the deal, 4 = no record stores, 8 = stop after the coordinate loads */) {
+#ifndef PCV_EXPERIMENTS
+  diag = 0;  // (the shipped library carries none of the timing-only cuts)
+#endif
   __shared__ double sxyz[3 * BLOCK];
   double *const sx = sxyz, *const sy = sxyz + BLOCK, *const sz = sxyz + 2 * BLOCK;
   __shared__ uint16_t sidx[BLOCK];
