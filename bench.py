@@ -85,7 +85,12 @@ def valu_issue_model(insts, n, launch_ms):
     cycles_per_point = sum(per_point[k] * cyc[k] for k in cyc)  # lane-instructions x cycles per wave64 instruction
     simd_cycles = cycles_per_point * n / 64.0                    # wave instructions = lane instructions / 64
     have = 1024 * clock * 1e9 * launch_ms * 1e-3
-    return {"frac": round(simd_cycles / have, 4), "sustained_clock_GHz": clock,
+    # the static split counts the kernel's cold code too (the out-of-line IEEE divisions are all f64-pipe instructions), so it
+    # prices the rest too high; pricing ALL of the rest as plain 32-bit instructions prices it too low: the truth lies between
+    low_per_point = (per_point["f64_add_mul_fma"] * cyc["f64_add_mul_fma"] + per_point["f64_convert"] * cyc["f64_convert"] +
+                     rest * cyc["b32_plain"])
+    hi, lo = simd_cycles / have, low_per_point * n / 64.0 / have
+    return {"frac": round(0.5 * (hi + lo), 4), "frac_bounds": [round(lo, 4), round(hi, 4)], "sustained_clock_GHz": clock,
             "cycles_per_class": {k: round(v, 3) for k, v in cyc.items()},
             "lane_insts_per_point_per_class": {k: round(v, 2) for k, v in per_point.items()},
             "simd_cycles_per_wave": round(cycles_per_point, 1), "simds": 1024,
