@@ -868,8 +868,9 @@ def main():
                         "avg_launch_ms": view["avg_launch_ms"], "launches": view["launches"]}
             if insts:
                 g = insts["f64_valu_insts_per_point"] * n / (view["avg_launch_ms"] * 1e-3) / 1e9
+                issue = valu_issue_model(insts, n, view["avg_launch_ms"])
                 roofline.update({"achieved": round(g, 1), "frac": round(g / F64_VALU_PEAK_GINST, 4),
-                                 "valu_issue": valu_issue_model(insts, n, view["avg_launch_ms"]),
+                                 "valu_issue": issue,
                                  "valu_insts_per_point": insts["valu_insts_per_point"],
                                  "f64_arithmetic_insts_per_point": insts["f64_valu_insts_per_point"],
                                  "f64_arithmetic_share_of_valu": insts["f64_share"],
@@ -880,6 +881,13 @@ def main():
             else:
                 roofline.update({"achieved": None, "frac": None,
                                  "source": insts_src or "no SQ-counter pass of this round found (tools/profile_bench.sh)"})
+            if insts and (roofline.get("valu_issue") or {}).get("cycles_per_class"):
+                # the same figure against what THIS part sustains: 1 024 SIMDs x 64 lanes / measured cycles per f64 instruction x
+                # the clock it held during the kernel (the nominal peak assumes 4.0 cycles at 2.4 GHz)
+                vi = roofline["valu_issue"]
+                pk = 1024 * 64 / vi["cycles_per_class"]["f64_add_mul_fma"] * vi["sustained_clock_GHz"]
+                roofline["peak_sustained_measured"] = round(pk, 1)
+                roofline["frac_of_sustained_measured_peak"] = round(roofline["achieved"] / pk, 4)
             roofline["traffic"] = traffic
             roofline["traffic_source"] = traffic_src
             roofline["hbm_view"] = dict(view, traffic=traffic, traffic_source=traffic_src)
