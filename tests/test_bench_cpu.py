@@ -61,3 +61,29 @@ def test_build_hash_follows_the_sources(tmp_path, monkeypatch):
     with open(dst / "pcv_sort.hip", "a") as f:
         f.write("// one more byte\n")
     assert bench.build_hash() != h
+
+
+def test_valu_issue_model_prices_classes_with_the_measured_costs():
+    """bench.valu_issue_model: dynamic per-class counts x the issue costs of this round's probe, against 1 024 SIMDs x the
+    clock the counter pass saw; the two bounds bracket the mid figure, and a faster launch gives a higher fraction."""
+    insts = {"valu_insts_per_point": 600.0, "f64_valu_insts_per_point": 190.0, "f64_arith_insts_per_point": 190.0,
+             "cvt_insts_per_point": 36.0, "rest_insts_per_point": 374.0, "rest_static_share_f64_other": 0.4,
+             "rest_static_share_cmp32": 0.06, "sustained_clock_GHz": 2.07}
+    r = bench.valu_issue_model(insts, 100_000_000, 2.2)
+    if r.get("frac") is None:  # no probe recorded for this round yet
+        assert "note" in r
+        return
+    lo, hi = r["frac_bounds"]
+    assert 0.0 < lo < r["frac"] < hi < 1.5
+    c = r["cycles_per_class"]
+    assert 3.5 < c["f64_add_mul_fma"] < 5.5 and 1.8 < c["b32_plain"] < 3.2 and c["b32_compare"] > c["b32_plain"]
+    assert bench.valu_issue_model(insts, 100_000_000, 1.1)["frac"] > r["frac"] * 1.9
+    # counters of an older profile (no per-class fields): the model says so instead of guessing
+    assert bench.valu_issue_model({"valu_insts_per_point": 600.0}, 100_000_000, 2.2)["frac"] is None
+
+
+def test_query_profile_is_quoted_only_for_the_running_build():
+    p = bench.query_profile("0000000000000000")
+    assert p.get("profile_matches_build") in (False, None) and "cull_nodes_kernel" not in p
+    q = bench.query_profile(bench.build_hash())
+    assert q.get("profile_matches_build") in (True, False, None)
