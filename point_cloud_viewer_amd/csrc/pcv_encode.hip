@@ -109,7 +109,8 @@ __device__ __forceinline__ void pcv_spec_emit(uint64_t i, uint64_t n, uint32_t r
                                               uint4* __restrict__ payload, uint32_t* __restrict__ inten_bits,
                                               uint4* __restrict__ wide, uint32_t* __restrict__ pool_ctr, uint32_t pool_cap,
                                               uint32_t* stage_key = nullptr /* LDS: the workgroup stores its 12-byte records itself */,
-                                              uint2* stage_pay = nullptr, uint32_t stage_slot = 0) {
+                                              uint2* stage_pay = nullptr, uint32_t stage_slot = 0,
+                                              uint32_t region_in = 0xffffffffu /* pool region of the wave's points, or "from i" */) {
   // staged records: the colour is OR-ed in by the lane that stores the record (input order: a coalesced load off the wave's
   // critical path); otherwise it is fetched here
   const uint32_t rgb = stage_key ? 0u : pcv_load_rgb(color + i * color_stride, i + 1 < n);
@@ -126,7 +127,9 @@ __device__ __forceinline__ void pcv_spec_emit(uint64_t i, uint64_t n, uint32_t r
     if (wm != 0ull) {  // wave-uniform
       // every lane of a wave holds points of ONE slice of 1 024 input points (the deal stays inside the workgroup's points,
       // and workgroups of 256 / 512 / 1 024 points start on multiples of their size)
-      const uint32_t region = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(i >> 10)) & (kPcvPoolRegions - 1u);
+      const uint32_t region = region_in != 0xffffffffu
+                                  ? region_in
+                                  : ((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(i >> 10)) & (kPcvPoolRegions - 1u));
       uint32_t base = 0;
       if (is_wide && (wm & ((1ull << (threadIdx.x & 63)) - 1ull)) == 0ull)
         base = __hip_atomic_fetch_add(pool_ctr + region, (uint32_t)__popcll(wm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -385,6 +388,9 @@ __device__ __forceinline__ uint32_t pcv_wave_incl_scan32(uint32_t v) {  // inclu
 #ifndef PCV4_KEEP_BRANCH
 #define PCV4_KEEP_BRANCH 1
 #endif
+#ifndef PCV_CHAIN_DEFAULT
+#define PCV_CHAIN_DEFAULT 4  /* which chain pass ships: 4 = one workgroup per 512 points, 5 = producer / consumer workgroups */
+#endif
 
 /* walk record of T'' node `idx`: the first lds_nodes records (T'' is level-major: the top of the tree) are mirrored in LDS */
 #define PCV4_WALK_AT(idx) pcv4_walk_at(walk, swalk, lds_nodes, (idx))
@@ -585,6 +591,129 @@ __global__ __launch_bounds__(BLOCK, 8) void spec_encode4_kernel(
       reinterpret_cast<uint2*>(payload)[o] = make_uint2(q.x, q.y | ((rgb & 0xffffu) << 16));
     }
   }
+}
+
+// ---- the chain pass as a producer / consumer workgroup (round 4, late) -------------------------------------------------------
+// spec_encode4_kernel's phases ADD (memory phase 0.74 ms + walk 1.2 + records 0.2, tools/chain_diag.sh): a workgroup issues
+// nothing while its coordinates, the depth look-up and the deal are under way, then walks, then stores, and a wave in its walk
+// issues only a sixth of the time — with 4.5 of a SIMD's 8 waves in their walk at any moment the vector ALU is 67 % busy.
+// Here the workgroups stay (4 per CU) and split the roles: wave 0 is the LOADER — it fetches the NEXT tile's coordinates,
+// looks the depths up, deals the tile by predicted depth and, one tile later, ORs the colours into the finished records and
+// stores them in input order; waves 1..7 do nothing but walk (448 points per tile, deepest wave first) and leave their
+// records in LDS. One barrier per tile joins the two; every buffer exists twice. Same arithmetic, same records, same pool.
+constexpr int kT5 = 448;  // points per tile: 7 walking waves x 64 lanes
+template <bool KEEP>
+__global__ __launch_bounds__(512, 8) void spec_encode5_kernel(
+    PcvLevels lv, const uint32_t* __restrict__ walk, uint64_t n, uint32_t ntiles, const double* __restrict__ x,
+    const double* __restrict__ y, const double* __restrict__ z, const uint8_t* __restrict__ color, uint32_t color_stride,
+    const float* __restrict__ intensity, uint32_t* __restrict__ rank, uint4* __restrict__ payload, uint32_t* __restrict__ inten_bits,
+    const uint8_t* __restrict__ depth_grid, float cells_per_unit, uint4* __restrict__ wide, uint32_t* __restrict__ pool_ctr,
+    uint32_t pool_cap) {
+  __shared__ double cx[2][kT5], cy[2][kT5], cz[2][kT5];  // the tile's coordinates, input order
+  __shared__ uint16_t sidx[2][kT5];                      // dealt slot -> input position (deepest class first)
+  __shared__ uint32_t okey[2][kT5];                      // finished records by input position (without the colour)
+  __shared__ uint2 opay[2][kT5];
+  __shared__ uint32_t kcnt[32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool stage = wide != nullptr;  // 12-byte records (20-byte records go out straight from the walking lanes)
+  const uint32_t* const swalk = nullptr;
+  constexpr uint32_t lds_nodes = 0;
+
+  auto prepare = [&](uint32_t tile, int b) {  // loader wave
+    const uint64_t base = (uint64_t)tile * kT5;
+    if (lane < 32) kcnt[lane] = 0;
+    uint32_t key[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      const uint32_t j = (uint32_t)(k * 64 + lane);
+      const uint64_t i = base + j;
+      key[k] = kSpecClasses - 1;  // padding lanes go last
+      if (i < n) {
+        const double qx = x[i], qy = y[i], qz = z[i];
+        cx[b][j] = qx, cy[b][j] = qy, cz[b][j] = qz;
+        constexpr float kTop = (float)((1 << kGridBits) - 1);
+        const uint32_t ix = (uint32_t)fminf(fmaxf((float)(qx - lv.root_min[0]) * cells_per_unit, 0.f), kTop);
+        const uint32_t iy = (uint32_t)fminf(fmaxf((float)(qy - lv.root_min[1]) * cells_per_unit, 0.f), kTop);
+        const uint32_t iz = (uint32_t)fminf(fmaxf((float)(qz - lv.root_min[2]) * cells_per_unit, 0.f), kTop);
+        key[k] = (uint32_t)(kSpecClasses - 2) - depth_grid[ix | (iy << kGridBits) | (iz << (2 * kGridBits))];  // deepest first
+      }
+    }
+    uint32_t pos[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) pos[k] = __hip_atomic_fetch_add(&kcnt[key[k]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const uint32_t cnt = kcnt[lane & 31];
+    const uint32_t excl = pcv_wave_incl_scan32(lane < 32 ? cnt : 0u) - cnt;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      const uint32_t slot = (uint32_t)__shfl((int)excl, (int)key[k], 64) + pos[k];
+      sidx[b][slot] = (uint16_t)(k * 64 + lane);
+    }
+  };
+  auto store_tile = [&](uint32_t tile, int b) {  // loader wave: input order again, full lines; the colour joins here
+    const uint64_t base = (uint64_t)tile * kT5;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      const uint32_t j = (uint32_t)(k * 64 + lane);
+      const uint64_t o = base + j;
+      if (o < n) {
+        const uint32_t rgb = pcv_load_rgb(color + o * color_stride, o + 1 < n);
+        const uint2 q = opay[b][j];
+        rank[o] = okey[b][j] | (rgb >> 16);
+        reinterpret_cast<uint2*>(payload)[o] = make_uint2(q.x, q.y | ((rgb & 0xffffu) << 16));
+      }
+    }
+  };
+  auto walk_tile = [&](uint32_t tile, int b) {  // waves 1..7
+    const uint32_t j = sidx[b][(wave - 1) * 64 + lane];
+    const uint64_t i = (uint64_t)tile * kT5 + j;
+    if (i >= n) return;
+    double px = cx[b][j], py = cy[b][j], pz = cz[b][j];
+    double mx = lv.root_min[0], my = lv.root_min[1], mz = lv.root_min[2];
+    double vx = 0, vy = 0, vz = 0;
+    double kx = 0, ky = 0, kz = 0;
+    int kl = 0;
+    int L = 0;
+    uint32_t rec = walk[0];
+    int U = 0;
+    if (lv.fast_ok && pcv_point_is_tame(px, py, pz)) {
+      PCV4_WALK(false)
+    } else {
+      PCV4_WALK(true)
+    }
+    if (KEEP && kl) {
+      vx = kx, vy = ky, vz = kz;
+      L = kl;
+    }
+    uint32_t leaf_enc;
+    if (lv.first_f32 < (1 << 20))
+      leaf_enc = L >= lv.first_u8 ? PCV_ENC_UINT8 : L >= lv.first_u16 ? PCV_ENC_UINT16 : L >= lv.first_f32 ? PCV_ENC_FLOAT32 : lv.enc[0];
+    else
+      leaf_enc = lv.enc[L];
+    pcv_spec_emit(i, n, rec, leaf_enc, vx, vy, vz, color, color_stride, intensity, rank, payload, inten_bits, wide, pool_ctr, pool_cap,
+                  stage ? okey[b] : nullptr, opay[b], j, tile & (kPcvPoolRegions - 1u));
+  };
+
+  uint32_t tile = blockIdx.x;
+  if (tile >= ntiles) return;
+  if (wave == 0) prepare(tile, 0);
+  __syncthreads();
+  uint32_t prev = 0xffffffffu;
+  int t = 0;
+  for (;;) {
+    const uint32_t next = tile + gridDim.x;
+    if (wave == 0) {
+      if (prev != 0xffffffffu && stage) store_tile(prev, (t - 1) & 1);
+      if (next < ntiles) prepare(next, (t + 1) & 1);
+    } else {
+      walk_tile(tile, t & 1);
+    }
+    __syncthreads();
+    prev = tile;
+    tile = next;
+    ++t;
+    if (tile >= ntiles) break;
+  }
+  if (wave == 0 && stage) store_tile(prev, (t - 1) & 1);
 }
 #undef PCV4_WALK
 #undef PCV4_LOOP
@@ -1236,6 +1365,23 @@ static void launch_spec_encode_t(pcv_ctx* ctx, const PcvLevels& lv, const uint32
   const float cells = lv.edge[0] > 0.0 ? (float)((double)(1 << kGridBits) / lv.edge[0]) : 0.f;
   const uint32_t pool_cap = (uint32_t)pcv_pool_region_entries(n);
   if (BIN) hipLaunchKernelGGL(spec_depth_grid_kernel, dim3((1u << (3 * kGridBits)) / 256), dim3(256), 0, ctx->stream, walk, depth_grid);
+  static const int chain_v = [] {
+    const char* e = pcv_experiment("PCV_CHAIN_V");  // experiments: 5 = the producer / consumer workgroups, 4 / 3 as before
+    return e ? atoi(e) : PCV_CHAIN_DEFAULT;
+  }();
+  if (BIN && BLOCK == 512 && chain_v == 5 && !routed.oct) {
+    static const int cus = [] {
+      int dev = 0, c = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) c = 256;
+      return c;
+    }();
+    const uint64_t ntiles64 = (n + kT5 - 1) / kT5;
+    const uint32_t ntiles = (uint32_t)ntiles64;
+    const uint32_t groups = (uint32_t)std::min<uint64_t>(ntiles64, (uint64_t)cus * 4);
+    hipLaunchKernelGGL((spec_encode5_kernel<true>), dim3(groups), dim3(512), 0, ctx->stream, lv, walk, n, ntiles, x, y, z, color, color_stride,
+                       intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr, pool_cap);
+    return;
+  }
   if (BIN && v4) {
     // walk records mirrored in LDS (PCV_CHAIN_LDS=entries, libpcv_hip_exp.so): measured and NOT shipped — with 4 096 / 6 144 /
     // 8 192 entries per workgroup of 512 (12 288 per 1 024) the pass takes 2.12-2.35 ms against 2.04 without: copying the

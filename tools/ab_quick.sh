@@ -17,7 +17,7 @@ for v in $RUNS; do
 import json
 try:
     d=json.loads(open('gpurun_out/${T}_$i.json').read().strip().splitlines()[-1])
-    print('$name', d['value'], d['ms_per_step'], {k.replace('_kernel',''):round(v,3) for k,v in (d.get('kernel_ms_per_step') or {}).items()})
+    print('$name', d['value'], d['ms_per_step'], (d.get('tree_digest') or '')[:8], {k.replace('_kernel',''):round(v,3) for k,v in (d.get('kernel_ms_per_step') or {}).items()})
 except Exception as e: print('$name', 'ERR', e)
 PY
 done
