@@ -597,10 +597,12 @@ __global__ __launch_bounds__(BLOCK, 8) void spec_encode4_kernel(
 // spec_encode4_kernel's phases ADD (memory phase 0.74 ms + walk 1.2 + records 0.2, tools/chain_diag.sh): a workgroup issues
 // nothing while its coordinates, the depth look-up and the deal are under way, then walks, then stores, and a wave in its walk
 // issues only a sixth of the time — with 4.5 of a SIMD's 8 waves in their walk at any moment the vector ALU is 67 % busy.
-// Here the workgroups stay (4 per CU) and split the roles: wave 0 is the LOADER — it fetches the NEXT tile's coordinates,
-// looks the depths up, deals the tile by predicted depth and, one tile later, ORs the colours into the finished records and
-// stores them in input order; waves 1..7 do nothing but walk (448 points per tile, deepest wave first) and leave their
-// records in LDS. One barrier per tile joins the two; every buffer exists twice. Same arithmetic, same records, same pool.
+// Here the workgroups stay (4 per CU) and split the roles. Wave 0 is the LOADER: it requests the coordinates of the tile after
+// next by LDS-DMA (global_load_lds: no registers, in flight for a whole tile's walk), looks up the depths of the NEXT tile,
+// deals it by predicted depth, and ORs the colours into the records of the PREVIOUS tile and stores them in input order.
+// Waves 1..7 do nothing but walk (448 points per tile, deepest wave first); a lane leaves its record in the LDS words its
+// point's coordinates came from (it is the only reader of both). Three coordinate buffers rotate; one barrier per tile joins
+// the roles. Same arithmetic, same records, same pool as spec_encode4_kernel.
 constexpr int kT5 = 448;  // points per tile: 7 walking waves x 64 lanes
 template <bool KEEP>
 __global__ __launch_bounds__(512, 8) void spec_encode5_kernel(
@@ -608,29 +610,50 @@ __global__ __launch_bounds__(512, 8) void spec_encode5_kernel(
     const double* __restrict__ y, const double* __restrict__ z, const uint8_t* __restrict__ color, uint32_t color_stride,
     const float* __restrict__ intensity, uint32_t* __restrict__ rank, uint4* __restrict__ payload, uint32_t* __restrict__ inten_bits,
     const uint8_t* __restrict__ depth_grid, float cells_per_unit, uint4* __restrict__ wide, uint32_t* __restrict__ pool_ctr,
-    uint32_t pool_cap) {
-  __shared__ double cx[2][kT5], cy[2][kT5], cz[2][kT5];  // the tile's coordinates, input order
-  __shared__ uint16_t sidx[2][kT5];                      // dealt slot -> input position (deepest class first)
-  __shared__ uint32_t okey[2][kT5];                      // finished records by input position (without the colour)
-  __shared__ uint2 opay[2][kT5];
+    uint32_t pool_cap, uint32_t dma_ok /* x, y, z are 16-byte aligned */) {
+  __shared__ __attribute__((aligned(16))) double cbuf[3][3][kT5];  // [ring slot][axis][input position]; later the records
+  __shared__ uint16_t sidx[2][kT5];                                 // dealt slot -> input position (deepest class first)
   __shared__ uint32_t kcnt[32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool stage = wide != nullptr;  // 12-byte records (20-byte records go out straight from the walking lanes)
   const uint32_t* const swalk = nullptr;
   constexpr uint32_t lds_nodes = 0;
+  typedef __attribute__((address_space(3))) void lds_void;
 
-  auto prepare = [&](uint32_t tile, int b) {  // loader wave
+  // coordinates of `tile` -> ring slot s (loader wave). Full tiles of aligned arrays by DMA (not waited for here).
+  auto fill = [&](uint32_t tile, int s) {
+    const uint64_t base = (uint64_t)tile * kT5;
+    if (dma_ok && base + kT5 <= n) {
+      const double* const src[3] = {x + base, y + base, z + base};
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {  // 448 doubles = 224 lanes x 16 bytes
+          const int idx = c * 64 + lane;
+          if (idx < kT5 / 2)
+            __builtin_amdgcn_global_load_lds((const void*)(src[a] + 2 * idx), (lds_void*)(&cbuf[s][a][c * 128]), 16, 0, 0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        const uint32_t j = (uint32_t)(k * 64 + lane);
+        const uint64_t i = base + j;
+        if (i < n) cbuf[s][0][j] = x[i], cbuf[s][1][j] = y[i], cbuf[s][2][j] = z[i];
+      }
+    }
+  };
+  // depth look-up and deal of the tile whose coordinates are in slot s (loader wave) -> sidx[sb]
+  auto deal = [&](uint32_t tile, int s, int sb) {
     const uint64_t base = (uint64_t)tile * kT5;
     if (lane < 32) kcnt[lane] = 0;
     uint32_t key[7];
 #pragma unroll
     for (int k = 0; k < 7; ++k) {
       const uint32_t j = (uint32_t)(k * 64 + lane);
-      const uint64_t i = base + j;
       key[k] = kSpecClasses - 1;  // padding lanes go last
-      if (i < n) {
-        const double qx = x[i], qy = y[i], qz = z[i];
-        cx[b][j] = qx, cy[b][j] = qy, cz[b][j] = qz;
+      if (base + j < n) {
+        const double qx = cbuf[s][0][j], qy = cbuf[s][1][j], qz = cbuf[s][2][j];
         constexpr float kTop = (float)((1 << kGridBits) - 1);
         const uint32_t ix = (uint32_t)fminf(fmaxf((float)(qx - lv.root_min[0]) * cells_per_unit, 0.f), kTop);
         const uint32_t iy = (uint32_t)fminf(fmaxf((float)(qy - lv.root_min[1]) * cells_per_unit, 0.f), kTop);
@@ -646,28 +669,14 @@ __global__ __launch_bounds__(512, 8) void spec_encode5_kernel(
 #pragma unroll
     for (int k = 0; k < 7; ++k) {
       const uint32_t slot = (uint32_t)__shfl((int)excl, (int)key[k], 64) + pos[k];
-      sidx[b][slot] = (uint16_t)(k * 64 + lane);
+      sidx[sb][slot] = (uint16_t)(k * 64 + lane);
     }
   };
-  auto store_tile = [&](uint32_t tile, int b) {  // loader wave: input order again, full lines; the colour joins here
-    const uint64_t base = (uint64_t)tile * kT5;
-#pragma unroll
-    for (int k = 0; k < 7; ++k) {
-      const uint32_t j = (uint32_t)(k * 64 + lane);
-      const uint64_t o = base + j;
-      if (o < n) {
-        const uint32_t rgb = pcv_load_rgb(color + o * color_stride, o + 1 < n);
-        const uint2 q = opay[b][j];
-        rank[o] = okey[b][j] | (rgb >> 16);
-        reinterpret_cast<uint2*>(payload)[o] = make_uint2(q.x, q.y | ((rgb & 0xffffu) << 16));
-      }
-    }
-  };
-  auto walk_tile = [&](uint32_t tile, int b) {  // waves 1..7
-    const uint32_t j = sidx[b][(wave - 1) * 64 + lane];
+  auto walk_tile = [&](uint32_t tile, int s, int sb) {  // waves 1..7
+    const uint32_t j = sidx[sb][(wave - 1) * 64 + lane];
     const uint64_t i = (uint64_t)tile * kT5 + j;
     if (i >= n) return;
-    double px = cx[b][j], py = cy[b][j], pz = cz[b][j];
+    double px = cbuf[s][0][j], py = cbuf[s][1][j], pz = cbuf[s][2][j];
     double mx = lv.root_min[0], my = lv.root_min[1], mz = lv.root_min[2];
     double vx = 0, vy = 0, vz = 0;
     double kx = 0, ky = 0, kz = 0;
@@ -689,31 +698,82 @@ __global__ __launch_bounds__(512, 8) void spec_encode5_kernel(
       leaf_enc = L >= lv.first_u8 ? PCV_ENC_UINT8 : L >= lv.first_u16 ? PCV_ENC_UINT16 : L >= lv.first_f32 ? PCV_ENC_FLOAT32 : lv.enc[0];
     else
       leaf_enc = lv.enc[L];
+    // the record goes where the point's x and y came from (this lane was their only reader): key in the x word, payload in y
     pcv_spec_emit(i, n, rec, leaf_enc, vx, vy, vz, color, color_stride, intensity, rank, payload, inten_bits, wide, pool_ctr, pool_cap,
-                  stage ? okey[b] : nullptr, opay[b], j, tile & (kPcvPoolRegions - 1u));
+                  stage ? reinterpret_cast<uint32_t*>(&cbuf[s][0][j]) : nullptr, reinterpret_cast<uint2*>(&cbuf[s][1][j]), 0u,
+                  tile & (kPcvPoolRegions - 1u));
   };
+#define PCV5_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory") /* no vmcnt(0): a DMA may be in flight */
 
   uint32_t tile = blockIdx.x;
   if (tile >= ntiles) return;
-  if (wave == 0) prepare(tile, 0);
-  __syncthreads();
+  if (wave == 0) {
+    fill(tile, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    deal(tile, 0, 0);
+    if (tile + gridDim.x < ntiles) fill(tile + gridDim.x, 1);
+  }
+  PCV5_BARRIER();
   uint32_t prev = 0xffffffffu;
   int t = 0;
   for (;;) {
     const uint32_t next = tile + gridDim.x;
+    const int s = t % 3, s_next = (t + 1) % 3, s_prev = (t + 2) % 3;
     if (wave == 0) {
-      if (prev != 0xffffffffu && stage) store_tile(prev, (t - 1) & 1);
-      if (next < ntiles) prepare(next, (t + 1) & 1);
+      // previous tile: its colours (requested first: they travel while the next tile is dealt)
+      uint32_t rgb[7];
+      const bool out = prev != 0xffffffffu && stage;
+      if (out) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+          const uint64_t o = (uint64_t)prev * kT5 + (uint32_t)(k * 64 + lane);
+          rgb[k] = o < n ? pcv_load_rgb(color + o * color_stride, o + 1 < n) : 0u;
+        }
+      }
+      if (next < ntiles) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // its coordinates have landed (requested one tile ago)
+        deal(next, s_next, (t + 1) & 1);
+      }
+      if (out) {  // input order again, full lines
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+          const uint32_t j = (uint32_t)(k * 64 + lane);
+          const uint64_t o = (uint64_t)prev * kT5 + j;
+          if (o < n) {
+            const uint32_t key = *reinterpret_cast<const uint32_t*>(&cbuf[s_prev][0][j]);
+            const uint2 q = *reinterpret_cast<const uint2*>(&cbuf[s_prev][1][j]);
+            rank[o] = key | (rgb[k] >> 16);
+            reinterpret_cast<uint2*>(payload)[o] = make_uint2(q.x, q.y | ((rgb[k] & 0xffffu) << 16));
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the records have left the slot the next request overwrites
+      if ((uint64_t)next + gridDim.x < ntiles) fill(next + gridDim.x, s_prev);
     } else {
-      walk_tile(tile, t & 1);
+      walk_tile(tile, s, t & 1);
     }
-    __syncthreads();
+    PCV5_BARRIER();
     prev = tile;
     tile = next;
     ++t;
     if (tile >= ntiles) break;
   }
-  if (wave == 0 && stage) store_tile(prev, (t - 1) & 1);
+  if (wave == 0 && stage) {  // the last tile's records
+    const int s_prev = (t + 2) % 3;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      const uint32_t j = (uint32_t)(k * 64 + lane);
+      const uint64_t o = (uint64_t)prev * kT5 + j;
+      if (o < n) {
+        const uint32_t rgb = pcv_load_rgb(color + o * color_stride, o + 1 < n);
+        const uint32_t key = *reinterpret_cast<const uint32_t*>(&cbuf[s_prev][0][j]);
+        const uint2 q = *reinterpret_cast<const uint2*>(&cbuf[s_prev][1][j]);
+        rank[o] = key | (rgb >> 16);
+        reinterpret_cast<uint2*>(payload)[o] = make_uint2(q.x, q.y | ((rgb & 0xffffu) << 16));
+      }
+    }
+  }
+#undef PCV5_BARRIER
 }
 #undef PCV4_WALK
 #undef PCV4_LOOP
@@ -1379,7 +1439,8 @@ static void launch_spec_encode_t(pcv_ctx* ctx, const PcvLevels& lv, const uint32
     const uint32_t ntiles = (uint32_t)ntiles64;
     const uint32_t groups = (uint32_t)std::min<uint64_t>(ntiles64, (uint64_t)cus * 4);
     hipLaunchKernelGGL((spec_encode5_kernel<true>), dim3(groups), dim3(512), 0, ctx->stream, lv, walk, n, ntiles, x, y, z, color, color_stride,
-                       intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr, pool_cap);
+                       intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr, pool_cap,
+                       (((uintptr_t)x | (uintptr_t)y | (uintptr_t)z) & 15u) == 0 ? 1u : 0u);
     return;
   }
   if (BIN && v4) {
