@@ -388,6 +388,20 @@ __device__ __forceinline__ uint32_t pcv_wave_incl_scan32(uint32_t v) {  // inclu
 #ifndef PCV4_KEEP_BRANCH
 #define PCV4_KEEP_BRANCH 1
 #endif
+/* PCV_WAVE_PRIO: the deal puts the deepest points into the first waves, so a workgroup's life is its first wave's walk; 1 = the
+   waves run at s_setprio 3, 3, 2, 2, 1, 1, 0, 0 (deepest first) so that the critical wave is issued ahead of the others */
+#ifndef PCV_WAVE_PRIO
+#define PCV_WAVE_PRIO 0
+#endif
+__device__ __forceinline__ void pcv_wave_prio(int rank8 /* 0 = deepest wave .. 7 */) {
+#if PCV_WAVE_PRIO
+  if (rank8 < 2) __builtin_amdgcn_s_setprio(3);
+  else if (rank8 < 4) __builtin_amdgcn_s_setprio(2);
+  else if (rank8 < 6) __builtin_amdgcn_s_setprio(1);
+#else
+  (void)rank8;
+#endif
+}
 #ifndef PCV_CHAIN_DEFAULT
 #define PCV_CHAIN_DEFAULT 4  /* which chain pass ships: 4 = one workgroup per 512 points, 5 = producer / consumer workgroups */
 #endif
@@ -533,6 +547,7 @@ __global__ __launch_bounds__(BLOCK, 8) void spec_encode4_kernel(
   __syncthreads();
   const int j = sidx[tid];
   i = (uint64_t)blockIdx.x * BLOCK + j;
+  pcv_wave_prio((tid >> 6) * 8 / (BLOCK / 64));
   const bool stage = wide != nullptr;  // grid-uniform: 12-byte records
   if ((diag & 2u) && j != 70000) return;
   double px = 0, py = 0, pz = 0;
@@ -610,7 +625,11 @@ __global__ __launch_bounds__(512, 8) void spec_encode5_kernel(
     const double* __restrict__ y, const double* __restrict__ z, const uint8_t* __restrict__ color, uint32_t color_stride,
     const float* __restrict__ intensity, uint32_t* __restrict__ rank, uint4* __restrict__ payload, uint32_t* __restrict__ inten_bits,
     const uint8_t* __restrict__ depth_grid, float cells_per_unit, uint4* __restrict__ wide, uint32_t* __restrict__ pool_ctr,
-    uint32_t pool_cap, uint32_t dma_ok /* x, y, z are 16-byte aligned */) {
+    uint32_t pool_cap, uint32_t dma_ok /* x, y, z are 16-byte aligned */,
+    uint32_t diag /* exp library, timing only: 1 = the walking waves do not walk, 2 = the loader neither deals nor stores */) {
+#ifndef PCV_EXPERIMENTS
+  diag = 0;
+#endif
   __shared__ __attribute__((aligned(16))) double cbuf[3][3][kT5];  // [ring slot][axis][input position]; later the records
   __shared__ uint16_t sidx[2][kT5];                                 // dealt slot -> input position (deepest class first)
   __shared__ uint32_t kcnt[32];
@@ -684,7 +703,10 @@ __global__ __launch_bounds__(512, 8) void spec_encode5_kernel(
     int L = 0;
     uint32_t rec = walk[0];
     int U = 0;
-    if (lv.fast_ok && pcv_point_is_tame(px, py, pz)) {
+    if (diag & 1u) {
+      vx = px;
+      L = lv.first_u16 < (1 << 20) ? lv.first_u16 : 0;  // (a 16-bit record: no pool entry)
+    } else if (lv.fast_ok && pcv_point_is_tame(px, py, pz)) {
       PCV4_WALK(false)
     } else {
       PCV4_WALK(true)
@@ -707,6 +729,7 @@ __global__ __launch_bounds__(512, 8) void spec_encode5_kernel(
 
   uint32_t tile = blockIdx.x;
   if (tile >= ntiles) return;
+  pcv_wave_prio(wave == 0 ? 0 : wave - 1);
   if (wave == 0) {
     fill(tile, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -730,11 +753,11 @@ __global__ __launch_bounds__(512, 8) void spec_encode5_kernel(
           rgb[k] = o < n ? pcv_load_rgb(color + o * color_stride, o + 1 < n) : 0u;
         }
       }
-      if (next < ntiles) {
+      if (next < ntiles && !(diag & 2u)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // its coordinates have landed (requested one tile ago)
         deal(next, s_next, (t + 1) & 1);
       }
-      if (out) {  // input order again, full lines
+      if (out && !(diag & 2u)) {  // input order again, full lines
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
           const uint32_t j = (uint32_t)(k * 64 + lane);
@@ -1438,9 +1461,34 @@ static void launch_spec_encode_t(pcv_ctx* ctx, const PcvLevels& lv, const uint32
     const uint64_t ntiles64 = (n + kT5 - 1) / kT5;
     const uint32_t ntiles = (uint32_t)ntiles64;
     const uint32_t groups = (uint32_t)std::min<uint64_t>(ntiles64, (uint64_t)cus * 4);
+    const uint32_t dma_ok = (((uintptr_t)x | (uintptr_t)y | (uintptr_t)z) & 15u) == 0 ? 1u : 0u;
+#ifdef PCV_EXPERIMENTS
+    static const uint32_t diag5 = [] {
+      const char* e = pcv_experiment("PCV_CHAIN_DIAG");
+      return e ? (uint32_t)atoi(e) : 0u;
+    }();
+    if (diag5) {  // timing only: the cut-down pass runs first and is timed on its own, then the real pass overwrites what it wrote
+      for (uint32_t d : {0u, diag5}) {
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        (void)hipEventRecord(e0, ctx->stream);
+        hipLaunchKernelGGL((spec_encode5_kernel<true>), dim3(groups), dim3(512), 0, ctx->stream, lv, walk, n, ntiles, x, y, z, color,
+                           color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr, pool_cap,
+                           dma_ok, d);
+        (void)hipEventRecord(e1, ctx->stream);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        fprintf(stderr, "PCV_CHAIN_DIAG=%u v5 groups=%u: %.3f ms\n", d, groups, ms);
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        (void)hipMemsetAsync(pool_ctr, 0, kPcvPoolRegions * 4, ctx->stream);
+      }
+    }
+#endif
     hipLaunchKernelGGL((spec_encode5_kernel<true>), dim3(groups), dim3(512), 0, ctx->stream, lv, walk, n, ntiles, x, y, z, color, color_stride,
-                       intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr, pool_cap,
-                       (((uintptr_t)x | (uintptr_t)y | (uintptr_t)z) & 15u) == 0 ? 1u : 0u);
+                       intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr, pool_cap, dma_ok, 0u);
     return;
   }
   if (BIN && v4) {
