@@ -109,8 +109,7 @@ __device__ __forceinline__ void pcv_spec_emit(uint64_t i, uint64_t n, uint32_t r
                                               uint4* __restrict__ payload, uint32_t* __restrict__ inten_bits,
                                               uint4* __restrict__ wide, uint32_t* __restrict__ pool_ctr, uint32_t pool_cap,
                                               uint32_t* stage_key = nullptr /* LDS: the workgroup stores its 12-byte records itself */,
-                                              uint2* stage_pay = nullptr, uint32_t stage_slot = 0,
-                                              uint32_t region_in = 0xffffffffu /* pool region of the wave's points, or "from i" */) {
+                                              uint2* stage_pay = nullptr, uint32_t stage_slot = 0) {
   // staged records: the colour is OR-ed in by the lane that stores the record (input order: a coalesced load off the wave's
   // critical path); otherwise it is fetched here
   const uint32_t rgb = stage_key ? 0u : pcv_load_rgb(color + i * color_stride, i + 1 < n);
@@ -127,9 +126,7 @@ __device__ __forceinline__ void pcv_spec_emit(uint64_t i, uint64_t n, uint32_t r
     if (wm != 0ull) {  // wave-uniform
       // every lane of a wave holds points of ONE slice of 1 024 input points (the deal stays inside the workgroup's points,
       // and workgroups of 256 / 512 / 1 024 points start on multiples of their size)
-      const uint32_t region = region_in != 0xffffffffu
-                                  ? region_in
-                                  : ((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(i >> 10)) & (kPcvPoolRegions - 1u));
+      const uint32_t region = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(i >> 10)) & (kPcvPoolRegions - 1u);
       uint32_t base = 0;
       if (is_wide && (wm & ((1ull << (threadIdx.x & 63)) - 1ull)) == 0ull)
         base = __hip_atomic_fetch_add(pool_ctr + region, (uint32_t)__popcll(wm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -388,23 +385,6 @@ __device__ __forceinline__ uint32_t pcv_wave_incl_scan32(uint32_t v) {  // inclu
 #ifndef PCV4_KEEP_BRANCH
 #define PCV4_KEEP_BRANCH 1
 #endif
-/* PCV_WAVE_PRIO: the deal puts the deepest points into the first waves, so a workgroup's life is its first wave's walk; 1 = the
-   waves run at s_setprio 3, 3, 2, 2, 1, 1, 0, 0 (deepest first) so that the critical wave is issued ahead of the others */
-#ifndef PCV_WAVE_PRIO
-#define PCV_WAVE_PRIO 0
-#endif
-__device__ __forceinline__ void pcv_wave_prio(int rank8 /* 0 = deepest wave .. 7 */) {
-#if PCV_WAVE_PRIO
-  if (rank8 < 2) __builtin_amdgcn_s_setprio(3);
-  else if (rank8 < 4) __builtin_amdgcn_s_setprio(2);
-  else if (rank8 < 6) __builtin_amdgcn_s_setprio(1);
-#else
-  (void)rank8;
-#endif
-}
-#ifndef PCV_CHAIN_DEFAULT
-#define PCV_CHAIN_DEFAULT 4  /* which chain pass ships: 4 = one workgroup per 512 points, 5 = producer / consumer workgroups */
-#endif
 
 /* walk record of T'' node `idx`: the first lds_nodes records (T'' is level-major: the top of the tree) are mirrored in LDS */
 #define PCV4_WALK_AT(idx) pcv4_walk_at(walk, swalk, lds_nodes, (idx))
@@ -547,7 +527,6 @@ __global__ __launch_bounds__(BLOCK, 8) void spec_encode4_kernel(
   __syncthreads();
   const int j = sidx[tid];
   i = (uint64_t)blockIdx.x * BLOCK + j;
-  pcv_wave_prio((tid >> 6) * 8 / (BLOCK / 64));
   const bool stage = wide != nullptr;  // grid-uniform: 12-byte records
   if ((diag & 2u) && j != 70000) return;
   double px = 0, py = 0, pz = 0;
@@ -606,197 +585,6 @@ __global__ __launch_bounds__(BLOCK, 8) void spec_encode4_kernel(
       reinterpret_cast<uint2*>(payload)[o] = make_uint2(q.x, q.y | ((rgb & 0xffffu) << 16));
     }
   }
-}
-
-// ---- the chain pass as a producer / consumer workgroup (round 4, late) -------------------------------------------------------
-// spec_encode4_kernel's phases ADD (memory phase 0.74 ms + walk 1.2 + records 0.2, tools/chain_diag.sh): a workgroup issues
-// nothing while its coordinates, the depth look-up and the deal are under way, then walks, then stores, and a wave in its walk
-// issues only a sixth of the time — with 4.5 of a SIMD's 8 waves in their walk at any moment the vector ALU is 67 % busy.
-// Here the workgroups stay (4 per CU) and split the roles. Wave 0 is the LOADER: it requests the coordinates of the tile after
-// next by LDS-DMA (global_load_lds: no registers, in flight for a whole tile's walk), looks up the depths of the NEXT tile,
-// deals it by predicted depth, and ORs the colours into the records of the PREVIOUS tile and stores them in input order.
-// Waves 1..7 do nothing but walk (448 points per tile, deepest wave first); a lane leaves its record in the LDS words its
-// point's coordinates came from (it is the only reader of both). Three coordinate buffers rotate; one barrier per tile joins
-// the roles. Same arithmetic, same records, same pool as spec_encode4_kernel.
-constexpr int kT5 = 448;  // points per tile: 7 walking waves x 64 lanes
-template <bool KEEP>
-__global__ __launch_bounds__(512, 8) void spec_encode5_kernel(
-    PcvLevels lv, const uint32_t* __restrict__ walk, uint64_t n, uint32_t ntiles, const double* __restrict__ x,
-    const double* __restrict__ y, const double* __restrict__ z, const uint8_t* __restrict__ color, uint32_t color_stride,
-    const float* __restrict__ intensity, uint32_t* __restrict__ rank, uint4* __restrict__ payload, uint32_t* __restrict__ inten_bits,
-    const uint8_t* __restrict__ depth_grid, float cells_per_unit, uint4* __restrict__ wide, uint32_t* __restrict__ pool_ctr,
-    uint32_t pool_cap, uint32_t dma_ok /* x, y, z are 16-byte aligned */,
-    uint32_t diag /* exp library, timing only: 1 = the walking waves do not walk, 2 = the loader neither deals nor stores */) {
-#ifndef PCV_EXPERIMENTS
-  diag = 0;
-#endif
-  __shared__ __attribute__((aligned(16))) double cbuf[3][3][kT5];  // [ring slot][axis][input position]; later the records
-  __shared__ uint16_t sidx[2][kT5];                                 // dealt slot -> input position (deepest class first)
-  __shared__ uint32_t kcnt[32];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const bool stage = wide != nullptr;  // 12-byte records (20-byte records go out straight from the walking lanes)
-  const uint32_t* const swalk = nullptr;
-  constexpr uint32_t lds_nodes = 0;
-  typedef __attribute__((address_space(3))) void lds_void;
-
-  // coordinates of `tile` -> ring slot s (loader wave). Full tiles of aligned arrays by DMA (not waited for here).
-  auto fill = [&](uint32_t tile, int s) {
-    const uint64_t base = (uint64_t)tile * kT5;
-    if (dma_ok && base + kT5 <= n) {
-      const double* const src[3] = {x + base, y + base, z + base};
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {  // 448 doubles = 224 lanes x 16 bytes
-          const int idx = c * 64 + lane;
-          if (idx < kT5 / 2)
-            __builtin_amdgcn_global_load_lds((const void*)(src[a] + 2 * idx), (lds_void*)(&cbuf[s][a][c * 128]), 16, 0, 0);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < 7; ++k) {
-        const uint32_t j = (uint32_t)(k * 64 + lane);
-        const uint64_t i = base + j;
-        if (i < n) cbuf[s][0][j] = x[i], cbuf[s][1][j] = y[i], cbuf[s][2][j] = z[i];
-      }
-    }
-  };
-  // depth look-up and deal of the tile whose coordinates are in slot s (loader wave) -> sidx[sb]
-  auto deal = [&](uint32_t tile, int s, int sb) {
-    const uint64_t base = (uint64_t)tile * kT5;
-    if (lane < 32) kcnt[lane] = 0;
-    uint32_t key[7];
-#pragma unroll
-    for (int k = 0; k < 7; ++k) {
-      const uint32_t j = (uint32_t)(k * 64 + lane);
-      key[k] = kSpecClasses - 1;  // padding lanes go last
-      if (base + j < n) {
-        const double qx = cbuf[s][0][j], qy = cbuf[s][1][j], qz = cbuf[s][2][j];
-        constexpr float kTop = (float)((1 << kGridBits) - 1);
-        const uint32_t ix = (uint32_t)fminf(fmaxf((float)(qx - lv.root_min[0]) * cells_per_unit, 0.f), kTop);
-        const uint32_t iy = (uint32_t)fminf(fmaxf((float)(qy - lv.root_min[1]) * cells_per_unit, 0.f), kTop);
-        const uint32_t iz = (uint32_t)fminf(fmaxf((float)(qz - lv.root_min[2]) * cells_per_unit, 0.f), kTop);
-        key[k] = (uint32_t)(kSpecClasses - 2) - depth_grid[ix | (iy << kGridBits) | (iz << (2 * kGridBits))];  // deepest first
-      }
-    }
-    uint32_t pos[7];
-#pragma unroll
-    for (int k = 0; k < 7; ++k) pos[k] = __hip_atomic_fetch_add(&kcnt[key[k]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    const uint32_t cnt = kcnt[lane & 31];
-    const uint32_t excl = pcv_wave_incl_scan32(lane < 32 ? cnt : 0u) - cnt;
-#pragma unroll
-    for (int k = 0; k < 7; ++k) {
-      const uint32_t slot = (uint32_t)__shfl((int)excl, (int)key[k], 64) + pos[k];
-      sidx[sb][slot] = (uint16_t)(k * 64 + lane);
-    }
-  };
-  auto walk_tile = [&](uint32_t tile, int s, int sb) {  // waves 1..7
-    const uint32_t j = sidx[sb][(wave - 1) * 64 + lane];
-    const uint64_t i = (uint64_t)tile * kT5 + j;
-    if (i >= n) return;
-    double px = cbuf[s][0][j], py = cbuf[s][1][j], pz = cbuf[s][2][j];
-    double mx = lv.root_min[0], my = lv.root_min[1], mz = lv.root_min[2];
-    double vx = 0, vy = 0, vz = 0;
-    double kx = 0, ky = 0, kz = 0;
-    int kl = 0;
-    int L = 0;
-    uint32_t rec = walk[0];
-    int U = 0;
-    if (diag & 1u) {
-      vx = px;
-      L = lv.first_u16 < (1 << 20) ? lv.first_u16 : 0;  // (a 16-bit record: no pool entry)
-    } else if (lv.fast_ok && pcv_point_is_tame(px, py, pz)) {
-      PCV4_WALK(false)
-    } else {
-      PCV4_WALK(true)
-    }
-    if (KEEP && kl) {
-      vx = kx, vy = ky, vz = kz;
-      L = kl;
-    }
-    uint32_t leaf_enc;
-    if (lv.first_f32 < (1 << 20))
-      leaf_enc = L >= lv.first_u8 ? PCV_ENC_UINT8 : L >= lv.first_u16 ? PCV_ENC_UINT16 : L >= lv.first_f32 ? PCV_ENC_FLOAT32 : lv.enc[0];
-    else
-      leaf_enc = lv.enc[L];
-    // the record goes where the point's x and y came from (this lane was their only reader): key in the x word, payload in y
-    pcv_spec_emit(i, n, rec, leaf_enc, vx, vy, vz, color, color_stride, intensity, rank, payload, inten_bits, wide, pool_ctr, pool_cap,
-                  stage ? reinterpret_cast<uint32_t*>(&cbuf[s][0][j]) : nullptr, reinterpret_cast<uint2*>(&cbuf[s][1][j]), 0u,
-                  tile & (kPcvPoolRegions - 1u));
-  };
-#define PCV5_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory") /* no vmcnt(0): a DMA may be in flight */
-
-  uint32_t tile = blockIdx.x;
-  if (tile >= ntiles) return;
-  pcv_wave_prio(wave == 0 ? 0 : wave - 1);
-  if (wave == 0) {
-    fill(tile, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    deal(tile, 0, 0);
-    if (tile + gridDim.x < ntiles) fill(tile + gridDim.x, 1);
-  }
-  PCV5_BARRIER();
-  uint32_t prev = 0xffffffffu;
-  int t = 0;
-  for (;;) {
-    const uint32_t next = tile + gridDim.x;
-    const int s = t % 3, s_next = (t + 1) % 3, s_prev = (t + 2) % 3;
-    if (wave == 0) {
-      // previous tile: its colours (requested first: they travel while the next tile is dealt)
-      uint32_t rgb[7];
-      const bool out = prev != 0xffffffffu && stage;
-      if (out) {
-#pragma unroll
-        for (int k = 0; k < 7; ++k) {
-          const uint64_t o = (uint64_t)prev * kT5 + (uint32_t)(k * 64 + lane);
-          rgb[k] = o < n ? pcv_load_rgb(color + o * color_stride, o + 1 < n) : 0u;
-        }
-      }
-      if (next < ntiles && !(diag & 2u)) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // its coordinates have landed (requested one tile ago)
-        deal(next, s_next, (t + 1) & 1);
-      }
-      if (out && !(diag & 2u)) {  // input order again, full lines
-#pragma unroll
-        for (int k = 0; k < 7; ++k) {
-          const uint32_t j = (uint32_t)(k * 64 + lane);
-          const uint64_t o = (uint64_t)prev * kT5 + j;
-          if (o < n) {
-            const uint32_t key = *reinterpret_cast<const uint32_t*>(&cbuf[s_prev][0][j]);
-            const uint2 q = *reinterpret_cast<const uint2*>(&cbuf[s_prev][1][j]);
-            rank[o] = key | (rgb[k] >> 16);
-            reinterpret_cast<uint2*>(payload)[o] = make_uint2(q.x, q.y | ((rgb[k] & 0xffffu) << 16));
-          }
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the records have left the slot the next request overwrites
-      if ((uint64_t)next + gridDim.x < ntiles) fill(next + gridDim.x, s_prev);
-    } else {
-      walk_tile(tile, s, t & 1);
-    }
-    PCV5_BARRIER();
-    prev = tile;
-    tile = next;
-    ++t;
-    if (tile >= ntiles) break;
-  }
-  if (wave == 0 && stage) {  // the last tile's records
-    const int s_prev = (t + 2) % 3;
-#pragma unroll
-    for (int k = 0; k < 7; ++k) {
-      const uint32_t j = (uint32_t)(k * 64 + lane);
-      const uint64_t o = (uint64_t)prev * kT5 + j;
-      if (o < n) {
-        const uint32_t rgb = pcv_load_rgb(color + o * color_stride, o + 1 < n);
-        const uint32_t key = *reinterpret_cast<const uint32_t*>(&cbuf[s_prev][0][j]);
-        const uint2 q = *reinterpret_cast<const uint2*>(&cbuf[s_prev][1][j]);
-        rank[o] = key | (rgb >> 16);
-        reinterpret_cast<uint2*>(payload)[o] = make_uint2(q.x, q.y | ((rgb & 0xffffu) << 16));
-      }
-    }
-  }
-#undef PCV5_BARRIER
 }
 #undef PCV4_WALK
 #undef PCV4_LOOP
@@ -1448,49 +1236,6 @@ static void launch_spec_encode_t(pcv_ctx* ctx, const PcvLevels& lv, const uint32
   const float cells = lv.edge[0] > 0.0 ? (float)((double)(1 << kGridBits) / lv.edge[0]) : 0.f;
   const uint32_t pool_cap = (uint32_t)pcv_pool_region_entries(n);
   if (BIN) hipLaunchKernelGGL(spec_depth_grid_kernel, dim3((1u << (3 * kGridBits)) / 256), dim3(256), 0, ctx->stream, walk, depth_grid);
-  static const int chain_v = [] {
-    const char* e = pcv_experiment("PCV_CHAIN_V");  // experiments: 5 = the producer / consumer workgroups, 4 / 3 as before
-    return e ? atoi(e) : PCV_CHAIN_DEFAULT;
-  }();
-  if (BIN && BLOCK == 512 && chain_v == 5 && !routed.oct) {
-    static const int cus = [] {
-      int dev = 0, c = 0;
-      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) c = 256;
-      return c;
-    }();
-    const uint64_t ntiles64 = (n + kT5 - 1) / kT5;
-    const uint32_t ntiles = (uint32_t)ntiles64;
-    const uint32_t groups = (uint32_t)std::min<uint64_t>(ntiles64, (uint64_t)cus * 4);
-    const uint32_t dma_ok = (((uintptr_t)x | (uintptr_t)y | (uintptr_t)z) & 15u) == 0 ? 1u : 0u;
-#ifdef PCV_EXPERIMENTS
-    static const uint32_t diag5 = [] {
-      const char* e = pcv_experiment("PCV_CHAIN_DIAG");
-      return e ? (uint32_t)atoi(e) : 0u;
-    }();
-    if (diag5) {  // timing only: the cut-down pass runs first and is timed on its own, then the real pass overwrites what it wrote
-      for (uint32_t d : {0u, diag5}) {
-        hipEvent_t e0, e1;
-        (void)hipEventCreate(&e0);
-        (void)hipEventCreate(&e1);
-        (void)hipEventRecord(e0, ctx->stream);
-        hipLaunchKernelGGL((spec_encode5_kernel<true>), dim3(groups), dim3(512), 0, ctx->stream, lv, walk, n, ntiles, x, y, z, color,
-                           color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr, pool_cap,
-                           dma_ok, d);
-        (void)hipEventRecord(e1, ctx->stream);
-        (void)hipEventSynchronize(e1);
-        float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, e0, e1);
-        fprintf(stderr, "PCV_CHAIN_DIAG=%u v5 groups=%u: %.3f ms\n", d, groups, ms);
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-        (void)hipMemsetAsync(pool_ctr, 0, kPcvPoolRegions * 4, ctx->stream);
-      }
-    }
-#endif
-    hipLaunchKernelGGL((spec_encode5_kernel<true>), dim3(groups), dim3(512), 0, ctx->stream, lv, walk, n, ntiles, x, y, z, color, color_stride,
-                       intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr, pool_cap, dma_ok, 0u);
-    return;
-  }
   if (BIN && v4) {
     // walk records mirrored in LDS (PCV_CHAIN_LDS=entries, libpcv_hip_exp.so): measured and NOT shipped — with 4 096 / 6 144 /
     // 8 192 entries per workgroup of 512 (12 288 per 1 024) the pass takes 2.12-2.35 ms against 2.04 without: copying the

@@ -385,13 +385,8 @@ void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* w
                             uint32_t color_stride, const float* intensity, uint32_t* rank, void* payload /* uint4[n] */,
                             uint32_t* inten_bits, uint8_t* depth_grid, void* wide, uint32_t* pool_ctr, const uint32_t* tree_info);
 constexpr uint32_t kPcvPoolRegions = 1024;
-// entries per region: every slice of 1 024 points (or every tile of 448 points of the producer / consumer pass, whose
-// regions go by tile) could be all Float32-coded
-inline uint64_t pcv_pool_region_entries(uint64_t n) {
-  const uint64_t by_slice = (((n + 1023) / 1024 + kPcvPoolRegions - 1) / kPcvPoolRegions) * 1024;
-  const uint64_t by_tile = (((n + 447) / 448 + kPcvPoolRegions - 1) / kPcvPoolRegions) * 448;
-  return by_slice > by_tile ? by_slice : by_tile;
-}
+// entries per region: every slice of 1 024 points could be all Float32-coded
+inline uint64_t pcv_pool_region_entries(uint64_t n) { return (((n + 1023) / 1024 + kPcvPoolRegions - 1) / kPcvPoolRegions) * 1024; }
 size_t pcv_spec_depth_grid_bytes();  // scratch for the depth-prediction grid of the binned pass
 void pcv_launch_rank_hist(pcv_ctx* ctx, const uint32_t* rank, uint64_t n, uint32_t num_bins, uint32_t* counts /* zeroed */,
                           int shift = 0);
