@@ -6,7 +6,8 @@ TAG=${1:-tl}; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d /tmp/${TAG}_tl -o r -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 4 --no-cpu-baseline --no-e2e --no-kernel-events "$@" > $OUT/${TAG}_tl.log 2>&1
+source $GRAFT_REPO_ROOT/tools/run_limited.sh
+run_limited 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/${TAG}_tl -o r -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 4 --no-cpu-baseline --no-e2e --no-kernel-events "$@" > $OUT/${TAG}_tl.log 2>&1
 python - /tmp/${TAG}_tl $OUT/${TAG}_timeline.txt <<'PY'
 import csv, glob, sys
 rows = []
