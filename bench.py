@@ -853,7 +853,7 @@ def main():
             # launch where one kernel runs with several key widths: the u32 upsweep, not the sample's u64 one)
             alias = {"promote_settle_kernel": "promote_settle_leaf_kernel", "promote_climb_kernel": "promote_climb_leaf_kernel",
                      "downsweep_rec_kernel": "downsweep_rec12_kernel", "upsweep_kernel<u32>": "upsweep_kernel",
-                     "spec_encode_kernel": "spec_encode4_kernel"}
+                     "spec_encode_kernel": "spec_encode_pair_kernel"}
             return per.get(name, per.get(alias.get(name, name))), os.path.relpath(path, ROOT)
 
         dom = max(timed, key=lambda k: timed[k][1])  # dominant kernel by accumulated time inside the timed region

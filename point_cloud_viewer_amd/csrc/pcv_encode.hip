@@ -586,6 +586,158 @@ __global__ __launch_bounds__(BLOCK, 8) void spec_encode4_kernel(
     }
   }
 }
+__device__ __forceinline__ uint32_t pcv_lane_again() {  // the lane number, recomputed (opaque to the compiler: nothing to keep live)
+  uint32_t zero = 0;
+  asm volatile("" : "+v"(zero));
+  return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zero));
+}
+// ---- the chain pass, tiles of two points per lane (round 4, second form) -------------------------------------------------
+// spec_encode4_kernel ends on a barrier (its records leave through LDS), and the deal hands the workgroup's DEEPEST points
+// to its first wave and the shallowest to its last: every wave of the workgroup then holds its slot until the deepest wave
+// is through — 9-10 level steps against a mean of 6.5. Here a workgroup takes 2 x BLOCK points, deals them into
+// 2 x BLOCK / 64 groups by predicted depth, and wave w walks group w (the deep end) and then group 2 x waves - 1 - w (the
+// shallow end): the waves reach the closing barrier together, the barriers and the latency of the loads, the depth look-up
+// and the deal are paid once per two points of a lane. Same walk, same arithmetic, same records.
+// LDS: the coordinates of the tile in two halves of BLOCK dealt slots ({x[BLOCK], y[BLOCK], z[BLOCK]} each); the first half
+// is dead once every wave has fetched its first group and becomes the staging area of the tile's 2 x BLOCK records.
+template <bool KEEP, int BLOCK, bool BALANCED = true /* false (experiments): wave w walks groups w and waves + w */>
+__global__ __launch_bounds__(BLOCK, 8) void spec_encode_pair_kernel(
+    PcvLevels lv, const uint32_t* __restrict__ walk, uint64_t n, const double* __restrict__ x, const double* __restrict__ y,
+    const double* __restrict__ z, PcvRouted routed, const uint8_t* __restrict__ color, uint32_t color_stride,
+    const float* __restrict__ intensity, uint32_t* __restrict__ rank, uint4* __restrict__ payload, uint32_t* __restrict__ inten_bits,
+    const uint8_t* __restrict__ depth_grid, float cells_per_unit /* 128 / root edge */, uint4* __restrict__ wide /* set: 12-byte records */,
+    uint32_t* __restrict__ pool_ctr, uint32_t pool_cap) {
+  constexpr int TILE = 2 * BLOCK, kGroups = TILE / 64;
+  __shared__ double sxyz[3 * TILE];  // slot s: half s / BLOCK, {x, y, z}[s % BLOCK]
+  __shared__ uint16_t sidx[TILE];
+  __shared__ uint32_t kcnt[32];  // points of the tile per depth class
+  uint32_t* const okey = reinterpret_cast<uint32_t*>(sxyz);          // TILE keys: the x of the first half
+  uint2* const opay = reinterpret_cast<uint2*>(sxyz + BLOCK);        // TILE payloads: its y and z
+  constexpr uint32_t lds_nodes = 0;  // (PCV4_WALK_AT: no LDS mirror of the walk records)
+  const uint32_t* const swalk = nullptr;
+  // the wave's number is a scalar and the lane number can be had again from nothing (mbcnt): no lane-indexed value needs to
+  // stay in a register across the walks
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  int lane = (int)pcv_lane_again(), tid = wave * 64 + lane;
+  const uint64_t base = (uint64_t)blockIdx.x * TILE;
+  const bool raw = routed.oct == nullptr;  // grid-uniform
+  const bool stage = wide != nullptr;      // grid-uniform: 12-byte records
+  if (tid < 32) kcnt[tid] = 0;
+  double qx[2], qy[2], qz[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const uint64_t i = base + (uint64_t)(h * BLOCK + tid);
+    qx[h] = qy[h] = qz[h] = 0.0;
+    if (i < n) {
+      if (raw) {
+        qx[h] = x[i], qy[h] = y[i], qz[h] = z[i];
+      } else {  // routed input: the position the sending rank held after level 1 (decode of the level-1 codes)
+        double t0, t1, t2, t3, t4, t5;
+        uint32_t dd;
+        (void)pcv_chain_start(lv, routed, x, y, z, i, qx[h], qy[h], qz[h], t0, t1, t2, t3, t4, t5, dd);
+      }
+    }
+  }
+  __syncthreads();  // the counters are zero (the coordinate loads are in flight)
+  uint32_t key[2], pos[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    key[h] = kSpecClasses - 1;  // padding lanes go last
+    if (base + (uint64_t)(h * BLOCK + tid) < n) {
+      // cell of the 128^3 grid over the root cube (NaN -> 0, out of range clamps) -> predicted depth (1..8, 8 = deeper)
+      constexpr float kTop = (float)((1 << kGridBits) - 1);
+      const uint32_t ix = (uint32_t)fminf(fmaxf((float)(qx[h] - lv.root_min[0]) * cells_per_unit, 0.f), kTop);
+      const uint32_t iy = (uint32_t)fminf(fmaxf((float)(qy[h] - lv.root_min[1]) * cells_per_unit, 0.f), kTop);
+      const uint32_t iz = (uint32_t)fminf(fmaxf((float)(qz[h] - lv.root_min[2]) * cells_per_unit, 0.f), kTop);
+      key[h] = (uint32_t)(kSpecClasses - 2) - depth_grid[ix | (iy << kGridBits) | (iz << (2 * kGridBits))];  // deepest first
+    }
+  }
+  // rank of a point among the tile's points of its class (any order inside a class will do)
+#pragma unroll
+  for (int h = 0; h < 2; ++h) pos[h] = __hip_atomic_fetch_add(&kcnt[key[h]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  __syncthreads();  // the counts are final
+  const uint32_t cnt = kcnt[lane & 31];
+  const uint32_t inc = pcv_wave_incl_scan32(lane < 32 ? cnt : 0u);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const uint32_t slot = (uint32_t)__shfl((int)(inc - cnt), (int)key[h], 64) + pos[h];  // classes ascending = deepest first
+    if (raw) {
+      double* const c = sxyz + (slot / BLOCK) * (3 * BLOCK) + (slot % BLOCK);
+      c[0] = qx[h], c[BLOCK] = qy[h], c[2 * BLOCK] = qz[h];
+    }
+    sidx[slot] = (uint16_t)(h * BLOCK + tid);
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int task = 0; task < 2; ++task) {
+    lane = (int)pcv_lane_again();
+    const int s = (task == 0 ? wave : BALANCED ? kGroups - 1 - wave : kGroups / 2 + wave) * 64 + lane;  // first the deep end, then the shallow end
+    const int j = sidx[s];
+    double px = 0, py = 0, pz = 0;
+    if (raw) {
+      const double* const c = sxyz + (s / BLOCK) * (3 * BLOCK) + (s % BLOCK);
+      px = c[0], py = c[BLOCK], pz = c[2 * BLOCK];
+    }
+    if (task == 0 && stage) __syncthreads();  // the first half now belongs to the records (the waves are still in step here)
+    const uint64_t i = base + (uint64_t)j;
+    if (i < n) {
+      double mx, my, mz;
+      double vx = 0, vy = 0, vz = 0;
+      double kx = 0, ky = 0, kz = 0;
+      int kl = 0;
+      uint32_t d1 = 0;
+      int L = 0;
+      uint32_t rec = walk[0];
+      if (raw) {
+        mx = lv.root_min[0], my = lv.root_min[1], mz = lv.root_min[2];
+      } else if (pcv_chain_start(lv, routed, x, y, z, i, px, py, pz, mx, my, mz, vx, vy, vz, d1) == 2 && !(rec & PCV_SPEC_LEAF)) {
+        L = 1;  // level 1 is given (digit + codes)
+        rec = walk[(rec & PCV_SPEC_INDEX_MASK) + d1];
+      }
+      int U = __builtin_amdgcn_readfirstlane(L);  // the wave's level counter (all lanes start at the same level: 0, or 1 for routed input)
+      if (lv.fast_ok && pcv_point_is_tame(px, py, pz)) {
+        PCV4_WALK(false)
+      } else {
+        PCV4_WALK(true)
+      }
+      // the record carries the codes of the first candidate on the path where there is one, else those of the predicted leaf
+      if (KEEP && kl) {
+        vx = kx, vy = ky, vz = kz;
+        L = kl;
+      }
+      // the point's index again, from its slot in the tile: keeping the 64-bit index alive across the loops costs a spill
+      uint32_t jj = (uint32_t)j;
+      asm volatile("" : "+v"(jj));
+      const uint64_t i2 = (uint64_t)blockIdx.x * TILE + jj;
+      uint32_t leaf_enc;  // (see spec_encode4_kernel)
+      if (lv.first_f32 < (1 << 20))
+        leaf_enc = L >= lv.first_u8 ? PCV_ENC_UINT8 : L >= lv.first_u16 ? PCV_ENC_UINT16 : L >= lv.first_f32 ? PCV_ENC_FLOAT32 : lv.enc[0];
+      else
+        leaf_enc = lv.enc[L];
+      pcv_spec_emit(i2, n, rec, leaf_enc, vx, vy, vz, color, color_stride, intensity, rank, payload, inten_bits, wide, pool_ctr, pool_cap,
+                    stage ? okey : nullptr, opay, jj);
+    }
+  }
+  if (stage) {  // input order again: full lines; the colour joins here
+    tid = wave * 64 + (int)pcv_lane_again();
+    uint32_t rgb[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const uint64_t o = base + (uint64_t)(h * BLOCK + tid);
+      rgb[h] = o < n ? pcv_load_rgb(color + o * color_stride, o + 1 < n) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const uint64_t o = base + (uint64_t)(h * BLOCK + tid);
+      if (o < n) {
+        const uint2 q = opay[h * BLOCK + tid];
+        rank[o] = okey[h * BLOCK + tid] | (rgb[h] >> 16);
+        reinterpret_cast<uint2*>(payload)[o] = make_uint2(q.x, q.y | ((rgb[h] & 0xffffu) << 16));
+      }
+    }
+  }
+}
 #undef PCV4_WALK
 #undef PCV4_LOOP
 #undef PCV4_KEEP_STEP
@@ -1231,12 +1383,27 @@ template <bool BIN, int BLOCK>
 static void launch_spec_encode_t(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* walk, uint64_t n, const double* x,
                                  const double* y, const double* z, const PcvRouted& routed, const uint8_t* color,
                                  uint32_t color_stride, const float* intensity, uint32_t* rank, void* payload,
-                                 uint32_t* inten_bits, uint8_t* depth_grid, void* wide, uint32_t* pool_ctr, bool v4, const uint32_t* tree_info) {
+                                 uint32_t* inten_bits, uint8_t* depth_grid, void* wide, uint32_t* pool_ctr, bool v4, bool pair,
+                                 const uint32_t* tree_info) {
   const dim3 grid((unsigned)((n + BLOCK - 1) / BLOCK));
   const float cells = lv.edge[0] > 0.0 ? (float)((double)(1 << kGridBits) / lv.edge[0]) : 0.f;
   const uint32_t pool_cap = (uint32_t)pcv_pool_region_entries(n);
   if (BIN) hipLaunchKernelGGL(spec_depth_grid_kernel, dim3((1u << (3 * kGridBits)) / 256), dim3(256), 0, ctx->stream, walk, depth_grid);
-  if (BIN && v4) {
+  if (BIN && v4 && pair && BLOCK <= 512) {  // tiles of 2 x BLOCK points (a tile must not span two pool regions: <= 1 024 points)
+    constexpr int PB = BLOCK <= 512 ? BLOCK : 512;
+#ifdef PCV_EXPERIMENTS
+    static const bool unbalanced = pcv_experiment("PCV_PAIR_UNBALANCED") != nullptr;
+    if (unbalanced) {
+      hipLaunchKernelGGL((spec_encode_pair_kernel<true, PB, false>), dim3((unsigned)((n + 2 * PB - 1) / (2 * PB))), dim3(PB), 0, ctx->stream, lv, walk, n, x,
+                         y, z, routed, color, color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide,
+                         pool_ctr, pool_cap);
+      return;
+    }
+#endif
+    hipLaunchKernelGGL((spec_encode_pair_kernel<true, PB>), dim3((unsigned)((n + 2 * PB - 1) / (2 * PB))), dim3(PB), 0, ctx->stream, lv, walk, n, x, y, z,
+                       routed, color, color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr,
+                       pool_cap);
+  } else if (BIN && v4) {
     // walk records mirrored in LDS (PCV_CHAIN_LDS=entries, libpcv_hip_exp.so): measured and NOT shipped — with 4 096 / 6 144 /
     // 8 192 entries per workgroup of 512 (12 288 per 1 024) the pass takes 2.12-2.35 ms against 2.04 without: copying the
     // table (30 KB per 512 points) costs the prologue what the LDS gathers save the walk, and above 5 000 entries a CU holds
@@ -1291,10 +1458,15 @@ void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* w
                             const uint32_t* tree_info /* device: [0] = number of T'' nodes (spec_tree_scan_kernel's info block) */) {
   if (n == 0) return;
   PcvProf prof(ctx, PCV_K_SPEC_ENCODE);
-  // PCV_CHAIN_V (experiments): 3 = round 3's kernel (ballot deal, packed digit), default 4
+  // PCV_CHAIN_V (experiments): 3 = round 3's kernel (ballot deal, packed digit), 4 = round 4's first form
   static const bool v4 = [] {
     const char* e = pcv_experiment("PCV_CHAIN_V");
     return !e || atoi(e) != 3;
+  }();
+  // tiles of two points per lane (spec_encode_pair_kernel) unless PCV_CHAIN_V=4 (experiments: one point per lane)
+  static const bool pair = [] {
+    const char* e = pcv_experiment("PCV_CHAIN_V");
+    return !e || atoi(e) > 4;
   }();
   const uint32_t pool_cap = (uint32_t)pcv_pool_region_entries(n);
   (void)pool_cap;
@@ -1334,16 +1506,16 @@ void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* w
 #endif
   if (!bin)
     launch_spec_encode_t<false, 256>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, inten_bits,
-                                     depth_grid, wide, pool_ctr, v4, tree_info);
+                                     depth_grid, wide, pool_ctr, v4, pair, tree_info);
   else if (bin_mode == 256)
     launch_spec_encode_t<true, 256>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, inten_bits,
-                                     depth_grid, wide, pool_ctr, v4, tree_info);
+                                     depth_grid, wide, pool_ctr, v4, pair, tree_info);
   else if (bin_mode == 512)
     launch_spec_encode_t<true, 512>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, inten_bits,
-                                     depth_grid, wide, pool_ctr, v4, tree_info);
+                                     depth_grid, wide, pool_ctr, v4, pair, tree_info);
   else
     launch_spec_encode_t<true, 1024>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, inten_bits,
-                                     depth_grid, wide, pool_ctr, v4, tree_info);
+                                     depth_grid, wide, pool_ctr, v4, pair, tree_info);
 }
 
 size_t pcv_spec_depth_grid_bytes() { return (size_t)1 << (3 * kGridBits); }

@@ -5,5 +5,5 @@
 mkdir -p gpurun_out
 for cfg in ${CONFIGS:-PCV_CHAIN_DIAG=1}; do
   echo "== $cfg"
-  env PCV_HIP_LIBRARY=exp ${cfg//,/ } timeout 120 python bench.py --steps 3 --warmup 1 --no-e2e --no-cpu-baseline --no-parity --no-kernel-events 2>&1 >/dev/null | grep PCV_CHAIN_DIAG | tail -4 | tr '\n' ' '; echo
+  env PCV_HIP_LIBRARY=exp PCV_CHAIN_V=4 ${cfg//,/ } timeout 120 python bench.py --steps 3 --warmup 1 --no-e2e --no-cpu-baseline --no-parity --no-kernel-events 2>&1 >/dev/null | grep PCV_CHAIN_DIAG | tail -4 | tr '\n' ' '; echo
 done
