@@ -600,7 +600,9 @@ __device__ __forceinline__ uint32_t pcv_lane_again() {  // the lane number, reco
 // and the deal are paid once per two points of a lane. Same walk, same arithmetic, same records.
 // LDS: the coordinates of the tile in two halves of BLOCK dealt slots ({x[BLOCK], y[BLOCK], z[BLOCK]} each); the first half
 // is dead once every wave has fetched its first group and becomes the staging area of the tile's 2 x BLOCK records.
-template <bool KEEP, int BLOCK, bool BALANCED = true /* false (experiments): wave w walks groups w and waves + w */>
+template <bool KEEP, int BLOCK, bool BALANCED = true /* false (experiments): wave w walks groups w and waves + w */,
+          bool FAKE = false /* true (experiments, timing only, wrong records): the walk gathers are served by a dummy table in LDS that
+                               ends every walk at the depth the grid predicts */>
 __global__ __launch_bounds__(BLOCK, 8) void spec_encode_pair_kernel(
     PcvLevels lv, const uint32_t* __restrict__ walk, uint64_t n, const double* __restrict__ x, const double* __restrict__ y,
     const double* __restrict__ z, PcvRouted routed, const uint8_t* __restrict__ color, uint32_t color_stride,
@@ -613,8 +615,9 @@ __global__ __launch_bounds__(BLOCK, 8) void spec_encode_pair_kernel(
   __shared__ uint32_t kcnt[32];  // points of the tile per depth class
   uint32_t* const okey = reinterpret_cast<uint32_t*>(sxyz);          // TILE keys: the x of the first half
   uint2* const opay = reinterpret_cast<uint2*>(sxyz + BLOCK);        // TILE payloads: its y and z
-  constexpr uint32_t lds_nodes = 0;  // (PCV4_WALK_AT: no LDS mirror of the walk records)
-  const uint32_t* const swalk = nullptr;
+  __shared__ uint32_t sfake[FAKE ? 2048 : 4];  // [(depth * 16 + level) * 8 + digit]
+  constexpr uint32_t lds_nodes = FAKE ? 0xffffffffu : 0u;  // (PCV4_WALK_AT: no LDS mirror of the walk records)
+  const uint32_t* const swalk = sfake;
   // the wave's number is a scalar and the lane number can be had again from nothing (mbcnt): no lane-indexed value needs to
   // stay in a register across the walks
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -623,6 +626,11 @@ __global__ __launch_bounds__(BLOCK, 8) void spec_encode_pair_kernel(
   const bool raw = routed.oct == nullptr;  // grid-uniform
   const bool stage = wide != nullptr;      // grid-uniform: 12-byte records
   if (tid < 32) kcnt[tid] = 0;
+  if (FAKE)
+    for (int e = tid; e < 2048; e += BLOCK) {
+      const uint32_t dp = (uint32_t)e >> 7, l = ((uint32_t)e >> 3) & 15u;
+      sfake[e] = ((dp * 16u + l + 1u) * 8u) | (l + 1u >= dp || l >= 14u ? PCV_SPEC_LEAF : 0u);
+    }
   double qx[2], qy[2], qz[2];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -665,14 +673,15 @@ __global__ __launch_bounds__(BLOCK, 8) void spec_encode_pair_kernel(
       double* const c = sxyz + (slot / BLOCK) * (3 * BLOCK) + (slot % BLOCK);
       c[0] = qx[h], c[BLOCK] = qy[h], c[2 * BLOCK] = qz[h];
     }
-    sidx[slot] = (uint16_t)(h * BLOCK + tid);
+    sidx[slot] = (uint16_t)((h * BLOCK + tid) | (FAKE ? (kSpecClasses - 2 - key[h]) << 11 : 0u));
   }
   __syncthreads();
 #pragma unroll 1
   for (int task = 0; task < 2; ++task) {
     lane = (int)pcv_lane_again();
     const int s = (task == 0 ? wave : BALANCED ? kGroups - 1 - wave : kGroups / 2 + wave) * 64 + lane;  // first the deep end, then the shallow end
-    const int j = sidx[s];
+    const uint32_t jd = sidx[s];
+    const int j = FAKE ? (int)(jd & 2047u) : (int)jd;
     double px = 0, py = 0, pz = 0;
     if (raw) {
       const double* const c = sxyz + (s / BLOCK) * (3 * BLOCK) + (s % BLOCK);
@@ -687,7 +696,7 @@ __global__ __launch_bounds__(BLOCK, 8) void spec_encode_pair_kernel(
       int kl = 0;
       uint32_t d1 = 0;
       int L = 0;
-      uint32_t rec = walk[0];
+      uint32_t rec = FAKE ? (((jd >> 11) & 15u) * 16u) * 8u : walk[0];
       if (raw) {
         mx = lv.root_min[0], my = lv.root_min[1], mz = lv.root_min[2];
       } else if (pcv_chain_start(lv, routed, x, y, z, i, px, py, pz, mx, my, mz, vx, vy, vz, d1) == 2 && !(rec & PCV_SPEC_LEAF)) {
@@ -1392,6 +1401,24 @@ static void launch_spec_encode_t(pcv_ctx* ctx, const PcvLevels& lv, const uint32
   if (BIN && v4 && pair && BLOCK <= 512) {  // tiles of 2 x BLOCK points (a tile must not span two pool regions: <= 1 024 points)
     constexpr int PB = BLOCK <= 512 ? BLOCK : 512;
 #ifdef PCV_EXPERIMENTS
+    static const bool fake = pcv_experiment("PCV_PAIR_FAKE_WALK") != nullptr;
+    if (fake) {  // timing only: the pass with its walk gathers served from LDS runs first and is timed on its own
+      hipEvent_t e0, e1;
+      (void)hipEventCreate(&e0);
+      (void)hipEventCreate(&e1);
+      (void)hipEventRecord(e0, ctx->stream);
+      hipLaunchKernelGGL((spec_encode_pair_kernel<true, PB, true, true>), dim3((unsigned)((n + 2 * PB - 1) / (2 * PB))), dim3(PB), 0, ctx->stream, lv, walk,
+                         n, x, y, z, routed, color, color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide,
+                         pool_ctr, pool_cap);
+      (void)hipEventRecord(e1, ctx->stream);
+      (void)hipEventSynchronize(e1);
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      fprintf(stderr, "PCV_PAIR_FAKE_WALK block=%d: %.3f ms\n", PB, ms);
+      (void)hipEventDestroy(e0);
+      (void)hipEventDestroy(e1);
+      (void)hipMemsetAsync(pool_ctr, 0, kPcvPoolRegions * 4, ctx->stream);
+    }
     static const bool unbalanced = pcv_experiment("PCV_PAIR_UNBALANCED") != nullptr;
     if (unbalanced) {
       hipLaunchKernelGGL((spec_encode_pair_kernel<true, PB, false>), dim3((unsigned)((n + 2 * PB - 1) / (2 * PB))), dim3(PB), 0, ctx->stream, lv, walk, n, x,
