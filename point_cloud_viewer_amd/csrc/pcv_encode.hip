@@ -592,12 +592,15 @@ __device__ __forceinline__ uint32_t pcv_lane_again() {  // the lane number, reco
   return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zero));
 }
 // ---- the chain pass, tiles of two points per lane (round 4, second form) -------------------------------------------------
-// spec_encode4_kernel ends on a barrier (its records leave through LDS), and the deal hands the workgroup's DEEPEST points
-// to its first wave and the shallowest to its last: every wave of the workgroup then holds its slot until the deepest wave
-// is through — 9-10 level steps against a mean of 6.5. Here a workgroup takes 2 x BLOCK points, deals them into
-// 2 x BLOCK / 64 groups by predicted depth, and wave w walks group w (the deep end) and then group 2 x waves - 1 - w (the
-// shallow end): the waves reach the closing barrier together, the barriers and the latency of the loads, the depth look-up
-// and the deal are paid once per two points of a lane. Same walk, same arithmetic, same records.
+// A workgroup of spec_encode4_kernel spends the first third of its life in a chain of dependent latencies — coordinate
+// loads, barrier, depth look-up, LDS atomic, barrier, scan, LDS write, barrier, fetch — during which its eight wave slots
+// issue next to nothing, and the phases of the four workgroups of a CU do not hide each other. Here a
+// workgroup takes 2 x BLOCK points through that chain at once (two points per lane: twice the loads in flight for the same
+// latency, half the barriers per point), deals them into 2 x BLOCK / 64 groups by predicted depth, and wave w walks group w
+// (the deep end) and then group 2 x waves - 1 - w (the shallow end), one after the other: the walk keeps its registers and
+// its 8 waves per SIMD. 2.24 -> 2.0 ms at 100 M points. (Which two groups a wave gets makes no measurable difference; the
+// pairing deep + shallow just keeps the waves of a workgroup together at the closing barrier.) Same walk, same
+// arithmetic, same records.
 // LDS: the coordinates of the tile in two halves of BLOCK dealt slots ({x[BLOCK], y[BLOCK], z[BLOCK]} each); the first half
 // is dead once every wave has fetched its first group and becomes the staging area of the tile's 2 x BLOCK records.
 template <bool KEEP, int BLOCK, bool BALANCED = true /* false (experiments): wave w walks groups w and waves + w */,
