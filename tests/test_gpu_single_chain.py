@@ -231,7 +231,9 @@ from test_gpu_build import assert_same
 want_bytes = int(sys.argv[2])
 ctx = pcv.Context(0)
 for n, cap, res, clusters, extent, sigma, with_int, seed in ((600_000, 20_000, 0.001, 6, 200.0, (0.2, 8.0), True, 2),
-                                                              (600_000, 20_000, 0.0001, 6, 200.0, (0.2, 8.0), False, 21)):
+                                                              (600_000, 20_000, 0.0001, 6, 200.0, (0.2, 8.0), False, 21),
+                                                              # >= 2^20 points: the depth-binned chain pass (a last tile of 544)
+                                                              (1_300_000, 30_000, 0.0002, 7, 220.0, (0.1, 7.0), True, 7)):
     x, y, z, rgb, bmin, bmax = synthetic.gaussian_clusters(n, seed=seed, num_clusters=clusters, extent=extent, sigma_range=sigma)
     inten = (np.arange(n) % 509).astype(np.float32) * 0.5 if with_int else None
     with O.max_points_per_node(cap):
@@ -251,7 +253,11 @@ print("alt-path ok")
                                               ({"PCV_SORT_ROWS": "0"}, 12),
                                               # the second pass counting its keys itself (equal chunks instead of pieces of
                                               # whole first-pass runs)
-                                              ({"PCV_SORT_ROWS2": "0"}, 12)])
+                                              ({"PCV_SORT_ROWS2": "0"}, 12),
+                                              # the chain pass with one point per lane (round 4's first form; what workgroups
+                                              # of 1 024 lanes still take), in tiles of 2 x 256 points, and round 3's kernel
+                                              ({"PCV_CHAIN_V": "4"}, 12), ({"PCV_SPEC_BIN": "256"}, 12), ({"PCV_SPEC_BIN": "1024"}, 12),
+                                              ({"PCV_CHAIN_V": "3"}, 12)])
 def test_alternative_kernels_behind_the_switches_are_byte_exact_too(env, record_bytes):
     """The 20-byte record format (what a predicted tree of more than 2^24 nodes falls back to) and the slot-wise settle
     kernel are selected by switches that are read once per process: run them in a child process against the oracle."""
