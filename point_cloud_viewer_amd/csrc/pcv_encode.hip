@@ -1344,47 +1344,39 @@ __global__ __launch_bounds__(256) void promote_climb_leaf_kernel(PcvPromoteTable
                                                                   const uint32_t* __restrict__ cx_hi,
                                                                   const uint32_t* __restrict__ cy_hi,
                                                                   const uint32_t* __restrict__ cz_hi, PromoteOut o) {
-  constexpr int kSlots = (int)kPcvClimbTile / 256;
   const PcvSettleItem it = items[blockIdx.x];
+  const uint32_t k = it.begin + threadIdx.x;
+  const bool live = k < it.end;
+  const uint32_t kk = live ? k : it.begin;
+  uint4 pay;
+  uint32_t slot_rel, inten = 0;
   const PcvNodeRec leaf = pt.leaf_rec[it.rank];
-  // every record load of the item is issued before the first is consumed (dead lanes re-read the item's first record)
-  uint4 pay[kSlots];
-  uint32_t slot_rel[kSlots], inten[kSlots], h[kSlots][3];
-#pragma unroll
-  for (int s = 0; s < kSlots; ++s) {
-    const uint32_t k = it.begin + threadIdx.x + 256u * s;
-    const uint32_t kk = k < it.end ? k : it.begin;
-    inten[s] = 0;
-    if (kClimb16) {
-      pay[s] = reinterpret_cast<const uint4*>(climbers)[kk];
-      slot_rel[s] = (kk - it.pad) << 3;  // j of the climber inside its leaf's stream
-    } else {
-      const PcvClimber c = climbers[kk];
-      pay[s] = c.pay;
-      slot_rel[s] = c.slot - leaf.lo;
-      inten[s] = c.inten;
-    }
-    h[s][0] = h[s][1] = h[s][2] = 0;
-    if (!kClimb16 && cx_hi) {
-      h[s][0] = cx_hi[leaf.lo + slot_rel[s]];
-      h[s][1] = cy_hi[leaf.lo + slot_rel[s]];
-      h[s][2] = cz_hi[leaf.lo + slot_rel[s]];
-    }
+  if (kClimb16) {
+    pay = reinterpret_cast<const uint4*>(climbers)[kk];
+    slot_rel = (kk - it.pad) << 3;  // j of the climber inside its leaf's stream
+  } else {
+    const PcvClimber c = climbers[kk];
+    pay = c.pay;
+    slot_rel = c.slot - leaf.lo;
+    inten = c.inten;
+  }
+  uint32_t h[3] = {0, 0, 0};
+  if (!kClimb16 && cx_hi) {
+    h[0] = cx_hi[leaf.lo + slot_rel];
+    h[1] = cy_hi[leaf.lo + slot_rel];
+    h[2] = cz_hi[leaf.lo + slot_rel];
   }
   const PcvNodeRec par = pt.node_rec[leaf.parent];  // a leaf with climbers is not the root
+  if (!live) return;
+  uint64_t code[3] = {pay.x | ((uint64_t)h[0] << 32), pay.y | ((uint64_t)h[1] << 32), pay.z | ((uint64_t)h[2] << 32)};
 #pragma unroll
-  for (int s = 0; s < kSlots; ++s) {
-    if (it.begin + threadIdx.x + 256u * s >= it.end) continue;
-    uint64_t code[3] = {pay[s].x | ((uint64_t)h[s][0] << 32), pay[s].y | ((uint64_t)h[s][1] << 32), pay[s].z | ((uint64_t)h[s][2] << 32)};
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const double q = pcv_decode_coord(leaf.enc, code[a], leaf.mn[a], leaf.edge);
-      code[a] = pcv_encode_coord(par.enc, q, par.mn[a], par.edge, PcvRecip{par.inv_edge, par.inv_edge_lo});
-    }
-    const uint32_t j = leaf.child_off + (slot_rel[s] >> 3);  // position in the parent's stream
-    promote_one<true>(pt, (uint64_t)par.lo + j, par, make_uint4((uint32_t)code[0], (uint32_t)code[1], (uint32_t)code[2], pay[s].w),
-                      (uint32_t)(code[0] >> 32), (uint32_t)(code[1] >> 32), (uint32_t)(code[2] >> 32), inten[s], o);
+  for (int a = 0; a < 3; ++a) {
+    const double q = pcv_decode_coord(leaf.enc, code[a], leaf.mn[a], leaf.edge);
+    code[a] = pcv_encode_coord(par.enc, q, par.mn[a], par.edge, PcvRecip{par.inv_edge, par.inv_edge_lo});
   }
+  const uint32_t j = leaf.child_off + (slot_rel >> 3);  // position in the parent's stream
+  promote_one<true>(pt, (uint64_t)par.lo + j, par, make_uint4((uint32_t)code[0], (uint32_t)code[1], (uint32_t)code[2], pay.w),
+                    (uint32_t)(code[0] >> 32), (uint32_t)(code[1] >> 32), (uint32_t)(code[2] >> 32), inten, o);
 }
 
 }  // namespace

@@ -132,10 +132,7 @@ struct alignas(16) PcvSettleItem {
 #define PCV_SETTLE_TILE 1024
 #endif
 constexpr uint32_t kPcvSettleTile = PCV_SETTLE_TILE;
-#ifndef PCV_CLIMB_TILE
-#define PCV_CLIMB_TILE 256
-#endif
-constexpr uint32_t kPcvClimbTile = PCV_CLIMB_TILE;  // a multiple of 256: the climb kernel's lanes take PCV_CLIMB_TILE / 256 records each
+constexpr uint32_t kPcvClimbTile = 256;
 // Leaves in rank order: leaf r holds the sorted slots [lo[r], lo[r] + count[r]). Writes the settle items (in slot order)
 // and returns their number (<= n / kPcvSettleTile + num_leaves).
 uint32_t pcv_settle_items(const uint32_t* lo, const uint32_t* count, uint32_t num_leaves, PcvSettleItem* out);
