@@ -524,6 +524,9 @@ def config5_leg(args, torch, pcv, ctx, dev, points):
     elapsed = time.perf_counter() - t0
     ctx.set_profiling(False)
     kstats = ctx.kernel_stats()
+    t = ctx.build(args.resolution, None, x, y, z, rgb, stage_times=True)  # (one more build, outside the timed region, for stage_ms)
+    info["stages"] = t.stage_ms()
+    t.free()
     parity = verify_build(ctx, args.resolution, x, y, z, rgb)
     del x, y, z, rgb
     ms = elapsed / steps * 1e3
@@ -555,7 +558,7 @@ def run_virtual_ranks(args, torch, pcv, dev):
     # the single-GPU build of the whole cloud: the reference the merged shards are compared with
     ctx = pcv.Context(0)
     t0 = time.perf_counter()
-    tree = ctx.build(args.resolution, None, x, y, z, rgb)
+    tree = ctx.build(args.resolution, None, x, y, z, rgb, stage_times=True)
     single_ms = (time.perf_counter() - t0) * 1e3
     meta = tree.meta()
     single = tree_digests(tree)
@@ -758,19 +761,20 @@ def main():
             bmin, bmax = ctx.aabb_reduce(x, y, z)
             bbox = pcv.Aabb(bmin, bmax)
 
-        def step():
+        def step(details=True):
             t = ctx.build(args.resolution, bbox, x, y, z, rgb,  # bbox None: K1 runs inside the step
                           single_chain=False if args.exact_pipeline else None)
-            info["nodes"], info["stages"], info["build"] = t.num_nodes, t.stage_ms(), t.build_info()
-            info.setdefault("gpu_ms", []).append(round(info["stages"]["total"], 3))
-            info.setdefault("all_stages", []).append({k: round(v, 2) for k, v in info["stages"].items()})
+            if details:  # (not inside the timed region: a dozen ctypes calls per step)
+                info["nodes"], info["stages"], info["build"] = t.num_nodes, t.stage_ms(), t.build_info()
+                info.setdefault("all_stages", []).append({k: round(v, 2) for k, v in info["stages"].items()})
+            info.setdefault("gpu_ms", []).append(round(t.total_gpu_ms(), 3))
             t.free()
     else:
         from point_cloud_viewer_amd import distributed as pdist
         builder = pdist.ShardedOctreeBuilder(ctx, dist, dev, shard_mode=args.shard_mode)
         bbox = builder.global_bbox(x, y, z)
 
-        def step():
+        def step(details=True):
             r = builder.build(args.resolution, bbox, x, y, z, rgb)
             info["nodes"], info["stages"] = r.num_nodes_local, r.stage_ms
             info["build"] = r.local.build_info() if hasattr(r.local, "build_info") else None
@@ -795,7 +799,7 @@ def main():
     t0 = time.perf_counter()
     step_marks = [t0]
     for _ in range(args.steps):
-        step()
+        step(False)
         step_marks.append(time.perf_counter())  # every step ends with a stream sync inside the library
     barrier()
     elapsed = time.perf_counter() - t0
@@ -807,6 +811,14 @@ def main():
         elapsed = float(tt.item())
     ctx.set_profiling(False)
     kstats = ctx.kernel_stats()
+    # stage times: the 16 stage events of a build cost its stream ~0.1 ms (PCV_BUILD_STAGE_TIMES, off by default and off in
+    # the timed region); `stage_ms` comes from two more builds AFTER the timed region with the stage events on
+    timed_gpu_ms = list(info.get("gpu_ms") or [])
+    ctx.stage_times = True
+    for _ in range(2):
+        step()
+    ctx.stage_times = False
+    info["gpu_ms"] = timed_gpu_ms
     per_rank = None
     if dist is not None:  # every rank's view of its last step: rows / bytes moved and the stage times (exchange, local build, merge)
         per_rank = [None] * world

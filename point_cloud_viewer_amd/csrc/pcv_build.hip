@@ -328,6 +328,7 @@ extern "C" int pcv_ctx_create(int device, void* stream, pcv_ctx** out) {
     delete c;
     return PCV_E_OOM;
   }
+  if (hipHostGetDevicePointer((void**)&c->mailbox_dev, c->mailbox, 0) != hipSuccess) c->mailbox_dev = c->mailbox;
   if (stream) {
     c->stream = (hipStream_t)stream;
   } else {
@@ -616,7 +617,9 @@ static int device_aabb(pcv_ctx* ctx, PcvScratch& sc, const DevPoints& d, double 
   double* partial;
   int rc = sc.get(&partial, (size_t)2048 * 6 + 6);
   if (rc) return rc;
-  double* out6 = partial + 2048 * 6;
+  // the final kernel stores the six doubles straight into the pinned mailbox (host memory the device can write): no copy
+  // kernel between the reduction and the host's wait
+  double* out6 = (double*)ctx->mailbox_dev;
   // the 16-byte vector loads need aligned bases; fall back to staging when the caller's views are not
   if (((uintptr_t)d.x | (uintptr_t)d.y | (uintptr_t)d.z) & 15) {
     double *x, *y, *z;
@@ -629,7 +632,6 @@ static int device_aabb(pcv_ctx* ctx, PcvScratch& sc, const DevPoints& d, double 
     pcv_launch_aabb(ctx, d.n, d.x, d.y, d.z, partial, out6);
   }
   double h[6];
-  PCV_HIP_CHECK(ctx, hipMemcpyAsync(ctx->mailbox, out6, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
   PCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   std::memcpy(h, ctx->mailbox, sizeof(h));
   for (int a = 0; a < 3; ++a) {
@@ -1027,9 +1029,10 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
   uint32_t *d_ord, *d_walk, *d_sparent, *d_info, *d_counts, *d_map, *d_pool_ctr;
   uint8_t* d_slevel;
   if ((rc = sc.get(&d_ord, nt.capacity)) || (rc = sc.get(&d_walk, tcap)) || (rc = sc.get(&d_sparent, tcap)) ||
-      (rc = sc.get(&d_slevel, tcap)) || (rc = sc.get(&d_info, 64)) || (rc = sc.get(&d_counts, tcap)) || (rc = sc.get(&d_map, tcap)) ||
-      (rc = sc.get(&d_pool_ctr, kPcvPoolRegions)))
+      (rc = sc.get(&d_slevel, tcap)) || (rc = sc.get(&d_info, 64)) || (rc = sc.get(&d_pool_ctr, kPcvPoolRegions + tcap)) ||
+      (rc = sc.get(&d_map, tcap)))
     return rc;
+  d_counts = d_pool_ctr + kPcvPoolRegions;  // the pool counters and the exact counts travel to the host in ONE copy
   uint32_t* rank = (uint32_t*)bs->keys_a;
   uint4* payload;
   // 12-byte records (pcv_internal.h) unless switched off (PCV_COMPACT_RECORDS=0, experiments) or the predicted tree could
@@ -1188,12 +1191,12 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
   PCV_HIP_CHECK(ctx, hipGetLastError());
   if ((rc = ctx->pinned_spec_reserve((size_t)tree.num_leaves * 8 + 512 + kPcvPoolRegions * 4))) return rc;
   uint8_t* hp = (uint8_t*)ctx->pinned_spec;
-  uint32_t* h_counts = (uint32_t*)hp;
-  const size_t map_off = ((size_t)tree.num_leaves * 4 + 255) & ~(size_t)255;
-  PCV_HIP_CHECK(ctx, hipMemcpyAsync(h_counts, d_counts, (size_t)tree.num_leaves * 4, hipMemcpyDeviceToHost, st));
-  // ... and with them the number of `wide` pool entries the chain pass handed out per region (pcv_spec_emit)
-  uint32_t* h_pool = (uint32_t*)(hp + (((size_t)tree.num_leaves * 8 + 256 + 63) & ~(size_t)63));
-  PCV_HIP_CHECK(ctx, hipMemcpyAsync(h_pool, d_pool_ctr, kPcvPoolRegions * 4, hipMemcpyDeviceToHost, st));
+  // the number of `wide` pool entries the chain pass handed out per region (pcv_spec_emit), then the exact counts: one
+  // block on the device, one copy (every small operation on `stream` costs a hand-over of ~10 us between two kernels)
+  uint32_t* h_pool = (uint32_t*)hp;
+  uint32_t* h_counts = h_pool + kPcvPoolRegions;
+  const size_t map_off = (((size_t)kPcvPoolRegions + tree.num_leaves) * 4 + 255) & ~(size_t)255;
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(h_pool, d_pool_ctr, ((size_t)kPcvPoolRegions + tree.num_leaves) * 4, hipMemcpyDeviceToHost, st));
   PCV_HIP_CHECK(ctx, hipEventRecord(ctx->spec_ev, st));  // the counts are on their way to the host
   // The map the record sort needs is computed on the device (spec_resolve_kernel), and the sort is queued behind it right
   // away: the counts' trip to the host, the host's own resolve and the table building all happen beside the sort instead
@@ -1240,13 +1243,15 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
   if (device_resolve) {
     uint32_t *d_nst, *d_base, *d_out;
     const uint32_t tn = (uint32_t)tree.prefix.size();
-    if ((rc = sc.get(&d_nst, tn)) || (rc = sc.get(&d_base, tn)) || (rc = sc.get(&d_out, 64))) return rc;
+    if ((rc = sc.get(&d_nst, tn)) || (rc = sc.get(&d_base, tn))) return rc;
+    // the kernel stores its verdict straight into the pinned mailbox (host memory the device can write): no copy between
+    // the resolve kernel and the sort
+    d_out = (uint32_t*)(ctx->mailbox_dev + kMailboxResolve);
     pcv_launch_spec_resolve(ctx, lv, params->resolution, sp.cap, sp.force_mask, d_walk, d_slevel, tn, d_counts, d_nst, d_base, d_map, d_out);
     PCV_HIP_CHECK(ctx, hipGetLastError());  // before the sort is queued behind it
     // {true leaves, too shallow} as the device sees them: read by pcv_build_finish (which synchronises anyway) and held
     // against the host's resolve — the device map drives the sort, the host's tree the tables
     ctx->mailbox[kMailboxResolve] = ~0ull;
-    PCV_HIP_CHECK(ctx, hipMemcpyAsync(ctx->mailbox + kMailboxResolve, d_out, 8, hipMemcpyDeviceToHost, st));
     bs->resolve_on_device = true;
     ctx->stage_end(PCV_STAGE_NODE_SPLIT);
     const uint32_t predicted_leaves = (uint32_t)std::count(tree.inner.begin(), tree.inner.end(), (uint8_t)0);
@@ -1337,6 +1342,7 @@ static int build_begin_impl(pcv_ctx* ctx, const pcv_build_params* params, const 
   PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[0], st));
   for (bool& on : ctx->stage_on) on = false;
   for (bool& open : ctx->stage_open) open = false;
+  ctx->stage_times = (params->flags & PCV_BUILD_STAGE_TIMES) != 0;
   ctx->stage_begin(PCV_STAGE_AABB);
   if (routed) {  // device-resident by contract
     d.n = n;

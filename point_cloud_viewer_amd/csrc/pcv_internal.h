@@ -114,6 +114,7 @@ struct pcv_ctx {
   // small pinned mailbox for scalar read-backs (counters, flags): a D2H copy into pageable memory (a stack variable)
   // makes the runtime pin pages on the fly, which now and then costs milliseconds in the middle of a build
   uint64_t* mailbox = nullptr;  // 64 x u64 for read-backs + 64 x u64 reserved for the replay ranges of a build in flight
+  uint64_t* mailbox_dev = nullptr;  // the same block as the device addresses it (kernels may store small verdicts there)
   // pinned host staging, grown on demand
   void* pinned = nullptr;
   size_t pinned_bytes = 0;
@@ -136,7 +137,9 @@ struct pcv_ctx {
   // per-stage begin / end events of the build in flight (a stage may be recorded out of order or not at all)
   hipEvent_t stage_b[PCV_NUM_STAGES] = {}, stage_e[PCV_NUM_STAGES] = {};
   bool stage_on[PCV_NUM_STAGES] = {}, stage_open[PCV_NUM_STAGES] = {};
+  bool stage_times = false;  // PCV_BUILD_STAGE_TIMES of the build in flight: without it no stage event is recorded
   void stage_begin(int s) {
+    if (!stage_times) return;
     (void)hipEventRecord(stage_b[s], stream);
     stage_on[s] = false;
     stage_open[s] = true;

@@ -80,6 +80,9 @@ class Context:
             raise L.PcvError(rc, f"pcv_ctx_create(device={device}) failed — is a HIP device visible?")
         self.handle = h
         self._children = weakref.WeakSet()  # octrees / shape sets that borrow this context's pool
+        # every build of this context records its per-stage GPU times (PCV_BUILD_STAGE_TIMES: ~0.1 ms of stream time per
+        # build); off, stage_ms() of a tree reports the total only. build(stage_times=...) overrides it per call.
+        self.stage_times = False
 
     def close(self):
         for child in list(getattr(self, "_children", [])):
@@ -180,16 +183,20 @@ class Context:
 
     # ---- the build -------------------------------------------------------------------------------
     def build(self, resolution, bounding_box, x, y, z, color, intensity=None, max_points_per_node=0,
-              speculate_depth=True, single_chain=None, check_resolve=False):
+              speculate_depth=True, single_chain=None, check_resolve=False, stage_times=None):
         """build_octree up to (not including) the file writes. bounding_box=None computes it on the
         device (== build_octree_from_file's find_bounding_box pass). single_chain: None = the library decides (from
         2^22 points on), True = force the single-chain build, False = exact two-chain pipeline; speculate_depth=False
         additionally computes and sorts full-depth keys. The result is identical in every mode. check_resolve: the
-        single-chain build compares the device's rank map with the host's entry by entry (PCV_BUILD_CHECK_RESOLVE)."""
+        single-chain build compares the device's rank map with the host's entry by entry (PCV_BUILD_CHECK_RESOLVE).
+        stage_times: record the GPU time of every stage for stage_ms() (PCV_BUILD_STAGE_TIMES: ~0.1 ms of stream time per
+        build; without it stage_ms() reports the total only); None = the context's `stage_times` attribute."""
         p, keep = self._points(x, y, z, color, intensity)
         flags = 0 if speculate_depth else L.BUILD_NO_SPECULATION
         if check_resolve:
             flags |= L.BUILD_CHECK_RESOLVE
+        if self.stage_times if stage_times is None else stage_times:
+            flags |= L.BUILD_STAGE_TIMES
         if single_chain is True:
             flags |= L.BUILD_FORCE_SINGLE_CHAIN
         elif single_chain is False:
@@ -389,7 +396,7 @@ class Context:
         rp.n = int(state["oct_rgb"].shape[0])
         rp.cx, rp.cy, rp.cz, rp.oct_rgb = (state[k].data_ptr() for k in ("cx", "cy", "cz", "oct_rgb"))
         rp.intensity = intensity.data_ptr() if intensity is not None else None
-        flags = (int(force_split_level1) & 0xFF) << 8
+        flags = ((int(force_split_level1) & 0xFF) << 8) | (L.BUILD_STAGE_TIMES if self.stage_times else 0)
         pr = self._params(resolution, bounding_box.min, bounding_box.max, max_points_per_node, flags)
         h = C.c_void_p()
         self._check(self.lib.pcv_build_begin_routed(self.handle, C.byref(pr), C.byref(rp), C.byref(h)))
@@ -400,7 +407,7 @@ class Context:
         """First half of the two-step build (multi-GPU path): topology + stream lengths. Returns a PendingBuild; the
         input tensors must stay alive until finish()."""
         p, keep = self._points(x, y, z, color, intensity)
-        flags = (int(force_split_level1) & 0xFF) << 8
+        flags = ((int(force_split_level1) & 0xFF) << 8) | (L.BUILD_STAGE_TIMES if self.stage_times else 0)
         pr = self._params(resolution, bounding_box.min, bounding_box.max, max_points_per_node, flags)
         h = C.c_void_p()
         self._check(self.lib.pcv_build_begin(self.handle, C.byref(pr), C.byref(p), C.byref(h)))
@@ -569,6 +576,12 @@ class OctreeResult:
         ptr, ln = C.c_void_p(), C.c_uint64()
         self.ctx._check(self.lib.pcv_octree_node_data(self.handle, i, which, C.byref(ptr), C.byref(ln)))
         return C.string_at(ptr, ln.value) if ln.value else b""
+
+    def total_gpu_ms(self):
+        """GPU time of the build from its first to its last kernel (PCV_STAGE_TOTAL; measured for every build)."""
+        ms = (C.c_float * L.NUM_STAGES)()
+        self.lib.pcv_octree_stage_ms(self.handle, ms, L.NUM_STAGES)
+        return float(ms[L.NUM_STAGES - 1])
 
     def stage_ms(self):
         ms = (C.c_float * L.NUM_STAGES)()

@@ -128,7 +128,7 @@ def test_device_resident_inputs_and_computed_bbox(ctx):
                                                            sigma_range=(0.1, 5.0))
     dx, dy, dz = (torch.from_numpy(a).cuda() for a in (x, y, z))
     dc = torch.from_numpy(rgb).cuda()
-    t = ctx.build(0.001, None, dx, dy, dz, dc)  # bbox computed on the device (find_bounding_box)
+    t = ctx.build(0.001, None, dx, dy, dz, dc, stage_times=True)  # bbox computed on the device (find_bounding_box)
     m = t.meta()
     assert np.array_equal(m["bbox_min"], bmin) and np.array_equal(m["bbox_max"], bmax)
     assert_same(t.to_dict(), O.build_closed(0.001, bmin, bmax, x, y, z, rgb, threads=4))

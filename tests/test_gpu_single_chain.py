@@ -122,7 +122,7 @@ def test_many_small_leaves_take_8_bit_digits_and_the_global_rank_map(ctx):
 def test_single_chain_is_the_default_from_4M_points_and_keeps_candidate_codes(ctx):
     n = 6_000_000
     x, y, z, rgb, bmin, bmax = synthetic.gaussian_clusters(n, seed=8, num_clusters=24, extent=500.0, sigma_range=(0.3, 9.0))
-    t = ctx.build(0.001, pcv.Aabb(bmin, bmax), x, y, z, rgb)
+    t = ctx.build(0.001, pcv.Aabb(bmin, bmax), x, y, z, rgb, stage_times=True)
     info = t.build_info()
     assert info["single_chain"] and info["attempts"] == 0, info
     assert info["kept_code_points"] > 0, info  # some node sat in the band and turned out to be a leaf
