@@ -1415,8 +1415,11 @@ static int build_begin_impl(pcv_ctx* ctx, const pcv_build_params* params, const 
     if ((rc = sc.get(&nt.prefix, cap)) || (rc = sc.get(&nt.lo, cap)) || (rc = sc.get(&nt.hi, cap)) ||
         (rc = sc.get(&nt.parent, cap)) || (rc = sc.get(&nt.first_child, cap)) || (rc = sc.get(&nt.level, cap)) ||
         (rc = sc.get(&nt.child_mask, cap)) || (rc = sc.get(&nt.open, cap)) ||
-        (rc = sc.get(&nt.bounds, (size_t)cap * 9)) || (rc = sc.get(&nt.counters, 64)))
+        (rc = sc.get(&nt.counters, 64)))
       return rc;
+    // (the sample tree of the single-chain build splits at a LOWERED threshold: twice the open nodes the capacity allows)
+    nt.max_open = (uint32_t)std::min<uint64_t>(2 * (n / max_points + 1) + 64, 1u << 22);
+    if ((rc = sc.get(&nt.bounds, std::max((size_t)cap * 9, (size_t)nt.max_open * 85)))) return rc;
   }
   uint32_t counters[64];
   bool keys32 = false;
@@ -2111,9 +2114,10 @@ extern "C" int pcv_node_split(pcv_ctx* ctx, const pcv_build_params* params, cons
   nt.prefix_lo = nullptr;
   if ((rc = sc.get(&nt.prefix, cap64)) || (rc = sc.get(&nt.lo, cap64)) || (rc = sc.get(&nt.hi, cap64)) ||
       (rc = sc.get(&nt.parent, cap64)) || (rc = sc.get(&nt.first_child, cap64)) || (rc = sc.get(&nt.level, cap64)) ||
-      (rc = sc.get(&nt.child_mask, cap64)) || (rc = sc.get(&nt.open, cap64)) || (rc = sc.get(&nt.bounds, (size_t)cap64 * 9)) ||
-      (rc = sc.get(&nt.counters, 64)))
+      (rc = sc.get(&nt.child_mask, cap64)) || (rc = sc.get(&nt.open, cap64)) || (rc = sc.get(&nt.counters, 64)))
     return rc;
+  nt.max_open = (uint32_t)std::min<uint64_t>(n / max_points + 64, 1u << 22);
+  if ((rc = sc.get(&nt.bounds, std::max((size_t)cap64 * 9, (size_t)nt.max_open * 85)))) return rc;
   uint8_t* d_pack;
   if ((rc = sc.get(&d_pack, kPcvPackHeader + ((size_t)cap64 + 8) * sizeof(PcvPackedNode)))) return rc;
   pcv_launch_node_split(ctx, nt, dk, false, (uint32_t)n, lv, params->resolution, max_points, (params->flags >> 8) & 0xffu);

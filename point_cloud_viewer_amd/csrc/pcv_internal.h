@@ -325,7 +325,9 @@ struct PcvNodeTableDev {
   uint8_t* level;
   uint8_t* child_mask;   // bit c set = child c exists
   uint8_t* open;         // 1 = split further (inner node), 0 = leaf
-  uint32_t* bounds;      // scratch: 9 bounds per node of the level being expanded
+  uint32_t* bounds;      // scratch: 9 bounds per node of the level being expanded (capacity x 9), or the lists and bounds of
+                         // the two-levels-per-launch kernels (85 x max_open), whichever is larger
+  uint32_t max_open = 0; // open nodes a level can have as far as the scratch goes (0: one level per launch pair only)
   uint32_t* counters;    // [0] node_count, [1] error flag, [2..] level_start[k] (k = 0..PCV_MAX_LEVELS+1)
 };
 // One node of the device table, packed for a single device-to-host copy (pcv_launch_pack_node_table): the copy starts

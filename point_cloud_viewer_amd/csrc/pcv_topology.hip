@@ -15,7 +15,13 @@
 
 namespace {
 
-enum { CNT_NODES = 0, CNT_ERROR = 1, CNT_LEVEL_START = 2 };
+enum { CNT_NODES = 0, CNT_ERROR = 1, CNT_LEVEL_START = 2, CNT_OPEN = 60 /* [60], [61]: entries of the two open-node lists */ };
+
+// scratch layout of the two-levels-per-launch kernels (see split2_search_kernel below)
+__device__ __forceinline__ uint32_t* pcv_split2_open_list(const PcvNodeTableDev& t, int which) {
+  return t.bounds + (size_t)81 * t.max_open + (size_t)which * t.max_open;
+}
+__device__ __forceinline__ uint32_t* split2_mid_list(const PcvNodeTableDev& t) { return t.bounds + (size_t)83 * t.max_open; }
 
 template <typename KeyT>
 __device__ __forceinline__ uint32_t wave_lower_bound(const KeyT* __restrict__ keys, uint32_t lo, uint32_t hi,
@@ -55,6 +61,218 @@ __global__ __launch_bounds__(256) void init_root_kernel(PcvNodeTableDev t, uint3
     t.counters[CNT_ERROR] = 0;
     t.counters[CNT_LEVEL_START + 0] = 0;
     t.counters[CNT_LEVEL_START + 1] = 1;
+    // two levels per launch (split2_*): the open nodes of the level to expand, as a list
+    t.counters[CNT_OPEN + 0] = n > 0 ? 1 : 0;
+    t.counters[CNT_OPEN + 1] = 0;
+    if (t.max_open) pcv_split2_open_list(t, 0)[0] = 0;
+  }
+}
+
+// ---- two levels per launch -------------------------------------------------------------------------------------------------
+// The sample tree of the single-chain build is ~12 levels of two launches each, every one of them 5-8 us of dispatch for
+// microseconds of work. Two levels go through ONE search launch and ONE assign launch:
+//   split2_search: one workgroup (8 waves) per OPEN node of level k - 1 (taken from a list, not found by scanning the
+//     level): its seven child boundaries (seven 64-ary searches, as split_search), then — the counts are now known — the
+//     seven boundaries of every child that could be split itself (count > capacity, or forced), 8 searches at a time;
+//   split2_assign: one workgroup appends level k exactly as split_assign does, keeps the open ones among the new nodes as a
+//     list in creation order, and appends level k + 1 from their boundaries; the open nodes of level k + 1 become the list
+//     of the next launch pair.
+// Same node table, same order (children in (parent, digit) order, levels breadth-first) as the one-level kernels.
+// Scratch (t.bounds): [9 x max_open child bounds | 72 x max_open grandchild bounds | 2 x max_open list A | list B | 2 x
+// max_open mid list], max_open = keys / capacity + 16 (an open node holds more than `capacity` keys; the root and the
+// forced level-1 nodes are the + 16).
+
+template <typename KeyT>
+__global__ __launch_bounds__(512) void split2_search_kernel(PcvNodeTableDev t, const KeyT* __restrict__ keys, int k, int cur,
+                                                             uint32_t max_points, uint32_t force_mask, int second_level) {
+  __shared__ uint32_t sb[9];
+  __shared__ uint32_t cand[8];
+  __shared__ uint32_t ncand;
+  const uint32_t count = t.counters[CNT_OPEN + cur];
+  const uint32_t idx = blockIdx.x;
+  if (idx >= count || idx >= t.max_open) return;  // workgroup-uniform
+  const uint32_t node = pcv_split2_open_list(t, cur)[idx];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int shift = 3 * (PCV_MAX_KEY_LEVELS - k);
+  const uint32_t lo = t.lo[node], hi = t.hi[node];
+  const uint64_t pfx = t.prefix[node];
+  if (wave == 0) {
+    if (lane == 0) sb[0] = lo, sb[8] = hi, ncand = 0;
+  } else {
+    const uint32_t b = wave_lower_bound<KeyT>(keys, lo, hi, (KeyT)(pfx | ((uint64_t)wave << shift)), lane);
+    if (lane == 0) sb[wave] = b;
+  }
+  __syncthreads();
+  uint32_t* bd = t.bounds + (size_t)idx * 9u;
+  if (threadIdx.x < 9) bd[threadIdx.x] = sb[threadIdx.x];
+  if (!second_level) return;
+  if (threadIdx.x == 0) {  // children that may be split themselves (a superset of what split2_assign will open)
+    uint32_t m = 0;
+    for (uint32_t c = 0; c < 8; ++c)
+      if (sb[c + 1] - sb[c] > max_points || (k == 1 && ((force_mask >> c) & 1u) && sb[c + 1] > sb[c])) cand[m++] = c;
+    ncand = m;
+  }
+  __syncthreads();
+  const uint32_t tasks = ncand * 7u;
+  uint32_t* bd2 = t.bounds + (size_t)9 * t.max_open + (size_t)idx * 72u;
+  for (uint32_t task = wave; task < tasks; task += 8u) {  // wave-uniform
+    const uint32_t c = cand[task / 7u], g = task % 7u + 1u;
+    const uint32_t clo = sb[c], chi = sb[c + 1];
+    const uint64_t target = pfx | ((uint64_t)c << shift) | ((uint64_t)g << (shift - 3));
+    const uint32_t b = wave_lower_bound<KeyT>(keys, clo, chi, (KeyT)target, lane);
+    if (lane == 0) {
+      bd2[c * 9u + g] = b;
+      if (g == 1) bd2[c * 9u] = clo, bd2[c * 9u + 8] = chi;
+    }
+  }
+}
+
+// one level appended by the whole workgroup: `src(i, b)` fills the 9 bounds of the i-th open parent and returns its node
+// index; children are created in (parent, digit) order from index `running`; the open ones among them are listed (in
+// creation order) in out_list with `out_src` = 8 x (parent's list position) + digit. Returns through shared memory.
+template <typename Src>
+__device__ __forceinline__ void split2_append_level(const PcvNodeTableDev& t, const PcvLevels& lv, double resolution, uint32_t max_points,
+                                                    int k, uint32_t force_mask, uint32_t parents, Src src, uint32_t* out_list,
+                                                    uint32_t* out_src, uint32_t* wave_tot, uint32_t* wave_open, uint32_t* running,
+                                                    uint32_t* running_open) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int shift = 3 * (PCV_MAX_KEY_LEVELS - k);
+  for (uint32_t chunk = 0; chunk < parents; chunk += 1024) {
+    const uint32_t i = chunk + threadIdx.x;
+    uint32_t b[9];
+    uint32_t mask = 0, cnt = 0, omask = 0, ocnt = 0, node = 0;
+    const bool active = i < parents;
+    if (active) {
+      node = src(i, b);
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        if (b[c + 1] > b[c]) {
+          mask |= 1u << c;
+          ++cnt;
+          // should_split_node (generation.rs:128-150): count > MAX && child edge > resolution; multi-GPU build: a level-1
+          // node that is split in the GLOBAL tree is split here too (PCV_BUILD_FORCE_SPLIT_L1)
+          bool open = b[c + 1] - b[c] > max_points && lv.edge[k] > resolution;
+          if (k == 1 && ((force_mask >> c) & 1u)) open = true;
+          if (open && k >= lv.nlevels) {  // would need digits beyond the key width
+            atomicOr(&t.counters[CNT_ERROR], 1u);
+            open = false;
+          }
+          if (open) omask |= 1u << c, ++ocnt;
+        }
+    }
+    uint32_t inc = cnt, oinc = ocnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t v = __shfl_up(inc, o, 64), w = __shfl_up(oinc, o, 64);
+      if (lane >= o) inc += v, oinc += w;
+    }
+    if (lane == 63) wave_tot[wave] = inc, wave_open[wave] = oinc;
+    __syncthreads();
+    uint32_t woff = 0, total = 0, ooff = 0, ototal = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      const uint32_t v = wave_tot[w], u = wave_open[w];
+      woff += (w < wave) ? v : 0u;
+      total += v;
+      ooff += (w < wave) ? u : 0u;
+      ototal += u;
+    }
+    const uint32_t first = *running + woff + inc - cnt;
+    uint32_t oslot = *running_open + ooff + oinc - ocnt;
+    if (active) {
+      t.first_child[node] = first;
+      t.child_mask[node] = (uint8_t)mask;
+      uint32_t j = first;
+      const uint64_t pfx = t.prefix[node];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        if (!((mask >> c) & 1u)) continue;
+        if (j < t.capacity) {
+          const bool open = (omask >> c) & 1u;
+          t.prefix[j] = pfx | ((uint64_t)c << shift);
+          if (t.prefix_lo) t.prefix_lo[j] = 0;
+          t.lo[j] = b[c];
+          t.hi[j] = b[c + 1];
+          t.parent[j] = node;
+          t.first_child[j] = 0;
+          t.level[j] = (uint8_t)k;
+          t.child_mask[j] = 0;
+          t.open[j] = open ? 1 : 0;
+          if (open) {
+            if (oslot < t.max_open) {
+              out_list[oslot] = j;
+              if (out_src) out_src[oslot] = i * 8u + (uint32_t)c;
+            } else {
+              atomicOr(&t.counters[CNT_ERROR], 2u);  // (cannot happen: an open node holds more than `capacity` keys)
+            }
+            ++oslot;
+          }
+        } else {
+          atomicOr(&t.counters[CNT_ERROR], 2u);  // node table capacity exceeded
+          if ((omask >> c) & 1u) ++oslot;
+        }
+        ++j;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *running += total, *running_open += ototal;
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(1024) void split2_assign_kernel(PcvNodeTableDev t, PcvLevels lv, double resolution, uint32_t max_points,
+                                                              int k, int cur, uint32_t force_mask, int second_level) {
+  __shared__ uint32_t wave_tot[16], wave_open[16];
+  __shared__ uint32_t running, running_open;
+  const uint32_t parents0 = t.counters[CNT_OPEN + cur] < t.max_open ? t.counters[CNT_OPEN + cur] : t.max_open;
+  const uint32_t* cur_list = pcv_split2_open_list(t, cur);
+  uint32_t* next_list = pcv_split2_open_list(t, cur ^ 1);
+  uint32_t* mid = split2_mid_list(t);  // [max_open] nodes, [max_open] sources
+  if (threadIdx.x == 0) running = t.counters[CNT_NODES], running_open = 0;
+  __syncthreads();
+  // level k from the child bounds of the open nodes of level k - 1
+  split2_append_level(
+      t, lv, resolution, max_points, k, force_mask, parents0,
+      [&](uint32_t i, uint32_t (&b)[9]) {
+        const uint32_t* bd = t.bounds + (size_t)i * 9u;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) b[c] = bd[c];
+        return cur_list[i];
+      },
+      second_level ? mid : next_list, second_level ? mid + t.max_open : nullptr, wave_tot, wave_open, &running, &running_open);
+  __syncthreads();
+  const uint32_t level_k_end = running < t.capacity ? running : t.capacity;
+  const uint32_t open_k = running_open < t.max_open ? running_open : t.max_open;
+  __syncthreads();
+  if (!second_level) {
+    if (threadIdx.x == 0) {
+      t.counters[CNT_NODES] = level_k_end;
+      t.counters[CNT_LEVEL_START + k + 1] = level_k_end;
+      t.counters[CNT_OPEN + (cur ^ 1)] = open_k;
+    }
+    return;
+  }
+  __threadfence_block();  // the mid list was written by this workgroup
+  if (threadIdx.x == 0) running_open = 0;
+  __syncthreads();
+  // level k + 1 from the grandchild bounds of the open nodes of level k
+  split2_append_level(
+      t, lv, resolution, max_points, k + 1, 0u, open_k,
+      [&](uint32_t i, uint32_t (&b)[9]) {
+        const uint32_t s = mid[t.max_open + i];  // 8 x (position of the parent's parent in the list) + digit
+        const uint32_t* bd = t.bounds + (size_t)9 * t.max_open + (size_t)(s >> 3) * 72u + (size_t)(s & 7u) * 9u;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) b[c] = bd[c];
+        return mid[i];
+      },
+      next_list, nullptr, wave_tot, wave_open, &running, &running_open);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t total_nodes = running < t.capacity ? running : t.capacity;
+    t.counters[CNT_NODES] = total_nodes;
+    t.counters[CNT_LEVEL_START + k + 1] = level_k_end;
+    t.counters[CNT_LEVEL_START + k + 2] = total_nodes;
+    t.counters[CNT_OPEN + (cur ^ 1)] = running_open < t.max_open ? running_open : t.max_open;
   }
 }
 
@@ -471,7 +689,33 @@ void pcv_launch_node_split(pcv_ctx* ctx, const PcvNodeTableDev& t, const void* s
                            uint32_t force_split_level1_mask, const uint64_t* sorted_lo) {
   hipStream_t s = ctx->stream;
   hipLaunchKernelGGL(init_root_kernel, dim3(1), dim3(256), 0, s, t, n);
-  for (int k = 1; k <= lv.nlevels; ++k) {
+  int k = 1;
+  // two levels per launch pair (u64 keys of one word; the scratch holds the lists of every open node a level can have:
+  // an open node holds more than `max_points_per_node` keys, + the root and the forced level-1 nodes)
+  static const bool two_levels = [] {
+    const char* e = pcv_experiment("PCV_SPLIT2");  // experiments: 0 = one level per launch pair
+    return !e || atoi(e) != 0;
+  }();
+  if (two_levels && !keys32 && !sorted_lo && max_points_per_node > 0 && t.max_open >= (uint64_t)n / max_points_per_node + 16) {
+    const unsigned grid = (unsigned)std::min<uint64_t>(t.max_open, (uint64_t)n / max_points_per_node + 16);
+    int cur = 0;
+    while (k <= lv.nlevels && k <= PCV_MAX_KEY_LEVELS) {
+      const int second = (k + 1 <= lv.nlevels && k + 1 <= PCV_MAX_KEY_LEVELS) ? 1 : 0;
+      {
+        PcvProf prof(ctx, PCV_K_SPLIT_SEARCH);
+        hipLaunchKernelGGL(split2_search_kernel<uint64_t>, dim3(grid), dim3(512), 0, s, t, (const uint64_t*)sorted_keys, k, cur,
+                           max_points_per_node, force_split_level1_mask, second);
+      }
+      {
+        PcvProf prof(ctx, PCV_K_SPLIT_ASSIGN);
+        hipLaunchKernelGGL(split2_assign_kernel, dim3(1), dim3(1024), 0, s, t, lv, resolution, max_points_per_node, k, cur,
+                           force_split_level1_mask, second);
+      }
+      k += 1 + second;
+      cur ^= 1;
+    }
+  }
+  for (; k <= lv.nlevels; ++k) {
     {
       PcvProf prof(ctx, PCV_K_SPLIT_SEARCH);
       if (keys32)

@@ -257,7 +257,10 @@ print("alt-path ok")
                                               # the chain pass with one point per lane (round 4's first form; what workgroups
                                               # of 1 024 lanes still take), in tiles of 2 x 256 points, and round 3's kernel
                                               ({"PCV_CHAIN_V": "4"}, 12), ({"PCV_SPEC_BIN": "256"}, 12), ({"PCV_SPEC_BIN": "1024"}, 12),
-                                              ({"PCV_CHAIN_V": "3"}, 12)])
+                                              ({"PCV_CHAIN_V": "3"}, 12),
+                                              # the sample tree split one level per launch pair (what u32 keys and levels
+                                              # beyond the first key word still take)
+                                              ({"PCV_SPLIT2": "0"}, 12)])
 def test_alternative_kernels_behind_the_switches_are_byte_exact_too(env, record_bytes):
     """The 20-byte record format (what a predicted tree of more than 2^24 nodes falls back to) and the slot-wise settle
     kernel are selected by switches that are read once per process: run them in a child process against the oracle."""
