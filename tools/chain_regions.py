@@ -25,6 +25,7 @@ COLD_OPS = ("v_div_scale_f64", "v_div_fmas_f64", "v_div_fixup_f64", "v_rcp_f64_e
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("-o", default=None)
+    ap.add_argument("--dump", default=None, help="print the instructions booked on this region")
     a = ap.parse_args()
     text = open(os.path.join(SRC, "pcv_encode.hip")).read().split("\n")
 
@@ -110,6 +111,8 @@ def main():
                 "vmem" if op.startswith(("global_", "buffer_", "flat_", "scratch_")) else "lds" if op.startswith("ds_") else "other")
         d = regions.setdefault(r, {"valu": 0, "valu_f64": 0, "salu": 0, "vmem": 0, "lds": 0, "other": 0})
         d[kind] += 1
+        if a.dump == r:
+            print(f"{cur_file}:{cur_line:5d}  b{bi:<4d} {t}")
         f64 = kind == "valu" and ("_f64" in op or "f64_" in op)
         if f64:
             d["valu_f64"] += 1
@@ -143,12 +146,14 @@ def main():
                            "(Float32 levels: gather block, conversion + decode block, digit compares): 45-47 x 7.05 = 320-330 of the "
                            "582, i.e. ~255 VALU per point outside the level steps, against the static bound of this text: 65 (loads, depth "
                            "look-up, deal) + <= 99 (fetch, tame test, set-up of the walk) + <= 88 (candidate copy, record encoding, "
-                           "pool entry, staging) + 30 (colour, stores); the Float32-pool and padding branches of fetch / after are "
-                           "the ~27 the bound overstates"}
+                           "pool entry, staging) + 30 (colour, stores); the first-candidate copies of the four loops (booked on the lines "
+                           "of their declarations, i.e. under fetch: 8 blocks of 4 moves) and the Float32-pool and padding branches of "
+                           "`after` are what the bound overstates"}
     js = json.dumps(out, indent=1)
     if a.o:
         open(a.o, "w").write(js)
-    print(js)
+    if not a.dump:
+        print(js)
 
 
 if __name__ == "__main__":
