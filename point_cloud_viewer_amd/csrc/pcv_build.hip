@@ -651,6 +651,7 @@ struct PcvBuild {
   PcvScratch sc;
   DevPoints d;
   uint64_t n = 0;
+  bool stage_times = false;  // PCV_BUILD_STAGE_TIMES of THIS build (a context may have begun another one before the finish)
   PcvLevels lv;
   uint64_t *keys_a = nullptr, *keys_b = nullptr;
   void* sort_scratch = nullptr;
@@ -1181,13 +1182,15 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
     int sgroups;
     uint64_t schunk;
     pcv_sort_rec12_geometry(n, &sgroups, &schunk);
-    uint32_t* rows;
-    if ((rc = sc.get(&rows, (size_t)sgroups * tree.num_leaves))) return rc;
-    pcv_launch_rank_hist_rows(ctx, rank, n, tree.num_leaves, d_counts, 8, sgroups, schunk, rows);
-    bs->spec_rows = rows;
-  } else {
-    pcv_launch_rank_hist(ctx, rank, n, tree.num_leaves, d_counts, compact ? 8 : 0);
+    uint32_t* rows = nullptr;
+    // the rows are an optimisation (up to ~1 GB beside the records for the biggest trees): a failed allocation falls
+    // back to the plain count, whose sort takes a counting pass instead
+    if (sc.get(&rows, (size_t)sgroups * tree.num_leaves) == PCV_OK) {
+      pcv_launch_rank_hist_rows(ctx, rank, n, tree.num_leaves, d_counts, 8, sgroups, schunk, rows);
+      bs->spec_rows = rows;
+    }
   }
+  if (!bs->spec_rows) pcv_launch_rank_hist(ctx, rank, n, tree.num_leaves, d_counts, compact ? 8 : 0);
   PCV_HIP_CHECK(ctx, hipGetLastError());
   if ((rc = ctx->pinned_spec_reserve((size_t)tree.num_leaves * 8 + 512 + kPcvPoolRegions * 4))) return rc;
   uint8_t* hp = (uint8_t*)ctx->pinned_spec;
@@ -1247,11 +1250,14 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
     // the kernel stores its verdict straight into the pinned mailbox (host memory the device can write): no copy between
     // the resolve kernel and the sort
     d_out = (uint32_t*)(ctx->mailbox_dev + kMailboxResolve);
+    // the sentinel goes in BEFORE the launch: nothing queued on the stream writes this slot until the kernel does, and a
+    // store after the launch could overwrite a verdict the kernel had already delivered
+    ctx->mailbox[kMailboxResolve] = ~0ull;
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
     pcv_launch_spec_resolve(ctx, lv, params->resolution, sp.cap, sp.force_mask, d_walk, d_slevel, tn, d_counts, d_nst, d_base, d_map, d_out);
     PCV_HIP_CHECK(ctx, hipGetLastError());  // before the sort is queued behind it
     // {true leaves, too shallow} as the device sees them: read by pcv_build_finish (which synchronises anyway) and held
     // against the host's resolve — the device map drives the sort, the host's tree the tables
-    ctx->mailbox[kMailboxResolve] = ~0ull;
     bs->resolve_on_device = true;
     ctx->stage_end(PCV_STAGE_NODE_SPLIT);
     const uint32_t predicted_leaves = (uint32_t)std::count(tree.inner.begin(), tree.inner.end(), (uint8_t)0);
@@ -1342,7 +1348,7 @@ static int build_begin_impl(pcv_ctx* ctx, const pcv_build_params* params, const 
   PCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev[0], st));
   for (bool& on : ctx->stage_on) on = false;
   for (bool& open : ctx->stage_open) open = false;
-  ctx->stage_times = (params->flags & PCV_BUILD_STAGE_TIMES) != 0;
+  ctx->stage_times = bs->stage_times = (params->flags & PCV_BUILD_STAGE_TIMES) != 0;
   ctx->stage_begin(PCV_STAGE_AABB);
   if (routed) {  // device-resident by contract
     d.n = n;
@@ -1686,6 +1692,7 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
   const uint64_t n = bs->n;
   const uint32_t M = bs->M;
   const size_t host_bytes = bs->host_bytes;
+  ctx->stage_times = bs->stage_times;  // the flag of this build, whatever the context has begun since
 
   uint64_t* keys_a = bs->keys_a;
   uint64_t* keys_b = bs->keys_b;
@@ -1956,6 +1963,11 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
     // integer rules to the same counts, so a difference is a bug — reported, never handed out as an octree
     uint32_t dev[2];
     std::memcpy(dev, ctx->mailbox + kMailboxResolve, sizeof(dev));
+    if (dev[0] == 0xffffffffu && dev[1] == 0xffffffffu) {  // the sentinel: the resolve kernel never delivered a verdict
+      t->nodes.clear();
+      t->num_points = 0;
+      return ctx->fail(PCV_E_HIP, "single-chain build: the device's resolve kernel wrote no verdict");
+    }
     bool same = dev[0] == bs->resolve_host_leaves && dev[1] == 0u;
     if (same && bs->resolve_check_map && !bs->resolve_host_map.empty()) {
       std::vector<uint32_t> dm(bs->resolve_host_map.size());
