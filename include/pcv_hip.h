@@ -262,6 +262,14 @@ int pcv_aabb_reduce(pcv_ctx* ctx, const pcv_points* points, double bbox_min[3], 
  * (no node below it can be split, generation.rs:137), capped at `cap`. */
 int pcv_level_table(const double bbox_min[3], const double bbox_max[3], double resolution, int cap, double* edge,
                     int32_t* encoding);
+/* The per-level shortcuts the single chain pass takes for this cube (host tables, for the tests that replay them in
+ * exact arithmetic): digit_mode[k] = how the octant digit of level k + 1 (node.rs:34-42) is read off the level-k codes
+ * (0 = comparison against the centre, 1 = from integer codes, 2 = from Float32 codes); code_threshold[k] = the power of
+ * two from which on a Float32 code of level k + 1 (codec.rs:115-121) is taken as 2 v - bit from the level-k code v
+ * instead of through the divide / cast chain (0.0 = the step always runs in full). Arrays of PCV_MAX_KEY_LEVELS + 2
+ * entries. Returns max_level as pcv_level_table. */
+int pcv_level_shortcuts(const double bbox_min[3], const double bbox_max[3], double resolution, uint32_t* digit_mode,
+                        double* code_threshold);
 
 /* K2: per-point path digits through the quantise->decode chain (ChildIndex::from_bounding_cube
  * node.rs:34-42, encode codec.rs:102-121, decode codec.rs:124-139, cube recurrence node.rs:157-172).

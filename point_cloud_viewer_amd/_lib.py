@@ -136,6 +136,8 @@ _SIGNATURES = {
     "pcv_aabb_reduce": (C.c_int, [_vp, C.POINTER(Points), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "pcv_level_table": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_int,
                                   C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
+    "pcv_level_shortcuts": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_uint32),
+                                      C.POINTER(C.c_double)]),
     "pcv_chain_keys": (C.c_int, [_vp, C.POINTER(BuildParams), C.POINTER(Points), C.c_int, _vp]),
     "pcv_route_buckets": (C.c_int, [_vp, C.POINTER(BuildParams), C.POINTER(Points), _vp, C.POINTER(C.c_uint64),
                                     C.POINTER(RouteState)]),

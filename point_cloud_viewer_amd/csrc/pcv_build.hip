@@ -517,6 +517,42 @@ int pcv_make_levels(const double bmin[3], const double bmax[3], double resolutio
       }
     }
     lv->fast_ok = tame ? 1 : 0;
+    // "codes from codes" (pcv_chain_dev.h, round 5): the step from the Float32 codes of level j to those of level j + 1.
+    // With v the level-j code, b = [v > 1/2] and w = 2 v - b (a float, exactly), the reference's chain computes
+    //   t = (RN(RN(fma(v, e_j, m_j)) - RN(m_j + b e_{j+1})) / e_{j+1}) = w + delta,
+    //   |delta| <= D = 1.01 (H / e_{j+1} + 3 u),   H = one ulp of the binade of the largest |coordinate| of the root cube
+    // (each of the two roundings at that magnitude is off by at most H / 2; the subtraction and the division add at most
+    // 2.1 u), and (float)clamp(t) == w whenever thr <= w < 1 for a power of two thr with D < thr 2^-25: the floats next to
+    // w are at least thr 2^-24 away. The table stores the high word of the smallest such thr with a factor of two in hand;
+    // steps whose thr would exceed 2^-8 are not admitted (most waves would hold a code below it).
+    {
+      static const bool code_steps = [] {  // PCV_CODE_STEPS=0: every level step in full (experiments)
+        const char* ev = pcv_experiment("PCV_CODE_STEPS");
+        return !ev || atoi(ev) != 0;
+      }();
+      const int none = 1 << 20;  // "no such step"
+      int cb = none, ce = none;
+      if (code_steps && tame && std::isfinite(amax) && amax > 0.0) {
+        const double H = std::ldexp(1.0, std::ilogb(amax * (1.0 + 0x1p-40)) - 52);
+        for (int j = 1; j + 1 <= filled && j + 1 < (int)e.size() && j <= PCV_MAX_KEY_LEVELS; ++j) {
+          if (c[j] != PCV_ENC_FLOAT32 || c[j + 1] != PCV_ENC_FLOAT32 || lv->digit_mode[j] != 2 || !(e[j + 1] > 0.0)) continue;
+          const double D = (H / e[j + 1] + 3.0 * 0x1p-53) * 1.01;
+          int ex = 0;
+          (void)std::frexp(2.0 * D * 0x1p+25, &ex);  // 2 D 2^25 = f 2^ex, 1/2 <= f < 1: thr = 2^ex is strictly above it
+          if (ex > -8) continue;
+          if (ex < -100) ex = -100;
+          lv->code_thr_hi[j] = (uint32_t)(1023 + ex) << 20;
+        }
+        for (cb = 1; cb <= PCV_MAX_KEY_LEVELS && !lv->code_thr_hi[cb]; ++cb) {
+        }
+        for (ce = cb; ce <= PCV_MAX_KEY_LEVELS && lv->code_thr_hi[ce]; ++ce) {
+        }
+        if (cb > PCV_MAX_KEY_LEVELS) cb = ce = none;
+        for (int j = ce < PCV_MAX_KEY_LEVELS + 2 ? ce : PCV_MAX_KEY_LEVELS + 2; j < PCV_MAX_KEY_LEVELS + 2; ++j) lv->code_thr_hi[j] = 0;  // one contiguous range
+      }
+      lv->code_begin = cb;
+      lv->code_end = ce;
+    }
     {
       const int never = 1 << 20;
       int f16 = never, f8 = never, f32 = never;
@@ -548,6 +584,25 @@ extern "C" int pcv_level_table(const double bbox_min[3], const double bbox_max[3
   for (int k = 0; k <= ml; ++k) {
     if (edge) edge[k] = e[k];
     if (encoding) encoding[k] = c[k];
+  }
+  return ml;
+}
+
+extern "C" int pcv_level_shortcuts(const double bbox_min[3], const double bbox_max[3], double resolution, uint32_t* digit_mode,
+                                   double* code_threshold) {
+  PcvLevels lv;
+  int ml = 0;
+  pcv_make_levels(bbox_min, bbox_max, resolution, PCV_MAX_LEVELS, &lv, &ml, nullptr, nullptr);
+  for (int k = 0; k < PCV_MAX_KEY_LEVELS + 2; ++k) {
+    if (digit_mode) digit_mode[k] = lv.digit_mode[k];
+    if (code_threshold) {
+      double thr = 0.0;
+      if (k >= lv.code_begin && k < lv.code_end && lv.code_thr_hi[k]) {
+        const uint64_t bits = (uint64_t)lv.code_thr_hi[k] << 32;
+        std::memcpy(&thr, &bits, 8);
+      }
+      code_threshold[k] = thr;
+    }
   }
   return ml;
 }

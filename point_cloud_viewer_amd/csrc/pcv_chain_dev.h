@@ -302,6 +302,23 @@ __device__ __forceinline__ void pcv_chain_apply_bits_t(PcvOctBits b, double ec, 
   py = pcv_decode_val<ENC>(cy, my, ec);
   pz = pcv_decode_val<ENC>(cz, mz, ec);
 }
+// The integer-coded levels of a tame point in a tame table with the level's maximum code (255 / 65535) and its double-double
+// reciprocal as SCALARS: the same operations as pcv_chain_apply_bits_t<PCV_ENC_UINT8 / UINT16, false>, so that the u16- and
+// the u8-coded levels of the chain pass share one loop body (round 5).
+__device__ __forceinline__ void pcv_chain_apply_bits_int(PcvOctBits b, double ec, PcvRecip ic, double maxval, PcvRecip rmax, double& px,
+                                                         double& py, double& pz, double& mx, double& my, double& mz, double& cx,
+                                                         double& cy, double& cz) {
+  mx = pcv_step_min(mx, b.x, ec);
+  my = pcv_step_min(my, b.y, ec);
+  mz = pcv_step_min(mz, b.z, ec);
+  cx = trunc(maxval * fmin(fmax(pcv_div_const<false>(px - mx, ec, ic), 0.0), 1.0));  // pcv_encode_val<integer, false>
+  cy = trunc(maxval * fmin(fmax(pcv_div_const<false>(py - my, ec, ic), 0.0), 1.0));
+  cz = trunc(maxval * fmin(fmax(pcv_div_const<false>(pz - mz, ec, ic), 0.0), 1.0));
+  px = __fma_rn(pcv_div_code(cx, rmax), ec, mx);  // pcv_decode_val<integer>
+  py = __fma_rn(pcv_div_code(cy, rmax), ec, my);
+  pz = __fma_rn(pcv_div_code(cz, rmax), ec, mz);
+}
+
 template <bool GUARD>
 __device__ __forceinline__ void pcv_chain_apply_bits(uint32_t enc, PcvOctBits b, double ec, PcvRecip ic, double& px, double& py, double& pz,
                                                      double& mx, double& my, double& mz, double& cx, double& cy, double& cz) {

@@ -186,193 +186,6 @@ __global__ __launch_bounds__(256) void spec_depth_grid_kernel(const uint32_t* __
   grid[c] = (uint8_t)((r & PCV_SPEC_LEAF) ? l : kGridBits + 1);
 }
 
-template <bool KEEP, bool BIN, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void spec_encode_kernel(
-    PcvLevels lv, const uint32_t* __restrict__ walk, uint64_t n, const double* __restrict__ x,
-    const double* __restrict__ y, const double* __restrict__ z, PcvRouted routed, const uint8_t* __restrict__ color,
-    uint32_t color_stride, const float* __restrict__ intensity, uint32_t* __restrict__ rank, uint4* __restrict__ payload,
-    uint32_t* __restrict__ inten_bits, const uint8_t* __restrict__ depth_grid,
-    float cells_per_unit /* 128 / root edge */, uint4* __restrict__ wide /* set: 12-byte records */,
-    uint32_t* __restrict__ pool_ctr, uint32_t pool_cap) {
-  constexpr int kWavesB = BLOCK / 64;
-  __shared__ double sx[BIN ? BLOCK : 1], sy[BIN ? BLOCK : 1], sz[BIN ? BLOCK : 1];
-  __shared__ uint16_t perm[BIN ? BLOCK : 1];
-  __shared__ uint16_t wcnt[BIN ? kWavesB : 1][kSpecClasses];
-  uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-  double px, py, pz, mx, my, mz;
-  double vx = 0, vy = 0, vz = 0;
-  double kx = 0, ky = 0, kz = 0;
-  int kl = 0;
-  uint32_t d1 = 0;
-  int L = 0;
-  uint32_t rec = walk[0];
-  if (BIN) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool in = i < n;
-    uint32_t key = kSpecClasses - 1;  // padding lanes go last
-    if (in) {
-      double qx, qy, qz;
-      if (routed.oct) {  // routed input: the position the sending rank held after level 1 (decode of the level-1 codes)
-        double t0, t1, t2, t3, t4, t5;
-        uint32_t dd;
-        (void)pcv_chain_start(lv, routed, x, y, z, i, qx, qy, qz, t0, t1, t2, t3, t4, t5, dd);
-      } else {
-        qx = x[i], qy = y[i], qz = z[i];
-        sx[tid] = qx, sy[tid] = qy, sz[tid] = qz;
-      }
-      // cell of the 128^3 grid over the root cube (NaN -> 0, out of range clamps) -> predicted depth (1..8, 8 = deeper)
-      constexpr float kTop = (float)((1 << kGridBits) - 1);
-      const uint32_t ix = (uint32_t)fminf(fmaxf((float)(qx - lv.root_min[0]) * cells_per_unit, 0.f), kTop);
-      const uint32_t iy = (uint32_t)fminf(fmaxf((float)(qy - lv.root_min[1]) * cells_per_unit, 0.f), kTop);
-      const uint32_t iz = (uint32_t)fminf(fmaxf((float)(qz - lv.root_min[2]) * cells_per_unit, 0.f), kTop);
-      const uint32_t l = depth_grid[ix | (iy << kGridBits) | (iz << (2 * kGridBits))];
-      key = (uint32_t)(kSpecClasses - 2 - l);  // deepest first
-    }
-    for (int k = tid; k < kWavesB * kSpecClasses; k += BLOCK) (&wcnt[0][0])[k] = 0;
-    __syncthreads();
-    // lanes of the wave with the same key: 5 ballots; the first of each group publishes the group size
-    uint64_t peers = ~0ull;
-#pragma unroll
-    for (int b = 0; b < 5; ++b) {
-      const bool bit = (key >> b) & 1u;
-      const uint64_t m = __ballot(bit);
-      peers &= bit ? m : ~m;
-    }
-    const uint32_t before = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
-    if (before == 0) wcnt[wave][key] = (uint16_t)__popcll(peers);
-    __syncthreads();
-    if (tid < 64) {  // offsets: keys ascending, inside a key the waves ascending
-      uint32_t tot = 0;
-      if (tid < kSpecClasses)
-        for (int w = 0; w < kWavesB; ++w) tot += wcnt[w][tid];
-      uint32_t inc = tot;
-#pragma unroll
-      for (int o = 1; o < 32; o <<= 1) {
-        const uint32_t v = __shfl_up(inc, o, 64);
-        if (tid >= o) inc += v;
-      }
-      if (tid < kSpecClasses) {
-        uint32_t run = inc - tot;
-        for (int w = 0; w < kWavesB; ++w) {
-          const uint32_t c = wcnt[w][tid];
-          wcnt[w][tid] = (uint16_t)run;
-          run += c;
-        }
-      }
-    }
-    __syncthreads();
-    perm[wcnt[wave][key] + before] = (uint16_t)tid;
-    __syncthreads();
-    const int j = perm[tid];
-    i = (uint64_t)blockIdx.x * BLOCK + j;
-    if (i >= n) return;
-    if (routed.oct) {  // wave-uniform
-      if (pcv_chain_start(lv, routed, x, y, z, i, px, py, pz, mx, my, mz, vx, vy, vz, d1) == 2 && !(rec & PCV_SPEC_LEAF)) {
-        L = 1;
-        rec = walk[(rec & PCV_SPEC_INDEX_MASK) + d1];
-      }
-    } else {
-      px = sx[j], py = sy[j], pz = sz[j];
-      mx = lv.root_min[0], my = lv.root_min[1], mz = lv.root_min[2];
-    }
-  } else {
-    if (i >= n) return;
-    if (pcv_chain_start(lv, routed, x, y, z, i, px, py, pz, mx, my, mz, vx, vy, vz, d1) == 2 && !(rec & PCV_SPEC_LEAF)) {
-      L = 1;  // routed input: level 1 is given (digit + codes)
-      rec = walk[(rec & PCV_SPEC_INDEX_MASK) + d1];
-    }
-  }
-#if PCV_KEEP_BRANCH  /* (experiment) a real branch around the copies: most waves have no lane at its first candidate */
-#define PCV_KEEP_STEP                                                                                                   \
-  if (KEEP) {                                                                                                           \
-    const bool take = (rec & PCV_SPEC_CANDIDATE) && kl == 0;                                                            \
-    if (__builtin_amdgcn_ballot_w64(take) != 0ull) {                                                                    \
-      asm volatile("" ::: "memory");                                                                                    \
-      if (take) {                                                                                                       \
-        kx = vx, ky = vy, kz = vz;                                                                                      \
-        kl = U;                                                                                                         \
-      }                                                                                                                 \
-    }                                                                                                                   \
-  }
-#else
-#define PCV_KEEP_STEP                                                                                                   \
-  if (KEEP && (rec & PCV_SPEC_CANDIDATE) && kl == 0) {                                                                  \
-    kx = vx, ky = vy, kz = vz;                                                                                          \
-    kl = U; /* candidates have level >= 1 */                                                                            \
-  }
-#endif
-/* Levels U + 1 .. LEND of the lanes that have not reached a leaf. U is the wave's level counter: every live lane is at
-   level U (they start together and step together), so it — and with it the level constants and `half` — stays in scalar
-   registers across the loops; L is the lane's own last level. Per level: the digit first, the child's record in flight
-   while the level's encode / decode arithmetic runs. */
-#define PCV_SPEC_LOOP(GUARD, LEND, APPLY)                                                                               \
-  while (U < (LEND)) {                                                                                                  \
-    const bool live = !(rec & PCV_SPEC_LEAF);                                                                           \
-    if (!__any(live)) break;                                                                                            \
-    const double half_next = lv.digit_half[U + 1];                                                                      \
-    if (live) {                                                                                                         \
-      PCV_KEEP_STEP                                                                                                     \
-      const uint32_t d = (!GUARD && half >= 1.0) ? pcv_digit_from_codes(half, vx, vy, vz)                               \
-                                                 : pcv_chain_digit(lv.edge[U], px, py, pz, mx, my, mz);                  \
-      const uint32_t next = walk[(rec & PCV_SPEC_INDEX_MASK) + d];                                                      \
-      const double ec = lv.edge[U + 1];                                                                                 \
-      const PcvRecip ic{lv.inv_edge[U + 1], lv.inv_edge_lo[U + 1]};                                                     \
-      APPLY;                                                                                                            \
-      rec = next;                                                                                                       \
-      L = U + 1;                                                                                                        \
-    }                                                                                                                   \
-    half = half_next;                                                                                                   \
-    ++U;                                                                                                                \
-  }
-#if PCV_ENC_SEGMENTS
-/* one loop per encoding range (PcvLevels::first_u16 / first_u8): Float32 / Float64-coded levels through the per-level   \
-   switch, then the u16-coded and the u8-coded levels as straight-line loops */                                         \
-#define PCV_SPEC_WALK(GUARD)                                                                                          \
-  /* >= 1: the next digit comes from this level's integer codes (fetched with the level's other constants) */          \
-  double half = lv.digit_half[U];                                                                                       \
-  {                                                                                                                     \
-    const int e0 = lv.first_u16 - 1 < lv.nlevels ? lv.first_u16 - 1 : lv.nlevels;                                       \
-    const int e1 = lv.first_u8 - 1 < lv.nlevels ? lv.first_u8 - 1 : lv.nlevels;                                         \
-    PCV_SPEC_LOOP(GUARD, e0, pcv_chain_apply<GUARD>(lv.enc[U + 1], d, ec, ic, px, py, pz, mx, my, mz, vx, vy, vz))          \
-    PCV_SPEC_LOOP(GUARD, e1, (pcv_chain_apply_t<PCV_ENC_UINT16, GUARD>(d, ec, ic, px, py, pz, mx, my, mz, vx, vy, vz))) \
-    PCV_SPEC_LOOP(GUARD, lv.nlevels, (pcv_chain_apply_t<PCV_ENC_UINT8, GUARD>(d, ec, ic, px, py, pz, mx, my, mz, vx, vy, vz))) \
-  }
-#else
-#define PCV_SPEC_WALK(GUARD)                                                                                          \
-  double half = lv.digit_half[U];                                                                                       \
-  PCV_SPEC_LOOP(GUARD, lv.nlevels, pcv_chain_apply<GUARD>(lv.enc[U + 1], d, ec, ic, px, py, pz, mx, my, mz, vx, vy, vz))
-#endif
-  // the wave's level counter (all lanes start at the same level: 0, or 1 for routed input)
-  int U = __builtin_amdgcn_readfirstlane(L);
-  if (lv.fast_ok && pcv_point_is_tame(px, py, pz)) {
-    PCV_SPEC_WALK(false)
-  } else {
-    PCV_SPEC_WALK(true)
-  }
-  // the record carries the codes of the first candidate on the path where there is one, else those of the predicted leaf
-  if (KEEP && kl) {
-    vx = kx, vy = ky, vz = kz;
-    L = kl;
-  }
-  pcv_spec_emit(i, n, rec, lv.enc[L], vx, vy, vz, color, color_stride, intensity, rank, payload, inten_bits, wide, pool_ctr, pool_cap);
-}
-
-// ---- the chain pass, round 4 ------------------------------------------------------------------------------------------------
-// Same walk, same arithmetic, same records as spec_encode_kernel above; what changed is everything AROUND the level steps —
-// by round 3's counters 242 of the 654 VALU instructions per point were not chain arithmetic:
-//   * the deal by predicted depth takes ONE returning LDS atomic per point (its rank among the points of its depth class in
-//     the workgroup) instead of five ballots and a two-level prefix over per-wave counts; every wave scans the 32 class
-//     counters itself in registers (DPP), and the coordinates go straight to their dealt LDS slot: three barriers, no
-//     permutation array;
-//   * Float32-coded levels — 4 of the 6.5 levels a point of the bench cloud walks — test the dividend's range with one
-//     comparison instead of three (pcv_unit_quotient_t<TAME>) and take the next digit from their codes (v > 1/2, ties to
-//     the exact comparison; pcv_chain_dev.h) instead of three additions, a halving and a comparison per coordinate: 48 -> 36
-//     f64-pipe instructions per level; they have a loop of their own (no per-level switch);
-//   * the octant bits stay lane masks (PcvOctBits): `min += bit * edge` and the child index read the comparison results
-//     directly;
-//   * the copy of the first candidate's codes sits behind a wave-uniform branch (most level steps of most waves meet no
-//     candidate): two compares instead of two compares + four moves per level;
-//   * one 32-bit colour load; pool entries for the Float32 codes (pcv_spec_emit).
 __device__ __forceinline__ uint32_t pcv_wave_incl_scan32(uint32_t v) {  // inclusive prefix over lanes 0..31 (DPP rows 0 and 1)
   v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
   v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
@@ -381,18 +194,39 @@ __device__ __forceinline__ uint32_t pcv_wave_incl_scan32(uint32_t v) {  // inclu
   v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1 and 3
   return v;
 }
-
-#ifndef PCV4_KEEP_BRANCH
-#define PCV4_KEEP_BRANCH 1
-#endif
-
-/* walk record of T'' node `idx`: the first lds_nodes records (T'' is level-major: the top of the tree) are mirrored in LDS */
-#define PCV4_WALK_AT(idx) pcv4_walk_at(walk, swalk, lds_nodes, (idx))
-__device__ __forceinline__ uint32_t pcv4_walk_at(const uint32_t* __restrict__ walk, const uint32_t* swalk, uint32_t lds_nodes, uint32_t idx) {
-  return idx < lds_nodes ? swalk[idx] : walk[idx];
+__device__ __forceinline__ uint32_t pcv_lane_again() {  // the lane number, recomputed (opaque to the compiler: nothing to keep live)
+  uint32_t zero = 0;
+  asm volatile("" : "+v"(zero));
+  return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zero));
 }
-#if PCV4_KEEP_BRANCH
-#define PCV4_KEEP_STEP                                                                                                  \
+
+// ---- the single chain pass (round 5): the ONE chain kernel of the shipped library ---------------------------------------------
+// Rounds 2-4 built this pass up (pcv_encode_exp.inc keeps those generations for A/B runs): depth-dealt tiles of two points
+// per lane (a workgroup of BLOCK lanes takes 2 x BLOCK points through ONE memory phase, deals them into groups of 64 by
+// predicted depth, wave w walks group w and then group 2 x waves - 1 - w), the deal by one returning LDS atomic per point,
+// octant bits as lane masks, first-candidate codes behind a wave-uniform branch, 12-byte records that leave through LDS in
+// input order, Float32 codes in the dense `wide` pool (one reservation per wave). Round 5 changes what a level step COSTS
+// and what surrounds it (43 % of the issue cycles were not level arithmetic):
+//   * CODES FROM CODES. A Float32-coded level re-decodes the position from a 24-bit code v, and the next level's code is,
+//     exactly, w = 2 v - bit — a float again. The f64 chain only perturbs that by its rounding noise (<= 2^-40 of the cube
+//     for the bench cloud), far below half a float ulp unless w is tiny: wherever PcvLevels::code_thr_hi admits the step
+//     (pcv_make_levels proves the bound per level) the pass keeps w and the level costs one compare, one select and two
+//     FMAs per coordinate instead of a subtraction, an exact division, a clamp, two conversions and the decode FMA —
+//     3 of the 4 Float32-coded steps of a bench-cloud point. A wave that holds a code below the threshold (or exactly 1/2 or
+//     1, where ties and clamps decide) runs the full step for that level; the position is materialised once, when the
+//     Float32-coded levels end.
+//   * RAW vs ROUTED input is a template parameter: the raw instantiation carries no level-1 decode, no per-lane selects of
+//     the root cube, none of its registers.
+//   * u16- and u8-coded levels share one loop (255 / 65535 and their reciprocals are scalars), so the walk has three loop
+//     bodies instead of four + the cold per-level switch.
+//   * The tame test is made once per point in the front phase (integer compare of the exponent words) and travels as a
+//     bit of the dealt slot number.
+//   * The record epilogue branches on a ballot of "Float32-coded record level": a wave runs one conversion arm; slots,
+//     bounds and the pool region are 32-bit / scalar arithmetic; intensity bits are copied in input order by the closing
+//     phase (coalesced) instead of by the dealt lanes.
+// Same walk, same records, same bytes.
+#define CP_WALK_AT(idx) walk[(idx)]
+#define CP_KEEP_STEP                                                                                                    \
   if (KEEP) {                                                                                                           \
     const bool take = (rec & PCV_SPEC_CANDIDATE) && kl == 0;                                                            \
     if (__builtin_amdgcn_ballot_w64(take) != 0ull) {                                                                    \
@@ -403,33 +237,32 @@ __device__ __forceinline__ uint32_t pcv4_walk_at(const uint32_t* __restrict__ wa
       }                                                                                                                 \
     }                                                                                                                   \
   }
-#else
-#define PCV4_KEEP_STEP                                                                                                  \
-  if (KEEP && (rec & PCV_SPEC_CANDIDATE) && kl == 0) {                                                                  \
-    kx = vx, ky = vy, kz = vz;                                                                                          \
-    kl = U;                                                                                                             \
+/* the octant bits of level U + 1 from level U's state: mode 1 / 2 = from its integer / Float32 codes (a Float32 code of
+   exactly 1/2 is a tie of the exact values: the comparison against the centre decides), else the comparison itself */
+#define CP_BITS(GUARD)                                                                                                  \
+  PcvOctBits b;                                                                                                         \
+  if (!GUARD && mode == 1u) {                                                                                           \
+    b = pcv_bits_from_codes(half, vx, vy, vz);                                                                          \
+  } else if (!GUARD && mode == 2u) {                                                                                    \
+    b = pcv_bits_from_codes(0.5, vx, vy, vz);                                                                           \
+    if (__builtin_expect(__any(pcv_f32_code_tie(vx, vy, vz)), 0)) b = pcv_chain_bits(lv.edge[U], px, py, pz, mx, my, mz); \
+  } else {                                                                                                              \
+    b = pcv_chain_bits(lv.edge[U], px, py, pz, mx, my, mz);                                                             \
   }
-#endif
-/* Levels U + 1 .. LEND of the lanes that have not reached a leaf (U: the wave's level counter, see spec_encode_kernel).
-   mode / half: how the digit of level U + 1 is taken from level U's codes (PcvLevels::digit_mode), scalar. */
-#define PCV4_LOOP(GUARD, LEND, APPLY)                                                                                   \
+/* Levels U + 1 .. LEND of the lanes that have not reached a leaf. U is the wave's level counter (every live lane is at
+   level U), so the level constants are scalars; L is the lane's own last level. The child's walk record is requested
+   right after the digit and lands while the level's arithmetic runs. */
+#define CP_LOOP(GUARD, LEND, SCALARS, APPLY)                                                                            \
   while (U < (LEND)) {                                                                                                  \
     const bool live = !(rec & PCV_SPEC_LEAF);                                                                           \
     if (!__any(live)) break;                                                                                            \
     const double half_next = lv.digit_half[U + 1];                                                                      \
     const uint32_t mode_next = lv.digit_mode[U + 1];                                                                    \
+    SCALARS                                                                                                             \
     if (live) {                                                                                                         \
-      PCV4_KEEP_STEP                                                                                                    \
-      PcvOctBits b;                                                                                                     \
-      if (!GUARD && mode == 1u) {                                                                                       \
-        b = pcv_bits_from_codes(half, vx, vy, vz);                                                                      \
-      } else if (!GUARD && mode == 2u) {                                                                                \
-        b = pcv_bits_from_codes(0.5, vx, vy, vz);                                                                       \
-        if (__builtin_expect(__any(pcv_f32_code_tie(vx, vy, vz)), 0)) b = pcv_chain_bits(lv.edge[U], px, py, pz, mx, my, mz);     \
-      } else {                                                                                                          \
-        b = pcv_chain_bits(lv.edge[U], px, py, pz, mx, my, mz);                                                                 \
-      }                                                                                                                 \
-      const uint32_t next = PCV4_WALK_AT((rec & PCV_SPEC_INDEX_MASK) + b.digit());                                      \
+      CP_KEEP_STEP                                                                                                      \
+      CP_BITS(GUARD)                                                                                                    \
+      const uint32_t next = CP_WALK_AT((rec & PCV_SPEC_INDEX_MASK) + b.digit());                                        \
       const double ec = lv.edge[U + 1];                                                                                 \
       const PcvRecip ic{lv.inv_edge[U + 1], lv.inv_edge_lo[U + 1]};                                                     \
       APPLY;                                                                                                            \
@@ -440,230 +273,138 @@ __device__ __forceinline__ uint32_t pcv4_walk_at(const uint32_t* __restrict__ wa
     mode = mode_next;                                                                                                   \
     ++U;                                                                                                                \
   }
-/* one loop per encoding range: Float64-coded levels (and tables that are not monotone) through the per-level switch, then
-   the Float32-, the u16- and the u8-coded levels as straight-line loops */
-#define PCV4_WALK(GUARD)                                                                                                \
+/* Float32 codes of level U + 1 from those of level U (see the header comment and pcv_make_levels). A wave with a code the
+   table does not admit takes the full step for ALL its live lanes: it is exact everywhere. Positions are not kept. */
+#define CP_CODE_LOOP(LEND)                                                                                              \
+  while (U < (LEND)) {                                                                                                  \
+    const bool live = !(rec & PCV_SPEC_LEAF);                                                                           \
+    if (!__any(live)) break;                                                                                            \
+    U = __builtin_amdgcn_readfirstlane(U);                                                                              \
+    const uint32_t thr_hi = lv.code_thr_hi[U];                                                                          \
+    if (live) {                                                                                                         \
+      CP_KEEP_STEP                                                                                                      \
+      const PcvOctBits b = pcv_bits_from_codes(0.5, vx, vy, vz);                                                        \
+      const double fx = __hiloint2double(b.x ? 0x3ff00000 : 0, 0), fy = __hiloint2double(b.y ? 0x3ff00000 : 0, 0),      \
+                   fz = __hiloint2double(b.z ? 0x3ff00000 : 0, 0);                                                      \
+      const double wx = __fma_rn(2.0, vx, -fx), wy = __fma_rn(2.0, vy, -fy), wz = __fma_rn(2.0, vz, -fz); /* exact */  \
+      const uint32_t hx = (uint32_t)__double2hiint(wx), hy = (uint32_t)__double2hiint(wy), hz = (uint32_t)__double2hiint(wz); \
+      const uint32_t hmin = min(min(hx, hy), hz), hmax = max(max(hx, hy), hz);                                          \
+      const double ec = lv.edge[U + 1];                                                                                 \
+      uint32_t next;                                                                                                    \
+      if (__builtin_expect(__any(hmin < thr_hi || hmax >= 0x3ff00000u), 0)) {                                           \
+        double px = __fma_rn(vx, lv.edge[U], mx), py = __fma_rn(vy, lv.edge[U], my), pz = __fma_rn(vz, lv.edge[U], mz); \
+        PcvOctBits bb = b;                                                                                              \
+        if (__any(pcv_f32_code_tie(vx, vy, vz))) bb = pcv_chain_bits(lv.edge[U], px, py, pz, mx, my, mz);               \
+        next = CP_WALK_AT((rec & PCV_SPEC_INDEX_MASK) + bb.digit());                                                    \
+        const PcvRecip ic{lv.inv_edge[U + 1], lv.inv_edge_lo[U + 1]};                                                   \
+        pcv_chain_apply_bits_t<PCV_ENC_FLOAT32, false>(bb, ec, ic, px, py, pz, mx, my, mz, vx, vy, vz);                 \
+      } else {                                                                                                          \
+        next = CP_WALK_AT((rec & PCV_SPEC_INDEX_MASK) + b.digit());                                                     \
+        mx = __fma_rn(fx, ec, mx), my = __fma_rn(fy, ec, my), mz = __fma_rn(fz, ec, mz); /* pcv_step_min */             \
+        vx = wx, vy = wy, vz = wz;                                                                                      \
+      }                                                                                                                 \
+      rec = next;                                                                                                       \
+      L = U + 1;                                                                                                        \
+    }                                                                                                                   \
+    asm volatile("s_add_i32 %0, %0, 1" : "+s"(U) : : "scc"); /* ++U, kept scalar */                                     \
+  }
+/* the tame walk: [generic per-level switch: Float64-coded levels, non-monotone tables — cold] -> Float32-coded levels in
+   full up to the first admitted code step -> code steps -> the position, once -> remaining Float32-coded levels -> integer-coded levels */
+#define CP_WALK_TAME                                                                                                    \
   {                                                                                                                     \
     double half = lv.digit_half[U];                                                                                     \
     uint32_t mode = lv.digit_mode[U];                                                                                   \
     const int e0 = lv.first_f32 - 1 < lv.nlevels ? lv.first_f32 - 1 : lv.nlevels;                                       \
     const int e1 = lv.first_u16 - 1 < lv.nlevels ? lv.first_u16 - 1 : lv.nlevels;                                       \
-    const int e2 = lv.first_u8 - 1 < lv.nlevels ? lv.first_u8 - 1 : lv.nlevels;                                         \
-    PCV4_LOOP(GUARD, e0, pcv_chain_apply_bits<GUARD>(lv.enc[U + 1], b, ec, ic, px, py, pz, mx, my, mz, vx, vy, vz))     \
-    PCV4_LOOP(GUARD, e1, (pcv_chain_apply_bits_t<PCV_ENC_FLOAT32, GUARD>(b, ec, ic, px, py, pz, mx, my, mz, vx, vy, vz))) \
-    PCV4_LOOP(GUARD, e2, (pcv_chain_apply_bits_t<PCV_ENC_UINT16, GUARD>(b, ec, ic, px, py, pz, mx, my, mz, vx, vy, vz))) \
-    PCV4_LOOP(GUARD, lv.nlevels, (pcv_chain_apply_bits_t<PCV_ENC_UINT8, GUARD>(b, ec, ic, px, py, pz, mx, my, mz, vx, vy, vz))) \
+    const int cb = lv.code_begin, ce = lv.code_end < lv.nlevels ? lv.code_end : lv.nlevels;                             \
+    if (__builtin_expect(U < e0, 0)) {                                                                                  \
+      CP_LOOP(false, e0, , pcv_chain_apply_bits<false>(lv.enc[U + 1], b, ec, ic, px, py, pz, mx, my, mz, vx, vy, vz))   \
+    }                                                                                                                   \
+    CP_LOOP(false, (e1 < cb ? e1 : cb), , (pcv_chain_apply_bits_t<PCV_ENC_FLOAT32, false>(b, ec, ic, px, py, pz, mx, my, mz, vx, vy, vz))) \
+    if (U == cb && cb < ce) {                                                                                           \
+      CP_CODE_LOOP(ce)                                                                                                  \
+      U = __builtin_amdgcn_readfirstlane(U);                                                                            \
+      px = __fma_rn(vx, lv.edge[U], mx), py = __fma_rn(vy, lv.edge[U], my), pz = __fma_rn(vz, lv.edge[U], mz);          \
+      half = lv.digit_half[U];                                                                                          \
+      mode = lv.digit_mode[U];                                                                                          \
+      CP_LOOP(false, e1, , (pcv_chain_apply_bits_t<PCV_ENC_FLOAT32, false>(b, ec, ic, px, py, pz, mx, my, mz, vx, vy, vz))) \
+    }                                                                                                                   \
+    CP_LOOP(false, lv.nlevels,                                                                                          \
+            const bool u8 = U + 1 >= lv.first_u8; const double maxval = u8 ? 255.0 : 65535.0;                           \
+            const PcvRecip rmax = u8 ? PCV_RECIP_255 : PCV_RECIP_65535;,                                                \
+            pcv_chain_apply_bits_int(b, ec, ic, maxval, rmax, px, py, pz, mx, my, mz, vx, vy, vz))                      \
+  }
+/* wild coordinates (NaN, infinities, |v| > 2^500) or an untamed table: every division guarded, every digit by comparison */
+#define CP_WALK_GUARDED                                                                                                 \
+  {                                                                                                                     \
+    double half = 0.0;                                                                                                  \
+    uint32_t mode = 0u;                                                                                                 \
+    CP_LOOP(true, lv.nlevels, , pcv_chain_apply_bits<true>(lv.enc[U + 1], b, ec, ic, px, py, pz, mx, my, mz, vx, vy, vz)) \
   }
 
-template <bool KEEP, int BLOCK>
-__global__ __launch_bounds__(BLOCK, 8) void spec_encode4_kernel(
+template <bool KEEP, bool RAW, int BLOCK>
+__global__ __launch_bounds__(BLOCK, 8) void chain_pass_kernel(
     PcvLevels lv, const uint32_t* __restrict__ walk, uint64_t n, const double* __restrict__ x, const double* __restrict__ y,
     const double* __restrict__ z, PcvRouted routed, const uint8_t* __restrict__ color, uint32_t color_stride,
     const float* __restrict__ intensity, uint32_t* __restrict__ rank, uint4* __restrict__ payload, uint32_t* __restrict__ inten_bits,
-    const uint8_t* __restrict__ depth_grid, float cells_per_unit /* 128 / root edge */, uint4* __restrict__ wide /* set: 12-byte records */,
-    uint32_t* __restrict__ pool_ctr, uint32_t pool_cap, uint32_t lds_cap /* walk records the dynamic LDS has room for (a multiple of 4) */,
-    const uint32_t* __restrict__ tree_info /* [0] = number of T'' nodes (spec_tree_scan_kernel) */,
-    uint32_t diag /* 0; libpcv_hip_exp.so PCV_CHAIN_DIAG (timing only, wrong records — the launcher runs the real pass afterwards):
-                     1 = no walk, 2 = stop after the deal, 4 = no record stores, 8 = stop after the coordinate loads */) {
-#ifndef PCV_EXPERIMENTS
-  diag = 0;  // (the shipped library carries none of the timing-only cuts)
-#endif
-  __shared__ double sxyz[3 * BLOCK];
-  double *const sx = sxyz, *const sy = sxyz + BLOCK, *const sz = sxyz + 2 * BLOCK;
-  __shared__ uint16_t sidx[BLOCK];
-  __shared__ uint32_t kcnt[32];  // points of the workgroup per depth class
-  // the records leave through LDS (12-byte records): after the deal a wave's 64 points are scattered over the workgroup's
-  // slice, and stored straight from the lanes every wave writes a few bytes into each of the slice's 16 + 32 lines — 384
-  // partial-line write requests per workgroup where 48 full lines do (round 4: the pass without its walk took 2.0 ms with
-  // these stores and 1.05 without, tools/chain_diag.sh)
-  // (in the coordinates' staging area, which is dead once every wave has fetched its dealt points: a barrier says so)
-  uint32_t* const okey = reinterpret_cast<uint32_t*>(sxyz);
-  uint2* const opay = reinterpret_cast<uint2*>(sxyz + BLOCK);
-  extern __shared__ uint32_t swalk[];  // the first lds_nodes walk records
-  const uint32_t tn4 = (tree_info[0] + 3u) & ~3u;  // (the table's allocation is a multiple of 256 bytes)
-  const uint32_t lds_nodes = tn4 < lds_cap ? tn4 : lds_cap;
-  const int tid = threadIdx.x, lane = tid & 63;
-  uint64_t i = (uint64_t)blockIdx.x * BLOCK + tid;
-  const bool raw = routed.oct == nullptr;  // grid-uniform
-  if (tid < 32) kcnt[tid] = 0;
-  // The walk table's top in LDS. By round 4's counters this pass is bound by the vector L1, not by its arithmetic: 858 M tag
-  // look-ups per launch = one in 70 % of all cycles of every CU's TCP (+ 11 % tag-conflict stalls), 549 per wave — 290 of
-  // them for the per-level gathers of walk records (64 lanes, ~40 different lines), 64 for the depth grid, the rest for the
-  // coordinates, the colour and the scattered record stores (profiles/r04_chain_pass_v4_before_lds_walk_counters.json). A
-  // workgroup copies the table once (30 KB for the 7 489 nodes of the bench tree: 234 lines) and its waves then gather from LDS.
-  for (uint32_t k = (uint32_t)tid * 4u; k < lds_nodes; k += (uint32_t)BLOCK * 4u)
-    *reinterpret_cast<uint4*>(swalk + k) = *reinterpret_cast<const uint4*>(walk + k);
-  const bool in = i < n;
-  double qx = 0.0, qy = 0.0, qz = 0.0;
-  if (in) {
-    if (raw) {
-      qx = x[i], qy = y[i], qz = z[i];
-    } else {  // routed input: the position the sending rank held after level 1 (decode of the level-1 codes)
-      double t0, t1, t2, t3, t4, t5;
-      uint32_t dd;
-      (void)pcv_chain_start(lv, routed, x, y, z, i, qx, qy, qz, t0, t1, t2, t3, t4, t5, dd);
-    }
-  }
-  if ((diag & 8u) && qx != 12345.678) return;
-  __syncthreads();  // the counters are zero (the coordinate loads are in flight)
-  uint32_t key = kSpecClasses - 1;  // padding lanes go last
-  if (in) {
-    // cell of the 128^3 grid over the root cube (NaN -> 0, out of range clamps) -> predicted depth (1..8, 8 = deeper)
-    constexpr float kTop = (float)((1 << kGridBits) - 1);
-    const uint32_t ix = (uint32_t)fminf(fmaxf((float)(qx - lv.root_min[0]) * cells_per_unit, 0.f), kTop);
-    const uint32_t iy = (uint32_t)fminf(fmaxf((float)(qy - lv.root_min[1]) * cells_per_unit, 0.f), kTop);
-    const uint32_t iz = (uint32_t)fminf(fmaxf((float)(qz - lv.root_min[2]) * cells_per_unit, 0.f), kTop);
-    key = (uint32_t)(kSpecClasses - 2) - depth_grid[ix | (iy << kGridBits) | (iz << (2 * kGridBits))];  // deepest first
-  }
-  // rank of the point among the workgroup's points of its class (any order inside a class will do: the deal only decides
-  // which lane walks which point)
-  const uint32_t pos = __hip_atomic_fetch_add(&kcnt[key], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  __syncthreads();  // the counts are final
-  const uint32_t cnt = kcnt[lane & 31];
-  const uint32_t inc = pcv_wave_incl_scan32(lane < 32 ? cnt : 0u);
-  const uint32_t slot = (uint32_t)__shfl((int)(inc - cnt), (int)key, 64) + pos;  // classes ascending = deepest first
-  if (raw) sx[slot] = qx, sy[slot] = qy, sz[slot] = qz;
-  sidx[slot] = (uint16_t)tid;
-  __syncthreads();
-  const int j = sidx[tid];
-  i = (uint64_t)blockIdx.x * BLOCK + j;
-  const bool stage = wide != nullptr;  // grid-uniform: 12-byte records
-  if ((diag & 2u) && j != 70000) return;
-  double px = 0, py = 0, pz = 0;
-  if (raw) px = sx[tid], py = sy[tid], pz = sz[tid];
-  if (stage) __syncthreads();  // the staging area now belongs to the records (the waves are still in step here)
-  if (i < n) {
-    double mx, my, mz;
-    double vx = 0, vy = 0, vz = 0;
-    double kx = 0, ky = 0, kz = 0;
-    int kl = 0;
-    uint32_t d1 = 0;
-    int L = 0;
-    uint32_t rec = walk[0];
-    if (raw) {
-      mx = lv.root_min[0], my = lv.root_min[1], mz = lv.root_min[2];
-    } else if (pcv_chain_start(lv, routed, x, y, z, i, px, py, pz, mx, my, mz, vx, vy, vz, d1) == 2 && !(rec & PCV_SPEC_LEAF)) {
-      L = 1;  // level 1 is given (digit + codes)
-      rec = PCV4_WALK_AT((rec & PCV_SPEC_INDEX_MASK) + d1);
-    }
-    int U = __builtin_amdgcn_readfirstlane(L);  // the wave's level counter (all lanes start at the same level: 0, or 1 for routed input)
-    if (diag & 1u) {
-      vx = px, vy = py, vz = pz;
-    } else if (lv.fast_ok && pcv_point_is_tame(px, py, pz)) {
-      PCV4_WALK(false)
-    } else {
-      PCV4_WALK(true)
-    }
-    // the record carries the codes of the first candidate on the path where there is one, else those of the predicted leaf
-    if (KEEP && kl) {
-      vx = kx, vy = ky, vz = kz;
-      L = kl;
-    }
-    // the point's index again, from its 9 / 10-bit slot: keeping the 64-bit index alive across the loops costs a spill
-    uint32_t jj = (uint32_t)j;
-    asm volatile("" : "+v"(jj));
-    const uint64_t i2 = (uint64_t)blockIdx.x * BLOCK + jj;
-    // encoding of the record's level: the table is monotone (Float64 -> Float32 -> u16 -> u8 with depth) unless first_f32 says
-    // "never" — three compares instead of a gather from the level table at the very end of the wave's critical path
-    uint32_t leaf_enc;
-    if (lv.first_f32 < (1 << 20))
-      leaf_enc = L >= lv.first_u8 ? PCV_ENC_UINT8 : L >= lv.first_u16 ? PCV_ENC_UINT16 : L >= lv.first_f32 ? PCV_ENC_FLOAT32 : lv.enc[0];
-    else
-      leaf_enc = lv.enc[L];
-    if (!((diag & 4u) && vx != 12345.678))
-      pcv_spec_emit(i2, n, rec, leaf_enc, vx, vy, vz, color, color_stride, intensity, rank, payload, inten_bits, wide, pool_ctr, pool_cap,
-                    stage ? okey : nullptr, opay, jj);
-  }
-  if (stage) {  // input order again: full lines; the colour joins here
-    const uint64_t o = (uint64_t)blockIdx.x * BLOCK + tid;
-    uint32_t rgb = 0;
-    if (o < n) rgb = pcv_load_rgb(color + o * color_stride, o + 1 < n);
-    __syncthreads();
-    if (o < n && !(diag & 4u)) {
-      const uint2 q = opay[tid];
-      rank[o] = okey[tid] | (rgb >> 16);
-      reinterpret_cast<uint2*>(payload)[o] = make_uint2(q.x, q.y | ((rgb & 0xffffu) << 16));
-    }
-  }
-}
-__device__ __forceinline__ uint32_t pcv_lane_again() {  // the lane number, recomputed (opaque to the compiler: nothing to keep live)
-  uint32_t zero = 0;
-  asm volatile("" : "+v"(zero));
-  return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, zero));
-}
-// ---- the chain pass, tiles of two points per lane (round 4, second form) -------------------------------------------------
-// A workgroup of spec_encode4_kernel spends the first third of its life in a chain of dependent latencies — coordinate
-// loads, barrier, depth look-up, LDS atomic, barrier, scan, LDS write, barrier, fetch — during which its eight wave slots
-// issue next to nothing, and the phases of the four workgroups of a CU do not hide each other. Here a
-// workgroup takes 2 x BLOCK points through that chain at once (two points per lane: twice the loads in flight for the same
-// latency, half the barriers per point), deals them into 2 x BLOCK / 64 groups by predicted depth, and wave w walks group w
-// (the deep end) and then group 2 x waves - 1 - w (the shallow end), one after the other: the walk keeps its registers and
-// its 8 waves per SIMD. 2.24 -> 2.0 ms at 100 M points. (Which two groups a wave gets makes no measurable difference; the
-// pairing deep + shallow just keeps the waves of a workgroup together at the closing barrier.) Same walk, same
-// arithmetic, same records.
-// LDS: the coordinates of the tile in two halves of BLOCK dealt slots ({x[BLOCK], y[BLOCK], z[BLOCK]} each); the first half
-// is dead once every wave has fetched its first group and becomes the staging area of the tile's 2 x BLOCK records.
-template <bool KEEP, int BLOCK, bool BALANCED = true /* false (experiments): wave w walks groups w and waves + w */,
-          bool FAKE = false /* true (experiments, timing only, wrong records): the walk gathers are served by a dummy table in LDS that
-                               ends every walk at the depth the grid predicts */>
-__global__ __launch_bounds__(BLOCK, 8) void spec_encode_pair_kernel(
-    PcvLevels lv, const uint32_t* __restrict__ walk, uint64_t n, const double* __restrict__ x, const double* __restrict__ y,
-    const double* __restrict__ z, PcvRouted routed, const uint8_t* __restrict__ color, uint32_t color_stride,
-    const float* __restrict__ intensity, uint32_t* __restrict__ rank, uint4* __restrict__ payload, uint32_t* __restrict__ inten_bits,
-    const uint8_t* __restrict__ depth_grid, float cells_per_unit /* 128 / root edge */, uint4* __restrict__ wide /* set: 12-byte records */,
-    uint32_t* __restrict__ pool_ctr, uint32_t pool_cap) {
+    const uint8_t* __restrict__ depth_grid /* null: no deal by depth (small builds) */, float cells_per_unit /* 128 / root edge */,
+    uint4* __restrict__ wide /* set: 12-byte records */, uint32_t* __restrict__ pool_ctr, uint32_t pool_cap) {
   constexpr int TILE = 2 * BLOCK, kGroups = TILE / 64;
+  static_assert(TILE <= 1024, "a tile must not span two pool regions, and its slot numbers share 16 bits with the wild flag");
+  constexpr uint32_t kWild = 0x8000u;
   __shared__ double sxyz[3 * TILE];  // slot s: half s / BLOCK, {x, y, z}[s % BLOCK]
   __shared__ uint16_t sidx[TILE];
   __shared__ uint32_t kcnt[32];  // points of the tile per depth class
-  uint32_t* const okey = reinterpret_cast<uint32_t*>(sxyz);          // TILE keys: the x of the first half
-  uint2* const opay = reinterpret_cast<uint2*>(sxyz + BLOCK);        // TILE payloads: its y and z
-  __shared__ uint32_t sfake[FAKE ? 2048 : 4];  // [(depth * 16 + level) * 8 + digit]
-  constexpr uint32_t lds_nodes = FAKE ? 0xffffffffu : 0u;  // (PCV4_WALK_AT: no LDS mirror of the walk records)
-  const uint32_t* const swalk = sfake;
+  // the first half of the coordinates is dead once every wave has fetched its first group: it stages the tile's records
+  uint32_t* const okey = reinterpret_cast<uint32_t*>(sxyz);    // TILE keys: the x of the first half
+  uint2* const opay = reinterpret_cast<uint2*>(sxyz + BLOCK);  // TILE payloads: its y and z
   // the wave's number is a scalar and the lane number can be had again from nothing (mbcnt): no lane-indexed value needs to
   // stay in a register across the walks
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   int lane = (int)pcv_lane_again(), tid = wave * 64 + lane;
   const uint64_t base = (uint64_t)blockIdx.x * TILE;
-  const bool raw = routed.oct == nullptr;  // grid-uniform
-  const bool stage = wide != nullptr;      // grid-uniform: 12-byte records
+  const uint32_t here = n - base < (uint64_t)TILE ? (uint32_t)(n - base) : (uint32_t)TILE;  // points of this tile (scalar)
+  const bool stage = wide != nullptr;  // grid-uniform: 12-byte records
   if (tid < 32) kcnt[tid] = 0;
-  if (FAKE)
-    for (int e = tid; e < 2048; e += BLOCK) {
-      const uint32_t dp = (uint32_t)e >> 7, l = ((uint32_t)e >> 3) & 15u;
-      sfake[e] = ((dp * 16u + l + 1u) * 8u) | (l + 1u >= dp || l >= 14u ? PCV_SPEC_LEAF : 0u);
-    }
   double qx[2], qy[2], qz[2];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    const uint64_t i = base + (uint64_t)(h * BLOCK + tid);
+    const uint32_t t = (uint32_t)(h * BLOCK + tid);
     qx[h] = qy[h] = qz[h] = 0.0;
-    if (i < n) {
-      if (raw) {
-        qx[h] = x[i], qy[h] = y[i], qz[h] = z[i];
+    if (t < here) {
+      if (RAW) {
+        qx[h] = x[base + t], qy[h] = y[base + t], qz[h] = z[base + t];
       } else {  // routed input: the position the sending rank held after level 1 (decode of the level-1 codes)
         double t0, t1, t2, t3, t4, t5;
         uint32_t dd;
-        (void)pcv_chain_start(lv, routed, x, y, z, i, qx[h], qy[h], qz[h], t0, t1, t2, t3, t4, t5, dd);
+        (void)pcv_chain_start(lv, routed, x, y, z, base + t, qx[h], qy[h], qz[h], t0, t1, t2, t3, t4, t5, dd);
       }
     }
   }
   __syncthreads();  // the counters are zero (the coordinate loads are in flight)
-  uint32_t key[2], pos[2];
+  uint32_t key[2], pos[2], wild[2];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     key[h] = kSpecClasses - 1;  // padding lanes go last
-    if (base + (uint64_t)(h * BLOCK + tid) < n) {
-      // cell of the 128^3 grid over the root cube (NaN -> 0, out of range clamps) -> predicted depth (1..8, 8 = deeper)
-      constexpr float kTop = (float)((1 << kGridBits) - 1);
-      const uint32_t ix = (uint32_t)fminf(fmaxf((float)(qx[h] - lv.root_min[0]) * cells_per_unit, 0.f), kTop);
-      const uint32_t iy = (uint32_t)fminf(fmaxf((float)(qy[h] - lv.root_min[1]) * cells_per_unit, 0.f), kTop);
-      const uint32_t iz = (uint32_t)fminf(fmaxf((float)(qz[h] - lv.root_min[2]) * cells_per_unit, 0.f), kTop);
-      key[h] = (uint32_t)(kSpecClasses - 2) - depth_grid[ix | (iy << kGridBits) | (iz << (2 * kGridBits))];  // deepest first
+    if ((uint32_t)(h * BLOCK + tid) < here) {
+      key[h] = 0;
+      if (depth_grid) {
+        // cell of the 128^3 grid over the root cube (NaN -> 0, out of range clamps) -> predicted depth (1..8, 8 = deeper)
+        constexpr float kTop = (float)((1 << kGridBits) - 1);
+        const uint32_t ix = (uint32_t)fminf(fmaxf((float)(qx[h] - lv.root_min[0]) * cells_per_unit, 0.f), kTop);
+        const uint32_t iy = (uint32_t)fminf(fmaxf((float)(qy[h] - lv.root_min[1]) * cells_per_unit, 0.f), kTop);
+        const uint32_t iz = (uint32_t)fminf(fmaxf((float)(qz[h] - lv.root_min[2]) * cells_per_unit, 0.f), kTop);
+        key[h] = (uint32_t)(kSpecClasses - 2) - depth_grid[ix | (iy << kGridBits) | (iz << (2 * kGridBits))];  // deepest first
+      }
     }
+    // pcv_point_is_tame, a little stricter (|v| < 2^500: one integer compare of the largest exponent word; NaN and the
+    // infinities have the largest of all) — the guarded walk is exact for every input, so "wild" may be over-reported
+    const uint32_t ex = max(max((uint32_t)__double2hiint(qx[h]) & 0x7fffffffu, (uint32_t)__double2hiint(qy[h]) & 0x7fffffffu),
+                            (uint32_t)__double2hiint(qz[h]) & 0x7fffffffu);
+    wild[h] = ex >= 0x5f300000u ? kWild : 0u;  // 2^500
   }
-  // rank of a point among the tile's points of its class (any order inside a class will do)
+  // rank of a point among the tile's points of its class (any order inside a class will do: the deal only decides which
+  // lane walks which point)
 #pragma unroll
   for (int h = 0; h < 2; ++h) pos[h] = __hip_atomic_fetch_add(&kcnt[key[h]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   __syncthreads();  // the counts are final
@@ -672,220 +413,140 @@ __global__ __launch_bounds__(BLOCK, 8) void spec_encode_pair_kernel(
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const uint32_t slot = (uint32_t)__shfl((int)(inc - cnt), (int)key[h], 64) + pos[h];  // classes ascending = deepest first
-    if (raw) {
+    if (RAW) {
       double* const c = sxyz + (slot / BLOCK) * (3 * BLOCK) + (slot % BLOCK);
       c[0] = qx[h], c[BLOCK] = qy[h], c[2 * BLOCK] = qz[h];
     }
-    sidx[slot] = (uint16_t)((h * BLOCK + tid) | (FAKE ? (kSpecClasses - 2 - key[h]) << 11 : 0u));
+    sidx[slot] = (uint16_t)((uint32_t)(h * BLOCK + tid) | wild[h]);
   }
   __syncthreads();
+  const uint32_t rec0 = walk[0];  // the root's record (scalar)
+  const bool monotone = lv.first_f32 < (1 << 20);
 #pragma unroll 1
   for (int task = 0; task < 2; ++task) {
     lane = (int)pcv_lane_again();
-    const int s = (task == 0 ? wave : BALANCED ? kGroups - 1 - wave : kGroups / 2 + wave) * 64 + lane;  // first the deep end, then the shallow end
+    const int s = (task == 0 ? wave : kGroups - 1 - wave) * 64 + lane;  // first the deep end, then the shallow end
     const uint32_t jd = sidx[s];
-    const int j = FAKE ? (int)(jd & 2047u) : (int)jd;
     double px = 0, py = 0, pz = 0;
-    if (raw) {
+    if (RAW) {
       const double* const c = sxyz + (s / BLOCK) * (3 * BLOCK) + (s % BLOCK);
       px = c[0], py = c[BLOCK], pz = c[2 * BLOCK];
     }
     if (task == 0 && stage) __syncthreads();  // the first half now belongs to the records (the waves are still in step here)
-    const uint64_t i = base + (uint64_t)j;
-    if (i < n) {
-      double mx, my, mz;
+    const uint32_t j = jd & (kWild - 1u);
+    if (j < here) {
+      double mx = lv.root_min[0], my = lv.root_min[1], mz = lv.root_min[2];
       double vx = 0, vy = 0, vz = 0;
       double kx = 0, ky = 0, kz = 0;
       int kl = 0;
-      uint32_t d1 = 0;
       int L = 0;
-      uint32_t rec = FAKE ? (((jd >> 11) & 15u) * 16u) * 8u : walk[0];
-      if (raw) {
-        mx = lv.root_min[0], my = lv.root_min[1], mz = lv.root_min[2];
-      } else if (pcv_chain_start(lv, routed, x, y, z, i, px, py, pz, mx, my, mz, vx, vy, vz, d1) == 2 && !(rec & PCV_SPEC_LEAF)) {
-        L = 1;  // level 1 is given (digit + codes)
-        rec = walk[(rec & PCV_SPEC_INDEX_MASK) + d1];
+      uint32_t rec = rec0;
+      if (!RAW) {
+        uint32_t d1 = 0;
+        if (pcv_chain_start(lv, routed, x, y, z, base + j, px, py, pz, mx, my, mz, vx, vy, vz, d1) == 2 && !(rec & PCV_SPEC_LEAF)) {
+          L = 1;  // level 1 is given (digit + codes)
+          rec = walk[(rec & PCV_SPEC_INDEX_MASK) + d1];
+        }
       }
-      int U = __builtin_amdgcn_readfirstlane(L);  // the wave's level counter (all lanes start at the same level: 0, or 1 for routed input)
-      if (lv.fast_ok && pcv_point_is_tame(px, py, pz)) {
-        PCV4_WALK(false)
+      // the wave's level counter (all lanes start at the same level: 0, or 1 for routed input). readfirstlane pins it to a
+      // scalar register: the level constants are then scalar loads and the loop control is SALU
+      // (made opaque first: a constant start would be folded and the compiler then keeps the counter in a VGPR)
+      int Ls = L;
+      asm volatile("" : "+v"(Ls));
+      int U = __builtin_amdgcn_readfirstlane(Ls);
+      if (lv.fast_ok && !(jd & kWild)) {
+        CP_WALK_TAME
       } else {
-        PCV4_WALK(true)
+        CP_WALK_GUARDED
       }
       // the record carries the codes of the first candidate on the path where there is one, else those of the predicted leaf
       if (KEEP && kl) {
         vx = kx, vy = ky, vz = kz;
         L = kl;
       }
-      // the point's index again, from its slot in the tile: keeping the 64-bit index alive across the loops costs a spill
-      uint32_t jj = (uint32_t)j;
+      // is the record's level Float32-coded (-> a `wide` pool entry)? The table is monotone (Float64 -> Float32 -> u16 -> u8 with
+      // depth) unless first_f32 says "never": two compares instead of a gather from the level table at the very end of the
+      // wave's critical path
+      const bool is_wide = monotone ? (L < lv.first_u16 && (L >= lv.first_f32 || lv.enc[0] > PCV_ENC_UINT16)) : lv.enc[L] > PCV_ENC_UINT16;
+      // the slot number again, from the dealt slot: nothing lane-indexed stays live across the loops
+      uint32_t jj = j;
       asm volatile("" : "+v"(jj));
-      const uint64_t i2 = (uint64_t)blockIdx.x * TILE + jj;
-      uint32_t leaf_enc;  // (see spec_encode4_kernel)
-      if (lv.first_f32 < (1 << 20))
-        leaf_enc = L >= lv.first_u8 ? PCV_ENC_UINT8 : L >= lv.first_u16 ? PCV_ENC_UINT16 : L >= lv.first_f32 ? PCV_ENC_FLOAT32 : lv.enc[0];
-      else
-        leaf_enc = lv.enc[L];
-      pcv_spec_emit(i2, n, rec, leaf_enc, vx, vy, vz, color, color_stride, intensity, rank, payload, inten_bits, wide, pool_ctr, pool_cap,
-                    stage ? okey : nullptr, opay, jj);
+      if (stage) {
+        const uint32_t key = (rec & PCV_SPEC_INDEX_MASK) << 8;  // the blue byte joins in the closing phase
+        const uint64_t wm = __ballot(is_wide);
+        uint2 out;
+        if (wm == 0ull) {  // wave-uniform: integer codes only (the deep groups)
+          out = make_uint2((uint32_t)vx | ((uint32_t)vy << 16), (uint32_t)vz);
+        } else {
+          // value domain -> raw code: the IEEE bits of the float (single-chain builds have no Float64-coded level:
+          // build_begin_impl sends those to the exact pipeline)
+          const uint32_t ccx = is_wide ? __float_as_uint((float)vx) : (uint32_t)vx, ccy = is_wide ? __float_as_uint((float)vy) : (uint32_t)vy,
+                         ccz = is_wide ? __float_as_uint((float)vz) : (uint32_t)vz;
+          out = make_uint2(ccx | (ccy << 16), ccz);
+          // ONE reservation per wave in the pool region of the tile's slice of 1 024 input points (scalar: a tile never
+          // spans two slices); the order in which waves reach the counter does not matter — the record names its entry
+          const uint32_t region = (uint32_t)(base >> 10) & (kPcvPoolRegions - 1u);
+          const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(wm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wm, 0u));
+          uint32_t first = 0;
+          if (is_wide && below == 0u)
+            first = __hip_atomic_fetch_add(pool_ctr + region, (uint32_t)__popcll(wm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          first = region * pool_cap + (uint32_t)__builtin_amdgcn_readlane((int)first, (int)__builtin_ctzll(wm));
+          if (is_wide) {
+            const uint32_t e = first + below;
+            wide[e] = make_uint4(ccx, ccy, ccz, 0u);
+            out = make_uint2(e, 0u);
+          }
+        }
+        okey[jj] = key;
+        opay[jj] = out;
+      } else {  // 20-byte records (a predicted tree that could outgrow 24 rank bits): the codes travel in full
+        const uint64_t i = base + jj;
+        const uint32_t rgb = pcv_load_rgb(color + i * color_stride, i + 1 < n);
+        rank[i] = rec & PCV_SPEC_INDEX_MASK;
+        payload[i] = is_wide ? make_uint4(__float_as_uint((float)vx), __float_as_uint((float)vy), __float_as_uint((float)vz), rgb)
+                             : make_uint4((uint32_t)vx, (uint32_t)vy, (uint32_t)vz, rgb);
+      }
     }
   }
-  if (stage) {  // input order again: full lines; the colour joins here
-    tid = wave * 64 + (int)pcv_lane_again();
+  // closing phase, input order again: full lines; the colour and the intensity bits join here
+  tid = wave * 64 + (int)pcv_lane_again();
+  if (stage) {
     uint32_t rgb[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const uint64_t o = base + (uint64_t)(h * BLOCK + tid);
-      rgb[h] = o < n ? pcv_load_rgb(color + o * color_stride, o + 1 < n) : 0u;
+      const uint32_t t = (uint32_t)(h * BLOCK + tid);
+      rgb[h] = t < here ? pcv_load_rgb(color + (base + t) * color_stride, base + t + 1 < n) : 0u;
     }
     __syncthreads();
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const uint64_t o = base + (uint64_t)(h * BLOCK + tid);
-      if (o < n) {
-        const uint2 q = opay[h * BLOCK + tid];
-        rank[o] = okey[h * BLOCK + tid] | (rgb[h] >> 16);
-        reinterpret_cast<uint2*>(payload)[o] = make_uint2(q.x, q.y | ((rgb[h] & 0xffffu) << 16));
+      const uint32_t t = (uint32_t)(h * BLOCK + tid);
+      if (t < here) {
+        const uint2 q = opay[t];
+        rank[base + t] = okey[t] | (rgb[h] >> 16);
+        reinterpret_cast<uint2*>(payload)[base + t] = make_uint2(q.x, q.y | ((rgb[h] & 0xffffu) << 16));
       }
     }
   }
+  if (inten_bits) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const uint32_t t = (uint32_t)(h * BLOCK + tid);
+      if (t < here) inten_bits[base + t] = __float_as_uint(intensity[base + t]);
+    }
+  }
 }
-#undef PCV4_WALK
-#undef PCV4_LOOP
-#undef PCV4_KEEP_STEP
-#undef PCV4_WALK_AT
+#undef CP_WALK_GUARDED
+#undef CP_WALK_TAME
+#undef CP_CODE_LOOP
+#undef CP_LOOP
+#undef CP_BITS
+#undef CP_KEEP_STEP
+#undef CP_WALK_AT
 
 #ifdef PCV_EXPERIMENTS
-// (libpcv_hip_exp.so only: measured slower than the kernel above — DESIGN.md §6, profiles/r03h_*)
-// Persistent form of the binned pass for raw (not routed) input. The kernel above starts one workgroup per 512 points:
-// its eight waves load coordinates, look the depth up, sort themselves through five barriers — and only then have
-// arithmetic to issue; with four such workgroups per CU the SIMDs idle a quarter of the time (VALU issue 71 %, half of
-// every wave's life in s_waitcnt). Here a workgroup stays and walks tile after tile:
-//   * a tile is 2 x BLOCK points, re-dealt by predicted depth into 2 x (BLOCK / 64) groups of 64; wave w walks group w
-//     (the deep end) and then group 2 x waves - 1 - w (the shallow end), so the waves of a workgroup finish together and
-//     the barrier that opens the next tile costs nobody a wait;
-//   * the NEXT tile's coordinates are loaded into registers before the walks start and land while they run.
-// Same arithmetic, same outputs as the kernel above (the deal only decides which lane walks which point).
-template <int BLOCK, bool PREFETCH>
-__global__ __launch_bounds__(BLOCK, PREFETCH ? 6 : 8) void spec_encode_persist_kernel(
-    PcvLevels lv, const uint32_t* __restrict__ walk, uint64_t n, uint32_t num_tiles, const double* __restrict__ x,
-    const double* __restrict__ y, const double* __restrict__ z, const uint8_t* __restrict__ color, uint32_t color_stride,
-    const float* __restrict__ intensity, uint32_t* __restrict__ rank, uint4* __restrict__ payload, uint32_t* __restrict__ inten_bits,
-    const uint8_t* __restrict__ depth_grid, float cells_per_unit, uint4* __restrict__ wide, uint32_t* __restrict__ pool_ctr, uint32_t pool_cap) {
-  constexpr bool KEEP = true;
-  constexpr int TILE = 2 * BLOCK, kWavesB = BLOCK / 64, kGroups = 2 * kWavesB;
-  __shared__ double sx[TILE], sy[TILE], sz[TILE];
-  __shared__ uint16_t perm[TILE];
-  __shared__ uint16_t wcnt[kGroups][kSpecClasses];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  double qx[2], qy[2], qz[2];
-  auto load_tile = [&](uint32_t tile) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const uint64_t i = (uint64_t)tile * TILE + (uint64_t)h * BLOCK + tid;
-      const bool in = i < n;
-      qx[h] = in ? x[i] : 0.0;
-      qy[h] = in ? y[i] : 0.0;
-      qz[h] = in ? z[i] : 0.0;
-    }
-  };
-  uint32_t tile = blockIdx.x;
-  if (PREFETCH && tile < num_tiles) load_tile(tile);
-  for (; tile < num_tiles; tile += gridDim.x) {
-    const uint64_t base = (uint64_t)tile * TILE;
-    if (!PREFETCH) load_tile(tile);  // (variant without the registers that carry the next tile across the walks)
-    uint32_t key[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      key[h] = kSpecClasses - 1;  // padding lanes go last
-      if (base + (uint64_t)h * BLOCK + tid < n) {
-        constexpr float kTop = (float)((1 << kGridBits) - 1);
-        const uint32_t ix = (uint32_t)fminf(fmaxf((float)(qx[h] - lv.root_min[0]) * cells_per_unit, 0.f), kTop);
-        const uint32_t iy = (uint32_t)fminf(fmaxf((float)(qy[h] - lv.root_min[1]) * cells_per_unit, 0.f), kTop);
-        const uint32_t iz = (uint32_t)fminf(fmaxf((float)(qz[h] - lv.root_min[2]) * cells_per_unit, 0.f), kTop);
-        key[h] = (uint32_t)(kSpecClasses - 2 - depth_grid[ix | (iy << kGridBits) | (iz << (2 * kGridBits))]);  // deepest first
-      }
-    }
-    __syncthreads();  // every wave is done with the previous tile's coordinates and deal
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      sx[h * BLOCK + tid] = qx[h];
-      sy[h * BLOCK + tid] = qy[h];
-      sz[h * BLOCK + tid] = qz[h];
-    }
-    for (int k = tid; k < kGroups * kSpecClasses; k += BLOCK) (&wcnt[0][0])[k] = 0;
-    __syncthreads();
-    // lanes of a 64-point row with the same key: 5 ballots; the first of each group publishes the group size
-    uint32_t before[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      uint64_t peers = ~0ull;
-#pragma unroll
-      for (int b = 0; b < 5; ++b) {
-        const bool bit = (key[h] >> b) & 1u;
-        const uint64_t m = __ballot(bit);
-        peers &= bit ? m : ~m;
-      }
-      before[h] = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
-      if (before[h] == 0) wcnt[h * kWavesB + wave][key[h]] = (uint16_t)__popcll(peers);
-    }
-    __syncthreads();
-    if (tid < 64) {  // offsets: keys ascending, inside a key the rows ascending
-      uint32_t tot = 0;
-      if (tid < kSpecClasses)
-        for (int w = 0; w < kGroups; ++w) tot += wcnt[w][tid];
-      uint32_t inc = tot;
-#pragma unroll
-      for (int o = 1; o < 32; o <<= 1) {
-        const uint32_t v = __shfl_up(inc, o, 64);
-        if (tid >= o) inc += v;
-      }
-      if (tid < kSpecClasses) {
-        uint32_t run = inc - tot;
-        for (int w = 0; w < kGroups; ++w) {
-          const uint32_t c = wcnt[w][tid];
-          wcnt[w][tid] = (uint16_t)run;
-          run += c;
-        }
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int h = 0; h < 2; ++h) perm[wcnt[h * kWavesB + wave][key[h]] + before[h]] = (uint16_t)(h * BLOCK + tid);
-    __syncthreads();
-    if (PREFETCH) {  // the next tile's coordinates travel while this one is walked
-      const uint32_t next = tile + gridDim.x;
-      if (next < num_tiles) load_tile(next);
-    }
-    for (int task = 0; task < 2; ++task) {
-      const int group = task == 0 ? wave : kGroups - 1 - wave;
-      const int j = perm[group * 64 + lane];
-      const uint64_t i = base + j;
-      if (i >= n) continue;
-      double px = sx[j], py = sy[j], pz = sz[j];
-      double mx = lv.root_min[0], my = lv.root_min[1], mz = lv.root_min[2];
-      double vx = 0, vy = 0, vz = 0;
-      double kx = 0, ky = 0, kz = 0;
-      int kl = 0;
-      int L = 0;
-      uint32_t rec = walk[0];
-      int U = 0;  // the wave's level counter: every lane starts at the root
-      if (lv.fast_ok && pcv_point_is_tame(px, py, pz)) {
-        PCV_SPEC_WALK(false)
-      } else {
-        PCV_SPEC_WALK(true)
-      }
-      if (kl) {
-        vx = kx, vy = ky, vz = kz;
-        L = kl;
-      }
-      pcv_spec_emit(i, n, rec, lv.enc[L], vx, vy, vz, color, color_stride, intensity, rank, payload, inten_bits, wide, pool_ctr, pool_cap);
-    }
-  }
-}
+#include "pcv_encode_exp.inc"
 #endif  // PCV_EXPERIMENTS
-#undef PCV_SPEC_WALK
-#undef PCV_SPEC_LOOP
 
 // Exact number of points per predicted leaf: LDS-privatised histogram of the rank array over the bins
 // [bin_base, bin_base + nbins), nbins <= kHistBins; one flush of the non-zero bins per workgroup.
@@ -1391,95 +1052,9 @@ void pcv_launch_leaf_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvWalkTabl
                      y, z, routed, color, color_stride, intensity, rank, (uint4*)payload, cx_hi, cy_hi, cz_hi, inten_bits);
 }
 
-template <bool BIN, int BLOCK>
-static void launch_spec_encode_t(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* walk, uint64_t n, const double* x,
-                                 const double* y, const double* z, const PcvRouted& routed, const uint8_t* color,
-                                 uint32_t color_stride, const float* intensity, uint32_t* rank, void* payload,
-                                 uint32_t* inten_bits, uint8_t* depth_grid, void* wide, uint32_t* pool_ctr, bool v4, bool pair,
-                                 const uint32_t* tree_info) {
-  const dim3 grid((unsigned)((n + BLOCK - 1) / BLOCK));
-  const float cells = lv.edge[0] > 0.0 ? (float)((double)(1 << kGridBits) / lv.edge[0]) : 0.f;
-  const uint32_t pool_cap = (uint32_t)pcv_pool_region_entries(n);
-  if (BIN) hipLaunchKernelGGL(spec_depth_grid_kernel, dim3((1u << (3 * kGridBits)) / 256), dim3(256), 0, ctx->stream, walk, depth_grid);
-  if (BIN && v4 && pair && BLOCK <= 512) {  // tiles of 2 x BLOCK points (a tile must not span two pool regions: <= 1 024 points)
-    constexpr int PB = BLOCK <= 512 ? BLOCK : 512;
 #ifdef PCV_EXPERIMENTS
-    static const bool fake = pcv_experiment("PCV_PAIR_FAKE_WALK") != nullptr;
-    if (fake) {  // timing only: the pass with its walk gathers served from LDS runs first and is timed on its own
-      hipEvent_t e0, e1;
-      (void)hipEventCreate(&e0);
-      (void)hipEventCreate(&e1);
-      (void)hipEventRecord(e0, ctx->stream);
-      hipLaunchKernelGGL((spec_encode_pair_kernel<true, PB, true, true>), dim3((unsigned)((n + 2 * PB - 1) / (2 * PB))), dim3(PB), 0, ctx->stream, lv, walk,
-                         n, x, y, z, routed, color, color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide,
-                         pool_ctr, pool_cap);
-      (void)hipEventRecord(e1, ctx->stream);
-      (void)hipEventSynchronize(e1);
-      float ms = 0.f;
-      (void)hipEventElapsedTime(&ms, e0, e1);
-      fprintf(stderr, "PCV_PAIR_FAKE_WALK block=%d: %.3f ms\n", PB, ms);
-      (void)hipEventDestroy(e0);
-      (void)hipEventDestroy(e1);
-      (void)hipMemsetAsync(pool_ctr, 0, kPcvPoolRegions * 4, ctx->stream);
-    }
-    static const bool unbalanced = pcv_experiment("PCV_PAIR_UNBALANCED") != nullptr;
-    if (unbalanced) {
-      hipLaunchKernelGGL((spec_encode_pair_kernel<true, PB, false>), dim3((unsigned)((n + 2 * PB - 1) / (2 * PB))), dim3(PB), 0, ctx->stream, lv, walk, n, x,
-                         y, z, routed, color, color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide,
-                         pool_ctr, pool_cap);
-      return;
-    }
+#include "pcv_encode_exp_launch.inc"
 #endif
-    hipLaunchKernelGGL((spec_encode_pair_kernel<true, PB>), dim3((unsigned)((n + 2 * PB - 1) / (2 * PB))), dim3(PB), 0, ctx->stream, lv, walk, n, x, y, z,
-                       routed, color, color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr,
-                       pool_cap);
-  } else if (BIN && v4) {
-    // walk records mirrored in LDS (PCV_CHAIN_LDS=entries, libpcv_hip_exp.so): measured and NOT shipped — with 4 096 / 6 144 /
-    // 8 192 entries per workgroup of 512 (12 288 per 1 024) the pass takes 2.12-2.35 ms against 2.04 without: copying the
-    // table (30 KB per 512 points) costs the prologue what the LDS gathers save the walk, and above 5 000 entries a CU holds
-    // three workgroups instead of four (profiles/r04_chain_pass_breakdown.json)
-    static const uint32_t lds_cap = [] {
-      const char* e = pcv_experiment("PCV_CHAIN_LDS");
-      return e ? (uint32_t)atoi(e) : 0u;
-    }();
-    const uint32_t lds_nodes = lds_cap & ~3u;
-    static const uint32_t diag = [] {
-      const char* e = pcv_experiment("PCV_CHAIN_DIAG");
-      return e ? (uint32_t)atoi(e) : 0u;
-    }();
-    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&spec_encode4_kernel<true, BLOCK>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
-    (void)ok;
-#ifdef PCV_EXPERIMENTS
-    if (diag) {  // timing only: the cut-down pass runs first and is timed on its own, then the real pass overwrites what it wrote
-      for (uint32_t d : {0u, diag}) {
-        hipEvent_t e0, e1;
-        (void)hipEventCreate(&e0);
-        (void)hipEventCreate(&e1);
-        (void)hipEventRecord(e0, ctx->stream);
-        hipLaunchKernelGGL((spec_encode4_kernel<true, BLOCK>), grid, dim3(BLOCK), (size_t)lds_nodes * 4, ctx->stream, lv, walk, n, x, y, z, routed,
-                           color, color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr,
-                           pool_cap, lds_nodes, tree_info, d);
-        (void)hipEventRecord(e1, ctx->stream);
-        (void)hipEventSynchronize(e1);
-        float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, e0, e1);
-        fprintf(stderr, "PCV_CHAIN_DIAG=%u block=%d lds=%u: %.3f ms\n", d, BLOCK, lds_nodes, ms);
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-        (void)hipMemsetAsync(pool_ctr, 0, kPcvPoolRegions * 4, ctx->stream);
-      }
-    }
-#endif
-    hipLaunchKernelGGL((spec_encode4_kernel<true, BLOCK>), grid, dim3(BLOCK), (size_t)lds_nodes * 4, ctx->stream, lv, walk, n, x, y, z, routed,
-                       color, color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr, pool_cap,
-                       lds_nodes, tree_info, 0u);
-  } else {
-    hipLaunchKernelGGL((spec_encode_kernel<true, BIN, BLOCK>), grid, dim3(BLOCK), 0, ctx->stream, lv, walk, n, x, y, z, routed, color,
-                       color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr, pool_cap);
-  }
-}
-
 void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* walk, uint64_t n, const double* x,
                             const double* y, const double* z, const PcvRouted& routed, const uint8_t* color,
                             uint32_t color_stride, const float* intensity, uint32_t* rank, void* payload,
@@ -1488,64 +1063,30 @@ void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* w
                             const uint32_t* tree_info /* device: [0] = number of T'' nodes (spec_tree_scan_kernel's info block) */) {
   if (n == 0) return;
   PcvProf prof(ctx, PCV_K_SPEC_ENCODE);
-  // PCV_CHAIN_V (experiments): 3 = round 3's kernel (ballot deal, packed digit), 4 = round 4's first form
-  static const bool v4 = [] {
-    const char* e = pcv_experiment("PCV_CHAIN_V");
-    return !e || atoi(e) != 3;
-  }();
-  // tiles of two points per lane (spec_encode_pair_kernel) unless PCV_CHAIN_V=4 (experiments: one point per lane)
-  static const bool pair = [] {
-    const char* e = pcv_experiment("PCV_CHAIN_V");
-    return !e || atoi(e) > 4;
-  }();
-  const uint32_t pool_cap = (uint32_t)pcv_pool_region_entries(n);
-  (void)pool_cap;
-  // PCV_SPEC_BIN (experiments): 0 = input order, 256 / 512 / 1024 = depth binning inside workgroups of that size
-  static const int bin_mode = [] {
-    const char* e = pcv_experiment("PCV_SPEC_BIN");
-    return e ? atoi(e) : 512;
-  }();
-  const bool bin = bin_mode != 0 && depth_grid != nullptr;
 #ifdef PCV_EXPERIMENTS
-  // raw input: the persistent kernel (PCV_SPEC_PERSIST=0, libpcv_hip_exp.so: one workgroup per 512 points as before;
-  // PCV_SPEC_PERSIST=k: k workgroups per CU)
-  static const int persist = [] {
-    const char* e = pcv_experiment("PCV_SPEC_PERSIST");
-    return e ? atoi(e) : 0;
+  // PCV_CHAIN_V = 3 / 4 / 5 (libpcv_hip_exp.so): round 3's kernel, round 4's one-point form, round 4's paired tiles
+  static const int chain_v = [] {
+    const char* e = pcv_experiment("PCV_CHAIN_V");
+    return e ? atoi(e) : 6;
   }();
-  if (bin && persist > 0 && !routed.oct && bin_mode == 512) {
-    constexpr int kTile = 1024;
-    const uint32_t num_tiles = (uint32_t)((n + kTile - 1) / kTile);
-    static const int cus = [] {
-      int dev = 0, c = 0;
-      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) c = 256;
-      return c;
-    }();
-    const float cells = lv.edge[0] > 0.0 ? (float)((double)(1 << kGridBits) / lv.edge[0]) : 0.f;
-    hipLaunchKernelGGL(spec_depth_grid_kernel, dim3((1u << (3 * kGridBits)) / 256), dim3(256), 0, ctx->stream, walk, depth_grid);
-    if (persist >= 100) {  // one tile of 1 024 points per workgroup, no prefetch registers: just the paired deal
-      hipLaunchKernelGGL((spec_encode_persist_kernel<512, false>), dim3(num_tiles), dim3(512), 0, ctx->stream, lv, walk, n, num_tiles, x, y, z,
-                         color, color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr, pool_cap);
-    } else {
-      const uint32_t groups = std::min<uint32_t>(num_tiles, (uint32_t)(cus * persist));
-      hipLaunchKernelGGL((spec_encode_persist_kernel<512, true>), dim3(groups), dim3(512), 0, ctx->stream, lv, walk, n, num_tiles, x, y, z,
-                         color, color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr, pool_cap);
-    }
+  if (chain_v >= 3 && chain_v <= 5) {
+    pcv_launch_spec_encode_old(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, inten_bits, depth_grid, wide,
+                               pool_ctr, tree_info);
     return;
   }
 #endif
-  if (!bin)
-    launch_spec_encode_t<false, 256>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, inten_bits,
-                                     depth_grid, wide, pool_ctr, v4, pair, tree_info);
-  else if (bin_mode == 256)
-    launch_spec_encode_t<true, 256>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, inten_bits,
-                                     depth_grid, wide, pool_ctr, v4, pair, tree_info);
-  else if (bin_mode == 512)
-    launch_spec_encode_t<true, 512>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, inten_bits,
-                                     depth_grid, wide, pool_ctr, v4, pair, tree_info);
+  (void)tree_info;
+  constexpr int kBlock = 512;  // tiles of 1 024 points: one pool region, 26 KB of LDS, four workgroups per CU
+  const dim3 grid((unsigned)((n + 2 * kBlock - 1) / (2 * kBlock)));
+  const float cells = lv.edge[0] > 0.0 ? (float)((double)(1 << kGridBits) / lv.edge[0]) : 0.f;
+  const uint32_t pool_cap = (uint32_t)pcv_pool_region_entries(n);
+  if (depth_grid) hipLaunchKernelGGL(spec_depth_grid_kernel, dim3((1u << (3 * kGridBits)) / 256), dim3(256), 0, ctx->stream, walk, depth_grid);
+  if (!routed.oct)
+    hipLaunchKernelGGL((chain_pass_kernel<true, true, kBlock>), grid, dim3(kBlock), 0, ctx->stream, lv, walk, n, x, y, z, routed, color, color_stride,
+                       intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr, pool_cap);
   else
-    launch_spec_encode_t<true, 1024>(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, inten_bits,
-                                     depth_grid, wide, pool_ctr, v4, pair, tree_info);
+    hipLaunchKernelGGL((chain_pass_kernel<true, false, kBlock>), grid, dim3(kBlock), 0, ctx->stream, lv, walk, n, x, y, z, routed, color, color_stride,
+                       intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr, pool_cap);
 }
 
 size_t pcv_spec_depth_grid_bytes() { return (size_t)1 << (3 * kGridBits); }

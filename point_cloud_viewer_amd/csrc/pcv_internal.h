@@ -44,6 +44,13 @@ struct PcvLevels {
   // straight-line loop per range instead of a switch per level.
   int32_t first_u16, first_u8;
   int32_t first_f32;  // levels [first_f32, first_u16) are Float32-coded ("never" when the table is not monotone)
+  // Float32 codes of level k + 1 straight from the Float32 codes of level k (round 5; pcv_chain_dev.h "codes from codes"):
+  // for the level steps k in [code_begin, code_end) the chain pass computes w = 2 v - bit per coordinate and keeps it as the
+  // level-(k + 1) code wherever code_thr_hi[k] <= hi32(w) < hi32(1.0) for all three coordinates (code_thr_hi[k] = the high
+  // word of the power of two below which a code of level k + 1 is too close to the rounding noise of the f64 chain to be
+  // predicted: the wave then runs the full step). code_begin == code_end: no step admitted.
+  uint32_t code_thr_hi[PCV_MAX_KEY_LEVELS + 2];
+  int32_t code_begin, code_end;
   int32_t nlevels;  // number of digit levels materialised in the keys (<= PCV_MAX_KEY_LEVELS; <= PCV_MAX_LEVELS deep)
   int32_t fast_ok;  // root min and all edges are tame: unguarded exact division is valid for tame points
 };

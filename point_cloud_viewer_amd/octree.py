@@ -461,6 +461,18 @@ def level_table(bbox_min, bbox_max, resolution, cap=64):
     return ml, np.array(edge[:ml + 1]), np.array(enc[:ml + 1], dtype=np.int32)
 
 
+def level_shortcuts(bbox_min, bbox_max, resolution):
+    """(max_level, digit_mode[k], code_threshold[k]): the per-level shortcuts of the single chain pass for this cube
+    (pcv_level_shortcuts; host tables, held against exact arithmetic by tests/test_oracle_kats.py)."""
+    lib = L.load_library()
+    bmin = (C.c_double * 3)(*[float(v) for v in bbox_min])
+    bmax = (C.c_double * 3)(*[float(v) for v in bbox_max])
+    mode = (C.c_uint32 * (L.MAX_KEY_LEVELS + 2))()
+    thr = (C.c_double * (L.MAX_KEY_LEVELS + 2))()
+    ml = lib.pcv_level_shortcuts(bmin, bmax, float(resolution), mode, thr)
+    return ml, np.array(mode[:], dtype=np.uint32), np.array(thr[:])
+
+
 class PendingBuild:
     """A tree between pcv_build_begin and pcv_build_finish."""
 

@@ -203,3 +203,75 @@ def test_octant_digit_from_float32_codes_at_the_admitted_ratio():
         p = float(Fraction(mn) + Fraction(0.5) * Fraction(e))
         tie_outcomes.add(p > centre)
     assert tie_outcomes == {False, True} or tie_outcomes == {False}, tie_outcomes  # the tie is decided by rounding, not by the code
+
+
+def test_float32_codes_from_codes_at_the_admitted_threshold():
+    """csrc/pcv_encode.hip CP_CODE_LOOP / pcv_make_levels (round 5): where the table admits the step, the Float32 code of
+    level k + 1 — (float)clamp((p_k - min_{k+1}) / edge_{k+1}, 0, 1) with p_k = fma(v, edge_k, min_k) the decoded level-k
+    position (codec.rs:115-121, 131-135; node.rs:157-172 for the cube) — equals w = 2 v - bit for every level-k code v whose
+    w is at least the level's threshold and below 1 (bit = v > 1/2). The thresholds are the LIBRARY's (pcv_level_shortcuts),
+    the chain is replayed in exact rational arithmetic (Fraction -> float is correctly rounded: the FMA, the subtraction
+    and the IEEE division), for cubes at the magnitudes the table was built for: the bench cloud's and ECEF's, with the
+    cube min at the far end of the root cube (largest rounding errors), w at and next to the threshold, next to 1 and random.
+    Below the threshold the prediction does fail (the reason the kernel runs the full step there): the test finds such a case."""
+    from fractions import Fraction as F
+    import math
+    import random
+    import point_cloud_viewer_amd as pcv
+    rnd = random.Random(5)
+    f32 = np.float32
+    failures_below = 0
+    admitted_steps = 0
+    checked = 0
+    for bmin, extent, res in (((3.0, -5.0, 1.0), 1093.7, 0.001),            # the bench cloud's magnitudes
+                              ((-2.7e6, -4.3e6, 3.8e6), 1100.0, 0.001),   # ECEF
+                              ((4.1e6, 4.8e6, 5.0e5), 8100.0, 0.001),     # ECEF, bigger cube
+                              ((-50.0, -50.0, -50.0), 100.0, 1e-4)):
+        bmax = tuple(b + extent for b in bmin)
+        ml, edge, enc = pcv.level_table(bmin, bmax, res, cap=40)
+        _, mode, thr = pcv.level_shortcuts(bmin, bmax, res)
+        for k in range(1, min(ml, 21)):
+            if thr[k] == 0.0:
+                continue
+            admitted_steps += 1
+            assert enc[k] == 3 and enc[k + 1] == 3 and mode[k] == 2, (k, enc[k], enc[k + 1], mode[k])  # PCV_ENC_FLOAT32
+            t = float(thr[k])
+            assert math.frexp(t)[0] == 0.5 and t <= 2.0 ** -8  # a power of two
+            e, e2 = float(edge[k]), float(edge[k + 1])
+            assert e2 * 2.0 == e
+            for trial in range(300):
+                # a level-k cube min somewhere in the root cube, biased to the corner with the largest magnitudes, arbitrary low bits
+                a = rnd.randrange(3)
+                lo, hi = bmin[a], bmin[a] + extent - e
+                m = (hi if abs(hi) > abs(lo) else lo) if trial % 2 == 0 else rnd.uniform(lo, hi)
+                m = float(np.nextafter(m, rnd.choice((-math.inf, math.inf)))) if trial % 3 == 0 else m
+                up = lambda f: float(np.nextafter(f32(f), f32(2.0)))
+                half_t = 0.5 + t / 2.0
+                hv = float(f32(half_t)) if float(f32(half_t)) >= half_t else up(half_t)  # smallest float32 v > 1/2 with 2 v - 1 >= t
+                vs = [t / 2.0, up(t / 2.0), float(f32(rnd.uniform(t / 2.0, 0.5))), float(f32(rnd.uniform(t / 2.0, 2.0 * t))),
+                      float(np.nextafter(f32(0.5), f32(0.0))),  # w next to 1 from below (bit 0)
+                      hv, up(hv), float(f32(rnd.uniform(hv, 1.0))), float(np.nextafter(f32(1.0), f32(0.0))), float(f32(rnd.random()))]
+                for v in vs:
+                    assert float(f32(v)) == v
+                    bit = 1 if v > 0.5 else 0
+                    w = 2.0 * v - bit  # exact
+                    if not (t <= w < 1.0):
+                        continue  # the kernel runs the full step for this wave
+                    assert float(f32(w)) == w
+                    p = float(F(m) + F(v) * F(e))            # decode: one rounding
+                    m2 = float(F(m) + bit * F(e2))           # pcv_step_min: one rounding
+                    x = float(F(p) - F(m2))
+                    q = float(F(x) / F(e2)) if x != 0 else 0.0
+                    got = float(f32(min(max(q, 0.0), 1.0)))
+                    assert got == w, (k, m, e, v, w, q, got)
+                    checked += 1
+                # below the threshold the chain's rounding noise does show: count the misses (never asserted to be zero)
+                w = float(f32(rnd.uniform(0.0, t * 2.0 ** -10)))
+                if w > 0.0:
+                    v = w / 2.0
+                    p = float(F(m) + F(v) * F(e))
+                    x = float(F(p) - F(m))
+                    q = float(F(x) / F(e2)) if x != 0 else 0.0
+                    failures_below += float(f32(min(max(q, 0.0), 1.0))) != w
+    assert admitted_steps >= 8 and checked > 20000, (admitted_steps, checked)
+    assert failures_below > 0  # the threshold is not vacuous
