@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 F64_VALU_PEAK_GINST = 39300  # vector FP64 78.6 TFLOP/s = 39.3 T FMA-instructions/s (SURVEY 8d "Roofline bound")
-ROUND = "r04"
+ROUND = "r05"
 
 # algorithmic HBM bytes per point and launch (DESIGN.md "Kernels"); kernels bound by f64 VALU issue are marked
 ALGO_BYTES = {
@@ -236,14 +236,15 @@ def compare_digests(want, got):
             "ok": not missing and not extra and not bad}
 
 
-def oracle_digests(resolution, bmin, bmax, x, y, z, rgb, threads=None):
+def oracle_digests(resolution, bmin, bmax, x, y, z, rgb, threads=None, intensity=None):
     """Closed-form CPU oracle on the same cloud (host copies of the device tensors): digest table + stats."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     hx, hy, hz, hrgb = x.cpu().numpy(), y.cpu().numpy(), z.cpu().numpy(), rgb.cpu().numpy()
+    hint = None if intensity is None else intensity.cpu().numpy()
     cores = threads or O.num_procs()
     t0 = time.perf_counter()
-    want, stats = O.build_closed_digests(resolution, bmin, bmax, hx, hy, hz, hrgb, threads=cores)
+    want, stats = O.build_closed_digests(resolution, bmin, bmax, hx, hy, hz, hrgb, hint, threads=cores)
     stats = dict(stats, oracle_s=round(time.perf_counter() - t0, 2), oracle_threads=cores)
     import numpy as np
     n = int(x.numel())
@@ -252,37 +253,56 @@ def oracle_digests(resolution, bmin, bmax, x, y, z, rgb, threads=None):
     return want, stats
 
 
-def verify_build(ctx, resolution, x, y, z, rgb, threads=None):
+def verify_build(ctx, resolution, x, y, z, rgb, threads=None, intensity=None, bbox=None):
     """Byte-for-byte parity of one more build against the closed-form CPU oracle on the SAME cloud: node ids, point
     counts, encodings and a digest of every node file (reference bar: point_cloud_test/tests/main.rs:10-23 sum of
     num_points == N, src/octree/generation.rs:289-403 for the bytes)."""
     n = int(x.numel())
     t0 = time.perf_counter()
-    tree = ctx.build(resolution, None, x, y, z, rgb)
+    tree = ctx.build(resolution, bbox, x, y, z, rgb, intensity)
     meta = tree.meta()
     got = tree_digests(tree)
     info = tree.build_info()
     tree.free()
     t1 = time.perf_counter()
-    want, stats = oracle_digests(resolution, meta["bbox_min"], meta["bbox_max"], x, y, z, rgb, threads)
+    want, stats = oracle_digests(resolution, meta["bbox_min"], meta["bbox_max"], x, y, z, rgb, threads, intensity)
     out = {"oracle": "closed-form CPU restatement of the reference (oracle/pcv_oracle_build.cpp), not the Rust binary", "points": n}
     out.update(compare_digests(want, got))
     out.update({"sum_num_points_gpu": int(sum(v[0] for v in got.values())), "sum_num_points_oracle": stats["total_points"],
                 "bbox_equals_numpy_minmax": stats["bbox_equals_numpy_minmax"],
                 "max_abs_position_error_m": stats["max_abs_position_error"],
-                "compared": "num_points, encoding, blake2b-128 of .xyz and .rgb of every node",
-                "tree_digest": digest_of_digests(got),
+                "compared": "num_points, encoding, blake2b-128 of .xyz and .rgb" + (" and .intensity" if intensity is not None else "") +
+                            " of every node",
+                "tree_digest": digest_of_digests(got), "record_bytes": info.get("record_bytes"),
                 "key_levels": info.get("key_levels"), "attempts": info.get("attempts"),
                 "gpu_build_plus_d2h_s": round(t1 - t0, 2), "oracle_s": stats["oracle_s"], "oracle_threads": stats["oracle_threads"]})
-    out["ok"] = bool(out["ok"] and stats["bbox_equals_numpy_minmax"])
+    out["ok"] = bool(out["ok"] and (stats["bbox_equals_numpy_minmax"] or bbox is not None))
     return out
 
 
-def config1(args):
-    """BASELINE config 1 (plumbing): 1 M uniform points in a local frame placed in ECEF, CPU oracle only."""
+def box_info():
+    """Clocks / power / temperature of GPU 0 as rocm-smi reports them (the same binary runs 5-7 % apart on
+    different boxes — the record downsweeps 1.01 vs 1.25 ms — and nothing in a bench line said which kind of box it was)."""
+    import subprocess
+    out = {}
+    try:
+        r = subprocess.run(["rocm-smi", "-d", "0", "--showclocks", "--showpower", "--showtemp", "--showperflevel", "--showmaxpower",
+                            "--showmemuse", "--json"], capture_output=True, text=True, timeout=20)
+        d = json.loads(r.stdout[r.stdout.index("{"):]) if "{" in r.stdout else {}
+        card = next(iter(d.values())) if d else {}
+        for k, v in card.items():
+            kl = k.lower()
+            if any(w in kl for w in ("sclk", "mclk", "fclk", "socclk", "power", "temperature", "performance level", "memory")):
+                out[k] = v
+    except Exception as e:  # noqa: BLE001 - the line of record must not depend on a monitoring tool
+        out["error"] = f"{type(e).__name__}: {e}"
+    return out
+
+
+def config1_cloud():
+    """The BASELINE config-1 cloud: 1 M uniform points of a 200 x 200 x 20 m local frame placed in ECEF, rgb = point
+    index, LOOSE bounding box of the transformed box corners (synthetic_data.rs:38-50)."""
     import numpy as np
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_lib as O
     n = 1_000_000
     rng = np.random.Generator(np.random.PCG64(80293751232))
     local = np.stack([rng.uniform(-100.0, 100.0, n), rng.uniform(-100.0, 100.0, n), rng.uniform(-10.0, 10.0, n)], axis=1)
@@ -302,6 +322,152 @@ def config1(args):
     idx = np.arange(n, dtype=np.int64)
     rgb = np.stack([(idx >> 16) & 255, (idx >> 8) & 255, idx & 255], axis=1).astype(np.uint8)
     x, y, z = (np.ascontiguousarray(p[:, k]) for k in range(3))
+    return n, x, y, z, rgb, bmin, bmax
+
+
+def config1_leg(pcv, ctx):
+    """Config 1 inside the default line: the CPU restatement's own timing (config 1 is the CPU plumbing line by definition)
+    and — what the CPU-only line cannot say — byte parity of the GPU build of the same 1 M points and loose box."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    n, x, y, z, rgb, bmin, bmax = config1_cloud()
+    cores = O.num_procs()
+    t0 = time.perf_counter()
+    want = O.build_closed(0.001, bmin, bmax, x, y, z, rgb, threads=cores)
+    oracle_s = time.perf_counter() - t0
+    out = {"workload": "BASELINE config 1: 1 M uniform points (200 x 200 x 20 m local frame placed in ECEF), rgb = point index, loose "
+                       "bbox, 1 mm", "points": n, "nodes": len(want.nodes), "oracle_closed_form_s": round(oracle_s, 2)}
+    for single_chain in (False, True):  # the exact pipeline (the default at this size) and the single-chain build, forced
+        t0 = time.perf_counter()
+        tree = ctx.build(0.001, pcv.Aabb(bmin, bmax), x, y, z, rgb, single_chain=single_chain)
+        ms = (time.perf_counter() - t0) * 1e3
+        got = tree.to_dict()
+        info = tree.build_info()
+        tree.free()
+        bad = [k for k in set(want.nodes) | set(got) if k not in got or k not in want.nodes or
+               any(got[k][f] != want.nodes[k][f] for f in ("num_points", "encoding", "xyz", "rgb"))]
+        out["single_chain" if single_chain else "exact_pipeline"] = {
+            "mismatching_nodes": len(bad), "ok": not bad, "host_arrays_to_host_blobs_ms": round(ms, 2),
+            "pipeline_ran": "single-chain" if info.get("single_chain") else "exact two-chain"}
+    out["ok"] = bool(out["exact_pipeline"]["ok"] and out["single_chain"]["ok"])
+    return out
+
+
+def intensity_leg(args, torch, pcv, ctx, dev, points, steps=5):
+    """The reference BINARY's payload (src/bin/build_octree.rs:47-52: attributes ["color", "intensity"]): the config-2
+    distribution with an f32 intensity plane (raw.rs:374-392: one more node file, 4 bytes per point). Timed builds of the
+    colour-only and the colour + intensity cloud back to back, byte parity of every node incl. `.intensity`."""
+    x, y, z, rgb = make_cloud(torch, points, seed=1, device=dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(99)
+    inten = torch.rand(points, generator=g, device=dev, dtype=torch.float32) * 4096.0
+    torch.cuda.synchronize()
+    res = {}
+    for name, plane in (("color_only", None), ("color_and_intensity", inten)):
+        for _ in range(2):
+            ctx.build(args.resolution, None, x, y, z, rgb, plane).free()
+        ctx.set_profiling("major")
+        ctx.reset_kernel_stats()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            t = ctx.build(args.resolution, None, x, y, z, rgb, plane)
+            info = t.build_info()
+            t.free()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        ctx.set_profiling(False)
+        ks = ctx.kernel_stats()
+        res[name] = {"ms_per_step": round(ms, 3), "Mpoints_per_s": round(points / (ms * 1e-3) / 1e6, 1), "record_bytes": info.get("record_bytes"),
+                     "kernel_ms_per_step": {k: round(v[1] / steps, 3) for k, v in ks.items() if v[0] > 0}}
+    parity = verify_build(ctx, args.resolution, x, y, z, rgb, intensity=inten)
+    del x, y, z, rgb, inten
+    return {"workload": f"{points / 1e6:g} M Gaussian-cluster points (config-2 distribution) + f32 intensity plane, 1 mm", "points": points,
+            "steps": steps, "color_only": res["color_only"], "color_and_intensity": res["color_and_intensity"],
+            "intensity_cost": round(res["color_and_intensity"]["ms_per_step"] / res["color_only"]["ms_per_step"] - 1.0, 4),
+            "parity": parity}
+
+
+def sharded_leg(args, torch, pcv, ctx, dev, x, y, z, rgb, want_digest, steps=5, virtual=8):
+    """The multi-GPU code path inside the default line on the config-2 cloud whose single-GPU octree the
+    oracle has just verified: (a) ShardedOctreeBuilder over RCCL at world size 1 — routing, the (empty) exchange, the routed
+    build, the top-node merge — timed; (b) `virtual` thread-ranks on this one GPU, contiguous slices, octants AND buckets:
+    the merged octree must have the verified digest and no node may be built twice. One device: none of this is a scaling
+    number — the path stays UNMEASURED ON REAL RANKS."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from thread_dist import run_ranks
+    from point_cloud_viewer_amd import distributed as pdist
+    import torch.distributed as dist
+    n = int(x.numel())
+    out = {"note": "one GPU: world-1 RCCL and thread-ranks sharing the device — code-path timing and parity, NOT scaling; unmeasured on real ranks",
+           "points": n, "want_tree_digest": want_digest}
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        w1 = {}
+        for mode in ("octants", "buckets"):
+            builder = pdist.ShardedOctreeBuilder(ctx, dist, dev, shard_mode=mode)
+            bbox = builder.global_bbox(x, y, z)
+            for _ in range(2):
+                builder.build(args.resolution, bbox, x, y, z, rgb).free()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                r = builder.build(args.resolution, bbox, x, y, z, rgb)
+                ex = r.exchange_info()
+                r.free()
+            dist.barrier()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / steps * 1e3
+            r = builder.build(args.resolution, bbox, x, y, z, rgb)
+            dig = digest_of_digests(sharded_digests(r))
+            r.free()
+            w1[mode] = {"ms_per_step": round(ms, 3), "Mpoints_per_s": round(n / (ms * 1e-3) / 1e6, 1), "stage_ms": ex["ms"],
+                        "rows_sent": ex["rows_sent"], "rows_received": ex["rows_received"], "tree_digest": dig,
+                        "digest_equal": dig == want_digest}
+        out["world1"] = dict(w1["octants"], rccl_ranks=1, shard_mode="octants", buckets=w1["buckets"])
+    finally:
+        dist.destroy_process_group()
+    vout = {}
+    for mode in ("octants", "buckets"):
+        def rank_main(rank, vdist, mode=mode):
+            torch.cuda.set_device(dev)
+            rctx = pcv.Context(dev.index or 0)
+            lo, hi = rank * n // virtual, (rank + 1) * n // virtual
+            sx, sy, sz, srgb = x[lo:hi], y[lo:hi], z[lo:hi], rgb[lo:hi]
+            builder = pdist.ShardedOctreeBuilder(rctx, vdist, dev, shard_mode=mode)
+            bbox = builder.global_bbox(sx, sy, sz)
+            res = builder.build(args.resolution, bbox, sx, sy, sz, srgb)
+            torch.cuda.synchronize()
+            dig = sharded_digests(res)
+            ex = res.exchange_info()
+            res.free()
+            rctx.close()
+            return dig, ex
+        results = run_ranks(virtual, rank_main)
+        merged, dup = {}, 0
+        for dig, _ in results:
+            for k, v in dig.items():
+                dup += k in merged
+                merged[k] = v
+        d = digest_of_digests(merged)
+        vout[mode] = {"tree_digest": d, "digest_equal": d == want_digest, "nodes": len(merged), "nodes_built_twice": dup,
+                      "points_owned_per_rank": results[0][1]["points_owned_per_rank"],
+                      "imbalance_max_over_mean": results[0][1]["imbalance_max_over_mean"],
+                      "rows_sent_per_rank": [r[1]["rows_sent"] for r in results]}
+    out[f"virtual{virtual}"] = vout
+    out["ok"] = bool(out["world1"]["digest_equal"] and out["world1"]["buckets"]["digest_equal"] and
+                     all(v["digest_equal"] and v["nodes_built_twice"] == 0 for v in vout.values()))
+    return out
+
+
+def config1(args):
+    """BASELINE config 1 (plumbing): 1 M uniform points in a local frame placed in ECEF, CPU oracle only."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    n, x, y, z, rgb, bmin, bmax = config1_cloud()
     cores = O.num_procs()
     import shutil
     import tempfile
@@ -680,6 +846,8 @@ def main():
     ap.add_argument("--config1", action="store_true", help="BASELINE config 1 (CPU plumbing line)")
     ap.add_argument("--no-legs", action="store_true",
                     help="default N=1 line only: skip the config-4 (`query`) and config-5 (`config5`) legs after the timed region")
+    ap.add_argument("--intensity-points", type=int, default=20_000_000,
+                    help="points of the colour + intensity leg of the default line (the reference binary's payload); 100000000 for the full-size record")
     ap.add_argument("--config5-points", type=int, default=500_000_000)
     ap.add_argument("--config5-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -786,6 +954,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    box = {"idle_before_warmup": box_info()} if rank == 0 else None
     if args.kernel_events != "none":
         ctx.set_profiling("major" if args.kernel_events == "major" else True)  # during warmup: the event pool exists before the timed region
     import gc
@@ -804,6 +973,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     gc.enable()
+    if rank == 0:
+        box["right_after_timed_region"] = box_info()
     per_step_ms = [round((b - a) * 1e3, 3) for a, b in zip(step_marks[:-1], step_marks[1:])]
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -865,7 +1036,7 @@ def main():
             # launch where one kernel runs with several key widths: the u32 upsweep, not the sample's u64 one)
             alias = {"promote_settle_kernel": "promote_settle_leaf_kernel", "promote_climb_kernel": "promote_climb_leaf_kernel",
                      "downsweep_rec_kernel": "downsweep_rec12_kernel", "upsweep_kernel<u32>": "upsweep_kernel",
-                     "spec_encode_kernel": "spec_encode_pair_kernel"}
+                     "spec_encode_kernel": "chain_pass_kernel"}
             return per.get(name, per.get(alias.get(name, name))), os.path.relpath(path, ROOT)
 
         dom = max(timed, key=lambda k: timed[k][1])  # dominant kernel by accumulated time inside the timed region
@@ -1103,8 +1274,12 @@ def main():
 
     # ---- the other single-GPU BASELINE configs, after the timed region of the default line: config 4 (frustum path on the
     # octree of this cloud) and config 5 (500 M ECEF points), each with its own timing and oracle parity ----
-    query, config5 = None, None
+    query, config5, sharded_out, config1_out, intensity_out = None, None, None, None, None
     if plain and rank == 0 and not args.no_parity and not args.no_legs:
+        try:  # the multi-GPU code path on this cloud: RCCL at world size 1 + 8 thread-ranks, digests against the verified one
+            sharded_out = sharded_leg(args, torch, pcv, ctx, dev, x, y, z, rgb, tree_digest)
+        except Exception as e:  # noqa: BLE001 - the leg reports its failure, the line of record still prints
+            sharded_out = {"error": f"{type(e).__name__}: {e}", "ok": False}
         try:
             qt = ctx.build(args.resolution, None, x, y, z, rgb)
             query = query_leg(args, ctx, qt)
@@ -1117,6 +1292,14 @@ def main():
             config5 = config5_leg(args, torch, pcv, ctx, dev, args.config5_points)
         except Exception as e:  # noqa: BLE001
             config5 = {"error": f"{type(e).__name__}: {e}", "parity": {"ok": False, "mismatching_nodes": None}}
+        try:
+            intensity_out = intensity_leg(args, torch, pcv, ctx, dev, args.intensity_points)
+        except Exception as e:  # noqa: BLE001
+            intensity_out = {"error": f"{type(e).__name__}: {e}", "parity": {"ok": False}}
+        try:
+            config1_out = config1_leg(pcv, ctx)
+        except Exception as e:  # noqa: BLE001
+            config1_out = {"error": f"{type(e).__name__}: {e}", "ok": False}
 
     if rank == 0:
         if config3:
@@ -1137,11 +1320,12 @@ def main():
                        "scope": "device-resident inputs -> bounding box (K1" + (" outside the step" if args.fixed_bbox else "") +
                                 ") + node table + node-contiguous .xyz/.rgb bytes in HBM; no D2H of the blobs, no file writes",
                        "points_per_gpu": n, "points_total": total, "resolution": args.resolution, "nodes": info.get("nodes"),
-                       "kernel_events_in_timed_region": args.kernel_events,
+                       "kernel_events_in_timed_region": args.kernel_events, "box": box,
                        "parallelism": "1 GPU" if world == 1 else
                        f"{world} GPUs, one process each, shard mode {args.shard_mode}: one all-to-all(v) over RCCL"},
             "roofline": roofline, "encode_sort": encode_sort, "cpu_baseline": cpu, "parity": parity, "tree_digest": tree_digest,
-            "end_to_end": e2e, "query": query, "config5": config5,
+            "end_to_end": e2e, "query": query, "config5": config5, "sharded": sharded_out, "intensity": intensity_out,
+            "config1": config1_out,
             "build_info": info.get("build"), "exchange": info.get("exchange"),
             "exchange_per_rank": None if per_rank is None else [
                 None if e is None else {"rank": r, "rows_sent": e["rows_sent"], "rows_received": e["rows_received"],

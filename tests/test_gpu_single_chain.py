@@ -254,10 +254,12 @@ print("alt-path ok")
                                               # the second pass counting its keys itself (equal chunks instead of pieces of
                                               # whole first-pass runs)
                                               ({"PCV_SORT_ROWS2": "0"}, 12),
-                                              # the chain pass with one point per lane (round 4's first form; what workgroups
-                                              # of 1 024 lanes still take), in tiles of 2 x 256 points, and round 3's kernel
-                                              ({"PCV_CHAIN_V": "4"}, 12), ({"PCV_SPEC_BIN": "256"}, 12), ({"PCV_SPEC_BIN": "1024"}, 12),
-                                              ({"PCV_CHAIN_V": "3"}, 12),
+                                              # the superseded chain kernels (pcv_encode_exp.inc): round 4's paired tiles (2 x 512
+                                              # and 2 x 256 points), its one-point form (workgroups of 512 and 1 024 lanes), round 3's
+                                              # kernel; and the shipped kernel with every Float32-coded level step taken in full
+                                              ({"PCV_CHAIN_V": "5"}, 12), ({"PCV_CHAIN_V": "5", "PCV_SPEC_BIN": "256"}, 12),
+                                              ({"PCV_CHAIN_V": "4"}, 12), ({"PCV_CHAIN_V": "4", "PCV_SPEC_BIN": "1024"}, 12),
+                                              ({"PCV_CHAIN_V": "3"}, 12), ({"PCV_CODE_STEPS": "0"}, 12),
                                               # the sample tree split one level per launch pair (what u32 keys and levels
                                               # beyond the first key word still take)
                                               ({"PCV_SPLIT2": "0"}, 12)])

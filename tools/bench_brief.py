@@ -25,3 +25,20 @@ if c:
     cp = c.get("parity") or {}
     print("config5:", c.get("error") or (c.get("value"), c.get("ms_per_step"), "parity ok=%s mismatching=%s nodes=%s" % (
         cp.get("ok"), cp.get("mismatching_nodes"), cp.get("nodes")), c.get("kernel_ms_per_step"), c.get("build_info")))
+sh = d.get("sharded")
+if sh:
+    w1 = sh.get("world1") or {}
+    print("sharded:", sh.get("error") or ("ok=%s" % sh.get("ok"), "world1", w1.get("ms_per_step"), w1.get("stage_ms"), "digest_equal", w1.get("digest_equal"),
+                                          "buckets", (w1.get("buckets") or {}).get("ms_per_step"),
+                                          {k: (v.get("digest_equal"), v.get("nodes_built_twice"), v.get("imbalance_max_over_mean")) for k, v in (sh.get("virtual8") or {}).items()}))
+it = d.get("intensity")
+if it:
+    ip = it.get("parity") or {}
+    print("intensity:", it.get("error") or (it.get("points"), "colour", (it.get("color_only") or {}).get("ms_per_step"), "+intensity",
+                                            (it.get("color_and_intensity") or {}).get("ms_per_step"), "cost", it.get("intensity_cost"),
+                                            "parity ok=%s mismatching=%s" % (ip.get("ok"), ip.get("mismatching_nodes")),
+                                            (it.get("color_and_intensity") or {}).get("kernel_ms_per_step")))
+c1 = d.get("config1")
+if c1:
+    print("config1:", c1.get("error") or (c1.get("ok"), c1.get("nodes"), c1.get("exact_pipeline"), c1.get("single_chain")))
+print(" box:", (d.get("config") or {}).get("box"))

@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round-4 GPU-box recipe, ONE gpurun call: stages picked by name, in the order given.
-#   usage: gpurun -- 'bash tools/r04_run.sh TAG stage [stage ...]'
+# Round-5 GPU-box recipe, ONE gpurun call: stages picked by name, in the order given.
+#   usage: gpurun -- 'bash tools/r05_run.sh TAG stage [stage ...]'
 #   tests     pytest -m gpu                               probes    tools/f64_rate.sh + scatter_probe runs
 #   bench     the default line (config 2 + legs 4 / 5)     quick     the default line without the legs (--no-legs)
 #   ab        timing-only A/B runs, RUNS="name[:ENV=VAL|libtag] ..." (tools/ab_quick.sh)
@@ -8,7 +8,7 @@
 #   qprofile  rocprofv3 passes of bench.py --query (tools/profile_query.sh)
 #   smoke     __graft_entry__.smoke()
 #   pmc       SQ / TA / TCP counter passes over the build (tools/pmc_pass.sh) -> gpurun_out/TAG_pmc.json
-TAG=${1:-r04}; shift
+TAG=${1:-r05}; shift
 mkdir -p gpurun_out
 for stage in "$@"; do
   t0=$(date +%s)
