@@ -529,8 +529,20 @@ def query_leg(args, ctx, tree):
         rel, sizes = tree.cull_nodes(shapes, with_sizes=True)
     wall_a = (time.perf_counter() - t0) / qsteps
     ks = ctx.kernel_stats()["cull_nodes_kernel"]
-    cull_ms = ks[1] / ks[0]
+    dense_ms = ks[1] / ks[0]
     pairs = args.frusta * M
+    # the same relations as per-frustum LISTS of the nodes that are not Out (pcv_cull_nodes_sparse): sizes only where the
+    # reference computes them, 13 bytes per listed node to the host instead of 9 bytes per pair
+    sp_counts = tree.cull_nodes_sparse(shapes, 0, with_sizes=False)[0]
+    sp_cap = max(1, int(sp_counts.max()))
+    tree.cull_nodes_sparse(shapes, sp_cap)
+    ctx.reset_kernel_stats()
+    t0 = time.perf_counter()
+    for _ in range(qsteps):
+        sp_counts, sp_idx, sp_rel, sp_sizes = tree.cull_nodes_sparse(shapes, sp_cap)
+    wall_s = (time.perf_counter() - t0) / qsteps
+    ks = ctx.kernel_stats()["cull_nodes_sparse_kernel"]
+    cull_ms = ks[1] / ks[0]
 
     ctx.reset_kernel_stats()
     vis, status = tree.visible_nodes(shapes)
@@ -565,12 +577,16 @@ def query_leg(args, ctx, tree):
     names = tree.node_names()
     nodes = {names[i]: dict(id=(tree.node(i).id_high, tree.node(i).id_low), num_points=tree.node(i).num_points)
              for i in range(M)}
-    rel_bad = size_bad = vis_bad = 0
+    rel_bad = size_bad = vis_bad = sparse_bad = 0
     t0 = time.perf_counter()
     for f in range(V):
         orel, osz = O.cull_cubes(O.SHAPE_FRUSTUM, mats[f], cubes, with_sizes=True)
         rel_bad += int((orel != rel[f]).sum())
         size_bad += int((~((osz == sizes[f]) | (np.isnan(osz) & np.isnan(sizes[f])))).sum())
+        keep = np.nonzero(orel != 2)[0]
+        k = int(sp_counts[f])
+        sparse_bad += int(not (k == keep.size and np.array_equal(sp_idx[f, :k], keep) and np.array_equal(sp_rel[f, :k], orel[keep]) and
+                               np.array_equal(sp_sizes[f, :k], osz[keep], equal_nan=True)))
     cpu_a = time.perf_counter() - t0
     t0 = time.perf_counter()
     for f in range(V):
@@ -611,7 +627,11 @@ def query_leg(args, ctx, tree):
             "config": {"workload": f"BASELINE config 4: octree of {npoints / 1e6:g} M Gaussian-cluster points "
                                    f"({M} nodes), {args.frusta} random camera frusta (Perspective3 aspect 1, fovy 1.2, "
                                    "near 0.1, far 100), batched transform + cull on 1 GPU", "nodes": M, "frusta": args.frusta},
-            "cull_nodes": {"kernel_ms": round(cull_ms, 3), "wall_ms_incl_D2H": round(wall_a * 1e3, 1), "pairs": pairs,
+            "cull_nodes": {"kernel_ms": round(cull_ms, 3), "wall_ms_incl_D2H": round(wall_s * 1e3, 1), "pairs": pairs,
+                           "api": "pcv_cull_nodes_sparse: per frustum the nodes that are not Out (node order) with relation + size on screen",
+                           "listed_nodes": int(sp_counts.sum()), "capacity_per_frustum": sp_cap,
+                           "dense_matrix": {"api": "pcv_cull_nodes: relation + size on screen of EVERY pair", "kernel_ms": round(dense_ms, 3),
+                                            "wall_ms_incl_D2H": round(wall_a * 1e3, 1)},
                            "relation_histogram": np.bincount(rel.ravel(), minlength=3).tolist()},
             "visible_nodes": {"kernel_ms": round(vis_ms, 3), "frusta_per_s": round(args.frusta / (vis_ms * 1e-3), 1),
                               "mean_visible": float(nvis.mean()), "max_visible": int(nvis.max()),
@@ -626,11 +646,11 @@ def query_leg(args, ctx, tree):
                                  "point out; avg_launch_ms = query_chunks_kernel (descriptors) + query_flags_kernel, HIP events"},
             "parity": {"oracle": "CPU restatement (oracle/pcv_oracle_query.cpp), not the Rust binary", "frusta_checked": V,
                        "pairs_checked": V * M, "relation_mismatches": rel_bad, "size_on_screen_mismatches": size_bad,
-                       "visible_list_mismatches": vis_bad,
+                       "sparse_list_mismatches": sparse_bad, "visible_list_mismatches": vis_bad,
                        "query_points_frusta_checked": min(args.cull_frusta, args.verify_cull_frusta),
                        "query_points_points_checked": pts_checked, "query_points_count_mismatches": cnt_bad,
                        "query_points_content_mismatches": pts_bad, "query_points_check_s": round(cpu_c, 1),
-                       "ok": rel_bad == 0 and size_bad == 0 and vis_bad == 0 and cnt_bad == 0 and pts_bad == 0},
+                       "ok": rel_bad == 0 and size_bad == 0 and sparse_bad == 0 and vis_bad == 0 and cnt_bad == 0 and pts_bad == 0},
             "cpu_baseline": None if V == 0 else {
                 "value": round(V * M / cpu_a / 1e6, 3), "unit": "Mpairs/s", "cores": 1, "kind": "port",
                 "sample": f"first {V} frusta x {M} nodes, SAT relation + size on screen, {cpu_a:.1f} s; "
@@ -693,10 +713,40 @@ def config5_leg(args, torch, pcv, ctx, dev, points):
     t = ctx.build(args.resolution, None, x, y, z, rgb, stage_times=True)  # (one more build, outside the timed region, for stage_ms)
     info["stages"] = t.stage_ms()
     t.free()
+    # K8 (query_flags_kernel) on ONE launch over every point of this tree: > 3 GB of encoded positions in, one flag byte per point
+    # out (the config-4 figure is taken on 70 us launches where ramp-up dominates)
+    k8 = None
+    try:
+        import numpy as np
+        t = ctx.build(args.resolution, None, x, y, z, rgb)
+        meta = t.meta()
+        lo, hi = np.asarray(meta["bbox_min"]), np.asarray(meta["bbox_max"])
+        big = ctx.shapes([("aabb", lo - 1.0, hi - (hi - lo) * 0.25)])  # every node visited, about half of the points kept
+        bpc = {1: 1, 2: 2, 3: 4, 4: 8}
+        tested = enc_bytes = 0
+        for i in range(t.num_nodes):
+            nd = t.node(i)
+            tested += nd.num_points
+            enc_bytes += nd.num_points * 3 * bpc[int(nd.encoding)]
+        ctx.set_profiling(True)
+        t.query_points(big, 0, capacity=1)  # warm: uploads nothing (device-resident blobs), sizes the scratch
+        ctx.reset_kernel_stats()
+        r = t.query_points(big, 0, capacity=1)
+        st = ctx.kernel_stats()
+        ctx.set_profiling(False)
+        big_ms = st["cull_points_kernel"][1]
+        gbs = (enc_bytes + tested) / (big_ms * 1e-3) / 1e9
+        k8 = {"bound": "hbm", "kernel": "query_flags_kernel", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+              "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": int(enc_bytes + tested), "avg_launch_ms": round(big_ms, 4),
+              "points_tested": int(tested), "kept": r["count"], "launches": st["cull_points_kernel"][0],
+              "note": "pcv_query_points with one AABB that visits every node of the 500 M-point tree: query_chunks_kernel + query_flags_kernel"}
+        t.free()
+    except Exception as e:  # noqa: BLE001
+        k8 = {"error": f"{type(e).__name__}: {e}"}
     parity = verify_build(ctx, args.resolution, x, y, z, rgb)
     del x, y, z, rgb
     ms = elapsed / steps * 1e3
-    return {"metric": "octree-build Mpoints/sec", "value": round(points / (ms * 1e-3) / 1e6, 2), "unit": "Mpoints/s",
+    return {"metric": "octree-build Mpoints/sec", "value": round(points / (ms * 1e-3) / 1e6, 2), "unit": "Mpoints/s", "query_flags_roofline": k8,
             "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 3), "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"BASELINE config 5 (ECEF-offset f64 input): {points / 1e6:g} M Gaussian-cluster points (64 clusters, "
                                    f"1000 m cube, sigma 1-20 m) offset by {offset} m, f64 SoA xyz + u8 rgb, resolution 1 mm, full "
@@ -848,6 +898,7 @@ def main():
                     help="default N=1 line only: skip the config-4 (`query`) and config-5 (`config5`) legs after the timed region")
     ap.add_argument("--intensity-points", type=int, default=20_000_000,
                     help="points of the colour + intensity leg of the default line (the reference binary's payload); 100000000 for the full-size record")
+    ap.add_argument("--only-intensity", action="store_true", help="run the colour + intensity leg alone (with --intensity-points) and print its record")
     ap.add_argument("--config5-points", type=int, default=500_000_000)
     ap.add_argument("--config5-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -886,6 +937,12 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if args.only_intensity:
+        ctx = pcv.Context(local_rank)
+        out = intensity_leg(args, torch, pcv, ctx, dev, args.intensity_points, steps=max(1, min(args.steps, 10)))
+        out["build_hash"] = build_hash()
+        print(json.dumps(out), flush=True)
+        return
     if args.virtual_ranks:
         out = run_virtual_ranks(args, torch, pcv, dev)
         import ctypes

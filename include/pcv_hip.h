@@ -448,6 +448,13 @@ int pcv_shapes_get(pcv_shapes* shapes, uint32_t i, double corners[24], double ax
  * major [shape][node] (node order as pcv_octree_node), host buffers. size_on_screen (nullable, same shape) is
  * relative_size_on_screen (src/octree/mod.rs:119-139) for the shape's clip_from_query; NaN where w == 0. */
 int pcv_cull_nodes(pcv_ctx* ctx, const pcv_shapes* shapes, pcv_octree* tree, uint8_t* relation, double* size_on_screen);
+/* Q2 as a list per shape (round 5): the nodes whose Relation is not Out (sat.rs:174-194), in node order —
+ * node_indices / relation / size_on_screen are [shape][capacity] host arrays, counts[shape] the number of such nodes
+ * (entries past `capacity` are dropped, the count is not). size_on_screen (nullable) is relative_size_on_screen
+ * (octree/mod.rs:119-139), computed for the listed nodes only — the nodes the reference projects (octree/mod.rs:261-272).
+ * The same Relations as pcv_cull_nodes without its shapes x nodes matrix (config 4: 60.7 M pairs, 0.24 % not Out). */
+int pcv_cull_nodes_sparse(pcv_ctx* ctx, const pcv_shapes* shapes, pcv_octree* tree, uint32_t capacity, uint32_t* counts,
+                          uint32_t* node_indices, uint8_t* relation, double* size_on_screen);
 
 /* Q3: Octree::get_visible_nodes (src/octree/mod.rs:228-283) for every frustum: node indices in the order the
  * reference's BinaryHeap pops them. counts[f] = number of visible nodes (may exceed `capacity`; only the first

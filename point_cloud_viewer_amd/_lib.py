@@ -176,6 +176,7 @@ _SIGNATURES = {
     "pcv_shapes_get": (C.c_int, [_vp, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                  C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
     "pcv_cull_nodes": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "pcv_cull_nodes_sparse": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _vp, _vp, _vp, _vp]),
     "pcv_visible_nodes": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _vp, _vp, _vp]),
     "pcv_nodes_in_location": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _vp, _vp]),
     "pcv_cull_points": (C.c_int, [_vp, _vp, C.c_uint32, C.POINTER(Points), C.POINTER(C.c_double), _vp,

@@ -283,7 +283,7 @@ static const char* kKernelNames[PCV_K_COUNT] = {
     "visible_nodes_kernel", "nodes_in_location_kernel", "cull_points_kernel", "transform_points_kernel",
     "query_compact_kernel", "route_bucket_kernel", "partition_count_kernel", "partition_scatter_kernel",
     "promote_climb_kernel", "spec_encode_kernel", "rank_hist_kernel", "spec_continue_kernel", "spec_replay_kernel", "upsweep_map_kernel",
-    "hist_from_rows_kernel"};
+    "hist_from_rows_kernel", "cull_nodes_sparse_kernel"};
 static_assert(sizeof(kKernelNames) / sizeof(kKernelNames[0]) == PCV_K_COUNT, "kernel name table out of sync");
 
 extern "C" int pcv_ctx_set_profiling(pcv_ctx* ctx, int enabled) {
@@ -999,7 +999,7 @@ static int queue_record_sort(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, const Pc
   bool rec_in_a = true;
   if (bs->spec_map_dev)
     rc = pcv_radix_sort_records_mapped(ctx, rank_a, rank_b, n, rank_bits, &pl, bs->sort_scratch, bs->spec_map_dev,
-                                       bs->spec_map_entries, &rec_in_a, compact && pl.nwords == 0 ? bs->spec_rows : nullptr);
+                                       bs->spec_map_entries, &rec_in_a, compact && pl.nwords <= 1 ? bs->spec_rows : nullptr);
   else
     rc = pcv_radix_sort_u32(ctx, rank_a, rank_b, n, 0, rank_bits, &pl, bs->sort_scratch, &rec_in_a);
   if (rc) return rc;

@@ -109,6 +109,7 @@ enum PcvKernelId {
   PCV_K_SPEC_REPLAY,
   PCV_K_SORT_UPSWEEP_MAP,
   PCV_K_SORT_HIST_ROWS,
+  PCV_K_CULL_NODES_SPARSE,
   PCV_K_COUNT
 };
 

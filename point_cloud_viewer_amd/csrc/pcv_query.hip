@@ -315,6 +315,54 @@ __global__ __launch_bounds__(256) void cull_nodes_kernel(const PcvShapeDev* __re
   if (sizes) sizes[o] = size_on_screen(s->clip_from_query, c.x, c.y, c.z, c.w);
 }
 
+// K7s (round 5): the same relations as a LIST per shape. 99.8 % of the (frustum, node) pairs of BASELINE config 4 are Out; the
+// dense matrix spends most of its time on the size on screen of pairs nobody looks at (two IEEE divisions per corner) and
+// its 546 MB on the way to the host. One workgroup per shape walks the node table in tiles of 256 and appends the nodes
+// that are not Out IN NODE ORDER: {node index, relation, relative_size_on_screen} — the size is computed for those only,
+// which is exactly where the reference computes it (octree/mod.rs:261-272: a node is projected when it is pushed).
+__global__ __launch_bounds__(256) void cull_nodes_sparse_kernel(const PcvShapeDev* __restrict__ shapes, uint32_t m,
+                                                                 const double* __restrict__ cubes /* m x 4 */, uint32_t capacity,
+                                                                 uint32_t* __restrict__ counts, uint32_t* __restrict__ out_node,
+                                                                 uint8_t* __restrict__ out_rel, double* __restrict__ out_size) {
+  __shared__ uint32_t wave_tot[4];
+  const PcvShapeDev* s = shapes + blockIdx.x;
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint64_t row = (uint64_t)blockIdx.x * capacity;
+  uint32_t base = 0;  // entries of this shape so far (uniform)
+  const bool valid = s->valid != 0;
+  for (uint32_t t0 = 0; t0 < m; t0 += 256) {
+    const uint32_t i = t0 + threadIdx.x;
+    double4 c = make_double4(0, 0, 0, 0);
+    int rel = 2;
+    if (i < m && valid) {
+      c = *reinterpret_cast<const double4*>(cubes + 4 * (uint64_t)i);
+      rel = sat_cube(s, c.x, c.y, c.z, c.w);
+    }
+    const bool keep = rel != 2;
+    const uint64_t b = __ballot(keep);
+    if (lane == 0) wave_tot[wave] = (uint32_t)__popcll(b);
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 4; ++w) {
+      const uint32_t v = wave_tot[w];
+      before += w < wave ? v : 0u;
+      total += v;
+    }
+    if (keep) {
+      const uint32_t pos = base + before + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+      if (pos < capacity) {
+        out_node[row + pos] = i;
+        out_rel[row + pos] = (uint8_t)rel;
+        if (out_size) out_size[row + pos] = size_on_screen(s->clip_from_query, c.x, c.y, c.z, c.w);
+      }
+    }
+    base += total;
+    __syncthreads();  // wave_tot is rewritten by the next tile
+  }
+  if (threadIdx.x == 0) counts[blockIdx.x] = base;
+}
+
 struct QTree {
   uint32_t m;
   const double* cubes;         // get_child-style cubes (min xyz, edge), node order = (level, index)
@@ -1221,6 +1269,43 @@ extern "C" int pcv_cull_nodes(pcv_ctx* ctx, const pcv_shapes* shapes, pcv_octree
   PCV_HIP_CHECK(ctx, hipGetLastError());
   PCV_HIP_CHECK(ctx, hipMemcpyAsync(relation, d_rel, (size_t)f * m, hipMemcpyDeviceToHost, ctx->stream));
   if (d_sz) PCV_HIP_CHECK(ctx, hipMemcpyAsync(size_on_screen_out, d_sz, (size_t)f * m * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->prof_resolve();
+  return PCV_OK;
+}
+
+extern "C" int pcv_cull_nodes_sparse(pcv_ctx* ctx, const pcv_shapes* shapes, pcv_octree* tree, uint32_t capacity, uint32_t* counts,
+                                     uint32_t* node_indices, uint8_t* relation, double* size_on_screen_out) {
+  if (!ctx) return PCV_E_INVALID;
+  if (!shapes || !tree || !counts || (capacity && (!node_indices || !relation))) return ctx->fail(PCV_E_INVALID, "null argument");
+  int rc = pcv_octree_prepare_query(tree);
+  if (rc) return rc;
+  const uint32_t m = tree->query->m, f = shapes->count;
+  if (f == 0) return PCV_OK;
+  if (m == 0) {
+    std::memset(counts, 0, (size_t)f * 4);
+    return PCV_OK;
+  }
+  PCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  PcvScratch sc(ctx);
+  const size_t rows = (size_t)f * (capacity ? capacity : 1);
+  uint32_t *d_cnt, *d_node;
+  uint8_t* d_rel;
+  double* d_sz = nullptr;
+  if ((rc = sc.get(&d_cnt, f)) || (rc = sc.get(&d_node, rows)) || (rc = sc.get(&d_rel, rows))) return rc;
+  if (size_on_screen_out && (rc = sc.get(&d_sz, rows))) return rc;
+  {
+    PcvProf prof(ctx, PCV_K_CULL_NODES_SPARSE);
+    hipLaunchKernelGGL(cull_nodes_sparse_kernel, dim3(f), dim3(256), 0, ctx->stream, shapes->dev, m, tree->query->fb_cubes, capacity, d_cnt,
+                       d_node, d_rel, d_sz);
+  }
+  PCV_HIP_CHECK(ctx, hipGetLastError());
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(counts, d_cnt, (size_t)f * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (capacity) {
+    PCV_HIP_CHECK(ctx, hipMemcpyAsync(node_indices, d_node, rows * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PCV_HIP_CHECK(ctx, hipMemcpyAsync(relation, d_rel, rows, hipMemcpyDeviceToHost, ctx->stream));
+    if (d_sz) PCV_HIP_CHECK(ctx, hipMemcpyAsync(size_on_screen_out, d_sz, rows * 8, hipMemcpyDeviceToHost, ctx->stream));
+  }
   PCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->prof_resolve();
   return PCV_OK;

@@ -590,7 +590,9 @@ struct DigitStateN {
 // the keys still carry PREDICTED leaf ranks; they are translated through the rank map (a copy in dynamic LDS) as they are
 // loaded — rank := map[rank], and where the map flags a replayed leaf (bit 30) the record's first payload word becomes its
 // input index — which is what upsweep_map_kernel does in a pass of its own otherwise.
-template <int BLOCK, int KPT, int R, int WPE, bool NT, int MAP = 0 /* 1: the map in LDS (half words), 2: in global memory */>
+// PL (round 5): ONE extra 4-byte plane travels with the record (the intensity of the reference binary's default payload,
+// src/bin/build_octree.rs:47-52): 16 bytes per record through the same tiles, 32 KB more LDS.
+template <int BLOCK, int KPT, int R, int WPE, bool NT, int MAP = 0 /* 1: the map in LDS (half words), 2: in global memory */, bool PL = false>
 __global__ __launch_bounds__(BLOCK, WPE) void downsweep_rec12_kernel(const uint32_t* __restrict__ keys_in,
                                                                      uint32_t* __restrict__ keys_out, uint64_t n, uint64_t chunk,
                                                                      int groups, int shift, int nbits,
@@ -601,12 +603,15 @@ __global__ __launch_bounds__(BLOCK, WPE) void downsweep_rec12_kernel(const uint3
                                                                      const uint2* __restrict__ ranges = nullptr /* set: piece k
                                                                      = the records [ranges[k].x, ranges[k].y) instead of chunk k */,
                                                                      const uint32_t* __restrict__ order = nullptr /* set: workgroup
-                                                                     b takes piece order[b] (largest pieces first) */) {
+                                                                     b takes piece order[b] (largest pieces first) */,
+                                                                     const uint32_t* __restrict__ plane_in = nullptr,
+                                                                     uint32_t* __restrict__ plane_out = nullptr) {
   constexpr int NW = BLOCK / 64, kTile = BLOCK * KPT, RW = R / 64;
   const uint32_t piece = order ? order[blockIdx.x] : blockIdx.x;
   static_assert(BLOCK >= R && R % 64 == 0 && KPT % 8 == 0, "geometry");
   __shared__ uint32_t skeys[kTile];
   __shared__ uint2 svec[kTile];
+  __shared__ uint32_t splane[PL ? kTile : 1];
   __shared__ DigitStateN<NW, R> S;
   extern __shared__ uint16_t smap_dyn[];  // MAP: map_entries half words: true rank (< 2^15) | replay mark << 15
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -644,14 +649,17 @@ __global__ __launch_bounds__(BLOCK, WPE) void downsweep_rec12_kernel(const uint3
 
   uint32_t key[KPT];
   uint2 vec[KPT];
+  uint32_t pln[PL ? KPT : 1];
   auto load_tile = [&](uint64_t base, uint32_t tile_n) {
     const uint32_t* __restrict__ kp = keys_in + base + wbase;
     const uint2* __restrict__ vp = vec_in + base + wbase;
+    const uint32_t* __restrict__ pp = PL ? plane_in + base + wbase : nullptr;
     if (tile_n == (uint32_t)kTile) {  // full tile: straight-line loads off one base address each
 #pragma unroll
       for (int i = 0; i < KPT; ++i) {
         key[i] = kp[i * 64];
         vec[i] = vp[i * 64];
+        if (PL) pln[i] = pp[i * 64];
       }
     } else {
 #pragma unroll
@@ -659,6 +667,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void downsweep_rec12_kernel(const uint3
         const bool valid = wbase + i * 64 < tile_n;
         key[i] = valid ? kp[i * 64] : 0u;
         vec[i] = valid ? vp[i * 64] : make_uint2(0u, 0u);
+        if (PL) pln[i] = valid ? pp[i * 64] : 0u;
       }
     }
     if (MAP == 1) {
@@ -761,6 +770,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void downsweep_rec12_kernel(const uint3
         const uint32_t p = S.whist[wave][d] + lpos[i];
         skeys[p] = key[i];
         svec[p] = vec[i];
+        if (PL) splane[p] = pln[i];
       }
     }
     __builtin_amdgcn_sched_barrier(0);  // the loads below must not be hoisted over the LDS scatter (twice the registers)
@@ -773,11 +783,13 @@ __global__ __launch_bounds__(BLOCK, WPE) void downsweep_rec12_kernel(const uint3
     for (int j0 = 0; j0 < KPT; j0 += 4) {
       uint32_t k4[4];
       uint2 v4[4];
+      uint32_t p4[PL ? 4 : 1];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const uint32_t p = (j0 + j) * BLOCK + t;
         k4[j] = skeys[p];
         v4[j] = svec[p];
+        if (PL) p4[j] = splane[p];
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -786,6 +798,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void downsweep_rec12_kernel(const uint3
           const uint32_t g = S.delta[(k4[j] >> shift) & mask] + p;
           keys_out[g] = k4[j];
           vec_out[g] = v4[j];
+          if (PL) plane_out[g] = p4[j];
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -892,11 +905,23 @@ __global__ __launch_bounds__(256) void pass2_layout_kernel(const uint32_t* __res
 // PCV_REC_VARIANT (libpcv_hip_exp.so): 3 = 1 024 x 8 (default), 4 = 512 x 16, 2 = 512 x 8 (tiles of 4 096), 0 = the
 // 256-lane kernel above
 static void rec12_launch(pcv_ctx* ctx, int variant, const SortGeom& g, const uint32_t* src, uint32_t* dst, uint64_t n, int shift,
-                         int nbits, const uint32_t* hist, const uint32_t* totals, const uint2* vin, uint2* vout) {
+                         int nbits, const uint32_t* hist, const uint32_t* totals, const uint2* vin, uint2* vout,
+                         const uint32_t* pin = nullptr, uint32_t* pout = nullptr) {
 #define PCV_REC12(B, K, R, W, NT)                                                                                              \
   hipLaunchKernelGGL((downsweep_rec12_kernel<B, K, R, W, NT>), dim3(g.groups), dim3(B), 0, ctx->stream, src, dst, n, g.chunk, g.groups, \
                      shift, nbits, hist, totals, vin, vout)
   const bool narrow = nbits <= 7;
+  if (pin) {  // records with one plane: tiles of 8 192 only
+    if (narrow)
+      hipLaunchKernelGGL((downsweep_rec12_kernel<1024, 8, 128, 4, false, 0, true>), dim3(g.groups), dim3(1024), 0, ctx->stream, src, dst, n, g.chunk,
+                         g.groups, shift, nbits, hist, totals, vin, vout, (const uint32_t*)nullptr, 0u, (const uint2*)nullptr,
+                         (const uint32_t*)nullptr, pin, pout);
+    else
+      hipLaunchKernelGGL((downsweep_rec12_kernel<1024, 8, 256, 4, false, 0, true>), dim3(g.groups), dim3(1024), 0, ctx->stream, src, dst, n, g.chunk,
+                         g.groups, shift, nbits, hist, totals, vin, vout, (const uint32_t*)nullptr, 0u, (const uint2*)nullptr,
+                         (const uint32_t*)nullptr, pin, pout);
+    return;
+  }
   switch (variant) {
     case 2:
       if (narrow) PCV_REC12(512, 8, 128, 4, false);
@@ -928,7 +953,9 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
     const char* e = pcv_experiment("PCV_REC_VARIANT");
     return e ? atoi(e) : 3;
   }();
-  const bool rec12 = compact && payload->nwords == 0 && rec_variant > 0;
+  // 12-byte records, alone or with ONE 4-byte plane (intensity); more planes (the exact pipeline's wide codes) take the 256-lane kernel
+  const bool with_plane = compact && payload->nwords == 1 && rec_variant == 3;
+  const bool rec12 = compact && (payload->nwords == 0 || with_plane) && rec_variant > 0;
   SortGeom g = make_geom(n, rec12 && rec_variant != 2 ? 8192 : kTileUnit);
   uint32_t* hist = (uint32_t*)scratch;
   uint32_t* totals = hist + (size_t)kRadix * kMaxGroups;
@@ -947,14 +974,16 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
     // the histogram from the rank counts, the map applied inside the downsweep (12-byte records in tiles of 8 192; the map in
     // dynamic LDS next to the kernel's 107-117 KB: up to 16 384 half-word entries)
     const bool from_rows = map && rows && shift == begin_bit && rec12 && rec_variant == 3 && nbits <= 8;
-    const bool map_in_lds = map_entries <= 16384;  // half words in <= 32 KB beside the kernel's 107-117 KB
+    // half words in <= 32 KB beside the kernel's 107-117 KB; with a plane the kernel holds 137-146 KB: <= 20 / 10 KB of map (bigger maps are gathered)
+    // (static LDS with a plane: 128 KB of tiles + 9.1 / 18.1 KB of digit state for 128 / 256 digit values)
+    const bool map_in_lds = map_entries <= (with_plane ? (nbits <= 7 ? 10000u : 5000u) : 16384u);
     if (from_rows) {
       static const bool pass2_rows_on = [] {
         const char* e = pcv_experiment("PCV_SORT_ROWS2");  // 0 = the second pass counts its keys itself (experiments)
         return !e || atoi(e) != 0;
       }();
       const int nbits2 = end_bit - (shift + width) < width ? end_bit - (shift + width) : width;
-      const bool two = pass2_rows_on && map_in_lds && shift + width < end_bit && shift + 2 * width >= end_bit && total_bits <= 14 &&
+      const bool two = pass2_rows_on && map_entries <= 16384 && shift + width < end_bit && shift + 2 * width >= end_bit && total_bits <= 14 &&
                        nbits2 >= 1 && g.groups >= 8;
       uint32_t* hist2 = totals + kRadix;
       uint32_t* totals2 = hist2 + (size_t)kRadix * kMaxGroups;
@@ -979,19 +1008,28 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
       uint2* vout = (uint2*)(in_a ? payload->vec_out : payload->vec_in);
       {
         PcvProf prof(ctx, PCV_K_SORT_DOWNSWEEP_REC);
-#define PCV_REC12_MAP(R, M)                                                                                                              \
+        const uint32_t* pin = with_plane ? (in_a ? payload->in[0] : payload->out[0]) : nullptr;
+        uint32_t* pout = with_plane ? (in_a ? payload->out[0] : payload->in[0]) : nullptr;
+#define PCV_REC12_MAP(R, M, P)                                                                                                           \
   {                                                                                                                                      \
-    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&downsweep_rec12_kernel<1024, 8, R, 4, false, M>),           \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 32768) == hipSuccess;                          \
+    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&downsweep_rec12_kernel<1024, 8, R, 4, false, M, P>),        \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, P ? (R == 128 ? 20480 : 10240) : 32768) == hipSuccess; \
     (void)ok;                                                                                                                            \
-    hipLaunchKernelGGL((downsweep_rec12_kernel<1024, 8, R, 4, false, M>), dim3(g.groups), dim3(1024), dyn, ctx->stream,                   \
+    hipLaunchKernelGGL((downsweep_rec12_kernel<1024, 8, R, 4, false, M, P>), dim3(g.groups), dim3(1024), dyn, ctx->stream,                \
                        (const uint32_t*)src, (uint32_t*)dst, n, g.chunk, g.groups, shift, nbits, hist, totals, vin, vout, map, map_entries, \
-                       (const uint2*)nullptr);                                                                                            \
+                       (const uint2*)nullptr, (const uint32_t*)nullptr, pin, pout);                                                       \
   }
-        if (nbits <= 7 && map_in_lds) PCV_REC12_MAP(128, 1)
-        else if (map_in_lds) PCV_REC12_MAP(256, 1)
-        else if (nbits <= 7) PCV_REC12_MAP(128, 2)
-        else PCV_REC12_MAP(256, 2)
+        if (with_plane) {
+          if (nbits <= 7 && map_in_lds) PCV_REC12_MAP(128, 1, true)
+          else if (map_in_lds) PCV_REC12_MAP(256, 1, true)
+          else if (nbits <= 7) PCV_REC12_MAP(128, 2, true)
+          else PCV_REC12_MAP(256, 2, true)
+        } else {
+          if (nbits <= 7 && map_in_lds) PCV_REC12_MAP(128, 1, false)
+          else if (map_in_lds) PCV_REC12_MAP(256, 1, false)
+          else if (nbits <= 7) PCV_REC12_MAP(128, 2, false)
+          else PCV_REC12_MAP(256, 2, false)
+        }
 #undef PCV_REC12_MAP
       }
       in_a = !in_a;
@@ -1018,14 +1056,20 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
         uint32_t* dst2 = (uint32_t*)(in_a ? b : a);
         const uint2* vin2 = (const uint2*)(in_a ? payload->vec_in : payload->vec_out);
         uint2* vout2 = (uint2*)(in_a ? payload->vec_out : payload->vec_in);
-        if (nbits2 <= 7)
-          hipLaunchKernelGGL((downsweep_rec12_kernel<1024, 8, 128, 4, false, 0>), dim3(pieces), dim3(1024), 0, ctx->stream, src2, dst2, n,
-                             g.chunk, pieces, shift + width, nbits2, hist2, totals2, vin2, vout2, (const uint32_t*)nullptr, 0u,
-                             (const uint2*)ranges, (const uint32_t*)order);
-        else
-          hipLaunchKernelGGL((downsweep_rec12_kernel<1024, 8, 256, 4, false, 0>), dim3(pieces), dim3(1024), 0, ctx->stream, src2, dst2, n,
-                             g.chunk, pieces, shift + width, nbits2, hist2, totals2, vin2, vout2, (const uint32_t*)nullptr, 0u,
-                             (const uint2*)ranges, (const uint32_t*)order);
+        const uint32_t* pin2 = with_plane ? (in_a ? payload->in[0] : payload->out[0]) : nullptr;
+        uint32_t* pout2 = with_plane ? (in_a ? payload->out[0] : payload->in[0]) : nullptr;
+#define PCV_REC12_P2(R, P)                                                                                                               \
+  hipLaunchKernelGGL((downsweep_rec12_kernel<1024, 8, R, 4, false, 0, P>), dim3(pieces), dim3(1024), 0, ctx->stream, src2, dst2, n, g.chunk, \
+                     pieces, shift + width, nbits2, hist2, totals2, vin2, vout2, (const uint32_t*)nullptr, 0u, (const uint2*)ranges,        \
+                     (const uint32_t*)order, pin2, pout2)
+        if (with_plane) {
+          if (nbits2 <= 7) PCV_REC12_P2(128, true);
+          else PCV_REC12_P2(256, true);
+        } else {
+          if (nbits2 <= 7) PCV_REC12_P2(128, false);
+          else PCV_REC12_P2(256, false);
+        }
+#undef PCV_REC12_P2
       }
       in_a = !in_a;
       break;
@@ -1080,7 +1124,7 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
       PcvProf prof(ctx, PCV_K_SORT_DOWNSWEEP_REC);
       if (rec12)
         rec12_launch(ctx, rec_variant, g, (const uint32_t*)src, (uint32_t*)dst, n, shift, nbits, hist, totals, (const uint2*)rp.vec_in,
-                     (uint2*)rp.vec_out);
+                     (uint2*)rp.vec_out, with_plane ? rp.plane_in[0] : nullptr, with_plane ? rp.plane_out[0] : nullptr);
       else if (compact)
         hipLaunchKernelGGL((downsweep_rec_kernel<true, true, uint2>), dim3(g.groups), dim3(kBlock), 0, ctx->stream, (const uint32_t*)src,
                            (uint32_t*)dst, n, g.chunk, g.groups, shift, nbits, hist, totals, rp);

@@ -630,6 +630,17 @@ class OctreeResult:
                                                 sizes.ctypes.data if with_sizes else None))
         return (rel, sizes) if with_sizes else rel
 
+    def cull_nodes_sparse(self, shapes, capacity, with_sizes=True):
+        """Per shape the nodes that are not Out, in node order: (counts[f], node_indices[f][capacity], relation, sizes)."""
+        f = shapes.count
+        counts = np.zeros(f, dtype=np.uint32)
+        idx = np.zeros((f, max(capacity, 1)), dtype=np.uint32)
+        rel = np.full((f, max(capacity, 1)), 2, dtype=np.uint8)
+        sizes = np.zeros((f, max(capacity, 1))) if with_sizes else None
+        self.ctx._check(self.lib.pcv_cull_nodes_sparse(self.ctx.handle, shapes.handle, self.handle, capacity, counts.ctypes.data,
+                                                       idx.ctypes.data, rel.ctypes.data, sizes.ctypes.data if with_sizes else None))
+        return counts, idx, rel, sizes
+
     def _traverse(self, fn, shapes, with_status):
         m, f = max(1, self.num_nodes), shapes.count
         counts = np.zeros(f, dtype=np.uint32)

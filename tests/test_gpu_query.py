@@ -87,6 +87,35 @@ def test_cull_nodes_relations_and_sizes(ctx, scene):
     assert {0, 1, 2} <= set(np.unique(rel))  # In, Cross and Out all occur
 
 
+def test_cull_nodes_sparse_lists_equal_the_dense_matrix(ctx, scene):
+    """pcv_cull_nodes_sparse: per shape the nodes whose sat() is not Out (sat.rs:174-194), in node order, with their Relation
+    and relative_size_on_screen (octree/mod.rs:119-139) — against the oracle directly, and against a capacity that truncates."""
+    rng = np.random.default_rng(13)
+    fr = random_frusta(rng, scene["bmin"], scene["bmax"], 48)
+    tree = scene["tree"]
+    m = tree.num_nodes
+    prepared = ctx.shapes([("frustum", c) for c, _ in fr] + [("frustum", np.zeros(16)), ("aabb", scene["bmin"] + 10, scene["bmin"] + 50)])
+    counts, idx, rel, sizes = tree.cull_nodes_sparse(prepared, m)
+    cubes = np.array([[*tree.node(i).cube_min, tree.node(i).cube_edge] for i in range(m)])
+    seen = 0
+    for f, (c, _) in enumerate(fr):
+        want_rel, want_sz = O.cull_cubes(O.SHAPE_FRUSTUM, c, cubes, with_sizes=True)
+        keep = np.nonzero(want_rel != 2)[0]
+        assert counts[f] == keep.size, f
+        assert np.array_equal(idx[f, :keep.size], keep) and np.array_equal(rel[f, :keep.size], want_rel[keep]), f
+        assert np.array_equal(sizes[f, :keep.size], want_sz[keep], equal_nan=True), f
+        seen += keep.size
+    assert seen > 100 and counts[48] == 0  # the singular matrix: no shape, nothing listed (dense: all Out)
+    want = O.cull_cubes(O.SHAPE_AABB, list(scene["bmin"] + 10) + list(scene["bmin"] + 50), cubes)
+    assert counts[49] == (want != 2).sum() and np.array_equal(idx[49, :counts[49]], np.nonzero(want != 2)[0])
+    cap = max(1, int(counts.max()) // 2)  # truncation: the counts stay, the lists are the prefixes
+    c2, i2, r2, _ = tree.cull_nodes_sparse(prepared, cap, with_sizes=False)
+    assert np.array_equal(c2, counts)
+    for f in range(prepared.count):
+        k = min(int(counts[f]), cap)
+        assert np.array_equal(i2[f, :k], idx[f, :k]) and np.array_equal(r2[f, :k], rel[f, :k])
+
+
 def test_visible_nodes_match_reference_traversal_order(ctx, scene):
     rng = np.random.default_rng(4)
     fr = random_frusta(rng, scene["bmin"], scene["bmax"], 64)

@@ -119,6 +119,26 @@ def test_many_small_leaves_take_8_bit_digits_and_the_global_rank_map(ctx):
     assert t.build_info()["record_bytes"] == 20, t.build_info()  # the predicted tree could outgrow 24 rank bits
 
 
+@pytest.mark.parametrize("n,cap,lo,hi", [(2_000_000, 250, 16_384, 65_536),   # 8-bit digits, the rank map gathered from global memory
+                                         (1_500_000, 1_500, 1_024, 8_192),   # <= 7-bit digits, the map's half-word copy in LDS beside the plane
+                                         (1_500_000, 420, 5_000, 16_384)])   # two passes from the rows, map bigger than the LDS left beside the plane
+def test_intensity_plane_rides_the_12_byte_record_sort(ctx, n, cap, lo, hi):
+    """The reference binary always builds ["color", "intensity"] (src/bin/build_octree.rs:47-52): the f32 plane travels with
+    the 12-byte records through the SAME two downsweeps (downsweep_rec12_kernel<..., PL = true>, histograms from the rank
+    counts) — in every map placement the kernel has. `.intensity` bytes checked like `.xyz` / `.rgb` (raw.rs:374-392)."""
+    x, y, z, rgb, bmin, bmax = synthetic.gaussian_clusters(n, seed=33, num_clusters=9, extent=250.0, sigma_range=(0.3, 7.0))
+    inten = ((np.arange(n, dtype=np.int64) * 2654435761) % 100_003).astype(np.float32) * 0.25 - 7.0
+    with O.max_points_per_node(cap):
+        want = O.build_closed(0.001, bmin, bmax, x, y, z, rgb, inten, threads=8)
+    leaves = len(want.nodes) - len({k[:-1] for k in want.nodes if len(k) > 1})
+    assert lo < leaves <= hi, leaves
+    t = ctx.build(0.001, pcv.Aabb(bmin, bmax), x, y, z, rgb, inten, max_points_per_node=cap, single_chain=True, check_resolve=True)
+    info = t.build_info()
+    assert info["single_chain"] and info["record_bytes"] == 12, info
+    assert_same(t.to_dict(), want, check_intensity=True)
+    t.free()
+
+
 def test_single_chain_is_the_default_from_4M_points_and_keeps_candidate_codes(ctx):
     n = 6_000_000
     x, y, z, rgb, bmin, bmax = synthetic.gaussian_clusters(n, seed=8, num_clusters=24, extent=500.0, sigma_range=(0.3, 9.0))

@@ -41,4 +41,8 @@ if it:
 c1 = d.get("config1")
 if c1:
     print("config1:", c1.get("error") or (c1.get("ok"), c1.get("nodes"), c1.get("exact_pipeline"), c1.get("single_chain")))
+if q and not q.get("error"):
+    print(" cull_nodes:", q.get("cull_nodes"))
+if c and not c.get("error"):
+    print(" config5 K8:", c.get("query_flags_roofline"))
 print(" box:", (d.get("config") or {}).get("box"))

@@ -22,6 +22,11 @@ for stage in "$@"; do
     quick) timeout 600 python bench.py --no-legs > gpurun_out/${TAG}_bench_quick.json 2> gpurun_out/${TAG}_bench_quick.err; echo "quick rc=$?"; tail -3 gpurun_out/${TAG}_bench_quick.err
            python tools/bench_brief.py gpurun_out/${TAG}_bench_quick.json;;
     ab) TAG=${TAG}_ab bash tools/ab_quick.sh;;
+    intensity) timeout 600 python bench.py --only-intensity --intensity-points ${IPOINTS:-100000000} --steps 10 > gpurun_out/${TAG}_intensity.json 2> gpurun_out/${TAG}_intensity.err; echo "intensity rc=$?"; tail -2 gpurun_out/${TAG}_intensity.err
+           python -c "
+import json; d=json.loads(open('gpurun_out/${TAG}_intensity.json').read().strip().splitlines()[-1])
+print('intensity', d['points'], 'colour', d['color_only']['ms_per_step'], '+intensity', d['color_and_intensity']['ms_per_step'], 'cost', d['intensity_cost'], 'parity', d['parity']['ok'], d['parity']['mismatching_nodes'])
+print(d['color_only']['kernel_ms_per_step']); print(d['color_and_intensity']['kernel_ms_per_step'])";;
     profile) bash tools/profile_bench.sh ${TAG}_prof > gpurun_out/${TAG}_prof.log 2>&1; echo "profile rc=$?"; tail -5 gpurun_out/${TAG}_prof.log;;
     qprofile) bash tools/profile_query.sh ${TAG} > gpurun_out/${TAG}_qprof.log 2>&1; echo "qprofile rc=$?"; tail -12 gpurun_out/${TAG}_qprof.log;;
     pmc) bash tools/pmc_pass.sh ${TAG} "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM_RD" \
