@@ -984,6 +984,7 @@ static int queue_record_sort(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, const Pc
       return rc;
     }
   }
+  if (bs->spec && t->has_intensity) pl.first_in0 = reinterpret_cast<const uint32_t*>(d.intensity);  // float bits, record order
   const int w_int = t->has_intensity ? 0 : -1;
   const int w_hi = wide ? (t->has_intensity ? 1 : 0) : -1;
   if (!bs->spec) {  // the single-chain build wrote (true-leaf rank, leaf codes, rgb[, intensity]) while it found the topology
@@ -1111,7 +1112,9 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
   } else if ((rc = sc.get(&payload, n))) {
     return rc;
   }
-  uint32_t* inten_bits = t->has_intensity ? (uint32_t*)bs->keys_a + n : nullptr;
+  // the intensity plane needs no copy: the chain pass leaves its records in input order, so the record sort's first pass
+  // reads the caller's own array (PcvSortPayload::first_in0, queue_record_sort) — 8 bytes per point less in the chain pass
+  uint32_t* inten_bits = nullptr;
   uint8_t* depth_grid = nullptr;
   if (n >= (1u << 20) && (rc = sc.get(&depth_grid, pcv_spec_depth_grid_bytes()))) return rc;  // small builds: not worth a 2 MiB fill
   const size_t h_walk = 256, h_parent = h_walk + (size_t)kFirst * 4, h_level = h_parent + (size_t)kFirst * 4;

@@ -305,6 +305,9 @@ struct PcvSortPayload {
   int nwords = 0;           // extra 32-bit payload planes that travel with the key (0..8)
   uint32_t* in[8] = {};
   uint32_t* out[8] = {};
+  // set: the FIRST pass reads plane 0 from here instead of in[0] (the caller's own array in record order — the intensity
+  // plane of the single-chain build needs no copy into the sort's buffers); later passes ping-pong between out[0] and in[0]
+  const uint32_t* first_in0 = nullptr;
 };
 size_t pcv_sort_scratch_bytes(uint64_t n);
 // Sorts keys_in -> ... ping-pong between (keys_a, payload.in) and (keys_b, payload.out). Returns in

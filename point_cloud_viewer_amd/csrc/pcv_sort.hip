@@ -1008,7 +1008,8 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
       uint2* vout = (uint2*)(in_a ? payload->vec_out : payload->vec_in);
       {
         PcvProf prof(ctx, PCV_K_SORT_DOWNSWEEP_REC);
-        const uint32_t* pin = with_plane ? (in_a ? payload->in[0] : payload->out[0]) : nullptr;
+        // (the first pass of the sort: in_a is true here)
+        const uint32_t* pin = with_plane ? (payload->first_in0 ? payload->first_in0 : in_a ? payload->in[0] : payload->out[0]) : nullptr;
         uint32_t* pout = with_plane ? (in_a ? payload->out[0] : payload->in[0]) : nullptr;
 #define PCV_REC12_MAP(R, M, P)                                                                                                           \
   {                                                                                                                                      \
@@ -1117,6 +1118,7 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
         rp.plane_in[w] = in_a ? payload->in[w] : payload->out[w];
         rp.plane_out[w] = in_a ? payload->out[w] : payload->in[w];
       }
+      if (shift == begin_bit && payload->nwords > 0 && payload->first_in0) rp.plane_in[0] = payload->first_in0;
       static const bool prefetch = [] {
         const char* e = pcv_experiment("PCV_REC_PREFETCH");  // 0 = the unpipelined kernel (experiments)
         return !e || atoi(e) != 0;
