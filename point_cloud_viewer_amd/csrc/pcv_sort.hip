@@ -592,7 +592,13 @@ struct DigitStateN {
 // input index — which is what upsweep_map_kernel does in a pass of its own otherwise.
 // PL (round 5): ONE extra 4-byte plane travels with the record (the intensity of the reference binary's default payload,
 // src/bin/build_octree.rs:47-52): 16 bytes per record through the same tiles, 32 KB more LDS.
-template <int BLOCK, int KPT, int R, int WPE, bool NT, int MAP = 0 /* 1: the map in LDS (half words), 2: in global memory */, bool PL = false>
+// WC (round 5, experiment behind PCV_REC_WC in libpcv_hip_exp.so): whole-line write combining. A digit's records leave a tile
+// only in 32-record blocks aligned to 32 records of the OUTPUT array (128 bytes of keys, 256 bytes of payloads); what is left
+// of a digit's run (< 32 records) waits in a carry buffer in LDS for the next tile of the piece (tools/scatter_probe.hip: runs
+// that start on 256-byte boundaries move the same bytes 20-26 % faster than runs at odd record offsets). 128 digit values only
+// (48 KB of carry next to the 107 KB of the tile), no plane, no map copy in LDS.
+template <int BLOCK, int KPT, int R, int WPE, bool NT, int MAP = 0 /* 1: the map in LDS (half words), 2: in global memory */, bool PL = false,
+          bool WC = false>
 __global__ __launch_bounds__(BLOCK, WPE) void downsweep_rec12_kernel(const uint32_t* __restrict__ keys_in,
                                                                      uint32_t* __restrict__ keys_out, uint64_t n, uint64_t chunk,
                                                                      int groups, int shift, int nbits,
@@ -612,6 +618,11 @@ __global__ __launch_bounds__(BLOCK, WPE) void downsweep_rec12_kernel(const uint3
   __shared__ uint32_t skeys[kTile];
   __shared__ uint2 svec[kTile];
   __shared__ uint32_t splane[PL ? kTile : 1];
+  static_assert(!WC || (R == 128 && BLOCK == 1024 && !PL && MAP != 1), "write combining: 128 digit values, 1 024 lanes, no plane, no LDS map");
+  __shared__ uint32_t wc_key[WC ? R * 32 : 1];  // carry: the records of digit d at output positions [W_d, W_d + count_d)
+  __shared__ uint2 wc_vec[WC ? R * 32 : 1];
+  __shared__ uint32_t wc_count[WC ? R : 1], wc_W[WC ? R : 1], wc_gb[WC ? R : 1], wc_A[WC ? R : 1], wc_ts[WC ? R : 1], wc_cnt[WC ? R : 1];
+  __shared__ uint32_t wc_seg[WC ? R + 1 : 1];  // exclusive prefix of the digits' block counts of this tile; [R] = their sum
   __shared__ DigitStateN<NW, R> S;
   extern __shared__ uint16_t smap_dyn[];  // MAP: map_entries half words: true rank (< 2^15) | replay mark << 15
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -635,6 +646,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void downsweep_rec12_kernel(const uint3
 #pragma unroll
     for (int w = 0; w < RW; ++w) woff += (w < wave) ? S.wave_tot[w] : 0u;
     if (t < R) S.digit_base[t] = woff + inc - tot + offsets[(uint64_t)t * groups + piece];
+    if (WC && t < R) wc_count[t] = 0;
     for (int k = t; k < NW * R; k += BLOCK) (&S.whist[0][0])[k] = 0;
     __syncthreads();
   }
@@ -742,7 +754,17 @@ __global__ __launch_bounds__(BLOCK, WPE) void downsweep_rec12_kernel(const uint3
         pre[w] = acc;
         acc += t < R ? S.whist[w][t] : 0u;
       }
-      uint32_t inc = acc;
+      // WC: the digit's aligned blocks of this tile are scanned in the upper half word of the same prefix (<= 8 192 records
+      // and <= 384 blocks per tile)
+      uint32_t wcW = 0, wcA = 0, nseg = 0, gb0 = 0;
+      if (WC && t < R) {
+        gb0 = S.digit_base[t];
+        wcW = gb0 - wc_count[t];
+        wcA = (gb0 + acc) & ~31u;
+        nseg = wcA > wcW ? (wcA >> 5) - (wcW >> 5) : 0u;
+      }
+      const uint32_t val = WC ? (acc | (nseg << 16)) : acc;
+      uint32_t inc = val;
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
         const uint32_t v = __shfl_up(inc, o, 64);
@@ -753,13 +775,19 @@ __global__ __launch_bounds__(BLOCK, WPE) void downsweep_rec12_kernel(const uint3
       uint32_t woff = 0;
 #pragma unroll
       for (int w = 0; w < RW; ++w) woff += (w < wave) ? S.wave_tot[w] : 0u;
-      const uint32_t start = woff + inc - acc;
+      const uint32_t excl = woff + inc - val;
+      const uint32_t start = WC ? (excl & 0xffffu) : excl;
       if (t < R) {
 #pragma unroll
         for (int w = 0; w < NW; ++w) S.whist[w][t] = start + pre[w];
         const uint32_t gb = S.digit_base[t];
         S.delta[t] = gb - start;
         S.digit_base[t] = gb + acc;
+        if (WC) {
+          wc_W[t] = wcW, wc_gb[t] = gb0, wc_A[t] = wcA, wc_ts[t] = start, wc_cnt[t] = acc;
+          wc_seg[t] = excl >> 16;
+          if (t == R - 1) wc_seg[R] = (excl >> 16) + nseg;
+        }
       }
       __syncthreads();
     }
@@ -779,6 +807,53 @@ __global__ __launch_bounds__(BLOCK, WPE) void downsweep_rec12_kernel(const uint3
       if (nbase < end) load_tile(nbase, (uint32_t)((end - nbase) < (uint64_t)kTile ? (end - nbase) : (uint64_t)kTile));
     }
     __syncthreads();
+    if constexpr (WC) {
+      // every half wave writes whole 32-record blocks: 128 contiguous, aligned bytes of keys and 256 of payloads
+      const uint32_t ns = wc_seg[R];
+      const uint32_t l32 = (uint32_t)t & 31u;
+      for (uint32_t q = (uint32_t)t >> 5; q < ns; q += BLOCK / 32) {
+        uint32_t lo = 0, hi = R;  // the digit of block q: the last one whose prefix is <= q
+#pragma unroll
+        for (int it = 0; it < 7; ++it) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (wc_seg[mid] <= q) lo = mid;
+          else hi = mid;
+        }
+        const uint32_t W = wc_W[lo], gb = wc_gb[lo];
+        const uint32_t P = (((W >> 5) + (q - wc_seg[lo])) << 5) + l32;
+        if (P >= W) {  // (the first block of a piece's digit may begin inside a line)
+          uint32_t k;
+          uint2 v;
+          if (P < gb) {
+            k = wc_key[lo * 32 + (P - W)];
+            v = wc_vec[lo * 32 + (P - W)];
+          } else {
+            const uint32_t src = wc_ts[lo] + (P - gb);
+            k = skeys[src];
+            v = svec[src];
+          }
+          keys_out[P] = k;
+          vec_out[P] = v;
+        }
+      }
+      __syncthreads();
+      {  // what is left of every digit's run goes to (or stays in) its carry: lanes 8 d .. 8 d + 7 serve digit d
+        const uint32_t d = (uint32_t)t >> 3;
+        const uint32_t c = wc_count[d], W = wc_W[d], gb = wc_gb[d], A = wc_A[d], cnt = wc_cnt[d], ts = wc_ts[d];
+        const bool wrote = A > W;
+        const uint32_t newc = wrote ? gb + cnt - A : c + cnt;
+#pragma unroll
+        for (uint32_t k8 = 0; k8 < 4; ++k8) {
+          const uint32_t sl = ((uint32_t)t & 7u) + 8u * k8;
+          if (wrote ? sl < newc : (sl >= c && sl < newc)) {
+            const uint32_t src = wrote ? ts + (A - gb) + sl : ts + (sl - c);
+            wc_key[d * 32 + sl] = skeys[src];
+            wc_vec[d * 32 + sl] = svec[src];
+          }
+        }
+        if (((uint32_t)t & 7u) == 0u) wc_count[d] = newc;
+      }
+    } else {
 #pragma unroll
     for (int j0 = 0; j0 < KPT; j0 += 4) {
       uint32_t k4[4];
@@ -803,8 +878,21 @@ __global__ __launch_bounds__(BLOCK, WPE) void downsweep_rec12_kernel(const uint3
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    }
     for (int k = t; k < NW * R; k += BLOCK) (&S.whist[0][0])[k] = 0;  // last read before the barrier above
     __syncthreads();
+  }
+  if constexpr (WC) {  // end of the piece: the carries leave as they are (the tail of every digit's run)
+    const uint32_t d = (uint32_t)t >> 3;
+    const uint32_t c = wc_count[d], W = S.digit_base[d] - c;
+#pragma unroll
+    for (uint32_t k8 = 0; k8 < 4; ++k8) {
+      const uint32_t sl = ((uint32_t)t & 7u) + 8u * k8;
+      if (sl < c) {
+        keys_out[W + sl] = wc_key[d * 32 + sl];
+        vec_out[W + sl] = wc_vec[d * 32 + sl];
+      }
+    }
   }
 }
 
@@ -1020,7 +1108,16 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
                        (const uint32_t*)src, (uint32_t*)dst, n, g.chunk, g.groups, shift, nbits, hist, totals, vin, vout, map, map_entries, \
                        (const uint2*)nullptr, (const uint32_t*)nullptr, pin, pout);                                                       \
   }
-        if (with_plane) {
+        // PCV_REC_WC (libpcv_hip_exp.so; bit 0: first pass, bit 1: second pass): the write-combining form of the downsweep
+        static const int rec_wc = [] {
+          const char* e = pcv_experiment("PCV_REC_WC");
+          return e ? atoi(e) : 0;
+        }();
+        if ((rec_wc & 1) && !with_plane && nbits <= 7) {
+          hipLaunchKernelGGL((downsweep_rec12_kernel<1024, 8, 128, 4, false, 2, false, true>), dim3(g.groups), dim3(1024), 0, ctx->stream,
+                             (const uint32_t*)src, (uint32_t*)dst, n, g.chunk, g.groups, shift, nbits, hist, totals, vin, vout, map, map_entries,
+                             (const uint2*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+        } else if (with_plane) {
           if (nbits <= 7 && map_in_lds) PCV_REC12_MAP(128, 1, true)
           else if (map_in_lds) PCV_REC12_MAP(256, 1, true)
           else if (nbits <= 7) PCV_REC12_MAP(128, 2, true)
@@ -1063,7 +1160,15 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
   hipLaunchKernelGGL((downsweep_rec12_kernel<1024, 8, R, 4, false, 0, P>), dim3(pieces), dim3(1024), 0, ctx->stream, src2, dst2, n, g.chunk, \
                      pieces, shift + width, nbits2, hist2, totals2, vin2, vout2, (const uint32_t*)nullptr, 0u, (const uint2*)ranges,        \
                      (const uint32_t*)order, pin2, pout2)
-        if (with_plane) {
+        static const int rec_wc2 = [] {
+          const char* e = pcv_experiment("PCV_REC_WC");
+          return e ? atoi(e) : 0;
+        }();
+        if ((rec_wc2 & 2) && !with_plane && nbits2 <= 7) {
+          hipLaunchKernelGGL((downsweep_rec12_kernel<1024, 8, 128, 4, false, 0, false, true>), dim3(pieces), dim3(1024), 0, ctx->stream, src2, dst2, n,
+                             g.chunk, pieces, shift + width, nbits2, hist2, totals2, vin2, vout2, (const uint32_t*)nullptr, 0u, (const uint2*)ranges,
+                             (const uint32_t*)order, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+        } else if (with_plane) {
           if (nbits2 <= 7) PCV_REC12_P2(128, true);
           else PCV_REC12_P2(256, true);
         } else {
