@@ -84,6 +84,10 @@ class Context:
         # build); off, stage_ms() of a tree reports the total only. build(stage_times=...) overrides it per call.
         self.stage_times = False
 
+    def trim(self):
+        """Give the cached scratch blocks of the context's pool back to the driver (pcv_ctx_trim)."""
+        self._check(self.lib.pcv_ctx_trim(self.handle))
+
     def close(self):
         for child in list(getattr(self, "_children", [])):
             child.free()
