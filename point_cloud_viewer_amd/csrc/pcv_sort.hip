@@ -1109,6 +1109,9 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
                        (const uint2*)nullptr, (const uint32_t*)nullptr, pin, pout);                                                       \
   }
         // PCV_REC_WC (libpcv_hip_exp.so; bit 0: first pass, bit 1: second pass): the write-combining form of the downsweep
+        // measured slower than the kernel that ships (profiles/r05_sort_same_box.json): not instantiated in libpcv_hip.so
+        bool wc_done = false;
+#ifdef PCV_EXPERIMENTS
         static const int rec_wc = [] {
           const char* e = pcv_experiment("PCV_REC_WC");
           return e ? atoi(e) : 0;
@@ -1117,6 +1120,10 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
           hipLaunchKernelGGL((downsweep_rec12_kernel<1024, 8, 128, 4, false, 2, false, true>), dim3(g.groups), dim3(1024), 0, ctx->stream,
                              (const uint32_t*)src, (uint32_t*)dst, n, g.chunk, g.groups, shift, nbits, hist, totals, vin, vout, map, map_entries,
                              (const uint2*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+          wc_done = true;
+        }
+#endif
+        if (wc_done) {
         } else if (with_plane) {
           if (nbits <= 7 && map_in_lds) PCV_REC12_MAP(128, 1, true)
           else if (map_in_lds) PCV_REC12_MAP(256, 1, true)
@@ -1160,6 +1167,8 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
   hipLaunchKernelGGL((downsweep_rec12_kernel<1024, 8, R, 4, false, 0, P>), dim3(pieces), dim3(1024), 0, ctx->stream, src2, dst2, n, g.chunk, \
                      pieces, shift + width, nbits2, hist2, totals2, vin2, vout2, (const uint32_t*)nullptr, 0u, (const uint2*)ranges,        \
                      (const uint32_t*)order, pin2, pout2)
+        bool wc2_done = false;
+#ifdef PCV_EXPERIMENTS
         static const int rec_wc2 = [] {
           const char* e = pcv_experiment("PCV_REC_WC");
           return e ? atoi(e) : 0;
@@ -1168,6 +1177,10 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
           hipLaunchKernelGGL((downsweep_rec12_kernel<1024, 8, 128, 4, false, 0, false, true>), dim3(pieces), dim3(1024), 0, ctx->stream, src2, dst2, n,
                              g.chunk, pieces, shift + width, nbits2, hist2, totals2, vin2, vout2, (const uint32_t*)nullptr, 0u, (const uint2*)ranges,
                              (const uint32_t*)order, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+          wc2_done = true;
+        }
+#endif
+        if (wc2_done) {
         } else if (with_plane) {
           if (nbits2 <= 7) PCV_REC12_P2(128, true);
           else PCV_REC12_P2(256, true);

@@ -37,7 +37,8 @@ def main():
         ms = (time.perf_counter() - t0) / 8 * 1e3
         ctx.set_profiling(False)
         ks = {k.replace("_kernel", ""): round(v[1] / 8, 3) for k, v in ctx.kernel_stats().items() if v[0] > 0}
-        print(json.dumps({"round": r, "ms_per_step": round(ms, 3), "kernels": ks, "junk_tensors": len(junk)}), flush=True)
+        print(json.dumps({"round": r, "pool_align": os.environ.get("PCV_POOL_ALIGN", "default (2 MiB)"), "ms_per_step": round(ms, 3), "kernels": ks,
+                          "junk_tensors": len(junk)}), flush=True)
         # move the next round's blocks: give the pool back, then take / release odd-sized blocks in between
         ctx.trim()
         if r % 2 == 0:
