@@ -172,7 +172,7 @@ def build_hash():
     d = os.path.join(ROOT, "point_cloud_viewer_amd", "csrc")
     h = hashlib.sha256()
     for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".h", ".cpp")) or name == "Makefile":
+        if name.endswith((".hip", ".h", ".cpp", ".inc")) or name == "Makefile":
             h.update(name.encode())
             with open(os.path.join(d, name), "rb") as f:
                 h.update(f.read())

@@ -392,6 +392,11 @@ __global__ __launch_bounds__(256) void route_plan_kernel(PcvLevels lv, uint64_t 
   if (threadIdx.x < 64) hist[threadIdx.x] = 0;
   __syncthreads();
   const uint64_t base = (uint64_t)blockIdx.x * kRouteTile + threadIdx.x;
+  // round 5: the usual case — a tame table whose level 1 is Float32-coded with the digit of level 2 readable off the level-1
+  // codes (PcvLevels::digit_mode, the rule the chain pass follows) — takes ONE unguarded level step and three compares per
+  // point instead of two guarded steps: the second digit is v > 1/2 per coordinate; a code of exactly 1/2 (a tie of the
+  // exact values) is decided by the comparison against the centre, as in the chain pass
+  const bool fast = lv.fast_ok && lv.nlevels >= 2 && lv.enc[1] == PCV_ENC_FLOAT32 && lv.digit_mode[1] == 2u;
 #pragma unroll 4
   for (int k = 0; k < kRouteTile / 256; ++k) {
     const uint64_t i = base + (uint64_t)k * 256;
@@ -400,8 +405,16 @@ __global__ __launch_bounds__(256) void route_plan_kernel(PcvLevels lv, uint64_t 
       double mx = lv.root_min[0], my = lv.root_min[1], mz = lv.root_min[2];
       double cx, cy, cz;
       uint32_t b = 0;
-      for (int l = 1; l <= lv.nlevels; ++l)  // nlevels <= 2 here; always the guarded (exact for any input) variant
+      if (fast && pcv_point_is_tame(px, py, pz)) {
+        const PcvOctBits b1 = pcv_chain_bits(lv.edge[0], px, py, pz, mx, my, mz);
+        pcv_chain_apply_bits_t<PCV_ENC_FLOAT32, false>(b1, lv.edge[1], PcvRecip{lv.inv_edge[1], lv.inv_edge_lo[1]}, px, py, pz, mx, my, mz, cx, cy, cz);
+        PcvOctBits b2 = pcv_bits_from_codes(0.5, cx, cy, cz);
+        if (__builtin_expect(pcv_f32_code_tie(cx, cy, cz), 0)) b2 = pcv_chain_bits(lv.edge[1], px, py, pz, mx, my, mz);
+        b = (b1.digit() << 3) | b2.digit();
+      } else {
+      for (int l = 1; l <= lv.nlevels; ++l)  // nlevels <= 2 here; the guarded (exact for any input) variant
         b = (b << 3) | pcv_chain_level<true>(lv.enc[l], lv.edge[l - 1], lv.edge[l], PcvRecip{lv.inv_edge[l], lv.inv_edge_lo[l]}, px, py, pz, mx, my, mz, cx, cy, cz);
+      }
       if (lv.nlevels < 2) b <<= 3;
       bucket[i] = (uint8_t)b;
       atomicAdd(&hist[b], 1u);

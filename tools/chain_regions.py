@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Static attribution of the chain pass's instructions to source regions (VERDICT r03 #2 asked for VALU + SALU per region).
 Compiles pcv_encode.hip for gfx950 with line tables (device only, no GPU needed), walks the ISA of
-spec_encode_pair_kernel<true, 512> and books every instruction on the source line its `.loc` names:
+chain_pass_kernel<true, true, 512> and books every instruction on the source line its `.loc` names:
   front   loads, depth look-up, deal (kernel text before the task loop; BOTH points of a lane are in this text)
   fetch   per task: dealt point from LDS, tame test, walk set-up
   walk    the PCV4_WALK macro text and pcv4_walk_at: live / KEEP tests, child gather, level constants, loop control
@@ -13,8 +13,8 @@ spec_encode_pair_kernel<true, 512> and books every instruction on the source lin
   cold    basic blocks that hold an IEEE division expansion (out-of-range fallback of the constant-divisor division)
 Inlined callees keep their own lines, so `level` is exact; which walk instantiation an instruction of pcv_chain_dev.h
 belongs to is taken from the last PCV4_WALK call site seen in layout order (approximate where blocks interleave).
-This is kernel TEXT, not a trace: the tame walk has four straight-line loops (per-level switch, Float32-, u16-, u8-coded
-levels) and a level step runs one of them.   usage: python tools/chain_regions.py [-o profiles/r04_chain_pass_regions.json]"""
+This is kernel TEXT, not a trace: the tame walk has the loops of CP_WALK_TAME (cold per-level switch, Float32-coded levels in full,
+Float32 codes from codes, integer-coded levels) and a level step runs one of them.   usage: python tools/chain_regions.py [-o profiles/r05_chain_pass_regions.json]"""
 import argparse, json, os, re, subprocess, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -35,16 +35,15 @@ def main():
                 return i
         raise SystemExit(f"anchor not found: {pat}")
 
-    k0 = line_of("void spec_encode_pair_kernel(")
+    k0 = line_of("void chain_pass_kernel(")
     task = line_of("for (int task = 0; task < 2; ++task)", k0)
-    w_tame = line_of("PCV4_WALK(false)", task)
-    w_guard = line_of("PCV4_WALK(true)", task)
-    store = line_of("if (stage) {  // input order again", w_guard)
-    k1 = line_of("#undef PCV4_WALK", store)
-    emit0 = line_of("void pcv_spec_emit(")
-    emit1 = line_of("// ---- single-chain build (pcv_spec.h)", emit0)
+    w_tame = line_of("        CP_WALK_TAME", task)
+    w_guard = line_of("        CP_WALK_GUARDED", task)
+    store = line_of("// closing phase, input order again", w_guard)
+    k1 = line_of("#undef CP_WALK_GUARDED", store)
     rgb0 = line_of("uint32_t pcv_load_rgb(")
-    walk_at = line_of("uint32_t pcv4_walk_at(")
+    emit0 = emit1 = rgb0 + 9  # (round 5: the record epilogue is kernel text between the walks and the closing phase)
+    walk_at = -10  # (the child gather is a macro now: its lines are the walk's)
     with tempfile.TemporaryDirectory() as td:
         asm = os.path.join(td, "enc.s")
         subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
@@ -56,7 +55,7 @@ def main():
         m = re.match(r'\s*\.file\s+(\d+)\s+"[^"]*"\s+"([^"]+)"', l)
         if m:
             files[int(m.group(1))] = os.path.basename(m.group(2))
-    start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN12_GLOBAL__N_123spec_encode_pair_kernelILb1ELi512ELb1ELb0EEE.*:", l))
+    start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN12_GLOBAL__N_117chain_pass_kernelILb1ELb1ELi512EEE.*:", l))
     body = []
     for l in lines[start + 1:]:
         body.append(l.strip())
@@ -124,13 +123,13 @@ def main():
                 sb["valu_f64"] += 1
             if op == "global_load_dword":
                 sb["child_gather"] += 1
-    out = {"kernel": "spec_encode_pair_kernel<true, 512>", "what": __doc__.split("usage:")[0].strip(),
+    out = {"kernel": "chain_pass_kernel<true, true, 512> (raw input)", "what": __doc__.split("usage:")[0].strip(),
            "static_instructions_per_region": regions,
            "largest_blocks_of_the_tame_walk": sorted(({"block": k, **v} for k, v in step_blocks.items() if v["valu"] >= 12),
                                                      key=lambda x: -x["valu"])[:14]}
-    valu_path = os.path.join(ROOT, "profiles", "r04_bench_100M_valu.json")
+    valu_path = os.path.join(ROOT, "profiles", "r05_bench_100M_valu.json")
     if os.path.exists(valu_path):
-        per = json.load(open(valu_path))["per_launch"].get("spec_encode_pair_kernel")
+        per = json.load(open(valu_path))["per_launch"].get("chain_pass_kernel")
         if per:
             g = lambda r: regions.get(r, {}).get("valu", 0)
             once = g("front") / 2.0 + g("fetch") + g("after") + g("store") / 2.0
