@@ -1056,9 +1056,11 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
   PcvLevels& lv = bs->lv;
   const uint64_t n = bs->n;
   int rc;
-  // sample stride: every 32nd point (>= 3 000 sample points per full node at the reference's capacity); small forced
-  // builds (tests) sample more densely
-  uint64_t stride = 32;
+  // sample stride: every 64th point (>= 1 500 sample points per full node at the reference's capacity: a candidate band of
+  // +-13 % around it); small forced builds (tests) sample more densely. Round 5, one call, 100 M points: stride 32 / 48 / 64 /
+  // 96 -> 5.02 / 4.97 / 4.95-4.98 / 4.96 ms per build — the sample phase shrinks by 0.07 ms, 1.5 M more points continue
+  // their chain in the settle pass, the prediction holds either way (profiles/r05_ab_sample_stride.json)
+  uint64_t stride = 64;
   if (const char* e = pcv_experiment("PCV_SPEC_STRIDE")) stride = (uint64_t)std::max(1, atoi(e));  // experiments
   while (stride > 1 && n / stride < 4096) stride >>= 1;
   // a node at the capacity must still hold a few dozen sample points, or the band around the capacity (five standard
