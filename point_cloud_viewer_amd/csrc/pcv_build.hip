@@ -39,6 +39,82 @@ void* PcvPool::alloc(size_t bytes, hipError_t* err) {
     return p;
   }
   void* p = nullptr;
+#ifdef PCV_EXPERIMENTS  // placement experiments (profiles/r05_placement_probe.json): neither helps, neither ships
+  // PCV_POOL_VMM=<chunk MiB> (libpcv_hip_exp.so, tools/placement_probe.py): big blocks assembled from physical chunks of that
+  // size mapped in a scrambled order. The scatter kernels of the build run 1.0-1.25 ms on whatever hipMalloc returns and
+  // 1.36-1.53 ms on physically CONTIGUOUS memory (PCV_POOL_CONTIG=1): their 131 072 write streams meet in the same
+  // memory channels when the physical addresses follow the virtual ones too regularly.
+  static const size_t vmm_chunk = [] {
+    const char* e = pcv_experiment("PCV_POOL_VMM");
+    return e ? (size_t)std::max(0, atoi(e)) << 20 : (size_t)0;
+  }();
+  if (vmm_chunk && bytes >= (64u << 20)) {
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device;
+    size_t gran = 0;
+    if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) == hipSuccess && gran) {
+      const size_t chunk = (vmm_chunk + gran - 1) / gran * gran;
+      const size_t size = (bytes + chunk - 1) / chunk * chunk;
+      const size_t nchunks = size / chunk;
+      void* va = nullptr;
+      PcvVmmBlock blk;
+      blk.size = size;
+      bool ok = hipMemAddressReserve(&va, size, 0, nullptr, 0) == hipSuccess;
+      for (size_t k = 0; ok && k < nchunks; ++k) {
+        hipMemGenericAllocationHandle_t h;
+        ok = hipMemCreate(&h, chunk, &prop, 0) == hipSuccess;
+        if (ok) blk.handles.push_back(h);
+      }
+      if (ok) {
+        // slot k of the address range gets chunk perm(k): a multiplicative scramble (odd multiplier modulo a power of two,
+        // values past nchunks skipped) — deterministic, no two slots share a chunk
+        size_t pow2 = 1;
+        while (pow2 < nchunks) pow2 <<= 1;
+        size_t slot = 0;
+        for (size_t v = 0; ok && v < pow2; ++v) {
+          const size_t c = (v * 0x9E3779B1ull + 12345u) & (pow2 - 1);
+          if (c >= nchunks) continue;
+          ok = hipMemMap((char*)va + slot * chunk, chunk, 0, blk.handles[c], 0) == hipSuccess;
+          ++slot;
+        }
+        ok = ok && slot == nchunks;
+      }
+      if (ok) {
+        hipMemAccessDesc ad = {};
+        ad.location.type = hipMemLocationTypeDevice;
+        ad.location.id = device;
+        ad.flags = hipMemAccessFlagsProtReadWrite;
+        ok = hipMemSetAccess(va, size, &ad, 1) == hipSuccess;
+      }
+      if (ok) {
+        vmm[va] = blk;
+        live[va] = bytes;
+        return va;
+      }
+      (void)hipGetLastError();
+      if (va) {
+        (void)hipMemUnmap(va, size);
+        for (auto h : blk.handles) (void)hipMemRelease(h);
+        (void)hipMemAddressFree(va, size);
+      }
+    }
+  }
+  // PCV_POOL_CONTIG=1 (libpcv_hip_exp.so, tools/placement_probe.py): big blocks asked for as physically contiguous memory
+  static const bool contig = [] {
+    const char* e = pcv_experiment("PCV_POOL_CONTIG");
+    return e && atoi(e) != 0;
+  }();
+  if (contig && bytes >= (8u << 20)) {
+    if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocContiguous) == hipSuccess) {
+      live[p] = bytes;
+      return p;
+    }
+    (void)hipGetLastError();
+    p = nullptr;
+  }
+#endif
   *err = hipMalloc(&p, bytes);
   if (*err != hipSuccess) {
     // drop the cache and retry once
@@ -56,8 +132,19 @@ void PcvPool::release(void* p) {
   free_blocks.insert({it->second, p});
   live.erase(it);
 }
+void PcvPool::free_block(void* p) {
+  auto it = vmm.find(p);
+  if (it == vmm.end()) {
+    (void)hipFree(p);
+    return;
+  }
+  (void)hipMemUnmap(p, it->second.size);
+  for (auto h : it->second.handles) (void)hipMemRelease(h);
+  (void)hipMemAddressFree(p, it->second.size);
+  vmm.erase(it);
+}
 void PcvPool::trim() {
-  for (auto& kv : free_blocks) (void)hipFree(kv.second);
+  for (auto& kv : free_blocks) free_block(kv.second);
   free_blocks.clear();
 }
 
@@ -324,6 +411,7 @@ extern "C" int pcv_ctx_create(int device, void* stream, pcv_ctx** out) {
   if (hipSetDevice(device) != hipSuccess) return PCV_E_HIP;
   pcv_ctx* c = new pcv_ctx();
   c->device = device;
+  c->pool.device = device;
   if (hipHostMalloc((void**)&c->mailbox, 136 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) {
     delete c;
     return PCV_E_OOM;
@@ -371,7 +459,11 @@ extern "C" void pcv_ctx_destroy(pcv_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   ctx->pool.trim();
-  for (auto& kv : ctx->pool.live) (void)hipFree(kv.first);
+  {
+    std::vector<void*> still;
+    for (auto& kv : ctx->pool.live) still.push_back(kv.first);
+    for (void* q : still) ctx->pool.free_block(q);
+  }
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->pinned_spec) (void)hipHostFree(ctx->pinned_spec);
   for (int k = 0; k < pcv_ctx::kRingSlots; ++k) {

@@ -71,9 +71,18 @@ struct PcvHostPool {
 };
 
 // Caching device allocator + pinned host scratch, one per context. Steady-state builds allocate nothing.
+// A pool block assembled from separately created physical chunks mapped into one address range in a scrambled order
+// (HIP virtual memory management; PcvPool::alloc explains why).
+struct PcvVmmBlock {
+  size_t size = 0;
+  std::vector<hipMemGenericAllocationHandle_t> handles;
+};
 struct PcvPool {
   std::multimap<size_t, void*> free_blocks;
   std::map<void*, size_t> live;
+  std::map<void*, PcvVmmBlock> vmm;  // blocks that must be unmapped / released instead of hipFree'd
+  int device = 0;
+  void free_block(void* p);
   void* alloc(size_t bytes, hipError_t* err);
   void release(void* p);
   void trim();

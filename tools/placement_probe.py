@@ -37,7 +37,7 @@ def main():
         ms = (time.perf_counter() - t0) / 8 * 1e3
         ctx.set_profiling(False)
         ks = {k.replace("_kernel", ""): round(v[1] / 8, 3) for k, v in ctx.kernel_stats().items() if v[0] > 0}
-        print(json.dumps({"round": r, "pool_align": os.environ.get("PCV_POOL_ALIGN", "default (2 MiB)"), "ms_per_step": round(ms, 3), "kernels": ks,
+        print(json.dumps({"round": r, "pool_contiguous": os.environ.get("PCV_POOL_CONTIG", "0"), "pool_vmm_chunk_MiB": os.environ.get("PCV_POOL_VMM", "0"), "ms_per_step": round(ms, 3), "kernels": ks,
                           "junk_tensors": len(junk)}), flush=True)
         # move the next round's blocks: give the pool back, then take / release odd-sized blocks in between
         ctx.trim()
