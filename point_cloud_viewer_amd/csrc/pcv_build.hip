@@ -1218,6 +1218,7 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
   PcvSpecTree tree;
   uint32_t info[4] = {0, 0, 0, 0};
   uint64_t* small_partner = nullptr;
+  uint32_t* d_sample_counts = nullptr;
   // Levels the sample keys cover first: a uniform cloud reaches the capacity at level log8(n / capacity); clustered clouds
   // go deeper, so eight levels on top (12 levels for the 100 M bench cloud whose deepest leaf sits at level 10, 13 for
   // 1 B points), at most 14. Every level less is a tenth of the sample's chain, three bits of its key sort and two
@@ -1250,13 +1251,26 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
     pcv_launch_chain_keys(ctx, lv, ns, stride, d.x, d.y, d.z, skeys_a, false, d.routed, stride > 1 ? clump_shift : 0u);
     bool in_a = true;
     host_lap("", true);
+    // The sample tree by counting the keys, three levels per launch pair (round 5, pcv_topology.hip): no sort, 2 x ceil(levels / 3)
+    // launches instead of 27. Taken whenever a level's open nodes fit the slot tables (an open sample node holds more than
+    // `threshold` keys); PCV_SAMPLE_COUNTS=0 (libpcv_hip_exp.so): the key sort + split by binary search of rounds 2-4.
+    static const bool counts_on = [] {
+      const char* e = pcv_experiment("PCV_SAMPLE_COUNTS");
+      return !e || atoi(e) != 0;
+    }();
+    const uint32_t thr_s = pcv_spec_sample_threshold(sp);
+    if (counts_on && thr_s > 0 && nt.max_open >= ns / thr_s + 16 && sample_levels <= PCV_MAX_KEY_LEVELS) {
+      if (!d_sample_counts && (rc = sc.get(&d_sample_counts, pcv_sample_count_scratch_words(nt.capacity, nt.max_open, full_levels)))) return rc;
+      pcv_launch_sample_tree_counts(ctx, nt, skeys_a, (uint32_t)ns, lv, params->resolution, thr_s, sp.force_mask, d_sample_counts);
+      host_lap("sample tree (counting) queued");
+    } else {
     if ((rc = pcv_radix_sort_u64(ctx, skeys_a, skeys_b, ns, 3 * (PCV_MAX_KEY_LEVELS - sample_levels), 3 * PCV_MAX_KEY_LEVELS,
                                  nullptr, bs->sort_scratch, &in_a)))
       return rc;
     host_lap("sample sort queued");
-    pcv_launch_node_split(ctx, nt, in_a ? skeys_a : skeys_b, false, (uint32_t)ns, lv, params->resolution,
-                          pcv_spec_sample_threshold(sp), sp.force_mask);
+    pcv_launch_node_split(ctx, nt, in_a ? skeys_a : skeys_b, false, (uint32_t)ns, lv, params->resolution, thr_s, sp.force_mask);
     host_lap("sample split queued");
+    }
     pcv_launch_spec_tree(ctx, nt, upper, sp.force_mask, d_ord, d_walk, d_sparent, d_slevel, d_info, d_pool_ctr);
     host_lap("spec tree queued");
     uint8_t* hs = (uint8_t*)ctx->pinned_spec;

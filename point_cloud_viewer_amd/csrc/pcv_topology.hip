@@ -130,11 +130,15 @@ __global__ __launch_bounds__(512) void split2_search_kernel(PcvNodeTableDev t, c
 // one level appended by the whole workgroup: `src(i, b)` fills the 9 bounds of the i-th open parent and returns its node
 // index; children are created in (parent, digit) order from index `running`; the open ones among them are listed (in
 // creation order) in out_list with `out_src` = 8 x (parent's list position) + digit. Returns through shared memory.
-template <typename Src>
+struct Split2NoHook {
+  __device__ __forceinline__ void operator()(uint32_t, uint32_t, uint32_t, int, bool, uint32_t) const {}
+};
+template <typename Src, typename Hook = Split2NoHook>
 __device__ __forceinline__ void split2_append_level(const PcvNodeTableDev& t, const PcvLevels& lv, double resolution, uint32_t max_points,
                                                     int k, uint32_t force_mask, uint32_t parents, Src src, uint32_t* out_list,
                                                     uint32_t* out_src, uint32_t* wave_tot, uint32_t* wave_open, uint32_t* running,
-                                                    uint32_t* running_open) {
+                                                    uint32_t* running_open,
+                                                    Hook hook = Hook() /* hook(child node, parent's list position, parent node, digit, open, its slot in out_list) */) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int shift = 3 * (PCV_MAX_KEY_LEVELS - k);
   for (uint32_t chunk = 0; chunk < parents; chunk += 1024) {
@@ -198,6 +202,7 @@ __device__ __forceinline__ void split2_append_level(const PcvNodeTableDev& t, co
           t.level[j] = (uint8_t)k;
           t.child_mask[j] = 0;
           t.open[j] = open ? 1 : 0;
+          hook(j, i, node, c, open, oslot);
           if (open) {
             if (oslot < t.max_open) {
               out_list[oslot] = j;
@@ -273,6 +278,162 @@ __global__ __launch_bounds__(1024) void split2_assign_kernel(PcvNodeTableDev t, 
     t.counters[CNT_LEVEL_START + k + 1] = level_k_end;
     t.counters[CNT_LEVEL_START + k + 2] = total_nodes;
     t.counters[CNT_OPEN + (cur ^ 1)] = running_open < t.max_open ? running_open : t.max_open;
+  }
+}
+
+// ---- the sample tree by COUNTING (round 5) -----------------------------------------------------------------------------------
+// The sample tree of the single-chain build came out of a five-pass key sort (15 launches) and a node split by binary search
+// in the sorted keys (12 launches): 0.28 ms of dependent 5-17 us launches for a table of a few thousand nodes. All the split
+// needs from the keys is HOW MANY of them carry each prefix the tree opens, so the keys are counted instead, three levels per
+// round (`group` g = levels 3 g + 1 .. 3 g + 3):
+//   sample_count_kernel   every key finds the open level-3g node above it — `slot` s — by g look-ups through the slot maps of
+//                         the groups above (map[g'][s' x 512 + the key's nine bits of group g'] = slot of the open node, or
+//                         NONE: nothing below a closed node is counted) and bumps its three counters of the slot: 8 + 64 + 512
+//                         per slot, global atomics (group 0: one slot, counted in LDS first). The same launch clears the
+//                         counters and the map of the NEXT group (they are only as big as the open nodes a level can have);
+//   sample_tree_kernel    ONE workgroup appends the group's three levels with split2_append_level — the code that lays out
+//                         the table from sorted keys: same (parent, digit) order, same open / forced / too-deep rules — taking
+//                         every child's count from the counters, and numbers the open nodes of level 3 g + 3 as the next
+//                         group's slots.
+// 2 x ceil(levels / 3) launches instead of 27, no sort. The node table is the one pcv_launch_node_split builds, except that
+// lo / hi hold running counts instead of positions in a sorted array (the predicted tree only takes hi - lo).
+constexpr uint32_t kSampleNone = 0xffffffffu;
+constexpr uint32_t kSlotCounters = 8 + 64 + 512;  // per slot: counts of the children, grandchildren, great-grandchildren
+struct SampleCountTables {
+  uint32_t* counts;  // [groups][max_open][kSlotCounters]
+  uint32_t* maps;    // [groups][max_open][512]
+  uint32_t* nslot;   // per node: the slot of the open group node above it (or its own, at a group boundary) ...
+  uint32_t* nq;      // ... and its digits below that node (0 .. 63)
+  uint32_t max_open;
+};
+__device__ __forceinline__ uint32_t* sample_counts(const SampleCountTables& c, int g) { return c.counts + (size_t)g * c.max_open * kSlotCounters; }
+__device__ __forceinline__ uint32_t* sample_map(const SampleCountTables& c, int g) { return c.maps + (size_t)g * c.max_open * 512u; }
+
+__global__ __launch_bounds__(256) void sample_count_kernel(const uint64_t* __restrict__ keys, uint32_t n, int g, int groups,
+                                                            SampleCountTables c) {
+  __shared__ uint32_t hist[kSlotCounters];
+  // the next group's tables (group 0's are cleared by sample_tree_init_kernel)
+  if (g + 1 < groups) {
+    uint32_t* nc = sample_counts(c, g + 1);
+    uint32_t* nm = sample_map(c, g + 1);
+    const size_t total_c = (size_t)c.max_open * kSlotCounters, total_m = (size_t)c.max_open * 512u;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total_c; i += (size_t)gridDim.x * 256) nc[i] = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total_m; i += (size_t)gridDim.x * 256) nm[i] = kSampleNone;
+  }
+  uint32_t* cnt = sample_counts(c, g);
+  if (g == 0) {
+    for (uint32_t i = threadIdx.x; i < kSlotCounters; i += 256) hist[i] = 0;
+    __syncthreads();
+  }
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const uint64_t key = keys[i];
+    uint32_t s = 0;
+    for (int q = 0; q < g && s != kSampleNone; ++q) {
+      const uint32_t bits = (uint32_t)(key >> (3 * (PCV_MAX_KEY_LEVELS - 3 * (q + 1)))) & 511u;
+      s = sample_map(c, q)[(size_t)s * 512u + bits];
+    }
+    if (s == kSampleNone) continue;
+    const int sh = 3 * (PCV_MAX_KEY_LEVELS - 3 * (g + 1));  // (negative for a last group that is cut short by the key width: the
+    const uint32_t bits = sh >= 0 ? (uint32_t)(key >> sh) & 511u : (uint32_t)(key << -sh) & 511u;  // missing digits count as 0)
+    if (g == 0) {
+      atomicAdd(&hist[bits >> 6], 1u);
+      atomicAdd(&hist[8 + (bits >> 3)], 1u);
+      atomicAdd(&hist[72 + bits], 1u);
+    } else {
+      uint32_t* row = cnt + (size_t)s * kSlotCounters;
+      atomicAdd(&row[bits >> 6], 1u);
+      atomicAdd(&row[8 + (bits >> 3)], 1u);
+      atomicAdd(&row[72 + bits], 1u);
+    }
+  }
+  if (g == 0) {
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < kSlotCounters; i += 256)
+      if (hist[i]) atomicAdd(&cnt[i], hist[i]);
+  }
+}
+
+// the root (init_root_kernel) + group 0's counters and map
+__global__ __launch_bounds__(256) void sample_tree_init_kernel(PcvNodeTableDev t, uint32_t n, SampleCountTables c) {
+  for (uint32_t i = threadIdx.x; i < kSlotCounters; i += 256) sample_counts(c, 0)[i] = 0;
+  for (uint32_t i = threadIdx.x; i < 512; i += 256) sample_map(c, 0)[i] = kSampleNone;
+  if (threadIdx.x == 0) {
+    t.prefix[0] = 0;
+    if (t.prefix_lo) t.prefix_lo[0] = 0;
+    t.lo[0] = 0;
+    t.hi[0] = n;
+    t.parent[0] = 0xffffffffu;
+    t.first_child[0] = 0;
+    t.level[0] = 0;
+    t.child_mask[0] = 0;
+    t.open[0] = n > 0 ? 1 : 0;
+    t.counters[CNT_NODES] = 1;
+    t.counters[CNT_ERROR] = 0;
+    t.counters[CNT_LEVEL_START + 0] = 0;
+    t.counters[CNT_LEVEL_START + 1] = 1;
+    t.counters[CNT_OPEN + 0] = n > 0 ? 1 : 0;
+    t.counters[CNT_OPEN + 1] = 0;
+    pcv_split2_open_list(t, 0)[0] = 0;
+    c.nslot[0] = 0;
+    c.nq[0] = 0;
+  }
+}
+
+__global__ __launch_bounds__(1024) void sample_tree_kernel(PcvNodeTableDev t, PcvLevels lv, double resolution, uint32_t max_points, int g,
+                                                            int cur /* which open list holds the open nodes of level 3 g */,
+                                                            uint32_t force_mask, SampleCountTables c) {
+  __shared__ uint32_t wave_tot[16], wave_open[16];
+  __shared__ uint32_t running, running_open;
+  const uint32_t* cnt = sample_counts(c, g);
+  uint32_t* map = sample_map(c, g);
+  if (threadIdx.x == 0) running = t.counters[CNT_NODES];
+  __syncthreads();
+  for (int r = 0; r < 3; ++r) {
+    const int k = 3 * g + r + 1;
+    if (k > lv.nlevels) break;  // (workgroup-uniform)
+    const uint32_t parents = t.counters[CNT_OPEN + cur] < t.max_open ? t.counters[CNT_OPEN + cur] : t.max_open;
+    const uint32_t* cur_list = pcv_split2_open_list(t, cur);
+    uint32_t* next_list = pcv_split2_open_list(t, cur ^ 1);
+    const uint32_t off = r == 0 ? 0u : r == 1 ? 8u : 72u;
+    if (threadIdx.x == 0) running_open = 0;
+    __syncthreads();
+    split2_append_level(
+        t, lv, resolution, max_points, k, force_mask, parents,
+        [&](uint32_t i, uint32_t (&b)[9]) {
+          const uint32_t node = cur_list[i];
+          const uint32_t* row = cnt + (size_t)c.nslot[node] * kSlotCounters + off + c.nq[node] * 8u;
+          b[0] = 0;
+#pragma unroll
+          for (int ch = 0; ch < 8; ++ch) b[ch + 1] = b[ch] + row[ch];
+          if (r == 2) {  // below closed or missing children nothing is counted in the next group
+            uint32_t* m = map + (size_t)c.nslot[node] * 512u + c.nq[node] * 8u;
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch) m[ch] = kSampleNone;
+          }
+          return node;
+        },
+        next_list, nullptr, wave_tot, wave_open, &running, &running_open,
+        [&](uint32_t j, uint32_t, uint32_t node, int ch, bool open, uint32_t oslot) {
+          const uint32_t s = c.nslot[node], q = c.nq[node] * 8u + (uint32_t)ch;
+          if (r < 2) {
+            c.nslot[j] = s;
+            c.nq[j] = q;
+          } else {  // a group boundary: the open node is a slot of the next group (its position among the level's open nodes)
+            c.nslot[j] = open && oslot < t.max_open ? oslot : 0u;
+            c.nq[j] = 0;
+            if (open && oslot < t.max_open) map[(size_t)s * 512u + q] = oslot;
+          }
+        });
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const uint32_t end = running < t.capacity ? running : t.capacity;
+      t.counters[CNT_NODES] = end;
+      t.counters[CNT_LEVEL_START + k + 1] = end;
+      t.counters[CNT_OPEN + (cur ^ 1)] = running_open < t.max_open ? running_open : t.max_open;
+    }
+    __threadfence_block();
+    __syncthreads();  // the next level reads the list and the counters this one wrote (same workgroup)
+    cur ^= 1;
   }
 }
 
@@ -678,6 +839,37 @@ void pcv_launch_spec_tree(pcv_ctx* ctx, const PcvNodeTableDev& t, double upper, 
   hipLaunchKernelGGL(spec_tree_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, t, ord, info, pool_ctr);
   hipLaunchKernelGGL(spec_tree_emit_kernel, dim3(64), dim3(256), 0, ctx->stream, t, ord, upper, force_mask, walk, sparent, slevel,
                      info);
+}
+
+size_t pcv_sample_count_scratch_words(uint32_t capacity, uint32_t max_open, int nlevels) {
+  const size_t groups = (size_t)(nlevels + 2) / 3;
+  return groups * (size_t)max_open * (kSlotCounters + 512u) + 2 * (size_t)capacity;
+}
+void pcv_launch_sample_tree_counts(pcv_ctx* ctx, const PcvNodeTableDev& t, const uint64_t* keys, uint32_t n, const PcvLevels& lv,
+                                   double resolution, uint32_t max_points_per_node, uint32_t force_split_level1_mask, uint32_t* scratch) {
+  hipStream_t s = ctx->stream;
+  const int groups = (lv.nlevels + 2) / 3;
+  SampleCountTables c;
+  c.max_open = t.max_open;
+  c.counts = scratch;
+  c.maps = c.counts + (size_t)groups * c.max_open * kSlotCounters;
+  c.nslot = c.maps + (size_t)groups * c.max_open * 512u;
+  c.nq = c.nslot + t.capacity;
+  hipLaunchKernelGGL(sample_tree_init_kernel, dim3(1), dim3(256), 0, s, t, n, c);
+  const unsigned grid = (unsigned)std::min<uint64_t>(512, ((uint64_t)n + 1023) / 1024 + 1);
+  int cur = 0;
+  for (int g = 0; g < groups; ++g) {
+    {
+      PcvProf prof(ctx, PCV_K_SPLIT_SEARCH);
+      hipLaunchKernelGGL(sample_count_kernel, dim3(grid), dim3(256), 0, s, keys, n, g, groups, c);
+    }
+    {
+      PcvProf prof(ctx, PCV_K_SPLIT_ASSIGN);
+      hipLaunchKernelGGL(sample_tree_kernel, dim3(1), dim3(1024), 0, s, t, lv, resolution, max_points_per_node, g, cur, force_split_level1_mask, c);
+    }
+    const int levels_here = std::min(3, lv.nlevels - 3 * g);
+    if (levels_here & 1) cur ^= 1;  // the open list flips once per level
+  }
 }
 
 void pcv_launch_pack_node_table(pcv_ctx* ctx, const PcvNodeTableDev& t, void* packed) {
