@@ -1261,7 +1261,10 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
     const uint32_t thr_s = pcv_spec_sample_threshold(sp);
     if (counts_on && thr_s > 0 && nt.max_open >= ns / thr_s + 16 && sample_levels <= PCV_MAX_KEY_LEVELS) {
       if (!d_sample_counts && (rc = sc.get(&d_sample_counts, pcv_sample_count_scratch_words(nt.capacity, nt.max_open, full_levels)))) return rc;
-      pcv_launch_sample_tree_counts(ctx, nt, skeys_a, (uint32_t)ns, lv, params->resolution, thr_s, sp.force_mask, d_sample_counts);
+      // (a count only matters up to the larger of the split threshold and the candidate band's upper end)
+      const double sat_d = std::fmax((double)thr_s, std::ceil(upper)) + 2.0;
+      const uint32_t sat = sat_d >= 4294967000.0 ? 0xfffffff0u : (uint32_t)sat_d;
+      pcv_launch_sample_tree_counts(ctx, nt, skeys_a, (uint32_t)ns, lv, params->resolution, thr_s, sp.force_mask, d_sample_counts, sat);
       host_lap("sample tree (counting) queued");
     } else {
     if ((rc = pcv_radix_sort_u64(ctx, skeys_a, skeys_b, ns, 3 * (PCV_MAX_KEY_LEVELS - sample_levels), 3 * PCV_MAX_KEY_LEVELS,

@@ -364,7 +364,8 @@ void pcv_launch_pack_node_table(pcv_ctx* ctx, const PcvNodeTableDev& t, void* pa
 // (pcv_topology.hip); scratch: pcv_sample_count_scratch_words() u32. Needs t.max_open > 0 and one-word keys.
 size_t pcv_sample_count_scratch_words(uint32_t capacity, uint32_t max_open, int nlevels);
 void pcv_launch_sample_tree_counts(pcv_ctx* ctx, const PcvNodeTableDev& t, const uint64_t* keys, uint32_t n, const PcvLevels& lv,
-                                   double resolution, uint32_t max_points_per_node, uint32_t force_split_level1_mask, uint32_t* scratch);
+                                   double resolution, uint32_t max_points_per_node, uint32_t force_split_level1_mask, uint32_t* scratch,
+                                   uint32_t saturate_above /* counters may stop growing beyond this: above the split threshold AND the candidate band */);
 // single-chain build: predicted tree on the device from the sample's node table. ord: capacity u32 of scratch; walk /
 // sparent: 1 + 8 x capacity u32; slevel: 1 + 8 x capacity bytes; info: 4 u32 (nodes, split error flags, sample nodes,
 // any candidate)

@@ -309,7 +309,22 @@ struct SampleCountTables {
 __device__ __forceinline__ uint32_t* sample_counts(const SampleCountTables& c, int g) { return c.counts + (size_t)g * c.max_open * kSlotCounters; }
 __device__ __forceinline__ uint32_t* sample_map(const SampleCountTables& c, int g) { return c.maps + (size_t)g * c.max_open * 512u; }
 
-__global__ __launch_bounds__(256) void sample_count_kernel(const uint64_t* __restrict__ keys, uint32_t n, int g, int groups,
+// one counter bump per group of lanes that hold the same counter (the sample keys of a clustered cloud crowd into a few
+// cells: left to themselves, 1.5 M keys put 10^5 atomics on ONE address of group 1, and same-address atomics retire one
+// after the other — 0.54 ms for that launch). The leader also skips the bump once the counter has passed `sat`: the
+// split only asks "more than the threshold?" and "inside the band?", a count beyond both may stop growing.
+__device__ __forceinline__ void sample_bump_grouped(uint32_t* __restrict__ cnt, uint32_t idx, bool valid, uint32_t sat, int lane) {
+  uint64_t rem = __ballot(valid);
+  while (rem) {  // wave-uniform
+    const int leader = (int)__builtin_ctzll(rem);
+    const uint32_t i0 = (uint32_t)__builtin_amdgcn_readlane((int)idx, leader);
+    const uint64_t same = __ballot(valid && idx == i0);
+    if (lane == leader && cnt[i0] <= sat) atomicAdd(&cnt[i0], (uint32_t)__popcll(same));
+    rem &= ~same;
+  }
+}
+
+__global__ __launch_bounds__(256) void sample_count_kernel(const uint64_t* __restrict__ keys, uint32_t n, int g, int groups, uint32_t sat,
                                                             SampleCountTables c) {
   __shared__ uint32_t hist[kSlotCounters];
   // the next group's tables (group 0's are cleared by sample_tree_init_kernel)
@@ -321,29 +336,35 @@ __global__ __launch_bounds__(256) void sample_count_kernel(const uint64_t* __res
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total_m; i += (size_t)gridDim.x * 256) nm[i] = kSampleNone;
   }
   uint32_t* cnt = sample_counts(c, g);
+  const int lane = threadIdx.x & 63;
   if (g == 0) {
     for (uint32_t i = threadIdx.x; i < kSlotCounters; i += 256) hist[i] = 0;
     __syncthreads();
   }
-  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    const uint64_t key = keys[i];
-    uint32_t s = 0;
-    for (int q = 0; q < g && s != kSampleNone; ++q) {
+  const int sh = 3 * (PCV_MAX_KEY_LEVELS - 3 * (g + 1));  // >= 0: at most 7 groups of three levels in a key word
+  const uint32_t per = (n + gridDim.x * 256u - 1u) / (gridDim.x * 256u);  // the same trip count for every lane (the ballots)
+  for (uint32_t it = 0; it < per; ++it) {
+    const uint32_t i = (it * gridDim.x + blockIdx.x) * 256u + threadIdx.x;
+    const bool in = i < n;
+    const uint64_t key = in ? keys[i] : 0ull;
+    uint32_t s = in ? 0u : kSampleNone;
+    for (int q = 0; q < g; ++q) {
       const uint32_t bits = (uint32_t)(key >> (3 * (PCV_MAX_KEY_LEVELS - 3 * (q + 1)))) & 511u;
-      s = sample_map(c, q)[(size_t)s * 512u + bits];
+      if (s != kSampleNone) s = sample_map(c, q)[(size_t)s * 512u + bits];
     }
-    if (s == kSampleNone) continue;
-    const int sh = 3 * (PCV_MAX_KEY_LEVELS - 3 * (g + 1));  // (negative for a last group that is cut short by the key width: the
-    const uint32_t bits = sh >= 0 ? (uint32_t)(key >> sh) & 511u : (uint32_t)(key << -sh) & 511u;  // missing digits count as 0)
+    const bool valid = s != kSampleNone;
+    const uint32_t bits = (uint32_t)(key >> sh) & 511u;
     if (g == 0) {
-      atomicAdd(&hist[bits >> 6], 1u);
-      atomicAdd(&hist[8 + (bits >> 3)], 1u);
-      atomicAdd(&hist[72 + bits], 1u);
+      if (valid) {
+        atomicAdd(&hist[bits >> 6], 1u);
+        atomicAdd(&hist[8 + (bits >> 3)], 1u);
+        atomicAdd(&hist[72 + bits], 1u);
+      }
     } else {
-      uint32_t* row = cnt + (size_t)s * kSlotCounters;
-      atomicAdd(&row[bits >> 6], 1u);
-      atomicAdd(&row[8 + (bits >> 3)], 1u);
-      atomicAdd(&row[72 + bits], 1u);
+      const uint32_t row = valid ? s * kSlotCounters : 0u;
+      sample_bump_grouped(cnt, row + (bits >> 6), valid, sat, lane);
+      sample_bump_grouped(cnt, row + 8u + (bits >> 3), valid, sat, lane);
+      if (valid && cnt[row + 72u + bits] <= sat) atomicAdd(&cnt[row + 72u + bits], 1u);  // 512 per slot: mostly one lane each
     }
   }
   if (g == 0) {
@@ -846,7 +867,8 @@ size_t pcv_sample_count_scratch_words(uint32_t capacity, uint32_t max_open, int 
   return groups * (size_t)max_open * (kSlotCounters + 512u) + 2 * (size_t)capacity;
 }
 void pcv_launch_sample_tree_counts(pcv_ctx* ctx, const PcvNodeTableDev& t, const uint64_t* keys, uint32_t n, const PcvLevels& lv,
-                                   double resolution, uint32_t max_points_per_node, uint32_t force_split_level1_mask, uint32_t* scratch) {
+                                   double resolution, uint32_t max_points_per_node, uint32_t force_split_level1_mask, uint32_t* scratch,
+                                   uint32_t saturate_above) {
   hipStream_t s = ctx->stream;
   const int groups = (lv.nlevels + 2) / 3;
   SampleCountTables c;
@@ -861,7 +883,7 @@ void pcv_launch_sample_tree_counts(pcv_ctx* ctx, const PcvNodeTableDev& t, const
   for (int g = 0; g < groups; ++g) {
     {
       PcvProf prof(ctx, PCV_K_SPLIT_SEARCH);
-      hipLaunchKernelGGL(sample_count_kernel, dim3(grid), dim3(256), 0, s, keys, n, g, groups, c);
+      hipLaunchKernelGGL(sample_count_kernel, dim3(grid), dim3(256), 0, s, keys, n, g, groups, saturate_above, c);
     }
     {
       PcvProf prof(ctx, PCV_K_SPLIT_ASSIGN);
