@@ -314,12 +314,15 @@ __device__ __forceinline__ uint32_t* sample_map(const SampleCountTables& c, int 
 // after the other — 0.54 ms for that launch). The leader also skips the bump once the counter has passed `sat`: the
 // split only asks "more than the threshold?" and "inside the band?", a count beyond both may stop growing.
 __device__ __forceinline__ void sample_bump_grouped(uint32_t* __restrict__ cnt, uint32_t idx, bool valid, uint32_t sat, int lane) {
-  uint64_t rem = __ballot(valid);
+  // every lane looks at its own counter first (one load latency for the wave, a stale value only costs a bump too many);
+  // the grouping loop below is register work only
+  const bool want = valid && cnt[idx] <= sat;
+  uint64_t rem = __ballot(want);
   while (rem) {  // wave-uniform
     const int leader = (int)__builtin_ctzll(rem);
     const uint32_t i0 = (uint32_t)__builtin_amdgcn_readlane((int)idx, leader);
-    const uint64_t same = __ballot(valid && idx == i0);
-    if (lane == leader && cnt[i0] <= sat) atomicAdd(&cnt[i0], (uint32_t)__popcll(same));
+    const uint64_t same = __ballot(want && idx == i0);
+    if (lane == leader) atomicAdd(&cnt[i0], (uint32_t)__popcll(same));
     rem &= ~same;
   }
 }
