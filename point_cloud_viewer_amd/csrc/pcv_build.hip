@@ -1251,14 +1251,17 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
     pcv_launch_chain_keys(ctx, lv, ns, stride, d.x, d.y, d.z, skeys_a, false, d.routed, stride > 1 ? clump_shift : 0u);
     bool in_a = true;
     host_lap("", true);
-    // The sample tree by counting the keys, three levels per launch pair (round 5, pcv_topology.hip): no sort, 2 x ceil(levels / 3)
-    // launches instead of 27. Taken whenever a level's open nodes fit the slot tables (an open sample node holds more than
-    // `threshold` keys); PCV_SAMPLE_COUNTS=0 (libpcv_hip_exp.so): the key sort + split by binary search of rounds 2-4.
+    // PCV_SAMPLE_COUNTS=1 (libpcv_hip_exp.so only): the sample tree by COUNTING the keys, three levels per launch pair
+    // (pcv_topology.hip): 9 launches instead of 27 and no sort — and 2-3 x SLOWER, measured: the 1.5 M keys cost 4.7 M
+    // device-scope atomics per group of levels and this part retires ~9 G of those per second (0.54 + 0.38 ms for the two
+    // middle groups against 0.28 ms for the whole key sort + split; profiles/r05_ab_sample_tree_by_counting_dropped.json)
+    const uint32_t thr_s = pcv_spec_sample_threshold(sp);
+    bool counted = false;
+#ifdef PCV_EXPERIMENTS
     static const bool counts_on = [] {
       const char* e = pcv_experiment("PCV_SAMPLE_COUNTS");
-      return !e || atoi(e) != 0;
+      return e && atoi(e) != 0;
     }();
-    const uint32_t thr_s = pcv_spec_sample_threshold(sp);
     if (counts_on && thr_s > 0 && nt.max_open >= ns / thr_s + 16 && sample_levels <= PCV_MAX_KEY_LEVELS) {
       if (!d_sample_counts && (rc = sc.get(&d_sample_counts, pcv_sample_count_scratch_words(nt.capacity, nt.max_open, full_levels)))) return rc;
       // (a count only matters up to the larger of the split threshold and the candidate band's upper end)
@@ -1266,7 +1269,10 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
       const uint32_t sat = sat_d >= 4294967000.0 ? 0xfffffff0u : (uint32_t)sat_d;
       pcv_launch_sample_tree_counts(ctx, nt, skeys_a, (uint32_t)ns, lv, params->resolution, thr_s, sp.force_mask, d_sample_counts, sat);
       host_lap("sample tree (counting) queued");
-    } else {
+      counted = true;
+    }
+#endif
+    if (!counted) {
     if ((rc = pcv_radix_sort_u64(ctx, skeys_a, skeys_b, ns, 3 * (PCV_MAX_KEY_LEVELS - sample_levels), 3 * PCV_MAX_KEY_LEVELS,
                                  nullptr, bs->sort_scratch, &in_a)))
       return rc;

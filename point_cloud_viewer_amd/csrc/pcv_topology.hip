@@ -281,8 +281,10 @@ __global__ __launch_bounds__(1024) void split2_assign_kernel(PcvNodeTableDev t, 
   }
 }
 
+#ifdef PCV_EXPERIMENTS  // measured slower than sort + split (see the note at the call site, pcv_build.hip): experiment library only
 // ---- the sample tree by COUNTING (round 5) -----------------------------------------------------------------------------------
-// The sample tree of the single-chain build came out of a five-pass key sort (15 launches) and a node split by binary search
+// MEASURED AND DROPPED (2-3 x slower than what it replaces: global atomics). The idea:
+// The sample tree of the single-chain build comes out of a five-pass key sort (15 launches) and a node split by binary search
 // in the sorted keys (12 launches): 0.28 ms of dependent 5-17 us launches for a table of a few thousand nodes. All the split
 // needs from the keys is HOW MANY of them carry each prefix the tree opens, so the keys are counted instead, three levels per
 // round (`group` g = levels 3 g + 1 .. 3 g + 3):
@@ -460,6 +462,8 @@ __global__ __launch_bounds__(1024) void sample_tree_kernel(PcvNodeTableDev t, Pc
     cur ^= 1;
   }
 }
+
+#endif  // PCV_EXPERIMENTS
 
 // (A) child boundaries of every open node of level k-1.
 template <typename KeyT>
@@ -865,6 +869,7 @@ void pcv_launch_spec_tree(pcv_ctx* ctx, const PcvNodeTableDev& t, double upper, 
                      info);
 }
 
+#ifdef PCV_EXPERIMENTS
 size_t pcv_sample_count_scratch_words(uint32_t capacity, uint32_t max_open, int nlevels) {
   const size_t groups = (size_t)(nlevels + 2) / 3;
   return groups * (size_t)max_open * (kSlotCounters + 512u) + 2 * (size_t)capacity;
@@ -896,6 +901,8 @@ void pcv_launch_sample_tree_counts(pcv_ctx* ctx, const PcvNodeTableDev& t, const
     if (levels_here & 1) cur ^= 1;  // the open list flips once per level
   }
 }
+
+#endif  // PCV_EXPERIMENTS
 
 void pcv_launch_pack_node_table(pcv_ctx* ctx, const PcvNodeTableDev& t, void* packed) {
   hipLaunchKernelGGL(pack_node_table_kernel, dim3(64), dim3(256), 0, ctx->stream, t, (uint8_t*)packed);

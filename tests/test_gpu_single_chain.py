@@ -282,8 +282,8 @@ print("alt-path ok")
                                               ({"PCV_CHAIN_V": "3"}, 12), ({"PCV_CODE_STEPS": "0"}, 12),
                                               # the write-combining form of the record downsweep, both passes (experiment)
                                               ({"PCV_REC_WC": "3"}, 12),
-                                              # the sample tree from sorted keys (rounds 2-4) instead of by counting
-                                              ({"PCV_SAMPLE_COUNTS": "0"}, 12),
+                                              # the sample tree by counting the keys instead of from sorted keys (experiment, slower)
+                                              ({"PCV_SAMPLE_COUNTS": "1"}, 12),
                                               # the sample tree split one level per launch pair (what u32 keys and levels
                                               # beyond the first key word still take)
                                               ({"PCV_SPLIT2": "0"}, 12)])
