@@ -54,7 +54,7 @@ def test_build_hash_follows_the_sources(tmp_path, monkeypatch):
     dst = tmp_path / "point_cloud_viewer_amd" / "csrc"
     os.makedirs(dst)
     for name in os.listdir(src):
-        if name.endswith((".hip", ".h", ".cpp")) or name == "Makefile":
+        if name.endswith((".hip", ".h", ".cpp", ".inc")) or name == "Makefile":
             shutil.copy(os.path.join(src, name), dst / name)
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     assert bench.build_hash() == h
