@@ -82,6 +82,9 @@ extern "C" {
     fn pcv_shapes_create(ctx: *mut pcv_ctx, shapes: *const PcvShape, count: u32, out: *mut *mut pcv_shapes) -> c_int;
     fn pcv_shapes_free(s: *mut pcv_shapes);
     fn pcv_visible_nodes(ctx: *mut pcv_ctx, frusta: *const pcv_shapes, t: *mut pcv_octree, capacity: u32, counts: *mut u32, node_indices: *mut u32, status: *mut i32) -> c_int;
+    // per frustum the nodes whose Relation is not Out, with relation and relative_size_on_screen (octree/mod.rs:119-139, 261-272)
+    #[allow(dead_code)]
+    fn pcv_cull_nodes_sparse(ctx: *mut pcv_ctx, shapes: *const pcv_shapes, t: *mut pcv_octree, capacity: u32, counts: *mut u32, node_indices: *mut u32, relation: *mut u8, size_on_screen: *mut c_double) -> c_int;
     fn pcv_nodes_in_location(ctx: *mut pcv_ctx, shapes: *const pcv_shapes, t: *mut pcv_octree, capacity: u32, counts: *mut u32, node_indices: *mut u32) -> c_int;
     fn pcv_query_node_points(ctx: *mut pcv_ctx, shapes: *const pcv_shapes, shape_index: u32, t: *mut pcv_octree, node: u64, interval: *const c_double, capacity: u64, mem: c_int, x: *mut c_double, y: *mut c_double, z: *mut c_double, rgb: *mut u8, intensity: *mut c_float, count: *mut u64) -> c_int;
     fn pcv_octree_has_intensity(t: *const pcv_octree) -> c_int;
