@@ -414,6 +414,8 @@ def sharded_leg(args, torch, pcv, ctx, dev, x, y, z, rgb, want_digest, steps=5, 
                 builder.build(args.resolution, bbox, x, y, z, rgb).free()
             dist.barrier()
             torch.cuda.synchronize()
+            ctx.set_profiling("major")
+            ctx.reset_kernel_stats()
             t0 = time.perf_counter()
             for _ in range(steps):
                 r = builder.build(args.resolution, bbox, x, y, z, rgb)
@@ -422,11 +424,13 @@ def sharded_leg(args, torch, pcv, ctx, dev, x, y, z, rgb, want_digest, steps=5, 
             dist.barrier()
             torch.cuda.synchronize()
             ms = (time.perf_counter() - t0) / steps * 1e3
+            ctx.set_profiling(False)
+            kms = {k: round(v[1] / steps, 3) for k, v in ctx.kernel_stats().items() if v[0] > 0}
             r = builder.build(args.resolution, bbox, x, y, z, rgb)
             dig = digest_of_digests(sharded_digests(r))
             r.free()
             w1[mode] = {"ms_per_step": round(ms, 3), "Mpoints_per_s": round(n / (ms * 1e-3) / 1e6, 1), "stage_ms": ex["ms"],
-                        "rows_sent": ex["rows_sent"], "rows_received": ex["rows_received"], "tree_digest": dig,
+                        "kernel_ms_per_step": kms, "rows_sent": ex["rows_sent"], "rows_received": ex["rows_received"], "tree_digest": dig,
                         "digest_equal": dig == want_digest}
         out["world1"] = dict(w1["octants"], rccl_ranks=1, shard_mode="octants", buckets=w1["buckets"])
     finally:
