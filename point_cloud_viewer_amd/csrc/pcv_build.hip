@@ -1176,7 +1176,8 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
   // The predicted tree is built on the device (sample split -> spec_tree kernels): the one chain pass starts without a
   // host round trip, and the host mirrors the tree (one small asynchronous copy) while that pass runs.
   constexpr uint32_t kFirst = 16384;  // T'' nodes mirrored by the first copy (a 100 M-point tree has ~7 500)
-  const size_t tcap = 1 + 8 * (size_t)nt.capacity;  // T'' nodes at most
+  // T'' nodes at most (at least 4 096 records: the chain pass may mirror the table's first 2 048 in LDS without asking how many exist)
+  const size_t tcap = std::max<size_t>(1 + 8 * (size_t)nt.capacity, 4096);
   uint32_t *d_ord, *d_walk, *d_sparent, *d_info, *d_counts, *d_map, *d_pool_ctr;
   uint8_t* d_slevel;
   if ((rc = sc.get(&d_ord, nt.capacity)) || (rc = sc.get(&d_walk, tcap)) || (rc = sc.get(&d_sparent, tcap)) ||

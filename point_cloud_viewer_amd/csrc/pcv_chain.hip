@@ -519,8 +519,16 @@ __global__ __launch_bounds__(256) void route_scatter_kernel(PcvLevels lv, uint64
       const uint32_t d = d1[i];
       const double mx = pcv_step_min(lv.root_min[0], (d & 4u) != 0u, e1), my = pcv_step_min(lv.root_min[1], (d & 2u) != 0u, e1),
                    mz = pcv_step_min(lv.root_min[2], (d & 1u) != 0u, e1);
-      const double cx = pcv_encode_val<PCV_ENC_FLOAT32, true>(x[idx], mx, e1, r1), cy = pcv_encode_val<PCV_ENC_FLOAT32, true>(y[idx], my, e1, r1),
-                   cz = pcv_encode_val<PCV_ENC_FLOAT32, true>(z[idx], mz, e1, r1);
+      // (round 5: a tame point in a tame table takes the unguarded quotient — the same value, one range test instead of three)
+      const double px = x[idx], py = y[idx], pz = z[idx];
+      double cx, cy, cz;
+      if (lv.fast_ok && pcv_point_is_tame(px, py, pz)) {
+        cx = pcv_encode_val<PCV_ENC_FLOAT32, false>(px, mx, e1, r1), cy = pcv_encode_val<PCV_ENC_FLOAT32, false>(py, my, e1, r1),
+        cz = pcv_encode_val<PCV_ENC_FLOAT32, false>(pz, mz, e1, r1);
+      } else {
+        cx = pcv_encode_val<PCV_ENC_FLOAT32, true>(px, mx, e1, r1), cy = pcv_encode_val<PCV_ENC_FLOAT32, true>(py, my, e1, r1),
+        cz = pcv_encode_val<PCV_ENC_FLOAT32, true>(pz, mz, e1, r1);
+      }
       const uint8_t* c = color + idx * color_stride;
       sp[0][o][pos] = d | ((uint32_t)c[0] << 8) | ((uint32_t)c[1] << 16) | ((uint32_t)c[2] << 24);
       sp[1][o][pos] = __float_as_uint((float)cx);  // value domain -> Float32 bit pattern (exact: cx is a float value)

@@ -225,7 +225,13 @@ __device__ __forceinline__ uint32_t pcv_lane_again() {  // the lane number, reco
 //     bounds and the pool region are 32-bit / scalar arithmetic; intensity bits are copied in input order by the closing
 //     phase (coalesced) instead of by the dealt lanes.
 // Same walk, same records, same bytes.
-#define CP_WALK_AT(idx) walk[(idx)]
+/* walk record of T'' node `idx`: the first TOP records (T'' is level-major: the top of the tree) are mirrored in LDS */
+#define CP_WALK_AT(idx) cp_walk_at<TOP>(walk, swalk, (idx))
+template <int TOP>
+__device__ __forceinline__ uint32_t cp_walk_at(const uint32_t* __restrict__ walk, const uint32_t* swalk, uint32_t idx) {
+  if (TOP == 0) return walk[idx];
+  return idx < (uint32_t)TOP ? swalk[idx] : walk[idx];
+}
 #define CP_KEEP_STEP                                                                                                    \
   if (KEEP) {                                                                                                           \
     const bool take = (rec & PCV_SPEC_CANDIDATE) && kl == 0;                                                            \
@@ -342,7 +348,7 @@ __device__ __forceinline__ uint32_t pcv_lane_again() {  // the lane number, reco
     CP_LOOP(true, lv.nlevels, , pcv_chain_apply_bits<true>(lv.enc[U + 1], b, ec, ic, px, py, pz, mx, my, mz, vx, vy, vz)) \
   }
 
-template <bool KEEP, bool RAW, int BLOCK>
+template <bool KEEP, bool RAW, int BLOCK, int TOP = 0 /* walk records mirrored in LDS (a multiple of 4 x BLOCK, or 0) */>
 __global__ __launch_bounds__(BLOCK, 8) void chain_pass_kernel(
     PcvLevels lv, const uint32_t* __restrict__ walk, uint64_t n, const double* __restrict__ x, const double* __restrict__ y,
     const double* __restrict__ z, PcvRouted routed, const uint8_t* __restrict__ color, uint32_t color_stride,
@@ -355,6 +361,8 @@ __global__ __launch_bounds__(BLOCK, 8) void chain_pass_kernel(
   __shared__ double sxyz[3 * TILE];  // slot s: half s / BLOCK, {x, y, z}[s % BLOCK]
   __shared__ uint16_t sidx[TILE];
   __shared__ uint32_t kcnt[32];  // points of the tile per depth class
+  __shared__ uint32_t swalk[TOP ? TOP : 4];
+  static_assert(TOP % (4 * BLOCK) == 0, "one uint4 per lane and round");
   // the first half of the coordinates is dead once every wave has fetched its first group: it stages the tile's records
   uint32_t* const okey = reinterpret_cast<uint32_t*>(sxyz);    // TILE keys: the x of the first half
   uint2* const opay = reinterpret_cast<uint2*>(sxyz + BLOCK);  // TILE payloads: its y and z
@@ -380,6 +388,13 @@ __global__ __launch_bounds__(BLOCK, 8) void chain_pass_kernel(
         (void)pcv_chain_start(lv, routed, x, y, z, base + t, qx[h], qy[h], qz[h], t0, t1, t2, t3, t4, t5, dd);
       }
     }
+  }
+  // the top of the walk table: requested behind the coordinates, stored to LDS before the deal's last barrier (the buffer is
+  // allocated for at least 1 + 8 x 8 192 records: reading past the tree's last node is harmless, never indexed)
+  uint4 wtop[TOP ? TOP / (4 * BLOCK) : 1];
+  if (TOP) {
+#pragma unroll
+    for (int k = 0; k < TOP / (4 * BLOCK); ++k) wtop[k] = reinterpret_cast<const uint4*>(walk)[k * BLOCK + tid];
   }
   __syncthreads();  // the counters are zero (the coordinate loads are in flight)
   uint32_t key[2], pos[2], wild[2];
@@ -418,6 +433,11 @@ __global__ __launch_bounds__(BLOCK, 8) void chain_pass_kernel(
       c[0] = qx[h], c[BLOCK] = qy[h], c[2 * BLOCK] = qz[h];
     }
     sidx[slot] = (uint16_t)((uint32_t)(h * BLOCK + tid) | wild[h]);
+  }
+  if (TOP) {
+    tid = wave * 64 + (int)pcv_lane_again();
+#pragma unroll
+    for (int k = 0; k < TOP / (4 * BLOCK); ++k) reinterpret_cast<uint4*>(swalk)[k * BLOCK + tid] = wtop[k];
   }
   __syncthreads();
   const uint32_t rec0 = walk[0];  // the root's record (scalar)
@@ -1081,6 +1101,21 @@ void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* w
   const float cells = lv.edge[0] > 0.0 ? (float)((double)(1 << kGridBits) / lv.edge[0]) : 0.f;
   const uint32_t pool_cap = (uint32_t)pcv_pool_region_entries(n);
   if (depth_grid) hipLaunchKernelGGL(spec_depth_grid_kernel, dim3((1u << (3 * kGridBits)) / 256), dim3(256), 0, ctx->stream, walk, depth_grid);
+#ifdef PCV_EXPERIMENTS
+  static const int chain_top = [] {  // PCV_CHAIN_TOP=2048 / 4096: that many walk records mirrored in LDS (raw input)
+    const char* e = pcv_experiment("PCV_CHAIN_TOP");
+    return e ? atoi(e) : 0;
+  }();
+  if (!routed.oct && (chain_top == 2048 || chain_top == 4096)) {
+    if (chain_top == 2048)
+      hipLaunchKernelGGL((chain_pass_kernel<true, true, kBlock, 2048>), grid, dim3(kBlock), 0, ctx->stream, lv, walk, n, x, y, z, routed, color,
+                         color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr, pool_cap);
+    else
+      hipLaunchKernelGGL((chain_pass_kernel<true, true, kBlock, 4096>), grid, dim3(kBlock), 0, ctx->stream, lv, walk, n, x, y, z, routed, color,
+                         color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr, pool_cap);
+    return;
+  }
+#endif
   if (!routed.oct)
     hipLaunchKernelGGL((chain_pass_kernel<true, true, kBlock>), grid, dim3(kBlock), 0, ctx->stream, lv, walk, n, x, y, z, routed, color, color_stride,
                        intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr, pool_cap);
