@@ -362,7 +362,8 @@ __global__ __launch_bounds__(BLOCK, 8) void chain_pass_kernel(
   __shared__ uint16_t sidx[TILE];
   __shared__ uint32_t kcnt[32];  // points of the tile per depth class
   __shared__ uint32_t swalk[TOP ? TOP : 4];
-  static_assert(TOP % (4 * BLOCK) == 0, "one uint4 per lane and round");
+  static_assert(TOP % 256 == 0, "whole waves of uint4 loads");
+  constexpr int kTopRounds = (TOP + 4 * BLOCK - 1) / (4 * BLOCK);
   // the first half of the coordinates is dead once every wave has fetched its first group: it stages the tile's records
   uint32_t* const okey = reinterpret_cast<uint32_t*>(sxyz);    // TILE keys: the x of the first half
   uint2* const opay = reinterpret_cast<uint2*>(sxyz + BLOCK);  // TILE payloads: its y and z
@@ -391,10 +392,11 @@ __global__ __launch_bounds__(BLOCK, 8) void chain_pass_kernel(
   }
   // the top of the walk table: requested behind the coordinates, stored to LDS before the deal's last barrier (the buffer is
   // allocated for at least 1 + 8 x 8 192 records: reading past the tree's last node is harmless, never indexed)
-  uint4 wtop[TOP ? TOP / (4 * BLOCK) : 1];
+  uint4 wtop[TOP ? kTopRounds : 1];
   if (TOP) {
 #pragma unroll
-    for (int k = 0; k < TOP / (4 * BLOCK); ++k) wtop[k] = reinterpret_cast<const uint4*>(walk)[k * BLOCK + tid];
+    for (int k = 0; k < kTopRounds; ++k)
+      if ((k * BLOCK + tid) * 4 < TOP) wtop[k] = reinterpret_cast<const uint4*>(walk)[k * BLOCK + tid];  // (wave-uniform)
   }
   __syncthreads();  // the counters are zero (the coordinate loads are in flight)
   uint32_t key[2], pos[2], wild[2];
@@ -437,7 +439,8 @@ __global__ __launch_bounds__(BLOCK, 8) void chain_pass_kernel(
   if (TOP) {
     tid = wave * 64 + (int)pcv_lane_again();
 #pragma unroll
-    for (int k = 0; k < TOP / (4 * BLOCK); ++k) reinterpret_cast<uint4*>(swalk)[k * BLOCK + tid] = wtop[k];
+    for (int k = 0; k < kTopRounds; ++k)
+      if ((k * BLOCK + tid) * 4 < TOP) reinterpret_cast<uint4*>(swalk)[k * BLOCK + tid] = wtop[k];
   }
   __syncthreads();
   const uint32_t rec0 = walk[0];  // the root's record (scalar)
@@ -1101,27 +1104,33 @@ void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* w
   const float cells = lv.edge[0] > 0.0 ? (float)((double)(1 << kGridBits) / lv.edge[0]) : 0.f;
   const uint32_t pool_cap = (uint32_t)pcv_pool_region_entries(n);
   if (depth_grid) hipLaunchKernelGGL(spec_depth_grid_kernel, dim3((1u << (3 * kGridBits)) / 256), dim3(256), 0, ctx->stream, walk, depth_grid);
+  // the first kTop walk records (levels 0-3 of T'' and the start of level 4: the table is level-major) are mirrored in LDS: with
+  // the Float32 code steps a shallow level step is shorter than the L2 round trip of its child gather. One call, 100 M points:
+  // 0 / 512 / 1 024 / 1 536 / 2 048 / 3 072 records -> 1.92-1.95 / 1.88 / 1.88 / 1.85 / 1.83-1.85 / 2.11 ms (3 072: 39 KB of LDS,
+  // registers); profiles/r05_ab_chain_pass_walk_top_in_lds.json. PCV_CHAIN_TOP (libpcv_hip_exp.so): another size, 0 = none.
+  constexpr int kTop = 2048;
+#define PCV_CHAIN_TOP_LAUNCH(RAWIN, T)                                                                                                  \
+  hipLaunchKernelGGL((chain_pass_kernel<true, RAWIN, kBlock, T>), grid, dim3(kBlock), 0, ctx->stream, lv, walk, n, x, y, z, routed, color, \
+                     color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr, pool_cap)
 #ifdef PCV_EXPERIMENTS
-  static const int chain_top = [] {  // PCV_CHAIN_TOP=2048 / 4096: that many walk records mirrored in LDS (raw input)
+  static const int chain_top = [] {
     const char* e = pcv_experiment("PCV_CHAIN_TOP");
-    return e ? atoi(e) : 0;
+    return e ? atoi(e) : kTop;
   }();
-  if (!routed.oct && (chain_top == 2048 || chain_top == 4096)) {
-    if (chain_top == 2048)
-      hipLaunchKernelGGL((chain_pass_kernel<true, true, kBlock, 2048>), grid, dim3(kBlock), 0, ctx->stream, lv, walk, n, x, y, z, routed, color,
-                         color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr, pool_cap);
-    else
-      hipLaunchKernelGGL((chain_pass_kernel<true, true, kBlock, 4096>), grid, dim3(kBlock), 0, ctx->stream, lv, walk, n, x, y, z, routed, color,
-                         color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr, pool_cap);
-    return;
+  if (!routed.oct && chain_top != kTop) {
+    switch (chain_top) {
+      case 0: PCV_CHAIN_TOP_LAUNCH(true, 0); return;
+      case 512: PCV_CHAIN_TOP_LAUNCH(true, 512); return;
+      case 1024: PCV_CHAIN_TOP_LAUNCH(true, 1024); return;
+      case 1536: PCV_CHAIN_TOP_LAUNCH(true, 1536); return;
+      case 3072: PCV_CHAIN_TOP_LAUNCH(true, 3072); return;
+      default: break;
+    }
   }
 #endif
-  if (!routed.oct)
-    hipLaunchKernelGGL((chain_pass_kernel<true, true, kBlock>), grid, dim3(kBlock), 0, ctx->stream, lv, walk, n, x, y, z, routed, color, color_stride,
-                       intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr, pool_cap);
-  else
-    hipLaunchKernelGGL((chain_pass_kernel<true, false, kBlock>), grid, dim3(kBlock), 0, ctx->stream, lv, walk, n, x, y, z, routed, color, color_stride,
-                       intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr, pool_cap);
+  if (!routed.oct) PCV_CHAIN_TOP_LAUNCH(true, kTop);
+  else PCV_CHAIN_TOP_LAUNCH(false, kTop);
+#undef PCV_CHAIN_TOP_LAUNCH
 }
 
 size_t pcv_spec_depth_grid_bytes() { return (size_t)1 << (3 * kGridBits); }
