@@ -64,8 +64,11 @@ def valu_issue_model(insts, n, launch_ms):
     the part sustained under that class), summed and divided by the SIMD cycles the launch had: 1 024 SIMDs x the clock the part
     sustained DURING THIS KERNEL (GRBM_GUI_ACTIVE / duration of the counter pass) x the launch time measured here."""
     path = os.path.join(ROOT, "profiles", f"{ROUND}_f64_rate.json")
-    if not os.path.exists(path):
-        return {"frac": None, "note": "no f64-rate probe recorded for this round (tools/f64_rate.sh)"}
+    if not os.path.exists(path):  # the issue costs are a property of the part, not of the build: the latest probe on record
+        older = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("_f64_rate.json"))
+        if not older:
+            return {"frac": None, "note": "no f64-rate probe on record (tools/f64_rate.sh)"}
+        path = os.path.join(ROOT, "profiles", older[-1])
     with open(path) as f:
         rate = json.load(f)
     by = {r["inst"]: r["cycles_at_sustained_clock"] or r["cycles_at_2.4GHz"] for r in rate["per_instruction"]}
