@@ -348,9 +348,7 @@ __device__ __forceinline__ uint32_t cp_walk_at(const uint32_t* __restrict__ walk
     CP_LOOP(true, lv.nlevels, , pcv_chain_apply_bits<true>(lv.enc[U + 1], b, ec, ic, px, py, pz, mx, my, mz, vx, vy, vz)) \
   }
 
-template <bool KEEP, bool RAW, int BLOCK, int TOP = 0 /* walk records mirrored in LDS (a multiple of 256, or 0) */,
-          int TILES = 1 /* tiles a workgroup takes one after the other: the coordinates of the next one are requested behind the
-                           colour loads of this one's closing phase, so that they travel while its records are stored */>
+template <bool KEEP, bool RAW, int BLOCK, int TOP = 0 /* walk records mirrored in LDS (a multiple of 4 x BLOCK, or 0) */>
 __global__ __launch_bounds__(BLOCK, 8) void chain_pass_kernel(
     PcvLevels lv, const uint32_t* __restrict__ walk, uint64_t n, const double* __restrict__ x, const double* __restrict__ y,
     const double* __restrict__ z, PcvRouted routed, const uint8_t* __restrict__ color, uint32_t color_stride,
@@ -373,36 +371,29 @@ __global__ __launch_bounds__(BLOCK, 8) void chain_pass_kernel(
   // stay in a register across the walks
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   int lane = (int)pcv_lane_again(), tid = wave * 64 + lane;
+  const uint64_t base = (uint64_t)blockIdx.x * TILE;
+  const uint32_t here = n - base < (uint64_t)TILE ? (uint32_t)(n - base) : (uint32_t)TILE;  // points of this tile (scalar)
   const bool stage = wide != nullptr;  // grid-uniform: 12-byte records
+  if (tid < 32) kcnt[tid] = 0;
   double qx[2], qy[2], qz[2];
-  // the coordinates of a tile (two points per lane), into registers
-  auto fetch = [&](uint64_t fbase, uint32_t fhere) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const uint32_t t = (uint32_t)(h * BLOCK + tid);
-      qx[h] = qy[h] = qz[h] = 0.0;
-      if (t < fhere) {
-        if (RAW) {
-          qx[h] = x[fbase + t], qy[h] = y[fbase + t], qz[h] = z[fbase + t];
-        } else {  // routed input: the position the sending rank held after level 1 (decode of the level-1 codes)
-          double t0, t1, t2, t3, t4, t5;
-          uint32_t dd;
-          (void)pcv_chain_start(lv, routed, x, y, z, fbase + t, qx[h], qy[h], qz[h], t0, t1, t2, t3, t4, t5, dd);
-        }
+  for (int h = 0; h < 2; ++h) {
+    const uint32_t t = (uint32_t)(h * BLOCK + tid);
+    qx[h] = qy[h] = qz[h] = 0.0;
+    if (t < here) {
+      if (RAW) {
+        qx[h] = x[base + t], qy[h] = y[base + t], qz[h] = z[base + t];
+      } else {  // routed input: the position the sending rank held after level 1 (decode of the level-1 codes)
+        double t0, t1, t2, t3, t4, t5;
+        uint32_t dd;
+        (void)pcv_chain_start(lv, routed, x, y, z, base + t, qx[h], qy[h], qz[h], t0, t1, t2, t3, t4, t5, dd);
       }
     }
-  };
-  auto tile_points = [&](uint64_t b) { return b >= n ? 0u : (n - b < (uint64_t)TILE ? (uint32_t)(n - b) : (uint32_t)TILE); };
-  fetch((uint64_t)blockIdx.x * (TILES * TILE), tile_points((uint64_t)blockIdx.x * (TILES * TILE)));
-#pragma unroll 1
-  for (int tile = 0; tile < TILES; ++tile) {
-  const uint64_t base = ((uint64_t)blockIdx.x * TILES + (uint64_t)tile) * TILE;
-  const uint32_t here = tile_points(base);  // points of this tile (scalar)
-  if (tid < 32) kcnt[tid] = 0;
+  }
   // the top of the walk table: requested behind the coordinates, stored to LDS before the deal's last barrier (the buffer is
   // allocated for at least 1 + 8 x 8 192 records: reading past the tree's last node is harmless, never indexed)
   uint4 wtop[TOP ? kTopRounds : 1];
-  if (TOP && tile == 0) {
+  if (TOP) {
 #pragma unroll
     for (int k = 0; k < kTopRounds; ++k)
       if ((k * BLOCK + tid) * 4 < TOP) wtop[k] = reinterpret_cast<const uint4*>(walk)[k * BLOCK + tid];  // (wave-uniform)
@@ -445,7 +436,7 @@ __global__ __launch_bounds__(BLOCK, 8) void chain_pass_kernel(
     }
     sidx[slot] = (uint16_t)((uint32_t)(h * BLOCK + tid) | wild[h]);
   }
-  if (TOP && tile == 0) {
+  if (TOP) {
     tid = wave * 64 + (int)pcv_lane_again();
 #pragma unroll
     for (int k = 0; k < kTopRounds; ++k)
@@ -549,11 +540,6 @@ __global__ __launch_bounds__(BLOCK, 8) void chain_pass_kernel(
       const uint32_t t = (uint32_t)(h * BLOCK + tid);
       rgb[h] = t < here ? pcv_load_rgb(color + (base + t) * color_stride, base + t + 1 < n) : 0u;
     }
-    if (TILES > 1 && tile + 1 < TILES) {  // the next tile's coordinates: requested BEHIND the colour (the loads retire in order)
-      __builtin_amdgcn_sched_barrier(0);
-      fetch(base + TILE, tile_points(base + TILE));
-      __builtin_amdgcn_sched_barrier(0);
-    }
     __syncthreads();
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -565,9 +551,6 @@ __global__ __launch_bounds__(BLOCK, 8) void chain_pass_kernel(
       }
     }
   }
-  else if (TILES > 1 && tile + 1 < TILES) {
-    fetch(base + TILE, tile_points(base + TILE));
-  }
   if (inten_bits) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -575,7 +558,6 @@ __global__ __launch_bounds__(BLOCK, 8) void chain_pass_kernel(
       if (t < here) inten_bits[base + t] = __float_as_uint(intensity[base + t]);
     }
   }
-  }  // tiles
 }
 #undef CP_WALK_GUARDED
 #undef CP_WALK_TAME
@@ -1130,22 +1112,6 @@ void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* w
 #define PCV_CHAIN_TOP_LAUNCH(RAWIN, T)                                                                                                  \
   hipLaunchKernelGGL((chain_pass_kernel<true, RAWIN, kBlock, T>), grid, dim3(kBlock), 0, ctx->stream, lv, walk, n, x, y, z, routed, color, \
                      color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr, pool_cap)
-#ifdef PCV_EXPERIMENTS
-  static const int chain_tiles = [] {  // PCV_CHAIN_TILES=2 / 4: tiles per workgroup, the next one's coordinates requested early
-    const char* e = pcv_experiment("PCV_CHAIN_TILES");
-    return e ? atoi(e) : 1;
-  }();
-  if (!routed.oct && (chain_tiles == 2 || chain_tiles == 4)) {
-    const unsigned tg = (unsigned)((n + (uint64_t)chain_tiles * 2 * kBlock - 1) / ((uint64_t)chain_tiles * 2 * kBlock));
-    if (chain_tiles == 2)
-      hipLaunchKernelGGL((chain_pass_kernel<true, true, kBlock, kTop, 2>), dim3(tg), dim3(kBlock), 0, ctx->stream, lv, walk, n, x, y, z, routed,
-                         color, color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr, pool_cap);
-    else
-      hipLaunchKernelGGL((chain_pass_kernel<true, true, kBlock, kTop, 4>), dim3(tg), dim3(kBlock), 0, ctx->stream, lv, walk, n, x, y, z, routed,
-                         color, color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr, pool_cap);
-    return;
-  }
-#endif
 #ifdef PCV_EXPERIMENTS
   static const int chain_top = [] {
     const char* e = pcv_experiment("PCV_CHAIN_TOP");
