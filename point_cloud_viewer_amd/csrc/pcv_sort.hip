@@ -924,9 +924,11 @@ __global__ __launch_bounds__(256) void hist_from_rows_kernel(const uint32_t* __r
 __global__ __launch_bounds__(256) void hist12_from_rows_kernel(const uint32_t* __restrict__ rows, uint32_t nbins,
                                                                 const uint32_t* __restrict__ map, int nbits1, int nbits2, int groups,
                                                                 uint32_t* __restrict__ hist1 /* [d1][groups] */,
-                                                                uint32_t* __restrict__ rows_true /* [groups][D1 * D2] */) {
+                                                                uint32_t* __restrict__ rows_true /* [groups][D1 * D2] */,
+                                                                int msd /* experiments: the FIRST pass takes the rank's upper nbits1 bits */) {
   __shared__ uint32_t tr[16384];  // 64 KB: ranks of up to 14 bits
   const uint32_t D1 = 1u << nbits1, D2 = 1u << nbits2, TB = D1 * D2;
+  const int sh1 = msd ? nbits2 : 0, sh2 = msd ? 0 : nbits1;
   for (uint32_t i = threadIdx.x; i < TB; i += 256) tr[i] = 0;
   __syncthreads();
   const uint32_t* row = rows + (uint64_t)blockIdx.x * nbins;
@@ -934,7 +936,7 @@ __global__ __launch_bounds__(256) void hist12_from_rows_kernel(const uint32_t* _
     const uint32_t c = row[b];
     if (c) {
       const uint32_t r = map[b] & PCV_SPEC_INDEX_MASK_SORT;
-      atomicAdd(&tr[(r & (D1 - 1u)) * D2 + ((r >> nbits1) & (D2 - 1u))], c);
+      atomicAdd(&tr[((r >> sh1) & (D1 - 1u)) * D2 + ((r >> sh2) & (D2 - 1u))], c);
     }
   }
   __syncthreads();
@@ -982,6 +984,48 @@ __global__ __launch_bounds__(256) void pass2_layout_kernel(const uint32_t* __res
     }
     order[before * (uint32_t)blocks + (uint32_t)blk] = (uint32_t)k;
   }
+}
+
+// (experiments, PCV_SORT_MSD) Most significant digit FIRST: the second pass then sorts every bucket of the first one by the lower
+// digit INSIDE the bucket's own range of the output. hist2[d2][piece] (piece = (d1, blk)) turns into the absolute position of
+// that (digit, piece) run: start of bucket d1 + records of the bucket with a smaller d2 + same d2, earlier blocks; the
+// downsweep's digit prefix (totals) is zeroed. One workgroup per first digit.
+__global__ __launch_bounds__(256) void msd_offsets_kernel(uint32_t* __restrict__ hist2, int pieces, int blocks, int nbits2,
+                                                           const uint32_t* __restrict__ totals1, uint32_t* __restrict__ totals2) {
+  __shared__ uint32_t wave_tot[4];
+  const int d1 = blockIdx.x;
+  const uint32_t D2 = 1u << nbits2, total = D2 * (uint32_t)blocks;
+  if (d1 == 0) totals2[threadIdx.x] = 0;  // kRadix == 256 entries
+  uint32_t start = 0;
+  for (int d = 0; d < d1; ++d) start += totals1[d];
+  const uint32_t per = (total + 255u) / 256u;
+  uint32_t running = start;  // (uniform) everything before the chunk of 256 x per values in flight
+  // value i of the bucket's sequence: digit i / blocks, block i % blocks
+  auto at = [&](uint32_t i) -> uint32_t& { return hist2[(uint64_t)(i / (uint32_t)blocks) * pieces + (uint32_t)d1 * blocks + i % (uint32_t)blocks]; };
+  const uint32_t begin = threadIdx.x * per;
+  uint32_t sum = 0;
+  for (uint32_t i = 0; i < per; ++i)
+    if (begin + i < total) sum += at(begin + i);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t inc = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) wave_tot[wave] = inc;
+  __syncthreads();
+  uint32_t woff = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) woff += (w < wave) ? wave_tot[w] : 0u;
+  uint32_t run = running + woff + inc - sum;
+  for (uint32_t i = 0; i < per; ++i)
+    if (begin + i < total) {
+      uint32_t& v = at(begin + i);
+      const uint32_t c = v;
+      v = run;
+      run += c;
+    }
 }
 
 // Geometry of the 12-byte record downsweep. What moves this kernel is the length of the write runs (tile / digit
@@ -1071,8 +1115,20 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
         return !e || atoi(e) != 0;
       }();
       const int nbits2 = end_bit - (shift + width) < width ? end_bit - (shift + width) : width;
+      bool msd = false;
+#ifdef PCV_EXPERIMENTS
+      static const bool msd_on = [] {
+        const char* e = pcv_experiment("PCV_SORT_MSD");  // 1: upper digit first, the second pass sorts inside every bucket
+        return e && atoi(e) != 0;
+      }();
+      msd = msd_on;
+#endif
       const bool two = pass2_rows_on && map_entries <= 16384 && shift + width < end_bit && shift + 2 * width >= end_bit && total_bits <= 14 &&
                        nbits2 >= 1 && g.groups >= 8;
+      msd = msd && two;
+      // first / second pass: (shift, bits) of their digits — the lower digit first, unless msd
+      const int p1_shift = msd ? shift + width : shift, p1_bits = msd ? nbits2 : nbits;
+      const int p2_shift = msd ? shift : shift + width, p2_bits = msd ? nbits : nbits2;
       uint32_t* hist2 = totals + kRadix;
       uint32_t* totals2 = hist2 + (size_t)kRadix * kMaxGroups;
       uint2* ranges = reinterpret_cast<uint2*>(totals2 + kRadix);
@@ -1080,9 +1136,9 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
       uint32_t* rows_true = order + kMaxGroups;
       {
         PcvProf prof(ctx, PCV_K_SORT_HIST_ROWS);
-        if (two)
-          hipLaunchKernelGGL(hist12_from_rows_kernel, dim3(g.groups), dim3(256), 0, ctx->stream, rows, map_entries, map, nbits, nbits2,
-                             g.groups, hist, rows_true);
+        if (two)  // (msd: the first pass takes the upper nbits2 bits, the second the lower nbits)
+          hipLaunchKernelGGL(hist12_from_rows_kernel, dim3(g.groups), dim3(256), 0, ctx->stream, rows, map_entries, map,
+                             p1_bits, p2_bits, g.groups, hist, rows_true, msd ? 1 : 0);
         else
           hipLaunchKernelGGL(hist_from_rows_kernel, dim3(g.groups), dim3(256), 0, ctx->stream, rows, map_entries, map, shift - begin_bit,
                              mask, g.groups, hist);
@@ -1105,8 +1161,8 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
                                                hipFuncAttributeMaxDynamicSharedMemorySize, P ? (R == 128 ? 20480 : 10240) : 32768) == hipSuccess; \
     (void)ok;                                                                                                                            \
     hipLaunchKernelGGL((downsweep_rec12_kernel<1024, 8, R, 4, false, M, P>), dim3(g.groups), dim3(1024), dyn, ctx->stream,                \
-                       (const uint32_t*)src, (uint32_t*)dst, n, g.chunk, g.groups, shift, nbits, hist, totals, vin, vout, map, map_entries, \
-                       (const uint2*)nullptr, (const uint32_t*)nullptr, pin, pout);                                                       \
+                       (const uint32_t*)src, (uint32_t*)dst, n, g.chunk, g.groups, p1_shift, p1_bits, hist, totals, vin, vout, map,       \
+                       map_entries, (const uint2*)nullptr, (const uint32_t*)nullptr, pin, pout);                                          \
   }
         // PCV_REC_WC (libpcv_hip_exp.so; bit 0: first pass, bit 1: second pass): the write-combining form of the downsweep
         // measured slower than the kernel that ships (profiles/r05_sort_same_box.json): not instantiated in libpcv_hip.so
@@ -1116,23 +1172,23 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
           const char* e = pcv_experiment("PCV_REC_WC");
           return e ? atoi(e) : 0;
         }();
-        if ((rec_wc & 1) && !with_plane && nbits <= 7) {
+        if ((rec_wc & 1) && !with_plane && p1_bits <= 7) {
           hipLaunchKernelGGL((downsweep_rec12_kernel<1024, 8, 128, 4, false, 2, false, true>), dim3(g.groups), dim3(1024), 0, ctx->stream,
-                             (const uint32_t*)src, (uint32_t*)dst, n, g.chunk, g.groups, shift, nbits, hist, totals, vin, vout, map, map_entries,
+                             (const uint32_t*)src, (uint32_t*)dst, n, g.chunk, g.groups, p1_shift, p1_bits, hist, totals, vin, vout, map, map_entries,
                              (const uint2*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr);
           wc_done = true;
         }
 #endif
         if (wc_done) {
         } else if (with_plane) {
-          if (nbits <= 7 && map_in_lds) PCV_REC12_MAP(128, 1, true)
+          if (p1_bits <= 7 && map_in_lds) PCV_REC12_MAP(128, 1, true)
           else if (map_in_lds) PCV_REC12_MAP(256, 1, true)
-          else if (nbits <= 7) PCV_REC12_MAP(128, 2, true)
+          else if (p1_bits <= 7) PCV_REC12_MAP(128, 2, true)
           else PCV_REC12_MAP(256, 2, true)
         } else {
-          if (nbits <= 7 && map_in_lds) PCV_REC12_MAP(128, 1, false)
+          if (p1_bits <= 7 && map_in_lds) PCV_REC12_MAP(128, 1, false)
           else if (map_in_lds) PCV_REC12_MAP(256, 1, false)
-          else if (nbits <= 7) PCV_REC12_MAP(128, 2, false)
+          else if (p1_bits <= 7) PCV_REC12_MAP(128, 2, false)
           else PCV_REC12_MAP(256, 2, false)
         }
 #undef PCV_REC12_MAP
@@ -1140,7 +1196,7 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
       in_a = !in_a;
       if (!two) continue;
       // second pass: pieces of whole first-pass runs, digit counts and ranges from rows_true and the first pass's offsets
-      const int D1 = 1 << nbits;
+      const int D1 = 1 << p1_bits;
       int blocks = kMaxGroups / D1;
       if (blocks > g.groups) blocks = g.groups;
       if (blocks < 1) blocks = 1;
@@ -1148,12 +1204,15 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
       const int pieces = D1 * blocks;
       {
         PcvProf prof(ctx, PCV_K_SORT_HIST_ROWS);
-        hipLaunchKernelGGL(pass2_layout_kernel, dim3(pieces), dim3(256), 0, ctx->stream, rows_true, nbits, nbits2, g.groups, blocks, gpb, hist,
+        hipLaunchKernelGGL(pass2_layout_kernel, dim3(pieces), dim3(256), 0, ctx->stream, rows_true, p1_bits, p2_bits, g.groups, blocks, gpb, hist,
                            totals, pieces, hist2, ranges, order);
       }
       {
         PcvProf prof(ctx, PCV_K_SORT_SCAN);
-        hipLaunchKernelGGL(scan_kernel, dim3(kRadix), dim3(256), 0, ctx->stream, hist2, pieces, totals2);
+        if (msd)  // absolute positions of every (digit, piece) run inside its bucket; no digit prefix
+          hipLaunchKernelGGL(msd_offsets_kernel, dim3(D1), dim3(256), 0, ctx->stream, hist2, pieces, blocks, p2_bits, totals, totals2);
+        else
+          hipLaunchKernelGGL(scan_kernel, dim3(kRadix), dim3(256), 0, ctx->stream, hist2, pieces, totals2);
       }
       {
         PcvProf prof(ctx, PCV_K_SORT_DOWNSWEEP_REC);
@@ -1165,7 +1224,7 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
         uint32_t* pout2 = with_plane ? (in_a ? payload->out[0] : payload->in[0]) : nullptr;
 #define PCV_REC12_P2(R, P)                                                                                                               \
   hipLaunchKernelGGL((downsweep_rec12_kernel<1024, 8, R, 4, false, 0, P>), dim3(pieces), dim3(1024), 0, ctx->stream, src2, dst2, n, g.chunk, \
-                     pieces, shift + width, nbits2, hist2, totals2, vin2, vout2, (const uint32_t*)nullptr, 0u, (const uint2*)ranges,        \
+                     pieces, p2_shift, p2_bits, hist2, totals2, vin2, vout2, (const uint32_t*)nullptr, 0u, (const uint2*)ranges,            \
                      (const uint32_t*)order, pin2, pout2)
         bool wc2_done = false;
 #ifdef PCV_EXPERIMENTS
@@ -1173,19 +1232,19 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
           const char* e = pcv_experiment("PCV_REC_WC");
           return e ? atoi(e) : 0;
         }();
-        if ((rec_wc2 & 2) && !with_plane && nbits2 <= 7) {
+        if ((rec_wc2 & 2) && !with_plane && p2_bits <= 7) {
           hipLaunchKernelGGL((downsweep_rec12_kernel<1024, 8, 128, 4, false, 0, false, true>), dim3(pieces), dim3(1024), 0, ctx->stream, src2, dst2, n,
-                             g.chunk, pieces, shift + width, nbits2, hist2, totals2, vin2, vout2, (const uint32_t*)nullptr, 0u, (const uint2*)ranges,
+                             g.chunk, pieces, p2_shift, p2_bits, hist2, totals2, vin2, vout2, (const uint32_t*)nullptr, 0u, (const uint2*)ranges,
                              (const uint32_t*)order, (const uint32_t*)nullptr, (uint32_t*)nullptr);
           wc2_done = true;
         }
 #endif
         if (wc2_done) {
         } else if (with_plane) {
-          if (nbits2 <= 7) PCV_REC12_P2(128, true);
+          if (p2_bits <= 7) PCV_REC12_P2(128, true);
           else PCV_REC12_P2(256, true);
         } else {
-          if (nbits2 <= 7) PCV_REC12_P2(128, false);
+          if (p2_bits <= 7) PCV_REC12_P2(128, false);
           else PCV_REC12_P2(256, false);
         }
 #undef PCV_REC12_P2

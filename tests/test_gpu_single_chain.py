@@ -282,6 +282,8 @@ print("alt-path ok")
                                               ({"PCV_CHAIN_V": "3"}, 12), ({"PCV_CODE_STEPS": "0"}, 12),
                                               # the write-combining form of the record downsweep, both passes (experiment)
                                               ({"PCV_REC_WC": "3"}, 12),
+                                              # the record sort's upper digit first, the second pass inside every bucket (experiment)
+                                              ({"PCV_SORT_MSD": "1"}, 12),
                                               # the sample tree by counting the keys instead of from sorted keys (experiment, slower)
                                               ({"PCV_SAMPLE_COUNTS": "1"}, 12),
                                               # the sample tree split one level per launch pair (what u32 keys and levels
