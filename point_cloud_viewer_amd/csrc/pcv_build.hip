@@ -370,7 +370,7 @@ static const char* kKernelNames[PCV_K_COUNT] = {
     "visible_nodes_kernel", "nodes_in_location_kernel", "cull_points_kernel", "transform_points_kernel",
     "query_compact_kernel", "route_bucket_kernel", "partition_count_kernel", "partition_scatter_kernel",
     "promote_climb_kernel", "spec_encode_kernel", "rank_hist_kernel", "spec_continue_kernel", "spec_replay_kernel", "upsweep_map_kernel",
-    "hist_from_rows_kernel", "cull_nodes_sparse_kernel"};
+    "hist_from_rows_kernel", "cull_nodes_sparse_kernel", "downsweep_settle_kernel"};
 static_assert(sizeof(kKernelNames) / sizeof(kKernelNames[0]) == PCV_K_COUNT, "kernel name table out of sync");
 
 extern "C" int pcv_ctx_set_profiling(pcv_ctx* ctx, int enabled) {
@@ -813,6 +813,7 @@ struct PcvBuild {
   void* spec_payload = nullptr;  // uint4[n]; uint2[n] with 12-byte records
   void* spec_wide = nullptr;     // set: 12-byte records (pcv_internal.h); uint4[n], the codes of Float32-coded leaves
   const uint32_t* spec_rows = nullptr;  // rank counts per sort workgroup (pcv_launch_rank_hist_rows), or null
+  PcvSortSecond sort_second;            // the record sort's second pass, held back until the node tables are up (pcv_build_finish)
   uint64_t wide_levels = 0;      // bit k: level k is Float32-coded
   struct FixRange {
     uint32_t lo, count, level;
@@ -1039,6 +1040,17 @@ static void host_lap(const char* what, bool reset = false) {
   t0 = now;
 }
 
+// The record sort's second pass settles the leaves' points itself (PcvSortFuse) where it can: the pass is held back until the
+// node tables are on the device. PCV_SETTLE_IN_SORT=0 (libpcv_hip_exp.so): the sort runs to its end, `settle` reads the records.
+static bool pcv_settle_in_sort() {
+  static const bool on = [] {
+    const char* e = pcv_experiment("PCV_SETTLE_IN_SORT");
+    const char* l = pcv_experiment("PCV_SETTLE_BY_LEAF");
+    return (!e || atoi(e) != 0) && (!l || atoi(l) != 0) && pcv_climb16_enabled();
+  }();
+  return on;
+}
+
 // K5 (exact pipeline only: `wt` set) + K3 stable record sort by leaf rank, queued on the stream; the outcome is left in
 // the build state for K6. num_leaves only sizes the digits: any upper bound of the number of true leaves will do.
 // record = rank (u32) + one 16-byte payload {code x, code y, code z, rgba}; optional 4-byte planes for the intensity
@@ -1092,7 +1104,8 @@ static int queue_record_sort(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, const Pc
   bool rec_in_a = true;
   if (bs->spec_map_dev)
     rc = pcv_radix_sort_records_mapped(ctx, rank_a, rank_b, n, rank_bits, &pl, bs->sort_scratch, bs->spec_map_dev,
-                                       bs->spec_map_entries, &rec_in_a, compact && pl.nwords <= 1 ? bs->spec_rows : nullptr);
+                                       bs->spec_map_entries, &rec_in_a, compact && pl.nwords <= 1 ? bs->spec_rows : nullptr,
+                                       compact && pl.nwords == 0 && pcv_settle_in_sort() ? &bs->sort_second : nullptr);
   else
     rc = pcv_radix_sort_u32(ctx, rank_a, rank_b, n, 0, rank_bits, &pl, bs->sort_scratch, &rec_in_a);
   if (rc) return rc;
@@ -1411,6 +1424,7 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
     bs->spec_map_dev = nullptr;
     bs->spec_rows = nullptr;
     bs->sort_queued = false;
+    bs->sort_second = PcvSortSecond();  // (a held-back second pass is simply never queued)
     bs->resolve_on_device = false;
     sc.detach(payload);
     ctx->dev_free(payload);
@@ -1486,6 +1500,8 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
     if ((rc = queue_record_sort(ctx, bs, t, nullptr, tt->num_leaves, false))) return rc;
     host_lap("record sort queued");
   }
+  // replayed leaves rewrite their SORTED records: the sort has to be complete in front of that
+  if (!bs->fix_ranges.empty() && (rc = pcv_radix_sort_records_second(ctx, &bs->sort_second, nullptr))) return rc;
   if ((rc = queue_replay(ctx, bs))) return rc;
   ctx->stage_begin(PCV_STAGE_TABLE);
   t->spec_stats[0] = tree.prefix.size();
@@ -1753,7 +1769,7 @@ static int build_begin_impl(pcv_ctx* ctx, const pcv_build_params* params, const 
   bs->host_bytes = host_bytes;
   if ((rc = ctx->pinned_reserve(host_bytes * 4 + (size_t)M * 72 + (size_t)M * 2 * sizeof(PcvNodeRec) + 1024 +
                                 (2 * (bs->n / kPcvSettleTile) + bs->n / (8 * kPcvClimbTile) + 3 * (size_t)M + 8) * sizeof(PcvSettleItem) +
-                                (size_t)M * pcv_cont_range_bytes())))
+                                (size_t)M * pcv_cont_range_bytes() + (size_t)M + 64)))
     return rc;
   uint8_t* hp = (uint8_t*)ctx->pinned;
   uint64_t* h_prefix = (uint64_t*)hp;
@@ -2024,6 +2040,8 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
     const char* e = pcv_experiment("PCV_SETTLE_BY_LEAF");
     return !e || atoi(e) != 0;
   }();
+  const bool fuse_sort = bs->spec && bs->sort_second.pending && by_leaf && !t->has_intensity && !wide && bs->spec_wide;
+  std::vector<uint8_t> fused_leaf;
   uint32_t* u_climb_base = (uint32_t*)(u_leaf_rec + num_leaves);
   const size_t items_off = (((size_t)(M + num_leaves) * sizeof(PcvNodeRec) + (size_t)num_leaves * 4) + 15) & ~(size_t)15;
   PcvSettleItem* u_items = (PcvSettleItem*)((uint8_t*)u_node_rec + items_off);
@@ -2036,7 +2054,22 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
       cnt[r] = h_hi[leaves[r]] - h_lo[leaves[r]];
       climbs[r] = u_leaf_rec[r].parent != 0xffffffffu;
     }
-    if (by_leaf) num_items = pcv_settle_items(u_leaf_lo, cnt.data(), num_leaves, u_items);
+    // the record sort's held-back second pass settles these leaves itself (PcvSortFuse): integer codes, not the root, no chain
+    // to continue; `settle` gets items for the others only (replayed leaves: the pass was queued unfused in front of the replay)
+    if (fuse_sort) {
+      fused_leaf.assign(num_leaves, 0);
+      std::vector<uint8_t> cont_leaf(num_leaves, 0);
+      for (uint32_t leaf : bs->cont_nodes) cont_leaf[rank_of[leaf]] = 1;
+      std::vector<uint32_t> cnt_left(cnt);
+      for (uint32_t r = 0; r < num_leaves; ++r)
+        if (climbs[r] && !cont_leaf[r] && u_leaf_rec[r].enc <= PCV_ENC_UINT16) {
+          fused_leaf[r] = 1;
+          cnt_left[r] = 0;
+        }
+      num_items = pcv_settle_items(u_leaf_lo, cnt_left.data(), num_leaves, u_items);
+    } else if (by_leaf) {
+      num_items = pcv_settle_items(u_leaf_lo, cnt.data(), num_leaves, u_items);
+    }
     num_climbers = pcv_climb_layout(cnt.data(), climbs.data(), num_leaves, u_climb_base, u_items + num_items, &num_citems);
     if (!by_leaf) num_citems = 0;
   }
@@ -2063,7 +2096,9 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
       for (uint32_t j = 0; j < num_items; ++j) u_items[j].pad = cont_of_rank[u_items[j].rank];
   }
   const size_t walk_bytes = ((size_t)M * 8 + 255) & ~(size_t)255;
-  const size_t rec_bytes = cont_items_off + (size_t)num_cont_items * sizeof(PcvSettleItem);
+  const size_t fused_off = cont_items_off + (size_t)num_cont_items * sizeof(PcvSettleItem);
+  if (fuse_sort) std::memcpy((uint8_t*)u_node_rec + fused_off, fused_leaf.data(), num_leaves);
+  const size_t rec_bytes = fused_off + (fuse_sort ? ((size_t)num_leaves + 15) & ~(size_t)15 : 0);
   // the tables live in a context-owned block; with the record sort already running they go up on the side stream (the
   // copy would otherwise queue behind the sort and sit, with its hand-over, between the sort and K6)
   if ((rc = ctx->table_dev_reserve(walk_bytes + rec_bytes + 256))) return rc;
@@ -2109,9 +2144,27 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
   }
   // the compact climber records live in the payload buffer the sort left unused (32 B x n / 8 < 16 B x n)
   void* climbers = rec_in_a ? (void*)pay_b : (void*)pay_a;
-  if (pcv_climber_bytes(num_climbers) > (size_t)n * (bs->spec_wide ? 8 : 16)) {
+  if (fuse_sort) {  // that buffer is the held-back pass's SOURCE: the (16-byte) climbers go to the free half of a key buffer
+    const size_t half = ((size_t)n * 4 + 15) & ~(size_t)15;
+    climbers = (void*)((uint8_t*)(rec_in_a ? keys_b : keys_a) + half);
+    if (half + (num_climbers + 1) * 16 > (uint64_t)n * 8) {
+      if ((rc = ctx->dev_alloc(&climbers, (size_t)(num_climbers + 1) * 16))) return rc;
+      sc.ptrs.push_back(climbers);
+    }
+  } else if (pcv_climber_bytes(num_climbers) > (size_t)n * (bs->spec_wide ? 8 : 16)) {
     if ((rc = ctx->dev_alloc(&climbers, pcv_climber_bytes(num_climbers)))) return rc;
     sc.ptrs.push_back(climbers);
+  }
+  if (bs->sort_second.pending) {  // the second pass of the record sort, now that tables and blobs exist
+    PcvSortFuse fz;
+    fz.leaf_rec = pt.leaf_rec;
+    fz.leaf_fused = d_up + walk_bytes + fused_off;
+    fz.climb_base = d_climb_base;
+    fz.climbers = climbers;
+    fz.xyz_blob = t->d_xyz;
+    fz.rgb_blob = t->d_rgb;
+    fz.num_leaves = num_leaves;
+    if ((rc = pcv_radix_sort_records_second(ctx, &bs->sort_second, fuse_sort ? &fz : nullptr))) return rc;
   }
   // leaves below a split first candidate: the leaf-wise settle kernel continues their chain itself (its items name the
   // range); the slot-wise kernel (experiments) gets the codes rewritten by a pass of its own first

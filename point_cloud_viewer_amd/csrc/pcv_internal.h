@@ -119,6 +119,7 @@ enum PcvKernelId {
   PCV_K_SORT_UPSWEEP_MAP,
   PCV_K_SORT_HIST_ROWS,
   PCV_K_CULL_NODES_SPARSE,
+  PCV_K_SORT_SETTLE,  // the record sort's second pass settling the leaves' points itself (PcvSortFuse)
   PCV_K_COUNT
 };
 
@@ -224,6 +225,7 @@ inline bool pcv_prof_is_major(int id) {
     case PCV_K_LEAF_ENCODE:
     case PCV_K_PROMOTE_ENCODE:
     case PCV_K_SORT_DOWNSWEEP_REC:
+    case PCV_K_SORT_SETTLE:
     case PCV_K_PROMOTE_CLIMB:
     case PCV_K_SPEC_ENCODE:
     case PCV_K_RANK_HIST:
@@ -328,9 +330,41 @@ int pcv_radix_sort_u32(pcv_ctx* ctx, uint32_t* keys_a, uint32_t* keys_b, uint64_
 
 // rows (pcv_launch_rank_hist_rows, map_entries counters per sort workgroup): the first pass takes its histogram from them and
 // applies the map inside its downsweep — the keys are not read an extra time
+// `second` set: a sort that takes the two-pass form with both histograms from the rank counts queues its first pass (and the
+// second one's layout) only and leaves what the second pass needs there (second->pending; *result_in_a already says where
+// the second pass will put the records); pcv_radix_sort_records_second queues that pass — plain, or settling the leaves' points
+// itself (PcvSortFuse). Any other form of the sort runs to its end and leaves second->pending false.
+struct PcvSortSecond {
+  bool pending = false;
+  const uint32_t* src = nullptr;   // keys after the first pass (rank << 8 | blue)
+  uint32_t* dst = nullptr;
+  const void* vec_src = nullptr;   // uint2 payloads after the first pass
+  void* vec_dst = nullptr;
+  uint64_t n = 0, chunk = 0;
+  int pieces = 0, shift = 0, nbits = 0;
+  int low_bits = 0, blocks = 1;  // piece k holds the records whose rank's lower `low_bits` bits are k / blocks
+  const uint32_t *hist = nullptr, *totals = nullptr, *order = nullptr;
+  const void* ranges = nullptr;
+};
+struct PcvNodeRec;
+// The second pass of the record sort as the producer of the final bytes: every run it would write is one leaf's records at
+// consecutive sorted slots (a piece holds ONE value of the rank's lower digit, the pass's digit is the upper one), so for the
+// leaves flagged here it does `settle`'s work on the record in flight — final rewrite + stores for seven of eight, the 16-byte
+// climber record for every eighth — instead of writing 12 bytes that `settle` would read back (24 bytes per point less).
+struct PcvSortFuse {
+  const PcvNodeRec* leaf_rec = nullptr;  // per true leaf rank
+  const uint8_t* leaf_fused = nullptr;   // per true leaf rank: 1 = settled here (u8 / u16 codes, no continuation, no replay, not the root)
+  const uint32_t* climb_base = nullptr;
+  void* climbers = nullptr;              // uint4 per climber
+  uint8_t* xyz_blob = nullptr;
+  uint8_t* rgb_blob = nullptr;
+  uint32_t num_leaves = 0;
+  uint32_t low_bits = 0, blocks = 1;  // (filled by pcv_radix_sort_records_second from the held-back pass)
+};
 int pcv_radix_sort_records_mapped(pcv_ctx* ctx, uint32_t* keys_a, uint32_t* keys_b, uint64_t n, int key_bits,
                                   PcvSortPayload* payload, void* scratch, const uint32_t* map, uint32_t map_entries,
-                                  bool* result_in_a, const uint32_t* rows = nullptr);
+                                  bool* result_in_a, const uint32_t* rows = nullptr, PcvSortSecond* second = nullptr);
+int pcv_radix_sort_records_second(pcv_ctx* ctx, PcvSortSecond* second, const PcvSortFuse* fuse /* or null: a plain pass */);
 
 // pcv_topology.hip — node split (topology from sorted keys).
 // Device node table, structure of arrays, BFS order (level-major, prefix-sorted inside a level).
@@ -459,6 +493,7 @@ struct PcvPromoteTables {
 // climb_base[leaf rank] = number of climbers (every 8th point of a non-root leaf) in the leaves before it; climbers:
 // pcv_climber_bytes(num_climbers) bytes of scratch that `settle` fills and `climb` consumes
 size_t pcv_climber_bytes(uint64_t num_climbers);
+bool pcv_climb16_enabled();  // leaf-wise kernels without intensity / Float64 planes keep 16-byte climber records
 void pcv_launch_promote_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvPromoteTables& pt, uint64_t n,
                                const uint32_t* rank, const void* payload /* uint4[n] */, const uint32_t* cx_hi,
                                const uint32_t* cy_hi, const uint32_t* cz_hi, const uint32_t* inten_bits,

@@ -16,6 +16,7 @@
 #include <cstdlib>
 
 #include "pcv_internal.h"
+#include "pcv_settle_dev.h"
 
 #define PCV_SPEC_INDEX_MASK_SORT 0x3fffffffu  // == PCV_SPEC_INDEX_MASK (pcv_spec.h)
 
@@ -597,8 +598,20 @@ struct DigitStateN {
 // of a digit's run (< 32 records) waits in a carry buffer in LDS for the next tile of the piece (tools/scatter_probe.hip: runs
 // that start on 256-byte boundaries move the same bytes 20-26 % faster than runs at odd record offsets). 128 digit values only
 // (48 KB of carry next to the 107 KB of the tile), no plane, no map copy in LDS.
+// the settling pass's view of a leaf (one entry per digit value of the piece, in LDS)
+struct alignas(16) FuseLeaf {
+  uint32_t lo, climb_base, flags, pad;
+  uint8_t* xyz;  // first byte of the leaf's .xyz content
+  uint8_t* rgb;
+  double mn[3], edge, inv_edge, inv_edge_lo;
+};
+constexpr uint32_t kFuseSettles = 1u, kFuseU8 = 2u;
+// FUSE (PcvSortFuse, pcv_internal.h): the pass is the LAST one of a two-pass sort whose pieces hold one value of the rank's lower
+// digit each: a digit's run inside a tile is then ONE leaf's records at consecutive sorted slots. Waves take whole runs: the leaf's
+// record comes through the scalar cache, and the run's records leave as final bytes / climber records (flagged leaves) or as
+// 12-byte records like in the plain pass (the others: `settle` finishes those).
 template <int BLOCK, int KPT, int R, int WPE, bool NT, int MAP = 0 /* 1: the map in LDS (half words), 2: in global memory */, bool PL = false,
-          bool WC = false>
+          bool WC = false, bool FUSE = false>
 __global__ __launch_bounds__(BLOCK, WPE) void downsweep_rec12_kernel(const uint32_t* __restrict__ keys_in,
                                                                      uint32_t* __restrict__ keys_out, uint64_t n, uint64_t chunk,
                                                                      int groups, int shift, int nbits,
@@ -611,8 +624,11 @@ __global__ __launch_bounds__(BLOCK, WPE) void downsweep_rec12_kernel(const uint3
                                                                      const uint32_t* __restrict__ order = nullptr /* set: workgroup
                                                                      b takes piece order[b] (largest pieces first) */,
                                                                      const uint32_t* __restrict__ plane_in = nullptr,
-                                                                     uint32_t* __restrict__ plane_out = nullptr) {
+                                                                     uint32_t* __restrict__ plane_out = nullptr,
+                                                                     PcvSortFuse fuse = PcvSortFuse()) {
   constexpr int NW = BLOCK / 64, kTile = BLOCK * KPT, RW = R / 64;
+  static_assert(!FUSE || (!PL && !WC && MAP == 0), "the settling pass: plain 12-byte records, second pass");
+  __shared__ FuseLeaf sleaf[FUSE ? R : 1];  // FUSE: the leaf of digit value d in this piece: rank = d << low_bits | the piece's lower digit
   const uint32_t piece = order ? order[blockIdx.x] : blockIdx.x;
   static_assert(BLOCK >= R && R % 64 == 0 && KPT % 8 == 0, "geometry");
   __shared__ uint32_t skeys[kTile];
@@ -627,6 +643,19 @@ __global__ __launch_bounds__(BLOCK, WPE) void downsweep_rec12_kernel(const uint3
   extern __shared__ uint16_t smap_dyn[];  // MAP: map_entries half words: true rank (< 2^15) | replay mark << 15
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const uint32_t mask = (1u << nbits) - 1u;
+  if (FUSE && t < R) {  // visible after the first barrier below
+    const uint32_t r = ((uint32_t)t << fuse.low_bits) | (piece / fuse.blocks);
+    FuseLeaf L{};
+    if ((uint32_t)t <= mask && r < fuse.num_leaves) {
+      const PcvNodeRec c = fuse.leaf_rec[r];
+      L.lo = c.lo, L.climb_base = fuse.climb_base[r];
+      L.flags = (fuse.leaf_fused[r] ? kFuseSettles : 0u) | (c.enc == PCV_ENC_UINT8 ? kFuseU8 : 0u);
+      L.xyz = fuse.xyz_blob + c.xyz_off, L.rgb = fuse.rgb_blob + c.point_off * 3;
+      L.mn[0] = c.mn[0], L.mn[1] = c.mn[1], L.mn[2] = c.mn[2];
+      L.edge = c.edge, L.inv_edge = c.inv_edge, L.inv_edge_lo = c.inv_edge_lo;
+    }
+    sleaf[t] = L;
+  }
   if (MAP == 1)
     for (uint32_t i = t; i < map_entries; i += BLOCK) {  // visible after the first barrier below
       const uint32_t m = gmap[i];
@@ -853,6 +882,65 @@ __global__ __launch_bounds__(BLOCK, WPE) void downsweep_rec12_kernel(const uint3
         }
         if (((uint32_t)t & 7u) == 0u) wc_count[d] = newc;
       }
+    } else if constexpr (FUSE) {
+      // every lane finishes the records at its own tile positions (consecutive lanes = consecutive sorted slots of a run): the run's
+      // leaf comes out of the piece's table in LDS (lanes of one run read one address: a broadcast)
+#pragma unroll 2
+      for (int i = 0; i < KPT; ++i) {
+        const uint32_t p = (uint32_t)i * BLOCK + (uint32_t)t;
+        if (!(full || p < tile_n)) continue;
+        const uint32_t k = skeys[p];
+        const uint2 q = svec[p];
+        const uint32_t d = (k >> shift) & mask;
+        const FuseLeaf& L = sleaf[d];
+        const uint32_t g = S.delta[d] + p;  // sorted slot
+        const uint32_t flags = L.flags;
+        if (!(flags & kFuseSettles)) {  // `settle` finishes this leaf: the 12-byte record as in the plain pass
+          keys_out[g] = k;
+          vec_out[g] = q;
+          continue;
+        }
+        const uint32_t j = g - L.lo;  // position in the leaf's stream
+        const uint32_t rgb = (q.y >> 16) | ((k & 0xffu) << 16);
+        const uint32_t c0 = q.x & 0xffffu, c1 = q.x >> 16, c2 = q.y & 0xffffu;
+        if ((j & 7u) == 0) {  // every eighth point climbs: its record for `climb`, dense per leaf
+          reinterpret_cast<uint4*>(fuse.climbers)[L.climb_base + (j >> 3)] = make_uint4(c0, c1, c2, rgb);
+          continue;
+        }
+        // final rewrite encode(decode(code)) at the leaf's own level (promote_final, pcv_settle_dev.h) with the
+        // encoding's constants as per-lane values: the same operations in the same order for u8 and u16
+        const bool u8 = (flags & kFuseU8) != 0;
+        const double maxval = u8 ? 255.0 : 65535.0;
+        const PcvRecip rm = u8 ? PCV_RECIP_255 : PCV_RECIP_65535;
+        uint32_t out[3];
+        const uint32_t cin[3] = {c0, c1, c2};
+        if (__builtin_expect(L.inv_edge != 0.0, 1)) {
+          const PcvRecip ie{L.inv_edge, L.inv_edge_lo};
+#pragma unroll
+          for (int a = 0; a < 3; ++a)
+            out[a] = pcv_fix_encode<false>(__fma_rn(pcv_div_code((double)cin[a], rm), L.edge, L.mn[a]), L.mn[a], L.edge, ie, maxval);
+        } else {
+          const uint32_t enc = u8 ? PCV_ENC_UINT8 : PCV_ENC_UINT16;
+#pragma unroll
+          for (int a = 0; a < 3; ++a)
+            out[a] = (uint32_t)pcv_encode_coord(enc, pcv_decode_coord(enc, cin[a], L.mn[a], L.edge), L.mn[a], L.edge, PcvRecip{0.0, 0.0});
+        }
+        const uint32_t slot = j - (j >> 3) - 1u;
+        const bool odd = (slot & 1u) != 0;
+        // 3 bytes at 3 x slot: one 2-byte store at the even address of the three + one byte
+        uint8_t* cd = L.rgb + (uint64_t)slot * 3;
+        *reinterpret_cast<uint16_t*>(cd + (odd ? 1 : 0)) = (uint16_t)(odd ? rgb >> 8 : rgb);
+        cd[odd ? 0 : 2] = (uint8_t)(odd ? rgb : rgb >> 16);
+        if (u8) {
+          uint8_t* x = L.xyz + (uint64_t)slot * 3;
+          *reinterpret_cast<uint16_t*>(x + (odd ? 1 : 0)) = (uint16_t)(odd ? out[1] | (out[2] << 8) : out[0] | (out[1] << 8));
+          x[odd ? 0 : 2] = (uint8_t)(odd ? out[0] : out[2]);
+        } else {  // 6 bytes at 6 x slot: one 4-byte store at the 4-aligned address of the six + one 2-byte store
+          uint8_t* x = L.xyz + (uint64_t)slot * 6;
+          *reinterpret_cast<uint32_t*>(x + (odd ? 2 : 0)) = odd ? out[1] | (out[2] << 16) : out[0] | (out[1] << 16);
+          *reinterpret_cast<uint16_t*>(x + (odd ? 0 : 4)) = (uint16_t)(odd ? out[0] : out[2]);
+        }
+      }
     } else {
 #pragma unroll
     for (int j0 = 0; j0 < KPT; j0 += 4) {
@@ -1073,8 +1161,9 @@ static void rec12_launch(pcv_ctx* ctx, int variant, const SortGeom& g, const uin
 template <typename KeyT>
 int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int end_bit, PcvSortPayload* payload,
                void* scratch, bool* result_in_a, const uint32_t* map = nullptr, uint32_t map_entries = 0,
-               const uint32_t* rows = nullptr) {
+               const uint32_t* rows = nullptr, PcvSortSecond* second = nullptr) {
   *result_in_a = true;
+  if (second) second->pending = false;
   if (n == 0 || end_bit <= begin_bit) return PCV_OK;
   if (n >= 0xffffffffull) return ctx->fail(PCV_E_INVALID, "radix sort: n must be < 2^32 - 1");
   const bool records = payload && (payload->vec_in || payload->nwords > 0);
@@ -1214,6 +1303,19 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
         else
           hipLaunchKernelGGL(scan_kernel, dim3(kRadix), dim3(256), 0, ctx->stream, hist2, pieces, totals2);
       }
+      if (second && !with_plane && !msd) {  // the caller queues the pass itself (pcv_radix_sort_records_second)
+        second->pending = true;
+        second->src = (const uint32_t*)(in_a ? a : b);
+        second->dst = (uint32_t*)(in_a ? b : a);
+        second->vec_src = in_a ? payload->vec_in : payload->vec_out;
+        second->vec_dst = in_a ? payload->vec_out : payload->vec_in;
+        second->n = n, second->chunk = g.chunk;
+        second->pieces = pieces, second->shift = p2_shift, second->nbits = p2_bits;
+        second->low_bits = p1_bits, second->blocks = blocks;
+        second->hist = hist2, second->totals = totals2, second->order = order, second->ranges = ranges;
+        in_a = !in_a;
+        break;
+      }
       {
         PcvProf prof(ctx, PCV_K_SORT_DOWNSWEEP_REC);
         const uint32_t* src2 = (const uint32_t*)(in_a ? a : b);
@@ -1346,9 +1448,31 @@ int pcv_radix_sort_u32(pcv_ctx* ctx, uint32_t* keys_a, uint32_t* keys_b, uint64_
 // (payload->vec_bytes == 8): the rank sits in bits 8.. of the key
 int pcv_radix_sort_records_mapped(pcv_ctx* ctx, uint32_t* keys_a, uint32_t* keys_b, uint64_t n, int key_bits,
                                   PcvSortPayload* payload, void* scratch, const uint32_t* map, uint32_t map_entries,
-                                  bool* result_in_a, const uint32_t* rows) {
+                                  bool* result_in_a, const uint32_t* rows, PcvSortSecond* second) {
   const int base = payload && payload->vec_bytes == 8 ? 8 : 0;
-  return radix_sort<uint32_t>(ctx, keys_a, keys_b, n, base, base + key_bits, payload, scratch, result_in_a, map, map_entries, rows);
+  return radix_sort<uint32_t>(ctx, keys_a, keys_b, n, base, base + key_bits, payload, scratch, result_in_a, map, map_entries, rows, second);
+}
+int pcv_radix_sort_records_second(pcv_ctx* ctx, PcvSortSecond* sd, const PcvSortFuse* fuse) {
+  if (!sd || !sd->pending) return PCV_OK;
+  sd->pending = false;
+#define PCV_REC12_SECOND(R, F, ARG)                                                                                                      \
+  hipLaunchKernelGGL((downsweep_rec12_kernel<1024, 8, R, 4, false, 0, false, false, F>), dim3(sd->pieces), dim3(1024), 0, ctx->stream,    \
+                     sd->src, sd->dst, sd->n, sd->chunk, sd->pieces, sd->shift, sd->nbits, sd->hist, sd->totals,                          \
+                     (const uint2*)sd->vec_src, (uint2*)sd->vec_dst, (const uint32_t*)nullptr, 0u, (const uint2*)sd->ranges, sd->order,    \
+                     (const uint32_t*)nullptr, (uint32_t*)nullptr, ARG)
+  if (fuse) {
+    PcvProf prof(ctx, PCV_K_SORT_SETTLE);
+    PcvSortFuse fz = *fuse;
+    fz.low_bits = (uint32_t)sd->low_bits, fz.blocks = (uint32_t)sd->blocks;
+    if (sd->nbits <= 7) PCV_REC12_SECOND(128, true, fz);
+    else PCV_REC12_SECOND(256, true, fz);
+  } else {
+    PcvProf prof(ctx, PCV_K_SORT_DOWNSWEEP_REC);
+    if (sd->nbits <= 7) PCV_REC12_SECOND(128, false, PcvSortFuse());
+    else PCV_REC12_SECOND(256, false, PcvSortFuse());
+  }
+#undef PCV_REC12_SECOND
+  return hipGetLastError() == hipSuccess ? PCV_OK : ctx->fail(PCV_E_HIP, "record sort: second pass");
 }
 void pcv_sort_rec12_geometry(uint64_t n, int* groups, uint64_t* chunk) {
   const SortGeom g = make_geom(n, 8192);
