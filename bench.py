@@ -52,6 +52,9 @@ ALGO_BYTES = {
     "rank_hist_kernel": 4.0,        # read ranks
     "spec_finalize_kernel": 8.0,    # rank read + write (+ payload patch of the points that take their kept codes)
     "upsweep_map_kernel": 8.0,      # rank read + mapped rank written back (+ the rare replay marks)
+    # the record sort's second pass settling the leaves' points itself: record in; 7 of 8 points leave as ~6 B xyz + 3 B rgb, every
+    # eighth as a 16-byte climber record (the few leaves it leaves to `settle` move 12 B out instead)
+    "downsweep_settle_kernel": 12.0 + 7.0 / 8.0 * 9.0 + 16.0 / 8.0,
 }
 VALU_F64_BOUND = ("leaf_encode_kernel", "chain_keys_kernel", "spec_encode_kernel")
 
@@ -1159,6 +1162,11 @@ def main():
         rec = timed.get("downsweep_rec_kernel")
         rec_passes = rec[0] / args.steps if rec else 0.0
         rec_ms = st.get("sort_records", 0.0)
+        # the settling second pass (downsweep_settle_kernel) is queued with the promotion stage, once the node tables are up: its
+        # event time joins the sort's here, its bytes are ALGO_BYTES' (it also does `settle`'s work for the leaves it finishes)
+        fused = timed.get("downsweep_settle_kernel")
+        fused_passes = fused[0] / args.steps if fused else 0.0
+        fused_ms = fused[1] / args.steps if fused else 0.0
         pass_b = 4.0 + 2 * rec_b  # per pass: 4 B histogram read + record read + record write
         # single-chain build with the first histogram taken from the rank counts (no upsweep_map launch): that pass does not
         # read the keys an extra time; with upsweep_map it reads them and writes the mapped keys back (4 B more)
@@ -1167,7 +1175,10 @@ def main():
         # upsweep<u32> launch either
         rows_both = rows_path and "upsweep_kernel<u32>" not in timed
         sort_b = rec_passes * pass_b + (-4.0 * rec_passes if rows_both else -4.0 if rows_path else (4.0 if "upsweep_map_kernel" in timed else 0.0))
-        record_sort = None if not rec else {"passes": rec_passes, "ms": round(rec_ms, 3), "record_bytes": rec_b,
+        sort_b += fused_passes * ALGO_BYTES["downsweep_settle_kernel"]
+        rec_ms += fused_ms
+        record_sort = None if not rec else {"passes": rec_passes + fused_passes, "ms": round(rec_ms, 3), "record_bytes": rec_b,
+                                            "second_pass_settles_the_leaves": bool(fused),
                                             "GB/s": round(n * sort_b / (rec_ms * 1e-3) / 1e9, 1) if rec_ms else None,
                                             "algorithmic_bytes_per_point": sort_b,
                                             "histograms": "both from the rank counts" if rows_both else "first from the rank counts" if rows_path else "own passes over the keys"}

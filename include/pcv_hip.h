@@ -249,6 +249,10 @@ uint64_t pcv_octree_spec_continued(const pcv_octree* t);
 /* Single-chain build with 12-byte records: number of points whose record left the chain pass with the codes of a
  * Float32-coded level (they wait in a dense side pool, the record names the entry); 0 otherwise. */
 uint64_t pcv_octree_wide_pool_entries(const pcv_octree* t);
+/* Single-chain build: points of the leaves whose final bytes the record sort's second pass produced itself (integer-coded
+ * leaves whose records hold their leaf codes; generation.rs:222-238 — the reference rewrites every point that stays in a
+ * node once); the other leaves' records are finished by the settle kernel. 0 when the sort ran to its end on its own. */
+uint64_t pcv_octree_settled_in_sort(const pcv_octree* t);
 /* Bytes of one record of the last build's record sort (rank + leaf codes + colour): 20, or 12 when the single-chain
  * build packed the record (16-bit codes; the points of Float32-coded levels travel as the index of their pool entry). */
 int pcv_octree_record_bytes(const pcv_octree* t);

@@ -133,6 +133,7 @@ _SIGNATURES = {
     "pcv_octree_record_bytes": (C.c_int, [_vp]),
     "pcv_octree_spec_continued": (C.c_uint64, [_vp]),
     "pcv_octree_wide_pool_entries": (C.c_uint64, [_vp]),
+    "pcv_octree_settled_in_sort": (C.c_uint64, [_vp]),
     "pcv_aabb_reduce": (C.c_int, [_vp, C.POINTER(Points), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "pcv_level_table": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_int,
                                   C.POINTER(C.c_double), C.POINTER(C.c_int32)]),

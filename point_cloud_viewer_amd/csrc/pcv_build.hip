@@ -887,6 +887,7 @@ extern "C" void pcv_octree_spec_stats(const pcv_octree* t, uint64_t stats[4]) {
 extern "C" int pcv_octree_record_bytes(const pcv_octree* t) { return t ? t->record_bytes : 0; }
 extern "C" uint64_t pcv_octree_spec_continued(const pcv_octree* t) { return t ? t->spec_continued : 0; }
 extern "C" uint64_t pcv_octree_wide_pool_entries(const pcv_octree* t) { return t ? t->wide_pool_entries : 0; }
+extern "C" uint64_t pcv_octree_settled_in_sort(const pcv_octree* t) { return t ? t->settled_in_sort : 0; }
 extern "C" int pcv_octree_device_blob(const pcv_octree* t, int which, const void** dptr, uint64_t* len) {
   if (!t || !dptr || !len || which < 0 || which > 2) return PCV_E_INVALID;
   *dptr = which == 0 ? t->d_xyz : (which == 1 ? t->d_rgb : t->d_int);
@@ -1500,9 +1501,9 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
     if ((rc = queue_record_sort(ctx, bs, t, nullptr, tt->num_leaves, false))) return rc;
     host_lap("record sort queued");
   }
-  // replayed leaves rewrite their SORTED records: the sort has to be complete in front of that
-  if (!bs->fix_ranges.empty() && (rc = pcv_radix_sort_records_second(ctx, &bs->sort_second, nullptr))) return rc;
-  if ((rc = queue_replay(ctx, bs))) return rc;
+  // replayed leaves rewrite their SORTED records: with the sort's second pass held back (PcvSortSecond) the replay is queued
+  // behind that pass, in pcv_build_finish
+  if (!bs->sort_second.pending && (rc = queue_replay(ctx, bs))) return rc;
   ctx->stage_begin(PCV_STAGE_TABLE);
   t->spec_stats[0] = tree.prefix.size();
   t->spec_stats[1] = (uint64_t)std::count(tree.inner.begin(), tree.inner.end(), (uint8_t)0);
@@ -2042,6 +2043,7 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
   }();
   const bool fuse_sort = bs->spec && bs->sort_second.pending && by_leaf && !t->has_intensity && !wide && bs->spec_wide;
   std::vector<uint8_t> fused_leaf;
+  uint64_t settled_points = 0;
   uint32_t* u_climb_base = (uint32_t*)(u_leaf_rec + num_leaves);
   const size_t items_off = (((size_t)(M + num_leaves) * sizeof(PcvNodeRec) + (size_t)num_leaves * 4) + 15) & ~(size_t)15;
   PcvSettleItem* u_items = (PcvSettleItem*)((uint8_t*)u_node_rec + items_off);
@@ -2060,11 +2062,16 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
       fused_leaf.assign(num_leaves, 0);
       std::vector<uint8_t> cont_leaf(num_leaves, 0);
       for (uint32_t leaf : bs->cont_nodes) cont_leaf[rank_of[leaf]] = 1;
+      for (const auto& fr : bs->fix_ranges) {  // replayed leaves: their records get their codes after the sort (queue_replay)
+        uint32_t r = (uint32_t)(std::lower_bound(u_leaf_lo, u_leaf_lo + num_leaves, fr.lo) - u_leaf_lo);
+        for (; r < num_leaves && u_leaf_lo[r] == fr.lo; ++r) cont_leaf[r] = 1;  // (empty leaves share their neighbour's first slot)
+      }
       std::vector<uint32_t> cnt_left(cnt);
       for (uint32_t r = 0; r < num_leaves; ++r)
         if (climbs[r] && !cont_leaf[r] && u_leaf_rec[r].enc <= PCV_ENC_UINT16) {
           fused_leaf[r] = 1;
           cnt_left[r] = 0;
+          settled_points += cnt[r];
         }
       num_items = pcv_settle_items(u_leaf_lo, cnt_left.data(), num_leaves, u_items);
     } else if (by_leaf) {
@@ -2155,6 +2162,7 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
     if ((rc = ctx->dev_alloc(&climbers, pcv_climber_bytes(num_climbers)))) return rc;
     sc.ptrs.push_back(climbers);
   }
+  t->settled_in_sort = fuse_sort ? settled_points : 0;
   if (bs->sort_second.pending) {  // the second pass of the record sort, now that tables and blobs exist
     PcvSortFuse fz;
     fz.leaf_rec = pt.leaf_rec;
@@ -2165,6 +2173,7 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
     fz.rgb_blob = t->d_rgb;
     fz.num_leaves = num_leaves;
     if ((rc = pcv_radix_sort_records_second(ctx, &bs->sort_second, fuse_sort ? &fz : nullptr))) return rc;
+    if ((rc = queue_replay(ctx, bs))) return rc;  // (held back with the pass: replayed leaves rewrite their sorted records)
   }
   // leaves below a split first candidate: the leaf-wise settle kernel continues their chain itself (its items name the
   // range); the slot-wise kernel (experiments) gets the codes rewritten by a pass of its own first

@@ -531,6 +531,7 @@ struct pcv_octree {
   uint64_t spec_stats[4] = {};  // single-chain build: nodes / leaves of the predicted tree, points in an unsplit first
                                 // candidate (their kept codes are their leaf codes), points that replayed the chain
   uint64_t wide_pool_entries = 0;  // single-chain build, 12-byte records: entries of the Float32-code pool the chain pass used
+  uint64_t settled_in_sort = 0;    // points of the leaves the record sort's second pass finished itself (PcvSortFuse)
   uint64_t spec_continued = 0;  // points whose chain was continued from the codes of a split candidate
   PcvOctreeQuery* query = nullptr;
   // octrees opened from a directory: node files are read on demand

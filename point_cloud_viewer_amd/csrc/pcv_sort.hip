@@ -610,22 +610,14 @@ constexpr uint32_t kFuseSettles = 1u, kFuseU8 = 2u;
 // digit each: a digit's run inside a tile is then ONE leaf's records at consecutive sorted slots. Waves take whole runs: the leaf's
 // record comes through the scalar cache, and the run's records leave as final bytes / climber records (flagged leaves) or as
 // 12-byte records like in the plain pass (the others: `settle` finishes those).
-template <int BLOCK, int KPT, int R, int WPE, bool NT, int MAP = 0 /* 1: the map in LDS (half words), 2: in global memory */, bool PL = false,
-          bool WC = false, bool FUSE = false>
-__global__ __launch_bounds__(BLOCK, WPE) void downsweep_rec12_kernel(const uint32_t* __restrict__ keys_in,
-                                                                     uint32_t* __restrict__ keys_out, uint64_t n, uint64_t chunk,
-                                                                     int groups, int shift, int nbits,
-                                                                     const uint32_t* __restrict__ offsets,
-                                                                     const uint32_t* __restrict__ totals,
-                                                                     const uint2* __restrict__ vec_in, uint2* __restrict__ vec_out,
-                                                                     const uint32_t* __restrict__ gmap = nullptr, uint32_t map_entries = 0,
-                                                                     const uint2* __restrict__ ranges = nullptr /* set: piece k
-                                                                     = the records [ranges[k].x, ranges[k].y) instead of chunk k */,
-                                                                     const uint32_t* __restrict__ order = nullptr /* set: workgroup
-                                                                     b takes piece order[b] (largest pieces first) */,
-                                                                     const uint32_t* __restrict__ plane_in = nullptr,
-                                                                     uint32_t* __restrict__ plane_out = nullptr,
-                                                                     PcvSortFuse fuse = PcvSortFuse()) {
+template <int BLOCK, int KPT, int R, int WPE, bool NT, int MAP, bool PL, bool WC, bool FUSE>
+__device__ __forceinline__ void downsweep_rec12_body(const uint32_t* __restrict__ keys_in, uint32_t* __restrict__ keys_out, uint64_t n,
+                                                     uint64_t chunk, int groups, int shift, int nbits, const uint32_t* __restrict__ offsets,
+                                                     const uint32_t* __restrict__ totals, const uint2* __restrict__ vec_in,
+                                                     uint2* __restrict__ vec_out, const uint32_t* __restrict__ gmap, uint32_t map_entries,
+                                                     const uint2* __restrict__ ranges, const uint32_t* __restrict__ order,
+                                                     const uint32_t* __restrict__ plane_in, uint32_t* __restrict__ plane_out,
+                                                     const PcvSortFuse& fuse) {
   constexpr int NW = BLOCK / 64, kTile = BLOCK * KPT, RW = R / 64;
   static_assert(!FUSE || (!PL && !WC && MAP == 0), "the settling pass: plain 12-byte records, second pass");
   __shared__ FuseLeaf sleaf[FUSE ? R : 1];  // FUSE: the leaf of digit value d in this piece: rank = d << low_bits | the piece's lower digit
@@ -985,6 +977,36 @@ __global__ __launch_bounds__(BLOCK, WPE) void downsweep_rec12_kernel(const uint3
 }
 
 
+template <int BLOCK, int KPT, int R, int WPE, bool NT, int MAP = 0 /* 1: the map in LDS (half words), 2: in global memory */, bool PL = false,
+          bool WC = false>
+__global__ __launch_bounds__(BLOCK, WPE) void downsweep_rec12_kernel(const uint32_t* __restrict__ keys_in,
+                                                                     uint32_t* __restrict__ keys_out, uint64_t n, uint64_t chunk,
+                                                                     int groups, int shift, int nbits,
+                                                                     const uint32_t* __restrict__ offsets,
+                                                                     const uint32_t* __restrict__ totals,
+                                                                     const uint2* __restrict__ vec_in, uint2* __restrict__ vec_out,
+                                                                     const uint32_t* __restrict__ gmap = nullptr, uint32_t map_entries = 0,
+                                                                     const uint2* __restrict__ ranges = nullptr /* set: piece k
+                                                                     = the records [ranges[k].x, ranges[k].y) instead of chunk k */,
+                                                                     const uint32_t* __restrict__ order = nullptr /* set: workgroup
+                                                                     b takes piece order[b] (largest pieces first) */,
+                                                                     const uint32_t* __restrict__ plane_in = nullptr,
+                                                                     uint32_t* __restrict__ plane_out = nullptr) {
+  downsweep_rec12_body<BLOCK, KPT, R, WPE, NT, MAP, PL, WC, false>(keys_in, keys_out, n, chunk, groups, shift, nbits, offsets, totals, vec_in,
+                                                                  vec_out, gmap, map_entries, ranges, order, plane_in, plane_out, PcvSortFuse());
+}
+// the settling form of the second pass (FUSE above): a kernel of its own name for the profiles
+template <int R>
+__global__ __launch_bounds__(1024, 4) void downsweep_settle_kernel(const uint32_t* __restrict__ keys_in, uint32_t* __restrict__ keys_out,
+                                                                   uint64_t n, uint64_t chunk, int groups, int shift, int nbits,
+                                                                   const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ totals,
+                                                                   const uint2* __restrict__ vec_in, uint2* __restrict__ vec_out,
+                                                                   const uint2* __restrict__ ranges, const uint32_t* __restrict__ order,
+                                                                   PcvSortFuse fuse) {
+  downsweep_rec12_body<1024, 8, R, 4, false, 0, false, false, true>(keys_in, keys_out, n, chunk, groups, shift, nbits, offsets, totals, vec_in,
+                                                                   vec_out, nullptr, 0u, ranges, order, nullptr, nullptr, fuse);
+}
+
 // First-pass histogram of the record sort from the per-workgroup rank counts (rank_hist rows, pcv_encode.hip) and the rank map:
 // workgroup g's count of digit d = sum over the predicted leaves b whose TRUE rank has digit d of rows[g][b]. One workgroup
 // per sort workgroup; the keys are not read.
@@ -1014,7 +1036,7 @@ __global__ __launch_bounds__(256) void hist12_from_rows_kernel(const uint32_t* _
                                                                 uint32_t* __restrict__ hist1 /* [d1][groups] */,
                                                                 uint32_t* __restrict__ rows_true /* [groups][D1 * D2] */,
                                                                 int msd /* experiments: the FIRST pass takes the rank's upper nbits1 bits */) {
-  __shared__ uint32_t tr[16384];  // 64 KB: ranks of up to 14 bits
+  extern __shared__ uint32_t tr[];  // D1 x D2 counters: 64 KB for ranks of 14 bits, 128 KB for 15
   const uint32_t D1 = 1u << nbits1, D2 = 1u << nbits2, TB = D1 * D2;
   const int sh1 = msd ? nbits2 : 0, sh2 = msd ? 0 : nbits1;
   for (uint32_t i = threadIdx.x; i < TB; i += 256) tr[i] = 0;
@@ -1158,6 +1180,10 @@ static void rec12_launch(pcv_ctx* ctx, int variant, const SortGeom& g, const uin
 #undef PCV_REC12
 }
 
+// true-rank counters per sort workgroup the scratch holds (hist12_from_rows_kernel): 2^14, and 2^15 for clouds big enough to have
+// that many leaves (128 MB of scratch instead of 64)
+static uint32_t rows_true_bins(uint64_t n) { return n >= 200000000ull ? 32768u : 16384u; }
+
 template <typename KeyT>
 int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int end_bit, PcvSortPayload* payload,
                void* scratch, bool* result_in_a, const uint32_t* map = nullptr, uint32_t map_entries = 0,
@@ -1212,8 +1238,9 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
       }();
       msd = msd_on;
 #endif
-      const bool two = pass2_rows_on && map_entries <= 16384 && shift + width < end_bit && shift + 2 * width >= end_bit && total_bits <= 14 &&
-                       nbits2 >= 1 && g.groups >= 8;
+      // (ranks of 15 bits — trees of up to 32 768 leaves — where the scratch holds their counters: rows_true_bins)
+      const bool two = pass2_rows_on && map_entries <= rows_true_bins(n) && shift + width < end_bit && shift + 2 * width >= end_bit &&
+                       (1u << total_bits) <= rows_true_bins(n) && nbits2 >= 1 && g.groups >= 8;
       msd = msd && two;
       // first / second pass: (shift, bits) of their digits — the lower digit first, unless msd
       const int p1_shift = msd ? shift + width : shift, p1_bits = msd ? nbits2 : nbits;
@@ -1225,9 +1252,13 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
       uint32_t* rows_true = order + kMaxGroups;
       {
         PcvProf prof(ctx, PCV_K_SORT_HIST_ROWS);
-        if (two)  // (msd: the first pass takes the upper nbits2 bits, the second the lower nbits)
-          hipLaunchKernelGGL(hist12_from_rows_kernel, dim3(g.groups), dim3(256), 0, ctx->stream, rows, map_entries, map,
-                             p1_bits, p2_bits, g.groups, hist, rows_true, msd ? 1 : 0);
+        if (two) {  // (msd: the first pass takes the upper nbits2 bits, the second the lower nbits)
+          static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&hist12_from_rows_kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 131072) == hipSuccess;
+          (void)ok;
+          hipLaunchKernelGGL(hist12_from_rows_kernel, dim3(g.groups), dim3(256), (size_t)4 << (p1_bits + p2_bits), ctx->stream, rows,
+                             map_entries, map, p1_bits, p2_bits, g.groups, hist, rows_true, msd ? 1 : 0);
+        }
         else
           hipLaunchKernelGGL(hist_from_rows_kernel, dim3(g.groups), dim3(256), 0, ctx->stream, rows, map_entries, map, shift - begin_bit,
                              mask, g.groups, hist);
@@ -1432,7 +1463,7 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
 // workgroup, 64 MB) — the last only for inputs whose record sort can take the two-pass rows path at all (12-byte records in
 // tiles of 8 192, i.e. >= 8 sort workgroups: n >= 65 536); small builds (tests, virtual ranks) get by with 2 MB
 size_t pcv_sort_scratch_bytes(uint64_t n) {
-  const size_t rows_true = make_geom(n, 8192).groups >= 8 ? 16384 * (size_t)kMaxGroups : 0;
+  const size_t rows_true = make_geom(n, 8192).groups >= 8 ? rows_true_bins(n) * (size_t)kMaxGroups : 0;
   return (2 * ((size_t)kRadix * kMaxGroups + kRadix) + 3 * (size_t)kMaxGroups + rows_true) * sizeof(uint32_t) + 256;
 }
 
@@ -1455,22 +1486,26 @@ int pcv_radix_sort_records_mapped(pcv_ctx* ctx, uint32_t* keys_a, uint32_t* keys
 int pcv_radix_sort_records_second(pcv_ctx* ctx, PcvSortSecond* sd, const PcvSortFuse* fuse) {
   if (!sd || !sd->pending) return PCV_OK;
   sd->pending = false;
-#define PCV_REC12_SECOND(R, F, ARG)                                                                                                      \
-  hipLaunchKernelGGL((downsweep_rec12_kernel<1024, 8, R, 4, false, 0, false, false, F>), dim3(sd->pieces), dim3(1024), 0, ctx->stream,    \
-                     sd->src, sd->dst, sd->n, sd->chunk, sd->pieces, sd->shift, sd->nbits, sd->hist, sd->totals,                          \
-                     (const uint2*)sd->vec_src, (uint2*)sd->vec_dst, (const uint32_t*)nullptr, 0u, (const uint2*)sd->ranges, sd->order,    \
-                     (const uint32_t*)nullptr, (uint32_t*)nullptr, ARG)
+#define PCV_REC12_SECOND(R)                                                                                                              \
+  hipLaunchKernelGGL((downsweep_rec12_kernel<1024, 8, R, 4, false, 0, false, false>), dim3(sd->pieces), dim3(1024), 0, ctx->stream, sd->src, \
+                     sd->dst, sd->n, sd->chunk, sd->pieces, sd->shift, sd->nbits, sd->hist, sd->totals, (const uint2*)sd->vec_src,         \
+                     (uint2*)sd->vec_dst, (const uint32_t*)nullptr, 0u, (const uint2*)sd->ranges, sd->order)
+#define PCV_REC12_SETTLE(R, ARG)                                                                                                         \
+  hipLaunchKernelGGL((downsweep_settle_kernel<R>), dim3(sd->pieces), dim3(1024), 0, ctx->stream, sd->src, sd->dst, sd->n, sd->chunk,      \
+                     sd->pieces, sd->shift, sd->nbits, sd->hist, sd->totals, (const uint2*)sd->vec_src, (uint2*)sd->vec_dst,              \
+                     (const uint2*)sd->ranges, sd->order, ARG)
   if (fuse) {
     PcvProf prof(ctx, PCV_K_SORT_SETTLE);
     PcvSortFuse fz = *fuse;
     fz.low_bits = (uint32_t)sd->low_bits, fz.blocks = (uint32_t)sd->blocks;
-    if (sd->nbits <= 7) PCV_REC12_SECOND(128, true, fz);
-    else PCV_REC12_SECOND(256, true, fz);
+    if (sd->nbits <= 7) PCV_REC12_SETTLE(128, fz);
+    else PCV_REC12_SETTLE(256, fz);
   } else {
     PcvProf prof(ctx, PCV_K_SORT_DOWNSWEEP_REC);
-    if (sd->nbits <= 7) PCV_REC12_SECOND(128, false, PcvSortFuse());
-    else PCV_REC12_SECOND(256, false, PcvSortFuse());
+    if (sd->nbits <= 7) PCV_REC12_SECOND(128);
+    else PCV_REC12_SECOND(256);
   }
+#undef PCV_REC12_SETTLE
 #undef PCV_REC12_SECOND
   return hipGetLastError() == hipSuccess ? PCV_OK : ctx->fail(PCV_E_HIP, "record sort: second pass");
 }

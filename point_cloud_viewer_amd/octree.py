@@ -608,7 +608,8 @@ class OctreeResult:
         """key_levels, attempts (0 = single-chain build, 1 = exact pipeline, >= 2 something was redone) and the
         single-chain statistics (predicted nodes / leaves, points whose leaf is an unsplit candidate, points whose chain
         was continued from a split candidate's codes, points that replayed the chain from their coordinates);
-        record_bytes: bytes per record of the record sort (20, or 12 packed)."""
+        record_bytes: bytes per record of the record sort (20, or 12 packed); settled_in_sort: points of the leaves the
+        record sort's second pass finished itself."""
         lv, at = C.c_int(), C.c_int()
         self.lib.pcv_octree_build_info(self.handle, C.byref(lv), C.byref(at))
         st = (C.c_uint64 * 4)()
@@ -616,7 +617,8 @@ class OctreeResult:
         return dict(key_levels=lv.value, attempts=at.value, single_chain=at.value == 0,
                     record_bytes=int(self.lib.pcv_octree_record_bytes(self.handle)), predicted_nodes=st[0], predicted_leaves=st[1], kept_code_points=st[2], replayed_points=st[3],
                     continued_points=int(self.lib.pcv_octree_spec_continued(self.handle)),
-                    wide_pool_entries=int(self.lib.pcv_octree_wide_pool_entries(self.handle)))
+                    wide_pool_entries=int(self.lib.pcv_octree_wide_pool_entries(self.handle)),
+                    settled_in_sort=int(self.lib.pcv_octree_settled_in_sort(self.handle)))
 
     def write_dir(self, directory):
         self.ctx._check(self.lib.pcv_octree_write_dir(self.handle, str(directory).encode()))

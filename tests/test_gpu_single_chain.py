@@ -139,6 +139,54 @@ def test_intensity_plane_rides_the_12_byte_record_sort(ctx, n, cap, lo, hi):
     t.free()
 
 
+@pytest.mark.parametrize("n,cap,lo,hi", [(1_500_000, 1_500, 1_024, 8_192),    # two passes of <= 7 bits: 128 digit values in the settling pass
+                                         (1_500_000, 800, 4_000, 16_384),     # 14 rank bits
+                                         (300_000_000, 55_000, 16_384, 32_768)])  # 15 rank bits (8 + 7): clouds of >= 200 M points only
+def test_second_sort_pass_settles_the_leaves(ctx, n, cap, lo, hi):
+    """Colour-only single-chain builds: the record sort's second pass writes the final bytes of the integer-coded leaves itself
+    (downsweep_settle_kernel: the rewrite of generation.rs:222-238 and the node-contiguous layout of raw.rs:361-450) and the
+    climber records of their every-8th points; the settle kernel only sees the leaves left over (Float32-coded ones, chains
+    to continue). Same bytes as the oracle; build_info says how many points went that way."""
+    if n > 10_000_000:  # the 15-bit geometry needs a cloud whose sort scratch holds 2^15 counters per workgroup: device-side cloud
+        import torch
+        import bench
+        dev = torch.device("cuda", 0)
+        x, y, z, rgb = bench.make_cloud(torch, n, seed=5, device=dev, clusters=40, extent=300.0, sigma=(0.5, 9.0))
+        t = ctx.build(0.001, None, x, y, z, rgb, max_points_per_node=cap, single_chain=True, check_resolve=True)
+        info = t.build_info()
+        leaves = info["predicted_leaves"]
+        assert lo < leaves <= hi, info
+        assert info["settled_in_sort"] > 0.5 * n, info
+        # no oracle at this size inside a unit test: the same build with the pass switched off is the reference (digest of every byte)
+        d1 = bench.digest_of_digests(bench.tree_digests(t))
+        t.free()
+        import os, subprocess, sys
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        code = ("import sys; sys.path.insert(0, sys.argv[1]); import torch, bench, point_cloud_viewer_amd as pcv\n"
+                "dev = torch.device('cuda', 0); ctx = pcv.Context(0)\n"
+                f"x, y, z, rgb = bench.make_cloud(torch, {n}, seed=5, device=dev, clusters=40, extent=300.0, sigma=(0.5, 9.0))\n"
+                f"t = ctx.build(0.001, None, x, y, z, rgb, max_points_per_node={cap}, single_chain=True, check_resolve=True)\n"
+                "assert t.build_info()['settled_in_sort'] == 0\nprint('digest', bench.digest_of_digests(bench.tree_digests(t)))\n")
+        del x, y, z, rgb
+        torch.cuda.empty_cache()
+        out = subprocess.run([sys.executable, "-c", code, root], env=dict(os.environ, PCV_HIP_LIBRARY="exp", PCV_SETTLE_IN_SORT="0"),
+                             capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0 and f"digest {d1}" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+        return
+    x, y, z, rgb, bmin, bmax = synthetic.gaussian_clusters(n, seed=33, num_clusters=9, extent=250.0, sigma_range=(0.3, 7.0))
+    with O.max_points_per_node(cap):
+        want = O.build_closed(0.001, bmin, bmax, x, y, z, rgb, threads=8)
+    leaves = len(want.nodes) - len({k[:-1] for k in want.nodes if len(k) > 1})
+    assert lo < leaves <= hi, leaves
+    for bbox in (pcv.Aabb(bmin, bmax), None):
+        t = ctx.build(0.001, bbox, x, y, z, rgb, max_points_per_node=cap, single_chain=True, check_resolve=True)
+        info = t.build_info()
+        assert info["single_chain"] and info["record_bytes"] == 12 and info["settled_in_sort"] > 0.5 * n, info
+        if bbox is not None:
+            assert_same(t.to_dict(), want)
+        t.free()
+
+
 def test_single_chain_is_the_default_from_4M_points_and_keeps_candidate_codes(ctx):
     n = 6_000_000
     x, y, z, rgb, bmin, bmax = synthetic.gaussian_clusters(n, seed=8, num_clusters=24, extent=500.0, sigma_range=(0.3, 9.0))
@@ -284,6 +332,8 @@ print("alt-path ok")
                                               ({"PCV_REC_WC": "3"}, 12),
                                               # the record sort's upper digit first, the second pass inside every bucket (experiment)
                                               ({"PCV_SORT_MSD": "1"}, 12),
+                                              # the record sort running to its end on its own, every leaf finished by the settle kernel
+                                              ({"PCV_SETTLE_IN_SORT": "0"}, 12),
                                               # the sample tree by counting the keys instead of from sorted keys (experiment, slower)
                                               ({"PCV_SAMPLE_COUNTS": "1"}, 12),
                                               # the sample tree split one level per launch pair (what u32 keys and levels
