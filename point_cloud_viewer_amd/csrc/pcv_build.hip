@@ -1106,7 +1106,7 @@ static int queue_record_sort(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, const Pc
   if (bs->spec_map_dev)
     rc = pcv_radix_sort_records_mapped(ctx, rank_a, rank_b, n, rank_bits, &pl, bs->sort_scratch, bs->spec_map_dev,
                                        bs->spec_map_entries, &rec_in_a, compact && pl.nwords <= 1 ? bs->spec_rows : nullptr,
-                                       compact && pl.nwords == 0 && pcv_settle_in_sort() ? &bs->sort_second : nullptr);
+                                       compact && pl.nwords <= 1 && !wide && pcv_settle_in_sort() ? &bs->sort_second : nullptr);
   else
     rc = pcv_radix_sort_u32(ctx, rank_a, rank_b, n, 0, rank_bits, &pl, bs->sort_scratch, &rec_in_a);
   if (rc) return rc;
@@ -2041,7 +2041,7 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
     const char* e = pcv_experiment("PCV_SETTLE_BY_LEAF");
     return !e || atoi(e) != 0;
   }();
-  const bool fuse_sort = bs->spec && bs->sort_second.pending && by_leaf && !t->has_intensity && !wide && bs->spec_wide;
+  const bool fuse_sort = bs->spec && bs->sort_second.pending && bs->sort_second.nbits <= 7 && by_leaf && !wide && bs->spec_wide;
   std::vector<uint8_t> fused_leaf;
   uint64_t settled_points = 0;
   uint32_t* u_climb_base = (uint32_t*)(u_leaf_rec + num_leaves);
@@ -2151,11 +2151,13 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
   }
   // the compact climber records live in the payload buffer the sort left unused (32 B x n / 8 < 16 B x n)
   void* climbers = rec_in_a ? (void*)pay_b : (void*)pay_a;
-  if (fuse_sort) {  // that buffer is the held-back pass's SOURCE: the (16-byte) climbers go to the free half of a key buffer
+  if (fuse_sort) {  // that buffer is the held-back pass's SOURCE: the (16-byte) climbers go to the free half of a key buffer — with
+                    // an intensity plane that half carries the plane, and the (32-byte) climbers get a block of their own
     const size_t half = ((size_t)n * 4 + 15) & ~(size_t)15;
     climbers = (void*)((uint8_t*)(rec_in_a ? keys_b : keys_a) + half);
-    if (half + (num_climbers + 1) * 16 > (uint64_t)n * 8) {
-      if ((rc = ctx->dev_alloc(&climbers, (size_t)(num_climbers + 1) * 16))) return rc;
+    const size_t need = t->has_intensity ? pcv_climber_bytes(num_climbers) : (size_t)(num_climbers + 1) * 16;
+    if (t->has_intensity || half + need > (uint64_t)n * 8) {
+      if ((rc = ctx->dev_alloc(&climbers, need))) return rc;
       sc.ptrs.push_back(climbers);
     }
   } else if (pcv_climber_bytes(num_climbers) > (size_t)n * (bs->spec_wide ? 8 : 16)) {
@@ -2171,6 +2173,7 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
     fz.climbers = climbers;
     fz.xyz_blob = t->d_xyz;
     fz.rgb_blob = t->d_rgb;
+    fz.inten_blob = t->d_int;
     fz.num_leaves = num_leaves;
     if ((rc = pcv_radix_sort_records_second(ctx, &bs->sort_second, fuse_sort ? &fz : nullptr))) return rc;
     if ((rc = queue_replay(ctx, bs))) return rc;  // (held back with the pass: replayed leaves rewrite their sorted records)

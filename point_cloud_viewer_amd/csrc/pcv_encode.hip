@@ -747,10 +747,7 @@ __constant__ uint32_t pcv_exp_settle_items = 0;
 #else
 #define PCV_WIDE_INDEX(i) (i)
 #endif
-struct alignas(16) PcvClimber {
-  uint4 pay;
-  uint32_t rank, slot, inten, pad;
-};
+// (PcvClimber: pcv_settle_dev.h)
 
 // one sorted slot of `settle`: finish it in its leaf, or hand it to `climb`
 // kClimb16: the climber record is the 16-byte payload alone {code x, code y, code z, rgb} — leaf, slot and position in the

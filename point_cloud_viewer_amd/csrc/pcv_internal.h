@@ -340,6 +340,8 @@ struct PcvSortSecond {
   uint32_t* dst = nullptr;
   const void* vec_src = nullptr;   // uint2 payloads after the first pass
   void* vec_dst = nullptr;
+  const uint32_t* plane_src = nullptr;  // the intensity plane travelling with the records, or null
+  uint32_t* plane_dst = nullptr;
   uint64_t n = 0, chunk = 0;
   int pieces = 0, shift = 0, nbits = 0;
   int low_bits = 0, blocks = 1;  // piece k holds the records whose rank's lower `low_bits` bits are k / blocks
@@ -355,9 +357,10 @@ struct PcvSortFuse {
   const PcvNodeRec* leaf_rec = nullptr;  // per true leaf rank
   const uint8_t* leaf_fused = nullptr;   // per true leaf rank: 1 = settled here (u8 / u16 codes, no continuation, no replay, not the root)
   const uint32_t* climb_base = nullptr;
-  void* climbers = nullptr;              // uint4 per climber
+  void* climbers = nullptr;              // uint4 per climber; PcvClimber (32 bytes) with an intensity plane
   uint8_t* xyz_blob = nullptr;
   uint8_t* rgb_blob = nullptr;
+  uint8_t* inten_blob = nullptr;         // set when the records travel with an intensity plane
   uint32_t num_leaves = 0;
   uint32_t low_bits = 0, blocks = 1;  // (filled by pcv_radix_sort_records_second from the held-back pass)
 };

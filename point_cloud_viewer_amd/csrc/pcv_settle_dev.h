@@ -99,4 +99,10 @@ __device__ __forceinline__ void promote_one(const PcvPromoteTables& pt, uint64_t
   }
 }
 
+// a climber as `settle` (or the record sort's settling pass) hands it to `climb` when the 16-byte payload alone will not do
+// (an intensity plane, Float64 high words): codes + colour, its leaf, its sorted slot, its intensity
+struct alignas(16) PcvClimber {
+  uint4 pay;
+  uint32_t rank, slot, inten, pad;
+};
 }  // namespace

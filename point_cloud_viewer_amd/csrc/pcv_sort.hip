@@ -600,10 +600,12 @@ struct DigitStateN {
 // (48 KB of carry next to the 107 KB of the tile), no plane, no map copy in LDS.
 // the settling pass's view of a leaf (one entry per digit value of the piece, in LDS)
 struct alignas(16) FuseLeaf {
-  uint32_t lo, climb_base, flags, pad;
+  uint32_t lo, climb_base, flags, rank;
   uint8_t* xyz;  // first byte of the leaf's .xyz content
   uint8_t* rgb;
   double mn[3], edge, inv_edge, inv_edge_lo;
+  uint8_t* inten;  // (intensity plane) first byte of the leaf's .intensity content
+  uint64_t pad;
 };
 constexpr uint32_t kFuseSettles = 1u, kFuseU8 = 2u;
 // FUSE (PcvSortFuse, pcv_internal.h): the pass is the LAST one of a two-pass sort whose pieces hold one value of the rank's lower
@@ -619,7 +621,7 @@ __device__ __forceinline__ void downsweep_rec12_body(const uint32_t* __restrict_
                                                      const uint32_t* __restrict__ plane_in, uint32_t* __restrict__ plane_out,
                                                      const PcvSortFuse& fuse) {
   constexpr int NW = BLOCK / 64, kTile = BLOCK * KPT, RW = R / 64;
-  static_assert(!FUSE || (!PL && !WC && MAP == 0), "the settling pass: plain 12-byte records, second pass");
+  static_assert(!FUSE || (!WC && MAP == 0), "the settling pass: second pass of 12-byte records (+ the intensity plane)");
   __shared__ FuseLeaf sleaf[FUSE ? R : 1];  // FUSE: the leaf of digit value d in this piece: rank = d << low_bits | the piece's lower digit
   const uint32_t piece = order ? order[blockIdx.x] : blockIdx.x;
   static_assert(BLOCK >= R && R % 64 == 0 && KPT % 8 == 0, "geometry");
@@ -642,7 +644,9 @@ __device__ __forceinline__ void downsweep_rec12_body(const uint32_t* __restrict_
       const PcvNodeRec c = fuse.leaf_rec[r];
       L.lo = c.lo, L.climb_base = fuse.climb_base[r];
       L.flags = (fuse.leaf_fused[r] ? kFuseSettles : 0u) | (c.enc == PCV_ENC_UINT8 ? kFuseU8 : 0u);
+      L.rank = r;
       L.xyz = fuse.xyz_blob + c.xyz_off, L.rgb = fuse.rgb_blob + c.point_off * 3;
+      L.inten = PL ? fuse.inten_blob + c.point_off * 4 : nullptr;
       L.mn[0] = c.mn[0], L.mn[1] = c.mn[1], L.mn[2] = c.mn[2];
       L.edge = c.edge, L.inv_edge = c.inv_edge, L.inv_edge_lo = c.inv_edge_lo;
     }
@@ -887,16 +891,19 @@ __device__ __forceinline__ void downsweep_rec12_body(const uint32_t* __restrict_
         const FuseLeaf& L = sleaf[d];
         const uint32_t g = S.delta[d] + p;  // sorted slot
         const uint32_t flags = L.flags;
+        const uint32_t inten = PL ? splane[p] : 0u;
         if (!(flags & kFuseSettles)) {  // `settle` finishes this leaf: the 12-byte record as in the plain pass
           keys_out[g] = k;
           vec_out[g] = q;
+          if (PL) plane_out[g] = inten;
           continue;
         }
         const uint32_t j = g - L.lo;  // position in the leaf's stream
         const uint32_t rgb = (q.y >> 16) | ((k & 0xffu) << 16);
         const uint32_t c0 = q.x & 0xffffu, c1 = q.x >> 16, c2 = q.y & 0xffffu;
         if ((j & 7u) == 0) {  // every eighth point climbs: its record for `climb`, dense per leaf
-          reinterpret_cast<uint4*>(fuse.climbers)[L.climb_base + (j >> 3)] = make_uint4(c0, c1, c2, rgb);
+          if (PL) reinterpret_cast<PcvClimber*>(fuse.climbers)[L.climb_base + (j >> 3)] = PcvClimber{make_uint4(c0, c1, c2, rgb), L.rank, g, inten, 0u};
+          else reinterpret_cast<uint4*>(fuse.climbers)[L.climb_base + (j >> 3)] = make_uint4(c0, c1, c2, rgb);
           continue;
         }
         // final rewrite encode(decode(code)) at the leaf's own level (promote_final, pcv_settle_dev.h) with the
@@ -919,6 +926,7 @@ __device__ __forceinline__ void downsweep_rec12_body(const uint32_t* __restrict_
         }
         const uint32_t slot = j - (j >> 3) - 1u;
         const bool odd = (slot & 1u) != 0;
+        if (PL) reinterpret_cast<uint32_t*>(L.inten)[slot] = inten;
         // 3 bytes at 3 x slot: one 2-byte store at the even address of the three + one byte
         uint8_t* cd = L.rgb + (uint64_t)slot * 3;
         *reinterpret_cast<uint16_t*>(cd + (odd ? 1 : 0)) = (uint16_t)(odd ? rgb >> 8 : rgb);
@@ -996,15 +1004,17 @@ __global__ __launch_bounds__(BLOCK, WPE) void downsweep_rec12_kernel(const uint3
                                                                   vec_out, gmap, map_entries, ranges, order, plane_in, plane_out, PcvSortFuse());
 }
 // the settling form of the second pass (FUSE above): a kernel of its own name for the profiles
-template <int R>
+// (128 digit values: the second digit of a rank of <= 15 bits has <= 7 bits)
+template <bool PL>
 __global__ __launch_bounds__(1024, 4) void downsweep_settle_kernel(const uint32_t* __restrict__ keys_in, uint32_t* __restrict__ keys_out,
                                                                    uint64_t n, uint64_t chunk, int groups, int shift, int nbits,
                                                                    const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ totals,
                                                                    const uint2* __restrict__ vec_in, uint2* __restrict__ vec_out,
                                                                    const uint2* __restrict__ ranges, const uint32_t* __restrict__ order,
+                                                                   const uint32_t* __restrict__ plane_in, uint32_t* __restrict__ plane_out,
                                                                    PcvSortFuse fuse) {
-  downsweep_rec12_body<1024, 8, R, 4, false, 0, false, false, true>(keys_in, keys_out, n, chunk, groups, shift, nbits, offsets, totals, vec_in,
-                                                                   vec_out, nullptr, 0u, ranges, order, nullptr, nullptr, fuse);
+  downsweep_rec12_body<1024, 8, 128, 4, false, 0, PL, false, true>(keys_in, keys_out, n, chunk, groups, shift, nbits, offsets, totals, vec_in,
+                                                                  vec_out, nullptr, 0u, ranges, order, plane_in, plane_out, fuse);
 }
 
 // First-pass histogram of the record sort from the per-workgroup rank counts (rank_hist rows, pcv_encode.hip) and the rank map:
@@ -1334,12 +1344,14 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
         else
           hipLaunchKernelGGL(scan_kernel, dim3(kRadix), dim3(256), 0, ctx->stream, hist2, pieces, totals2);
       }
-      if (second && !with_plane && !msd) {  // the caller queues the pass itself (pcv_radix_sort_records_second)
+      if (second && !msd) {  // the caller queues the pass itself (pcv_radix_sort_records_second)
         second->pending = true;
         second->src = (const uint32_t*)(in_a ? a : b);
         second->dst = (uint32_t*)(in_a ? b : a);
         second->vec_src = in_a ? payload->vec_in : payload->vec_out;
         second->vec_dst = in_a ? payload->vec_out : payload->vec_in;
+        second->plane_src = with_plane ? (in_a ? payload->in[0] : payload->out[0]) : nullptr;
+        second->plane_dst = with_plane ? (in_a ? payload->out[0] : payload->in[0]) : nullptr;
         second->n = n, second->chunk = g.chunk;
         second->pieces = pieces, second->shift = p2_shift, second->nbits = p2_bits;
         second->low_bits = p1_bits, second->blocks = blocks;
@@ -1486,24 +1498,28 @@ int pcv_radix_sort_records_mapped(pcv_ctx* ctx, uint32_t* keys_a, uint32_t* keys
 int pcv_radix_sort_records_second(pcv_ctx* ctx, PcvSortSecond* sd, const PcvSortFuse* fuse) {
   if (!sd || !sd->pending) return PCV_OK;
   sd->pending = false;
-#define PCV_REC12_SECOND(R)                                                                                                              \
-  hipLaunchKernelGGL((downsweep_rec12_kernel<1024, 8, R, 4, false, 0, false, false>), dim3(sd->pieces), dim3(1024), 0, ctx->stream, sd->src, \
+#define PCV_REC12_SECOND(R, P)                                                                                                           \
+  hipLaunchKernelGGL((downsweep_rec12_kernel<1024, 8, R, 4, false, 0, P, false>), dim3(sd->pieces), dim3(1024), 0, ctx->stream, sd->src,     \
                      sd->dst, sd->n, sd->chunk, sd->pieces, sd->shift, sd->nbits, sd->hist, sd->totals, (const uint2*)sd->vec_src,         \
-                     (uint2*)sd->vec_dst, (const uint32_t*)nullptr, 0u, (const uint2*)sd->ranges, sd->order)
-#define PCV_REC12_SETTLE(R, ARG)                                                                                                         \
-  hipLaunchKernelGGL((downsweep_settle_kernel<R>), dim3(sd->pieces), dim3(1024), 0, ctx->stream, sd->src, sd->dst, sd->n, sd->chunk,      \
+                     (uint2*)sd->vec_dst, (const uint32_t*)nullptr, 0u, (const uint2*)sd->ranges, sd->order, sd->plane_src, sd->plane_dst)
+#define PCV_REC12_SETTLE(P, ARG)                                                                                                         \
+  hipLaunchKernelGGL((downsweep_settle_kernel<P>), dim3(sd->pieces), dim3(1024), 0, ctx->stream, sd->src, sd->dst, sd->n, sd->chunk,      \
                      sd->pieces, sd->shift, sd->nbits, sd->hist, sd->totals, (const uint2*)sd->vec_src, (uint2*)sd->vec_dst,              \
-                     (const uint2*)sd->ranges, sd->order, ARG)
-  if (fuse) {
+                     (const uint2*)sd->ranges, sd->order, sd->plane_src, sd->plane_dst, ARG)
+  const bool plane = sd->plane_src != nullptr;
+  if (fuse && sd->nbits <= 7 && (!plane || fuse->inten_blob)) {
     PcvProf prof(ctx, PCV_K_SORT_SETTLE);
     PcvSortFuse fz = *fuse;
     fz.low_bits = (uint32_t)sd->low_bits, fz.blocks = (uint32_t)sd->blocks;
-    if (sd->nbits <= 7) PCV_REC12_SETTLE(128, fz);
-    else PCV_REC12_SETTLE(256, fz);
+    if (plane) PCV_REC12_SETTLE(true, fz);
+    else PCV_REC12_SETTLE(false, fz);
   } else {
+    if (fuse) return ctx->fail(PCV_E_INVALID, "record sort: the settling pass needs a second digit of <= 7 bits");
     PcvProf prof(ctx, PCV_K_SORT_DOWNSWEEP_REC);
-    if (sd->nbits <= 7) PCV_REC12_SECOND(128);
-    else PCV_REC12_SECOND(256);
+    if (sd->nbits <= 7 && plane) PCV_REC12_SECOND(128, true);
+    else if (sd->nbits <= 7) PCV_REC12_SECOND(128, false);
+    else if (plane) PCV_REC12_SECOND(256, true);
+    else PCV_REC12_SECOND(256, false);
   }
 #undef PCV_REC12_SETTLE
 #undef PCV_REC12_SECOND

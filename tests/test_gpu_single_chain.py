@@ -185,6 +185,16 @@ def test_second_sort_pass_settles_the_leaves(ctx, n, cap, lo, hi):
         if bbox is not None:
             assert_same(t.to_dict(), want)
         t.free()
+    # the reference binary's payload (src/bin/build_octree.rs:47-52): the intensity plane goes through the settling pass too
+    # (downsweep_settle_kernel<true>: 4 bytes per point into .intensity, 32-byte climber records)
+    inten = ((np.arange(n, dtype=np.int64) * 2654435761) % 100_003).astype(np.float32) * 0.25 - 7.0
+    with O.max_points_per_node(cap):
+        want = O.build_closed(0.001, bmin, bmax, x, y, z, rgb, inten, threads=8)
+    t = ctx.build(0.001, pcv.Aabb(bmin, bmax), x, y, z, rgb, inten, max_points_per_node=cap, single_chain=True, check_resolve=True)
+    info = t.build_info()
+    assert info["single_chain"] and info["record_bytes"] == 12 and info["settled_in_sort"] > 0.5 * n, info
+    assert_same(t.to_dict(), want, check_intensity=True)
+    t.free()
 
 
 def test_single_chain_is_the_default_from_4M_points_and_keeps_candidate_codes(ctx):
