@@ -377,15 +377,19 @@ def intensity_leg(args, torch, pcv, ctx, dev, points, steps=5):
         ctx.reset_kernel_stats()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        marks = []
         for _ in range(steps):
             t = ctx.build(args.resolution, None, x, y, z, rgb, plane)
             info = t.build_info()
             t.free()
+            marks.append(time.perf_counter())  # host time the step was queued at (the builds run one behind the host)
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / steps * 1e3
         ctx.set_profiling(False)
         ks = ctx.kernel_stats()
         res[name] = {"ms_per_step": round(ms, 3), "Mpoints_per_s": round(points / (ms * 1e-3) / 1e6, 1), "record_bytes": info.get("record_bytes"),
+                     "host_ms_between_steps": [round((b - a) * 1e3, 2) for a, b in zip([t0] + marks[:-1], marks)],
+                     "settled_in_sort": info.get("settled_in_sort"),
                      "kernel_ms_per_step": {k: round(v[1] / steps, 3) for k, v in ks.items() if v[0] > 0}}
     parity = verify_build(ctx, args.resolution, x, y, z, rgb, intensity=inten)
     del x, y, z, rgb, inten
@@ -1371,7 +1375,7 @@ def main():
         except Exception as e:  # noqa: BLE001
             config5 = {"error": f"{type(e).__name__}: {e}", "parity": {"ok": False, "mismatching_nodes": None}}
         try:
-            intensity_out = intensity_leg(args, torch, pcv, ctx, dev, args.intensity_points)
+            intensity_out = intensity_leg(args, torch, pcv, ctx, dev, args.intensity_points, steps=10)
         except Exception as e:  # noqa: BLE001
             intensity_out = {"error": f"{type(e).__name__}: {e}", "parity": {"ok": False}}
         try:

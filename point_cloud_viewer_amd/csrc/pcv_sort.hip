@@ -18,6 +18,9 @@
 #include "pcv_internal.h"
 #include "pcv_settle_dev.h"
 
+#ifndef PCV_FUSE_DIAG
+#define PCV_FUSE_DIAG 0
+#endif
 #define PCV_SPEC_INDEX_MASK_SORT 0x3fffffffu  // == PCV_SPEC_INDEX_MASK (pcv_spec.h)
 
 namespace {
@@ -913,12 +916,21 @@ __device__ __forceinline__ void downsweep_rec12_body(const uint32_t* __restrict_
         const PcvRecip rm = u8 ? PCV_RECIP_255 : PCV_RECIP_65535;
         uint32_t out[3];
         const uint32_t cin[3] = {c0, c1, c2};
+#if PCV_FUSE_DIAG == 2
+        out[0] = c0, out[1] = c1, out[2] = c2;
+        if (L.inv_edge == 123.0) {
+#else
         if (__builtin_expect(L.inv_edge != 0.0, 1)) {
+#endif
           const PcvRecip ie{L.inv_edge, L.inv_edge_lo};
 #pragma unroll
           for (int a = 0; a < 3; ++a)
             out[a] = pcv_fix_encode<false>(__fma_rn(pcv_div_code((double)cin[a], rm), L.edge, L.mn[a]), L.mn[a], L.edge, ie, maxval);
+#if PCV_FUSE_DIAG == 2
+        } else if (L.inv_edge == 124.0) {
+#else
         } else {
+#endif
           const uint32_t enc = u8 ? PCV_ENC_UINT8 : PCV_ENC_UINT16;
 #pragma unroll
           for (int a = 0; a < 3; ++a)
@@ -926,6 +938,9 @@ __device__ __forceinline__ void downsweep_rec12_body(const uint32_t* __restrict_
         }
         const uint32_t slot = j - (j >> 3) - 1u;
         const bool odd = (slot & 1u) != 0;
+#if PCV_FUSE_DIAG == 1  // (timing experiments, tools/build_variants.sh: 1 = no final stores, 2 = no rewrite; never shipped)
+        if (out[0] != 0x7fffffffu) continue;
+#endif
         if (PL) reinterpret_cast<uint32_t*>(L.inten)[slot] = inten;
         // 3 bytes at 3 x slot: one 2-byte store at the even address of the three + one byte
         uint8_t* cd = L.rgb + (uint64_t)slot * 3;
