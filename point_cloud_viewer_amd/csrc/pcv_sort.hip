@@ -1020,16 +1020,16 @@ __global__ __launch_bounds__(BLOCK, WPE) void downsweep_rec12_kernel(const uint3
 }
 // the settling form of the second pass (FUSE above): a kernel of its own name for the profiles
 // (128 digit values: the second digit of a rank of <= 15 bits has <= 7 bits)
-template <bool PL>
-__global__ __launch_bounds__(1024, 4) void downsweep_settle_kernel(const uint32_t* __restrict__ keys_in, uint32_t* __restrict__ keys_out,
+template <bool PL, int BLOCK = 1024>
+__global__ __launch_bounds__(BLOCK, 4) void downsweep_settle_kernel(const uint32_t* __restrict__ keys_in, uint32_t* __restrict__ keys_out,
                                                                    uint64_t n, uint64_t chunk, int groups, int shift, int nbits,
                                                                    const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ totals,
                                                                    const uint2* __restrict__ vec_in, uint2* __restrict__ vec_out,
                                                                    const uint2* __restrict__ ranges, const uint32_t* __restrict__ order,
                                                                    const uint32_t* __restrict__ plane_in, uint32_t* __restrict__ plane_out,
                                                                    PcvSortFuse fuse) {
-  downsweep_rec12_body<1024, 8, 128, 4, false, 0, PL, false, true>(keys_in, keys_out, n, chunk, groups, shift, nbits, offsets, totals, vec_in,
-                                                                  vec_out, nullptr, 0u, ranges, order, plane_in, plane_out, fuse);
+  downsweep_rec12_body<BLOCK, 8, 128, 4, false, 0, PL, false, true>(keys_in, keys_out, n, chunk, groups, shift, nbits, offsets, totals, vec_in,
+                                                                   vec_out, nullptr, 0u, ranges, order, plane_in, plane_out, fuse);
 }
 
 // First-pass histogram of the record sort from the per-workgroup rank counts (rank_hist rows, pcv_encode.hip) and the rank map:
@@ -1324,6 +1324,21 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
           wc_done = true;
         }
 #endif
+#ifdef PCV_EXPERIMENTS
+        static const int rec_block = [] {  // PCV_REC_BLOCK=512: the first pass in tiles of 4 096, two workgroups per CU
+          const char* e = pcv_experiment("PCV_REC_BLOCK");
+          return e ? atoi(e) : 1024;
+        }();
+        if (!wc_done && rec_block == 512 && !with_plane && p1_bits <= 7 && map_in_lds && dyn <= 28672) {
+          static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&downsweep_rec12_kernel<512, 8, 128, 4, false, 1, false>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 28672) == hipSuccess;
+          (void)ok;
+          hipLaunchKernelGGL((downsweep_rec12_kernel<512, 8, 128, 4, false, 1, false>), dim3(g.groups), dim3(512), dyn, ctx->stream,
+                             (const uint32_t*)src, (uint32_t*)dst, n, g.chunk, g.groups, p1_shift, p1_bits, hist, totals, vin, vout, map,
+                             map_entries, (const uint2*)nullptr, (const uint32_t*)nullptr, pin, pout);
+          wc_done = true;
+        }
+#endif
         if (wc_done) {
         } else if (with_plane) {
           if (p1_bits <= 7 && map_in_lds) PCV_REC12_MAP(128, 1, true)
@@ -1526,8 +1541,29 @@ int pcv_radix_sort_records_second(pcv_ctx* ctx, PcvSortSecond* sd, const PcvSort
     PcvProf prof(ctx, PCV_K_SORT_SETTLE);
     PcvSortFuse fz = *fuse;
     fz.low_bits = (uint32_t)sd->low_bits, fz.blocks = (uint32_t)sd->blocks;
+    // colour-only records: tiles of 4 096 (512 lanes), TWO workgroups per CU — the pass is bound by its own phases (loads, LDS
+    // ranking, barriers), not by bytes, and a second workgroup fills them: 0.69-0.70 -> 0.63-0.64 ms at 100 M points in one call
+    // (tiles of 2 048, four workgroups: 0.75). With the intensity plane two workgroups' LDS does not fit: tiles of 8 192.
+    int settle_block = 512;
+#ifdef PCV_EXPERIMENTS
+    static const int settle_block_env = [] {  // PCV_SETTLE_BLOCK=1024 / 256 (libpcv_hip_exp.so)
+      const char* e = pcv_experiment("PCV_SETTLE_BLOCK");
+      return e ? atoi(e) : 0;
+    }();
+    if (settle_block_env) settle_block = settle_block_env;
+#endif
+#define PCV_REC12_SETTLE_B(B)                                                                                                            \
+  hipLaunchKernelGGL((downsweep_settle_kernel<false, B>), dim3(sd->pieces), dim3(B), 0, ctx->stream, sd->src, sd->dst, sd->n, sd->chunk,  \
+                     sd->pieces, sd->shift, sd->nbits, sd->hist, sd->totals, (const uint2*)sd->vec_src, (uint2*)sd->vec_dst,              \
+                     (const uint2*)sd->ranges, sd->order, sd->plane_src, sd->plane_dst, fz)
     if (plane) PCV_REC12_SETTLE(true, fz);
-    else PCV_REC12_SETTLE(false, fz);
+#ifdef PCV_EXPERIMENTS
+    else if (settle_block == 1024) PCV_REC12_SETTLE_B(1024);
+    else if (settle_block == 256) PCV_REC12_SETTLE_B(256);
+#endif
+    else PCV_REC12_SETTLE_B(512);
+#undef PCV_REC12_SETTLE_B
+    (void)settle_block;
   } else {
     if (fuse) return ctx->fail(PCV_E_INVALID, "record sort: the settling pass needs a second digit of <= 7 bits");
     PcvProf prof(ctx, PCV_K_SORT_DOWNSWEEP_REC);
