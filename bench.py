@@ -1083,13 +1083,24 @@ def main():
             ALGO_BYTES.update({"downsweep_rec_kernel": 2 * 12.0, "promote_settle_kernel": 12.0 + 7.0 / 8.0 * 9.0,
                                "spec_encode_kernel": 24.0 + 3.0 + 12.0})
 
+        # the record sort's second pass finishes most leaves itself (build_info settled_in_sort): `settle` then only sees the points
+        # of the leaves left over, and the pass moves 12 B in + 12 B out for those
+        settled = float((info.get("build") or {}).get("settled_in_sort") or 0)
+
+        def algo_bytes(name):
+            if settled and name == "promote_settle_kernel":
+                return ALGO_BYTES[name] * (n - settled)
+            if settled and name == "downsweep_settle_kernel":
+                return ALGO_BYTES[name] * settled + 24.0 * (n - settled)
+            return ALGO_BYTES.get(name, 0.0) * n
+
         def hbm_view(name):
             launches, ms = timed[name]
             avg_ms = ms / launches
-            gbs = ALGO_BYTES.get(name, 0.0) * n / (avg_ms * 1e-3) / 1e9
+            gbs = algo_bytes(name) / (avg_ms * 1e-3) / 1e9
             return {"kernel": name, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(gbs / HBM_PEAK_GBS, 4), "avg_launch_ms": round(avg_ms, 4), "launches": launches,
-                    "algorithmic_bytes_per_launch": ALGO_BYTES.get(name, 0.0) * n}
+                    "algorithmic_bytes_per_launch": algo_bytes(name)}
 
         profile_state = {"matches": None}
 
@@ -1179,7 +1190,7 @@ def main():
         # upsweep<u32> launch either
         rows_both = rows_path and "upsweep_kernel<u32>" not in timed
         sort_b = rec_passes * pass_b + (-4.0 * rec_passes if rows_both else -4.0 if rows_path else (4.0 if "upsweep_map_kernel" in timed else 0.0))
-        sort_b += fused_passes * ALGO_BYTES["downsweep_settle_kernel"]
+        sort_b += fused_passes * algo_bytes("downsweep_settle_kernel") / n
         rec_ms += fused_ms
         record_sort = None if not rec else {"passes": rec_passes + fused_passes, "ms": round(rec_ms, 3), "record_bytes": rec_b,
                                             "second_pass_settles_the_leaves": bool(fused),
