@@ -608,7 +608,8 @@ struct alignas(16) FuseLeaf {
   uint8_t* rgb;
   double mn[3], edge, inv_edge, inv_edge_lo;
   uint8_t* inten;  // (intensity plane) first byte of the leaf's .intensity content
-  uint64_t pad;
+  uint32_t count;  // points of the leaf as the HOST's tree has it: a record outside [lo, lo + count) is never settled here
+  uint32_t pad;
 };
 constexpr uint32_t kFuseSettles = 1u, kFuseU8 = 2u;
 // FUSE (PcvSortFuse, pcv_internal.h): the pass is the LAST one of a two-pass sort whose pieces hold one value of the rank's lower
@@ -648,6 +649,7 @@ __device__ __forceinline__ void downsweep_rec12_body(const uint32_t* __restrict_
       L.lo = c.lo, L.climb_base = fuse.climb_base[r];
       L.flags = (fuse.leaf_fused[r] ? kFuseSettles : 0u) | (c.enc == PCV_ENC_UINT8 ? kFuseU8 : 0u);
       L.rank = r;
+      L.count = (r + 1u < fuse.num_leaves ? fuse.leaf_rec[r + 1u].lo : (uint32_t)n) - c.lo;  // leaves lie in rank order
       L.xyz = fuse.xyz_blob + c.xyz_off, L.rgb = fuse.rgb_blob + c.point_off * 3;
       L.inten = PL ? fuse.inten_blob + c.point_off * 4 : nullptr;
       L.mn[0] = c.mn[0], L.mn[1] = c.mn[1], L.mn[2] = c.mn[2];
@@ -895,7 +897,9 @@ __device__ __forceinline__ void downsweep_rec12_body(const uint32_t* __restrict_
         const uint32_t g = S.delta[d] + p;  // sorted slot
         const uint32_t flags = L.flags;
         const uint32_t inten = PL ? splane[p] : 0u;
-        if (!(flags & kFuseSettles)) {  // `settle` finishes this leaf: the 12-byte record as in the plain pass
+        // (g - lo < count always holds when the device's rank map and the host's tree agree — the build checks that they do,
+        // but only at its end: a record that falls outside its leaf keeps its 12 bytes instead of being written anywhere)
+        if (!(flags & kFuseSettles) || g - L.lo >= L.count) {  // `settle` finishes this leaf: the record as in the plain pass
           keys_out[g] = k;
           vec_out[g] = q;
           if (PL) plane_out[g] = inten;
