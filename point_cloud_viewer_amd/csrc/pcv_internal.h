@@ -336,6 +336,7 @@ int pcv_radix_sort_u32(pcv_ctx* ctx, uint32_t* keys_a, uint32_t* keys_b, uint64_
 // itself (PcvSortFuse). Any other form of the sort runs to its end and leaves second->pending false.
 struct PcvSortSecond {
   bool pending = false;
+  bool join_side = false;          // the pass's layout kernels were queued on the context's side stream
   const uint32_t* src = nullptr;   // keys after the first pass (rank << 8 | blue)
   uint32_t* dst = nullptr;
   const void* vec_src = nullptr;   // uint2 payloads after the first pass

@@ -1296,6 +1296,9 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
         PcvProf prof(ctx, PCV_K_SORT_SCAN);
         hipLaunchKernelGGL(scan_kernel, dim3(kRadix), dim3(256), 0, ctx->stream, hist, g.groups, totals);
       }
+      // held-back second pass: its layout (two small kernels that need the histograms above, not the first pass) runs on the side
+      // stream BESIDE the first pass; pcv_radix_sort_records_second joins the streams in front of the pass
+      const bool side_layout = two && second && !msd && ctx->side && ctx->side_begin() == PCV_OK;
       const size_t dyn = map_in_lds ? (((size_t)map_entries * 2 + 15) & ~(size_t)15) : 0;
       const uint2* vin = (const uint2*)(in_a ? payload->vec_in : payload->vec_out);
       uint2* vout = (uint2*)(in_a ? payload->vec_out : payload->vec_in);
@@ -1366,6 +1369,7 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
       if (blocks < 1) blocks = 1;
       const int gpb = (g.groups + blocks - 1) / blocks;
       const int pieces = D1 * blocks;
+      if (side_layout) std::swap(ctx->stream, ctx->side);
       {
         PcvProf prof(ctx, PCV_K_SORT_HIST_ROWS);
         hipLaunchKernelGGL(pass2_layout_kernel, dim3(pieces), dim3(256), 0, ctx->stream, rows_true, p1_bits, p2_bits, g.groups, blocks, gpb, hist,
@@ -1378,8 +1382,10 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
         else
           hipLaunchKernelGGL(scan_kernel, dim3(kRadix), dim3(256), 0, ctx->stream, hist2, pieces, totals2);
       }
+      if (side_layout) std::swap(ctx->stream, ctx->side);
       if (second && !msd) {  // the caller queues the pass itself (pcv_radix_sort_records_second)
         second->pending = true;
+        second->join_side = side_layout;
         second->src = (const uint32_t*)(in_a ? a : b);
         second->dst = (uint32_t*)(in_a ? b : a);
         second->vec_src = in_a ? payload->vec_in : payload->vec_out;
@@ -1532,6 +1538,7 @@ int pcv_radix_sort_records_mapped(pcv_ctx* ctx, uint32_t* keys_a, uint32_t* keys
 int pcv_radix_sort_records_second(pcv_ctx* ctx, PcvSortSecond* sd, const PcvSortFuse* fuse) {
   if (!sd || !sd->pending) return PCV_OK;
   sd->pending = false;
+  if (sd->join_side && ctx->side_end() != PCV_OK) return ctx->fail(PCV_E_HIP, "record sort: side stream");
 #define PCV_REC12_SECOND(R, P)                                                                                                           \
   hipLaunchKernelGGL((downsweep_rec12_kernel<1024, 8, R, 4, false, 0, P, false>), dim3(sd->pieces), dim3(1024), 0, ctx->stream, sd->src,     \
                      sd->dst, sd->n, sd->chunk, sd->pieces, sd->shift, sd->nbits, sd->hist, sd->totals, (const uint2*)sd->vec_src,         \
