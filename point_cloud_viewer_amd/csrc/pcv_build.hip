@@ -2041,7 +2041,7 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
     const char* e = pcv_experiment("PCV_SETTLE_BY_LEAF");
     return !e || atoi(e) != 0;
   }();
-  const bool fuse_sort = bs->spec && bs->sort_second.pending && bs->sort_second.nbits <= 7 && by_leaf && !wide && bs->spec_wide;
+  const bool fuse_sort = bs->spec && bs->sort_second.pending && (bs->sort_second.nbits <= 7 || !t->has_intensity) && by_leaf && !wide && bs->spec_wide;
   std::vector<uint8_t> fused_leaf;
   uint64_t settled_points = 0;
   uint32_t* u_climb_base = (uint32_t*)(u_leaf_rec + num_leaves);

@@ -602,15 +602,14 @@ struct DigitStateN {
 // that start on 256-byte boundaries move the same bytes 20-26 % faster than runs at odd record offsets). 128 digit values only
 // (48 KB of carry next to the 107 KB of the tile), no plane, no map copy in LDS.
 // the settling pass's view of a leaf (one entry per digit value of the piece, in LDS)
-struct alignas(16) FuseLeaf {
-  uint32_t lo, climb_base, flags, rank;
-  uint8_t* xyz;  // first byte of the leaf's .xyz content
-  uint8_t* rgb;
+struct alignas(16) FuseLeaf {  // 80 bytes: with the intensity plane two workgroups' tables, tiles and digit state fill the CU's LDS
+  uint32_t lo, climb_base, flags;
+  uint32_t count;      // points of the leaf as the HOST's tree has it: a record outside [lo, lo + count) is never settled here
+  uint64_t xyz_off;    // byte offset of the leaf's .xyz content in the xyz blob
+  uint64_t point_off;  // point offset of the leaf in the rgb / intensity blobs
   double mn[3], edge, inv_edge, inv_edge_lo;
-  uint8_t* inten;  // (intensity plane) first byte of the leaf's .intensity content
-  uint32_t count;  // points of the leaf as the HOST's tree has it: a record outside [lo, lo + count) is never settled here
-  uint32_t pad;
 };
+static_assert(sizeof(FuseLeaf) == 80, "leaf table entry");
 constexpr uint32_t kFuseSettles = 1u, kFuseU8 = 2u;
 // FUSE (PcvSortFuse, pcv_internal.h): the pass is the LAST one of a two-pass sort whose pieces hold one value of the rank's lower
 // digit each: a digit's run inside a tile is then ONE leaf's records at consecutive sorted slots. Waves take whole runs: the leaf's
@@ -648,10 +647,8 @@ __device__ __forceinline__ void downsweep_rec12_body(const uint32_t* __restrict_
       const PcvNodeRec c = fuse.leaf_rec[r];
       L.lo = c.lo, L.climb_base = fuse.climb_base[r];
       L.flags = (fuse.leaf_fused[r] ? kFuseSettles : 0u) | (c.enc == PCV_ENC_UINT8 ? kFuseU8 : 0u);
-      L.rank = r;
       L.count = (r + 1u < fuse.num_leaves ? fuse.leaf_rec[r + 1u].lo : (uint32_t)n) - c.lo;  // leaves lie in rank order
-      L.xyz = fuse.xyz_blob + c.xyz_off, L.rgb = fuse.rgb_blob + c.point_off * 3;
-      L.inten = PL ? fuse.inten_blob + c.point_off * 4 : nullptr;
+      L.xyz_off = c.xyz_off, L.point_off = c.point_off;
       L.mn[0] = c.mn[0], L.mn[1] = c.mn[1], L.mn[2] = c.mn[2];
       L.edge = c.edge, L.inv_edge = c.inv_edge, L.inv_edge_lo = c.inv_edge_lo;
     }
@@ -909,7 +906,9 @@ __device__ __forceinline__ void downsweep_rec12_body(const uint32_t* __restrict_
         const uint32_t rgb = (q.y >> 16) | ((k & 0xffu) << 16);
         const uint32_t c0 = q.x & 0xffffu, c1 = q.x >> 16, c2 = q.y & 0xffffu;
         if ((j & 7u) == 0) {  // every eighth point climbs: its record for `climb`, dense per leaf
-          if (PL) reinterpret_cast<PcvClimber*>(fuse.climbers)[L.climb_base + (j >> 3)] = PcvClimber{make_uint4(c0, c1, c2, rgb), L.rank, g, inten, 0u};
+          if (PL)  // (the leaf's rank: this digit above the piece's lower digit)
+            reinterpret_cast<PcvClimber*>(fuse.climbers)[L.climb_base + (j >> 3)] =
+                PcvClimber{make_uint4(c0, c1, c2, rgb), (d << fuse.low_bits) | (piece / fuse.blocks), g, inten, 0u};
           else reinterpret_cast<uint4*>(fuse.climbers)[L.climb_base + (j >> 3)] = make_uint4(c0, c1, c2, rgb);
           continue;
         }
@@ -945,17 +944,18 @@ __device__ __forceinline__ void downsweep_rec12_body(const uint32_t* __restrict_
 #if PCV_FUSE_DIAG == 1  // (timing experiments, tools/build_variants.sh: 1 = no final stores, 2 = no rewrite; never shipped)
         if (out[0] != 0x7fffffffu) continue;
 #endif
-        if (PL) reinterpret_cast<uint32_t*>(L.inten)[slot] = inten;
+        const uint64_t pidx = L.point_off + slot;
+        if (PL) reinterpret_cast<uint32_t*>(fuse.inten_blob)[pidx] = inten;
         // 3 bytes at 3 x slot: one 2-byte store at the even address of the three + one byte
-        uint8_t* cd = L.rgb + (uint64_t)slot * 3;
+        uint8_t* cd = fuse.rgb_blob + pidx * 3;
         *reinterpret_cast<uint16_t*>(cd + (odd ? 1 : 0)) = (uint16_t)(odd ? rgb >> 8 : rgb);
         cd[odd ? 0 : 2] = (uint8_t)(odd ? rgb : rgb >> 16);
         if (u8) {
-          uint8_t* x = L.xyz + (uint64_t)slot * 3;
+          uint8_t* x = fuse.xyz_blob + L.xyz_off + (uint64_t)slot * 3;
           *reinterpret_cast<uint16_t*>(x + (odd ? 1 : 0)) = (uint16_t)(odd ? out[1] | (out[2] << 8) : out[0] | (out[1] << 8));
           x[odd ? 0 : 2] = (uint8_t)(odd ? out[0] : out[2]);
         } else {  // 6 bytes at 6 x slot: one 4-byte store at the 4-aligned address of the six + one 2-byte store
-          uint8_t* x = L.xyz + (uint64_t)slot * 6;
+          uint8_t* x = fuse.xyz_blob + L.xyz_off + (uint64_t)slot * 6;
           *reinterpret_cast<uint32_t*>(x + (odd ? 2 : 0)) = odd ? out[1] | (out[2] << 16) : out[0] | (out[1] << 16);
           *reinterpret_cast<uint16_t*>(x + (odd ? 0 : 4)) = (uint16_t)(odd ? out[0] : out[2]);
         }
@@ -1023,8 +1023,8 @@ __global__ __launch_bounds__(BLOCK, WPE) void downsweep_rec12_kernel(const uint3
                                                                   vec_out, gmap, map_entries, ranges, order, plane_in, plane_out, PcvSortFuse());
 }
 // the settling form of the second pass (FUSE above): a kernel of its own name for the profiles
-// (128 digit values: the second digit of a rank of <= 15 bits has <= 7 bits)
-template <bool PL, int BLOCK = 1024>
+// (R = 128 digit values: the second digit of a rank of <= 15 bits has <= 7 bits; 256 for ranks of 16 bits)
+template <bool PL, int BLOCK = 1024, int R = 128>
 __global__ __launch_bounds__(BLOCK, 4) void downsweep_settle_kernel(const uint32_t* __restrict__ keys_in, uint32_t* __restrict__ keys_out,
                                                                    uint64_t n, uint64_t chunk, int groups, int shift, int nbits,
                                                                    const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ totals,
@@ -1032,7 +1032,7 @@ __global__ __launch_bounds__(BLOCK, 4) void downsweep_settle_kernel(const uint32
                                                                    const uint2* __restrict__ ranges, const uint32_t* __restrict__ order,
                                                                    const uint32_t* __restrict__ plane_in, uint32_t* __restrict__ plane_out,
                                                                    PcvSortFuse fuse) {
-  downsweep_rec12_body<BLOCK, 8, 128, 4, false, 0, PL, false, true>(keys_in, keys_out, n, chunk, groups, shift, nbits, offsets, totals, vec_in,
+  downsweep_rec12_body<BLOCK, 8, R, 4, false, 0, PL, false, true>(keys_in, keys_out, n, chunk, groups, shift, nbits, offsets, totals, vec_in,
                                                                    vec_out, nullptr, 0u, ranges, order, plane_in, plane_out, fuse);
 }
 
@@ -1065,26 +1065,34 @@ __global__ __launch_bounds__(256) void hist12_from_rows_kernel(const uint32_t* _
                                                                 uint32_t* __restrict__ hist1 /* [d1][groups] */,
                                                                 uint32_t* __restrict__ rows_true /* [groups][D1 * D2] */,
                                                                 int msd /* experiments: the FIRST pass takes the rank's upper nbits1 bits */) {
-  extern __shared__ uint32_t tr[];  // D1 x D2 counters: 64 KB for ranks of 14 bits, 128 KB for 15
+  extern __shared__ uint32_t tr[];  // D1 x D2 counters: 64 KB for ranks of 14 bits, 128 KB for 15; 16 bits: two rounds of 128 KB
   const uint32_t D1 = 1u << nbits1, D2 = 1u << nbits2, TB = D1 * D2;
   const int sh1 = msd ? nbits2 : 0, sh2 = msd ? 0 : nbits1;
-  for (uint32_t i = threadIdx.x; i < TB; i += 256) tr[i] = 0;
-  __syncthreads();
+  const uint32_t rounds = TB > 32768u ? TB / 32768u : 1u, D1r = D1 / rounds, TBr = D1r * D2;  // a round takes D1r values of the first digit
   const uint32_t* row = rows + (uint64_t)blockIdx.x * nbins;
-  for (uint32_t b = threadIdx.x; b < nbins; b += 256) {
-    const uint32_t c = row[b];
-    if (c) {
-      const uint32_t r = map[b] & PCV_SPEC_INDEX_MASK_SORT;
-      atomicAdd(&tr[((r >> sh1) & (D1 - 1u)) * D2 + ((r >> sh2) & (D2 - 1u))], c);
-    }
-  }
-  __syncthreads();
   uint32_t* out = rows_true + (uint64_t)blockIdx.x * TB;
-  for (uint32_t i = threadIdx.x; i < TB; i += 256) out[i] = tr[i];
-  uint32_t s = 0;
-  if (threadIdx.x < D1)
-    for (uint32_t d2 = 0; d2 < D2; ++d2) s += tr[threadIdx.x * D2 + ((d2 + threadIdx.x) & (D2 - 1u))];  // skewed: no bank conflict
-  hist1[(uint64_t)threadIdx.x * groups + blockIdx.x] = s;  // all kRadix rows are scanned
+  hist1[(uint64_t)threadIdx.x * groups + blockIdx.x] = 0;  // all kRadix rows are scanned (digit values >= D1 stay empty)
+  for (uint32_t rd = 0; rd < rounds; ++rd) {
+    const uint32_t d1_lo = rd * D1r;
+    for (uint32_t i = threadIdx.x; i < TBr; i += 256) tr[i] = 0;
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nbins; b += 256) {
+      const uint32_t c = row[b];
+      if (c) {
+        const uint32_t r = map[b] & PCV_SPEC_INDEX_MASK_SORT;
+        const uint32_t d1 = ((r >> sh1) & (D1 - 1u)) - d1_lo;
+        if (d1 < D1r) atomicAdd(&tr[d1 * D2 + ((r >> sh2) & (D2 - 1u))], c);
+      }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < TBr; i += 256) out[(uint64_t)d1_lo * D2 + i] = tr[i];
+    if (threadIdx.x < D1r) {
+      uint32_t s = 0;
+      for (uint32_t d2 = 0; d2 < D2; ++d2) s += tr[threadIdx.x * D2 + ((d2 + threadIdx.x) & (D2 - 1u))];  // skewed: no bank conflict
+      hist1[(uint64_t)(d1_lo + threadIdx.x) * groups + blockIdx.x] = s;
+    }
+    __syncthreads();
+  }
 }
 // piece k of the second pass (see above): its digit counts and its record range. offsets1 / totals1: the first pass's scanned
 // histogram. One workgroup of 256 lanes per piece.
@@ -1210,8 +1218,8 @@ static void rec12_launch(pcv_ctx* ctx, int variant, const SortGeom& g, const uin
 }
 
 // true-rank counters per sort workgroup the scratch holds (hist12_from_rows_kernel): 2^14, and 2^15 for clouds big enough to have
-// that many leaves (128 MB of scratch instead of 64)
-static uint32_t rows_true_bins(uint64_t n) { return n >= 200000000ull ? 32768u : 16384u; }
+// that many leaves (128 MB of scratch instead of 64), 2^16 from 500 M points on (256 MB)
+static uint32_t rows_true_bins(uint64_t n) { return n >= 500000000ull ? 65536u : n >= 200000000ull ? 32768u : 16384u; }
 
 template <typename KeyT>
 int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int end_bit, PcvSortPayload* payload,
@@ -1285,7 +1293,7 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
           static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&hist12_from_rows_kernel),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 131072) == hipSuccess;
           (void)ok;
-          hipLaunchKernelGGL(hist12_from_rows_kernel, dim3(g.groups), dim3(256), (size_t)4 << (p1_bits + p2_bits), ctx->stream, rows,
+          hipLaunchKernelGGL(hist12_from_rows_kernel, dim3(g.groups), dim3(256), std::min<size_t>((size_t)4 << (p1_bits + p2_bits), 131072), ctx->stream, rows,
                              map_entries, map, p1_bits, p2_bits, g.groups, hist, rows_true, msd ? 1 : 0);
         }
         else
@@ -1548,7 +1556,7 @@ int pcv_radix_sort_records_second(pcv_ctx* ctx, PcvSortSecond* sd, const PcvSort
                      sd->pieces, sd->shift, sd->nbits, sd->hist, sd->totals, (const uint2*)sd->vec_src, (uint2*)sd->vec_dst,              \
                      (const uint2*)sd->ranges, sd->order, sd->plane_src, sd->plane_dst, ARG)
   const bool plane = sd->plane_src != nullptr;
-  if (fuse && sd->nbits <= 7 && (!plane || fuse->inten_blob)) {
+  if (fuse && (sd->nbits <= 7 || !plane) && (!plane || fuse->inten_blob)) {
     PcvProf prof(ctx, PCV_K_SORT_SETTLE);
     PcvSortFuse fz = *fuse;
     fz.low_bits = (uint32_t)sd->low_bits, fz.blocks = (uint32_t)sd->blocks;
@@ -1567,7 +1575,17 @@ int pcv_radix_sort_records_second(pcv_ctx* ctx, PcvSortSecond* sd, const PcvSort
   hipLaunchKernelGGL((downsweep_settle_kernel<false, B>), dim3(sd->pieces), dim3(B), 0, ctx->stream, sd->src, sd->dst, sd->n, sd->chunk,  \
                      sd->pieces, sd->shift, sd->nbits, sd->hist, sd->totals, (const uint2*)sd->vec_src, (uint2*)sd->vec_dst,              \
                      (const uint2*)sd->ranges, sd->order, sd->plane_src, sd->plane_dst, fz)
-    if (plane) PCV_REC12_SETTLE(true, fz);
+    if (sd->nbits > 7)  // ranks of 16 bits, colour-only: 256 digit values, tiles of 8 192
+      hipLaunchKernelGGL((downsweep_settle_kernel<false, 1024, 256>), dim3(sd->pieces), dim3(1024), 0, ctx->stream, sd->src, sd->dst, sd->n,
+                         sd->chunk, sd->pieces, sd->shift, sd->nbits, sd->hist, sd->totals, (const uint2*)sd->vec_src, (uint2*)sd->vec_dst,
+                         (const uint2*)sd->ranges, sd->order, sd->plane_src, sd->plane_dst, fz);
+#ifdef PCV_EXPERIMENTS
+    else if (plane && settle_block == 512 && settle_block_env == 512)  // PCV_SETTLE_BLOCK=512 with the plane: two workgroups fill the LDS exactly
+      hipLaunchKernelGGL((downsweep_settle_kernel<true, 512>), dim3(sd->pieces), dim3(512), 0, ctx->stream, sd->src, sd->dst, sd->n, sd->chunk,
+                         sd->pieces, sd->shift, sd->nbits, sd->hist, sd->totals, (const uint2*)sd->vec_src, (uint2*)sd->vec_dst,
+                         (const uint2*)sd->ranges, sd->order, sd->plane_src, sd->plane_dst, fz);
+#endif
+    else if (plane) PCV_REC12_SETTLE(true, fz);
 #ifdef PCV_EXPERIMENTS
     else if (settle_block == 1024) PCV_REC12_SETTLE_B(1024);
     else if (settle_block == 256) PCV_REC12_SETTLE_B(256);
@@ -1576,7 +1594,7 @@ int pcv_radix_sort_records_second(pcv_ctx* ctx, PcvSortSecond* sd, const PcvSort
 #undef PCV_REC12_SETTLE_B
     (void)settle_block;
   } else {
-    if (fuse) return ctx->fail(PCV_E_INVALID, "record sort: the settling pass needs a second digit of <= 7 bits");
+    if (fuse) return ctx->fail(PCV_E_INVALID, "record sort: the settling pass with an intensity plane needs a second digit of <= 7 bits");
     PcvProf prof(ctx, PCV_K_SORT_DOWNSWEEP_REC);
     if (sd->nbits <= 7 && plane) PCV_REC12_SECOND(128, true);
     else if (sd->nbits <= 7) PCV_REC12_SECOND(128, false);

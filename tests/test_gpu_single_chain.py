@@ -141,7 +141,8 @@ def test_intensity_plane_rides_the_12_byte_record_sort(ctx, n, cap, lo, hi):
 
 @pytest.mark.parametrize("n,cap,lo,hi", [(1_500_000, 1_500, 1_024, 8_192),    # two passes of <= 7 bits: 128 digit values in the settling pass
                                          (1_500_000, 800, 4_000, 16_384),     # 14 rank bits
-                                         (300_000_000, 55_000, 16_384, 32_768)])  # 15 rank bits (8 + 7): clouds of >= 200 M points only
+                                         (300_000_000, 55_000, 16_384, 32_768),   # 15 rank bits (8 + 7): clouds of >= 200 M points only
+                                         (520_000_000, 55_000, 32_768, 65_536)])  # 16 rank bits (8 + 8, 256 digit values): >= 500 M points
 def test_second_sort_pass_settles_the_leaves(ctx, n, cap, lo, hi):
     """Colour-only single-chain builds: the record sort's second pass writes the final bytes of the integer-coded leaves itself
     (downsweep_settle_kernel: the rewrite of generation.rs:222-238 and the node-contiguous layout of raw.rs:361-450) and the
