@@ -87,3 +87,38 @@ def test_random_build_equals_oracle(ctx, seed, kind):
         t = ctx.build(res, pcv.Aabb(bmin, bmax), x, y, z, rgb, inten, max_points_per_node=cap, single_chain=single_chain)
         assert_same(t.to_dict(), want, check_intensity=inten is not None)
         t.free()
+
+
+# ---- the same generator at sizes where the record sort takes its two-pass form: the second pass writes the node bytes of the
+# integer-coded leaves itself (downsweep_settle_kernel) — ties on octant planes, repeated positions and far-away origins through
+# THAT rewrite (generation.rs:222-238), with and without the intensity plane
+SETTLED = {"cases": 0, "settled": 0}
+BIG_CASES = [(seed, KINDS[seed % len(KINDS)]) for seed in range(28)]
+
+
+@pytest.mark.parametrize("seed,kind", BIG_CASES)
+def test_random_build_through_the_settling_sort_pass(ctx, seed, kind):
+    rng = np.random.default_rng(5000 + seed)
+    n = int(rng.choice([300_000, 600_000]))
+    origin = np.array(rng.choice([0.0, -3.5, 1.0e3, 4.2e6, -6.3e6], 3), dtype=np.float64) + rng.random(3)
+    edge = float(rng.choice([1.0, 37.3, 256.0, 1000.0]))
+    x, y, z = _cloud(rng, kind, n, origin, edge)
+    pad = edge * float(rng.choice([0.0, 0.01, 0.5]))
+    bmin, bmax = origin - pad, origin + edge + pad
+    res = edge / 2.0 ** float(rng.uniform(9, 18))
+    cap = int(rng.choice([150, 400, 1_500]))
+    rgb = rng.integers(0, 256, (n, 3), dtype=np.uint8)
+    inten = rng.random(n).astype(np.float32) if rng.random() < 0.4 else None
+    with O.max_points_per_node(cap):
+        want = O.build_closed(res, bmin, bmax, x, y, z, rgb, inten, threads=8)
+    t = ctx.build(res, pcv.Aabb(bmin, bmax), x, y, z, rgb, inten, max_points_per_node=cap, single_chain=True)
+    info = t.build_info()
+    assert_same(t.to_dict(), want, check_intensity=inten is not None)
+    t.free()
+    SETTLED["cases"] += 1
+    SETTLED["settled"] += 1 if info["settled_in_sort"] > 0 else 0
+
+
+def test_the_cases_above_went_through_the_settling_pass():
+    """(duplicates / line / plane clouds have few leaves or fall back to the exact pipeline: not every case can)"""
+    assert SETTLED["cases"] == len(BIG_CASES) and SETTLED["settled"] >= SETTLED["cases"] // 3, SETTLED
