@@ -296,6 +296,43 @@ def test_query_points_large(ctx):
     assert tree.query_points(prepared, 0, capacity=1)["count"] == tree.num_points
 
 
+def test_boxes_on_integer_coded_nodes_are_tested_on_the_codes_with_the_same_ties(ctx):
+    """Axis-aligned boxes take code bounds on u8 / u16-coded nodes (CodeBounds, pcv_query.hip: the decode is monotone in the code, so
+    `mins <= p < maxs`, aabb.rs:46-48, is `lo <= code < hi`): boxes whose faces are EXACTLY decoded point positions (p == min is
+    inside, p == max is not), one and two ulps beside them, boxes that miss the cloud, an inverted and a NaN box — against the
+    oracle's decode-and-compare, with and without the intensity interval. 3 M points: descriptors written on the device."""
+    x, y, z, rgb, bmin, bmax = synthetic.gaussian_clusters(3_000_000, seed=6, num_clusters=4, extent=300.0, sigma_range=(0.5, 20.0))
+    inten = (np.arange(x.size) % 251).astype(np.float32)
+    tree = ctx.build(0.001, pcv.Aabb(bmin, bmax), x, y, z, rgb, inten, max_points_per_node=20000)
+    with O.max_points_per_node(20000):
+        want = O.build_closed(0.001, bmin, bmax, x, y, z, rgb, inten, threads=8)
+    scene = dict(bmin=bmin, bmax=bmax, tree=tree, oracle=want, names=tree.node_names())
+    # decoded positions of a few stored points (u16- and u8-coded nodes) as box faces
+    index_of = {name: i for i, name in enumerate(scene["names"])}
+    rng = np.random.default_rng(12)
+    faces = []
+    for name, nd in want.nodes.items():
+        if nd["num_points"] > 100 and len(faces) < 6 and rng.random() < 0.02:
+            info = tree.node(index_of[name])
+            px, py, pz = O.decode_positions(nd["encoding"], info.cube_min, info.cube_edge, nd["xyz"])
+            k = int(rng.integers(0, px.size))
+            faces.append(np.array([px[k], py[k], pz[k]]))
+    assert len(faces) >= 4
+    boxes = []
+    for a, b in zip(faces[0::2], faces[1::2]):
+        lo, hi = np.minimum(a, b), np.maximum(a, b)
+        boxes += [(lo, hi), (np.nextafter(lo, np.inf), np.nextafter(hi, np.inf)), (np.nextafter(lo, -np.inf), np.nextafter(hi, -np.inf)),
+                  (lo - 7.5, hi + 3.25)]
+    boxes += [(bmax + 1.0, bmax + 2.0), (bmin + 50.0, bmin + 20.0), (np.array([np.nan, bmin[1], bmin[2]]), bmax),
+              (bmin, np.array([bmax[0], np.nan, bmax[2]])), (bmin - 1.0, bmax + 1.0)]
+    shapes = [("aabb", lo, hi) for lo, hi in boxes]
+    kinds = [(O.SHAPE_AABB, list(lo) + list(hi)) for lo, hi in boxes]
+    prepared = ctx.shapes(shapes)
+    assert check_query_points(scene, prepared, kinds, intervals=(None, (20.0, 180.0))) >= 8
+    assert tree.query_points(prepared, len(boxes) - 1, capacity=1)["count"] == tree.num_points
+    tree.free()
+
+
 def test_nodes_blob_matches_web_viewer_wire_format(ctx, scene):
     # octree_web_viewer/src/backend.rs:90-177
     import struct
