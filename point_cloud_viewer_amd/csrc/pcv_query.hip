@@ -881,30 +881,8 @@ __host__ __device__ inline ChunkDesc make_chunk_desc(const QueryJob& jb, uint32_
   return d;
 }
 
-// Axis-aligned boxes against integer-coded nodes (round 5): the decode v -> fma(v / max, edge, min) is monotone in the code (a
-// chain of correctly rounded monotone operations, edge > 0), so `mins <= p < maxs` (aabb.rs:46-48) on the decoded position is
-// `lo <= code < hi` per axis on the CODE, with lo = the first code whose decoded value satisfies `min <= p` and hi = the first one
-// that fails `p < max` — found with the kernel's own decode by bisection (17 steps), once per chunk. The per-point test is then
-// six integer compares and the kernel is left with its bytes. v[0] == 0xffffffff: no bounds (Float32 / Float64 codes).
-struct alignas(32) CodeBounds {
-  uint32_t v[6];  // lo x, y, z; hi x, y, z
-  uint32_t pad[2];
-};
-__device__ __forceinline__ uint32_t first_code_where(uint32_t enc, double mn, double edge, double bound, bool upper) {
-  uint32_t lo = 0, hi = enc == PCV_ENC_UINT8 ? 256u : 65536u;
-  while (lo < hi) {
-    const uint32_t mid = (lo + hi) >> 1;
-    const double p = pcv_decode_coord(enc, mid, mn, edge);
-    if (upper ? !(p < bound) : (bound <= p)) hi = mid;  // (NaN bounds: `min <= p` never holds, `p < max` never holds)
-    else lo = mid + 1;
-  }
-  return lo;
-}
-
 __global__ __launch_bounds__(256) void query_chunks_kernel(const QueryJob* __restrict__ jobs, uint32_t njobs, uint32_t nchunks,
-                                                            uint32_t shift, ChunkDesc* __restrict__ desc,
-                                                            const PcvShapeDev* __restrict__ aabb /* set: the shape is a box */,
-                                                            CodeBounds* __restrict__ bounds /* or null */) {
+                                                            uint32_t shift, ChunkDesc* __restrict__ desc) {
   const uint32_t c = blockIdx.x * 256 + threadIdx.x;
   if (c >= nchunks) return;
   uint32_t lo = 0, hi = njobs;  // last job with chunk_first <= c
@@ -913,58 +891,7 @@ __global__ __launch_bounds__(256) void query_chunks_kernel(const QueryJob* __res
     if (jobs[mid].chunk_first <= c) lo = mid;
     else hi = mid;
   }
-  const QueryJob jb = jobs[lo];
-  desc[c] = make_chunk_desc(jb, c, shift);
-  if (bounds) {
-    CodeBounds b;
-    b.v[0] = 0xffffffffu;
-    if (aabb && jb.enc <= PCV_ENC_UINT16 && jb.cube_edge > 0.0) {
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        b.v[a] = first_code_where(jb.enc, jb.cube_min[a], jb.cube_edge, aabb->bmin[a], false);
-        b.v[3 + a] = first_code_where(jb.enc, jb.cube_min[a], jb.cube_edge, aabb->bmax[a], true);
-      }
-    }
-    b.pad[0] = b.pad[1] = 0;
-    bounds[c] = b;
-  }
-}
-
-// keep flags of one chunk from code bounds (see CodeBounds): no decode
-template <int ENC>
-__device__ __forceinline__ uint32_t staged_keep_codes(const uint4* stage, uint32_t skew, const CodeBounds& cb, uint32_t cnt,
-                                                      const float* __restrict__ attr, double lo, double hi, uint32_t lane,
-                                                      uint8_t* __restrict__ keep) {
-  constexpr uint32_t stride = ENC == PCV_ENC_UINT8 ? 3u : 6u;
-  const uint8_t* bytes = reinterpret_cast<const uint8_t*>(stage) + skew;
-  uint32_t tot = 0;
-  for (uint32_t g0 = 0; g0 < cnt; g0 += kGroup) {
-    unsigned long long b[4];
-#pragma unroll
-    for (uint32_t r = 0; r < 4; ++r) {
-      const uint32_t q = g0 + r * 64 + lane;
-      bool k = false;
-      if (q < cnt) {
-        uint32_t c0, c1, c2;
-        if (ENC == PCV_ENC_UINT8) {
-          const uint8_t* at = bytes + q * stride;
-          c0 = at[0], c1 = at[1], c2 = at[2];
-        } else {
-          const uint16_t* at = reinterpret_cast<const uint16_t*>(bytes + q * stride);
-          c0 = at[0], c1 = at[1], c2 = at[2];
-        }
-        k = c0 >= cb.v[0] && c0 < cb.v[3] && c1 >= cb.v[1] && c1 < cb.v[4] && c2 >= cb.v[2] && c2 < cb.v[5];
-        if (attr) {  // iterator.rs:82-91 + math/mod.rs:86-88
-          const double a = (double)attr[q];
-          k = k && (lo <= a && a <= hi);
-        }
-      }
-      b[r] = __ballot(k);
-    }
-    store_keep(keep + g0, cnt - g0, b, lane);
-    tot += (uint32_t)(__popcll(b[0]) + __popcll(b[1]) + __popcll(b[2]) + __popcll(b[3]));
-  }
-  return tot;
+  desc[c] = make_chunk_desc(jobs[lo], c, shift);
 }
 
 // pass 1: keep flag per point of every chunk + kept count per chunk. Persistent waves: wave w takes chunks w, w + W,
@@ -976,8 +903,7 @@ __global__ __launch_bounds__(256) void query_flags_kernel(const PcvShapeDev* __r
                                                            const uint8_t* __restrict__ xyz_blob,
                                                            const float* __restrict__ inten_blob, int has_interval, double lo,
                                                            double hi, uint8_t* __restrict__ keep,
-                                                           uint32_t* __restrict__ chunk_counts,
-                                                           const CodeBounds* __restrict__ bounds /* boxes only, or null */) {
+                                                           uint32_t* __restrict__ chunk_counts) {
   __shared__ uint4 stage_all[4][kStageSlots];
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   uint4* stage = stage_all[wave];
@@ -987,12 +913,6 @@ __global__ __launch_bounds__(256) void query_flags_kernel(const PcvShapeDev* __r
   const ContainParams<KIND> shape = load_contain<KIND>(shape_dev);
   ChunkDesc d = desc[c];  // wave-uniform: scalar loads
   ChunkDesc dn = desc[min(c + nwaves, nchunks - 1)];
-  const bool coded = KIND == PCV_SHAPE_AABB && bounds != nullptr;
-  CodeBounds cb{}, cbn{};
-  if (coded) {
-    cb = bounds[c];
-    cbn = bounds[min(c + nwaves, nchunks - 1)];
-  }
   StageRegs sr = stage_issue(xyz_blob, d.src, d.cnt * enc_stride(d.enc), lane);
   for (;;) {
     const uint32_t skew = sr.skew;
@@ -1000,20 +920,10 @@ __global__ __launch_bounds__(256) void query_flags_kernel(const PcvShapeDev* __r
     const uint32_t cn = c + nwaves;
     if (cn < nchunks) sr = stage_issue(xyz_blob, dn.src, dn.cnt * enc_stride(dn.enc), lane);
     const ChunkDesc dnn = desc[min(cn + nwaves, nchunks - 1)];
-    CodeBounds cbnn{};
-    if (coded) cbnn = bounds[min(cn + nwaves, nchunks - 1)];
-    const float* at = has_interval ? inten_blob + d.attr_index : nullptr;
-    uint32_t tot;
-    if (coded && cb.v[0] != 0xffffffffu && d.enc == PCV_ENC_UINT16)
-      tot = staged_keep_codes<PCV_ENC_UINT16>(stage, skew, cb, d.cnt, at, lo, hi, lane, keep + d.keep_off);
-    else if (coded && cb.v[0] != 0xffffffffu && d.enc == PCV_ENC_UINT8)
-      tot = staged_keep_codes<PCV_ENC_UINT8>(stage, skew, cb, d.cnt, at, lo, hi, lane, keep + d.keep_off);
-    else
-      tot = staged_keep<KIND>(shape, stage, skew, d.enc, d.cube_min, d.cube_edge, d.cnt, at, lo, hi, lane, keep + d.keep_off);
+    const uint32_t tot = staged_keep<KIND>(shape, stage, skew, d.enc, d.cube_min, d.cube_edge, d.cnt,
+                                           has_interval ? inten_blob + d.attr_index : nullptr, lo, hi, lane, keep + d.keep_off);
     if (lane == 0) chunk_counts[c] = tot;
     if (cn >= nchunks) break;
-    cb = cbn;
-    cbn = cbnn;
     // the LDS slice is rewritten by the next commit: every lane must be done reading it
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1718,10 +1628,6 @@ static int query_points_impl(pcv_ctx* ctx, const pcv_shapes* shapes, uint32_t sh
   uint8_t* d_keep;
   uint32_t* d_cc;
   unsigned long long* d_total;
-  // boxes against integer-coded nodes are tested on the codes (CodeBounds): the bounds are made with the descriptors on the device
-  const bool box = !host_desc && shapes->kinds[shape_index] == PCV_SHAPE_AABB;
-  CodeBounds* d_bounds = nullptr;
-  if (box && (rc = sc.get(&d_bounds, nchunks))) return rc;
   if ((!host_desc && (rc = sc.get(&d_jobs, njobs))) || (rc = sc.get(&d_keep, keep_total)) ||
       (rc = sc.get(&d_cc, ((size_t)nchunks + 3) & ~(size_t)3)) || (rc = sc.get(&d_total, 1)) || (rc = sc.get(&d_desc, nchunks)))
     return rc;
@@ -1733,11 +1639,11 @@ static int query_points_impl(pcv_ctx* ctx, const pcv_shapes* shapes, uint32_t sh
     PcvProf prof(ctx, PCV_K_CULL_POINTS);
     if (!host_desc)
       hipLaunchKernelGGL(query_chunks_kernel, dim3((nchunks + 255) / 256), dim3(256), 0, ctx->stream, d_jobs, njobs, nchunks, shift,
-                         d_desc, box ? shapes->dev + shape_index : (const PcvShapeDev*)nullptr, d_bounds);
+                         d_desc);
 #define PCV_CALL(K)                                                                                                      \
   hipLaunchKernelGGL(query_flags_kernel<K>, dim3(nb_flags), dim3(256), 0, ctx->stream, shapes->dev + shape_index, d_desc, \
                      nchunks, tree->d_xyz, (const float*)tree->d_int, interval ? 1 : 0, interval ? interval[0] : 0.0,      \
-                     interval ? interval[1] : 0.0, d_keep, d_cc, (const CodeBounds*)d_bounds)
+                     interval ? interval[1] : 0.0, d_keep, d_cc)
     PCV_DISPATCH_KIND(shapes->kinds[shape_index], PCV_CALL)
 #undef PCV_CALL
   }

@@ -296,11 +296,10 @@ def test_query_points_large(ctx):
     assert tree.query_points(prepared, 0, capacity=1)["count"] == tree.num_points
 
 
-def test_boxes_on_integer_coded_nodes_are_tested_on_the_codes_with_the_same_ties(ctx):
-    """Axis-aligned boxes take code bounds on u8 / u16-coded nodes (CodeBounds, pcv_query.hip: the decode is monotone in the code, so
-    `mins <= p < maxs`, aabb.rs:46-48, is `lo <= code < hi`): boxes whose faces are EXACTLY decoded point positions (p == min is
-    inside, p == max is not), one and two ulps beside them, boxes that miss the cloud, an inverted and a NaN box — against the
-    oracle's decode-and-compare, with and without the intensity interval. 3 M points: descriptors written on the device."""
+def test_box_faces_on_decoded_positions_keep_the_reference_ties(ctx):
+    """`mins <= p < maxs` (aabb.rs:46-48) on decoded positions: boxes whose faces are EXACTLY decoded point positions (p == min is
+    inside, p == max is not), one ulp beside them, boxes that miss the cloud, an inverted and a NaN box — against the oracle's
+    decode-and-compare, with and without the intensity interval. 3 M points: descriptors written on the device."""
     x, y, z, rgb, bmin, bmax = synthetic.gaussian_clusters(3_000_000, seed=6, num_clusters=4, extent=300.0, sigma_range=(0.5, 20.0))
     inten = (np.arange(x.size) % 251).astype(np.float32)
     tree = ctx.build(0.001, pcv.Aabb(bmin, bmax), x, y, z, rgb, inten, max_points_per_node=20000)
