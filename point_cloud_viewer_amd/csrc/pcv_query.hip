@@ -755,65 +755,6 @@ __device__ __forceinline__ uint32_t staged_keep_enc(const ContainParams<KIND>& s
   }
   return tot;
 }
-// The same for integer codes when the slice starts on an 8-byte boundary (it does whenever the chunk starts at a node's first
-// byte or a whole number of full chunks behind it): lane l takes points 4 l .. 4 l + 3 of every group of 256 — 24 (12) contiguous
-// bytes, three 8-byte (4-byte) LDS reads instead of twelve 2-byte (1-byte) ones — and writes their four flags as the one dword
-// store_keep would assemble from four ballots.
-template <int KIND, int ENC>
-__device__ __forceinline__ uint32_t staged_keep_quads(const ContainParams<KIND>& shape, const uint4* stage, uint32_t skew,
-                                                      const double* cube_min, double cube_edge, uint32_t cnt,
-                                                      const float* __restrict__ attr, double lo, double hi, uint32_t lane,
-                                                      uint8_t* __restrict__ keep) {
-  static_assert(ENC == PCV_ENC_UINT8 || ENC == PCV_ENC_UINT16, "integer codes");
-  const uint8_t* bytes = reinterpret_cast<const uint8_t*>(stage) + skew;
-  uint32_t mine = 0;
-  for (uint32_t g0 = 0; g0 < cnt; g0 += kGroup) {
-    const uint32_t q0 = g0 + 4u * lane;
-    uint32_t c[12];
-    if (ENC == PCV_ENC_UINT16) {
-      const uint2* at = reinterpret_cast<const uint2*>(bytes + (size_t)q0 * 6u);
-      const uint2 a = at[0], b = at[1], d = at[2];  // x0 y0 | z0 x1 ; y1 z1 | x2 y2 ; z2 x3 | y3 z3
-      const uint32_t w[6] = {a.x, a.y, b.x, b.y, d.x, d.y};
-#pragma unroll
-      for (int k = 0; k < 12; ++k) c[k] = (w[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
-    } else {
-      const uint32_t* at = reinterpret_cast<const uint32_t*>(bytes + (size_t)q0 * 3u);
-      const uint32_t w[3] = {at[0], at[1], at[2]};
-#pragma unroll
-      for (int k = 0; k < 12; ++k) c[k] = (w[k >> 2] >> ((k & 3) * 8)) & 0xffu;
-    }
-    uint32_t word = 0;
-#pragma unroll
-    for (uint32_t j = 0; j < 4; ++j) {
-      const uint32_t q = q0 + j;
-      bool k = false;
-      if (q < cnt) {
-        k = shape_contains<KIND>(shape, V3d{pcv_decode_coord(ENC, c[3 * j], cube_min[0], cube_edge),
-                                            pcv_decode_coord(ENC, c[3 * j + 1], cube_min[1], cube_edge),
-                                            pcv_decode_coord(ENC, c[3 * j + 2], cube_min[2], cube_edge)});
-        if (attr) {  // iterator.rs:82-91 + math/mod.rs:86-88
-          const double a = (double)attr[q];
-          k = k && (lo <= a && a <= hi);
-        }
-      }
-      word |= (k ? 1u : 0u) << (8 * j);
-    }
-    uint8_t* kp = keep + g0;
-    const uint32_t left = cnt - g0, q = 4u * lane;
-    if ((reinterpret_cast<uintptr_t>(kp) & 3u) == 0 && q + 3 < left) {
-      *reinterpret_cast<uint32_t*>(kp + q) = word;
-    } else {
-#pragma unroll
-      for (uint32_t j = 0; j < 4; ++j)
-        if (q + j < left) kp[q + j] = (uint8_t)((word >> (8 * j)) & 1u);
-    }
-    mine += (uint32_t)__popc(word);
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
-  return mine;
-}
-
 template <int KIND>
 __device__ __forceinline__ uint32_t staged_keep(const ContainParams<KIND>& shape, const uint4* stage, uint32_t skew,
                                                 uint32_t enc, const double* cube_min, double cube_edge, uint32_t cnt,
@@ -821,10 +762,8 @@ __device__ __forceinline__ uint32_t staged_keep(const ContainParams<KIND>& shape
                                                 uint8_t* __restrict__ keep) {
   switch (enc) {  // wave-uniform
     case PCV_ENC_UINT8:
-      if ((skew & 7u) == 0) return staged_keep_quads<KIND, PCV_ENC_UINT8>(shape, stage, skew, cube_min, cube_edge, cnt, attr, lo, hi, lane, keep);
       return staged_keep_enc<KIND, PCV_ENC_UINT8>(shape, stage, skew, cube_min, cube_edge, cnt, attr, lo, hi, lane, keep);
     case PCV_ENC_UINT16:
-      if ((skew & 7u) == 0) return staged_keep_quads<KIND, PCV_ENC_UINT16>(shape, stage, skew, cube_min, cube_edge, cnt, attr, lo, hi, lane, keep);
       return staged_keep_enc<KIND, PCV_ENC_UINT16>(shape, stage, skew, cube_min, cube_edge, cnt, attr, lo, hi, lane, keep);
     case PCV_ENC_FLOAT32:
       return staged_keep_enc<KIND, PCV_ENC_FLOAT32>(shape, stage, skew, cube_min, cube_edge, cnt, attr, lo, hi, lane, keep);
