@@ -20,7 +20,8 @@ Other modes (never the driver's default): --verify forces the oracle comparison 
 (sharded path, --ecef ...); --ecef is BASELINE config 5; --query is BASELINE config 4 (frustum path) with parity of all
 frusta; --config1 is BASELINE config 1 (CPU plumbing line, no GPU work timed).
 
-Prints ONE JSON line on rank 0.
+Rank 0 writes the whole record to bench_detail.json, prints a trimmed copy of it and then, as the LAST stdout line, the
+line of record (<= 4 KB: contract fields + roofline + cpu_baseline + one parity verdict per BASELINE config).
 """
 import argparse
 import json
@@ -34,7 +35,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 F64_VALU_PEAK_GINST = 39300  # vector FP64 78.6 TFLOP/s = 39.3 T FMA-instructions/s (SURVEY 8d "Roofline bound")
-ROUND = "r05"
+ROUND = "r06"
 
 # algorithmic HBM bytes per point and launch (DESIGN.md "Kernels"); kernels bound by f64 VALU issue are marked
 ALGO_BYTES = {
@@ -875,6 +876,171 @@ def run_virtual_ranks(args, torch, pcv, dev):
     return out
 
 
+# ---- the line of record (the driver parses the LAST stdout line; r05's 22 KB line was cut and left parsed = null) ----
+FINAL_LINE_LIMIT = 4096   # bytes of the last stdout line
+DETAIL_LINE_LIMIT = 7000  # bytes of the earlier, trimmed detail line (the whole record goes to bench_detail.json)
+
+# the library's event slots -> the kernel symbols rocprofv3 lists for the single-chain build with 12-byte records (the slot of a
+# stage is shared by the kernels that can fill it; kernel_ms_per_step names the one that ran)
+SLOT_TO_SYMBOL_12 = {"spec_encode_kernel": "chain_pass_kernel", "downsweep_rec_kernel": "downsweep_rec12_kernel",
+                     "promote_settle_kernel": "promote_settle_leaf_kernel", "promote_climb_kernel": "promote_climb_leaf_kernel",
+                     "hist_from_rows_kernel": "hist12_from_rows_kernel"}
+
+
+def kernel_symbol(slot, build_info):
+    b = build_info or {}
+    if b.get("single_chain") and b.get("record_bytes") == 12:
+        return SLOT_TO_SYMBOL_12.get(slot, slot)
+    if b.get("single_chain"):
+        return {"spec_encode_kernel": "chain_pass_kernel", "promote_settle_kernel": "promote_settle_leaf_kernel",
+                "promote_climb_kernel": "promote_climb_leaf_kernel"}.get(slot, slot)
+    return slot
+
+
+def _leg_parity(leg, key="parity"):
+    """{ok, mismatching_nodes, tree_digest} of a leg's parity record (None when the leg did not run)."""
+    if not leg:
+        return None
+    if "error" in leg:
+        return {"ok": False, "error": str(leg["error"])[:120]}
+    p = leg.get(key) if key else leg
+    if not isinstance(p, dict):
+        return {"ok": bool(leg.get("ok"))}
+    out = {"ok": bool(p.get("ok"))}
+    for k in ("mismatching_nodes", "nodes", "tree_digest"):
+        if p.get(k) is not None:
+            out[k] = p[k]
+    return out
+
+
+def _shrink(obj, max_str=160, max_list=8):
+    """A copy of a record with long strings cut and long lists summarised (the earlier detail line; nothing is cut from the file)."""
+    if isinstance(obj, dict):
+        return {k: _shrink(v, max_str, max_list) for k, v in obj.items()
+                if k not in ("box", "source", "note", "compared", "oracle", "traffic_source", "first_mismatches")}
+    if isinstance(obj, (list, tuple)):
+        if len(obj) > max_list and all(isinstance(v, (int, float)) for v in obj):
+            s = sorted(obj)
+            return {"n": len(obj), "min": s[0], "median": s[len(s) // 2], "max": s[-1]}
+        return [_shrink(v, max_str, max_list) for v in obj[:max_list]]
+    if isinstance(obj, str) and len(obj) > max_str:
+        return obj[:max_str - 1] + "~"
+    return obj
+
+
+def final_line(out):
+    """The last stdout line: the fields the driver's contract names + roofline + cpu_baseline + one parity verdict per BASELINE
+    config, <= FINAL_LINE_LIMIT bytes. Everything else is in bench_detail.json (and, trimmed, on the line before)."""
+    roof = out.get("roofline") or {}
+    hv = roof.get("hbm_view") or (roof if roof.get("bound") == "hbm" else {})
+    binfo = out.get("build_info") or {}
+    sym = lambda k: kernel_symbol(k, binfo)
+    r = None
+    if roof:
+        r = {"bound": roof.get("bound"), "kernel": sym(roof.get("kernel")), "achieved": roof.get("achieved"),
+             "peak": roof.get("peak"), "unit": roof.get("unit"), "frac": roof.get("frac"),
+             "avg_launch_ms": roof.get("avg_launch_ms"),
+             "algorithmic_bytes_per_launch": hv.get("algorithmic_bytes_per_launch"), "traffic": roof.get("traffic"),
+             "hbm_view": {"achieved": hv.get("achieved"), "peak": hv.get("peak"), "unit": hv.get("unit"), "frac": hv.get("frac")}}
+        if roof.get("bound") == "valu_f64":
+            r["valu_insts_per_point"] = roof.get("valu_insts_per_point")
+            r["f64_arithmetic_insts_per_point"] = roof.get("f64_arithmetic_insts_per_point")
+            r["valu_issue_frac"] = (roof.get("valu_issue") or {}).get("frac")
+        big = roof.get("largest_hbm_kernel")
+        if big:
+            r["largest_hbm_kernel"] = {"kernel": sym(big.get("kernel")), "achieved": big.get("achieved"), "frac": big.get("frac"),
+                                       "avg_launch_ms": big.get("avg_launch_ms"), "traffic": big.get("traffic"),
+                                       "algorithmic_bytes_per_launch": big.get("algorithmic_bytes_per_launch")}
+        r["profile_matches_build"] = roof.get("profile_matches_build")
+    es = out.get("encode_sort") or None
+    if es:
+        rs = es.get("record_sort") or {}
+        es = {"GB/s": es.get("GB/s"), "frac_of_8TBps": None if es.get("GB/s") is None else round(es["GB/s"] / HBM_PEAK_GBS, 4),
+              "ms": es.get("ms"), "algorithmic_bytes_per_point": round(es.get("algorithmic_bytes_per_point") or 0.0, 2),
+              "record_sort": {"GB/s": rs.get("GB/s"), "frac_of_8TBps": None if rs.get("GB/s") is None else round(rs["GB/s"] / HBM_PEAK_GBS, 4),
+                              "ms": rs.get("ms")}}
+    cpu = out.get("cpu_baseline")
+    if cpu:
+        cpu = dict(cpu, sample=str(cpu.get("sample", ""))[:200])
+    cfg = out.get("config") or {}
+    sh = out.get("sharded") or None
+    parity = {"config2": _leg_parity(out, "parity") if out.get("parity") else None,
+              "config1": _leg_parity(out.get("config1"), None), "config4": _leg_parity(out.get("query")),
+              "config5": _leg_parity(out.get("config5")), "intensity": _leg_parity(out.get("intensity")),
+              "sharded": None if not sh else ({"ok": False, "error": str(sh["error"])[:120]} if "error" in sh else
+                                              {"ok": bool(sh.get("ok")), "world1_digest_equal": (sh.get("world1") or {}).get("digest_equal"),
+                                               "virtual8_digest_equal": {m: v.get("digest_equal") for m, v in (sh.get("virtual8") or {}).items()
+                                                                         if isinstance(v, dict)}})}
+    e2e = out.get("end_to_end") or None
+    if e2e:
+        fb = e2e.get("from_batches") or {}
+        e2e = {"Mpoints_per_s_incl_files": e2e.get("Mpoints_per_s_incl_files"),
+               "from_ply_Mpoints_per_s_incl_files": (e2e.get("from_ply_file") or {}).get("Mpoints_per_s_incl_files"),
+               "from_batches_Mpoints_per_s_incl_files": fb.get("Mpoints_per_s_incl_files")}
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                    "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = {"workload": str(cfg.get("workload", ""))[:260], "scope": str(cfg.get("scope", ""))[:200],
+                      "points_per_gpu": cfg.get("points_per_gpu"), "points_total": cfg.get("points_total"),
+                      "nodes": cfg.get("nodes"), "parallelism": str(cfg.get("parallelism", ""))[:120]}
+    line.update({"roofline": r, "encode_sort": es, "cpu_baseline": cpu, "parity": parity, "tree_digest": out.get("tree_digest"),
+                 "end_to_end": e2e,
+                 "kernel_ms_per_step": {sym(k): v for k, v in (out.get("kernel_ms_per_step") or {}).items()}})
+    for k in ("n1_same_cloud", "rccl_ranks", "sharded_stage_ms"):
+        if out.get(k) is not None:
+            line[k] = out[k]
+    c5, q = out.get("config5") or {}, out.get("query") or {}
+    legs = {}
+    if c5.get("value") is not None:
+        legs["config5_Mpoints_per_s"] = c5.get("value")
+    if (sh or {}).get("world1"):
+        legs["sharded_world1_ms"] = sh["world1"].get("ms_per_step")
+    if q.get("value") is not None:
+        legs["config4_" + str(q.get("unit", "value")).replace(" ", "_")] = q.get("value")
+    if legs:
+        line["legs"] = legs
+    line["detail"] = "bench_detail.json (the whole record; a trimmed copy is the stdout line before this one)"
+    # never longer than the limit: drop the least important objects first
+    for drop in ("legs", "kernel_ms_per_step", "end_to_end", "encode_sort"):
+        if len(json.dumps(line)) <= FINAL_LINE_LIMIT:
+            break
+        line.pop(drop, None)
+    if len(json.dumps(line)) > FINAL_LINE_LIMIT:
+        line["config"]["workload"] = line["config"]["workload"][:80]
+        line["config"].pop("scope", None)
+        if line.get("cpu_baseline"):
+            line["cpu_baseline"]["sample"] = line["cpu_baseline"]["sample"][:60]
+    return line
+
+
+def detail_line(out):
+    """The earlier stdout line: the whole record with notes, box dumps and step lists cut, legs dropped from the back until it fits."""
+    d = {"bench_detail": _shrink(out)}
+    for drop in ("config1", "intensity", "end_to_end", "sharded", "query", "config5", "roofline"):
+        if len(json.dumps(d)) <= DETAIL_LINE_LIMIT:
+            break
+        leg = d["bench_detail"].get(drop)
+        if isinstance(leg, dict):
+            d["bench_detail"][drop] = {k: v for k, v in leg.items() if not isinstance(v, (dict, list))}
+    if len(json.dumps(d)) > DETAIL_LINE_LIMIT:
+        d = {"bench_detail": {"see": "bench_detail.json", "keys": sorted(out)}}
+    return d
+
+
+def emit(out):
+    """bench_detail.json (whole record) -> the trimmed detail line -> the line of record, in that order; the last line is the
+    one the driver parses."""
+    text = json.dumps(out)
+    for path in (os.path.join(ROOT, "bench_detail.json"), os.path.join(ROOT, "gpurun_out", "bench_detail.json")):
+        try:
+            if os.path.isdir(os.path.dirname(path)):
+                with open(path, "w") as f:
+                    f.write(text + "\n")
+        except OSError as e:  # a read-only tree must not cost the line of record
+            print(f"bench_detail.json not written: {e}", file=sys.stderr)
+    print(json.dumps(detail_line(out)), flush=True)
+    print(json.dumps(final_line(out)), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -926,6 +1092,9 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true", help="same as --kernel-events none")
     ap.add_argument("--exact-pipeline", action="store_true",
                     help="force the exact two-chain pipeline (K2 keys + key sort + node split + K5) instead of the single-chain build")
+    ap.add_argument("--full-line", action="store_true",
+                    help="print the whole record as ONE stdout line (rounds 1-5; tools/ that post-process it) instead of "
+                         "bench_detail.json + a trimmed detail line + the <= 4 KB line of record")
     ap.add_argument("--fixed-bbox", action="store_true",
                     help="take the bounding box as an argument (K1 outside the step), as round 1 measured")
     args = ap.parse_args()
@@ -1443,7 +1612,10 @@ def main():
     if rank == 0:
         if world > 1:
             time.sleep(1.5)  # let the other ranks finish writing their own teardown chatter first
-        print(json.dumps(out), flush=True)
+        if args.full_line:
+            print(json.dumps(out), flush=True)
+        else:
+            emit(out)
 
 
 if __name__ == "__main__":

@@ -87,3 +87,56 @@ def test_query_profile_is_quoted_only_for_the_running_build():
     assert p.get("profile_matches_build") in (False, None) and "cull_nodes_kernel" not in p
     q = bench.query_profile(bench.build_hash())
     assert q.get("profile_matches_build") in (True, False, None)
+
+
+def _recorded_full_record():
+    """The whole record of a default run of an earlier round (22 KB as one line: what the driver failed to parse in round 5)."""
+    import json
+    for line in open(os.path.join(ROOT, "profiles", "r05_bench_100M.json")):
+        if line.startswith("{"):
+            return json.loads(line)
+    raise AssertionError("no JSON line in profiles/r05_bench_100M.json")
+
+
+def test_final_line_is_small(tmp_path, monkeypatch, capsys):
+    """the LAST stdout line is the line of record and stays under 4 KB whatever the legs carry; it holds the
+    contract fields, roofline, cpu_baseline and one parity verdict per BASELINE config; the whole record goes to a file."""
+    import json
+    out = _recorded_full_record()
+    assert len(json.dumps(out)) > 16_000
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    os.makedirs(tmp_path / "gpurun_out")
+    bench.emit(out)
+    lines = capsys.readouterr().out.strip().splitlines()
+    assert len(lines) == 2
+    detail, last = lines
+    assert len(last) < 4096 and len(detail) < 8192 and len(detail) + len(last) < 12_000
+    rec = json.loads(last)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in rec, k
+    assert rec["value"] == out["value"] and rec["ms_per_step"] == out["ms_per_step"]
+    assert rec["config"]["workload"].startswith("BASELINE config 2") and "model" not in rec["config"]
+    r = rec["roofline"]
+    assert r["frac"] == out["roofline"]["frac"] and r["traffic"] == out["roofline"]["traffic"] and r["hbm_view"]["frac"]
+    assert r["kernel"] == "chain_pass_kernel"  # the symbol rocprofv3 lists, not the library's event slot
+    assert set(rec["kernel_ms_per_step"]) >= {"chain_pass_kernel", "downsweep_rec12_kernel", "promote_settle_leaf_kernel",
+                                              "downsweep_settle_kernel", "aabb_partial_kernel"}
+    assert rec["cpu_baseline"]["kind"] == "port" and rec["cpu_baseline"]["cores"] == out["cpu_baseline"]["cores"]
+    assert rec["encode_sort"]["frac_of_8TBps"] == round(out["encode_sort"]["GB/s"] / 8000.0, 4)
+    p = rec["parity"]
+    assert p["config2"] == {"ok": True, "mismatching_nodes": 0, "nodes": 6073, "tree_digest": out["tree_digest"]}
+    assert all(p[k]["ok"] for k in ("config1", "config4", "config5", "intensity", "sharded"))
+    whole = json.loads(open(tmp_path / "bench_detail.json").read())
+    assert whole == out and json.loads(open(tmp_path / "gpurun_out" / "bench_detail.json").read()) == out
+    assert "bench_detail" in json.loads(detail)
+    # a leg that failed is a verdict, not a crash of the line; a record without legs (N > 1, --no-legs) still prints
+    out2 = dict(out, config5={"error": "RuntimeError: " + "x" * 500}, query=None, sharded=None, intensity=None, config1=None)
+    rec2 = bench.final_line(out2)
+    assert rec2["parity"]["config5"]["ok"] is False and rec2["parity"]["config4"] is None
+    # pathological growth (every string 10 x longer) still fits: the line sheds its optional objects
+    fat = json.loads(json.dumps(out))
+    fat["config"]["workload"] *= 10
+    fat["cpu_baseline"]["sample"] *= 10
+    fat["kernel_ms_per_step"] = {f"kernel_with_a_long_name_{i}": 1.0 for i in range(200)}
+    assert len(json.dumps(bench.final_line(fat))) <= bench.FINAL_LINE_LIMIT
