@@ -437,10 +437,20 @@ def sharded_leg(args, torch, pcv, ctx, dev, x, y, z, rgb, want_digest, steps=5, 
             ms = (time.perf_counter() - t0) / steps * 1e3
             ctx.set_profiling(False)
             kms = {k: round(v[1] / steps, 3) for k, v in ctx.kernel_stats().items() if v[0] > 0}
+            # the same with K1 + the 6-number all-reduce INSIDE the step: the scope of the unsharded step and of `--gpus N`
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                builder.build(args.resolution, builder.global_bbox(x, y, z), x, y, z, rgb).free()
+            dist.barrier()
+            torch.cuda.synchronize()
+            ms_bbox = (time.perf_counter() - t0) / steps * 1e3
             r = builder.build(args.resolution, bbox, x, y, z, rgb)
             dig = digest_of_digests(sharded_digests(r))
             r.free()
-            w1[mode] = {"ms_per_step": round(ms, 3), "Mpoints_per_s": round(n / (ms * 1e-3) / 1e6, 1), "stage_ms": ex["ms"],
+            w1[mode] = {"ms_per_step": round(ms, 3), "ms_per_step_bbox_inside": round(ms_bbox, 3),
+                        "Mpoints_per_s": round(n / (ms * 1e-3) / 1e6, 1), "stage_ms": ex["ms"],
                         "kernel_ms_per_step": kms, "rows_sent": ex["rows_sent"], "rows_received": ex["rows_received"], "tree_digest": dig,
                         "digest_equal": dig == want_digest}
         out["world1"] = dict(w1["octants"], rccl_ranks=1, shard_mode="octants", buckets=w1["buckets"])
@@ -1041,6 +1051,37 @@ def emit(out):
     print(json.dumps(final_line(out)), flush=True)
 
 
+def n1_same_cloud_leg(args, torch, pcv, dev, device_index, total, steps=3, warmup=2):
+    """The N = 1 reference of a `--gpus N` line: rank 0 regenerates the WHOLE config-3 cloud (the block generator makes any
+    slice reproducible) and builds it unsharded — the same scope as the sharded step (K1 inside), 1 B points = 27 GB of input
+    + ~80 GB of build scratch on one 288 GB part — so that value / n1_same_cloud.value is a like-for-like speed-up."""
+    try:
+        c1 = pcv.Context(device_index)
+        x, y, z, rgb = make_cloud_slice(torch, total, 0, total, seed=args.seed3, device=dev)
+        for _ in range(warmup):
+            c1.build(args.resolution, None, x, y, z, rgb).free()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            c1.build(args.resolution, None, x, y, z, rgb).free()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        out = {"points": total, "steps": steps, "warmup": warmup, "ms_per_step": round(dt * 1e3, 3),
+               "value": round(total / dt / 1e6, 2), "unit": "Mpoints/s",
+               "scope": "rank 0, one GPU, unsharded pcv_build_octree with K1 inside the step, the same cloud"}
+        if not args.no_n1_digest:
+            t = c1.build(args.resolution, None, x, y, z, rgb)
+            out["nodes"], out["tree_digest"] = t.num_nodes, digest_of_digests(tree_digests(t))
+            t.free()
+        del x, y, z, rgb
+        c1.close()
+        torch.cuda.empty_cache()
+        return out
+    except Exception as e:  # noqa: BLE001 - the sharded measurement must not die with its reference
+        torch.cuda.empty_cache()
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1092,6 +1133,10 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true", help="same as --kernel-events none")
     ap.add_argument("--exact-pipeline", action="store_true",
                     help="force the exact two-chain pipeline (K2 keys + key sort + node split + K5) instead of the single-chain build")
+    ap.add_argument("--n1-same-cloud", action="store_true",
+                    help="config 3: also build the whole cloud unsharded on rank 0 before the timed region (default with N > 1)")
+    ap.add_argument("--no-n1", action="store_true", help="N > 1: skip the unsharded reference build of the same cloud on rank 0")
+    ap.add_argument("--no-n1-digest", action="store_true", help="N > 1: no digest comparison of the merged octree with the unsharded one")
     ap.add_argument("--full-line", action="store_true",
                     help="print the whole record as ONE stdout line (rounds 1-5; tools/ that post-process it) instead of "
                          "bench_detail.json + a trimmed detail line + the <= 4 KB line of record")
@@ -1164,6 +1209,11 @@ def main():
         total = n * world
         x, y, z, rgb = make_cloud(torch, n, seed=1 + rank, device=dev, offset=offset)  # ends with a device synchronize
     ctx = pcv.Context(local_rank)  # the library's own stream; torch work is ordered explicitly (wait_torch)
+    n1 = None
+    if config3 and rank == 0 and (world > 1 or args.n1_same_cloud) and not args.no_n1:
+        # the SAME cloud built unsharded on this one GPU (own context, released afterwards) while the other ranks wait at the
+        # warm-up's first collective: the line then carries its own N = 1 reference (VERDICT r05 #2b)
+        n1 = n1_same_cloud_leg(args, torch, pcv, dev, local_rank, total)
 
     info = {}
     if not sharded:
@@ -1186,7 +1236,10 @@ def main():
         bbox = builder.global_bbox(x, y, z)
 
         def step(details=True):
-            r = builder.build(args.resolution, bbox, x, y, z, rgb)
+            # the same scope as the unsharded step: K1 over the local slice + ONE 6-number all-reduce (min of [lo, -hi]) are
+            # INSIDE the step (VERDICT r05 #2a); --fixed-bbox takes the box as an argument, as the reference's library entry does
+            box = bbox if args.fixed_bbox else builder.global_bbox(x, y, z)
+            r = builder.build(args.resolution, box, x, y, z, rgb)
             info["nodes"], info["stages"] = r.num_nodes_local, r.stage_ms
             info["build"] = r.local.build_info() if hasattr(r.local, "build_info") else None
             info["exchange"] = r.exchange_info()
@@ -1397,10 +1450,11 @@ def main():
     if not sharded and rank == 0 and (args.verify or (plain and not args.no_parity)):
         parity = verify_build(ctx, args.resolution, x, y, z, rgb)
         tree_digest = parity.get("tree_digest")
-    elif sharded and (args.verify or args.digest):
+    elif sharded and (args.verify or args.digest or (n1 is not None and "tree_digest" in n1) or
+                      (world > 1 and not args.no_n1 and not args.no_n1_digest)):
         # sharded path: every rank hashes its subtrees, rank 0 merges them with the all-reduced top nodes; --verify:
         # rank 0 regenerates the whole cloud (the block generator makes any slice reproducible) for the oracle
-        r = builder.build(args.resolution, bbox, x, y, z, rgb)
+        r = builder.build(args.resolution, builder.global_bbox(x, y, z), x, y, z, rgb)
         mine = sharded_digests(r)
         r.free()
         gathered = [None] * world if rank == 0 else None
@@ -1412,6 +1466,9 @@ def main():
                     dup += k in merged
                     merged[k] = v
             tree_digest = digest_of_digests(merged)
+            if n1 is not None and "tree_digest" in n1:
+                n1["digest_equal"] = bool(n1["tree_digest"] == tree_digest and dup == 0)
+                n1["speedup"] = None  # filled in below, once `value` is known
             if args.verify:
                 if config3:
                     wx, wy, wz, wrgb = make_cloud_slice(torch, total, 0, total, seed=args.seed3, device=dev)
@@ -1580,7 +1637,9 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload,
                        "scope": "device-resident inputs -> bounding box (K1" + (" outside the step" if args.fixed_bbox else "") +
-                                ") + node table + node-contiguous .xyz/.rgb bytes in HBM; no D2H of the blobs, no file writes",
+                                (" + one 6-number all-reduce" if sharded and not args.fixed_bbox else "") +
+                                (") + routing + ONE all-to-all(v) + per-rank subtree builds + top-node all-reduce: node table" if sharded else ") + node table") +
+                                " + node-contiguous .xyz/.rgb bytes in HBM; no D2H of the blobs, no file writes",
                        "points_per_gpu": n, "points_total": total, "resolution": args.resolution, "nodes": info.get("nodes"),
                        "kernel_events_in_timed_region": args.kernel_events, "box": box,
                        "parallelism": "1 GPU" if world == 1 else
@@ -1594,10 +1653,17 @@ def main():
                                         "bytes_sent": e["bytes_sent"], "bytes_received": e["bytes_received"], "ms": e["ms"]}
                 for r, e in enumerate(per_rank)],
             "rccl_ranks": world if dist is not None else None,
+            "n1_same_cloud": n1,
+            "sharded_stage_ms": None if not sharded else {k: round(v, 3) for k, v in (info.get("stages") or {}).items()
+                                                          if k in ("bbox", "exchange", "local_build", "top_merge")},
             "stage_ms": {k: round(v, 3) for k, v in (info.get("stages") or {}).items()},
             "wall_ms_each_step": per_step_ms, "gpu_ms_each_step": (info.get("gpu_ms") or [])[-args.steps:],
             "kernel_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in kstats.items() if v[0] > 0},
         }
+        if n1 and n1.get("value"):
+            n1["speedup"] = round(value / n1["value"], 4)
+            n1["note"] = (f"speed-up of {world} rank(s) over one GPU on the same {total} points, both with the bounding box inside "
+                          "the step; efficiency = speedup / n_gpus")
         if os.environ.get("PCV_BENCH_DEBUG"):
             out["stages_each_step"] = info.get("all_stages") or []
     # RCCL prints a version banner on stdout when the communicator goes away: tear it down and flush the C streams

@@ -281,11 +281,12 @@ class ShardedOctreeBuilder:
         big = np.finfo(np.float64).max
         if n_local == 0:  # an empty slice must not pull the box towards Aabb::zero()
             bmin, bmax = np.full(3, big), np.full(3, -big)
-        lo = torch.tensor(np.asarray(bmin), dtype=torch.float64, device=self.device)
-        hi = torch.tensor(np.asarray(bmax), dtype=torch.float64, device=self.device)
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        return _oct.Aabb(lo.cpu().numpy(), hi.cpu().numpy())
+        # ONE collective and one read-back: min over [lo, -hi] (negation is exact), 6 numbers
+        v = torch.tensor(np.concatenate([np.asarray(bmin, dtype=np.float64), -np.asarray(bmax, dtype=np.float64)]),
+                         dtype=torch.float64, device=self.device)
+        dist.all_reduce(v, op=dist.ReduceOp.MIN)
+        h = v.cpu().numpy()
+        return _oct.Aabb(h[:3].copy(), -h[3:])
 
     def _after_torch(self):
         if hasattr(self.backend, "after_torch"):
