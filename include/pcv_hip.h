@@ -137,6 +137,41 @@ typedef struct pcv_build_params {
  * the result holds the finished node table and node-contiguous .xyz/.rgb/.intensity bytes. */
 int pcv_build_octree(pcv_ctx* ctx, const pcv_build_params* params, const pcv_points* points, pcv_octree** out);
 
+/* Limits of one call (stated here, not discovered at run time): positions are addressed with 32 bits, so a build takes at
+ * most 2^32 - 2 points (PCV_E_INVALID above that); everything is device-resident, about 80 bytes of HBM per point at the
+ * peak of a build (27-31 B of input + records, rank counts, the wide-code pool and the output blobs), so ONE 288 GB MI355X
+ * ends at roughly 3 x 10^9 points. The reference streams any size through node files (generation.rs:58-126); larger clouds
+ * go through the multi-GPU path (pcv_route_* + pcv_build_begin_routed), which shards by subtree. */
+#define PCV_MAX_POINTS_PER_BUILD 0xfffffffeull
+
+/* ---- streaming batch ingest: the reference's `impl Iterator<Item = PointsBatch>` (generation.rs:289-295) ------------
+ * A PointsBatch (src/lib.rs:102-107) holds `position: Vec<Point3<f64>>` — AoS, 24 bytes per point — "color"
+ * Vec<Vector3<u8>> (3 bytes per point) and optionally "intensity" Vec<f32> (src/octree/mod.rs:62-74), and arrives 500 000
+ * points at a time (src/lib.rs:52). These calls take the batches AS THEY ARE, one at a time:
+ *   pcv_ingest_begin   num_points_hint = NumberOfPoints::num_points() of the stream (0 = unknown: the device arrays grow);
+ *                      has_intensity = the attribute list names "intensity" (then every batch must carry it).
+ *   pcv_ingest_append  copies the batch's three arrays side by side into one chunk of the context's pinned ring, queues ONE
+ *                      DMA for the chunk and ONE kernel that transposes the positions AoS -> SoA into place behind the
+ *                      points already on the device, copies colour / intensity behind theirs and folds the batch into the
+ *                      running bounding box (find_bounding_box, generation.rs:256-270). Returns when both are queued — the
+ *                      caller's arrays are free again and the next batch can be produced while this one goes up. Batches of
+ *                      any size (split into pieces of 2^20 points inside); n == 0 is a no-op. Host memory: the ring
+ *                      (3 x 32 MiB), whatever the size of the cloud.
+ *   pcv_ingest_bbox    the bounding box of the points appended so far (waits for the queued batches); Aabb::zero() for none.
+ *   pcv_ingest_finish  pcv_build_octree on the ingested cloud; with PCV_BUILD_COMPUTE_BBOX the box folded during the ingest
+ *                      is used (no pass over the cloud), otherwise params->bbox_* as build_octree takes it from its caller.
+ *                      ALWAYS consumes the ingest, whatever it returns.
+ *   pcv_ingest_abort   drops an ingest without building.
+ * One ingest at a time per context; no other call on the context between begin and finish except pcv_last_error. */
+typedef struct pcv_ingest pcv_ingest;
+int pcv_ingest_begin(pcv_ctx* ctx, uint64_t num_points_hint, int has_intensity, pcv_ingest** out);
+int pcv_ingest_append(pcv_ingest* ingest, const double* xyz /* n x 3, x y z per point (host) */, const uint8_t* rgb /* n x 3 (host) */,
+                      const float* intensity /* n (host), NULL without the attribute */, uint64_t n);
+uint64_t pcv_ingest_num_points(const pcv_ingest* ingest);
+int pcv_ingest_bbox(pcv_ingest* ingest, double bbox_min[3], double bbox_max[3]);
+int pcv_ingest_finish(pcv_ingest* ingest, const pcv_build_params* params, pcv_octree** out);
+void pcv_ingest_abort(pcv_ingest* ingest);
+
 /* The same build in two steps, for the multi-GPU path: when the level-2 subtrees of one level-1 node live on
  * different ranks, the every-8th promotion (generation.rs:195-253) into the level-1 node and into the root runs over
  * streams that span ranks, so the stream offsets must be agreed between the topology and the encode phase.
@@ -231,10 +266,14 @@ void pcv_octree_free(pcv_octree* t);
 #define PCV_STAGE_NODE_SPLIT 3
 #define PCV_STAGE_TABLE 4      /* node-table D2H + host finalize + H2D */
 #define PCV_STAGE_LEAF_ENCODE 5
-#define PCV_STAGE_SORT_RECORDS 6
-#define PCV_STAGE_PROMOTE_ENCODE 7
-#define PCV_STAGE_TOTAL 8
-#define PCV_NUM_STAGES 9
+#define PCV_STAGE_SORT_RECORDS 6 /* the record sort's FIRST pass (+ histograms); a sort that runs to its end on its own: all passes */
+#define PCV_STAGE_PROMOTE_ENCODE 7 /* from the node tables to the finished blobs; CONTAINS PCV_STAGE_SORT_SECOND */
+/* The record sort's second pass when it is held back until the node tables are up (it then settles the leaves' points itself,
+ * pcv_octree_settled_in_sort): queued inside PCV_STAGE_PROMOTE_ENCODE, measured on its own here — sort time =
+ * SORT_RECORDS + SORT_SECOND, promotion proper = PROMOTE_ENCODE - SORT_SECOND. 0 when no pass was held back. */
+#define PCV_STAGE_SORT_SECOND 8
+#define PCV_STAGE_TOTAL 9
+#define PCV_NUM_STAGES 10
 int pcv_octree_stage_ms(const pcv_octree* t, float* ms, int cap);
 /* How the last build went: attempts == 0: single-chain build (key_levels = levels the sample keys covered);
  * attempts == 1: exact pipeline, the sampled depth estimate held (key_levels = digit levels sorted);

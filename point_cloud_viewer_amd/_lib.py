@@ -23,9 +23,9 @@ BUILD_NO_SINGLE_CHAIN = 8
 BUILD_CHECK_RESOLVE = 16
 BUILD_STAGE_TIMES = 32
 MAX_KEY_LEVELS = 21
-NUM_STAGES = 9
+NUM_STAGES = 10
 STAGE_NAMES = ["aabb", "chain_keys", "sort_keys", "node_split", "table", "leaf_encode", "sort_records",
-               "promote_encode", "total"]
+               "promote_encode", "sort_second", "total"]
 
 _ERR_NAMES = {PCV_E_INVALID: "PCV_E_INVALID", PCV_E_HIP: "PCV_E_HIP", PCV_E_IO: "PCV_E_IO", PCV_E_OOM: "PCV_E_OOM",
               PCV_E_DEPTH: "PCV_E_DEPTH", PCV_E_NOT_FOUND: "PCV_E_NOT_FOUND"}
@@ -117,6 +117,12 @@ _SIGNATURES = {
     "pcv_ctx_kernel_stats": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64),
                                        C.POINTER(C.c_double)]),
     "pcv_build_octree": (C.c_int, [_vp, C.POINTER(BuildParams), C.POINTER(Points), C.POINTER(_vp)]),
+    "pcv_ingest_begin": (C.c_int, [_vp, C.c_uint64, C.c_int, C.POINTER(_vp)]),
+    "pcv_ingest_append": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint64]),
+    "pcv_ingest_num_points": (C.c_uint64, [_vp]),
+    "pcv_ingest_bbox": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "pcv_ingest_finish": (C.c_int, [_vp, C.POINTER(BuildParams), C.POINTER(_vp)]),
+    "pcv_ingest_abort": (None, [_vp]),
     "pcv_octree_num_nodes": (C.c_uint64, [_vp]),
     "pcv_octree_num_points": (C.c_uint64, [_vp]),
     "pcv_octree_has_intensity": (C.c_int, [_vp]),

@@ -282,22 +282,27 @@ int pcv_ctx::h2d(void* dst, const void* src, size_t bytes) {
   });
 }
 
+// The ring of pinned chunks and the host threads that fill them, created on first use (h2d_fill, pcv_ingest_begin).
+int pcv_ctx::ring_ensure() {
+  if (ring[0]) return PCV_OK;
+  for (int k = 0; k < kRingSlots; ++k) {
+    if (hipHostMalloc(&ring[k], kRingChunk, hipHostMallocDefault) != hipSuccess) return fail(PCV_E_OOM, "hipHostMalloc (staging ring)");
+    if (hipEventCreateWithFlags(&ring_ev[k], hipEventDisableTiming) != hipSuccess) return fail(PCV_E_HIP, "hipEventCreate");
+  }
+  unsigned hw = std::thread::hardware_concurrency();
+  // copies into pinned memory saturate the link with 7 threads; preads from a file (pcv_build_octree_from_ply) want more
+  unsigned workers = hw >= 64 ? 15 : (hw >= 16 ? 7 : (hw > 2 ? hw / 2 - 1 : 0));
+  if (const char* e = pcv_experiment("PCV_H2D_THREADS")) workers = (unsigned)std::max(0, atoi(e));
+  host_pool.start(workers);
+  return PCV_OK;
+}
+
 // Host -> device through the ring of pinned chunks: `fill(to, off, len)` produces bytes [off, off + len) of the source
 // into pinned memory (a memcpy from pageable memory, a pread from a file) and is called from the context's host threads,
 // 2 MiB per call, several calls in parallel; one DMA per 32 MiB chunk follows. false from `fill` -> PCV_E_IO.
 int pcv_ctx::h2d_fill(void* dst, size_t bytes, const std::function<bool(uint8_t*, size_t, size_t)>& fill) {
   if (bytes == 0) return PCV_OK;
-  if (!ring[0]) {
-    for (int k = 0; k < kRingSlots; ++k) {
-      if (hipHostMalloc(&ring[k], kRingChunk, hipHostMallocDefault) != hipSuccess) return fail(PCV_E_OOM, "hipHostMalloc (staging ring)");
-      if (hipEventCreateWithFlags(&ring_ev[k], hipEventDisableTiming) != hipSuccess) return fail(PCV_E_HIP, "hipEventCreate");
-    }
-    unsigned hw = std::thread::hardware_concurrency();
-    // copies into pinned memory saturate the link with 7 threads; preads from a file (pcv_build_octree_from_ply) want more
-    unsigned workers = hw >= 64 ? 15 : (hw >= 16 ? 7 : (hw > 2 ? hw / 2 - 1 : 0));
-    if (const char* e = pcv_experiment("PCV_H2D_THREADS")) workers = (unsigned)std::max(0, atoi(e));
-    host_pool.start(workers);
-  }
+  if (int rc = ring_ensure()) return rc;
   // one part per worker (the caller works too) and chunk, not less than 256 KiB
   const size_t nworkers = host_pool.threads.size() + 1;
   const size_t kPart = std::max<size_t>(256u << 10, ((kRingChunk + nworkers - 1) / nworkers + 4095) & ~(size_t)4095);
@@ -370,7 +375,7 @@ static const char* kKernelNames[PCV_K_COUNT] = {
     "visible_nodes_kernel", "nodes_in_location_kernel", "cull_points_kernel", "transform_points_kernel",
     "query_compact_kernel", "route_bucket_kernel", "partition_count_kernel", "partition_scatter_kernel",
     "promote_climb_kernel", "spec_encode_kernel", "rank_hist_kernel", "spec_continue_kernel", "spec_replay_kernel", "upsweep_map_kernel",
-    "hist_from_rows_kernel", "cull_nodes_sparse_kernel", "downsweep_settle_kernel"};
+    "hist_from_rows_kernel", "cull_nodes_sparse_kernel", "downsweep_settle_kernel", "ingest_batch_kernel"};
 static_assert(sizeof(kKernelNames) / sizeof(kKernelNames[0]) == PCV_K_COUNT, "kernel name table out of sync");
 
 extern "C" int pcv_ctx_set_profiling(pcv_ctx* ctx, int enabled) {
@@ -835,6 +840,12 @@ struct PcvBuild {
   std::vector<uint8_t> resolve_host_inner;  // T'' node is an inner node: its map entry is never read (the device leaves it unwritten)
   PcvSortPayload pl;
   explicit PcvBuild(pcv_ctx* c) : ctx(c), sc(c) {}
+  // A build dropped between begin and finish (an error in finish before the held-back pass was queued, a tree freed without
+  // finish): the pass's layout kernels on the side stream write into `sc`'s sort scratch; the main stream must be ordered behind
+  // them before the members below hand that scratch back to the pool
+  ~PcvBuild() {
+    if (sort_second.pending && sort_second.join_side) (void)ctx->side_end();
+  }
 };
 
 extern "C" void pcv_octree_free(pcv_octree* t) {
@@ -1425,7 +1436,10 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
     bs->spec_map_dev = nullptr;
     bs->spec_rows = nullptr;
     bs->sort_queued = false;
-    bs->sort_second = PcvSortSecond();  // (a held-back second pass is simply never queued)
+    // a held-back second pass is simply never queued — but its layout kernels may still be running on the side stream, writing
+    // into the sort scratch that goes back to the (main-stream-ordered) pool below: join them first
+    if (bs->sort_second.pending && bs->sort_second.join_side) (void)ctx->side_end();
+    bs->sort_second = PcvSortSecond();
     bs->resolve_on_device = false;
     sc.detach(payload);
     ctx->dev_free(payload);
@@ -2175,7 +2189,10 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
     fz.rgb_blob = t->d_rgb;
     fz.inten_blob = t->d_int;
     fz.num_leaves = num_leaves;
-    if ((rc = pcv_radix_sort_records_second(ctx, &bs->sort_second, fuse_sort ? &fz : nullptr))) return rc;
+    ctx->stage_begin(PCV_STAGE_SORT_SECOND);  // (nested in PROMOTE_ENCODE: the sort's pass is accounted on its own)
+    rc = pcv_radix_sort_records_second(ctx, &bs->sort_second, fuse_sort ? &fz : nullptr);
+    ctx->stage_end(PCV_STAGE_SORT_SECOND);
+    if (rc) return rc;
     if ((rc = queue_replay(ctx, bs))) return rc;  // (held back with the pass: replayed leaves rewrite their sorted records)
   }
   // leaves below a split first candidate: the leaf-wise settle kernel continues their chain itself (its items name the

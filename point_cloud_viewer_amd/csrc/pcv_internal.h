@@ -120,6 +120,7 @@ enum PcvKernelId {
   PCV_K_SORT_HIST_ROWS,
   PCV_K_CULL_NODES_SPARSE,
   PCV_K_SORT_SETTLE,  // the record sort's second pass settling the leaves' points itself (PcvSortFuse)
+  PCV_K_INGEST,       // pcv_ingest_append: AoS -> SoA transposition + attribute copies + bounding-box fold of one batch
   PCV_K_COUNT
 };
 
@@ -149,6 +150,7 @@ struct pcv_ctx {
   bool ring_busy[kRingSlots] = {};
   int ring_next = 0;
   PcvHostPool host_pool;
+  int ring_ensure();
   int h2d(void* dst, const void* src, size_t bytes);  // asynchronous on `stream` from the device's point of view
   int h2d_fill(void* dst, size_t bytes, const std::function<bool(uint8_t* to, size_t off, size_t len)>& fill);
   hipEvent_t ev[PCV_NUM_STAGES + 2] = {};

@@ -946,10 +946,13 @@ __device__ __forceinline__ void downsweep_rec12_body(const uint32_t* __restrict_
 #endif
         const uint64_t pidx = L.point_off + slot;
         if (PL) reinterpret_cast<uint32_t*>(fuse.inten_blob)[pidx] = inten;
-        // 3 bytes at 3 x slot: one 2-byte store at the even address of the three + one byte
+        // 3 bytes at 3 x pidx: one 2-byte store at the EVEN address of the three + one byte. The parity is the address's, i.e.
+        // pidx's, not slot's: a leaf's point_off may be odd (the .xyz stores below may use slot's, xyz_off is
+        // 16-byte aligned)
         uint8_t* cd = fuse.rgb_blob + pidx * 3;
-        *reinterpret_cast<uint16_t*>(cd + (odd ? 1 : 0)) = (uint16_t)(odd ? rgb >> 8 : rgb);
-        cd[odd ? 0 : 2] = (uint8_t)(odd ? rgb : rgb >> 16);
+        const bool odd_rgb = (pidx & 1u) != 0;
+        *reinterpret_cast<uint16_t*>(cd + (odd_rgb ? 1 : 0)) = (uint16_t)(odd_rgb ? rgb >> 8 : rgb);
+        cd[odd_rgb ? 0 : 2] = (uint8_t)(odd_rgb ? rgb : rgb >> 16);
         if (u8) {
           uint8_t* x = fuse.xyz_blob + L.xyz_off + (uint64_t)slot * 3;
           *reinterpret_cast<uint16_t*>(x + (odd ? 1 : 0)) = (uint16_t)(odd ? out[1] | (out[2] << 8) : out[0] | (out[1] << 8));
@@ -1219,7 +1222,18 @@ static void rec12_launch(pcv_ctx* ctx, int variant, const SortGeom& g, const uin
 
 // true-rank counters per sort workgroup the scratch holds (hist12_from_rows_kernel): 2^14, and 2^15 for clouds big enough to have
 // that many leaves (128 MB of scratch instead of 64), 2^16 from 500 M points on (256 MB)
-static uint32_t rows_true_bins(uint64_t n) { return n >= 500000000ull ? 65536u : n >= 200000000ull ? 32768u : 16384u; }
+static uint32_t rows_true_bins(uint64_t n) {
+#ifdef PCV_EXPERIMENTS
+  // PCV_ROWS_TRUE_BINS=32768 / 65536 (libpcv_hip_exp.so): the 15- / 16-bit rank geometries on a cloud small enough for the CPU
+  // oracle to check them (tests/test_gpu_single_chain.py)
+  static const uint32_t forced = [] {
+    const char* e = pcv_experiment("PCV_ROWS_TRUE_BINS");
+    return e ? (uint32_t)atoi(e) : 0u;
+  }();
+  if (forced) return forced;
+#endif
+  return n >= 500000000ull ? 65536u : n >= 200000000ull ? 32768u : 16384u;
+}
 
 template <typename KeyT>
 int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int end_bit, PcvSortPayload* payload,
@@ -1594,7 +1608,11 @@ int pcv_radix_sort_records_second(pcv_ctx* ctx, PcvSortSecond* sd, const PcvSort
 #undef PCV_REC12_SETTLE_B
     (void)settle_block;
   } else {
-    if (fuse) return ctx->fail(PCV_E_INVALID, "record sort: the settling pass with an intensity plane needs a second digit of <= 7 bits");
+    // (the caller decides with the same condition whether to pass `fuse`, pcv_build_finish `fuse_sort`; should the two ever drift
+    // apart the build must not degrade silently into leaves nobody settles: one message per cause)
+    if (fuse && plane && sd->nbits > 7)
+      return ctx->fail(PCV_E_INVALID, "record sort: the settling pass with an intensity plane needs a second digit of <= 7 bits");
+    if (fuse) return ctx->fail(PCV_E_INVALID, "record sort: the settling pass with an intensity plane needs the octree's intensity blob");
     PcvProf prof(ctx, PCV_K_SORT_DOWNSWEEP_REC);
     if (sd->nbits <= 7 && plane) PCV_REC12_SECOND(128, true);
     else if (sd->nbits <= 7) PCV_REC12_SECOND(128, false);

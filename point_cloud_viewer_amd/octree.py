@@ -214,6 +214,13 @@ class Context:
         del keep
         return OctreeResult(self, h)
 
+    def ingest(self, num_points_hint=0, has_intensity=False):
+        """Streaming batch ingest (pcv_ingest_begin): the reference's `impl Iterator<Item = PointsBatch>` input of
+        build_octree (generation.rs:289-295), one batch at a time in the reference's own AoS layout."""
+        h = C.c_void_p()
+        self._check(self.lib.pcv_ingest_begin(self.handle, int(num_points_hint), 1 if has_intensity else 0, C.byref(h)))
+        return Ingest(self, h, has_intensity)
+
     def build_from_ply(self, resolution, filename, with_intensity=False, max_points_per_node=0):
         """build_octree_from_file (generation.rs:272-287) with the decode on the device: the file's vertex records go up as
         they are, a HIP kernel casts x / y / z to f64 and adds the header offset (ply.rs:488-493), the bounding box is
@@ -475,6 +482,72 @@ def level_shortcuts(bbox_min, bbox_max, resolution):
     thr = (C.c_double * (L.MAX_KEY_LEVELS + 2))()
     ml = lib.pcv_level_shortcuts(bmin, bmax, float(resolution), mode, thr)
     return ml, np.array(mode[:], dtype=np.uint32), np.array(thr[:])
+
+
+class Ingest:
+    """One pcv_ingest: batches of `PointsBatch` shape (src/lib.rs:102-107) go to the device as they are — positions (n, 3)
+    f64 AoS like Vec<Point3<f64>>, colour (n, 3) u8, intensity (n,) f32 — and `finish` builds the octree."""
+
+    def __init__(self, ctx, handle, has_intensity):
+        self.ctx, self.lib, self.handle, self.has_intensity = ctx, ctx.lib, handle, bool(has_intensity)
+
+    def append(self, position, color, intensity=None):
+        pos = np.ascontiguousarray(position, dtype=np.float64)
+        if pos.ndim != 2 or pos.shape[1] != 3:
+            raise ValueError("position must be (n, 3): one Point3<f64> per row")
+        n = pos.shape[0]
+        col = np.ascontiguousarray(color, dtype=np.uint8)
+        if col.shape != (n, 3):
+            raise ValueError("color must be (n, 3) u8")
+        inten = None
+        if self.has_intensity:
+            if intensity is None:
+                raise ValueError("the ingest was begun with intensity: every batch must carry it")
+            inten = np.ascontiguousarray(intensity, dtype=np.float32)
+            if inten.shape != (n,):
+                raise ValueError("intensity must be (n,) f32")
+        if self.handle is None:
+            raise ValueError("the ingest is finished")
+        self.ctx._check(self.lib.pcv_ingest_append(self.handle, pos.ctypes.data, col.ctypes.data,
+                                                   None if inten is None else inten.ctypes.data, n))
+
+    @property
+    def num_points(self):
+        return int(self.lib.pcv_ingest_num_points(self.handle)) if self.handle is not None else 0
+
+    def bbox(self):
+        lo, hi = (C.c_double * 3)(), (C.c_double * 3)()
+        self.ctx._check(self.lib.pcv_ingest_bbox(self.handle, lo, hi))
+        return np.array(lo[:]), np.array(hi[:])
+
+    def finish(self, resolution, bounding_box=None, max_points_per_node=0, single_chain=None, stage_times=None):
+        """pcv_ingest_finish: bounding_box None = the box folded during the ingest (find_bounding_box); consumes the ingest."""
+        flags = 0
+        if self.ctx.stage_times if stage_times is None else stage_times:
+            flags |= L.BUILD_STAGE_TIMES
+        if single_chain is True:
+            flags |= L.BUILD_FORCE_SINGLE_CHAIN
+        elif single_chain is False:
+            flags |= L.BUILD_NO_SINGLE_CHAIN
+        if bounding_box is None:
+            pr = self.ctx._params(resolution, None, None, max_points_per_node, flags | L.BUILD_COMPUTE_BBOX)
+        else:
+            pr = self.ctx._params(resolution, bounding_box.min, bounding_box.max, max_points_per_node, flags)
+        h, mine = C.c_void_p(), self.handle
+        self.handle = None  # consumed whatever the call returns
+        self.ctx._check(self.lib.pcv_ingest_finish(mine, C.byref(pr), C.byref(h)))
+        return OctreeResult(self.ctx, h)
+
+    def abort(self):
+        if self.handle is not None:
+            self.lib.pcv_ingest_abort(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.abort()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
 
 
 class PendingBuild:
@@ -839,7 +912,10 @@ def default_context():
 def build_octree(output_directory, resolution, bounding_box, points, attributes=("color",), ctx=None,
                  max_points_per_node=0):
     """Drop-in for reference `build_octree` (generation.rs:289-295): builds on the GPU and writes the
-    reference's directory layout. `points` = dict(x=, y=, z=, color=, intensity=optional)."""
+    reference's directory layout. `points` = dict(x=, y=, z=, color=, intensity=optional) — or, like the reference, an
+    ITERATOR OF BATCHES, each dict(position=(n, 3) f64, color=(n, 3) u8[, intensity=(n,) f32]) (PointsBatch,
+    src/lib.rs:102-107): the batches are streamed to the device one at a time (pcv_ingest_*), host memory stays O(batch).
+    An iterator with `num_points` (NumberOfPoints, src/lib.rs:56-58) sizes the device arrays up front."""
     attributes = tuple(attributes)
     if "color" not in attributes:
         raise ValueError("the octree format requires the 'color' attribute (on_disk.rs:20-22)")
@@ -847,6 +923,21 @@ def build_octree(output_directory, resolution, bounding_box, points, attributes=
         if a not in ("color", "intensity"):
             raise ValueError(f"unsupported attribute {a!r} (octree/mod.rs:62-74 implies color and intensity)")
     ctx = ctx or default_context()
+    if not isinstance(points, dict):
+        want_intensity = "intensity" in attributes
+        hint = getattr(points, "num_points", 0)
+        ing = ctx.ingest(hint() if callable(hint) else int(hint or 0), want_intensity)
+        try:
+            for batch in points:
+                if want_intensity and batch.get("intensity") is None:
+                    raise ValueError("attribute 'intensity' requested but not present in the input")
+                ing.append(batch["position"], batch["color"], batch.get("intensity") if want_intensity else None)
+        except BaseException:
+            ing.abort()
+            raise
+        tree = ing.finish(resolution, bounding_box, max_points_per_node)
+        tree.write_dir(output_directory)
+        return tree
     inten = points.get("intensity") if "intensity" in attributes else None
     if "intensity" in attributes and inten is None:
         raise ValueError("attribute 'intensity' requested but not present in the input")

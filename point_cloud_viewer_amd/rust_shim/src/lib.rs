@@ -67,12 +67,20 @@ type pcv_ctx = c_void;
 type pcv_octree = c_void;
 #[allow(non_camel_case_types)]
 type pcv_shapes = c_void;
+#[allow(non_camel_case_types)]
+type pcv_ingest = c_void;
 
 extern "C" {
     fn pcv_ctx_create(device: c_int, stream: *mut c_void, out: *mut *mut pcv_ctx) -> c_int;
     fn pcv_ctx_destroy(ctx: *mut pcv_ctx);
     fn pcv_last_error(ctx: *const pcv_ctx) -> *const c_char;
+    #[allow(dead_code)]
     fn pcv_build_octree(ctx: *mut pcv_ctx, params: *const PcvBuildParams, points: *const PcvPoints, out: *mut *mut pcv_octree) -> c_int;
+    // streaming batch ingest: `impl Iterator<Item = PointsBatch>` of generation.rs:289-295, one batch per call
+    fn pcv_ingest_begin(ctx: *mut pcv_ctx, num_points_hint: u64, has_intensity: c_int, out: *mut *mut pcv_ingest) -> c_int;
+    fn pcv_ingest_append(ingest: *mut pcv_ingest, xyz: *const c_double, rgb: *const u8, intensity: *const c_float, n: u64) -> c_int;
+    fn pcv_ingest_finish(ingest: *mut pcv_ingest, params: *const PcvBuildParams, out: *mut *mut pcv_octree) -> c_int;
+    fn pcv_ingest_abort(ingest: *mut pcv_ingest);
     fn pcv_build_octree_from_ply(ctx: *mut pcv_ctx, params: *const PcvBuildParams, path: *const c_char, with_intensity: c_int, out: *mut *mut pcv_octree) -> c_int;
     fn pcv_octree_write_dir(t: *mut pcv_octree, directory: *const c_char) -> c_int;
     fn pcv_octree_open_dir(ctx: *mut pcv_ctx, directory: *const c_char, out: *mut *mut pcv_octree) -> c_int;
@@ -121,9 +129,12 @@ thread_local! {
     static CONTEXT: HipContext = HipContext::new(0).expect("no MI355X visible (there is no CPU fallback)");
 }
 
-/// Same signature and behaviour as `point_viewer::octree::build_octree` (generation.rs:289-295): drains the batch
-/// iterator into SoA staging (one pass, no per-level files), builds on the GPU, writes the directory. The library
-/// stages the (pageable) SoA arrays through its ring of pinned chunks, one DMA per 32 MiB.
+/// Same signature and behaviour as `point_viewer::octree::build_octree` (generation.rs:289-295). The batches go to the
+/// device ONE AT A TIME and AS THEY ARE (pcv_ingest_append): `batch.position` is a `Vec<Point3<f64>>` — `Point3<f64>` is
+/// `#[repr(C)]` over `[f64; 3]`, so the vector is n x 3 contiguous doubles — "color" a `Vec<Vector3<u8>>` (n x 3 bytes),
+/// "intensity" a `Vec<f32>`. The library copies the three slices into its pinned ring, queues one DMA and one kernel that
+/// transposes AoS -> SoA on the device, and returns; the iterator produces its next batch meanwhile. No whole-cloud host
+/// vector exists at any time (host memory: the ring, 3 x 32 MiB), nothing is transposed on the host.
 pub fn build_octree(
     output_directory: impl AsRef<Path>,
     resolution: f64,
@@ -131,51 +142,42 @@ pub fn build_octree(
     input: impl Iterator<Item = PointsBatch> + NumberOfPoints + Send,
     attributes: &[&str],
 ) {
-    let n = input.num_points();
-    let (mut x, mut y, mut z) = (Vec::with_capacity(n), Vec::with_capacity(n), Vec::with_capacity(n));
-    let mut rgb: Vec<u8> = Vec::with_capacity(3 * n);
-    let mut intensity: Vec<f32> = Vec::new();
     let want_intensity = attributes.contains(&"intensity");
-    for batch in input {
-        // AoS Point3<f64> -> SoA, one pass per batch over contiguous memory (reserved above: no reallocation)
-        x.extend(batch.position.iter().map(|p| p.x));
-        y.extend(batch.position.iter().map(|p| p.y));
-        z.extend(batch.position.iter().map(|p| p.z));
-        match batch.attributes.get("color") {
-            // Vector3<u8> is three contiguous bytes: the whole batch is one memcpy
-            Some(AttributeData::U8Vec3(c)) => rgb.extend_from_slice(unsafe { std::slice::from_raw_parts(c.as_ptr() as *const u8, 3 * c.len()) }),
-            _ => panic!("color attribute (U8Vec3) is required"),
-        }
-        if want_intensity {
-            match batch.attributes.get("intensity") {
-                Some(AttributeData::F32(i)) => intensity.extend_from_slice(i),
-                _ => panic!("intensity requested but missing"), // generation.rs:167-177 unwrap()
-            }
-        }
-    }
     CONTEXT.with(|ctx| {
-    let params = PcvBuildParams {
-        resolution,
-        bbox_min: [bounding_box.min().x, bounding_box.min().y, bounding_box.min().z],
-        bbox_max: [bounding_box.max().x, bounding_box.max().y, bounding_box.max().z],
-        max_points_per_node: 0,
-        flags: 0,
-    };
-    let points = PcvPoints {
-        n: x.len() as u64,
-        x: x.as_ptr(),
-        y: y.as_ptr(),
-        z: z.as_ptr(),
-        color: rgb.as_ptr(),
-        color_stride: 3,
-        intensity: if want_intensity { intensity.as_ptr() } else { std::ptr::null() },
-        mem: 0,
-    };
-    let mut tree = std::ptr::null_mut();
-    ctx.check(unsafe { pcv_build_octree(ctx.0, &params, &points, &mut tree) });
-    let dir = CString::new(output_directory.as_ref().to_str().unwrap()).unwrap();
-    ctx.check(unsafe { pcv_octree_write_dir(tree, dir.as_ptr()) });
-    unsafe { pcv_octree_free(tree) };
+        let mut ingest = std::ptr::null_mut();
+        ctx.check(unsafe { pcv_ingest_begin(ctx.0, input.num_points() as u64, want_intensity as c_int, &mut ingest) });
+        for batch in input {
+            let color = match batch.attributes.get("color") {
+                Some(AttributeData::U8Vec3(c)) => c.as_ptr() as *const u8,
+                _ => panic!("color attribute (U8Vec3) is required"), // on_disk.rs:20-22
+            };
+            let intensity = if want_intensity {
+                match batch.attributes.get("intensity") {
+                    Some(AttributeData::F32(i)) => i.as_ptr(),
+                    _ => panic!("intensity requested but missing"), // generation.rs:167-177 unwrap()
+                }
+            } else {
+                std::ptr::null()
+            };
+            let rc = unsafe { pcv_ingest_append(ingest, batch.position.as_ptr() as *const c_double, color, intensity, batch.position.len() as u64) };
+            if rc != 0 {
+                unsafe { pcv_ingest_abort(ingest) };
+                ctx.check(rc);
+            }
+            // `batch` is dropped here: the library has copied it into pinned memory before returning
+        }
+        let params = PcvBuildParams {
+            resolution,
+            bbox_min: [bounding_box.min().x, bounding_box.min().y, bounding_box.min().z],
+            bbox_max: [bounding_box.max().x, bounding_box.max().y, bounding_box.max().z],
+            max_points_per_node: 0,
+            flags: 0,
+        };
+        let mut tree = std::ptr::null_mut();
+        ctx.check(unsafe { pcv_ingest_finish(ingest, &params, &mut tree) }); // consumes the ingest whatever it returns
+        let dir = CString::new(output_directory.as_ref().to_str().unwrap()).unwrap();
+        ctx.check(unsafe { pcv_octree_write_dir(tree, dir.as_ptr()) });
+        unsafe { pcv_octree_free(tree) };
     });
 }
 
