@@ -344,6 +344,10 @@ int pcv_route_buckets(pcv_ctx* ctx, const pcv_build_params* params, const pcv_po
  *                      straight to the point's place in its owner's buffer: row k (in input order) of the rows owned by rank
  *                      r goes to row k of dst[r]'s planes. Replaces ChildIndex::from_bounding_cube (node.rs:34-42) + the
  *                      first encode step (codec.rs:102-121) of generation.rs:78-99 for the multi-GPU exchange. */
+/* pcv_route_plan, params->flags: ownership goes by ROOT OCTANT (BASELINE north_star: shard by the top-3-bit prefix) — the
+ * bucket of a point is its level-1 digit alone (bucket = d1 << 3, the counts of the other buckets are 0): three comparisons
+ * against the root cube's centre per point (node.rs:34-42) instead of a level step of the chain. pcv_route_scatter is the same. */
+#define PCV_ROUTE_OCTANTS_ONLY 64u
 typedef struct pcv_route_dst {
   uint32_t* oct_rgb;
   uint32_t* cx;
@@ -495,7 +499,10 @@ int pcv_cull_nodes(pcv_ctx* ctx, const pcv_shapes* shapes, pcv_octree* tree, uin
  * node_indices / relation / size_on_screen are [shape][capacity] host arrays, counts[shape] the number of such nodes
  * (entries past `capacity` are dropped, the count is not). size_on_screen (nullable) is relative_size_on_screen
  * (octree/mod.rs:119-139), computed for the listed nodes only — the nodes the reference projects (octree/mod.rs:261-272).
- * The same Relations as pcv_cull_nodes without its shapes x nodes matrix (config 4: 60.7 M pairs, 0.24 % not Out). */
+ * The same Relations as pcv_cull_nodes without its shapes x nodes matrix (config 4: 60.7 M pairs, 0.24 % not Out).
+ * Round 6: found by a walk down the tree, like the reference's own traversals (octree_iterator.rs:30-43) — a subtree is
+ * skipped only under a node that is Out by a margin far above the rounding error of its descendants' bounds, and any shape
+ * that meets an Out node without that margin is evaluated flat: the lists equal pcv_cull_nodes' rows in every case. */
 int pcv_cull_nodes_sparse(pcv_ctx* ctx, const pcv_shapes* shapes, pcv_octree* tree, uint32_t capacity, uint32_t* counts,
                           uint32_t* node_indices, uint8_t* relation, double* size_on_screen);
 

@@ -22,6 +22,7 @@ BUILD_FORCE_SINGLE_CHAIN = 4
 BUILD_NO_SINGLE_CHAIN = 8
 BUILD_CHECK_RESOLVE = 16
 BUILD_STAGE_TIMES = 32
+ROUTE_OCTANTS_ONLY = 64
 MAX_KEY_LEVELS = 21
 NUM_STAGES = 10
 STAGE_NAMES = ["aabb", "chain_keys", "sort_keys", "node_split", "table", "leaf_encode", "sort_records",

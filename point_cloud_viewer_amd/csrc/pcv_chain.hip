@@ -387,7 +387,8 @@ constexpr int kRouteTile = kPartTile;  // 4 096 points: 256 lanes x 16 rows, wav
 __global__ __launch_bounds__(256) void route_plan_kernel(PcvLevels lv, uint64_t n, const double* __restrict__ x,
                                                           const double* __restrict__ y, const double* __restrict__ z,
                                                           uint8_t* __restrict__ bucket, uint16_t* __restrict__ tile_hist /* [tiles][64] */,
-                                                          unsigned long long* __restrict__ counts /* [64] */) {
+                                                          unsigned long long* __restrict__ counts /* [64] */,
+                                                          bool octants_only /* PCV_ROUTE_OCTANTS_ONLY: bucket = d1 << 3 */) {
   __shared__ uint32_t hist[64];
   if (threadIdx.x < 64) hist[threadIdx.x] = 0;
   __syncthreads();
@@ -405,7 +406,11 @@ __global__ __launch_bounds__(256) void route_plan_kernel(PcvLevels lv, uint64_t 
       double mx = lv.root_min[0], my = lv.root_min[1], mz = lv.root_min[2];
       double cx, cy, cz;
       uint32_t b = 0;
-      if (fast && pcv_point_is_tame(px, py, pz)) {
+      if (octants_only) {
+        // round 6: ownership by root octant (BASELINE north_star: the top-3-bit prefix) needs the level-1 digit alone — three
+        // comparisons against the root cube's centre (node.rs:34-42), for any input: the pass is a plain stream of the coordinates
+        b = pcv_chain_bits(lv.edge[0], px, py, pz, mx, my, mz).digit() << 3;
+      } else if (fast && pcv_point_is_tame(px, py, pz)) {
         const PcvOctBits b1 = pcv_chain_bits(lv.edge[0], px, py, pz, mx, my, mz);
         pcv_chain_apply_bits_t<PCV_ENC_FLOAT32, false>(b1, lv.edge[1], PcvRecip{lv.inv_edge[1], lv.inv_edge_lo[1]}, px, py, pz, mx, my, mz, cx, cy, cz);
         PcvOctBits b2 = pcv_bits_from_codes(0.5, cx, cy, cz);
@@ -415,7 +420,7 @@ __global__ __launch_bounds__(256) void route_plan_kernel(PcvLevels lv, uint64_t 
       for (int l = 1; l <= lv.nlevels; ++l)  // nlevels <= 2 here; the guarded (exact for any input) variant
         b = (b << 3) | pcv_chain_level<true>(lv.enc[l], lv.edge[l - 1], lv.edge[l], PcvRecip{lv.inv_edge[l], lv.inv_edge_lo[l]}, px, py, pz, mx, my, mz, cx, cy, cz);
       }
-      if (lv.nlevels < 2) b <<= 3;
+      if (lv.nlevels < 2 && !octants_only) b <<= 3;
       bucket[i] = (uint8_t)b;
       atomicAdd(&hist[b], 1u);
     }
@@ -423,6 +428,59 @@ __global__ __launch_bounds__(256) void route_plan_kernel(PcvLevels lv, uint64_t 
   __syncthreads();
   if (threadIdx.x < 64) {
     const uint32_t v = hist[threadIdx.x];
+    tile_hist[(uint64_t)blockIdx.x * 64 + threadIdx.x] = (uint16_t)v;  // <= 4 096
+    if (v) atomicAdd(&counts[threadIdx.x], (unsigned long long)v);
+  }
+}
+
+// pass 1 when ownership goes by root octant (PCV_ROUTE_OCTANTS_ONLY, round 6): the level-1 digit alone — three comparisons against
+// the root cube's centre (node.rs:34-42), exact for any input — so the pass is a plain stream: every lane takes 4 x 4 consecutive
+// points (16-byte loads, one dword of bucket bytes per store), the tile's 8 counts are wave ballots (the shared histogram's
+// LDS atomics would all land on 8 addresses: 0.62 ms measured for the pass that way, the cost of the full level step).
+__global__ __launch_bounds__(256) void route_octants_kernel(PcvLevels lv, uint64_t n, const double* __restrict__ x,
+                                                             const double* __restrict__ y, const double* __restrict__ z,
+                                                             uint8_t* __restrict__ bucket, uint16_t* __restrict__ tile_hist /* [tiles][64] */,
+                                                             unsigned long long* __restrict__ counts /* [64] */) {
+  __shared__ uint32_t wave_cnt[4][8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const double e0 = lv.edge[0];
+  const double mx = lv.root_min[0], my = lv.root_min[1], mz = lv.root_min[2];
+  const double cx = (mx + (mx + e0)) / 2.0, cy = (my + (my + e0)) / 2.0, cz = (mz + (mz + e0)) / 2.0;  // pcv_chain_bits' centre
+  uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // wave-uniform
+  const uint64_t tile0 = (uint64_t)blockIdx.x * kRouteTile;
+#pragma unroll
+  for (int k = 0; k < kRouteTile / 1024; ++k) {
+    const uint64_t i = tile0 + (uint64_t)k * 1024 + (uint64_t)threadIdx.x * 4;
+    uint32_t d[4] = {0xffu, 0xffu, 0xffu, 0xffu};
+    if (i + 4 <= n) {  // (the arrays come from the pool or are checked for 16-byte alignment by the caller)
+      const double2 xa = *reinterpret_cast<const double2*>(x + i), xb = *reinterpret_cast<const double2*>(x + i + 2);
+      const double2 ya = *reinterpret_cast<const double2*>(y + i), yb = *reinterpret_cast<const double2*>(y + i + 2);
+      const double2 za = *reinterpret_cast<const double2*>(z + i), zb = *reinterpret_cast<const double2*>(z + i + 2);
+      d[0] = (xa.x > cx ? 4u : 0u) | (ya.x > cy ? 2u : 0u) | (za.x > cz ? 1u : 0u);
+      d[1] = (xa.y > cx ? 4u : 0u) | (ya.y > cy ? 2u : 0u) | (za.y > cz ? 1u : 0u);
+      d[2] = (xb.x > cx ? 4u : 0u) | (yb.x > cy ? 2u : 0u) | (zb.x > cz ? 1u : 0u);
+      d[3] = (xb.y > cx ? 4u : 0u) | (yb.y > cy ? 2u : 0u) | (zb.y > cz ? 1u : 0u);
+      *reinterpret_cast<uint32_t*>(bucket + i) = (d[0] << 3) | (d[1] << 11) | (d[2] << 19) | (d[3] << 27);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (i + j < n) {
+          d[j] = (x[i + j] > cx ? 4u : 0u) | (y[i + j] > cy ? 2u : 0u) | (z[i + j] > cz ? 1u : 0u);
+          bucket[i + j] = (uint8_t)(d[j] << 3);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (uint32_t o = 0; o < 8; ++o) cnt[o] += (uint32_t)__popcll(__ballot(d[j] == o));
+  }
+  if (lane == 0)
+#pragma unroll
+    for (int o = 0; o < 8; ++o) wave_cnt[wave][o] = cnt[o];
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const uint32_t o = threadIdx.x >> 3;
+    const uint32_t v = (threadIdx.x & 7u) == 0u ? wave_cnt[0][o] + wave_cnt[1][o] + wave_cnt[2][o] + wave_cnt[3][o] : 0u;
     tile_hist[(uint64_t)blockIdx.x * 64 + threadIdx.x] = (uint16_t)v;  // <= 4 096
     if (v) atomicAdd(&counts[threadIdx.x], (unsigned long long)v);
   }
@@ -724,8 +782,15 @@ extern "C" int pcv_route_plan(pcv_ctx* ctx, const pcv_build_params* params, cons
   PCV_HIP_CHECK(ctx, hipMemsetAsync(d_counts, 0, 64 * 8, ctx->stream));
   {
     PcvProf prof(ctx, PCV_K_ROUTE_BUCKET);
-    hipLaunchKernelGGL(route_plan_kernel, dim3((unsigned)pcv_route_tiles(points->n)), dim3(256), 0, ctx->stream, lv, points->n, points->x,
-                       points->y, points->z, bucket, tile_hist, d_counts);
+    const bool octants_only = (params->flags & PCV_ROUTE_OCTANTS_ONLY) != 0u && lv.nlevels >= 1;
+    // the streaming form wants 16-byte loads and dword stores: aligned bases (pool blocks and torch tensors are; views may not be)
+    const bool aligned = ((((uintptr_t)points->x | (uintptr_t)points->y | (uintptr_t)points->z) & 15) | ((uintptr_t)bucket & 3)) == 0;
+    if (octants_only && aligned)
+      hipLaunchKernelGGL(route_octants_kernel, dim3((unsigned)pcv_route_tiles(points->n)), dim3(256), 0, ctx->stream, lv, points->n, points->x,
+                         points->y, points->z, bucket, tile_hist, d_counts);
+    else
+      hipLaunchKernelGGL(route_plan_kernel, dim3((unsigned)pcv_route_tiles(points->n)), dim3(256), 0, ctx->stream, lv, points->n, points->x,
+                         points->y, points->z, bucket, tile_hist, d_counts, octants_only);
   }
   PCV_HIP_CHECK(ctx, hipGetLastError());
   PCV_HIP_CHECK(ctx, hipMemcpyAsync(ctx->mailbox, d_counts, 64 * 8, hipMemcpyDeviceToHost, ctx->stream));

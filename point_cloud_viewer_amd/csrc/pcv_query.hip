@@ -245,6 +245,22 @@ __global__ __launch_bounds__(64) void shape_setup_kernel(PcvShapeDev* shapes, ui
 // products — 6 min/max + 4 adds instead of 16 adds + 16 min/max. Only when a bound comes out non-finite (inf / NaN
 // inputs) are the 8 corners folded literally, in aabb.rs:114-125 order, so that f64::min / max skip NaNs as they do
 // in the reference.
+// the interval of the cube [l, h]^3 on one axis (see sat_cube): its three least / greatest products, or — non-finite bounds — its
+// eight corners folded literally
+__device__ __forceinline__ void sat_axis_interval(double lx, double hx, double ly, double hy, double lz, double hz, double ax, double ay,
+                                                  double az, double& bmin, double& bmax, double& magnitude) {
+  const double plx = lx * ax, phx = hx * ax, ply = ly * ay, phy = hy * ay, plz = lz * az, phz = hz * az;
+  bmin = (fmin(plx, phx) + fmin(ply, phy)) + fmin(plz, phz);
+  bmax = (fmax(plx, phx) + fmax(ply, phy)) + fmax(plz, phz);
+  magnitude = ((fabs(plx) + fabs(phx)) + (fabs(ply) + fabs(phy))) + (fabs(plz) + fabs(phz));
+  if (!(fabs(bmin) <= 1.7976931348623157e308 && fabs(bmax) <= 1.7976931348623157e308)) {
+    // corners in aabb.rs:114-125 order: (l,l,l) (h,l,l) (l,h,l) (h,h,l) (l,l,h) (h,l,h) (l,h,h) (h,h,h)
+    double c0 = (plx + ply) + plz, c1 = (phx + ply) + plz, c2 = (plx + phy) + plz, c3 = (phx + phy) + plz;
+    double c4 = (plx + ply) + phz, c5 = (phx + ply) + phz, c6 = (plx + phy) + phz, c7 = (phx + phy) + phz;
+    bmin = fmin(fmin(fmin(fmin(fmin(fmin(fmin(fmin(1.7976931348623157e308, c0), c1), c2), c3), c4), c5), c6), c7);
+    bmax = fmax(fmax(fmax(fmax(fmax(fmax(fmax(fmax(-1.7976931348623157e308, c0), c1), c2), c3), c4), c5), c6), c7);
+  }
+}
 __device__ __forceinline__ int sat_cube(const PcvShapeDev* __restrict__ s, double mnx, double mny, double mnz, double edge) {
   if (s->kind == PCV_SHAPE_ALL) return 1;  // AllPoints intersects everything (math/mod.rs:139-160) -> "not Out"
   // Cube::to_aabb: Aabb::new(min, min + edge) (inf / sup)
@@ -255,17 +271,8 @@ __device__ __forceinline__ int sat_cube(const PcvShapeDev* __restrict__ s, doubl
   bool cross = false;
   const int na = s->naxes;
   for (int a = 0; a < na; ++a) {
-    const double ax = s->axes[3 * a], ay = s->axes[3 * a + 1], az = s->axes[3 * a + 2];
-    const double plx = lx * ax, phx = hx * ax, ply = ly * ay, phy = hy * ay, plz = lz * az, phz = hz * az;
-    double bmin = (fmin(plx, phx) + fmin(ply, phy)) + fmin(plz, phz);
-    double bmax = (fmax(plx, phx) + fmax(ply, phy)) + fmax(plz, phz);
-    if (!(fabs(bmin) <= 1.7976931348623157e308 && fabs(bmax) <= 1.7976931348623157e308)) {
-      // corners in aabb.rs:114-125 order: (l,l,l) (h,l,l) (l,h,l) (h,h,l) (l,l,h) (h,l,h) (l,h,h) (h,h,h)
-      double c0 = (plx + ply) + plz, c1 = (phx + ply) + plz, c2 = (plx + phy) + plz, c3 = (phx + phy) + plz;
-      double c4 = (plx + ply) + phz, c5 = (phx + ply) + phz, c6 = (plx + phy) + phz, c7 = (phx + phy) + phz;
-      bmin = fmin(fmin(fmin(fmin(fmin(fmin(fmin(fmin(1.7976931348623157e308, c0), c1), c2), c3), c4), c5), c6), c7);
-      bmax = fmax(fmax(fmax(fmax(fmax(fmax(fmax(fmax(-1.7976931348623157e308, c0), c1), c2), c3), c4), c5), c6), c7);
-    }
+    double bmin, bmax, mag;
+    sat_axis_interval(lx, hx, ly, hy, lz, hz, s->axes[3 * a], s->axes[3 * a + 1], s->axes[3 * a + 2], bmin, bmax, mag);
     const double amin = s->amin[a], amax = s->amax[a];
     if (bmin > amax || bmax < amin) return 2;
     cross = cross || (amin > bmin || bmax > amax);
@@ -323,8 +330,10 @@ __global__ __launch_bounds__(256) void cull_nodes_kernel(const PcvShapeDev* __re
 __global__ __launch_bounds__(256) void cull_nodes_sparse_kernel(const PcvShapeDev* __restrict__ shapes, uint32_t m,
                                                                  const double* __restrict__ cubes /* m x 4 */, uint32_t capacity,
                                                                  uint32_t* __restrict__ counts, uint32_t* __restrict__ out_node,
-                                                                 uint8_t* __restrict__ out_rel, double* __restrict__ out_size) {
+                                                                 uint8_t* __restrict__ out_rel, double* __restrict__ out_size,
+                                                                 const uint32_t* __restrict__ redo /* set: only the flagged shapes */) {
   __shared__ uint32_t wave_tot[4];
+  if (redo && !redo[blockIdx.x]) return;  // (uniform) the tree walk finished this shape
   const PcvShapeDev* s = shapes + blockIdx.x;
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t row = (uint64_t)blockIdx.x * capacity;
@@ -361,6 +370,202 @@ __global__ __launch_bounds__(256) void cull_nodes_sparse_kernel(const PcvShapeDe
     __syncthreads();  // wave_tot is rewritten by the next tile
   }
   if (threadIdx.x == 0) counts[blockIdx.x] = base;
+}
+
+// K7t (round 6): the same lists, descending the tree like the reference's own traversals do (octree_iterator.rs:30-43,
+// octree/mod.rs:261-272: children are only tested under a parent that is not Out). 99.76 % of the pairs of BASELINE config 4 are
+// Out and nearly all of them sit under an Out ancestor. One WAVE per shape walks the tree breadth first — node order is
+// (level, index), so the breadth-first order of the kept nodes IS the list's order.
+//   * The wave's lanes are the shape's AXES, not the children: lane l holds axis l mod 32 of the shape (<= 26) in registers for
+//     the whole walk, lanes 0-31 test one child of the popped node, lanes 32-63 the next, and three ballots give both Relations
+//     (Out if any axis separates, else Cross if the cube sticks out on any axis, else In: sat.rs:174-194 does not depend on the
+//     order of the axes). A first form with one child per lane and the loop over the axes inside ran 286-370 us for the 10 000
+//     frusta: every round paid all 26 axes for a handful of busy lanes; the flat kernel needed 431.
+//   * The queue (LDS) holds the kept INNER nodes only (87 % of a tree's nodes are leaves: listed, never expanded), each with its
+//     cube, first child and child mask, so a popped node costs no dependent global load: its children's cubes are the recurrence
+//     step NodeId::find_bounding_cube takes (node.rs:160-170: edge /= 2; min += bit * edge) — how the table's own cubes were
+//     made (tests/test_gpu_query.py checks it on the node table) — and the children's own masks are requested (lanes 0-7) before
+//     the tests and used after them.
+//   * relative_size_on_screen of a popped node's kept children: eight lanes per child, one corner each (size_on_screen_by_corner).
+// A subtree is skipped only under a node that is Out BY A MARGIN: some axis separates it by more than 1e-9 of the magnitudes
+// involved — ~10^6 times the rounding error of any cube inside this one (a descendant's bounds lie within a few ulps of its
+// ancestor's: min += bit * edge only adds, max = min + edge) — so every descendant is Out for the flat evaluation too. A shape
+// that meets an Out node without that margin (a face within an ulp of a cube face, non-finite bounds), whose frontier outgrows
+// the queue, or that is AllPoints, is flagged and redone by the flat kernel (cull_nodes_sparse_kernel with `redo`): the lists
+// are the flat kernel's in every case.
+__device__ __forceinline__ double size_on_screen_by_corner(const double* __restrict__ m, double mnx, double mny, double mnz, double edge,
+                                                           uint32_t corner) {
+  // lanes 8 g .. 8 g + 7 take the eight corners of cube g (size_on_screen's order), each its own projection and its two divisions;
+  // the corners' clamped x / y are folded with min / max across the eight lanes (a min / max over a set: the order of the fold only
+  // decides the sign of a zero)
+  const double px = ((0x56u >> corner) & 1u) ? mnx + edge : mnx, py = ((0x9au >> corner) & 1u) ? mny + edge : mny,
+               pz = ((0xe2u >> corner) & 1u) ? mnz + edge : mnz;
+  double v[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = ((M4(m, r, 0) * px + M4(m, r, 1) * py) + M4(m, r, 2) * pz) + M4(m, r, 3) * 1.0;
+  bool bad = v[3] == 0.0;
+  double lox = clamp_num(v[0] / v[3], -1., 1.), loy = clamp_num(v[1] / v[3], -1., 1.);
+  double hix = lox, hiy = loy;
+#pragma unroll
+  for (int o = 1; o < 8; o <<= 1) {
+    lox = fmin(lox, __shfl_xor(lox, o, 64));
+    hix = fmax(hix, __shfl_xor(hix, o, 64));
+    loy = fmin(loy, __shfl_xor(loy, o, 64));
+    hiy = fmax(hiy, __shfl_xor(hiy, o, 64));
+    bad = bad || (__shfl_xor((int)bad, o, 64) != 0);
+  }
+  if (bad) return __longlong_as_double(0x7ff8000000000000LL);
+  return (hix - lox) * (hiy - loy);
+}
+struct CullEntry {
+  double mnx, mny, mnz, edge;
+  uint32_t first_child, mask;
+};
+constexpr uint32_t kCullQueue = 128;  // kept inner nodes waiting for their children to be tested, per wave (5 KiB: LDS does not bound the occupancy)
+// this lane's axis against the cube (mn, mn + edge): does it separate (Out), does the cube stick out (Cross), does it separate by
+// the margin
+struct AxisTest {
+  bool sep, cross, robust;
+};
+__device__ __forceinline__ AxisTest cull_axis_test(bool on, double ax, double ay, double az, double amin, double amax, double mnx,
+                                                   double mny, double mnz, double edge) {
+  const double ax_ = mnx + edge, ay_ = mny + edge, az_ = mnz + edge;  // Cube::to_aabb, as sat_cube
+  const double lx = fmin(mnx, ax_), hx = fmax(mnx, ax_), ly = fmin(mny, ay_), hy = fmax(mny, ay_), lz = fmin(mnz, az_), hz = fmax(mnz, az_);
+  double bmin, bmax, mag;
+  sat_axis_interval(lx, hx, ly, hy, lz, hz, ax, ay, az, bmin, bmax, mag);
+  AxisTest t;
+  t.sep = on && (bmin > amax || bmax < amin);
+  t.cross = on && (amin > bmin || bmax > amax);
+  const double scale = mag + (fabs(amin) + fabs(amax));
+  t.robust = on && fmax(bmin - amax, amin - bmax) > 1e-9 * scale && scale <= 1.7976931348623157e308;  // (NaN / inf anywhere: no)
+  return t;
+}
+template <bool SIZES>
+__global__ __launch_bounds__(256) void cull_nodes_tree_kernel(const PcvShapeDev* __restrict__ shapes, uint32_t nshapes, uint32_t m,
+                                                               const double* __restrict__ cubes /* m x 4, find_bounding_cube */,
+                                                               const uint32_t* __restrict__ first_child, const uint8_t* __restrict__ child_mask,
+                                                               uint32_t capacity, uint32_t* __restrict__ counts, uint32_t* __restrict__ out_node,
+                                                               uint8_t* __restrict__ out_rel, double* __restrict__ out_size,
+                                                               uint32_t* __restrict__ redo) {
+  __shared__ CullEntry queue[4][kCullQueue];
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const uint32_t f = blockIdx.x * 4 + wave;
+  if (f >= nshapes) return;  // wave-uniform
+  const PcvShapeDev* s = shapes + f;
+  const uint64_t row = (uint64_t)f * capacity;
+  CullEntry* q = queue[wave];
+  uint32_t head = 0, tail = 0;  // queue of kept inner nodes
+  uint32_t nout = 0;            // listed nodes
+  const int na = s->naxes;
+  bool again = s->kind == PCV_SHAPE_ALL;  // (every node: the flat kernel lists them as fast)
+  // this lane's axis, for the whole walk
+  const uint32_t axis = lane & 31u;
+  const bool on = (int)axis < na;
+  double ax = 0, ay = 0, az = 0, amin = 0, amax = 0;
+  if (on) {
+    ax = s->axes[3 * axis], ay = s->axes[3 * axis + 1], az = s->axes[3 * axis + 2];
+    amin = s->amin[axis], amax = s->amax[axis];
+  }
+  if (s->valid && !again) {
+    {  // the root (both halves of the wave test it: the lower one's ballot bits are read)
+      const double4 c = *reinterpret_cast<const double4*>(cubes);
+      const AxisTest t = cull_axis_test(on, ax, ay, az, amin, amax, c.x, c.y, c.z, c.w);
+      const uint32_t sep = (uint32_t)__ballot(t.sep), cross = (uint32_t)__ballot(t.cross), rob = (uint32_t)__ballot(t.robust);
+      if (sep == 0u) {
+        const uint32_t cm = child_mask[0];
+        if (lane == 0) {
+          if (capacity) {  // (entries past `capacity` are dropped, the count is not: capacity 0 only counts)
+            out_node[row] = 0;
+            out_rel[row] = (uint8_t)(cross ? 1 : 0);
+            if (SIZES) out_size[row] = size_on_screen(s->clip_from_query, c.x, c.y, c.z, c.w);
+          }
+          q[0] = CullEntry{c.x, c.y, c.z, c.w, first_child[0], cm};
+        }
+        nout = 1;
+        tail = cm ? 1u : 0u;
+      } else {
+        again = rob == 0u;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    while (head < tail && !again) {
+      const CullEntry e = q[head & (kCullQueue - 1u)];  // (one address: a broadcast)
+      const uint32_t pmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.mask);
+      const uint32_t pfirst = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.first_child);
+      // the children's own masks / first children: requested now (lanes 0-7), used after the tests
+      uint32_t cm = 0, cf = 0;
+      const uint32_t mychild = pfirst + (uint32_t)__popc(pmask & ((1u << (lane & 7u)) - 1u));
+      if (lane < 8u && ((pmask >> lane) & 1u)) {
+        cm = child_mask[mychild];
+        cf = first_child[mychild];
+      }
+      const double half = e.edge / 2.0;  // node.rs:160-170
+      uint32_t kept_mask = 0, cross_mask = 0;  // per digit (wave-uniform)
+      for (uint32_t rest = pmask; rest != 0u && !again;) {
+        const uint32_t d0 = (uint32_t)__builtin_ctz(rest);
+        rest &= rest - 1u;
+        const uint32_t d1 = rest ? (uint32_t)__builtin_ctz(rest) : 8u;
+        rest &= rest - 1u;  // (0 & anything stays 0)
+        const uint32_t digit = lane < 32u ? d0 : d1;
+        const bool lane_on = on && digit < 8u;
+        const double cx = e.mnx + ((digit & 4u) ? half : 0.0), cy = e.mny + ((digit & 2u) ? half : 0.0), cz = e.mnz + ((digit & 1u) ? half : 0.0);
+        const AxisTest t = cull_axis_test(lane_on, ax, ay, az, amin, amax, cx, cy, cz, half);
+        const uint64_t sep = __ballot(t.sep), cross = __ballot(t.cross), rob = __ballot(t.robust);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const uint32_t d = h ? d1 : d0;
+          if (d >= 8u) continue;
+          const uint32_t sp = (uint32_t)(sep >> (32 * h)), cr = (uint32_t)(cross >> (32 * h)), rb = (uint32_t)(rob >> (32 * h));
+          if (sp == 0u) {
+            kept_mask |= 1u << d;
+            if (cr) cross_mask |= 1u << d;
+          } else if (rb == 0u) {
+            again = true;  // Out without the margin: its subtree cannot be skipped
+          }
+        }
+      }
+      const uint32_t kept = (uint32_t)__popc(kept_mask);
+      if (again) break;
+      const bool mine = lane < 8u && ((kept_mask >> lane) & 1u);
+      const uint32_t k = (uint32_t)__popc(kept_mask & ((1u << (lane & 7u)) - 1u));
+      if (mine && nout + k < capacity) {  // (entries past `capacity` are dropped, the count is not)
+        out_node[row + nout + k] = mychild;
+        out_rel[row + nout + k] = (uint8_t)((cross_mask >> lane) & 1u);
+      }
+      if (SIZES && kept && nout < capacity) {  // lanes 8 g .. 8 g + 7: the eight corners of the g-th kept child
+        const uint32_t g = lane >> 3;
+        uint32_t mk = kept_mask;
+        for (uint32_t i = 0; i < g && mk; ++i) mk &= mk - 1u;  // drop the g lowest set bits
+        const uint32_t d = mk ? (uint32_t)__builtin_ctz(mk) : (uint32_t)__builtin_ctz(kept_mask);  // (idle groups redo the first: no divergence)
+        const double cx = e.mnx + ((d & 4u) ? half : 0.0), cy = e.mny + ((d & 2u) ? half : 0.0), cz = e.mnz + ((d & 1u) ? half : 0.0);
+        const double sz = size_on_screen_by_corner(s->clip_from_query, cx, cy, cz, half, lane & 7u);
+        if (g < kept && nout + g < capacity && (lane & 7u) == 0u) out_size[row + nout + g] = sz;
+      }
+      const bool inner = mine && cm != 0u;
+      const uint32_t inner_mask = (uint32_t)__ballot(inner);
+      const uint32_t pushed = (uint32_t)__popc(inner_mask);
+      if (tail + pushed - (head + 1u) > kCullQueue) {  // a frontier wider than the queue: the flat kernel
+        again = true;
+        break;
+      }
+      if (inner) {
+        const double cx = e.mnx + ((lane & 4u) ? half : 0.0), cy = e.mny + ((lane & 2u) ? half : 0.0), cz = e.mnz + ((lane & 1u) ? half : 0.0);
+        q[(tail + (uint32_t)__popc(inner_mask & ((1u << lane) - 1u))) & (kCullQueue - 1u)] = CullEntry{cx, cy, cz, half, cf, cm};
+      }
+      nout += kept;
+      tail += pushed;
+      head += 1u;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
+  if (lane == 0) {
+    counts[f] = nout;
+    redo[f] = again ? 1u : 0u;
+  }
 }
 
 struct QTree {
@@ -442,6 +647,13 @@ __global__ __launch_bounds__(256) void visible_nodes_kernel(const PcvShapeDev* _
   uint32_t* o = out + (uint64_t)f * capacity;
   uint32_t len = 0, nout = 0;  // lane 0's
   int32_t st = 0;
+  // this lane's axis of the shape, for the whole traversal (lanes 0-31 and 32-63 hold the same axes)
+  const bool on = (int)(lane & 31u) < s->naxes;
+  double ax = 0, ay = 0, az = 0, amin = 0, amax = 0;
+  if (on) {
+    ax = s->axes[3 * (lane & 31u)], ay = s->axes[3 * (lane & 31u) + 1], az = s->axes[3 * (lane & 31u) + 2];
+    amin = s->amin[lane & 31u], amax = s->amax[lane & 31u];
+  }
   if (!s->valid) {  // .expect("Invalid projection matrix.")
     if (lane == 0) {
       counts[f] = 0;
@@ -465,24 +677,56 @@ __global__ __launch_bounds__(256) void visible_nodes_kernel(const PcvShapeDev* _
     }
     node = (uint32_t)__shfl((int)node, 0);
     relation = (uint32_t)__shfl((int)relation, 0);
-    const uint32_t mask = t.child_mask[node];
-    // maybe_push_node on the children that exist: one lane per child
+    const uint32_t mask = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)t.child_mask[node]);
+    // maybe_push_node on the children that exist (round 6: the wave's lanes are the shape's AXES — lanes 0-31 test one child,
+    // lanes 32-63 the next, three ballots give both Relations — and a kept child's size on screen is computed by eight lanes, one
+    // corner each; one lane per child with the 26 axes and the 8 corners in loops left 56 lanes idle for ~3 000 instructions per pop)
     const uint32_t c = t.first_child[node] + (uint32_t)__popc(mask & ((1u << (lane & 7)) - 1u));
-    uint32_t rel = 2;
-    double sz = 0.0;
-    if (lane < 8 && ((mask >> lane) & 1u)) {
-      const double* cb = t.cubes + 4 * (uint64_t)c;
-      rel = 0;
-      if (relation == 1u) rel = (uint32_t)sat_cube(s, cb[0], cb[1], cb[2], cb[3]);
-      if (rel != 2u) sz = size_on_screen(s->clip_from_query, cb[0], cb[1], cb[2], cb[3]);
+    double4 cb = make_double4(0, 0, 0, 0);
+    if (lane < 8 && ((mask >> lane) & 1u)) cb = *reinterpret_cast<const double4*>(t.cubes + 4 * (uint64_t)c);  // Node::get_child cubes
+    uint32_t kept_mask = mask, cross_mask = 0;  // children of an In node are In without a test (octree/mod.rs:261-272)
+    if (relation == 1u && s->kind == PCV_SHAPE_ALL) {
+      cross_mask = mask;  // sat_cube: AllPoints is "not Out" of everything, reported as Cross
+    } else if (relation == 1u) {
+      kept_mask = 0;
+      for (uint32_t rest = mask; rest != 0u;) {
+        const uint32_t d0 = (uint32_t)__builtin_ctz(rest);
+        rest &= rest - 1u;
+        const uint32_t d1 = rest ? (uint32_t)__builtin_ctz(rest) : 8u;
+        rest &= rest - 1u;
+        const uint32_t digit = lane < 32u ? d0 : d1;
+        const int src = (int)(digit & 7u);
+        const double cx = __shfl(cb.x, src), cy = __shfl(cb.y, src), cz = __shfl(cb.z, src), ce = __shfl(cb.w, src);
+        const AxisTest at = cull_axis_test(on && digit < 8u, ax, ay, az, amin, amax, cx, cy, cz, ce);
+        const uint64_t sep = __ballot(at.sep), cross = __ballot(at.cross);
+        if ((uint32_t)sep == 0u) {
+          kept_mask |= 1u << d0;
+          if ((uint32_t)cross) cross_mask |= 1u << d0;
+        }
+        if (d1 < 8u && (uint32_t)(sep >> 32) == 0u) {
+          kept_mask |= 1u << d1;
+          if ((uint32_t)(cross >> 32)) cross_mask |= 1u << d1;
+        }
+      }
     }
+    double sz = 0.0;  // lane 8 g: the size of the g-th kept child
+    if (kept_mask) {
+      const uint32_t g = lane >> 3;
+      uint32_t mk = kept_mask;
+      for (uint32_t i = 0; i < g && mk; ++i) mk &= mk - 1u;
+      const int src = (int)(mk ? __builtin_ctz(mk) : __builtin_ctz(kept_mask));  // (idle groups redo the first: no divergence)
+      const double cx = __shfl(cb.x, src), cy = __shfl(cb.y, src), cz = __shfl(cb.z, src), ce = __shfl(cb.w, src);
+      sz = size_on_screen_by_corner(s->clip_from_query, cx, cy, cz, ce, lane & 7u);
+    }
+    uint32_t g = 0;
     for (int ci = 0; ci < 8; ++ci) {  // pushes in child order, like the reference's loop
-      const uint32_t r = (uint32_t)__shfl((int)rel, ci);
-      const double z = __shfl(sz, ci);
+      if (!((kept_mask >> ci) & 1u)) continue;  // (wave-uniform)
+      const double z = __shfl(sz, (int)(8u * g));
       const uint32_t cc = (uint32_t)__shfl((int)c, ci);
-      if (lane == 0 && r != 2u) {
+      ++g;
+      if (lane == 0) {
         if (z != z) st = 2;
-        d.set(len, HeapEntry{z, cc, r});
+        d.set(len, HeapEntry{z, cc, (cross_mask >> ci) & 1u});
         heap_sift_up(d, 0, len);
         ++len;
       }
@@ -1294,11 +1538,36 @@ extern "C" int pcv_cull_nodes_sparse(pcv_ctx* ctx, const pcv_shapes* shapes, pcv
   double* d_sz = nullptr;
   if ((rc = sc.get(&d_cnt, f)) || (rc = sc.get(&d_node, rows)) || (rc = sc.get(&d_rel, rows))) return rc;
   if (size_on_screen_out && (rc = sc.get(&d_sz, rows))) return rc;
+  uint32_t* d_redo;
+  if ((rc = sc.get(&d_redo, f))) return rc;
+  // PCV_CULL_FLAT=1 (libpcv_hip_exp.so): the flat kernel alone, as round 5 shipped it (the checker of the tree walk's lists)
+  static const bool flat_only = [] {
+    const char* e = pcv_experiment("PCV_CULL_FLAT");
+    return e && atoi(e) != 0;
+  }();
   {
     PcvProf prof(ctx, PCV_K_CULL_NODES_SPARSE);
+    if (!flat_only) {
+      if (d_sz)
+        hipLaunchKernelGGL(cull_nodes_tree_kernel<true>, dim3((f + 3) / 4), dim3(256), 0, ctx->stream, shapes->dev, f, m, tree->query->fb_cubes,
+                           tree->query->first_child, tree->query->child_mask, capacity, d_cnt, d_node, d_rel, d_sz, d_redo);
+      else
+        hipLaunchKernelGGL(cull_nodes_tree_kernel<false>, dim3((f + 3) / 4), dim3(256), 0, ctx->stream, shapes->dev, f, m, tree->query->fb_cubes,
+                           tree->query->first_child, tree->query->child_mask, capacity, d_cnt, d_node, d_rel, d_sz, d_redo);
+    }
     hipLaunchKernelGGL(cull_nodes_sparse_kernel, dim3(f), dim3(256), 0, ctx->stream, shapes->dev, m, tree->query->fb_cubes, capacity, d_cnt,
-                       d_node, d_rel, d_sz);
+                       d_node, d_rel, d_sz, flat_only ? (const uint32_t*)nullptr : (const uint32_t*)d_redo);
   }
+#ifdef PCV_EXPERIMENTS
+  if (!flat_only && pcv_experiment("PCV_CULL_DEBUG")) {  // how many shapes the tree walk handed to the flat kernel
+    std::vector<uint32_t> h(f);
+    PCV_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), d_redo, (size_t)f * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    uint32_t r = 0;
+    for (uint32_t v : h) r += v;
+    fprintf(stderr, "[pcv cull] %u of %u shapes redone by the flat kernel\n", r, f);
+  }
+#endif
   PCV_HIP_CHECK(ctx, hipGetLastError());
   PCV_HIP_CHECK(ctx, hipMemcpyAsync(counts, d_cnt, (size_t)f * 4, hipMemcpyDeviceToHost, ctx->stream));
   if (capacity) {

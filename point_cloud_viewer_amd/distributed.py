@@ -127,9 +127,13 @@ class HipBackend:
         histogram; the state is four 4-byte planes: the Float32 level-1 codes and octant digit | rgb)."""
         return self.ctx.route_buckets(resolution, bbox, x, y, z, rgb, with_state)
 
-    def route_plan(self, resolution, bbox, x, y, z):
-        """Two-pass routing, first pass: (bucket bytes, per-tile bucket histograms, 64 counts) — no state is written."""
-        return self.ctx.route_plan(resolution, bbox, x, y, z)
+    def route_plan(self, resolution, bbox, x, y, z, octants_only=False):
+        """Two-pass routing, first pass: (bucket bytes, per-tile bucket histograms, 64 counts) — no state is written.
+        octants_only (shard mode "octants"): the level-1 digit alone, three comparisons per point. The two work arrays are
+        kept across builds (a steady stream of equally sized slices allocates nothing)."""
+        out = self.ctx.route_plan(resolution, bbox, x, y, z, octants_only, getattr(self, "_plan_buffers", None))
+        self._plan_buffers = out[:2]
+        return out
 
     def route_scatter(self, resolution, bbox, x, y, z, rgb, intensity, bucket, tile_hist, rank_of_bucket, dsts):
         """Second pass: the level-1 state computed again and stored straight into the owners' buffers."""
@@ -271,6 +275,10 @@ class ShardedOctreeBuilder:
         if self.world > 8:
             raise ValueError("the sharded build addresses at most 8 ranks (one node)")
         self.backend = backend or HipBackend(ctx, device)
+        # send / receive planes of the exchange, kept across builds; a build's result views the receive planes only until the
+        # routed build has read them (pcv_build_begin_routed copies nothing, but finish() is synchronous), so the next build
+        # may overwrite them
+        self._exchange_buffers = {}
 
     # -- global bounding box (== find_bounding_box over the whole input, generation.rs:256-270) --
     def global_bbox(self, x, y, z):
@@ -317,11 +325,17 @@ class ShardedOctreeBuilder:
         recv_off = np.concatenate([[0], np.cumsum(recv_counts)]).astype(np.int64)
         names = list(planes)
 
-        def empty_like_rows(p, rows):
-            return torch.empty((rows,) + tuple(p.shape[1:]), dtype=p.dtype, device=p.device)
+        def rows_of(side, k, p, rows):
+            # exchange buffers kept across builds (VERDICT r05 #2c): a view of the builder's block when it is big enough
+            key = (side, k, p.dtype, tuple(p.shape[1:]))
+            have = self._exchange_buffers.get(key)
+            if have is None or int(have.shape[0]) < rows or have.device != p.device:
+                have = torch.empty((max(rows, 1),) + tuple(p.shape[1:]), dtype=p.dtype, device=p.device)
+                self._exchange_buffers[key] = have
+            return have[:rows]
 
-        send = {k: empty_like_rows(planes[k], n_local) for k in names}
-        recv = {k: empty_like_rows(planes[k], n_recv) for k in names}
+        send = {k: rows_of("send", k, planes[k], n_local) for k in names}
+        recv = {k: rows_of("recv", k, planes[k], n_recv) for k in names}
         dsts = []
         for r in range(world):
             buf, off, cnt = (recv, recv_off[rank], send_counts[rank]) if r == rank else (send, send_off[r], send_counts[r])
@@ -370,7 +384,10 @@ class ShardedOctreeBuilder:
         if two_pass:
             # the state never exists in input order: pass 1 leaves bucket bytes + tile histograms, pass 2 (inside _route, once
             # the plan is known) writes every point's state straight into its owner's buffer; `planes` only describes the rows
-            bucket, tile_hist, counts = self.backend.route_plan(resolution, bbox, x, y, z)
+            if self.shard_mode == "octants":  # the owner is a function of the level-1 digit: no level step in the plan
+                bucket, tile_hist, counts = self.backend.route_plan(resolution, bbox, x, y, z, True)
+            else:
+                bucket, tile_hist, counts = self.backend.route_plan(resolution, bbox, x, y, z)
             planes = {k: torch.empty(0, dtype=torch.int32, device=self.device) for k in ("cx", "cy", "cz", "oct_rgb")}
             if intensity is not None:
                 planes["intensity"] = torch.empty(0, dtype=intensity.dtype, device=self.device)
@@ -388,10 +405,13 @@ class ShardedOctreeBuilder:
         row_bytes = sum(int(p.element_size()) * (int(p.numel()) // max(int(p.shape[0]), 1) if int(p.shape[0]) else
                                                   int(np.prod(p.shape[1:], dtype=np.int64))) for p in planes.values())
         # one all-gather of the 64 local counts gives every rank the global counts AND the whole send matrix
-        mine = torch.tensor(np.asarray(counts, dtype=np.int64), device=self.device)
-        every = [torch.empty_like(mine) for _ in range(world)]
-        self.dist.all_gather(every, mine)
-        per_rank = torch.stack(every).cpu().numpy()  # per_rank[src][bucket]
+        if world == 1:  # (a one-rank group: the gathered table is the local one; RCCL would only add a launch and a sync)
+            per_rank = np.asarray(counts, dtype=np.int64).reshape(1, 64)
+        else:
+            mine = torch.tensor(np.asarray(counts, dtype=np.int64), device=self.device)
+            every = torch.empty((world, 64), dtype=torch.int64, device=self.device)
+            self.dist.all_gather(list(every.unbind(0)), mine)  # rows of ONE tensor: one read-back instead of a stack + copy
+            per_rank = every.cpu().numpy()  # per_rank[src][bucket]
         rank_of_bucket, split_mask = plan_buckets(per_rank.sum(axis=0), world, cap, can_split, self.shard_mode)
         matrix = np.stack([np.bincount(rank_of_bucket, weights=per_rank[src], minlength=world) for src in range(world)])
         matrix = matrix.astype(np.int64)  # matrix[src][dst]

@@ -350,17 +350,22 @@ class Context:
         counts = np.array(counts[:], dtype=np.int64)
         return (bucket, counts, state) if with_state else (bucket, counts)
 
-    def route_plan(self, resolution, bounding_box, x, y, z):
+    def route_plan(self, resolution, bounding_box, x, y, z, octants_only=False, out=None):
         """First pass of the two-pass routing (pcv_route_plan): (bucket uint8 tensor, per-tile bucket histograms, 64 counts)
-        for device-resident points; the histograms are what pcv_route_scatter derives every owner's row offsets from."""
+        for device-resident points; the histograms are what pcv_route_scatter derives every owner's row offsets from.
+        octants_only: ownership by root octant — the bucket is the level-1 digit alone (PCV_ROUTE_OCTANTS_ONLY). out: (bucket,
+        tile_hist) tensors of an earlier call with the same number of points, reused."""
         import torch
         p, keep = self._points(x, y, z, None)
         if p.mem != L.MEM_DEVICE:
             raise ValueError("route_plan needs device tensors")
-        pr = self._params(resolution, bounding_box.min, bounding_box.max)
-        bucket = torch.empty(p.n, dtype=torch.uint8, device=x.device)
+        pr = self._params(resolution, bounding_box.min, bounding_box.max, 0, L.ROUTE_OCTANTS_ONLY if octants_only else 0)
         tiles = int(self.lib.pcv_route_tiles(p.n))
-        tile_hist = torch.empty((max(tiles, 1), 64), dtype=torch.int16, device=x.device)
+        if out is not None and int(out[0].numel()) == p.n and int(out[1].shape[0]) == max(tiles, 1):
+            bucket, tile_hist = out
+        else:
+            bucket = torch.empty(p.n, dtype=torch.uint8, device=x.device)
+            tile_hist = torch.empty((max(tiles, 1), 64), dtype=torch.int16, device=x.device)
         counts = (C.c_uint64 * 64)()
         self._check(self.lib.pcv_route_plan(self.handle, C.byref(pr), C.byref(p), bucket.data_ptr(), tile_hist.data_ptr(), counts))
         return bucket, tile_hist, np.array(counts[:], dtype=np.int64)

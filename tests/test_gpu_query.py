@@ -116,6 +116,66 @@ def test_cull_nodes_sparse_lists_equal_the_dense_matrix(ctx, scene):
         assert np.array_equal(i2[f, :k], idx[f, :k]) and np.array_equal(r2[f, :k], rel[f, :k])
 
 
+def test_cull_nodes_sparse_tree_walk_never_differs_from_the_flat_evaluation(ctx, scene):
+    """Round 6: the lists come from a walk down the tree (octree_iterator.rs:30-43: children only under a parent that is not
+    Out) that skips a subtree only under a node that is Out BY A MARGIN; everything else is redone flat. Shapes built to sit
+    ON the margin: boxes whose faces lie exactly on, one ulp inside and one ulp outside faces of node cubes (an Out node without
+    the margin: flat redo), boxes that swallow the whole tree (more kept nodes than the wave's queue: flat redo), a box far away
+    (the root Out by a margin: nothing listed) — each list must equal the dense matrix's row (pcv_cull_nodes), which evaluates
+    every pair on its own."""
+    tree = scene["tree"]
+    m = tree.num_nodes
+    nodes = [tree.node(i) for i in range(m)]
+    # what the walk relies on: a node's cube in the table IS the recurrence step from its parent's cube in the table
+    # (NodeId::find_bounding_cube, node.rs:160-170: edge /= 2; min += bit * edge) — bit for bit, up to the sign of a zero
+    by_name = dict(zip(scene["names"], nodes))
+    for name, nd in by_name.items():
+        if name == "r":
+            continue
+        par, digit = by_name[name[:-1]], int(name[-1])
+        half = par.cube_edge / 2.0
+        want = [par.cube_min[0] + (half if digit & 4 else 0.0), par.cube_min[1] + (half if digit & 2 else 0.0),
+                par.cube_min[2] + (half if digit & 1 else 0.0)]
+        assert nd.cube_edge == half and list(nd.cube_min) == want, name
+    deep = [nd for nd in nodes if nd.level >= 3][:: max(1, m // 40)][:40]
+    shapes = []
+    for nd in deep:
+        lo = np.array(nd.cube_min)
+        hi = lo + nd.cube_edge
+        for step in (0, -1, 1):  # the box's max face ON / one ulp below / one ulp above the node's min face along x
+            face = lo[0] if step == 0 else np.nextafter(lo[0], -np.inf if step < 0 else np.inf)
+            shapes.append(("aabb", [face - 0.75 * nd.cube_edge, lo[1], lo[2]], [face, hi[1], hi[2]]))
+        shapes.append(("aabb", hi, hi + 0.5 * nd.cube_edge))  # touching the node's max corner
+    shapes.append(("aabb", scene["bmin"] - 1.0, scene["bmax"] + 1.0))          # everything In
+    shapes.append(("aabb", scene["bmin"] + 1e-3, scene["bmax"] - 1e-3))        # nearly everything
+    shapes.append(("aabb", scene["bmax"] + 1000.0, scene["bmax"] + 2000.0))    # nothing
+    prepared = ctx.shapes(shapes)
+    dense = tree.cull_nodes(prepared)
+    counts, idx, rel, _ = tree.cull_nodes_sparse(prepared, m, with_sizes=False)
+    redone = 0
+    for f in range(len(shapes)):
+        keep = np.nonzero(dense[f] != 2)[0]
+        assert counts[f] == keep.size, (f, shapes[f])
+        assert np.array_equal(idx[f, :keep.size], keep) and np.array_equal(rel[f, :keep.size], dense[f][keep]), (f, shapes[f])
+        redone += keep.size > 1024
+    assert counts[-1] == 0 and counts[-3] == m
+    # a tree wide enough to overflow the wave's queue of 1 024 kept nodes: the whole-scene boxes are redone flat
+    x, y, z = scene["x"], scene["y"], scene["z"]
+    rgb = np.zeros((x.size, 3), np.uint8)
+    big = ctx.build(0.001, pcv.Aabb(scene["bmin"], scene["bmax"]), x, y, z, rgb, max_points_per_node=120)
+    mb = big.num_nodes
+    assert mb > 4000
+    dense = big.cull_nodes(prepared)
+    counts, idx, rel, _ = big.cull_nodes_sparse(prepared, mb, with_sizes=False)
+    for f in range(len(shapes)):
+        keep = np.nonzero(dense[f] != 2)[0]
+        assert counts[f] == keep.size, (f, shapes[f])
+        assert np.array_equal(idx[f, :keep.size], keep) and np.array_equal(rel[f, :keep.size], dense[f][keep]), (f, shapes[f])
+        redone += keep.size > 1024
+    assert counts[-3] == mb and redone >= 2
+    big.free()
+
+
 def test_visible_nodes_match_reference_traversal_order(ctx, scene):
     rng = np.random.default_rng(4)
     fr = random_frusta(rng, scene["bmin"], scene["bmax"], 64)

@@ -136,6 +136,44 @@ def test_two_pass_routing_equals_state_plus_partition():
             assert np.array_equal(dsts[d]["intensity"].cpu().numpy(), inten[sel])
 
 
+def test_octants_only_plan_is_the_level_1_digit_of_the_full_plan():
+    """PCV_ROUTE_OCTANTS_ONLY (round 6; BASELINE north_star: shard by the top-3-bit prefix): bucket = d1 << 3 with d1 the digit
+    ChildIndex::from_bounding_cube gives against the root cube (node.rs:34-42) — the upper three bits of the full plan's bucket —
+    for tame points, NaN / infinite coordinates, an input that ends inside a group of four, and unaligned views (the general
+    kernel); the scatter pass then delivers the same rows as with the full plan when ownership goes by octant."""
+    import torch
+    n = 200_003
+    x, y, z, rgb, bmin, bmax = synthetic.gaussian_clusters(n, seed=35, num_clusters=7, extent=150.0, sigma_range=(0.05, 8.0))
+    x[5], y[77], z[4099] = np.nan, np.inf, -np.inf
+    x[9000:9040] = (bmin[0] + (bmin[0] + max(bmax - bmin))) / 2.0  # on the centre plane: strict > decides (node.rs:37-41)
+    ctx = pcv.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    bbox = pcv.Aabb(bmin, bmax)
+    tx, ty, tz, trgb = (torch.from_numpy(a).cuda() for a in (x, y, z, rgb))
+    full, _, full_counts = ctx.route_plan(0.001, bbox, tx, ty, tz)
+    b8, th8, c8 = ctx.route_plan(0.001, bbox, tx, ty, tz, octants_only=True)
+    want = (full.cpu().numpy() >> 3) << 3
+    assert np.array_equal(b8.cpu().numpy(), want)
+    assert np.array_equal(c8.reshape(8, 8)[:, 0], full_counts.reshape(8, 8).sum(axis=1)) and c8.reshape(8, 8)[:, 1:].sum() == 0
+    th = th8.cpu().numpy().astype(np.int64)
+    for t in (0, 3, th.shape[0] - 1):
+        assert np.array_equal(th[t], np.bincount(want[t * 4096:(t + 1) * 4096], minlength=64))
+    # views at odd offsets take the general kernel: the same bytes
+    b8v, _, c8v = ctx.route_plan(0.001, bbox, tx[1:], ty[1:], tz[1:], octants_only=True)
+    assert np.array_equal(b8v.cpu().numpy(), want[1:]) and c8v.sum() == n - 1
+    for world in (2, 8):
+        rank_of, _ = pdist.plan_buckets(c8, world, 5000, True, "octants")
+        owner = rank_of[want].astype(np.int64)
+        cnt = np.bincount(owner, minlength=world)
+        out = []
+        for bucket, hist in ((b8, th8), (full, ctx.route_plan(0.001, bbox, tx, ty, tz)[1])):
+            dsts = [{k: torch.empty(int(q), dtype=torch.int32, device="cuda") for k in ("oct_rgb", "cx", "cy", "cz")} for q in cnt]
+            ctx.route_scatter(0.001, bbox, tx, ty, tz, trgb, bucket, hist, rank_of, dsts)
+            out.append(dsts)
+        for d in range(world):
+            for k in ("oct_rgb", "cx", "cy", "cz"):
+                assert torch.equal(out[0][d][k], out[1][d][k]), (world, d, k)
+
+
 @pytest.mark.parametrize("world,cap,with_intensity,compress", [(2, 0, False, True), (4, 20_000, True, True),
                                                                 (8, 3_000, False, True), (4, 20_000, True, False)])
 def test_virtual_ranks_on_one_gpu(world, cap, with_intensity, compress, tmp_path):

@@ -207,8 +207,8 @@ def test_second_sort_pass_settles_the_leaves(ctx, n, cap, lo, hi):
     t.free()
 
 
-@pytest.mark.parametrize("n,cap,bins,lo,hi", [(8_000_000, 1_300, 32768, 16_384, 32_768),   # ranks of 15 bits: 8 + 7, 128 digit values in the settling pass
-                                             (7_800_000, 600, 65536, 32_768, 65_536)])    # ranks of 16 bits: 8 + 8, downsweep_settle_kernel<false, 1024, 256>
+@pytest.mark.parametrize("n,cap,bins,lo,hi", [(8_000_000, 2_500, 32768, 16_384, 32_768),   # ranks of 15 bits: 8 + 7, 128 digit values in the settling pass
+                                             (8_000_000, 1_300, 65536, 32_768, 65_536)])    # ranks of 16 bits: 8 + 8, downsweep_settle_kernel<false, 1024, 256>
 def test_wide_rank_geometries_against_the_oracle(n, cap, bins, lo, hi):
     """The 15- and 16-bit rank geometries of the settling pass are taken from 200 M / 500 M points on (their counters need 128 /
     256 MB of sort scratch), where a unit test has no oracle. The experiment library can be told to take them on a small cloud
