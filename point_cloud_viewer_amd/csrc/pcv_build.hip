@@ -839,6 +839,7 @@ struct PcvBuild {
   std::vector<uint32_t> resolve_host_map;
   std::vector<uint8_t> resolve_host_inner;  // T'' node is an inner node: its map entry is never read (the device leaves it unwritten)
   PcvSortPayload pl;
+  bool color_late = false;  // single-chain build: the chain pass wrote its 12-byte records without the colour
   explicit PcvBuild(pcv_ctx* c) : ctx(c), sc(c) {}
   // A build dropped between begin and finish (an error in finish before the held-back pass was queued, a tree freed without
   // finish): the pass's layout kernels on the side stream write into `sc`'s sort scratch; the main stream must be ordered behind
@@ -1114,6 +1115,17 @@ static int queue_record_sort(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, const Pc
   int rank_bits = 1;
   while ((1ull << rank_bits) < num_leaves) ++rank_bits;
   bool rec_in_a = true;
+  if (bs->spec && bs->color_late) {
+    // the first pass of the rows form reads the colour as it loads the records; any other form of the sort (the rank-count rows
+    // did not fit, experiments) gets it joined in place first
+    const bool first_pass_joins = bs->spec_map_dev && compact && pl.nwords <= 1 && bs->spec_rows && pcv_sort_first_pass_joins_color(n);
+    if (first_pass_joins) {
+      pl.color_in = d.color;
+      pl.color_stride = d.color_stride;
+    } else {
+      pcv_launch_join_color(ctx, n, d.color, d.color_stride, rank_a, pay_a);
+    }
+  }
   if (bs->spec_map_dev)
     rc = pcv_radix_sort_records_mapped(ctx, rank_a, rank_b, n, rank_bits, &pl, bs->sort_scratch, bs->spec_map_dev,
                                        bs->spec_map_entries, &rec_in_a, compact && pl.nwords <= 1 ? bs->spec_rows : nullptr,
@@ -1320,8 +1332,18 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
     // ---- the one chain pass (queued before the host has seen the tree) ----
     ctx->stage_begin(PCV_STAGE_LEAF_ENCODE);
     lv.nlevels = full_levels;
+    // round 6, measured and NOT shipped (PCV_COLOR_LATE=1, libpcv_hip_exp.so; profiles/r06_ab_colour_joins_in_the_sort_dropped.json):
+    // the 12-byte records leave the pass without their colour and the record sort's first pass — which reads every record in
+    // input order anyway — fetches it from the caller's array. The chain pass gains 0.13 ms (1.86 -> 1.73 at 100 M points), the
+    // sort's first pass loses 0.31 (0.59 -> 0.90): eight more (unaligned) loads per lane on top of its sixteen — that pass is
+    // bound by the issue of its vector-memory instructions, not by bytes. Same octree either way.
+    static const bool color_late_on = [] {
+      const char* e = pcv_experiment("PCV_COLOR_LATE");
+      return e && atoi(e) != 0;
+    }();
+    bs->color_late = color_late_on && compact;
     pcv_launch_spec_encode(ctx, lv, d_walk, n, d.x, d.y, d.z, d.routed, d.color, d.color_stride, d.intensity, rank, payload,
-                           inten_bits, depth_grid, wide, d_pool_ctr /* zeroed by the spec_tree kernels */, d_info);
+                           inten_bits, depth_grid, wide, d_pool_ctr /* zeroed by the spec_tree kernels */, d_info, bs->color_late);
     ctx->stage_end(PCV_STAGE_LEAF_ENCODE);
     host_lap("chain pass queued");
 

@@ -482,7 +482,28 @@ __global__ __launch_bounds__(256) void route_octants_kernel(PcvLevels lv, uint64
     const uint32_t o = threadIdx.x >> 3;
     const uint32_t v = (threadIdx.x & 7u) == 0u ? wave_cnt[0][o] + wave_cnt[1][o] + wave_cnt[2][o] + wave_cnt[3][o] : 0u;
     tile_hist[(uint64_t)blockIdx.x * 64 + threadIdx.x] = (uint16_t)v;  // <= 4 096
-    if (v) atomicAdd(&counts[threadIdx.x], (unsigned long long)v);
+  }
+  // (no global counters here: 24 414 workgroups adding to the same 8 addresses is what held the first form of this pass at
+  // 0.58 ms; the 64 counts are the column sums of the tile histograms, route_hist_sum_kernel)
+}
+// counts[b] += sum over this workgroup's tiles of tile_hist[tile][b]: 128 workgroups x 16 rows of tiles per step, then 64 atomics
+// per workgroup (counts is zeroed by the caller)
+constexpr int kHistSumBlocks = 128;
+__global__ __launch_bounds__(1024) void route_hist_sum_kernel(const uint16_t* __restrict__ tile_hist, uint32_t ntiles,
+                                                               unsigned long long* __restrict__ counts) {
+  __shared__ unsigned long long part[16][64];
+  const uint32_t col = threadIdx.x & 63u, r0 = threadIdx.x >> 6;
+  const uint32_t per = (ntiles + gridDim.x - 1) / gridDim.x;
+  const uint32_t t0 = blockIdx.x * per, t1 = t0 + per < ntiles ? t0 + per : ntiles;
+  unsigned long long acc = 0;
+  for (uint32_t t = t0 + r0; t < t1; t += 16) acc += tile_hist[(uint64_t)t * 64 + col];
+  part[r0][col] = acc;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    unsigned long long v = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v += part[r][threadIdx.x];
+    if (v) atomicAdd(&counts[threadIdx.x], v);
   }
 }
 
@@ -785,10 +806,11 @@ extern "C" int pcv_route_plan(pcv_ctx* ctx, const pcv_build_params* params, cons
     const bool octants_only = (params->flags & PCV_ROUTE_OCTANTS_ONLY) != 0u && lv.nlevels >= 1;
     // the streaming form wants 16-byte loads and dword stores: aligned bases (pool blocks and torch tensors are; views may not be)
     const bool aligned = ((((uintptr_t)points->x | (uintptr_t)points->y | (uintptr_t)points->z) & 15) | ((uintptr_t)bucket & 3)) == 0;
-    if (octants_only && aligned)
+    if (octants_only && aligned) {
       hipLaunchKernelGGL(route_octants_kernel, dim3((unsigned)pcv_route_tiles(points->n)), dim3(256), 0, ctx->stream, lv, points->n, points->x,
                          points->y, points->z, bucket, tile_hist, d_counts);
-    else
+      hipLaunchKernelGGL(route_hist_sum_kernel, dim3(kHistSumBlocks), dim3(1024), 0, ctx->stream, tile_hist, (uint32_t)pcv_route_tiles(points->n), d_counts);
+    } else
       hipLaunchKernelGGL(route_plan_kernel, dim3((unsigned)pcv_route_tiles(points->n)), dim3(256), 0, ctx->stream, lv, points->n, points->x,
                          points->y, points->z, bucket, tile_hist, d_counts, octants_only);
   }

@@ -346,7 +346,11 @@ __device__ __forceinline__ uint32_t cp_walk_at(const uint32_t* __restrict__ walk
     CP_LOOP(true, lv.nlevels, , pcv_chain_apply_bits<true>(lv.enc[U + 1], b, ec, ic, px, py, pz, mx, my, mz, vx, vy, vz)) \
   }
 
-template <bool KEEP, bool RAW, int BLOCK, int TOP = 0 /* walk records mirrored in LDS (a multiple of 4 x BLOCK, or 0) */>
+// DIAG (libpcv_hip_exp.so only). Bit 1 (PCV_COLOR_LATE=1, a correct build): the 12-byte records leave WITHOUT their colour — the
+// record sort's first pass reads it from the caller's array as it loads the records (PcvSortPayload::color_in): no colour loads
+// behind the walks (1.86 -> 1.73 ms for the pass at 100 M points; the sort pass loses more than that: not shipped). Bits 2 and 4
+// (PCV_CHAIN_DIAG, TIMING ONLY — the octree is wrong): no walks (front + closing phases alone), no record stores.
+template <bool KEEP, bool RAW, int BLOCK, int TOP = 0 /* walk records mirrored in LDS (a multiple of 4 x BLOCK, or 0) */, int DIAG = 0>
 __global__ __launch_bounds__(BLOCK, 8) void chain_pass_kernel(
     PcvLevels lv, const uint32_t* __restrict__ walk, uint64_t n, const double* __restrict__ x, const double* __restrict__ y,
     const double* __restrict__ z, PcvRouted routed, const uint8_t* __restrict__ color, uint32_t color_stride,
@@ -475,7 +479,9 @@ __global__ __launch_bounds__(BLOCK, 8) void chain_pass_kernel(
       int Ls = L;
       asm volatile("" : "+v"(Ls));
       int U = __builtin_amdgcn_readfirstlane(Ls);
-      if (lv.fast_ok && !(jd & kWild)) {
+      if (DIAG & 2) {
+        vx = px, vy = py, vz = pz;
+      } else if (lv.fast_ok && !(jd & kWild)) {
         CP_WALK_TAME
       } else {
         CP_WALK_GUARDED
@@ -536,13 +542,13 @@ __global__ __launch_bounds__(BLOCK, 8) void chain_pass_kernel(
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const uint32_t t = (uint32_t)(h * BLOCK + tid);
-      rgb[h] = t < here ? pcv_load_rgb(color + (base + t) * color_stride, base + t + 1 < n) : 0u;
+      rgb[h] = (!(DIAG & 1) && t < here) ? pcv_load_rgb(color + (base + t) * color_stride, base + t + 1 < n) : 0u;
     }
     __syncthreads();
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const uint32_t t = (uint32_t)(h * BLOCK + tid);
-      if (t < here) {
+      if (t < here && (!(DIAG & 4) || okey[t] == 0x12345678u)) {
         const uint2 q = opay[t];
         rank[base + t] = okey[t] | (rgb[h] >> 16);
         reinterpret_cast<uint2*>(payload)[base + t] = make_uint2(q.x, q.y | ((rgb[h] & 0xffffu) << 16));
@@ -989,7 +995,8 @@ void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* w
                             uint32_t color_stride, const float* intensity, uint32_t* rank, void* payload,
                             uint32_t* inten_bits, uint8_t* depth_grid /* pcv_spec_depth_grid_bytes() of scratch, or null */,
                             void* wide, uint32_t* pool_ctr /* kPcvPoolRegions zeroed counters: entries of `wide` handed out per region */,
-                            const uint32_t* tree_info /* device: [0] = number of T'' nodes (spec_tree_scan_kernel's info block) */) {
+                            const uint32_t* tree_info /* device: [0] = number of T'' nodes (spec_tree_scan_kernel's info block) */,
+                            bool color_late) {
   if (n == 0) return;
   PcvProf prof(ctx, PCV_K_SPEC_ENCODE);
 #ifdef PCV_EXPERIMENTS
@@ -1001,6 +1008,7 @@ void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* w
   if (chain_v >= 3 && chain_v <= 5) {
     pcv_launch_spec_encode_old(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, inten_bits, depth_grid, wide,
                                pool_ctr, tree_info);
+    // (the superseded kernels write the colour themselves: OR-ing it in again later changes nothing)
     return;
   }
 #endif
@@ -1023,6 +1031,25 @@ void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* w
     const char* e = pcv_experiment("PCV_CHAIN_TOP");
     return e ? atoi(e) : kTop;
   }();
+  static const int chain_diag = [] {
+    const char* e = pcv_experiment("PCV_CHAIN_DIAG");
+    return e ? atoi(e) : 0;
+  }();
+#define PCV_CHAIN_DIAG_LAUNCH(D)                                                                                                         \
+  hipLaunchKernelGGL((chain_pass_kernel<true, true, kBlock, kTop, D>), grid, dim3(kBlock), 0, ctx->stream, lv, walk, n, x, y, z, routed, color, \
+                     color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr, pool_cap)
+  if (!routed.oct && chain_diag) {
+    switch (chain_diag) {
+      case 1: PCV_CHAIN_DIAG_LAUNCH(1); return;
+      case 2: PCV_CHAIN_DIAG_LAUNCH(2); return;
+      case 3: PCV_CHAIN_DIAG_LAUNCH(3); return;
+      case 4: PCV_CHAIN_DIAG_LAUNCH(4); return;
+      case 6: PCV_CHAIN_DIAG_LAUNCH(6); return;
+      case 7: PCV_CHAIN_DIAG_LAUNCH(7); return;
+      default: break;
+    }
+  }
+#undef PCV_CHAIN_DIAG_LAUNCH
   if (!routed.oct && chain_top != kTop) {
     switch (chain_top) {
       case 0: PCV_CHAIN_TOP_LAUNCH(true, 0); return;
@@ -1034,12 +1061,38 @@ void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* w
     }
   }
 #endif
+#ifdef PCV_EXPERIMENTS  // (PCV_COLOR_LATE=1: measured, slower overall, not instantiated in libpcv_hip.so)
+#define PCV_CHAIN_LATE_LAUNCH(RAWIN)                                                                                                     \
+  hipLaunchKernelGGL((chain_pass_kernel<true, RAWIN, kBlock, kTop, 1>), grid, dim3(kBlock), 0, ctx->stream, lv, walk, n, x, y, z, routed, color, \
+                     color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr, pool_cap)
+  if (color_late && wide) {  // (12-byte records only: the 20-byte form fetches the colour in its record epilogue)
+    if (!routed.oct) PCV_CHAIN_LATE_LAUNCH(true);
+    else PCV_CHAIN_LATE_LAUNCH(false);
+    return;
+  }
+#undef PCV_CHAIN_LATE_LAUNCH
+#endif
+  (void)color_late;
   if (!routed.oct) PCV_CHAIN_TOP_LAUNCH(true, kTop);
   else PCV_CHAIN_TOP_LAUNCH(false, kTop);
 #undef PCV_CHAIN_TOP_LAUNCH
 }
 
 size_t pcv_spec_depth_grid_bytes() { return (size_t)1 << (3 * kGridBits); }
+
+__global__ __launch_bounds__(256) void join_color_kernel(uint64_t n, const uint8_t* __restrict__ color, uint32_t color_stride,
+                                                          uint32_t* __restrict__ keys, uint2* __restrict__ payload) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t rgb = pcv_load_rgb(color + i * color_stride, i + 1 < n);
+  keys[i] |= rgb >> 16;
+  payload[i].y |= (rgb & 0xffffu) << 16;
+}
+void pcv_launch_join_color(pcv_ctx* ctx, uint64_t n, const uint8_t* color, uint32_t color_stride, uint32_t* keys, void* payload_uint2) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(join_color_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, color, color_stride, keys,
+                     (uint2*)payload_uint2);
+}
 
 void pcv_launch_rank_hist(pcv_ctx* ctx, const uint32_t* rank, uint64_t n, uint32_t num_bins, uint32_t* counts, int shift) {
   if (n == 0 || num_bins == 0) return;

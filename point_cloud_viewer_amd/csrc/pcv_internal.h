@@ -321,8 +321,14 @@ struct PcvSortPayload {
   // set: the FIRST pass reads plane 0 from here instead of in[0] (the caller's own array in record order — the intensity
   // plane of the single-chain build needs no copy into the sort's buffers); later passes ping-pong between out[0] and in[0]
   const uint32_t* first_in0 = nullptr;
+  // set (round 6): the records arrive WITHOUT their colour — key = rank << 8, the upper half of payload .y empty — and the first
+  // pass of the 12-byte record sort reads r, g, b of record i at color_in + i * color_stride (the caller's array, input order) as
+  // it loads the record; what it writes is the record with colour (blue in the key's low byte, red / green in payload .y)
+  const uint8_t* color_in = nullptr;
+  uint32_t color_stride = 3;
 };
 size_t pcv_sort_scratch_bytes(uint64_t n);
+bool pcv_sort_first_pass_joins_color(uint64_t n);
 // Sorts keys_in -> ... ping-pong between (keys_a, payload.in) and (keys_b, payload.out). Returns in
 // *result_in_a whether the final sorted data is in the a-side (true) or b-side (false).
 int pcv_radix_sort_u64(pcv_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint64_t n, int begin_bit, int end_bit,
@@ -454,7 +460,11 @@ void pcv_launch_leaf_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvWalkTabl
 void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* walk, uint64_t n, const double* x,
                             const double* y, const double* z, const PcvRouted& routed, const uint8_t* color,
                             uint32_t color_stride, const float* intensity, uint32_t* rank, void* payload /* uint4[n] */,
-                            uint32_t* inten_bits, uint8_t* depth_grid, void* wide, uint32_t* pool_ctr, const uint32_t* tree_info);
+                            uint32_t* inten_bits, uint8_t* depth_grid, void* wide, uint32_t* pool_ctr, const uint32_t* tree_info,
+                            bool color_late = false /* 12-byte records leave without their colour (PcvSortPayload::color_in) */);
+// The colour joined into records that left the chain pass without it, in place (the record sort's first pass does this on the
+// fly; this pass exists for the sorts that cannot: the rank-count rows did not fit, experiments).
+void pcv_launch_join_color(pcv_ctx* ctx, uint64_t n, const uint8_t* color, uint32_t color_stride, uint32_t* keys, void* payload_uint2);
 constexpr uint32_t kPcvPoolRegions = 1024;
 // entries per region: every slice of 1 024 points could be all Float32-coded
 inline uint64_t pcv_pool_region_entries(uint64_t n) { return (((n + 1023) / 1024 + kPcvPoolRegions - 1) / kPcvPoolRegions) * 1024; }

@@ -622,7 +622,8 @@ __device__ __forceinline__ void downsweep_rec12_body(const uint32_t* __restrict_
                                                      uint2* __restrict__ vec_out, const uint32_t* __restrict__ gmap, uint32_t map_entries,
                                                      const uint2* __restrict__ ranges, const uint32_t* __restrict__ order,
                                                      const uint32_t* __restrict__ plane_in, uint32_t* __restrict__ plane_out,
-                                                     const PcvSortFuse& fuse) {
+                                                     const PcvSortFuse& fuse, const uint8_t* __restrict__ color_in = nullptr,
+                                                     uint32_t color_stride = 3) {
   constexpr int NW = BLOCK / 64, kTile = BLOCK * KPT, RW = R / 64;
   static_assert(!FUSE || (!WC && MAP == 0), "the settling pass: second pass of 12-byte records (+ the intensity plane)");
   __shared__ FuseLeaf sleaf[FUSE ? R : 1];  // FUSE: the leaf of digit value d in this piece: rank = d << low_bits | the piece's lower digit
@@ -707,6 +708,24 @@ __device__ __forceinline__ void downsweep_rec12_body(const uint32_t* __restrict_
         key[i] = valid ? kp[i * 64] : 0u;
         vec[i] = valid ? vp[i * 64] : make_uint2(0u, 0u);
         if (PL) pln[i] = valid ? pp[i * 64] : 0u;
+      }
+    }
+    if (MAP != 0 && color_in) {  // (wave-uniform) the first pass of records that left the chain pass without their colour
+#pragma unroll
+      for (int i = 0; i < KPT; ++i) {
+        const uint64_t idx = base + wbase + (uint32_t)(i * 64);
+        if (tile_n == (uint32_t)kTile || wbase + i * 64 < tile_n) {
+          const uint8_t* c = color_in + idx * color_stride;
+          uint32_t rgb;  // r | g << 8 | b << 16 (pcv_load_rgb: one unaligned dword where a fourth byte exists behind the colour)
+          if (idx + 1 < n) {
+            __builtin_memcpy(&rgb, c, 4);
+            rgb &= 0xffffffu;
+          } else {
+            rgb = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16);
+          }
+          key[i] |= rgb >> 16;
+          vec[i].y |= (rgb & 0xffffu) << 16;
+        }
       }
     }
     if (MAP == 1) {
@@ -1021,9 +1040,13 @@ __global__ __launch_bounds__(BLOCK, WPE) void downsweep_rec12_kernel(const uint3
                                                                      const uint32_t* __restrict__ order = nullptr /* set: workgroup
                                                                      b takes piece order[b] (largest pieces first) */,
                                                                      const uint32_t* __restrict__ plane_in = nullptr,
-                                                                     uint32_t* __restrict__ plane_out = nullptr) {
+                                                                     uint32_t* __restrict__ plane_out = nullptr,
+                                                                     const uint8_t* __restrict__ color_in = nullptr /* MAP != 0: the
+                                                                     records come without colour, record i's is here */,
+                                                                     uint32_t color_stride = 3) {
   downsweep_rec12_body<BLOCK, KPT, R, WPE, NT, MAP, PL, WC, false>(keys_in, keys_out, n, chunk, groups, shift, nbits, offsets, totals, vec_in,
-                                                                  vec_out, gmap, map_entries, ranges, order, plane_in, plane_out, PcvSortFuse());
+                                                                  vec_out, gmap, map_entries, ranges, order, plane_in, plane_out, PcvSortFuse(),
+                                                                  color_in, color_stride);
 }
 // the settling form of the second pass (FUSE above): a kernel of its own name for the profiles
 // (R = 128 digit values: the second digit of a rank of <= 15 bits has <= 7 bits; 256 for ranks of 16 bits)
@@ -1336,7 +1359,7 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
     (void)ok;                                                                                                                            \
     hipLaunchKernelGGL((downsweep_rec12_kernel<1024, 8, R, 4, false, M, P>), dim3(g.groups), dim3(1024), dyn, ctx->stream,                \
                        (const uint32_t*)src, (uint32_t*)dst, n, g.chunk, g.groups, p1_shift, p1_bits, hist, totals, vin, vout, map,       \
-                       map_entries, (const uint2*)nullptr, (const uint32_t*)nullptr, pin, pout);                                          \
+                       map_entries, (const uint2*)nullptr, (const uint32_t*)nullptr, pin, pout, payload->color_in, payload->color_stride); \
   }
         // PCV_REC_WC (libpcv_hip_exp.so; bit 0: first pass, bit 1: second pass): the write-combining form of the downsweep
         // measured slower than the kernel that ships (profiles/r05_sort_same_box.json): not instantiated in libpcv_hip.so
@@ -1346,7 +1369,7 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
           const char* e = pcv_experiment("PCV_REC_WC");
           return e ? atoi(e) : 0;
         }();
-        if ((rec_wc & 1) && !with_plane && p1_bits <= 7) {
+        if ((rec_wc & 1) && !with_plane && p1_bits <= 7 && !payload->color_in) {
           hipLaunchKernelGGL((downsweep_rec12_kernel<1024, 8, 128, 4, false, 2, false, true>), dim3(g.groups), dim3(1024), 0, ctx->stream,
                              (const uint32_t*)src, (uint32_t*)dst, n, g.chunk, g.groups, p1_shift, p1_bits, hist, totals, vin, vout, map, map_entries,
                              (const uint2*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr);
@@ -1358,7 +1381,7 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
           const char* e = pcv_experiment("PCV_REC_BLOCK");
           return e ? atoi(e) : 1024;
         }();
-        if (!wc_done && rec_block == 512 && !with_plane && p1_bits <= 7 && map_in_lds && dyn <= 28672) {
+        if (!wc_done && rec_block == 512 && !with_plane && p1_bits <= 7 && map_in_lds && dyn <= 28672 && !payload->color_in) {
           static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&downsweep_rec12_kernel<512, 8, 128, 4, false, 1, false>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 28672) == hipSuccess;
           (void)ok;
@@ -1539,6 +1562,17 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
 size_t pcv_sort_scratch_bytes(uint64_t n) {
   const size_t rows_true = make_geom(n, 8192).groups >= 8 ? rows_true_bins(n) * (size_t)kMaxGroups : 0;
   return (2 * ((size_t)kRadix * kMaxGroups + kRadix) + 3 * (size_t)kMaxGroups + rows_true) * sizeof(uint32_t) + 256;
+}
+
+// Does the first pass of a mapped 12-byte record sort with rank-count rows read the records' colour itself (PcvSortPayload::color_in)?
+// It does in the form that ships (the rows-based downsweep_rec12_kernel<..., MAP != 0>); the experiment variants of the record
+// kernel (PCV_REC_VARIANT, libpcv_hip_exp.so) do not.
+bool pcv_sort_first_pass_joins_color(uint64_t n) {
+  static const int rec_variant = [] {
+    const char* e = pcv_experiment("PCV_REC_VARIANT");
+    return e ? atoi(e) : 3;
+  }();
+  return n > 0 && rec_variant == 3;
 }
 
 int pcv_radix_sort_u64(pcv_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint64_t n, int begin_bit, int end_bit,

@@ -55,7 +55,7 @@ def main():
         m = re.match(r'\s*\.file\s+(\d+)\s+"[^"]*"\s+"([^"]+)"', l)
         if m:
             files[int(m.group(1))] = os.path.basename(m.group(2))
-    start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN12_GLOBAL__N_117chain_pass_kernelILb1ELb1ELi512E(Li2048E)?E.*:", l))
+    start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN12_GLOBAL__N_117chain_pass_kernelILb1ELb1ELi512ELi2048ELi0EE.*:", l))
     body = []
     for l in lines[start + 1:]:
         body.append(l.strip())
