@@ -539,6 +539,10 @@ __global__ __launch_bounds__(BLOCK, 8) void chain_pass_kernel(
   tid = wave * 64 + (int)pcv_lane_again();
   if (stage) {
     uint32_t rgb[2];
+    // (round 6, measured: requesting the colour in the front phase and parking it in LDS, or fetching it as aligned dwords + two
+    // ds_bpermute per lane, changes nothing — 1.85 ms either way against 1.72 without any colour, PCV_CHAIN_DIAG=1: what the
+    // colour costs the pass is neither the latency in front of this barrier nor the unaligned loads;
+    // profiles/r06_ab_colour_joins_in_the_sort_dropped.json)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const uint32_t t = (uint32_t)(h * BLOCK + tid);
