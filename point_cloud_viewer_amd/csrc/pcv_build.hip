@@ -1417,7 +1417,7 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
   PCV_HIP_CHECK(ctx, hipGetLastError());
   if ((rc = ctx->pinned_spec_reserve((size_t)tree.num_leaves * 8 + 512 + kPcvPoolRegions * 4))) return rc;
   uint8_t* hp = (uint8_t*)ctx->pinned_spec;
-  // the number of `wide` pool entries the chain pass handed out per region (pcv_spec_emit), then the exact counts: one
+  // the number of `wide` pool entries the chain pass handed out per region (the record epilogue of chain_pass_kernel), then the exact counts: one
   // block on the device, one copy (every small operation on `stream` costs a hand-over of ~10 us between two kernels)
   uint32_t* h_pool = (uint32_t*)hp;
   uint32_t* h_counts = h_pool + kPcvPoolRegions;

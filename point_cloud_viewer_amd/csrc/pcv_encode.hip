@@ -101,54 +101,6 @@ __device__ __forceinline__ uint32_t pcv_load_rgb(const uint8_t* __restrict__ c, 
   }
   return (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16);
 }
-__device__ __forceinline__ void pcv_spec_emit(uint64_t i, uint64_t n, uint32_t rec, uint32_t leaf_enc, double vx, double vy, double vz,
-                                              const uint8_t* __restrict__ color, uint32_t color_stride,
-                                              const float* __restrict__ intensity, uint32_t* __restrict__ rank,
-                                              uint4* __restrict__ payload, uint32_t* __restrict__ inten_bits,
-                                              uint4* __restrict__ wide, uint32_t* __restrict__ pool_ctr, uint32_t pool_cap,
-                                              uint32_t* stage_key = nullptr /* LDS: the workgroup stores its 12-byte records itself */,
-                                              uint2* stage_pay = nullptr, uint32_t stage_slot = 0) {
-  // staged records: the colour is OR-ed in by the lane that stores the record (input order: a coalesced load off the wave's
-  // critical path); otherwise it is fetched here
-  const uint32_t rgb = stage_key ? 0u : pcv_load_rgb(color + i * color_stride, i + 1 < n);
-  const bool is_wide = leaf_enc > PCV_ENC_UINT16;
-  // value domain -> raw code: the integer itself (u8 / u16), the IEEE bits of the float (Float32); single-chain builds have
-  // no Float64-coded level (build_begin_impl sends those to the exact pipeline)
-  const uint32_t ccx = is_wide ? __float_as_uint((float)vx) : (uint32_t)vx, ccy = is_wide ? __float_as_uint((float)vy) : (uint32_t)vy,
-                 ccz = is_wide ? __float_as_uint((float)vz) : (uint32_t)vz;
-  if (wide) {
-    const uint32_t key = ((rec & PCV_SPEC_INDEX_MASK) << 8) | (rgb >> 16);
-    const uint32_t rg = (rgb & 0xffffu) << 16;
-    uint2 out = make_uint2(ccx | (ccy << 16), ccz | rg);
-    const uint64_t wm = __ballot(is_wide);
-    if (wm != 0ull) {  // wave-uniform
-      // every lane of a wave holds points of ONE slice of 1 024 input points (the deal stays inside the workgroup's points,
-      // and workgroups of 256 / 512 / 1 024 points start on multiples of their size)
-      const uint32_t region = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(i >> 10)) & (kPcvPoolRegions - 1u);
-      uint32_t base = 0;
-      if (is_wide && (wm & ((1ull << (threadIdx.x & 63)) - 1ull)) == 0ull)
-        base = __hip_atomic_fetch_add(pool_ctr + region, (uint32_t)__popcll(wm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      base = region * pool_cap + (uint32_t)__builtin_amdgcn_readlane((int)base, (int)__builtin_ctzll(wm));
-      if (is_wide) {
-        const uint32_t e = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(wm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wm, 0u));
-        wide[e] = make_uint4(ccx, ccy, ccz, 0u);
-        out = make_uint2(e, rg);
-      }
-    }
-    if (stage_key) {
-      stage_key[stage_slot] = key;
-      stage_pay[stage_slot] = out;
-    } else {
-      rank[i] = key;
-      reinterpret_cast<uint2*>(payload)[i] = out;
-    }
-  } else {  // 20-byte records (a predicted tree that could outgrow 24 rank bits): the codes travel in full
-    rank[i] = rec & PCV_SPEC_INDEX_MASK;
-    payload[i] = make_uint4(ccx, ccy, ccz, rgb);
-  }
-  if (inten_bits) inten_bits[i] = __float_as_uint(intensity[i]);
-}
-
 // ---- single-chain build (pcv_spec.h): ONE chain pass down the predicted tree T'' --------------------------------------
 // Every inner node of T'' has all eight children (consecutive walk records), so a digit indexes the child directly.
 // A point passing through a candidate node (sampled count close to the capacity) leaves this pass with the codes it has
@@ -199,7 +151,8 @@ __device__ __forceinline__ uint32_t pcv_lane_again() {  // the lane number, reco
 }
 
 // ---- the single chain pass (round 5): the ONE chain kernel of the shipped library ---------------------------------------------
-// Rounds 2-4 built this pass up (pcv_encode_exp.inc keeps those generations for A/B runs): depth-dealt tiles of two points
+// Rounds 2-4 built this pass up (their three kernel generations were deleted in round 6; the A/B records stay under profiles/,
+// the text in the git history of pcv_encode_exp.inc): depth-dealt tiles of two points
 // per lane (a workgroup of BLOCK lanes takes 2 x BLOCK points through ONE memory phase, deals them into groups of 64 by
 // predicted depth, wave w walks group w and then group 2 x waves - 1 - w), the deal by one returning LDS atomic per point,
 // octant bits as lane masks, first-candidate codes behind a wave-uniform branch, 12-byte records that leave through LDS in
@@ -575,9 +528,6 @@ __global__ __launch_bounds__(BLOCK, 8) void chain_pass_kernel(
 #undef CP_KEEP_STEP
 #undef CP_WALK_AT
 
-#ifdef PCV_EXPERIMENTS
-#include "pcv_encode_exp.inc"
-#endif  // PCV_EXPERIMENTS
 
 // Exact number of points per predicted leaf: LDS-privatised histogram of the rank array over the bins
 // [bin_base, bin_base + nbins), nbins <= kHistBins; one flush of the non-zero bins per workgroup.
@@ -991,9 +941,6 @@ void pcv_launch_leaf_encode(pcv_ctx* ctx, const PcvLevels& lv, const PcvWalkTabl
                      y, z, routed, color, color_stride, intensity, rank, (uint4*)payload, cx_hi, cy_hi, cz_hi, inten_bits);
 }
 
-#ifdef PCV_EXPERIMENTS
-#include "pcv_encode_exp_launch.inc"
-#endif
 void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* walk, uint64_t n, const double* x,
                             const double* y, const double* z, const PcvRouted& routed, const uint8_t* color,
                             uint32_t color_stride, const float* intensity, uint32_t* rank, void* payload,
@@ -1003,19 +950,6 @@ void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* w
                             bool color_late) {
   if (n == 0) return;
   PcvProf prof(ctx, PCV_K_SPEC_ENCODE);
-#ifdef PCV_EXPERIMENTS
-  // PCV_CHAIN_V = 3 / 4 / 5 (libpcv_hip_exp.so): round 3's kernel, round 4's one-point form, round 4's paired tiles
-  static const int chain_v = [] {
-    const char* e = pcv_experiment("PCV_CHAIN_V");
-    return e ? atoi(e) : 6;
-  }();
-  if (chain_v >= 3 && chain_v <= 5) {
-    pcv_launch_spec_encode_old(ctx, lv, walk, n, x, y, z, routed, color, color_stride, intensity, rank, payload, inten_bits, depth_grid, wide,
-                               pool_ctr, tree_info);
-    // (the superseded kernels write the colour themselves: OR-ing it in again later changes nothing)
-    return;
-  }
-#endif
   (void)tree_info;
   constexpr int kBlock = 512;  // tiles of 1 024 points: one pool region, 26 KB of LDS, four workgroups per CU
   const dim3 grid((unsigned)((n + 2 * kBlock - 1) / (2 * kBlock)));

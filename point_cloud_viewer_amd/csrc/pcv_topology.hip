@@ -626,7 +626,7 @@ __global__ __launch_bounds__(256) void pack_node_table_kernel(PcvNodeTableDev t,
 __global__ __launch_bounds__(1024) void spec_tree_scan_kernel(PcvNodeTableDev t, uint32_t* __restrict__ ord,
                                                                uint32_t* __restrict__ info, uint32_t* __restrict__ pool_ctr) {
   static_assert(kPcvPoolRegions <= 1024, "one counter per lane");
-  // the chain pass's pool counters (entries of `wide` handed out per region, pcv_encode.hip pcv_spec_emit): zero before every pass
+  // the chain pass's pool counters (entries of `wide` handed out per region, pcv_encode.hip chain_pass_kernel): zero before every pass
   if (pool_ctr && threadIdx.x < kPcvPoolRegions) pool_ctr[threadIdx.x] = 0;
   __shared__ uint32_t wave_tot[16];
   __shared__ uint32_t running;

@@ -378,12 +378,9 @@ print("alt-path ok")
                                               # the second pass counting its keys itself (equal chunks instead of pieces of
                                               # whole first-pass runs)
                                               ({"PCV_SORT_ROWS2": "0"}, 12),
-                                              # the superseded chain kernels (pcv_encode_exp.inc): round 4's paired tiles (2 x 512
-                                              # and 2 x 256 points), its one-point form (workgroups of 512 and 1 024 lanes), round 3's
-                                              # kernel; and the shipped kernel with every Float32-coded level step taken in full
-                                              ({"PCV_CHAIN_V": "5"}, 12), ({"PCV_CHAIN_V": "5", "PCV_SPEC_BIN": "256"}, 12),
-                                              ({"PCV_CHAIN_V": "4"}, 12), ({"PCV_CHAIN_V": "4", "PCV_SPEC_BIN": "1024"}, 12),
-                                              ({"PCV_CHAIN_V": "3"}, 12), ({"PCV_CODE_STEPS": "0"}, 12),
+                                              # the shipped chain kernel with every Float32-coded level step taken in full; with
+                                              # the colour joined by the record sort's first pass instead (round 6, measured, dropped)
+                                              ({"PCV_CODE_STEPS": "0"}, 12), ({"PCV_COLOR_LATE": "1"}, 12),
                                               # the write-combining form of the record downsweep, both passes (experiment)
                                               ({"PCV_REC_WC": "3"}, 12),
                                               # the record sort's upper digit first, the second pass inside every bucket (experiment)
