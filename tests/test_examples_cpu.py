@@ -10,7 +10,7 @@ EX = os.path.join(ROOT, "examples")
 
 def test_examples_compile_as_c11_and_cxx17():
     subprocess.check_call(["make", "-s", "-C", EX])
-    for exe in ("build_octree", "query_octree"):
+    for exe in ("build_octree", "query_octree", "ingest_batches"):
         p = subprocess.run([os.path.join(EX, "bin", exe)], capture_output=True, text=True)
         assert p.returncode == 2 and "usage" in p.stderr  # loads libpcv_hip.so, parses no arguments
 

@@ -149,3 +149,27 @@ def test_misuse_is_reported_not_crashed(ctx):
     # the context is still good
     x, y, z, rgb, bmin, bmax = synthetic.gaussian_clusters(50_000, seed=72, num_clusters=2, extent=30.0, sigma_range=(0.1, 1.0))
     ctx.build(0.001, pcv.Aabb(bmin, bmax), x, y, z, rgb).free()
+
+
+def test_c_host_binary_streams_batches_to_the_same_directory(tmp_path):
+    """examples/ingest_batches.c (gcc -std=c11): the library entry build_octree(dir, resolution, bbox, batches, attributes)
+    over the C ABI in a separate non-Python process, one 100 000-point AoS batch of host memory at a time — the directory
+    equals the oracle's literal build with the bounding box of the cloud."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "bin", "ingest_batches")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "examples")])
+    n = 350_017
+    x, y, z, rgb, _, _ = synthetic.gaussian_clusters(n, seed=73, num_clusters=4, extent=80.0, sigma_range=(0.05, 3.0))
+    inten = (np.arange(n) % 29).astype(np.float32) * 0.5
+    np.stack([x, y, z], axis=1).astype("<f8").tofile(tmp_path / "xyz.f64")
+    rgb.tofile(tmp_path / "rgb.u8")
+    inten.astype("<f4").tofile(tmp_path / "int.f32")
+    p = subprocess.run([exe, str(tmp_path / "xyz.f64"), str(tmp_path / "rgb.u8"), str(tmp_path / "int.f32"), str(n), "100000",
+                        str(tmp_path / "c_out"), "0.001"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    assert f"{n} points in batches of 100000" in p.stdout
+    bmin, bmax = O.aabb(x, y, z)
+    O.build_literal_dir(tmp_path / "cpu", 0.001, bmin, bmax, x, y, z, rgb, inten, threads=4)
+    assert not O.compare_octrees(O.load_dir(tmp_path / "c_out"), O.load_dir(tmp_path / "cpu"))
