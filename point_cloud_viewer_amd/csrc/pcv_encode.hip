@@ -301,8 +301,7 @@ __device__ __forceinline__ uint32_t cp_walk_at(const uint32_t* __restrict__ walk
 
 // DIAG (libpcv_hip_exp.so only). Bit 1 (PCV_COLOR_LATE=1, a correct build): the 12-byte records leave WITHOUT their colour — the
 // record sort's first pass reads it from the caller's array as it loads the records (PcvSortPayload::color_in): no colour loads
-// behind the walks (1.86 -> 1.73 ms for the pass at 100 M points; the sort pass loses more than that: not shipped). Bits 2 and 4
-// (PCV_CHAIN_DIAG, TIMING ONLY — the octree is wrong): no walks (front + closing phases alone), no record stores.
+// behind the walks (1.86 -> 1.73 ms for the pass at 100 M points; the sort pass loses more than that: not shipped).
 template <bool KEEP, bool RAW, int BLOCK, int TOP = 0 /* walk records mirrored in LDS (a multiple of 4 x BLOCK, or 0) */, int DIAG = 0>
 __global__ __launch_bounds__(BLOCK, 8) void chain_pass_kernel(
     PcvLevels lv, const uint32_t* __restrict__ walk, uint64_t n, const double* __restrict__ x, const double* __restrict__ y,
@@ -432,9 +431,7 @@ __global__ __launch_bounds__(BLOCK, 8) void chain_pass_kernel(
       int Ls = L;
       asm volatile("" : "+v"(Ls));
       int U = __builtin_amdgcn_readfirstlane(Ls);
-      if (DIAG & 2) {
-        vx = px, vy = py, vz = pz;
-      } else if (lv.fast_ok && !(jd & kWild)) {
+      if (lv.fast_ok && !(jd & kWild)) {
         CP_WALK_TAME
       } else {
         CP_WALK_GUARDED
@@ -493,7 +490,7 @@ __global__ __launch_bounds__(BLOCK, 8) void chain_pass_kernel(
   if (stage) {
     uint32_t rgb[2];
     // (round 6, measured: requesting the colour in the front phase and parking it in LDS, or fetching it as aligned dwords + two
-    // ds_bpermute per lane, changes nothing — 1.85 ms either way against 1.72 without any colour, PCV_CHAIN_DIAG=1: what the
+    // ds_bpermute per lane, changes nothing — 1.85 ms either way against 1.72 without any colour (a timing-only variant): what the
     // colour costs the pass is neither the latency in front of this barrier nor the unaligned loads;
     // profiles/r06_ab_colour_joins_in_the_sort_dropped.json)
 #pragma unroll
@@ -505,7 +502,7 @@ __global__ __launch_bounds__(BLOCK, 8) void chain_pass_kernel(
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const uint32_t t = (uint32_t)(h * BLOCK + tid);
-      if (t < here && (!(DIAG & 4) || okey[t] == 0x12345678u)) {
+      if (t < here) {
         const uint2 q = opay[t];
         rank[base + t] = okey[t] | (rgb[h] >> 16);
         reinterpret_cast<uint2*>(payload)[base + t] = make_uint2(q.x, q.y | ((rgb[h] & 0xffffu) << 16));
@@ -969,25 +966,6 @@ void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* w
     const char* e = pcv_experiment("PCV_CHAIN_TOP");
     return e ? atoi(e) : kTop;
   }();
-  static const int chain_diag = [] {
-    const char* e = pcv_experiment("PCV_CHAIN_DIAG");
-    return e ? atoi(e) : 0;
-  }();
-#define PCV_CHAIN_DIAG_LAUNCH(D)                                                                                                         \
-  hipLaunchKernelGGL((chain_pass_kernel<true, true, kBlock, kTop, D>), grid, dim3(kBlock), 0, ctx->stream, lv, walk, n, x, y, z, routed, color, \
-                     color_stride, intensity, rank, (uint4*)payload, inten_bits, depth_grid, cells, (uint4*)wide, pool_ctr, pool_cap)
-  if (!routed.oct && chain_diag) {
-    switch (chain_diag) {
-      case 1: PCV_CHAIN_DIAG_LAUNCH(1); return;
-      case 2: PCV_CHAIN_DIAG_LAUNCH(2); return;
-      case 3: PCV_CHAIN_DIAG_LAUNCH(3); return;
-      case 4: PCV_CHAIN_DIAG_LAUNCH(4); return;
-      case 6: PCV_CHAIN_DIAG_LAUNCH(6); return;
-      case 7: PCV_CHAIN_DIAG_LAUNCH(7); return;
-      default: break;
-    }
-  }
-#undef PCV_CHAIN_DIAG_LAUNCH
   if (!routed.oct && chain_top != kTop) {
     switch (chain_top) {
       case 0: PCV_CHAIN_TOP_LAUNCH(true, 0); return;
