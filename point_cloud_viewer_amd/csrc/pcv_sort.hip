@@ -1286,7 +1286,21 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
   // sectors. Keys-only sorts keep full 8-bit digits (fewest passes is what counts there).
   const int total_bits = end_bit - begin_bit;
   const int passes = (total_bits + 7) / 8;
-  const int width = records ? (total_bits + passes - 1) / passes : 8;
+  int width = records ? (total_bits + passes - 1) / passes : 8;
+#ifdef PCV_EXPERIMENTS
+  // PCV_SORT_FLIP=1 (libpcv_hip_exp.so): a two-pass record sort takes the NARROWER digit first (13 bits -> 6 + 7 instead of 7 + 6):
+  // with PCV_REC_BLOCK=512 the first pass then runs two workgroups per CU on tiles of 4 096 with the runs of 64 records it has today
+  static const bool flip = [] {
+    const char* e = pcv_experiment("PCV_SORT_FLIP");
+    return e && atoi(e) != 0;
+  }();
+  const bool flipped = flip && records && passes == 2 && (total_bits & 1) && map && rows;
+  const int width2 = width;  // the second pass's width when flipped
+  if (flipped) width = total_bits / 2;
+#else
+  constexpr bool flipped = false;
+  const int width2 = width;
+#endif
   for (int shift = begin_bit; shift < end_bit; shift += width) {
     int nbits = end_bit - shift < width ? end_bit - shift : width;
     uint32_t mask = (1u << nbits) - 1u;
@@ -1303,7 +1317,7 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
         const char* e = pcv_experiment("PCV_SORT_ROWS2");  // 0 = the second pass counts its keys itself (experiments)
         return !e || atoi(e) != 0;
       }();
-      const int nbits2 = end_bit - (shift + width) < width ? end_bit - (shift + width) : width;
+      const int nbits2 = flipped ? width2 : (end_bit - (shift + width) < width ? end_bit - (shift + width) : width);
       bool msd = false;
 #ifdef PCV_EXPERIMENTS
       static const bool msd_on = [] {
@@ -1313,7 +1327,7 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
       msd = msd_on;
 #endif
       // (ranks of 15 bits — trees of up to 32 768 leaves — where the scratch holds their counters: rows_true_bins)
-      const bool two = pass2_rows_on && map_entries <= rows_true_bins(n) && shift + width < end_bit && shift + 2 * width >= end_bit &&
+      const bool two = pass2_rows_on && map_entries <= rows_true_bins(n) && shift + width < end_bit && shift + width + nbits2 >= end_bit &&
                        (1u << total_bits) <= rows_true_bins(n) && nbits2 >= 1 && g.groups >= 8;
       msd = msd && two;
       // first / second pass: (shift, bits) of their digits — the lower digit first, unless msd
