@@ -22,7 +22,8 @@
 extern "C" {
 #endif
 
-#define PCV_ABI_VERSION 1
+/* 2 (round 6): pcv_ingest_*, PCV_ROUTE_OCTANTS_ONLY, PCV_STAGE_SORT_SECOND (PCV_STAGE_TOTAL moved from 8 to 9) */
+#define PCV_ABI_VERSION 2
 
 /* status codes (reference: error-chain kinds src/errors.rs:18-48; the builder itself panics) */
 #define PCV_OK 0

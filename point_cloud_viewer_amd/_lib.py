@@ -13,6 +13,7 @@ _alt = os.environ.get("PCV_HIP_LIBRARY")
 LIB_PATH = os.path.join(_HERE, "libpcv_hip_exp.so") if _alt == "exp" else (_alt or os.path.join(_HERE, "libpcv_hip.so"))
 
 PCV_OK = 0
+ABI_VERSION = 2  # include/pcv_hip.h PCV_ABI_VERSION
 PCV_E_INVALID, PCV_E_HIP, PCV_E_IO, PCV_E_OOM, PCV_E_DEPTH, PCV_E_NOT_FOUND = -1, -2, -3, -4, -5, -6
 MEM_HOST, MEM_DEVICE = 0, 1
 ENC_UINT8, ENC_UINT16, ENC_FLOAT32, ENC_FLOAT64 = 1, 2, 3, 4
@@ -219,5 +220,8 @@ def load_library():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
+    if lib.pcv_abi_version() != ABI_VERSION:  # a stale libpcv_hip.so next to newer bindings: fail loudly, not subtly
+        raise ImportError(f"{LIB_PATH} has ABI version {lib.pcv_abi_version()}, these bindings are written for {ABI_VERSION}: "
+                          "rebuild it (make -C point_cloud_viewer_amd/csrc)")
     _lib = lib
     return lib

@@ -71,6 +71,7 @@ type pcv_shapes = c_void;
 type pcv_ingest = c_void;
 
 extern "C" {
+    fn pcv_abi_version() -> c_int;
     fn pcv_ctx_create(device: c_int, stream: *mut c_void, out: *mut *mut pcv_ctx) -> c_int;
     fn pcv_ctx_destroy(ctx: *mut pcv_ctx);
     fn pcv_last_error(ctx: *const pcv_ctx) -> *const c_char;
@@ -102,6 +103,10 @@ pub struct HipContext(*mut pcv_ctx);
 
 impl HipContext {
     pub fn new(device: i32) -> Result<Self, String> {
+        // include/pcv_hip.h PCV_ABI_VERSION these declarations were written against (2: pcv_ingest_*, PCV_STAGE_SORT_SECOND)
+        if unsafe { pcv_abi_version() } != 2 {
+            return Err(format!("libpcv_hip.so has ABI version {}, this veneer expects 2", unsafe { pcv_abi_version() }));
+        }
         let mut ctx = std::ptr::null_mut();
         match unsafe { pcv_ctx_create(device, std::ptr::null_mut(), &mut ctx) } {
             0 => Ok(HipContext(ctx)),

@@ -20,7 +20,7 @@ def test_library_loads_and_exports_declared_abi():
     for name in sorted(declared):
         assert hasattr(lib, name), f"libpcv_hip.so does not export {name}"
     assert declared == set(_lib.exported_symbols()), declared ^ set(_lib.exported_symbols())
-    assert lib.pcv_abi_version() == 1
+    assert lib.pcv_abi_version() == 2
 
 
 def test_level_table_matches_oracle():
