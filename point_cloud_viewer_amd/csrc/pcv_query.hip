@@ -579,12 +579,17 @@ struct QTree {
 // K7b: one wave per frustum. Lanes 0..7 run the SAT + size_on_screen of the popped node's children side by side;
 // lane 0 owns the BinaryHeap (std's pop / push sift order restated, so the pop order is the reference's). The first
 // kHeapLds heap slots live in LDS, anything deeper in the frustum's global scratch (m entries).
+// Round 6: an entry carries what popping it needs — the node's first child, its child mask, whether it holds points — fetched
+// when the node was PUSHED (beside the SAT / size arithmetic of its siblings), so a pop is followed by ONE global load (the node's
+// cube; its children's cubes are Node::get_child steps from it, node.rs:190-211) instead of two dependent rounds of them.
 struct HeapEntry {
   double size;
   uint32_t node;
-  uint32_t relation;
+  uint32_t first_child;
+  uint32_t bits;  // child mask in bits 0..7, bit 8: Relation::Cross (else In), bit 9: the node holds no points
+  uint32_t pad;
 };
-constexpr uint32_t kHeapLds = 384;  // 16 B entries: 4 waves x 6 KiB per workgroup
+constexpr uint32_t kHeapLds = 256;  // 24 B entries: 4 waves x 6 KiB per workgroup
 struct WaveHeap {
   HeapEntry* lds;
   HeapEntry* glb;  // indexed by heap slot too (its first kHeapLds slots stay unused)
@@ -664,30 +669,41 @@ __global__ __launch_bounds__(256) void visible_nodes_kernel(const PcvShapeDev* _
   if (t.m > 0 && lane == 0) {  // maybe_push_node(root, Cross)
     double sz = size_on_screen(s->clip_from_query, t.cubes[0], t.cubes[1], t.cubes[2], t.cubes[3]);
     if (sz != sz) st = 2;
-    d.set(0, HeapEntry{sz, 0u, 1u});
+    d.set(0, HeapEntry{sz, 0u, t.first_child[0], (uint32_t)t.child_mask[0] | 0x100u | (t.empty[0] ? 0x200u : 0u), 0u});
     len = 1;
   }
+  const bool all_points = s->kind == PCV_SHAPE_ALL;
   for (;;) {
     if (!__shfl((int)(len > 0 && st == 0), 0)) break;
-    uint32_t node = 0, relation = 0;
+    uint32_t node = 0, first = 0, bits = 0;
     if (lane == 0) {
       const HeapEntry item = heap_pop(d, len);
       node = item.node;
-      relation = item.relation;
+      first = item.first_child;
+      bits = item.bits;
     }
-    node = (uint32_t)__shfl((int)node, 0);
-    relation = (uint32_t)__shfl((int)relation, 0);
-    const uint32_t mask = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)t.child_mask[node]);
-    // maybe_push_node on the children that exist (round 6: the wave's lanes are the shape's AXES — lanes 0-31 test one child,
-    // lanes 32-63 the next, three ballots give both Relations — and a kept child's size on screen is computed by eight lanes, one
-    // corner each; one lane per child with the 26 axes and the 8 corners in loops left 56 lanes idle for ~3 000 instructions per pop)
-    const uint32_t c = t.first_child[node] + (uint32_t)__popc(mask & ((1u << (lane & 7)) - 1u));
-    double4 cb = make_double4(0, 0, 0, 0);
-    if (lane < 8 && ((mask >> lane) & 1u)) cb = *reinterpret_cast<const double4*>(t.cubes + 4 * (uint64_t)c);  // Node::get_child cubes
+    node = (uint32_t)__builtin_amdgcn_readfirstlane((int)node);  // (lane 0 is the first active lane)
+    first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
+    bits = (uint32_t)__builtin_amdgcn_readfirstlane((int)bits);
+    const uint32_t mask = bits & 0xffu;
+    const bool cross_parent = (bits & 0x100u) != 0u;
+    // the popped node's cube (one address for the wave) — the only load a pop waits for
+    const double4 pc = *reinterpret_cast<const double4*>(t.cubes + 4 * (uint64_t)node);
+    // what the children's own entries will need, requested now (lanes 0-7), used when they are pushed
+    const uint32_t c = first + (uint32_t)__popc(mask & ((1u << (lane & 7)) - 1u));
+    uint32_t cbits = 0, cfirst = 0;
+    if (lane < 8 && ((mask >> lane) & 1u)) {
+      cbits = (uint32_t)t.child_mask[c] | (t.empty[c] ? 0x200u : 0u);
+      cfirst = t.first_child[c];
+    }
+    const double half = pc.w / 2.;  // Node::get_child (node.rs:190-211): min += half only where the bit is set
+    // maybe_push_node on the children that exist: the wave's lanes are the shape's AXES — lanes 0-31 test one child, lanes 32-63
+    // the next, two ballots give both Relations — and a kept child's size on screen is computed by eight lanes, one corner each
+    // (one lane per child with the 26 axes and the 8 corners in loops left 56 lanes idle for ~3 000 instructions per pop)
     uint32_t kept_mask = mask, cross_mask = 0;  // children of an In node are In without a test (octree/mod.rs:261-272)
-    if (relation == 1u && s->kind == PCV_SHAPE_ALL) {
+    if (cross_parent && all_points) {
       cross_mask = mask;  // sat_cube: AllPoints is "not Out" of everything, reported as Cross
-    } else if (relation == 1u) {
+    } else if (cross_parent) {
       kept_mask = 0;
       for (uint32_t rest = mask; rest != 0u;) {
         const uint32_t d0 = (uint32_t)__builtin_ctz(rest);
@@ -695,9 +711,8 @@ __global__ __launch_bounds__(256) void visible_nodes_kernel(const PcvShapeDev* _
         const uint32_t d1 = rest ? (uint32_t)__builtin_ctz(rest) : 8u;
         rest &= rest - 1u;
         const uint32_t digit = lane < 32u ? d0 : d1;
-        const int src = (int)(digit & 7u);
-        const double cx = __shfl(cb.x, src), cy = __shfl(cb.y, src), cz = __shfl(cb.z, src), ce = __shfl(cb.w, src);
-        const AxisTest at = cull_axis_test(on && digit < 8u, ax, ay, az, amin, amax, cx, cy, cz, ce);
+        const double cx = (digit & 4u) ? pc.x + half : pc.x, cy = (digit & 2u) ? pc.y + half : pc.y, cz = (digit & 1u) ? pc.z + half : pc.z;
+        const AxisTest at = cull_axis_test(on && digit < 8u, ax, ay, az, amin, amax, cx, cy, cz, half);
         const uint64_t sep = __ballot(at.sep), cross = __ballot(at.cross);
         if ((uint32_t)sep == 0u) {
           kept_mask |= 1u << d0;
@@ -714,24 +729,24 @@ __global__ __launch_bounds__(256) void visible_nodes_kernel(const PcvShapeDev* _
       const uint32_t g = lane >> 3;
       uint32_t mk = kept_mask;
       for (uint32_t i = 0; i < g && mk; ++i) mk &= mk - 1u;
-      const int src = (int)(mk ? __builtin_ctz(mk) : __builtin_ctz(kept_mask));  // (idle groups redo the first: no divergence)
-      const double cx = __shfl(cb.x, src), cy = __shfl(cb.y, src), cz = __shfl(cb.z, src), ce = __shfl(cb.w, src);
-      sz = size_on_screen_by_corner(s->clip_from_query, cx, cy, cz, ce, lane & 7u);
+      const uint32_t dg = (uint32_t)(mk ? __builtin_ctz(mk) : __builtin_ctz(kept_mask));  // (idle groups redo the first: no divergence)
+      const double cx = (dg & 4u) ? pc.x + half : pc.x, cy = (dg & 2u) ? pc.y + half : pc.y, cz = (dg & 1u) ? pc.z + half : pc.z;
+      sz = size_on_screen_by_corner(s->clip_from_query, cx, cy, cz, half, lane & 7u);
     }
     uint32_t g = 0;
     for (int ci = 0; ci < 8; ++ci) {  // pushes in child order, like the reference's loop
       if (!((kept_mask >> ci) & 1u)) continue;  // (wave-uniform)
       const double z = __shfl(sz, (int)(8u * g));
-      const uint32_t cc = (uint32_t)__shfl((int)c, ci);
+      const uint32_t cc = (uint32_t)__shfl((int)c, ci), cf = (uint32_t)__shfl((int)cfirst, ci), cb = (uint32_t)__shfl((int)cbits, ci);
       ++g;
       if (lane == 0) {
         if (z != z) st = 2;
-        d.set(len, HeapEntry{z, cc, (cross_mask >> ci) & 1u});
+        d.set(len, HeapEntry{z, cc, cf, cb | (((cross_mask >> ci) & 1u) << 8), 0u});
         heap_sift_up(d, 0, len);
         ++len;
       }
     }
-    if (lane == 0 && !t.empty[node]) {
+    if (lane == 0 && !(bits & 0x200u)) {
       if (nout < capacity) o[nout] = node;
       ++nout;
     }
