@@ -77,11 +77,18 @@ def test_random_shapes_relations_equal_oracle(ctx, scene, seed):
         c, _ = O.frustum_new(eye, _unit_quat(rng), persp)
         shapes.append(("frustum", c))
         want_kind.append((O.SHAPE_FRUSTUM, np.asarray(c, dtype=np.float64).ravel()))
-    rel = scene["tree"].cull_nodes(ctx.shapes(shapes))
+    prepared = ctx.shapes(shapes)
+    rel = scene["tree"].cull_nodes(prepared)
+    # round 6: the per-shape lists come from a walk down the tree that may skip a subtree only under a node that is Out by a
+    # margin — boxes ON and one ulp beside the cube planes are exactly where that margin decides; the lists must be the rows'
+    counts, idx, srel, _ = scene["tree"].cull_nodes_sparse(prepared, scene["tree"].num_nodes, with_sizes=False)
     seen = set()
     for i, (kind, params) in enumerate(want_kind):
         want = O.cull_cubes(kind, params, scene["cubes"])
         assert np.array_equal(rel[i], want), (seed, i, shapes[i][0])
+        keep = np.nonzero(want != 2)[0]
+        assert counts[i] == keep.size and np.array_equal(idx[i, :keep.size], keep) and np.array_equal(srel[i, :keep.size], want[keep]), \
+            (seed, i, shapes[i][0], "sparse list")
         seen |= set(np.unique(want).tolist())
     assert {0, 1, 2} <= seen
 
