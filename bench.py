@@ -971,7 +971,7 @@ def final_line(out):
                               "ms": rs.get("ms")}}
     cpu = out.get("cpu_baseline")
     if cpu:
-        cpu = dict(cpu, sample=str(cpu.get("sample", ""))[:200])
+        cpu = {k: (str(v)[:200] if k == "sample" else v) for k, v in cpu.items() if k != "note"}
     cfg = out.get("config") or {}
     sh = out.get("sharded") or None
     parity = {"config2": _leg_parity(out, "parity") if out.get("parity") else None,
@@ -1521,9 +1521,9 @@ def main():
                 shutil.rmtree(d, ignore_errors=True)
         cpu = None if cdt is None else {"value": round(m / cdt / 1e6, 3), "unit": "Mpoints/s", "cores": cores, "kind": "port",
                "sample": f"first {m} points of the same cloud, literal file-streaming restatement of the reference "
-                         f"(oracle/pcv_oracle_build.cpp) incl. node-file writes on tmpfs, {cores} OpenMP threads, {cdt:.1f} s; "
-                         "scope differs from `value` (device-resident build without file writes) — the like-for-like "
-                         "figure is end_to_end.Mpoints_per_s_incl_files"}
+                         f"(oracle/pcv_oracle_build.cpp) incl. node files on tmpfs, {cores} OpenMP threads, {cdt:.1f} s",
+               "note": "scope differs from `value` (device-resident build without file writes) — the like-for-like figure is "
+                       "end_to_end.Mpoints_per_s_incl_files"}
 
     e2e = None
     if rank == 0 and world == 1 and not args.no_e2e and not sharded:
