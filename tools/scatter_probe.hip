@@ -90,6 +90,66 @@ __global__ __launch_bounds__(1024) void runs_kernel(const uint32_t* __restrict__
     }
   }
 }
+// round 6: the same pattern with the record as ONE 12-byte element (key and payload side by side): a run of R records is one
+// contiguous piece of 12 R bytes instead of two pieces of 4 R and 8 R bytes — half as many write streams, half as many partial
+// lines where runs begin and end
+struct Rec12 {
+  uint32_t a, b, c;
+};
+template <int LOG_R>
+__global__ __launch_bounds__(1024) void runs_aos_kernel(const Rec12* __restrict__ in, Rec12* __restrict__ out, uint32_t chunk, uint32_t groups,
+                                                        uint32_t stride_d, uint32_t stride_g, uint32_t skew_on) {
+  constexpr uint32_t R = 1u << LOG_R;
+  const uint32_t g = blockIdx.x, t = threadIdx.x;
+  const uint64_t in0 = (uint64_t)g * chunk;
+  Rec12 r[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = in[in0 + j * 1024 + t];
+  const uint32_t tiles = chunk >> 13;
+  for (uint32_t tile = 0; tile < tiles; ++tile) {
+    Rec12 r2[8];
+    if (tile + 1 < tiles) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r2[j] = in[in0 + (uint64_t)(tile + 1) * 8192 + j * 1024 + t];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t p = j * 1024 + t, d = p >> LOG_R;
+      const uint32_t skew = skew_on ? ((d * 131u + g * 17u) & 31u) | 1u : 0u;
+      out[(uint64_t)d * stride_d + (uint64_t)g * stride_g + skew + tile * R + (p & (R - 1u))] = r[j];
+    }
+    if (tile + 1 < tiles) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r[j] = r2[j];
+    }
+  }
+}
+template <int LOG_R>
+static int time_runs_aos(const void* in, void* out, uint32_t chunk, uint32_t groups, uint32_t skew, hipEvent_t a, hipEvent_t b, double bytes) {
+  const uint32_t D = 8192u >> LOG_R;
+  const uint32_t per = chunk / D + 64;
+  const uint32_t stride_g = (per + 63u) & ~63u;
+  const uint32_t stride_d = stride_g * groups;
+  float best = 1e9f, sum = 0;
+  for (int rep = 0; rep < 6; ++rep) {
+    CK(hipEventRecord(a));
+    hipLaunchKernelGGL((runs_aos_kernel<LOG_R>), dim3(groups), dim3(1024), 0, 0, (const Rec12*)in, (Rec12*)out, chunk, groups, stride_d, stride_g, skew);
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    float ms;
+    CK(hipEventElapsedTime(&ms, a, b));
+    if (rep) {
+      best = std::min(best, ms);
+      sum += ms;
+    }
+  }
+  printf("{\"pattern\": \"runs, 12-byte records as ONE array\", \"run_records\": %u, \"digit_values\": %u, \"bases\": \"%s\", \"best_ms\": %.4f, "
+         "\"mean_ms\": %.4f, \"GBps_best\": %.1f, \"frac_of_8TBps\": %.3f}\n",
+         1u << LOG_R, D, skew ? "skewed (odd record offsets)" : "aligned", best, sum / 5, bytes / (best * 1e-3) / 1e9, bytes / (best * 1e-3) / 8e12);
+  fflush(stdout);
+  return 0;
+}
+
 __global__ __launch_bounds__(1024) void copy12_kernel(const uint32_t* __restrict__ kin, const uint2* __restrict__ vin, uint32_t* __restrict__ kout,
                                                       uint2* __restrict__ vout, uint32_t chunk) {
   const uint64_t in0 = (uint64_t)blockIdx.x * chunk;
@@ -197,6 +257,19 @@ static int run_runs(uint64_t n_req) {
     }
     printf("{\"pattern\": \"straight copy (same arrays, same workgroups)\", \"best_ms\": %.4f, \"GBps_best\": %.1f, \"frac_of_8TBps\": %.3f}\n", best,
            bytes / (best * 1e-3) / 1e9, bytes / (best * 1e-3) / 8e12);
+  }
+  {  // round 6: the AoS form, in buffers of its own (12 n bytes each way, the same padding)
+    void *ain, *aout;
+    CK(hipMalloc(&ain, n * 12));
+    CK(hipMalloc(&aout, room * 12));
+    CK(hipMemset(ain, 3, n * 12));
+    for (uint32_t skew = 0; skew < 2; ++skew) {
+      if (time_runs_aos<5>(ain, aout, chunk, groups, skew, a, b, bytes)) return 1;
+      if (time_runs_aos<6>(ain, aout, chunk, groups, skew, a, b, bytes)) return 1;
+      if (time_runs_aos<7>(ain, aout, chunk, groups, skew, a, b, bytes)) return 1;
+    }
+    CK(hipFree(ain));
+    CK(hipFree(aout));
   }
   for (uint32_t skew = 0; skew < 2; ++skew) {
     if (time_runs<5, false>(kin, vin, kout, vout, chunk, groups, skew, a, b, bytes)) return 1;
