@@ -576,6 +576,12 @@ def query_leg(args, ctx, tree):
     vis_ms = ks[1] / ks[0]
     nvis = np.array([len(v) for v in vis])
 
+    # PointCloud::nodes_in_location (octree/mod.rs:309-323) of every frustum: the hierarchical walk (round 6: one wave per shape)
+    tree.nodes_in_location(shapes)
+    ctx.reset_kernel_stats()
+    nil = tree.nodes_in_location(shapes)
+    nil_ms = ctx.kernel_stats()["nodes_in_location_kernel"][1]
+
     ctx.reset_kernel_stats()
     kept = 0
     kept_each = []
@@ -614,6 +620,11 @@ def query_leg(args, ctx, tree):
         sparse_bad += int(not (k == keep.size and np.array_equal(sp_idx[f, :k], keep) and np.array_equal(sp_rel[f, :k], orel[keep]) and
                                np.array_equal(sp_sizes[f, :k], osz[keep], equal_nan=True)))
     cpu_a = time.perf_counter() - t0
+    # nodes_in_location: the walk prunes under every Out node, the sparse list holds every node that is not Out — the same list
+    # unless a child of an Out node is itself not Out (an ulp-level tie); against the oracle's NodeIdsIterator for the first 1 000
+    nil_bad = sum(int(not np.array_equal(np.asarray(nil[f], dtype=np.int64), sp_idx[f, :int(sp_counts[f])].astype(np.int64))) for f in range(V))
+    nil_oracle_bad = sum(int([names[int(i)] for i in nil[f]] != O.nodes_in_location(bmin, bmax, nodes, O.SHAPE_FRUSTUM, mats[f]))
+                         for f in range(min(V, 1000)))
     t0 = time.perf_counter()
     for f in range(V):
         want = O.get_visible_nodes(bmin, bmax, nodes, mats[f])
@@ -662,6 +673,9 @@ def query_leg(args, ctx, tree):
             "visible_nodes": {"kernel_ms": round(vis_ms, 3), "frusta_per_s": round(args.frusta / (vis_ms * 1e-3), 1),
                               "mean_visible": float(nvis.mean()), "max_visible": int(nvis.max()),
                               "status_nonzero": int((status != 0).sum())},
+            "nodes_in_location": {"kernel_ms": round(nil_ms, 3), "frusta_per_s": round(args.frusta / (nil_ms * 1e-3), 1),
+                                  "listed_nodes": int(sum(len(v) for v in nil)),
+                                  "api": "pcv_nodes_in_location: NodeIdsIterator's walk (children only under a node that is not Out) of every frustum"},
             "query_points": {"frusta": args.cull_frusta, "kept_points": int(kept), "kernel_ms": round(q_ms, 3),
                              "kernel_ms_split": q_split},
             "roofline": {"bound": "hbm", "kernel": "query_flags_kernel", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
@@ -673,10 +687,13 @@ def query_leg(args, ctx, tree):
             "parity": {"oracle": "CPU restatement (oracle/pcv_oracle_query.cpp), not the Rust binary", "frusta_checked": V,
                        "pairs_checked": V * M, "relation_mismatches": rel_bad, "size_on_screen_mismatches": size_bad,
                        "sparse_list_mismatches": sparse_bad, "visible_list_mismatches": vis_bad,
+                       "nodes_in_location_vs_sparse_lists_mismatches": nil_bad,
+                       "nodes_in_location_vs_oracle_mismatches_first_1000": nil_oracle_bad,
                        "query_points_frusta_checked": min(args.cull_frusta, args.verify_cull_frusta),
                        "query_points_points_checked": pts_checked, "query_points_count_mismatches": cnt_bad,
                        "query_points_content_mismatches": pts_bad, "query_points_check_s": round(cpu_c, 1),
-                       "ok": rel_bad == 0 and size_bad == 0 and sparse_bad == 0 and vis_bad == 0 and cnt_bad == 0 and pts_bad == 0},
+                       "ok": (rel_bad == 0 and size_bad == 0 and sparse_bad == 0 and vis_bad == 0 and cnt_bad == 0 and pts_bad == 0 and
+                              nil_oracle_bad == 0)},
             "cpu_baseline": None if V == 0 else {
                 "value": round(V * M / cpu_a / 1e6, 3), "unit": "Mpairs/s", "cores": 1, "kind": "port",
                 "sample": f"first {V} frusta x {M} nodes, SAT relation + size on screen, {cpu_a:.1f} s; "

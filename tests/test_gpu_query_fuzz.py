@@ -91,6 +91,12 @@ def test_random_shapes_relations_equal_oracle(ctx, scene, seed):
             (seed, i, shapes[i][0], "sparse list")
         seen |= set(np.unique(want).tolist())
     assert {0, 1, 2} <= seen
+    # ... and PointCloud::nodes_in_location (octree/mod.rs:309-323) of every shape — the same walk, pruning under EVERY Out node —
+    # against the oracle's NodeIdsIterator
+    got = scene["tree"].nodes_in_location(prepared)
+    on, names = scene["oracle"].nodes, scene["names"]
+    for i, (kind, params) in enumerate(want_kind):
+        assert [names[k] for k in got[i]] == O.nodes_in_location(scene["bmin"], scene["bmax"], on, kind, params), (seed, i, shapes[i][0])
 
 
 @pytest.mark.parametrize("seed", range(3))
