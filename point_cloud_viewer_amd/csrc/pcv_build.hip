@@ -761,16 +761,18 @@ static int stage_points(pcv_ctx* ctx, PcvScratch& sc, const pcv_points* p, bool 
   return PCV_OK;
 }
 
-static int device_aabb(pcv_ctx* ctx, PcvScratch& sc, const DevPoints& d, double bmin[3], double bmax[3]) {
-  if (d.n == 0) {  // Aabb::zero() (generation.rs:269)
-    for (int a = 0; a < 3; ++a) bmin[a] = bmax[a] = 0.;
-    return PCV_OK;
-  }
+static void host_lap(const char* what, bool reset = false);
+// K1 in two halves, so that the caller can do host work (allocations) while the reduction runs.
+// The final kernel stores the six doubles straight into the pinned mailbox (host memory the device can write), which holds a
+// sentinel until then: the host polls the mailbox instead of waiting for the stream — the blocked wait of a stream synchronize
+// wakes up 20-30 us after a 0.4 ms kernel has ended, the poll sees the stores within a few.
+static const uint64_t kAabbSentinel = 0x7ff8dead0badbeefull;  // a NaN no fmin / fmax reduction of the kernel can produce
+static int device_aabb_launch(pcv_ctx* ctx, PcvScratch& sc, const DevPoints& d) {
   double* partial;
   int rc = sc.get(&partial, (size_t)2048 * 6 + 6);
   if (rc) return rc;
-  // the final kernel stores the six doubles straight into the pinned mailbox (host memory the device can write): no copy
-  // kernel between the reduction and the host's wait
+  for (int a = 0; a < 6; ++a) ctx->mailbox[a] = kAabbSentinel;  // nothing queued on the stream writes these slots before the kernel does
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);
   double* out6 = (double*)ctx->mailbox_dev;
   // the 16-byte vector loads need aligned bases; fall back to staging when the caller's views are not
   if (((uintptr_t)d.x | (uintptr_t)d.y | (uintptr_t)d.z) & 15) {
@@ -783,14 +785,43 @@ static int device_aabb(pcv_ctx* ctx, PcvScratch& sc, const DevPoints& d, double 
   } else {
     pcv_launch_aabb(ctx, d.n, d.x, d.y, d.z, partial, out6);
   }
+  PCV_HIP_CHECK(ctx, hipGetLastError());
+  return PCV_OK;
+}
+static int device_aabb_wait(pcv_ctx* ctx, double bmin[3], double bmax[3]) {
+  static const bool poll_on = [] {
+    const char* e = pcv_experiment("PCV_AABB_POLL");  // experiments: 0 = wait for the stream
+    return !e || atoi(e) != 0;
+  }();
+  host_lap("", true);
+  volatile uint64_t* box = ctx->mailbox;
+  bool seen = false;
+  if (poll_on) {
+    for (uint32_t spin = 0; !seen; ++spin) {
+      seen = true;
+      for (int a = 0; a < 6; ++a) seen = seen && box[a] != kAabbSentinel;
+      // every few thousand reads: is the stream still alive? (a failed launch would never deliver)
+      if (!seen && (spin & 0xfff) == 0xfff && hipStreamQuery(ctx->stream) != hipErrorNotReady) break;
+    }
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+  }
+  if (!seen) PCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  host_lap("bbox: wait");
   double h[6];
-  PCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   std::memcpy(h, ctx->mailbox, sizeof(h));
   for (int a = 0; a < 3; ++a) {
     bmin[a] = h[a];
     bmax[a] = h[3 + a];
   }
   return PCV_OK;
+}
+static int device_aabb(pcv_ctx* ctx, PcvScratch& sc, const DevPoints& d, double bmin[3], double bmax[3]) {
+  if (d.n == 0) {  // Aabb::zero() (generation.rs:269)
+    for (int a = 0; a < 3; ++a) bmin[a] = bmax[a] = 0.;
+    return PCV_OK;
+  }
+  int rc = device_aabb_launch(ctx, sc, d);
+  return rc ? rc : device_aabb_wait(ctx, bmin, bmax);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1044,7 +1075,7 @@ extern "C" int pcv_build_begin_routed(pcv_ctx* ctx, const pcv_build_params* para
 // sort kernel queued), printed to stderr
 #include <atomic>
 #include <chrono>
-static void host_lap(const char* what, bool reset = false) {
+static void host_lap(const char* what, bool reset) {
   static const bool on = pcv_experiment("PCV_HOST_TIMING") != nullptr;
   static std::chrono::steady_clock::time_point t0;
   if (!on) return;
@@ -1218,7 +1249,7 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
   uint32_t *d_ord, *d_walk, *d_sparent, *d_info, *d_counts, *d_map, *d_pool_ctr;
   uint8_t* d_slevel;
   if ((rc = sc.get(&d_ord, nt.capacity)) || (rc = sc.get(&d_walk, tcap)) || (rc = sc.get(&d_sparent, tcap)) ||
-      (rc = sc.get(&d_slevel, tcap)) || (rc = sc.get(&d_info, 64)) || (rc = sc.get(&d_pool_ctr, kPcvPoolRegions + tcap)) ||
+      (rc = sc.get(&d_slevel, tcap)) || (rc = sc.get(&d_info, 64)) || (rc = sc.get(&d_pool_ctr, kPcvPoolRegions + tcap + 4)) ||
       (rc = sc.get(&d_map, tcap)))
     return rc;
   d_counts = d_pool_ctr + kPcvPoolRegions;  // the pool counters and the exact counts travel to the host in ONE copy
@@ -1286,7 +1317,17 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
       const char* e = pcv_experiment("PCV_SAMPLE_CLUMP_SHIFT");  // experiments: 0 = single points
       return e ? (uint32_t)std::min(6, std::max(0, atoi(e))) : 3u;
     }();
-    pcv_launch_chain_keys(ctx, lv, ns, stride, d.x, d.y, d.z, skeys_a, false, d.routed, stride > 1 ? clump_shift : 0u);
+    // the key sort of the sample: one launch per 9-bit digit (pcv_sort_keys_onesweep); chain_keys clears its counters on the way
+    static const bool onesweep_on = [] {
+      const char* e = pcv_experiment("PCV_SAMPLE_ONESWEEP");  // libpcv_hip_exp.so: 1 = on (measured: no faster, see pcv_sort.hip)
+      return e && atoi(e) != 0;
+    }();
+    host_lap("bbox -> sample keys");
+    uint32_t* one = nullptr;
+    const int sbits = 3 * sample_levels;
+    if (onesweep_on && pcv_onesweep_fits(ns, sbits) && (rc = sc.get(&one, pcv_onesweep_scratch_words(ns, sbits) + 4))) return rc;
+    pcv_launch_chain_keys(ctx, lv, ns, stride, d.x, d.y, d.z, skeys_a, false, d.routed, stride > 1 ? clump_shift : 0u, one,
+                          one ? pcv_onesweep_zero_words(ns, sbits) : 0);
     bool in_a = true;
     host_lap("", true);
     // PCV_SAMPLE_COUNTS=1 (libpcv_hip_exp.so only): the sample tree by COUNTING the keys, three levels per launch pair
@@ -1311,9 +1352,10 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
     }
 #endif
     if (!counted) {
-    if ((rc = pcv_radix_sort_u64(ctx, skeys_a, skeys_b, ns, 3 * (PCV_MAX_KEY_LEVELS - sample_levels), 3 * PCV_MAX_KEY_LEVELS,
-                                 nullptr, bs->sort_scratch, &in_a)))
-      return rc;
+    if (one) rc = pcv_sort_keys_onesweep(ctx, skeys_a, skeys_b, ns, 3 * (PCV_MAX_KEY_LEVELS - sample_levels), 3 * PCV_MAX_KEY_LEVELS, one, &in_a);
+    else rc = pcv_radix_sort_u64(ctx, skeys_a, skeys_b, ns, 3 * (PCV_MAX_KEY_LEVELS - sample_levels), 3 * PCV_MAX_KEY_LEVELS, nullptr,
+                                 bs->sort_scratch, &in_a);
+    if (rc) return rc;
     host_lap("sample sort queued");
     pcv_launch_node_split(ctx, nt, in_a ? skeys_a : skeys_b, false, (uint32_t)ns, lv, params->resolution, thr_s, sp.force_mask);
     host_lap("sample split queued");
@@ -1342,8 +1384,14 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
       return e && atoi(e) != 0;
     }();
     bs->color_late = color_late_on && compact;
+    // the exact counters (d_counts) are cleared by the depth-grid kernel in front of the pass where there is one; small builds
+    // clear them with a fill on `stream`
+    const size_t counts_words = (tcap + 3) & ~(size_t)3;
+    const bool zero_in_grid = depth_grid && (((uintptr_t)d_counts & 15) == 0);
+    if (!zero_in_grid) PCV_HIP_CHECK(ctx, hipMemsetAsync(d_counts, 0, tcap * 4, st));
     pcv_launch_spec_encode(ctx, lv, d_walk, n, d.x, d.y, d.z, d.routed, d.color, d.color_stride, d.intensity, rank, payload,
-                           inten_bits, depth_grid, wide, d_pool_ctr /* zeroed by the spec_tree kernels */, d_info, bs->color_late);
+                           inten_bits, depth_grid, wide, d_pool_ctr /* zeroed by the spec_tree kernels */, d_info, bs->color_late,
+                           zero_in_grid ? d_counts : nullptr, zero_in_grid ? counts_words : 0);
     ctx->stage_end(PCV_STAGE_LEAF_ENCODE);
     host_lap("chain pass queued");
 
@@ -1353,14 +1401,9 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
     PCV_HIP_CHECK(ctx, hipMemcpyAsync(hs + h_parent, d_sparent, first * 4, hipMemcpyDeviceToHost, ctx->side));
     PCV_HIP_CHECK(ctx, hipMemcpyAsync(hs + h_level, d_slevel, first, hipMemcpyDeviceToHost, ctx->side));
     PCV_HIP_CHECK(ctx, hipEventRecord(ctx->spec_ev, ctx->side));
-    PCV_HIP_CHECK(ctx, hipMemsetAsync(d_counts, 0, tcap * 4, ctx->side));
-    PCV_HIP_CHECK(ctx, hipEventRecord(ctx->side_join, ctx->side));  // `stream` waits for it below
 
     // ---- meanwhile: the host's view of the tree ----
     PCV_HIP_CHECK(ctx, hipEventSynchronize(ctx->spec_ev));
-    // whatever is queued on `stream` from here on (the counting pass, a second round, the exact pipeline) comes after
-    // the side stream's zero fill of the counters
-    PCV_HIP_CHECK(ctx, hipStreamWaitEvent(st, ctx->side_join, 0));
     std::memcpy(info, hs, sizeof(info));
     if (info[1] & 2u) return PCV_OK;  // table capacity: let the exact pipeline report it
     if (info[1] & 1u) {               // deeper than the sample keys
@@ -1422,8 +1465,11 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
   uint32_t* h_pool = (uint32_t*)hp;
   uint32_t* h_counts = h_pool + kPcvPoolRegions;
   const size_t map_off = (((size_t)kPcvPoolRegions + tree.num_leaves) * 4 + 255) & ~(size_t)255;
-  PCV_HIP_CHECK(ctx, hipMemcpyAsync(h_pool, d_pool_ctr, ((size_t)kPcvPoolRegions + tree.num_leaves) * 4, hipMemcpyDeviceToHost, st));
-  PCV_HIP_CHECK(ctx, hipEventRecord(ctx->spec_ev, st));  // the counts are on their way to the host
+  // (the copy travels on the side stream, behind an event of `stream`: a copy command between the count and the resolve kernel costs
+  // `stream` two hand-overs of ~10 us; nothing queued on `stream` later writes these counters)
+  if (ctx->side_begin() != PCV_OK) return ctx->fail(PCV_E_HIP, "single-chain build: side stream");
+  PCV_HIP_CHECK(ctx, hipMemcpyAsync(h_pool, d_pool_ctr, ((size_t)kPcvPoolRegions + tree.num_leaves) * 4, hipMemcpyDeviceToHost, ctx->side));
+  PCV_HIP_CHECK(ctx, hipEventRecord(ctx->spec_ev, ctx->side));  // the counts are on their way to the host
   // The map the record sort needs is computed on the device (spec_resolve_kernel), and the sort is queued behind it right
   // away: the counts' trip to the host, the host's own resolve and the table building all happen beside the sort instead
   // of in front of it. The sort's digit widths come from the number of PREDICTED leaves (an upper bound of the true
@@ -1594,7 +1640,15 @@ static int build_begin_impl(pcv_ctx* ctx, const pcv_build_params* params, const 
   }
 
   double bmin[3], bmax[3];
-  if (params->flags & PCV_BUILD_COMPUTE_BBOX) {
+  if ((params->flags & PCV_BUILD_COMPUTE_BBOX) && n > 0) {
+    // K1 is queued; the build's three big scratch blocks are taken from the pool while it runs (the host has nothing else to do
+    // for 0.4 ms at 100 M points, and these calls are the slow ones of what follows the box)
+    if ((rc = device_aabb_launch(ctx, sc, d))) return rc;
+    if ((rc = sc.get(&bs->keys_a, n)) || (rc = sc.get(&bs->keys_b, n))) return rc;
+    if ((rc = ctx->dev_alloc(&bs->sort_scratch, pcv_sort_scratch_bytes(n)))) return rc;
+    sc.ptrs.push_back(bs->sort_scratch);
+    if ((rc = device_aabb_wait(ctx, bmin, bmax))) return rc;
+  } else if (params->flags & PCV_BUILD_COMPUTE_BBOX) {
     if ((rc = device_aabb(ctx, sc, d, bmin, bmax))) return rc;
   } else {
     for (int a = 0; a < 3; ++a) {
@@ -1632,9 +1686,11 @@ static int build_begin_impl(pcv_ctx* ctx, const pcv_build_params* params, const 
   uint64_t*& keys_a = bs->keys_a;
   uint64_t*& keys_b = bs->keys_b;
   void*& sort_scratch = bs->sort_scratch;
-  if ((rc = sc.get(&keys_a, n)) || (rc = sc.get(&keys_b, n))) return rc;
-  if ((rc = ctx->dev_alloc(&sort_scratch, pcv_sort_scratch_bytes(n)))) return rc;
-  sc.ptrs.push_back(sort_scratch);
+  if (!keys_a) {  // (taken while K1 ran when the build computes its own box)
+    if ((rc = sc.get(&keys_a, n)) || (rc = sc.get(&keys_b, n))) return rc;
+    if ((rc = ctx->dev_alloc(&sort_scratch, pcv_sort_scratch_bytes(n)))) return rc;
+    sc.ptrs.push_back(sort_scratch);
+  }
   const int full_levels = lv.nlevels;
   int spec_levels = full_levels;
 
@@ -2151,6 +2207,9 @@ extern "C" int pcv_build_finish(pcv_octree* t, const pcv_top_layout* top) {
   if (!bs->spec) PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_up, u_walk, (size_t)M * 8, hipMemcpyHostToDevice, up_st));  // K5 only
   PCV_HIP_CHECK(ctx, hipMemcpyAsync(d_up + walk_bytes, u_node_rec, rec_bytes, hipMemcpyHostToDevice, up_st));
   if (up_side && (rc = ctx->side_end())) return ctx->fail(rc, "side stream");
+  // (the side stream is in order: this join also covers the layout of the record sort's held-back pass, queued there before the
+  // tables — one cross-stream wait in front of that pass instead of two, each ~10 us of idle stream)
+  if (up_side) bs->sort_second.join_side = false;
   const uint32_t* d_climb_base = (const uint32_t*)(d_up + walk_bytes + (size_t)(M + num_leaves) * sizeof(PcvNodeRec));
   wt.walk = (const uint64_t*)d_up;
   wt.num_nodes = M;

@@ -105,8 +105,10 @@ template <typename KeyT>
 __global__ __launch_bounds__(256) void chain_keys_kernel(PcvLevels lv, uint64_t n, uint64_t stride, uint32_t clump_shift,
                                                           const double* __restrict__ x, const double* __restrict__ y,
                                                           const double* __restrict__ z, PcvRouted routed,
-                                                          KeyT* __restrict__ keys) {
+                                                          KeyT* __restrict__ keys, uint4* __restrict__ zero, uint32_t zero_vecs) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  // the counters of the sort that takes these keys next (pcv_sort_keys_onesweep) are cleared on the way: no launch of their own
+  for (uint64_t j = i; j < zero_vecs; j += (uint64_t)gridDim.x * 256) zero[j] = make_uint4(0u, 0u, 0u, 0u);
   if (i >= n) return;
   // sample i of a strided sample taken in clumps of 2^clump_shift consecutive points (same density: one clump every
   // stride x clump points): a lone 8-byte coordinate costs a whole cache line, a clump uses the line it fetches
@@ -893,16 +895,18 @@ int pcv_launch_aabb(pcv_ctx* ctx, uint64_t n, const double* x, const double* y, 
 
 void pcv_launch_chain_keys(pcv_ctx* ctx, const PcvLevels& lv, uint64_t n, uint64_t stride, const double* x,
                            const double* y, const double* z, void* keys, bool keys32, const PcvRouted& routed,
-                           uint32_t clump_shift) {
+                           uint32_t clump_shift, uint32_t* zero, size_t zero_words) {
   if (n == 0) return;
+  uint4* zv = reinterpret_cast<uint4*>(zero);
+  const uint32_t zn = zero ? (uint32_t)((zero_words + 3) / 4) : 0u;
   uint64_t blocks = (n + 255) / 256;
   PcvProf prof(ctx, PCV_K_CHAIN_KEYS);
   if (keys32)
     hipLaunchKernelGGL(chain_keys_kernel<uint32_t>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, lv, n, stride,
-                       clump_shift, x, y, z, routed, (uint32_t*)keys);
+                       clump_shift, x, y, z, routed, (uint32_t*)keys, zv, zn);
   else
     hipLaunchKernelGGL(chain_keys_kernel<uint64_t>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, lv, n, stride,
-                       clump_shift, x, y, z, routed, (uint64_t*)keys);
+                       clump_shift, x, y, z, routed, (uint64_t*)keys, zv, zn);
 }
 
 void pcv_launch_chain_keys_deep(pcv_ctx* ctx, const PcvLevels& lv, uint64_t n, const double* x, const double* y,

@@ -122,8 +122,12 @@ constexpr int kSpecClasses = 24;  // predicted depth 0..21 (+ padding lanes)
 #endif
 constexpr int kGridBits = PCV_GRID_BITS;  // 128^3 cells, 2 MiB: stays in L2
 
-__global__ __launch_bounds__(256) void spec_depth_grid_kernel(const uint32_t* __restrict__ walk, uint8_t* __restrict__ grid) {
+__global__ __launch_bounds__(256) void spec_depth_grid_kernel(const uint32_t* __restrict__ walk, uint8_t* __restrict__ grid,
+                                                              uint4* __restrict__ zero, uint32_t zero_vecs) {
   const uint32_t c = blockIdx.x * 256 + threadIdx.x;  // grid is exactly 2^21 cells
+  // the exact per-leaf counters of the count that follows the chain pass are cleared here: a fill on the side stream would have
+  // to be joined in front of that count (a cross-stream wait between two kernels is ~15 us of idle stream)
+  for (uint32_t j = c; j < zero_vecs; j += 1u << (3 * kGridBits)) zero[j] = make_uint4(0u, 0u, 0u, 0u);
   constexpr uint32_t kM = (1u << kGridBits) - 1u;
   const uint32_t ix = c & kM, iy = (c >> kGridBits) & kM, iz = c >> (2 * kGridBits);
   uint32_t r = walk[0];
@@ -944,7 +948,7 @@ void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* w
                             uint32_t* inten_bits, uint8_t* depth_grid /* pcv_spec_depth_grid_bytes() of scratch, or null */,
                             void* wide, uint32_t* pool_ctr /* kPcvPoolRegions zeroed counters: entries of `wide` handed out per region */,
                             const uint32_t* tree_info /* device: [0] = number of T'' nodes (spec_tree_scan_kernel's info block) */,
-                            bool color_late) {
+                            bool color_late, uint32_t* zero, size_t zero_words) {
   if (n == 0) return;
   PcvProf prof(ctx, PCV_K_SPEC_ENCODE);
   (void)tree_info;
@@ -952,7 +956,9 @@ void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* w
   const dim3 grid((unsigned)((n + 2 * kBlock - 1) / (2 * kBlock)));
   const float cells = lv.edge[0] > 0.0 ? (float)((double)(1 << kGridBits) / lv.edge[0]) : 0.f;
   const uint32_t pool_cap = (uint32_t)pcv_pool_region_entries(n);
-  if (depth_grid) hipLaunchKernelGGL(spec_depth_grid_kernel, dim3((1u << (3 * kGridBits)) / 256), dim3(256), 0, ctx->stream, walk, depth_grid);
+  if (depth_grid)  // (zero: 16-byte aligned, a multiple of four words — or the caller clears it itself)
+    hipLaunchKernelGGL(spec_depth_grid_kernel, dim3((1u << (3 * kGridBits)) / 256), dim3(256), 0, ctx->stream, walk, depth_grid, (uint4*)zero,
+                       (uint32_t)(zero_words / 4));
   // the first kTop walk records (levels 0-3 of T'' and the start of level 4: the table is level-major) are mirrored in LDS: with
   // the Float32 code steps a shallow level step is shorter than the L2 round trip of its child gather. One call, 100 M points:
   // 0 / 512 / 1 024 / 1 536 / 2 048 / 3 072 records -> 1.92-1.95 / 1.88 / 1.88 / 1.85 / 1.83-1.85 / 2.11 ms (3 072: 39 KB of LDS,

@@ -307,7 +307,8 @@ struct PcvRouted {
 // clump_shift: the strided sample is taken in clumps of 2^clump_shift consecutive points (0 = single points).
 void pcv_launch_chain_keys(pcv_ctx* ctx, const PcvLevels& lv, uint64_t n, uint64_t stride, const double* x,
                            const double* y, const double* z, void* keys, bool keys32, const PcvRouted& routed = PcvRouted(),
-                           uint32_t clump_shift = 0);
+                           uint32_t clump_shift = 0, uint32_t* zero = nullptr /* zero_words words (rounded up to 4) cleared on the way */,
+                           size_t zero_words = 0);
 void pcv_launch_depth_probe(pcv_ctx* ctx, const uint64_t* sorted, uint32_t n, uint32_t gap, uint32_t* out);
 
 // pcv_sort.hip — stable LSD radix sort, 8-bit digits, reduce-then-scan with LDS histograms.
@@ -335,6 +336,13 @@ int pcv_radix_sort_u64(pcv_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint64_
                        PcvSortPayload* payload, void* scratch, bool* result_in_a);
 int pcv_radix_sort_u32(pcv_ctx* ctx, uint32_t* keys_a, uint32_t* keys_b, uint64_t n, int begin_bit, int end_bit,
                        PcvSortPayload* payload, void* scratch, bool* result_in_a);
+// The sample's key sort, one launch per 9-bit digit (pcv_sort.hip: onesweep_keys_kernel). `scratch`: pcv_onesweep_scratch_words
+// words whose first pcv_onesweep_zero_words are zero when the sort starts.
+bool pcv_onesweep_fits(uint64_t n, int bits);
+size_t pcv_onesweep_zero_words(uint64_t n, int bits);
+size_t pcv_onesweep_scratch_words(uint64_t n, int bits);
+int pcv_sort_keys_onesweep(pcv_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint64_t n, int begin_bit, int end_bit, uint32_t* scratch,
+                           bool* result_in_a, int diag = 0 /* timing-only variants (pcv_exp_time_key_sort, libpcv_hip_exp.so) */);
 
 // rows (pcv_launch_rank_hist_rows, map_entries counters per sort workgroup): the first pass takes its histogram from them and
 // applies the map inside its downsweep — the keys are not read an extra time
@@ -461,7 +469,9 @@ void pcv_launch_spec_encode(pcv_ctx* ctx, const PcvLevels& lv, const uint32_t* w
                             const double* y, const double* z, const PcvRouted& routed, const uint8_t* color,
                             uint32_t color_stride, const float* intensity, uint32_t* rank, void* payload /* uint4[n] */,
                             uint32_t* inten_bits, uint8_t* depth_grid, void* wide, uint32_t* pool_ctr, const uint32_t* tree_info,
-                            bool color_late = false /* 12-byte records leave without their colour (PcvSortPayload::color_in) */);
+                            bool color_late = false /* 12-byte records leave without their colour (PcvSortPayload::color_in) */,
+                            uint32_t* zero = nullptr /* with depth_grid: zero_words words (16-byte aligned, a multiple of 4) cleared before the pass */,
+                            size_t zero_words = 0);
 // The colour joined into records that left the chain pass without it, in place (the record sort's first pass does this on the
 // fly; this pass exists for the sorts that cannot: the rank-count rows did not fit, experiments).
 void pcv_launch_join_color(pcv_ctx* ctx, uint64_t n, const uint8_t* color, uint32_t color_stride, uint32_t* keys, void* payload_uint2);

@@ -1568,7 +1568,264 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
   return PCV_OK;
 }
 
+
+// ---- the sample's key sort: one launch per digit ("onesweep") --------------------------------------
+// The sample of the single-chain build is 1.5 M keys (12.5 MB) at 100 M points: upsweep + scan + downsweep per 8-bit digit
+// were fifteen dependent launches of 6-14 us each, every one of them bound by its own launch and drain. Here the digit counts
+// of ALL passes are taken once (key_hist_kernel), and every pass is
+// ONE kernel over tiles of 8 192 keys: a tile ranks its keys in LDS, publishes its digit counts (512 values + one flag word), adds
+// up the counts of the tiles before it — back to the nearest tile whose inclusive prefix is already there; with all 191 tiles of
+// a 100 M-point build's sample resident at once that is usually tile 0, and the sum is 190 independent loads per lane instead of
+// a chain of dependent ones (a look-back over value+flag words, 32 at a time, cost 11 us per pass; this one ~3) — and writes its runs.
+// Tiles are handed out by a ticket, so a tile only ever waits for tiles that are already running. Digits are up to 9 bits wide
+// (512 lanes, lane t owns digit t): 36 bits of key are four launches.
+constexpr int kOneBlock = 512, kOneKpt = 16, kOneTile = kOneBlock * kOneKpt, kOneWaves = kOneBlock / 64, kOneRadix = 512;
+constexpr int kOneHistGroups = 128;   // workgroups of key_hist_kernel
+constexpr int kOneMaxPasses = 8;
+
+struct OnePasses {
+  int passes;
+  int shift[kOneMaxPasses], bits[kOneMaxPasses];
+};
+
+__global__ __launch_bounds__(kOneBlock) void key_hist_kernel(const uint64_t* __restrict__ keys, uint32_t n, OnePasses ps,
+                                                             uint32_t* __restrict__ ghist /* [passes][512], zero */) {
+  __shared__ uint32_t h[kOneMaxPasses][kOneRadix];
+  for (int i = threadIdx.x; i < ps.passes * kOneRadix; i += kOneBlock) (&h[0][0])[i] = 0;
+  __syncthreads();
+  const uint32_t per = ((n + kOneHistGroups - 1) / kOneHistGroups + 1u) & ~1u;  // even: 16-byte loads stay aligned
+  const uint32_t begin = min(n, blockIdx.x * per), end = min(n, begin + per);
+  typedef uint64_t Vec2 __attribute__((ext_vector_type(2)));
+  uint32_t i = begin + 2u * threadIdx.x;
+  for (; i + 2u * kOneBlock * 3u + 2u <= end; i += 2u * kOneBlock * 4u) {  // four loads in flight
+    Vec2 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const Vec2*>(keys + i + 2u * kOneBlock * u);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        for (int p = 0; p < ps.passes; ++p) atomicAdd(&h[p][(uint32_t)(v[u][k] >> ps.shift[p]) & ((1u << ps.bits[p]) - 1u)], 1u);
+  }
+  for (; i < end; i += 2u * kOneBlock)
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      if (i + k < end) {
+        const uint64_t key = keys[i + k];
+        for (int p = 0; p < ps.passes; ++p) atomicAdd(&h[p][(uint32_t)(key >> ps.shift[p]) & ((1u << ps.bits[p]) - 1u)], 1u);
+      }
+  __syncthreads();
+  for (int j = threadIdx.x; j < ps.passes * kOneRadix; j += kOneBlock) {
+    const uint32_t c = (&h[0][0])[j];
+    if (c) atomicAdd(&ghist[j], c);  // 128 workgroups x (a few hundred non-empty digits): ghist was cleared with the tickets
+  }
+}
+
+// exclusive prefix over the 512 lanes of the workgroup (lane t -> sum of v of lanes < t); `tot` (8 words of LDS) is scratch
+__device__ __forceinline__ uint32_t one_block_exclusive(uint32_t v, uint32_t* tot, int lane, int wave) {
+  uint32_t inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t u = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += u;
+  }
+  if (lane == 63) tot[wave] = inc;
+  __syncthreads();
+  uint32_t woff = 0;
+#pragma unroll
+  for (int w = 0; w < kOneWaves; ++w) woff += w < wave ? tot[w] : 0u;
+  __syncthreads();
+  return woff + inc - v;
+}
+
+// keeps in (plo, phi) the lanes whose digit agrees with this lane's in bit B
+template <int B>
+__device__ __forceinline__ void one_match_bit(uint32_t d, uint32_t& plo, uint32_t& phi) {
+  int m;  // all ones when bit B of the digit is set
+  asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(d), "n"(B));
+  const uint64_t bal = __builtin_amdgcn_ballot_w64(m != 0);
+  plo = __builtin_amdgcn_bitop3_b32(plo, (uint32_t)bal, (uint32_t)m, 0x90);  // p & ~(ballot ^ m)
+  phi = __builtin_amdgcn_bitop3_b32(phi, (uint32_t)(bal >> 32), (uint32_t)m, 0x90);
+}
+
+__global__ __launch_bounds__(kOneBlock) void onesweep_keys_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint32_t n,
+                                                                  int shift, int nbits, const uint32_t* __restrict__ ghist /* [512] of this pass */,
+                                                                  uint32_t* __restrict__ ticket, uint32_t* __restrict__ flags /* [tiles], zero */,
+                                                                  uint32_t* __restrict__ vals /* [tiles][2][512] */, int diag) {
+  extern __shared__ uint64_t skeys[];  // kOneTile keys (64 KB)
+  __shared__ uint32_t whist[kOneWaves][kOneRadix];
+  __shared__ uint32_t delta[kOneRadix];
+  __shared__ uint32_t tot[kOneWaves];
+  __shared__ uint32_t s_tile;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (t == 0) s_tile = atomicAdd(ticket, 1u);
+#pragma unroll
+  for (int w = 0; w < kOneWaves; ++w) whist[w][t] = 0;
+  const uint32_t gcount = ghist[t];  // the digit's count over the whole input (key_hist_kernel)
+  __syncthreads();
+  const uint32_t tile = s_tile;
+  const uint32_t base = tile * (uint32_t)kOneTile;
+  const uint32_t tile_n = min((uint32_t)kOneTile, n - base);
+  const uint32_t mask = (1u << nbits) - 1u;
+  const uint32_t wbase = wave * 64 * kOneKpt + lane;
+  uint64_t key[kOneKpt];
+#pragma unroll
+  for (int i = 0; i < kOneKpt; ++i) {
+    const uint32_t li = wbase + i * 64;
+    key[i] = li < tile_n ? in[base + li] : 0ull;
+    if (diag & 8) key[i] = (uint64_t)li << shift;  // timing only (pcv_exp_time_key_sort)
+  }
+  // rank of every key among the earlier keys of its digit inside the wave's slice (stable: iteration-major, lane-minor)
+  uint16_t lpos[kOneKpt];
+#pragma unroll
+  for (int i = 0; i < kOneKpt; ++i) {
+    const bool valid = wbase + i * 64 < tile_n;
+    const uint32_t d = (uint32_t)(key[i] >> shift) & mask;
+    if (diag & 2) {
+      lpos[i] = 0;
+      continue;
+    }
+    const uint64_t vm = __ballot(valid);
+    uint32_t plo = (uint32_t)vm, phi = (uint32_t)(vm >> 32);
+    one_match_bit<0>(d, plo, phi), one_match_bit<1>(d, plo, phi), one_match_bit<2>(d, plo, phi), one_match_bit<3>(d, plo, phi);
+    one_match_bit<4>(d, plo, phi);  // (bits above the digit's width are zero in every lane: matching them changes nothing)
+    if (nbits > 5) one_match_bit<5>(d, plo, phi);  // wave-uniform
+    if (nbits > 6) one_match_bit<6>(d, plo, phi);
+    if (nbits > 7) one_match_bit<7>(d, plo, phi);
+    if (nbits > 8) one_match_bit<8>(d, plo, phi);
+    const uint32_t below = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+    uint32_t* slot = &whist[wave][d];
+    const uint32_t pre = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (valid && below == 0)
+      (void)__hip_atomic_fetch_add(slot, (uint32_t)(__popc(plo) + __popc(phi)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    lpos[i] = (uint16_t)(pre + below);
+  }
+  __syncthreads();
+  uint32_t pre_w[kOneWaves], mine = 0;
+#pragma unroll
+  for (int w = 0; w < kOneWaves; ++w) {
+    pre_w[w] = mine;
+    mine += whist[w][t];
+  }
+  // This tile's digit counts for the tiles after it: the 512 values first, then ONE flag word (1 = counts there, 2 = inclusive
+  // prefix there too). Polling touches the flags only; the values are summed with independent loads once they are known to be there.
+  uint32_t* agg = vals + (size_t)tile * 2u * kOneRadix;  // [tile][0] counts, [tile][1] inclusive prefix
+  __hip_atomic_store(agg + t, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tile == 0) __hip_atomic_store(agg + kOneRadix + t, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // No fence: an agent-scope release writes back the whole L2 of the XCD (25 us here). The values are agent-scope atomic stores
+  // (written through on their own); once they are acknowledged (vmcnt 0) in every lane, the flag may follow.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (t == 0) __hip_atomic_store(flags + tile, tile == 0 ? 2u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  uint32_t excl = 0;
+  if (tile > 0 && !(diag & 1)) {
+    if (wave == 0) {  // lane l looks at tile hi - l: the nearest tile with a prefix, once every tile after it has its counts
+      int64_t hi = (int64_t)tile - 1, found = -1;
+      uint32_t spins = 0;
+      while (found < 0) {
+        const int64_t j = hi - lane;
+        const uint32_t f = j >= 0 ? __hip_atomic_load(flags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
+        const uint64_t pm = __ballot(f == 2u);
+        const int first = pm ? (int)__builtin_ctzll(pm) : 64;
+        if (__ballot(f == 0u && lane < first)) {  // counts missing in front of it: look again
+          if (++spins > (1u << 24)) __builtin_trap();  // a tile that never publishes: fail loudly, never hang
+          __builtin_amdgcn_s_sleep(2);
+          continue;
+        }
+        if (first < 64) found = hi - first;
+        else hi -= 64;
+      }
+      if (lane == 0) s_tile = (uint32_t)found;
+    }
+    __syncthreads();
+    const uint32_t from = s_tile;
+    excl = __hip_atomic_load(vals + ((size_t)from * 2u + 1u) * kOneRadix + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t j = from + 1u;
+    for (; j + 16u <= tile; j += 16u) {
+      uint32_t v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = __hip_atomic_load(vals + (size_t)(j + u) * 2u * kOneRadix + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int u = 0; u < 16; ++u) excl += v[u];
+    }
+    for (; j < tile; ++j) excl += __hip_atomic_load(vals + (size_t)j * 2u * kOneRadix + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(agg + kOneRadix + t, excl + mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(flags + tile, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  const uint32_t gstart = one_block_exclusive(gcount, tot, lane, wave);  // keys of smaller digits in the whole input
+  const uint32_t lstart = one_block_exclusive(mine, tot, lane, wave);    // ... in this tile
+#pragma unroll
+  for (int w = 0; w < kOneWaves; ++w) whist[w][t] = lstart + pre_w[w];
+  delta[t] = gstart + excl - lstart;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < kOneKpt; ++i)
+    if (wbase + i * 64 < tile_n) skeys[whist[wave][(uint32_t)(key[i] >> shift) & mask] + lpos[i]] = key[i];
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kOneKpt; ++j) {
+    const uint32_t p = j * kOneBlock + t;
+    if (p < tile_n) {
+      const uint64_t k = skeys[diag & 2 ? p : p];
+      uint32_t at = delta[(uint32_t)(k >> shift) & mask] + p;
+      if (diag) at = (diag & 4) ? p : min(at, n - 1u);  // timing-only variants: anywhere inside the buffer
+      out[at] = k;
+    }
+  }
+}
+
 }  // namespace
+
+// The sample's key sort (see onesweep_keys_kernel). scratch: [tickets 64 words | digit counts passes x 512 | flags passes x tiles |
+// values passes x tiles x 2 x 512]; everything in front of the values ZERO when key_hist_kernel starts — pcv_onesweep_zero_words(n,
+// bits) words (the caller lets the kernel that writes the keys clear them: no launch of its own).
+static int onesweep_passes(int bits) { return (bits + 8) / 9; }
+bool pcv_onesweep_fits(uint64_t n, int bits) { return n > 0 && n < (1ull << 30) && bits > 0 && onesweep_passes(bits) <= kOneMaxPasses; }
+size_t pcv_onesweep_zero_words(uint64_t n, int bits) {
+  const size_t tiles = (size_t)((n + kOneTile - 1) / kOneTile);
+  return 64 + (size_t)onesweep_passes(bits) * (kOneRadix + ((tiles + 3) & ~(size_t)3));
+}
+size_t pcv_onesweep_scratch_words(uint64_t n, int bits) {
+  const size_t tiles = (size_t)((n + kOneTile - 1) / kOneTile);
+  return ((pcv_onesweep_zero_words(n, bits) + 63) & ~(size_t)63) + (size_t)onesweep_passes(bits) * tiles * 2 * kOneRadix;
+}
+int pcv_sort_keys_onesweep(pcv_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint64_t n, int begin_bit, int end_bit, uint32_t* scratch,
+                           bool* result_in_a, int diag) {
+  const int bits = end_bit - begin_bit;
+  if (!pcv_onesweep_fits(n, bits)) return ctx->fail(PCV_E_INVALID, "onesweep key sort: size");
+  OnePasses ps{};
+  ps.passes = onesweep_passes(bits);
+  for (int p = 0, at = begin_bit; p < ps.passes; ++p) {  // digits as even as they come: 36 bits = 4 x 9, 39 = 5 x 8 (the last one 7)
+    const int w = (end_bit - at + (ps.passes - p) - 1) / (ps.passes - p);
+    ps.shift[p] = at, ps.bits[p] = w, at += w;
+  }
+  const uint32_t tiles = (uint32_t)((n + kOneTile - 1) / kOneTile);
+  uint32_t* tickets = scratch;
+  const size_t tiles4 = ((size_t)tiles + 3) & ~(size_t)3;
+  uint32_t* ghist = scratch + 64;
+  uint32_t* flags = ghist + (size_t)ps.passes * kOneRadix;
+  uint32_t* vals = scratch + ((pcv_onesweep_zero_words(n, bits) + 63) & ~(size_t)63);
+  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&onesweep_keys_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  kOneTile * 8) == hipSuccess;
+  if (!attr_ok) return ctx->fail(PCV_E_HIP, "onesweep key sort: LDS");
+  {
+    PcvProf prof(ctx, PCV_K_SORT_UPSWEEP64);
+    hipLaunchKernelGGL(key_hist_kernel, dim3(kOneHistGroups), dim3(kOneBlock), 0, ctx->stream, keys_a, (uint32_t)n, ps, ghist);
+  }
+  bool in_a = true;
+  for (int p = 0; p < ps.passes; ++p) {
+    PcvProf prof(ctx, PCV_K_SORT_DOWNSWEEP64);
+    hipLaunchKernelGGL(onesweep_keys_kernel, dim3(tiles), dim3(kOneBlock), kOneTile * 8, ctx->stream, in_a ? keys_a : keys_b, in_a ? keys_b : keys_a,
+                       (uint32_t)n, ps.shift[p], ps.bits[p], ghist + (size_t)p * kOneRadix, tickets + p,
+                       flags + (size_t)p * tiles4, vals + (size_t)p * tiles * 2 * kOneRadix, diag);
+    in_a = !in_a;
+  }
+  PCV_HIP_CHECK(ctx, hipGetLastError());
+  *result_in_a = in_a;
+  return PCV_OK;
+}
 
 // two histograms + totals, the second pass's piece ranges, and the rank counts re-indexed by true rank (16 384 per sort
 // workgroup, 64 MB) — the last only for inputs whose record sort can take the two-pass rows path at all (12-byte records in
@@ -1676,3 +1933,40 @@ void pcv_sort_rec12_geometry(uint64_t n, int* groups, uint64_t* chunk) {
   *groups = g.groups;
   *chunk = g.chunk;
 }
+
+#ifdef PCV_EXPERIMENTS
+// libpcv_hip_exp.so only: times `iters` key sorts of n pseudo-random `bits`-bit keys (HIP events around each sort);
+// onesweep != 0: pcv_sort_keys_onesweep (diag = timing-only variants of its kernel), else the three-kernel radix sort.
+__global__ void exp_fill_keys_kernel(uint64_t* k, uint32_t n, int bits, int top) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint64_t x = (uint64_t)i * 0x9e3779b97f4a7c15ull + 0x1234567ull;
+  x ^= x >> 29, x *= 0xbf58476d1ce4e5b9ull, x ^= x >> 32;
+  k[i] = (x & ((1ull << bits) - 1ull)) << (top - bits);
+}
+extern "C" int pcv_exp_time_key_sort(pcv_ctx* ctx, uint64_t n, int bits, int onesweep, int diag, int iters, float* ms_out) {
+  void *a = nullptr, *b = nullptr, *sc = nullptr, *sc2 = nullptr;
+  const int top = 3 * PCV_MAX_KEY_LEVELS;
+  int rc;
+  if ((rc = ctx->dev_alloc(&a, n * 8 + 256)) || (rc = ctx->dev_alloc(&b, n * 8 + 256)) ||
+      (rc = ctx->dev_alloc(&sc, pcv_onesweep_scratch_words(n, bits) * 4 + 64)) || (rc = ctx->dev_alloc(&sc2, pcv_sort_scratch_bytes(n))))
+    return rc;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0), hipEventCreate(&e1);
+  for (int it = 0; it < iters; ++it) {
+    hipLaunchKernelGGL(exp_fill_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (uint64_t*)a, (uint32_t)n, bits, top);
+    hipMemsetAsync(sc, 0, pcv_onesweep_zero_words(n, bits) * 4, ctx->stream);
+    hipEventRecord(e0, ctx->stream);
+    bool in_a;
+    if (onesweep) rc = pcv_sort_keys_onesweep(ctx, (uint64_t*)a, (uint64_t*)b, n, top - bits, top, (uint32_t*)sc, &in_a, diag);
+    else rc = pcv_radix_sort_u64(ctx, (uint64_t*)a, (uint64_t*)b, n, top - bits, top, nullptr, sc2, &in_a);
+    hipEventRecord(e1, ctx->stream);
+    hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms_out[it], e0, e1);
+    if (rc) break;
+  }
+  hipEventDestroy(e0), hipEventDestroy(e1);
+  ctx->dev_free(a), ctx->dev_free(b), ctx->dev_free(sc), ctx->dev_free(sc2);
+  return rc;
+}
+#endif
