@@ -322,8 +322,7 @@ int pcv_ctx::h2d_fill(void* dst, size_t bytes, const std::function<bool(uint8_t*
 #endif
   for (size_t off = 0; off < bytes; off += kRingChunk) {
     const size_t len = bytes - off < kRingChunk ? bytes - off : kRingChunk;
-    const int slot = ring_next;
-    ring_next = (ring_next + 1) % kRingSlots;
+    const int slot = ring_take();
     if (ring_busy[slot]) PCV_H2D_T(t_wait, PCV_HIP_CHECK(this, hipEventSynchronize(ring_ev[slot])))  // its previous DMA has left the chunk
     uint8_t* chunk = (uint8_t*)ring[slot];
     PCV_H2D_T(t_fill, host_pool.run((len + kPart - 1) / kPart, [&](size_t p) {

@@ -21,6 +21,8 @@
 #include <limits>
 
 #include "pcv_internal.h"
+#include <chrono>
+#include <vector>
 
 namespace {
 
@@ -151,16 +153,31 @@ struct pcv_ingest {
   uint8_t* rgb = nullptr;
   float* inten = nullptr;
   uint8_t* stage[pcv_ctx::kRingSlots] = {};  // device partners of the pinned ring chunks
+  hipEvent_t read_ev[pcv_ctx::kRingSlots] = {};  // the transposition kernel has read the staging chunk: the copy stream may refill it
+  bool read_busy[pcv_ctx::kRingSlots] = {};
+  // the pinned chunk being filled: batches are packed into it one after the other and go up in ONE DMA when the next batch does
+  // not fit (or at finish): a DMA of 13.5 MB — one batch of 500 000 points — runs at 40 GB/s, one of 27 MB at 50
+  struct Seg {
+    size_t off, rgb_off, int_off;  // byte offsets inside the chunk
+    uint32_t m;
+    uint64_t at;  // index of the segment's first point in the device arrays
+  };
+  int cur_slot = -1;
+  size_t cur_fill = 0;
+  std::vector<Seg> segs;
   unsigned long long* acc = nullptr;         // 6 ordered keys: running min xyz, max xyz
   bool failed = false;
 };
 
 static void ingest_release(pcv_ingest* g) {
   pcv_ctx* ctx = g->ctx;
+  if (g->cur_slot >= 0 && ctx->ring_held == g->cur_slot) ctx->ring_held = -1;
   for (void* p : {(void*)g->x, (void*)g->y, (void*)g->z, (void*)g->rgb, (void*)g->inten, (void*)g->acc})
     if (p) ctx->dev_free(p);
   for (auto& s : g->stage)
     if (s) ctx->dev_free(s);
+  for (auto& e : g->read_ev)
+    if (e) (void)hipEventDestroy(e);
   delete g;
 }
 
@@ -216,6 +233,11 @@ extern "C" int pcv_ingest_begin(pcv_ctx* ctx, uint64_t num_points_hint, int has_
       ingest_release(g);
       return rc;
     }
+  for (auto& e : g->read_ev)
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+      ingest_release(g);
+      return ctx->fail(PCV_E_HIP, "pcv_ingest_begin: hipEventCreate");
+    }
   const double inf = std::numeric_limits<double>::infinity();
   uint64_t init[6] = {ordered_key_host(inf), ordered_key_host(inf), ordered_key_host(inf),
                       ordered_key_host(-inf), ordered_key_host(-inf), ordered_key_host(-inf)};
@@ -231,8 +253,57 @@ extern "C" int pcv_ingest_begin(pcv_ctx* ctx, uint64_t num_points_hint, int has_
 
 extern "C" uint64_t pcv_ingest_num_points(const pcv_ingest* g) { return g ? g->n : 0; }
 
+// PCV_INGEST_TRACE=1 (libpcv_hip_exp.so): where an append's host time goes, summed over the ingest and printed by finish
+static double g_trace_us[4];  // wait for the ring slot, copy into the pinned chunk, queue DMA + kernel, whole call
+static inline double trace_now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// The pinned chunk in hand goes up: one DMA, one transposition kernel per batch in it.
+// The DMAs travel on the side stream, the kernels on `stream`: on ONE stream every DMA pays two hand-overs between the copy
+// engine and the compute queue (DMA k+1 cannot start before kernel k has ended). The kernels wait for their DMA (ring_ev), the DMA
+// that refills a staging chunk for the kernels that read it (read_ev); the stream order of `stream` is what keeps the
+// destination arrays (and their growth, ingest_reserve) consistent. PCV_INGEST_ONE_STREAM=1 (libpcv_hip_exp.so): everything on `stream`.
+static int ingest_flush(pcv_ingest* g) {
+  if (g->cur_slot < 0) return PCV_OK;
+  pcv_ctx* ctx = g->ctx;
+  const int slot = g->cur_slot;
+  g->cur_slot = -1;
+  if (ctx->ring_held == slot) ctx->ring_held = -1;
+  static const bool one_stream = [] {
+    const char* e = pcv_experiment("PCV_INGEST_ONE_STREAM");
+    return (e && atoi(e) != 0);
+  }();
+  hipStream_t cs = one_stream || !ctx->side ? ctx->stream : ctx->side;
+  uint8_t* st = g->stage[slot];
+  bool ok = true;
+  if (cs != ctx->stream && g->read_busy[slot]) ok = hipStreamWaitEvent(cs, g->read_ev[slot], 0) == hipSuccess;
+  ok = ok && hipMemcpyAsync(st, ctx->ring[slot], g->cur_fill, hipMemcpyHostToDevice, cs) == hipSuccess &&
+       hipEventRecord(ctx->ring_ev[slot], cs) == hipSuccess;
+  if (ok && cs != ctx->stream) ok = hipStreamWaitEvent(ctx->stream, ctx->ring_ev[slot], 0) == hipSuccess;
+  if (!ok) {
+    g->failed = true;
+    return ctx->fail(PCV_E_HIP, "pcv_ingest_append: queuing the DMA of a chunk of batches failed");
+  }
+  ctx->ring_busy[slot] = true;
+  for (const pcv_ingest::Seg& sg : g->segs) {
+    PcvProf prof(ctx, PCV_K_INGEST);
+    const uint32_t tiles = (uint32_t)((sg.m + kIngestTile - 1) / kIngestTile);
+    hipLaunchKernelGGL(ingest_batch_kernel, dim3(tiles < 1024u ? tiles : 1024u), dim3(kIngestBlock), 0, ctx->stream, sg.m,
+                       (const double*)(st + sg.off), g->x + sg.at, g->y + sg.at, g->z + sg.at, (const uint8_t*)(st + sg.rgb_off), g->rgb + sg.at * 3,
+                       (const uint8_t*)(st + sg.int_off), g->has_intensity ? (uint8_t*)(g->inten + sg.at) : nullptr, g->acc);
+  }
+  g->segs.clear();
+  if (hipGetLastError() != hipSuccess || (cs != ctx->stream && hipEventRecord(g->read_ev[slot], ctx->stream) != hipSuccess)) {
+    g->failed = true;
+    return ctx->fail(PCV_E_HIP, "pcv_ingest_append: launching ingest_batch_kernel failed");
+  }
+  g->read_busy[slot] = cs != ctx->stream;
+  return PCV_OK;
+}
+
 extern "C" int pcv_ingest_append(pcv_ingest* g, const double* xyz, const uint8_t* rgb, const float* intensity, uint64_t n) {
   if (!g) return PCV_E_INVALID;
+  static const bool trace = pcv_experiment("PCV_INGEST_TRACE") != nullptr;
+  const double tr0 = trace ? trace_now() : 0.0;
   pcv_ctx* ctx = g->ctx;
   if (g->failed) return ctx->fail(PCV_E_INVALID, "pcv_ingest_append after a failed append: the ingest can only be finished or aborted");
   if (n == 0) return PCV_OK;
@@ -245,21 +316,37 @@ extern "C" int pcv_ingest_append(pcv_ingest* g, const double* xyz, const uint8_t
   const size_t nworkers = ctx->host_pool.threads.size() + 1;
   for (uint64_t done = 0; done < n; done += kIngestSub) {
     const uint64_t m = n - done < kIngestSub ? n - done : kIngestSub;
-    const int slot = ctx->ring_next;
-    ctx->ring_next = (ctx->ring_next + 1) % pcv_ctx::kRingSlots;
-    if (ctx->ring_busy[slot]) PCV_HIP_CHECK(ctx, hipEventSynchronize(ctx->ring_ev[slot]));  // its previous DMA has left the chunk
-    uint8_t* chunk = (uint8_t*)ctx->ring[slot];
-    // chunk layout: positions at 0; colour and intensity at offsets CONGRUENT modulo 16 to where they go on the device, so
-    // that the kernel copies whole 16-byte words
+    // the batch's place in the chunk: positions at a 256-byte boundary; colour and intensity at offsets CONGRUENT modulo 16 to
+    // where they go on the device (the arrays' bases are 256-byte aligned), so that the kernel copies whole 16-byte words
     const size_t xyz_bytes = (size_t)m * 24, rgb_bytes = (size_t)m * 3, int_bytes = g->has_intensity ? (size_t)m * 4 : 0;
-    const size_t rgb_off = ((xyz_bytes + 15) & ~(size_t)15) + (((uintptr_t)(g->rgb + g->n * 3)) & 15);
-    const size_t int_off = ((rgb_off + rgb_bytes + 15) & ~(size_t)15) + (g->has_intensity ? (((uintptr_t)(g->inten + g->n)) & 15) : 0);
-    const size_t total = int_off + int_bytes;
+    size_t off, rgb_off, int_off, total;
+    auto place = [&](size_t base) {
+      off = (base + 255) & ~(size_t)255;
+      rgb_off = ((off + xyz_bytes + 15) & ~(size_t)15) + ((g->n * 3) & 15);
+      int_off = ((rgb_off + rgb_bytes + 15) & ~(size_t)15) + (g->has_intensity ? ((g->n * 4) & 15) : 0);
+      total = int_off + int_bytes;
+    };
+    place(g->cur_slot >= 0 ? g->cur_fill : 0);
+    double tr1 = trace ? trace_now() : 0.0, tr2 = tr1;
+    if (g->cur_slot >= 0 && total > pcv_ctx::kRingChunk) {  // the chunk in hand is full: up it goes
+      if ((rc = ingest_flush(g))) return rc;
+      place(0);
+      if (trace) g_trace_us[2] += trace_now() - tr1, tr1 = tr2 = trace_now();
+    }
+    if (g->cur_slot < 0) {
+      const int slot = ctx->ring_take();
+      if (ctx->ring_busy[slot]) PCV_HIP_CHECK(ctx, hipEventSynchronize(ctx->ring_ev[slot]));  // its previous DMA has left the chunk
+      g->cur_slot = slot;
+      g->cur_fill = 0;
+      if (ctx->ring_held < 0) ctx->ring_held = slot;  // (one ingest fills a chunk at a time: a second ingest on the same context flushes as it goes, below)
+      tr2 = trace ? trace_now() : 0.0;
+    }
+    uint8_t* chunk = (uint8_t*)ctx->ring[g->cur_slot];
     const uint8_t* sx = (const uint8_t*)(xyz + done * 3);
     const uint8_t* sc = rgb + done * 3;
     const uint8_t* si = g->has_intensity ? (const uint8_t*)(intensity + done) : nullptr;
-    if (total < (256u << 10) || nworkers == 1) {
-      std::memcpy(chunk, sx, xyz_bytes);
+    if (xyz_bytes + rgb_bytes + int_bytes < (256u << 10) || nworkers == 1) {
+      std::memcpy(chunk + off, sx, xyz_bytes);
       std::memcpy(chunk + rgb_off, sc, rgb_bytes);
       if (int_bytes) std::memcpy(chunk + int_off, si, int_bytes);
     } else {
@@ -271,7 +358,7 @@ extern "C" int pcv_ingest_append(pcv_ingest* g, const double* xyz, const uint8_t
         while (b < e) {  // [b, e) may straddle regions
           if (b < xyz_bytes) {
             const size_t len = (e < xyz_bytes ? e : xyz_bytes) - b;
-            std::memcpy(chunk + b, sx + b, len);
+            std::memcpy(chunk + off + b, sx + b, len);
             b += len;
           } else if (b < xyz_bytes + rgb_bytes) {
             const size_t o = b - xyz_bytes, len = (e < xyz_bytes + rgb_bytes ? e : xyz_bytes + rgb_bytes) - b;
@@ -285,35 +372,20 @@ extern "C" int pcv_ingest_append(pcv_ingest* g, const double* xyz, const uint8_t
         }
       });
     }
-    uint8_t* st = g->stage[slot];
-    // (DMA and kernel on ONE stream: the stream's order is also what keeps a later DMA from overwriting a staging chunk its
-    // kernel has not read yet. Alternating the DMAs between two streams — two copy engines — moved nothing: 52-55 ms for 100 M
-    // points either way, tools/ingest_probe.py)
-    if (hipMemcpyAsync(st, chunk, total, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-        hipEventRecord(ctx->ring_ev[slot], ctx->stream) != hipSuccess) {
-      g->failed = true;
-      return ctx->fail(PCV_E_HIP, "pcv_ingest_append: queuing the batch's DMA failed");
-    }
-    ctx->ring_busy[slot] = true;
-    {
-      PcvProf prof(ctx, PCV_K_INGEST);
-      const uint32_t tiles = (uint32_t)((m + kIngestTile - 1) / kIngestTile);
-      hipLaunchKernelGGL(ingest_batch_kernel, dim3(tiles < 1024u ? tiles : 1024u), dim3(kIngestBlock), 0, ctx->stream, (uint32_t)m,
-                         (const double*)st, g->x + g->n, g->y + g->n, g->z + g->n, (const uint8_t*)(st + rgb_off), g->rgb + g->n * 3,
-                         (const uint8_t*)(st + int_off), g->has_intensity ? (uint8_t*)(g->inten + g->n) : nullptr, g->acc);
-    }
-    if (hipGetLastError() != hipSuccess) {
-      g->failed = true;
-      return ctx->fail(PCV_E_HIP, "pcv_ingest_append: launching ingest_batch_kernel failed");
-    }
+    g->segs.push_back(pcv_ingest::Seg{off, rgb_off, int_off, (uint32_t)m, g->n});
+    g->cur_fill = total;
     g->n += m;
+    if (ctx->ring_held != g->cur_slot && (rc = ingest_flush(g))) return rc;  // another ingest of this context holds the marker
+    if (trace) g_trace_us[0] += tr2 - tr1, g_trace_us[1] += trace_now() - tr2;
   }
+  if (trace) g_trace_us[3] += trace_now() - tr0;
   return PCV_OK;
 }
 
 extern "C" void pcv_ingest_abort(pcv_ingest* g) {
   if (!g) return;
   (void)hipSetDevice(g->ctx->device);
+  if (g->ctx->side) (void)hipStreamSynchronize(g->ctx->side);  // a DMA whose kernel was never queued (a failed append)
   (void)hipStreamSynchronize(g->ctx->stream);
   ingest_release(g);
 }
@@ -323,6 +395,10 @@ extern "C" int pcv_ingest_bbox(pcv_ingest* g, double bbox_min[3], double bbox_ma
   pcv_ctx* ctx = g->ctx;
   if (!bbox_min || !bbox_max) return ctx->fail(PCV_E_INVALID, "null output");
   PCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (!g->failed) {  // the batches still in the pinned chunk in hand
+    const int frc = ingest_flush(g);
+    if (frc) return frc;
+  }
   PCV_HIP_CHECK(ctx, hipMemcpyAsync(ctx->mailbox, g->acc, 48, hipMemcpyDeviceToHost, ctx->stream));
   PCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   const double inf = std::numeric_limits<double>::infinity();
@@ -336,6 +412,11 @@ extern "C" int pcv_ingest_bbox(pcv_ingest* g, double bbox_min[3], double bbox_ma
 }
 
 extern "C" int pcv_ingest_finish(pcv_ingest* g, const pcv_build_params* params, pcv_octree** out) {
+  if (pcv_experiment("PCV_INGEST_TRACE")) {
+    fprintf(stderr, "[ingest] wait slot %.1f ms, copy to pinned %.1f ms, queue %.1f ms, appends in all %.1f ms\n", g_trace_us[0] * 1e-3,
+            g_trace_us[1] * 1e-3, g_trace_us[2] * 1e-3, g_trace_us[3] * 1e-3);
+    g_trace_us[0] = g_trace_us[1] = g_trace_us[2] = g_trace_us[3] = 0.0;
+  }
   if (!g) return PCV_E_INVALID;
   pcv_ctx* ctx = g->ctx;
   int rc = PCV_OK;
@@ -344,6 +425,7 @@ extern "C" int pcv_ingest_finish(pcv_ingest* g, const pcv_build_params* params, 
   else if (g->failed)
     rc = ctx->fail(PCV_E_INVALID, "pcv_ingest_finish after a failed append");
   if (out) *out = nullptr;
+  if (rc == PCV_OK) rc = ingest_flush(g);  // the batches still in the pinned chunk in hand
   if (rc == PCV_OK) {
     pcv_build_params p = *params;
     if (p.flags & PCV_BUILD_COMPUTE_BBOX) {  // the box was folded batch by batch: no pass over the cloud
@@ -362,6 +444,7 @@ extern "C" int pcv_ingest_finish(pcv_ingest* g, const pcv_build_params* params, 
     }
   }
   (void)hipSetDevice(ctx->device);
+  if (g->failed && ctx->side) (void)hipStreamSynchronize(ctx->side);  // a DMA whose kernel was never queued
   (void)hipStreamSynchronize(ctx->stream);
   ingest_release(g);
   return rc;

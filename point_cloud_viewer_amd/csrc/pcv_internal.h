@@ -149,6 +149,13 @@ struct pcv_ctx {
   hipEvent_t ring_ev[kRingSlots] = {};
   bool ring_busy[kRingSlots] = {};
   int ring_next = 0;
+  int ring_held = -1;  // a chunk an ingest is still filling (pcv_ingest.hip): the other users of the ring pass it over
+  int ring_take() {
+    int slot = ring_next;
+    if (slot == ring_held) slot = (slot + 1) % kRingSlots;
+    ring_next = (slot + 1) % kRingSlots;
+    return slot;
+  }
   PcvHostPool host_pool;
   int ring_ensure();
   int h2d(void* dst, const void* src, size_t bytes);  // asynchronous on `stream` from the device's point of view

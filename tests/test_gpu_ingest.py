@@ -106,6 +106,35 @@ def test_the_stream_may_be_longer_than_the_hint(ctx):
     tree.free()
 
 
+def test_other_calls_between_appends_do_not_touch_the_batches_in_hand(ctx):
+    """Batches are packed into a pinned chunk and go up when it is full: a build from host arrays (which takes chunks of the same
+    ring), a second ingest and a bbox query in the middle of the stream must leave the batches still in hand alone."""
+    n = 900_000
+    x, y, z, rgb, bmin, bmax = synthetic.gaussian_clusters(n, seed=74, num_clusters=5, extent=150.0, sigma_range=(0.2, 5.0))
+    ref = ctx.build(0.001, pcv.Aabb(bmin, bmax), x, y, z, rgb, max_points_per_node=15_000).to_dict()
+    pos = np.stack([x, y, z], axis=1)
+    a = ctx.ingest(n, has_intensity=False)
+    b = ctx.ingest(0, has_intensity=False)
+    cuts = [0, 100_000, 100_007, 400_000, 650_000, n]
+    for k in range(len(cuts) - 1):
+        lo, hi = cuts[k], cuts[k + 1]
+        a.append(pos[lo:hi], rgb[lo:hi])  # stays in the chunk in hand (13 MB at most here)
+        if k == 0:
+            other = ctx.build(0.001, pcv.Aabb(bmin, bmax), x[:300_000], y[:300_000], z[:300_000], rgb[:300_000])  # host arrays: the ring
+            assert other.num_points == 300_000
+            other.free()
+        if k == 1:
+            blo, bhi = a.bbox()  # flushes what is in hand
+            assert np.array_equal(blo, [x[:hi].min(), y[:hi].min(), z[:hi].min()]) and np.array_equal(bhi, [x[:hi].max(), y[:hi].max(), z[:hi].max()])
+        b.append(pos[lo:hi], rgb[lo:hi])  # a second ingest of the same context, interleaved
+    ta = a.finish(0.001, pcv.Aabb(bmin, bmax), max_points_per_node=15_000)
+    tb = b.finish(0.001, pcv.Aabb(bmin, bmax), max_points_per_node=15_000)
+    same_tree(ta.to_dict(), ref)
+    same_tree(tb.to_dict(), ref)
+    ta.free()
+    tb.free()
+
+
 def test_build_octree_from_an_iterator_of_batches_writes_the_reference_directory(ctx, tmp_path):
     """The Python mirror of build_octree(dir, resolution, bbox, impl Iterator<Item = PointsBatch>, attributes):
     the directory equals the oracle's literal file-streaming build of the same cloud."""

@@ -24,7 +24,7 @@ ctx = pcv.Context(0)
 base = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
 d = tempfile.mkdtemp(prefix="pcv_ingest_probe_", dir=base)
 try:
-    for batch in (500_000, 500_000, 1_000_000, 4_000_000):
+    for batch in [int(b) for b in os.environ.get("BATCHES", "500000,500000,1000000,4000000").split(",")]:
         rows = []
         for rep in range(4):
             shutil.rmtree(os.path.join(d, "o"), ignore_errors=True)
