@@ -1286,7 +1286,9 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
   PcvSpecTree tree;
   uint32_t info[4] = {0, 0, 0, 0};
   uint64_t* small_partner = nullptr;
+#ifdef PCV_EXPERIMENTS
   uint32_t* d_sample_counts = nullptr;
+#endif
   // Levels the sample keys cover first: a uniform cloud reaches the capacity at level log8(n / capacity); clustered clouds
   // go deeper, so eight levels on top (12 levels for the 100 M bench cloud whose deepest leaf sits at level 10, 13 for
   // 1 B points), at most 14. Every level less is a tenth of the sample's chain, three bits of its key sort and two
@@ -1316,17 +1318,21 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
       const char* e = pcv_experiment("PCV_SAMPLE_CLUMP_SHIFT");  // experiments: 0 = single points
       return e ? (uint32_t)std::min(6, std::max(0, atoi(e))) : 3u;
     }();
-    // the key sort of the sample: one launch per 9-bit digit (pcv_sort_keys_onesweep); chain_keys clears its counters on the way
+    uint32_t* one = nullptr;  // (scratch of the one-launch-per-digit key sort: libpcv_hip_exp.so, PCV_SAMPLE_ONESWEEP=1; pcv_sort.hip)
+    size_t one_zero_words = 0;
+#ifdef PCV_EXPERIMENTS
     static const bool onesweep_on = [] {
-      const char* e = pcv_experiment("PCV_SAMPLE_ONESWEEP");  // libpcv_hip_exp.so: 1 = on (measured: no faster, see pcv_sort.hip)
+      const char* e = pcv_experiment("PCV_SAMPLE_ONESWEEP");
       return e && atoi(e) != 0;
     }();
-    host_lap("bbox -> sample keys");
-    uint32_t* one = nullptr;
     const int sbits = 3 * sample_levels;
-    if (onesweep_on && pcv_onesweep_fits(ns, sbits) && (rc = sc.get(&one, pcv_onesweep_scratch_words(ns, sbits) + 4))) return rc;
-    pcv_launch_chain_keys(ctx, lv, ns, stride, d.x, d.y, d.z, skeys_a, false, d.routed, stride > 1 ? clump_shift : 0u, one,
-                          one ? pcv_onesweep_zero_words(ns, sbits) : 0);
+    if (onesweep_on && pcv_onesweep_fits(ns, sbits)) {
+      if ((rc = sc.get(&one, pcv_onesweep_scratch_words(ns, sbits) + 4))) return rc;
+      one_zero_words = pcv_onesweep_zero_words(ns, sbits);
+    }
+#endif
+    host_lap("bbox -> sample keys");
+    pcv_launch_chain_keys(ctx, lv, ns, stride, d.x, d.y, d.z, skeys_a, false, d.routed, stride > 1 ? clump_shift : 0u, one, one_zero_words);
     bool in_a = true;
     host_lap("", true);
     // PCV_SAMPLE_COUNTS=1 (libpcv_hip_exp.so only): the sample tree by COUNTING the keys, three levels per launch pair
@@ -1351,8 +1357,11 @@ static int single_chain_topology(pcv_ctx* ctx, PcvBuild* bs, pcv_octree* t, cons
     }
 #endif
     if (!counted) {
+#ifdef PCV_EXPERIMENTS
     if (one) rc = pcv_sort_keys_onesweep(ctx, skeys_a, skeys_b, ns, 3 * (PCV_MAX_KEY_LEVELS - sample_levels), 3 * PCV_MAX_KEY_LEVELS, one, &in_a);
-    else rc = pcv_radix_sort_u64(ctx, skeys_a, skeys_b, ns, 3 * (PCV_MAX_KEY_LEVELS - sample_levels), 3 * PCV_MAX_KEY_LEVELS, nullptr,
+    else
+#endif
+      rc = pcv_radix_sort_u64(ctx, skeys_a, skeys_b, ns, 3 * (PCV_MAX_KEY_LEVELS - sample_levels), 3 * PCV_MAX_KEY_LEVELS, nullptr,
                                  bs->sort_scratch, &in_a);
     if (rc) return rc;
     host_lap("sample sort queued");

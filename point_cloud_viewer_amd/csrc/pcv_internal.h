@@ -343,6 +343,7 @@ int pcv_radix_sort_u64(pcv_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint64_
                        PcvSortPayload* payload, void* scratch, bool* result_in_a);
 int pcv_radix_sort_u32(pcv_ctx* ctx, uint32_t* keys_a, uint32_t* keys_b, uint64_t n, int begin_bit, int end_bit,
                        PcvSortPayload* payload, void* scratch, bool* result_in_a);
+#ifdef PCV_EXPERIMENTS
 // The sample's key sort, one launch per 9-bit digit (pcv_sort.hip: onesweep_keys_kernel). `scratch`: pcv_onesweep_scratch_words
 // words whose first pcv_onesweep_zero_words are zero when the sort starts.
 bool pcv_onesweep_fits(uint64_t n, int bits);
@@ -350,6 +351,7 @@ size_t pcv_onesweep_zero_words(uint64_t n, int bits);
 size_t pcv_onesweep_scratch_words(uint64_t n, int bits);
 int pcv_sort_keys_onesweep(pcv_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uint64_t n, int begin_bit, int end_bit, uint32_t* scratch,
                            bool* result_in_a, int diag = 0 /* timing-only variants (pcv_exp_time_key_sort, libpcv_hip_exp.so) */);
+#endif
 
 // rows (pcv_launch_rank_hist_rows, map_entries counters per sort workgroup): the first pass takes its histogram from them and
 // applies the map inside its downsweep — the keys are not read an extra time

@@ -1569,7 +1569,15 @@ int radix_sort(pcv_ctx* ctx, KeyT* a, KeyT* b, uint64_t n, int begin_bit, int en
 }
 
 
-// ---- the sample's key sort: one launch per digit ("onesweep") --------------------------------------
+// ---- the sample's key sort with ONE launch per digit ("onesweep"): measured, no faster, libpcv_hip_exp.so only --------------
+// Round 6: upsweep + scan + downsweep per 8-bit digit are fifteen dependent launches of 6-14 us for the 1.5 M sample keys of a
+// 100 M-point build. One kernel per 9-bit digit (tiles of 8 192 keys, digit counts published per tile, a look-back over the tiles
+// before) is four launches + one counting pass — and takes the same time (tools/key_sort_probe.py, 1.56 M keys of 36 bits:
+// 110 us either way; 15.6 M keys: 495 against 610): the kernel without its look-back runs 14 us per pass, the look-back costs
+// another 11 — what one workgroup publishes reaches another XCD's workgroup through memory, not through its L2 (an agent-scope
+// release fence writes the whole L2 back: 25 us), so two dependent hand-overs inside the kernel cost what the two extra launches
+// did. Kept for the record (PCV_SAMPLE_ONESWEEP=1); profiles/r06_ab_sample_key_sort_one_launch_per_digit_dropped.json.
+#ifdef PCV_EXPERIMENTS
 // The sample of the single-chain build is 1.5 M keys (12.5 MB) at 100 M points: upsweep + scan + downsweep per 8-bit digit
 // were fifteen dependent launches of 6-14 us each, every one of them bound by its own launch and drain. Here the digit counts
 // of ALL passes are taken once (key_hist_kernel), and every pass is
@@ -1776,8 +1784,11 @@ __global__ __launch_bounds__(kOneBlock) void onesweep_keys_kernel(const uint64_t
   }
 }
 
+#endif  // PCV_EXPERIMENTS (onesweep kernels)
+
 }  // namespace
 
+#ifdef PCV_EXPERIMENTS
 // The sample's key sort (see onesweep_keys_kernel). scratch: [tickets 64 words | digit counts passes x 512 | flags passes x tiles |
 // values passes x tiles x 2 x 512]; everything in front of the values ZERO when key_hist_kernel starts — pcv_onesweep_zero_words(n,
 // bits) words (the caller lets the kernel that writes the keys clear them: no launch of its own).
@@ -1826,6 +1837,7 @@ int pcv_sort_keys_onesweep(pcv_ctx* ctx, uint64_t* keys_a, uint64_t* keys_b, uin
   *result_in_a = in_a;
   return PCV_OK;
 }
+#endif  // PCV_EXPERIMENTS (onesweep host side)
 
 // two histograms + totals, the second pass's piece ranges, and the rank counts re-indexed by true rank (16 384 per sort
 // workgroup, 64 MB) — the last only for inputs whose record sort can take the two-pass rows path at all (12-byte records in
