@@ -508,8 +508,10 @@ __global__ __launch_bounds__(BLOCK, 8) void chain_pass_kernel(
       const uint32_t t = (uint32_t)(h * BLOCK + tid);
       if (t < here) {
         const uint2 q = opay[t];
-        rank[base + t] = okey[t] | (rgb[h] >> 16);
-        reinterpret_cast<uint2*>(payload)[base + t] = make_uint2(q.x, q.y | ((rgb[h] & 0xffffu) << 16));
+        // streaming stores: the records are read next by other kernels, long after they have left the L2 — written through, they
+        // leave less for the write-back at the kernel's end (the pass and the count behind it: -15 us together, A B A B in one call)
+        __builtin_nontemporal_store(okey[t] | (rgb[h] >> 16), &rank[base + t]);
+        __builtin_nontemporal_store(((uint64_t)(q.y | ((rgb[h] & 0xffffu) << 16)) << 32) | q.x, reinterpret_cast<uint64_t*>(payload) + base + t);
       }
     }
   }
