@@ -151,19 +151,21 @@ int pcv_build_octree(pcv_ctx* ctx, const pcv_build_params* params, const pcv_poi
  * points at a time (src/lib.rs:52). These calls take the batches AS THEY ARE, one at a time:
  *   pcv_ingest_begin   num_points_hint = NumberOfPoints::num_points() of the stream (0 = unknown: the device arrays grow);
  *                      has_intensity = the attribute list names "intensity" (then every batch must carry it).
- *   pcv_ingest_append  copies the batch's three arrays side by side into one chunk of the context's pinned ring, queues ONE
- *                      DMA for the chunk and ONE kernel that transposes the positions AoS -> SoA into place behind the
- *                      points already on the device, copies colour / intensity behind theirs and folds the batch into the
- *                      running bounding box (find_bounding_box, generation.rs:256-270). Returns when both are queued — the
- *                      caller's arrays are free again and the next batch can be produced while this one goes up. Batches of
- *                      any size (split into pieces of 2^20 points inside); n == 0 is a no-op. Host memory: the ring
- *                      (3 x 32 MiB), whatever the size of the cloud.
+ *   pcv_ingest_append  copies the batch's three arrays side by side into the chunk of the context's pinned ring it has in
+ *                      hand; a chunk that cannot take the next batch goes up in ONE DMA (32 MiB: two batches of 500 000
+ *                      points), followed by ONE kernel per batch that transposes the positions AoS -> SoA into place behind
+ *                      the points already on the device, copies colour / intensity behind theirs and folds the batch into
+ *                      the running bounding box (find_bounding_box, generation.rs:256-270). Returns when the batch is in
+ *                      the chunk — the caller's arrays are free again and the next batch can be produced while earlier
+ *                      ones go up. Batches of any size (split into pieces of 2^20 points inside); n == 0 is a no-op. Host
+ *                      memory: the ring (3 x 32 MiB), whatever the size of the cloud.
  *   pcv_ingest_bbox    the bounding box of the points appended so far (waits for the queued batches); Aabb::zero() for none.
  *   pcv_ingest_finish  pcv_build_octree on the ingested cloud; with PCV_BUILD_COMPUTE_BBOX the box folded during the ingest
  *                      is used (no pass over the cloud), otherwise params->bbox_* as build_octree takes it from its caller.
  *                      ALWAYS consumes the ingest, whatever it returns.
  *   pcv_ingest_abort   drops an ingest without building.
- * One ingest at a time per context; no other call on the context between begin and finish except pcv_last_error. */
+ * Other calls on the context between begin and finish (another ingest, a build from host arrays) are allowed: the chunk in
+ * hand is theirs to pass over, not to reuse. */
 typedef struct pcv_ingest pcv_ingest;
 int pcv_ingest_begin(pcv_ctx* ctx, uint64_t num_points_hint, int has_intensity, pcv_ingest** out);
 int pcv_ingest_append(pcv_ingest* ingest, const double* xyz /* n x 3, x y z per point (host) */, const uint8_t* rgb /* n x 3 (host) */,
