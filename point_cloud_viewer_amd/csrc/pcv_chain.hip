@@ -36,9 +36,13 @@ __global__ __launch_bounds__(kAabbBlock) void aabb_partial_kernel(uint64_t n, co
   // two points per lane per iteration: 16-byte loads, fully coalesced
   for (uint64_t i = ((uint64_t)blockIdx.x * kAabbBlock + threadIdx.x) * 2; i < n; i += stride) {
     if (i + 1 < n) {
-      double2 vx = *reinterpret_cast<const double2*>(x + i);
-      double2 vy = *reinterpret_cast<const double2*>(y + i);
-      double2 vz = *reinterpret_cast<const double2*>(z + i);
+      // streaming (nontemporal) loads: every byte is read once — 0.385 -> 0.335-0.36 ms for 100 M points (6.7-7.2 TB/s),
+      // A B A B in one call (the same loads in the chain pass, the count and the record sort gained nothing)
+      typedef double d2v __attribute__((ext_vector_type(2)));
+      const d2v ax = __builtin_nontemporal_load(reinterpret_cast<const d2v*>(x + i));
+      const d2v ay = __builtin_nontemporal_load(reinterpret_cast<const d2v*>(y + i));
+      const d2v az = __builtin_nontemporal_load(reinterpret_cast<const d2v*>(z + i));
+      const double2 vx = make_double2(ax.x, ax.y), vy = make_double2(ay.x, ay.y), vz = make_double2(az.x, az.y);
       lo[0] = fmin(lo[0], fmin(vx.x, vx.y));
       hi[0] = fmax(hi[0], fmax(vx.x, vx.y));
       lo[1] = fmin(lo[1], fmin(vy.x, vy.y));

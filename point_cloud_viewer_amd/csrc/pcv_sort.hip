@@ -1964,20 +1964,20 @@ extern "C" int pcv_exp_time_key_sort(pcv_ctx* ctx, uint64_t n, int bits, int one
       (rc = ctx->dev_alloc(&sc, pcv_onesweep_scratch_words(n, bits) * 4 + 64)) || (rc = ctx->dev_alloc(&sc2, pcv_sort_scratch_bytes(n))))
     return rc;
   hipEvent_t e0, e1;
-  hipEventCreate(&e0), hipEventCreate(&e1);
+  (void)hipEventCreate(&e0), (void)hipEventCreate(&e1);
   for (int it = 0; it < iters; ++it) {
     hipLaunchKernelGGL(exp_fill_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (uint64_t*)a, (uint32_t)n, bits, top);
-    hipMemsetAsync(sc, 0, pcv_onesweep_zero_words(n, bits) * 4, ctx->stream);
-    hipEventRecord(e0, ctx->stream);
+    (void)hipMemsetAsync(sc, 0, pcv_onesweep_zero_words(n, bits) * 4, ctx->stream);
+    (void)hipEventRecord(e0, ctx->stream);
     bool in_a;
     if (onesweep) rc = pcv_sort_keys_onesweep(ctx, (uint64_t*)a, (uint64_t*)b, n, top - bits, top, (uint32_t*)sc, &in_a, diag);
     else rc = pcv_radix_sort_u64(ctx, (uint64_t*)a, (uint64_t*)b, n, top - bits, top, nullptr, sc2, &in_a);
-    hipEventRecord(e1, ctx->stream);
-    hipEventSynchronize(e1);
-    hipEventElapsedTime(&ms_out[it], e0, e1);
+    (void)hipEventRecord(e1, ctx->stream);
+    (void)hipEventSynchronize(e1);
+    (void)hipEventElapsedTime(&ms_out[it], e0, e1);
     if (rc) break;
   }
-  hipEventDestroy(e0), hipEventDestroy(e1);
+  (void)hipEventDestroy(e0), (void)hipEventDestroy(e1);
   ctx->dev_free(a), ctx->dev_free(b), ctx->dev_free(sc), ctx->dev_free(sc2);
   return rc;
 }
