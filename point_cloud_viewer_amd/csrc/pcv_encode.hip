@@ -887,16 +887,25 @@ __global__ __launch_bounds__(256) void promote_climb_kernel(
 
 // Leaf-wise climb: one workgroup per <= 256 consecutive climber records of ONE leaf (they are dense per leaf). Every
 // climber climbs at least once, from its leaf into the leaf's parent: both records are wave-uniform scalar loads that
-// run beside the climber loads, and that first step is straight-line code; only the every-8th climbers go on with
-// per-lane parent records.
+// run beside the climber loads, and that first step is straight-line code.
 // kClimb16: 16-byte climber records (the payload alone); the item's pad holds the leaf's first climber index, so the
 // record's own index gives its slot (lo + 8 q) and its place in the parent's stream (child_off + q).
+// Round 6: the climbers that go on past the parent — every eighth of them, 8 lanes of each wave, then 1 — are gathered through
+// LDS into the first lanes of the workgroup and climb on there, with per-lane parent records: the per-lane loop costs one wave
+// what it cost four (the kernel is compute-bound: ~300 VALU per climber for the first step and its final rewrite alone;
+// profiles/r06_ab_climb_persistent_workgroups_dropped.json).
+struct ClimbOn {
+  uint64_t code[3];
+  uint32_t rgb, inten, j, node;  // position j in the stream of node `node`
+};
 template <bool kClimb16>
 __global__ __launch_bounds__(256) void promote_climb_leaf_kernel(PcvPromoteTables pt, const PcvSettleItem* __restrict__ items,
                                                                   const PcvClimber* __restrict__ climbers,
                                                                   const uint32_t* __restrict__ cx_hi,
                                                                   const uint32_t* __restrict__ cy_hi,
                                                                   const uint32_t* __restrict__ cz_hi, PromoteOut o) {
+  __shared__ uint32_t wave_on[4];
+  __shared__ ClimbOn queue[36];  // <= 256 / 8 + 1 climbers of an item go on
   const PcvSettleItem it = items[blockIdx.x];
   const uint32_t k = it.begin + threadIdx.x;
   const bool live = k < it.end;
@@ -920,7 +929,6 @@ __global__ __launch_bounds__(256) void promote_climb_leaf_kernel(PcvPromoteTable
     h[2] = cz_hi[leaf.lo + slot_rel];
   }
   const PcvNodeRec par = pt.node_rec[leaf.parent];  // a leaf with climbers is not the root
-  if (!live) return;
   uint64_t code[3] = {pay.x | ((uint64_t)h[0] << 32), pay.y | ((uint64_t)h[1] << 32), pay.z | ((uint64_t)h[2] << 32)};
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
@@ -928,8 +936,33 @@ __global__ __launch_bounds__(256) void promote_climb_leaf_kernel(PcvPromoteTable
     code[a] = pcv_encode_coord(par.enc, q, par.mn[a], par.edge, PcvRecip{par.inv_edge, par.inv_edge_lo});
   }
   const uint32_t j = leaf.child_off + (slot_rel >> 3);  // position in the parent's stream
-  promote_one<true>(pt, (uint64_t)par.lo + j, par, make_uint4((uint32_t)code[0], (uint32_t)code[1], (uint32_t)code[2], pay.w),
-                    (uint32_t)(code[0] >> 32), (uint32_t)(code[1] >> 32), (uint32_t)(code[2] >> 32), inten, o);
+  const bool goes_on = live && par.parent != 0xffffffffu && (j & 7u) == 0;
+  if (live && !goes_on)  // stays in the parent: the final rewrite there
+    promote_one<false>(pt, (uint64_t)par.lo + j, par, make_uint4((uint32_t)code[0], (uint32_t)code[1], (uint32_t)code[2], pay.w),
+                       (uint32_t)(code[0] >> 32), (uint32_t)(code[1] >> 32), (uint32_t)(code[2] >> 32), inten, o);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint64_t m = __ballot(goes_on);
+  if (lane == 0) wave_on[wave] = (uint32_t)__popcll(m);
+  __syncthreads();
+  uint32_t before = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    before += w < wave ? wave_on[w] : 0u;
+    total += wave_on[w];
+  }
+  if (total == 0) return;  // workgroup-uniform
+  if (goes_on) {
+    ClimbOn& q = queue[before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))];
+    q.code[0] = code[0], q.code[1] = code[1], q.code[2] = code[2];
+    q.rgb = pay.w, q.inten = inten, q.j = j, q.node = leaf.parent;
+  }
+  __syncthreads();
+  if (threadIdx.x < total) {
+    const ClimbOn q = queue[threadIdx.x];
+    const PcvNodeRec cur = pt.node_rec[q.node];
+    promote_one<true>(pt, (uint64_t)cur.lo + q.j, cur, make_uint4((uint32_t)q.code[0], (uint32_t)q.code[1], (uint32_t)q.code[2], q.rgb),
+                      (uint32_t)(q.code[0] >> 32), (uint32_t)(q.code[1] >> 32), (uint32_t)(q.code[2] >> 32), q.inten, o);
+  }
 }
 
 }  // namespace
