@@ -34,7 +34,9 @@ int main() {
   hipEvent_t e0, e1, fork;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
   const int reps = 200, iters = 2000;
-  for (int mode = 0; mode < 4; ++mode) {
+  hipEvent_t join;
+  CK(hipEventCreateWithFlags(&join, hipEventDisableTiming));
+  for (int mode = 0; mode < 7; ++mode) {
     std::vector<float> ms;
     int wrong = 0;
     for (int r = 0; r < reps; ++r) {
@@ -45,6 +47,10 @@ int main() {
       if (mode == 1) { CK(hipEventRecord(fork, a)); CK(hipStreamWaitEvent(b, fork, 0)); hipLaunchKernelGGL(observe, dim3(1), dim3(1), 0, b, flag, seen); }
       if (mode == 2) { hipError_t w = hipStreamWaitValue32(b, flag, seq, hipStreamWaitValueEq, 0xffffffffu); if (w != hipSuccess) { printf("hipStreamWaitValue32: %s\n", hipGetErrorString(w)); return 0; }
                        hipLaunchKernelGGL(observe, dim3(1), dim3(1), 0, b, flag, seen); }
+      // joins: the side stream does a little work that ended long ago; `a` waits for it between k1 and k2
+      if (mode == 4) { hipLaunchKernelGGL(observe, dim3(1), dim3(1), 0, b, flag, seen); CK(hipEventRecord(join, b)); CK(hipStreamWaitEvent(a, join, 0)); }
+      if (mode == 5) { hipLaunchKernelGGL(observe, dim3(1), dim3(1), 0, b, flag, seen); CK(hipStreamWriteValue32(b, flag, seq, 0)); CK(hipStreamWaitValue32(a, flag, seq, hipStreamWaitValueGte, 0xffffffffu)); }
+      if (mode == 6) { CK(hipStreamWaitValue32(a, flag, 0, hipStreamWaitValueGte, 0xffffffffu)); }  // a wait that is already satisfied
       if (mode == 2 || mode == 3) hipLaunchKernelGGL(busy_flag, dim3(64), dim3(256), 0, a, out, iters, flag, seq);
       else hipLaunchKernelGGL(busy, dim3(64), dim3(256), 0, a, out, iters);
       CK(hipEventRecord(e1, a));
@@ -55,7 +61,8 @@ int main() {
       if (mode == 2 && seen[0] != seq) ++wrong;
     }
     std::sort(ms.begin(), ms.end());
-    const char* names[4] = {"k1 -> k2", "k1 -> eventRecord(fork) -> k2", "k1 -> k2(stores flag), side: waitValue32 -> observe", "k1 -> k2(stores flag), no side stream"};
+    const char* names[7] = {"k1 -> k2", "k1 -> eventRecord(fork) -> k2", "k1 -> k2(stores flag), side: waitValue32 -> observe", "k1 -> k2(stores flag), no side stream",
+                            "k1 -> waitEvent(side's event) -> k2", "k1 -> waitValue32(flag the side stream wrote) -> k2", "k1 -> waitValue32(already true) -> k2"};
     printf("%-56s median %.1f us  min %.1f us  side saw a stale flag: %d of %d\n", names[mode], ms[reps / 2] * 1e3, ms[0] * 1e3, wrong, reps);
   }
   return 0;
