@@ -930,10 +930,20 @@ __global__ __launch_bounds__(256) void promote_climb_leaf_kernel(PcvPromoteTable
   }
   const PcvNodeRec par = pt.node_rec[leaf.parent];  // a leaf with climbers is not the root
   uint64_t code[3] = {pay.x | ((uint64_t)h[0] << 32), pay.y | ((uint64_t)h[1] << 32), pay.z | ((uint64_t)h[2] << 32)};
+  if (par.enc <= PCV_ENC_UINT16 && par.inv_edge != 0.0) {  // wave-uniform
+    // integer codes in a tame cube (the host zeroes inv_edge otherwise): the decoded position lies inside the leaf's cube, which
+    // lies inside the parent's — the exact constant-divisor division needs no range check (as in promote_final)
+    const double maxval = par.enc == PCV_ENC_UINT8 ? 255.0 : 65535.0;
 #pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    const double q = pcv_decode_coord(leaf.enc, code[a], leaf.mn[a], leaf.edge);
-    code[a] = pcv_encode_coord(par.enc, q, par.mn[a], par.edge, PcvRecip{par.inv_edge, par.inv_edge_lo});
+    for (int a = 0; a < 3; ++a)
+      code[a] = pcv_fix_encode<false>(pcv_decode_coord(leaf.enc, code[a], leaf.mn[a], leaf.edge), par.mn[a], par.edge,
+                                      PcvRecip{par.inv_edge, par.inv_edge_lo}, maxval);
+  } else {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const double q = pcv_decode_coord(leaf.enc, code[a], leaf.mn[a], leaf.edge);
+      code[a] = pcv_encode_coord(par.enc, q, par.mn[a], par.edge, PcvRecip{par.inv_edge, par.inv_edge_lo});
+    }
   }
   const uint32_t j = leaf.child_off + (slot_rel >> 3);  // position in the parent's stream
   const bool goes_on = live && par.parent != 0xffffffffu && (j & 7u) == 0;
